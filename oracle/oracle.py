@@ -1,0 +1,186 @@
+"""
+ORACLE (test infrastructure, NOT product code) -- ctypes front-end of oracle/liboracle.so (ida_oracle.c + generated
+model functions).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MODE_I, MODE_V, MODE_DT = 0, 1, 2
+VAL_CONST, VAL_HOLD, VAL_REST = 0, 1, 2
+NAN = math.nan
+
+BOUND_FIELDS = ["V_max", "V_min", "SOC_max", "SOC_min", "T_max", "c_s_n_max", "I_max", "I_min", "eta_plating_min",
+                "c_e_min", "dfilm_max"]
+
+
+class Bounds(C.Structure):
+    _fields_ = [(f, C.c_double) for f in BOUND_FIELDS]
+
+
+class Run(C.Structure):
+    _fields_ = [("mode", C.c_int), ("value_kind", C.c_int), ("value", C.c_double), ("tf", C.c_double), ("bounds", Bounds)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("abstol_init", C.c_double), ("reltol_init", C.c_double),
+                ("maxiters", C.c_int), ("check_bounds", C.c_int), ("interp_final", C.c_int), ("max_order", C.c_int),
+                ("jac_every_step", C.c_int)]
+
+
+class RunInfo(C.Structure):
+    _fields_ = [("flag", C.c_int), ("iterations", C.c_int), ("t_end", C.c_double), ("V", C.c_double), ("I", C.c_double),
+                ("SOC", C.c_double), ("T_avg", C.c_double)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(f, C.c_long) for f in ["n_steps", "n_res", "n_jac", "n_fact", "n_solve", "n_newton", "n_errfail",
+                                       "n_convfail", "sum_kp2", "n_init_iters"]]
+
+
+def build(force=False):
+    so = os.path.join(HERE, "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", HERE], stdout=subprocess.DEVNULL)
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_theta_key.restype = C.c_char_p
+    return _lib
+
+
+def meta(variant):
+    with open(os.path.join(HERE, "gen", variant + ".json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def default_bounds(cathode="LCO", **over):
+    from .dfn_model import BOUNDS_DEFAULT
+    d = dict(BOUNDS_DEFAULT[cathode])
+    d["eta_plating_min"] = d.pop("η_plating_min")
+    d.update(over)
+    return Bounds(**d)
+
+
+def default_opts(**over):
+    d = dict(abstol=1e-6, reltol=1e-3, maxiters=10000, check_bounds=1, interp_final=1, max_order=5, jac_every_step=0)
+    d.update(over)
+    d.setdefault("abstol_init", d["abstol"])
+    d.setdefault("reltol_init", d["reltol"])
+    return Opts(**d)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def theta_vector(variant, overrides=None):
+    m = meta(variant)
+    th = np.array(m["theta_default"], dtype=np.float64)
+    if overrides:
+        for k, v in overrides.items():
+            th[m["theta_keys"].index(k)] = v
+    return th
+
+
+def simulate(variant, theta, SOC0, runs, opts=None, max_out=20000, Y_init=None):
+    """runs: list of dicts(mode, value, value_kind, tf, bounds=Bounds).  Returns dict with per-point outputs, final
+    state, per-run info and counters."""
+    L = lib()
+    m = meta(variant)
+    N = m["N"]
+    opts = opts or default_opts()
+    arr = (Run * len(runs))()
+    for k, r in enumerate(runs):
+        arr[k].mode = r.get("mode", MODE_I)
+        arr[k].value_kind = r.get("value_kind", VAL_CONST)
+        arr[k].value = r.get("value", 0.0)
+        arr[k].tf = r.get("tf", 1e6)
+        arr[k].bounds = r.get("bounds") or default_bounds()
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    out = {k: np.zeros(max_out) for k in ("t", "V", "I", "SOC", "T")}
+    n_out = C.c_int(0)
+    Yf = np.zeros(N)
+    YPf = np.zeros(N)
+    info = (RunInfo * len(runs))()
+    cnt = Counters()
+    yi = None if Y_init is None else _dp(np.ascontiguousarray(Y_init, dtype=np.float64))
+    rc = L.orc_simulate(variant.encode(), _dp(theta), C.c_double(SOC0), len(runs), arr, C.byref(opts), max_out,
+                        _dp(out["t"]), _dp(out["V"]), _dp(out["I"]), _dp(out["SOC"]), _dp(out["T"]), C.byref(n_out),
+                        _dp(Yf), _dp(YPf), info, C.byref(cnt), yi)
+    n = min(n_out.value, max_out)
+    res = {k: v[:n].copy() for k, v in out.items()}
+    res.update(rc=rc, Y=Yf, YP=YPf,
+               runs=[dict(flag=i.flag, iterations=i.iterations, t_end=i.t_end, V=i.V, I=i.I, SOC=i.SOC, T_avg=i.T_avg) for i in info],
+               counters={f: getattr(cnt, f) for f, _ in Counters._fields_})
+    return res
+
+
+def residual(variant, theta, Y, YP, mode=MODE_I, value=0.0):
+    L = lib()
+    N = meta(variant)["N"]
+    out = np.zeros(N)
+    rc = L.orc_residual(variant.encode(), _dp(np.ascontiguousarray(theta)), mode, C.c_double(value),
+                        _dp(np.ascontiguousarray(Y, dtype=np.float64)), _dp(np.ascontiguousarray(YP, dtype=np.float64)), _dp(out))
+    assert rc == 0, rc
+    return out
+
+
+def jacobian(variant, theta, Y, YP, cj, mode=MODE_I, value=0.0):
+    """full N x N Jacobian dF/dY + cj dF/dYP (base rows + control row) as (colptr, rowval, nzval)."""
+    L = lib()
+    N = meta(variant)["N"]
+    nnz = C.c_int(0)
+    th = np.ascontiguousarray(theta)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    YP = np.ascontiguousarray(YP, dtype=np.float64)
+    L.orc_jacobian(variant.encode(), _dp(th), mode, C.c_double(value), _dp(Y), _dp(YP), C.c_double(cj), C.byref(nnz), None, None, None)
+    cp = np.zeros(N + 1, dtype=np.int32)
+    ri = np.zeros(nnz.value, dtype=np.int32)
+    nz = np.zeros(nnz.value)
+    rc = L.orc_jacobian(variant.encode(), _dp(th), mode, C.c_double(value), _dp(Y), _dp(YP), C.c_double(cj), C.byref(nnz),
+                        cp.ctypes.data_as(C.POINTER(C.c_int)), ri.ctypes.data_as(C.POINTER(C.c_int)), _dp(nz))
+    assert rc == 0, rc
+    return cp, ri, nz
+
+
+def initial_guess(variant, theta, SOC):
+    L = lib()
+    N = meta(variant)["N"]
+    Y = np.zeros(N)
+    L.orc_initial_guess(variant.encode(), _dp(np.ascontiguousarray(theta)), C.c_double(SOC), _dp(Y))
+    return Y
+
+
+def init_consistent(variant, theta, Y, mode=MODE_I, value=0.0, reltol_init=1e-3):
+    L = lib()
+    Y = np.array(Y, dtype=np.float64)
+    YP = np.zeros_like(Y)
+    it = C.c_int(0)
+    rc = L.orc_init_consistent(variant.encode(), _dp(np.ascontiguousarray(theta)), mode, C.c_double(value),
+                               C.c_double(reltol_init), _dp(Y), _dp(YP), C.byref(it))
+    return rc, Y, YP, it.value
+
+
+def linear_solve(variant, theta, Y, YP, cj, b, mode=MODE_I, value=0.0):
+    L = lib()
+    b = np.array(b, dtype=np.float64)
+    rc = L.orc_linear_solve(variant.encode(), _dp(np.ascontiguousarray(theta)), mode, C.c_double(value),
+                            _dp(np.ascontiguousarray(Y, dtype=np.float64)), _dp(np.ascontiguousarray(YP, dtype=np.float64)),
+                            C.c_double(cj), _dp(b))
+    assert rc == 0, rc
+    return b
