@@ -1,0 +1,160 @@
+/*
+ * petlion_hip.h -- C ABI of the MI355X-native DFN/P2D time-stepping path (libpetlion_hip.so).
+ *
+ * This is the drop-in boundary a Julia host binds with `ccall` (bindings/julia/PetlionHIP.jl).
+ * Every entry point names the reference interface it replaces; citations are relative to the reference repository
+ * (MarcBerliner/PETLION.jl @ v1.0.6).  Plain C, caller-owned arrays, no callbacks, no exceptions across the boundary.
+ *
+ * Conventions
+ *   - all reals are IEEE fp64 (the reference is Float64 everywhere, src/structures.jl:337).
+ *   - batched arrays are cell-major: X[cell*stride + k]  (one cell's vector is contiguous, like the reference's Vector).
+ *   - `ptr_kind`: PLH_HOST  = the arrays are host memory (the library stages them through the device);
+ *                 PLH_DEVICE = the arrays already live in this GPU's HBM (no copies; asynchronous on `stream`).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - return value: 0 ok; <0 API misuse / HIP failure (PLH_E_*).  Per-cell outcomes are reported in `status`/`flag` arrays
+ *     using the reference's exit flags 0..11 (src/checks.jl:6,40,47,66,73,90,97,116,152,175,194,217) and negative codes
+ *     for the reference's error() paths.
+ *   - a handle is used by one host thread at a time (the reference model object is not re-entrant either,
+ *     src/external.jl:135-139); different handles / GPUs may be used concurrently.
+ */
+#ifndef PETLION_HIP_H
+#define PETLION_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLH_HOST 0
+#define PLH_DEVICE 1
+
+#define PLH_E_ARG (-1)          /* invalid argument */
+#define PLH_E_UNSUPPORTED (-2)  /* model option outside the hot-path scope */
+#define PLH_E_HIP (-3)          /* HIP runtime failure (no GPU, out of memory, launch failure) */
+
+/* chemistries: reference src/params.jl:5-289 (LCO + LiC6), 295-507 (NMC + LiC6_NMC) */
+#define PLH_CHEM_LCO_LIC6 0
+#define PLH_CHEM_NMC_LIC6 1
+
+/* operating modes = the control row of the DAE (reference src/physics_equations/input_methods.jl:9,40,182-189,
+ * src/physics_equations/scalar_residual.jl:167-172) */
+#define PLH_MODE_I 0   /* current, C-rate:      Y[I] - value                      */
+#define PLH_MODE_V 1   /* voltage, V:           Phi_s[1] - Phi_s[end] - value     */
+#define PLH_MODE_DT 2  /* dT_avg/dt, K/s:       value - sum_i w_i YP[T_i] / L     (temperature models only) */
+
+/* how `value` is obtained (reference input_methods.jl:11-30,53-63; model_evaluation.jl:165-170) */
+#define PLH_VAL_CONST 0
+#define PLH_VAL_HOLD 1  /* :hold  -- the value reached at the end of the previous run */
+#define PLH_VAL_REST 2  /* :rest  -- I = 0, all bound checks skipped (src/checks.jl:12,388) */
+
+/* per-cell status beyond the reference's exit flags */
+#define PLH_FLAG_RUNNING (-1)
+#define PLH_ERR_INIT (-11)      /* "Could not initialize DAE in 100 iterations", src/model_evaluation.jl:456 */
+#define PLH_ERR_STALL (-12)     /* "Model failed to converge at t = ...", src/checks.jl:233,236 */
+#define PLH_ERR_MAXITERS (-13)  /* "Reached max iterations", src/checks.jl:239 */
+#define PLH_ERR_OUTPUT_FULL (-14)
+
+typedef struct plh_model_s* plh_model_t;
+
+/* mirrors the structural keyword arguments of petlion(cathode; N_p, ..., temperature, aging)
+ * (reference src/params.jl:119-174, src/external.jl:2-18) */
+typedef struct {
+  int chemistry;                                  /* PLH_CHEM_* */
+  int N_p, N_s, N_n, N_a, N_z, N_r_p, N_r_n;      /* reference defaults: 10 each */
+  int temperature;                                /* 0/1 */
+  int aging_SEI;                                  /* 0/1 */
+  int real_bytes;                                 /* 8 */
+} plh_model_desc;
+
+/* reference boundary_stop_conditions (src/structures.jl:237-250); NaN disables a bound */
+typedef struct {
+  double V_max, V_min, SOC_max, SOC_min, T_max, c_s_n_max, I_max, I_min, eta_plating_min, c_e_min, dfilm_max;
+} plh_bounds;
+
+/* one run of a protocol == one simulate()/simulate!() call (src/model_evaluation.jl:11-97) */
+typedef struct {
+  int mode;        /* PLH_MODE_* */
+  int value_kind;  /* PLH_VAL_*  */
+  double value;
+  double tf;       /* run length in run-local time; reference default 1e6 (model_evaluation.jl:13) */
+  plh_bounds bounds;
+} plh_run;
+
+/* reference options_simulation (src/structures.jl:266-285), the numerical subset */
+typedef struct {
+  double abstol, reltol, abstol_init, reltol_init;   /* reference defaults 1e-6, 1e-3, =abstol, =reltol */
+  int maxiters;                                      /* 10000 */
+  int check_bounds, interp_final;                    /* 1, 1 */
+  int max_order;                                     /* BDF order cap, 5 */
+  int jac_every_step;                                /* 0: IDA's Jacobian-reuse policy */
+} plh_opts;
+
+/* per-cell, per-run summary == run_info + the printed summary (src/structures.jl:40-44, 678-746) */
+typedef struct {
+  int flag;          /* exit flag 0..11 or PLH_ERR_* */
+  int iterations;    /* run.info.iterations */
+  double t_end, V, I, SOC, T_avg;
+} plh_run_info;
+
+/* per-cell device counters: the roofline contract of SURVEY.md 8(d) */
+typedef struct {
+  long long n_steps, n_res, n_jac, n_fact, n_solve, n_newton, n_errfail, n_convfail, sum_kp2, n_init_iters;
+} plh_counters;
+
+/* outputs of plh_integrate; any pointer may be NULL.  Saved points are the reference's per-step pushes of
+ * set_vars! (src/save_outputs.jl:11-40): t = 0 of every run + every accepted step; the last point of a run that ended on
+ * a bound is the back-interpolated one (src/model_evaluation.jl:369-382). */
+typedef struct {
+  int max_pts;                       /* row stride of the per-point arrays */
+  double *t, *V, *I, *SOC, *T_avg;   /* [n_cells][max_pts] */
+  int* n_pts;                        /* [n_cells] */
+  double *Y_final, *YP_final;        /* [n_cells][n_states] */
+  plh_run_info* run_info;            /* [n_cells][n_runs] */
+  plh_counters* counters;            /* [n_cells] */
+} plh_outputs;
+
+/* ---- model handle: replaces petlion()'s generated-function bundle p.funcs (src/structures.jl:315-334) ---- */
+int plh_model_create(const plh_model_desc* desc, plh_model_t* out);
+void plh_model_destroy(plh_model_t m);
+int plh_n_states(plh_model_t m);     /* p.N.tot  */
+int plh_n_diff(plh_model_t m);       /* p.N.diff */
+int plh_n_theta(plh_model_t m);      /* length(θ_keys), src/generate_functions.jl:327-363 */
+const char* plh_theta_key(plh_model_t m, int i);   /* UTF-8 names identical to the reference Symbols, sorted like θ_keys */
+double plh_theta_default(plh_model_t m, int i);    /* chemistry defaults, src/params.jl */
+/* CSC pattern (0-based) of the full N x N Jacobian for a mode == [J_y_sp ; scalar row] of
+ * _get_jacobian_combined (src/physics_equations/scalar_residual.jl:500-522).  colptr/rowval may be NULL to query nnz. */
+int plh_jac_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval);
+const char* plh_last_error(void);
+
+/* ---- batched evaluators (single-cell seam = n_cells 1, PLH_HOST) ---- */
+/* initial_guess!(out, SOC, θ, X_applied)  (src/states_definition.jl:80-121): Y[cell][N], Y[I] = 0 */
+int plh_initial_guess(plh_model_t m, int n_cells, const double* theta, const double* SOC, double* Y, int ptr_kind, void* stream);
+/* R_full(res,t,Y,YP,p,run) = f_diff! ++ f_alg! ++ scalar_residual!  (scalar_residual.jl:558-583) */
+int plh_residual(plh_model_t m, int n_cells, const double* theta, const double* Y, const double* YP, int mode, double value,
+                 double* F, int ptr_kind, void* stream);
+/* J_full(J,t,Y,YP,γ,p,run): nzval[cell][nnz] in the CSC order of plh_jac_pattern  (scalar_residual.jl:588-602) */
+int plh_jacobian(plh_model_t m, int n_cells, const double* theta, const double* Y, const double* YP, double cj, int mode,
+                 double* nzval, int ptr_kind, void* stream);
+/* x = J_full \ b  with the structured (particle-resolvent + block-Thomas + border) solver that replaces KLU
+ * (src/model_evaluation.jl:271, 417-428): b[cell][N] in, x out in place */
+int plh_linear_solve(plh_model_t m, int n_cells, const double* theta, const double* Y, const double* YP, double cj, int mode,
+                     double* b, int ptr_kind, void* stream);
+/* newtons_method! (src/model_evaluation.jl:430-480): Y in/out, YP out, status[cell] 0 or PLH_ERR_INIT, iters[cell] */
+int plh_init_consistent(plh_model_t m, int n_cells, const double* theta, int mode, double value, double reltol_init,
+                        double* Y, double* YP, int* status, int* iters, int ptr_kind, void* stream);
+
+/* ---- the hot path: ensemble integrate == simulate()/simulate!() chains over independent cells ----
+ * theta[cell][n_theta]; SOC0[cell]; one protocol (runs[n_runs], host memory) shared by all cells.
+ * Y_init / t_init (both NULL for a new solution): continue a previous solution like simulate!(sol, p, ...)
+ * (src/model_evaluation.jl:87-97, 206-209): Y_init[cell][n_states] = sol.Y[end], t_init[cell] = sol.t[end],
+ * SOC0[cell] = sol.SOC[end]; the first run is then a continuation run (t0 = nextfloat(t_init), tstop at 1 s, :hold works).
+ * One wavefront integrates one cell for the whole protocol inside a single kernel launch. */
+int plh_integrate(plh_model_t m, int n_cells, const double* theta, const double* SOC0, const double* Y_init, const double* t_init,
+                  int n_runs, const plh_run* runs, const plh_opts* opts, const plh_outputs* out, int ptr_kind, void* stream);
+
+/* timing of the last plh_integrate kernel on its stream, measured with HIP events (ms); <0 if unavailable */
+double plh_last_kernel_ms(plh_model_t m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

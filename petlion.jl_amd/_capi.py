@@ -1,0 +1,125 @@
+"""ctypes binding of the C ABI in include/petlion_hip.h (libpetlion_hip.so).
+
+The product path has NO CPU fallback: `load()` raises if the HIP library is missing, and `plh_model_create` fails loudly
+when no GPU is visible.  (tests may pass an explicit `path=` to exercise the same C ABI built against the test-only wave
+emulator; the package itself never does.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpetlion_hip.so")
+
+PLH_HOST, PLH_DEVICE = 0, 1
+MODE_I, MODE_V, MODE_DT = 0, 1, 2
+VAL_CONST, VAL_HOLD, VAL_REST = 0, 1, 2
+CHEM_LCO, CHEM_NMC = 0, 1
+FLAG_RUNNING, ERR_INIT, ERR_STALL, ERR_MAXITERS, ERR_OUTPUT_FULL = -1, -11, -12, -13, -14
+
+BOUND_FIELDS = ["V_max", "V_min", "SOC_max", "SOC_min", "T_max", "c_s_n_max", "I_max", "I_min", "eta_plating_min",
+                "c_e_min", "dfilm_max"]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(f, C.c_int) for f in ["chemistry", "N_p", "N_s", "N_n", "N_a", "N_z", "N_r_p", "N_r_n", "temperature",
+                                      "aging_SEI", "real_bytes"]]
+
+
+class Bounds(C.Structure):
+    _fields_ = [(f, C.c_double) for f in BOUND_FIELDS]
+
+
+class Run(C.Structure):
+    _fields_ = [("mode", C.c_int), ("value_kind", C.c_int), ("value", C.c_double), ("tf", C.c_double), ("bounds", Bounds)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("abstol_init", C.c_double), ("reltol_init", C.c_double),
+                ("maxiters", C.c_int), ("check_bounds", C.c_int), ("interp_final", C.c_int), ("max_order", C.c_int),
+                ("jac_every_step", C.c_int)]
+
+
+class RunInfo(C.Structure):
+    _fields_ = [("flag", C.c_int), ("iterations", C.c_int), ("t_end", C.c_double), ("V", C.c_double), ("I", C.c_double),
+                ("SOC", C.c_double), ("T_avg", C.c_double)]
+
+
+COUNTER_FIELDS = ["n_steps", "n_res", "n_jac", "n_fact", "n_solve", "n_newton", "n_errfail", "n_convfail", "sum_kp2",
+                  "n_init_iters"]
+
+
+class CountersS(C.Structure):
+    _fields_ = [(f, C.c_longlong) for f in COUNTER_FIELDS]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("max_pts", C.c_int), ("t", C.c_void_p), ("V", C.c_void_p), ("I", C.c_void_p), ("SOC", C.c_void_p),
+                ("T_avg", C.c_void_p), ("n_pts", C.c_void_p), ("Y_final", C.c_void_p), ("YP_final", C.c_void_p),
+                ("run_info", C.c_void_p), ("counters", C.c_void_p)]
+
+
+RUN_INFO_DTYPE = np.dtype([("flag", np.int32), ("iterations", np.int32), ("t_end", np.float64), ("V", np.float64),
+                           ("I", np.float64), ("SOC", np.float64), ("T_avg", np.float64)], align=True)
+COUNTERS_DTYPE = np.dtype([(f, np.int64) for f in COUNTER_FIELDS], align=True)
+assert RUN_INFO_DTYPE.itemsize == C.sizeof(RunInfo) and COUNTERS_DTYPE.itemsize == C.sizeof(CountersS)
+
+EXPORTS = ["plh_model_create", "plh_model_destroy", "plh_n_states", "plh_n_diff", "plh_n_theta", "plh_theta_key",
+           "plh_theta_default", "plh_jac_pattern", "plh_last_error", "plh_initial_guess", "plh_residual", "plh_jacobian",
+           "plh_linear_solve", "plh_init_consistent", "plh_integrate", "plh_last_kernel_ms"]
+
+
+class PetlionHipError(RuntimeError):
+    pass
+
+
+_cache = {}
+
+
+def load(path=None):
+    """Load the C-ABI library.  Fails loudly if it has not been built (`python __graft_entry__.py build`)."""
+    path = path or LIB_PATH
+    if path in _cache:
+        return _cache[path]
+    if not os.path.exists(path):
+        raise PetlionHipError("%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'); "
+                              "there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    lib.plh_theta_key.restype = C.c_char_p
+    lib.plh_theta_key.argtypes = [C.c_void_p, C.c_int]
+    lib.plh_theta_default.restype = C.c_double
+    lib.plh_theta_default.argtypes = [C.c_void_p, C.c_int]
+    lib.plh_last_error.restype = C.c_char_p
+    lib.plh_last_kernel_ms.restype = C.c_double
+    lib.plh_last_kernel_ms.argtypes = [C.c_void_p]
+    lib.plh_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]
+    lib.plh_model_destroy.argtypes = [C.c_void_p]
+    for f in ("plh_n_states", "plh_n_diff", "plh_n_theta"):
+        getattr(lib, f).argtypes = [C.c_void_p]
+    lib.plh_jac_pattern.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    vp, i, d = C.c_void_p, C.c_int, C.c_double
+    lib.plh_initial_guess.argtypes = [vp, i, vp, vp, vp, i, vp]
+    lib.plh_residual.argtypes = [vp, i, vp, vp, vp, i, d, vp, i, vp]
+    lib.plh_jacobian.argtypes = [vp, i, vp, vp, vp, d, i, vp, i, vp]
+    lib.plh_linear_solve.argtypes = [vp, i, vp, vp, vp, d, i, vp, i, vp]
+    lib.plh_init_consistent.argtypes = [vp, i, vp, i, d, d, vp, vp, vp, vp, i, vp]
+    lib.plh_integrate.argtypes = [vp, i, vp, vp, vp, vp, i, C.POINTER(Run), C.POINTER(Opts), C.POINTER(Outputs), i, vp]
+    _cache[path] = lib
+    return lib
+
+
+def check(lib, rc, what):
+    if rc != 0:
+        raise PetlionHipError("%s failed (%d): %s" % (what, rc, lib.plh_last_error().decode("utf-8", "replace")))
+
+
+def ptr(a):
+    """void* of a numpy array (host) or a torch tensor (device)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()

@@ -1,0 +1,333 @@
+"""Host-side mirror of the reference's user API for the hot path, over the C ABI (include/petlion_hip.h):
+
+    p   = petlion(LCO; N_p=10, ..., temperature=false)         reference src/external.jl:2-18, src/params.jl:119-174
+    sol = simulate(p, tf; I=-1, SOC=1, V_min=..., reltol=...)    reference src/model_evaluation.jl:11-85
+    simulate!(sol, p, tf; V=:hold, I_min=1/20)                  reference src/model_evaluation.jl:87-97   (here: simulate_b)
+    ens = simulate_ensemble(p, Theta, protocol; SOC=...)         new: the ensemble axis the MI355X path exists for
+
+Julia spellings map as  simulate! -> simulate_b,  :hold -> "hold",  :rest -> "rest",  p.θ[:D_sp] -> p.θ["D_sp"].
+Everything numerical happens in the HIP library; this file only marshals arguments (no CPU compute path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi as cap
+from .params import EXIT_REASONS, Bounds, Opts, bounds_LCO, calc_I1C, theta_LCO
+
+LCO = "LCO"
+NMC = "NMC"
+
+
+class _N:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class Model:
+    """The reference's `model` struct, reduced to the data contracts of the hot path (src/structures.jl:336-345)."""
+
+    def __init__(self, cathode, N, temperature, aging, lib_path=None):
+        if cathode != LCO:
+            raise NotImplementedError("only the LCO/LiC6 chemistry is implemented on the device in this round")
+        self.cathode = cathode
+        self.N = N
+        self.temperature = bool(temperature)
+        self.aging = aging
+        self.θ = theta_LCO()
+        self.θ["I1C"] = calc_I1C(self.θ)
+        self.bounds = bounds_LCO()
+        self.opts = Opts()
+        self._lib = cap.load(lib_path)
+        desc = cap.ModelDesc(cap.CHEM_LCO, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, int(self.temperature), int(bool(aging)), 8)
+        h = C.c_void_p()
+        cap.check(self._lib, self._lib.plh_model_create(C.byref(desc), C.byref(h)), "plh_model_create")
+        self._h = h
+        self.N.tot = self._lib.plh_n_states(h)
+        self.N.diff = self._lib.plh_n_diff(h)
+        self.N.alg = self.N.tot - self.N.diff
+        self.θ_keys = [self._lib.plh_theta_key(h, i).decode("utf-8") for i in range(self._lib.plh_n_theta(h))]
+
+    theta = property(lambda self: self.θ)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.plh_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def theta_vector(self, overrides=None):
+        """dense θ_tot in θ_keys order (update_θ!, src/generate_functions.jl:364-372)."""
+        th = dict(self.θ)
+        if overrides:
+            th.update(overrides)
+        return np.array([th[k] for k in self.θ_keys], dtype=np.float64)
+
+    def jac_pattern(self, mode=cap.MODE_I):
+        nnz = C.c_int(0)
+        cap.check(self._lib, self._lib.plh_jac_pattern(self._h, mode, C.byref(nnz), None, None), "plh_jac_pattern")
+        cp = np.zeros(self.N.tot + 1, dtype=np.int32)
+        ri = np.zeros(nnz.value, dtype=np.int32)
+        cap.check(self._lib, self._lib.plh_jac_pattern(self._h, mode, C.byref(nnz), cp.ctypes.data, ri.ctypes.data), "plh_jac_pattern")
+        return cp, ri
+
+
+def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_r_n=10, temperature=False,
+            solid_diffusion="Fickian", Fickian_method="finite_difference", aging=False, jacobian="symbolic", SOC=1.0,
+            _lib_path=None):
+    """petlion(cathode; kwargs...) -- reference src/params.jl:119-174.  `jacobian` is accepted and ignored (the device
+    Jacobian is hand-derived); unsupported structural options raise."""
+    if solid_diffusion != "Fickian" or Fickian_method != "finite_difference":
+        raise NotImplementedError("only Fickian finite-difference solid diffusion is in the hot-path scope (SURVEY.md 8a)")
+    p = Model(cathode, _N(p=N_p, s=N_s, n=N_n, a=N_a, z=N_z, r_p=N_r_p, r_n=N_r_n), temperature, aging, _lib_path)
+    p.opts.SOC = SOC
+    return p
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+_INPUTS = ("I", "V", "dT")
+_MODE = {"I": cap.MODE_I, "V": cap.MODE_V, "dT": cap.MODE_DT}
+_BOUND_KW = Bounds.FIELDS
+
+
+def _make_run(p, name, inp, tf, bounds):
+    r = cap.Run()
+    r.mode = _MODE[name]
+    if isinstance(inp, str):
+        if inp == "hold":
+            r.value_kind, r.value = cap.VAL_HOLD, 0.0
+        elif inp == "rest":
+            if name != "I":
+                raise ValueError("Unsupported input symbol.")       # input_methods.jl:24
+            r.value_kind, r.value = cap.VAL_REST, 0.0
+        else:
+            raise ValueError("Unsupported input symbol.")
+    elif callable(inp):
+        raise NotImplementedError("function inputs are outside this round's scope (SURVEY.md 8f item 1)")
+    else:
+        r.value_kind, r.value = cap.VAL_CONST, float(inp)
+    r.tf = float(tf)
+    for f in cap.BOUND_FIELDS:
+        setattr(r.bounds, f, getattr(bounds, "η_plating_min" if f == "eta_plating_min" else f))
+    return r
+
+
+def _opts_struct(o):
+    return cap.Opts(o.abstol, o.reltol, o.abstol if o.abstol_init is None else o.abstol_init,
+                    o.reltol if o.reltol_init is None else o.reltol_init, int(o.maxiters), int(bool(o.check_bounds)),
+                    int(bool(o.interp_final)), int(o.max_order), int(bool(o.jac_every_step)))
+
+
+class RunResult:
+    def __init__(self, name, tspan, flag, iterations, info):
+        self.name = name
+        self.tspan = tspan
+        self.flag = int(flag)
+        self.exit_reason = EXIT_REASONS.get(int(flag), "error %d" % flag)
+        self.iterations = int(iterations)
+        self.info = info
+
+
+class Solution:
+    """reference `solution` (src/outputs.jl:78-105), for the outputs the device records per step."""
+
+    def __init__(self):
+        self.t = np.zeros(0)
+        self.V = np.zeros(0)
+        self.I = np.zeros(0)
+        self.SOC = np.zeros(0)
+        self.P = np.zeros(0)
+        self.Y = None          # last state vector (sol.Y[end])
+        self.YP = None
+        self.results = []
+        self.counters = None
+
+    def __len__(self):
+        return len(self.t)
+
+    def isempty(self):
+        return len(self.results) == 0
+
+    def __repr__(self):
+        if self.isempty():
+            return "PETLION simulation (empty)"
+        r = self.results[-1]
+        runs = " → ".join(x.name for x in self.results)
+        return ("PETLION simulation\n  --------\n  Runs:    %s\n  Time:    %.2f s\n  Current: %.4gC\n  Voltage: %.4f V\n"
+                "  Power:   %.4f W/m²\n  SOC:     %.4f\n  Exit:    %s" % (runs, self.t[-1], self.I[-1], self.V[-1], self.P[-1], self.SOC[-1], r.exit_reason))
+
+
+def exit_reasons(sol):
+    return [r.exit_reason for r in sol.results]
+
+
+def final_exit_reason(sol):
+    return sol.results[-1].exit_reason
+
+
+def _split_kwargs(p, kw):
+    inputs = {k: kw.pop(k) for k in list(kw) if k in _INPUTS}
+    if len(inputs) != 1:
+        raise ValueError("exactly one input (I, V or dT) must be selected")     # check_input_arguments, checks.jl:270-282
+    bounds = p.bounds.copy(**{k: kw.pop(k) for k in list(kw) if k in _BOUND_KW})
+    return inputs, bounds, kw
+
+
+def simulate(p, tf=1e6, *, sol=None, SOC=None, **kw):
+    """simulate(p, tf; I=..|V=..|dT=.., SOC, abstol, reltol, ..., V_max, V_min, ...) for ONE cell (n_cells = 1 ensemble)."""
+    inputs, bounds, rest = _split_kwargs(p, kw)
+    o = Opts()
+    o.__dict__.update(p.opts.__dict__)
+    for k, v in rest.items():
+        if not hasattr(o, k):
+            raise TypeError("unknown keyword %r" % k)
+        setattr(o, k, v)
+    (name, inp), = inputs.items()
+    new = sol is None or sol.isempty()
+    sol = Solution() if sol is None else sol
+    soc0 = (p.opts.SOC if SOC is None else SOC) if new else sol.SOC[-1]
+    ens = _integrate(p, p.theta_vector()[None, :], np.array([soc0]), [_make_run(p, name, inp, tf, bounds)], o,
+                     Y_init=None if new else sol.Y[None, :], t_init=None if new else np.array([sol.t[-1]]))
+    n = int(ens["n_pts"][0])
+    I1C = calc_I1C(p.θ)
+    for fld in ("t", "V", "I", "SOC"):
+        setattr(sol, fld, np.concatenate([getattr(sol, fld), ens[fld][0, :n]]))
+    sol.P = sol.I * I1C * sol.V                                   # calc_P, scalar_residual.jl:87
+    sol.Y, sol.YP = ens["Y"][0].copy(), ens["YP"][0].copy()
+    ri = ens["run_info"][0, 0]
+    if ri["flag"] < 0:
+        raise RuntimeError(EXIT_REASONS.get(int(ri["flag"]), "error"))      # the reference's error() paths
+    t_start = ens["t"][0, 0]
+    sol.results.append(RunResult(name, (t_start, ri["t_end"]), ri["flag"], ri["iterations"], ri))
+    sol.counters = ens["counters"][0]
+    return sol
+
+
+def simulate_b(sol, p, tf=1e6, **kw):
+    """simulate!(sol, p, tf; kw...) -- continue `sol` (reference src/model_evaluation.jl:87-97)."""
+    return simulate(p, tf, sol=sol, **kw)
+
+
+def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, stream=None, max_points=None):
+    """one plh_integrate call; numpy in / numpy out (host pointers) or torch device tensors (device=True)."""
+    lib, h = p._lib, p._h
+    n = theta.shape[0]
+    N = p.N.tot
+    arr = (cap.Run * len(runs))(*runs)
+    os_ = _opts_struct(o)
+    mp = int(max_points or o.max_points)
+    out = cap.Outputs()
+    out.max_pts = mp
+    if device:
+        import torch
+        dev = theta.device
+        mk = lambda *shape, dt=torch.float64: torch.empty(*shape, dtype=dt, device=dev)
+        bufs = dict(t=mk(n, mp), V=mk(n, mp), I=mk(n, mp), SOC=mk(n, mp), n_pts=mk(n, dt=torch.int32), Y=mk(n, N), YP=mk(n, N),
+                    run_info=torch.empty(n * len(runs) * cap.RUN_INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev),
+                    counters=torch.empty(n * cap.COUNTERS_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+        kind = cap.PLH_DEVICE
+    else:
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        SOC0 = np.ascontiguousarray(SOC0, dtype=np.float64)
+        bufs = dict(t=np.zeros((n, mp)), V=np.zeros((n, mp)), I=np.zeros((n, mp)), SOC=np.zeros((n, mp)), n_pts=np.zeros(n, np.int32),
+                    Y=np.zeros((n, N)), YP=np.zeros((n, N)), run_info=np.zeros((n, len(runs)), cap.RUN_INFO_DTYPE),
+                    counters=np.zeros(n, cap.COUNTERS_DTYPE))
+        if Y_init is not None:
+            Y_init = np.ascontiguousarray(Y_init, dtype=np.float64)
+            t_init = np.ascontiguousarray(t_init, dtype=np.float64)
+        kind = cap.PLH_HOST
+    out.t, out.V, out.I, out.SOC = cap.ptr(bufs["t"]), cap.ptr(bufs["V"]), cap.ptr(bufs["I"]), cap.ptr(bufs["SOC"])
+    out.T_avg = None
+    out.n_pts, out.Y_final, out.YP_final = cap.ptr(bufs["n_pts"]), cap.ptr(bufs["Y"]), cap.ptr(bufs["YP"])
+    out.run_info, out.counters = cap.ptr(bufs["run_info"]), cap.ptr(bufs["counters"])
+    cap.check(lib, lib.plh_integrate(h, n, cap.ptr(theta), cap.ptr(SOC0), cap.ptr(Y_init), cap.ptr(t_init), len(runs), arr,
+                                     C.byref(os_), C.byref(out), kind, stream), "plh_integrate")
+    bufs["kernel_ms"] = lib.plh_last_kernel_ms(h)
+    return bufs
+
+
+class EnsembleSolution:
+    """Per-cell results of an ensemble run (arrays indexed [cell, point]); sol[i] gives a single-cell Solution."""
+
+    def __init__(self, p, bufs, run_names):
+        self.p = p
+        self.t, self.V, self.I, self.SOC = bufs["t"], bufs["V"], bufs["I"], bufs["SOC"]
+        self.n_pts = bufs["n_pts"]
+        self.Y, self.YP = bufs["Y"], bufs["YP"]
+        self.run_info = bufs["run_info"]
+        self.counters = bufs["counters"]
+        self.run_names = run_names
+        self.kernel_ms = bufs.get("kernel_ms", -1.0)
+
+    @property
+    def n_cells(self):
+        return self.t.shape[0]
+
+    def flags(self):
+        return self.run_info["flag"]
+
+    def __getitem__(self, i):
+        s = Solution()
+        n = int(self.n_pts[i])
+        s.t, s.V, s.I, s.SOC = self.t[i, :n].copy(), self.V[i, :n].copy(), self.I[i, :n].copy(), self.SOC[i, :n].copy()
+        s.P = s.I * calc_I1C(self.p.θ) * s.V
+        s.Y, s.YP = self.Y[i].copy(), self.YP[i].copy()
+        t0 = 0.0
+        for k, nm in enumerate(self.run_names):
+            ri = self.run_info[i, k]
+            s.results.append(RunResult(nm, (t0, ri["t_end"]), ri["flag"], ri["iterations"], ri))
+            t0 = ri["t_end"]
+        s.counters = self.counters[i]
+        return s
+
+
+def make_protocol(p, protocol):
+    """protocol: list of dicts like {"I": 2, "tf": 1800, "V_max": 4.1} / {"V": "hold", "I_min": 1/20} -- each dict is the
+    keyword set of one simulate()/simulate!() call."""
+    runs, names = [], []
+    for step in protocol:
+        step = dict(step)
+        tf = step.pop("tf", 1e6)
+        inputs, bounds, rest = _split_kwargs(p, step)
+        if rest:
+            raise TypeError("unknown protocol keys %r" % list(rest))
+        (name, inp), = inputs.items()
+        runs.append(_make_run(p, name, inp, tf, bounds))
+        names.append(name)
+    return runs, names
+
+
+def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, stream=None, max_points=None):
+    """Integrate an ensemble of independent cells on this process's GPU.
+
+    Theta: [n_cells, n_theta] array in `p.θ_keys` order (numpy = host memory; torch CUDA tensor with device=True = already in HBM).
+    protocol: list of run dicts (see make_protocol) shared by all cells.  SOC: scalar or [n_cells] initial SOC.
+    """
+    runs, names = make_protocol(p, protocol)
+    o = opts or p.opts
+    n = Theta.shape[0]
+    soc = p.opts.SOC if SOC is None else SOC
+    if device:
+        import torch
+        soc0 = soc if hasattr(soc, "device") else torch.full((n,), float(soc), dtype=torch.float64, device=Theta.device)
+    else:
+        soc0 = np.full(n, float(soc)) if np.isscalar(soc) else np.asarray(soc, dtype=np.float64)
+    bufs = _integrate(p, Theta, soc0, runs, o, device=device, stream=stream, max_points=max_points)
+    if device:
+        bufs["run_info"] = bufs["run_info"].cpu().numpy().view(cap.RUN_INFO_DTYPE).reshape(n, len(runs))
+        bufs["counters"] = bufs["counters"].cpu().numpy().view(cap.COUNTERS_DTYPE).reshape(n)
+    return EnsembleSolution(p, bufs, names)
+
+
+def theta_matrix(p, n_cells, overrides=None):
+    """[n_cells, n_theta] matrix of the model's current θ, with per-cell overrides {key: array[n_cells]}."""
+    Th = np.tile(p.theta_vector(), (n_cells, 1))
+    if overrides:
+        for k, v in overrides.items():
+            Th[:, p.θ_keys.index(k)] = v
+    return Th

@@ -1,0 +1,634 @@
+// dfn_cell.h -- device functions: one 64-lane wavefront owns one cell; the whole cell state lives in LDS.
+//
+// Replaces, for ensembles of independent cells, the reference's generated evaluators and its IDA+KLU stack:
+//   residual      f_diff!/f_alg!/scalar_residual!   (reference src/physics_equations/residuals.jl, scalar_residual.jl:167-172,558-583)
+//   Jacobian      J_y! / J_y_alg!                    (reference src/generate_functions.jl:289-325)  -- hand-derived, structured
+//   linear solve  KLU                                (reference src/model_evaluation.jl:271,417-428) -- particle resolvent + block-Thomas
+//   init Newton   newtons_method!                    (reference src/model_evaluation.jl:430-480)
+//   integrator    Sundials IDA via step!             (reference src/model_evaluation.jl:234-333)
+//   stop logic    check_simulation_stop! etc.        (reference src/checks.jl:1-249, src/model_evaluation.jl:369-382)
+//
+// Discretisation handled: N_p = N_s = N_n = 10, N_r_p = N_r_n = 10 (the reference defaults, src/params.jl:124-136),
+// isothermal, no aging (configs C1/C2/C4 of SURVEY.md 8d).  Finite-volume rows are evaluated in conservative
+// edge-flux form (row i = flux_i - flux_{i-1}), which is algebraically identical to the reference's matrix form
+// (residuals.jl:6-106, 554-654) and lets 29 lanes own the 29 control-volume edges.
+//
+// Vocabulary kept deliberately small (threadIdx, __shfl_*, __syncthreads, __shared__) so that the identical source
+// also compiles against tests/wave_emu (a test-only lock-step wave emulator used for CPU debugging).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/petlion_hip.h"
+
+namespace pl {
+
+constexpr int WAVE = 64;
+constexpr int NP = 10, NS = 10, NN = 10, NR = 10, NE = NP + NS + NN, NJ = NP + NN;
+constexpr int O_CE = 0, O_CS = NE, O_J = O_CS + NJ * NR, O_PE = O_J + NJ, O_PS = O_PE + NE, O_I = O_PS + NJ;
+constexpr int NST = O_I + 1, NDIFF = O_J, NALG = NST - NDIFF;
+constexpr int NPAD = 304;
+constexpr int MAXORD = 5;
+constexpr double FAR = 96485.3321233;      // reference src/structures.jl:10
+constexpr double RGAS = 8.31446261815324;  // reference src/structures.jl:11
+constexpr double TREF = 298.15;
+
+// theta keys the device reads (LCO isothermal: this is exactly the sorted key list)
+enum Key { K_D_n, K_D_p, K_D_s, K_D_sn, K_D_sp, K_Ea_D_sn, K_Ea_D_sp, K_Ea_k_n, K_Ea_k_p, K_Rp_n, K_Rp_p, K_T0,
+           K_brugg_n, K_brugg_p, K_brugg_s, K_c_e0, K_c_max_n, K_c_max_p, K_k_n, K_k_p, K_l_n, K_l_p, K_l_s, K_tplus,
+           K_th_max_n, K_th_max_p, K_th_min_n, K_th_min_p, K_sig_n, K_sig_p, K_eps_fn, K_eps_fp, K_eps_n, K_eps_p,
+           K_eps_s, K_COUNT };
+
+// read-only model tables in device memory
+struct Tables {
+  double M[NR * NR], LAM[NR], V[NR * NR], W[NR * NR];   // radial operator and its eigen-decomposition
+  double BJ;                                            // surface-row BC factor
+  int thidx[K_COUNT];                                   // position of each key in the theta vector (-1: absent)
+  int chem;
+  int P;
+  int nnz[3];                                           // full-Jacobian nnz per mode
+  const unsigned* csc_code[3];                          // per mode: decode word of every CSC entry
+};
+
+struct CellConst {
+  double h[3], eps[3], bf[3], Dc[3];
+  double a_p, a_n, sig_p, sig_n, kp, kn, cmaxp, cmaxn, kap_p, kap_n, bj_p, bj_n;
+  double T0, fRT, Kfac, I1C, tplus, JI0, JI29, ce0;
+  double thmin_p, thmax_p, thmin_n, thmax_n;
+  int iso_ref;   // T0 == TREF exactly (temperature_switch, reference custom_functions.jl:1)
+};
+
+struct CellLDS {
+  double phi[MAXORD + 1][NPAD];
+  double ewt[NPAD], yy[NPAD], yp[NPAD], ee[NPAD], delta[NPAD];
+  // structured Jacobian pool (cj not included)
+  double ceL[NE], ceD[NE], ceU[NE], ceJ[NE];
+  double peL[NE], peD[NE], peU[NE], pcL[NE], pcD[NE], pcU[NE], peJ[NE];
+  double gce[NJ], gcs[NJ], gpe[NJ], gps[NJ], psJ[NJ];
+  // eliminated system
+  double dj[NJ], fS[NE], fP[NE], fQ[NE];
+  double Dinv[NE][9], LD[NE][9];
+  double rhs3[NE][3], y3[NE][3], x2[NE][3];
+  double w9[NJ];
+  double sig[2];
+  double kapv[2];
+  CellConst cc;
+};
+
+// per-lane registers that persist across phases
+struct LaneRegs {
+  double Mrow[NR];      // row (lane % 10) of the radial operator
+  double Ainv[2][NR];   // row (lane % 10) of (kappa M - cj I)^-1 for the p / n electrode
+  double wreg[4];       // particle partial solutions kept across the Thomas phase
+};
+
+__device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
+__host__ __device__ __forceinline__ int sec_of(int i) { return i < NP ? 0 : (i < NP + NS ? 1 : 2); }
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// closures (reference src/physics_equations/custom_functions.jl)
+// ------------------------------------------------------------------------------------------------------------------
+// K_eff(c_e, T), custom_functions.jl:96 ; returns K and dK/dc
+__device__ __forceinline__ void keff(double c, double T, double& K, double& dK) {
+  const double A = -10.5 + 0.668 * 1e-3 * c + 0.494 * 1e-6 * c * c;
+  const double B = 0.074 - 1.78 * 1e-5 * c - 8.86 * 1e-10 * c * c;
+  const double C = -6.96 * 1e-5 + 2.8 * 1e-8 * c;
+  const double P = A + B * T + C * T * T;
+  const double dP = (0.668 * 1e-3 + 2 * 0.494 * 1e-6 * c) + (-1.78 * 1e-5 - 2 * 8.86 * 1e-10 * c) * T + 2.8 * 1e-8 * T * T;
+  K = 1e-4 * c * P * P;
+  dK = 1e-4 * (P * P + 2.0 * c * P * dP);
+}
+
+// OCV_LCO, custom_functions.jl:123-136 ; U(x,T) and dU/dx
+__device__ __forceinline__ void ocv_lco(double x, double T, int iso_ref, double& U, double& dUdx) {
+  const double x2 = x * x, x4 = x2 * x2, x6 = x4 * x2, x8 = x4 * x4, x10 = x8 * x2;
+  const double P = -4.656 + 88.669 * x2 - 401.119 * x4 + 342.909 * x6 - 462.471 * x8 + 433.434 * x10;
+  const double Q = -1 + 18.933 * x2 - 79.532 * x4 + 37.311 * x6 - 73.083 * x8 + 95.96 * x10;
+  const double dP = x * (2 * 88.669 - 4 * 401.119 * x2 + 6 * 342.909 * x4 - 8 * 462.471 * x6 + 10 * 433.434 * x8);
+  const double dQ = x * (2 * 18.933 - 4 * 79.532 * x2 + 6 * 37.311 * x4 - 8 * 73.083 * x6 + 10 * 95.96 * x8);
+  U = P / Q;
+  dUdx = (dP * Q - P * dQ) / (Q * Q);
+  if (!iso_ref) {
+    const double x3 = x2 * x;
+    const double n = 0.199521039 - 0.928373822 * x + 1.364550689000003 * x2 - 0.6115448939999998 * x3;
+    const double d = 1 - 5.661479886999997 * x + 11.47636191 * x2 - 9.82431213599998 * x3 + 3.048755063 * x4;
+    const double dn = -0.928373822 + 2 * 1.364550689000003 * x - 3 * 0.6115448939999998 * x2;
+    const double dd = -5.661479886999997 + 2 * 11.47636191 * x - 3 * 9.82431213599998 * x2 + 4 * 3.048755063 * x3;
+    U += -0.001 * n / d * (T - TREF);
+    dUdx += -0.001 * (dn * d - n * dd) / (d * d) * (T - TREF);
+  }
+}
+
+// OCV_LiC6, custom_functions.jl:139-152
+__device__ __forceinline__ void ocv_lic6(double x, double T, int iso_ref, double& U, double& dUdx) {
+  const double s0 = sqrt(x > 0.0 ? x : 0.0);
+  const double xm = x > 1e-4 ? x : 1e-4;
+  const double s1 = sqrt(xm);
+  const double e1 = exp(0.9 - 15 * x), e2 = exp(0.4465 * x - 0.4108);
+  U = 0.7222 + 0.1387 * x + 0.029 * s0 - 0.0172 / x + 0.0019 / (s1 * x) + 0.2808 * e1 - 0.7984 * e2;
+  double d = 0.1387 + 0.0172 / (x * x) - 0.2808 * 15 * e1 - 0.7984 * 0.4465 * e2;
+  if (x > 0.0) d += 0.029 * 0.5 / s0;
+  if (x > 1e-4) d += 0.0019 * (-1.5) / (x * x * s1);
+  else d += -0.0019 / (s1 * x * x);
+  dUdx = d;
+  if (!iso_ref) {
+    const double x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x, x6 = x3 * x3, x7 = x6 * x, x8 = x4 * x4;
+    const double n = 0.001 * (0.005269056 + 3.299265709 * x - 91.79325798 * x2 + 1004.911008 * x3 - 5812.278127 * x4 + 19329.7549 * x5 - 37147.8947 * x6 + 38379.18127 * x7 - 16515.05308 * x8);
+    const double q = 1 - 48.09287227 * x + 1017.234804 * x2 - 10481.80419 * x3 + 59431.3 * x4 - 195881.6488 * x5 + 374577.3152 * x6 - 385821.1607 * x7 + 165705.8597 * x8;
+    const double dn = 0.001 * (3.299265709 - 2 * 91.79325798 * x + 3 * 1004.911008 * x2 - 4 * 5812.278127 * x3 + 5 * 19329.7549 * x4 - 6 * 37147.8947 * x5 + 7 * 38379.18127 * x6 - 8 * 16515.05308 * x7);
+    const double dq = -48.09287227 + 2 * 1017.234804 * x - 3 * 10481.80419 * x2 + 4 * 59431.3 * x3 - 5 * 195881.6488 * x4 + 6 * 374577.3152 * x5 - 7 * 385821.1607 * x6 + 8 * 165705.8597 * x7;
+    U += n / q * (T - TREF);
+    dUdx += (dn * q - n * dq) / (q * q) * (T - TREF);
+  }
+}
+
+// harmonic-mean edge interpolation H(beta; a, b) = ab/(beta b + (1-beta) a), numerical_tools.jl:106-156
+__device__ __forceinline__ double hmean(double beta, double a, double b) { return a * b / (beta * b + (1.0 - beta) * a); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-cell constants from theta (build_auxiliary_states!, reference aux...jl:6-52, and the Arrhenius closures)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ inline void cell_setup(CellLDS& S, LaneRegs& R, const Tables* __restrict__ tb, const double* __restrict__ th) {
+  const int lane = lane_id();
+  if (lane == 0) {
+    CellConst& c = S.cc;
+    const int* ix = tb->thidx;
+    const double lp = th[ix[K_l_p]], ls = th[ix[K_l_s]], ln = th[ix[K_l_n]];
+    c.h[0] = lp / NP; c.h[1] = ls / NS; c.h[2] = ln / NN;
+    const double efp = th[ix[K_eps_fp]], efn = th[ix[K_eps_fn]];
+    const double esp = 1.0 - (efp + th[ix[K_eps_p]]);       // active_material, aux...jl:537-545
+    const double esn = 1.0 - (efn + th[ix[K_eps_n]]);
+    c.eps[0] = 1.0 - (efp + esp);                           // build_ϵ!, aux...jl:92-105
+    c.eps[1] = th[ix[K_eps_s]];
+    c.eps[2] = 1.0 - (efn + esn);
+    c.bf[0] = pow(c.eps[0], th[ix[K_brugg_p]]);
+    c.bf[1] = pow(c.eps[1], th[ix[K_brugg_s]]);
+    c.bf[2] = pow(c.eps[2], th[ix[K_brugg_n]]);
+    c.Dc[0] = th[ix[K_D_p]] * c.bf[0];                      // D_eff_linear, custom_functions.jl:59-69
+    c.Dc[1] = th[ix[K_D_s]] * c.bf[1];
+    c.Dc[2] = th[ix[K_D_n]] * c.bf[2];
+    const double Rp_p = th[ix[K_Rp_p]], Rp_n = th[ix[K_Rp_n]];
+    c.a_p = 3 * esp / Rp_p; c.a_n = 3 * esn / Rp_n;         // build_a!, aux...jl:124-139
+    c.sig_p = th[ix[K_sig_p]] * esp; c.sig_n = th[ix[K_sig_n]] * esn;
+    const double T0 = th[ix[K_T0]];
+    c.T0 = T0; c.iso_ref = (T0 == TREF);
+    double arr_kp = 1.0, arr_kn = 1.0, arr_dp = 1.0, arr_dn = 1.0;   // temperature_switch, custom_functions.jl:1,16-31,44-57
+    if (!c.iso_ref) {
+      const double dT = 1.0 / T0 - 1.0 / TREF;
+      arr_kp = exp(-(th[ix[K_Ea_k_p]] / RGAS) * dT); arr_kn = exp(-(th[ix[K_Ea_k_n]] / RGAS) * dT);
+      arr_dp = exp(-(th[ix[K_Ea_D_sp]] / RGAS) * dT); arr_dn = exp(-(th[ix[K_Ea_D_sn]] / RGAS) * dT);
+    }
+    c.kp = th[ix[K_k_p]] * arr_kp; c.kn = th[ix[K_k_n]] * arr_kn;
+    c.cmaxp = th[ix[K_c_max_p]]; c.cmaxn = th[ix[K_c_max_n]];
+    c.kap_p = th[ix[K_D_sp]] * arr_dp / (Rp_p * Rp_p); c.kap_n = th[ix[K_D_sn]] * arr_dn / (Rp_n * Rp_n);
+    c.bj_p = -tb->BJ / Rp_p; c.bj_n = -tb->BJ / Rp_n;
+    c.fRT = 0.5 * FAR / (RGAS * T0);
+    c.tplus = th[ix[K_tplus]];
+    c.Kfac = 2 * RGAS * (1 - c.tplus) * 1.0 / FAR;          // nu = 1: thermodynamic_factor_linear, custom_functions.jl:177
+    c.thmin_p = th[ix[K_th_min_p]]; c.thmax_p = th[ix[K_th_max_p]];
+    c.thmin_n = th[ix[K_th_min_n]]; c.thmax_n = th[ix[K_th_max_n]];
+    const double qa = esp * lp * c.cmaxp * (c.thmin_p - c.thmax_p);
+    const double qb = esn * ln * c.cmaxn * (c.thmax_n - c.thmin_n);
+    c.I1C = (FAR / 3600.0) * (qa < qb ? qa : qb);           // calc_I1C, aux...jl:632-647
+    c.JI0 = c.I1C * c.h[0] / c.sig_p;                       // d(Phi_s row of first p node)/dI
+    c.JI29 = -c.I1C * c.h[2] / c.sig_n;                     // d(Phi_s row of last n node)/dI
+    c.ce0 = th[ix[K_c_e0]];
+    S.kapv[0] = c.kap_p; S.kapv[1] = c.kap_n;
+  }
+  const int r = lane % NR;
+  for (int k = 0; k < NR; k++) R.Mrow[k] = tb->M[r * NR + k];
+  for (int k = 0; k < NR; k++) { R.Ainv[0][k] = 0.0; R.Ainv[1][k] = 0.0; }
+  for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
+  __syncthreads();
+}
+
+// initial_guess!, reference src/states_definition.jl:80-121
+__device__ inline void cell_initial_guess(CellLDS& S, double* Y, double SOC) {
+  const int lane = lane_id();
+  const CellConst& c = S.cc;
+  const double csp = c.cmaxp * (SOC * (c.thmax_p - c.thmin_p) + c.thmin_p);
+  const double csn = c.cmaxn * (SOC * (c.thmax_n - c.thmin_n) + c.thmin_n);
+  double Up, Un, d;
+  ocv_lco(csp / c.cmaxp, c.T0, c.iso_ref, Up, d);
+  ocv_lic6(csn / c.cmaxn, c.T0, c.iso_ref, Un, d);
+  for (int n = lane; n < NST; n += WAVE) {
+    double v = 0.0;
+    if (n < O_CS) v = c.ce0;
+    else if (n < O_CS + NP * NR) v = csp;
+    else if (n < O_J) v = csn;
+    else if (n >= O_PS && n < O_PS + NP) v = Up;
+    else if (n >= O_PS + NP && n < O_I) v = Un;
+    Y[n] = v;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// node pass shared by the residual and the Jacobian partials.  Lane i < 30 owns control volume i and edge i (i|i+1).
+// ------------------------------------------------------------------------------------------------------------------
+template <bool WANT_RES, bool WANT_JAC>
+__device__ inline void cell_node_pass(CellLDS& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
+  const int lane = lane_id();
+  const CellConst& c = S.cc;
+  const int i = lane < NE ? lane : NE - 1;
+  const bool act = lane < NE;
+  const int sc = sec_of(i);
+  const bool elec = sc != 1;
+  const int jx = sc == 0 ? i : i - NS;                 // index into j / Phi_s / particles
+  const double h = c.h[sc];
+  const double ce = Y[O_CE + i], pe = Y[O_PE + i];
+  double K, dK; keff(ce, c.T0, K, dK);
+  K *= c.bf[sc]; dK *= c.bf[sc];
+  const double D = c.Dc[sc];
+  const double ce_n = __shfl_down(ce, 1), pe_n = __shfl_down(pe, 1), K_n = __shfl_down(K, 1), dK_n = __shfl_down(dK, 1), D_n = __shfl_down(D, 1);
+  // edge i : geometry (numerical_tools.jl:106-215)
+  double beta = 0.5, dist = h;
+  if (i == NP - 1) { beta = (c.h[0] / 2) / (c.h[1] / 2 + c.h[0] / 2); dist = c.h[0] / 2 + c.h[1] / 2; }
+  if (i == NP + NS - 1) { beta = (c.h[1] / 2) / (c.h[2] / 2 + c.h[1] / 2); dist = c.h[1] / 2 + c.h[2] / 2; }
+  const bool edge = i < NE - 1;
+  const double denK = beta * K_n + (1 - beta) * K, Kh = K * K_n / denK;
+  const double denD = beta * D_n + (1 - beta) * D, Dh = D * D_n / denD;
+  const double denC = beta * ce_n + (1 - beta) * ce, cb = ce * ce_n / denC;
+  const double Tb = c.T0 * c.T0 / (beta * c.T0 + (1 - beta) * c.T0);
+  const double dc = (ce_n - ce) / dist;
+  const double w = Kh / dist;
+  const double g = Kh * Tb * dc / cb;
+  double E = edge ? w * (pe - pe_n) + c.Kfac * g : 0.0;   // Phi_e-row edge flux
+  double Nf = edge ? Dh * dc : 0.0;                        // c_e-row edge flux
+  const double E_p = __shfl_up(E, 1), Nf_p = __shfl_up(Nf, 1);
+  const double Em = i > 0 ? E_p : 0.0, Nm = i > 0 ? Nf_p : 0.0;
+  // electrode quantities
+  const double a = sc == 0 ? c.a_p : c.a_n;
+  const double jv = elec ? Y[O_J + jx] : 0.0;
+  const double ps = elec ? Y[O_PS + jx] : 0.0;
+  const double cs = elec ? Y[O_CS + jx * NR + NR - 1] : 1.0;
+  const double cmax = sc == 0 ? c.cmaxp : c.cmaxn;
+  const double kk = sc == 0 ? c.kp : c.kn;
+  const double sg = sc == 0 ? c.sig_p : c.sig_n;
+  double U = 0, dU = 0;
+  if (sc == 0) ocv_lco(cs / cmax, c.T0, c.iso_ref, U, dU);
+  else if (sc == 2) ocv_lic6(cs / cmax, c.T0, c.iso_ref, U, dU);
+  const double eta = ps - pe - U;
+  const double arg = ce * cs * (cmax - cs);
+  const double sq = sqrt(arg > 0.0 ? arg : 0.0);
+  const double xx = c.fRT * eta;
+  const double sh = sinh(xx);
+  const double ps_p = __shfl_up(ps, 1), ps_n = __shfl_down(ps, 1);
+  const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
+  if (WANT_RES) {
+    if (act) {
+      const double src = elec ? (1 - c.tplus) * 1.0 * a * jv : 0.0;
+      Fo[O_CE + i] = ((Nf - Nm) / h + src) / c.eps[sc] - YP[O_CE + i];                 // residuals_c_e!, residuals.jl:6-106
+      Fo[O_PE + i] = (i < NE - 1) ? (E - Em - (elec ? h * FAR * a * jv : 0.0)) : pe;   // residuals_Φ_e!, residuals.jl:554-654
+      if (elec) {
+        Fo[O_J + jx] = 2.0 * kk * sq * sh - jv;                                        // residuals_j!, residuals.jl:491-517
+        double lap = first ? (-ps + ps_n) : (last ? (ps_p - ps) : (ps_p - 2 * ps + ps_n));
+        double f = h * h * a * FAR * jv;
+        const double Idens = Y[O_I] * c.I1C;
+        if (i == 0) f += -Idens * h;
+        if (i == NE - 1) f += Idens * h;
+        Fo[O_PS + jx] = lap - f / sg;                                                  // residuals_Φ_s!, residuals.jl:656-703
+      }
+    }
+    if (lane == 0) {                                                                   // scalar_residual!, scalar_residual.jl:167-172
+      Fo[O_I] = (mode == PLH_MODE_I) ? (Y[O_I] - value) : (Y[O_PS] - Y[O_PS + NJ - 1] - value);
+    }
+  }
+  if (WANT_JAC) {
+    // edge derivatives
+    const double dKh_a = dK * beta * K_n * K_n / (denK * denK), dKh_b = dK_n * (1 - beta) * K * K / (denK * denK);
+    const double dcb_a = beta * ce_n * ce_n / (denC * denC), dcb_b = (1 - beta) * ce * ce / (denC * denC);
+    const double Tq = Tb / dist;
+    const double dg_a = Tq * (dKh_a * (ce_n - ce) / cb - Kh / cb - Kh * (ce_n - ce) * dcb_a / (cb * cb));
+    const double dg_b = Tq * (dKh_b * (ce_n - ce) / cb + Kh / cb - Kh * (ce_n - ce) * dcb_b / (cb * cb));
+    double Ea = edge ? (pe - pe_n) * dKh_a / dist + c.Kfac * dg_a : 0.0;
+    double Eb = edge ? (pe - pe_n) * dKh_b / dist + c.Kfac * dg_b : 0.0;
+    double we = edge ? w : 0.0;
+    double Na = edge ? -Dh / dist : 0.0, Nb = edge ? Dh / dist : 0.0;     // D_eff_linear: dD/dc = 0
+    const double Ea_p = __shfl_up(Ea, 1), Eb_p = __shfl_up(Eb, 1), we_p = __shfl_up(we, 1), Na_p = __shfl_up(Na, 1), Nb_p = __shfl_up(Nb, 1);
+    if (act) {
+      const double he = h * c.eps[sc];
+      S.ceL[i] = i > 0 ? -Na_p / he : 0.0;
+      S.ceD[i] = (Na - (i > 0 ? Nb_p : 0.0)) / he;
+      S.ceU[i] = Nb / he;
+      S.ceJ[i] = elec ? (1 - c.tplus) * a / c.eps[sc] : 0.0;
+      if (i < NE - 1) {
+        S.peL[i] = i > 0 ? -we_p : 0.0; S.peD[i] = (i > 0 ? we_p : 0.0) + we; S.peU[i] = -we;
+        S.pcL[i] = i > 0 ? -Ea_p : 0.0; S.pcD[i] = Ea - (i > 0 ? Eb_p : 0.0); S.pcU[i] = Eb;
+        S.peJ[i] = elec ? -h * FAR * a : 0.0;
+      } else {
+        S.peL[i] = 0; S.peD[i] = 1.0; S.peU[i] = 0; S.pcL[i] = 0; S.pcD[i] = 0; S.pcU[i] = 0; S.peJ[i] = 0;
+      }
+      if (elec) {
+        const double ch = cosh(xx);
+        const double pos = arg > 0.0 ? 1.0 : 0.0;
+        const double inv_sq = pos > 0 ? 1.0 / sq : 0.0;
+        S.gce[jx] = kk * sh * cs * (cmax - cs) * inv_sq;
+        S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * ch * c.fRT * (-dU / cmax));
+        S.gps[jx] = 2.0 * kk * sq * ch * c.fRT;
+        S.gpe[jx] = -S.gps[jx];
+        S.psJ[jx] = -h * h * a * FAR / sg;
+      }
+    }
+  }
+}
+
+// c_s rows (residuals_c_s_avg!, Fickian FDM, residuals.jl:128-180): lane -> (particle = pass*6 + lane/10, row = lane%10)
+__device__ inline void cell_cs_rows(CellLDS& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
+  const int lane = lane_id();
+  const CellConst& c = S.cc;
+  const int r = lane % NR, g = lane / NR;
+  for (int pass = 0; pass < 4; pass++) {
+    const int p = pass * 6 + g;
+    if (lane < 60 && p < NJ) {
+      const double* cs = Y + O_CS + p * NR;
+      double acc = 0.0;
+      for (int k = 0; k < NR; k++) acc += R.Mrow[k] * cs[k];
+      const double kap = p < NP ? c.kap_p : c.kap_n;
+      double rhs = kap * acc;
+      if (r == NR - 1) rhs += (p < NP ? c.bj_p : c.bj_n) * Y[O_J + p];
+      Fo[O_CS + p * NR + r] = rhs - YP[O_CS + p * NR + r];
+    }
+  }
+}
+
+// full residual F(Y, YP) -> Fo (all three are LDS vectors)
+__device__ inline void cell_residual(CellLDS& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo, int mode, double value) {
+  cell_node_pass<true, false>(S, Y, YP, Fo, mode, value);
+  cell_cs_rows(S, R, Y, YP, Fo);
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// linear algebra: J = dF/dY + cj dF/dYP  ->  particle resolvent + j elimination + block-Thomas (3x3) + border
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inv3(const double* A, double* B) {
+  const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+  const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  const double id = 1.0 / det;
+  B[0] = c00 * id; B[1] = (A[2] * A[7] - A[1] * A[8]) * id; B[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  B[3] = c01 * id; B[4] = (A[0] * A[8] - A[2] * A[6]) * id; B[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  B[6] = c02 * id; B[7] = (A[1] * A[6] - A[0] * A[7]) * id; B[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+// node block D_i (3x3 over [c_e, Phi_e, Phi_s]) after eliminating c_s and j ; alg_only: c_e is not an unknown
+__device__ __forceinline__ void node_block(const CellLDS& S, int i, double cj, bool alg_only, double* D) {
+  const int sc = sec_of(i);
+  const bool elec = sc != 1;
+  const int jx = sc == 0 ? i : i - NS;
+  if (alg_only) { D[0] = 1.0; D[1] = 0.0; D[2] = 0.0; D[3] = 0.0; }
+  else { D[0] = S.ceD[i] - cj; D[1] = 0.0; D[2] = 0.0; D[3] = S.pcD[i]; }
+  D[4] = S.peD[i]; D[5] = 0.0; D[6] = 0.0; D[7] = 0.0; D[8] = 1.0;
+  if (elec) {
+    const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
+    D[8] = (first || last) ? -1.0 : -2.0;
+    const double gc = alg_only ? 0.0 : S.gce[jx], ge = S.gpe[jx], gs = S.gps[jx];
+    const double fs = alg_only ? 0.0 : S.fS[i], fp = S.fP[i], fq = S.fQ[i];
+    D[0] -= fs * gc; D[1] -= fs * ge; D[2] -= fs * gs;
+    D[3] -= fp * gc; D[4] -= fp * ge; D[5] -= fp * gs;
+    D[6] -= fq * gc; D[7] -= fq * ge; D[8] -= fq * gs;
+  }
+}
+
+// factor the Newton matrix at the Jacobian partials currently in S (cell_node_pass<.,true> must have run).
+// mode selects the control row; alg_only = the 71x71 algebraic block of the consistent-initialisation Newton.
+__device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
+  const int lane = lane_id();
+  const CellConst& c = S.cc;
+  // 1. particle resolvent rows: (kappa M - cj I)^-1 = V diag(1/(kappa lam - cj)) W
+  if (!alg_only) {
+    const int r = lane % NR;
+    for (int el = 0; el < 2; el++) {
+      const double kap = el == 0 ? c.kap_p : c.kap_n;
+      double acc[NR];
+      for (int k = 0; k < NR; k++) acc[k] = 0.0;
+      for (int m = 0; m < NR; m++) {
+        const double f = tb->V[r * NR + m] / (kap * tb->LAM[m] - cj);
+        for (int k = 0; k < NR; k++) acc[k] += f * tb->W[m * NR + k];
+      }
+      for (int k = 0; k < NR; k++) R.Ainv[el][k] = acc[k];
+      if (lane == NR - 1) S.sig[el] = acc[NR - 1];
+    }
+  }
+  __syncthreads();
+  // 2. Schur-complemented j pivot and the j-elimination factors
+  if (lane < NE) {
+    const int i = lane, sc = sec_of(i);
+    if (sc != 1) {
+      const int jx = sc == 0 ? i : i - NS;
+      const double bj = sc == 0 ? c.bj_p : c.bj_n;
+      const double d = alg_only ? -1.0 : (-1.0 - S.gcs[jx] * S.sig[sc == 0 ? 0 : 1] * bj);
+      S.dj[jx] = d;
+      S.fS[i] = S.ceJ[i] / d; S.fP[i] = S.peJ[i] / d; S.fQ[i] = S.psJ[jx] / d;
+    } else { S.fS[i] = 0; S.fP[i] = 0; S.fQ[i] = 0; }
+  }
+  __syncthreads();
+  // 3. block-Thomas factorisation, executed redundantly by every lane (LDS broadcast reads, no cross-lane traffic)
+  double Dinv_prev[9];
+  for (int i = 0; i < NE; i++) {
+    double D[9];
+    node_block(S, i, cj, alg_only, D);
+    double LDm[9];
+    if (i > 0) {
+      // L_i = [[ceL,0,0],[pcL,peL,0],[0,0,psL]],  U_{i-1} = [[ceU,0,0],[pcU,peU,0],[0,0,psU]]
+      const int scp = sec_of(i - 1), sci = sec_of(i);
+      const double l00 = alg_only ? 0.0 : S.ceL[i], l10 = alg_only ? 0.0 : S.pcL[i], l11 = S.peL[i];
+      const double l22 = (sci != 1 && scp == sci) ? 1.0 : 0.0;
+      for (int k = 0; k < 3; k++) {
+        LDm[k] = l00 * Dinv_prev[k];
+        LDm[3 + k] = l10 * Dinv_prev[k] + l11 * Dinv_prev[3 + k];
+        LDm[6 + k] = l22 * Dinv_prev[6 + k];
+      }
+      const double u00 = alg_only ? 0.0 : S.ceU[i - 1], u10 = alg_only ? 0.0 : S.pcU[i - 1], u11 = S.peU[i - 1];
+      const double u22 = l22;
+      for (int rr = 0; rr < 3; rr++) {
+        D[rr * 3 + 0] -= LDm[rr * 3 + 0] * u00 + LDm[rr * 3 + 1] * u10;
+        D[rr * 3 + 1] -= LDm[rr * 3 + 1] * u11;
+        D[rr * 3 + 2] -= LDm[rr * 3 + 2] * u22;
+      }
+    } else {
+      for (int k = 0; k < 9; k++) LDm[k] = 0.0;
+    }
+    inv3(D, Dinv_prev);
+    if (lane == 0) for (int k = 0; k < 9; k++) { S.Dinv[i][k] = Dinv_prev[k]; S.LD[i][k] = LDm[k]; }
+  }
+  __syncthreads();
+  // 4. border vector for modes whose control row is not "I = value":  x2 = T^-1 (column of I)
+  if (mode != PLH_MODE_I) {
+    double y[3] = {0, 0, 0};
+    for (int i = 0; i < NE; i++) {     // rhs: JI0 in the Phi_s slot of node 0, JI29 in node 29
+      const double b2 = (i == 0) ? c.JI0 : ((i == NE - 1) ? c.JI29 : 0.0);
+      const double* L = S.LD[i];
+      const double n0 = -(L[0] * y[0] + L[1] * y[1] + L[2] * y[2]);
+      const double n1 = -(L[3] * y[0] + L[4] * y[1] + L[5] * y[2]);
+      const double n2 = b2 - (L[6] * y[0] + L[7] * y[1] + L[8] * y[2]);
+      y[0] = n0; y[1] = n1; y[2] = n2;
+      if (lane == 0) { S.y3[i][0] = n0; S.y3[i][1] = n1; S.y3[i][2] = n2; }
+    }
+    __syncthreads();
+    double x[3] = {0, 0, 0};
+    for (int i = NE - 1; i >= 0; i--) {
+      double t0 = S.y3[i][0], t1 = S.y3[i][1], t2 = S.y3[i][2];
+      if (i < NE - 1) {
+        const int sci = sec_of(i), scn = sec_of(i + 1);
+        const double u00 = alg_only ? 0.0 : S.ceU[i], u10 = alg_only ? 0.0 : S.pcU[i], u11 = S.peU[i];
+        const double u22 = (sci != 1 && scn == sci) ? 1.0 : 0.0;
+        t0 -= u00 * x[0]; t1 -= u10 * x[0] + u11 * x[1]; t2 -= u22 * x[2];
+      }
+      const double* Di = S.Dinv[i];
+      x[0] = Di[0] * t0 + Di[1] * t1 + Di[2] * t2;
+      x[1] = Di[3] * t0 + Di[4] * t1 + Di[5] * t2;
+      x[2] = Di[6] * t0 + Di[7] * t1 + Di[8] * t2;
+      if (lane == 0) { S.x2[i][0] = x[0]; S.x2[i][1] = x[1]; S.x2[i][2] = x[2]; }
+    }
+    __syncthreads();
+  }
+}
+
+// solve J x = b in place (b is an LDS vector of NST entries).  alg_only: only rows/cols NDIFF.. are touched.
+__device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, bool alg_only) {
+  const int lane = lane_id();
+  const CellConst& c = S.cc;
+  const int r = lane % NR, g = lane / NR;
+  // a. particle partial solutions  w = A^-1 b_cs
+  if (!alg_only) {
+    for (int pass = 0; pass < 4; pass++) {
+      const int p = pass * 6 + g;
+      double w = 0.0;
+      if (lane < 60 && p < NJ) {
+        const double* bc = b + O_CS + p * NR;
+        const double* Ai = R.Ainv[p < NP ? 0 : 1];
+        for (int k = 0; k < NR; k++) w += Ai[k] * bc[k];
+        if (r == NR - 1) S.w9[p] = w;
+      }
+      R.wreg[pass] = w;
+    }
+  }
+  __syncthreads();
+  // b. fold c_s and j elimination into the node right-hand sides
+  double bjp = 0.0;
+  int jx = 0; bool elec = false;
+  if (lane < NE) {
+    const int i = lane, sc = sec_of(i);
+    elec = sc != 1; jx = sc == 0 ? i : i - NS;
+    double r0 = alg_only ? 0.0 : b[O_CE + i], r1 = b[O_PE + i], r2 = 0.0;
+    if (elec) {
+      bjp = b[O_J + jx] - (alg_only ? 0.0 : S.gcs[jx] * S.w9[jx]);
+      r2 = b[O_PS + jx];
+      if (!alg_only) r0 -= S.fS[i] * bjp;
+      r1 -= S.fP[i] * bjp; r2 -= S.fQ[i] * bjp;
+      if (mode == PLH_MODE_I) {             // control row: 1 * x_I = b_I
+        if (i == 0) r2 -= c.JI0 * b[O_I];
+        if (i == NE - 1) r2 -= c.JI29 * b[O_I];
+      }
+    }
+    S.rhs3[i][0] = r0; S.rhs3[i][1] = r1; S.rhs3[i][2] = r2;
+  }
+  __syncthreads();
+  // c. block-Thomas forward / backward, redundantly on every lane; lane i keeps node i's solution
+  double y[3] = {0, 0, 0};
+  for (int i = 0; i < NE; i++) {
+    const double* L = S.LD[i];
+    const double n0 = S.rhs3[i][0] - (L[0] * y[0] + L[1] * y[1] + L[2] * y[2]);
+    const double n1 = S.rhs3[i][1] - (L[3] * y[0] + L[4] * y[1] + L[5] * y[2]);
+    const double n2 = S.rhs3[i][2] - (L[6] * y[0] + L[7] * y[1] + L[8] * y[2]);
+    y[0] = n0; y[1] = n1; y[2] = n2;
+    if (lane == 0) { S.y3[i][0] = n0; S.y3[i][1] = n1; S.y3[i][2] = n2; }
+  }
+  __syncthreads();
+  double x[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  double xs0 = 0, xs29 = 0;
+  for (int i = NE - 1; i >= 0; i--) {
+    double t0 = S.y3[i][0], t1 = S.y3[i][1], t2 = S.y3[i][2];
+    if (i < NE - 1) {
+      const int sci = sec_of(i), scn = sec_of(i + 1);
+      const double u00 = alg_only ? 0.0 : S.ceU[i], u10 = alg_only ? 0.0 : S.pcU[i], u11 = S.peU[i];
+      const double u22 = (sci != 1 && scn == sci) ? 1.0 : 0.0;
+      t0 -= u00 * x[0]; t1 -= u10 * x[0] + u11 * x[1]; t2 -= u22 * x[2];
+    }
+    const double* Di = S.Dinv[i];
+    x[0] = Di[0] * t0 + Di[1] * t1 + Di[2] * t2;
+    x[1] = Di[3] * t0 + Di[4] * t1 + Di[5] * t2;
+    x[2] = Di[6] * t0 + Di[7] * t1 + Di[8] * t2;
+    if (i == lane) { mx[0] = x[0]; mx[1] = x[1]; mx[2] = x[2]; }
+    if (i == NE - 1) xs29 = x[2];
+    if (i == 0) xs0 = x[2];
+  }
+  // d. border: control row couples Phi_s[first] - Phi_s[last] (voltage mode)
+  double xI;
+  if (mode == PLH_MODE_I) xI = b[O_I];
+  else {
+    const double d2 = S.x2[0][2] - S.x2[NE - 1][2];
+    xI = ((xs0 - xs29) - b[O_I]) / d2;
+    if (lane < NE) { mx[0] -= xI * S.x2[lane][0]; mx[1] -= xI * S.x2[lane][1]; mx[2] -= xI * S.x2[lane][2]; }
+  }
+  __syncthreads();
+  // e. back-substitute j, write node unknowns
+  if (lane < NE) {
+    const int i = lane;
+    if (!alg_only) b[O_CE + i] = mx[0];
+    b[O_PE + i] = mx[1];
+    if (elec) {
+      b[O_PS + jx] = mx[2];
+      const double gc = alg_only ? 0.0 : S.gce[jx];
+      b[O_J + jx] = (bjp - gc * mx[0] - S.gpe[jx] * mx[1] - S.gps[jx] * mx[2]) / S.dj[jx];
+    }
+  }
+  if (lane == 0) b[O_I] = xI;
+  __syncthreads();
+  // f. particles:  dc = w - (A^-1 e_last) * bj * dj
+  if (!alg_only) {
+    for (int pass = 0; pass < 4; pass++) {
+      const int p = pass * 6 + g;
+      if (lane < 60 && p < NJ) {
+        const int el = p < NP ? 0 : 1;
+        const double bj = el == 0 ? c.bj_p : c.bj_n;
+        b[O_CS + p * NR + r] = R.wreg[pass] - R.Ainv[el][NR - 1] * bj * b[O_J + p];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// one entry of the full Jacobian in CSC order from its decode word (see build_csc_codes in petlion_hip.hip)
+//   word = type<<24 | a<<16 | b<<8 | c
+enum JT { JT_CE_L = 1, JT_CE_D, JT_CE_U, JT_CE_J, JT_CS_CS, JT_CS_J, JT_J_CE, JT_J_CS, JT_J_J, JT_J_PE, JT_J_PS,
+          JT_PE_CL, JT_PE_CD, JT_PE_CU, JT_PE_L, JT_PE_D, JT_PE_U, JT_PE_J, JT_PS_L, JT_PS_D, JT_PS_U, JT_PS_J, JT_PS_I,
+          JT_CTRL_P1, JT_CTRL_M1 };
+__device__ inline double jac_entry(const CellLDS& S, const Tables* __restrict__ tb, unsigned w, double cj) {
+  const int t = w >> 24, a = (w >> 16) & 255, bb = (w >> 8) & 255, cc = w & 255;
+  const CellConst& c = S.cc;
+  switch (t) {
+    case JT_CE_L: return S.ceL[a];
+    case JT_CE_D: return S.ceD[a] - cj;
+    case JT_CE_U: return S.ceU[a];
+    case JT_CE_J: return S.ceJ[a];
+    case JT_CS_CS: return (a < NP ? c.kap_p : c.kap_n) * tb->M[bb * NR + cc] - (bb == cc ? cj : 0.0);
+    case JT_CS_J: return a < NP ? c.bj_p : c.bj_n;
+    case JT_J_CE: return S.gce[a];
+    case JT_J_CS: return S.gcs[a];
+    case JT_J_J: return -1.0;
+    case JT_J_PE: return S.gpe[a];
+    case JT_J_PS: return S.gps[a];
+    case JT_PE_CL: return S.pcL[a];
+    case JT_PE_CD: return S.pcD[a];
+    case JT_PE_CU: return S.pcU[a];
+    case JT_PE_L: return S.peL[a];
+    case JT_PE_D: return S.peD[a];
+    case JT_PE_U: return S.peU[a];
+    case JT_PE_J: return S.peJ[a];
+    case JT_PS_L: return 1.0;
+    case JT_PS_D: return bb ? -1.0 : -2.0;
+    case JT_PS_U: return 1.0;
+    case JT_PS_J: return S.psJ[a];
+    case JT_PS_I: return a == 0 ? c.JI0 : c.JI29;
+    case JT_CTRL_P1: return 1.0;
+    case JT_CTRL_M1: return -1.0;
+  }
+  return 0.0;
+}
+
+}  // namespace pl

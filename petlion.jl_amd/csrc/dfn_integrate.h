@@ -1,0 +1,501 @@
+// dfn_integrate.h -- device-side time stepping for one cell per wavefront.
+//
+//  * consistent initialisation  = newtons_method!                      (reference src/model_evaluation.jl:430-480)
+//  * variable-order (1..5) variable-step BDF with modified Newton      = what the reference gets from SUNDIALS IDA through
+//    Sundials.jl's step! (reference src/model_evaluation.jl:259-287, 312-333); algorithm restated from the IDA documentation
+//    (fixed-leading-coefficient BDF, DASSL lineage): IDASetCoeffs / IDANls / IDATestError / IDAHandleNFlag /
+//    IDACompleteStep / IDAGetSolution and the ONE_STEP_TSTOP stop tests.  SUNDIALS' documented default constants are used.
+//  * run logic: tstops, SOC trapezoid, stop conditions with direction guards, back-interpolation of the last point
+//                                                                       (reference src/checks.jl:1-249, src/model_evaluation.jl:174-232, 288-382,
+//                                                                        src/physics_equations/scalar_residual.jl:103-111)
+// All scalars of the integrator are wave-uniform (every lane holds the same value); vectors live in LDS and are processed
+// lane-strided (element n -> lane n % 64).
+#pragma once
+#include "dfn_cell.h"
+
+namespace pl {
+
+struct IdaScalars {
+  double psi[MAXORD + 1], alpha[MAXORD + 1], beta[MAXORD + 1], sigma[MAXORD + 1], gamma[MAXORD + 1];
+  double tn, hh, hused, cj, cjlast, cjold, cjratio, ss, rr, h0_forced;
+  int kk, kused, knew, phase, ns, maxord;
+  int nst;
+};
+
+struct Counters { long long n_steps, n_res, n_jac, n_fact, n_solve, n_newton, n_errfail, n_convfail, sum_kp2, n_init_iters; };
+
+#define PL_VEC(n) for (int n = lane; n < NST; n += WAVE)
+
+__device__ __forceinline__ double wrms(const double* v, const double* w) {
+  const int lane = lane_id();
+  double s = 0.0;
+  PL_VEC(n) { const double p = v[n] * w[n]; s += p * p; }
+  return sqrt(wave_sum(s) / NST);
+}
+
+// ---- consistent initialisation (newtons_method!) : Y (LDS, in/out), YP (LDS, out).  returns 0 / PLH_ERR_INIT ----
+__device__ inline int cell_init_consistent(CellLDS& S, LaneRegs& R, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
+                                           int mode, double value, double reltol_init, Counters& cnt) {
+  const int lane = lane_id();
+  PL_VEC(n) YP[n] = 0.0;
+  __syncthreads();
+  int ok = 0;
+  for (int iter = 1; iter <= 100; iter++) {
+    cell_node_pass<true, true>(S, Y, YP, res, mode, value);      // R_alg + J_alg partials (differential rows ignored)
+    __syncthreads();
+    cell_factor(S, R, tb, 0.0, mode, true);
+    cell_solve(S, R, res, mode, true);
+    cnt.n_res++; cnt.n_jac++; cnt.n_fact++; cnt.n_solve++; cnt.n_init_iters++;
+    double s = 0.0;
+    for (int n = NDIFF + lane; n < NST; n += WAVE) { const double d = res[n]; Y[n] -= d; s += d * d; }
+    const double nrm = sqrt(wave_sum(s));
+    __syncthreads();
+    if (nrm < reltol_init) { ok = 1; break; }
+    if (!(nrm == nrm)) break;
+  }
+  if (!ok) return PLH_ERR_INIT;
+  // YP_diff = rhs_diff(Y)   (R_diff with YP = 0)
+  cell_residual(S, R, Y, YP, res, mode, value);
+  cnt.n_res++;
+  for (int n = lane; n < NDIFF; n += WAVE) YP[n] = res[n];
+  __syncthreads();
+  // finite-difference estimate of the algebraic derivatives (model_evaluation.jl:462-477)
+  const double ce0 = S.cc.ce0;
+  const double epsce = nextafter(ce0, 1e300) - ce0;
+  double dt = sqrt(epsce);
+  if (10.0 * reltol_init > dt) dt = 10.0 * reltol_init;
+  PL_VEC(n) Ytmp[n] = Y[n] + dt * YP[n];
+  __syncthreads();
+  cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
+  __syncthreads();
+  cell_solve(S, R, res, mode, true);
+  cnt.n_res++; cnt.n_solve++;
+  for (int n = NDIFF + lane; n < NST; n += WAVE) YP[n] = -res[n] / dt;
+  __syncthreads();
+  return 0;
+}
+
+// ---- IDA pieces ----
+__device__ inline void ida_reinit(CellLDS& S, IdaScalars& I, const double* y0, const double* yp0, int maxord) {
+  const int lane = lane_id();
+  I.tn = 0.0; I.nst = 0; I.kk = 0; I.kused = 0; I.hused = 0.0; I.hh = 0.0; I.maxord = maxord;
+  I.cjratio = 1.0; I.ss = 20.0; I.phase = 0; I.ns = 0; I.h0_forced = 0.0; I.cj = 0.0; I.cjlast = 0.0; I.cjold = 0.0; I.rr = 0.0; I.knew = 0;
+  for (int k = 0; k <= MAXORD; k++) { I.psi[k] = 0; I.alpha[k] = 0; I.beta[k] = 0; I.sigma[k] = 0; I.gamma[k] = 0; }
+  PL_VEC(n) { S.phi[0][n] = y0[n]; S.phi[1][n] = yp0[n]; }
+  __syncthreads();
+}
+
+__device__ inline void set_ewt(CellLDS& S, double rtol, double atol) {
+  const int lane = lane_id();
+  PL_VEC(n) S.ewt[n] = 1.0 / (rtol * fabs(S.phi[0][n]) + atol);
+  __syncthreads();
+}
+
+__device__ inline double ida_set_coeffs(CellLDS& S, IdaScalars& I) {
+  const int lane = lane_id();
+  const int kk = I.kk; const double hh = I.hh;
+  if (hh != I.hused || kk != I.kused) I.ns = 0;
+  I.ns = (I.ns + 1 < I.kused + 2) ? I.ns + 1 : I.kused + 2;
+  if (kk + 1 >= I.ns) {
+    I.beta[0] = 1.0; I.alpha[0] = 1.0; double temp1 = hh; I.gamma[0] = 0.0; I.sigma[0] = 1.0;
+    for (int i = 1; i <= kk; i++) {
+      const double temp2 = I.psi[i - 1]; I.psi[i - 1] = temp1; I.beta[i] = I.beta[i - 1] * I.psi[i - 1] / temp2; temp1 = temp2 + hh;
+      I.alpha[i] = hh / temp1; I.sigma[i] = i * I.sigma[i - 1] * I.alpha[i]; I.gamma[i] = I.gamma[i - 1] + I.alpha[i - 1] / hh;
+    }
+    I.psi[kk] = temp1;
+  }
+  double alphas = 0.0, alpha0 = 0.0;
+  for (int i = 0; i < kk; i++) { alphas -= 1.0 / (i + 1); alpha0 -= I.alpha[i]; }
+  I.cjlast = I.cj; I.cj = -alphas / hh;
+  double ck = fabs(I.alpha[kk] + alphas - alpha0); if (ck < I.alpha[kk]) ck = I.alpha[kk];
+  for (int i = I.ns; i <= kk; i++) { const double b = I.beta[i]; PL_VEC(n) S.phi[i][n] *= b; }
+  I.tn += hh;
+  __syncthreads();
+  return ck;
+}
+
+// yy = ypred + ee, yp = yppred + cj ee with the predictor re-summed from phi (no separate predictor storage)
+__device__ inline void form_iterate(CellLDS& S, const IdaScalars& I) {
+  const int lane = lane_id();
+  PL_VEC(n) {
+    double a = S.phi[0][n], b = 0.0;
+    for (int j = 1; j <= I.kk; j++) { const double p = S.phi[j][n]; a += p; b += I.gamma[j] * p; }
+    const double e = S.ee[n];
+    S.yy[n] = a + e; S.yp[n] = b + I.cj * e;
+  }
+  __syncthreads();
+}
+
+// IDANls + Newton + convergence test.  0 ok, 1 recoverable failure
+__device__ inline int ida_nls(CellLDS& S, LaneRegs& R, const Tables* tb, IdaScalars& I, int mode, double value, int jac_every_step, Counters& cnt) {
+  const int lane = lane_id();
+  const double epsNewt = 0.33, toldel = 0.0001 * epsNewt;
+  int callLSetup = 0;
+  if (I.nst == 0) { I.cjold = I.cj; I.ss = 20.0; callLSetup = 1; }
+  else {
+    I.cjratio = I.cj / I.cjold;
+    const double temp1 = (1.0 - 0.25) / (1.0 + 0.25), temp2 = 1.0 / temp1;
+    if (I.cjratio < temp1 || I.cjratio > temp2) callLSetup = 1;
+    if (I.cj != I.cjlast) I.ss = 100.0;
+    if (jac_every_step) callLSetup = 1;
+  }
+  PL_VEC(n) S.ee[n] = 0.0;
+  __syncthreads();
+  int jcur = 0, ret = 0;
+  for (;;) {
+    form_iterate(S, I);
+    if (callLSetup) {
+      cell_node_pass<true, true>(S, S.yy, S.yp, S.delta, mode, value);
+      cell_cs_rows(S, R, S.yy, S.yp, S.delta);
+      __syncthreads();
+      cell_factor(S, R, tb, I.cj, mode, false);
+      cnt.n_res++; cnt.n_jac++; cnt.n_fact++;
+      I.cjold = I.cj; I.cjratio = 1.0; I.ss = 20.0; jcur = 1;
+    } else {
+      cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
+      cnt.n_res++;
+    }
+    int m = 0; double oldnrm = 0.0;
+    for (;;) {
+      cnt.n_newton++; cnt.n_solve++;
+      PL_VEC(n) S.delta[n] = -S.delta[n];
+      __syncthreads();
+      cell_solve(S, R, S.delta, mode, false);
+      const double sc = (I.cjratio != 1.0) ? 2.0 / (1.0 + I.cjratio) : 1.0;
+      double s = 0.0;
+      PL_VEC(n) { const double d = S.delta[n] * sc; S.ee[n] += d; const double p = d * S.ewt[n]; s += p * p; }
+      const double delnrm = sqrt(wave_sum(s) / NST);
+      __syncthreads();
+      ret = 2;
+      if (m == 0) { oldnrm = delnrm; if (delnrm <= toldel) ret = 0; }
+      else { const double rate = pow(delnrm / oldnrm, 1.0 / m); if (rate > 0.9) ret = 1; else I.ss = rate / (1.0 - rate); }
+      if (ret == 2 && I.ss * delnrm <= epsNewt) ret = 0;
+      if (!(delnrm == delnrm)) ret = 1;
+      if (ret == 0) { jcur = 0; break; }
+      if (ret != 2) break;
+      m++; if (m >= 4) { ret = 1; break; }
+      form_iterate(S, I);
+      cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
+      cnt.n_res++;
+    }
+    if (ret > 0 && !jcur) { callLSetup = 1; PL_VEC(n) S.ee[n] = 0.0; __syncthreads(); continue; }
+    break;
+  }
+  form_iterate(S, I);
+  return ret;
+}
+
+__device__ inline int ida_test_error(CellLDS& S, IdaScalars& I, double ck, double& err_k, double& err_km1) {
+  const int lane = lane_id();
+  const int kk = I.kk;
+  double s0 = 0, s1 = 0, s2 = 0;
+  PL_VEC(n) {
+    const double w = S.ewt[n], e = S.ee[n];
+    double p = e * w; s0 += p * p;
+    if (kk > 1) { const double d1 = S.phi[kk][n] + e; p = d1 * w; s1 += p * p;
+      if (kk > 2) { const double d2 = d1 + S.phi[kk - 1][n]; p = d2 * w; s2 += p * p; } }
+  }
+  const double enorm_k = sqrt(wave_sum(s0) / NST);
+  err_k = I.sigma[kk] * enorm_k; const double terr_k = (kk + 1) * err_k;
+  I.knew = kk; err_km1 = 0.0;
+  if (kk > 1) {
+    const double enorm_km1 = sqrt(wave_sum(s1) / NST); err_km1 = I.sigma[kk - 1] * enorm_km1; const double terr_km1 = kk * err_km1;
+    if (kk > 2) {
+      const double enorm_km2 = sqrt(wave_sum(s2) / NST); const double err_km2 = I.sigma[kk - 2] * enorm_km2; const double terr_km2 = (kk - 1) * err_km2;
+      if ((terr_km1 > terr_km2 ? terr_km1 : terr_km2) <= terr_k) I.knew = kk - 1;
+    } else if (terr_km1 <= 0.5 * terr_k) I.knew = kk - 1;
+  }
+  return (ck * enorm_k > 1.0) ? 1 : 0;
+}
+
+__device__ inline void ida_restore(CellLDS& S, IdaScalars& I, double saved_t) {
+  const int lane = lane_id();
+  I.tn = saved_t;
+  for (int j = 1; j <= I.kk; j++) I.psi[j - 1] = I.psi[j] - I.hh;
+  if (I.ns <= I.kk) for (int j = I.ns; j <= I.kk; j++) { const double b = 1.0 / I.beta[j]; PL_VEC(n) S.phi[j][n] *= b; }
+  __syncthreads();
+}
+
+__device__ inline void ida_complete_step(CellLDS& S, IdaScalars& I, double err_k, double err_km1) {
+  const int lane = lane_id();
+  I.nst++;
+  const int kdiff = I.kk - I.kused; I.kused = I.kk; I.hused = I.hh;
+  if (I.knew == I.kk - 1 || I.kk == I.maxord) I.phase = 1;
+  if (I.phase == 0) { if (I.nst > 1) { I.kk++; I.hh *= 2.0; } }
+  else {
+    int action = 0;
+    double err_kp1 = 0.0, err_knew;
+    if (I.knew == I.kk - 1) action = 1;
+    else if (I.kk == I.maxord) action = 2;
+    else if (I.kk + 1 >= I.ns || kdiff == 1) action = 2;
+    if (action == 0) {
+      double s = 0.0;
+      PL_VEC(n) { const double p = (S.ee[n] - S.phi[I.kk + 1][n]) * S.ewt[n]; s += p * p; }
+      const double enorm = sqrt(wave_sum(s) / NST); err_kp1 = enorm / (I.kk + 2);
+      const double terr_k = (I.kk + 1) * err_k, terr_kp1 = (I.kk + 2) * err_kp1;
+      if (I.kk == 1) action = (terr_kp1 >= 0.5 * terr_k) ? 2 : 3;
+      else { const double terr_km1 = I.kk * err_km1;
+        if (terr_km1 <= (terr_k < terr_kp1 ? terr_k : terr_kp1)) action = 1; else if (terr_kp1 >= terr_k) action = 2; else action = 3; }
+    }
+    if (action == 3) { I.kk++; err_knew = err_kp1; } else if (action == 1) { I.kk--; err_knew = err_km1; } else err_knew = err_k;
+    double hnew = I.hh; I.rr = pow(2.0 * err_knew + 0.0001, -1.0 / (I.kk + 1));
+    if (I.rr >= 2.0) hnew = 2.0 * I.hh;
+    else if (I.rr <= 1.0) { I.rr = I.rr < 0.9 ? I.rr : 0.9; I.rr = I.rr > 0.5 ? I.rr : 0.5; hnew = I.hh * I.rr; }
+    I.hh = hnew;
+  }
+  const int ku = I.kused;
+  PL_VEC(n) {
+    const double e = S.ee[n];
+    if (ku < I.maxord) S.phi[ku + 1][n] = e;
+    double acc = S.phi[ku][n] + e; S.phi[ku][n] = acc;
+    for (int j = ku - 1; j >= 0; j--) { acc += S.phi[j][n]; S.phi[j][n] = acc; }
+  }
+  __syncthreads();
+}
+
+// IDAGetSolution(t): y -> yo, y' -> ypo (LDS vectors)
+__device__ inline void ida_get_solution(CellLDS& S, const IdaScalars& I, double t, double* yo, double* ypo) {
+  const int lane = lane_id();
+  int kord = I.kused; if (kord == 0) kord = 1;
+  const double delt = t - I.tn;
+  double c = 1.0, d = 0.0, gam = delt / I.psi[0];
+  double cv[MAXORD + 1], dv[MAXORD + 1];
+  cv[0] = c;
+  for (int j = 1; j <= kord; j++) { d = d * gam + c / I.psi[j - 1]; c = c * gam; gam = (delt + I.psi[j - 1]) / I.psi[j]; cv[j] = c; dv[j - 1] = d; }
+  PL_VEC(n) {
+    double s = 0.0, sp = 0.0;
+    for (int j = 0; j <= kord; j++) s += cv[j] * S.phi[j][n];
+    for (int j = 1; j <= kord; j++) sp += dv[j - 1] * S.phi[j][n];
+    yo[n] = s; ypo[n] = sp;
+  }
+  __syncthreads();
+}
+
+// one IDASolve(ONE_STEP_TSTOP) call: advances, returns y(tret), y'(tret) in S.yy / S.yp.  0 ok, <0 failure
+__device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaScalars& I, double tstop, double& tret, int mode, double value,
+                               const plh_opts& o, Counters& cnt) {
+  const int lane = lane_id();
+  const double uround = 2.220446049250313e-16;
+  if (I.nst == 0) {
+    set_ewt(S, o.reltol, o.abstol);
+    const double tdist = fabs(tstop - I.tn);
+    double hh = I.h0_forced;
+    if (hh == 0.0) {
+      hh = 0.001 * tdist;
+      const double ypnorm = wrms(S.phi[1], S.ewt);
+      if (ypnorm > 0.5 / hh) hh = 0.5 / ypnorm;
+    }
+    if ((I.tn + hh - tstop) * hh > 0.0) hh = (tstop - I.tn) * (1.0 - 4.0 * uround);
+    I.hh = hh; I.kk = 0; I.kused = 0;
+    PL_VEC(n) S.phi[1][n] *= hh;
+    __syncthreads();
+  } else {
+    const double troundoff = 100.0 * uround * (fabs(I.tn) + fabs(I.hh));
+    if (fabs(I.tn - tstop) <= troundoff) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; return 0; }
+    if ((I.tn + I.hh - tstop) * I.hh > 0.0) I.hh = (tstop - I.tn) * (1.0 - 4.0 * uround);
+    set_ewt(S, o.reltol, o.abstol);
+  }
+  const double saved_t = I.tn; int ncf = 0, nef = 0; double err_k = 0, err_km1 = 0;
+  if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; I.psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; }
+  for (;;) {
+    const double ck = ida_set_coeffs(S, I);
+    const int nflag = ida_nls(S, R, tb, I, mode, value, o.jac_every_step, cnt);
+    int errfail = 0;
+    if (nflag == 0) errfail = ida_test_error(S, I, ck, err_k, err_km1);
+    if (nflag != 0 || errfail) {
+      ida_restore(S, I, saved_t);
+      I.phase = 1;
+      if (!errfail) {
+        cnt.n_convfail++;
+        I.rr = 0.25; I.hh *= I.rr; ncf++;
+        if (ncf >= 10) return PLH_ERR_STALL;
+      } else {
+        cnt.n_errfail++; nef++;
+        if (nef == 1) { const double err_knew = (I.kk == I.knew) ? err_k : err_km1; I.kk = I.knew;
+          I.rr = 0.9 * pow(2.0 * err_knew + 0.0001, -1.0 / (I.kk + 1)); I.rr = I.rr < 0.9 ? I.rr : 0.9; I.rr = I.rr > 0.25 ? I.rr : 0.25; I.hh *= I.rr; }
+        else if (nef == 2) { I.kk = I.knew; I.rr = 0.25; I.hh *= I.rr; }
+        else if (nef < 10) { I.kk = 1; I.rr = 0.25; I.hh *= I.rr; }
+        else return PLH_ERR_STALL;
+      }
+      const double tscale = fabs(I.tn) > 1.0 ? fabs(I.tn) : 1.0;
+      if (fabs(I.hh) < 1e-14 * tscale) return PLH_ERR_STALL;
+      if (I.nst == 0) { I.psi[0] = I.hh; const double rr = I.rr; PL_VEC(n) S.phi[1][n] *= rr; __syncthreads(); }
+      continue;
+    }
+    break;
+  }
+  cnt.n_steps++; cnt.sum_kp2 += I.kk + 2;
+  ida_complete_step(S, I, err_k, err_km1);
+  const double troundoff = 100.0 * uround * (fabs(I.tn) + fabs(I.hh));
+  if (fabs(I.tn - tstop) <= troundoff) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; return 0; }
+  if ((I.tn + I.hh - tstop) * I.hh > 0.0) I.hh = (tstop - I.tn) * (1.0 - 4.0 * uround);
+  ida_get_solution(S, I, I.tn, S.yy, S.yp); tret = I.tn;
+  return 0;
+}
+
+// ---- stop conditions (check_simulation_stop!, src/checks.jl:1-224); scalars are wave-uniform ----
+struct PrevVals { double frac, V, SOC, I, c_s_n, c_e_min, eta_pl; };
+
+__device__ __forceinline__ double cellV(const double* Y) { return Y[O_PS] - Y[O_PS + NJ - 1]; }
+
+__device__ inline void check_stop(const CellLDS& S, const plh_run& run, const plh_opts& o, double t, double tf, const double* Y, const double* YP,
+                                  double SOC, PrevVals& pv, int& flag) {
+  const double eps = t < 1.0 ? o.reltol : 0.0;
+  if (t >= tf) { flag = 0; return; }
+  if (!o.check_bounds || run.value_kind == PLH_VAL_REST) return;
+  const plh_bounds& b = run.bounds;
+  const double Ic = Y[O_I];
+  if (run.mode != PLH_MODE_I) {                                                         // check_stop_I, checks.jl:31-54
+    const double dI = YP[O_I];
+    if ((Ic - b.I_max > eps) && dI > 0) { const double f = (pv.I - b.I_max) / (pv.I - Ic); if (f < pv.frac) { pv.frac = f; flag = 7; } }
+    else if ((b.I_min - Ic > eps) && dI < 0) { const double f = (pv.I - b.I_min) / (pv.I - Ic); if (f < pv.frac) { pv.frac = f; flag = 8; } }
+    pv.I = Ic;
+  }
+  if (run.mode != PLH_MODE_V) {                                                         // check_stop_V, checks.jl:56-81
+    const double V = cellV(Y), dV = cellV(YP);
+    if ((b.V_min - V > eps) && dV < 0) { const double f = (pv.V - b.V_min) / (pv.V - V); if (f < pv.frac) { pv.frac = f; flag = 1; } }
+    else if ((V - b.V_max > eps) && dV > 0) { const double f = (pv.V - b.V_max) / (pv.V - V); if (f < pv.frac) { pv.frac = f; flag = 2; } }
+    pv.V = V;
+  }
+  {                                                                                     // check_stop_SOC, checks.jl:83-104
+    if ((b.SOC_min - SOC > eps) && Ic < 0) { const double f = (pv.SOC - b.SOC_min) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; flag = 3; } }
+    else if ((SOC - b.SOC_max > eps) && Ic > 0) { const double f = (pv.SOC - b.SOC_max) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; flag = 4; } }
+    pv.SOC = SOC;
+  }
+  if (b.c_s_n_max == b.c_s_n_max) {                                                     // check_stop_c_s_surf, checks.jl:141-161
+    double cm = -1e300; for (int i = 0; i < NN; i++) { const double v = Y[O_CS + NP * NR + (i + 1) * NR - 1]; cm = v > cm ? v : cm; }
+    const double lim = b.c_s_n_max * S.cc.cmaxn;
+    if (Ic > 0 && cm - lim > eps) { const double f = (pv.c_s_n - lim) / (pv.c_s_n - cm); if (f < pv.frac) { pv.frac = f; flag = 6; } }
+    pv.c_s_n = cm;
+  }
+  if (b.c_e_min == b.c_e_min) {                                                         // check_stop_c_e, checks.jl:163-183
+    double cm = 1e300; for (int i = 0; i < NE; i++) { const double v = Y[O_CE + i]; cm = v < cm ? v : cm; }
+    if (b.c_e_min - cm > eps) { const double f = (pv.c_e_min - b.c_e_min) / (pv.c_e_min - cm); if (f < pv.frac) { pv.frac = f; flag = 9; } }
+    pv.c_e_min = cm;
+  }
+  if (b.eta_plating_min == b.eta_plating_min) {                                         // check_stop_η_plating, checks.jl:185-201
+    const double ep = Y[O_PS + NP] - Y[O_PE + NP + NS], dep = YP[O_PS + NP] - YP[O_PE + NP + NS];
+    if (b.eta_plating_min - ep > eps && dep < 0) { const double f = (pv.eta_pl - b.eta_plating_min) / (pv.eta_pl - ep); if (f < pv.frac) { pv.frac = f; flag = 11; } }
+    pv.eta_pl = ep;
+  }
+}
+
+struct CellOut {
+  double *t, *V, *I, *SOC, *T;
+  int max_pts;
+};
+
+// the whole protocol for one cell.  Yprev/YPprev: per-cell scratch in HBM holding the previous accepted point (needed only for
+// the back-interpolation at the end of a run; written with coalesced fire-and-forget stores every step).
+__device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
+                                     const CellOut& out, int* n_pts_out, plh_run_info* info, Counters& cnt, double* Yfin, double* YPfin,
+                                     double* Yprev, double* YPprev) {
+  const int lane = lane_id();
+  IdaScalars I;
+  int nout = 0;
+  double t_global = 0.0, SOC = SOC0, prev_V = 0, prev_I = 0;
+  bool have_prev = false;
+  const double T0 = S.cc.T0;
+  if (Yinit) {                                                          // simulate!(sol, ...): continue from sol.Y[end]
+    PL_VEC(n) S.yy[n] = Yinit[n];
+    __syncthreads();
+    have_prev = true; t_global = t_init; prev_V = cellV(S.yy); prev_I = S.yy[O_I];
+  }
+  auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
+    if (lane == 0 && idx < out.max_pts) {
+      if (out.t) out.t[idx] = tt;
+      if (out.V) out.V[idx] = cellV(Y);
+      if (out.I) out.I[idx] = Y[O_I];
+      if (out.SOC) out.SOC[idx] = soc;
+      if (out.T) out.T[idx] = T0;
+    }
+  };
+  for (int r = 0; r < n_runs; r++) {
+    const plh_run run = runs[r];
+    const int mode = run.mode;
+    const bool new_run = !have_prev;
+    double t0;
+    // S.yy holds the current state Y, S.yp the current YP between steps
+    if (new_run) { t0 = 0.0; cell_initial_guess(S, S.yy, SOC0); SOC = SOC0; }
+    else t0 = nextafter(t_global, 1e300);                               // initial_time, model_evaluation.jl:112
+    // initial_current! (input_methods.jl:11-74)
+    double value = run.value, Iguess;
+    if (mode == PLH_MODE_I) {
+      if (run.value_kind == PLH_VAL_HOLD) value = have_prev ? prev_I : 0.0;
+      else if (run.value_kind == PLH_VAL_REST) value = 0.0;
+      Iguess = value;
+    } else {
+      if (run.value_kind == PLH_VAL_HOLD) { value = prev_V; Iguess = prev_V; }
+      else if (have_prev && prev_I != 0.0) Iguess = prev_I;
+      else { const double OCV = cellV(S.yy); Iguess = value > OCV ? 1.0 : -1.0; }
+    }
+    __syncthreads();
+    if (lane == 0) S.yy[O_I] = Iguess;
+    __syncthreads();
+    int flag = PLH_FLAG_RUNNING;
+    int ierr = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, o.reltol_init, cnt);
+    plh_run_info ri; ri.flag = PLH_FLAG_RUNNING; ri.iterations = 0; ri.t_end = t_global; ri.V = 0; ri.I = 0; ri.SOC = SOC; ri.T_avg = T0;
+    if (ierr != 0) { ri.flag = ierr; if (lane == 0) info[r] = ri; for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; info[q] = z; } break; }
+    ida_reinit(S, I, S.yy, S.yp, o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD);
+    double tstops[2]; int nts = 0, its = 0;
+    if (!new_run && run.tf > 1.0) tstops[nts++] = 1.0;                  // postfix_integrator!, model_evaluation.jl:288-310
+    tstops[nts++] = run.tf;
+    PrevVals pv; pv.frac = 1.0; pv.V = -1; pv.SOC = -1; pv.I = -1; pv.c_s_n = -1; pv.c_e_min = -1; pv.eta_pl = -1;
+    save_pt(nout, t0, S.yy, SOC); nout++;
+    check_stop(S, run, o, 0.0, run.tf, S.yy, S.yp, SOC, pv, flag);
+    PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
+    __syncthreads();
+    double tprev = 0.0, t = 0.0, t_prev_saved = t0; int iter = 1; bool stalled_once = false;
+    double I_prev_pt = S.yy[O_I];
+    while (flag == PLH_FLAG_RUNNING) {
+      double tret = t; tprev = t;
+      const int sf = ida_step(S, R, tb, I, tstops[its], tret, mode, value, o, cnt);
+      if (sf != 0) {
+        if (I.nst == 0 && !stalled_once) {                              // check_solve, checks.jl:227-237
+          stalled_once = true;
+          PL_VEC(n) { S.yy[n] = Yprev[n]; S.yp[n] = YPprev[n]; }
+          __syncthreads();
+          ida_reinit(S, I, S.yy, S.yp, I.maxord); I.h0_forced = o.reltol; iter++; t = tprev; continue;
+        }
+        flag = sf; break;
+      }
+      if (tret >= tstops[its] && its + 1 < nts) its++;
+      iter++; t = tret;
+      const double SOC_new = SOC + 0.5 * ((t + t0) - t_prev_saved) * (S.yy[O_I] + I_prev_pt) / 3600.0;   // calc_SOC, scalar_residual.jl:103-111
+      SOC = SOC_new;
+      save_pt(nout, t + t0, S.yy, SOC); nout++;
+      check_stop(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
+      if (t == tprev) { flag = PLH_ERR_STALL; break; }
+      if (iter == o.maxiters) { flag = PLH_ERR_MAXITERS; break; }
+      if (nout >= out.max_pts && out.max_pts > 0 && flag == PLH_FLAG_RUNNING) { flag = PLH_ERR_OUTPUT_FULL; break; }
+      if (flag == PLH_FLAG_RUNNING) {
+        __syncthreads();
+        PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
+        __syncthreads();
+        t_prev_saved = t + t0; I_prev_pt = S.yy[O_I];
+      }
+    }
+    double t_end = t + t0;
+    if (flag > 0 && o.interp_final && t > 1.0) {                        // interp_final_points!, model_evaluation.jl:369-382
+      const double fr = pv.frac;
+      const double ti = fr * (t - tprev) + tprev;
+      __syncthreads();
+      PL_VEC(n) { S.yy[n] = fr * (S.yy[n] - Yprev[n]) + Yprev[n]; S.yp[n] = fr * (S.yp[n] - YPprev[n]) + YPprev[n]; }
+      __syncthreads();
+      SOC = SOC + 0.5 * ((ti + t0) - (t + t0)) * (S.yy[O_I] + S.yy[O_I]) / 3600.0;
+      t_end = ti + t0;
+      save_pt(nout - 1, t_end, S.yy, SOC);
+    }
+    ri.flag = flag; ri.iterations = iter; ri.t_end = t_end; ri.V = cellV(S.yy); ri.I = S.yy[O_I]; ri.SOC = SOC; ri.T_avg = T0;
+    if (lane == 0) info[r] = ri;
+    t_global = t_end; have_prev = true; prev_V = ri.V; prev_I = ri.I;
+    if (flag < 0) { for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; z.iterations = 0; info[q] = z; } break; }
+    __syncthreads();
+  }
+  if (lane == 0 && n_pts_out) *n_pts_out = nout < out.max_pts ? nout : out.max_pts;
+  __syncthreads();
+  if (Yfin) PL_VEC(n) Yfin[n] = S.yy[n];
+  if (YPfin) PL_VEC(n) YPfin[n] = S.yp[n];
+}
+
+}  // namespace pl

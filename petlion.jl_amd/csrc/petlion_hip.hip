@@ -1,0 +1,403 @@
+// petlion_hip.hip -- kernels + the C ABI of include/petlion_hip.h  (libpetlion_hip.so, gfx950).
+//
+// One workgroup = one 64-lane wavefront = one cell.  Grid = n_cells workgroups; ~38 KB of LDS per workgroup, so four cells are
+// resident per CU (one per SIMD) and 1024 cells fill the 256 CUs of an MI355X in a single wave of workgroups.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dfn_integrate.h"
+#include "radial_tables_nr10.h"
+
+#ifndef PL_WAVE_EMU
+#define PL_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#endif
+
+using namespace pl;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_vec(double* dst, const double* __restrict__ src) {
+  const int lane = lane_id();
+  for (int n = lane; n < NST; n += WAVE) dst[n] = src[n];
+}
+__device__ __forceinline__ void store_vec(double* __restrict__ dst, const double* src) {
+  const int lane = lane_id();
+  for (int n = lane; n < NST; n += WAVE) dst[n] = src[n];
+}
+
+__global__ __launch_bounds__(64) void k_initial_guess(const Tables* tb, int n_cells, const double* theta, const double* SOC, double* Y) {
+  __shared__ CellLDS S;
+  LaneRegs R;
+  const int cell = blockIdx.x;
+  if (cell >= n_cells) return;
+  cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
+  cell_initial_guess(S, S.yy, SOC[cell]);
+  store_vec(Y + (size_t)cell * NST, S.yy);
+}
+
+__global__ __launch_bounds__(64) void k_residual(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+                                                 int mode, double value, double* F) {
+  __shared__ CellLDS S;
+  LaneRegs R;
+  const int cell = blockIdx.x;
+  if (cell >= n_cells) return;
+  cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
+  load_vec(S.yy, Y + (size_t)cell * NST); load_vec(S.yp, YP + (size_t)cell * NST);
+  __syncthreads();
+  cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
+  store_vec(F + (size_t)cell * NST, S.delta);
+}
+
+__global__ __launch_bounds__(64) void k_jacobian(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+                                                 double cj, int mode, double* nz) {
+  __shared__ CellLDS S;
+  LaneRegs R;
+  const int cell = blockIdx.x;
+  if (cell >= n_cells) return;
+  cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
+  load_vec(S.yy, Y + (size_t)cell * NST); load_vec(S.yp, YP + (size_t)cell * NST);
+  __syncthreads();
+  cell_node_pass<false, true>(S, S.yy, S.yp, S.delta, mode, 0.0);
+  __syncthreads();
+  const int nnz = tb->nnz[mode];
+  const unsigned* code = tb->csc_code[mode];
+  double* out = nz + (size_t)cell * nnz;
+  for (int k = lane_id(); k < nnz; k += WAVE) out[k] = jac_entry(S, tb, code[k], cj);
+}
+
+__global__ __launch_bounds__(64) void k_linear_solve(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+                                                     double cj, int mode, double* b) {
+  __shared__ CellLDS S;
+  LaneRegs R;
+  const int cell = blockIdx.x;
+  if (cell >= n_cells) return;
+  cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
+  load_vec(S.yy, Y + (size_t)cell * NST); load_vec(S.yp, YP + (size_t)cell * NST); load_vec(S.delta, b + (size_t)cell * NST);
+  __syncthreads();
+  cell_node_pass<false, true>(S, S.yy, S.yp, S.ee, mode, 0.0);
+  __syncthreads();
+  cell_factor(S, R, tb, cj, mode, false);
+  cell_solve(S, R, S.delta, mode, false);
+  store_vec(b + (size_t)cell * NST, S.delta);
+}
+
+__global__ __launch_bounds__(64) void k_init_consistent(const Tables* tb, int n_cells, const double* theta, int mode, double value,
+                                                        double reltol_init, double* Y, double* YP, int* status, int* iters) {
+  __shared__ CellLDS S;
+  LaneRegs R;
+  const int cell = blockIdx.x;
+  if (cell >= n_cells) return;
+  cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
+  load_vec(S.yy, Y + (size_t)cell * NST);
+  __syncthreads();
+  Counters cnt; memset(&cnt, 0, sizeof(cnt));
+  const int rc = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, reltol_init, cnt);
+  store_vec(Y + (size_t)cell * NST, S.yy); store_vec(YP + (size_t)cell * NST, S.yp);
+  if (lane_id() == 0) { if (status) status[cell] = rc; if (iters) iters[cell] = (int)cnt.n_init_iters; }
+}
+
+struct IntegrateArgs {
+  const Tables* tb; int n_cells; const double* theta; const double* SOC0; const double* Y_init; const double* t_init; int n_runs; const plh_run* runs; plh_opts opts;
+  plh_outputs out; double* scratch;   // scratch: [n_cells][2][NST]
+};
+
+__global__ __launch_bounds__(64) void k_integrate(IntegrateArgs a) {
+  __shared__ CellLDS S;
+  LaneRegs R;
+  const int cell = blockIdx.x;
+  if (cell >= a.n_cells) return;
+  cell_setup(S, R, a.tb, a.theta + (size_t)cell * a.tb->P);
+  Counters cnt; memset(&cnt, 0, sizeof(cnt));
+  CellOut co;
+  const size_t off = (size_t)cell * a.out.max_pts;
+  co.max_pts = a.out.max_pts;
+  co.t = a.out.t ? a.out.t + off : nullptr; co.V = a.out.V ? a.out.V + off : nullptr; co.I = a.out.I ? a.out.I + off : nullptr;
+  co.SOC = a.out.SOC ? a.out.SOC + off : nullptr; co.T = a.out.T_avg ? a.out.T_avg + off : nullptr;
+  cell_simulate(S, R, a.tb, a.SOC0[cell], a.Y_init ? a.Y_init + (size_t)cell * NST : nullptr, a.t_init ? a.t_init[cell] : 0.0, a.n_runs, a.runs, a.opts, co, a.out.n_pts ? a.out.n_pts + cell : nullptr,
+                a.out.run_info + (size_t)cell * a.n_runs, cnt,
+                a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
+                a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST);
+  if (lane_id() == 0 && a.out.counters) {
+    plh_counters* c = a.out.counters + cell;
+    c->n_steps = cnt.n_steps; c->n_res = cnt.n_res; c->n_jac = cnt.n_jac; c->n_fact = cnt.n_fact; c->n_solve = cnt.n_solve;
+    c->n_newton = cnt.n_newton; c->n_errfail = cnt.n_errfail; c->n_convfail = cnt.n_convfail; c->sum_kp2 = cnt.sum_kp2; c->n_init_iters = cnt.n_init_iters;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return fail(PLH_E_HIP, std::string(#x) + ": " + hipGetErrorString(e__)); } while (0)
+
+static const char* const KEY_NAMES_LCO_ISO[K_COUNT] = {
+    "D_n", "D_p", "D_s", "D_sn", "D_sp", "Ea_D_sn", "Ea_D_sp", "Ea_k_n", "Ea_k_p", "Rp_n", "Rp_p", "T₀", "brugg_n", "brugg_p", "brugg_s",
+    "c_e₀", "c_max_n", "c_max_p", "k_n", "k_p", "l_n", "l_p", "l_s", "t₊", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "σ_n", "σ_p",
+    "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s"};
+// chemistry defaults, reference src/params.jl:5-117 (LCO, LiC6), 176-226 (system_LCO_LiC6)
+static const double DEFAULTS_LCO_ISO[K_COUNT] = {
+    7.5e-10, 7.5e-10, 7.5e-10, 3.9e-14, 1e-14, 5000.0, 5000.0, 5000.0, 5000.0, 2e-6, 2e-6, 25 + 273.15, 4.0, 4.0, 4.0,
+    1000.0, 30555.0, 51554.0, 5.0310e-11, 2.334e-11, 88e-6, 80e-6, 25e-6, 0.364, 0.85510, 0.49550, 0.01429, 0.99174, 100.0, 100.0,
+    0.0326, 0.025, 0.485, 0.385, 0.724};
+
+struct plh_model_s {
+  plh_model_desc desc;
+  Tables h_tb;
+  Tables* d_tb = nullptr;
+  std::vector<int> colptr[3], rowval[3];
+  std::vector<unsigned> code[3];
+  unsigned* d_code[3] = {nullptr, nullptr, nullptr};
+  double* scratch = nullptr; size_t scratch_cells = 0;
+  plh_run* d_runs = nullptr; int runs_cap = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
+};
+
+// decode word of the structural Jacobian entry (r, c), 0 if structurally zero
+static unsigned classify(const Tables& tb, int mode, int r, int c) {
+  auto W = [](int t, int a, int b, int cc) { return (unsigned)((t << 24) | (a << 16) | (b << 8) | cc); };
+  auto node_of_j = [](int jx) { return jx < NP ? jx : jx + NS; };
+  if (r == O_I) {
+    if (mode == PLH_MODE_I) return c == O_I ? W(JT_CTRL_P1, 0, 0, 0) : 0;
+    if (mode == PLH_MODE_V) return c == O_PS ? W(JT_CTRL_P1, 0, 0, 0) : (c == O_PS + NJ - 1 ? W(JT_CTRL_M1, 0, 0, 0) : 0);
+    return 0;
+  }
+  if (r < O_CS) {                                   // c_e row i
+    const int i = r, sc = sec_of(i);
+    if (c < O_CS) { if (c == i - 1) return W(JT_CE_L, i, 0, 0); if (c == i) return W(JT_CE_D, i, 0, 0); if (c == i + 1) return W(JT_CE_U, i, 0, 0); return 0; }
+    if (sc != 1 && c == O_J + (sc == 0 ? i : i - NS)) return W(JT_CE_J, i, 0, 0);
+    return 0;
+  }
+  if (r < O_J) {                                    // c_s row (p, rr)
+    const int p = (r - O_CS) / NR, rr = (r - O_CS) % NR;
+    if (c >= O_CS && c < O_J && (c - O_CS) / NR == p) { const int cc = (c - O_CS) % NR; return (tb.M[rr * NR + cc] != 0.0 || rr == cc) ? W(JT_CS_CS, p, rr, cc) : 0; }
+    if (rr == NR - 1 && c == O_J + p) return W(JT_CS_J, p, 0, 0);
+    return 0;
+  }
+  if (r < O_PE) {                                   // j row
+    const int jx = r - O_J, nd = node_of_j(jx);
+    if (c == O_CE + nd) return W(JT_J_CE, jx, 0, 0);
+    if (c == O_CS + jx * NR + NR - 1) return W(JT_J_CS, jx, 0, 0);
+    if (c == r) return W(JT_J_J, jx, 0, 0);
+    if (c == O_PE + nd) return W(JT_J_PE, jx, 0, 0);
+    if (c == O_PS + jx) return W(JT_J_PS, jx, 0, 0);
+    return 0;
+  }
+  if (r < O_PS) {                                   // Phi_e row i
+    const int i = r - O_PE, sc = sec_of(i);
+    if (i == NE - 1) return c == r ? W(JT_PE_D, i, 0, 0) : 0;
+    if (c < O_CS) { if (c == i - 1) return W(JT_PE_CL, i, 0, 0); if (c == i) return W(JT_PE_CD, i, 0, 0); if (c == i + 1) return W(JT_PE_CU, i, 0, 0); return 0; }
+    if (c >= O_PE && c < O_PS) { const int k = c - O_PE; if (k == i - 1) return W(JT_PE_L, i, 0, 0); if (k == i) return W(JT_PE_D, i, 0, 0); if (k == i + 1) return W(JT_PE_U, i, 0, 0); return 0; }
+    if (sc != 1 && c == O_J + (sc == 0 ? i : i - NS)) return W(JT_PE_J, i, 0, 0);
+    return 0;
+  }
+  {                                                 // Phi_s row jx
+    const int jx = r - O_PS;
+    const bool first = (jx == 0) || (jx == NP), last = (jx == NP - 1) || (jx == NJ - 1);
+    if (c >= O_PS && c < O_I) { const int k = c - O_PS; if (k == jx - 1 && !first) return W(JT_PS_L, jx, 0, 0); if (k == jx) return W(JT_PS_D, jx, (first || last) ? 1 : 0, 0); if (k == jx + 1 && !last) return W(JT_PS_U, jx, 0, 0); return 0; }
+    if (c == O_J + jx) return W(JT_PS_J, jx, 0, 0);
+    if (c == O_I && jx == 0) return W(JT_PS_I, 0, 0, 0);
+    if (c == O_I && jx == NJ - 1) return W(JT_PS_I, 1, 0, 0);
+    return 0;
+  }
+}
+
+// ---- staging helpers: host arrays are copied through temporary device buffers ----
+struct Stage {
+  std::vector<void*> tmp;
+  int kind; hipStream_t st;
+  Stage(int k, void* s) : kind(k), st((hipStream_t)s) {}
+  ~Stage() { for (void* p : tmp) hipFree(p); }
+  template <class T> const T* in(const T* p, size_t n) {
+    if (!p || kind == PLH_DEVICE) return p;
+    void* d = nullptr; if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return nullptr;
+    tmp.push_back(d); hipMemcpy(d, p, n * sizeof(T), hipMemcpyHostToDevice); return (const T*)d;
+  }
+  template <class T> T* buf(T* p, size_t n, bool copy_in) {
+    if (!p || kind == PLH_DEVICE) return p;
+    void* d = nullptr; if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return nullptr;
+    tmp.push_back(d); if (copy_in) hipMemcpy(d, p, n * sizeof(T), hipMemcpyHostToDevice); return (T*)d;
+  }
+  template <class T> void back(T* host, const T* dev, size_t n) { if (host && kind != PLH_DEVICE) hipMemcpy(host, dev, n * sizeof(T), hipMemcpyDeviceToHost); }
+};
+#define CHECK_MODEL(m) do { if (!(m)) return fail(PLH_E_ARG, "null model"); } while (0)
+#define CHECK_MODE(mode) do { if ((mode) != PLH_MODE_I && (mode) != PLH_MODE_V) return fail(PLH_E_UNSUPPORTED, "operating mode not available for this model (I and V are)"); } while (0)
+#define FINISH(stage) do { if ((stage).kind != PLH_DEVICE) HIPCHK(hipStreamSynchronize((stage).st)); HIPCHK(hipGetLastError()); } while (0)
+
+
+extern "C" {
+
+const char* plh_last_error(void) { return g_err.c_str(); }
+
+int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
+  if (!d || !out) return fail(PLH_E_ARG, "null argument");
+  if (d->real_bytes != 8) return fail(PLH_E_UNSUPPORTED, "only fp64 (real_bytes = 8) is implemented");
+  if (d->chemistry != PLH_CHEM_LCO_LIC6) return fail(PLH_E_UNSUPPORTED, "chemistry: only LCO/LiC6 is implemented in this round");
+  if (d->temperature || d->aging_SEI) return fail(PLH_E_UNSUPPORTED, "temperature / aging models are not implemented in this round");
+  if (d->N_p != NP || d->N_s != NS || d->N_n != NN || d->N_r_p != NR || d->N_r_n != NR)
+    return fail(PLH_E_UNSUPPORTED, "discretisation: only N_p = N_s = N_n = N_r_p = N_r_n = 10 is instantiated");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(PLH_E_HIP, "no HIP device visible: the product path has no CPU fallback");
+  plh_model_s* m = new plh_model_s();
+  m->desc = *d;
+  Tables& tb = m->h_tb;
+  memset(&tb, 0, sizeof(tb));
+  memcpy(tb.M, PL_RADIAL_M, sizeof(tb.M)); memcpy(tb.LAM, PL_RADIAL_LAM, sizeof(tb.LAM));
+  memcpy(tb.V, PL_RADIAL_V, sizeof(tb.V)); memcpy(tb.W, PL_RADIAL_W, sizeof(tb.W));
+  tb.BJ = PL_RADIAL_BJ_FACTOR; tb.chem = d->chemistry; tb.P = K_COUNT;
+  for (int k = 0; k < K_COUNT; k++) tb.thidx[k] = k;
+  for (int mode = 0; mode < 2; mode++) {
+    m->colptr[mode].assign(NST + 1, 0);
+    for (int c = 0; c < NST; c++) {
+      for (int r = 0; r < NST; r++) { const unsigned w = classify(tb, mode, r, c); if (w) { m->rowval[mode].push_back(r); m->code[mode].push_back(w); } }
+      m->colptr[mode][c + 1] = (int)m->rowval[mode].size();
+    }
+    tb.nnz[mode] = (int)m->rowval[mode].size();
+    if (hipMalloc((void**)&m->d_code[mode], m->code[mode].size() * sizeof(unsigned)) != hipSuccess) { delete m; return fail(PLH_E_HIP, "hipMalloc failed"); }
+    hipMemcpy(m->d_code[mode], m->code[mode].data(), m->code[mode].size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    tb.csc_code[mode] = m->d_code[mode];
+  }
+  if (hipMalloc((void**)&m->d_tb, sizeof(Tables)) != hipSuccess) { delete m; return fail(PLH_E_HIP, "hipMalloc failed"); }
+  hipMemcpy(m->d_tb, &tb, sizeof(Tables), hipMemcpyHostToDevice);
+  hipEventCreate(&m->ev0); hipEventCreate(&m->ev1);
+  *out = m;
+  return 0;
+}
+
+void plh_model_destroy(plh_model_t m) {
+  if (!m) return;
+  for (int k = 0; k < 3; k++) if (m->d_code[k]) hipFree(m->d_code[k]);
+  if (m->d_tb) hipFree(m->d_tb);
+  if (m->scratch) hipFree(m->scratch);
+  if (m->d_runs) hipFree(m->d_runs);
+  if (m->ev0) hipEventDestroy(m->ev0);
+  if (m->ev1) hipEventDestroy(m->ev1);
+  delete m;
+}
+
+int plh_n_states(plh_model_t m) { return m ? NST : PLH_E_ARG; }
+int plh_n_diff(plh_model_t m) { return m ? NDIFF : PLH_E_ARG; }
+int plh_n_theta(plh_model_t m) { return m ? K_COUNT : PLH_E_ARG; }
+const char* plh_theta_key(plh_model_t m, int i) { return (m && i >= 0 && i < K_COUNT) ? KEY_NAMES_LCO_ISO[i] : nullptr; }
+double plh_theta_default(plh_model_t m, int i) { return (m && i >= 0 && i < K_COUNT) ? DEFAULTS_LCO_ISO[i] : NAN; }
+
+int plh_jac_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval) {
+  if (!m || !nnz) return fail(PLH_E_ARG, "null argument");
+  if (mode < 0 || mode > 1) return fail(PLH_E_UNSUPPORTED, "mode not available for this model");
+  *nnz = (int)m->rowval[mode].size();
+  if (colptr) memcpy(colptr, m->colptr[mode].data(), (NST + 1) * sizeof(int));
+  if (rowval) memcpy(rowval, m->rowval[mode].data(), m->rowval[mode].size() * sizeof(int));
+  return 0;
+}
+
+int plh_initial_guess(plh_model_t m, int n, const double* theta, const double* SOC, double* Y, int kind, void* stream) {
+  CHECK_MODEL(m); if (n <= 0 || !theta || !SOC || !Y) return fail(PLH_E_ARG, "bad argument");
+  Stage s(kind, stream);
+  const double* th = s.in(theta, (size_t)n * K_COUNT); const double* so = s.in(SOC, n); double* y = s.buf(Y, (size_t)n * NST, false);
+  PL_LAUNCH(k_initial_guess, n, WAVE, s.st, m->d_tb, n, th, so, y);
+  FINISH(s); s.back(Y, y, (size_t)n * NST);
+  return 0;
+}
+
+int plh_residual(plh_model_t m, int n, const double* theta, const double* Y, const double* YP, int mode, double value, double* F, int kind, void* stream) {
+  CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP || !F) return fail(PLH_E_ARG, "bad argument");
+  Stage s(kind, stream);
+  const double* th = s.in(theta, (size_t)n * K_COUNT); const double* y = s.in(Y, (size_t)n * NST); const double* yp = s.in(YP, (size_t)n * NST);
+  double* f = s.buf(F, (size_t)n * NST, false);
+  PL_LAUNCH(k_residual, n, WAVE, s.st, m->d_tb, n, th, y, yp, mode, value, f);
+  FINISH(s); s.back(F, f, (size_t)n * NST);
+  return 0;
+}
+
+int plh_jacobian(plh_model_t m, int n, const double* theta, const double* Y, const double* YP, double cj, int mode, double* nzval, int kind, void* stream) {
+  CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP || !nzval) return fail(PLH_E_ARG, "bad argument");
+  Stage s(kind, stream);
+  const size_t nnz = m->rowval[mode].size();
+  const double* th = s.in(theta, (size_t)n * K_COUNT); const double* y = s.in(Y, (size_t)n * NST); const double* yp = s.in(YP, (size_t)n * NST);
+  double* z = s.buf(nzval, (size_t)n * nnz, false);
+  PL_LAUNCH(k_jacobian, n, WAVE, s.st, m->d_tb, n, th, y, yp, cj, mode, z);
+  FINISH(s); s.back(nzval, z, (size_t)n * nnz);
+  return 0;
+}
+
+int plh_linear_solve(plh_model_t m, int n, const double* theta, const double* Y, const double* YP, double cj, int mode, double* b, int kind, void* stream) {
+  CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP || !b) return fail(PLH_E_ARG, "bad argument");
+  Stage s(kind, stream);
+  const double* th = s.in(theta, (size_t)n * K_COUNT); const double* y = s.in(Y, (size_t)n * NST); const double* yp = s.in(YP, (size_t)n * NST);
+  double* bb = s.buf(b, (size_t)n * NST, true);
+  PL_LAUNCH(k_linear_solve, n, WAVE, s.st, m->d_tb, n, th, y, yp, cj, mode, bb);
+  FINISH(s); s.back(b, bb, (size_t)n * NST);
+  return 0;
+}
+
+int plh_init_consistent(plh_model_t m, int n, const double* theta, int mode, double value, double reltol_init, double* Y, double* YP, int* status,
+                        int* iters, int kind, void* stream) {
+  CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP) return fail(PLH_E_ARG, "bad argument");
+  Stage s(kind, stream);
+  const double* th = s.in(theta, (size_t)n * K_COUNT);
+  double* y = s.buf(Y, (size_t)n * NST, true); double* yp = s.buf(YP, (size_t)n * NST, false);
+  int* st = s.buf(status, n, false); int* it = s.buf(iters, n, false);
+  PL_LAUNCH(k_init_consistent, n, WAVE, s.st, m->d_tb, n, th, mode, value, reltol_init, y, yp, st, it);
+  FINISH(s);
+  s.back(Y, y, (size_t)n * NST); s.back(YP, yp, (size_t)n * NST); s.back(status, st, n); s.back(iters, it, n);
+  return 0;
+}
+
+int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0, const double* Y_init, const double* t_init, int n_runs,
+                  const plh_run* runs, const plh_opts* opts, const plh_outputs* out, int kind, void* stream) {
+  CHECK_MODEL(m);
+  if (n <= 0 || !theta || !SOC0 || n_runs <= 0 || !runs || !opts || !out || !out->run_info) return fail(PLH_E_ARG, "bad argument");
+  for (int r = 0; r < n_runs; r++) {
+    CHECK_MODE(runs[r].mode);
+    if (runs[r].value_kind < 0 || runs[r].value_kind > 2) return fail(PLH_E_ARG, "bad value_kind");
+    if (!(runs[r].tf > 0)) return fail(PLH_E_ARG, "run length tf must be positive");
+  }
+  if (out->max_pts < 0) return fail(PLH_E_ARG, "max_pts");
+  if ((Y_init == nullptr) != (t_init == nullptr)) return fail(PLH_E_ARG, "Y_init and t_init must be given together");
+  Stage s(kind, stream);
+  if (m->scratch_cells < (size_t)n) {
+    if (m->scratch) hipFree(m->scratch);
+    HIPCHK(hipMalloc((void**)&m->scratch, (size_t)n * 2 * NST * sizeof(double)));
+    m->scratch_cells = n;
+  }
+  IntegrateArgs a;
+  a.tb = m->d_tb; a.n_cells = n; a.n_runs = n_runs; a.opts = *opts; a.scratch = m->scratch;
+  a.theta = s.in(theta, (size_t)n * K_COUNT); a.SOC0 = s.in(SOC0, n);
+  a.Y_init = s.in(Y_init, (size_t)n * NST); a.t_init = s.in(t_init, n);
+  // the protocol is always host memory
+  if (m->runs_cap < n_runs) { if (m->d_runs) hipFree(m->d_runs); HIPCHK(hipMalloc((void**)&m->d_runs, n_runs * sizeof(plh_run))); m->runs_cap = n_runs; }
+  HIPCHK(hipMemcpyAsync(m->d_runs, runs, n_runs * sizeof(plh_run), hipMemcpyHostToDevice, s.st));
+  a.runs = m->d_runs;
+  const size_t np = (size_t)n * out->max_pts;
+  a.out = *out;
+  a.out.t = s.buf(out->t, np, false); a.out.V = s.buf(out->V, np, false); a.out.I = s.buf(out->I, np, false);
+  a.out.SOC = s.buf(out->SOC, np, false); a.out.T_avg = s.buf(out->T_avg, np, false); a.out.n_pts = s.buf(out->n_pts, n, false);
+  a.out.Y_final = s.buf(out->Y_final, (size_t)n * NST, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * NST, false);
+  a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
+  hipEventRecord(m->ev0, s.st);
+  PL_LAUNCH(k_integrate, n, WAVE, s.st, a);
+  hipEventRecord(m->ev1, s.st);
+  m->timed = true;
+  FINISH(s);
+  s.back(out->t, a.out.t, np); s.back(out->V, a.out.V, np); s.back(out->I, a.out.I, np); s.back(out->SOC, a.out.SOC, np);
+  s.back(out->T_avg, a.out.T_avg, np); s.back(out->n_pts, a.out.n_pts, n);
+  s.back(out->Y_final, a.out.Y_final, (size_t)n * NST); s.back(out->YP_final, a.out.YP_final, (size_t)n * NST);
+  s.back(out->run_info, a.out.run_info, (size_t)n * n_runs); s.back(out->counters, a.out.counters, n);
+  return 0;
+}
+
+double plh_last_kernel_ms(plh_model_t m) {
+  if (!m || !m->timed) return -1.0;
+  if (hipEventSynchronize(m->ev1) != hipSuccess) return -1.0;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, m->ev0, m->ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+"""Ensemble sharding over the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Cells are independent for the whole trajectory, so the data path has NO collective: the only exchanges are
+the scatter of parameter rows before and the gather of per-cell summaries after the integration -- exactly the
+north-star's "RCCL only for the ensemble scatter/gather".  Payloads are tiny (65 536 cells x 35 parameters x 8 B = 18 MB;
+summaries ~100 B/cell), so the per-link xGMI bandwidth is irrelevant; what matters is that the partition is static,
+balanced and reproducible: contiguous blocks, rank r owns cells [r*n/G, (r+1)*n/G).
+
+A single trajectory never spans GPUs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SUMMARY_FIELDS = ("flag", "iterations", "t_end", "V", "I", "SOC", "n_steps", "n_newton")
+
+
+def shard_bounds(n_cells, world_size):
+    """start offsets of the contiguous, balanced partition (len = world_size + 1)."""
+    base, rem = divmod(n_cells, world_size)
+    sizes = [base + (1 if r < rem else 0) for r in range(world_size)]
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+def summarize(ens):
+    """[n_cells, len(SUMMARY_FIELDS)] float64 summary of the LAST run of every cell."""
+    ri = ens.run_info[:, -1]
+    c = ens.counters
+    return np.stack([ri["flag"].astype(np.float64), ri["iterations"].astype(np.float64), ri["t_end"], ri["V"], ri["I"], ri["SOC"],
+                     c["n_steps"].astype(np.float64), c["n_newton"].astype(np.float64)], axis=1)
+
+
+def ensemble_run(p, Theta, protocol, SOC=1.0, *, group=None, device=None, local_integrate=None):
+    """Scatter Theta ([n_cells, n_theta], significant on rank 0 only) over the ranks of `group`, integrate each shard on the
+    rank's GPU, gather the per-cell summaries back to rank 0.
+
+    Returns (summary [n_cells, 8] on rank 0 / None elsewhere, local EnsembleSolution-or-summary).
+    `local_integrate(Theta_shard: np.ndarray, SOC) -> np.ndarray [m, 8]` replaces the GPU integration (tests use it to
+    check the sharding logic on CPU ranks with the gloo backend).
+    """
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    # 1. broadcast the ensemble shape, 2. scatter padded equal-size shards
+    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    if rank == 0:
+        Theta = np.ascontiguousarray(Theta, dtype=np.float64)
+        meta[0], meta[1] = Theta.shape
+    dist.broadcast(meta, src=0, group=group)
+    n, P = int(meta[0]), int(meta[1])
+    off = shard_bounds(n, world)
+    m_max = int((off[1:] - off[:-1]).max())
+    mine = torch.zeros(m_max, P, dtype=torch.float64, device=device)
+    if rank == 0:
+        full = torch.from_numpy(Theta).to(device)
+        chunks = []
+        for r in range(world):
+            c = torch.zeros(m_max, P, dtype=torch.float64, device=device)
+            c[: off[r + 1] - off[r]] = full[off[r]:off[r + 1]]
+            chunks.append(c)
+        dist.scatter(mine, chunks, src=0, group=group)
+    else:
+        dist.scatter(mine, None, src=0, group=group)
+    m = int(off[rank + 1] - off[rank])
+    local = None
+    if m > 0:
+        if local_integrate is not None:
+            summ = np.asarray(local_integrate(mine[:m].cpu().numpy(), SOC), dtype=np.float64)
+        else:
+            from .api import simulate_ensemble
+            local = simulate_ensemble(p, mine[:m].contiguous(), protocol, SOC=SOC, device=True)
+            summ = summarize(local)
+    else:
+        summ = np.zeros((0, len(SUMMARY_FIELDS)))
+    # 3. gather summaries (padded to m_max rows)
+    pad = torch.zeros(m_max, len(SUMMARY_FIELDS), dtype=torch.float64, device=device)
+    pad[:m] = torch.from_numpy(summ).to(device)
+    if rank == 0:
+        parts = [torch.zeros_like(pad) for _ in range(world)]
+        dist.gather(pad, parts, dst=0, group=group)
+        out = np.concatenate([parts[r][: off[r + 1] - off[r]].cpu().numpy() for r in range(world)], axis=0)
+        return out, (local if local is not None else summ)
+    dist.gather(pad, None, dst=0, group=group)
+    return None, (local if local is not None else summ)

@@ -1,0 +1,101 @@
+"""Chemistry parameter tables, default bounds and default options -- the host-side data contract of petlion().
+
+Restated from the reference's parameter files (values only): LCO src/params.jl:5-56, LiC6 58-117, system_LCO_LiC6 176-289.
+Key names are the reference's Symbols (UTF-8), so `p.θ["ϵ_p"] = 0.485` reads like the reference's `p.θ[:ϵ_p] = 0.485`.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+F = 96485.3321233          # src/structures.jl:10
+R = 8.31446261815324       # src/structures.jl:11
+
+
+def theta_LCO():
+    th = OrderedDict()
+    # LCO cathode, src/params.jl:10-45
+    th.update({"D_sp": 1e-14, "D_p": 7.5e-10, "k_p": 2.334e-11, "λ_MHC_p": 6.26e-20, "θ_min_p": 0.99174, "θ_max_p": 0.49550,
+               "l_p": 80e-6, "σ_p": 100.0, "ϵ_p": 0.385, "ϵ_fp": 0.025, "brugg_p": 4.0, "c_max_p": 51554.0, "Rp_p": 2e-6,
+               "λ_p": 2.1, "ρ_p": 2500.0, "Cp_p": 700.0, "Ea_D_sp": 5000.0, "Ea_k_p": 5000.0})
+    # LiC6 anode, src/params.jl:61-110
+    th.update({"D_sn": 3.9e-14, "D_n": 7.5e-10, "k_n": 5.0310e-11, "λ_MHC_n": 6.26e-20, "θ_max_n": 0.85510, "θ_min_n": 0.01429,
+               "l_n": 88e-6, "σ_n": 100.0, "ϵ_n": 0.485, "ϵ_fn": 0.0326, "brugg_n": 4.0, "c_max_n": 30555.0, "Rp_n": 2e-6,
+               "λ_n": 1.7, "ρ_n": 2500.0, "Cp_n": 700.0, "Ea_D_sn": 5000.0, "Ea_k_n": 5000.0,
+               "R_SEI": 0.01, "M_n": 7.3e-4, "k_n_aging": 1.0, "i_0_jside": 1.5e-6, "Uref_s": 0.4, "w": 2.0})
+    # system_LCO_LiC6, src/params.jl:179-226
+    th.update({"D_s": 7.5e-10, "l_s": 25e-6, "l_a": 10e-6, "l_z": 10e-6, "σ_a": 3.55e7, "σ_z": 5.96e7, "ϵ_s": 0.724,
+               "brugg_s": 4.0, "t₊": 0.364, "c_e₀": 1000.0, "T₀": 25 + 273.15, "T_amb": 25 + 273.15,
+               "λ_s": 0.16, "λ_a": 237.0, "λ_z": 401.0, "ρ_s": 1100.0, "ρ_a": 2700.0, "ρ_z": 8940.0,
+               "Cp_s": 700.0, "Cp_a": 897.0, "Cp_z": 385.0, "h_cell": 1.0})
+    return th
+
+
+def calc_I1C(th):
+    """1C current density [A/m^2], reference src/physics_equations/auxiliary_states_and_coefficients.jl:632-647."""
+    eps_sp = 1.0 - (th["ϵ_fp"] + th["ϵ_p"])
+    eps_sn = 1.0 - (th["ϵ_fn"] + th["ϵ_n"])
+    return (F / 3600.0) * min(eps_sp * th["l_p"] * th["c_max_p"] * (th["θ_min_p"] - th["θ_max_p"]),
+                              eps_sn * th["l_n"] * th["c_max_n"] * (th["θ_max_n"] - th["θ_min_n"]))
+
+
+class Bounds:
+    """reference boundary_stop_conditions (src/structures.jl:237-250); NaN = bound disabled."""
+    FIELDS = ("V_max", "V_min", "SOC_max", "SOC_min", "T_max", "c_s_n_max", "I_max", "I_min", "η_plating_min", "c_e_min", "dfilm_max")
+
+    def __init__(self, **kw):
+        for f in self.FIELDS:
+            setattr(self, f, math.nan)
+        for k, v in kw.items():
+            if k not in self.FIELDS:
+                raise KeyError(k)
+            setattr(self, k, float(v))
+
+    def copy(self, **over):
+        b = Bounds(**{f: getattr(self, f) for f in self.FIELDS})
+        for k, v in over.items():
+            if k not in self.FIELDS:
+                raise KeyError(k)
+            setattr(b, k, float(v))
+        return b
+
+    def __repr__(self):
+        return "Bounds(" + ", ".join("%s=%g" % (f, getattr(self, f)) for f in self.FIELDS if not math.isnan(getattr(self, f))) + ")"
+
+
+def bounds_LCO():
+    """src/params.jl:233-252"""
+    return Bounds(V_min=2.5, V_max=4.3, SOC_min=0.0, SOC_max=1.0, T_max=55 + 273.15)
+
+
+class Opts:
+    """reference options_simulation (src/structures.jl:266-285) with the LCO defaults of src/params.jl:255-283."""
+    def __init__(self, SOC=1.0):
+        self.SOC = SOC
+        self.outputs = ("t", "V")
+        self.abstol = 1e-6
+        self.reltol = 1e-3
+        self.abstol_init = None     # None -> abstol (model_evaluation.jl:21)
+        self.reltol_init = None     # None -> reltol (model_evaluation.jl:22)
+        self.maxiters = 10_000
+        self.check_bounds = True
+        self.reinit = True
+        self.verbose = False
+        self.interp_final = True
+        self.tstops = []
+        self.tdiscon = []
+        self.interp_bc = "interpolate"
+        # build-specific knobs (not in the reference)
+        self.max_order = 5
+        self.jac_every_step = False
+        self.max_points = 2048      # capacity of the per-cell output buffers
+
+
+# reference exit strings, src/checks.jl:6-217
+EXIT_REASONS = {
+    0: "Final time reached", 1: "Below min. voltage", 2: "Above max. voltage", 3: "Below min. SOC", 4: "Above max. SOC",
+    5: "Above max. temperature", 6: "Above max. c_s_n", 7: "Above max. C-rate", 8: "Below min. C-rate", 9: "Below min. c_e",
+    10: "Above max. film growth rate", 11: "Below min. η_plating",
+    -1: "(not run)", -11: "Could not initialize DAE", -12: "Model failed to converge", -13: "Reached max iterations",
+    -14: "Output buffer full",
+}

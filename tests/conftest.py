@@ -1,0 +1,43 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "wave_emu"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import pkgload
+    return pkgload.load()
+
+
+@pytest.fixture(scope="session")
+def O():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def emu_model(pkg):
+    """the product's device + host source compiled against the TEST-ONLY wave emulator (CPU debugging aid)."""
+    import build_emu
+    return pkg.petlion(pkg.LCO, _lib_path=build_emu.build())
+
+
+@pytest.fixture(scope="session")
+def hip_model(pkg):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    g.build_hip()
+    return pkg.petlion(pkg.LCO)

@@ -1,0 +1,123 @@
+"""Parity checks of the C-ABI library against the oracle, shared by the emulator (CPU) and HIP (GPU) test modules."""
+import ctypes as C
+
+import numpy as np
+
+VARIANT = "lco_iso"
+SECTIONS = [("c_e", 0, 30), ("c_s", 30, 230), ("j", 230, 250), ("Phi_e", 250, 280), ("Phi_s", 280, 300), ("I", 300, 301)]
+
+
+def realistic_states(O, th, n, seed=0):
+    """states along a 1C discharge + random perturbations (so that every term of the equations is exercised)."""
+    rng = np.random.default_rng(seed)
+    ro = O.simulate(VARIANT, th, 1.0, [dict(mode=O.MODE_I, value=-1.0, tf=600.0 * (1 + 4 * rng.random()))])
+    Ys, YPs = [], []
+    for _ in range(n):
+        Ys.append(ro["Y"] * (1 + 1e-3 * rng.standard_normal(ro["Y"].size)))
+        YPs.append(ro["YP"] * (1 + 1e-2 * rng.standard_normal(ro["Y"].size)))
+    return np.array(Ys), np.array(YPs)
+
+
+def check_keys_and_pattern(p, O):
+    cap = p._lib
+    meta = O.meta(VARIANT)
+    assert p.θ_keys == meta["theta_keys"]
+    assert np.array_equal(p.theta_vector(), np.array(meta["theta_default"]))
+    th = p.theta_vector()
+    N = p.N.tot
+    for mode, nnz_expect in ((0, 2139), (1, 2140)):     # Z = 2139 in CC mode
+        cp, ri = p.jac_pattern(mode)
+        ocp, ori, _ = O.jacobian(VARIANT, th, np.ones(N), np.zeros(N), 1.0, mode, 0.0)
+        assert len(ri) == nnz_expect
+        assert np.array_equal(cp, ocp) and np.array_equal(ri, ori)
+
+
+def check_evaluators(p, O, n_cells=3):
+    lib, h = p._lib, p._h
+    th = p.theta_vector()
+    N = p.N.tot
+    Y, YP = realistic_states(O, th, n_cells)
+    Th = np.tile(th, (n_cells, 1))
+    Th[:, p.θ_keys.index("D_sp")] *= np.linspace(0.5, 2.0, n_cells)
+    Th[:, p.θ_keys.index("k_n")] *= np.linspace(2.0, 0.5, n_cells)
+    Th[1:, p.θ_keys.index("T₀")] = 310.0          # exercises the Arrhenius / dU/dT branches (T0 != T_ref)
+    Th = np.ascontiguousarray(Th)
+    # initial guess
+    soc = np.linspace(0.1, 0.9, n_cells)
+    Yg = np.zeros((n_cells, N))
+    assert lib.plh_initial_guess(h, n_cells, Th.ctypes.data, soc.ctypes.data, Yg.ctypes.data, 0, None) == 0
+    for i in range(n_cells):
+        assert np.allclose(Yg[i], O.initial_guess(VARIANT, Th[i], soc[i]), rtol=1e-12, atol=0)
+    for mode, val in ((0, -1.0), (1, 3.9)):
+        F = np.zeros((n_cells, N))
+        assert lib.plh_residual(h, n_cells, Th.ctypes.data, Y.ctypes.data, YP.ctypes.data, mode, val, F.ctypes.data, 0, None) == 0
+        nnz = len(p.jac_pattern(mode)[1])
+        cj = 0.37
+        nz = np.zeros((n_cells, nnz))
+        assert lib.plh_jacobian(h, n_cells, Th.ctypes.data, Y.ctypes.data, YP.ctypes.data, cj, mode, nz.ctypes.data, 0, None) == 0
+        rng = np.random.default_rng(1)
+        b = rng.standard_normal((n_cells, N))
+        x = b.copy()
+        assert lib.plh_linear_solve(h, n_cells, Th.ctypes.data, Y.ctypes.data, YP.ctypes.data, cj, mode, x.ctypes.data, 0, None) == 0
+        for i in range(n_cells):
+            Fo = O.residual(VARIANT, Th[i], Y[i], YP[i], mode, val)
+            # rounding-level criterion: |dF_i| <= 1e-12 * (magnitude of the terms entering row i) = sum_k |J_ik Y_k| + |YP_i|
+            ocp, ori_, onz_ = O.jacobian(VARIANT, Th[i], Y[i], YP[i], 0.0, mode, val)
+            term = np.abs(YP[i]).copy()
+            for c in range(N):
+                sl = slice(ocp[c], ocp[c + 1])
+                np.add.at(term, ori_[sl], np.abs(onz_[sl] * Y[i, c]))
+            bad = np.abs(F[i] - Fo) > 1e-12 * term + 1e-300
+            assert not bad.any(), (mode, i, np.nonzero(bad)[0][:5], np.abs(F[i] - Fo)[bad][:5], term[bad][:5])
+            _, ori, onz = O.jacobian(VARIANT, Th[i], Y[i], YP[i], cj, mode, val)
+            rel = np.abs(nz[i] - onz) / (np.abs(onz) + 1e-300)
+            assert rel.max() < 1e-9, (mode, i, rel.max(), int(ori[rel.argmax()]))
+            xo = O.linear_solve(VARIANT, Th[i], Y[i], YP[i], cj, b[i], mode, val)
+            for name, a, e in SECTIONS:
+                assert np.abs(x[i, a:e] - xo[a:e]).max() <= 1e-7 * (np.abs(xo[a:e]).max() + 1e-300), (mode, i, name)
+
+
+def check_init(p, O):
+    lib, h = p._lib, p._h
+    th = p.theta_vector()
+    N = p.N.tot
+    Y0 = O.initial_guess(VARIANT, th, 0.0)
+    Y0[-1] = 2.0
+    rc, Yo, YPo, ito = O.init_consistent(VARIANT, th, Y0, O.MODE_I, 2.0)
+    Y, YP = Y0.copy(), np.zeros(N)
+    st, it = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    assert lib.plh_init_consistent(h, 1, th.ctypes.data, 0, 2.0, 1e-3, Y.ctypes.data, YP.ctypes.data, st.ctypes.data, it.ctypes.data, 0, None) == 0
+    assert st[0] == 0 and it[0] == ito == 4
+    assert np.abs(Y - Yo).max() <= 1e-12 * np.abs(Yo).max()
+    # the finite-difference estimate of YP_alg is intrinsically noisy (difference quotient of a Newton update): 1e-6 of scale
+    assert np.abs(YP - YPo).max() <= 1e-6 * np.abs(YPo).max()
+    V0 = Y[280] - Y[299]
+    assert abs(V0 - 2.863495104606893) < 1e-10       # reference examples/model_inputs_and_outputs.ipynb:152
+    return V0
+
+
+def runs_to_oracle(O, p, pkg, protocol):
+    runs, _ = pkg.make_protocol(p, protocol)
+    out = []
+    for r in runs:
+        b = O.Bounds(**{f: getattr(r.bounds, f) for f in O.BOUND_FIELDS})
+        out.append(dict(mode=r.mode, value_kind=r.value_kind, value=r.value, tf=r.tf, bounds=b))
+    return out
+
+
+def compare_trajectory(ens, i, ro, rtol_state=1e-6, same_decisions=True):
+    info = ens.run_info[i]
+    for k, rr in enumerate(ro["runs"]):
+        assert info[k]["flag"] == rr["flag"], (i, k, info[k], rr)
+        if same_decisions:
+            assert info[k]["iterations"] == rr["iterations"], (i, k, info[k], rr)
+        assert abs(info[k]["t_end"] - rr["t_end"]) <= rtol_state * max(1.0, rr["t_end"]), (i, k, info[k]["t_end"], rr["t_end"])
+    n = int(ens.n_pts[i])
+    if same_decisions:
+        assert n == len(ro["t"])
+        assert np.abs(ens.t[i, :n] - ro["t"]).max() <= 10 * rtol_state * max(1.0, ro["t"][-1])
+        assert np.abs(ens.V[i, :n] - ro["V"]).max() <= 10 * rtol_state * 4.0
+        for f in ("n_steps", "n_res", "n_jac", "n_newton", "n_errfail", "n_convfail"):
+            assert ens.counters[i][f] == ro["counters"][f], f
+    rel = np.abs(ens.Y[i] - ro["Y"]) / (np.abs(ro["Y"]) + 1e-9)
+    assert rel.max() <= rtol_state, (i, rel.max(), int(rel.argmax()))

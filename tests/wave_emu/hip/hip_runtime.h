@@ -1,0 +1,110 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- a lock-step 64-lane wavefront emulator for debugging the device source of
+ * petlion.jl_amd/csrc/*.hip on a machine without a GPU (this container).  It is NOT a CPU fallback of the
+ * product: the package never loads it, it is built only by tests/wave_emu/build_emu.py, into
+ * tests/wave_emu/libpetlion_emu.so, and only the `-m "not gpu"` tests (and developers) use it.
+ *
+ * Model: one workgroup = one wave of 64 lanes; every lane is a ucontext fiber with its own stack; the scheduler runs
+ * the lanes round-robin from sync point to sync point (__syncthreads / __shfl_*), which reproduces SIMT semantics
+ * for convergent code.  Blocks run one after another.  __shared__ -> static, so exactly one block is live.
+ */
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define PL_WAVE_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct emu_dim3 { unsigned x, y, z; emu_dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+typedef emu_dim3 dim3;
+
+namespace wave_emu {
+constexpr int LANES = 64;
+struct State {
+  ucontext_t main_ctx;
+  ucontext_t lane_ctx[LANES];
+  bool done[LANES];
+  int cur;
+  unsigned block;
+  unsigned grid;
+  double xbuf[LANES];
+  std::function<void()> body;
+  std::vector<char*> stacks;
+};
+inline State& st() { static State s; return s; }
+inline void yield() { State& s = st(); swapcontext(&s.lane_ctx[s.cur], &s.main_ctx); }
+inline void lane_entry() { State& s = st(); s.body(); s.done[s.cur] = true; swapcontext(&s.lane_ctx[s.cur], &s.main_ctx); }
+inline void run_block(unsigned b, unsigned grid, const std::function<void()>& body) {
+  State& s = st();
+  const size_t STK = 1 << 20;
+  if (s.stacks.empty()) for (int l = 0; l < LANES; l++) s.stacks.push_back((char*)malloc(STK));
+  s.body = body; s.block = b; s.grid = grid;
+  for (int l = 0; l < LANES; l++) {
+    s.done[l] = false; getcontext(&s.lane_ctx[l]);
+    s.lane_ctx[l].uc_stack.ss_sp = s.stacks[l]; s.lane_ctx[l].uc_stack.ss_size = STK; s.lane_ctx[l].uc_link = &s.main_ctx;
+    makecontext(&s.lane_ctx[l], (void (*)())lane_entry, 0);
+  }
+  for (;;) {
+    int alive = 0;
+    for (int l = 0; l < LANES; l++) if (!s.done[l]) { alive++; s.cur = l; swapcontext(&s.main_ctx, &s.lane_ctx[l]); }
+    if (!alive) break;
+  }
+}
+struct TidProxy { struct X { operator unsigned() const { return (unsigned)st().cur; } } x; };
+struct BidProxy { struct X { operator unsigned() const { return st().block; } } x; };
+struct GdimProxy { struct X { operator unsigned() const { return st().grid; } } x; };
+}  // namespace wave_emu
+
+static wave_emu::TidProxy threadIdx;
+static wave_emu::BidProxy blockIdx;
+static wave_emu::GdimProxy gridDim;
+
+inline void __syncthreads() { wave_emu::yield(); }
+inline double __shfl(double v, int src) {
+  auto& s = wave_emu::st(); int me = s.cur; s.xbuf[me] = v; wave_emu::yield();
+  double r = (src >= 0 && src < wave_emu::LANES) ? s.xbuf[src] : v; wave_emu::yield(); return r;
+}
+inline double __shfl_down(double v, int d) { return __shfl(v, wave_emu::st().cur + d); }
+inline double __shfl_up(double v, int d) { return __shfl(v, wave_emu::st().cur - d); }
+inline double __shfl_xor(double v, int m) { return __shfl(v, wave_emu::st().cur ^ m); }
+inline int __shfl(int v, int src) { return (int)__shfl((double)v, src); }
+
+/* ---- minimal runtime API used by the C ABI layer ---- */
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef struct emu_event_s { double t; }* hipEvent_t;
+#define hipSuccess 0
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+#define hipMemcpyDeviceToDevice 3
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event_s{0}; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = -1.f; return 0; }
+
+#define PL_LAUNCH(kernel, grid, block, stream, ...)                                      \
+  do { unsigned g__ = (grid);                                                            \
+       for (unsigned b__ = 0; b__ < g__; b__++) wave_emu::run_block(b__, g__, [&]() { kernel(__VA_ARGS__); }); } while (0)
