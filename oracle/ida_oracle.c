@@ -262,10 +262,12 @@ static void splu_solve(const splu* f, double* b) {
   for (int k = 0; k < n; k++) y[k] = 0.0;
 }
 
-/* SUNLinSol_KLU-style setup: refactor, fall back to a full factorization if the cheap rcond estimate is tiny */
+/* klu!() / SUNLinSol_KLU setup after the first call = klu_refactor: numeric refactorisation with the stored pivot
+ * sequence (reference src/model_evaluation.jl:417-428; its rcond-triggered re-pivoting is commented out there).  A full
+ * factorisation with fresh pivoting is done the first time and whenever the refactorisation breaks down. */
 static int splu_setup(splu* f, const int* cp, const int* ri, const double* ax) {
   int rc = splu_refactor(f, cp, ri, ax);
-  if (rc != 0 || f->rcond < 3.67e-11) { f->factored = 0; rc = splu_factor(f, cp, ri, ax); }
+  if (rc != 0) { f->factored = 0; rc = splu_factor(f, cp, ri, ax); }
   return rc;
 }
 
@@ -754,17 +756,20 @@ static int find_key(const orc_model* m, const char* k) { for (int i = 0; i < m->
  * Outputs one row per saved point (t=0 of a new solution and every accepted step; the last point of a run is
  * replaced by the back-interpolated one), like the reference's default outputs (:t,:V) plus I, SOC, T_avg.
  */
-int orc_simulate(const char* variant, const double* theta, double SOC0, int n_runs, const orc_run* runs, const orc_opts* opts,
+typedef struct { orc_model M; evalb ev[3]; int ev_ok[3]; ida_t I; int ida_ok; } orc_ctx;
+
+static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_runs, const orc_run* runs, const orc_opts* opts,
                  int max_out, double* out_t, double* out_V, double* out_I, double* out_SOC, double* out_T, int* n_out,
                  double* Y_final, double* YP_final, orc_runinfo* info, orc_counters* counters, const double* Y_init) {
-  orc_model M; if (get_model(variant, &M) != 0) return -100;
+  orc_model M = ctx->M;
+  evalb* ev = ctx->ev; int* ev_ok = ctx->ev_ok;
   int N = M.N; orc_counters cz; memset(&cz, 0, sizeof(cz)); orc_counters* cnt = counters ? counters : &cz; memset(cnt, 0, sizeof(*cnt));
   int kc = find_key(&M, "c_e₀"), kT0 = find_key(&M, "T₀"), kcm = find_key(&M, "c_max_n");
   double c_e0 = kc >= 0 ? theta[kc] : 1000.0, T0 = kT0 >= 0 ? theta[kT0] : 298.15, c_max_n = kcm >= 0 ? theta[kcm] : 1.0;
   double* Y = (double*)calloc(N, sizeof(double)); double* YP = (double*)calloc(N, sizeof(double));
   double* Yprev = (double*)calloc(N, sizeof(double)); double* YPprev = (double*)calloc(N, sizeof(double));
-  ida_t I; ida_alloc(&I, N);
-  evalb ev[3]; int ev_ok[3] = {0, 0, 0};
+  if (!ctx->ida_ok) { ida_alloc(&ctx->I, N); ctx->ida_ok = 1; }
+  ida_t* Ip = &ctx->I;
   int nout = 0, rc = 0; double t_global = 0.0, SOC = SOC0; int have_prev = 0; double prev_V = 0, prev_I = 0;
 #define SAVE(tt_, Y_, SOC_) do { if (nout < max_out) { if (out_t) out_t[nout] = (tt_); if (out_V) out_V[nout] = calc_V(&M, (Y_)); if (out_I) out_I[nout] = (Y_)[M.o_I]; \
     if (out_SOC) out_SOC[nout] = (SOC_); if (out_T) out_T[nout] = calc_Tavg(&M, ev[run->mode].w, (Y_), T0); } nout++; } while (0)
@@ -796,11 +801,12 @@ int orc_simulate(const char* variant, const double* theta, double SOC0, int n_ru
       if (have_prev) Y[M.o_I] = prev_I; else Y[M.o_I] = 1.0;      /* input_methods.jl:171-176 */
     }
     if (!ev_ok[mode]) { if (evalb_init(&ev[mode], &M, theta, mode, value, cnt) != 0) { rc = -102; break; } ev_ok[mode] = 1; }
-    evalb* e = &ev[mode]; e->value = value; e->th = theta;
+    evalb* e = &ev[mode]; e->value = value; e->th = theta; e->cnt = cnt;
+    if (M.thermal) M.dT_weights(e->w, theta);
     int ierr = newtons_method(e, Y, YP, opts, c_e0);
     orc_runinfo* ri = &info[r]; memset(ri, 0, sizeof(*ri)); ri->flag = -1;
     if (ierr != 0) { ri->flag = ierr; ri->t_end = t_global; rc = 1; break; }
-    ida_reinit(&I, e, opts, Y, YP);
+    ida_reinit(Ip, e, opts, Y, YP);
     /* tstops (postfix_integrator!, model_evaluation.jl:288-310): {1.0 if continuation} U {tf} */
     double tstops[2]; int nts = 0, its = 0;
     if (!new_run && run->tf > 1.0) tstops[nts++] = 1.0;
@@ -817,11 +823,11 @@ int orc_simulate(const char* variant, const double* theta, double SOC0, int n_ru
     /* --- solve! --- */
     while (flag == -1) {
       double tret; tprev = t;
-      int sf = ida_step(&I, tstops[its], &tret, Y, YP);
+      int sf = ida_step(Ip, tstops[its], &tret, Y, YP);
       if (sf != 0) {
         /* check_solve, checks.jl:227-237: a stall on the very first step is retried once with h0 = reltol */
-        if (I.nst == 0 && !stalled_once) { stalled_once = 1; memcpy(Y, Yprev, N * sizeof(double)); memcpy(YP, YPprev, N * sizeof(double));
-          ida_reinit(&I, e, opts, Y, YP); I.h0_forced = opts->reltol; iter++; t = tprev; continue; }
+        if (Ip->nst == 0 && !stalled_once) { stalled_once = 1; memcpy(Y, Yprev, N * sizeof(double)); memcpy(YP, YPprev, N * sizeof(double));
+          ida_reinit(Ip, e, opts, Y, YP); Ip->h0_forced = opts->reltol; iter++; t = tprev; continue; }
         flag = sf; break;
       }
       if (tret >= tstops[its] && its + 1 < nts) its++;
@@ -857,9 +863,43 @@ int orc_simulate(const char* variant, const double* theta, double SOC0, int n_ru
   if (n_out) *n_out = nout;
   if (Y_final) memcpy(Y_final, Y, N * sizeof(double));
   if (YP_final) memcpy(YP_final, YP, N * sizeof(double));
-  for (int k = 0; k < 3; k++) if (ev_ok[k]) evalb_free(&ev[k]);
-  ida_free(&I); free(Y); free(YP); free(Yprev); free(YPprev);
+  free(Y); free(YP); free(Yprev); free(YPprev);
   return rc;
+}
+
+static void ctx_free(orc_ctx* c) { for (int k = 0; k < 3; k++) if (c->ev_ok[k]) evalb_free(&c->ev[k]); if (c->ida_ok) ida_free(&c->I); }
+
+int orc_simulate(const char* variant, const double* theta, double SOC0, int n_runs, const orc_run* runs, const orc_opts* opts,
+                 int max_out, double* out_t, double* out_V, double* out_I, double* out_SOC, double* out_T, int* n_out,
+                 double* Y_final, double* YP_final, orc_runinfo* info, orc_counters* counters, const double* Y_init) {
+  orc_ctx* ctx = (orc_ctx*)calloc(1, sizeof(orc_ctx));
+  if (get_model(variant, &ctx->M) != 0) { free(ctx); return -100; }
+  int rc = simulate_core(ctx, theta, SOC0, n_runs, runs, opts, max_out, out_t, out_V, out_I, out_SOC, out_T, n_out, Y_final, YP_final, info, counters, Y_init);
+  ctx_free(ctx); free(ctx);
+  return rc;
+}
+
+/* CPU-baseline leg of bench.py: n_traj trajectories, one after another on the calling thread, theta[k % n_theta_sets].
+ * The evaluator bundle (CSC pattern, fill-reducing ordering, pivot sequence) is created once and reused, like the
+ * reference's cached integrator / KLU symbolic analysis (src/model_evaluation.jl:240-251).  Returns the number of
+ * trajectories that ended with a non-negative flag; t_end_sum is a checksum. */
+int orc_run_batch(const char* variant, int n_theta_sets, const double* thetas, double SOC0, int n_runs, const orc_run* runs,
+                  const orc_opts* opts, int n_traj, double* t_end_sum, orc_counters* total) {
+  orc_ctx* ctx = (orc_ctx*)calloc(1, sizeof(orc_ctx));
+  if (get_model(variant, &ctx->M) != 0) { free(ctx); return -100; }
+  int P = ctx->M.P, ok = 0; double acc = 0.0;
+  orc_runinfo* info = (orc_runinfo*)calloc(n_runs, sizeof(orc_runinfo));
+  orc_counters c; if (total) memset(total, 0, sizeof(*total));
+  for (int k = 0; k < n_traj; k++) {
+    int nout = 0;
+    int rc = simulate_core(ctx, thetas + (size_t)(k % n_theta_sets) * P, SOC0, n_runs, runs, opts, 0, NULL, NULL, NULL, NULL, NULL, &nout, NULL, NULL, info, &c, NULL);
+    if (rc == 0) { ok++; acc += info[n_runs - 1].t_end; }
+    if (total) { total->n_steps += c.n_steps; total->n_res += c.n_res; total->n_jac += c.n_jac; total->n_fact += c.n_fact; total->n_solve += c.n_solve;
+      total->n_newton += c.n_newton; total->n_errfail += c.n_errfail; total->n_convfail += c.n_convfail; total->sum_kp2 += c.sum_kp2; total->n_init_iters += c.n_init_iters; }
+  }
+  if (t_end_sum) *t_end_sum = acc;
+  free(info); ctx_free(ctx); free(ctx);
+  return ok;
 }
 
 /* ------------------------------------------------------------------------------------------------------------ */

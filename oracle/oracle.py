@@ -184,3 +184,19 @@ def linear_solve(variant, theta, Y, YP, cj, b, mode=MODE_I, value=0.0):
                             C.c_double(cj), _dp(b))
     assert rc == 0, rc
     return b
+
+
+def run_batch(variant, thetas, SOC0, runs, n_traj, opts=None):
+    """time-able CPU batch (bench.py cpu_baseline): returns (n_ok, t_end_sum, counters dict)"""
+    L = lib()
+    opts = opts or default_opts()
+    arr = (Run * len(runs))()
+    for k, r in enumerate(runs):
+        arr[k].mode = r.get("mode", MODE_I); arr[k].value_kind = r.get("value_kind", VAL_CONST)
+        arr[k].value = r.get("value", 0.0); arr[k].tf = r.get("tf", 1e6); arr[k].bounds = r.get("bounds") or default_bounds()
+    thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+    s = C.c_double(0.0)
+    cnt = Counters()
+    ok = L.orc_run_batch(variant.encode(), thetas.shape[0], _dp(thetas), C.c_double(SOC0), len(runs), arr, C.byref(opts), int(n_traj),
+                         C.byref(s), C.byref(cnt))
+    return ok, s.value, {f: getattr(cnt, f) for f, _ in Counters._fields_}

@@ -105,6 +105,16 @@ def runs_to_oracle(O, p, pkg, protocol):
     return out
 
 
+def state_rel_err(Y, Yo):
+    """the parity metric for state vectors: max over the state sections of  max|dY| / max|Y_oracle|  (each physical field is
+    compared relative to its own scale; a component-wise ratio would blow up on near-zero entries such as j in the separator-side
+    nodes or Phi_e next to the reference node)."""
+    worst = 0.0
+    for _, a, e in SECTIONS:
+        worst = max(worst, np.abs(Y[a:e] - Yo[a:e]).max() / (np.abs(Yo[a:e]).max() + 1e-300))
+    return worst
+
+
 def compare_trajectory(ens, i, ro, rtol_state=1e-6, same_decisions=True):
     info = ens.run_info[i]
     for k, rr in enumerate(ro["runs"]):
@@ -119,5 +129,4 @@ def compare_trajectory(ens, i, ro, rtol_state=1e-6, same_decisions=True):
         assert np.abs(ens.V[i, :n] - ro["V"]).max() <= 10 * rtol_state * 4.0
         for f in ("n_steps", "n_res", "n_jac", "n_newton", "n_errfail", "n_convfail"):
             assert ens.counters[i][f] == ro["counters"][f], f
-    rel = np.abs(ens.Y[i] - ro["Y"]) / (np.abs(ro["Y"]) + 1e-9)
-    assert rel.max() <= rtol_state, (i, rel.max(), int(rel.argmax()))
+    assert state_rel_err(ens.Y[i], ro["Y"]) <= rtol_state, (i, state_rel_err(ens.Y[i], ro["Y"]))

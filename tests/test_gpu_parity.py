@@ -1,0 +1,152 @@
+"""GPU parity tests: the HIP path (through the C ABI, real MI355X) against the oracle on the same seeded inputs, plus
+size-independent properties at BASELINE.json's full sizes."""
+import numpy as np
+import pytest
+
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def splitmix_u01(seed, cell, k):
+    """counter-based RNG of SURVEY.md 8(d): splitmix64(seed ^ cell*0x9E3779B97F4A7C15 ^ k) -> [0,1)"""
+    M = (1 << 64) - 1
+    z = (seed ^ (cell * 0x9E3779B97F4A7C15) ^ k) & M
+    z = (z + 0x9E3779B97F4A7C15) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z = z ^ (z >> 31)
+    return (z >> 11) / float(1 << 53)
+
+
+SWEEP_KEYS = ("D_sp", "D_sn", "D_p", "D_s", "D_n", "k_p", "k_n")      # config C4, SURVEY.md 8(d)
+
+
+def sweep_theta(pkg, p, n, seed=4):
+    over = {}
+    for k, key in enumerate(SWEEP_KEYS):
+        u = np.array([splitmix_u01(seed, c, k) for c in range(n)])
+        over[key] = p.θ[key] * 2.0 ** (2 * u - 1)
+    return pkg.theta_matrix(p, n, over)
+
+
+def test_native_library_is_the_hip_build(hip_model, pkg):
+    import os
+    assert hip_model._lib._name.endswith(os.path.join("petlion.jl_amd", "libpetlion_hip.so"))
+
+
+def test_keys_and_jacobian_pattern(hip_model, O):
+    parity.check_keys_and_pattern(hip_model, O)
+
+
+def test_evaluators_residual_jacobian_solve(hip_model, O):
+    parity.check_evaluators(hip_model, O, n_cells=5)
+
+
+def test_consistent_initialisation(hip_model, O):
+    parity.check_init(hip_model, O)
+
+
+def test_c1_single_cell_known_answers(hip_model, pkg):
+    """config C1 through the host API on the GPU (notebook KATs)"""
+    sol = pkg.simulate(hip_model, I=-1, SOC=1)
+    assert sol.results[-1].flag == 3 and abs(sol.t[-1] - 3600.0) < 1e-5 and abs(sol.V[-1] - 2.9357) < 6e-3
+    sol = pkg.simulate(hip_model, 1800, I=2, SOC=0, V_max=4.1)
+    assert abs(sol.V[0] - 2.863495104606893) < 1e-10
+    pkg.simulate_b(sol, hip_model, V="hold", V_max=4.1, I_min=1 / 20)
+    assert pkg.exit_reasons(sol) == ["Above max. voltage", "Above max. SOC"]
+    assert abs(sol.t[-1] - 2440.61) < 1e-2 * 2440.61 and abs(sol.I[-1] - 0.1955) < 1e-2 * 0.1955
+
+
+def test_c2_1024_identical_cells(hip_model, O, pkg):
+    """config C2: 1024 identical 1C discharges: every cell returns the identical trajectory, equal to the oracle's"""
+    import torch
+    p = hip_model
+    n = 1024
+    Th = pkg.theta_matrix(p, n)
+    ens = pkg.simulate_ensemble(p, torch.from_numpy(Th).cuda(), [{"I": -1.0}], SOC=1.0, device=True)
+    torch.cuda.synchronize()
+    t, V, Y, npts = ens.t.cpu().numpy(), ens.V.cpu().numpy(), ens.Y.cpu().numpy(), ens.n_pts.cpu().numpy()
+    assert (npts == npts[0]).all() and (ens.run_info["flag"] == 3).all()
+    assert (t == t[0]).all() and (V == V[0]).all() and (Y == Y[0]).all()          # bitwise identical across cells
+    ro = O.simulate("lco_iso", Th[0], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}]))
+    host = pkg.EnsembleSolution(p, dict(t=t, V=V, I=ens.I.cpu().numpy(), SOC=ens.SOC.cpu().numpy(), n_pts=npts, Y=Y, YP=ens.YP.cpu().numpy(),
+                                        run_info=ens.run_info, counters=ens.counters), ["I"])
+    parity.compare_trajectory(host, 0, ro, rtol_state=1e-6)
+    parity.compare_trajectory(host, n - 1, ro, rtol_state=1e-6)
+
+
+def test_c4_parameter_sweep_subset_vs_oracle(hip_model, O, pkg):
+    """config C4 inputs (seed 4, 7-parameter log-uniform jitter): first 48 cells against the oracle, state within 1e-6"""
+    p = hip_model
+    n = 48
+    Th = sweep_theta(pkg, p, n)
+    ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0)
+    worst = 0.0
+    n_same = 0
+    for i in range(n):
+        ro = O.simulate("lco_iso", Th[i], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}]))
+        assert ens.run_info[i, 0]["flag"] == ro["runs"][0]["flag"]
+        same = ens.run_info[i, 0]["iterations"] == ro["runs"][0]["iterations"]
+        n_same += int(same)
+        rel = parity.state_rel_err(ens.Y[i], ro["Y"])
+        # a step-acceptance decision on a razor's edge may flip between two correct implementations; then the two
+        # trajectories agree to the integration tolerance only
+        tol = 1e-6 if same else 2e-3
+        assert rel <= tol, (i, same, rel)
+        assert abs(ens.run_info[i, 0]["t_end"] - ro["runs"][0]["t_end"]) <= tol * ro["runs"][0]["t_end"]
+        worst = max(worst, rel if same else 0.0)
+    assert n_same >= n - 2, n_same
+    print("C4 subset: %d/%d cells with identical step decisions, worst rel state deviation %.2e" % (n_same, n, worst))
+
+
+def test_c4_full_shard_properties(hip_model, pkg):
+    """8192 cells (one GPU's shard of config C4): size-independent properties of every trajectory"""
+    import torch
+    p = hip_model
+    n = 8192
+    Th = sweep_theta(pkg, p, n)
+    ens = pkg.simulate_ensemble(p, torch.from_numpy(Th).cuda(), [{"I": -1.0}], SOC=1.0, device=True, max_points=512)
+    torch.cuda.synchronize()
+    flags = ens.run_info["flag"][:, 0]
+    assert np.isin(flags, (1, 3)).all(), np.unique(flags)         # ends on V_min or SOC_min, never an error
+    t, V, soc, npts = ens.t.cpu().numpy(), ens.V.cpu().numpy(), ens.SOC.cpu().numpy(), ens.n_pts.cpu().numpy()
+    tend = ens.run_info["t_end"][:, 0]
+    # a 1C discharge from SOC 1 ends at exactly 3600 s when it ends on SOC_min (linear back-interpolation of a linear SOC)
+    assert np.abs(tend[flags == 3] - 3600.0).max() < 1e-6
+    assert (tend[flags == 1] < 3600.0).all()
+    for i in range(0, n, 97):
+        k = npts[i]
+        assert (np.diff(t[i, :k]) > 0).all() and (np.diff(soc[i, :k]) < 0).all()
+        assert abs(soc[i, k - 1] - (1.0 - tend[i] / 3600.0)) < 1e-9          # coulomb counting closes
+    # sharding property: the same cells integrated as two half-batches give bitwise the same answers
+    half = pkg.simulate_ensemble(p, torch.from_numpy(Th[: n // 2]).cuda(), [{"I": -1.0}], SOC=1.0, device=True, max_points=512)
+    assert (half.Y.cpu().numpy() == ens.Y.cpu().numpy()[: n // 2]).all()
+
+
+def test_cc_cv_protocol(hip_model, O, pkg):
+    p = hip_model
+    proto = [{"I": 2.0, "tf": 1800.0, "V_max": 4.1}, {"V": "hold", "V_max": 4.1, "I_min": 1 / 20}]
+    o = pkg.Opts(); o.jac_every_step = True
+    ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 4), proto, SOC=0.0, opts=o)
+    ro = O.simulate("lco_iso", p.theta_vector(), 0.0, parity.runs_to_oracle(O, p, pkg, proto), opts=O.default_opts(jac_every_step=1))
+    parity.compare_trajectory(ens, 3, ro, rtol_state=1e-6)
+    ens2 = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 4), proto, SOC=0.0)
+    ro2 = O.simulate("lco_iso", p.theta_vector(), 0.0, parity.runs_to_oracle(O, p, pkg, proto))
+    assert [int(f) for f in ens2.run_info[0]["flag"]] == [2, 4]
+    assert abs(ens2.run_info[0, 0]["t_end"] - ro2["runs"][0]["t_end"]) < 1e-6 * ro2["runs"][0]["t_end"]
+    assert abs(ens2.run_info[0, 1]["t_end"] - ro2["runs"][1]["t_end"]) < 2e-3 * ro2["runs"][1]["t_end"]
+
+
+def test_gitt_like_rest_hold_chain(hip_model, O, pkg):
+    """pulse / rest chain (the GITT pattern of examples/GITT.ipynb on the LCO model): 4 x (180 s at 1C, 600 s rest)"""
+    p = hip_model
+    proto = []
+    for _ in range(4):
+        proto += [{"I": 1.0, "tf": 180.0}, {"I": "rest", "tf": 600.0}]
+    ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 2), proto, SOC=0.0)
+    ro = O.simulate("lco_iso", p.theta_vector(), 0.0, parity.runs_to_oracle(O, p, pkg, proto))
+    assert (ens.run_info["flag"][0] == 0).all() and [r["flag"] for r in ro["runs"]] == [0] * 8
+    assert abs(ens.run_info[0, -1]["t_end"] - 4 * 780.0) < 1e-5
+    assert abs(ens.run_info[0, -1]["SOC"] - 4 * 180 / 3600) < 1e-6
+    assert parity.state_rel_err(ens.Y[0], ro["Y"]) < 1e-4
