@@ -86,6 +86,7 @@ typedef struct {
   int check_bounds, interp_final;                    /* 1, 1 */
   int max_order;                                     /* BDF order cap, 5 */
   int jac_every_step;                                /* 0: IDA's Jacobian-reuse policy */
+  double init_step;                                  /* 0: IDA's automatic h0 = 0.5/||y'||_wrms; >0: IDASetInitStep (src/checks.jl:231) */
 } plh_opts;
 
 /* per-cell, per-run summary == run_info + the printed summary (src/structures.jl:40-44, 678-746) */

@@ -295,6 +295,7 @@ typedef struct {   /* reference options_simulation, src/structures.jl:266-285 */
   int check_bounds, interp_final;
   int max_order;      /* 5 */
   int jac_every_step; /* 0 = IDA policy (default); 1 = refresh each step (ablation) */
+  double init_step;   /* 0 = automatic; > 0 = IDASetInitStep */
 } orc_opts;
 
 typedef struct {
@@ -628,7 +629,7 @@ static int ida_step(ida_t* I, double tstop, double* tret, double* yret, double* 
   if (I->nst == 0) {
     set_ewt(I, I->phi[0]);
     double tdist = fabs(tstop - I->tn);
-    double hh = I->h0_forced;
+    double hh = I->h0_forced != 0.0 ? I->h0_forced : I->o->init_step;
     if (hh == 0.0) {
       hh = 0.001 * tdist;
       double ypnorm = wrms(N, I->phi[1], I->ewt);

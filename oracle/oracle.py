@@ -32,7 +32,7 @@ class Run(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("abstol_init", C.c_double), ("reltol_init", C.c_double),
                 ("maxiters", C.c_int), ("check_bounds", C.c_int), ("interp_final", C.c_int), ("max_order", C.c_int),
-                ("jac_every_step", C.c_int)]
+                ("jac_every_step", C.c_int), ("init_step", C.c_double)]
 
 
 class RunInfo(C.Structure):
@@ -77,7 +77,7 @@ def default_bounds(cathode="LCO", **over):
 
 
 def default_opts(**over):
-    d = dict(abstol=1e-6, reltol=1e-3, maxiters=10000, check_bounds=1, interp_final=1, max_order=5, jac_every_step=0)
+    d = dict(abstol=1e-6, reltol=1e-3, maxiters=10000, check_bounds=1, interp_final=1, max_order=5, jac_every_step=0, init_step=0.0)
     d.update(over)
     d.setdefault("abstol_init", d["abstol"])
     d.setdefault("reltol_init", d["reltol"])

@@ -120,7 +120,7 @@ def _make_run(p, name, inp, tf, bounds):
 def _opts_struct(o):
     return cap.Opts(o.abstol, o.reltol, o.abstol if o.abstol_init is None else o.abstol_init,
                     o.reltol if o.reltol_init is None else o.reltol_init, int(o.maxiters), int(bool(o.check_bounds)),
-                    int(bool(o.interp_final)), int(o.max_order), int(bool(o.jac_every_step)))
+                    int(bool(o.interp_final)), int(o.max_order), int(bool(o.jac_every_step)), float(o.init_step))
 
 
 class RunResult:

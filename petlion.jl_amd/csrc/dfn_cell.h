@@ -70,13 +70,17 @@ struct CellLDS {
   double w9[NJ];
   double sig[2];
   double kapv[2];
+  // wave-uniform BDF coefficient arrays (dynamically indexed by the order -> LDS, not registers/scratch)
+  double ida_psi[MAXORD + 1], ida_alpha[MAXORD + 1], ida_beta[MAXORD + 1], ida_sigma[MAXORD + 1], ida_gamma[MAXORD + 1];
+  double ida_out[4];
+  long long cnt[10];   // device counters (n_steps, n_res, n_jac, n_fact, n_solve, n_newton, n_errfail, n_convfail, sum_kp2, n_init_iters)
   CellConst cc;
 };
 
 // per-lane registers that persist across phases
 struct LaneRegs {
   double Mrow[NR];      // row (lane % 10) of the radial operator
-  double Ainv[2][NR];   // row (lane % 10) of (kappa M - cj I)^-1 for the p / n electrode
+  double AinvP[NR], AinvN[NR];   // row (lane % 10) of (kappa M - cj I)^-1 for the p / n electrode
   double wreg[4];       // particle partial solutions kept across the Thomas phase
 };
 
@@ -200,7 +204,7 @@ __device__ inline void cell_setup(CellLDS& S, LaneRegs& R, const Tables* __restr
   }
   const int r = lane % NR;
   for (int k = 0; k < NR; k++) R.Mrow[k] = tb->M[r * NR + k];
-  for (int k = 0; k < NR; k++) { R.Ainv[0][k] = 0.0; R.Ainv[1][k] = 0.0; }
+  for (int k = 0; k < NR; k++) { R.AinvP[k] = 0.0; R.AinvN[k] = 0.0; }
   for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
   __syncthreads();
 }
@@ -409,7 +413,7 @@ __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __rest
         const double f = tb->V[r * NR + m] / (kap * tb->LAM[m] - cj);
         for (int k = 0; k < NR; k++) acc[k] += f * tb->W[m * NR + k];
       }
-      for (int k = 0; k < NR; k++) R.Ainv[el][k] = acc[k];
+      for (int k = 0; k < NR; k++) { if (el == 0) R.AinvP[k] = acc[k]; else R.AinvN[k] = acc[k]; }
       if (lane == NR - 1) S.sig[el] = acc[NR - 1];
     }
   }
@@ -428,6 +432,7 @@ __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __rest
   __syncthreads();
   // 3. block-Thomas factorisation, executed redundantly by every lane (LDS broadcast reads, no cross-lane traffic)
   double Dinv_prev[9];
+#pragma unroll 1
   for (int i = 0; i < NE; i++) {
     double D[9];
     node_block(S, i, cj, alg_only, D);
@@ -459,6 +464,7 @@ __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __rest
   // 4. border vector for modes whose control row is not "I = value":  x2 = T^-1 (column of I)
   if (mode != PLH_MODE_I) {
     double y[3] = {0, 0, 0};
+#pragma unroll 1
     for (int i = 0; i < NE; i++) {     // rhs: JI0 in the Phi_s slot of node 0, JI29 in node 29
       const double b2 = (i == 0) ? c.JI0 : ((i == NE - 1) ? c.JI29 : 0.0);
       const double* L = S.LD[i];
@@ -470,6 +476,7 @@ __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __rest
     }
     __syncthreads();
     double x[3] = {0, 0, 0};
+#pragma unroll 1
     for (int i = NE - 1; i >= 0; i--) {
       double t0 = S.y3[i][0], t1 = S.y3[i][1], t2 = S.y3[i][2];
       if (i < NE - 1) {
@@ -500,8 +507,8 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
       double w = 0.0;
       if (lane < 60 && p < NJ) {
         const double* bc = b + O_CS + p * NR;
-        const double* Ai = R.Ainv[p < NP ? 0 : 1];
-        for (int k = 0; k < NR; k++) w += Ai[k] * bc[k];
+        const bool isp = p < NP;
+        for (int k = 0; k < NR; k++) w += (isp ? R.AinvP[k] : R.AinvN[k]) * bc[k];
         if (r == NR - 1) S.w9[p] = w;
       }
       R.wreg[pass] = w;
@@ -530,6 +537,7 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
   __syncthreads();
   // c. block-Thomas forward / backward, redundantly on every lane; lane i keeps node i's solution
   double y[3] = {0, 0, 0};
+#pragma unroll 2
   for (int i = 0; i < NE; i++) {
     const double* L = S.LD[i];
     const double n0 = S.rhs3[i][0] - (L[0] * y[0] + L[1] * y[1] + L[2] * y[2]);
@@ -541,6 +549,7 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
   __syncthreads();
   double x[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
   double xs0 = 0, xs29 = 0;
+#pragma unroll 2
   for (int i = NE - 1; i >= 0; i--) {
     double t0 = S.y3[i][0], t1 = S.y3[i][1], t2 = S.y3[i][2];
     if (i < NE - 1) {
@@ -586,12 +595,13 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
       if (lane < 60 && p < NJ) {
         const int el = p < NP ? 0 : 1;
         const double bj = el == 0 ? c.bj_p : c.bj_n;
-        b[O_CS + p * NR + r] = R.wreg[pass] - R.Ainv[el][NR - 1] * bj * b[O_J + p];
+        b[O_CS + p * NR + r] = R.wreg[pass] - (el == 0 ? R.AinvP[NR - 1] : R.AinvN[NR - 1]) * bj * b[O_J + p];
       }
     }
   }
   __syncthreads();
 }
+
 
 // one entry of the full Jacobian in CSC order from its decode word (see build_csc_codes in petlion_hip.hip)
 //   word = type<<24 | a<<16 | b<<8 | c

@@ -15,14 +15,16 @@
 
 namespace pl {
 
-struct IdaScalars {
-  double psi[MAXORD + 1], alpha[MAXORD + 1], beta[MAXORD + 1], sigma[MAXORD + 1], gamma[MAXORD + 1];
+struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live in CellLDS (S.ida_*)
   double tn, hh, hused, cj, cjlast, cjold, cjratio, ss, rr, h0_forced;
   int kk, kused, knew, phase, ns, maxord;
   int nst;
 };
 
-struct Counters { long long n_steps, n_res, n_jac, n_fact, n_solve, n_newton, n_errfail, n_convfail, sum_kp2, n_init_iters; };
+// device counters live in LDS (S.cnt), incremented by lane 0; indices:
+enum Cnt { C_STEPS, C_RES, C_JAC, C_FACT, C_SOLVE, C_NEWTON, C_ERRFAIL, C_CONVFAIL, C_SUMKP2, C_INIT };
+struct Counters { CellLDS* S; };
+__device__ __forceinline__ void cnt_add(Counters& c, int k, long long v = 1) { if (lane_id() == 0) c.S->cnt[k] += v; }
 
 #define PL_VEC(n) for (int n = lane; n < NST; n += WAVE)
 
@@ -45,7 +47,7 @@ __device__ inline int cell_init_consistent(CellLDS& S, LaneRegs& R, const Tables
     __syncthreads();
     cell_factor(S, R, tb, 0.0, mode, true);
     cell_solve(S, R, res, mode, true);
-    cnt.n_res++; cnt.n_jac++; cnt.n_fact++; cnt.n_solve++; cnt.n_init_iters++;
+    cnt_add(cnt, C_RES); cnt_add(cnt, C_JAC); cnt_add(cnt, C_FACT); cnt_add(cnt, C_SOLVE); cnt_add(cnt, C_INIT);
     double s = 0.0;
     for (int n = NDIFF + lane; n < NST; n += WAVE) { const double d = res[n]; Y[n] -= d; s += d * d; }
     const double nrm = sqrt(wave_sum(s));
@@ -56,7 +58,7 @@ __device__ inline int cell_init_consistent(CellLDS& S, LaneRegs& R, const Tables
   if (!ok) return PLH_ERR_INIT;
   // YP_diff = rhs_diff(Y)   (R_diff with YP = 0)
   cell_residual(S, R, Y, YP, res, mode, value);
-  cnt.n_res++;
+  cnt_add(cnt, C_RES);
   for (int n = lane; n < NDIFF; n += WAVE) YP[n] = res[n];
   __syncthreads();
   // finite-difference estimate of the algebraic derivatives (model_evaluation.jl:462-477)
@@ -69,7 +71,7 @@ __device__ inline int cell_init_consistent(CellLDS& S, LaneRegs& R, const Tables
   cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
   __syncthreads();
   cell_solve(S, R, res, mode, true);
-  cnt.n_res++; cnt.n_solve++;
+  cnt_add(cnt, C_RES); cnt_add(cnt, C_SOLVE);
   for (int n = NDIFF + lane; n < NST; n += WAVE) YP[n] = -res[n] / dt;
   __syncthreads();
   return 0;
@@ -80,7 +82,7 @@ __device__ inline void ida_reinit(CellLDS& S, IdaScalars& I, const double* y0, c
   const int lane = lane_id();
   I.tn = 0.0; I.nst = 0; I.kk = 0; I.kused = 0; I.hused = 0.0; I.hh = 0.0; I.maxord = maxord;
   I.cjratio = 1.0; I.ss = 20.0; I.phase = 0; I.ns = 0; I.h0_forced = 0.0; I.cj = 0.0; I.cjlast = 0.0; I.cjold = 0.0; I.rr = 0.0; I.knew = 0;
-  for (int k = 0; k <= MAXORD; k++) { I.psi[k] = 0; I.alpha[k] = 0; I.beta[k] = 0; I.sigma[k] = 0; I.gamma[k] = 0; }
+  if (lane <= MAXORD) { S.ida_psi[lane] = 0; S.ida_alpha[lane] = 0; S.ida_beta[lane] = 0; S.ida_sigma[lane] = 0; S.ida_gamma[lane] = 0; }
   PL_VEC(n) { S.phi[0][n] = y0[n]; S.phi[1][n] = yp0[n]; }
   __syncthreads();
 }
@@ -96,19 +98,24 @@ __device__ inline double ida_set_coeffs(CellLDS& S, IdaScalars& I) {
   const int kk = I.kk; const double hh = I.hh;
   if (hh != I.hused || kk != I.kused) I.ns = 0;
   I.ns = (I.ns + 1 < I.kused + 2) ? I.ns + 1 : I.kused + 2;
-  if (kk + 1 >= I.ns) {
-    I.beta[0] = 1.0; I.alpha[0] = 1.0; double temp1 = hh; I.gamma[0] = 0.0; I.sigma[0] = 1.0;
-    for (int i = 1; i <= kk; i++) {
-      const double temp2 = I.psi[i - 1]; I.psi[i - 1] = temp1; I.beta[i] = I.beta[i - 1] * I.psi[i - 1] / temp2; temp1 = temp2 + hh;
-      I.alpha[i] = hh / temp1; I.sigma[i] = i * I.sigma[i - 1] * I.alpha[i]; I.gamma[i] = I.gamma[i - 1] + I.alpha[i - 1] / hh;
+  if (lane == 0) {
+    if (kk + 1 >= I.ns) {
+      S.ida_beta[0] = 1.0; S.ida_alpha[0] = 1.0; double temp1 = hh; S.ida_gamma[0] = 0.0; S.ida_sigma[0] = 1.0;
+      for (int i = 1; i <= kk; i++) {
+        const double temp2 = S.ida_psi[i - 1]; S.ida_psi[i - 1] = temp1; S.ida_beta[i] = S.ida_beta[i - 1] * temp1 / temp2; temp1 = temp2 + hh;
+        S.ida_alpha[i] = hh / temp1; S.ida_sigma[i] = i * S.ida_sigma[i - 1] * S.ida_alpha[i]; S.ida_gamma[i] = S.ida_gamma[i - 1] + S.ida_alpha[i - 1] / hh;
+      }
+      S.ida_psi[kk] = temp1;
     }
-    I.psi[kk] = temp1;
+    double alphas = 0.0, alpha0 = 0.0;
+    for (int i = 0; i < kk; i++) { alphas -= 1.0 / (i + 1); alpha0 -= S.ida_alpha[i]; }
+    double ck = fabs(S.ida_alpha[kk] + alphas - alpha0); if (ck < S.ida_alpha[kk]) ck = S.ida_alpha[kk];
+    S.ida_out[0] = -alphas / hh; S.ida_out[1] = ck;
   }
-  double alphas = 0.0, alpha0 = 0.0;
-  for (int i = 0; i < kk; i++) { alphas -= 1.0 / (i + 1); alpha0 -= I.alpha[i]; }
-  I.cjlast = I.cj; I.cj = -alphas / hh;
-  double ck = fabs(I.alpha[kk] + alphas - alpha0); if (ck < I.alpha[kk]) ck = I.alpha[kk];
-  for (int i = I.ns; i <= kk; i++) { const double b = I.beta[i]; PL_VEC(n) S.phi[i][n] *= b; }
+  __syncthreads();
+  I.cjlast = I.cj; I.cj = S.ida_out[0];
+  const double ck = S.ida_out[1];
+  for (int i = I.ns; i <= kk; i++) { const double b = S.ida_beta[i]; PL_VEC(n) S.phi[i][n] *= b; }
   I.tn += hh;
   __syncthreads();
   return ck;
@@ -119,7 +126,7 @@ __device__ inline void form_iterate(CellLDS& S, const IdaScalars& I) {
   const int lane = lane_id();
   PL_VEC(n) {
     double a = S.phi[0][n], b = 0.0;
-    for (int j = 1; j <= I.kk; j++) { const double p = S.phi[j][n]; a += p; b += I.gamma[j] * p; }
+    for (int j = 1; j <= I.kk; j++) { const double p = S.phi[j][n]; a += p; b += S.ida_gamma[j] * p; }
     const double e = S.ee[n];
     S.yy[n] = a + e; S.yp[n] = b + I.cj * e;
   }
@@ -149,15 +156,15 @@ __device__ inline int ida_nls(CellLDS& S, LaneRegs& R, const Tables* tb, IdaScal
       cell_cs_rows(S, R, S.yy, S.yp, S.delta);
       __syncthreads();
       cell_factor(S, R, tb, I.cj, mode, false);
-      cnt.n_res++; cnt.n_jac++; cnt.n_fact++;
+      cnt_add(cnt, C_RES); cnt_add(cnt, C_JAC); cnt_add(cnt, C_FACT);
       I.cjold = I.cj; I.cjratio = 1.0; I.ss = 20.0; jcur = 1;
     } else {
       cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
-      cnt.n_res++;
+      cnt_add(cnt, C_RES);
     }
     int m = 0; double oldnrm = 0.0;
     for (;;) {
-      cnt.n_newton++; cnt.n_solve++;
+      cnt_add(cnt, C_NEWTON); cnt_add(cnt, C_SOLVE);
       PL_VEC(n) S.delta[n] = -S.delta[n];
       __syncthreads();
       cell_solve(S, R, S.delta, mode, false);
@@ -176,7 +183,7 @@ __device__ inline int ida_nls(CellLDS& S, LaneRegs& R, const Tables* tb, IdaScal
       m++; if (m >= 4) { ret = 1; break; }
       form_iterate(S, I);
       cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
-      cnt.n_res++;
+      cnt_add(cnt, C_RES);
     }
     if (ret > 0 && !jcur) { callLSetup = 1; PL_VEC(n) S.ee[n] = 0.0; __syncthreads(); continue; }
     break;
@@ -196,12 +203,12 @@ __device__ inline int ida_test_error(CellLDS& S, IdaScalars& I, double ck, doubl
       if (kk > 2) { const double d2 = d1 + S.phi[kk - 1][n]; p = d2 * w; s2 += p * p; } }
   }
   const double enorm_k = sqrt(wave_sum(s0) / NST);
-  err_k = I.sigma[kk] * enorm_k; const double terr_k = (kk + 1) * err_k;
+  err_k = S.ida_sigma[kk] * enorm_k; const double terr_k = (kk + 1) * err_k;
   I.knew = kk; err_km1 = 0.0;
   if (kk > 1) {
-    const double enorm_km1 = sqrt(wave_sum(s1) / NST); err_km1 = I.sigma[kk - 1] * enorm_km1; const double terr_km1 = kk * err_km1;
+    const double enorm_km1 = sqrt(wave_sum(s1) / NST); err_km1 = S.ida_sigma[kk - 1] * enorm_km1; const double terr_km1 = kk * err_km1;
     if (kk > 2) {
-      const double enorm_km2 = sqrt(wave_sum(s2) / NST); const double err_km2 = I.sigma[kk - 2] * enorm_km2; const double terr_km2 = (kk - 1) * err_km2;
+      const double enorm_km2 = sqrt(wave_sum(s2) / NST); const double err_km2 = S.ida_sigma[kk - 2] * enorm_km2; const double terr_km2 = (kk - 1) * err_km2;
       if ((terr_km1 > terr_km2 ? terr_km1 : terr_km2) <= terr_k) I.knew = kk - 1;
     } else if (terr_km1 <= 0.5 * terr_k) I.knew = kk - 1;
   }
@@ -211,8 +218,8 @@ __device__ inline int ida_test_error(CellLDS& S, IdaScalars& I, double ck, doubl
 __device__ inline void ida_restore(CellLDS& S, IdaScalars& I, double saved_t) {
   const int lane = lane_id();
   I.tn = saved_t;
-  for (int j = 1; j <= I.kk; j++) I.psi[j - 1] = I.psi[j] - I.hh;
-  if (I.ns <= I.kk) for (int j = I.ns; j <= I.kk; j++) { const double b = 1.0 / I.beta[j]; PL_VEC(n) S.phi[j][n] *= b; }
+  if (lane == 0) for (int j = 1; j <= I.kk; j++) S.ida_psi[j - 1] = S.ida_psi[j] - I.hh;
+  if (I.ns <= I.kk) for (int j = I.ns; j <= I.kk; j++) { const double b = 1.0 / S.ida_beta[j]; PL_VEC(n) S.phi[j][n] *= b; }
   __syncthreads();
 }
 
@@ -258,14 +265,18 @@ __device__ inline void ida_get_solution(CellLDS& S, const IdaScalars& I, double 
   const int lane = lane_id();
   int kord = I.kused; if (kord == 0) kord = 1;
   const double delt = t - I.tn;
-  double c = 1.0, d = 0.0, gam = delt / I.psi[0];
-  double cv[MAXORD + 1], dv[MAXORD + 1];
-  cv[0] = c;
-  for (int j = 1; j <= kord; j++) { d = d * gam + c / I.psi[j - 1]; c = c * gam; gam = (delt + I.psi[j - 1]) / I.psi[j]; cv[j] = c; dv[j - 1] = d; }
+  double c = 1.0, d = 0.0, gam = delt / S.ida_psi[0];
+  double c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;   // static registers instead of cv[]/dv[]
+#define PL_GS_STEP(J, CV, DV) if (J <= kord) { d = d * gam + c / S.ida_psi[J - 1]; c = c * gam; gam = (delt + S.ida_psi[J - 1]) / S.ida_psi[J <= MAXORD ? J : MAXORD]; CV = c; DV = d; }
+  PL_GS_STEP(1, c1, d0) PL_GS_STEP(2, c2, d1) PL_GS_STEP(3, c3, d2) PL_GS_STEP(4, c4, d3) PL_GS_STEP(5, c5, d4)
+#undef PL_GS_STEP
   PL_VEC(n) {
-    double s = 0.0, sp = 0.0;
-    for (int j = 0; j <= kord; j++) s += cv[j] * S.phi[j][n];
-    for (int j = 1; j <= kord; j++) sp += dv[j - 1] * S.phi[j][n];
+    const double p1 = S.phi[1][n], p2 = S.phi[2][n], p3 = S.phi[3][n], p4 = S.phi[4][n], p5 = S.phi[5][n];
+    double s = S.phi[0][n] + c1 * p1, sp = d0 * p1;
+    if (kord >= 2) { s += c2 * p2; sp += d1 * p2; }
+    if (kord >= 3) { s += c3 * p3; sp += d2 * p3; }
+    if (kord >= 4) { s += c4 * p4; sp += d3 * p4; }
+    if (kord >= 5) { s += c5 * p5; sp += d4 * p5; }
     yo[n] = s; ypo[n] = sp;
   }
   __syncthreads();
@@ -279,7 +290,7 @@ __device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaSca
   if (I.nst == 0) {
     set_ewt(S, o.reltol, o.abstol);
     const double tdist = fabs(tstop - I.tn);
-    double hh = I.h0_forced;
+    double hh = I.h0_forced != 0.0 ? I.h0_forced : o.init_step;
     if (hh == 0.0) {
       hh = 0.001 * tdist;
       const double ypnorm = wrms(S.phi[1], S.ewt);
@@ -296,7 +307,7 @@ __device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaSca
     set_ewt(S, o.reltol, o.abstol);
   }
   const double saved_t = I.tn; int ncf = 0, nef = 0; double err_k = 0, err_km1 = 0;
-  if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; I.psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; }
+  if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; __syncthreads(); }
   for (;;) {
     const double ck = ida_set_coeffs(S, I);
     const int nflag = ida_nls(S, R, tb, I, mode, value, o.jac_every_step, cnt);
@@ -306,11 +317,11 @@ __device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaSca
       ida_restore(S, I, saved_t);
       I.phase = 1;
       if (!errfail) {
-        cnt.n_convfail++;
+        cnt_add(cnt, C_CONVFAIL);
         I.rr = 0.25; I.hh *= I.rr; ncf++;
         if (ncf >= 10) return PLH_ERR_STALL;
       } else {
-        cnt.n_errfail++; nef++;
+        cnt_add(cnt, C_ERRFAIL); nef++;
         if (nef == 1) { const double err_knew = (I.kk == I.knew) ? err_k : err_km1; I.kk = I.knew;
           I.rr = 0.9 * pow(2.0 * err_knew + 0.0001, -1.0 / (I.kk + 1)); I.rr = I.rr < 0.9 ? I.rr : 0.9; I.rr = I.rr > 0.25 ? I.rr : 0.25; I.hh *= I.rr; }
         else if (nef == 2) { I.kk = I.knew; I.rr = 0.25; I.hh *= I.rr; }
@@ -319,12 +330,12 @@ __device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaSca
       }
       const double tscale = fabs(I.tn) > 1.0 ? fabs(I.tn) : 1.0;
       if (fabs(I.hh) < 1e-14 * tscale) return PLH_ERR_STALL;
-      if (I.nst == 0) { I.psi[0] = I.hh; const double rr = I.rr; PL_VEC(n) S.phi[1][n] *= rr; __syncthreads(); }
+      if (I.nst == 0) { if (lane == 0) S.ida_psi[0] = I.hh; const double rr = I.rr; PL_VEC(n) S.phi[1][n] *= rr; __syncthreads(); }
       continue;
     }
     break;
   }
-  cnt.n_steps++; cnt.sum_kp2 += I.kk + 2;
+  cnt_add(cnt, C_STEPS); cnt_add(cnt, C_SUMKP2, I.kk + 2);
   ida_complete_step(S, I, err_k, err_km1);
   const double troundoff = 100.0 * uround * (fabs(I.tn) + fabs(I.hh));
   if (fabs(I.tn - tstop) <= troundoff) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; return 0; }
@@ -411,7 +422,7 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
     }
   };
   for (int r = 0; r < n_runs; r++) {
-    const plh_run run = runs[r];
+    const plh_run& run = runs[r];
     const int mode = run.mode;
     const bool new_run = !have_prev;
     double t0;
@@ -437,9 +448,9 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
     plh_run_info ri; ri.flag = PLH_FLAG_RUNNING; ri.iterations = 0; ri.t_end = t_global; ri.V = 0; ri.I = 0; ri.SOC = SOC; ri.T_avg = T0;
     if (ierr != 0) { ri.flag = ierr; if (lane == 0) info[r] = ri; for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; info[q] = z; } break; }
     ida_reinit(S, I, S.yy, S.yp, o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD);
-    double tstops[2]; int nts = 0, its = 0;
-    if (!new_run && run.tf > 1.0) tstops[nts++] = 1.0;                  // postfix_integrator!, model_evaluation.jl:288-310
-    tstops[nts++] = run.tf;
+    // tstops = {1.0 if continuation} U {tf}   (postfix_integrator!, model_evaluation.jl:288-310)
+    const bool two_stops = !new_run && run.tf > 1.0;
+    int its = 0; const int nts = two_stops ? 2 : 1;
     PrevVals pv; pv.frac = 1.0; pv.V = -1; pv.SOC = -1; pv.I = -1; pv.c_s_n = -1; pv.c_e_min = -1; pv.eta_pl = -1;
     save_pt(nout, t0, S.yy, SOC); nout++;
     check_stop(S, run, o, 0.0, run.tf, S.yy, S.yp, SOC, pv, flag);
@@ -449,7 +460,8 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
     double I_prev_pt = S.yy[O_I];
     while (flag == PLH_FLAG_RUNNING) {
       double tret = t; tprev = t;
-      const int sf = ida_step(S, R, tb, I, tstops[its], tret, mode, value, o, cnt);
+      const double tstop_now = (two_stops && its == 0) ? 1.0 : run.tf;
+      const int sf = ida_step(S, R, tb, I, tstop_now, tret, mode, value, o, cnt);
       if (sf != 0) {
         if (I.nst == 0 && !stalled_once) {                              // check_solve, checks.jl:227-237
           stalled_once = true;
@@ -459,7 +471,7 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
         }
         flag = sf; break;
       }
-      if (tret >= tstops[its] && its + 1 < nts) its++;
+      if (tret >= tstop_now && its + 1 < nts) its++;
       iter++; t = tret;
       const double SOC_new = SOC + 0.5 * ((t + t0) - t_prev_saved) * (S.yy[O_I] + I_prev_pt) / 3600.0;   // calc_SOC, scalar_residual.jl:103-111
       SOC = SOC_new;

@@ -96,10 +96,12 @@ __global__ __launch_bounds__(64) void k_init_consistent(const Tables* tb, int n_
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec(S.yy, Y + (size_t)cell * NST);
   __syncthreads();
-  Counters cnt; memset(&cnt, 0, sizeof(cnt));
+  Counters cnt; cnt.S = &S; if (lane_id() < 10) S.cnt[lane_id()] = 0;
+  __syncthreads();
   const int rc = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, reltol_init, cnt);
   store_vec(Y + (size_t)cell * NST, S.yy); store_vec(YP + (size_t)cell * NST, S.yp);
-  if (lane_id() == 0) { if (status) status[cell] = rc; if (iters) iters[cell] = (int)cnt.n_init_iters; }
+  __syncthreads();
+  if (lane_id() == 0) { if (status) status[cell] = rc; if (iters) iters[cell] = (int)S.cnt[C_INIT]; }
 }
 
 struct IntegrateArgs {
@@ -113,7 +115,8 @@ __global__ __launch_bounds__(64) void k_integrate(IntegrateArgs a) {
   const int cell = blockIdx.x;
   if (cell >= a.n_cells) return;
   cell_setup(S, R, a.tb, a.theta + (size_t)cell * a.tb->P);
-  Counters cnt; memset(&cnt, 0, sizeof(cnt));
+  Counters cnt; cnt.S = &S; if (lane_id() < 10) S.cnt[lane_id()] = 0;
+  __syncthreads();
   CellOut co;
   const size_t off = (size_t)cell * a.out.max_pts;
   co.max_pts = a.out.max_pts;
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(64) void k_integrate(IntegrateArgs a) {
                 a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST);
   if (lane_id() == 0 && a.out.counters) {
     plh_counters* c = a.out.counters + cell;
-    c->n_steps = cnt.n_steps; c->n_res = cnt.n_res; c->n_jac = cnt.n_jac; c->n_fact = cnt.n_fact; c->n_solve = cnt.n_solve;
-    c->n_newton = cnt.n_newton; c->n_errfail = cnt.n_errfail; c->n_convfail = cnt.n_convfail; c->sum_kp2 = cnt.sum_kp2; c->n_init_iters = cnt.n_init_iters;
+    c->n_steps = S.cnt[C_STEPS]; c->n_res = S.cnt[C_RES]; c->n_jac = S.cnt[C_JAC]; c->n_fact = S.cnt[C_FACT]; c->n_solve = S.cnt[C_SOLVE];
+    c->n_newton = S.cnt[C_NEWTON]; c->n_errfail = S.cnt[C_ERRFAIL]; c->n_convfail = S.cnt[C_CONVFAIL]; c->sum_kp2 = S.cnt[C_SUMKP2]; c->n_init_iters = S.cnt[C_INIT];
   }
 }
 

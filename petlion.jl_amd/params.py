@@ -88,6 +88,7 @@ class Opts:
         # build-specific knobs (not in the reference)
         self.max_order = 5
         self.jac_every_step = False
+        self.init_step = 0.0        # 0 = IDA's automatic initial step; > 0 = IDASetInitStep
         self.max_points = 2048      # capacity of the per-cell output buffers
 
 

@@ -43,3 +43,12 @@ def test_cc_cv_with_fresh_jacobians(emu_model, O, pkg):
     assert abs(ens2.run_info[0, 0]["t_end"] - ro2["runs"][0]["t_end"]) < 1e-6 * ro2["runs"][0]["t_end"]      # CC leg: tight
     assert abs(ens2.run_info[0, 1]["t_end"] - ro2["runs"][1]["t_end"]) < 2e-3 * ro2["runs"][1]["t_end"]      # CV leg: reltol
     assert abs(ens2.run_info[0, 1]["I"] - ro2["runs"][1]["I"]) < 1e-2 * ro2["runs"][1]["I"]
+
+
+def test_c4_sweep_cells_pinned_initial_step(emu_model, O, pkg):
+    """6 cells of the C4 parameter sweep with h0 pinned: same decisions, end state to 1e-6 (see test_gpu_parity.py for the
+    tolerance structure with the automatic h0)."""
+    import test_gpu_parity as tg
+    o = pkg.Opts(); o.init_step = 1e-2
+    n_same, errs = tg.sweep_check(pkg, emu_model, O, 6, opts=o, oopts=O.default_opts(init_step=1e-2))
+    assert n_same == 6 and errs[-1] <= 1e-6, (n_same, errs)
