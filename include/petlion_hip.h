@@ -99,6 +99,8 @@ typedef struct {
 /* per-cell device counters: the roofline contract of SURVEY.md 8(d) */
 typedef struct {
   long long n_steps, n_res, n_jac, n_fact, n_solve, n_newton, n_errfail, n_convfail, sum_kp2, n_init_iters;
+  long long cyc[8];   /* shader cycles per phase (residual, jacobian+factor, solve, newton vector ops, step control, init, output, total);
+                         filled only by the profiling build (-DPL_PHASE_TIMERS), zero otherwise */
 } plh_counters;
 
 /* outputs of plh_integrate; any pointer may be NULL.  Saved points are the reference's per-step pushes of

@@ -53,7 +53,7 @@ COUNTER_FIELDS = ["n_steps", "n_res", "n_jac", "n_fact", "n_solve", "n_newton", 
 
 
 class CountersS(C.Structure):
-    _fields_ = [(f, C.c_longlong) for f in COUNTER_FIELDS]
+    _fields_ = [(f, C.c_longlong) for f in COUNTER_FIELDS] + [("cyc", C.c_longlong * 8)]
 
 
 class Outputs(C.Structure):
@@ -64,7 +64,7 @@ class Outputs(C.Structure):
 
 RUN_INFO_DTYPE = np.dtype([("flag", np.int32), ("iterations", np.int32), ("t_end", np.float64), ("V", np.float64),
                            ("I", np.float64), ("SOC", np.float64), ("T_avg", np.float64)], align=True)
-COUNTERS_DTYPE = np.dtype([(f, np.int64) for f in COUNTER_FIELDS], align=True)
+COUNTERS_DTYPE = np.dtype([(f, np.int64) for f in COUNTER_FIELDS] + [("cyc", np.int64, (8,))], align=True)
 assert RUN_INFO_DTYPE.itemsize == C.sizeof(RunInfo) and COUNTERS_DTYPE.itemsize == C.sizeof(CountersS)
 
 EXPORTS = ["plh_model_create", "plh_model_destroy", "plh_n_states", "plh_n_diff", "plh_n_theta", "plh_theta_key",

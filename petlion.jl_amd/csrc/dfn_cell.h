@@ -65,14 +65,15 @@ struct CellLDS {
   double gce[NJ], gcs[NJ], gpe[NJ], gps[NJ], psJ[NJ];
   // eliminated system
   double dj[NJ], fS[NE], fP[NE], fQ[NE];
-  double Dinv[NE][9], LD[NE][9];
-  double rhs3[NE][3], y3[NE][3], x2[NE][3];
+  double Dinv[NE][9], LD[NE][9], GU[NE][9];   // Thomas factors: D'^-1, L D'^-1(prev), D'^-1 U
+  double x2[NE][3];
   double w9[NJ];
   double sig[2];
   double kapv[2];
   // wave-uniform BDF coefficient arrays (dynamically indexed by the order -> LDS, not registers/scratch)
   double ida_psi[MAXORD + 1], ida_alpha[MAXORD + 1], ida_beta[MAXORD + 1], ida_sigma[MAXORD + 1], ida_gamma[MAXORD + 1];
   double ida_out[4];
+  long long cyc[8];    // per-phase cycle sums (profiling build only)
   long long cnt[10];   // device counters (n_steps, n_res, n_jac, n_fact, n_solve, n_newton, n_errfail, n_convfail, sum_kp2, n_init_iters)
   CellConst cc;
 };
@@ -85,12 +86,56 @@ struct LaneRegs {
 };
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
+
+// Phase separator between LDS producers and consumers.  A workgroup here is exactly ONE wavefront, and the LDS instructions of one
+// wave execute in program order, so no s_barrier is needed -- and __syncthreads() would cost a workgroup-scope fence that also
+// waits (s_waitcnt vmcnt(0)) for this wave's fire-and-forget global stores (per-step outputs).  On the GPU this is therefore only
+// a compiler barrier (the compiler still inserts the lgkmcnt waits that real data dependences need); the lock-step emulator
+// yields to the other lanes.
+#ifdef PL_WAVE_EMU
+#define PL_SYNC() __syncthreads()
+#else
+#define PL_SYNC() __asm__ volatile("" ::: "memory")
+#endif
+
+// optional per-phase cycle accounting (profiling build: -DPL_PHASE_TIMERS)
+enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_OUTPUT, PH_TOTAL };
+#if defined(PL_PHASE_TIMERS) && !defined(PL_WAVE_EMU)
+#define PL_TIC() const long long pl_t0__ = (long long)__builtin_readcyclecounter()
+#define PL_TOC(S_, ph) do { if (lane_id() == 0) (S_).cyc[ph] += (long long)__builtin_readcyclecounter() - pl_t0__; } while (0)
+#else
+#define PL_TIC() do {} while (0)
+#define PL_TOC(S_, ph) do {} while (0)
+#endif
 __host__ __device__ __forceinline__ int sec_of(int i) { return i < NP ? 0 : (i < NP + NS ? 1 : 2); }
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+// ---- cross-lane primitives.  gfx950: DPP moves (probed on hardware, tools/probes/dpp_probe.hip: wave_shr:1 / wave_shl:1 shift
+// across the whole 64-lane wave, boundary lanes keep `old`), v_readlane for broadcasts.  Emulator: __shfl. ----
+#ifndef PL_WAVE_EMU
+template <int CTRL> __device__ __forceinline__ double dpp_mov0(double v) {     // out-of-range source lanes read 0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ double shift_up1(double v) { return dpp_mov0<0x138>(v); }     // lane i <- lane i-1 (lane 0 <- 0)
+__device__ __forceinline__ double shift_down1(double v) { return dpp_mov0<0x130>(v); }   // lane i <- lane i+1 (lane 63 <- 0)
+__device__ __forceinline__ double lane_bcast(double v, int src) {                         // wave-uniform src
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_mov0<0x111>(v); v += dpp_mov0<0x112>(v); v += dpp_mov0<0x114>(v); v += dpp_mov0<0x118>(v);   // row_shr 1,2,4,8: inclusive row scan
+  return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
+}
+#else
+__device__ __forceinline__ double shift_up1(double v) { const double r = __shfl_up(v, 1); return lane_id() == 0 ? 0.0 : r; }
+__device__ __forceinline__ double shift_down1(double v) { const double r = __shfl_down(v, 1); return lane_id() == WAVE - 1 ? 0.0 : r; }
+__device__ __forceinline__ double lane_bcast(double v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 1; o < 16; o <<= 1) { const double r = __shfl_up(v, o); if ((lane_id() & 15) >= o) v += r; }
+  return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // closures (reference src/physics_equations/custom_functions.jl)
@@ -206,7 +251,7 @@ __device__ inline void cell_setup(CellLDS& S, LaneRegs& R, const Tables* __restr
   for (int k = 0; k < NR; k++) R.Mrow[k] = tb->M[r * NR + k];
   for (int k = 0; k < NR; k++) { R.AinvP[k] = 0.0; R.AinvN[k] = 0.0; }
   for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
-  __syncthreads();
+  PL_SYNC();
 }
 
 // initial_guess!, reference src/states_definition.jl:80-121
@@ -218,7 +263,7 @@ __device__ inline void cell_initial_guess(CellLDS& S, double* Y, double SOC) {
   double Up, Un, d;
   ocv_lco(csp / c.cmaxp, c.T0, c.iso_ref, Up, d);
   ocv_lic6(csn / c.cmaxn, c.T0, c.iso_ref, Un, d);
-  for (int n = lane; n < NST; n += WAVE) {
+  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < (NST + WAVE - 1) / WAVE; k__++, n += WAVE) if (n < NST) {
     double v = 0.0;
     if (n < O_CS) v = c.ce0;
     else if (n < O_CS + NP * NR) v = csp;
@@ -227,7 +272,7 @@ __device__ inline void cell_initial_guess(CellLDS& S, double* Y, double SOC) {
     else if (n >= O_PS + NP && n < O_I) v = Un;
     Y[n] = v;
   }
-  __syncthreads();
+  PL_SYNC();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -247,7 +292,7 @@ __device__ inline void cell_node_pass(CellLDS& S, const double* Y, const double*
   double K, dK; keff(ce, c.T0, K, dK);
   K *= c.bf[sc]; dK *= c.bf[sc];
   const double D = c.Dc[sc];
-  const double ce_n = __shfl_down(ce, 1), pe_n = __shfl_down(pe, 1), K_n = __shfl_down(K, 1), dK_n = __shfl_down(dK, 1), D_n = __shfl_down(D, 1);
+  const double ce_n = shift_down1(ce), pe_n = shift_down1(pe), K_n = shift_down1(K), dK_n = shift_down1(dK), D_n = shift_down1(D);
   // edge i : geometry (numerical_tools.jl:106-215)
   double beta = 0.5, dist = h;
   if (i == NP - 1) { beta = (c.h[0] / 2) / (c.h[1] / 2 + c.h[0] / 2); dist = c.h[0] / 2 + c.h[1] / 2; }
@@ -262,7 +307,7 @@ __device__ inline void cell_node_pass(CellLDS& S, const double* Y, const double*
   const double g = Kh * Tb * dc / cb;
   double E = edge ? w * (pe - pe_n) + c.Kfac * g : 0.0;   // Phi_e-row edge flux
   double Nf = edge ? Dh * dc : 0.0;                        // c_e-row edge flux
-  const double E_p = __shfl_up(E, 1), Nf_p = __shfl_up(Nf, 1);
+  const double E_p = shift_up1(E), Nf_p = shift_up1(Nf);
   const double Em = i > 0 ? E_p : 0.0, Nm = i > 0 ? Nf_p : 0.0;
   // electrode quantities
   const double a = sc == 0 ? c.a_p : c.a_n;
@@ -280,7 +325,7 @@ __device__ inline void cell_node_pass(CellLDS& S, const double* Y, const double*
   const double sq = sqrt(arg > 0.0 ? arg : 0.0);
   const double xx = c.fRT * eta;
   const double sh = sinh(xx);
-  const double ps_p = __shfl_up(ps, 1), ps_n = __shfl_down(ps, 1);
+  const double ps_p = shift_up1(ps), ps_n = shift_down1(ps);
   const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
   if (WANT_RES) {
     if (act) {
@@ -312,7 +357,7 @@ __device__ inline void cell_node_pass(CellLDS& S, const double* Y, const double*
     double Eb = edge ? (pe - pe_n) * dKh_b / dist + c.Kfac * dg_b : 0.0;
     double we = edge ? w : 0.0;
     double Na = edge ? -Dh / dist : 0.0, Nb = edge ? Dh / dist : 0.0;     // D_eff_linear: dD/dc = 0
-    const double Ea_p = __shfl_up(Ea, 1), Eb_p = __shfl_up(Eb, 1), we_p = __shfl_up(we, 1), Na_p = __shfl_up(Na, 1), Nb_p = __shfl_up(Nb, 1);
+    const double Ea_p = shift_up1(Ea), Eb_p = shift_up1(Eb), we_p = shift_up1(we), Na_p = shift_up1(Na), Nb_p = shift_up1(Nb);
     if (act) {
       const double he = h * c.eps[sc];
       S.ceL[i] = i > 0 ? -Na_p / he : 0.0;
@@ -363,7 +408,7 @@ __device__ inline void cell_cs_rows(CellLDS& S, const LaneRegs& R, const double*
 __device__ inline void cell_residual(CellLDS& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo, int mode, double value) {
   cell_node_pass<true, false>(S, Y, YP, Fo, mode, value);
   cell_cs_rows(S, R, Y, YP, Fo);
-  __syncthreads();
+  PL_SYNC();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -397,6 +442,38 @@ __device__ __forceinline__ void node_block(const CellLDS& S, int i, double cj, b
   }
 }
 
+// forward / backward substitution with the factors in S.LD / S.Dinv / S.GU as systolic sweeps: lane i holds node i's right-hand
+// side (r0,r1,r2) on entry and node i's solution on exit.  The recurrence value travels lane -> lane+1 (forward) and
+// lane -> lane-1 (backward) through DPP shifts.  Every lane re-evaluates its own recurrence at every stage: a lane whose
+// predecessor is final reproduces its final value (the update is idempotent), so no per-stage select is needed; lane 0 (LD = 0)
+// and lane NE-1 (GU = 0) are final from the start and the wavefront advances one lane per stage.
+__device__ __forceinline__ void thomas_sweeps(const CellLDS& S, double& r0, double& r1, double& r2) {
+  const int lane = lane_id();
+  const int i = lane < NE ? lane : NE - 1;
+  double L[9], G[9];
+  for (int k = 0; k < 9; k++) { L[k] = S.LD[i][k]; G[k] = S.GU[i][k]; }
+  double y0 = r0, y1 = r1, y2 = r2;
+#pragma unroll 4
+  for (int it = 1; it < NE; it++) {
+    const double p0 = shift_up1(y0), p1 = shift_up1(y1), p2 = shift_up1(y2);
+    y0 = r0 - (L[0] * p0 + L[1] * p1 + L[2] * p2);
+    y1 = r1 - (L[3] * p0 + L[4] * p1 + L[5] * p2);
+    y2 = r2 - (L[6] * p0 + L[7] * p1 + L[8] * p2);
+  }
+  // backward: x_i = z_i - G_i x_{i+1},  z = Dinv y,  G = Dinv U
+  const double* Di = S.Dinv[i];
+  const double z0 = Di[0] * y0 + Di[1] * y1 + Di[2] * y2, z1 = Di[3] * y0 + Di[4] * y1 + Di[5] * y2, z2 = Di[6] * y0 + Di[7] * y1 + Di[8] * y2;
+  double x0 = z0, x1 = z1, x2 = z2;
+#pragma unroll 4
+  for (int it = NE - 2; it >= 0; it--) {
+    const double q0 = shift_down1(x0), q1 = shift_down1(x1), q2 = shift_down1(x2);
+    x0 = z0 - (G[0] * q0 + G[1] * q1 + G[2] * q2);
+    x1 = z1 - (G[3] * q0 + G[4] * q1 + G[5] * q2);
+    x2 = z2 - (G[6] * q0 + G[7] * q1 + G[8] * q2);
+  }
+  r0 = x0; r1 = x1; r2 = x2;
+}
+
 // factor the Newton matrix at the Jacobian partials currently in S (cell_node_pass<.,true> must have run).
 // mode selects the control row; alg_only = the 71x71 algebraic block of the consistent-initialisation Newton.
 __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
@@ -417,7 +494,7 @@ __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __rest
       if (lane == NR - 1) S.sig[el] = acc[NR - 1];
     }
   }
-  __syncthreads();
+  PL_SYNC();
   // 2. Schur-complemented j pivot and the j-elimination factors
   if (lane < NE) {
     const int i = lane, sc = sec_of(i);
@@ -429,69 +506,59 @@ __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __rest
       S.fS[i] = S.ceJ[i] / d; S.fP[i] = S.peJ[i] / d; S.fQ[i] = S.psJ[jx] / d;
     } else { S.fS[i] = 0; S.fP[i] = 0; S.fQ[i] = 0; }
   }
-  __syncthreads();
-  // 3. block-Thomas factorisation, executed redundantly by every lane (LDS broadcast reads, no cross-lane traffic)
-  double Dinv_prev[9];
-#pragma unroll 1
-  for (int i = 0; i < NE; i++) {
-    double D[9];
+  PL_SYNC();
+  // 3. block-Thomas factorisation as a systolic sweep: lane i owns node i; at iteration i lane i receives Dinv_{i-1} from lane i-1
+  //    through DPP shifts, forms LD_i = L_i Dinv_{i-1} and D'_i = D_i - LD_i U_{i-1}, inverts it and keeps the result.
+  {
+    const int i = lane < NE ? lane : NE - 1;
+    double D[9], Dinv[9], LDm[9];
     node_block(S, i, cj, alg_only, D);
-    double LDm[9];
-    if (i > 0) {
-      // L_i = [[ceL,0,0],[pcL,peL,0],[0,0,psL]],  U_{i-1} = [[ceU,0,0],[pcU,peU,0],[0,0,psU]]
-      const int scp = sec_of(i - 1), sci = sec_of(i);
-      const double l00 = alg_only ? 0.0 : S.ceL[i], l10 = alg_only ? 0.0 : S.pcL[i], l11 = S.peL[i];
-      const double l22 = (sci != 1 && scp == sci) ? 1.0 : 0.0;
+    const int sci = sec_of(i), scp = sec_of(i > 0 ? i - 1 : 0);
+    const double l00 = (alg_only || i == 0) ? 0.0 : S.ceL[i], l10 = (alg_only || i == 0) ? 0.0 : S.pcL[i], l11 = i == 0 ? 0.0 : S.peL[i];
+    const double l22 = (i > 0 && sci != 1 && scp == sci) ? 1.0 : 0.0;
+    const double u00 = (alg_only || i == 0) ? 0.0 : S.ceU[i - 1], u10 = (alg_only || i == 0) ? 0.0 : S.pcU[i - 1], u11 = i == 0 ? 0.0 : S.peU[i - 1];
+    const double u22 = l22;
+    for (int k = 0; k < 9; k++) LDm[k] = 0.0;
+    inv3(D, Dinv);                                      // correct for lane 0; refined below for the others
+#pragma unroll 1
+    for (int it = 1; it < NE; it++) {
+      double P[9];
+      for (int k = 0; k < 9; k++) P[k] = shift_up1(Dinv[k]);
+      double Ln[9], Dn[9], Dni[9];
       for (int k = 0; k < 3; k++) {
-        LDm[k] = l00 * Dinv_prev[k];
-        LDm[3 + k] = l10 * Dinv_prev[k] + l11 * Dinv_prev[3 + k];
-        LDm[6 + k] = l22 * Dinv_prev[6 + k];
+        Ln[k] = l00 * P[k];
+        Ln[3 + k] = l10 * P[k] + l11 * P[3 + k];
+        Ln[6 + k] = l22 * P[6 + k];
       }
-      const double u00 = alg_only ? 0.0 : S.ceU[i - 1], u10 = alg_only ? 0.0 : S.pcU[i - 1], u11 = S.peU[i - 1];
-      const double u22 = l22;
       for (int rr = 0; rr < 3; rr++) {
-        D[rr * 3 + 0] -= LDm[rr * 3 + 0] * u00 + LDm[rr * 3 + 1] * u10;
-        D[rr * 3 + 1] -= LDm[rr * 3 + 1] * u11;
-        D[rr * 3 + 2] -= LDm[rr * 3 + 2] * u22;
+        Dn[rr * 3 + 0] = D[rr * 3 + 0] - (Ln[rr * 3 + 0] * u00 + Ln[rr * 3 + 1] * u10);
+        Dn[rr * 3 + 1] = D[rr * 3 + 1] - Ln[rr * 3 + 1] * u11;
+        Dn[rr * 3 + 2] = D[rr * 3 + 2] - Ln[rr * 3 + 2] * u22;
       }
-    } else {
-      for (int k = 0; k < 9; k++) LDm[k] = 0.0;
+      inv3(Dn, Dni);
+      const bool me = lane == it;
+      for (int k = 0; k < 9; k++) { Dinv[k] = me ? Dni[k] : Dinv[k]; LDm[k] = me ? Ln[k] : LDm[k]; }
     }
-    inv3(D, Dinv_prev);
-    if (lane == 0) for (int k = 0; k < 9; k++) { S.Dinv[i][k] = Dinv_prev[k]; S.LD[i][k] = LDm[k]; }
+    if (lane < NE) {
+      // G = Dinv U_i with U_i = [[ceU,0,0],[pcU,peU,0],[0,0,psU]] (zero for the last node)
+      const int scn = sec_of(i < NE - 1 ? i + 1 : NE - 1);
+      const double v00 = (alg_only || i == NE - 1) ? 0.0 : S.ceU[i], v10 = (alg_only || i == NE - 1) ? 0.0 : S.pcU[i], v11 = i == NE - 1 ? 0.0 : S.peU[i];
+      const double v22 = (i < NE - 1 && sci != 1 && scn == sci) ? 1.0 : 0.0;
+      for (int rr = 0; rr < 3; rr++) {
+        S.GU[lane][rr * 3 + 0] = Dinv[rr * 3 + 0] * v00 + Dinv[rr * 3 + 1] * v10;
+        S.GU[lane][rr * 3 + 1] = Dinv[rr * 3 + 1] * v11;
+        S.GU[lane][rr * 3 + 2] = Dinv[rr * 3 + 2] * v22;
+      }
+      for (int k = 0; k < 9; k++) { S.Dinv[lane][k] = Dinv[k]; S.LD[lane][k] = LDm[k]; }
+    }
   }
-  __syncthreads();
+  PL_SYNC();
   // 4. border vector for modes whose control row is not "I = value":  x2 = T^-1 (column of I)
   if (mode != PLH_MODE_I) {
-    double y[3] = {0, 0, 0};
-#pragma unroll 1
-    for (int i = 0; i < NE; i++) {     // rhs: JI0 in the Phi_s slot of node 0, JI29 in node 29
-      const double b2 = (i == 0) ? c.JI0 : ((i == NE - 1) ? c.JI29 : 0.0);
-      const double* L = S.LD[i];
-      const double n0 = -(L[0] * y[0] + L[1] * y[1] + L[2] * y[2]);
-      const double n1 = -(L[3] * y[0] + L[4] * y[1] + L[5] * y[2]);
-      const double n2 = b2 - (L[6] * y[0] + L[7] * y[1] + L[8] * y[2]);
-      y[0] = n0; y[1] = n1; y[2] = n2;
-      if (lane == 0) { S.y3[i][0] = n0; S.y3[i][1] = n1; S.y3[i][2] = n2; }
-    }
-    __syncthreads();
-    double x[3] = {0, 0, 0};
-#pragma unroll 1
-    for (int i = NE - 1; i >= 0; i--) {
-      double t0 = S.y3[i][0], t1 = S.y3[i][1], t2 = S.y3[i][2];
-      if (i < NE - 1) {
-        const int sci = sec_of(i), scn = sec_of(i + 1);
-        const double u00 = alg_only ? 0.0 : S.ceU[i], u10 = alg_only ? 0.0 : S.pcU[i], u11 = S.peU[i];
-        const double u22 = (sci != 1 && scn == sci) ? 1.0 : 0.0;
-        t0 -= u00 * x[0]; t1 -= u10 * x[0] + u11 * x[1]; t2 -= u22 * x[2];
-      }
-      const double* Di = S.Dinv[i];
-      x[0] = Di[0] * t0 + Di[1] * t1 + Di[2] * t2;
-      x[1] = Di[3] * t0 + Di[4] * t1 + Di[5] * t2;
-      x[2] = Di[6] * t0 + Di[7] * t1 + Di[8] * t2;
-      if (lane == 0) { S.x2[i][0] = x[0]; S.x2[i][1] = x[1]; S.x2[i][2] = x[2]; }
-    }
-    __syncthreads();
+    double r0 = 0.0, r1 = 0.0, r2 = lane == 0 ? c.JI0 : (lane == NE - 1 ? c.JI29 : 0.0);
+    thomas_sweeps(S, r0, r1, r2);
+    if (lane < NE) { S.x2[lane][0] = r0; S.x2[lane][1] = r1; S.x2[lane][2] = r2; }
+    PL_SYNC();
   }
 }
 
@@ -500,23 +567,25 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const int r = lane % NR, g = lane / NR;
-  // a. particle partial solutions  w = A^-1 b_cs
+  // a. particle partial solutions  w = A^-1 b_cs   (pass 0: particles 0-5 cathode; pass 1: 6-11 mixed; passes 2,3: anode)
   if (!alg_only) {
+#pragma unroll
     for (int pass = 0; pass < 4; pass++) {
       const int p = pass * 6 + g;
       double w = 0.0;
       if (lane < 60 && p < NJ) {
         const double* bc = b + O_CS + p * NR;
-        const bool isp = p < NP;
-        for (int k = 0; k < NR; k++) w += (isp ? R.AinvP[k] : R.AinvN[k]) * bc[k];
+        if (pass == 0) { for (int k = 0; k < NR; k++) w += R.AinvP[k] * bc[k]; }
+        else if (pass >= 2) { for (int k = 0; k < NR; k++) w += R.AinvN[k] * bc[k]; }
+        else { const bool isp = p < NP; for (int k = 0; k < NR; k++) w += (isp ? R.AinvP[k] : R.AinvN[k]) * bc[k]; }
         if (r == NR - 1) S.w9[p] = w;
       }
       R.wreg[pass] = w;
     }
   }
-  __syncthreads();
+  PL_SYNC();
   // b. fold c_s and j elimination into the node right-hand sides
-  double bjp = 0.0;
+  double bjp = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0;
   int jx = 0; bool elec = false;
   if (lane < NE) {
     const int i = lane, sc = sec_of(i);
@@ -532,49 +601,21 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
         if (i == NE - 1) r2 -= c.JI29 * b[O_I];
       }
     }
-    S.rhs3[i][0] = r0; S.rhs3[i][1] = r1; S.rhs3[i][2] = r2;
+    m0 = r0; m1 = r1; m2 = r2;
   }
-  __syncthreads();
-  // c. block-Thomas forward / backward, redundantly on every lane; lane i keeps node i's solution
-  double y[3] = {0, 0, 0};
-#pragma unroll 2
-  for (int i = 0; i < NE; i++) {
-    const double* L = S.LD[i];
-    const double n0 = S.rhs3[i][0] - (L[0] * y[0] + L[1] * y[1] + L[2] * y[2]);
-    const double n1 = S.rhs3[i][1] - (L[3] * y[0] + L[4] * y[1] + L[5] * y[2]);
-    const double n2 = S.rhs3[i][2] - (L[6] * y[0] + L[7] * y[1] + L[8] * y[2]);
-    y[0] = n0; y[1] = n1; y[2] = n2;
-    if (lane == 0) { S.y3[i][0] = n0; S.y3[i][1] = n1; S.y3[i][2] = n2; }
-  }
-  __syncthreads();
-  double x[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
-  double xs0 = 0, xs29 = 0;
-#pragma unroll 2
-  for (int i = NE - 1; i >= 0; i--) {
-    double t0 = S.y3[i][0], t1 = S.y3[i][1], t2 = S.y3[i][2];
-    if (i < NE - 1) {
-      const int sci = sec_of(i), scn = sec_of(i + 1);
-      const double u00 = alg_only ? 0.0 : S.ceU[i], u10 = alg_only ? 0.0 : S.pcU[i], u11 = S.peU[i];
-      const double u22 = (sci != 1 && scn == sci) ? 1.0 : 0.0;
-      t0 -= u00 * x[0]; t1 -= u10 * x[0] + u11 * x[1]; t2 -= u22 * x[2];
-    }
-    const double* Di = S.Dinv[i];
-    x[0] = Di[0] * t0 + Di[1] * t1 + Di[2] * t2;
-    x[1] = Di[3] * t0 + Di[4] * t1 + Di[5] * t2;
-    x[2] = Di[6] * t0 + Di[7] * t1 + Di[8] * t2;
-    if (i == lane) { mx[0] = x[0]; mx[1] = x[1]; mx[2] = x[2]; }
-    if (i == NE - 1) xs29 = x[2];
-    if (i == 0) xs0 = x[2];
-  }
+  // c. block-Thomas forward / backward substitution (systolic, registers + DPP)
+  thomas_sweeps(S, m0, m1, m2);
+  double mx[3] = {m0, m1, m2};
   // d. border: control row couples Phi_s[first] - Phi_s[last] (voltage mode)
   double xI;
   if (mode == PLH_MODE_I) xI = b[O_I];
   else {
+    const double xs0 = lane_bcast(m2, 0), xs29 = lane_bcast(m2, NE - 1);
     const double d2 = S.x2[0][2] - S.x2[NE - 1][2];
     xI = ((xs0 - xs29) - b[O_I]) / d2;
     if (lane < NE) { mx[0] -= xI * S.x2[lane][0]; mx[1] -= xI * S.x2[lane][1]; mx[2] -= xI * S.x2[lane][2]; }
   }
-  __syncthreads();
+  PL_SYNC();
   // e. back-substitute j, write node unknowns
   if (lane < NE) {
     const int i = lane;
@@ -587,7 +628,7 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
     }
   }
   if (lane == 0) b[O_I] = xI;
-  __syncthreads();
+  PL_SYNC();
   // f. particles:  dc = w - (A^-1 e_last) * bj * dj
   if (!alg_only) {
     for (int pass = 0; pass < 4; pass++) {
@@ -599,7 +640,7 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
       }
     }
   }
-  __syncthreads();
+  PL_SYNC();
 }
 
 

@@ -26,7 +26,9 @@ enum Cnt { C_STEPS, C_RES, C_JAC, C_FACT, C_SOLVE, C_NEWTON, C_ERRFAIL, C_CONVFA
 struct Counters { CellLDS* S; };
 __device__ __forceinline__ void cnt_add(Counters& c, int k, long long v = 1) { if (lane_id() == 0) c.S->cnt[k] += v; }
 
-#define PL_VEC(n) for (int n = lane; n < NST; n += WAVE)
+// lane-strided sweep over the N state entries: exactly 5 trips (301 = 4*64 + 45), fully unrolled so that the LDS loads of all
+// trips are issued back to back (one latency instead of five); only the last trip is predicated.
+#define PL_VEC(n) _Pragma("unroll") for (int k__ = 0, n = lane; k__ < (NST + WAVE - 1) / WAVE; k__++, n += WAVE) if (k__ < NST / WAVE || n < NST)
 
 __device__ __forceinline__ double wrms(const double* v, const double* w) {
   const int lane = lane_id();
@@ -40,18 +42,18 @@ __device__ inline int cell_init_consistent(CellLDS& S, LaneRegs& R, const Tables
                                            int mode, double value, double reltol_init, Counters& cnt) {
   const int lane = lane_id();
   PL_VEC(n) YP[n] = 0.0;
-  __syncthreads();
+  PL_SYNC();
   int ok = 0;
   for (int iter = 1; iter <= 100; iter++) {
     cell_node_pass<true, true>(S, Y, YP, res, mode, value);      // R_alg + J_alg partials (differential rows ignored)
-    __syncthreads();
+    PL_SYNC();
     cell_factor(S, R, tb, 0.0, mode, true);
     cell_solve(S, R, res, mode, true);
     cnt_add(cnt, C_RES); cnt_add(cnt, C_JAC); cnt_add(cnt, C_FACT); cnt_add(cnt, C_SOLVE); cnt_add(cnt, C_INIT);
     double s = 0.0;
     for (int n = NDIFF + lane; n < NST; n += WAVE) { const double d = res[n]; Y[n] -= d; s += d * d; }
     const double nrm = sqrt(wave_sum(s));
-    __syncthreads();
+    PL_SYNC();
     if (nrm < reltol_init) { ok = 1; break; }
     if (!(nrm == nrm)) break;
   }
@@ -60,20 +62,20 @@ __device__ inline int cell_init_consistent(CellLDS& S, LaneRegs& R, const Tables
   cell_residual(S, R, Y, YP, res, mode, value);
   cnt_add(cnt, C_RES);
   for (int n = lane; n < NDIFF; n += WAVE) YP[n] = res[n];
-  __syncthreads();
+  PL_SYNC();
   // finite-difference estimate of the algebraic derivatives (model_evaluation.jl:462-477)
   const double ce0 = S.cc.ce0;
   const double epsce = nextafter(ce0, 1e300) - ce0;
   double dt = sqrt(epsce);
   if (10.0 * reltol_init > dt) dt = 10.0 * reltol_init;
   PL_VEC(n) Ytmp[n] = Y[n] + dt * YP[n];
-  __syncthreads();
+  PL_SYNC();
   cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
-  __syncthreads();
+  PL_SYNC();
   cell_solve(S, R, res, mode, true);
   cnt_add(cnt, C_RES); cnt_add(cnt, C_SOLVE);
   for (int n = NDIFF + lane; n < NST; n += WAVE) YP[n] = -res[n] / dt;
-  __syncthreads();
+  PL_SYNC();
   return 0;
 }
 
@@ -84,13 +86,13 @@ __device__ inline void ida_reinit(CellLDS& S, IdaScalars& I, const double* y0, c
   I.cjratio = 1.0; I.ss = 20.0; I.phase = 0; I.ns = 0; I.h0_forced = 0.0; I.cj = 0.0; I.cjlast = 0.0; I.cjold = 0.0; I.rr = 0.0; I.knew = 0;
   if (lane <= MAXORD) { S.ida_psi[lane] = 0; S.ida_alpha[lane] = 0; S.ida_beta[lane] = 0; S.ida_sigma[lane] = 0; S.ida_gamma[lane] = 0; }
   PL_VEC(n) { S.phi[0][n] = y0[n]; S.phi[1][n] = yp0[n]; }
-  __syncthreads();
+  PL_SYNC();
 }
 
 __device__ inline void set_ewt(CellLDS& S, double rtol, double atol) {
   const int lane = lane_id();
   PL_VEC(n) S.ewt[n] = 1.0 / (rtol * fabs(S.phi[0][n]) + atol);
-  __syncthreads();
+  PL_SYNC();
 }
 
 __device__ inline double ida_set_coeffs(CellLDS& S, IdaScalars& I) {
@@ -112,12 +114,12 @@ __device__ inline double ida_set_coeffs(CellLDS& S, IdaScalars& I) {
     double ck = fabs(S.ida_alpha[kk] + alphas - alpha0); if (ck < S.ida_alpha[kk]) ck = S.ida_alpha[kk];
     S.ida_out[0] = -alphas / hh; S.ida_out[1] = ck;
   }
-  __syncthreads();
+  PL_SYNC();
   I.cjlast = I.cj; I.cj = S.ida_out[0];
   const double ck = S.ida_out[1];
   for (int i = I.ns; i <= kk; i++) { const double b = S.ida_beta[i]; PL_VEC(n) S.phi[i][n] *= b; }
   I.tn += hh;
-  __syncthreads();
+  PL_SYNC();
   return ck;
 }
 
@@ -130,7 +132,7 @@ __device__ inline void form_iterate(CellLDS& S, const IdaScalars& I) {
     const double e = S.ee[n];
     S.yy[n] = a + e; S.yp[n] = b + I.cj * e;
   }
-  __syncthreads();
+  PL_SYNC();
 }
 
 // IDANls + Newton + convergence test.  0 ok, 1 recoverable failure
@@ -147,45 +149,52 @@ __device__ inline int ida_nls(CellLDS& S, LaneRegs& R, const Tables* tb, IdaScal
     if (jac_every_step) callLSetup = 1;
   }
   PL_VEC(n) S.ee[n] = 0.0;
-  __syncthreads();
+  PL_SYNC();
   int jcur = 0, ret = 0;
   for (;;) {
-    form_iterate(S, I);
+    { PL_TIC(); form_iterate(S, I); PL_TOC(S, PH_NEWTVEC); }
     if (callLSetup) {
+      PL_TIC();
       cell_node_pass<true, true>(S, S.yy, S.yp, S.delta, mode, value);
       cell_cs_rows(S, R, S.yy, S.yp, S.delta);
-      __syncthreads();
+      PL_SYNC();
       cell_factor(S, R, tb, I.cj, mode, false);
       cnt_add(cnt, C_RES); cnt_add(cnt, C_JAC); cnt_add(cnt, C_FACT);
       I.cjold = I.cj; I.cjratio = 1.0; I.ss = 20.0; jcur = 1;
+      PL_TOC(S, PH_JACFACT);
     } else {
+      PL_TIC();
       cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
       cnt_add(cnt, C_RES);
+      PL_TOC(S, PH_RES);
     }
     int m = 0; double oldnrm = 0.0;
     for (;;) {
       cnt_add(cnt, C_NEWTON); cnt_add(cnt, C_SOLVE);
+      { PL_TIC();
       PL_VEC(n) S.delta[n] = -S.delta[n];
-      __syncthreads();
+      PL_SYNC();
       cell_solve(S, R, S.delta, mode, false);
+      PL_TOC(S, PH_SOLVE); }
+      PL_TIC();
       const double sc = (I.cjratio != 1.0) ? 2.0 / (1.0 + I.cjratio) : 1.0;
       double s = 0.0;
       PL_VEC(n) { const double d = S.delta[n] * sc; S.ee[n] += d; const double p = d * S.ewt[n]; s += p * p; }
       const double delnrm = sqrt(wave_sum(s) / NST);
-      __syncthreads();
+      PL_SYNC();
       ret = 2;
       if (m == 0) { oldnrm = delnrm; if (delnrm <= toldel) ret = 0; }
       else { const double rate = pow(delnrm / oldnrm, 1.0 / m); if (rate > 0.9) ret = 1; else I.ss = rate / (1.0 - rate); }
       if (ret == 2 && I.ss * delnrm <= epsNewt) ret = 0;
       if (!(delnrm == delnrm)) ret = 1;
+      PL_TOC(S, PH_NEWTVEC);
       if (ret == 0) { jcur = 0; break; }
       if (ret != 2) break;
       m++; if (m >= 4) { ret = 1; break; }
-      form_iterate(S, I);
-      cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
-      cnt_add(cnt, C_RES);
+      { PL_TIC(); form_iterate(S, I); PL_TOC(S, PH_NEWTVEC); }
+      { PL_TIC(); cell_residual(S, R, S.yy, S.yp, S.delta, mode, value); cnt_add(cnt, C_RES); PL_TOC(S, PH_RES); }
     }
-    if (ret > 0 && !jcur) { callLSetup = 1; PL_VEC(n) S.ee[n] = 0.0; __syncthreads(); continue; }
+    if (ret > 0 && !jcur) { callLSetup = 1; PL_VEC(n) S.ee[n] = 0.0; PL_SYNC(); continue; }
     break;
   }
   form_iterate(S, I);
@@ -220,7 +229,7 @@ __device__ inline void ida_restore(CellLDS& S, IdaScalars& I, double saved_t) {
   I.tn = saved_t;
   if (lane == 0) for (int j = 1; j <= I.kk; j++) S.ida_psi[j - 1] = S.ida_psi[j] - I.hh;
   if (I.ns <= I.kk) for (int j = I.ns; j <= I.kk; j++) { const double b = 1.0 / S.ida_beta[j]; PL_VEC(n) S.phi[j][n] *= b; }
-  __syncthreads();
+  PL_SYNC();
 }
 
 __device__ inline void ida_complete_step(CellLDS& S, IdaScalars& I, double err_k, double err_km1) {
@@ -257,7 +266,7 @@ __device__ inline void ida_complete_step(CellLDS& S, IdaScalars& I, double err_k
     double acc = S.phi[ku][n] + e; S.phi[ku][n] = acc;
     for (int j = ku - 1; j >= 0; j--) { acc += S.phi[j][n]; S.phi[j][n] = acc; }
   }
-  __syncthreads();
+  PL_SYNC();
 }
 
 // IDAGetSolution(t): y -> yo, y' -> ypo (LDS vectors)
@@ -279,7 +288,7 @@ __device__ inline void ida_get_solution(CellLDS& S, const IdaScalars& I, double 
     if (kord >= 5) { s += c5 * p5; sp += d4 * p5; }
     yo[n] = s; ypo[n] = sp;
   }
-  __syncthreads();
+  PL_SYNC();
 }
 
 // one IDASolve(ONE_STEP_TSTOP) call: advances, returns y(tret), y'(tret) in S.yy / S.yp.  0 ok, <0 failure
@@ -299,7 +308,7 @@ __device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaSca
     if ((I.tn + hh - tstop) * hh > 0.0) hh = (tstop - I.tn) * (1.0 - 4.0 * uround);
     I.hh = hh; I.kk = 0; I.kused = 0;
     PL_VEC(n) S.phi[1][n] *= hh;
-    __syncthreads();
+    PL_SYNC();
   } else {
     const double troundoff = 100.0 * uround * (fabs(I.tn) + fabs(I.hh));
     if (fabs(I.tn - tstop) <= troundoff) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; return 0; }
@@ -307,12 +316,12 @@ __device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaSca
     set_ewt(S, o.reltol, o.abstol);
   }
   const double saved_t = I.tn; int ncf = 0, nef = 0; double err_k = 0, err_km1 = 0;
-  if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; __syncthreads(); }
+  if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; PL_SYNC(); }
   for (;;) {
-    const double ck = ida_set_coeffs(S, I);
+    double ck; { PL_TIC(); ck = ida_set_coeffs(S, I); PL_TOC(S, PH_STEPCTL); }
     const int nflag = ida_nls(S, R, tb, I, mode, value, o.jac_every_step, cnt);
     int errfail = 0;
-    if (nflag == 0) errfail = ida_test_error(S, I, ck, err_k, err_km1);
+    if (nflag == 0) { PL_TIC(); errfail = ida_test_error(S, I, ck, err_k, err_km1); PL_TOC(S, PH_STEPCTL); }
     if (nflag != 0 || errfail) {
       ida_restore(S, I, saved_t);
       I.phase = 1;
@@ -330,17 +339,19 @@ __device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaSca
       }
       const double tscale = fabs(I.tn) > 1.0 ? fabs(I.tn) : 1.0;
       if (fabs(I.hh) < 1e-14 * tscale) return PLH_ERR_STALL;
-      if (I.nst == 0) { if (lane == 0) S.ida_psi[0] = I.hh; const double rr = I.rr; PL_VEC(n) S.phi[1][n] *= rr; __syncthreads(); }
+      if (I.nst == 0) { if (lane == 0) S.ida_psi[0] = I.hh; const double rr = I.rr; PL_VEC(n) S.phi[1][n] *= rr; PL_SYNC(); }
       continue;
     }
     break;
   }
   cnt_add(cnt, C_STEPS); cnt_add(cnt, C_SUMKP2, I.kk + 2);
+  PL_TIC();
   ida_complete_step(S, I, err_k, err_km1);
   const double troundoff = 100.0 * uround * (fabs(I.tn) + fabs(I.hh));
-  if (fabs(I.tn - tstop) <= troundoff) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; return 0; }
+  if (fabs(I.tn - tstop) <= troundoff) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; PL_TOC(S, PH_STEPCTL); return 0; }
   if ((I.tn + I.hh - tstop) * I.hh > 0.0) I.hh = (tstop - I.tn) * (1.0 - 4.0 * uround);
   ida_get_solution(S, I, I.tn, S.yy, S.yp); tret = I.tn;
+  PL_TOC(S, PH_STEPCTL);
   return 0;
 }
 
@@ -409,7 +420,7 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
   const double T0 = S.cc.T0;
   if (Yinit) {                                                          // simulate!(sol, ...): continue from sol.Y[end]
     PL_VEC(n) S.yy[n] = Yinit[n];
-    __syncthreads();
+    PL_SYNC();
     have_prev = true; t_global = t_init; prev_V = cellV(S.yy); prev_I = S.yy[O_I];
   }
   auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
@@ -440,11 +451,11 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
       else if (have_prev && prev_I != 0.0) Iguess = prev_I;
       else { const double OCV = cellV(S.yy); Iguess = value > OCV ? 1.0 : -1.0; }
     }
-    __syncthreads();
+    PL_SYNC();
     if (lane == 0) S.yy[O_I] = Iguess;
-    __syncthreads();
+    PL_SYNC();
     int flag = PLH_FLAG_RUNNING;
-    int ierr = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, o.reltol_init, cnt);
+    int ierr; { PL_TIC(); ierr = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, o.reltol_init, cnt); PL_TOC(S, PH_INIT); }
     plh_run_info ri; ri.flag = PLH_FLAG_RUNNING; ri.iterations = 0; ri.t_end = t_global; ri.V = 0; ri.I = 0; ri.SOC = SOC; ri.T_avg = T0;
     if (ierr != 0) { ri.flag = ierr; if (lane == 0) info[r] = ri; for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; info[q] = z; } break; }
     ida_reinit(S, I, S.yy, S.yp, o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD);
@@ -455,7 +466,7 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
     save_pt(nout, t0, S.yy, SOC); nout++;
     check_stop(S, run, o, 0.0, run.tf, S.yy, S.yp, SOC, pv, flag);
     PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
-    __syncthreads();
+    PL_SYNC();
     double tprev = 0.0, t = 0.0, t_prev_saved = t0; int iter = 1; bool stalled_once = false;
     double I_prev_pt = S.yy[O_I];
     while (flag == PLH_FLAG_RUNNING) {
@@ -466,13 +477,14 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
         if (I.nst == 0 && !stalled_once) {                              // check_solve, checks.jl:227-237
           stalled_once = true;
           PL_VEC(n) { S.yy[n] = Yprev[n]; S.yp[n] = YPprev[n]; }
-          __syncthreads();
+          PL_SYNC();
           ida_reinit(S, I, S.yy, S.yp, I.maxord); I.h0_forced = o.reltol; iter++; t = tprev; continue;
         }
         flag = sf; break;
       }
       if (tret >= tstop_now && its + 1 < nts) its++;
       iter++; t = tret;
+      PL_TIC();
       const double SOC_new = SOC + 0.5 * ((t + t0) - t_prev_saved) * (S.yy[O_I] + I_prev_pt) / 3600.0;   // calc_SOC, scalar_residual.jl:103-111
       SOC = SOC_new;
       save_pt(nout, t + t0, S.yy, SOC); nout++;
@@ -481,19 +493,18 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
       if (iter == o.maxiters) { flag = PLH_ERR_MAXITERS; break; }
       if (nout >= out.max_pts && out.max_pts > 0 && flag == PLH_FLAG_RUNNING) { flag = PLH_ERR_OUTPUT_FULL; break; }
       if (flag == PLH_FLAG_RUNNING) {
-        __syncthreads();
-        PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
-        __syncthreads();
+        PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }      // fire-and-forget: read back only when a bound fires
         t_prev_saved = t + t0; I_prev_pt = S.yy[O_I];
       }
+      PL_TOC(S, PH_OUTPUT);
     }
     double t_end = t + t0;
     if (flag > 0 && o.interp_final && t > 1.0) {                        // interp_final_points!, model_evaluation.jl:369-382
       const double fr = pv.frac;
       const double ti = fr * (t - tprev) + tprev;
-      __syncthreads();
+      PL_SYNC();
       PL_VEC(n) { S.yy[n] = fr * (S.yy[n] - Yprev[n]) + Yprev[n]; S.yp[n] = fr * (S.yp[n] - YPprev[n]) + YPprev[n]; }
-      __syncthreads();
+      PL_SYNC();
       SOC = SOC + 0.5 * ((ti + t0) - (t + t0)) * (S.yy[O_I] + S.yy[O_I]) / 3600.0;
       t_end = ti + t0;
       save_pt(nout - 1, t_end, S.yy, SOC);
@@ -502,10 +513,10 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
     if (lane == 0) info[r] = ri;
     t_global = t_end; have_prev = true; prev_V = ri.V; prev_I = ri.I;
     if (flag < 0) { for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; z.iterations = 0; info[q] = z; } break; }
-    __syncthreads();
+    PL_SYNC();
   }
   if (lane == 0 && n_pts_out) *n_pts_out = nout < out.max_pts ? nout : out.max_pts;
-  __syncthreads();
+  PL_SYNC();
   if (Yfin) PL_VEC(n) Yfin[n] = S.yy[n];
   if (YPfin) PL_VEC(n) YPfin[n] = S.yp[n];
 }

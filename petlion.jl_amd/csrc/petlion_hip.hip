@@ -24,11 +24,11 @@ using namespace pl;
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_vec(double* dst, const double* __restrict__ src) {
   const int lane = lane_id();
-  for (int n = lane; n < NST; n += WAVE) dst[n] = src[n];
+  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < (NST + WAVE - 1) / WAVE; k__++, n += WAVE) if (n < NST) dst[n] = src[n];
 }
 __device__ __forceinline__ void store_vec(double* __restrict__ dst, const double* src) {
   const int lane = lane_id();
-  for (int n = lane; n < NST; n += WAVE) dst[n] = src[n];
+  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < (NST + WAVE - 1) / WAVE; k__++, n += WAVE) if (n < NST) dst[n] = src[n];
 }
 
 __global__ __launch_bounds__(64) void k_initial_guess(const Tables* tb, int n_cells, const double* theta, const double* SOC, double* Y) {
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void k_residual(const Tables* tb, int n_cells, 
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec(S.yy, Y + (size_t)cell * NST); load_vec(S.yp, YP + (size_t)cell * NST);
-  __syncthreads();
+  PL_SYNC();
   cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
   store_vec(F + (size_t)cell * NST, S.delta);
 }
@@ -62,9 +62,9 @@ __global__ __launch_bounds__(64) void k_jacobian(const Tables* tb, int n_cells, 
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec(S.yy, Y + (size_t)cell * NST); load_vec(S.yp, YP + (size_t)cell * NST);
-  __syncthreads();
+  PL_SYNC();
   cell_node_pass<false, true>(S, S.yy, S.yp, S.delta, mode, 0.0);
-  __syncthreads();
+  PL_SYNC();
   const int nnz = tb->nnz[mode];
   const unsigned* code = tb->csc_code[mode];
   double* out = nz + (size_t)cell * nnz;
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(64) void k_linear_solve(const Tables* tb, int n_cel
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec(S.yy, Y + (size_t)cell * NST); load_vec(S.yp, YP + (size_t)cell * NST); load_vec(S.delta, b + (size_t)cell * NST);
-  __syncthreads();
+  PL_SYNC();
   cell_node_pass<false, true>(S, S.yy, S.yp, S.ee, mode, 0.0);
-  __syncthreads();
+  PL_SYNC();
   cell_factor(S, R, tb, cj, mode, false);
   cell_solve(S, R, S.delta, mode, false);
   store_vec(b + (size_t)cell * NST, S.delta);
@@ -95,12 +95,12 @@ __global__ __launch_bounds__(64) void k_init_consistent(const Tables* tb, int n_
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec(S.yy, Y + (size_t)cell * NST);
-  __syncthreads();
+  PL_SYNC();
   Counters cnt; cnt.S = &S; if (lane_id() < 10) S.cnt[lane_id()] = 0;
-  __syncthreads();
+  PL_SYNC();
   const int rc = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, reltol_init, cnt);
   store_vec(Y + (size_t)cell * NST, S.yy); store_vec(YP + (size_t)cell * NST, S.yp);
-  __syncthreads();
+  PL_SYNC();
   if (lane_id() == 0) { if (status) status[cell] = rc; if (iters) iters[cell] = (int)S.cnt[C_INIT]; }
 }
 
@@ -116,7 +116,9 @@ __global__ __launch_bounds__(64) void k_integrate(IntegrateArgs a) {
   if (cell >= a.n_cells) return;
   cell_setup(S, R, a.tb, a.theta + (size_t)cell * a.tb->P);
   Counters cnt; cnt.S = &S; if (lane_id() < 10) S.cnt[lane_id()] = 0;
-  __syncthreads();
+  if (lane_id() < 8) S.cyc[lane_id()] = 0;
+  PL_SYNC();
+  PL_TIC();
   CellOut co;
   const size_t off = (size_t)cell * a.out.max_pts;
   co.max_pts = a.out.max_pts;
@@ -126,8 +128,11 @@ __global__ __launch_bounds__(64) void k_integrate(IntegrateArgs a) {
                 a.out.run_info + (size_t)cell * a.n_runs, cnt,
                 a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
                 a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST);
+  PL_TOC(S, PH_TOTAL);
+  PL_SYNC();
   if (lane_id() == 0 && a.out.counters) {
     plh_counters* c = a.out.counters + cell;
+    for (int k = 0; k < 8; k++) c->cyc[k] = S.cyc[k];
     c->n_steps = S.cnt[C_STEPS]; c->n_res = S.cnt[C_RES]; c->n_jac = S.cnt[C_JAC]; c->n_fact = S.cnt[C_FACT]; c->n_solve = S.cnt[C_SOLVE];
     c->n_newton = S.cnt[C_NEWTON]; c->n_errfail = S.cnt[C_ERRFAIL]; c->n_convfail = S.cnt[C_CONVFAIL]; c->sum_kp2 = S.cnt[C_SUMKP2]; c->n_init_iters = S.cnt[C_INIT];
   }
