@@ -25,7 +25,7 @@ constexpr int WAVE = 64;
 constexpr int NP = 10, NS = 10, NN = 10, NR = 10, NE = NP + NS + NN, NJ = NP + NN;
 constexpr int O_CE = 0, O_CS = NE, O_J = O_CS + NJ * NR, O_PE = O_J + NJ, O_PS = O_PE + NE, O_I = O_PS + NJ;
 constexpr int NST = O_I + 1, NDIFF = O_J, NALG = NST - NDIFF;
-constexpr int NPAD = 304;
+constexpr int NPAD = 302;
 constexpr int MAXORD = 5;
 constexpr double FAR = 96485.3321233;      // reference src/structures.jl:10
 constexpr double RGAS = 8.31446261815324;  // reference src/structures.jl:11
@@ -65,7 +65,9 @@ struct CellLDS {
   double gce[NJ], gcs[NJ], gpe[NJ], gps[NJ], psJ[NJ];
   // eliminated system
   double dj[NJ], fS[NE], fP[NE], fQ[NE];
-  double Dinv[NE][9], LD[NE][9], GU[NE][9];   // Thomas factors: D'^-1, L D'^-1(prev), D'^-1 U
+  double Dinv[NE][9], LD[NE][9];   // Thomas factors: D'^-1 and L D'^-1(prev)
+  double Ainv[2][NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
+  double Mr[NR * NR];               // radial operator (copy of Tables::M)
   double x2[NE][3];
   double w9[NJ];
   double sig[2];
@@ -80,8 +82,6 @@ struct CellLDS {
 
 // per-lane registers that persist across phases
 struct LaneRegs {
-  double Mrow[NR];      // row (lane % 10) of the radial operator
-  double AinvP[NR], AinvN[NR];   // row (lane % 10) of (kappa M - cj I)^-1 for the p / n electrode
   double wreg[4];       // particle partial solutions kept across the Thomas phase
 };
 
@@ -247,9 +247,7 @@ __device__ inline void cell_setup(CellLDS& S, LaneRegs& R, const Tables* __restr
     c.ce0 = th[ix[K_c_e0]];
     S.kapv[0] = c.kap_p; S.kapv[1] = c.kap_n;
   }
-  const int r = lane % NR;
-  for (int k = 0; k < NR; k++) R.Mrow[k] = tb->M[r * NR + k];
-  for (int k = 0; k < NR; k++) { R.AinvP[k] = 0.0; R.AinvN[k] = 0.0; }
+  for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->M[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; }
   for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
   PL_SYNC();
 }
@@ -395,7 +393,8 @@ __device__ inline void cell_cs_rows(CellLDS& S, const LaneRegs& R, const double*
     if (lane < 60 && p < NJ) {
       const double* cs = Y + O_CS + p * NR;
       double acc = 0.0;
-      for (int k = 0; k < NR; k++) acc += R.Mrow[k] * cs[k];
+      const double* Mrow = S.Mr + r * NR;
+      for (int k = 0; k < NR; k++) acc += Mrow[k] * cs[k];
       const double kap = p < NP ? c.kap_p : c.kap_n;
       double rhs = kap * acc;
       if (r == NR - 1) rhs += (p < NP ? c.bj_p : c.bj_n) * Y[O_J + p];
@@ -447,11 +446,21 @@ __device__ __forceinline__ void node_block(const CellLDS& S, int i, double cj, b
 // lane -> lane-1 (backward) through DPP shifts.  Every lane re-evaluates its own recurrence at every stage: a lane whose
 // predecessor is final reproduces its final value (the update is idempotent), so no per-stage select is needed; lane 0 (LD = 0)
 // and lane NE-1 (GU = 0) are final from the start and the wavefront advances one lane per stage.
-__device__ __forceinline__ void thomas_sweeps(const CellLDS& S, double& r0, double& r1, double& r2) {
+__device__ __forceinline__ void thomas_sweeps(const CellLDS& S, bool alg_only, double& r0, double& r1, double& r2) {
   const int lane = lane_id();
   const int i = lane < NE ? lane : NE - 1;
-  double L[9], G[9];
-  for (int k = 0; k < 9; k++) { L[k] = S.LD[i][k]; G[k] = S.GU[i][k]; }
+  double L[9], Di[9], G[9];
+  for (int k = 0; k < 9; k++) { L[k] = S.LD[i][k]; Di[k] = S.Dinv[i][k]; }
+  {   // G = Dinv U_i with U_i = [[ceU,0,0],[pcU,peU,0],[0,0,psU]] (zero for the last node; c_e couplings absent in the algebraic block)
+    const int sci = sec_of(i), scn = sec_of(i < NE - 1 ? i + 1 : NE - 1);
+    const double v00 = (alg_only || i == NE - 1) ? 0.0 : S.ceU[i], v10 = (alg_only || i == NE - 1) ? 0.0 : S.pcU[i], v11 = i == NE - 1 ? 0.0 : S.peU[i];
+    const double v22 = (i < NE - 1 && sci != 1 && scn == sci) ? 1.0 : 0.0;
+    for (int rr = 0; rr < 3; rr++) {
+      G[rr * 3 + 0] = Di[rr * 3 + 0] * v00 + Di[rr * 3 + 1] * v10;
+      G[rr * 3 + 1] = Di[rr * 3 + 1] * v11;
+      G[rr * 3 + 2] = Di[rr * 3 + 2] * v22;
+    }
+  }
   double y0 = r0, y1 = r1, y2 = r2;
 #pragma unroll 4
   for (int it = 1; it < NE; it++) {
@@ -461,7 +470,6 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS& S, double& r0, doub
     y2 = r2 - (L[6] * p0 + L[7] * p1 + L[8] * p2);
   }
   // backward: x_i = z_i - G_i x_{i+1},  z = Dinv y,  G = Dinv U
-  const double* Di = S.Dinv[i];
   const double z0 = Di[0] * y0 + Di[1] * y1 + Di[2] * y2, z1 = Di[3] * y0 + Di[4] * y1 + Di[5] * y2, z2 = Di[6] * y0 + Di[7] * y1 + Di[8] * y2;
   double x0 = z0, x1 = z1, x2 = z2;
 #pragma unroll 4
@@ -490,7 +498,7 @@ __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __rest
         const double f = tb->V[r * NR + m] / (kap * tb->LAM[m] - cj);
         for (int k = 0; k < NR; k++) acc[k] += f * tb->W[m * NR + k];
       }
-      for (int k = 0; k < NR; k++) { if (el == 0) R.AinvP[k] = acc[k]; else R.AinvN[k] = acc[k]; }
+      if (lane < NR) for (int k = 0; k < NR; k++) S.Ainv[el][r * NR + k] = acc[k];
       if (lane == NR - 1) S.sig[el] = acc[NR - 1];
     }
   }
@@ -540,15 +548,6 @@ __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __rest
       for (int k = 0; k < 9; k++) { Dinv[k] = me ? Dni[k] : Dinv[k]; LDm[k] = me ? Ln[k] : LDm[k]; }
     }
     if (lane < NE) {
-      // G = Dinv U_i with U_i = [[ceU,0,0],[pcU,peU,0],[0,0,psU]] (zero for the last node)
-      const int scn = sec_of(i < NE - 1 ? i + 1 : NE - 1);
-      const double v00 = (alg_only || i == NE - 1) ? 0.0 : S.ceU[i], v10 = (alg_only || i == NE - 1) ? 0.0 : S.pcU[i], v11 = i == NE - 1 ? 0.0 : S.peU[i];
-      const double v22 = (i < NE - 1 && sci != 1 && scn == sci) ? 1.0 : 0.0;
-      for (int rr = 0; rr < 3; rr++) {
-        S.GU[lane][rr * 3 + 0] = Dinv[rr * 3 + 0] * v00 + Dinv[rr * 3 + 1] * v10;
-        S.GU[lane][rr * 3 + 1] = Dinv[rr * 3 + 1] * v11;
-        S.GU[lane][rr * 3 + 2] = Dinv[rr * 3 + 2] * v22;
-      }
       for (int k = 0; k < 9; k++) { S.Dinv[lane][k] = Dinv[k]; S.LD[lane][k] = LDm[k]; }
     }
   }
@@ -556,7 +555,7 @@ __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __rest
   // 4. border vector for modes whose control row is not "I = value":  x2 = T^-1 (column of I)
   if (mode != PLH_MODE_I) {
     double r0 = 0.0, r1 = 0.0, r2 = lane == 0 ? c.JI0 : (lane == NE - 1 ? c.JI29 : 0.0);
-    thomas_sweeps(S, r0, r1, r2);
+    thomas_sweeps(S, alg_only, r0, r1, r2);
     if (lane < NE) { S.x2[lane][0] = r0; S.x2[lane][1] = r1; S.x2[lane][2] = r2; }
     PL_SYNC();
   }
@@ -575,9 +574,8 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
       double w = 0.0;
       if (lane < 60 && p < NJ) {
         const double* bc = b + O_CS + p * NR;
-        if (pass == 0) { for (int k = 0; k < NR; k++) w += R.AinvP[k] * bc[k]; }
-        else if (pass >= 2) { for (int k = 0; k < NR; k++) w += R.AinvN[k] * bc[k]; }
-        else { const bool isp = p < NP; for (int k = 0; k < NR; k++) w += (isp ? R.AinvP[k] : R.AinvN[k]) * bc[k]; }
+        const double* Ai = S.Ainv[p < NP ? 0 : 1] + r * NR;
+        for (int k = 0; k < NR; k++) w += Ai[k] * bc[k];
         if (r == NR - 1) S.w9[p] = w;
       }
       R.wreg[pass] = w;
@@ -604,7 +602,7 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
     m0 = r0; m1 = r1; m2 = r2;
   }
   // c. block-Thomas forward / backward substitution (systolic, registers + DPP)
-  thomas_sweeps(S, m0, m1, m2);
+  thomas_sweeps(S, alg_only, m0, m1, m2);
   double mx[3] = {m0, m1, m2};
   // d. border: control row couples Phi_s[first] - Phi_s[last] (voltage mode)
   double xI;
@@ -636,7 +634,7 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
       if (lane < 60 && p < NJ) {
         const int el = p < NP ? 0 : 1;
         const double bj = el == 0 ? c.bj_p : c.bj_n;
-        b[O_CS + p * NR + r] = R.wreg[pass] - (el == 0 ? R.AinvP[NR - 1] : R.AinvN[NR - 1]) * bj * b[O_J + p];
+        b[O_CS + p * NR + r] = R.wreg[pass] - S.Ainv[el][r * NR + NR - 1] * bj * b[O_J + p];
       }
     }
   }

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 sqlite outputs under gpurun_out/prof_<tag>/ into small tracked text summaries under profiles/.
+usage: python tools/summarize_profile.py <tag> [label]"""
+import collections, glob, os, sqlite3, sys
+tag = sys.argv[1]; label = sys.argv[2] if len(sys.argv) > 2 else tag
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+out = os.path.join(ROOT, "profiles", "%s_rocprofv3_summary.md" % label)
+L = ["# rocprofv3 summary `%s`" % label, "",
+     "Command profiled (GPU box, 1x MI355X): `python bench.py --steps 5 --warmup 2 --no-cpu-baseline` for the kernel trace,",
+     "`--steps 2 --warmup 1` for each PMC pass (separate passes, never combined with sys/hip traces). Source: tools/prof.sh.", ""]
+con = sqlite3.connect(os.path.join(src, "trace", "trace_results.db")); cur = con.cursor()
+L += ["## `rocprofv3 --kernel-trace --stats` : top kernels", "", "| kernel | calls | total (us) | average (us) | % |", "|---|---|---|---|---|"]
+for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 6"):
+    L.append("| `%s` | %d | %.1f | %.1f | %.2f |" % (r[0][:70], r[1], r[2] / 1e3 if r[2] > 1e6 else r[2], r[3] / 1e3 if r[3] > 1e5 else r[3], r[4]))
+rows = cur.execute("select duration, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels where name like 'k_integrate%'").fetchall()
+d = [r[0] for r in rows]
+L += ["", "`k_integrate`: %d dispatches, duration min/avg/max = %.1f / %.1f / %.1f us; grid %d x wg %d; arch VGPR %s, AGPR %s, SGPR %s, LDS %s B, scratch %s B/lane"
+      % (len(d), min(d) / 1e3, sum(d) / len(d) / 1e3, max(d) / 1e3, rows[0][6], rows[0][7], rows[0][1], rows[0][2], rows[0][3], rows[0][4], rows[0][5]), ""]
+L += ["## PMC passes (per k_integrate launch = 1024 cells = 1024 wavefronts; averages over the dispatches of the run)", "", "| counter | value per launch | per wavefront |", "|---|---|---|"]
+vals = {}
+for dbf in sorted(glob.glob(os.path.join(src, "pmc*", "*.db"))):
+    con = sqlite3.connect(dbf); cur = con.cursor()
+    cur.execute("select * from counters_collection limit 1"); cols = [c[0] for c in cur.description]
+    acc = collections.defaultdict(list)
+    for r in cur.execute("select * from counters_collection"):
+        rec = dict(zip(cols, r))
+        if "k_integrate" in str(rec.get("kernel_name", rec.get("name", ""))):
+            acc[rec["counter_name"]].append(rec["value"])
+    for k, v in acc.items():
+        vals[k] = sum(v) / len(v)
+for k in sorted(vals):
+    L.append("| %s | %.4g | %.4g |" % (k, vals[k], vals[k] / 1024))
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    rd, wr = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024     # KiB -> B; gfx950 FETCH_SIZE reads 1/2 (MI355X_MICROARCH.md, HBM)
+    L += ["", "HBM traffic per launch (FETCH_SIZE x 1024 B x 2 [gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md section HBM] + WRITE_SIZE x 1024 B, write side uncalibrated):",
+          "read %.1f MB + write %.1f MB = %.1f MB per launch = %.1f kB per trajectory." % (rd / 1e6, wr / 1e6, (rd + wr) / 1e6, (rd + wr) / 1024 / 1e3)]
+if "SQ_WAVE_CYCLES" in vals:
+    L += ["", "SQ_WAVE_CYCLES etc. count quad-cycles: %.3g shader cycles per wavefront; VALU-active fraction %.0f %%, s_waitcnt-parked fraction %.0f %%."
+          % (4 * vals["SQ_WAVE_CYCLES"] / 1024, 100 * vals.get("SQ_ACTIVE_INST_ANY", 0) / vals["SQ_WAVE_CYCLES"], 100 * vals.get("SQ_WAIT_ANY", 0) / vals["SQ_WAVE_CYCLES"])]
+open(out, "w").write("\n".join(L) + "\n")
+print(open(out).read())
