@@ -1,0 +1,136 @@
+# PetlionHIP.jl -- thin `ccall` layer over libpetlion_hip.so (include/petlion_hip.h) for a PETLION.jl host.
+#
+# NOT EXECUTED in the build container (no Julia there); kept deliberately mechanical: every function is one ccall.
+# Usage sketch (see INTEGRATION.md):
+#
+#     using PETLION, .PetlionHIP
+#     p    = petlion(LCO)                                   # the stock model object: θ, N, opts, bounds
+#     h    = PetlionHIP.Model(p)                            # device handle for the same structural options
+#     Θ    = PetlionHIP.theta_matrix(h, p, n_cells)         # n_cells × n_theta, θ_keys order of the device library
+#     Θ[:, PetlionHIP.key_index(h, :D_sp)] .*= 2 .^ (2rand(n_cells) .- 1)
+#     ens  = PetlionHIP.simulate_ensemble(h, p, Θ, [(I = -1,)]; SOC = 1.0)
+#     ens.t_end, ens.flag, ens.V[:, i] ...
+module PetlionHIP
+
+const lib = get(ENV, "PETLION_HIP_LIB", joinpath(@__DIR__, "..", "..", "petlion.jl_amd", "libpetlion_hip.so"))
+
+const PLH_HOST = Cint(0)
+const MODE = Dict(:I => Cint(0), :V => Cint(1), :dT => Cint(2))
+const VAL_CONST, VAL_HOLD, VAL_REST = Cint(0), Cint(1), Cint(2)
+
+struct ModelDesc
+    chemistry::Cint; N_p::Cint; N_s::Cint; N_n::Cint; N_a::Cint; N_z::Cint; N_r_p::Cint; N_r_n::Cint
+    temperature::Cint; aging_SEI::Cint; real_bytes::Cint
+end
+struct Bounds      # boundary_stop_conditions, src/structures.jl:237-250
+    V_max::Cdouble; V_min::Cdouble; SOC_max::Cdouble; SOC_min::Cdouble; T_max::Cdouble; c_s_n_max::Cdouble
+    I_max::Cdouble; I_min::Cdouble; η_plating_min::Cdouble; c_e_min::Cdouble; dfilm_max::Cdouble
+end
+struct Run
+    mode::Cint; value_kind::Cint; value::Cdouble; tf::Cdouble; bounds::Bounds
+end
+struct Opts
+    abstol::Cdouble; reltol::Cdouble; abstol_init::Cdouble; reltol_init::Cdouble
+    maxiters::Cint; check_bounds::Cint; interp_final::Cint; max_order::Cint; jac_every_step::Cint; init_step::Cdouble
+end
+struct RunInfo
+    flag::Cint; iterations::Cint; t_end::Cdouble; V::Cdouble; I::Cdouble; SOC::Cdouble; T_avg::Cdouble
+end
+struct Counters
+    n_steps::Clonglong; n_res::Clonglong; n_jac::Clonglong; n_fact::Clonglong; n_solve::Clonglong; n_newton::Clonglong
+    n_errfail::Clonglong; n_convfail::Clonglong; sum_kp2::Clonglong; n_init_iters::Clonglong; cyc::NTuple{8,Clonglong}
+end
+struct Outputs
+    max_pts::Cint; t::Ptr{Cdouble}; V::Ptr{Cdouble}; I::Ptr{Cdouble}; SOC::Ptr{Cdouble}; T_avg::Ptr{Cdouble}
+    n_pts::Ptr{Cint}; Y_final::Ptr{Cdouble}; YP_final::Ptr{Cdouble}; run_info::Ptr{RunInfo}; counters::Ptr{Counters}
+end
+
+lasterror() = unsafe_string(ccall((:plh_last_error, lib), Cstring, ()))
+check(rc, what) = rc == 0 || error("$what failed ($rc): $(lasterror())")
+
+mutable struct Model
+    h::Ptr{Cvoid}
+    N::Int; N_diff::Int; θ_keys::Vector{Symbol}
+    function Model(p)   # p::PETLION.model -- reads only p.N and p.numerics
+        N = p.N
+        chem = p.numerics.cathode == PETLION.LCO ? 0 : 1
+        d = Ref(ModelDesc(chem, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, p.numerics.temperature == true, p.numerics.aging == :SEI, 8))
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:plh_model_create, lib), Cint, (Ref{ModelDesc}, Ref{Ptr{Cvoid}}), d, h), "plh_model_create")
+        n = ccall((:plh_n_theta, lib), Cint, (Ptr{Cvoid},), h[])
+        keys = [Symbol(unsafe_string(ccall((:plh_theta_key, lib), Cstring, (Ptr{Cvoid}, Cint), h[], i - 1))) for i in 1:n]
+        m = new(h[], ccall((:plh_n_states, lib), Cint, (Ptr{Cvoid},), h[]), ccall((:plh_n_diff, lib), Cint, (Ptr{Cvoid},), h[]), keys)
+        finalizer(x -> ccall((:plh_model_destroy, lib), Cvoid, (Ptr{Cvoid},), x.h), m)
+    end
+end
+
+key_index(m::Model, k::Symbol) = findfirst(==(k), m.θ_keys)
+"n_cells × n_theta matrix (row = one cell's θ_tot, update_θ! order of src/generate_functions.jl:364-372)"
+theta_matrix(m::Model, p, n_cells) = repeat(permutedims([Float64(p.θ[k]) for k in m.θ_keys]), n_cells, 1)
+
+bounds_of(b; kw...) = Bounds((get(kw, f, getfield(b, f)) for f in (:V_max, :V_min, :SOC_max, :SOC_min, :T_max, :c_s_n_max, :I_max, :I_min, :η_plating_min, :c_e_min, :dfilm_max))...)
+
+function make_run(p, step::NamedTuple)
+    name = first(k for k in keys(step) if haskey(MODE, k))
+    x = step[name]
+    kind, val = x === :hold ? (VAL_HOLD, 0.0) : x === :rest ? (VAL_REST, 0.0) : (VAL_CONST, Float64(x))
+    kw = Dict(k => Float64(v) for (k, v) in pairs(step) if k ∉ (name, :tf))
+    Run(MODE[name], kind, val, Float64(get(step, :tf, 1e6)), bounds_of(p.bounds; kw...))
+end
+
+"""
+    simulate_ensemble(m, p, Θ, protocol; SOC=p.opts.SOC, max_pts=2048)
+
+`protocol` = vector of NamedTuples, each the keyword set of one `simulate`/`simulate!` call, e.g.
+`[(I = 2, tf = 1800, V_max = 4.1), (V = :hold, I_min = 1/20)]`.  Θ is n_cells × n_theta (row-major is what the C side wants, so
+the transposed copy is passed).
+"""
+function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.opts.SOC, max_pts = 2048, Y_init = nothing, t_init = nothing)
+    n = size(Θ, 1)
+    runs = [make_run(p, s) for s in protocol]
+    o = p.opts
+    opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0))
+    Θt = permutedims(Θ)                                   # column-major n_theta × n_cells == row-major cells
+    soc = SOC isa Number ? fill(Float64(SOC), n) : Vector{Float64}(SOC)
+    t = zeros(max_pts, n); V = similar(t); I = similar(t); S = similar(t)
+    npts = zeros(Cint, n); Y = zeros(m.N, n); YP = zeros(m.N, n)
+    info = Matrix{RunInfo}(undef, length(runs), n); cnt = Vector{Counters}(undef, n)
+    GC.@preserve t V I S npts Y YP info cnt begin
+        out = Ref(Outputs(max_pts, pointer(t), pointer(V), pointer(I), pointer(S), C_NULL, pointer(npts), pointer(Y), pointer(YP), pointer(info), pointer(cnt)))
+        rc = ccall((:plh_integrate, lib), Cint,
+                   (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Run}, Ref{Opts}, Ref{Outputs}, Cint, Ptr{Cvoid}),
+                   m.h, n, Θt, soc, Y_init === nothing ? C_NULL : pointer(Y_init), t_init === nothing ? C_NULL : pointer(t_init),
+                   length(runs), runs, opts, out, PLH_HOST, C_NULL)
+        check(rc, "plh_integrate")
+    end
+    (t = t, V = V, I = I, SOC = S, n_pts = npts, Y = Y, YP = YP, run_info = info, counters = cnt,
+     flag = [info[end, i].flag for i in 1:n], t_end = [info[end, i].t_end for i in 1:n])
+end
+
+# ---- seam 1: the five generated functions of p.funcs (src/structures.jl:315-334) as single-cell evaluators ----
+function residual!(res::Vector{Float64}, m::Model, Y, YP, θ; mode = :I, value = 0.0)
+    check(ccall((:plh_residual, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{Cdouble}, Cint, Ptr{Cvoid}),
+                m.h, 1, θ, Y, YP, MODE[mode], value, res, PLH_HOST, C_NULL), "plh_residual")
+    res
+end
+f_diff!(out, m::Model, Y, YP, θ) = (r = residual!(zeros(m.N), m, Y, YP, θ); out .= @view r[1:m.N_diff]; nothing)
+f_alg!(out, m::Model, Y, YP, θ) = (r = residual!(zeros(m.N), m, Y, YP, θ); out .= @view r[m.N_diff+1:m.N-1]; nothing)
+function J_full!(nzval::Vector{Float64}, m::Model, Y, YP, γ, θ; mode = :I)
+    check(ccall((:plh_jacobian, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cint, Ptr{Cdouble}, Cint, Ptr{Cvoid}),
+                m.h, 1, θ, Y, YP, γ, MODE[mode], nzval, PLH_HOST, C_NULL), "plh_jacobian")
+    nzval
+end
+function initial_guess!(out::Vector{Float64}, m::Model, SOC, θ)
+    check(ccall((:plh_initial_guess, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cvoid}), m.h, 1, θ, SOC, out, PLH_HOST, C_NULL), "plh_initial_guess")
+    out
+end
+"0-based CSC pattern (colptr, rowval) of [J_y_sp ; control row] for a mode"
+function jac_pattern(m::Model; mode = :I)
+    nnz = Ref{Cint}(0)
+    ccall((:plh_jac_pattern, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}, Ptr{Cint}, Ptr{Cint}), m.h, MODE[mode], nnz, C_NULL, C_NULL)
+    cp = zeros(Cint, m.N + 1); ri = zeros(Cint, nnz[])
+    check(ccall((:plh_jac_pattern, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}, Ptr{Cint}, Ptr{Cint}), m.h, MODE[mode], nnz, cp, ri), "plh_jac_pattern")
+    cp, ri
+end
+
+end # module
