@@ -772,8 +772,13 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
   if (!ctx->ida_ok) { ida_alloc(&ctx->I, N); ctx->ida_ok = 1; }
   ida_t* Ip = &ctx->I;
   int nout = 0, rc = 0; double t_global = 0.0, SOC = SOC0; int have_prev = 0; double prev_V = 0, prev_I = 0;
-#define SAVE(tt_, Y_, SOC_) do { if (nout < max_out) { if (out_t) out_t[nout] = (tt_); if (out_V) out_V[nout] = calc_V(&M, (Y_)); if (out_I) out_I[nout] = (Y_)[M.o_I]; \
-    if (out_SOC) out_SOC[nout] = (SOC_); if (out_T) out_T[nout] = calc_Tavg(&M, ev[run->mode].w, (Y_), T0); } nout++; } while (0)
+#define SAVE(tt_, Y_, SOC_) do { if (nout < max_out) { \
+      if (out_t) { out_t[nout] = (tt_); } \
+      if (out_V) { out_V[nout] = calc_V(&M, (Y_)); } \
+      if (out_I) { out_I[nout] = (Y_)[M.o_I]; } \
+      if (out_SOC) { out_SOC[nout] = (SOC_); } \
+      if (out_T) { out_T[nout] = calc_Tavg(&M, ev[run->mode].w, (Y_), T0); } } \
+    nout++; } while (0)
 #define REPLACE_LAST(tt_, Y_, SOC_) do { nout--; SAVE(tt_, Y_, SOC_); } while (0)
   for (int r = 0; r < n_runs; r++) {
     const orc_run* run = &runs[r];

@@ -100,24 +100,38 @@ __device__ inline double ida_set_coeffs(CellLDS& S, IdaScalars& I) {
   const int kk = I.kk; const double hh = I.hh;
   if (hh != I.hused || kk != I.kused) I.ns = 0;
   I.ns = (I.ns + 1 < I.kused + 2) ? I.ns + 1 : I.kused + 2;
-  if (lane == 0) {
-    if (kk + 1 >= I.ns) {
-      S.ida_beta[0] = 1.0; S.ida_alpha[0] = 1.0; double temp1 = hh; S.ida_gamma[0] = 0.0; S.ida_sigma[0] = 1.0;
-      for (int i = 1; i <= kk; i++) {
-        const double temp2 = S.ida_psi[i - 1]; S.ida_psi[i - 1] = temp1; S.ida_beta[i] = S.ida_beta[i - 1] * temp1 / temp2; temp1 = temp2 + hh;
-        S.ida_alpha[i] = hh / temp1; S.ida_sigma[i] = i * S.ida_sigma[i - 1] * S.ida_alpha[i]; S.ida_gamma[i] = S.ida_gamma[i - 1] + S.ida_alpha[i - 1] / hh;
+  if (kk + 1 >= I.ns) {
+    // IDASetCoeffs recurrences; the divisions are done by lanes 0..kk in parallel, the (division-free) prefix products/sums by lane 0:
+    //   psi_new[0] = h, psi_new[i] = psi_old[i-1] + h ; alpha[i] = h/psi_new[i] ; beta[i] = prod_{m<=i} psi_new[m-1]/psi_old[m-1] ;
+    //   sigma[i] = i sigma[i-1] alpha[i] ; gamma[i] = gamma[i-1] + alpha[i-1]/h
+    const int i = lane <= kk ? lane : 0;
+    const double po_im1 = i > 0 ? S.ida_psi[i - 1] : 1.0, po_im2 = i > 1 ? S.ida_psi[i - 2] : 1.0;
+    const double pn_i = i > 0 ? po_im1 + hh : hh;
+    const double pn_im1 = i > 1 ? po_im2 + hh : hh;
+    const double al = i > 0 ? hh / pn_i : 1.0;
+    const double q = i > 0 ? pn_im1 / po_im1 : 1.0;
+    const double al_prev = i > 1 ? hh / pn_im1 : 1.0;
+    const double g = i > 0 ? al_prev / hh : 0.0;
+    PL_SYNC();
+    if (lane <= kk) { S.ida_psi[lane] = pn_i; S.ida_alpha[lane] = al; S.ida_beta[lane] = q; S.ida_gamma[lane] = g; }
+    PL_SYNC();
+    if (lane == 0) {
+      double b = 1.0, sg = 1.0, gm = 0.0;
+      S.ida_sigma[0] = 1.0;
+      for (int m = 1; m <= kk; m++) {
+        b *= S.ida_beta[m]; S.ida_beta[m] = b;
+        sg = m * sg * S.ida_alpha[m]; S.ida_sigma[m] = sg;
+        gm += S.ida_gamma[m]; S.ida_gamma[m] = gm;
       }
-      S.ida_psi[kk] = temp1;
     }
-    double alphas = 0.0, alpha0 = 0.0;
-    for (int i = 0; i < kk; i++) { alphas -= 1.0 / (i + 1); alpha0 -= S.ida_alpha[i]; }
-    double ck = fabs(S.ida_alpha[kk] + alphas - alpha0); if (ck < S.ida_alpha[kk]) ck = S.ida_alpha[kk];
-    S.ida_out[0] = -alphas / hh; S.ida_out[1] = ck;
+    PL_SYNC();
   }
-  PL_SYNC();
-  I.cjlast = I.cj; I.cj = S.ida_out[0];
-  const double ck = S.ida_out[1];
-  for (int i = I.ns; i <= kk; i++) { const double b = S.ida_beta[i]; PL_VEC(n) S.phi[i][n] *= b; }
+  double alphas = 0.0, alpha0 = 0.0;
+  for (int m = 0; m < kk; m++) { alphas -= 1.0 / (m + 1); alpha0 -= S.ida_alpha[m]; }
+  I.cjlast = I.cj; I.cj = -alphas / hh;
+  const double ak = S.ida_alpha[kk];
+  double ck = fabs(ak + alphas - alpha0); if (ck < ak) ck = ak;
+  for (int m = I.ns; m <= kk; m++) { const double b = S.ida_beta[m]; PL_VEC(n) S.phi[m][n] *= b; }
   I.tn += hh;
   PL_SYNC();
   return ck;
@@ -172,19 +186,17 @@ __device__ inline int ida_nls(CellLDS& S, LaneRegs& R, const Tables* tb, IdaScal
     for (;;) {
       cnt_add(cnt, C_NEWTON); cnt_add(cnt, C_SOLVE);
       { PL_TIC();
-      PL_VEC(n) S.delta[n] = -S.delta[n];
-      PL_SYNC();
-      cell_solve(S, R, S.delta, mode, false);
+      cell_solve(S, R, S.delta, mode, false);           // x = J^-1 F ; the Newton correction is -x
       PL_TOC(S, PH_SOLVE); }
       PL_TIC();
-      const double sc = (I.cjratio != 1.0) ? 2.0 / (1.0 + I.cjratio) : 1.0;
+      const double sc = (I.cjratio != 1.0) ? -2.0 / (1.0 + I.cjratio) : -1.0;
       double s = 0.0;
       PL_VEC(n) { const double d = S.delta[n] * sc; S.ee[n] += d; const double p = d * S.ewt[n]; s += p * p; }
       const double delnrm = sqrt(wave_sum(s) / NST);
       PL_SYNC();
       ret = 2;
       if (m == 0) { oldnrm = delnrm; if (delnrm <= toldel) ret = 0; }
-      else { const double rate = pow(delnrm / oldnrm, 1.0 / m); if (rate > 0.9) ret = 1; else I.ss = rate / (1.0 - rate); }
+      else { const double q = delnrm / oldnrm; const double rate = (m == 1) ? q : pow(q, 1.0 / m); if (rate > 0.9) ret = 1; else I.ss = rate / (1.0 - rate); }
       if (ret == 2 && I.ss * delnrm <= epsNewt) ret = 0;
       if (!(delnrm == delnrm)) ret = 1;
       PL_TOC(S, PH_NEWTVEC);
@@ -254,7 +266,7 @@ __device__ inline void ida_complete_step(CellLDS& S, IdaScalars& I, double err_k
         if (terr_km1 <= (terr_k < terr_kp1 ? terr_k : terr_kp1)) action = 1; else if (terr_kp1 >= terr_k) action = 2; else action = 3; }
     }
     if (action == 3) { I.kk++; err_knew = err_kp1; } else if (action == 1) { I.kk--; err_knew = err_km1; } else err_knew = err_k;
-    double hnew = I.hh; I.rr = pow(2.0 * err_knew + 0.0001, -1.0 / (I.kk + 1));
+    double hnew = I.hh; I.rr = exp(-log(2.0 * err_knew + 0.0001) / (I.kk + 1));   // = (2 err + 1e-4)^(-1/(k+1))
     if (I.rr >= 2.0) hnew = 2.0 * I.hh;
     else if (I.rr <= 1.0) { I.rr = I.rr < 0.9 ? I.rr : 0.9; I.rr = I.rr > 0.5 ? I.rr : 0.5; hnew = I.hh * I.rr; }
     I.hh = hnew;
@@ -274,10 +286,14 @@ __device__ inline void ida_get_solution(CellLDS& S, const IdaScalars& I, double 
   const int lane = lane_id();
   int kord = I.kused; if (kord == 0) kord = 1;
   const double delt = t - I.tn;
-  double c = 1.0, d = 0.0, gam = delt / S.ida_psi[0];
-  double c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;   // static registers instead of cv[]/dv[]
-#define PL_GS_STEP(J, CV, DV) if (J <= kord) { d = d * gam + c / S.ida_psi[J - 1]; c = c * gam; gam = (delt + S.ida_psi[J - 1]) / S.ida_psi[J <= MAXORD ? J : MAXORD]; CV = c; DV = d; }
-  PL_GS_STEP(1, c1, d0) PL_GS_STEP(2, c2, d1) PL_GS_STEP(3, c3, d2) PL_GS_STEP(4, c4, d3) PL_GS_STEP(5, c5, d4)
+  // reciprocals of psi[0..kord] by lanes 0..kord in parallel (the recurrence below is then division-free)
+  const double rp_mine = 1.0 / S.ida_psi[lane <= MAXORD ? lane : MAXORD];
+  const double rp0 = lane_bcast(rp_mine, 0), rp1 = lane_bcast(rp_mine, 1), rp2 = lane_bcast(rp_mine, 2), rp3 = lane_bcast(rp_mine, 3),
+               rp4 = lane_bcast(rp_mine, 4), rp5 = lane_bcast(rp_mine, 5);
+  double c = 1.0, d = 0.0, gam = delt * rp0;
+  double c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;
+#define PL_GS_STEP(J, RPJM1, RPJ, CV, DV) if (J <= kord) { d = d * gam + c * RPJM1; c = c * gam; gam = (delt + S.ida_psi[J - 1]) * RPJ; CV = c; DV = d; }
+  PL_GS_STEP(1, rp0, rp1, c1, d0) PL_GS_STEP(2, rp1, rp2, c2, d1) PL_GS_STEP(3, rp2, rp3, c3, d2) PL_GS_STEP(4, rp3, rp4, c4, d3) PL_GS_STEP(5, rp4, rp5, c5, d4)
 #undef PL_GS_STEP
   PL_VEC(n) {
     const double p1 = S.phi[1][n], p2 = S.phi[2][n], p3 = S.phi[3][n], p4 = S.phi[4][n], p5 = S.phi[5][n];
@@ -332,7 +348,7 @@ __device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaSca
       } else {
         cnt_add(cnt, C_ERRFAIL); nef++;
         if (nef == 1) { const double err_knew = (I.kk == I.knew) ? err_k : err_km1; I.kk = I.knew;
-          I.rr = 0.9 * pow(2.0 * err_knew + 0.0001, -1.0 / (I.kk + 1)); I.rr = I.rr < 0.9 ? I.rr : 0.9; I.rr = I.rr > 0.25 ? I.rr : 0.25; I.hh *= I.rr; }
+          I.rr = 0.9 * exp(-log(2.0 * err_knew + 0.0001) / (I.kk + 1)); I.rr = I.rr < 0.9 ? I.rr : 0.9; I.rr = I.rr > 0.25 ? I.rr : 0.25; I.hh *= I.rr; }
         else if (nef == 2) { I.kk = I.knew; I.rr = 0.25; I.hh *= I.rr; }
         else if (nef < 10) { I.kk = 1; I.rr = 0.25; I.hh *= I.rr; }
         else return PLH_ERR_STALL;

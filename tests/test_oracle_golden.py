@@ -111,3 +111,66 @@ def test_rest_and_hold_semantics(O):
     assert abs(ro["runs"][0]["t_end"] - 180.0) < 1e-9 and abs(ro["runs"][1]["t_end"] - 780.0) < 1e-6
     assert ro["runs"][1]["I"] == 0.0 and ro["runs"][2]["I"] == 0.0        # :hold after a rest holds I = 0
     assert abs(ro["runs"][1]["SOC"] - 1.0 * 180 / 3600) < 1e-6
+
+
+def test_thermal_cc_ct_cv_notebook(O):
+    """reference examples/fast_charging_CC-CT-CV.ipynb: temperature=true, SOC0=0, T_max=40 C, V_max=4.1, I_max=4, I_min=1/20;
+    simulate(p, I=4) -> simulate!(dT=:hold) -> simulate!(V=:hold).  Exercises the T rows, the heat sources, the dT control row and its
+    algebraic twin (scalar_residual.jl:347-372)."""
+    th = O.theta_vector("lco_thermal")
+    m = O.meta("lco_thermal")
+    assert m["N"] == 351 and m["nnz"] + 1 == 2883          # SURVEY.md App. D (C3, CC mode)
+    b = O.default_bounds(T_max=313.15, V_max=4.1, I_max=4.0, I_min=1 / 20)
+    runs = [dict(mode=O.MODE_I, value=4.0, bounds=b), dict(mode=O.MODE_DT, value_kind=O.VAL_HOLD, bounds=b),
+            dict(mode=O.MODE_V, value_kind=O.VAL_HOLD, bounds=b)]
+    ro = O.simulate("lco_thermal", th, 0.0, runs)
+    assert ro["rc"] == 0
+    for key, r in zip(("thermal_4C", "thermal_dT_hold", "thermal_V_hold"), ro["runs"]):
+        k = G["runs"][key]
+        assert r["flag"] == k["flag"], (key, r)
+        assert abs(r["t_end"] - k["t_end"]) <= k["tol"]["t_end_rel"] * k["t_end"], (key, r["t_end"])
+        if "V_abs" in k["tol"]:
+            assert abs(r["V"] - k["V_end"]) < k["tol"]["V_abs"]
+        if "I_rel" in k["tol"]:
+            assert abs(r["I"] - k["I_end"]) <= k["tol"]["I_rel"] * k["I_end"], (key, r["I"])
+        assert abs(r["SOC"] - k["SOC_end"]) < 2e-3
+    assert abs(ro["runs"][0]["T_avg"] - 313.15) < 1e-6 and abs(ro["runs"][1]["T_avg"] - 313.15) < 1e-4     # CT leg holds 40 C
+    assert abs(ro["runs"][2]["T_avg"] - (25.6963 + 273.15)) < 0.05
+
+
+def test_thermal_jacobian_vs_complex_step(O):
+    m = dm.Model("LCO", temperature=True)
+    th = O.theta_vector("lco_thermal")
+    thd = dict(m.theta)
+    ro = O.simulate("lco_thermal", th, 0.2, [dict(mode=O.MODE_I, value=3.0, tf=120.0, bounds=O.default_bounds(T_max=400.0))])
+    Y, YP, cj = ro["Y"], ro["YP"], 0.5
+    N = 351
+    for mode, val in ((O.MODE_I, 3.0), (O.MODE_DT, 0.0)):
+        cp, ri, nz = O.jacobian("lco_thermal", th, Y, YP, cj, mode, val)
+        J = np.zeros((N, N))
+        for c in range(N):
+            J[ri[cp[c]:cp[c + 1]], c] = nz[cp[c]:cp[c + 1]]
+        ops, h = dm.FloatOps(), 1e-30
+        for c in list(range(0, N, 11)) + [N - 1]:
+            Yc = [complex(v) for v in Y]; Yc[c] += 1j * h
+            dY = np.imag(np.array(dm.residual(m, ops, Yc, [complex(v) for v in YP], thd, mode, val))) / h
+            YPc = [complex(v) for v in YP]; YPc[c] += 1j * h
+            dYP = np.imag(np.array(dm.residual(m, ops, [complex(v) for v in Y], YPc, thd, mode, val))) / h
+            col = dY + cj * dYP
+            assert np.abs(J[:, c] - col).max() <= 1e-9 * (np.abs(col).max() + 1e-300), (mode, c)
+
+
+def test_nmc_sei_variant(O):
+    """config C5's model (NMC + aging=:SEI; SEI parameters borrowed from LiC6): sizes, I1C, a GITT pulse."""
+    m = O.meta("nmc_iso_sei")
+    assert m["N"] == 322 and m["N_diff"] == 241 and m["nnz"] + 1 == 2269 and m["nnz_alg"] + 1 == 314     # SURVEY.md App. D (C5)
+    assert abs(dm.calc_I1C(dm.theta_NMC()) - 19.966706096404245) < 1e-12                                 # survey-computed, not a reference KAT
+    th = O.theta_vector("nmc_iso_sei")
+    b = O.default_bounds("NMC")
+    runs = [dict(mode=O.MODE_I, value=1.0, tf=180.0, bounds=b), dict(mode=O.MODE_I, value_kind=O.VAL_REST, tf=7200.0, bounds=b)]
+    ro = O.simulate("nmc_iso_sei", th, 0.0, runs)
+    assert [r["flag"] for r in ro["runs"]] == [0, 0]
+    SOH = ro["Y"][30 + 200 + 10]        # layout: c_e 30 | c_s 200 | film 10 | SOH
+    film = ro["Y"][230:240]
+    assert 0 < 1 - SOH < 1e-5 and (film > 0).all() and film.max() < 1e-9     # SOH after the first pulse ~ 1 - 1.3e-6 (SURVEY 8d)
+    assert abs(ro["runs"][1]["SOC"] - 0.05) < 1e-6
