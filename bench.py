@@ -75,11 +75,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    local_dev = local_rank % ndev            # normally identity; lets the multi-process path be exercised on a 1-GPU box
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")     # "nccl" == RCCL over xGMI; "gloo" only for testing the rank logic
+    cdev = dev if backend == "nccl" else torch.device("cpu")   # device of the collective payloads
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as g
     g.build_hip()
@@ -94,14 +101,13 @@ def main():
 
     # ---- ensemble scatter (RCCL, outside the timed region): rank 0 owns Theta ----
     if world > 1:
-        meta = torch.zeros(1, dtype=torch.int64, device=dev)
-        mine = torch.empty(n_local, len(p.θ_keys), dtype=torch.float64, device=dev)
+        mine = torch.empty(n_local, len(p.θ_keys), dtype=torch.float64, device=cdev)
         if rank == 0:
-            full = torch.from_numpy(pkg.theta_matrix(p, n_total)).to(dev)
-            dist.scatter(mine, list(full.chunk(world, dim=0)), src=0)
+            full = torch.from_numpy(pkg.theta_matrix(p, n_total)).to(cdev)
+            dist.scatter(mine, [c.contiguous() for c in full.chunk(world, dim=0)], src=0)
         else:
             dist.scatter(mine, None, src=0)
-        Theta = mine
+        Theta = mine.to(dev)
     else:
         Theta = torch.from_numpy(pkg.theta_matrix(p, n_local)).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -125,7 +131,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -136,7 +142,7 @@ def main():
     assert np.abs(ens.run_info["t_end"][:, 0] - 3600.0).max() < 1e-5
     summ = pd.summarize(ens)
     if world > 1:
-        mine_s = torch.from_numpy(summ).to(dev)
+        mine_s = torch.from_numpy(summ).to(cdev)
         parts = [torch.empty_like(mine_s) for _ in range(world)] if rank == 0 else None
         dist.gather(mine_s, parts, dst=0)
         if rank == 0:
