@@ -194,6 +194,15 @@ __device__ __forceinline__ void ocv_lic6(double x, double T, int iso_ref, double
   }
 }
 
+// sinh and cosh from ONE expm1 and one division (ocml's sinh alone costs ~670 cycles of dependent latency on gfx950):
+//   u = e^x - 1 ;  sinh x = (u + u/(u+1))/2 ,  cosh x = sinh x + 1/(u+1)   -- accurate for small |x| as well (no cancellation)
+__device__ __forceinline__ void sinh_cosh(double x, double& sh, double& ch) {
+  const double u = expm1(x);
+  const double r = 1.0 / (u + 1.0);
+  sh = 0.5 * (u + u * r);
+  ch = sh + r;
+}
+
 // harmonic-mean edge interpolation H(beta; a, b) = ab/(beta b + (1-beta) a), numerical_tools.jl:106-156
 __device__ __forceinline__ double hmean(double beta, double a, double b) { return a * b / (beta * b + (1.0 - beta) * a); }
 
@@ -285,63 +294,73 @@ __device__ inline void cell_node_pass(CellLDS& S, const double* Y, const double*
   const int sc = sec_of(i);
   const bool elec = sc != 1;
   const int jx = sc == 0 ? i : i - NS;                 // index into j / Phi_s / particles
-  const double h = c.h[sc];
+  // ---- every LDS operand of this pass is loaded here, up front (one latency instead of one stall per use) ----
   const double ce = Y[O_CE + i], pe = Y[O_PE + i];
-  double K, dK; keff(ce, c.T0, K, dK);
-  K *= c.bf[sc]; dK *= c.bf[sc];
-  const double D = c.Dc[sc];
+  const double jv_l = Y[O_J + jx], ps_l = Y[O_PS + jx], cs_l = Y[O_CS + jx * NR + NR - 1], yI = Y[O_I];
+  const double ypce = WANT_RES ? YP[O_CE + i] : 0.0;
+  const double h0 = c.h[0], h1 = c.h[1], h2 = c.h[2], e0 = c.eps[0], e1 = c.eps[1], e2 = c.eps[2];
+  const double bf0 = c.bf[0], bf1 = c.bf[1], bf2 = c.bf[2], dc0 = c.Dc[0], dc1 = c.Dc[1], dc2 = c.Dc[2];
+  const double cT0 = c.T0, cKfac = c.Kfac, ctplus = c.tplus, cfRT = c.fRT, cI1C = c.I1C;
+  const double ca_p = c.a_p, ca_n = c.a_n, csg_p = c.sig_p, csg_n = c.sig_n, ckp = c.kp, ckn = c.kn, ccmp = c.cmaxp, ccmn = c.cmaxn;
+  const int ciso = c.iso_ref;
+  const double h = sc == 0 ? h0 : (sc == 1 ? h1 : h2);
+  const double epsc = sc == 0 ? e0 : (sc == 1 ? e1 : e2);
+  const double bfc = sc == 0 ? bf0 : (sc == 1 ? bf1 : bf2);
+  double K, dK; keff(ce, cT0, K, dK);
+  K *= bfc; dK *= bfc;
+  const double D = sc == 0 ? dc0 : (sc == 1 ? dc1 : dc2);
   const double ce_n = shift_down1(ce), pe_n = shift_down1(pe), K_n = shift_down1(K), dK_n = shift_down1(dK), D_n = shift_down1(D);
   // edge i : geometry (numerical_tools.jl:106-215)
   double beta = 0.5, dist = h;
-  if (i == NP - 1) { beta = (c.h[0] / 2) / (c.h[1] / 2 + c.h[0] / 2); dist = c.h[0] / 2 + c.h[1] / 2; }
-  if (i == NP + NS - 1) { beta = (c.h[1] / 2) / (c.h[2] / 2 + c.h[1] / 2); dist = c.h[1] / 2 + c.h[2] / 2; }
+  if (i == NP - 1) { beta = (h0 / 2) / (h1 / 2 + h0 / 2); dist = h0 / 2 + h1 / 2; }
+  if (i == NP + NS - 1) { beta = (h1 / 2) / (h2 / 2 + h1 / 2); dist = h1 / 2 + h2 / 2; }
   const bool edge = i < NE - 1;
   const double denK = beta * K_n + (1 - beta) * K, Kh = K * K_n / denK;
   const double denD = beta * D_n + (1 - beta) * D, Dh = D * D_n / denD;
   const double denC = beta * ce_n + (1 - beta) * ce, cb = ce * ce_n / denC;
-  const double Tb = c.T0 * c.T0 / (beta * c.T0 + (1 - beta) * c.T0);
+  const double Tb = cT0 * cT0 / (beta * cT0 + (1 - beta) * cT0);
   const double dc = (ce_n - ce) / dist;
   const double w = Kh / dist;
   const double g = Kh * Tb * dc / cb;
-  double E = edge ? w * (pe - pe_n) + c.Kfac * g : 0.0;   // Phi_e-row edge flux
+  double E = edge ? w * (pe - pe_n) + cKfac * g : 0.0;   // Phi_e-row edge flux
   double Nf = edge ? Dh * dc : 0.0;                        // c_e-row edge flux
   const double E_p = shift_up1(E), Nf_p = shift_up1(Nf);
   const double Em = i > 0 ? E_p : 0.0, Nm = i > 0 ? Nf_p : 0.0;
   // electrode quantities
-  const double a = sc == 0 ? c.a_p : c.a_n;
-  const double jv = elec ? Y[O_J + jx] : 0.0;
-  const double ps = elec ? Y[O_PS + jx] : 0.0;
-  const double cs = elec ? Y[O_CS + jx * NR + NR - 1] : 1.0;
-  const double cmax = sc == 0 ? c.cmaxp : c.cmaxn;
-  const double kk = sc == 0 ? c.kp : c.kn;
-  const double sg = sc == 0 ? c.sig_p : c.sig_n;
+  const double a = sc == 0 ? ca_p : ca_n;
+  const double jv = elec ? jv_l : 0.0;
+  const double ps = elec ? ps_l : 0.0;
+  const double cs = elec ? cs_l : 1.0;
+  const double cmax = sc == 0 ? ccmp : ccmn;
+  const double kk = sc == 0 ? ckp : ckn;
+  const double sg = sc == 0 ? csg_p : csg_n;
   double U = 0, dU = 0;
-  if (sc == 0) ocv_lco(cs / cmax, c.T0, c.iso_ref, U, dU);
-  else if (sc == 2) ocv_lic6(cs / cmax, c.T0, c.iso_ref, U, dU);
+  if (sc == 0) ocv_lco(cs / cmax, cT0, ciso, U, dU);
+  else if (sc == 2) ocv_lic6(cs / cmax, cT0, ciso, U, dU);
   const double eta = ps - pe - U;
   const double arg = ce * cs * (cmax - cs);
   const double sq = sqrt(arg > 0.0 ? arg : 0.0);
-  const double xx = c.fRT * eta;
-  const double sh = sinh(xx);
+  const double xx = cfRT * eta;
+  double sh, chh; sinh_cosh(xx, sh, chh);
   const double ps_p = shift_up1(ps), ps_n = shift_down1(ps);
   const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
   if (WANT_RES) {
     if (act) {
-      const double src = elec ? (1 - c.tplus) * 1.0 * a * jv : 0.0;
-      Fo[O_CE + i] = ((Nf - Nm) / h + src) / c.eps[sc] - YP[O_CE + i];                 // residuals_c_e!, residuals.jl:6-106
+      const double src = elec ? (1 - ctplus) * 1.0 * a * jv : 0.0;
+      Fo[O_CE + i] = ((Nf - Nm) / h + src) / epsc - ypce;                 // residuals_c_e!, residuals.jl:6-106
       Fo[O_PE + i] = (i < NE - 1) ? (E - Em - (elec ? h * FAR * a * jv : 0.0)) : pe;   // residuals_Φ_e!, residuals.jl:554-654
       if (elec) {
         Fo[O_J + jx] = 2.0 * kk * sq * sh - jv;                                        // residuals_j!, residuals.jl:491-517
         double lap = first ? (-ps + ps_n) : (last ? (ps_p - ps) : (ps_p - 2 * ps + ps_n));
         double f = h * h * a * FAR * jv;
-        const double Idens = Y[O_I] * c.I1C;
+        const double Idens = yI * cI1C;
         if (i == 0) f += -Idens * h;
         if (i == NE - 1) f += Idens * h;
         Fo[O_PS + jx] = lap - f / sg;                                                  // residuals_Φ_s!, residuals.jl:656-703
       }
     }
     if (lane == 0) {                                                                   // scalar_residual!, scalar_residual.jl:167-172
-      Fo[O_I] = (mode == PLH_MODE_I) ? (Y[O_I] - value) : (Y[O_PS] - Y[O_PS + NJ - 1] - value);
+      Fo[O_I] = (mode == PLH_MODE_I) ? (yI - value) : (Y[O_PS] - Y[O_PS + NJ - 1] - value);
     }
   }
   if (WANT_JAC) {
@@ -351,17 +370,17 @@ __device__ inline void cell_node_pass(CellLDS& S, const double* Y, const double*
     const double Tq = Tb / dist;
     const double dg_a = Tq * (dKh_a * (ce_n - ce) / cb - Kh / cb - Kh * (ce_n - ce) * dcb_a / (cb * cb));
     const double dg_b = Tq * (dKh_b * (ce_n - ce) / cb + Kh / cb - Kh * (ce_n - ce) * dcb_b / (cb * cb));
-    double Ea = edge ? (pe - pe_n) * dKh_a / dist + c.Kfac * dg_a : 0.0;
-    double Eb = edge ? (pe - pe_n) * dKh_b / dist + c.Kfac * dg_b : 0.0;
+    double Ea = edge ? (pe - pe_n) * dKh_a / dist + cKfac * dg_a : 0.0;
+    double Eb = edge ? (pe - pe_n) * dKh_b / dist + cKfac * dg_b : 0.0;
     double we = edge ? w : 0.0;
     double Na = edge ? -Dh / dist : 0.0, Nb = edge ? Dh / dist : 0.0;     // D_eff_linear: dD/dc = 0
     const double Ea_p = shift_up1(Ea), Eb_p = shift_up1(Eb), we_p = shift_up1(we), Na_p = shift_up1(Na), Nb_p = shift_up1(Nb);
     if (act) {
-      const double he = h * c.eps[sc];
+      const double he = h * epsc;
       S.ceL[i] = i > 0 ? -Na_p / he : 0.0;
       S.ceD[i] = (Na - (i > 0 ? Nb_p : 0.0)) / he;
       S.ceU[i] = Nb / he;
-      S.ceJ[i] = elec ? (1 - c.tplus) * a / c.eps[sc] : 0.0;
+      S.ceJ[i] = elec ? (1 - ctplus) * a / epsc : 0.0;
       if (i < NE - 1) {
         S.peL[i] = i > 0 ? -we_p : 0.0; S.peD[i] = (i > 0 ? we_p : 0.0) + we; S.peU[i] = -we;
         S.pcL[i] = i > 0 ? -Ea_p : 0.0; S.pcD[i] = Ea - (i > 0 ? Eb_p : 0.0); S.pcU[i] = Eb;
@@ -370,12 +389,12 @@ __device__ inline void cell_node_pass(CellLDS& S, const double* Y, const double*
         S.peL[i] = 0; S.peD[i] = 1.0; S.peU[i] = 0; S.pcL[i] = 0; S.pcD[i] = 0; S.pcU[i] = 0; S.peJ[i] = 0;
       }
       if (elec) {
-        const double ch = cosh(xx);
+        const double ch = chh;
         const double pos = arg > 0.0 ? 1.0 : 0.0;
         const double inv_sq = pos > 0 ? 1.0 / sq : 0.0;
         S.gce[jx] = kk * sh * cs * (cmax - cs) * inv_sq;
-        S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * ch * c.fRT * (-dU / cmax));
-        S.gps[jx] = 2.0 * kk * sq * ch * c.fRT;
+        S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * ch * cfRT * (-dU / cmax));
+        S.gps[jx] = 2.0 * kk * sq * ch * cfRT;
         S.gpe[jx] = -S.gps[jx];
         S.psJ[jx] = -h * h * a * FAR / sg;
       }
@@ -387,19 +406,34 @@ __device__ inline void cell_node_pass(CellLDS& S, const double* Y, const double*
 __device__ inline void cell_cs_rows(CellLDS& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
   const int lane = lane_id();
   const CellConst& c = S.cc;
-  const int r = lane % NR, g = lane / NR;
+  const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
+  double Mrow[NR];
+  for (int k = 0; k < NR; k++) Mrow[k] = S.Mr[r * NR + k];
+  // the four passes are independent: four accumulation chains side by side (particle index clamped so that every lane computes)
+  int pp[4]; double acc[4];
+#pragma unroll
+  for (int pass = 0; pass < 4; pass++) { const int p = pass * 6 + g; pp[pass] = p < NJ ? p : NJ - 1; acc[pass] = 0.0; }
+  // issue every LDS load first (one latency), then the arithmetic
+  double v[4][NR], jv[4], ypv[4];
+#pragma unroll
+  for (int pass = 0; pass < 4; pass++) {
+#pragma unroll
+    for (int k = 0; k < NR; k++) v[pass][k] = Y[O_CS + pp[pass] * NR + k];
+    jv[pass] = Y[O_J + pp[pass]];
+    ypv[pass] = YP[O_CS + pp[pass] * NR + r];
+  }
+  const double kap_p = c.kap_p, kap_n = c.kap_n, bj_p = c.bj_p, bj_n = c.bj_n;
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) acc[pass] += Mrow[k] * v[pass][k];
+  }
+#pragma unroll
   for (int pass = 0; pass < 4; pass++) {
     const int p = pass * 6 + g;
-    if (lane < 60 && p < NJ) {
-      const double* cs = Y + O_CS + p * NR;
-      double acc = 0.0;
-      const double* Mrow = S.Mr + r * NR;
-      for (int k = 0; k < NR; k++) acc += Mrow[k] * cs[k];
-      const double kap = p < NP ? c.kap_p : c.kap_n;
-      double rhs = kap * acc;
-      if (r == NR - 1) rhs += (p < NP ? c.bj_p : c.bj_n) * Y[O_J + p];
-      Fo[O_CS + p * NR + r] = rhs - YP[O_CS + p * NR + r];
-    }
+    double rhs = (p < NP ? kap_p : kap_n) * acc[pass];
+    if (r == NR - 1) rhs += (p < NP ? bj_p : bj_n) * jv[pass];
+    if (lane < 60 && p < NJ) Fo[O_CS + p * NR + r] = rhs - ypv[pass];
   }
 }
 
@@ -527,29 +561,26 @@ __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __rest
     const double u00 = (alg_only || i == 0) ? 0.0 : S.ceU[i - 1], u10 = (alg_only || i == 0) ? 0.0 : S.pcU[i - 1], u11 = i == 0 ? 0.0 : S.peU[i - 1];
     const double u22 = l22;
     for (int k = 0; k < 9; k++) LDm[k] = 0.0;
-    inv3(D, Dinv);                                      // correct for lane 0; refined below for the others
+    inv3(D, Dinv);                                      // final for lane 0 (its L is zero); the others converge below
+    // every lane re-evaluates its recurrence at every stage; once its predecessor is final the result is final and stable
+    // (idempotent update), so no per-stage select is needed and the wavefront advances one lane per stage
 #pragma unroll 1
     for (int it = 1; it < NE; it++) {
-      double P[9];
+      double P[9], Dn[9];
       for (int k = 0; k < 9; k++) P[k] = shift_up1(Dinv[k]);
-      double Ln[9], Dn[9], Dni[9];
       for (int k = 0; k < 3; k++) {
-        Ln[k] = l00 * P[k];
-        Ln[3 + k] = l10 * P[k] + l11 * P[3 + k];
-        Ln[6 + k] = l22 * P[6 + k];
+        LDm[k] = l00 * P[k];
+        LDm[3 + k] = l10 * P[k] + l11 * P[3 + k];
+        LDm[6 + k] = l22 * P[6 + k];
       }
       for (int rr = 0; rr < 3; rr++) {
-        Dn[rr * 3 + 0] = D[rr * 3 + 0] - (Ln[rr * 3 + 0] * u00 + Ln[rr * 3 + 1] * u10);
-        Dn[rr * 3 + 1] = D[rr * 3 + 1] - Ln[rr * 3 + 1] * u11;
-        Dn[rr * 3 + 2] = D[rr * 3 + 2] - Ln[rr * 3 + 2] * u22;
+        Dn[rr * 3 + 0] = D[rr * 3 + 0] - (LDm[rr * 3 + 0] * u00 + LDm[rr * 3 + 1] * u10);
+        Dn[rr * 3 + 1] = D[rr * 3 + 1] - LDm[rr * 3 + 1] * u11;
+        Dn[rr * 3 + 2] = D[rr * 3 + 2] - LDm[rr * 3 + 2] * u22;
       }
-      inv3(Dn, Dni);
-      const bool me = lane == it;
-      for (int k = 0; k < 9; k++) { Dinv[k] = me ? Dni[k] : Dinv[k]; LDm[k] = me ? Ln[k] : LDm[k]; }
+      inv3(Dn, Dinv);
     }
-    if (lane < NE) {
-      for (int k = 0; k < 9; k++) { S.Dinv[lane][k] = Dinv[k]; S.LD[lane][k] = LDm[k]; }
-    }
+    if (lane < NE) for (int k = 0; k < 9; k++) { S.Dinv[lane][k] = Dinv[k]; S.LD[lane][k] = LDm[k]; }
   }
   PL_SYNC();
   // 4. border vector for modes whose control row is not "I = value":  x2 = T^-1 (column of I)
@@ -566,19 +597,32 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const int r = lane % NR, g = lane / NR;
-  // a. particle partial solutions  w = A^-1 b_cs   (pass 0: particles 0-5 cathode; pass 1: 6-11 mixed; passes 2,3: anode)
+  // a. particle partial solutions  w = A^-1 b_cs : four independent accumulation chains (pass = particles pass*6 .. pass*6+5)
   if (!alg_only) {
+    const int gg = lane < 60 ? g : 5;
+    int pp[4]; double w[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) { const int p = pass * 6 + gg; pp[pass] = p < NJ ? p : NJ - 1; w[pass] = 0.0; }
+    double AP[NR], AN[NR], bv[4][NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) { AP[k] = S.Ainv[0][r * NR + k]; AN[k] = S.Ainv[1][r * NR + k]; }
 #pragma unroll
     for (int pass = 0; pass < 4; pass++) {
-      const int p = pass * 6 + g;
-      double w = 0.0;
-      if (lane < 60 && p < NJ) {
-        const double* bc = b + O_CS + p * NR;
-        const double* Ai = S.Ainv[p < NP ? 0 : 1] + r * NR;
-        for (int k = 0; k < NR; k++) w += Ai[k] * bc[k];
-        if (r == NR - 1) S.w9[p] = w;
-      }
-      R.wreg[pass] = w;
+#pragma unroll
+      for (int k = 0; k < NR; k++) bv[pass][k] = b[O_CS + pp[pass] * NR + k];
+    }
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      w[0] += AP[k] * bv[0][k];                                   // pass 0: particles 0..5 (cathode)
+      w[1] += (pp[1] < NP ? AP[k] : AN[k]) * bv[1][k];            // pass 1: particles 6..11 (mixed)
+      w[2] += AN[k] * bv[2][k];                                   // passes 2,3: anode
+      w[3] += AN[k] * bv[3][k];
+    }
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+      const int p = pass * 6 + gg;
+      if (lane < 60 && p < NJ && r == NR - 1) S.w9[p] = w[pass];
+      R.wreg[pass] = w[pass];
     }
   }
   PL_SYNC();
