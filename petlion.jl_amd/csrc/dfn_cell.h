@@ -23,9 +23,21 @@ namespace pl {
 
 constexpr int WAVE = 64;
 constexpr int NP = 10, NS = 10, NN = 10, NR = 10, NE = NP + NS + NN, NJ = NP + NN;
-constexpr int O_CE = 0, O_CS = NE, O_J = O_CS + NJ * NR, O_PE = O_J + NJ, O_PS = O_PE + NE, O_I = O_PS + NJ;
-constexpr int NST = O_I + 1, NDIFF = O_J, NALG = NST - NDIFF;
-constexpr int NPAD = 302;
+constexpr int O_CE = 0, O_CS = NE, N_CECS = O_CS + NJ * NR;      // c_e and c_s_avg lead every layout (reference src/external.jl:275-365)
+
+// Model traits: state layout  Y = [ c_e | c_s_avg | film, SOH (SEI) || j | Phi_e | Phi_s | j_s (SEI) | I ]  and closures.
+template <int CHEM_, bool SEI_> struct ModelT {
+  static constexpr int CHEM = CHEM_;                 // PLH_CHEM_LCO_LIC6 / PLH_CHEM_NMC_LIC6
+  static constexpr bool SEI = SEI_;
+  static constexpr int O_FILM = N_CECS, O_SOH = O_FILM + NN;
+  static constexpr int NDIFF = SEI_ ? O_SOH + 1 : N_CECS;
+  static constexpr int O_J = NDIFF, O_PE = O_J + NJ, O_PS = O_PE + NE, O_JS = O_PS + NJ, O_I = SEI_ ? O_JS + NN : O_PS + NJ;
+  static constexpr int NST = O_I + 1, NALG = NST - NDIFF;
+  static constexpr int NPAD = NST + (NST & 1);
+  static constexpr int NTRIP = (NST + WAVE - 1) / WAVE;
+};
+using ModelLcoIso = ModelT<PLH_CHEM_LCO_LIC6, false>;
+#define PL_MODEL(M) [[maybe_unused]] constexpr int O_J = M::O_J, O_PE = M::O_PE, O_PS = M::O_PS, O_I = M::O_I, NST = M::NST, NDIFF = M::NDIFF, NTRIP = M::NTRIP
 constexpr int MAXORD = 5;
 constexpr double FAR = 96485.3321233;      // reference src/structures.jl:10
 constexpr double RGAS = 8.31446261815324;  // reference src/structures.jl:11
@@ -56,9 +68,9 @@ struct CellConst {
   int iso_ref;   // T0 == TREF exactly (temperature_switch, reference custom_functions.jl:1)
 };
 
-struct CellLDS {
-  double phi[MAXORD + 1][NPAD];
-  double ewt[NPAD], yy[NPAD], yp[NPAD], ee[NPAD], delta[NPAD];
+template <class M> struct CellLDS {
+  double phi[MAXORD + 1][M::NPAD];
+  double ewt[M::NPAD], yy[M::NPAD], yp[M::NPAD], ee[M::NPAD], delta[M::NPAD];
   // structured Jacobian pool (cj not included)
   double ceL[NE], ceD[NE], ceU[NE], ceJ[NE];
   double peL[NE], peD[NE], peU[NE], pcL[NE], pcD[NE], pcU[NE], peJ[NE];
@@ -209,7 +221,9 @@ __device__ __forceinline__ double hmean(double beta, double a, double b) { retur
 // ------------------------------------------------------------------------------------------------------------------
 // per-cell constants from theta (build_auxiliary_states!, reference aux...jl:6-52, and the Arrhenius closures)
 // ------------------------------------------------------------------------------------------------------------------
-__device__ inline void cell_setup(CellLDS& S, LaneRegs& R, const Tables* __restrict__ tb, const double* __restrict__ th) {
+template <class M>
+__device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, const double* __restrict__ th) {
+  PL_MODEL(M);
   const int lane = lane_id();
   if (lane == 0) {
     CellConst& c = S.cc;
@@ -262,7 +276,9 @@ __device__ inline void cell_setup(CellLDS& S, LaneRegs& R, const Tables* __restr
 }
 
 // initial_guess!, reference src/states_definition.jl:80-121
-__device__ inline void cell_initial_guess(CellLDS& S, double* Y, double SOC) {
+template <class M>
+__device__ inline void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) {
+  PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const double csp = c.cmaxp * (SOC * (c.thmax_p - c.thmin_p) + c.thmin_p);
@@ -270,7 +286,7 @@ __device__ inline void cell_initial_guess(CellLDS& S, double* Y, double SOC) {
   double Up, Un, d;
   ocv_lco(csp / c.cmaxp, c.T0, c.iso_ref, Up, d);
   ocv_lic6(csn / c.cmaxn, c.T0, c.iso_ref, Un, d);
-  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < (NST + WAVE - 1) / WAVE; k__++, n += WAVE) if (n < NST) {
+  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (n < NST) {
     double v = 0.0;
     if (n < O_CS) v = c.ce0;
     else if (n < O_CS + NP * NR) v = csp;
@@ -285,8 +301,9 @@ __device__ inline void cell_initial_guess(CellLDS& S, double* Y, double SOC) {
 // ------------------------------------------------------------------------------------------------------------------
 // node pass shared by the residual and the Jacobian partials.  Lane i < 30 owns control volume i and edge i (i|i+1).
 // ------------------------------------------------------------------------------------------------------------------
-template <bool WANT_RES, bool WANT_JAC>
-__device__ inline void cell_node_pass(CellLDS& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
+template <bool WANT_RES, bool WANT_JAC, class M>
+__device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
+  PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const int i = lane < NE ? lane : NE - 1;
@@ -403,7 +420,9 @@ __device__ inline void cell_node_pass(CellLDS& S, const double* Y, const double*
 }
 
 // c_s rows (residuals_c_s_avg!, Fickian FDM, residuals.jl:128-180): lane -> (particle = pass*6 + lane/10, row = lane%10)
-__device__ inline void cell_cs_rows(CellLDS& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
+template <class M>
+__device__ inline void cell_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
+  PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
@@ -438,7 +457,9 @@ __device__ inline void cell_cs_rows(CellLDS& S, const LaneRegs& R, const double*
 }
 
 // full residual F(Y, YP) -> Fo (all three are LDS vectors)
-__device__ inline void cell_residual(CellLDS& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo, int mode, double value) {
+template <class M>
+__device__ inline void cell_residual(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo, int mode, double value) {
+  PL_MODEL(M);
   cell_node_pass<true, false>(S, Y, YP, Fo, mode, value);
   cell_cs_rows(S, R, Y, YP, Fo);
   PL_SYNC();
@@ -457,7 +478,9 @@ __device__ __forceinline__ void inv3(const double* A, double* B) {
 }
 
 // node block D_i (3x3 over [c_e, Phi_e, Phi_s]) after eliminating c_s and j ; alg_only: c_e is not an unknown
-__device__ __forceinline__ void node_block(const CellLDS& S, int i, double cj, bool alg_only, double* D) {
+template <class M>
+__device__ __forceinline__ void node_block(const CellLDS<M>& S, int i, double cj, bool alg_only, double* D) {
+  PL_MODEL(M);
   const int sc = sec_of(i);
   const bool elec = sc != 1;
   const int jx = sc == 0 ? i : i - NS;
@@ -480,7 +503,9 @@ __device__ __forceinline__ void node_block(const CellLDS& S, int i, double cj, b
 // lane -> lane-1 (backward) through DPP shifts.  Every lane re-evaluates its own recurrence at every stage: a lane whose
 // predecessor is final reproduces its final value (the update is idempotent), so no per-stage select is needed; lane 0 (LD = 0)
 // and lane NE-1 (GU = 0) are final from the start and the wavefront advances one lane per stage.
-__device__ __forceinline__ void thomas_sweeps(const CellLDS& S, bool alg_only, double& r0, double& r1, double& r2) {
+template <class M>
+__device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only, double& r0, double& r1, double& r2) {
+  PL_MODEL(M);
   const int lane = lane_id();
   const int i = lane < NE ? lane : NE - 1;
   double L[9], Di[9], G[9];
@@ -518,7 +543,9 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS& S, bool alg_only, d
 
 // factor the Newton matrix at the Jacobian partials currently in S (cell_node_pass<.,true> must have run).
 // mode selects the control row; alg_only = the 71x71 algebraic block of the consistent-initialisation Newton.
-__device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
+template <class M>
+__device__ inline void cell_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
+  PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
   // 1. particle resolvent rows: (kappa M - cj I)^-1 = V diag(1/(kappa lam - cj)) W
@@ -593,7 +620,9 @@ __device__ inline void cell_factor(CellLDS& S, LaneRegs& R, const Tables* __rest
 }
 
 // solve J x = b in place (b is an LDS vector of NST entries).  alg_only: only rows/cols NDIFF.. are touched.
-__device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, bool alg_only) {
+template <class M>
+__device__ inline void cell_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_only) {
+  PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const int r = lane % NR, g = lane / NR;
@@ -691,7 +720,9 @@ __device__ inline void cell_solve(CellLDS& S, LaneRegs& R, double* b, int mode, 
 enum JT { JT_CE_L = 1, JT_CE_D, JT_CE_U, JT_CE_J, JT_CS_CS, JT_CS_J, JT_J_CE, JT_J_CS, JT_J_J, JT_J_PE, JT_J_PS,
           JT_PE_CL, JT_PE_CD, JT_PE_CU, JT_PE_L, JT_PE_D, JT_PE_U, JT_PE_J, JT_PS_L, JT_PS_D, JT_PS_U, JT_PS_J, JT_PS_I,
           JT_CTRL_P1, JT_CTRL_M1 };
-__device__ inline double jac_entry(const CellLDS& S, const Tables* __restrict__ tb, unsigned w, double cj) {
+template <class M>
+__device__ inline double jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
+  PL_MODEL(M);
   const int t = w >> 24, a = (w >> 16) & 255, bb = (w >> 8) & 255, cc = w & 255;
   const CellConst& c = S.cc;
   switch (t) {

@@ -23,14 +23,16 @@ struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live 
 
 // device counters live in LDS (S.cnt), incremented by lane 0; indices:
 enum Cnt { C_STEPS, C_RES, C_JAC, C_FACT, C_SOLVE, C_NEWTON, C_ERRFAIL, C_CONVFAIL, C_SUMKP2, C_INIT };
-struct Counters { CellLDS* S; };
-__device__ __forceinline__ void cnt_add(Counters& c, int k, long long v = 1) { if (lane_id() == 0) c.S->cnt[k] += v; }
+struct Counters { long long* cnt; };
+__device__ __forceinline__ void cnt_add(Counters& c, int k, long long v = 1) { if (lane_id() == 0) c.cnt[k] += v; }
 
 // lane-strided sweep over the N state entries: exactly 5 trips (301 = 4*64 + 45), fully unrolled so that the LDS loads of all
 // trips are issued back to back (one latency instead of five); only the last trip is predicated.
-#define PL_VEC(n) _Pragma("unroll") for (int k__ = 0, n = lane; k__ < (NST + WAVE - 1) / WAVE; k__++, n += WAVE) if (k__ < NST / WAVE || n < NST)
+#define PL_VEC(n) _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (k__ < NST / WAVE || n < NST)
 
+template <class M>
 __device__ __forceinline__ double wrms(const double* v, const double* w) {
+  PL_MODEL(M);
   const int lane = lane_id();
   double s = 0.0;
   PL_VEC(n) { const double p = v[n] * w[n]; s += p * p; }
@@ -38,8 +40,10 @@ __device__ __forceinline__ double wrms(const double* v, const double* w) {
 }
 
 // ---- consistent initialisation (newtons_method!) : Y (LDS, in/out), YP (LDS, out).  returns 0 / PLH_ERR_INIT ----
-__device__ inline int cell_init_consistent(CellLDS& S, LaneRegs& R, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
+template <class M>
+__device__ inline int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
                                            int mode, double value, double reltol_init, Counters& cnt) {
+  PL_MODEL(M);
   const int lane = lane_id();
   PL_VEC(n) YP[n] = 0.0;
   PL_SYNC();
@@ -80,7 +84,9 @@ __device__ inline int cell_init_consistent(CellLDS& S, LaneRegs& R, const Tables
 }
 
 // ---- IDA pieces ----
-__device__ inline void ida_reinit(CellLDS& S, IdaScalars& I, const double* y0, const double* yp0, int maxord) {
+template <class M>
+__device__ inline void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0, const double* yp0, int maxord) {
+  PL_MODEL(M);
   const int lane = lane_id();
   I.tn = 0.0; I.nst = 0; I.kk = 0; I.kused = 0; I.hused = 0.0; I.hh = 0.0; I.maxord = maxord;
   I.cjratio = 1.0; I.ss = 20.0; I.phase = 0; I.ns = 0; I.h0_forced = 0.0; I.cj = 0.0; I.cjlast = 0.0; I.cjold = 0.0; I.rr = 0.0; I.knew = 0;
@@ -89,13 +95,17 @@ __device__ inline void ida_reinit(CellLDS& S, IdaScalars& I, const double* y0, c
   PL_SYNC();
 }
 
-__device__ inline void set_ewt(CellLDS& S, double rtol, double atol) {
+template <class M>
+__device__ inline void set_ewt(CellLDS<M>& S, double rtol, double atol) {
+  PL_MODEL(M);
   const int lane = lane_id();
   PL_VEC(n) S.ewt[n] = 1.0 / (rtol * fabs(S.phi[0][n]) + atol);
   PL_SYNC();
 }
 
-__device__ inline double ida_set_coeffs(CellLDS& S, IdaScalars& I) {
+template <class M>
+__device__ inline double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
+  PL_MODEL(M);
   const int lane = lane_id();
   const int kk = I.kk; const double hh = I.hh;
   if (hh != I.hused || kk != I.kused) I.ns = 0;
@@ -138,7 +148,9 @@ __device__ inline double ida_set_coeffs(CellLDS& S, IdaScalars& I) {
 }
 
 // yy = ypred + ee, yp = yppred + cj ee with the predictor re-summed from phi (no separate predictor storage)
-__device__ inline void form_iterate(CellLDS& S, const IdaScalars& I) {
+template <class M>
+__device__ inline void form_iterate(CellLDS<M>& S, const IdaScalars& I) {
+  PL_MODEL(M);
   const int lane = lane_id();
   PL_VEC(n) {
     double a = S.phi[0][n], b = 0.0;
@@ -150,7 +162,9 @@ __device__ inline void form_iterate(CellLDS& S, const IdaScalars& I) {
 }
 
 // IDANls + Newton + convergence test.  0 ok, 1 recoverable failure
-__device__ inline int ida_nls(CellLDS& S, LaneRegs& R, const Tables* tb, IdaScalars& I, int mode, double value, int jac_every_step, Counters& cnt) {
+template <class M>
+__device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, int mode, double value, int jac_every_step, Counters& cnt) {
+  PL_MODEL(M);
   const int lane = lane_id();
   const double epsNewt = 0.33, toldel = 0.0001 * epsNewt;
   int callLSetup = 0;
@@ -213,7 +227,9 @@ __device__ inline int ida_nls(CellLDS& S, LaneRegs& R, const Tables* tb, IdaScal
   return ret;
 }
 
-__device__ inline int ida_test_error(CellLDS& S, IdaScalars& I, double ck, double& err_k, double& err_km1) {
+template <class M>
+__device__ inline int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, double& err_k, double& err_km1) {
+  PL_MODEL(M);
   const int lane = lane_id();
   const int kk = I.kk;
   double s0 = 0, s1 = 0, s2 = 0;
@@ -236,7 +252,9 @@ __device__ inline int ida_test_error(CellLDS& S, IdaScalars& I, double ck, doubl
   return (ck * enorm_k > 1.0) ? 1 : 0;
 }
 
-__device__ inline void ida_restore(CellLDS& S, IdaScalars& I, double saved_t) {
+template <class M>
+__device__ inline void ida_restore(CellLDS<M>& S, IdaScalars& I, double saved_t) {
+  PL_MODEL(M);
   const int lane = lane_id();
   I.tn = saved_t;
   if (lane == 0) for (int j = 1; j <= I.kk; j++) S.ida_psi[j - 1] = S.ida_psi[j] - I.hh;
@@ -244,7 +262,9 @@ __device__ inline void ida_restore(CellLDS& S, IdaScalars& I, double saved_t) {
   PL_SYNC();
 }
 
-__device__ inline void ida_complete_step(CellLDS& S, IdaScalars& I, double err_k, double err_km1) {
+template <class M>
+__device__ inline void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double err_km1) {
+  PL_MODEL(M);
   const int lane = lane_id();
   I.nst++;
   const int kdiff = I.kk - I.kused; I.kused = I.kk; I.hused = I.hh;
@@ -282,7 +302,9 @@ __device__ inline void ida_complete_step(CellLDS& S, IdaScalars& I, double err_k
 }
 
 // IDAGetSolution(t): y -> yo, y' -> ypo (LDS vectors)
-__device__ inline void ida_get_solution(CellLDS& S, const IdaScalars& I, double t, double* yo, double* ypo) {
+template <class M>
+__device__ inline void ida_get_solution(CellLDS<M>& S, const IdaScalars& I, double t, double* yo, double* ypo) {
+  PL_MODEL(M);
   const int lane = lane_id();
   int kord = I.kused; if (kord == 0) kord = 1;
   const double delt = t - I.tn;
@@ -308,8 +330,10 @@ __device__ inline void ida_get_solution(CellLDS& S, const IdaScalars& I, double 
 }
 
 // one IDASolve(ONE_STEP_TSTOP) call: advances, returns y(tret), y'(tret) in S.yy / S.yp.  0 ok, <0 failure
-__device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaScalars& I, double tstop, double& tret, int mode, double value,
+template <class M>
+__device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, double tstop, double& tret, int mode, double value,
                                const plh_opts& o, Counters& cnt) {
+  PL_MODEL(M);
   const int lane = lane_id();
   const double uround = 2.220446049250313e-16;
   if (I.nst == 0) {
@@ -318,7 +342,7 @@ __device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaSca
     double hh = I.h0_forced != 0.0 ? I.h0_forced : o.init_step;
     if (hh == 0.0) {
       hh = 0.001 * tdist;
-      const double ypnorm = wrms(S.phi[1], S.ewt);
+      const double ypnorm = wrms<M>(S.phi[1], S.ewt);
       if (ypnorm > 0.5 / hh) hh = 0.5 / ypnorm;
     }
     if ((I.tn + hh - tstop) * hh > 0.0) hh = (tstop - I.tn) * (1.0 - 4.0 * uround);
@@ -374,10 +398,13 @@ __device__ inline int ida_step(CellLDS& S, LaneRegs& R, const Tables* tb, IdaSca
 // ---- stop conditions (check_simulation_stop!, src/checks.jl:1-224); scalars are wave-uniform ----
 struct PrevVals { double frac, V, SOC, I, c_s_n, c_e_min, eta_pl; };
 
-__device__ __forceinline__ double cellV(const double* Y) { return Y[O_PS] - Y[O_PS + NJ - 1]; }
+template <class M>
+__device__ __forceinline__ double cellV(const double* Y) { return Y[M::O_PS] - Y[M::O_PS + NJ - 1]; }
 
-__device__ inline void check_stop(const CellLDS& S, const plh_run& run, const plh_opts& o, double t, double tf, const double* Y, const double* YP,
+template <class M>
+__device__ inline void check_stop(const CellLDS<M>& S, const plh_run& run, const plh_opts& o, double t, double tf, const double* Y, const double* YP,
                                   double SOC, PrevVals& pv, int& flag) {
+  PL_MODEL(M);
   const double eps = t < 1.0 ? o.reltol : 0.0;
   if (t >= tf) { flag = 0; return; }
   if (!o.check_bounds || run.value_kind == PLH_VAL_REST) return;
@@ -390,7 +417,7 @@ __device__ inline void check_stop(const CellLDS& S, const plh_run& run, const pl
     pv.I = Ic;
   }
   if (run.mode != PLH_MODE_V) {                                                         // check_stop_V, checks.jl:56-81
-    const double V = cellV(Y), dV = cellV(YP);
+    const double V = cellV<M>(Y), dV = cellV<M>(YP);
     if ((b.V_min - V > eps) && dV < 0) { const double f = (pv.V - b.V_min) / (pv.V - V); if (f < pv.frac) { pv.frac = f; flag = 1; } }
     else if ((V - b.V_max > eps) && dV > 0) { const double f = (pv.V - b.V_max) / (pv.V - V); if (f < pv.frac) { pv.frac = f; flag = 2; } }
     pv.V = V;
@@ -425,9 +452,11 @@ struct CellOut {
 
 // the whole protocol for one cell.  Yprev/YPprev: per-cell scratch in HBM holding the previous accepted point (needed only for
 // the back-interpolation at the end of a run; written with coalesced fire-and-forget stores every step).
-__device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
+template <class M>
+__device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
                                      const CellOut& out, int* n_pts_out, plh_run_info* info, Counters& cnt, double* Yfin, double* YPfin,
                                      double* Yprev, double* YPprev) {
+  PL_MODEL(M);
   const int lane = lane_id();
   IdaScalars I;
   int nout = 0;
@@ -437,12 +466,12 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
   if (Yinit) {                                                          // simulate!(sol, ...): continue from sol.Y[end]
     PL_VEC(n) S.yy[n] = Yinit[n];
     PL_SYNC();
-    have_prev = true; t_global = t_init; prev_V = cellV(S.yy); prev_I = S.yy[O_I];
+    have_prev = true; t_global = t_init; prev_V = cellV<M>(S.yy); prev_I = S.yy[O_I];
   }
   auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
     if (lane == 0 && idx < out.max_pts) {
       if (out.t) out.t[idx] = tt;
-      if (out.V) out.V[idx] = cellV(Y);
+      if (out.V) out.V[idx] = cellV<M>(Y);
       if (out.I) out.I[idx] = Y[O_I];
       if (out.SOC) out.SOC[idx] = soc;
       if (out.T) out.T[idx] = T0;
@@ -465,7 +494,7 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
     } else {
       if (run.value_kind == PLH_VAL_HOLD) { value = prev_V; Iguess = prev_V; }
       else if (have_prev && prev_I != 0.0) Iguess = prev_I;
-      else { const double OCV = cellV(S.yy); Iguess = value > OCV ? 1.0 : -1.0; }
+      else { const double OCV = cellV<M>(S.yy); Iguess = value > OCV ? 1.0 : -1.0; }
     }
     PL_SYNC();
     if (lane == 0) S.yy[O_I] = Iguess;
@@ -525,7 +554,7 @@ __device__ inline void cell_simulate(CellLDS& S, LaneRegs& R, const Tables* tb, 
       t_end = ti + t0;
       save_pt(nout - 1, t_end, S.yy, SOC);
     }
-    ri.flag = flag; ri.iterations = iter; ri.t_end = t_end; ri.V = cellV(S.yy); ri.I = S.yy[O_I]; ri.SOC = SOC; ri.T_avg = T0;
+    ri.flag = flag; ri.iterations = iter; ri.t_end = t_end; ri.V = cellV<M>(S.yy); ri.I = S.yy[O_I]; ri.SOC = SOC; ri.T_avg = T0;
     if (lane == 0) info[r] = ri;
     t_global = t_end; have_prev = true; prev_V = ri.V; prev_I = ri.I;
     if (flag < 0) { for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; z.iterations = 0; info[q] = z; } break; }

@@ -22,46 +22,49 @@ using namespace pl;
 // ---------------------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_vec(double* dst, const double* __restrict__ src) {
+template <class M> __device__ __forceinline__ void load_vec(double* dst, const double* __restrict__ src) {
   const int lane = lane_id();
-  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < (NST + WAVE - 1) / WAVE; k__++, n += WAVE) if (n < NST) dst[n] = src[n];
+  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < M::NTRIP; k__++, n += WAVE) if (n < M::NST) dst[n] = src[n];
 }
-__device__ __forceinline__ void store_vec(double* __restrict__ dst, const double* src) {
+template <class M> __device__ __forceinline__ void store_vec(double* __restrict__ dst, const double* src) {
   const int lane = lane_id();
-  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < (NST + WAVE - 1) / WAVE; k__++, n += WAVE) if (n < NST) dst[n] = src[n];
+  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < M::NTRIP; k__++, n += WAVE) if (n < M::NST) dst[n] = src[n];
 }
 
-__global__ __launch_bounds__(64) void k_initial_guess(const Tables* tb, int n_cells, const double* theta, const double* SOC, double* Y) {
-  __shared__ CellLDS S;
+template <class M> __global__ __launch_bounds__(64) void k_initial_guess(const Tables* tb, int n_cells, const double* theta, const double* SOC, double* Y) {
+  __shared__ CellLDS<M> S;
+  constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   cell_initial_guess(S, S.yy, SOC[cell]);
-  store_vec(Y + (size_t)cell * NST, S.yy);
+  store_vec<M>(Y + (size_t)cell * NST, S.yy);
 }
 
-__global__ __launch_bounds__(64) void k_residual(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+template <class M> __global__ __launch_bounds__(64) void k_residual(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                  int mode, double value, double* F) {
-  __shared__ CellLDS S;
+  __shared__ CellLDS<M> S;
+  constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
-  load_vec(S.yy, Y + (size_t)cell * NST); load_vec(S.yp, YP + (size_t)cell * NST);
+  load_vec<M>(S.yy, Y + (size_t)cell * NST); load_vec<M>(S.yp, YP + (size_t)cell * NST);
   PL_SYNC();
   cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
-  store_vec(F + (size_t)cell * NST, S.delta);
+  store_vec<M>(F + (size_t)cell * NST, S.delta);
 }
 
-__global__ __launch_bounds__(64) void k_jacobian(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+template <class M> __global__ __launch_bounds__(64) void k_jacobian(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                  double cj, int mode, double* nz) {
-  __shared__ CellLDS S;
+  __shared__ CellLDS<M> S;
+  constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
-  load_vec(S.yy, Y + (size_t)cell * NST); load_vec(S.yp, YP + (size_t)cell * NST);
+  load_vec<M>(S.yy, Y + (size_t)cell * NST); load_vec<M>(S.yp, YP + (size_t)cell * NST);
   PL_SYNC();
   cell_node_pass<false, true>(S, S.yy, S.yp, S.delta, mode, 0.0);
   PL_SYNC();
@@ -71,35 +74,37 @@ __global__ __launch_bounds__(64) void k_jacobian(const Tables* tb, int n_cells, 
   for (int k = lane_id(); k < nnz; k += WAVE) out[k] = jac_entry(S, tb, code[k], cj);
 }
 
-__global__ __launch_bounds__(64) void k_linear_solve(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+template <class M> __global__ __launch_bounds__(64) void k_linear_solve(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                      double cj, int mode, double* b) {
-  __shared__ CellLDS S;
+  __shared__ CellLDS<M> S;
+  constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
-  load_vec(S.yy, Y + (size_t)cell * NST); load_vec(S.yp, YP + (size_t)cell * NST); load_vec(S.delta, b + (size_t)cell * NST);
+  load_vec<M>(S.yy, Y + (size_t)cell * NST); load_vec<M>(S.yp, YP + (size_t)cell * NST); load_vec<M>(S.delta, b + (size_t)cell * NST);
   PL_SYNC();
   cell_node_pass<false, true>(S, S.yy, S.yp, S.ee, mode, 0.0);
   PL_SYNC();
   cell_factor(S, R, tb, cj, mode, false);
   cell_solve(S, R, S.delta, mode, false);
-  store_vec(b + (size_t)cell * NST, S.delta);
+  store_vec<M>(b + (size_t)cell * NST, S.delta);
 }
 
-__global__ __launch_bounds__(64) void k_init_consistent(const Tables* tb, int n_cells, const double* theta, int mode, double value,
+template <class M> __global__ __launch_bounds__(64) void k_init_consistent(const Tables* tb, int n_cells, const double* theta, int mode, double value,
                                                         double reltol_init, double* Y, double* YP, int* status, int* iters) {
-  __shared__ CellLDS S;
+  __shared__ CellLDS<M> S;
+  constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
-  load_vec(S.yy, Y + (size_t)cell * NST);
+  load_vec<M>(S.yy, Y + (size_t)cell * NST);
   PL_SYNC();
-  Counters cnt; cnt.S = &S; if (lane_id() < 10) S.cnt[lane_id()] = 0;
+  Counters cnt; cnt.cnt = S.cnt; if (lane_id() < 10) S.cnt[lane_id()] = 0;
   PL_SYNC();
   const int rc = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, reltol_init, cnt);
-  store_vec(Y + (size_t)cell * NST, S.yy); store_vec(YP + (size_t)cell * NST, S.yp);
+  store_vec<M>(Y + (size_t)cell * NST, S.yy); store_vec<M>(YP + (size_t)cell * NST, S.yp);
   PL_SYNC();
   if (lane_id() == 0) { if (status) status[cell] = rc; if (iters) iters[cell] = (int)S.cnt[C_INIT]; }
 }
@@ -109,13 +114,14 @@ struct IntegrateArgs {
   plh_outputs out; double* scratch;   // scratch: [n_cells][2][NST]
 };
 
-__global__ __launch_bounds__(64) void k_integrate(IntegrateArgs a) {
-  __shared__ CellLDS S;
+template <class M> __global__ __launch_bounds__(64) void k_integrate(IntegrateArgs a) {
+  __shared__ CellLDS<M> S;
+  constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;
   if (cell >= a.n_cells) return;
   cell_setup(S, R, a.tb, a.theta + (size_t)cell * a.tb->P);
-  Counters cnt; cnt.S = &S; if (lane_id() < 10) S.cnt[lane_id()] = 0;
+  Counters cnt; cnt.cnt = S.cnt; if (lane_id() < 10) S.cnt[lane_id()] = 0;
   if (lane_id() < 8) S.cyc[lane_id()] = 0;
   PL_SYNC();
   PL_TIC();
@@ -157,6 +163,9 @@ static const double DEFAULTS_LCO_ISO[K_COUNT] = {
 
 struct plh_model_s {
   plh_model_desc desc;
+  int variant = 0;                 // index into the instantiated ModelT<> list (PL_DISPATCH)
+  int N = 0, Nd = 0, P = 0;        // states, differential states, theta entries
+  const char* const* key_names = nullptr; const double* key_defaults = nullptr;
   Tables h_tb;
   Tables* d_tb = nullptr;
   std::vector<int> colptr[3], rowval[3];
@@ -168,7 +177,9 @@ struct plh_model_s {
 };
 
 // decode word of the structural Jacobian entry (r, c), 0 if structurally zero
+template <class M>
 static unsigned classify(const Tables& tb, int mode, int r, int c) {
+  PL_MODEL(M);
   auto W = [](int t, int a, int b, int cc) { return (unsigned)((t << 24) | (a << 16) | (b << 8) | cc); };
   auto node_of_j = [](int jx) { return jx < NP ? jx : jx + NS; };
   if (r == O_I) {
@@ -239,6 +250,29 @@ struct Stage {
 #define FINISH(stage) do { if ((stage).kind != PLH_DEVICE) HIPCHK(hipStreamSynchronize((stage).st)); HIPCHK(hipGetLastError()); } while (0)
 
 
+// instantiated model variants
+enum { V_LCO_ISO = 0 };
+#define PL_DISPATCH(m, ...) do { switch ((m)->variant) { \
+    case V_LCO_ISO: { using M = ModelT<PLH_CHEM_LCO_LIC6, false>; __VA_ARGS__; } break; \
+    default: return fail(PLH_E_UNSUPPORTED, "model variant not instantiated"); } } while (0)
+
+template <class M> static int build_patterns(plh_model_s* m) {
+  Tables& tb = m->h_tb;
+  for (int mode = 0; mode < 2; mode++) {
+    m->colptr[mode].assign(M::NST + 1, 0);
+    for (int c = 0; c < M::NST; c++) {
+      for (int r = 0; r < M::NST; r++) { const unsigned w = classify<M>(tb, mode, r, c); if (w) { m->rowval[mode].push_back(r); m->code[mode].push_back(w); } }
+      m->colptr[mode][c + 1] = (int)m->rowval[mode].size();
+    }
+    tb.nnz[mode] = (int)m->rowval[mode].size();
+    if (hipMalloc((void**)&m->d_code[mode], m->code[mode].size() * sizeof(unsigned)) != hipSuccess) return PLH_E_HIP;
+    hipMemcpy(m->d_code[mode], m->code[mode].data(), m->code[mode].size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    tb.csc_code[mode] = m->d_code[mode];
+  }
+  m->N = M::NST; m->Nd = M::NDIFF;
+  return 0;
+}
+
 extern "C" {
 
 const char* plh_last_error(void) { return g_err.c_str(); }
@@ -258,19 +292,11 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   memset(&tb, 0, sizeof(tb));
   memcpy(tb.M, PL_RADIAL_M, sizeof(tb.M)); memcpy(tb.LAM, PL_RADIAL_LAM, sizeof(tb.LAM));
   memcpy(tb.V, PL_RADIAL_V, sizeof(tb.V)); memcpy(tb.W, PL_RADIAL_W, sizeof(tb.W));
-  tb.BJ = PL_RADIAL_BJ_FACTOR; tb.chem = d->chemistry; tb.P = K_COUNT;
+  tb.BJ = PL_RADIAL_BJ_FACTOR; tb.chem = d->chemistry;
+  m->variant = V_LCO_ISO; m->P = K_COUNT; m->key_names = KEY_NAMES_LCO_ISO; m->key_defaults = DEFAULTS_LCO_ISO;
+  tb.P = m->P;
   for (int k = 0; k < K_COUNT; k++) tb.thidx[k] = k;
-  for (int mode = 0; mode < 2; mode++) {
-    m->colptr[mode].assign(NST + 1, 0);
-    for (int c = 0; c < NST; c++) {
-      for (int r = 0; r < NST; r++) { const unsigned w = classify(tb, mode, r, c); if (w) { m->rowval[mode].push_back(r); m->code[mode].push_back(w); } }
-      m->colptr[mode][c + 1] = (int)m->rowval[mode].size();
-    }
-    tb.nnz[mode] = (int)m->rowval[mode].size();
-    if (hipMalloc((void**)&m->d_code[mode], m->code[mode].size() * sizeof(unsigned)) != hipSuccess) { delete m; return fail(PLH_E_HIP, "hipMalloc failed"); }
-    hipMemcpy(m->d_code[mode], m->code[mode].data(), m->code[mode].size() * sizeof(unsigned), hipMemcpyHostToDevice);
-    tb.csc_code[mode] = m->d_code[mode];
-  }
+  { int rc = 0; PL_DISPATCH(m, rc = build_patterns<M>(m)); if (rc != 0) { delete m; return fail(rc, "pattern construction failed"); } }
   if (hipMalloc((void**)&m->d_tb, sizeof(Tables)) != hipSuccess) { delete m; return fail(PLH_E_HIP, "hipMalloc failed"); }
   hipMemcpy(m->d_tb, &tb, sizeof(Tables), hipMemcpyHostToDevice);
   hipEventCreate(&m->ev0); hipEventCreate(&m->ev1);
@@ -289,17 +315,17 @@ void plh_model_destroy(plh_model_t m) {
   delete m;
 }
 
-int plh_n_states(plh_model_t m) { return m ? NST : PLH_E_ARG; }
-int plh_n_diff(plh_model_t m) { return m ? NDIFF : PLH_E_ARG; }
-int plh_n_theta(plh_model_t m) { return m ? K_COUNT : PLH_E_ARG; }
-const char* plh_theta_key(plh_model_t m, int i) { return (m && i >= 0 && i < K_COUNT) ? KEY_NAMES_LCO_ISO[i] : nullptr; }
-double plh_theta_default(plh_model_t m, int i) { return (m && i >= 0 && i < K_COUNT) ? DEFAULTS_LCO_ISO[i] : NAN; }
+int plh_n_states(plh_model_t m) { return m ? m->N : PLH_E_ARG; }
+int plh_n_diff(plh_model_t m) { return m ? m->Nd : PLH_E_ARG; }
+int plh_n_theta(plh_model_t m) { return m ? m->P : PLH_E_ARG; }
+const char* plh_theta_key(plh_model_t m, int i) { return (m && i >= 0 && i < m->P) ? m->key_names[i] : nullptr; }
+double plh_theta_default(plh_model_t m, int i) { return (m && i >= 0 && i < m->P) ? m->key_defaults[i] : NAN; }
 
 int plh_jac_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval) {
   if (!m || !nnz) return fail(PLH_E_ARG, "null argument");
   if (mode < 0 || mode > 1) return fail(PLH_E_UNSUPPORTED, "mode not available for this model");
   *nnz = (int)m->rowval[mode].size();
-  if (colptr) memcpy(colptr, m->colptr[mode].data(), (NST + 1) * sizeof(int));
+  if (colptr) memcpy(colptr, m->colptr[mode].data(), (m->N + 1) * sizeof(int));
   if (rowval) memcpy(rowval, m->rowval[mode].data(), m->rowval[mode].size() * sizeof(int));
   return 0;
 }
@@ -307,19 +333,19 @@ int plh_jac_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval)
 int plh_initial_guess(plh_model_t m, int n, const double* theta, const double* SOC, double* Y, int kind, void* stream) {
   CHECK_MODEL(m); if (n <= 0 || !theta || !SOC || !Y) return fail(PLH_E_ARG, "bad argument");
   Stage s(kind, stream);
-  const double* th = s.in(theta, (size_t)n * K_COUNT); const double* so = s.in(SOC, n); double* y = s.buf(Y, (size_t)n * NST, false);
-  PL_LAUNCH(k_initial_guess, n, WAVE, s.st, m->d_tb, n, th, so, y);
-  FINISH(s); s.back(Y, y, (size_t)n * NST);
+  const double* th = s.in(theta, (size_t)n * m->P); const double* so = s.in(SOC, n); double* y = s.buf(Y, (size_t)n * m->N, false);
+  PL_DISPATCH(m, PL_LAUNCH(k_initial_guess<M>, n, WAVE, s.st, m->d_tb, n, th, so, y));
+  FINISH(s); s.back(Y, y, (size_t)n * m->N);
   return 0;
 }
 
 int plh_residual(plh_model_t m, int n, const double* theta, const double* Y, const double* YP, int mode, double value, double* F, int kind, void* stream) {
   CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP || !F) return fail(PLH_E_ARG, "bad argument");
   Stage s(kind, stream);
-  const double* th = s.in(theta, (size_t)n * K_COUNT); const double* y = s.in(Y, (size_t)n * NST); const double* yp = s.in(YP, (size_t)n * NST);
-  double* f = s.buf(F, (size_t)n * NST, false);
-  PL_LAUNCH(k_residual, n, WAVE, s.st, m->d_tb, n, th, y, yp, mode, value, f);
-  FINISH(s); s.back(F, f, (size_t)n * NST);
+  const double* th = s.in(theta, (size_t)n * m->P); const double* y = s.in(Y, (size_t)n * m->N); const double* yp = s.in(YP, (size_t)n * m->N);
+  double* f = s.buf(F, (size_t)n * m->N, false);
+  PL_DISPATCH(m, PL_LAUNCH(k_residual<M>, n, WAVE, s.st, m->d_tb, n, th, y, yp, mode, value, f));
+  FINISH(s); s.back(F, f, (size_t)n * m->N);
   return 0;
 }
 
@@ -327,9 +353,9 @@ int plh_jacobian(plh_model_t m, int n, const double* theta, const double* Y, con
   CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP || !nzval) return fail(PLH_E_ARG, "bad argument");
   Stage s(kind, stream);
   const size_t nnz = m->rowval[mode].size();
-  const double* th = s.in(theta, (size_t)n * K_COUNT); const double* y = s.in(Y, (size_t)n * NST); const double* yp = s.in(YP, (size_t)n * NST);
+  const double* th = s.in(theta, (size_t)n * m->P); const double* y = s.in(Y, (size_t)n * m->N); const double* yp = s.in(YP, (size_t)n * m->N);
   double* z = s.buf(nzval, (size_t)n * nnz, false);
-  PL_LAUNCH(k_jacobian, n, WAVE, s.st, m->d_tb, n, th, y, yp, cj, mode, z);
+  PL_DISPATCH(m, PL_LAUNCH(k_jacobian<M>, n, WAVE, s.st, m->d_tb, n, th, y, yp, cj, mode, z));
   FINISH(s); s.back(nzval, z, (size_t)n * nnz);
   return 0;
 }
@@ -337,10 +363,10 @@ int plh_jacobian(plh_model_t m, int n, const double* theta, const double* Y, con
 int plh_linear_solve(plh_model_t m, int n, const double* theta, const double* Y, const double* YP, double cj, int mode, double* b, int kind, void* stream) {
   CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP || !b) return fail(PLH_E_ARG, "bad argument");
   Stage s(kind, stream);
-  const double* th = s.in(theta, (size_t)n * K_COUNT); const double* y = s.in(Y, (size_t)n * NST); const double* yp = s.in(YP, (size_t)n * NST);
-  double* bb = s.buf(b, (size_t)n * NST, true);
-  PL_LAUNCH(k_linear_solve, n, WAVE, s.st, m->d_tb, n, th, y, yp, cj, mode, bb);
-  FINISH(s); s.back(b, bb, (size_t)n * NST);
+  const double* th = s.in(theta, (size_t)n * m->P); const double* y = s.in(Y, (size_t)n * m->N); const double* yp = s.in(YP, (size_t)n * m->N);
+  double* bb = s.buf(b, (size_t)n * m->N, true);
+  PL_DISPATCH(m, PL_LAUNCH(k_linear_solve<M>, n, WAVE, s.st, m->d_tb, n, th, y, yp, cj, mode, bb));
+  FINISH(s); s.back(b, bb, (size_t)n * m->N);
   return 0;
 }
 
@@ -348,12 +374,12 @@ int plh_init_consistent(plh_model_t m, int n, const double* theta, int mode, dou
                         int* iters, int kind, void* stream) {
   CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP) return fail(PLH_E_ARG, "bad argument");
   Stage s(kind, stream);
-  const double* th = s.in(theta, (size_t)n * K_COUNT);
-  double* y = s.buf(Y, (size_t)n * NST, true); double* yp = s.buf(YP, (size_t)n * NST, false);
+  const double* th = s.in(theta, (size_t)n * m->P);
+  double* y = s.buf(Y, (size_t)n * m->N, true); double* yp = s.buf(YP, (size_t)n * m->N, false);
   int* st = s.buf(status, n, false); int* it = s.buf(iters, n, false);
-  PL_LAUNCH(k_init_consistent, n, WAVE, s.st, m->d_tb, n, th, mode, value, reltol_init, y, yp, st, it);
+  PL_DISPATCH(m, PL_LAUNCH(k_init_consistent<M>, n, WAVE, s.st, m->d_tb, n, th, mode, value, reltol_init, y, yp, st, it));
   FINISH(s);
-  s.back(Y, y, (size_t)n * NST); s.back(YP, yp, (size_t)n * NST); s.back(status, st, n); s.back(iters, it, n);
+  s.back(Y, y, (size_t)n * m->N); s.back(YP, yp, (size_t)n * m->N); s.back(status, st, n); s.back(iters, it, n);
   return 0;
 }
 
@@ -371,13 +397,13 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   Stage s(kind, stream);
   if (m->scratch_cells < (size_t)n) {
     if (m->scratch) hipFree(m->scratch);
-    HIPCHK(hipMalloc((void**)&m->scratch, (size_t)n * 2 * NST * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&m->scratch, (size_t)n * 2 * m->N * sizeof(double)));
     m->scratch_cells = n;
   }
   IntegrateArgs a;
   a.tb = m->d_tb; a.n_cells = n; a.n_runs = n_runs; a.opts = *opts; a.scratch = m->scratch;
-  a.theta = s.in(theta, (size_t)n * K_COUNT); a.SOC0 = s.in(SOC0, n);
-  a.Y_init = s.in(Y_init, (size_t)n * NST); a.t_init = s.in(t_init, n);
+  a.theta = s.in(theta, (size_t)n * m->P); a.SOC0 = s.in(SOC0, n);
+  a.Y_init = s.in(Y_init, (size_t)n * m->N); a.t_init = s.in(t_init, n);
   // the protocol is always host memory
   if (m->runs_cap < n_runs) { if (m->d_runs) hipFree(m->d_runs); HIPCHK(hipMalloc((void**)&m->d_runs, n_runs * sizeof(plh_run))); m->runs_cap = n_runs; }
   HIPCHK(hipMemcpyAsync(m->d_runs, runs, n_runs * sizeof(plh_run), hipMemcpyHostToDevice, s.st));
@@ -386,16 +412,16 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   a.out = *out;
   a.out.t = s.buf(out->t, np, false); a.out.V = s.buf(out->V, np, false); a.out.I = s.buf(out->I, np, false);
   a.out.SOC = s.buf(out->SOC, np, false); a.out.T_avg = s.buf(out->T_avg, np, false); a.out.n_pts = s.buf(out->n_pts, n, false);
-  a.out.Y_final = s.buf(out->Y_final, (size_t)n * NST, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * NST, false);
+  a.out.Y_final = s.buf(out->Y_final, (size_t)n * m->N, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * m->N, false);
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
   hipEventRecord(m->ev0, s.st);
-  PL_LAUNCH(k_integrate, n, WAVE, s.st, a);
+  PL_DISPATCH(m, PL_LAUNCH(k_integrate<M>, n, WAVE, s.st, a));
   hipEventRecord(m->ev1, s.st);
   m->timed = true;
   FINISH(s);
   s.back(out->t, a.out.t, np); s.back(out->V, a.out.V, np); s.back(out->I, a.out.I, np); s.back(out->SOC, a.out.SOC, np);
   s.back(out->T_avg, a.out.T_avg, np); s.back(out->n_pts, a.out.n_pts, n);
-  s.back(out->Y_final, a.out.Y_final, (size_t)n * NST); s.back(out->YP_final, a.out.YP_final, (size_t)n * NST);
+  s.back(out->Y_final, a.out.Y_final, (size_t)n * m->N); s.back(out->YP_final, a.out.YP_final, (size_t)n * m->N);
   s.back(out->run_info, a.out.run_info, (size_t)n * n_runs); s.back(out->counters, a.out.counters, n);
   return 0;
 }
