@@ -16,7 +16,7 @@ import math
 import numpy as np
 
 from . import _capi as cap
-from .params import EXIT_REASONS, Bounds, Opts, bounds_LCO, calc_I1C, theta_LCO
+from .params import EXIT_REASONS, Bounds, Opts, bounds_LCO, bounds_NMC, calc_I1C, theta_LCO, theta_NMC
 
 LCO = "LCO"
 NMC = "NMC"
@@ -31,18 +31,18 @@ class Model:
     """The reference's `model` struct, reduced to the data contracts of the hot path (src/structures.jl:336-345)."""
 
     def __init__(self, cathode, N, temperature, aging, lib_path=None):
-        if cathode != LCO:
-            raise NotImplementedError("only the LCO/LiC6 chemistry is implemented on the device in this round")
+        if cathode not in (LCO, NMC):
+            raise NotImplementedError("chemistry %r is outside the hot-path scope (LCO and NMC are built)" % (cathode,))
         self.cathode = cathode
         self.N = N
         self.temperature = bool(temperature)
         self.aging = aging
-        self.θ = theta_LCO()
+        self.θ = theta_LCO() if cathode == LCO else theta_NMC()
         self.θ["I1C"] = calc_I1C(self.θ)
-        self.bounds = bounds_LCO()
+        self.bounds = bounds_LCO() if cathode == LCO else bounds_NMC()
         self.opts = Opts()
         self._lib = cap.load(lib_path)
-        desc = cap.ModelDesc(cap.CHEM_LCO, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, int(self.temperature), int(bool(aging)), 8)
+        desc = cap.ModelDesc(cap.CHEM_LCO if cathode == LCO else cap.CHEM_NMC, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, int(self.temperature), int(bool(aging)), 8)
         h = C.c_void_p()
         cap.check(self._lib, self._lib.plh_model_create(C.byref(desc), C.byref(h)), "plh_model_create")
         self._h = h
@@ -50,6 +50,7 @@ class Model:
         self.N.diff = self._lib.plh_n_diff(h)
         self.N.alg = self.N.tot - self.N.diff
         self.θ_keys = [self._lib.plh_theta_key(h, i).decode("utf-8") for i in range(self._lib.plh_n_theta(h))]
+        self.variant = "%s_iso%s" % (cathode.lower(), "_sei" if aging else "")      # name of the matching oracle variant (tests)
 
     theta = property(lambda self: self.θ)
 

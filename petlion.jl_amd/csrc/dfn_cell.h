@@ -43,10 +43,11 @@ constexpr double FAR = 96485.3321233;      // reference src/structures.jl:10
 constexpr double RGAS = 8.31446261815324;  // reference src/structures.jl:11
 constexpr double TREF = 298.15;
 
-// theta keys the device reads (LCO isothermal: this is exactly the sorted key list)
-enum Key { K_D_n, K_D_p, K_D_s, K_D_sn, K_D_sp, K_Ea_D_sn, K_Ea_D_sp, K_Ea_k_n, K_Ea_k_p, K_Rp_n, K_Rp_p, K_T0,
-           K_brugg_n, K_brugg_p, K_brugg_s, K_c_e0, K_c_max_n, K_c_max_p, K_k_n, K_k_p, K_l_n, K_l_p, K_l_s, K_tplus,
-           K_th_max_n, K_th_max_p, K_th_min_n, K_th_min_p, K_sig_n, K_sig_p, K_eps_fn, K_eps_fp, K_eps_n, K_eps_p,
+// theta keys the device reads: the union over the model variants; Tables::thidx maps a key to its position in the variant's
+// theta vector (the reference's sorted theta_keys) or -1 when the variant does not have it.
+enum Key { K_D_n, K_D_p, K_D_s, K_D_sn, K_D_sp, K_Ea_D_sn, K_Ea_D_sp, K_Ea_k_n, K_Ea_k_p, K_M_n, K_R_SEI, K_Rp_n, K_Rp_p, K_T0, K_Uref_s,
+           K_brugg_n, K_brugg_p, K_brugg_s, K_c_e0, K_c_max_n, K_c_max_p, K_i_0_jside, K_k_n, K_k_n_aging, K_k_p, K_l_n, K_l_p, K_l_s,
+           K_tplus, K_w, K_th_max_n, K_th_max_p, K_th_min_n, K_th_min_p, K_rho_n, K_sig_n, K_sig_p, K_eps_fn, K_eps_fp, K_eps_n, K_eps_p,
            K_eps_s, K_COUNT };
 
 // read-only model tables in device memory
@@ -206,6 +207,27 @@ __device__ __forceinline__ void ocv_lic6(double x, double T, int iso_ref, double
   }
 }
 
+// OCV_NMC, custom_functions.jl:154-162 (dU/dT = 0)
+__device__ __forceinline__ void ocv_nmc(double x, double& U, double& dUdx) {
+  U = -10.72 * x * x * x * x + 23.88 * x * x * x - 16.77 * x * x + 2.595 * x + 4.563;
+  dUdx = -4 * 10.72 * x * x * x + 3 * 23.88 * x * x - 2 * 16.77 * x + 2.595;
+}
+// OCV_LiC6_with_NMC, custom_functions.jl:164-174 (dU/dT = 0)
+__device__ __forceinline__ void ocv_lic6_nmc(double x, double& U, double& dUdx) {
+  const double e1 = exp(-61.79 * x), e2 = exp(-665.8 * x), e3 = exp(39.42 * x - 41.92);
+  const double a1 = 25.59 * x - 4.099, a2 = 32.49 * x - 15.74;
+  U = 0.1493 + 0.8493 * e1 + 0.3824 * e2 - e3 - 0.03131 * atan(a1) - 0.009434 * atan(a2);
+  dUdx = -61.79 * 0.8493 * e1 - 665.8 * 0.3824 * e2 - 39.42 * e3 - 0.03131 * 25.59 / (1.0 + a1 * a1) - 0.009434 * 32.49 / (1.0 + a2 * a2);
+}
+// D_eff(c_e, T), custom_functions.jl:83 (NMC system default, params.jl:407): 1e-4 * 10^(-4.43 - 54/(T - 229 - 5e-3 c) - 0.22e-3 c)
+__device__ __forceinline__ void deff_nmc(double c, double T, double& D, double& dD) {
+  const double LN10 = 2.302585092994046;
+  const double u = T - 229 - 5e-3 * c;
+  const double ex = -4.43 - 54.0 / u - 0.22e-3 * c;
+  D = 1e-4 * exp(LN10 * ex);
+  dD = D * LN10 * (-54.0 * 5e-3 / (u * u) - 0.22e-3);
+}
+
 // sinh and cosh from ONE expm1 and one division (ocml's sinh alone costs ~670 cycles of dependent latency on gfx950):
 //   u = e^x - 1 ;  sinh x = (u + u/(u+1))/2 ,  cosh x = sinh x + 1/(u+1)   -- accurate for small |x| as well (no cancellation)
 __device__ __forceinline__ void sinh_cosh(double x, double& sh, double& ch) {
@@ -239,9 +261,9 @@ __device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     c.bf[0] = pow(c.eps[0], th[ix[K_brugg_p]]);
     c.bf[1] = pow(c.eps[1], th[ix[K_brugg_s]]);
     c.bf[2] = pow(c.eps[2], th[ix[K_brugg_n]]);
-    c.Dc[0] = th[ix[K_D_p]] * c.bf[0];                      // D_eff_linear, custom_functions.jl:59-69
-    c.Dc[1] = th[ix[K_D_s]] * c.bf[1];
-    c.Dc[2] = th[ix[K_D_n]] * c.bf[2];
+    if (M::CHEM == PLH_CHEM_LCO_LIC6) {                     // D_eff_linear, custom_functions.jl:59-69
+      c.Dc[0] = th[ix[K_D_p]] * c.bf[0]; c.Dc[1] = th[ix[K_D_s]] * c.bf[1]; c.Dc[2] = th[ix[K_D_n]] * c.bf[2];
+    } else { c.Dc[0] = c.Dc[1] = c.Dc[2] = 0.0; }           // NMC: D_eff(c_e, T) per control volume (node pass)
     const double Rp_p = th[ix[K_Rp_p]], Rp_n = th[ix[K_Rp_n]];
     c.a_p = 3 * esp / Rp_p; c.a_n = 3 * esn / Rp_n;         // build_a!, aux...jl:124-139
     c.sig_p = th[ix[K_sig_p]] * esp; c.sig_n = th[ix[K_sig_n]] * esn;
@@ -284,8 +306,8 @@ __device__ inline void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) 
   const double csp = c.cmaxp * (SOC * (c.thmax_p - c.thmin_p) + c.thmin_p);
   const double csn = c.cmaxn * (SOC * (c.thmax_n - c.thmin_n) + c.thmin_n);
   double Up, Un, d;
-  ocv_lco(csp / c.cmaxp, c.T0, c.iso_ref, Up, d);
-  ocv_lic6(csn / c.cmaxn, c.T0, c.iso_ref, Un, d);
+  if (M::CHEM == PLH_CHEM_LCO_LIC6) { ocv_lco(csp / c.cmaxp, c.T0, c.iso_ref, Up, d); ocv_lic6(csn / c.cmaxn, c.T0, c.iso_ref, Un, d); }
+  else { ocv_nmc(csp / c.cmaxp, Up, d); ocv_lic6_nmc(csn / c.cmaxn, Un, d); }
   _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (n < NST) {
     double v = 0.0;
     if (n < O_CS) v = c.ce0;
@@ -325,8 +347,11 @@ __device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const doub
   const double bfc = sc == 0 ? bf0 : (sc == 1 ? bf1 : bf2);
   double K, dK; keff(ce, cT0, K, dK);
   K *= bfc; dK *= bfc;
-  const double D = sc == 0 ? dc0 : (sc == 1 ? dc1 : dc2);
+  double D, dD;
+  if (M::CHEM == PLH_CHEM_LCO_LIC6) { D = sc == 0 ? dc0 : (sc == 1 ? dc1 : dc2); dD = 0.0; }
+  else { deff_nmc(ce, cT0, D, dD); D *= bfc; dD *= bfc; }
   const double ce_n = shift_down1(ce), pe_n = shift_down1(pe), K_n = shift_down1(K), dK_n = shift_down1(dK), D_n = shift_down1(D);
+  const double dD_n = (WANT_JAC && M::CHEM != PLH_CHEM_LCO_LIC6) ? shift_down1(dD) : 0.0;
   // edge i : geometry (numerical_tools.jl:106-215)
   double beta = 0.5, dist = h;
   if (i == NP - 1) { beta = (h0 / 2) / (h1 / 2 + h0 / 2); dist = h0 / 2 + h1 / 2; }
@@ -352,8 +377,13 @@ __device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const doub
   const double kk = sc == 0 ? ckp : ckn;
   const double sg = sc == 0 ? csg_p : csg_n;
   double U = 0, dU = 0;
-  if (sc == 0) ocv_lco(cs / cmax, cT0, ciso, U, dU);
-  else if (sc == 2) ocv_lic6(cs / cmax, cT0, ciso, U, dU);
+  if (M::CHEM == PLH_CHEM_LCO_LIC6) {
+    if (sc == 0) ocv_lco(cs / cmax, cT0, ciso, U, dU);
+    else if (sc == 2) ocv_lic6(cs / cmax, cT0, ciso, U, dU);
+  } else {
+    if (sc == 0) ocv_nmc(cs / cmax, U, dU);
+    else if (sc == 2) ocv_lic6_nmc(cs / cmax, U, dU);
+  }
   const double eta = ps - pe - U;
   const double arg = ce * cs * (cmax - cs);
   const double sq = sqrt(arg > 0.0 ? arg : 0.0);
@@ -390,7 +420,9 @@ __device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const doub
     double Ea = edge ? (pe - pe_n) * dKh_a / dist + cKfac * dg_a : 0.0;
     double Eb = edge ? (pe - pe_n) * dKh_b / dist + cKfac * dg_b : 0.0;
     double we = edge ? w : 0.0;
-    double Na = edge ? -Dh / dist : 0.0, Nb = edge ? Dh / dist : 0.0;     // D_eff_linear: dD/dc = 0
+    // N = Dh (c_{i+1} - c_i)/dist ; Dh = harmonic mean of D_i, D_{i+1} (dD/dc = 0 for D_eff_linear)
+    const double dDh_a = dD * beta * D_n * D_n / (denD * denD), dDh_b = dD_n * (1 - beta) * D * D / (denD * denD);
+    double Na = edge ? (dDh_a * (ce_n - ce) - Dh) / dist : 0.0, Nb = edge ? (dDh_b * (ce_n - ce) + Dh) / dist : 0.0;
     const double Ea_p = shift_up1(Ea), Eb_p = shift_up1(Eb), we_p = shift_up1(we), Na_p = shift_up1(Na), Nb_p = shift_up1(Nb);
     if (act) {
       const double he = h * epsc;

@@ -151,15 +151,33 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return fail(PLH_E_HIP, std::string(#x) + ": " + hipGetErrorString(e__)); } while (0)
 
-static const char* const KEY_NAMES_LCO_ISO[K_COUNT] = {
+// names of the Key enum entries (reference Symbols, UTF-8)
+static const char* const KEY_ENUM_NAMES[K_COUNT] = {
+    "D_n", "D_p", "D_s", "D_sn", "D_sp", "Ea_D_sn", "Ea_D_sp", "Ea_k_n", "Ea_k_p", "M_n", "R_SEI", "Rp_n", "Rp_p", "T₀", "Uref_s",
+    "brugg_n", "brugg_p", "brugg_s", "c_e₀", "c_max_n", "c_max_p", "i_0_jside", "k_n", "k_n_aging", "k_p", "l_n", "l_p", "l_s",
+    "t₊", "w", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "ρ_n", "σ_n", "σ_p", "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s"};
+// per variant: the sorted theta_keys the reference's generated functions would receive (generate_functions.jl:327-363, 387) and
+// the chemistry defaults (reference src/params.jl:5-117, 176-226 LCO/LiC6; 295-367, 436-452 NMC/LiC6_NMC)
+static const char* const KEYS_LCO_ISO[] = {
     "D_n", "D_p", "D_s", "D_sn", "D_sp", "Ea_D_sn", "Ea_D_sp", "Ea_k_n", "Ea_k_p", "Rp_n", "Rp_p", "T₀", "brugg_n", "brugg_p", "brugg_s",
     "c_e₀", "c_max_n", "c_max_p", "k_n", "k_p", "l_n", "l_p", "l_s", "t₊", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "σ_n", "σ_p",
     "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s"};
-// chemistry defaults, reference src/params.jl:5-117 (LCO, LiC6), 176-226 (system_LCO_LiC6)
-static const double DEFAULTS_LCO_ISO[K_COUNT] = {
+static const double DEFAULTS_LCO_ISO[] = {
     7.5e-10, 7.5e-10, 7.5e-10, 3.9e-14, 1e-14, 5000.0, 5000.0, 5000.0, 5000.0, 2e-6, 2e-6, 25 + 273.15, 4.0, 4.0, 4.0,
     1000.0, 30555.0, 51554.0, 5.0310e-11, 2.334e-11, 88e-6, 80e-6, 25e-6, 0.364, 0.85510, 0.49550, 0.01429, 0.99174, 100.0, 100.0,
     0.0326, 0.025, 0.485, 0.385, 0.724};
+static const char* const KEYS_NMC_ISO[] = {
+    "D_sn", "D_sp", "Ea_D_sn", "Ea_D_sp", "Ea_k_n", "Ea_k_p", "Rp_n", "Rp_p", "T₀", "brugg_n", "brugg_p", "brugg_s", "c_e₀", "c_max_n", "c_max_p",
+    "k_n", "k_p", "l_n", "l_p", "l_s", "t₊", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "σ_n", "σ_p", "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s"};
+static const double DEFAULTS_NMC_ISO[] = {
+    1.5e-14, 2e-14, 4e4, 2.5e4, 3e4, 3e4, 10e-6, 7.5e-6, 25 + 273.15, 1.5, 1.5, 1.5, 1200.0, 31080.0, 51830.0,
+    6.3466e-10, 6.3066e-10, 48e-6, 41.6e-6, 25e-6, 0.38, 0.790813, 0.359749, 0.001, 0.955473, 100.0, 100.0, 0.038, 0.12, 0.3, 0.3, 0.4};
+struct VariantInfo { int chem, sei, nkeys; const char* const* keys; const double* defaults; };
+enum { V_LCO_ISO = 0, V_NMC_ISO = 1, V_COUNT };
+static const VariantInfo VARIANTS[V_COUNT] = {
+    {PLH_CHEM_LCO_LIC6, 0, 35, KEYS_LCO_ISO, DEFAULTS_LCO_ISO},
+    {PLH_CHEM_NMC_LIC6, 0, 32, KEYS_NMC_ISO, DEFAULTS_NMC_ISO},
+};
 
 struct plh_model_s {
   plh_model_desc desc;
@@ -251,9 +269,9 @@ struct Stage {
 
 
 // instantiated model variants
-enum { V_LCO_ISO = 0 };
 #define PL_DISPATCH(m, ...) do { switch ((m)->variant) { \
     case V_LCO_ISO: { using M = ModelT<PLH_CHEM_LCO_LIC6, false>; __VA_ARGS__; } break; \
+    case V_NMC_ISO: { using M = ModelT<PLH_CHEM_NMC_LIC6, false>; __VA_ARGS__; } break; \
     default: return fail(PLH_E_UNSUPPORTED, "model variant not instantiated"); } } while (0)
 
 template <class M> static int build_patterns(plh_model_s* m) {
@@ -280,8 +298,11 @@ const char* plh_last_error(void) { return g_err.c_str(); }
 int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   if (!d || !out) return fail(PLH_E_ARG, "null argument");
   if (d->real_bytes != 8) return fail(PLH_E_UNSUPPORTED, "only fp64 (real_bytes = 8) is implemented");
-  if (d->chemistry != PLH_CHEM_LCO_LIC6) return fail(PLH_E_UNSUPPORTED, "chemistry: only LCO/LiC6 is implemented in this round");
-  if (d->temperature || d->aging_SEI) return fail(PLH_E_UNSUPPORTED, "temperature / aging models are not implemented in this round");
+  if (d->chemistry != PLH_CHEM_LCO_LIC6 && d->chemistry != PLH_CHEM_NMC_LIC6) return fail(PLH_E_UNSUPPORTED, "unknown chemistry");
+  if (d->temperature) return fail(PLH_E_UNSUPPORTED, "temperature = true is not implemented on the device yet");
+  int variant = -1;
+  for (int v = 0; v < V_COUNT; v++) if (VARIANTS[v].chem == d->chemistry && VARIANTS[v].sei == (d->aging_SEI ? 1 : 0)) variant = v;
+  if (variant < 0) return fail(PLH_E_UNSUPPORTED, "this chemistry / aging combination is not instantiated on the device yet");
   if (d->N_p != NP || d->N_s != NS || d->N_n != NN || d->N_r_p != NR || d->N_r_n != NR)
     return fail(PLH_E_UNSUPPORTED, "discretisation: only N_p = N_s = N_n = N_r_p = N_r_n = 10 is instantiated");
   int ndev = 0;
@@ -293,9 +314,12 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   memcpy(tb.M, PL_RADIAL_M, sizeof(tb.M)); memcpy(tb.LAM, PL_RADIAL_LAM, sizeof(tb.LAM));
   memcpy(tb.V, PL_RADIAL_V, sizeof(tb.V)); memcpy(tb.W, PL_RADIAL_W, sizeof(tb.W));
   tb.BJ = PL_RADIAL_BJ_FACTOR; tb.chem = d->chemistry;
-  m->variant = V_LCO_ISO; m->P = K_COUNT; m->key_names = KEY_NAMES_LCO_ISO; m->key_defaults = DEFAULTS_LCO_ISO;
+  m->variant = variant; m->P = VARIANTS[variant].nkeys; m->key_names = VARIANTS[variant].keys; m->key_defaults = VARIANTS[variant].defaults;
   tb.P = m->P;
-  for (int k = 0; k < K_COUNT; k++) tb.thidx[k] = k;
+  for (int k = 0; k < K_COUNT; k++) {
+    tb.thidx[k] = -1;
+    for (int q = 0; q < m->P; q++) if (!strcmp(KEY_ENUM_NAMES[k], m->key_names[q])) tb.thidx[k] = q;
+  }
   { int rc = 0; PL_DISPATCH(m, rc = build_patterns<M>(m)); if (rc != 0) { delete m; return fail(rc, "pattern construction failed"); } }
   if (hipMalloc((void**)&m->d_tb, sizeof(Tables)) != hipSuccess) { delete m; return fail(PLH_E_HIP, "hipMalloc failed"); }
   hipMemcpy(m->d_tb, &tb, sizeof(Tables), hipMemcpyHostToDevice);

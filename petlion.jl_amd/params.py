@@ -31,6 +31,20 @@ def theta_LCO():
     return th
 
 
+def theta_NMC():
+    """NMC cathode + LiC6_NMC anode + system_NMC_LiC6: reference src/params.jl:295-332, 334-367, 436-452.
+    The SEI block (R_SEI ... w, rho_n) is NOT defined by the reference for this chemistry; aging=:SEI borrows the LiC6 values of
+    src/params.jl:98-110 and rho_n = 2500 (params.jl:90) -- a build decision, stated in DESIGN.md."""
+    th = OrderedDict()
+    th.update({"D_sp": 2e-14, "k_p": 6.3066e-10, "θ_min_p": 0.955473, "θ_max_p": 0.359749, "l_p": 41.6e-6, "σ_p": 100.0, "ϵ_p": 0.3,
+               "ϵ_fp": 0.12, "brugg_p": 1.5, "c_max_p": 51830.0, "Rp_p": 7.5e-6, "Ea_D_sp": 2.5e4, "Ea_k_p": 3e4})
+    th.update({"D_sn": 1.5e-14, "k_n": 6.3466e-10, "θ_max_n": 0.790813, "θ_min_n": 0.001, "l_n": 48e-6, "σ_n": 100.0, "ϵ_n": 0.3,
+               "ϵ_fn": 0.038, "brugg_n": 1.5, "c_max_n": 31080.0, "Rp_n": 10e-6, "Ea_D_sn": 4e4, "Ea_k_n": 3e4})
+    th.update({"l_s": 25e-6, "ϵ_s": 0.4, "brugg_s": 1.5, "t₊": 0.38, "c_e₀": 1200.0, "T₀": 25 + 273.15, "T_amb": 25 + 273.15})
+    th.update({"R_SEI": 0.01, "M_n": 7.3e-4, "k_n_aging": 1.0, "i_0_jside": 1.5e-6, "Uref_s": 0.4, "w": 2.0, "ρ_n": 2500.0})
+    return th
+
+
 def calc_I1C(th):
     """1C current density [A/m^2], reference src/physics_equations/auxiliary_states_and_coefficients.jl:632-647."""
     eps_sp = 1.0 - (th["ϵ_fp"] + th["ϵ_p"])
@@ -66,6 +80,11 @@ class Bounds:
 def bounds_LCO():
     """src/params.jl:233-252"""
     return Bounds(V_min=2.5, V_max=4.3, SOC_min=0.0, SOC_max=1.0, T_max=55 + 273.15)
+
+
+def bounds_NMC():
+    """src/params.jl:456-475"""
+    return Bounds(V_min=2.8, V_max=4.2, SOC_min=0.0, SOC_max=1.0)
 
 
 class Opts:

@@ -41,3 +41,14 @@ def hip_model(pkg):
     import __graft_entry__ as g
     g.build_hip()
     return pkg.petlion(pkg.LCO)
+
+
+@pytest.fixture(scope="session")
+def emu_model_nmc(pkg):
+    import build_emu
+    return pkg.petlion(pkg.NMC, _lib_path=build_emu.build())
+
+
+@pytest.fixture(scope="session")
+def hip_model_nmc(pkg, hip_model):
+    return pkg.petlion(pkg.NMC)

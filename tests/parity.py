@@ -3,14 +3,13 @@ import ctypes as C
 
 import numpy as np
 
-VARIANT = "lco_iso"
 SECTIONS = [("c_e", 0, 30), ("c_s", 30, 230), ("j", 230, 250), ("Phi_e", 250, 280), ("Phi_s", 280, 300), ("I", 300, 301)]
 
 
-def realistic_states(O, th, n, seed=0):
+def realistic_states(O, th, n, seed=0, variant="lco_iso"):
     """states along a 1C discharge + random perturbations (so that every term of the equations is exercised)."""
     rng = np.random.default_rng(seed)
-    ro = O.simulate(VARIANT, th, 1.0, [dict(mode=O.MODE_I, value=-1.0, tf=600.0 * (1 + 4 * rng.random()))])
+    ro = O.simulate(variant, th, 1.0, [dict(mode=O.MODE_I, value=-1.0, tf=600.0 * (1 + 4 * rng.random()))])
     Ys, YPs = [], []
     for _ in range(n):
         Ys.append(ro["Y"] * (1 + 1e-3 * rng.standard_normal(ro["Y"].size)))
@@ -19,7 +18,7 @@ def realistic_states(O, th, n, seed=0):
 
 
 def check_keys_and_pattern(p, O):
-    cap = p._lib
+    VARIANT = p.variant
     meta = O.meta(VARIANT)
     assert p.θ_keys == meta["theta_keys"]
     assert np.array_equal(p.theta_vector(), np.array(meta["theta_default"]))
@@ -33,10 +32,11 @@ def check_keys_and_pattern(p, O):
 
 
 def check_evaluators(p, O, n_cells=3):
+    VARIANT = p.variant
     lib, h = p._lib, p._h
     th = p.theta_vector()
     N = p.N.tot
-    Y, YP = realistic_states(O, th, n_cells)
+    Y, YP = realistic_states(O, th, n_cells, variant=VARIANT)
     Th = np.tile(th, (n_cells, 1))
     Th[:, p.θ_keys.index("D_sp")] *= np.linspace(0.5, 2.0, n_cells)
     Th[:, p.θ_keys.index("k_n")] *= np.linspace(2.0, 0.5, n_cells)
@@ -77,7 +77,8 @@ def check_evaluators(p, O, n_cells=3):
                 assert np.abs(x[i, a:e] - xo[a:e]).max() <= 1e-7 * (np.abs(xo[a:e]).max() + 1e-300), (mode, i, name)
 
 
-def check_init(p, O):
+def check_init(p, O, V0_expected=2.863495104606893):
+    VARIANT = p.variant
     lib, h = p._lib, p._h
     th = p.theta_vector()
     N = p.N.tot
@@ -87,12 +88,13 @@ def check_init(p, O):
     Y, YP = Y0.copy(), np.zeros(N)
     st, it = np.zeros(1, np.int32), np.zeros(1, np.int32)
     assert lib.plh_init_consistent(h, 1, th.ctypes.data, 0, 2.0, 1e-3, Y.ctypes.data, YP.ctypes.data, st.ctypes.data, it.ctypes.data, 0, None) == 0
-    assert st[0] == 0 and it[0] == ito == 4
+    assert st[0] == 0 and it[0] == ito
     assert np.abs(Y - Yo).max() <= 1e-12 * np.abs(Yo).max()
     # the finite-difference estimate of YP_alg is intrinsically noisy (difference quotient of a Newton update): 1e-6 of scale
     assert np.abs(YP - YPo).max() <= 1e-6 * np.abs(YPo).max()
     V0 = Y[280] - Y[299]
-    assert abs(V0 - 2.863495104606893) < 1e-10       # reference examples/model_inputs_and_outputs.ipynb:152
+    if V0_expected is not None:
+        assert abs(V0 - V0_expected) < 1e-10       # reference examples/model_inputs_and_outputs.ipynb:152
     return V0
 
 

@@ -52,3 +52,16 @@ def test_c4_sweep_cells_pinned_initial_step(emu_model, O, pkg):
     o = pkg.Opts(); o.init_step = 1e-2
     n_same, errs = tg.sweep_check(pkg, emu_model, O, 6, opts=o, oopts=O.default_opts(init_step=1e-2))
     assert n_same == 6 and errs[-1] <= 1e-6, (n_same, errs)
+
+
+def test_nmc_chemistry_evaluators_and_discharge(emu_model_nmc, O, pkg):
+    """second chemistry (NMC / LiC6_NMC, reference src/params.jl:295-507): nonlinear D_eff(c_e,T), its own OCVs, brugg = 1.5"""
+    p = emu_model_nmc
+    parity.check_keys_and_pattern(p, O)
+    parity.check_evaluators(p, O, n_cells=3)
+    parity.check_init(p, O, None)
+    Th = pkg.theta_matrix(p, 1)
+    ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0)
+    ro = O.simulate("nmc_iso", Th[0], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}]))
+    assert ro["runs"][0]["flag"] == 1                      # NMC bounds: V_min = 2.8 fires before SOC_min
+    parity.compare_trajectory(ens, 0, ro, rtol_state=1e-6)

@@ -174,3 +174,15 @@ def test_gitt_like_rest_hold_chain(hip_model, O, pkg):
     assert abs(ens.run_info[0, -1]["t_end"] - 4 * 780.0) < 1e-5
     assert abs(ens.run_info[0, -1]["SOC"] - 4 * 180 / 3600) < 1e-6
     assert parity.state_rel_err(ens.Y[0], ro["Y"]) < 1e-4
+
+
+def test_nmc_chemistry(hip_model_nmc, O, pkg):
+    p = hip_model_nmc
+    parity.check_keys_and_pattern(p, O)
+    parity.check_evaluators(p, O, n_cells=4)
+    parity.check_init(p, O, None)
+    Th = pkg.theta_matrix(p, 16, {"D_sp": p.θ["D_sp"] * np.linspace(0.6, 1.6, 16)})
+    ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0)
+    for i in (0, 7, 15):
+        ro = O.simulate("nmc_iso", Th[i], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}]))
+        parity.compare_trajectory(ens, i, ro, rtol_state=5e-6)
