@@ -36,6 +36,9 @@ class Model:
         self.cathode = cathode
         self.N = N
         self.temperature = bool(temperature)
+        if aging not in (False, None, True, "SEI"):
+            raise NotImplementedError("aging=%r: the reference knows false and :SEI (src/params.jl:119-174)" % (aging,))
+        aging = "SEI" if aging in (True, "SEI") else False
         self.aging = aging
         self.θ = theta_LCO() if cathode == LCO else theta_NMC()
         self.θ["I1C"] = calc_I1C(self.θ)

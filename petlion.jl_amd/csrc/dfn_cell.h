@@ -9,7 +9,7 @@
 //   stop logic    check_simulation_stop! etc.        (reference src/checks.jl:1-249, src/model_evaluation.jl:369-382)
 //
 // Discretisation handled: N_p = N_s = N_n = 10, N_r_p = N_r_n = 10 (the reference defaults, src/params.jl:124-136),
-// isothermal, no aging (configs C1/C2/C4 of SURVEY.md 8d).  Finite-volume rows are evaluated in conservative
+// isothermal, LCO/LiC6 or NMC/LiC6, with or without SEI aging (configs C1/C2/C4/C5 of SURVEY.md 8d).  Finite-volume rows are evaluated in conservative
 // edge-flux form (row i = flux_i - flux_{i-1}), which is algebraically identical to the reference's matrix form
 // (residuals.jl:6-106, 554-654) and lets 29 lanes own the 29 control-volume edges.
 //
@@ -37,7 +37,8 @@ template <int CHEM_, bool SEI_> struct ModelT {
   static constexpr int NTRIP = (NST + WAVE - 1) / WAVE;
 };
 using ModelLcoIso = ModelT<PLH_CHEM_LCO_LIC6, false>;
-#define PL_MODEL(M) [[maybe_unused]] constexpr int O_J = M::O_J, O_PE = M::O_PE, O_PS = M::O_PS, O_I = M::O_I, NST = M::NST, NDIFF = M::NDIFF, NTRIP = M::NTRIP
+#define PL_MODEL(M) [[maybe_unused]] constexpr int O_J = M::O_J, O_PE = M::O_PE, O_PS = M::O_PS, O_I = M::O_I, NST = M::NST, NDIFF = M::NDIFF, NTRIP = M::NTRIP, \
+                                       O_FILM = M::O_FILM, O_SOH = M::O_SOH, O_JS = M::O_JS
 constexpr int MAXORD = 5;
 constexpr double FAR = 96485.3321233;      // reference src/structures.jl:10
 constexpr double RGAS = 8.31446261815324;  // reference src/structures.jl:11
@@ -66,7 +67,18 @@ struct CellConst {
   double a_p, a_n, sig_p, sig_n, kp, kn, cmaxp, cmaxn, kap_p, kap_n, bj_p, bj_n;
   double T0, fRT, Kfac, I1C, tplus, JI0, JI29, ce0;
   double thmin_p, thmax_p, thmin_n, thmax_n;
+  double R_SEI, rkag, Mrho, i0F, wexp, Uref;   // SEI: R_SEI, 1/k_n_aging, M_n/rho_n, i_0_jside/F, w, Uref_s
   int iso_ref;   // T0 == TREF exactly (temperature_switch, reference custom_functions.jl:1)
+};
+
+// Jacobian pool of the SEI rows (anode nodes k = 0..NN-1); empty for models without aging so that their LDS footprint is unchanged
+template <bool SEI> struct SeiPool {};
+template <> struct SeiPool<true> {
+  double jjJ[NN], jjF[NN];                                          // d(j row)/d(j, film)
+  double jsPS[NN], jsPE[NN], jsJ[NN], jsJS[NN], jsF[NN], jsI[NN];   // d(j_s row)/d(Phi_s, Phi_e, j, j_s, film, I)
+  double Wl[NN][9];                                                 // inverse of the node-local (j, j_s, film) block
+  double sohw[NN];                                                  // d(rhs_SOH)/d j_s: trapezoid + end-extrapolation weights
+  double cjf;                                                       // cj of the current factorisation
 };
 
 template <class M> struct CellLDS {
@@ -77,7 +89,8 @@ template <class M> struct CellLDS {
   double peL[NE], peD[NE], peU[NE], pcL[NE], pcD[NE], pcU[NE], peJ[NE];
   double gce[NJ], gcs[NJ], gpe[NJ], gps[NJ], psJ[NJ];
   // eliminated system
-  double dj[NJ], fS[NE], fP[NE], fQ[NE];
+  double dj[NJ], nphi[NE][3];      // j pivot; phi_c = omega . A_ux[:,c] (node block D[r][c] -= t_r phi_c, t = (ceJ, peJ, psJ))
+  double colI[NE][3];              // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
   double Dinv[NE][9], LD[NE][9];   // Thomas factors: D'^-1 and L D'^-1(prev)
   double Ainv[2][NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
   double Mr[NR * NR];               // radial operator (copy of Tables::M)
@@ -85,6 +98,7 @@ template <class M> struct CellLDS {
   double w9[NJ];
   double sig[2];
   double kapv[2];
+  SeiPool<M::SEI> sei;
   // wave-uniform BDF coefficient arrays (dynamically indexed by the order -> LDS, not registers/scratch)
   double ida_psi[MAXORD + 1], ida_alpha[MAXORD + 1], ida_beta[MAXORD + 1], ida_sigma[MAXORD + 1], ida_gamma[MAXORD + 1];
   double ida_out[4];
@@ -291,6 +305,26 @@ __device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     c.JI29 = -c.I1C * c.h[2] / c.sig_n;                     // d(Phi_s row of last n node)/dI
     c.ce0 = th[ix[K_c_e0]];
     S.kapv[0] = c.kap_p; S.kapv[1] = c.kap_n;
+    c.R_SEI = c.rkag = c.Mrho = c.i0F = c.wexp = c.Uref = 0.0;
+    if constexpr (M::SEI) {
+      c.R_SEI = th[ix[K_R_SEI]]; c.rkag = 1.0 / th[ix[K_k_n_aging]]; c.Mrho = th[ix[K_M_n]] / th[ix[K_rho_n]];
+      c.i0F = th[ix[K_i_0_jside]] / FAR; c.wexp = th[ix[K_w]]; c.Uref = th[ix[K_Uref_s]];
+      // residuals_SOH!, residuals.jl:278-297: rhs_SOH = F a_n/(3600 I1C) * trapz(x l_n, [extrap_0(j_s[1:3]); j_s; extrap_0(j_s[end:-1:end-2])])
+      // (extrapolate_section / extrap_x_0, external.jl:469-523) -- linear in j_s, so it is a fixed weight vector
+      double x[NN + 2], wq[NN + 2], e[3];
+      x[0] = 0.0; x[NN + 1] = 1.0;
+      for (int k = 0; k < NN; k++) x[k + 1] = 1.0 / (2 * NN) + k * ((1.0 - 1.0 / NN) / (NN - 1));
+      for (int m = 0; m < NN + 2; m++) wq[m] = 0.5 * ((m > 0 ? x[m] - x[m - 1] : 0.0) + (m < NN + 1 ? x[m + 1] - x[m] : 0.0));
+      for (int u = 0; u < 3; u++) {       // extrapolation to 0 of the parabola through (x1..x3, unit vector u)
+        const double y0 = u == 0, y1 = u == 1, y2 = u == 2, x0 = x[1], x1 = x[2], x2 = x[3];
+        const double q = (y2 - y0 - (x2 - x0) / (x1 - x0) * (y1 - y0)) / (x2 * x2 - x0 * x0 - (x1 * x1 - x0 * x0) / (x1 - x0) * (x2 - x0));
+        e[u] = y0 - q * x0 * x0 - (y1 - y0 - q * (x1 * x1 - x0 * x0)) / (x1 - x0) * x0;
+      }
+      const double C = FAR * c.a_n / (3600.0 * c.I1C) * ln;
+      for (int k = 0; k < NN; k++)
+        S.sei.sohw[k] = C * (wq[k + 1] + (k < 3 ? wq[0] * e[k] : 0.0) + (k > NN - 4 ? wq[NN + 1] * e[NN - 1 - k] : 0.0));
+      S.sei.cjf = 0.0;
+    }
   }
   for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->M[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; }
   for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
@@ -312,9 +346,10 @@ __device__ inline void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) 
     double v = 0.0;
     if (n < O_CS) v = c.ce0;
     else if (n < O_CS + NP * NR) v = csp;
-    else if (n < O_J) v = csn;
+    else if (n < N_CECS) v = csn;
     else if (n >= O_PS && n < O_PS + NP) v = Up;
-    else if (n >= O_PS + NP && n < O_I) v = Un;
+    else if (n >= O_PS + NP && n < O_PS + NJ) v = Un;
+    else if (M::SEI && n == O_SOH) v = 1.0;               // film = 0, SOH = 1, j_s = 0 (states_definition.jl:80-121)
     Y[n] = v;
   }
   PL_SYNC();
@@ -337,6 +372,12 @@ __device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const doub
   const double ce = Y[O_CE + i], pe = Y[O_PE + i];
   const double jv_l = Y[O_J + jx], ps_l = Y[O_PS + jx], cs_l = Y[O_CS + jx * NR + NR - 1], yI = Y[O_I];
   const double ypce = WANT_RES ? YP[O_CE + i] : 0.0;
+  // SEI (anode nodes): side-reaction flux j_s, film thickness, film resistance R_film = R_SEI + film/k_n_aging (aux...jl:272-300)
+  const int ks = (M::SEI && sc == 2) ? i - (NP + NS) : 0;
+  double js = 0.0, film = 0.0, ypfilm = 0.0;
+  if constexpr (M::SEI) { js = Y[O_JS + ks]; film = Y[O_FILM + ks]; if (WANT_RES) ypfilm = YP[O_FILM + ks]; if (sc != 2) { js = 0.0; film = 0.0; } }
+  const double cRSEI = c.R_SEI, crkag = c.rkag, cMrho = c.Mrho, ci0F = c.i0F, cwexp = c.wexp, cUref = c.Uref;
+  const double Rfilm = cRSEI + film * crkag;
   const double h0 = c.h[0], h1 = c.h[1], h2 = c.h[2], e0 = c.eps[0], e1 = c.eps[1], e2 = c.eps[2];
   const double bf0 = c.bf[0], bf1 = c.bf[1], bf2 = c.bf[2], dc0 = c.Dc[0], dc1 = c.Dc[1], dc2 = c.Dc[2];
   const double cT0 = c.T0, cKfac = c.Kfac, ctplus = c.tplus, cfRT = c.fRT, cI1C = c.I1C;
@@ -384,7 +425,8 @@ __device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const doub
     if (sc == 0) ocv_nmc(cs / cmax, U, dU);
     else if (sc == 2) ocv_lic6_nmc(cs / cmax, U, dU);
   }
-  const double eta = ps - pe - U;
+  const double jt = jv + js;                             // j_total (aux...jl:160-178) drives the c_e / Phi_e / Phi_s sources
+  const double eta = (M::SEI && sc == 2) ? ps - pe - U - FAR * jv * Rfilm : ps - pe - U;
   const double arg = ce * cs * (cmax - cs);
   const double sq = sqrt(arg > 0.0 ? arg : 0.0);
   const double xx = cfRT * eta;
@@ -393,18 +435,29 @@ __device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const doub
   const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
   if (WANT_RES) {
     if (act) {
-      const double src = elec ? (1 - ctplus) * 1.0 * a * jv : 0.0;
+      const double src = elec ? (1 - ctplus) * 1.0 * a * jt : 0.0;
       Fo[O_CE + i] = ((Nf - Nm) / h + src) / epsc - ypce;                 // residuals_c_e!, residuals.jl:6-106
-      Fo[O_PE + i] = (i < NE - 1) ? (E - Em - (elec ? h * FAR * a * jv : 0.0)) : pe;   // residuals_Φ_e!, residuals.jl:554-654
+      Fo[O_PE + i] = (i < NE - 1) ? (E - Em - (elec ? h * FAR * a * jt : 0.0)) : pe;   // residuals_Φ_e!, residuals.jl:554-654
       if (elec) {
         Fo[O_J + jx] = 2.0 * kk * sq * sh - jv;                                        // residuals_j!, residuals.jl:491-517
         double lap = first ? (-ps + ps_n) : (last ? (ps_p - ps) : (ps_p - 2 * ps + ps_n));
-        double f = h * h * a * FAR * jv;
+        double f = h * h * a * FAR * jt;
         const double Idens = yI * cI1C;
         if (i == 0) f += -Idens * h;
         if (i == NE - 1) f += Idens * h;
         Fo[O_PS + jx] = lap - f / sg;                                                  // residuals_Φ_s!, residuals.jl:656-703
       }
+    }
+    if constexpr (M::SEI) {
+      const double Idens = yI * cI1C;
+      double calc = 0.0;                                                               // residuals_j_s!, residuals.jl:519-552
+      if (Idens > 0.0) calc = -(ci0F * pow(Idens / cI1C, cwexp)) * exp(-cfRT * (ps - pe - cUref - FAR * jt * Rfilm));
+      if (act && sc == 2) {
+        Fo[O_JS + ks] = js - calc;
+        Fo[O_FILM + ks] = -js * cMrho - ypfilm;                                        // residuals_film!, residuals.jl:260-276
+      }
+      const double soh = wave_sum((act && sc == 2) ? S.sei.sohw[ks] * js : 0.0);       // residuals_SOH!, residuals.jl:278-297
+      if (lane == 0) Fo[O_SOH] = soh - YP[O_SOH];
     }
     if (lane == 0) {                                                                   // scalar_residual!, scalar_residual.jl:167-172
       Fo[O_I] = (mode == PLH_MODE_I) ? (yI - value) : (Y[O_PS] - Y[O_PS + NJ - 1] - value);
@@ -446,6 +499,24 @@ __device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const doub
         S.gps[jx] = 2.0 * kk * sq * ch * cfRT;
         S.gpe[jx] = -S.gps[jx];
         S.psJ[jx] = -h * h * a * FAR / sg;
+        if constexpr (M::SEI) {
+          if (sc == 2) {
+            S.sei.jjJ[ks] = -1.0 - S.gps[jx] * FAR * Rfilm;  // d(j row)/dj: eta_n carries -F j R_film
+            S.sei.jjF[ks] = -S.gps[jx] * FAR * jv * crkag;   // d(j row)/d film
+            const double Idens = yI * cI1C;
+            if (Idens > 0.0) {
+              const double Cr = Idens / cI1C;
+              const double Ex = exp(-cfRT * (ps - pe - cUref - FAR * jt * Rfilm));
+              const double aAE = cfRT * ci0F * pow(Cr, cwexp) * Ex;
+              S.sei.jsPS[ks] = -aAE; S.sei.jsPE[ks] = aAE;
+              S.sei.jsJ[ks] = aAE * FAR * Rfilm; S.sei.jsJS[ks] = 1.0 + aAE * FAR * Rfilm;
+              S.sei.jsF[ks] = aAE * FAR * jt * crkag;
+              S.sei.jsI[ks] = cwexp * ci0F * pow(Cr, cwexp - 1.0) * Ex;
+            } else {
+              S.sei.jsPS[ks] = 0.0; S.sei.jsPE[ks] = 0.0; S.sei.jsJ[ks] = 0.0; S.sei.jsJS[ks] = 1.0; S.sei.jsF[ks] = 0.0; S.sei.jsI[ks] = 0.0;
+            }
+          }
+        }
       }
     }
   }
@@ -522,8 +593,8 @@ __device__ __forceinline__ void node_block(const CellLDS<M>& S, int i, double cj
   if (elec) {
     const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
     D[8] = (first || last) ? -1.0 : -2.0;
-    const double gc = alg_only ? 0.0 : S.gce[jx], ge = S.gpe[jx], gs = S.gps[jx];
-    const double fs = alg_only ? 0.0 : S.fS[i], fp = S.fP[i], fq = S.fQ[i];
+    const double gc = S.nphi[i][0], ge = S.nphi[i][1], gs = S.nphi[i][2];      // phi (already zero in column c_e when alg_only)
+    const double fs = alg_only ? 0.0 : S.ceJ[i], fp = S.peJ[i], fq = S.psJ[jx];
     D[0] -= fs * gc; D[1] -= fs * ge; D[2] -= fs * gs;
     D[3] -= fp * gc; D[4] -= fp * ge; D[5] -= fp * gs;
     D[6] -= fq * gc; D[7] -= fq * ge; D[8] -= fq * gs;
@@ -596,17 +667,48 @@ __device__ inline void cell_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __r
     }
   }
   PL_SYNC();
-  // 2. Schur-complemented j pivot and the j-elimination factors
+  // 2. node-local elimination.  Without SEI the local unknown is j (pivot d = -1 - gcs sigma bj after the particle Schur complement);
+  //    with SEI the anode nodes eliminate u = (j, j_s, film) through the inverse W of their 3x3 local block.  Both cases reduce to
+  //    D[r][c] -= t_r phi_c with t = (ceJ, peJ, psJ) (j and j_s enter the node rows only through j_total) and phi = omega . A_ux,
+  //    omega = W[j,:] + W[j_s,:]; the j_s rows also depend on I, which adds -t_r omega_{j_s} d(j_s row)/dI to the column of I.
   if (lane < NE) {
     const int i = lane, sc = sec_of(i);
+    double ph0 = 0.0, ph1 = 0.0, ph2 = 0.0, cI0 = 0.0, cI1 = 0.0, cI2 = 0.0;
     if (sc != 1) {
       const int jx = sc == 0 ? i : i - NS;
       const double bj = sc == 0 ? c.bj_p : c.bj_n;
-      const double d = alg_only ? -1.0 : (-1.0 - S.gcs[jx] * S.sig[sc == 0 ? 0 : 1] * bj);
-      S.dj[jx] = d;
-      S.fS[i] = S.ceJ[i] / d; S.fP[i] = S.peJ[i] / d; S.fQ[i] = S.psJ[jx] / d;
-    } else { S.fS[i] = 0; S.fP[i] = 0; S.fQ[i] = 0; }
+      const double schur = alg_only ? 0.0 : S.gcs[jx] * S.sig[sc == 0 ? 0 : 1] * bj;
+      if (i == 0) cI2 = c.JI0;
+      if (i == NE - 1) cI2 = c.JI29;
+      bool local3 = false;
+      if constexpr (M::SEI) {
+        if (sc == 2) {
+          const int k = i - (NP + NS);
+          double A[9], Wm[9];
+          A[0] = S.sei.jjJ[k] - schur; A[1] = 0.0; A[2] = alg_only ? 0.0 : S.sei.jjF[k];
+          A[3] = S.sei.jsJ[k]; A[4] = S.sei.jsJS[k]; A[5] = alg_only ? 0.0 : S.sei.jsF[k];
+          A[6] = 0.0; A[7] = alg_only ? 0.0 : -c.Mrho; A[8] = alg_only ? 1.0 : -cj;
+          inv3(A, Wm);
+          for (int q = 0; q < 9; q++) S.sei.Wl[k][q] = Wm[q];
+          const double w0 = Wm[0] + Wm[3], w1 = Wm[1] + Wm[4];
+          ph0 = alg_only ? 0.0 : w0 * S.gce[jx];
+          ph1 = w0 * S.gpe[jx] + w1 * S.sei.jsPE[k];
+          ph2 = w0 * S.gps[jx] + w1 * S.sei.jsPS[k];
+          const double qI = w1 * S.sei.jsI[k];
+          cI0 -= (alg_only ? 0.0 : S.ceJ[i]) * qI; cI1 -= S.peJ[i] * qI; cI2 -= S.psJ[jx] * qI;
+          local3 = true;
+        }
+      }
+      if (!local3) {
+        const double d = -1.0 - schur;
+        S.dj[jx] = d;
+        ph0 = alg_only ? 0.0 : S.gce[jx] / d; ph1 = S.gpe[jx] / d; ph2 = S.gps[jx] / d;
+      }
+    }
+    S.nphi[i][0] = ph0; S.nphi[i][1] = ph1; S.nphi[i][2] = ph2;
+    S.colI[i][0] = cI0; S.colI[i][1] = cI1; S.colI[i][2] = cI2;
   }
+  if constexpr (M::SEI) { if (lane == 0) S.sei.cjf = cj; }
   PL_SYNC();
   // 3. block-Thomas factorisation as a systolic sweep: lane i owns node i; at iteration i lane i receives Dinv_{i-1} from lane i-1
   //    through DPP shifts, forms LD_i = L_i Dinv_{i-1} and D'_i = D_i - LD_i U_{i-1}, inverts it and keeps the result.
@@ -644,7 +746,8 @@ __device__ inline void cell_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __r
   PL_SYNC();
   // 4. border vector for modes whose control row is not "I = value":  x2 = T^-1 (column of I)
   if (mode != PLH_MODE_I) {
-    double r0 = 0.0, r1 = 0.0, r2 = lane == 0 ? c.JI0 : (lane == NE - 1 ? c.JI29 : 0.0);
+    const int il = lane < NE ? lane : NE - 1;
+    double r0 = lane < NE ? S.colI[il][0] : 0.0, r1 = lane < NE ? S.colI[il][1] : 0.0, r2 = lane < NE ? S.colI[il][2] : 0.0;
     thomas_sweeps(S, alg_only, r0, r1, r2);
     if (lane < NE) { S.x2[lane][0] = r0; S.x2[lane][1] = r1; S.x2[lane][2] = r2; }
     PL_SYNC();
@@ -688,20 +791,33 @@ __device__ inline void cell_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mod
   }
   PL_SYNC();
   // b. fold c_s and j elimination into the node right-hand sides
-  double bjp = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0;
-  int jx = 0; bool elec = false;
+  double bjp = 0.0, bjs = 0.0, bfl = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0;
+  int jx = 0; bool elec = false, sei_node = false;
   if (lane < NE) {
     const int i = lane, sc = sec_of(i);
     elec = sc != 1; jx = sc == 0 ? i : i - NS;
+    sei_node = M::SEI && sc == 2;
     double r0 = alg_only ? 0.0 : b[O_CE + i], r1 = b[O_PE + i], r2 = 0.0;
     if (elec) {
       bjp = b[O_J + jx] - (alg_only ? 0.0 : S.gcs[jx] * S.w9[jx]);
       r2 = b[O_PS + jx];
-      if (!alg_only) r0 -= S.fS[i] * bjp;
-      r1 -= S.fP[i] * bjp; r2 -= S.fQ[i] * bjp;
+      double beta;                          // omega . b_u : what the eliminated local unknowns feed back into the node rows
+      bool local3 = false;
+      if constexpr (M::SEI) {
+        if (sc == 2) {
+          const int k = i - (NP + NS);
+          bjs = b[O_JS + k]; bfl = alg_only ? 0.0 : b[O_FILM + k];
+          const double* Wm = S.sei.Wl[k];
+          beta = (Wm[0] + Wm[3]) * bjp + (Wm[1] + Wm[4]) * bjs + (Wm[2] + Wm[5]) * bfl;
+          local3 = true;
+        }
+      }
+      if (!local3) beta = bjp / S.dj[jx];
+      if (!alg_only) r0 -= S.ceJ[i] * beta;
+      r1 -= S.peJ[i] * beta; r2 -= S.psJ[jx] * beta;
       if (mode == PLH_MODE_I) {             // control row: 1 * x_I = b_I
-        if (i == 0) r2 -= c.JI0 * b[O_I];
-        if (i == NE - 1) r2 -= c.JI29 * b[O_I];
+        const double bI = b[O_I];
+        r0 -= S.colI[i][0] * bI; r1 -= S.colI[i][1] * bI; r2 -= S.colI[i][2] * bI;
       }
     }
     m0 = r0; m1 = r1; m2 = r2;
@@ -719,7 +835,8 @@ __device__ inline void cell_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mod
     if (lane < NE) { mx[0] -= xI * S.x2[lane][0]; mx[1] -= xI * S.x2[lane][1]; mx[2] -= xI * S.x2[lane][2]; }
   }
   PL_SYNC();
-  // e. back-substitute j, write node unknowns
+  // e. back-substitute the node-local unknowns (j; with SEI also j_s and film), write node unknowns
+  double djs = 0.0;
   if (lane < NE) {
     const int i = lane;
     if (!alg_only) b[O_CE + i] = mx[0];
@@ -727,8 +844,27 @@ __device__ inline void cell_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mod
     if (elec) {
       b[O_PS + jx] = mx[2];
       const double gc = alg_only ? 0.0 : S.gce[jx];
-      b[O_J + jx] = (bjp - gc * mx[0] - S.gpe[jx] * mx[1] - S.gps[jx] * mx[2]) / S.dj[jx];
+      const double v0 = bjp - gc * mx[0] - S.gpe[jx] * mx[1] - S.gps[jx] * mx[2];
+      bool local3 = false;
+      if constexpr (M::SEI) {
+        if (sei_node) {
+          const int k = i - (NP + NS);
+          const double* Wm = S.sei.Wl[k];
+          const double v1 = bjs - S.sei.jsPE[k] * mx[1] - S.sei.jsPS[k] * mx[2] - S.sei.jsI[k] * xI;
+          b[O_J + jx] = Wm[0] * v0 + Wm[1] * v1 + Wm[2] * bfl;
+          djs = Wm[3] * v0 + Wm[4] * v1 + Wm[5] * bfl;
+          b[O_JS + k] = djs;
+          if (!alg_only) b[O_FILM + k] = Wm[6] * v0 + Wm[7] * v1 + Wm[8] * bfl;
+          djs *= S.sei.sohw[k];
+          local3 = true;
+        }
+      }
+      if (!local3) b[O_J + jx] = v0 / S.dj[jx];
     }
+  }
+  if constexpr (M::SEI) {                   // SOH row: sum_k sohw_k dj_s,k - cj dSOH = b_SOH (decoupled from everything else)
+    const double sd = wave_sum(djs);
+    if (lane == 0 && !alg_only) b[O_SOH] = (sd - b[O_SOH]) / S.sei.cjf;
   }
   if (lane == 0) b[O_I] = xI;
   PL_SYNC();
@@ -751,7 +887,8 @@ __device__ inline void cell_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mod
 //   word = type<<24 | a<<16 | b<<8 | c
 enum JT { JT_CE_L = 1, JT_CE_D, JT_CE_U, JT_CE_J, JT_CS_CS, JT_CS_J, JT_J_CE, JT_J_CS, JT_J_J, JT_J_PE, JT_J_PS,
           JT_PE_CL, JT_PE_CD, JT_PE_CU, JT_PE_L, JT_PE_D, JT_PE_U, JT_PE_J, JT_PS_L, JT_PS_D, JT_PS_U, JT_PS_J, JT_PS_I,
-          JT_CTRL_P1, JT_CTRL_M1 };
+          JT_CTRL_P1, JT_CTRL_M1,
+          JT_CE_JS, JT_PE_JS, JT_PS_JS, JT_J_F, JT_F_JS, JT_F_F, JT_SOH_JS, JT_SOH_SOH, JT_JS_PS, JT_JS_PE, JT_JS_J, JT_JS_JS, JT_JS_F, JT_JS_I };
 template <class M>
 __device__ inline double jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
   PL_MODEL(M);
@@ -766,7 +903,7 @@ __device__ inline double jac_entry(const CellLDS<M>& S, const Tables* __restrict
     case JT_CS_J: return a < NP ? c.bj_p : c.bj_n;
     case JT_J_CE: return S.gce[a];
     case JT_J_CS: return S.gcs[a];
-    case JT_J_J: return -1.0;
+    case JT_J_J: if constexpr (M::SEI) { if (a >= NP) return S.sei.jjJ[a - NP]; } return -1.0;
     case JT_J_PE: return S.gpe[a];
     case JT_J_PS: return S.gps[a];
     case JT_PE_CL: return S.pcL[a];
@@ -783,6 +920,24 @@ __device__ inline double jac_entry(const CellLDS<M>& S, const Tables* __restrict
     case JT_PS_I: return a == 0 ? c.JI0 : c.JI29;
     case JT_CTRL_P1: return 1.0;
     case JT_CTRL_M1: return -1.0;
+    case JT_CE_JS: return S.ceJ[a];         // j and j_s enter the node rows through j_total: same coefficients
+    case JT_PE_JS: return S.peJ[a];
+    case JT_PS_JS: return S.psJ[a];
+  }
+  if constexpr (M::SEI) {
+    switch (t) {
+      case JT_J_F: return S.sei.jjF[a];
+      case JT_F_JS: return -c.Mrho;
+      case JT_F_F: return -cj;
+      case JT_SOH_JS: return S.sei.sohw[a];
+      case JT_SOH_SOH: return -cj;
+      case JT_JS_PS: return S.sei.jsPS[a];
+      case JT_JS_PE: return S.sei.jsPE[a];
+      case JT_JS_J: return S.sei.jsJ[a];
+      case JT_JS_JS: return S.sei.jsJS[a];
+      case JT_JS_F: return S.sei.jsF[a];
+      case JT_JS_I: return S.sei.jsI[a];
+    }
   }
   return 0.0;
 }

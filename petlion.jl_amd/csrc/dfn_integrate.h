@@ -396,7 +396,7 @@ __device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, Ida
 }
 
 // ---- stop conditions (check_simulation_stop!, src/checks.jl:1-224); scalars are wave-uniform ----
-struct PrevVals { double frac, V, SOC, I, c_s_n, c_e_min, eta_pl; };
+struct PrevVals { double frac, V, SOC, I, c_s_n, c_e_min, eta_pl, dfilm; };
 
 template <class M>
 __device__ __forceinline__ double cellV(const double* Y) { return Y[M::O_PS] - Y[M::O_PS + NJ - 1]; }
@@ -442,6 +442,11 @@ __device__ inline void check_stop(const CellLDS<M>& S, const plh_run& run, const
     const double ep = Y[O_PS + NP] - Y[O_PE + NP + NS], dep = YP[O_PS + NP] - YP[O_PE + NP + NS];
     if (b.eta_plating_min - ep > eps && dep < 0) { const double f = (pv.eta_pl - b.eta_plating_min) / (pv.eta_pl - ep); if (f < pv.frac) { pv.frac = f; flag = 11; } }
     pv.eta_pl = ep;
+  }
+  if constexpr (M::SEI) {                                                               // check_stop_dfilm, checks.jl:203-224
+    double dm = -1e300; for (int i = 0; i < NN; i++) { const double v = YP[O_FILM + i]; dm = v > dm ? v : dm; }
+    if (b.dfilm_max == b.dfilm_max && dm - b.dfilm_max > eps) { const double f = (pv.dfilm - b.dfilm_max) / (pv.dfilm - dm); if (f < pv.frac) { pv.frac = f; flag = 10; } }
+    pv.dfilm = dm;
   }
 }
 
@@ -507,7 +512,7 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     // tstops = {1.0 if continuation} U {tf}   (postfix_integrator!, model_evaluation.jl:288-310)
     const bool two_stops = !new_run && run.tf > 1.0;
     int its = 0; const int nts = two_stops ? 2 : 1;
-    PrevVals pv; pv.frac = 1.0; pv.V = -1; pv.SOC = -1; pv.I = -1; pv.c_s_n = -1; pv.c_e_min = -1; pv.eta_pl = -1;
+    PrevVals pv; pv.frac = 1.0; pv.V = -1; pv.SOC = -1; pv.I = -1; pv.c_s_n = -1; pv.c_e_min = -1; pv.eta_pl = -1; pv.dfilm = -1;
     save_pt(nout, t0, S.yy, SOC); nout++;
     check_stop(S, run, o, 0.0, run.tf, S.yy, S.yp, SOC, pv, flag);
     PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }

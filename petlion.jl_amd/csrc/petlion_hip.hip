@@ -172,11 +172,30 @@ static const char* const KEYS_NMC_ISO[] = {
 static const double DEFAULTS_NMC_ISO[] = {
     1.5e-14, 2e-14, 4e4, 2.5e4, 3e4, 3e4, 10e-6, 7.5e-6, 25 + 273.15, 1.5, 1.5, 1.5, 1200.0, 31080.0, 51830.0,
     6.3466e-10, 6.3066e-10, 48e-6, 41.6e-6, 25e-6, 0.38, 0.790813, 0.359749, 0.001, 0.955473, 100.0, 100.0, 0.038, 0.12, 0.3, 0.3, 0.4};
+// aging = :SEI adds M_n, R_SEI, Uref_s, i_0_jside, k_n_aging, w, rho_n (reference src/params.jl:90,98-110; NMC borrows them)
+static const char* const KEYS_LCO_SEI[] = {
+    "D_n", "D_p", "D_s", "D_sn", "D_sp", "Ea_D_sn", "Ea_D_sp", "Ea_k_n", "Ea_k_p", "M_n", "R_SEI", "Rp_n", "Rp_p", "T₀", "Uref_s",
+    "brugg_n", "brugg_p", "brugg_s", "c_e₀", "c_max_n", "c_max_p", "i_0_jside", "k_n", "k_n_aging", "k_p", "l_n", "l_p", "l_s",
+    "t₊", "w", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "ρ_n", "σ_n", "σ_p", "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s"};
+static const double DEFAULTS_LCO_SEI[] = {
+    7.5e-10, 7.5e-10, 7.5e-10, 3.9e-14, 1e-14, 5000.0, 5000.0, 5000.0, 5000.0, 7.3e-4, 0.01, 2e-6, 2e-6, 25 + 273.15, 0.4,
+    4.0, 4.0, 4.0, 1000.0, 30555.0, 51554.0, 1.5e-6, 5.0310e-11, 1.0, 2.334e-11, 88e-6, 80e-6, 25e-6,
+    0.364, 2.0, 0.85510, 0.49550, 0.01429, 0.99174, 2500.0, 100.0, 100.0, 0.0326, 0.025, 0.485, 0.385, 0.724};
+static const char* const KEYS_NMC_SEI[] = {
+    "D_sn", "D_sp", "Ea_D_sn", "Ea_D_sp", "Ea_k_n", "Ea_k_p", "M_n", "R_SEI", "Rp_n", "Rp_p", "T₀", "Uref_s", "brugg_n", "brugg_p", "brugg_s",
+    "c_e₀", "c_max_n", "c_max_p", "i_0_jside", "k_n", "k_n_aging", "k_p", "l_n", "l_p", "l_s", "t₊", "w", "θ_max_n", "θ_max_p", "θ_min_n",
+    "θ_min_p", "ρ_n", "σ_n", "σ_p", "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s"};
+static const double DEFAULTS_NMC_SEI[] = {
+    1.5e-14, 2e-14, 4e4, 2.5e4, 3e4, 3e4, 7.3e-4, 0.01, 10e-6, 7.5e-6, 25 + 273.15, 0.4, 1.5, 1.5, 1.5,
+    1200.0, 31080.0, 51830.0, 1.5e-6, 6.3466e-10, 1.0, 6.3066e-10, 48e-6, 41.6e-6, 25e-6, 0.38, 2.0, 0.790813, 0.359749, 0.001,
+    0.955473, 2500.0, 100.0, 100.0, 0.038, 0.12, 0.3, 0.3, 0.4};
 struct VariantInfo { int chem, sei, nkeys; const char* const* keys; const double* defaults; };
-enum { V_LCO_ISO = 0, V_NMC_ISO = 1, V_COUNT };
+enum { V_LCO_ISO = 0, V_NMC_ISO = 1, V_LCO_SEI = 2, V_NMC_SEI = 3, V_COUNT };
 static const VariantInfo VARIANTS[V_COUNT] = {
     {PLH_CHEM_LCO_LIC6, 0, 35, KEYS_LCO_ISO, DEFAULTS_LCO_ISO},
     {PLH_CHEM_NMC_LIC6, 0, 32, KEYS_NMC_ISO, DEFAULTS_NMC_ISO},
+    {PLH_CHEM_LCO_LIC6, 1, 42, KEYS_LCO_SEI, DEFAULTS_LCO_SEI},
+    {PLH_CHEM_NMC_LIC6, 1, 39, KEYS_NMC_SEI, DEFAULTS_NMC_SEI},
 };
 
 struct plh_model_s {
@@ -209,16 +228,24 @@ static unsigned classify(const Tables& tb, int mode, int r, int c) {
     const int i = r, sc = sec_of(i);
     if (c < O_CS) { if (c == i - 1) return W(JT_CE_L, i, 0, 0); if (c == i) return W(JT_CE_D, i, 0, 0); if (c == i + 1) return W(JT_CE_U, i, 0, 0); return 0; }
     if (sc != 1 && c == O_J + (sc == 0 ? i : i - NS)) return W(JT_CE_J, i, 0, 0);
+    if (M::SEI && sc == 2 && c == O_JS + (i - NP - NS)) return W(JT_CE_JS, i, 0, 0);
     return 0;
   }
-  if (r < O_J) {                                    // c_s row (p, rr)
+  if (r < N_CECS) {                                 // c_s row (p, rr)
     const int p = (r - O_CS) / NR, rr = (r - O_CS) % NR;
-    if (c >= O_CS && c < O_J && (c - O_CS) / NR == p) { const int cc = (c - O_CS) % NR; return (tb.M[rr * NR + cc] != 0.0 || rr == cc) ? W(JT_CS_CS, p, rr, cc) : 0; }
+    if (c >= O_CS && c < N_CECS && (c - O_CS) / NR == p) { const int cc = (c - O_CS) % NR; return (tb.M[rr * NR + cc] != 0.0 || rr == cc) ? W(JT_CS_CS, p, rr, cc) : 0; }
     if (rr == NR - 1 && c == O_J + p) return W(JT_CS_J, p, 0, 0);
+    return 0;
+  }
+  if (M::SEI && r < O_J) {                          // film rows (residuals_film!) and the SOH row (residuals_SOH!)
+    if (r < O_SOH) { const int k = r - O_FILM; if (c == r) return W(JT_F_F, k, 0, 0); if (c == O_JS + k) return W(JT_F_JS, k, 0, 0); return 0; }
+    if (c == r) return W(JT_SOH_SOH, 0, 0, 0);
+    if (c >= O_JS && c < O_JS + NN) return W(JT_SOH_JS, c - O_JS, 0, 0);
     return 0;
   }
   if (r < O_PE) {                                   // j row
     const int jx = r - O_J, nd = node_of_j(jx);
+    if (M::SEI && jx >= NP && c == O_FILM + jx - NP) return W(JT_J_F, jx - NP, 0, 0);
     if (c == O_CE + nd) return W(JT_J_CE, jx, 0, 0);
     if (c == O_CS + jx * NR + NR - 1) return W(JT_J_CS, jx, 0, 0);
     if (c == r) return W(JT_J_J, jx, 0, 0);
@@ -232,12 +259,24 @@ static unsigned classify(const Tables& tb, int mode, int r, int c) {
     if (c < O_CS) { if (c == i - 1) return W(JT_PE_CL, i, 0, 0); if (c == i) return W(JT_PE_CD, i, 0, 0); if (c == i + 1) return W(JT_PE_CU, i, 0, 0); return 0; }
     if (c >= O_PE && c < O_PS) { const int k = c - O_PE; if (k == i - 1) return W(JT_PE_L, i, 0, 0); if (k == i) return W(JT_PE_D, i, 0, 0); if (k == i + 1) return W(JT_PE_U, i, 0, 0); return 0; }
     if (sc != 1 && c == O_J + (sc == 0 ? i : i - NS)) return W(JT_PE_J, i, 0, 0);
+    if (M::SEI && sc == 2 && c == O_JS + (i - NP - NS)) return W(JT_PE_JS, i, 0, 0);
+    return 0;
+  }
+  if (M::SEI && r >= O_JS) {                        // j_s row k (residuals_j_s!)
+    const int k = r - O_JS, jx = NP + k, nd = NP + NS + k;
+    if (c == O_PS + jx) return W(JT_JS_PS, k, 0, 0);
+    if (c == O_PE + nd) return W(JT_JS_PE, k, 0, 0);
+    if (c == O_J + jx) return W(JT_JS_J, k, 0, 0);
+    if (c == r) return W(JT_JS_JS, k, 0, 0);
+    if (c == O_FILM + k) return W(JT_JS_F, k, 0, 0);
+    if (c == O_I) return W(JT_JS_I, k, 0, 0);
     return 0;
   }
   {                                                 // Phi_s row jx
     const int jx = r - O_PS;
     const bool first = (jx == 0) || (jx == NP), last = (jx == NP - 1) || (jx == NJ - 1);
-    if (c >= O_PS && c < O_I) { const int k = c - O_PS; if (k == jx - 1 && !first) return W(JT_PS_L, jx, 0, 0); if (k == jx) return W(JT_PS_D, jx, (first || last) ? 1 : 0, 0); if (k == jx + 1 && !last) return W(JT_PS_U, jx, 0, 0); return 0; }
+    if (M::SEI && jx >= NP && c == O_JS + jx - NP) return W(JT_PS_JS, jx, 0, 0);
+    if (c >= O_PS && c < O_PS + NJ) { const int k = c - O_PS; if (k == jx - 1 && !first) return W(JT_PS_L, jx, 0, 0); if (k == jx) return W(JT_PS_D, jx, (first || last) ? 1 : 0, 0); if (k == jx + 1 && !last) return W(JT_PS_U, jx, 0, 0); return 0; }
     if (c == O_J + jx) return W(JT_PS_J, jx, 0, 0);
     if (c == O_I && jx == 0) return W(JT_PS_I, 0, 0, 0);
     if (c == O_I && jx == NJ - 1) return W(JT_PS_I, 1, 0, 0);
@@ -272,6 +311,8 @@ struct Stage {
 #define PL_DISPATCH(m, ...) do { switch ((m)->variant) { \
     case V_LCO_ISO: { using M = ModelT<PLH_CHEM_LCO_LIC6, false>; __VA_ARGS__; } break; \
     case V_NMC_ISO: { using M = ModelT<PLH_CHEM_NMC_LIC6, false>; __VA_ARGS__; } break; \
+    case V_LCO_SEI: { using M = ModelT<PLH_CHEM_LCO_LIC6, true>; __VA_ARGS__; } break; \
+    case V_NMC_SEI: { using M = ModelT<PLH_CHEM_NMC_LIC6, true>; __VA_ARGS__; } break; \
     default: return fail(PLH_E_UNSUPPORTED, "model variant not instantiated"); } } while (0)
 
 template <class M> static int build_patterns(plh_model_s* m) {

@@ -52,3 +52,25 @@ def emu_model_nmc(pkg):
 @pytest.fixture(scope="session")
 def hip_model_nmc(pkg, hip_model):
     return pkg.petlion(pkg.NMC)
+
+
+@pytest.fixture(scope="session")
+def emu_model_sei(pkg):
+    import build_emu
+    return pkg.petlion(pkg.LCO, aging="SEI", _lib_path=build_emu.build())
+
+
+@pytest.fixture(scope="session")
+def emu_model_nmc_sei(pkg):
+    import build_emu
+    return pkg.petlion(pkg.NMC, aging="SEI", _lib_path=build_emu.build())
+
+
+@pytest.fixture(scope="session")
+def hip_model_sei(pkg, hip_model):
+    return pkg.petlion(pkg.LCO, aging="SEI")
+
+
+@pytest.fixture(scope="session")
+def hip_model_nmc_sei(pkg, hip_model):
+    return pkg.petlion(pkg.NMC, aging="SEI")

@@ -4,12 +4,21 @@ import ctypes as C
 import numpy as np
 
 SECTIONS = [("c_e", 0, 30), ("c_s", 30, 230), ("j", 230, 250), ("Phi_e", 250, 280), ("Phi_s", 280, 300), ("I", 300, 301)]
+SECTIONS_SEI = [("c_e", 0, 30), ("c_s", 30, 230), ("film", 230, 240), ("SOH", 240, 241), ("j", 241, 261), ("Phi_e", 261, 291),
+                ("Phi_s", 291, 311), ("j_s", 311, 321), ("I", 321, 322)]
+
+
+def sections_for(n_states):
+    return SECTIONS_SEI if n_states == 322 else SECTIONS
 
 
 def realistic_states(O, th, n, seed=0, variant="lco_iso"):
     """states along a 1C discharge + random perturbations (so that every term of the equations is exercised)."""
     rng = np.random.default_rng(seed)
-    ro = O.simulate(variant, th, 1.0, [dict(mode=O.MODE_I, value=-1.0, tf=600.0 * (1 + 4 * rng.random()))])
+    if variant.endswith("_sei"):    # the side reaction is active only while charging (residuals.jl:519-552)
+        ro = O.simulate(variant, th, 0.1, [dict(mode=O.MODE_I, value=1.0, tf=600.0 * (1 + 3 * rng.random()))])
+    else:
+        ro = O.simulate(variant, th, 1.0, [dict(mode=O.MODE_I, value=-1.0, tf=600.0 * (1 + 4 * rng.random()))])
     Ys, YPs = [], []
     for _ in range(n):
         Ys.append(ro["Y"] * (1 + 1e-3 * rng.standard_normal(ro["Y"].size)))
@@ -24,7 +33,8 @@ def check_keys_and_pattern(p, O):
     assert np.array_equal(p.theta_vector(), np.array(meta["theta_default"]))
     th = p.theta_vector()
     N = p.N.tot
-    for mode, nnz_expect in ((0, 2139), (1, 2140)):     # Z = 2139 in CC mode
+    Z = 2269 if p.aging else 2139                       # Z = 2139 in CC mode (+130 with SEI)
+    for mode, nnz_expect in ((0, Z), (1, Z + 1)):
         cp, ri = p.jac_pattern(mode)
         ocp, ori, _ = O.jacobian(VARIANT, th, np.ones(N), np.zeros(N), 1.0, mode, 0.0)
         assert len(ri) == nnz_expect
@@ -73,7 +83,7 @@ def check_evaluators(p, O, n_cells=3):
             rel = np.abs(nz[i] - onz) / (np.abs(onz) + 1e-300)
             assert rel.max() < 1e-9, (mode, i, rel.max(), int(ori[rel.argmax()]))
             xo = O.linear_solve(VARIANT, Th[i], Y[i], YP[i], cj, b[i], mode, val)
-            for name, a, e in SECTIONS:
+            for name, a, e in sections_for(N):
                 assert np.abs(x[i, a:e] - xo[a:e]).max() <= 1e-7 * (np.abs(xo[a:e]).max() + 1e-300), (mode, i, name)
 
 
@@ -92,7 +102,8 @@ def check_init(p, O, V0_expected=2.863495104606893):
     assert np.abs(Y - Yo).max() <= 1e-12 * np.abs(Yo).max()
     # the finite-difference estimate of YP_alg is intrinsically noisy (difference quotient of a Newton update): 1e-6 of scale
     assert np.abs(YP - YPo).max() <= 1e-6 * np.abs(YPo).max()
-    V0 = Y[280] - Y[299]
+    ps = dict((n, a) for n, a, _ in sections_for(N))["Phi_s"]
+    V0 = Y[ps] - Y[ps + 19]
     if V0_expected is not None:
         assert abs(V0 - V0_expected) < 1e-10       # reference examples/model_inputs_and_outputs.ipynb:152
     return V0
@@ -112,7 +123,7 @@ def state_rel_err(Y, Yo):
     compared relative to its own scale; a component-wise ratio would blow up on near-zero entries such as j in the separator-side
     nodes or Phi_e next to the reference node)."""
     worst = 0.0
-    for _, a, e in SECTIONS:
+    for _, a, e in sections_for(len(Yo)):
         worst = max(worst, np.abs(Y[a:e] - Yo[a:e]).max() / (np.abs(Yo[a:e]).max() + 1e-300))
     return worst
 

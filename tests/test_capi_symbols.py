@@ -39,4 +39,6 @@ def test_unsupported_options_are_refused(pkg):
     with pytest.raises(NotImplementedError):
         pkg.petlion(pkg.LCO, solid_diffusion="polynomial")
     with pytest.raises(NotImplementedError):
-        pkg.petlion(pkg.NMC)
+        pkg.petlion("LFP")
+    with pytest.raises(NotImplementedError):
+        pkg.petlion(pkg.LCO, aging="R_film")

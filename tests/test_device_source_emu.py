@@ -65,3 +65,34 @@ def test_nmc_chemistry_evaluators_and_discharge(emu_model_nmc, O, pkg):
     ro = O.simulate("nmc_iso", Th[0], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}]))
     assert ro["runs"][0]["flag"] == 1                      # NMC bounds: V_min = 2.8 fires before SOC_min
     parity.compare_trajectory(ens, 0, ro, rtol_state=1e-6)
+
+
+GITT_SEI = [{"I": 1.0, "tf": 300.0}, {"I": "rest", "tf": 300.0}, {"I": -0.5, "tf": 300.0}, {"I": "rest", "tf": 200.0}, {"I": 1.0, "tf": 300.0}]
+
+
+def check_sei_model(p, O, pkg):
+    """aging = :SEI (film, SOH, j_s rows; reference residuals.jl:260-297,519-552): evaluators, consistent initialisation, a CC charge
+    with identical step decisions, and a pulse/rest chain with IDA's first step pinned (the default first step amplifies the
+    finite-difference YP_alg estimate of newtons_method!, DESIGN.md "reproducibility floor")."""
+    parity.check_keys_and_pattern(p, O)
+    parity.check_evaluators(p, O, n_cells=3)
+    parity.check_init(p, O, None)
+    th = p.theta_vector()
+    proto = [{"I": 1.0, "tf": 1500.0}]
+    ens = pkg.simulate_ensemble(p, th[None, :], proto, SOC=0.0)
+    ro = O.simulate(p.variant, th, 0.0, parity.runs_to_oracle(O, p, pkg, proto))
+    parity.compare_trajectory(ens, 0, ro, rtol_state=1e-6)
+    film = ens.Y[0][230:240]
+    assert (film > 0).all() and ens.Y[0][240] < 1.0          # the side reaction ran: film grew, SOH dropped
+    o = pkg.Opts(); o.jac_every_step = True; o.init_step = 1e-2
+    ens = pkg.simulate_ensemble(p, th[None, :], GITT_SEI, SOC=0.3, opts=o)
+    ro = O.simulate(p.variant, th, 0.3, parity.runs_to_oracle(O, p, pkg, GITT_SEI), opts=O.default_opts(jac_every_step=1, init_step=1e-2))
+    parity.compare_trajectory(ens, 0, ro, rtol_state=1e-6)
+
+
+def test_lco_sei_aging(emu_model_sei, O, pkg):
+    check_sei_model(emu_model_sei, O, pkg)
+
+
+def test_nmc_sei_aging_c5_model(emu_model_nmc_sei, O, pkg):
+    check_sei_model(emu_model_nmc_sei, O, pkg)

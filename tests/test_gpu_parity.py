@@ -186,3 +186,37 @@ def test_nmc_chemistry(hip_model_nmc, O, pkg):
     for i in (0, 7, 15):
         ro = O.simulate("nmc_iso", Th[i], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}]))
         parity.compare_trajectory(ens, i, ro, rtol_state=5e-6)
+
+
+def test_lco_sei_aging(hip_model_sei, O, pkg):
+    import test_device_source_emu as te
+    te.check_sei_model(hip_model_sei, O, pkg)
+
+
+def test_c5_nmc_sei_gitt_ensemble(hip_model_nmc_sei, O, pkg):
+    """config C5's model (NMC + SEI aging) on a pulse/rest protocol over an ensemble with jittered kinetics:
+    evaluator parity, per-cell oracle parity on a subset (first step pinned), and ensemble-wide bookkeeping properties."""
+    import test_device_source_emu as te
+    p = hip_model_nmc_sei
+    te.check_sei_model(p, O, pkg)
+    n = 512
+    rng = np.random.default_rng(5)
+    Th = pkg.theta_matrix(p, n, {"k_n": p.θ["k_n"] * 2.0 ** (2 * rng.random(n) - 1), "D_sn": p.θ["D_sn"] * 2.0 ** (2 * rng.random(n) - 1),
+                                 "i_0_jside": p.θ["i_0_jside"] * 2.0 ** (2 * rng.random(n) - 1)})
+    proto = []
+    for _ in range(3):
+        proto += [{"I": 1.0, "tf": 240.0}, {"I": "rest", "tf": 360.0}]
+    o = pkg.Opts(); o.jac_every_step = True; o.init_step = 1e-2
+    ens = pkg.simulate_ensemble(p, Th, proto, SOC=0.2, opts=o)
+    assert (ens.run_info["flag"] == 0).all()
+    assert np.abs(ens.run_info["t_end"][:, -1] - 1800.0).max() < 1e-5
+    assert np.abs(ens.run_info["SOC"][:, -1] - (0.2 + 3 * 240 / 3600)).max() < 1e-6
+    film, soh = ens.Y[:, 230:240], ens.Y[:, 240]
+    assert (film > 0).all() and (soh < 1.0).all() and (soh > 0.999).all()
+    # more exchange current of the side reaction -> more film (monotone in i_0_jside at fixed everything else is not testable
+    # here because k_n and D_sn vary too; the rank correlation is still strong)
+    k = p.θ_keys.index("i_0_jside")
+    assert np.corrcoef(np.argsort(np.argsort(Th[:, k])), np.argsort(np.argsort(film.mean(axis=1))))[0, 1] > 0.9
+    for i in (0, 101, 511):
+        ro = O.simulate(p.variant, Th[i], 0.2, parity.runs_to_oracle(O, p, pkg, proto), opts=O.default_opts(jac_every_step=1, init_step=1e-2))
+        parity.compare_trajectory(ens, i, ro, rtol_state=2e-6)
