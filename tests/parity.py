@@ -123,8 +123,11 @@ def state_rel_err(Y, Yo):
     compared relative to its own scale; a component-wise ratio would blow up on near-zero entries such as j in the separator-side
     nodes or Phi_e next to the reference node)."""
     worst = 0.0
-    for _, a, e in sections_for(len(Yo)):
-        worst = max(worst, np.abs(Y[a:e] - Yo[a:e]).max() / (np.abs(Yo[a:e]).max() + 1e-300))
+    for name, a, e in sections_for(len(Yo)):
+        # a field that is identically zero in exact arithmetic (j_s while not charging, I at rest) holds only solver round-off
+        # (~1e-23 in the oracle's sparse LU, exactly 0 on the device): floor its scale well below any physical magnitude
+        floor = {"j_s": 1e-15, "j": 1e-12, "I": 1e-9}.get(name, 1e-300)
+        worst = max(worst, np.abs(Y[a:e] - Yo[a:e]).max() / max(np.abs(Yo[a:e]).max(), floor))
     return worst
 
 
@@ -139,7 +142,16 @@ def compare_trajectory(ens, i, ro, rtol_state=1e-6, same_decisions=True):
     if same_decisions:
         assert n == len(ro["t"])
         assert np.abs(ens.t[i, :n] - ro["t"]).max() <= 10 * rtol_state * max(1.0, ro["t"][-1])
-        assert np.abs(ens.V[i, :n] - ro["V"]).max() <= 10 * rtol_state * 4.0
+        # V is compared at equal step index; the step times themselves agree only to ~rtol_state * t (the step-size controller is a
+        # continuous function of rounding-level differences), so near a voltage knee the comparison allows the first-order
+        # effect of that time offset: |dV| <= 10 rtol * 4 V + 2 |dV/dt| |dt|
+        dt = np.abs(ens.t[i, :n] - ro["t"])
+        slope = np.zeros(n)
+        if n > 2:
+            dtt = np.diff(ro["t"])
+            sl = np.abs(np.diff(ro["V"])) / np.where(dtt > 0, dtt, np.inf)     # run boundaries repeat t: no slope there
+            slope[1:] = sl; slope[:-1] = np.maximum(slope[:-1], sl)
+        assert (np.abs(ens.V[i, :n] - ro["V"]) <= 10 * rtol_state * 4.0 + 2 * slope * dt).all()
         for f in ("n_steps", "n_res", "n_jac", "n_newton", "n_errfail", "n_convfail"):
             assert ens.counters[i][f] == ro["counters"][f], f
     assert state_rel_err(ens.Y[i], ro["Y"]) <= rtol_state, (i, state_rel_err(ens.Y[i], ro["Y"]))
