@@ -53,7 +53,7 @@ class Model:
         self.N.diff = self._lib.plh_n_diff(h)
         self.N.alg = self.N.tot - self.N.diff
         self.θ_keys = [self._lib.plh_theta_key(h, i).decode("utf-8") for i in range(self._lib.plh_n_theta(h))]
-        self.variant = "%s_iso%s" % (cathode.lower(), "_sei" if aging else "")      # name of the matching oracle variant (tests)
+        self.variant = "%s_%s%s" % (cathode.lower(), "thermal" if self.temperature else "iso", "_sei" if aging else "")   # matching oracle variant (tests)
 
     theta = property(lambda self: self.θ)
 

@@ -24,13 +24,17 @@ namespace pl {
 constexpr int WAVE = 64;
 constexpr int NP = 10, NS = 10, NN = 10, NR = 10, NE = NP + NS + NN, NJ = NP + NN;
 constexpr int O_CE = 0, O_CS = NE, N_CECS = O_CS + NJ * NR;      // c_e and c_s_avg lead every layout (reference src/external.jl:275-365)
+constexpr int NA = 10, NZ = 10, NT = NA + NE + NZ;               // current collectors; temperature nodes a|p|s|n|z
 
-// Model traits: state layout  Y = [ c_e | c_s_avg | film, SOH (SEI) || j | Phi_e | Phi_s | j_s (SEI) | I ]  and closures.
-template <int CHEM_, bool SEI_> struct ModelT {
+// Model traits: state layout  Y = [ c_e | c_s_avg | T (thermal) | film, SOH (SEI) || j | Phi_e | Phi_s | j_s (SEI) | I ]  and closures.
+template <int CHEM_, bool SEI_, bool THERMAL_ = false> struct ModelT {
   static constexpr int CHEM = CHEM_;                 // PLH_CHEM_LCO_LIC6 / PLH_CHEM_NMC_LIC6
   static constexpr bool SEI = SEI_;
-  static constexpr int O_FILM = N_CECS, O_SOH = O_FILM + NN;
-  static constexpr int NDIFF = SEI_ ? O_SOH + 1 : N_CECS;
+  static constexpr bool THERMAL = THERMAL_;
+  static constexpr int NB = THERMAL_ ? 4 : 3;        // node block size of the block-Thomas solve: (c_e, Phi_e, Phi_s[, T])
+  static constexpr int O_T = N_CECS;
+  static constexpr int O_FILM = N_CECS + (THERMAL_ ? NT : 0), O_SOH = O_FILM + NN;
+  static constexpr int NDIFF = SEI_ ? O_SOH + 1 : O_FILM;
   static constexpr int O_J = NDIFF, O_PE = O_J + NJ, O_PS = O_PE + NE, O_JS = O_PS + NJ, O_I = SEI_ ? O_JS + NN : O_PS + NJ;
   static constexpr int NST = O_I + 1, NALG = NST - NDIFF;
   static constexpr int NPAD = NST + (NST & 1);
@@ -49,7 +53,9 @@ constexpr double TREF = 298.15;
 enum Key { K_D_n, K_D_p, K_D_s, K_D_sn, K_D_sp, K_Ea_D_sn, K_Ea_D_sp, K_Ea_k_n, K_Ea_k_p, K_M_n, K_R_SEI, K_Rp_n, K_Rp_p, K_T0, K_Uref_s,
            K_brugg_n, K_brugg_p, K_brugg_s, K_c_e0, K_c_max_n, K_c_max_p, K_i_0_jside, K_k_n, K_k_n_aging, K_k_p, K_l_n, K_l_p, K_l_s,
            K_tplus, K_w, K_th_max_n, K_th_max_p, K_th_min_n, K_th_min_p, K_rho_n, K_sig_n, K_sig_p, K_eps_fn, K_eps_fp, K_eps_n, K_eps_p,
-           K_eps_s, K_COUNT };
+           K_eps_s,
+           K_Cp_a, K_Cp_n, K_Cp_p, K_Cp_s, K_Cp_z, K_T_amb, K_h_cell, K_l_a, K_l_z, K_lam_a, K_lam_n, K_lam_p, K_lam_s, K_lam_z,
+           K_rho_a, K_rho_p, K_rho_s, K_rho_z, K_sig_a, K_sig_z, K_COUNT };
 
 // read-only model tables in device memory
 struct Tables {
@@ -68,6 +74,8 @@ struct CellConst {
   double T0, fRT, Kfac, I1C, tplus, JI0, JI29, ce0;
   double thmin_p, thmax_p, thmin_n, thmax_n;
   double R_SEI, rkag, Mrho, i0F, wexp, Uref;   // SEI: R_SEI, 1/k_n_aging, M_n/rho_n, i_0_jside/F, w, Uref_s
+  double EaKp, EaKn, EaDp, EaDn;               // thermal: activation energies / R (kp, kn, kap_p, kap_n then hold the T_ref values)
+  double r2h[3], qps_r, qps_l, qsn_r, qsn_l;   // thermal: gradient-stencil factors 1/(2h), 2/(3hp+hs), 2/(hp+3hs), 2/(3hs+hn), 2/(hs+3hn)
   int iso_ref;   // T0 == TREF exactly (temperature_switch, reference custom_functions.jl:1)
 };
 
@@ -81,6 +89,35 @@ template <> struct SeiPool<true> {
   double cjf;                                                       // cj of the current factorisation
 };
 
+// pools of the thermal model (temperature = true; functions in dfn_thermal.h).  T lives on NT = 50 nodes (a | p | s | n | z); the
+// 30 cell-sandwich nodes carry T as the 4th unknown of the block-Thomas node block, the two collector chains are eliminated
+// onto their neighbours, and the four T rows whose one-sided gradient stencils reach a second neighbour (nodes 0, 9, 20, 29)
+// are handled as a rank-4 Woodbury update of the block-tridiagonal matrix.
+template <bool TH> struct ThermalPool {};
+template <> struct ThermalPool<true> {
+  // heat-conduction stencil of residuals_T! (residuals.jl:299-489), already divided by rho*Cp:  aL T[it-1] + aD T[it] + aU T[it+1] + aC
+  double aL[NT], aD[NT], aU[NT], aC[NT], rc[NT], wT[NT];   // rc = 1/(rho Cp); wT = temperature_weighting w_i / L (aux...jl:649-679)
+  double qI[2], qIJ[2];                                    // collector rows: Joule heat qI * I^2 ; qIJ = d(row)/dI at the last Jacobian pass
+  double kapP[NJ], dkapP[NJ];                              // per-particle D_s(T)/Rp^2 and its T derivative
+  // Jacobian partials that exist only with temperature
+  double ptL[NE], ptD[NE], ptU[NE];                        // Phi_e rows x T
+  double gT[NJ];                                           // j rows x T
+  double TcL[NE], TcD[NE], TcU[NE], TeL[NE], TeD[NE], TeU[NE], TsL[NE], TsD[NE], TsU[NE], TtD[NE];   // T rows x (c_e, Phi_e, Phi_s, T)
+  double TJ[NJ], Tcs[NJ];                                  // T rows x (j, c_s surface)
+  double TX2[4][3];                                        // out-of-band T-row entries: rows of nodes 0, 9, 20, 29 x (c_e, Phi_e, Phi_s) of nodes 2, 7, 22, 27
+  // particle resolvent in spectral form (per particle: kappa differs with T)
+  double rdiag[NJ][NR], AinvE[NJ][NR], AinvQ[NJ][NR], Wc[NJ][NR];
+  // node-local elimination
+  double tq[NE][4], phi4[NE][4], colI4[NE][4];
+  // collector chains (tridiagonal scalar systems)
+  double cP[2][NA], cM[2][NA], zc[2][NA], zI[2][NA], zb[2][NA];
+  // Woodbury and border
+  double Z[4][NE][4], Cinv[16], x2[NE][4], vB[NE][4];
+  double vcoll[2][NA];
+  double bord[4];                                          // [0] d2 = d - v.x2, [1] d (direct I entry of the control row), [2..3] spare
+  double cjf;
+};
+
 template <class M> struct CellLDS {
   double phi[MAXORD + 1][M::NPAD];
   double ewt[M::NPAD], yy[M::NPAD], yp[M::NPAD], ee[M::NPAD], delta[M::NPAD];
@@ -91,7 +128,7 @@ template <class M> struct CellLDS {
   // eliminated system
   double dj[NJ], nphi[NE][3];      // j pivot; phi_c = omega . A_ux[:,c] (node block D[r][c] -= t_r phi_c, t = (ceJ, peJ, psJ))
   double colI[NE][3];              // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
-  double Dinv[NE][9], LD[NE][9];   // Thomas factors: D'^-1 and L D'^-1(prev)
+  double Dinv[NE][M::NB * M::NB], LD[NE][M::NB * M::NB];   // Thomas factors: D'^-1 and L D'^-1(prev)
   double Ainv[2][NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
   double Mr[NR * NR];               // radial operator (copy of Tables::M)
   double x2[NE][3];
@@ -99,10 +136,12 @@ template <class M> struct CellLDS {
   double sig[2];
   double kapv[2];
   SeiPool<M::SEI> sei;
+  ThermalPool<M::THERMAL> th;
   // wave-uniform BDF coefficient arrays (dynamically indexed by the order -> LDS, not registers/scratch)
   double ida_psi[MAXORD + 1], ida_alpha[MAXORD + 1], ida_beta[MAXORD + 1], ida_sigma[MAXORD + 1], ida_gamma[MAXORD + 1];
   double ida_out[4];
   long long cyc[8];    // per-phase cycle sums (profiling build only)
+  const Tables* tb;    // model tables (set by cell_setup)
   long long cnt[10];   // device counters (n_steps, n_res, n_jac, n_fact, n_solve, n_newton, n_errfail, n_convfail, sum_kp2, n_init_iters)
   CellConst cc;
 };
@@ -254,6 +293,16 @@ __device__ __forceinline__ void sinh_cosh(double x, double& sh, double& ch) {
 // harmonic-mean edge interpolation H(beta; a, b) = ab/(beta b + (1-beta) a), numerical_tools.jl:106-156
 __device__ __forceinline__ double hmean(double beta, double a, double b) { return a * b / (beta * b + (1.0 - beta) * a); }
 
+// thermal-model counterparts (dfn_thermal.h); the generic entry points below dispatch to them when M::THERMAL
+template <class M> __device__ inline void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th);
+template <bool WANT_RES, bool WANT_JAC, class M>
+__device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value);
+template <bool WANT_JAC, class M> __device__ inline void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const double* Y, const double* YP, double* Fo);
+template <class M> __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only);
+template <class M> __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, int mode, bool alg_only);
+template <class M> __device__ inline double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj);
+constexpr int PL_MODE_DT_TWIN = 3;   // dT control row with YP_T replaced by rhs_T(Y): the consistent-initialisation form (scalar_residual.jl:347-372)
+
 // ------------------------------------------------------------------------------------------------------------------
 // per-cell constants from theta (build_auxiliary_states!, reference aux...jl:6-52, and the Arrhenius closures)
 // ------------------------------------------------------------------------------------------------------------------
@@ -284,7 +333,7 @@ __device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     const double T0 = th[ix[K_T0]];
     c.T0 = T0; c.iso_ref = (T0 == TREF);
     double arr_kp = 1.0, arr_kn = 1.0, arr_dp = 1.0, arr_dn = 1.0;   // temperature_switch, custom_functions.jl:1,16-31,44-57
-    if (!c.iso_ref) {
+    if (!c.iso_ref && !M::THERMAL) {   // with temperature = true the Arrhenius factors are evaluated per node from T(x)
       const double dT = 1.0 / T0 - 1.0 / TREF;
       arr_kp = exp(-(th[ix[K_Ea_k_p]] / RGAS) * dT); arr_kn = exp(-(th[ix[K_Ea_k_n]] / RGAS) * dT);
       arr_dp = exp(-(th[ix[K_Ea_D_sp]] / RGAS) * dT); arr_dn = exp(-(th[ix[K_Ea_D_sn]] / RGAS) * dT);
@@ -305,7 +354,16 @@ __device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     c.JI29 = -c.I1C * c.h[2] / c.sig_n;                     // d(Phi_s row of last n node)/dI
     c.ce0 = th[ix[K_c_e0]];
     S.kapv[0] = c.kap_p; S.kapv[1] = c.kap_n;
+    S.tb = tb;
     c.R_SEI = c.rkag = c.Mrho = c.i0F = c.wexp = c.Uref = 0.0;
+    c.EaKp = c.EaKn = c.EaDp = c.EaDn = 0.0;
+    if constexpr (M::THERMAL) {
+      c.iso_ref = 0;                                        // the temperature_switch always takes the exp branch (custom_functions.jl:1)
+      c.EaKp = th[ix[K_Ea_k_p]] / RGAS; c.EaKn = th[ix[K_Ea_k_n]] / RGAS; c.EaDp = th[ix[K_Ea_D_sp]] / RGAS; c.EaDn = th[ix[K_Ea_D_sn]] / RGAS;
+      for (int q = 0; q < 3; q++) c.r2h[q] = 1.0 / (2.0 * c.h[q]);
+      c.qps_r = 2.0 / (3 * c.h[0] + c.h[1]); c.qps_l = 2.0 / (c.h[0] + 3 * c.h[1]);
+      c.qsn_r = 2.0 / (3 * c.h[1] + c.h[2]); c.qsn_l = 2.0 / (c.h[1] + 3 * c.h[2]);
+    }
     if constexpr (M::SEI) {
       c.R_SEI = th[ix[K_R_SEI]]; c.rkag = 1.0 / th[ix[K_k_n_aging]]; c.Mrho = th[ix[K_M_n]] / th[ix[K_rho_n]];
       c.i0F = th[ix[K_i_0_jside]] / FAR; c.wexp = th[ix[K_w]]; c.Uref = th[ix[K_Uref_s]];
@@ -329,6 +387,7 @@ __device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __re
   for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->M[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; }
   for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
   PL_SYNC();
+  if constexpr (M::THERMAL) thermal_setup(S, tb, th);
 }
 
 // initial_guess!, reference src/states_definition.jl:80-121
@@ -347,6 +406,7 @@ __device__ inline void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) 
     if (n < O_CS) v = c.ce0;
     else if (n < O_CS + NP * NR) v = csp;
     else if (n < N_CECS) v = csn;
+    else if (M::THERMAL && n < M::O_T + NT) v = c.T0;
     else if (n >= O_PS && n < O_PS + NP) v = Up;
     else if (n >= O_PS + NP && n < O_PS + NJ) v = Un;
     else if (M::SEI && n == O_SOH) v = 1.0;               // film = 0, SOH = 1, j_s = 0 (states_definition.jl:80-121)
@@ -359,7 +419,7 @@ __device__ inline void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) 
 // node pass shared by the residual and the Jacobian partials.  Lane i < 30 owns control volume i and edge i (i|i+1).
 // ------------------------------------------------------------------------------------------------------------------
 template <bool WANT_RES, bool WANT_JAC, class M>
-__device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
+__device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -524,7 +584,7 @@ __device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const doub
 
 // c_s rows (residuals_c_s_avg!, Fickian FDM, residuals.jl:128-180): lane -> (particle = pass*6 + lane/10, row = lane%10)
 template <class M>
-__device__ inline void cell_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
+__device__ inline void iso_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -559,12 +619,31 @@ __device__ inline void cell_cs_rows(CellLDS<M>& S, const LaneRegs& R, const doub
   }
 }
 
+// ---- generic entry points: dispatch to the isothermal or the thermal implementation ----
+template <bool WANT_RES, bool WANT_JAC, class M>
+__device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
+  if constexpr (M::THERMAL) thermal_node_pass<WANT_RES, WANT_JAC>(S, Y, YP, Fo, mode, value);
+  else iso_node_pass<WANT_RES, WANT_JAC>(S, Y, YP, Fo, mode, value);
+}
+template <bool WANT_JAC = false, class M>
+__device__ inline void cell_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
+  if constexpr (M::THERMAL) thermal_cs_rows<WANT_JAC>(S, S.tb, Y, YP, Fo);
+  else iso_cs_rows(S, R, Y, YP, Fo);
+}
 // full residual F(Y, YP) -> Fo (all three are LDS vectors)
 template <class M>
 __device__ inline void cell_residual(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo, int mode, double value) {
-  PL_MODEL(M);
   cell_node_pass<true, false>(S, Y, YP, Fo, mode, value);
-  cell_cs_rows(S, R, Y, YP, Fo);
+  if constexpr (M::THERMAL) PL_SYNC();                      // the particle rows read the per-node D_s(T) written by the node pass
+  cell_cs_rows<false>(S, R, Y, YP, Fo);
+  PL_SYNC();
+}
+// residual + Jacobian partials in one pass (the Newton-matrix refresh of the corrector)
+template <class M>
+__device__ inline void cell_res_jac(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo, int mode, double value) {
+  cell_node_pass<true, true>(S, Y, YP, Fo, mode, value);
+  if constexpr (M::THERMAL) PL_SYNC();
+  cell_cs_rows<true>(S, R, Y, YP, Fo);
   PL_SYNC();
 }
 
@@ -647,7 +726,7 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only
 // factor the Newton matrix at the Jacobian partials currently in S (cell_node_pass<.,true> must have run).
 // mode selects the control row; alg_only = the 71x71 algebraic block of the consistent-initialisation Newton.
 template <class M>
-__device__ inline void cell_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
+__device__ inline void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -756,7 +835,7 @@ __device__ inline void cell_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __r
 
 // solve J x = b in place (b is an LDS vector of NST entries).  alg_only: only rows/cols NDIFF.. are touched.
 template <class M>
-__device__ inline void cell_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_only) {
+__device__ inline void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_only) {
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -890,7 +969,7 @@ enum JT { JT_CE_L = 1, JT_CE_D, JT_CE_U, JT_CE_J, JT_CS_CS, JT_CS_J, JT_J_CE, JT
           JT_CTRL_P1, JT_CTRL_M1,
           JT_CE_JS, JT_PE_JS, JT_PS_JS, JT_J_F, JT_F_JS, JT_F_F, JT_SOH_JS, JT_SOH_SOH, JT_JS_PS, JT_JS_PE, JT_JS_J, JT_JS_JS, JT_JS_F, JT_JS_I };
 template <class M>
-__device__ inline double jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
+__device__ inline double iso_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
   PL_MODEL(M);
   const int t = w >> 24, a = (w >> 16) & 255, bb = (w >> 8) & 255, cc = w & 255;
   const CellConst& c = S.cc;
@@ -942,4 +1021,22 @@ __device__ inline double jac_entry(const CellLDS<M>& S, const Tables* __restrict
   return 0.0;
 }
 
+template <class M>
+__device__ inline void cell_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
+  if constexpr (M::THERMAL) thermal_factor(S, R, tb, cj, mode, alg_only);
+  else iso_factor(S, R, tb, cj, mode, alg_only);
+}
+template <class M>
+__device__ inline void cell_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_only) {
+  if constexpr (M::THERMAL) thermal_solve(S, R, S.tb, b, mode, alg_only);
+  else iso_solve(S, R, b, mode, alg_only);
+}
+template <class M>
+__device__ inline double jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
+  if constexpr (M::THERMAL) return thermal_jac_entry(S, tb, w, cj);
+  else return iso_jac_entry(S, tb, w, cj);
+}
+
 }  // namespace pl
+
+#include "dfn_thermal.h"

@@ -47,6 +47,8 @@ __device__ inline int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tab
   const int lane = lane_id();
   PL_VEC(n) YP[n] = 0.0;
   PL_SYNC();
+  // the dT control row contains YP_T; the algebraic system uses its twin with YP_T -> rhs_T(Y) (scalar_residual.jl:347-372)
+  if (M::THERMAL && mode == PLH_MODE_DT) mode = PL_MODE_DT_TWIN;
   int ok = 0;
   for (int iter = 1; iter <= 100; iter++) {
     cell_node_pass<true, true>(S, Y, YP, res, mode, value);      // R_alg + J_alg partials (differential rows ignored)
@@ -63,7 +65,7 @@ __device__ inline int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tab
   }
   if (!ok) return PLH_ERR_INIT;
   // YP_diff = rhs_diff(Y)   (R_diff with YP = 0)
-  cell_residual(S, R, Y, YP, res, mode, value);
+  cell_residual(S, R, Y, YP, res, mode == PL_MODE_DT_TWIN ? PLH_MODE_DT : mode, value);
   cnt_add(cnt, C_RES);
   for (int n = lane; n < NDIFF; n += WAVE) YP[n] = res[n];
   PL_SYNC();
@@ -183,9 +185,7 @@ __device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaS
     { PL_TIC(); form_iterate(S, I); PL_TOC(S, PH_NEWTVEC); }
     if (callLSetup) {
       PL_TIC();
-      cell_node_pass<true, true>(S, S.yy, S.yp, S.delta, mode, value);
-      cell_cs_rows(S, R, S.yy, S.yp, S.delta);
-      PL_SYNC();
+      cell_res_jac(S, R, S.yy, S.yp, S.delta, mode, value);
       cell_factor(S, R, tb, I.cj, mode, false);
       cnt_add(cnt, C_RES); cnt_add(cnt, C_JAC); cnt_add(cnt, C_FACT);
       I.cjold = I.cj; I.cjratio = 1.0; I.ss = 20.0; jcur = 1;
@@ -396,16 +396,25 @@ __device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, Ida
 }
 
 // ---- stop conditions (check_simulation_stop!, src/checks.jl:1-224); scalars are wave-uniform ----
-struct PrevVals { double frac, V, SOC, I, c_s_n, c_e_min, eta_pl, dfilm; };
+struct PrevVals { double frac, V, SOC, I, c_s_n, c_e_min, eta_pl, dfilm, T; };
 
 template <class M>
 __device__ __forceinline__ double cellV(const double* Y) { return Y[M::O_PS] - Y[M::O_PS + NJ - 1]; }
+
+// calc_T_avg / temperature_weighting (aux...jl:649-679): wave-uniform, every lane must call it
+template <class M>
+__device__ __forceinline__ double cellTavg(const CellLDS<M>& S, const double* Y) {
+  if constexpr (M::THERMAL) { const int lane = lane_id(); return wave_sum(lane < NT ? S.th.wT[lane] * Y[M::O_T + lane] : 0.0); }
+  else return S.cc.T0;
+}
 
 template <class M>
 __device__ inline void check_stop(const CellLDS<M>& S, const plh_run& run, const plh_opts& o, double t, double tf, const double* Y, const double* YP,
                                   double SOC, PrevVals& pv, int& flag) {
   PL_MODEL(M);
   const double eps = t < 1.0 ? o.reltol : 0.0;
+  [[maybe_unused]] double Tav = 0.0, dTav = 0.0;
+  if constexpr (M::THERMAL) { Tav = cellTavg<M>(S, Y); dTav = cellTavg<M>(S, YP); }     // (all lanes, before any early return)
   if (t >= tf) { flag = 0; return; }
   if (!o.check_bounds || run.value_kind == PLH_VAL_REST) return;
   const plh_bounds& b = run.bounds;
@@ -426,6 +435,12 @@ __device__ inline void check_stop(const CellLDS<M>& S, const plh_run& run, const
     if ((b.SOC_min - SOC > eps) && Ic < 0) { const double f = (pv.SOC - b.SOC_min) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; flag = 3; } }
     else if ((SOC - b.SOC_max > eps) && Ic > 0) { const double f = (pv.SOC - b.SOC_max) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; flag = 4; } }
     pv.SOC = SOC;
+  }
+  if constexpr (M::THERMAL) {                                                           // check_stop_T, checks.jl:106-124
+    if (b.T_max == b.T_max && run.mode != PLH_MODE_DT) {
+      if (Tav - b.T_max > eps && dTav > 0) { const double f = (pv.T - b.T_max) / (pv.T - Tav); if (f < pv.frac) { pv.frac = f; flag = 5; } }
+      pv.T = Tav;
+    }
   }
   if (b.c_s_n_max == b.c_s_n_max) {                                                     // check_stop_c_s_surf, checks.jl:141-161
     double cm = -1e300; for (int i = 0; i < NN; i++) { const double v = Y[O_CS + NP * NR + (i + 1) * NR - 1]; cm = v > cm ? v : cm; }
@@ -474,12 +489,13 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     have_prev = true; t_global = t_init; prev_V = cellV<M>(S.yy); prev_I = S.yy[O_I];
   }
   auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
+    const double Tav = (M::THERMAL && out.T) ? cellTavg<M>(S, Y) : T0;
     if (lane == 0 && idx < out.max_pts) {
       if (out.t) out.t[idx] = tt;
       if (out.V) out.V[idx] = cellV<M>(Y);
       if (out.I) out.I[idx] = Y[O_I];
       if (out.SOC) out.SOC[idx] = soc;
-      if (out.T) out.T[idx] = T0;
+      if (out.T) out.T[idx] = Tav;
     }
   };
   for (int r = 0; r < n_runs; r++) {
@@ -496,10 +512,13 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
       if (run.value_kind == PLH_VAL_HOLD) value = have_prev ? prev_I : 0.0;
       else if (run.value_kind == PLH_VAL_REST) value = 0.0;
       Iguess = value;
-    } else {
+    } else if (mode == PLH_MODE_V) {
       if (run.value_kind == PLH_VAL_HOLD) { value = prev_V; Iguess = prev_V; }
       else if (have_prev && prev_I != 0.0) Iguess = prev_I;
       else { const double OCV = cellV<M>(S.yy); Iguess = value > OCV ? 1.0 : -1.0; }
+    } else {                                                            // dT: custom_res! (model_evaluation.jl:155-172): :hold -> 0 K/s
+      if (run.value_kind == PLH_VAL_HOLD) value = 0.0;
+      Iguess = have_prev ? prev_I : 1.0;                                // input_methods.jl:171-176
     }
     PL_SYNC();
     if (lane == 0) S.yy[O_I] = Iguess;
@@ -512,7 +531,7 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     // tstops = {1.0 if continuation} U {tf}   (postfix_integrator!, model_evaluation.jl:288-310)
     const bool two_stops = !new_run && run.tf > 1.0;
     int its = 0; const int nts = two_stops ? 2 : 1;
-    PrevVals pv; pv.frac = 1.0; pv.V = -1; pv.SOC = -1; pv.I = -1; pv.c_s_n = -1; pv.c_e_min = -1; pv.eta_pl = -1; pv.dfilm = -1;
+    PrevVals pv; pv.frac = 1.0; pv.V = -1; pv.SOC = -1; pv.I = -1; pv.c_s_n = -1; pv.c_e_min = -1; pv.eta_pl = -1; pv.dfilm = -1; pv.T = -1;
     save_pt(nout, t0, S.yy, SOC); nout++;
     check_stop(S, run, o, 0.0, run.tf, S.yy, S.yp, SOC, pv, flag);
     PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
@@ -559,7 +578,7 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
       t_end = ti + t0;
       save_pt(nout - 1, t_end, S.yy, SOC);
     }
-    ri.flag = flag; ri.iterations = iter; ri.t_end = t_end; ri.V = cellV<M>(S.yy); ri.I = S.yy[O_I]; ri.SOC = SOC; ri.T_avg = T0;
+    ri.flag = flag; ri.iterations = iter; ri.t_end = t_end; ri.V = cellV<M>(S.yy); ri.I = S.yy[O_I]; ri.SOC = SOC; ri.T_avg = cellTavg<M>(S, S.yy);
     if (lane == 0) info[r] = ri;
     t_global = t_end; have_prev = true; prev_V = ri.V; prev_I = ri.I;
     if (flag < 0) { for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; z.iterations = 0; info[q] = z; } break; }

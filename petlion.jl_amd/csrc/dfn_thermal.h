@@ -1,0 +1,817 @@
+// dfn_thermal.h -- the temperature = true model (config C3): lumped-in-y 1D heat equation over a | p | s | n | z coupled to the DFN rows.
+//
+// Replaces, for ensembles, what the reference generates from residuals_T! (src/physics_equations/residuals.jl:299-489),
+// build_heat_generation_rates! (auxiliary_states_and_coefficients.jl:344-518), the T-dependent closures
+// (custom_functions.jl:1-57,96,123-152) and the dT control row (input_methods.jl:182-189, scalar_residual.jl:167-172,347-372).
+//
+// Structure of the Newton matrix and how it is solved (one wavefront per cell, included at the end of dfn_cell.h):
+//   * particles: (kappa_i M - cj I) with kappa_i = D_s(T_i)/Rp^2 differing per node -> spectral resolvent
+//     V diag(1/(kappa_i lam - cj)) W applied as two 10x10 mat-vecs; the T_i column of the particle rows folds into the node block
+//   * j: node-local pivot as in the isothermal model (with the extra T column)
+//   * current collectors: two scalar tridiagonal chains (10 nodes each), eliminated onto T of node 0 / node 29 and the column of I
+//   * 30 cell-sandwich nodes: block-tridiagonal, 4x4 blocks over (c_e, Phi_e, Phi_s, T), systolic DPP sweeps
+//   * the one-sided 3-point gradient stencils of the ohmic heat (nodes 0, 9, 20, 29) reach a second neighbour: rank-4 Woodbury
+//   * control row (I, V, dT, and the algebraic twin of dT used by the consistent initialisation): bordered solve
+#pragma once
+
+namespace pl {
+
+// K_eff(c_e, T) with both partials, custom_functions.jl:96
+__device__ __forceinline__ void keff_T(double c, double T, double& K, double& dKc, double& dKT) {
+  const double A = -10.5 + 0.668 * 1e-3 * c + 0.494 * 1e-6 * c * c;
+  const double B = 0.074 - 1.78 * 1e-5 * c - 8.86 * 1e-10 * c * c;
+  const double C = -6.96 * 1e-5 + 2.8 * 1e-8 * c;
+  const double P = A + B * T + C * T * T;
+  const double dPc = (0.668 * 1e-3 + 2 * 0.494 * 1e-6 * c) + (-1.78 * 1e-5 - 2 * 8.86 * 1e-10 * c) * T + 2.8 * 1e-8 * T * T;
+  const double dPT = B + 2.0 * C * T;
+  K = 1e-4 * c * P * P;
+  dKc = 1e-4 * (P * P + 2.0 * c * P * dPc);
+  dKT = 2e-4 * c * P * dPT;
+}
+
+// OCV_LCO with the entropic term always on (temperature = true), custom_functions.jl:123-136: U, dU/dx, dU/dT, d2U/dxdT
+__device__ __forceinline__ void ocv_lco_T(double x, double T, double& U, double& dUdx, double& dUdT, double& ddUdT) {
+  const double x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x6 = x4 * x2, x8 = x4 * x4, x10 = x8 * x2;
+  const double P = -4.656 + 88.669 * x2 - 401.119 * x4 + 342.909 * x6 - 462.471 * x8 + 433.434 * x10;
+  const double Q = -1 + 18.933 * x2 - 79.532 * x4 + 37.311 * x6 - 73.083 * x8 + 95.96 * x10;
+  const double dP = x * (2 * 88.669 - 4 * 401.119 * x2 + 6 * 342.909 * x4 - 8 * 462.471 * x6 + 10 * 433.434 * x8);
+  const double dQ = x * (2 * 18.933 - 4 * 79.532 * x2 + 6 * 37.311 * x4 - 8 * 73.083 * x6 + 10 * 95.96 * x8);
+  const double n = 0.199521039 - 0.928373822 * x + 1.364550689000003 * x2 - 0.6115448939999998 * x3;
+  const double d = 1 - 5.661479886999997 * x + 11.47636191 * x2 - 9.82431213599998 * x3 + 3.048755063 * x4;
+  const double dn = -0.928373822 + 2 * 1.364550689000003 * x - 3 * 0.6115448939999998 * x2;
+  const double dd = -5.661479886999997 + 2 * 11.47636191 * x - 3 * 9.82431213599998 * x2 + 4 * 3.048755063 * x3;
+  dUdT = -0.001 * n / d;
+  ddUdT = -0.001 * (dn * d - n * dd) / (d * d);
+  U = P / Q + dUdT * (T - TREF);
+  dUdx = (dP * Q - P * dQ) / (Q * Q) + ddUdT * (T - TREF);
+}
+
+// OCV_LiC6, custom_functions.jl:139-152
+__device__ __forceinline__ void ocv_lic6_T(double x, double T, double& U, double& dUdx, double& dUdT, double& ddUdT) {
+  const double s0 = sqrt(x > 0.0 ? x : 0.0);
+  const double xm = x > 1e-4 ? x : 1e-4;
+  const double s1 = sqrt(xm);
+  const double e1 = exp(0.9 - 15 * x), e2 = exp(0.4465 * x - 0.4108);
+  U = 0.7222 + 0.1387 * x + 0.029 * s0 - 0.0172 / x + 0.0019 / (s1 * x) + 0.2808 * e1 - 0.7984 * e2;
+  double dv = 0.1387 + 0.0172 / (x * x) - 0.2808 * 15 * e1 - 0.7984 * 0.4465 * e2;
+  if (x > 0.0) dv += 0.029 * 0.5 / s0;
+  if (x > 1e-4) dv += 0.0019 * (-1.5) / (x * x * s1);
+  else dv += -0.0019 / (s1 * x * x);
+  const double x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x, x6 = x3 * x3, x7 = x6 * x, x8 = x4 * x4;
+  const double n = 0.001 * (0.005269056 + 3.299265709 * x - 91.79325798 * x2 + 1004.911008 * x3 - 5812.278127 * x4 + 19329.7549 * x5 - 37147.8947 * x6 + 38379.18127 * x7 - 16515.05308 * x8);
+  const double q = 1 - 48.09287227 * x + 1017.234804 * x2 - 10481.80419 * x3 + 59431.3 * x4 - 195881.6488 * x5 + 374577.3152 * x6 - 385821.1607 * x7 + 165705.8597 * x8;
+  const double dn = 0.001 * (3.299265709 - 2 * 91.79325798 * x + 3 * 1004.911008 * x2 - 4 * 5812.278127 * x3 + 5 * 19329.7549 * x4 - 6 * 37147.8947 * x5 + 7 * 38379.18127 * x6 - 8 * 16515.05308 * x7);
+  const double dq = -48.09287227 + 2 * 1017.234804 * x - 3 * 10481.80419 * x2 + 4 * 59431.3 * x3 - 5 * 195881.6488 * x4 + 6 * 374577.3152 * x5 - 7 * 385821.1607 * x6 + 8 * 165705.8597 * x7;
+  dUdT = n / q;
+  ddUdT = (dn * q - n * dq) / (q * q);
+  U += dUdT * (T - TREF);
+  dUdx = dv + ddUdT * (T - TREF);
+}
+
+__device__ __forceinline__ int tsec_of(int it) { return it < NA ? 0 : (it < NA + NP ? 1 : (it < NA + NP + NS ? 2 : (it < NA + NE ? 3 : 4))); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// constants of the heat equation (lanes 0..49 own one T node each)
+// ------------------------------------------------------------------------------------------------------------------
+template <class M>
+__device__ inline void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th) {
+  static_assert(M::CHEM == PLH_CHEM_LCO_LIC6 && !M::SEI, "temperature = true is instantiated for LCO/LiC6 without aging");
+  const int lane = lane_id();
+  const CellConst& c = S.cc;
+  const int* ix = tb->thidx;
+  auto& TP = S.th;
+  if (lane < NT) {
+    const int it = lane, k = tsec_of(it);
+    const double la = th[ix[K_l_a]], lz = th[ix[K_l_z]];
+    const double hh[5] = {la / NA, c.h[0], c.h[1], c.h[2], lz / NZ};
+    const double lam[5] = {th[ix[K_lam_a]], th[ix[K_lam_p]], th[ix[K_lam_s]], th[ix[K_lam_n]], th[ix[K_lam_z]]};
+    const double rcp[5] = {th[ix[K_rho_a]] * th[ix[K_Cp_a]], th[ix[K_rho_p]] * th[ix[K_Cp_p]], th[ix[K_rho_s]] * th[ix[K_Cp_s]],
+                           th[ix[K_rho_n]] * th[ix[K_Cp_n]], th[ix[K_rho_z]] * th[ix[K_Cp_z]]};
+    const int loc = it - k * 10;                         // every section has 10 nodes
+    const bool first = loc == 0, last = loc == 9;
+    const double h = hh[k], lm = lam[k];
+    double aL = first ? 0.0 : lm / (h * h), aU = last ? 0.0 : lm / (h * h), aD = -(aL + aU), aC = 0.0;
+    if (last && k < 4) {                                  // left CV of an interface (residuals.jl:354-439)
+      const double hl = h, hr = hh[k + 1];
+      const double beta = (hl / 2) / (hl / 2 + hr / 2);
+      const double lif = hmean(beta, lm, lam[k + 1]);
+      const double last_l = lm / hl, first_r = lif / (hr / 2 + hl / 2);
+      aL = last_l / hl; aD = -(last_l + first_r) / hl; aU = first_r / hl;
+    }
+    if (first && k > 0) {                                 // right CV of an interface
+      const double hl = hh[k - 1], hr = h;
+      const double beta = (hl / 2) / (hl / 2 + hr / 2);
+      const double lif = hmean(beta, lam[k - 1], lm);
+      const double first_r = lif / (hr / 2 + hl / 2), second_r = lm / hr;
+      aL = first_r / hr; aD = -(second_r + first_r) / hr; aU = second_r / hr;
+    }
+    const double hc = th[ix[K_h_cell]], Tamb = th[ix[K_T_amb]];
+    if (it == 0) { aD -= hc / h; aC = hc * Tamb / h; }                   // convective BCs at the two outer faces
+    if (it == NT - 1) { aD -= hc / h; aC = hc * Tamb / h; }
+    const double rc = 1.0 / rcp[k];
+    TP.aL[it] = aL * rc; TP.aD[it] = aD * rc; TP.aU[it] = aU * rc; TP.aC[it] = aC * rc; TP.rc[it] = rc;
+    TP.wT[it] = h / (la + (c.h[0] * NP + c.h[1] * NS + c.h[2] * NN) + lz);
+    if (it == 0) TP.qI[0] = c.I1C * c.I1C / th[ix[K_sig_a]] * rc;
+    if (it == NT - 1) TP.qI[1] = c.I1C * c.I1C / th[ix[K_sig_z]] * rc;
+  }
+  if (lane < 12) (&TP.TX2[0][0])[lane] = 0.0;
+  if (lane == 0) TP.cjf = 0.0;
+  PL_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// node pass: lanes 0..29 own control volume i / edge i of the cell sandwich; lanes 32..51 own the 20 collector T rows
+// ------------------------------------------------------------------------------------------------------------------
+template <bool WANT_RES, bool WANT_JAC, class M>
+__device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
+  PL_MODEL(M);
+  constexpr int O_T = M::O_T;
+  const int lane = lane_id();
+  const CellConst& c = S.cc;
+  auto& TP = S.th;
+  const int i = lane < NE ? lane : NE - 1;
+  const bool act = lane < NE;
+  const int sc = sec_of(i);
+  const bool elec = sc != 1;
+  const int jx = sc == 0 ? i : i - NS;
+  const int it = NA + i;
+  const double ce = Y[O_CE + i], pe = Y[O_PE + i], T = Y[O_T + it], Tl = Y[O_T + it - 1], Tr = Y[O_T + it + 1];
+  const double jv_l = Y[O_J + jx], ps_l = Y[O_PS + jx], cs_l = Y[O_CS + jx * NR + NR - 1], yI = Y[O_I];
+  const double ypce = WANT_RES ? YP[O_CE + i] : 0.0, ypT = WANT_RES ? YP[O_T + it] : 0.0;
+  const double h0 = c.h[0], h1 = c.h[1], h2 = c.h[2];
+  const double h = sc == 0 ? h0 : (sc == 1 ? h1 : h2);
+  const double epsc = c.eps[sc], bfc = c.bf[sc];
+  const double cKfac = c.Kfac, ctplus = c.tplus, cI1C = c.I1C;
+  double K, dKc, dKT; keff_T(ce, T, K, dKc, dKT);
+  K *= bfc; dKc *= bfc; dKT *= bfc;
+  const double D = c.Dc[sc];                                            // D_eff_linear: no c_e / T dependence (custom_functions.jl:59-69)
+  const double ce_n = shift_down1(ce), pe_n = shift_down1(pe), K_n = shift_down1(K), dKc_n = shift_down1(dKc), dKT_n = shift_down1(dKT), T_n = shift_down1(T);
+  const double ce_p = shift_up1(ce), pe_p = shift_up1(pe);
+  double beta = 0.5, dist = h;
+  if (i == NP - 1) { beta = (h0 / 2) / (h1 / 2 + h0 / 2); dist = h0 / 2 + h1 / 2; }
+  if (i == NP + NS - 1) { beta = (h1 / 2) / (h2 / 2 + h1 / 2); dist = h1 / 2 + h2 / 2; }
+  const bool edge = i < NE - 1;
+  const double denK = beta * K_n + (1 - beta) * K, Kh = K * K_n / denK;
+  const double D_n = shift_down1(D);
+  const double denD = beta * D_n + (1 - beta) * D, Dhm = D * D_n / denD;    // differs from D only at the p|s and s|n interfaces
+  const double denC = beta * ce_n + (1 - beta) * ce, cb = ce * ce_n / denC;
+  const double denT = beta * T_n + (1 - beta) * T, Tb = T * T_n / denT;
+  const double dc = (ce_n - ce) / dist;
+  const double w = Kh / dist;
+  const double g = Kh * Tb * dc / cb;
+  const double E = edge ? w * (pe - pe_n) + cKfac * g : 0.0;
+  const double Nf = edge ? Dhm * dc : 0.0;
+  const double E_p = shift_up1(E), Nf_p = shift_up1(Nf);
+  const double Em = i > 0 ? E_p : 0.0, Nm = i > 0 ? Nf_p : 0.0;
+  // electrode quantities with per-node Arrhenius factors
+  const double a = sc == 0 ? c.a_p : c.a_n;
+  const double jv = elec ? jv_l : 0.0, ps = elec ? ps_l : 0.0, cs = elec ? cs_l : 1.0;
+  const double cmax = sc == 0 ? c.cmaxp : c.cmaxn;
+  const double sg = sc == 0 ? c.sig_p : c.sig_n;
+  const double rT = 1.0 / T;
+  const double dinv = rT - 1.0 / TREF;
+  const double EaK = sc == 0 ? c.EaKp : c.EaKn, EaD = sc == 0 ? c.EaDp : c.EaDn;
+  const double kk = (sc == 0 ? c.kp : c.kn) * exp(-EaK * dinv);
+  const double kap = (sc == 0 ? c.kap_p : c.kap_n) * exp(-EaD * dinv);
+  if (act && elec) { TP.kapP[jx] = kap; if (WANT_JAC) TP.dkapP[jx] = kap * EaD * rT * rT; }
+  double U = 0, dU = 0, dUdT = 0, ddUdT = 0;
+  if (sc == 0) ocv_lco_T(cs / cmax, T, U, dU, dUdT, ddUdT);
+  else if (sc == 2) ocv_lic6_T(cs / cmax, T, U, dU, dUdT, ddUdT);
+  const double eta = ps - pe - U;
+  const double arg = ce * cs * (cmax - cs);
+  const double sq = sqrt(arg > 0.0 ? arg : 0.0);
+  const double fRT = 0.5 * FAR / RGAS * rT;
+  const double xx = fRT * eta;
+  double sh, chh; sinh_cosh(xx, sh, chh);
+  const double ps_p = shift_up1(ps), ps_n = shift_down1(ps);
+  const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
+  // gradient stencils of the heat sources (build_heat_generation_rates!, aux...jl:344-518): X' = em X[i-1] + e0 X[i] + ep X[i+1] + e2 X[i+-2]
+  const bool far_right = (i == 0) || (i == NP + NS);                    // the second neighbour is i+2 (else i-2)
+  // (both shifts are issued by every lane: cross-lane operations must not sit in divergent control flow)
+  const double ce_nn = shift_down1(ce_n), ce_pp = shift_up1(ce_p), pe_nn = shift_down1(pe_n), pe_pp = shift_up1(pe_p);
+  const double ps_nn = shift_down1(ps_n), ps_pp = shift_up1(ps_p);
+  const double ce_2 = far_right ? ce_nn : ce_pp, pe_2 = far_right ? pe_nn : pe_pp, ps_2 = far_right ? ps_nn : ps_pp;
+  const double r2 = c.r2h[sc];
+  double em = -r2, e0 = 0.0, ep = r2, e2 = 0.0;                         // electrolyte quantities (Phi_e, c_e)
+  if (i == 0) { em = 0.0; e0 = -3 * r2; ep = 4 * r2; e2 = -r2; }
+  else if (i == NP - 1) { em = -c.qps_r; ep = c.qps_r; }
+  else if (i == NP) { em = -c.qps_l; ep = c.qps_l; }
+  else if (i == NP + NS - 1) { em = -c.qsn_r; ep = c.qsn_r; }
+  else if (i == NP + NS) { em = -c.qsn_l; ep = c.qsn_l; }
+  else if (i == NE - 1) { ep = 0.0; e0 = 3 * r2; em = -4 * r2; e2 = r2; }
+  double sm = -r2, s0 = 0.0, sp = r2, s2 = 0.0;                         // Phi_s within one electrode
+  if (first) { sm = 0.0; s0 = -3 * r2; sp = 4 * r2; s2 = -r2; }
+  else if (last) { sp = 0.0; s0 = 3 * r2; sm = -4 * r2; s2 = r2; }
+  if (!elec) { sm = s0 = sp = s2 = 0.0; }
+  const double dPe = em * pe_p + e0 * pe + ep * pe_n + e2 * pe_2;
+  const double dce = em * ce_p + e0 * ce + ep * ce_n + e2 * ce_2;
+  const double dPs = sm * ps_p + s0 * ps + sp * ps_n + s2 * ps_2;
+  const double rc = TP.rc[it];
+  const double Faj = elec ? FAR * a * jv : 0.0;
+  if (WANT_RES) {
+    if (act) {
+      const double src = elec ? (1 - ctplus) * 1.0 * a * jv : 0.0;
+      Fo[O_CE + i] = ((Nf - Nm) / h + src) / epsc - ypce;                 // residuals_c_e!, residuals.jl:6-106
+      Fo[O_PE + i] = (i < NE - 1) ? (E - Em - (elec ? h * FAR * a * jv : 0.0)) : pe;   // residuals_Φ_e!, residuals.jl:554-654
+      if (elec) {
+        Fo[O_J + jx] = 2.0 * kk * sq * sh - jv;                                        // residuals_j!, residuals.jl:491-517
+        const double lap = first ? (-ps + ps_n) : (last ? (ps_p - ps) : (ps_p - 2 * ps + ps_n));
+        double f = h * h * a * FAR * jv;
+        const double Idens = yI * cI1C;
+        if (i == 0) f += -Idens * h;
+        if (i == NE - 1) f += Idens * h;
+        Fo[O_PS + jx] = lap - f / sg;                                                  // residuals_Φ_s!, residuals.jl:656-703
+      }
+      // residuals_T!, residuals.jl:299-489 ; heat sources aux...jl:344-518
+      const double qrr = Faj * (T * dUdT + eta);
+      const double qohm = K * dPe * dPe + cKfac * K * T * (dce / ce) * dPe + (elec ? sg * dPs * dPs : 0.0);
+      Fo[O_T + it] = TP.aL[it] * Tl + TP.aD[it] * T + TP.aU[it] * Tr + TP.aC[it] + (qrr + qohm) * rc - ypT;
+    }
+    if (lane >= 32 && lane < 32 + NA + NZ) {                                          // current-collector rows
+      const int k = lane - 32, ic = k < NA ? k : NA + NE + (k - NA);
+      const double Tc = Y[O_T + ic], Tcl = ic > 0 ? Y[O_T + ic - 1] : 0.0, Tcr = ic < NT - 1 ? Y[O_T + ic + 1] : 0.0;
+      Fo[O_T + ic] = TP.aL[ic] * Tcl + TP.aD[ic] * Tc + TP.aU[ic] * Tcr + TP.aC[ic] + TP.qI[k < NA ? 0 : 1] * yI * yI - YP[O_T + ic];
+    }
+    if (mode == PLH_MODE_I || mode == PLH_MODE_V) {                                    // scalar_residual!, scalar_residual.jl:167-172
+      if (lane == 0) Fo[O_I] = (mode == PLH_MODE_I) ? (yI - value) : (Y[O_PS] - Y[O_PS + NJ - 1] - value);
+    } else if (mode == PLH_MODE_DT) {                                                  // constant_temperature: value - sum w_i YP[T_i] / L
+      const double sT = wave_sum(lane < NT ? TP.wT[lane] * YP[O_T + lane] : 0.0);
+      if (lane == 0) Fo[O_I] = value - sT;
+    } else {                                                                           // algebraic twin: YP_T -> rhs_T(Y), scalar_residual.jl:347-372
+      PL_SYNC();
+      const double sT = wave_sum(lane < NT ? TP.wT[lane] * (Fo[O_T + lane] + YP[O_T + lane]) : 0.0);
+      if (lane == 0) Fo[O_I] = value - sT;
+    }
+  }
+  if (WANT_JAC) {
+    if (lane == 0) { TP.qIJ[0] = 2.0 * TP.qI[0] * yI; TP.qIJ[1] = 2.0 * TP.qI[1] * yI; }   // d(collector row)/dI (Joule heat ~ I^2)
+    const double dKh_a = beta * K_n * K_n / (denK * denK), dKh_b = (1 - beta) * K * K / (denK * denK);   // dKh/dK_i, dKh/dK_{i+1}
+    const double dcb_a = beta * ce_n * ce_n / (denC * denC), dcb_b = (1 - beta) * ce * ce / (denC * denC);
+    const double dTb_a = beta * T_n * T_n / (denT * denT), dTb_b = (1 - beta) * T * T / (denT * denT);
+    const double Tq = Tb / dist;
+    const double dcn = ce_n - ce;
+    const double dg_a = Tq * (dKh_a * dKc * dcn / cb - Kh / cb - Kh * dcn * dcb_a / (cb * cb));
+    const double dg_b = Tq * (dKh_b * dKc_n * dcn / cb + Kh / cb - Kh * dcn * dcb_b / (cb * cb));
+    const double Ea = edge ? (pe - pe_n) * dKh_a * dKc / dist + cKfac * dg_a : 0.0;
+    const double Eb = edge ? (pe - pe_n) * dKh_b * dKc_n / dist + cKfac * dg_b : 0.0;
+    const double gq = dc / cb;                                                         // g = Kh Tb gq
+    const double ETa = edge ? (pe - pe_n) * dKh_a * dKT / dist + cKfac * gq * (dKh_a * dKT * Tb + Kh * dTb_a) : 0.0;
+    const double ETb = edge ? (pe - pe_n) * dKh_b * dKT_n / dist + cKfac * gq * (dKh_b * dKT_n * Tb + Kh * dTb_b) : 0.0;
+    const double we = edge ? w : 0.0;
+    const double Na = edge ? -Dhm / dist : 0.0, Nb = edge ? Dhm / dist : 0.0;
+    const double Ea_p = shift_up1(Ea), Eb_p = shift_up1(Eb), we_p = shift_up1(we), Na_p = shift_up1(Na), Nb_p = shift_up1(Nb);
+    const double ETa_p = shift_up1(ETa), ETb_p = shift_up1(ETb);
+    if (act) {
+      const double he = h * epsc;
+      S.ceL[i] = i > 0 ? -Na_p / he : 0.0;
+      S.ceD[i] = (Na - (i > 0 ? Nb_p : 0.0)) / he;
+      S.ceU[i] = Nb / he;
+      S.ceJ[i] = elec ? (1 - ctplus) * a / epsc : 0.0;
+      if (i < NE - 1) {
+        S.peL[i] = i > 0 ? -we_p : 0.0; S.peD[i] = (i > 0 ? we_p : 0.0) + we; S.peU[i] = -we;
+        S.pcL[i] = i > 0 ? -Ea_p : 0.0; S.pcD[i] = Ea - (i > 0 ? Eb_p : 0.0); S.pcU[i] = Eb;
+        TP.ptL[i] = i > 0 ? -ETa_p : 0.0; TP.ptD[i] = ETa - (i > 0 ? ETb_p : 0.0); TP.ptU[i] = ETb;
+        S.peJ[i] = elec ? -h * FAR * a : 0.0;
+      } else {
+        S.peL[i] = 0; S.peD[i] = 1.0; S.peU[i] = 0; S.pcL[i] = 0; S.pcD[i] = 0; S.pcU[i] = 0; S.peJ[i] = 0;
+        TP.ptL[i] = 0; TP.ptD[i] = 0; TP.ptU[i] = 0;
+      }
+      if (elec) {
+        const double pos = arg > 0.0 ? 1.0 : 0.0;
+        const double inv_sq = pos > 0 ? 1.0 / sq : 0.0;
+        S.gce[jx] = kk * sh * cs * (cmax - cs) * inv_sq;
+        S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * chh * fRT * (-dU / cmax));
+        S.gps[jx] = 2.0 * kk * sq * chh * fRT;
+        S.gpe[jx] = -S.gps[jx];
+        TP.gT[jx] = 2.0 * kk * sq * (EaK * rT * rT * sh + chh * (-xx * rT - fRT * dUdT));
+        S.psJ[jx] = -h * h * a * FAR / sg;
+        TP.TJ[jx] = rc * FAR * a * (T * dUdT + eta);
+        TP.Tcs[jx] = rc * Faj * (T * ddUdT - dU) / cmax;
+      }
+      // T row: couplings to (c_e, Phi_e, Phi_s, T) of nodes i-1, i, i+1 (+ the second neighbour at the four one-sided stencils)
+      const double qPe = 2.0 * K * dPe + cKfac * K * T * (dce / ce);               // dQ/d(dPe)
+      const double qCe = cKfac * K * T * dPe / ce;                                   // dQ/d(dce)
+      const double qPs = elec ? 2.0 * sg * dPs : 0.0;                                // dQ/d(dPs)
+      const double qce_loc = dKc * dPe * dPe + cKfac * T * dPe * (dKc * dce / ce - K * dce / (ce * ce));
+      TP.TcL[i] = rc * qCe * em; TP.TcD[i] = rc * (qCe * e0 + qce_loc); TP.TcU[i] = rc * qCe * ep;
+      TP.TeL[i] = rc * qPe * em; TP.TeD[i] = rc * (qPe * e0 - Faj); TP.TeU[i] = rc * qPe * ep;
+      TP.TsL[i] = rc * qPs * sm; TP.TsD[i] = rc * (qPs * s0 + Faj); TP.TsU[i] = rc * qPs * sp;
+      TP.TtD[i] = rc * (dKT * dPe * dPe + cKfac * (dKT * T + K) * (dce / ce) * dPe);   // (the reversible + reaction heat has no net dT term)
+      if (i == 0) { TP.TX2[0][0] = rc * qCe * e2; TP.TX2[0][1] = rc * qPe * e2; TP.TX2[0][2] = rc * qPs * s2; }
+      if (i == NP - 1) { TP.TX2[1][0] = 0.0; TP.TX2[1][1] = 0.0; TP.TX2[1][2] = rc * qPs * s2; }
+      if (i == NP + NS) { TP.TX2[2][0] = 0.0; TP.TX2[2][1] = 0.0; TP.TX2[2][2] = rc * qPs * s2; }
+      if (i == NE - 1) { TP.TX2[3][0] = rc * qCe * e2; TP.TX2[3][1] = rc * qPe * e2; TP.TX2[3][2] = rc * qPs * s2; }
+    }
+  }
+}
+
+// c_s rows with per-particle kappa(T) (residuals_c_s_avg!, residuals.jl:128-180); WANT_JAC also stores W c (needed for the T column)
+template <bool WANT_JAC, class M>
+__device__ inline void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const double* Y, const double* YP, double* Fo) {
+  PL_MODEL(M);
+  const int lane = lane_id();
+  const CellConst& c = S.cc;
+  auto& TP = S.th;
+  const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
+  double Mrow[NR], Wrow[NR];
+  for (int k = 0; k < NR; k++) { Mrow[k] = S.Mr[r * NR + k]; if (WANT_JAC) Wrow[k] = tb->W[r * NR + k]; }
+#pragma unroll
+  for (int pass = 0; pass < 4; pass++) {
+    const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
+    double acc = 0.0, wc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NR; k++) { const double v = Y[O_CS + p * NR + k]; acc += Mrow[k] * v; if (WANT_JAC) wc += Wrow[k] * v; }
+    double rhs = TP.kapP[p] * acc;
+    if (r == NR - 1) rhs += (p < NP ? c.bj_p : c.bj_n) * Y[O_J + p];
+    if (lane < 60 && p0 < NJ) { Fo[O_CS + p * NR + r] = rhs - YP[O_CS + p * NR + r]; if (WANT_JAC) TP.Wc[p][r] = wc; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// linear algebra
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inv4(const double* A, double* B) {
+  // cofactor expansion through the 2x2 minors of the top and bottom row pairs
+  const double s0 = A[0] * A[5] - A[4] * A[1], s1 = A[0] * A[6] - A[4] * A[2], s2 = A[0] * A[7] - A[4] * A[3];
+  const double s3 = A[1] * A[6] - A[5] * A[2], s4 = A[1] * A[7] - A[5] * A[3], s5 = A[2] * A[7] - A[6] * A[3];
+  const double c5 = A[10] * A[15] - A[14] * A[11], c4 = A[9] * A[15] - A[13] * A[11], c3 = A[9] * A[14] - A[13] * A[10];
+  const double c2 = A[8] * A[15] - A[12] * A[11], c1 = A[8] * A[14] - A[12] * A[10], c0 = A[8] * A[13] - A[12] * A[9];
+  const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+  const double id = 1.0 / det;
+  B[0] = (A[5] * c5 - A[6] * c4 + A[7] * c3) * id;
+  B[1] = (-A[1] * c5 + A[2] * c4 - A[3] * c3) * id;
+  B[2] = (A[13] * s5 - A[14] * s4 + A[15] * s3) * id;
+  B[3] = (-A[9] * s5 + A[10] * s4 - A[11] * s3) * id;
+  B[4] = (-A[4] * c5 + A[6] * c2 - A[7] * c1) * id;
+  B[5] = (A[0] * c5 - A[2] * c2 + A[3] * c1) * id;
+  B[6] = (-A[12] * s5 + A[14] * s2 - A[15] * s1) * id;
+  B[7] = (A[8] * s5 - A[10] * s2 + A[11] * s1) * id;
+  B[8] = (A[4] * c4 - A[5] * c2 + A[7] * c0) * id;
+  B[9] = (-A[0] * c4 + A[1] * c2 - A[3] * c0) * id;
+  B[10] = (A[12] * s4 - A[13] * s2 + A[15] * s0) * id;
+  B[11] = (-A[8] * s4 + A[9] * s2 - A[11] * s0) * id;
+  B[12] = (-A[4] * c3 + A[5] * c1 - A[6] * c0) * id;
+  B[13] = (A[0] * c3 - A[1] * c1 + A[2] * c0) * id;
+  B[14] = (-A[12] * s3 + A[13] * s1 - A[14] * s0) * id;
+  B[15] = (A[8] * s3 - A[9] * s1 + A[10] * s0) * id;
+}
+
+// the sparse off-diagonal node blocks.  Lower block of node i (rows of i x unknowns of i-1) / upper block (rows of i x unknowns of i+1):
+//   [ ce 0 0 0 ; pc pe 0 pt ; 0 0 s 0 ; Tc Te Ts Tt ]
+struct OffBlk { double ce, pc, pe, pt, s, Tc, Te, Ts, Tt; };
+template <class M> __device__ __forceinline__ OffBlk lower_blk(const CellLDS<M>& S, int i, bool alg_only) {
+  OffBlk b; const auto& TP = S.th;
+  const int sci = sec_of(i), scp = sec_of(i > 0 ? i - 1 : 0);
+  const bool z = i == 0;
+  b.ce = (alg_only || z) ? 0.0 : S.ceL[i]; b.pc = (alg_only || z) ? 0.0 : S.pcL[i]; b.pe = z ? 0.0 : S.peL[i]; b.pt = (alg_only || z) ? 0.0 : TP.ptL[i];
+  b.s = (!z && sci != 1 && scp == sci) ? 1.0 : 0.0;
+  const bool zt = alg_only || z;
+  b.Tc = zt ? 0.0 : TP.TcL[i]; b.Te = zt ? 0.0 : TP.TeL[i]; b.Ts = zt ? 0.0 : TP.TsL[i]; b.Tt = zt ? 0.0 : TP.aL[NA + i];
+  return b;
+}
+template <class M> __device__ __forceinline__ OffBlk upper_blk(const CellLDS<M>& S, int i, bool alg_only) {
+  OffBlk b; const auto& TP = S.th;
+  const int sci = sec_of(i), scn = sec_of(i < NE - 1 ? i + 1 : NE - 1);
+  const bool z = i == NE - 1;
+  b.ce = (alg_only || z) ? 0.0 : S.ceU[i]; b.pc = (alg_only || z) ? 0.0 : S.pcU[i]; b.pe = z ? 0.0 : S.peU[i]; b.pt = (alg_only || z) ? 0.0 : TP.ptU[i];
+  b.s = (!z && sci != 1 && scn == sci) ? 1.0 : 0.0;
+  const bool zt = alg_only || z;
+  b.Tc = zt ? 0.0 : TP.TcU[i]; b.Te = zt ? 0.0 : TP.TeU[i]; b.Ts = zt ? 0.0 : TP.TsU[i]; b.Tt = zt ? 0.0 : TP.aU[NA + i];
+  return b;
+}
+
+// systolic forward/backward substitution for NRHS right-hand sides at once (see thomas_sweeps in dfn_cell.h); r[q][0..3] in/out
+template <int NRHS, class M>
+__device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_only, double (&r)[NRHS][4]) {
+  const int lane = lane_id();
+  const int i = lane < NE ? lane : NE - 1;
+  double L[16], Di[16], G[16];
+  for (int k = 0; k < 16; k++) { L[k] = S.LD[i][k]; Di[k] = S.Dinv[i][k]; }
+  {
+    const OffBlk u = upper_blk(S, i, alg_only);
+    for (int rr = 0; rr < 4; rr++) {       // G = Dinv U
+      const double d0 = Di[rr * 4], d1 = Di[rr * 4 + 1], d2 = Di[rr * 4 + 2], d3 = Di[rr * 4 + 3];
+      G[rr * 4 + 0] = d0 * u.ce + d1 * u.pc + d3 * u.Tc;
+      G[rr * 4 + 1] = d1 * u.pe + d3 * u.Te;
+      G[rr * 4 + 2] = d2 * u.s + d3 * u.Ts;
+      G[rr * 4 + 3] = d1 * u.pt + d3 * u.Tt;
+    }
+  }
+  double y[NRHS][4];
+  for (int q = 0; q < NRHS; q++) for (int k = 0; k < 4; k++) y[q][k] = r[q][k];
+#pragma unroll 2
+  for (int itr = 1; itr < NE; itr++) {
+#pragma unroll
+    for (int q = 0; q < NRHS; q++) {
+      const double p0 = shift_up1(y[q][0]), p1 = shift_up1(y[q][1]), p2 = shift_up1(y[q][2]), p3 = shift_up1(y[q][3]);
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) y[q][rr] = r[q][rr] - (L[rr * 4] * p0 + L[rr * 4 + 1] * p1 + L[rr * 4 + 2] * p2 + L[rr * 4 + 3] * p3);
+    }
+  }
+  double z[NRHS][4];
+#pragma unroll
+  for (int q = 0; q < NRHS; q++) {
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) z[q][rr] = Di[rr * 4] * y[q][0] + Di[rr * 4 + 1] * y[q][1] + Di[rr * 4 + 2] * y[q][2] + Di[rr * 4 + 3] * y[q][3];
+    for (int k = 0; k < 4; k++) r[q][k] = z[q][k];
+  }
+#pragma unroll 2
+  for (int itr = NE - 2; itr >= 0; itr--) {
+#pragma unroll
+    for (int q = 0; q < NRHS; q++) {
+      const double q0 = shift_down1(r[q][0]), q1 = shift_down1(r[q][1]), q2 = shift_down1(r[q][2]), q3 = shift_down1(r[q][3]);
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) r[q][rr] = z[q][rr] - (G[rr * 4] * q0 + G[rr * 4 + 1] * q1 + G[rr * 4 + 2] * q2 + G[rr * 4 + 3] * q3);
+    }
+  }
+}
+
+// rows of the Woodbury update: node (lane) and column weights of the four out-of-band T-row entries
+__device__ __forceinline__ int wb_src_node(int k) { return k == 0 ? 2 : (k == 1 ? NP - 3 : (k == 2 ? NP + NS + 2 : NE - 3)); }
+__device__ __forceinline__ int wb_row_node(int k) { return k == 0 ? 0 : (k == 1 ? NP - 1 : (k == 2 ? NP + NS : NE - 1)); }
+
+// s_k = (out-of-band row k) . y   for the solution held one node per lane
+template <class M>
+__device__ __forceinline__ void wb_dots(const CellLDS<M>& S, const double* y, double* s) {
+  const auto& TP = S.th;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int src = wb_src_node(k);
+    s[k] = TP.TX2[k][0] * lane_bcast(y[0], src) + TP.TX2[k][1] * lane_bcast(y[1], src) + TP.TX2[k][2] * lane_bcast(y[2], src);
+  }
+}
+// y -= Z C^-1 s
+template <class M>
+__device__ __forceinline__ void wb_apply(const CellLDS<M>& S, double* y, const double* s) {
+  const auto& TP = S.th;
+  const int lane = lane_id();
+  const int i = lane < NE ? lane : NE - 1;
+  double m[4];
+  for (int a = 0; a < 4; a++) m[a] = TP.Cinv[a * 4] * s[0] + TP.Cinv[a * 4 + 1] * s[1] + TP.Cinv[a * 4 + 2] * s[2] + TP.Cinv[a * 4 + 3] * s[3];
+  for (int cc = 0; cc < 4; cc++) y[cc] -= TP.Z[0][i][cc] * m[0] + TP.Z[1][i][cc] * m[1] + TP.Z[2][i][cc] * m[2] + TP.Z[3][i][cc] * m[3];
+}
+
+template <class M>
+__device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
+  PL_MODEL(M);
+  const int lane = lane_id();
+  const CellConst& c = S.cc;
+  auto& TP = S.th;
+  const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
+  // 1. particle resolvents in spectral form
+  if (!alg_only) {
+    const double lam_r = tb->LAM[r];
+    for (int pass = 0; pass < 4; pass++) {
+      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
+      if (lane < 60 && p0 < NJ) TP.rdiag[p][r] = 1.0 / (TP.kapP[p] * lam_r - cj);
+    }
+    PL_SYNC();
+    double Vrow[NR], wl[NR], lm[NR];
+    for (int m = 0; m < NR; m++) { Vrow[m] = tb->V[r * NR + m]; wl[m] = tb->W[m * NR + NR - 1]; lm[m] = tb->LAM[m]; }
+    for (int pass = 0; pass < 4; pass++) {
+      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
+      double ae = 0.0, aq = 0.0;
+      for (int m = 0; m < NR; m++) { const double f = Vrow[m] * TP.rdiag[p][m]; ae += f * wl[m]; aq += f * lm[m] * TP.Wc[p][m]; }
+      if (lane < 60 && p0 < NJ) { TP.AinvE[p][r] = ae; TP.AinvQ[p][r] = aq * TP.dkapP[p]; }
+    }
+    // 2. collector chains: (aL, aD - cj, aU) x = rhs by the Thomas algorithm, lane 62 = Al, lane 63 = Cu.  Two fixed right-hand
+    //    sides: the coupling to T of the neighbouring cell node (Al: last row, through aU; Cu: first row, through aL) and the column of I
+    if (lane >= 62) {
+      const int q = lane - 62, base = q == 0 ? 0 : NA + NE;
+      double cp[NA], fc[NA], fi[NA];
+      for (int k = 0; k < NA; k++) {
+        const int ic = base + k;
+        const double rcpl = (q == 0 && k == NA - 1) ? TP.aU[ic] : ((q == 1 && k == 0) ? TP.aL[ic] : 0.0);
+        if (k == 0) { TP.cM[q][0] = 0.0; cp[0] = 1.0 / (TP.aD[ic] - cj); fc[0] = rcpl; fi[0] = TP.qIJ[q]; }
+        else {
+          const double mlt = TP.aL[ic] * cp[k - 1];
+          TP.cM[q][k] = mlt;
+          cp[k] = 1.0 / ((TP.aD[ic] - cj) - mlt * TP.aU[ic - 1]);
+          fc[k] = rcpl - mlt * fc[k - 1]; fi[k] = TP.qIJ[q] - mlt * fi[k - 1];
+        }
+        TP.cP[q][k] = cp[k];
+      }
+      double xc = 0.0, xi = 0.0;
+      for (int k = NA - 1; k >= 0; k--) {
+        const double up = k < NA - 1 ? TP.aU[base + k] : 0.0;
+        xc = (fc[k] - up * xc) * cp[k]; xi = (fi[k] - up * xi) * cp[k];
+        TP.zc[q][k] = xc; TP.zI[q][k] = xi;
+      }
+    }
+  }
+  PL_SYNC();
+  // 3. node-local elimination of j (and the particle / collector Schur complements)
+  if (lane < NE) {
+    const int i = lane, sc = sec_of(i);
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0, cI2 = 0, cI3 = 0;
+    if (sc != 1) {
+      const int jx = sc == 0 ? i : i - NS;
+      const double bj = sc == 0 ? c.bj_p : c.bj_n;
+      const double sig = alg_only ? 0.0 : TP.AinvE[jx][NR - 1], tau = alg_only ? 0.0 : TP.AinvQ[jx][NR - 1];
+      const double d = -1.0 - S.gcs[jx] * sig * bj;
+      S.dj[jx] = d;
+      p0 = alg_only ? 0.0 : S.gce[jx] / d; p1 = S.gpe[jx] / d; p2 = S.gps[jx] / d; p3 = alg_only ? 0.0 : (TP.gT[jx] - S.gcs[jx] * tau) / d;
+      t0 = alg_only ? 0.0 : S.ceJ[i]; t1 = S.peJ[i]; t2 = S.psJ[jx]; t3 = alg_only ? 0.0 : TP.TJ[jx] - TP.Tcs[jx] * sig * bj;
+      if (i == 0) cI2 = c.JI0;
+      if (i == NE - 1) cI2 = c.JI29;
+    }
+    if (!alg_only) {                                       // the collectors' column of I, folded onto T of the neighbouring node
+      if (i == 0) cI3 = -TP.aL[NA] * TP.zI[0][NA - 1];
+      if (i == NE - 1) cI3 = -TP.aU[NA + NE - 1] * TP.zI[1][0];
+    }
+    TP.tq[i][0] = t0; TP.tq[i][1] = t1; TP.tq[i][2] = t2; TP.tq[i][3] = t3;
+    TP.phi4[i][0] = p0; TP.phi4[i][1] = p1; TP.phi4[i][2] = p2; TP.phi4[i][3] = p3;
+    TP.colI4[i][0] = 0.0; TP.colI4[i][1] = 0.0; TP.colI4[i][2] = cI2; TP.colI4[i][3] = cI3;
+  }
+  if (lane == 0) TP.cjf = cj;
+  PL_SYNC();
+  // 4. block-Thomas factorisation with 4x4 blocks (systolic, see iso_factor)
+  {
+    const int i = lane < NE ? lane : NE - 1;
+    const int sc = sec_of(i);
+    const bool elec = sc != 1;
+    const int jx = sc == 0 ? i : i - NS;
+    double D[16], Dinv[16], LDm[16];
+    for (int k = 0; k < 16; k++) { D[k] = 0.0; LDm[k] = 0.0; }
+    if (alg_only) { D[0] = 1.0; D[15] = 1.0; }
+    else {
+      D[0] = S.ceD[i] - cj; D[4] = S.pcD[i]; D[7] = TP.ptD[i];
+      D[12] = TP.TcD[i]; D[13] = TP.TeD[i]; D[14] = TP.TsD[i]; D[15] = TP.aD[NA + i] - cj + TP.TtD[i];
+      if (elec) D[15] -= TP.Tcs[jx] * TP.AinvQ[jx][NR - 1];
+      if (i == 0) D[15] -= TP.aL[NA] * TP.zc[0][NA - 1];
+      if (i == NE - 1) D[15] -= TP.aU[NA + NE - 1] * TP.zc[1][0];
+    }
+    D[5] = S.peD[i];
+    D[10] = 1.0;
+    if (elec) {
+      const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
+      D[10] = (first || last) ? -1.0 : -2.0;
+      for (int rr = 0; rr < 4; rr++) for (int cc = 0; cc < 4; cc++) D[rr * 4 + cc] -= TP.tq[i][rr] * TP.phi4[i][cc];
+    }
+    const OffBlk l = lower_blk(S, i, alg_only);
+    const OffBlk u = upper_blk(S, i > 0 ? i - 1 : 0, alg_only);      // U of the previous node (unused for i = 0: l is zero)
+    inv4(D, Dinv);
+#pragma unroll 1
+    for (int itr = 1; itr < NE; itr++) {
+      double P[16], Dn[16];
+      for (int k = 0; k < 16; k++) P[k] = shift_up1(Dinv[k]);
+      for (int k = 0; k < 4; k++) {
+        LDm[k] = l.ce * P[k];
+        LDm[4 + k] = l.pc * P[k] + l.pe * P[4 + k] + l.pt * P[12 + k];
+        LDm[8 + k] = l.s * P[8 + k];
+        LDm[12 + k] = l.Tc * P[k] + l.Te * P[4 + k] + l.Ts * P[8 + k] + l.Tt * P[12 + k];
+      }
+      for (int rr = 0; rr < 4; rr++) {
+        const double a0 = LDm[rr * 4], a1 = LDm[rr * 4 + 1], a2 = LDm[rr * 4 + 2], a3 = LDm[rr * 4 + 3];
+        Dn[rr * 4 + 0] = D[rr * 4 + 0] - (a0 * u.ce + a1 * u.pc + a3 * u.Tc);
+        Dn[rr * 4 + 1] = D[rr * 4 + 1] - (a1 * u.pe + a3 * u.Te);
+        Dn[rr * 4 + 2] = D[rr * 4 + 2] - (a2 * u.s + a3 * u.Ts);
+        Dn[rr * 4 + 3] = D[rr * 4 + 3] - (a1 * u.pt + a3 * u.Tt);
+      }
+      inv4(Dn, Dinv);
+    }
+    if (lane < NE) for (int k = 0; k < 16; k++) { S.Dinv[lane][k] = Dinv[k]; S.LD[lane][k] = LDm[k]; }
+  }
+  PL_SYNC();
+  // 5. Woodbury columns Z = Bb^-1 E (E = unit vectors at the T rows of nodes 0, 9, 20, 29) and the capacitance matrix
+  const int i = lane < NE ? lane : NE - 1;
+  if (!alg_only) {
+    double rz[4][4];
+    for (int k = 0; k < 4; k++) { for (int cc = 0; cc < 4; cc++) rz[k][cc] = 0.0; if (lane == wb_row_node(k)) rz[k][3] = 1.0; }
+    {
+      double ra[2][4];
+      for (int h2 = 0; h2 < 2; h2++) {
+        for (int q = 0; q < 2; q++) for (int cc = 0; cc < 4; cc++) ra[q][cc] = rz[h2 * 2 + q][cc];
+        thermal_sweeps<2>(S, alg_only, ra);
+        for (int q = 0; q < 2; q++) for (int cc = 0; cc < 4; cc++) rz[h2 * 2 + q][cc] = ra[q][cc];
+      }
+    }
+    if (lane < NE) for (int k = 0; k < 4; k++) for (int cc = 0; cc < 4; cc++) TP.Z[k][lane][cc] = rz[k][cc];
+    // C = I + Vw^T Z  (4x4), inverted redundantly by every lane, stored by lane 0
+    double C[16], Ci[16];
+    for (int k = 0; k < 4; k++) {
+      double s[4]; wb_dots(S, rz[k], s);                    // column k of Vw^T Z
+      for (int a = 0; a < 4; a++) C[a * 4 + k] = s[a] + (a == k ? 1.0 : 0.0);
+    }
+    inv4(C, Ci);
+    if (lane < 16) TP.Cinv[lane] = Ci[lane];
+  } else {
+    if (lane < 16) TP.Cinv[lane] = (lane % 5 == 0) ? 1.0 : 0.0;
+    if (lane < NE) for (int k = 0; k < 4; k++) for (int cc = 0; cc < 4; cc++) TP.Z[k][lane][cc] = 0.0;
+  }
+  PL_SYNC();
+  // 6. border: control row v (per node) and x2 = B^-1 (column of I)
+  {
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, dI = 0.0;     // control row over the node unknowns, direct I entry
+    double u[4] = {0.0, 0.0, 0.0, 0.0};
+    if (lane < NE) for (int cc = 0; cc < 4; cc++) u[cc] = TP.colI4[i][cc];
+    if (mode == PLH_MODE_I) dI = 1.0;
+    else if (mode == PLH_MODE_V) { if (lane == 0) v2 = 1.0; if (lane == NE - 1) v2 = -1.0; }
+    else if (mode == PLH_MODE_DT) {
+      if (lane < NE) v3 = -cj * TP.wT[NA + i];
+      // collector part: sum_k vc_k dT_k with dT = zb - zc dT_end - zI xI
+      double vc = 0.0, vi = 0.0;
+      for (int k = 0; k < NA; k++) {
+        if (lane == 0) { vc += TP.wT[k] * TP.zc[0][k]; vi += TP.wT[k] * TP.zI[0][k]; }
+        if (lane == NE - 1) { vc += TP.wT[NA + NE + k] * TP.zc[1][k]; vi += TP.wT[NA + NE + k] * TP.zI[1][k]; }
+      }
+      v3 -= -cj * vc;                                       // -(-cj w) zc
+      dI = wave_sum((lane == 0 || lane == NE - 1) ? cj * vi : 0.0);   // -(-cj w) zI
+    } else {                                                // PL_MODE_DT_TWIN: -(sum_i w_i d rhs_T,i / d y_alg)
+      // T row i depends on Phi_e, Phi_s of nodes i-1, i, i+1 (TeL/D/U, TsL/D/U), on j_i (TJ) and, for the four one-sided stencils, on a second neighbour
+      const double wi = lane < NE ? TP.wT[NA + i] : 0.0;
+      const double eU = shift_up1(lane < NE ? wi * TP.TeU[i] : 0.0), eL = shift_down1(lane < NE ? wi * TP.TeL[i] : 0.0);
+      const double sU = shift_up1(lane < NE ? wi * TP.TsU[i] : 0.0), sL = shift_down1(lane < NE ? wi * TP.TsL[i] : 0.0);
+      if (lane < NE) {
+        v1 = -(eU + wi * TP.TeD[i] + (lane < NE - 1 ? eL : 0.0));
+        v2 = -(sU + wi * TP.TsD[i] + (lane < NE - 1 ? sL : 0.0));
+        for (int k = 0; k < 4; k++) if (lane == wb_src_node(k)) { const double wr = TP.wT[NA + wb_row_node(k)]; v1 -= wr * TP.TX2[k][1]; v2 -= wr * TP.TX2[k][2]; }
+        const int sc = sec_of(i);
+        if (sc != 1) {                                     // j eliminated: v_x -= v_j phi
+          const int jx = sc == 0 ? i : i - NS;
+          const double vj = -wi * TP.TJ[jx];
+          v1 -= vj * TP.phi4[i][1]; v2 -= vj * TP.phi4[i][2];
+          TP.vB[i][0] = vj;                                // kept for the right-hand side (b_I -= v_j beta); slot 0 is free in the algebraic system
+        } else TP.vB[i][0] = 0.0;
+      }
+      // the collector rows depend on I only (Joule heat): -(sum_k w_k) d rhs_k/dI
+      dI = -(NA * TP.wT[0] * TP.qIJ[0] + NZ * TP.wT[NT - 1] * TP.qIJ[1]);
+    }
+    if (lane < NE) { if (mode != PL_MODE_DT_TWIN) TP.vB[i][0] = v0; TP.vB[i][1] = v1; TP.vB[i][2] = v2; TP.vB[i][3] = v3; }
+    if (mode != PLH_MODE_I) {
+      // column of I: in dT / twin mode the collector rows add their I dependence to T of nodes 0 / 29 (through zI)
+      double ra[1][4] = {{u[0], u[1], u[2], u[3]}};
+      thermal_sweeps<1>(S, alg_only, ra);
+      if (!alg_only) { double s[4]; wb_dots(S, ra[0], s); wb_apply(S, ra[0], s); }
+      if (lane < NE) for (int cc = 0; cc < 4; cc++) TP.x2[lane][cc] = ra[0][cc];
+      const double vx = wave_sum(lane < NE ? v1 * ra[0][1] + v2 * ra[0][2] + v3 * ra[0][3] + (mode == PL_MODE_DT_TWIN ? 0.0 : v0 * ra[0][0]) : 0.0);
+      if (lane == 0) { TP.bord[0] = dI - vx; TP.bord[1] = dI; }
+    } else if (lane == 0) { TP.bord[0] = 1.0; TP.bord[1] = 1.0; }
+  }
+  PL_SYNC();
+}
+
+template <class M>
+__device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, int mode, bool alg_only) {
+  PL_MODEL(M);
+  constexpr int O_T = M::O_T;
+  const int lane = lane_id();
+  const CellConst& c = S.cc;
+  auto& TP = S.th;
+  const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
+  // a. particle partial solutions w = A_p^-1 b_cs  (two mat-vecs through the spectral form); collector forward/backward substitution
+  if (!alg_only) {
+    double Wrow[NR], Vrow[NR];
+    for (int k = 0; k < NR; k++) { Wrow[k] = tb->W[r * NR + k]; Vrow[k] = tb->V[r * NR + k]; }
+    for (int pass = 0; pass < 4; pass++) {
+      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
+      double y = 0.0;
+      for (int k = 0; k < NR; k++) y += Wrow[k] * b[O_CS + p * NR + k];
+      if (lane < 60 && p0 < NJ) TP.Wc[p][r] = y * TP.rdiag[p][r];      // Wc is free between a factorisation and the next Jacobian pass
+    }
+    if (lane >= 62) {
+      const int q = lane - 62, base = q == 0 ? 0 : NA + NE;
+      double f[NA];
+      for (int k = 0; k < NA; k++) f[k] = b[O_T + base + k] - (k > 0 ? TP.cM[q][k] * f[k - 1] : 0.0);
+      double x = 0.0;
+      for (int k = NA - 1; k >= 0; k--) { x = (f[k] - (k < NA - 1 ? TP.aU[base + k] * x : 0.0)) * TP.cP[q][k]; TP.zb[q][k] = x; }
+    }
+    PL_SYNC();
+    for (int pass = 0; pass < 4; pass++) {
+      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
+      double w = 0.0;
+      for (int m = 0; m < NR; m++) w += Vrow[m] * TP.Wc[p][m];
+      if (lane < 60 && p0 < NJ && r == NR - 1) S.w9[p] = w;
+      R.wreg[pass] = w;
+    }
+  }
+  PL_SYNC();
+  // b. node right-hand sides
+  const int i = lane < NE ? lane : NE - 1;
+  const int sc = sec_of(i);
+  const bool elec = lane < NE && sc != 1;
+  const int jx = sc == 0 ? i : i - NS;
+  double beta = 0.0;
+  double y[4] = {0.0, 0.0, 0.0, 0.0};
+  if (lane < NE) {
+    y[0] = alg_only ? 0.0 : b[O_CE + i]; y[1] = b[O_PE + i]; y[2] = 0.0; y[3] = alg_only ? 0.0 : b[O_T + NA + i];
+    if (elec) {
+      const double w9 = alg_only ? 0.0 : S.w9[jx];
+      const double bjp = b[O_J + jx] - S.gcs[jx] * w9;
+      y[2] = b[O_PS + jx];
+      if (!alg_only) y[3] -= TP.Tcs[jx] * w9;
+      beta = bjp / S.dj[jx];
+      for (int cc = 0; cc < 4; cc++) y[cc] -= TP.tq[i][cc] * beta;
+    }
+    if (!alg_only) {
+      if (i == 0) y[3] -= TP.aL[NA] * TP.zb[0][NA - 1];
+      if (i == NE - 1) y[3] -= TP.aU[NA + NE - 1] * TP.zb[1][0];
+    }
+  }
+  double xI = 0.0;
+  if (mode == PLH_MODE_I) {
+    xI = b[O_I];
+    if (lane < NE) for (int cc = 0; cc < 4; cc++) y[cc] -= TP.colI4[i][cc] * xI;
+  }
+  // c. block-Thomas sweeps + Woodbury correction
+  {
+    double ra[1][4] = {{y[0], y[1], y[2], y[3]}};
+    thermal_sweeps<1>(S, alg_only, ra);
+    for (int cc = 0; cc < 4; cc++) y[cc] = ra[0][cc];
+    if (!alg_only) { double s[4]; wb_dots(S, y, s); wb_apply(S, y, s); }
+  }
+  // d. border
+  if (mode != PLH_MODE_I) {
+    double bI = b[O_I];
+    double vy = 0.0;
+    if (lane < NE) {
+      vy = TP.vB[i][1] * y[1] + TP.vB[i][2] * y[2] + TP.vB[i][3] * y[3];
+      if (mode == PL_MODE_DT_TWIN) vy += TP.vB[i][0] * beta;           // v_j (b_j'/d): the eliminated j part of the twin row
+      else vy += TP.vB[i][0] * y[0];
+    }
+    if (mode == PLH_MODE_DT) {                                          // collector T's in the control row: -cj w_k zb_k
+      if (lane >= 32 && lane < 32 + NA + NZ) { const int k = lane - 32, q = k < NA ? 0 : 1, kk = k < NA ? k : k - NA; vy += -TP.cjf * TP.wT[q == 0 ? kk : NA + NE + kk] * TP.zb[q][kk]; }
+    }
+    const double vsum = wave_sum(vy);
+    xI = (bI - vsum) / TP.bord[0];
+    if (lane < NE) for (int cc = 0; cc < 4; cc++) y[cc] -= xI * TP.x2[i][cc];
+  }
+  PL_SYNC();
+  // e. write node unknowns, back-substitute j and the collectors
+  if (lane < NE) {
+    if (!alg_only) { b[O_CE + i] = y[0]; b[O_T + NA + i] = y[3]; }
+    b[O_PE + i] = y[1];
+    if (elec) {
+      b[O_PS + jx] = y[2];
+      b[O_J + jx] = beta - (TP.phi4[i][0] * y[0] + TP.phi4[i][1] * y[1] + TP.phi4[i][2] * y[2] + TP.phi4[i][3] * y[3]);
+    }
+  }
+  if (lane == 0) b[O_I] = xI;
+  if (!alg_only) {
+    const double T0n = lane_bcast(y[3], 0), T29n = lane_bcast(y[3], NE - 1);
+    if (lane >= 32 && lane < 32 + NA + NZ) {
+      const int k = lane - 32, q = k < NA ? 0 : 1, kk = k < NA ? k : k - NA;
+      b[O_T + (q == 0 ? kk : NA + NE + kk)] = TP.zb[q][kk] - TP.zc[q][kk] * (q == 0 ? T0n : T29n) - TP.zI[q][kk] * xI;
+    }
+  }
+  PL_SYNC();
+  // f. particles: dc = w - A^-1 e_last bj dj - A^-1 q dT
+  if (!alg_only) {
+    for (int pass = 0; pass < 4; pass++) {
+      const int p = pass * 6 + g;
+      if (lane < 60 && p < NJ) {
+        const double bj = p < NP ? c.bj_p : c.bj_n;
+        const int nd = p < NP ? p : p + NS;
+        b[O_CS + p * NR + r] = R.wreg[pass] - TP.AinvE[p][r] * bj * b[O_J + p] - TP.AinvQ[p][r] * b[O_T + NA + nd];
+      }
+    }
+  }
+  PL_SYNC();
+}
+
+}  // namespace pl
+
+namespace pl {
+
+// Jacobian entry types that exist only with temperature (decode word as in iso_jac_entry: type<<24 | a<<16 | b<<8 | c)
+enum JTT { TT_CS_T = 64, TT_J_T, TT_PE_TL, TT_PE_TD, TT_PE_TU, TT_T_TL, TT_T_TD, TT_T_TU, TT_T_CL, TT_T_CD, TT_T_CU, TT_T_EL, TT_T_ED, TT_T_EU,
+           TT_T_SL, TT_T_SD, TT_T_SU, TT_T_J, TT_T_CS, TT_T_X2, TT_T_I, TT_CTRL_T };
+
+template <class M>
+__device__ inline double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
+  PL_MODEL(M);
+  const int t = w >> 24, a = (w >> 16) & 255, bb = (w >> 8) & 255, cc = w & 255;
+  const auto& TP = S.th;
+  switch (t) {
+    case JT_CS_CS: return TP.kapP[a] * tb->M[bb * NR + cc] - (bb == cc ? cj : 0.0);
+    case TT_CS_T: {                                      // d(kappa_p(T) (M c)_r)/dT ; evaluated at the state in S.yy
+      double acc = 0.0;
+      for (int k = 0; k < NR; k++) acc += tb->M[bb * NR + k] * S.yy[O_CS + a * NR + k];
+      return TP.dkapP[a] * acc;
+    }
+    case TT_J_T: return TP.gT[a];
+    case TT_PE_TL: return TP.ptL[a];
+    case TT_PE_TD: return TP.ptD[a];
+    case TT_PE_TU: return TP.ptU[a];
+    case TT_T_TL: return TP.aL[a];
+    case TT_T_TD: return TP.aD[a] - cj + ((a >= NA && a < NA + NE) ? TP.TtD[a - NA] : 0.0);
+    case TT_T_TU: return TP.aU[a];
+    case TT_T_CL: return TP.TcL[a];
+    case TT_T_CD: return TP.TcD[a];
+    case TT_T_CU: return TP.TcU[a];
+    case TT_T_EL: return TP.TeL[a];
+    case TT_T_ED: return TP.TeD[a];
+    case TT_T_EU: return TP.TeU[a];
+    case TT_T_SL: return TP.TsL[a];
+    case TT_T_SD: return TP.TsD[a];
+    case TT_T_SU: return TP.TsU[a];
+    case TT_T_J: return TP.TJ[a];
+    case TT_T_CS: return TP.Tcs[a];
+    case TT_T_X2: return TP.TX2[a][bb];
+    case TT_T_I: return TP.qIJ[a];
+    case TT_CTRL_T: return -cj * TP.wT[a];
+  }
+  return iso_jac_entry(S, tb, w, cj);
+}
+
+}  // namespace pl

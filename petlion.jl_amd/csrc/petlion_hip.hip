@@ -66,8 +66,7 @@ template <class M> __global__ __launch_bounds__(64) void k_jacobian(const Tables
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec<M>(S.yy, Y + (size_t)cell * NST); load_vec<M>(S.yp, YP + (size_t)cell * NST);
   PL_SYNC();
-  cell_node_pass<false, true>(S, S.yy, S.yp, S.delta, mode, 0.0);
-  PL_SYNC();
+  cell_res_jac(S, R, S.yy, S.yp, S.delta, mode, 0.0);
   const int nnz = tb->nnz[mode];
   const unsigned* code = tb->csc_code[mode];
   double* out = nz + (size_t)cell * nnz;
@@ -84,8 +83,7 @@ template <class M> __global__ __launch_bounds__(64) void k_linear_solve(const Ta
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec<M>(S.yy, Y + (size_t)cell * NST); load_vec<M>(S.yp, YP + (size_t)cell * NST); load_vec<M>(S.delta, b + (size_t)cell * NST);
   PL_SYNC();
-  cell_node_pass<false, true>(S, S.yy, S.yp, S.ee, mode, 0.0);
-  PL_SYNC();
+  cell_res_jac(S, R, S.yy, S.yp, S.ee, mode, 0.0);
   cell_factor(S, R, tb, cj, mode, false);
   cell_solve(S, R, S.delta, mode, false);
   store_vec<M>(b + (size_t)cell * NST, S.delta);
@@ -155,7 +153,9 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 static const char* const KEY_ENUM_NAMES[K_COUNT] = {
     "D_n", "D_p", "D_s", "D_sn", "D_sp", "Ea_D_sn", "Ea_D_sp", "Ea_k_n", "Ea_k_p", "M_n", "R_SEI", "Rp_n", "Rp_p", "T₀", "Uref_s",
     "brugg_n", "brugg_p", "brugg_s", "c_e₀", "c_max_n", "c_max_p", "i_0_jside", "k_n", "k_n_aging", "k_p", "l_n", "l_p", "l_s",
-    "t₊", "w", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "ρ_n", "σ_n", "σ_p", "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s"};
+    "t₊", "w", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "ρ_n", "σ_n", "σ_p", "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s",
+    "Cp_a", "Cp_n", "Cp_p", "Cp_s", "Cp_z", "T_amb", "h_cell", "l_a", "l_z", "λ_a", "λ_n", "λ_p", "λ_s", "λ_z",
+    "ρ_a", "ρ_p", "ρ_s", "ρ_z", "σ_a", "σ_z"};
 // per variant: the sorted theta_keys the reference's generated functions would receive (generate_functions.jl:327-363, 387) and
 // the chemistry defaults (reference src/params.jl:5-117, 176-226 LCO/LiC6; 295-367, 436-452 NMC/LiC6_NMC)
 static const char* const KEYS_LCO_ISO[] = {
@@ -189,13 +189,25 @@ static const double DEFAULTS_NMC_SEI[] = {
     1.5e-14, 2e-14, 4e4, 2.5e4, 3e4, 3e4, 7.3e-4, 0.01, 10e-6, 7.5e-6, 25 + 273.15, 0.4, 1.5, 1.5, 1.5,
     1200.0, 31080.0, 51830.0, 1.5e-6, 6.3466e-10, 1.0, 6.3066e-10, 48e-6, 41.6e-6, 25e-6, 0.38, 2.0, 0.790813, 0.359749, 0.001,
     0.955473, 2500.0, 100.0, 100.0, 0.038, 0.12, 0.3, 0.3, 0.4};
-struct VariantInfo { int chem, sei, nkeys; const char* const* keys; const double* defaults; };
-enum { V_LCO_ISO = 0, V_NMC_ISO = 1, V_LCO_SEI = 2, V_NMC_SEI = 3, V_COUNT };
+// temperature = true adds the heat-equation parameters (reference src/params.jl:40-45, 85-96, 200-226)
+static const char* const KEYS_LCO_THERMAL[] = {
+    "Cp_a", "Cp_n", "Cp_p", "Cp_s", "Cp_z", "D_n", "D_p", "D_s", "D_sn", "D_sp", "Ea_D_sn", "Ea_D_sp", "Ea_k_n", "Ea_k_p", "Rp_n", "Rp_p",
+    "T_amb", "T₀", "brugg_n", "brugg_p", "brugg_s", "c_e₀", "c_max_n", "c_max_p", "h_cell", "k_n", "k_p", "l_a", "l_n", "l_p", "l_s", "l_z",
+    "t₊", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "λ_a", "λ_n", "λ_p", "λ_s", "λ_z", "ρ_a", "ρ_n", "ρ_p", "ρ_s", "ρ_z",
+    "σ_a", "σ_n", "σ_p", "σ_z", "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s"};
+static const double DEFAULTS_LCO_THERMAL[] = {
+    897.0, 700.0, 700.0, 700.0, 385.0, 7.5e-10, 7.5e-10, 7.5e-10, 3.9e-14, 1e-14, 5000.0, 5000.0, 5000.0, 5000.0, 2e-6, 2e-6,
+    25 + 273.15, 25 + 273.15, 4.0, 4.0, 4.0, 1000.0, 30555.0, 51554.0, 1.0, 5.0310e-11, 2.334e-11, 10e-6, 88e-6, 80e-6, 25e-6, 10e-6,
+    0.364, 0.85510, 0.49550, 0.01429, 0.99174, 237.0, 1.7, 2.1, 0.16, 401.0, 2700.0, 2500.0, 2500.0, 1100.0, 8940.0,
+    3.55e7, 100.0, 100.0, 5.96e7, 0.0326, 0.025, 0.485, 0.385, 0.724};
+struct VariantInfo { int chem, sei, thermal, nkeys; const char* const* keys; const double* defaults; };
+enum { V_LCO_ISO = 0, V_NMC_ISO = 1, V_LCO_SEI = 2, V_NMC_SEI = 3, V_LCO_THERMAL = 4, V_COUNT };
 static const VariantInfo VARIANTS[V_COUNT] = {
-    {PLH_CHEM_LCO_LIC6, 0, 35, KEYS_LCO_ISO, DEFAULTS_LCO_ISO},
-    {PLH_CHEM_NMC_LIC6, 0, 32, KEYS_NMC_ISO, DEFAULTS_NMC_ISO},
-    {PLH_CHEM_LCO_LIC6, 1, 42, KEYS_LCO_SEI, DEFAULTS_LCO_SEI},
-    {PLH_CHEM_NMC_LIC6, 1, 39, KEYS_NMC_SEI, DEFAULTS_NMC_SEI},
+    {PLH_CHEM_LCO_LIC6, 0, 0, 35, KEYS_LCO_ISO, DEFAULTS_LCO_ISO},
+    {PLH_CHEM_NMC_LIC6, 0, 0, 32, KEYS_NMC_ISO, DEFAULTS_NMC_ISO},
+    {PLH_CHEM_LCO_LIC6, 1, 0, 42, KEYS_LCO_SEI, DEFAULTS_LCO_SEI},
+    {PLH_CHEM_NMC_LIC6, 1, 0, 39, KEYS_NMC_SEI, DEFAULTS_NMC_SEI},
+    {PLH_CHEM_LCO_LIC6, 0, 1, 56, KEYS_LCO_THERMAL, DEFAULTS_LCO_THERMAL},
 };
 
 struct plh_model_s {
@@ -222,7 +234,61 @@ static unsigned classify(const Tables& tb, int mode, int r, int c) {
   if (r == O_I) {
     if (mode == PLH_MODE_I) return c == O_I ? W(JT_CTRL_P1, 0, 0, 0) : 0;
     if (mode == PLH_MODE_V) return c == O_PS ? W(JT_CTRL_P1, 0, 0, 0) : (c == O_PS + NJ - 1 ? W(JT_CTRL_M1, 0, 0, 0) : 0);
+    if (M::THERMAL && mode == PLH_MODE_DT) return (c >= M::O_T && c < M::O_T + NT) ? W(TT_CTRL_T, c - M::O_T, 0, 0) : 0;
     return 0;
+  }
+  if constexpr (M::THERMAL) {                       // entries that exist only with temperature; everything else falls through
+    constexpr int O_T = M::O_T;
+    const bool cT = c >= O_T && c < O_T + NT;
+    const int ct = c - O_T;                         // T node of the column
+    if (r >= O_CS && r < N_CECS && cT) { const int p = (r - O_CS) / NR; return ct == NA + node_of_j(p) ? W(TT_CS_T, p, (r - O_CS) % NR, 0) : 0; }
+    if (r >= O_J && r < O_PE && cT) { const int jx = r - O_J; return ct == NA + node_of_j(jx) ? W(TT_J_T, jx, 0, 0) : 0; }
+    if (r >= O_PE && r < O_PS && cT) {
+      const int i = r - O_PE, k = ct - NA;
+      if (i == NE - 1) return 0;
+      if (k == i - 1 && i > 0) return W(TT_PE_TL, i, 0, 0);
+      if (k == i) return W(TT_PE_TD, i, 0, 0);
+      if (k == i + 1) return W(TT_PE_TU, i, 0, 0);
+      return 0;
+    }
+    if (r >= O_T && r < O_T + NT) {                 // T row (residuals_T!)
+      const int it = r - O_T;
+      if (cT) { if (ct == it - 1) return W(TT_T_TL, it, 0, 0); if (ct == it) return W(TT_T_TD, it, 0, 0); if (ct == it + 1) return W(TT_T_TU, it, 0, 0); return 0; }
+      if (it < NA || it >= NA + NE) return c == O_I ? W(TT_T_I, it < NA ? 0 : 1, 0, 0) : 0;
+      const int i = it - NA, sc = sec_of(i);
+      const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
+      const int far = (i == 0 || i == NP + NS) ? i + 2 : i - 2;      // second neighbour of the one-sided stencils
+      const int xk = i == 0 ? 0 : (i == NP - 1 ? 1 : (i == NP + NS ? 2 : 3));
+      if (c < O_CS) {                               // c_e columns
+        if (c == i - 1 && i > 0) return W(TT_T_CL, i, 0, 0);
+        if (c == i) return W(TT_T_CD, i, 0, 0);
+        if (c == i + 1 && i < NE - 1) return W(TT_T_CU, i, 0, 0);
+        if ((i == 0 || i == NE - 1) && c == far) return W(TT_T_X2, xk, 0, 0);
+        return 0;
+      }
+      if (c >= O_PE && c < O_PS) {                  // Phi_e columns (the diagonal only through the reaction heat: electrodes, and the one-sided ends)
+        const int k = c - O_PE;
+        if (k == i - 1 && i > 0) return W(TT_T_EL, i, 0, 0);
+        if (k == i && sc != 1) return W(TT_T_ED, i, 0, 0);
+        if (k == i + 1 && i < NE - 1) return W(TT_T_EU, i, 0, 0);
+        if ((i == 0 || i == NE - 1) && k == far) return W(TT_T_X2, xk, 1, 0);
+        return 0;
+      }
+      if (sc == 1) return 0;
+      const int jx = sc == 0 ? i : i - NS;
+      if (c >= O_PS && c < O_PS + NJ) {
+        const int k = c - O_PS, kf = (i == 0 || i == NP + NS) ? jx + 2 : jx - 2;
+        if (k == jx - 1 && !first) return W(TT_T_SL, i, 0, 0);
+        if (k == jx) return W(TT_T_SD, i, 0, 0);
+        if (k == jx + 1 && !last) return W(TT_T_SU, i, 0, 0);
+        if ((first || last) && k == kf) return W(TT_T_X2, xk, 2, 0);
+        return 0;
+      }
+      if (c == O_J + jx) return W(TT_T_J, jx, 0, 0);
+      if (c == O_CS + jx * NR + NR - 1) return W(TT_T_CS, jx, 0, 0);
+      return 0;
+    }
+    if (cT) return 0;
   }
   if (r < O_CS) {                                   // c_e row i
     const int i = r, sc = sec_of(i);
@@ -303,7 +369,8 @@ struct Stage {
   template <class T> void back(T* host, const T* dev, size_t n) { if (host && kind != PLH_DEVICE) hipMemcpy(host, dev, n * sizeof(T), hipMemcpyDeviceToHost); }
 };
 #define CHECK_MODEL(m) do { if (!(m)) return fail(PLH_E_ARG, "null model"); } while (0)
-#define CHECK_MODE(mode) do { if ((mode) != PLH_MODE_I && (mode) != PLH_MODE_V) return fail(PLH_E_UNSUPPORTED, "operating mode not available for this model (I and V are)"); } while (0)
+#define CHECK_MODE(mode) do { if ((mode) != PLH_MODE_I && (mode) != PLH_MODE_V && !((mode) == PLH_MODE_DT && m->desc.temperature)) \
+    return fail(PLH_E_UNSUPPORTED, "operating mode not available for this model (I and V; dT with temperature = true)"); } while (0)
 #define FINISH(stage) do { if ((stage).kind != PLH_DEVICE) HIPCHK(hipStreamSynchronize((stage).st)); HIPCHK(hipGetLastError()); } while (0)
 
 
@@ -313,11 +380,12 @@ struct Stage {
     case V_NMC_ISO: { using M = ModelT<PLH_CHEM_NMC_LIC6, false>; __VA_ARGS__; } break; \
     case V_LCO_SEI: { using M = ModelT<PLH_CHEM_LCO_LIC6, true>; __VA_ARGS__; } break; \
     case V_NMC_SEI: { using M = ModelT<PLH_CHEM_NMC_LIC6, true>; __VA_ARGS__; } break; \
+    case V_LCO_THERMAL: { using M = ModelT<PLH_CHEM_LCO_LIC6, false, true>; __VA_ARGS__; } break; \
     default: return fail(PLH_E_UNSUPPORTED, "model variant not instantiated"); } } while (0)
 
 template <class M> static int build_patterns(plh_model_s* m) {
   Tables& tb = m->h_tb;
-  for (int mode = 0; mode < 2; mode++) {
+  for (int mode = 0; mode < (M::THERMAL ? 3 : 2); mode++) {
     m->colptr[mode].assign(M::NST + 1, 0);
     for (int c = 0; c < M::NST; c++) {
       for (int r = 0; r < M::NST; r++) { const unsigned w = classify<M>(tb, mode, r, c); if (w) { m->rowval[mode].push_back(r); m->code[mode].push_back(w); } }
@@ -340,10 +408,12 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   if (!d || !out) return fail(PLH_E_ARG, "null argument");
   if (d->real_bytes != 8) return fail(PLH_E_UNSUPPORTED, "only fp64 (real_bytes = 8) is implemented");
   if (d->chemistry != PLH_CHEM_LCO_LIC6 && d->chemistry != PLH_CHEM_NMC_LIC6) return fail(PLH_E_UNSUPPORTED, "unknown chemistry");
-  if (d->temperature) return fail(PLH_E_UNSUPPORTED, "temperature = true is not implemented on the device yet");
   int variant = -1;
-  for (int v = 0; v < V_COUNT; v++) if (VARIANTS[v].chem == d->chemistry && VARIANTS[v].sei == (d->aging_SEI ? 1 : 0)) variant = v;
-  if (variant < 0) return fail(PLH_E_UNSUPPORTED, "this chemistry / aging combination is not instantiated on the device yet");
+  for (int v = 0; v < V_COUNT; v++)
+    if (VARIANTS[v].chem == d->chemistry && VARIANTS[v].sei == (d->aging_SEI ? 1 : 0) && VARIANTS[v].thermal == (d->temperature ? 1 : 0)) variant = v;
+  if (variant < 0) return fail(PLH_E_UNSUPPORTED, "this chemistry / temperature / aging combination is not instantiated on the device (built: LCO and NMC "
+                                                  "isothermal with or without SEI aging, LCO with temperature)");
+  if (d->temperature && (d->N_a != NA || d->N_z != NZ)) return fail(PLH_E_UNSUPPORTED, "discretisation: only N_a = N_z = 10 is instantiated");
   if (d->N_p != NP || d->N_s != NS || d->N_n != NN || d->N_r_p != NR || d->N_r_n != NR)
     return fail(PLH_E_UNSUPPORTED, "discretisation: only N_p = N_s = N_n = N_r_p = N_r_n = 10 is instantiated");
   int ndev = 0;
@@ -388,7 +458,7 @@ double plh_theta_default(plh_model_t m, int i) { return (m && i >= 0 && i < m->P
 
 int plh_jac_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval) {
   if (!m || !nnz) return fail(PLH_E_ARG, "null argument");
-  if (mode < 0 || mode > 1) return fail(PLH_E_UNSUPPORTED, "mode not available for this model");
+  if (mode < 0 || mode > 2 || m->rowval[mode].empty()) return fail(PLH_E_UNSUPPORTED, "mode not available for this model");
   *nnz = (int)m->rowval[mode].size();
   if (colptr) memcpy(colptr, m->colptr[mode].data(), (m->N + 1) * sizeof(int));
   if (rowval) memcpy(rowval, m->rowval[mode].data(), m->rowval[mode].size() * sizeof(int));

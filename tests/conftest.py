@@ -74,3 +74,14 @@ def hip_model_sei(pkg, hip_model):
 @pytest.fixture(scope="session")
 def hip_model_nmc_sei(pkg, hip_model):
     return pkg.petlion(pkg.NMC, aging="SEI")
+
+
+@pytest.fixture(scope="session")
+def emu_model_thermal(pkg):
+    import build_emu
+    return pkg.petlion(pkg.LCO, temperature=True, _lib_path=build_emu.build())
+
+
+@pytest.fixture(scope="session")
+def hip_model_thermal(pkg, hip_model):
+    return pkg.petlion(pkg.LCO, temperature=True)

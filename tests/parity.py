@@ -8,14 +8,19 @@ SECTIONS_SEI = [("c_e", 0, 30), ("c_s", 30, 230), ("film", 230, 240), ("SOH", 24
                 ("Phi_s", 291, 311), ("j_s", 311, 321), ("I", 321, 322)]
 
 
+SECTIONS_THERMAL = [("c_e", 0, 30), ("c_s", 30, 230), ("T", 230, 280), ("j", 280, 300), ("Phi_e", 300, 330), ("Phi_s", 330, 350), ("I", 350, 351)]
+
+
 def sections_for(n_states):
-    return SECTIONS_SEI if n_states == 322 else SECTIONS
+    return {322: SECTIONS_SEI, 351: SECTIONS_THERMAL}.get(n_states, SECTIONS)
 
 
 def realistic_states(O, th, n, seed=0, variant="lco_iso"):
     """states along a 1C discharge + random perturbations (so that every term of the equations is exercised)."""
     rng = np.random.default_rng(seed)
-    if variant.endswith("_sei"):    # the side reaction is active only while charging (residuals.jl:519-552)
+    if variant.endswith("_thermal"):  # a 3C charge heats the cell: non-trivial T(x) and heat sources
+        ro = O.simulate(variant, th, 0.1, [dict(mode=O.MODE_I, value=3.0, tf=200.0 * (1 + 3 * rng.random()))])
+    elif variant.endswith("_sei"):    # the side reaction is active only while charging (residuals.jl:519-552)
         ro = O.simulate(variant, th, 0.1, [dict(mode=O.MODE_I, value=1.0, tf=600.0 * (1 + 3 * rng.random()))])
     else:
         ro = O.simulate(variant, th, 1.0, [dict(mode=O.MODE_I, value=-1.0, tf=600.0 * (1 + 4 * rng.random()))])
@@ -33,8 +38,8 @@ def check_keys_and_pattern(p, O):
     assert np.array_equal(p.theta_vector(), np.array(meta["theta_default"]))
     th = p.theta_vector()
     N = p.N.tot
-    Z = 2269 if p.aging else 2139                       # Z = 2139 in CC mode (+130 with SEI)
-    for mode, nnz_expect in ((0, Z), (1, Z + 1)):
+    Z = 2883 if p.temperature else (2269 if p.aging else 2139)   # Z = 2139 in CC mode (+130 with SEI; 2883 thermal)
+    for mode, nnz_expect in ((0, Z), (1, Z + 1)) + (((2, 2932),) if p.temperature else ()):
         cp, ri = p.jac_pattern(mode)
         ocp, ori, _ = O.jacobian(VARIANT, th, np.ones(N), np.zeros(N), 1.0, mode, 0.0)
         assert len(ri) == nnz_expect
@@ -58,7 +63,7 @@ def check_evaluators(p, O, n_cells=3):
     assert lib.plh_initial_guess(h, n_cells, Th.ctypes.data, soc.ctypes.data, Yg.ctypes.data, 0, None) == 0
     for i in range(n_cells):
         assert np.allclose(Yg[i], O.initial_guess(VARIANT, Th[i], soc[i]), rtol=1e-12, atol=0)
-    for mode, val in ((0, -1.0), (1, 3.9)):
+    for mode, val in ((0, -1.0), (1, 3.9)) + (((2, 0.01),) if p.temperature else ()):
         F = np.zeros((n_cells, N))
         assert lib.plh_residual(h, n_cells, Th.ctypes.data, Y.ctypes.data, YP.ctypes.data, mode, val, F.ctypes.data, 0, None) == 0
         nnz = len(p.jac_pattern(mode)[1])
@@ -73,10 +78,12 @@ def check_evaluators(p, O, n_cells=3):
             Fo = O.residual(VARIANT, Th[i], Y[i], YP[i], mode, val)
             # rounding-level criterion: |dF_i| <= 1e-12 * (magnitude of the terms entering row i) = sum_k |J_ik Y_k| + |YP_i|
             ocp, ori_, onz_ = O.jacobian(VARIANT, Th[i], Y[i], YP[i], 0.0, mode, val)
-            term = np.abs(YP[i]).copy()
+            _, _, onz1 = O.jacobian(VARIANT, Th[i], Y[i], YP[i], 1.0, mode, val)     # J(cj=1) - J(cj=0) = dF/dYP
+            term = np.zeros(N)
+            term[-1] = abs(val)
             for c in range(N):
                 sl = slice(ocp[c], ocp[c + 1])
-                np.add.at(term, ori_[sl], np.abs(onz_[sl] * Y[i, c]))
+                np.add.at(term, ori_[sl], np.abs(onz_[sl] * Y[i, c]) + np.abs((onz1[sl] - onz_[sl]) * YP[i, c]))
             bad = np.abs(F[i] - Fo) > 1e-12 * term + 1e-300
             assert not bad.any(), (mode, i, np.nonzero(bad)[0][:5], np.abs(F[i] - Fo)[bad][:5], term[bad][:5])
             _, ori, onz = O.jacobian(VARIANT, Th[i], Y[i], YP[i], cj, mode, val)

@@ -96,3 +96,43 @@ def test_lco_sei_aging(emu_model_sei, O, pkg):
 
 def test_nmc_sei_aging_c5_model(emu_model_nmc_sei, O, pkg):
     check_sei_model(emu_model_nmc_sei, O, pkg)
+
+
+CC_CT_CV_KW = dict(T_max=313.15, V_max=4.1, I_max=4.0, I_min=1 / 20)
+CC_CT_CV = [dict(I=4.0, **CC_CT_CV_KW), dict(dT="hold", **CC_CT_CV_KW), dict(V="hold", **CC_CT_CV_KW)]
+
+
+def check_thermal_model(p, O, pkg, Th=None, cells=(0,)):
+    """temperature = true (config C3's model): evaluators in the I / V / dT modes, consistent initialisation, the CC leg with identical
+    step decisions at 1e-6, and the reference's CC-CT-CV fast-charge protocol (examples/fast_charging_CC-CT-CV.ipynb).
+    The dT control row sums 50 nearly cancelling conduction terms (flux conservation), so the current found by its algebraic twin
+    carries ~1e-6 relative round-off in the reference formulation itself; the CT/CV legs are therefore compared at 1e-3 like the
+    notebook KATs, and the CC leg at 1e-6."""
+    import json, os
+    parity.check_keys_and_pattern(p, O)
+    parity.check_evaluators(p, O, n_cells=2)
+    parity.check_init(p, O, None)
+    if Th is None:
+        Th = p.theta_vector()[None, :]
+    ens1 = pkg.simulate_ensemble(p, Th, CC_CT_CV[:1], SOC=0.0)
+    ens = pkg.simulate_ensemble(p, Th, CC_CT_CV, SOC=0.0)
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "notebook_kats.json")))
+    for i in cells:
+        ro1 = O.simulate(p.variant, Th[i], 0.0, parity.runs_to_oracle(O, p, pkg, CC_CT_CV[:1]))
+        parity.compare_trajectory(ens1, i, ro1, rtol_state=1e-6)
+        assert ro1["runs"][0]["flag"] == 5 and abs(ens1.run_info[i, 0]["T_avg"] - 313.15) < 1e-6      # stops on T_max, back-interpolated
+        ro = O.simulate(p.variant, Th[i], 0.0, parity.runs_to_oracle(O, p, pkg, CC_CT_CV))
+        for k, rr in enumerate(ro["runs"]):
+            info = ens.run_info[i, k]
+            assert info["flag"] == rr["flag"] and abs(int(info["iterations"]) - rr["iterations"]) <= 2, (i, k, info, rr)
+            assert abs(info["t_end"] - rr["t_end"]) <= 1e-3 * rr["t_end"] and abs(info["I"] - rr["I"]) <= 1e-2 * abs(rr["I"]), (i, k, info, rr)
+            assert abs(info["T_avg"] - rr["T_avg"]) < 1e-2 and abs(info["SOC"] - rr["SOC"]) < 1e-4
+        assert abs(ens.run_info[i, 1]["T_avg"] - 313.15) < 1e-4                                        # the CT leg holds 40 C
+    if np.array_equal(Th[0], p.theta_vector()):       # default parameters: the notebook's printed values
+        for key, info in zip(("thermal_4C", "thermal_dT_hold", "thermal_V_hold"), ens.run_info[0]):
+            k = G["runs"][key]
+            assert info["flag"] == k["flag"] and abs(info["t_end"] - k["t_end"]) <= k["tol"]["t_end_rel"] * k["t_end"], (key, info)
+
+
+def test_lco_thermal_cc_ct_cv(emu_model_thermal, O, pkg):
+    check_thermal_model(emu_model_thermal, O, pkg)

@@ -220,3 +220,22 @@ def test_c5_nmc_sei_gitt_ensemble(hip_model_nmc_sei, O, pkg):
     for i in (0, 101, 511):
         ro = O.simulate(p.variant, Th[i], 0.2, parity.runs_to_oracle(O, p, pkg, proto), opts=O.default_opts(jac_every_step=1, init_step=1e-2))
         parity.compare_trajectory(ens, i, ro, rtol_state=2e-6)
+
+
+def test_c3_thermal_cc_ct_cv_ensemble(hip_model_thermal, O, pkg):
+    """config C3 on a 256-cell shard: LCO with temperature = true, CC-CT-CV fast charge, cells differ by T_amb and h_cell
+    (T_amb = 298.15 + 5 (u - 0.5) K, h_cell = 2^(2u - 1))."""
+    import test_device_source_emu as te
+    p = hip_model_thermal
+    n = 256
+    rng = np.random.default_rng(3)
+    Th = pkg.theta_matrix(p, n, {"T_amb": 298.15 + 5 * (rng.random(n) - 0.5), "h_cell": 2.0 ** (2 * rng.random(n) - 1)})
+    Th[0] = p.theta_vector()
+    te.check_thermal_model(p, O, pkg, Th=Th, cells=(0, 1, 100, 255))
+    ens = pkg.simulate_ensemble(p, Th, te.CC_CT_CV, SOC=0.0)
+    fl = ens.run_info["flag"]
+    assert (fl[:, 0] == 5).all() and (fl[:, 1] == 2).all() and np.isin(fl[:, 2], (4, 8)).all()
+    assert np.abs(ens.run_info["T_avg"][:, 1] - 313.15).max() < 1e-3
+    # warmer surroundings / weaker cooling -> the 40 C limit is reached earlier
+    k = p.θ_keys.index("T_amb")
+    assert np.corrcoef(Th[:, k], ens.run_info["t_end"][:, 0])[0, 1] < -0.5
