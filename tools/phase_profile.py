@@ -16,10 +16,20 @@ if not os.path.exists(lib) or os.path.getmtime(lib) < newest:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                            "-DPL_PHASE_TIMERS", src, "-o", lib])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-p = pkg.petlion(pkg.LCO, _lib_path=lib)
+which = sys.argv[2] if len(sys.argv) > 2 else "iso"
+if which == "thermal":
+    p = pkg.petlion(pkg.LCO, temperature=True, _lib_path=lib)
+    kw = dict(T_max=313.15, V_max=4.1, I_max=4.0, I_min=1 / 20)
+    proto, soc = [dict(I=4.0, **kw), dict(dT="hold", **kw), dict(V="hold", **kw)], 0.0
+elif which == "sei":
+    p = pkg.petlion(pkg.NMC, aging="SEI", _lib_path=lib)
+    proto, soc = [{"I": 1.0, "tf": 180.0}, {"I": "rest", "tf": 7200.0}] * 3, 0.0
+else:
+    p = pkg.petlion(pkg.LCO, _lib_path=lib)
+    proto, soc = [{"I": -1.0}], 1.0
 Th = torch.from_numpy(pkg.theta_matrix(p, n)).cuda()
 for _ in range(3):
-    ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0, device=True, max_points=256)
+    ens = pkg.simulate_ensemble(p, Th, proto, SOC=soc, device=True, max_points=1024)
 names = ["residual", "jac+factor", "solve", "newton-vec", "step-ctl", "init", "output", "TOTAL"]
 cyc = ens.counters["cyc"].astype(np.float64)
 c = ens.counters
