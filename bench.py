@@ -151,6 +151,18 @@ def main():
     bytes_launch = algorithmic_bytes(ens.counters, ens.n_pts.cpu().numpy())
     kavg_ms = float(np.mean(kernel_ms))
 
+    # measured HBM traffic per launch: PMC counters cannot be collected from inside the timed process, so the value is the one
+    # committed under profiles/ for this exact workload (same command under rocprofv3 --pmc, see tools/prof.sh); null otherwise
+    traffic = None
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+        if cands:
+            tj = json.load(open(cands[-1]))
+            if tj.get("cells_per_launch") == n_local and tj.get("workload") == "C2":
+                traffic = float(tj["hbm_bytes_per_launch"])
+    except Exception:
+        traffic = None
     if rank == 0:
         traj_s = n_total * args.steps / elapsed
         out = {
@@ -162,7 +174,8 @@ def main():
                        "cells_per_gpu": n_local, "cells_total": n_total, "sharding": "independent cells, contiguous blocks, no data-path collective",
                        "steps_per_trajectory": float(ens.counters["n_steps"].mean()), "newton_iters_per_trajectory": float(ens.counters["n_newton"].mean())},
             "roofline": {"bound": "hbm", "achieved": bytes_launch / (kavg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": bytes_launch / (kavg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": bytes_launch / (kavg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, from profiles/*_traffic.json)",
                          "kernel": "k_integrate", "kernel_ms_avg": kavg_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "algorithmic_bytes_per_trajectory": bytes_launch / n_local,
                          "note": "algorithmic bytes = SURVEY 8(d) streaming model; the kernel is LDS-resident, see DESIGN.md and profiles/ for measured HBM traffic"},

@@ -13,7 +13,7 @@ con = sqlite3.connect(os.path.join(src, "trace", "trace_results.db")); cur = con
 L += ["## `rocprofv3 --kernel-trace --stats` : top kernels", "", "| kernel | calls | total (us) | average (us) | % |", "|---|---|---|---|---|"]
 for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 6"):
     L.append("| `%s` | %d | %.1f | %.1f | %.2f |" % (r[0][:70], r[1], r[2] / 1e3 if r[2] > 1e6 else r[2], r[3] / 1e3 if r[3] > 1e5 else r[3], r[4]))
-rows = cur.execute("select duration, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels where name like 'k_integrate%'").fetchall()
+rows = cur.execute("select duration, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels where name like '%k_integrate%'").fetchall()
 d = [r[0] for r in rows]
 L += ["", "`k_integrate`: %d dispatches, duration min/avg/max = %.1f / %.1f / %.1f us; grid %d x wg %d; arch VGPR %s, AGPR %s, SGPR %s, LDS %s B, scratch %s B/lane"
       % (len(d), min(d) / 1e3, sum(d) / len(d) / 1e3, max(d) / 1e3, rows[0][6], rows[0][7], rows[0][1], rows[0][2], rows[0][3], rows[0][4], rows[0][5]), ""]
@@ -35,6 +35,11 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     rd, wr = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024     # KiB -> B; gfx950 FETCH_SIZE reads 1/2 (MI355X_MICROARCH.md, HBM)
     L += ["", "HBM traffic per launch (FETCH_SIZE x 1024 B x 2 [gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md section HBM] + WRITE_SIZE x 1024 B, write side uncalibrated):",
           "read %.1f MB + write %.1f MB = %.1f MB per launch = %.1f kB per trajectory." % (rd / 1e6, wr / 1e6, (rd + wr) / 1e6, (rd + wr) / 1024 / 1e3)]
+    import json
+    json.dump({"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "cells_per_launch": 1024, "workload": "C2",
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`; "
+                         "FETCH_SIZE x 1024 B x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE x 1024 B; see %s_rocprofv3_summary.md" % label},
+              open(os.path.join(ROOT, "profiles", "%s_traffic.json" % label), "w"), indent=1)
 if "SQ_WAVE_CYCLES" in vals:
     L += ["", "SQ_WAVE_CYCLES etc. count quad-cycles: %.3g shader cycles per wavefront; VALU-active fraction %.0f %%, s_waitcnt-parked fraction %.0f %%."
           % (4 * vals["SQ_WAVE_CYCLES"] / 1024, 100 * vals.get("SQ_ACTIVE_INST_ANY", 0) / vals["SQ_WAVE_CYCLES"], 100 * vals.get("SQ_WAIT_ANY", 0) / vals["SQ_WAVE_CYCLES"])]
