@@ -15,7 +15,7 @@ module PetlionHIP
 const lib = get(ENV, "PETLION_HIP_LIB", joinpath(@__DIR__, "..", "..", "petlion.jl_amd", "libpetlion_hip.so"))
 
 const PLH_HOST = Cint(0)
-const MODE = Dict(:I => Cint(0), :V => Cint(1), :dT => Cint(2))
+const MODE = Dict(:I => Cint(0), :V => Cint(1), :dT => Cint(2), :P => Cint(3), :η_p => Cint(4))
 const VAL_CONST, VAL_HOLD, VAL_REST = Cint(0), Cint(1), Cint(2)
 
 struct ModelDesc

@@ -40,6 +40,9 @@ extern "C" {
 #define PLH_MODE_I 0   /* current, C-rate:      Y[I] - value                      */
 #define PLH_MODE_V 1   /* voltage, V:           Phi_s[1] - Phi_s[end] - value     */
 #define PLH_MODE_DT 2  /* dT_avg/dt, K/s:       value - sum_i w_i YP[T_i] / L     (temperature models only) */
+#define PLH_MODE_P 3   /* power, W/m^2:         Y[I] I1C (Phi_s[1] - Phi_s[end]) - value   (method_P, input_methods.jl:80-111) */
+#define PLH_MODE_ETA_P 4 /* plating overpotential, V: Phi_s.n[1] - Phi_e.n[1] - value     (method_η_p, input_methods.jl:113-152) */
+#define PLH_N_MODES 5
 
 /* how `value` is obtained (reference input_methods.jl:11-30,53-63; model_evaluation.jl:165-170) */
 #define PLH_VAL_CONST 0

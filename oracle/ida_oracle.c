@@ -274,7 +274,7 @@ static int splu_setup(splu* f, const int* cp, const int* ri, const double* ax) {
 /* ------------------------------------------------------------------------------------------------------------ */
 /* public structs                                                                                               */
 /* ------------------------------------------------------------------------------------------------------------ */
-enum { ORC_MODE_I = 0, ORC_MODE_V = 1, ORC_MODE_DT = 2 };
+enum { ORC_MODE_I = 0, ORC_MODE_V = 1, ORC_MODE_DT = 2, ORC_MODE_P = 3, ORC_MODE_ETAP = 4, ORC_NMODES = 5 };
 enum { ORC_VAL_CONST = 0, ORC_VAL_HOLD = 1, ORC_VAL_REST = 2 };
 
 typedef struct {   /* reference boundary_stop_conditions, src/structures.jl:237-250 ; NaN disables a bound */
@@ -326,6 +326,7 @@ typedef struct {
   /* algebraic Jacobian CSC (N_alg x N_alg) */
   int *acp, *ari; double* aax; int annz; int* abase_map; int an_ctrl; int actrl_pos[64]; int actrl_col[64];
   double *tmp_nz, *w;
+  double I1C;
   splu lu, alu;
   orc_counters* cnt;
 } evalb;
@@ -334,6 +335,8 @@ static int ctrl_columns(const orc_model* m, int mode, int* cols, int alg_only) {
   int n = 0;
   if (mode == ORC_MODE_I) cols[n++] = m->o_I;
   else if (mode == ORC_MODE_V) { cols[n++] = m->o_ps; cols[n++] = m->o_ps + m->Np + m->Nn - 1; }
+  else if (mode == ORC_MODE_P) { cols[n++] = m->o_ps; cols[n++] = m->o_ps + m->Np + m->Nn - 1; cols[n++] = m->o_I; }   /* scalar_residual.jl:212-218 */
+  else if (mode == ORC_MODE_ETAP) { cols[n++] = m->o_pe + m->Np + m->Ns; cols[n++] = m->o_ps + m->Np; }              /* scalar_residual.jl:219-225 */
   else if (mode == ORC_MODE_DT) {
     if (!alg_only) { int nt = m->Na + m->Np + m->Ns + m->Nn + m->Nz; for (int i = 0; i < nt; i++) cols[n++] = m->o_T + i; }
     else { for (int i = 0; i < m->nnz_twin; i++) cols[n++] = m->Nd + m->twin_cols[i]; }
@@ -355,6 +358,18 @@ static void build_pattern(int N, int rows_base, const int* bcp, const int* bri, 
   *cp_o = cp; *ri_o = ri; *nnz_o = nz; *bmap_o = bmap;
 }
 
+static int find_key(const orc_model* m, const char* k);
+/* calc_I1C, reference auxiliary_states_and_coefficients.jl:632-647 */
+static double calc_I1C_c(const orc_model* m, const double* th) {
+  const char* nm[10] = {"ϵ_fp", "ϵ_p", "ϵ_fn", "ϵ_n", "l_p", "l_n", "c_max_p", "c_max_n", "θ_min_p", "θ_max_p"};
+  double v[12];
+  for (int i = 0; i < 10; i++) { int k = find_key(m, nm[i]); v[i] = k >= 0 ? th[k] : NAN; }
+  { int k = find_key(m, "θ_max_n"); v[10] = k >= 0 ? th[k] : NAN; k = find_key(m, "θ_min_n"); v[11] = k >= 0 ? th[k] : NAN; }
+  const double eps_sp = 1.0 - (v[0] + v[1]), eps_sn = 1.0 - (v[2] + v[3]);
+  const double a = eps_sp * v[4] * v[6] * (v[8] - v[9]), b = eps_sn * v[5] * v[7] * (v[10] - v[11]);
+  return (96485.3321233 / 3600.0) * (a < b ? a : b);
+}
+
 static int evalb_init(evalb* e, const orc_model* m, const double* th, int mode, double value, orc_counters* cnt) {
   memset(e, 0, sizeof(*e));
   e->m = *m; e->th = th; e->mode = mode; e->value = value; e->cnt = cnt;
@@ -367,6 +382,7 @@ static int evalb_init(evalb* e, const orc_model* m, const double* th, int mode, 
   e->ax = (double*)calloc(e->nnz, sizeof(double)); e->aax = (double*)calloc(e->annz, sizeof(double));
   e->tmp_nz = (double*)calloc(m->nnz + 64, sizeof(double)); e->w = (double*)calloc(N, sizeof(double));
   if (m->thermal) m->dT_weights(e->w, th);
+  e->I1C = calc_I1C_c(m, th);
   splu_init(&e->lu, N, e->cp, e->ri); splu_init(&e->alu, Na, e->acp, e->ari);
   return 0;
 }
@@ -379,6 +395,8 @@ static double ctrl_residual(const evalb* e, const double* Y, const double* YP) {
   const orc_model* m = &e->m;
   if (e->mode == ORC_MODE_I) return Y[m->o_I] - e->value;                                         /* method_I */
   if (e->mode == ORC_MODE_V) return Y[m->o_ps] - Y[m->o_ps + m->Np + m->Nn - 1] - e->value;       /* method_V */
+  if (e->mode == ORC_MODE_P) return Y[m->o_I] * e->I1C * (Y[m->o_ps] - Y[m->o_ps + m->Np + m->Nn - 1]) - e->value;   /* method_P = calc_P, scalar_residual.jl:87 */
+  if (e->mode == ORC_MODE_ETAP) return Y[m->o_ps + m->Np] - Y[m->o_pe + m->Np + m->Ns] - e->value;                  /* method_η_p = calc_η_plating, :92 */
   double s = 0.0; int nt = m->Na + m->Np + m->Ns + m->Nn + m->Nz;                                 /* dT */
   for (int i = 0; i < nt; i++) s += e->w[i] * YP[m->o_T + i];
   return e->value - s;
@@ -398,6 +416,14 @@ static void R_alg(evalb* e, double* res /*N_alg*/, const double* Y, const double
   else res[Na - 1] = ctrl_residual(e, Y, YP);
   if (e->cnt) e->cnt->n_res++;
 }
+/* scalar_jacobian! for the P and η_p rows (scalar_residual.jl:189-202); pos = positions of the ctrl_columns() entries */
+static void ctrl_row_P_etap(const evalb* e, const double* Y, double* ax, const int* pos) {
+  const orc_model* m = &e->m;
+  if (e->mode == ORC_MODE_P) {
+    const double I = Y[m->o_I] * e->I1C, V = Y[m->o_ps] - Y[m->o_ps + m->Np + m->Nn - 1];
+    ax[pos[0]] = I; ax[pos[1]] = -I; ax[pos[2]] = V * e->I1C;
+  } else { ax[pos[0]] = -1.0; ax[pos[1]] = 1.0; }
+}
 /* J_full (scalar_residual.jl:588-602, 174-202) */
 static void J_full(evalb* e, const double* Y, const double* YP, double cj) {
   const orc_model* m = &e->m;
@@ -405,6 +431,7 @@ static void J_full(evalb* e, const double* Y, const double* YP, double cj) {
   for (int p = 0; p < m->nnz; p++) e->ax[e->base_map[p]] = e->tmp_nz[p];
   if (e->mode == ORC_MODE_I) e->ax[e->ctrl_pos[0]] = 1.0;
   else if (e->mode == ORC_MODE_V) { e->ax[e->ctrl_pos[0]] = 1.0; e->ax[e->ctrl_pos[1]] = -1.0; }
+  else if (e->mode == ORC_MODE_P || e->mode == ORC_MODE_ETAP) ctrl_row_P_etap(e, Y, e->ax, e->ctrl_pos);
   else for (int k = 0; k < e->n_ctrl; k++) e->ax[e->ctrl_pos[k]] = -cj * e->w[k];
   if (e->cnt) e->cnt->n_jac++;
 }
@@ -414,6 +441,7 @@ static void J_alg(evalb* e, const double* Y, const double* YP) {
   for (int p = 0; p < m->nnz_alg; p++) e->aax[e->abase_map[p]] = e->tmp_nz[p];
   if (e->mode == ORC_MODE_I) e->aax[e->actrl_pos[0]] = 1.0;
   else if (e->mode == ORC_MODE_V) { e->aax[e->actrl_pos[0]] = 1.0; e->aax[e->actrl_pos[1]] = -1.0; }
+  else if (e->mode == ORC_MODE_P || e->mode == ORC_MODE_ETAP) ctrl_row_P_etap(e, Y, e->aax, e->actrl_pos);
   else { m->dT_twin_jac(e->tmp_nz, Y, YP, 0.0, e->th); for (int k = 0; k < e->an_ctrl; k++) e->aax[e->actrl_pos[k]] = e->tmp_nz[k]; }
   if (e->cnt) e->cnt->n_jac++;
 }
@@ -757,7 +785,7 @@ static int find_key(const orc_model* m, const char* k) { for (int i = 0; i < m->
  * Outputs one row per saved point (t=0 of a new solution and every accepted step; the last point of a run is
  * replaced by the back-interpolated one), like the reference's default outputs (:t,:V) plus I, SOC, T_avg.
  */
-typedef struct { orc_model M; evalb ev[3]; int ev_ok[3]; ida_t I; int ida_ok; } orc_ctx;
+typedef struct { orc_model M; evalb ev[ORC_NMODES]; int ev_ok[ORC_NMODES]; ida_t I; int ida_ok; } orc_ctx;
 
 static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_runs, const orc_run* runs, const orc_opts* opts,
                  int max_out, double* out_t, double* out_V, double* out_I, double* out_SOC, double* out_T, int* n_out,
@@ -771,7 +799,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
   double* Yprev = (double*)calloc(N, sizeof(double)); double* YPprev = (double*)calloc(N, sizeof(double));
   if (!ctx->ida_ok) { ida_alloc(&ctx->I, N); ctx->ida_ok = 1; }
   ida_t* Ip = &ctx->I;
-  int nout = 0, rc = 0; double t_global = 0.0, SOC = SOC0; int have_prev = 0; double prev_V = 0, prev_I = 0;
+  int nout = 0, rc = 0; double t_global = 0.0, SOC = SOC0; int have_prev = 0; double prev_V = 0, prev_I = 0, prev_etap = 0;
 #define SAVE(tt_, Y_, SOC_) do { if (nout < max_out) { \
       if (out_t) { out_t[nout] = (tt_); } \
       if (out_V) { out_V[nout] = calc_V(&M, (Y_)); } \
@@ -783,7 +811,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
   for (int r = 0; r < n_runs; r++) {
     const orc_run* run = &runs[r];
     int mode = run->mode;
-    if (mode < 0 || mode > 2) { rc = -101; break; }
+    if (mode < 0 || mode >= ORC_NMODES) { rc = -101; break; }
     int new_run = !have_prev;
     /* --- initialize_simulation! --- */
     double t0;
@@ -802,6 +830,13 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
     } else if (mode == ORC_MODE_V) {
       if (run->value_kind == ORC_VAL_HOLD) { value = prev_V; Y[M.o_I] = prev_V; /* input_methods.jl:58 (guess only) */ }
       else { if (have_prev && prev_I != 0.0) Y[M.o_I] = prev_I; else { double OCV = calc_V(&M, Y); Y[M.o_I] = value > OCV ? 1.0 : -1.0; } }
+    } else if (mode == ORC_MODE_P) {          /* input_methods.jl:86-103 */
+      if (run->value_kind == ORC_VAL_HOLD) { value = prev_I * calc_I1C_c(&M, theta) * prev_V; Y[M.o_I] = prev_I; }
+      else if (run->value_kind == ORC_VAL_REST) { value = 0.0; Y[M.o_I] = 0.0; }
+      else Y[M.o_I] = value / (calc_V(&M, Y) * calc_I1C_c(&M, theta));
+    } else if (mode == ORC_MODE_ETAP) {       /* input_methods.jl:120-142 */
+      if (run->value_kind == ORC_VAL_HOLD) { value = prev_etap; Y[M.o_I] = prev_I; }
+      else { if (have_prev) Y[M.o_I] = prev_I; else { double OCV = calc_V(&M, Y); Y[M.o_I] = value > OCV ? 1.0 : -1.0; } }
     } else { /* dT: custom_res! (model_evaluation.jl:155-172): :hold -> hold_val = 0 */
       if (run->value_kind == ORC_VAL_HOLD) value = 0.0;
       if (have_prev) Y[M.o_I] = prev_I; else Y[M.o_I] = 1.0;      /* input_methods.jl:171-176 */
@@ -863,7 +898,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
     }
     ri->flag = flag; ri->iterations = iter; ri->t_end = t_end; ri->V = calc_V(&M, Y); ri->I = Y[M.o_I]; ri->SOC = SOC;
     ri->T_avg = calc_Tavg(&M, e->w, Y, T0);
-    t_global = t_end; have_prev = 1; prev_V = ri->V; prev_I = ri->I;
+    t_global = t_end; have_prev = 1; prev_V = ri->V; prev_I = ri->I; prev_etap = Y[M.o_ps + M.Np] - Y[M.o_pe + M.Np + M.Ns];
     if (flag < 0) { rc = 1; break; }
   }
   if (n_out) *n_out = nout;
@@ -873,7 +908,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
   return rc;
 }
 
-static void ctx_free(orc_ctx* c) { for (int k = 0; k < 3; k++) if (c->ev_ok[k]) evalb_free(&c->ev[k]); if (c->ida_ok) ida_free(&c->I); }
+static void ctx_free(orc_ctx* c) { for (int k = 0; k < ORC_NMODES; k++) if (c->ev_ok[k]) evalb_free(&c->ev[k]); if (c->ida_ok) ida_free(&c->I); }
 
 int orc_simulate(const char* variant, const double* theta, double SOC0, int n_runs, const orc_run* runs, const orc_opts* opts,
                  int max_out, double* out_t, double* out_V, double* out_I, double* out_SOC, double* out_T, int* n_out,

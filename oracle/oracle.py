@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-MODE_I, MODE_V, MODE_DT = 0, 1, 2
+MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETAP = 0, 1, 2, 3, 4
 VAL_CONST, VAL_HOLD, VAL_REST = 0, 1, 2
 NAN = math.nan
 

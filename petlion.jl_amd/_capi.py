@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpetlion_hip.so")
 
 PLH_HOST, PLH_DEVICE = 0, 1
-MODE_I, MODE_V, MODE_DT = 0, 1, 2
+MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETA_P = 0, 1, 2, 3, 4
 VAL_CONST, VAL_HOLD, VAL_REST = 0, 1, 2
 CHEM_LCO, CHEM_NMC = 0, 1
 FLAG_RUNNING, ERR_INIT, ERR_STALL, ERR_MAXITERS, ERR_OUTPUT_FULL = -1, -11, -12, -13, -14

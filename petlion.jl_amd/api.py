@@ -94,8 +94,8 @@ def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-_INPUTS = ("I", "V", "dT")
-_MODE = {"I": cap.MODE_I, "V": cap.MODE_V, "dT": cap.MODE_DT}
+_INPUTS = ("I", "V", "dT", "P", "η_p")
+_MODE = {"I": cap.MODE_I, "V": cap.MODE_V, "dT": cap.MODE_DT, "P": cap.MODE_P, "η_p": cap.MODE_ETA_P}
 _BOUND_KW = Bounds.FIELDS
 
 
@@ -106,8 +106,8 @@ def _make_run(p, name, inp, tf, bounds):
         if inp == "hold":
             r.value_kind, r.value = cap.VAL_HOLD, 0.0
         elif inp == "rest":
-            if name != "I":
-                raise ValueError("Unsupported input symbol.")       # input_methods.jl:24
+            if name not in ("I", "P"):
+                raise ValueError("Unsupported input symbol.")       # input_methods.jl:24,97
             r.value_kind, r.value = cap.VAL_REST, 0.0
         else:
             raise ValueError("Unsupported input symbol.")

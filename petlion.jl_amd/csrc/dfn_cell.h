@@ -64,8 +64,8 @@ struct Tables {
   int thidx[K_COUNT];                                   // position of each key in the theta vector (-1: absent)
   int chem;
   int P;
-  int nnz[3];                                           // full-Jacobian nnz per mode
-  const unsigned* csc_code[3];                          // per mode: decode word of every CSC entry
+  int nnz[PLH_N_MODES];                                 // full-Jacobian nnz per mode
+  const unsigned* csc_code[PLH_N_MODES];                          // per mode: decode word of every CSC entry
 };
 
 struct CellConst {
@@ -132,6 +132,7 @@ template <class M> struct CellLDS {
   double Ainv[2][NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
   double Mr[NR * NR];               // radial operator (copy of Tables::M)
   double x2[NE][3];
+  double ctrlJ[2], bord;           // P-mode control row at the last Jacobian pass (I*I1C, V*I1C); border pivot d - v.x2
   double w9[NJ];
   double sig[2];
   double kapv[2];
@@ -301,7 +302,7 @@ template <bool WANT_JAC, class M> __device__ inline void thermal_cs_rows(CellLDS
 template <class M> __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only);
 template <class M> __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, int mode, bool alg_only);
 template <class M> __device__ inline double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj);
-constexpr int PL_MODE_DT_TWIN = 3;   // dT control row with YP_T replaced by rhs_T(Y): the consistent-initialisation form (scalar_residual.jl:347-372)
+constexpr int PL_MODE_DT_TWIN = 16;   // dT control row with YP_T replaced by rhs_T(Y): the consistent-initialisation form (scalar_residual.jl:347-372)
 
 // ------------------------------------------------------------------------------------------------------------------
 // per-cell constants from theta (build_auxiliary_states!, reference aux...jl:6-52, and the Arrhenius closures)
@@ -520,10 +521,13 @@ __device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const doubl
       if (lane == 0) Fo[O_SOH] = soh - YP[O_SOH];
     }
     if (lane == 0) {                                                                   // scalar_residual!, scalar_residual.jl:167-172
-      Fo[O_I] = (mode == PLH_MODE_I) ? (yI - value) : (Y[O_PS] - Y[O_PS + NJ - 1] - value);
+      const double Vc = Y[O_PS] - Y[O_PS + NJ - 1];
+      Fo[O_I] = mode == PLH_MODE_I ? yI - value : (mode == PLH_MODE_V ? Vc - value : (mode == PLH_MODE_P ? yI * cI1C * Vc - value   // method_P
+                                                   : Y[O_PS + NP] - Y[O_PE + NP + NS] - value));                                    // method_η_p
     }
   }
   if (WANT_JAC) {
+    if (lane == 0) { S.ctrlJ[0] = yI * cI1C; S.ctrlJ[1] = (Y[O_PS] - Y[O_PS + NJ - 1]) * cI1C; }   // scalar_jacobian! of method_P
     // edge derivatives
     const double dKh_a = dK * beta * K_n * K_n / (denK * denK), dKh_b = dK_n * (1 - beta) * K * K / (denK * denK);
     const double dcb_a = beta * ce_n * ce_n / (denC * denC), dcb_b = (1 - beta) * ce * ce / (denC * denC);
@@ -829,6 +833,9 @@ __device__ inline void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     double r0 = lane < NE ? S.colI[il][0] : 0.0, r1 = lane < NE ? S.colI[il][1] : 0.0, r2 = lane < NE ? S.colI[il][2] : 0.0;
     thomas_sweeps(S, alg_only, r0, r1, r2);
     if (lane < NE) { S.x2[lane][0] = r0; S.x2[lane][1] = r1; S.x2[lane][2] = r2; }
+    // border pivot d - v.x2 of the control row (v, d): V: Phi_s[1] - Phi_s[end]; P: I I1C (same) with d = V I1C; eta_p: Phi_s.n[1] - Phi_e.n[1]
+    const double vx = (mode == PLH_MODE_ETA_P) ? lane_bcast(r2, NP + NS) - lane_bcast(r1, NP + NS) : lane_bcast(r2, 0) - lane_bcast(r2, NE - 1);
+    if (lane == 0) S.bord = (mode == PLH_MODE_P) ? S.ctrlJ[1] - S.ctrlJ[0] * vx : -vx;
     PL_SYNC();
   }
 }
@@ -908,9 +915,9 @@ __device__ inline void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode
   double xI;
   if (mode == PLH_MODE_I) xI = b[O_I];
   else {
-    const double xs0 = lane_bcast(m2, 0), xs29 = lane_bcast(m2, NE - 1);
-    const double d2 = S.x2[0][2] - S.x2[NE - 1][2];
-    xI = ((xs0 - xs29) - b[O_I]) / d2;
+    double vm = (mode == PLH_MODE_ETA_P) ? lane_bcast(m2, NP + NS) - lane_bcast(m1, NP + NS) : lane_bcast(m2, 0) - lane_bcast(m2, NE - 1);
+    if (mode == PLH_MODE_P) vm *= S.ctrlJ[0];
+    xI = (b[O_I] - vm) / S.bord;
     if (lane < NE) { mx[0] -= xI * S.x2[lane][0]; mx[1] -= xI * S.x2[lane][1]; mx[2] -= xI * S.x2[lane][2]; }
   }
   PL_SYNC();
@@ -967,7 +974,7 @@ __device__ inline void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode
 enum JT { JT_CE_L = 1, JT_CE_D, JT_CE_U, JT_CE_J, JT_CS_CS, JT_CS_J, JT_J_CE, JT_J_CS, JT_J_J, JT_J_PE, JT_J_PS,
           JT_PE_CL, JT_PE_CD, JT_PE_CU, JT_PE_L, JT_PE_D, JT_PE_U, JT_PE_J, JT_PS_L, JT_PS_D, JT_PS_U, JT_PS_J, JT_PS_I,
           JT_CTRL_P1, JT_CTRL_M1,
-          JT_CE_JS, JT_PE_JS, JT_PS_JS, JT_J_F, JT_F_JS, JT_F_F, JT_SOH_JS, JT_SOH_SOH, JT_JS_PS, JT_JS_PE, JT_JS_J, JT_JS_JS, JT_JS_F, JT_JS_I };
+          JT_CTRL_PA, JT_CTRL_PB, JT_CTRL_PI, JT_CE_JS, JT_PE_JS, JT_PS_JS, JT_J_F, JT_F_JS, JT_F_F, JT_SOH_JS, JT_SOH_SOH, JT_JS_PS, JT_JS_PE, JT_JS_J, JT_JS_JS, JT_JS_F, JT_JS_I };
 template <class M>
 __device__ inline double iso_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
   PL_MODEL(M);
@@ -999,6 +1006,9 @@ __device__ inline double iso_jac_entry(const CellLDS<M>& S, const Tables* __rest
     case JT_PS_I: return a == 0 ? c.JI0 : c.JI29;
     case JT_CTRL_P1: return 1.0;
     case JT_CTRL_M1: return -1.0;
+    case JT_CTRL_PA: return S.ctrlJ[0];
+    case JT_CTRL_PB: return -S.ctrlJ[0];
+    case JT_CTRL_PI: return S.ctrlJ[1];
     case JT_CE_JS: return S.ceJ[a];         // j and j_s enter the node rows through j_total: same coefficients
     case JT_PE_JS: return S.peJ[a];
     case JT_PS_JS: return S.psJ[a];

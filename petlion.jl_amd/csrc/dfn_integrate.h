@@ -480,13 +480,13 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
   const int lane = lane_id();
   IdaScalars I;
   int nout = 0;
-  double t_global = 0.0, SOC = SOC0, prev_V = 0, prev_I = 0;
+  double t_global = 0.0, SOC = SOC0, prev_V = 0, prev_I = 0, prev_etap = 0;
   bool have_prev = false;
   const double T0 = S.cc.T0;
   if (Yinit) {                                                          // simulate!(sol, ...): continue from sol.Y[end]
     PL_VEC(n) S.yy[n] = Yinit[n];
     PL_SYNC();
-    have_prev = true; t_global = t_init; prev_V = cellV<M>(S.yy); prev_I = S.yy[O_I];
+    have_prev = true; t_global = t_init; prev_V = cellV<M>(S.yy); prev_I = S.yy[O_I]; prev_etap = S.yy[O_PS + NP] - S.yy[O_PE + NP + NS];
   }
   auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
     const double Tav = (M::THERMAL && out.T) ? cellTavg<M>(S, Y) : T0;
@@ -515,6 +515,14 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     } else if (mode == PLH_MODE_V) {
       if (run.value_kind == PLH_VAL_HOLD) { value = prev_V; Iguess = prev_V; }
       else if (have_prev && prev_I != 0.0) Iguess = prev_I;
+      else { const double OCV = cellV<M>(S.yy); Iguess = value > OCV ? 1.0 : -1.0; }
+    } else if (mode == PLH_MODE_P) {                                    // input_methods.jl:86-103
+      if (run.value_kind == PLH_VAL_HOLD) { value = prev_I * S.cc.I1C * prev_V; Iguess = prev_I; }
+      else if (run.value_kind == PLH_VAL_REST) { value = 0.0; Iguess = 0.0; }
+      else Iguess = value / (cellV<M>(S.yy) * S.cc.I1C);
+    } else if (mode == PLH_MODE_ETA_P) {                                // input_methods.jl:120-142
+      if (run.value_kind == PLH_VAL_HOLD) { value = prev_etap; Iguess = prev_I; }
+      else if (have_prev) Iguess = prev_I;
       else { const double OCV = cellV<M>(S.yy); Iguess = value > OCV ? 1.0 : -1.0; }
     } else {                                                            // dT: custom_res! (model_evaluation.jl:155-172): :hold -> 0 K/s
       if (run.value_kind == PLH_VAL_HOLD) value = 0.0;
@@ -580,7 +588,7 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     }
     ri.flag = flag; ri.iterations = iter; ri.t_end = t_end; ri.V = cellV<M>(S.yy); ri.I = S.yy[O_I]; ri.SOC = SOC; ri.T_avg = cellTavg<M>(S, S.yy);
     if (lane == 0) info[r] = ri;
-    t_global = t_end; have_prev = true; prev_V = ri.V; prev_I = ri.I;
+    t_global = t_end; have_prev = true; prev_V = ri.V; prev_I = ri.I; prev_etap = S.yy[O_PS + NP] - S.yy[O_PE + NP + NS];
     if (flag < 0) { for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; z.iterations = 0; info[q] = z; } break; }
     PL_SYNC();
   }

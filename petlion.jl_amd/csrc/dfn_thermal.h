@@ -232,8 +232,10 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
       const double Tc = Y[O_T + ic], Tcl = ic > 0 ? Y[O_T + ic - 1] : 0.0, Tcr = ic < NT - 1 ? Y[O_T + ic + 1] : 0.0;
       Fo[O_T + ic] = TP.aL[ic] * Tcl + TP.aD[ic] * Tc + TP.aU[ic] * Tcr + TP.aC[ic] + TP.qI[k < NA ? 0 : 1] * yI * yI - YP[O_T + ic];
     }
-    if (mode == PLH_MODE_I || mode == PLH_MODE_V) {                                    // scalar_residual!, scalar_residual.jl:167-172
-      if (lane == 0) Fo[O_I] = (mode == PLH_MODE_I) ? (yI - value) : (Y[O_PS] - Y[O_PS + NJ - 1] - value);
+    if (mode == PLH_MODE_I || mode == PLH_MODE_V || mode == PLH_MODE_P || mode == PLH_MODE_ETA_P) {   // scalar_residual!, scalar_residual.jl:167-172
+      const double Vc = Y[O_PS] - Y[O_PS + NJ - 1];
+      if (lane == 0) Fo[O_I] = mode == PLH_MODE_I ? yI - value : (mode == PLH_MODE_V ? Vc - value : (mode == PLH_MODE_P ? yI * cI1C * Vc - value
+                                                                  : Y[O_PS + NP] - Y[O_PE + NP + NS] - value));
     } else if (mode == PLH_MODE_DT) {                                                  // constant_temperature: value - sum w_i YP[T_i] / L
       const double sT = wave_sum(lane < NT ? TP.wT[lane] * YP[O_T + lane] : 0.0);
       if (lane == 0) Fo[O_I] = value - sT;
@@ -245,6 +247,7 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
   }
   if (WANT_JAC) {
     if (lane == 0) { TP.qIJ[0] = 2.0 * TP.qI[0] * yI; TP.qIJ[1] = 2.0 * TP.qI[1] * yI; }   // d(collector row)/dI (Joule heat ~ I^2)
+    if (lane == 0) { S.ctrlJ[0] = yI * cI1C; S.ctrlJ[1] = (Y[O_PS] - Y[O_PS + NJ - 1]) * cI1C; }   // scalar_jacobian! of method_P
     const double dKh_a = beta * K_n * K_n / (denK * denK), dKh_b = (1 - beta) * K * K / (denK * denK);   // dKh/dK_i, dKh/dK_{i+1}
     const double dcb_a = beta * ce_n * ce_n / (denC * denC), dcb_b = (1 - beta) * ce * ce / (denC * denC);
     const double dTb_a = beta * T_n * T_n / (denT * denT), dTb_b = (1 - beta) * T * T / (denT * denT);
@@ -607,6 +610,8 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     if (lane < NE) for (int cc = 0; cc < 4; cc++) u[cc] = TP.colI4[i][cc];
     if (mode == PLH_MODE_I) dI = 1.0;
     else if (mode == PLH_MODE_V) { if (lane == 0) v2 = 1.0; if (lane == NE - 1) v2 = -1.0; }
+    else if (mode == PLH_MODE_P) { if (lane == 0) v2 = S.ctrlJ[0]; if (lane == NE - 1) v2 = -S.ctrlJ[0]; dI = S.ctrlJ[1]; }
+    else if (mode == PLH_MODE_ETA_P) { if (lane == NP + NS) { v2 = 1.0; v1 = -1.0; } }
     else if (mode == PLH_MODE_DT) {
       if (lane < NE) v3 = -cj * TP.wT[NA + i];
       // collector part: sum_k vc_k dT_k with dT = zb - zc dT_end - zI xI

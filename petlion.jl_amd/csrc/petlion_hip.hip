@@ -217,9 +217,9 @@ struct plh_model_s {
   const char* const* key_names = nullptr; const double* key_defaults = nullptr;
   Tables h_tb;
   Tables* d_tb = nullptr;
-  std::vector<int> colptr[3], rowval[3];
-  std::vector<unsigned> code[3];
-  unsigned* d_code[3] = {nullptr, nullptr, nullptr};
+  std::vector<int> colptr[PLH_N_MODES], rowval[PLH_N_MODES];
+  std::vector<unsigned> code[PLH_N_MODES];
+  unsigned* d_code[PLH_N_MODES] = {};
   double* scratch = nullptr; size_t scratch_cells = 0;
   plh_run* d_runs = nullptr; int runs_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
@@ -235,6 +235,8 @@ static unsigned classify(const Tables& tb, int mode, int r, int c) {
     if (mode == PLH_MODE_I) return c == O_I ? W(JT_CTRL_P1, 0, 0, 0) : 0;
     if (mode == PLH_MODE_V) return c == O_PS ? W(JT_CTRL_P1, 0, 0, 0) : (c == O_PS + NJ - 1 ? W(JT_CTRL_M1, 0, 0, 0) : 0);
     if (M::THERMAL && mode == PLH_MODE_DT) return (c >= M::O_T && c < M::O_T + NT) ? W(TT_CTRL_T, c - M::O_T, 0, 0) : 0;
+    if (mode == PLH_MODE_P) return c == O_PS ? W(JT_CTRL_PA, 0, 0, 0) : (c == O_PS + NJ - 1 ? W(JT_CTRL_PB, 0, 0, 0) : (c == O_I ? W(JT_CTRL_PI, 0, 0, 0) : 0));
+    if (mode == PLH_MODE_ETA_P) return c == O_PE + NP + NS ? W(JT_CTRL_M1, 0, 0, 0) : (c == O_PS + NP ? W(JT_CTRL_P1, 0, 0, 0) : 0);
     return 0;
   }
   if constexpr (M::THERMAL) {                       // entries that exist only with temperature; everything else falls through
@@ -369,8 +371,8 @@ struct Stage {
   template <class T> void back(T* host, const T* dev, size_t n) { if (host && kind != PLH_DEVICE) hipMemcpy(host, dev, n * sizeof(T), hipMemcpyDeviceToHost); }
 };
 #define CHECK_MODEL(m) do { if (!(m)) return fail(PLH_E_ARG, "null model"); } while (0)
-#define CHECK_MODE(mode) do { if ((mode) != PLH_MODE_I && (mode) != PLH_MODE_V && !((mode) == PLH_MODE_DT && m->desc.temperature)) \
-    return fail(PLH_E_UNSUPPORTED, "operating mode not available for this model (I and V; dT with temperature = true)"); } while (0)
+#define CHECK_MODE(mode) do { if ((mode) != PLH_MODE_I && (mode) != PLH_MODE_V && (mode) != PLH_MODE_P && (mode) != PLH_MODE_ETA_P && !((mode) == PLH_MODE_DT && m->desc.temperature)) \
+    return fail(PLH_E_UNSUPPORTED, "operating mode not available for this model (I, V, P, eta_p; dT with temperature = true)"); } while (0)
 #define FINISH(stage) do { if ((stage).kind != PLH_DEVICE) HIPCHK(hipStreamSynchronize((stage).st)); HIPCHK(hipGetLastError()); } while (0)
 
 
@@ -385,7 +387,8 @@ struct Stage {
 
 template <class M> static int build_patterns(plh_model_s* m) {
   Tables& tb = m->h_tb;
-  for (int mode = 0; mode < (M::THERMAL ? 3 : 2); mode++) {
+  for (int mode = 0; mode < PLH_N_MODES; mode++) {
+    if (mode == PLH_MODE_DT && !M::THERMAL) continue;
     m->colptr[mode].assign(M::NST + 1, 0);
     for (int c = 0; c < M::NST; c++) {
       for (int r = 0; r < M::NST; r++) { const unsigned w = classify<M>(tb, mode, r, c); if (w) { m->rowval[mode].push_back(r); m->code[mode].push_back(w); } }
@@ -441,7 +444,7 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
 
 void plh_model_destroy(plh_model_t m) {
   if (!m) return;
-  for (int k = 0; k < 3; k++) if (m->d_code[k]) hipFree(m->d_code[k]);
+  for (int k = 0; k < PLH_N_MODES; k++) if (m->d_code[k]) hipFree(m->d_code[k]);
   if (m->d_tb) hipFree(m->d_tb);
   if (m->scratch) hipFree(m->scratch);
   if (m->d_runs) hipFree(m->d_runs);
@@ -458,7 +461,7 @@ double plh_theta_default(plh_model_t m, int i) { return (m && i >= 0 && i < m->P
 
 int plh_jac_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval) {
   if (!m || !nnz) return fail(PLH_E_ARG, "null argument");
-  if (mode < 0 || mode > 2 || m->rowval[mode].empty()) return fail(PLH_E_UNSUPPORTED, "mode not available for this model");
+  if (mode < 0 || mode >= PLH_N_MODES || m->rowval[mode].empty()) return fail(PLH_E_UNSUPPORTED, "mode not available for this model");
   *nnz = (int)m->rowval[mode].size();
   if (colptr) memcpy(colptr, m->colptr[mode].data(), (m->N + 1) * sizeof(int));
   if (rowval) memcpy(rowval, m->rowval[mode].data(), m->rowval[mode].size() * sizeof(int));

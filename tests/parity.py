@@ -39,7 +39,7 @@ def check_keys_and_pattern(p, O):
     th = p.theta_vector()
     N = p.N.tot
     Z = 2883 if p.temperature else (2269 if p.aging else 2139)   # Z = 2139 in CC mode (+130 with SEI; 2883 thermal)
-    for mode, nnz_expect in ((0, Z), (1, Z + 1)) + (((2, 2932),) if p.temperature else ()):
+    for mode, nnz_expect in ((0, Z), (1, Z + 1), (3, Z + 2), (4, Z + 1)) + (((2, 2932),) if p.temperature else ()):
         cp, ri = p.jac_pattern(mode)
         ocp, ori, _ = O.jacobian(VARIANT, th, np.ones(N), np.zeros(N), 1.0, mode, 0.0)
         assert len(ri) == nnz_expect
@@ -63,7 +63,7 @@ def check_evaluators(p, O, n_cells=3):
     assert lib.plh_initial_guess(h, n_cells, Th.ctypes.data, soc.ctypes.data, Yg.ctypes.data, 0, None) == 0
     for i in range(n_cells):
         assert np.allclose(Yg[i], O.initial_guess(VARIANT, Th[i], soc[i]), rtol=1e-12, atol=0)
-    for mode, val in ((0, -1.0), (1, 3.9)) + (((2, 0.01),) if p.temperature else ()):
+    for mode, val in ((0, -1.0), (1, 3.9), (3, -80.0), (4, 0.05)) + (((2, 0.01),) if p.temperature else ()):   # I, V, P, eta_p (, dT)
         F = np.zeros((n_cells, N))
         assert lib.plh_residual(h, n_cells, Th.ctypes.data, Y.ctypes.data, YP.ctypes.data, mode, val, F.ctypes.data, 0, None) == 0
         nnz = len(p.jac_pattern(mode)[1])
@@ -133,7 +133,7 @@ def state_rel_err(Y, Yo):
     for name, a, e in sections_for(len(Yo)):
         # a field that is identically zero in exact arithmetic (j_s while not charging, I at rest) holds only solver round-off
         # (~1e-23 in the oracle's sparse LU, exactly 0 on the device): floor its scale well below any physical magnitude
-        floor = {"j_s": 1e-15, "j": 1e-12, "I": 1e-9}.get(name, 1e-300)
+        floor = {"j_s": 1e-15, "j": 1e-12, "I": 1e-9, "film": 1e-16}.get(name, 1e-300)
         worst = max(worst, np.abs(Y[a:e] - Yo[a:e]).max() / max(np.abs(Yo[a:e]).max(), floor))
     return worst
 

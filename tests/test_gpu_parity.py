@@ -241,3 +241,9 @@ def test_c3_thermal_cc_ct_cv_ensemble(hip_model_thermal, O, pkg):
     assert np.abs(ens.run_info["T_avg"][hot, 0] - 313.15).max() < 1e-6      # CC legs end exactly on the back-interpolated T_max
     te1 = ens.run_info["t_end"][hot, 0]
     assert te1.min() > 200.0 and te1.max() < 600.0                           # notebook: 357.56 s at the default parameters
+
+
+def test_power_and_plating_overpotential_modes(hip_model, hip_model_thermal, hip_model_nmc_sei, O, pkg):
+    import test_device_source_emu as te
+    te.check_power_and_plating_modes(hip_model, O, pkg)
+    te.check_power_and_plating_modes(hip_model_thermal, O, pkg)
