@@ -129,6 +129,7 @@ template <class M> struct CellLDS {
   double dj[NJ], nphi[NE][3];      // j pivot; phi_c = omega . A_ux[:,c] (node block D[r][c] -= t_r phi_c, t = (ceJ, peJ, psJ))
   double colI[NE][3];              // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
   double Dinv[NE][M::NB * M::NB], LD[NE][M::NB * M::NB];   // Thomas factors: D'^-1 and L D'^-1(prev)
+  double LDmid[M::NB * M::NB];                             // closing block of the twisted factorisation
   double Ainv[2][NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
   double Mr[NR * NR];               // radial operator (copy of Tables::M)
   double x2[NE][3];
@@ -684,41 +685,61 @@ __device__ __forceinline__ void node_block(const CellLDS<M>& S, int i, double cj
   }
 }
 
-// forward / backward substitution with the factors in S.LD / S.Dinv / S.GU as systolic sweeps: lane i holds node i's right-hand
-// side (r0,r1,r2) on entry and node i's solution on exit.  The recurrence value travels lane -> lane+1 (forward) and
-// lane -> lane-1 (backward) through DPP shifts.  Every lane re-evaluates its own recurrence at every stage: a lane whose
-// predecessor is final reproduces its final value (the update is idempotent), so no per-stage select is needed; lane 0 (LD = 0)
-// and lane NE-1 (GU = 0) are final from the start and the wavefront advances one lane per stage.
+// ---- twisted (two-ended) block-Thomas in a mirrored lane layout ----
+// Nodes 0..14 are eliminated forwards and live in lanes 0..14; nodes 29..15 are eliminated backwards and live in lanes 32..46 (node 29 in
+// lane 32), so BOTH halves run the same "take the value of the lane below" recurrence (one DPP wave_shr:1 per value and stage) and the
+// chain is 14 stages instead of 29.  Node 15 closes the system: it takes node 14's value through a v_readlane broadcast.  The
+// back-substitution runs the other way with wave_shl:1; lane 15 is a ghost that re-publishes node 15's solution for node 14.
+// Every lane re-evaluates its recurrence at every stage (idempotent once its predecessor is final), so there are no per-stage selects.
+constexpr int TW_MID = NE / 2, TW_BASE = 32;
+__device__ __forceinline__ int tw_node(int lane) { return lane < TW_MID ? lane : ((lane >= TW_BASE && lane < TW_BASE + (NE - TW_MID)) ? NE - 1 - (lane - TW_BASE) : -1); }
+__host__ __device__ constexpr int tw_lane(int node) { return node < TW_MID ? node : TW_BASE + (NE - 1 - node); }
+__device__ __forceinline__ double l22_of(int n) { return (n > 0 && sec_of(n) != 1 && sec_of(n - 1) == sec_of(n)) ? 1.0 : 0.0; }   // Phi_s row n x Phi_s[n-1]
+__device__ __forceinline__ double u22_of(int n) { return (n < NE - 1 && sec_of(n) != 1 && sec_of(n + 1) == sec_of(n)) ? 1.0 : 0.0; }
+
+// forward / backward substitution with the factors in S.LD / S.Dinv / S.LDmid: the lane of node n (tw_lane) holds node n's right-hand side
+// on entry and node n's solution on exit.
 template <class M>
 __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only, double& r0, double& r1, double& r2) {
   PL_MODEL(M);
   const int lane = lane_id();
-  const int i = lane < NE ? lane : NE - 1;
-  double L[9], Di[9], G[9];
-  for (int k = 0; k < 9; k++) { L[k] = S.LD[i][k]; Di[k] = S.Dinv[i][k]; }
-  {   // G = Dinv U_i with U_i = [[ceU,0,0],[pcU,peU,0],[0,0,psU]] (zero for the last node; c_e couplings absent in the algebraic block)
-    const int sci = sec_of(i), scn = sec_of(i < NE - 1 ? i + 1 : NE - 1);
-    const double v00 = (alg_only || i == NE - 1) ? 0.0 : S.ceU[i], v10 = (alg_only || i == NE - 1) ? 0.0 : S.pcU[i], v11 = i == NE - 1 ? 0.0 : S.peU[i];
-    const double v22 = (i < NE - 1 && sci != 1 && scn == sci) ? 1.0 : 0.0;
+  const int nd = tw_node(lane);
+  const bool act = nd >= 0, top = lane < TW_MID;
+  const int i = act ? nd : 0;
+  double C[9], Di[9], G[9], Lm[9];
+  for (int k = 0; k < 9; k++) { C[k] = act ? S.LD[i][k] : 0.0; Di[k] = act ? S.Dinv[i][k] : 0.0; Lm[k] = nd == TW_MID ? S.LDmid[k] : 0.0; }
+  {   // back-substitution block: top x_n = z_n - Dinv U_n x_{n+1}; bottom x_n = z_n - Dinv L_n x_{n-1}; node TW_MID is closed (G = 0)
+    const bool z = !act || nd == TW_MID;
+    const double v00 = (alg_only || z) ? 0.0 : (top ? S.ceU[i] : S.ceL[i]), v10 = (alg_only || z) ? 0.0 : (top ? S.pcU[i] : S.pcL[i]);
+    const double v11 = z ? 0.0 : (top ? S.peU[i] : S.peL[i]);
+    const double v22 = z ? 0.0 : (top ? u22_of(i) : l22_of(i));
     for (int rr = 0; rr < 3; rr++) {
       G[rr * 3 + 0] = Di[rr * 3 + 0] * v00 + Di[rr * 3 + 1] * v10;
       G[rr * 3 + 1] = Di[rr * 3 + 1] * v11;
       G[rr * 3 + 2] = Di[rr * 3 + 2] * v22;
     }
   }
+  if (!act) { r0 = 0.0; r1 = 0.0; r2 = 0.0; }
   double y0 = r0, y1 = r1, y2 = r2;
-#pragma unroll 4
-  for (int it = 1; it < NE; it++) {
+#pragma unroll 2
+  for (int it = 1; it < TW_MID; it++) {
     const double p0 = shift_up1(y0), p1 = shift_up1(y1), p2 = shift_up1(y2);
-    y0 = r0 - (L[0] * p0 + L[1] * p1 + L[2] * p2);
-    y1 = r1 - (L[3] * p0 + L[4] * p1 + L[5] * p2);
-    y2 = r2 - (L[6] * p0 + L[7] * p1 + L[8] * p2);
+    y0 = r0 - (C[0] * p0 + C[1] * p1 + C[2] * p2);
+    y1 = r1 - (C[3] * p0 + C[4] * p1 + C[5] * p2);
+    y2 = r2 - (C[6] * p0 + C[7] * p1 + C[8] * p2);
   }
-  // backward: x_i = z_i - G_i x_{i+1},  z = Dinv y,  G = Dinv U
-  const double z0 = Di[0] * y0 + Di[1] * y1 + Di[2] * y2, z1 = Di[3] * y0 + Di[4] * y1 + Di[5] * y2, z2 = Di[6] * y0 + Di[7] * y1 + Di[8] * y2;
+  {   // closing node: y_mid -= (L_mid Dinv_{mid-1}) y_{mid-1}
+    const double m0 = lane_bcast(y0, TW_MID - 1), m1 = lane_bcast(y1, TW_MID - 1), m2 = lane_bcast(y2, TW_MID - 1);
+    y0 -= Lm[0] * m0 + Lm[1] * m1 + Lm[2] * m2; y1 -= Lm[3] * m0 + Lm[4] * m1 + Lm[5] * m2; y2 -= Lm[6] * m0 + Lm[7] * m1 + Lm[8] * m2;
+  }
+  double z0 = Di[0] * y0 + Di[1] * y1 + Di[2] * y2, z1 = Di[3] * y0 + Di[4] * y1 + Di[5] * y2, z2 = Di[6] * y0 + Di[7] * y1 + Di[8] * y2;
+  {   // ghost of the closing node in lane TW_MID (its G is zero: it just holds x_mid for lane TW_MID-1)
+    const double g0 = lane_bcast(z0, tw_lane(TW_MID)), g1 = lane_bcast(z1, tw_lane(TW_MID)), g2 = lane_bcast(z2, tw_lane(TW_MID));
+    if (lane == TW_MID) { z0 = g0; z1 = g1; z2 = g2; }
+  }
   double x0 = z0, x1 = z1, x2 = z2;
-#pragma unroll 4
-  for (int it = NE - 2; it >= 0; it--) {
+#pragma unroll 2
+  for (int it = 0; it < TW_MID; it++) {
     const double q0 = shift_down1(x0), q1 = shift_down1(x1), q2 = shift_down1(x2);
     x0 = z0 - (G[0] * q0 + G[1] * q1 + G[2] * q2);
     x1 = z1 - (G[3] * q0 + G[4] * q1 + G[5] * q2);
@@ -793,48 +814,65 @@ __device__ inline void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
   }
   if constexpr (M::SEI) { if (lane == 0) S.sei.cjf = cj; }
   PL_SYNC();
-  // 3. block-Thomas factorisation as a systolic sweep: lane i owns node i; at iteration i lane i receives Dinv_{i-1} from lane i-1
-  //    through DPP shifts, forms LD_i = L_i Dinv_{i-1} and D'_i = D_i - LD_i U_{i-1}, inverts it and keeps the result.
+  // 3. twisted block-Thomas factorisation (lane layout of thomas_sweeps): top nodes D'_n = D_n - L_n D'^-1_{n-1} U_{n-1}, bottom nodes
+  //    D'_n = D_n - U_n D'^-1_{n+1} L_{n+1}; with the mirrored layout both read "a P b" with P = the factor of the lane below.
   {
-    const int i = lane < NE ? lane : NE - 1;
-    double D[9], Dinv[9], LDm[9];
+    const int nd = tw_node(lane);
+    const bool act = nd >= 0, top = lane < TW_MID;
+    const int i = act ? nd : 0;
+    double D[9], Dinv[9], LDm[9], Dn[9];
     node_block(S, i, cj, alg_only, D);
-    const int sci = sec_of(i), scp = sec_of(i > 0 ? i - 1 : 0);
-    const double l00 = (alg_only || i == 0) ? 0.0 : S.ceL[i], l10 = (alg_only || i == 0) ? 0.0 : S.pcL[i], l11 = i == 0 ? 0.0 : S.peL[i];
-    const double l22 = (i > 0 && sci != 1 && scp == sci) ? 1.0 : 0.0;
-    const double u00 = (alg_only || i == 0) ? 0.0 : S.ceU[i - 1], u10 = (alg_only || i == 0) ? 0.0 : S.pcU[i - 1], u11 = i == 0 ? 0.0 : S.peU[i - 1];
-    const double u22 = l22;
-    for (int k = 0; k < 9; k++) LDm[k] = 0.0;
-    inv3(D, Dinv);                                      // final for lane 0 (its L is zero); the others converge below
-    // every lane re-evaluates its recurrence at every stage; once its predecessor is final the result is final and stable
-    // (idempotent update), so no per-stage select is needed and the wavefront advances one lane per stage
+    // a = left block (L_n for top, U_n for bottom), b = right block (U_{n-1} for top, L_{n+1} for bottom); zero at the two chain heads
+    const bool head = !act || nd == 0 || nd == NE - 1;
+    const int nb = top ? (i > 0 ? i - 1 : 0) : (i < NE - 1 ? i + 1 : NE - 1);
+    const double a00 = (alg_only || head) ? 0.0 : (top ? S.ceL[i] : S.ceU[i]), a10 = (alg_only || head) ? 0.0 : (top ? S.pcL[i] : S.pcU[i]);
+    const double a11 = head ? 0.0 : (top ? S.peL[i] : S.peU[i]), a22 = head ? 0.0 : (top ? l22_of(i) : u22_of(i));
+    const double b00 = (alg_only || head) ? 0.0 : (top ? S.ceU[nb] : S.ceL[nb]), b10 = (alg_only || head) ? 0.0 : (top ? S.pcU[nb] : S.pcL[nb]);
+    const double b11 = head ? 0.0 : (top ? S.peU[nb] : S.peL[nb]), b22 = a22;
+    for (int k = 0; k < 9; k++) { LDm[k] = 0.0; Dn[k] = D[k]; }
+    inv3(D, Dinv);
 #pragma unroll 1
-    for (int it = 1; it < NE; it++) {
-      double P[9], Dn[9];
+    for (int it = 1; it < TW_MID; it++) {
+      double P[9];
       for (int k = 0; k < 9; k++) P[k] = shift_up1(Dinv[k]);
       for (int k = 0; k < 3; k++) {
-        LDm[k] = l00 * P[k];
-        LDm[3 + k] = l10 * P[k] + l11 * P[3 + k];
-        LDm[6 + k] = l22 * P[6 + k];
+        LDm[k] = a00 * P[k];
+        LDm[3 + k] = a10 * P[k] + a11 * P[3 + k];
+        LDm[6 + k] = a22 * P[6 + k];
       }
       for (int rr = 0; rr < 3; rr++) {
-        Dn[rr * 3 + 0] = D[rr * 3 + 0] - (LDm[rr * 3 + 0] * u00 + LDm[rr * 3 + 1] * u10);
-        Dn[rr * 3 + 1] = D[rr * 3 + 1] - LDm[rr * 3 + 1] * u11;
-        Dn[rr * 3 + 2] = D[rr * 3 + 2] - LDm[rr * 3 + 2] * u22;
+        Dn[rr * 3 + 0] = D[rr * 3 + 0] - (LDm[rr * 3 + 0] * b00 + LDm[rr * 3 + 1] * b10);
+        Dn[rr * 3 + 1] = D[rr * 3 + 1] - LDm[rr * 3 + 1] * b11;
+        Dn[rr * 3 + 2] = D[rr * 3 + 2] - LDm[rr * 3 + 2] * b22;
       }
       inv3(Dn, Dinv);
     }
-    if (lane < NE) for (int k = 0; k < 9; k++) { S.Dinv[lane][k] = Dinv[k]; S.LD[lane][k] = LDm[k]; }
+    {   // closing node TW_MID: D'' = D'_mid - L_mid D'^-1_{mid-1} U_{mid-1}
+      double P[9], L2[9], Dm[9], Dmi[9];
+      for (int k = 0; k < 9; k++) P[k] = lane_bcast(Dinv[k], TW_MID - 1);
+      const double c00 = alg_only ? 0.0 : S.ceL[TW_MID], c10 = alg_only ? 0.0 : S.pcL[TW_MID], c11 = S.peL[TW_MID], c22 = l22_of(TW_MID);
+      const double e00 = alg_only ? 0.0 : S.ceU[TW_MID - 1], e10 = alg_only ? 0.0 : S.pcU[TW_MID - 1], e11 = S.peU[TW_MID - 1], e22 = c22;
+      for (int k = 0; k < 3; k++) { L2[k] = c00 * P[k]; L2[3 + k] = c10 * P[k] + c11 * P[3 + k]; L2[6 + k] = c22 * P[6 + k]; }
+      for (int rr = 0; rr < 3; rr++) {
+        Dm[rr * 3 + 0] = Dn[rr * 3 + 0] - (L2[rr * 3 + 0] * e00 + L2[rr * 3 + 1] * e10);
+        Dm[rr * 3 + 1] = Dn[rr * 3 + 1] - L2[rr * 3 + 1] * e11;
+        Dm[rr * 3 + 2] = Dn[rr * 3 + 2] - L2[rr * 3 + 2] * e22;
+      }
+      inv3(Dm, Dmi);
+      if (nd == TW_MID) for (int k = 0; k < 9; k++) { Dinv[k] = Dmi[k]; S.LDmid[k] = L2[k]; }
+    }
+    if (act) for (int k = 0; k < 9; k++) { S.Dinv[i][k] = Dinv[k]; S.LD[i][k] = LDm[k]; }
   }
   PL_SYNC();
   // 4. border vector for modes whose control row is not "I = value":  x2 = T^-1 (column of I)
   if (mode != PLH_MODE_I) {
-    const int il = lane < NE ? lane : NE - 1;
-    double r0 = lane < NE ? S.colI[il][0] : 0.0, r1 = lane < NE ? S.colI[il][1] : 0.0, r2 = lane < NE ? S.colI[il][2] : 0.0;
+    const int nd = tw_node(lane);
+    const int il = nd >= 0 ? nd : 0;
+    double r0 = nd >= 0 ? S.colI[il][0] : 0.0, r1 = nd >= 0 ? S.colI[il][1] : 0.0, r2 = nd >= 0 ? S.colI[il][2] : 0.0;
     thomas_sweeps(S, alg_only, r0, r1, r2);
-    if (lane < NE) { S.x2[lane][0] = r0; S.x2[lane][1] = r1; S.x2[lane][2] = r2; }
+    if (nd >= 0) { S.x2[nd][0] = r0; S.x2[nd][1] = r1; S.x2[nd][2] = r2; }
     // border pivot d - v.x2 of the control row (v, d): V: Phi_s[1] - Phi_s[end]; P: I I1C (same) with d = V I1C; eta_p: Phi_s.n[1] - Phi_e.n[1]
-    const double vx = (mode == PLH_MODE_ETA_P) ? lane_bcast(r2, NP + NS) - lane_bcast(r1, NP + NS) : lane_bcast(r2, 0) - lane_bcast(r2, NE - 1);
+    const double vx = (mode == PLH_MODE_ETA_P) ? lane_bcast(r2, tw_lane(NP + NS)) - lane_bcast(r1, tw_lane(NP + NS)) : lane_bcast(r2, tw_lane(0)) - lane_bcast(r2, tw_lane(NE - 1));
     if (lane == 0) S.bord = (mode == PLH_MODE_P) ? S.ctrlJ[1] - S.ctrlJ[0] * vx : -vx;
     PL_SYNC();
   }
@@ -879,8 +917,9 @@ __device__ inline void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode
   // b. fold c_s and j elimination into the node right-hand sides
   double bjp = 0.0, bjs = 0.0, bfl = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0;
   int jx = 0; bool elec = false, sei_node = false;
-  if (lane < NE) {
-    const int i = lane, sc = sec_of(i);
+  const int nd = tw_node(lane);                 // node of this lane in the twisted layout of thomas_sweeps (-1: idle)
+  if (nd >= 0) {
+    const int i = nd, sc = sec_of(i);
     elec = sc != 1; jx = sc == 0 ? i : i - NS;
     sei_node = M::SEI && sc == 2;
     double r0 = alg_only ? 0.0 : b[O_CE + i], r1 = b[O_PE + i], r2 = 0.0;
@@ -915,16 +954,16 @@ __device__ inline void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode
   double xI;
   if (mode == PLH_MODE_I) xI = b[O_I];
   else {
-    double vm = (mode == PLH_MODE_ETA_P) ? lane_bcast(m2, NP + NS) - lane_bcast(m1, NP + NS) : lane_bcast(m2, 0) - lane_bcast(m2, NE - 1);
+    double vm = (mode == PLH_MODE_ETA_P) ? lane_bcast(m2, tw_lane(NP + NS)) - lane_bcast(m1, tw_lane(NP + NS)) : lane_bcast(m2, tw_lane(0)) - lane_bcast(m2, tw_lane(NE - 1));
     if (mode == PLH_MODE_P) vm *= S.ctrlJ[0];
     xI = (b[O_I] - vm) / S.bord;
-    if (lane < NE) { mx[0] -= xI * S.x2[lane][0]; mx[1] -= xI * S.x2[lane][1]; mx[2] -= xI * S.x2[lane][2]; }
+    if (nd >= 0) { mx[0] -= xI * S.x2[nd][0]; mx[1] -= xI * S.x2[nd][1]; mx[2] -= xI * S.x2[nd][2]; }
   }
   PL_SYNC();
   // e. back-substitute the node-local unknowns (j; with SEI also j_s and film), write node unknowns
   double djs = 0.0;
-  if (lane < NE) {
-    const int i = lane;
+  if (nd >= 0) {
+    const int i = nd;
     if (!alg_only) b[O_CE + i] = mx[0];
     b[O_PE + i] = mx[1];
     if (elec) {
