@@ -383,15 +383,19 @@ template <class M> __device__ __forceinline__ OffBlk upper_blk(const CellLDS<M>&
   return b;
 }
 
-// systolic forward/backward substitution for NRHS right-hand sides at once (see thomas_sweeps in dfn_cell.h); r[q][0..3] in/out
+// twisted systolic forward/backward substitution for NRHS right-hand sides at once, in the mirrored lane layout of thomas_sweeps
+// (dfn_cell.h): the lane of node n (tw_lane) holds r[q][0..3] on entry and the solution on exit
 template <int NRHS, class M>
 __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_only, double (&r)[NRHS][4]) {
   const int lane = lane_id();
-  const int i = lane < NE ? lane : NE - 1;
-  double L[16], Di[16], G[16];
-  for (int k = 0; k < 16; k++) { L[k] = S.LD[i][k]; Di[k] = S.Dinv[i][k]; }
+  const int nd = tw_node(lane);
+  const bool act = nd >= 0, top = lane < TW_MID;
+  const int i = act ? nd : 0;
+  double C[16], Di[16], G[16], Lm[16];
+  for (int k = 0; k < 16; k++) { C[k] = act ? S.LD[i][k] : 0.0; Di[k] = act ? S.Dinv[i][k] : 0.0; Lm[k] = nd == TW_MID ? S.LDmid[k] : 0.0; }
   {
-    const OffBlk u = upper_blk(S, i, alg_only);
+    OffBlk u = top ? upper_blk(S, i, alg_only) : lower_blk(S, i, alg_only);     // back-substitution block (zero for the closing node)
+    if (!act || nd == TW_MID) { u.ce = u.pc = u.pe = u.pt = u.s = u.Tc = u.Te = u.Ts = u.Tt = 0.0; }
     for (int rr = 0; rr < 4; rr++) {       // G = Dinv U
       const double d0 = Di[rr * 4], d1 = Di[rr * 4 + 1], d2 = Di[rr * 4 + 2], d3 = Di[rr * 4 + 3];
       G[rr * 4 + 0] = d0 * u.ce + d1 * u.pc + d3 * u.Tc;
@@ -401,25 +405,30 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
     }
   }
   double y[NRHS][4];
-  for (int q = 0; q < NRHS; q++) for (int k = 0; k < 4; k++) y[q][k] = r[q][k];
+  for (int q = 0; q < NRHS; q++) for (int k = 0; k < 4; k++) { if (!act) r[q][k] = 0.0; y[q][k] = r[q][k]; }
 #pragma unroll 2
-  for (int itr = 1; itr < NE; itr++) {
+  for (int itr = 1; itr < TW_MID; itr++) {
 #pragma unroll
     for (int q = 0; q < NRHS; q++) {
       const double p0 = shift_up1(y[q][0]), p1 = shift_up1(y[q][1]), p2 = shift_up1(y[q][2]), p3 = shift_up1(y[q][3]);
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) y[q][rr] = r[q][rr] - (L[rr * 4] * p0 + L[rr * 4 + 1] * p1 + L[rr * 4 + 2] * p2 + L[rr * 4 + 3] * p3);
+      for (int rr = 0; rr < 4; rr++) y[q][rr] = r[q][rr] - (C[rr * 4] * p0 + C[rr * 4 + 1] * p1 + C[rr * 4 + 2] * p2 + C[rr * 4 + 3] * p3);
     }
   }
   double z[NRHS][4];
 #pragma unroll
   for (int q = 0; q < NRHS; q++) {
+    const double m0 = lane_bcast(y[q][0], TW_MID - 1), m1 = lane_bcast(y[q][1], TW_MID - 1), m2 = lane_bcast(y[q][2], TW_MID - 1), m3 = lane_bcast(y[q][3], TW_MID - 1);
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) y[q][rr] -= Lm[rr * 4] * m0 + Lm[rr * 4 + 1] * m1 + Lm[rr * 4 + 2] * m2 + Lm[rr * 4 + 3] * m3;
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) z[q][rr] = Di[rr * 4] * y[q][0] + Di[rr * 4 + 1] * y[q][1] + Di[rr * 4 + 2] * y[q][2] + Di[rr * 4 + 3] * y[q][3];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) { const double gz = lane_bcast(z[q][rr], tw_lane(TW_MID)); if (lane == TW_MID) z[q][rr] = gz; }   // ghost of the closing node
     for (int k = 0; k < 4; k++) r[q][k] = z[q][k];
   }
 #pragma unroll 2
-  for (int itr = NE - 2; itr >= 0; itr--) {
+  for (int itr = 0; itr < TW_MID; itr++) {
 #pragma unroll
     for (int q = 0; q < NRHS; q++) {
       const double q0 = shift_down1(r[q][0]), q1 = shift_down1(r[q][1]), q2 = shift_down1(r[q][2]), q3 = shift_down1(r[q][3]);
@@ -440,15 +449,15 @@ __device__ __forceinline__ void wb_dots(const CellLDS<M>& S, const double* y, do
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int src = wb_src_node(k);
-    s[k] = TP.TX2[k][0] * lane_bcast(y[0], src) + TP.TX2[k][1] * lane_bcast(y[1], src) + TP.TX2[k][2] * lane_bcast(y[2], src);
+    s[k] = TP.TX2[k][0] * lane_bcast(y[0], tw_lane(src)) + TP.TX2[k][1] * lane_bcast(y[1], tw_lane(src)) + TP.TX2[k][2] * lane_bcast(y[2], tw_lane(src));
   }
 }
 // y -= Z C^-1 s
 template <class M>
 __device__ __forceinline__ void wb_apply(const CellLDS<M>& S, double* y, const double* s) {
   const auto& TP = S.th;
-  const int lane = lane_id();
-  const int i = lane < NE ? lane : NE - 1;
+  const int nd = tw_node(lane_id());
+  const int i = nd >= 0 ? nd : 0;
   double m[4];
   for (int a = 0; a < 4; a++) m[a] = TP.Cinv[a * 4] * s[0] + TP.Cinv[a * 4 + 1] * s[1] + TP.Cinv[a * 4 + 2] * s[2] + TP.Cinv[a * 4 + 3] * s[3];
   for (int cc = 0; cc < 4; cc++) y[cc] -= TP.Z[0][i][cc] * m[0] + TP.Z[1][i][cc] * m[1] + TP.Z[2][i][cc] * m[2] + TP.Z[3][i][cc] * m[3];
@@ -528,13 +537,15 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
   }
   if (lane == 0) TP.cjf = cj;
   PL_SYNC();
-  // 4. block-Thomas factorisation with 4x4 blocks (systolic, see iso_factor)
+  // 4. twisted block-Thomas factorisation with 4x4 blocks (lane layout and recurrences as in iso_factor step 3)
+  const int nd = tw_node(lane);
+  const bool act = nd >= 0, top = lane < TW_MID;
+  const int i = act ? nd : 0;
   {
-    const int i = lane < NE ? lane : NE - 1;
     const int sc = sec_of(i);
     const bool elec = sc != 1;
     const int jx = sc == 0 ? i : i - NS;
-    double D[16], Dinv[16], LDm[16];
+    double D[16], Dinv[16], LDm[16], Dn[16];
     for (int k = 0; k < 16; k++) { D[k] = 0.0; LDm[k] = 0.0; }
     if (alg_only) { D[0] = 1.0; D[15] = 1.0; }
     else {
@@ -551,69 +562,65 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
       D[10] = (first || last) ? -1.0 : -2.0;
       for (int rr = 0; rr < 4; rr++) for (int cc = 0; cc < 4; cc++) D[rr * 4 + cc] -= TP.tq[i][rr] * TP.phi4[i][cc];
     }
-    const OffBlk l = lower_blk(S, i, alg_only);
-    const OffBlk u = upper_blk(S, i > 0 ? i - 1 : 0, alg_only);      // U of the previous node (unused for i = 0: l is zero)
+    // a = left block (L_n top / U_n bottom), b = right block (U_{n-1} top / L_{n+1} bottom); zero at the chain heads and in idle lanes
+    OffBlk a = top ? lower_blk(S, i, alg_only) : upper_blk(S, i, alg_only);
+    const int nb = top ? (i > 0 ? i - 1 : 0) : (i < NE - 1 ? i + 1 : NE - 1);
+    const OffBlk b = top ? upper_blk(S, nb, alg_only) : lower_blk(S, nb, alg_only);
+    if (!act) { a.ce = a.pc = a.pe = a.pt = a.s = a.Tc = a.Te = a.Ts = a.Tt = 0.0; }
+    for (int k = 0; k < 16; k++) Dn[k] = D[k];
     inv4(D, Dinv);
 #pragma unroll 1
-    for (int itr = 1; itr < NE; itr++) {
-      double P[16], Dn[16];
+    for (int itr = 1; itr < TW_MID; itr++) {
+      double P[16];
       for (int k = 0; k < 16; k++) P[k] = shift_up1(Dinv[k]);
       for (int k = 0; k < 4; k++) {
-        LDm[k] = l.ce * P[k];
-        LDm[4 + k] = l.pc * P[k] + l.pe * P[4 + k] + l.pt * P[12 + k];
-        LDm[8 + k] = l.s * P[8 + k];
-        LDm[12 + k] = l.Tc * P[k] + l.Te * P[4 + k] + l.Ts * P[8 + k] + l.Tt * P[12 + k];
+        LDm[k] = a.ce * P[k];
+        LDm[4 + k] = a.pc * P[k] + a.pe * P[4 + k] + a.pt * P[12 + k];
+        LDm[8 + k] = a.s * P[8 + k];
+        LDm[12 + k] = a.Tc * P[k] + a.Te * P[4 + k] + a.Ts * P[8 + k] + a.Tt * P[12 + k];
       }
       for (int rr = 0; rr < 4; rr++) {
         const double a0 = LDm[rr * 4], a1 = LDm[rr * 4 + 1], a2 = LDm[rr * 4 + 2], a3 = LDm[rr * 4 + 3];
-        Dn[rr * 4 + 0] = D[rr * 4 + 0] - (a0 * u.ce + a1 * u.pc + a3 * u.Tc);
-        Dn[rr * 4 + 1] = D[rr * 4 + 1] - (a1 * u.pe + a3 * u.Te);
-        Dn[rr * 4 + 2] = D[rr * 4 + 2] - (a2 * u.s + a3 * u.Ts);
-        Dn[rr * 4 + 3] = D[rr * 4 + 3] - (a1 * u.pt + a3 * u.Tt);
+        Dn[rr * 4 + 0] = D[rr * 4 + 0] - (a0 * b.ce + a1 * b.pc + a3 * b.Tc);
+        Dn[rr * 4 + 1] = D[rr * 4 + 1] - (a1 * b.pe + a3 * b.Te);
+        Dn[rr * 4 + 2] = D[rr * 4 + 2] - (a2 * b.s + a3 * b.Ts);
+        Dn[rr * 4 + 3] = D[rr * 4 + 3] - (a1 * b.pt + a3 * b.Tt);
       }
       inv4(Dn, Dinv);
     }
-    if (lane < NE) for (int k = 0; k < 16; k++) { S.Dinv[lane][k] = Dinv[k]; S.LD[lane][k] = LDm[k]; }
-  }
-  PL_SYNC();
-  // 5. Woodbury columns Z = Bb^-1 E (E = unit vectors at the T rows of nodes 0, 9, 20, 29) and the capacitance matrix
-  const int i = lane < NE ? lane : NE - 1;
-  if (!alg_only) {
-    double rz[4][4];
-    for (int k = 0; k < 4; k++) { for (int cc = 0; cc < 4; cc++) rz[k][cc] = 0.0; if (lane == wb_row_node(k)) rz[k][3] = 1.0; }
-    {
-      double ra[2][4];
-      for (int h2 = 0; h2 < 2; h2++) {
-        for (int q = 0; q < 2; q++) for (int cc = 0; cc < 4; cc++) ra[q][cc] = rz[h2 * 2 + q][cc];
-        thermal_sweeps<2>(S, alg_only, ra);
-        for (int q = 0; q < 2; q++) for (int cc = 0; cc < 4; cc++) rz[h2 * 2 + q][cc] = ra[q][cc];
+    {   // closing node TW_MID: D'' = D'_mid - L_mid D'^-1_{mid-1} U_{mid-1}
+      double P[16], L2[16], Dm[16], Dmi[16];
+      for (int k = 0; k < 16; k++) P[k] = lane_bcast(Dinv[k], TW_MID - 1);
+      const OffBlk c = lower_blk(S, TW_MID, alg_only), e = upper_blk(S, TW_MID - 1, alg_only);
+      for (int k = 0; k < 4; k++) {
+        L2[k] = c.ce * P[k];
+        L2[4 + k] = c.pc * P[k] + c.pe * P[4 + k] + c.pt * P[12 + k];
+        L2[8 + k] = c.s * P[8 + k];
+        L2[12 + k] = c.Tc * P[k] + c.Te * P[4 + k] + c.Ts * P[8 + k] + c.Tt * P[12 + k];
       }
+      for (int rr = 0; rr < 4; rr++) {
+        const double a0 = L2[rr * 4], a1 = L2[rr * 4 + 1], a2 = L2[rr * 4 + 2], a3 = L2[rr * 4 + 3];
+        Dm[rr * 4 + 0] = Dn[rr * 4 + 0] - (a0 * e.ce + a1 * e.pc + a3 * e.Tc);
+        Dm[rr * 4 + 1] = Dn[rr * 4 + 1] - (a1 * e.pe + a3 * e.Te);
+        Dm[rr * 4 + 2] = Dn[rr * 4 + 2] - (a2 * e.s + a3 * e.Ts);
+        Dm[rr * 4 + 3] = Dn[rr * 4 + 3] - (a1 * e.pt + a3 * e.Tt);
+      }
+      inv4(Dm, Dmi);
+      if (nd == TW_MID) for (int k = 0; k < 16; k++) { Dinv[k] = Dmi[k]; S.LDmid[k] = L2[k]; }
     }
-    if (lane < NE) for (int k = 0; k < 4; k++) for (int cc = 0; cc < 4; cc++) TP.Z[k][lane][cc] = rz[k][cc];
-    // C = I + Vw^T Z  (4x4), inverted redundantly by every lane, stored by lane 0
-    double C[16], Ci[16];
-    for (int k = 0; k < 4; k++) {
-      double s[4]; wb_dots(S, rz[k], s);                    // column k of Vw^T Z
-      for (int a = 0; a < 4; a++) C[a * 4 + k] = s[a] + (a == k ? 1.0 : 0.0);
-    }
-    inv4(C, Ci);
-    if (lane < 16) TP.Cinv[lane] = Ci[lane];
-  } else {
-    if (lane < 16) TP.Cinv[lane] = (lane % 5 == 0) ? 1.0 : 0.0;
-    if (lane < NE) for (int k = 0; k < 4; k++) for (int cc = 0; cc < 4; cc++) TP.Z[k][lane][cc] = 0.0;
+    if (act) for (int k = 0; k < 16; k++) { S.Dinv[i][k] = Dinv[k]; S.LD[i][k] = LDm[k]; }
   }
-  PL_SYNC();
-  // 6. border: control row v (per node) and x2 = B^-1 (column of I)
+  // 6a. control row over the node unknowns (computed in the lane = node layout: the twin needs neighbour shifts), stored in TP.vB
+  double dI = 0.0;
   {
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, dI = 0.0;     // control row over the node unknowns, direct I entry
-    double u[4] = {0.0, 0.0, 0.0, 0.0};
-    if (lane < NE) for (int cc = 0; cc < 4; cc++) u[cc] = TP.colI4[i][cc];
+    const int ln = lane < NE ? lane : NE - 1;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
     if (mode == PLH_MODE_I) dI = 1.0;
     else if (mode == PLH_MODE_V) { if (lane == 0) v2 = 1.0; if (lane == NE - 1) v2 = -1.0; }
     else if (mode == PLH_MODE_P) { if (lane == 0) v2 = S.ctrlJ[0]; if (lane == NE - 1) v2 = -S.ctrlJ[0]; dI = S.ctrlJ[1]; }
     else if (mode == PLH_MODE_ETA_P) { if (lane == NP + NS) { v2 = 1.0; v1 = -1.0; } }
     else if (mode == PLH_MODE_DT) {
-      if (lane < NE) v3 = -cj * TP.wT[NA + i];
+      if (lane < NE) v3 = -cj * TP.wT[NA + ln];
       // collector part: sum_k vc_k dT_k with dT = zb - zc dT_end - zI xI
       double vc = 0.0, vi = 0.0;
       for (int k = 0; k < NA; k++) {
@@ -624,35 +631,63 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
       dI = wave_sum((lane == 0 || lane == NE - 1) ? cj * vi : 0.0);   // -(-cj w) zI
     } else {                                                // PL_MODE_DT_TWIN: -(sum_i w_i d rhs_T,i / d y_alg)
       // T row i depends on Phi_e, Phi_s of nodes i-1, i, i+1 (TeL/D/U, TsL/D/U), on j_i (TJ) and, for the four one-sided stencils, on a second neighbour
-      const double wi = lane < NE ? TP.wT[NA + i] : 0.0;
-      const double eU = shift_up1(lane < NE ? wi * TP.TeU[i] : 0.0), eL = shift_down1(lane < NE ? wi * TP.TeL[i] : 0.0);
-      const double sU = shift_up1(lane < NE ? wi * TP.TsU[i] : 0.0), sL = shift_down1(lane < NE ? wi * TP.TsL[i] : 0.0);
+      const double wi = lane < NE ? TP.wT[NA + ln] : 0.0;
+      const double eU = shift_up1(lane < NE ? wi * TP.TeU[ln] : 0.0), eL = shift_down1(lane < NE ? wi * TP.TeL[ln] : 0.0);
+      const double sU = shift_up1(lane < NE ? wi * TP.TsU[ln] : 0.0), sL = shift_down1(lane < NE ? wi * TP.TsL[ln] : 0.0);
       if (lane < NE) {
-        v1 = -(eU + wi * TP.TeD[i] + (lane < NE - 1 ? eL : 0.0));
-        v2 = -(sU + wi * TP.TsD[i] + (lane < NE - 1 ? sL : 0.0));
+        v1 = -(eU + wi * TP.TeD[ln] + (lane < NE - 1 ? eL : 0.0));
+        v2 = -(sU + wi * TP.TsD[ln] + (lane < NE - 1 ? sL : 0.0));
         for (int k = 0; k < 4; k++) if (lane == wb_src_node(k)) { const double wr = TP.wT[NA + wb_row_node(k)]; v1 -= wr * TP.TX2[k][1]; v2 -= wr * TP.TX2[k][2]; }
-        const int sc = sec_of(i);
+        const int sc = sec_of(ln);
         if (sc != 1) {                                     // j eliminated: v_x -= v_j phi
-          const int jx = sc == 0 ? i : i - NS;
+          const int jx = sc == 0 ? ln : ln - NS;
           const double vj = -wi * TP.TJ[jx];
-          v1 -= vj * TP.phi4[i][1]; v2 -= vj * TP.phi4[i][2];
-          TP.vB[i][0] = vj;                                // kept for the right-hand side (b_I -= v_j beta); slot 0 is free in the algebraic system
-        } else TP.vB[i][0] = 0.0;
+          v1 -= vj * TP.phi4[ln][1]; v2 -= vj * TP.phi4[ln][2];
+          v0 = vj;                                         // kept for the right-hand side (b_I -= v_j beta); slot 0 is free in the algebraic system
+        }
       }
       // the collector rows depend on I only (Joule heat): -(sum_k w_k) d rhs_k/dI
       dI = -(NA * TP.wT[0] * TP.qIJ[0] + NZ * TP.wT[NT - 1] * TP.qIJ[1]);
     }
-    if (lane < NE) { if (mode != PL_MODE_DT_TWIN) TP.vB[i][0] = v0; TP.vB[i][1] = v1; TP.vB[i][2] = v2; TP.vB[i][3] = v3; }
-    if (mode != PLH_MODE_I) {
-      // column of I: in dT / twin mode the collector rows add their I dependence to T of nodes 0 / 29 (through zI)
-      double ra[1][4] = {{u[0], u[1], u[2], u[3]}};
-      thermal_sweeps<1>(S, alg_only, ra);
-      if (!alg_only) { double s[4]; wb_dots(S, ra[0], s); wb_apply(S, ra[0], s); }
-      if (lane < NE) for (int cc = 0; cc < 4; cc++) TP.x2[lane][cc] = ra[0][cc];
-      const double vx = wave_sum(lane < NE ? v1 * ra[0][1] + v2 * ra[0][2] + v3 * ra[0][3] + (mode == PL_MODE_DT_TWIN ? 0.0 : v0 * ra[0][0]) : 0.0);
-      if (lane == 0) { TP.bord[0] = dI - vx; TP.bord[1] = dI; }
-    } else if (lane == 0) { TP.bord[0] = 1.0; TP.bord[1] = 1.0; }
+    if (lane < NE) { TP.vB[ln][0] = v0; TP.vB[ln][1] = v1; TP.vB[ln][2] = v2; TP.vB[ln][3] = v3; }
   }
+  PL_SYNC();
+  // 5. Woodbury columns Z = Bb^-1 E (E = unit vectors at the T rows of nodes 0, 9, 20, 29) and the capacitance matrix
+  if (!alg_only) {
+    double rz[4][4];
+    for (int k = 0; k < 4; k++) { for (int cc = 0; cc < 4; cc++) rz[k][cc] = 0.0; if (nd == wb_row_node(k)) rz[k][3] = 1.0; }
+    {
+      double ra[2][4];
+      for (int h2 = 0; h2 < 2; h2++) {
+        for (int q = 0; q < 2; q++) for (int cc = 0; cc < 4; cc++) ra[q][cc] = rz[h2 * 2 + q][cc];
+        thermal_sweeps<2>(S, alg_only, ra);
+        for (int q = 0; q < 2; q++) for (int cc = 0; cc < 4; cc++) rz[h2 * 2 + q][cc] = ra[q][cc];
+      }
+    }
+    if (act) for (int k = 0; k < 4; k++) for (int cc = 0; cc < 4; cc++) TP.Z[k][i][cc] = rz[k][cc];
+    // C = I + Vw^T Z  (4x4), inverted redundantly by every lane, stored by lane 0
+    double C[16], Ci[16];
+    for (int k = 0; k < 4; k++) {
+      double s[4]; wb_dots(S, rz[k], s);                    // column k of Vw^T Z
+      for (int a = 0; a < 4; a++) C[a * 4 + k] = s[a] + (a == k ? 1.0 : 0.0);
+    }
+    inv4(C, Ci);
+    if (lane < 16) TP.Cinv[lane] = Ci[lane];
+  } else {
+    if (lane < 16) TP.Cinv[lane] = (lane % 5 == 0) ? 1.0 : 0.0;
+    if (act) for (int k = 0; k < 4; k++) for (int cc = 0; cc < 4; cc++) TP.Z[k][i][cc] = 0.0;
+  }
+  PL_SYNC();
+  // 6b. border: x2 = B^-1 (column of I) and the pivot d - v.x2
+  if (mode != PLH_MODE_I) {
+    double ra[1][4] = {{0.0, 0.0, 0.0, 0.0}};
+    if (act) for (int cc = 0; cc < 4; cc++) ra[0][cc] = TP.colI4[i][cc];
+    thermal_sweeps<1>(S, alg_only, ra);
+    if (!alg_only) { double s[4]; wb_dots(S, ra[0], s); wb_apply(S, ra[0], s); }
+    if (act) for (int cc = 0; cc < 4; cc++) TP.x2[i][cc] = ra[0][cc];
+    const double vx = wave_sum(act ? TP.vB[i][1] * ra[0][1] + TP.vB[i][2] * ra[0][2] + TP.vB[i][3] * ra[0][3] + (mode == PL_MODE_DT_TWIN ? 0.0 : TP.vB[i][0] * ra[0][0]) : 0.0);
+    if (lane == 0) { TP.bord[0] = dI - vx; TP.bord[1] = dI; }
+  } else if (lane == 0) { TP.bord[0] = 1.0; TP.bord[1] = 1.0; }
   PL_SYNC();
 }
 
@@ -692,13 +727,15 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
   }
   PL_SYNC();
   // b. node right-hand sides
-  const int i = lane < NE ? lane : NE - 1;
+  const int nd = tw_node(lane);                   // twisted lane layout of thermal_sweeps
+  const bool act = nd >= 0;
+  const int i = act ? nd : 0;
   const int sc = sec_of(i);
-  const bool elec = lane < NE && sc != 1;
+  const bool elec = act && sc != 1;
   const int jx = sc == 0 ? i : i - NS;
   double beta = 0.0;
   double y[4] = {0.0, 0.0, 0.0, 0.0};
-  if (lane < NE) {
+  if (act) {
     y[0] = alg_only ? 0.0 : b[O_CE + i]; y[1] = b[O_PE + i]; y[2] = 0.0; y[3] = alg_only ? 0.0 : b[O_T + NA + i];
     if (elec) {
       const double w9 = alg_only ? 0.0 : S.w9[jx];
@@ -716,7 +753,7 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
   double xI = 0.0;
   if (mode == PLH_MODE_I) {
     xI = b[O_I];
-    if (lane < NE) for (int cc = 0; cc < 4; cc++) y[cc] -= TP.colI4[i][cc] * xI;
+    if (act) for (int cc = 0; cc < 4; cc++) y[cc] -= TP.colI4[i][cc] * xI;
   }
   // c. block-Thomas sweeps + Woodbury correction
   {
@@ -729,7 +766,7 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
   if (mode != PLH_MODE_I) {
     double bI = b[O_I];
     double vy = 0.0;
-    if (lane < NE) {
+    if (act) {
       vy = TP.vB[i][1] * y[1] + TP.vB[i][2] * y[2] + TP.vB[i][3] * y[3];
       if (mode == PL_MODE_DT_TWIN) vy += TP.vB[i][0] * beta;           // v_j (b_j'/d): the eliminated j part of the twin row
       else vy += TP.vB[i][0] * y[0];
@@ -739,11 +776,11 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
     }
     const double vsum = wave_sum(vy);
     xI = (bI - vsum) / TP.bord[0];
-    if (lane < NE) for (int cc = 0; cc < 4; cc++) y[cc] -= xI * TP.x2[i][cc];
+    if (act) for (int cc = 0; cc < 4; cc++) y[cc] -= xI * TP.x2[i][cc];
   }
   PL_SYNC();
   // e. write node unknowns, back-substitute j and the collectors
-  if (lane < NE) {
+  if (act) {
     if (!alg_only) { b[O_CE + i] = y[0]; b[O_T + NA + i] = y[3]; }
     b[O_PE + i] = y[1];
     if (elec) {
@@ -753,7 +790,7 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
   }
   if (lane == 0) b[O_I] = xI;
   if (!alg_only) {
-    const double T0n = lane_bcast(y[3], 0), T29n = lane_bcast(y[3], NE - 1);
+    const double T0n = lane_bcast(y[3], tw_lane(0)), T29n = lane_bcast(y[3], tw_lane(NE - 1));
     if (lane >= 32 && lane < 32 + NA + NZ) {
       const int k = lane - 32, q = k < NA ? 0 : 1, kk = k < NA ? k : k - NA;
       b[O_T + (q == 0 ? kk : NA + NE + kk)] = TP.zb[q][kk] - TP.zc[q][kk] * (q == 0 ? T0n : T29n) - TP.zI[q][kk] * xI;
