@@ -16,7 +16,7 @@
 namespace pl {
 
 struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live in CellLDS (S.ida_*)
-  double tn, hh, hused, cj, cjlast, cjold, cjratio, ss, rr, h0_forced;
+  double tn, hh, hused, cj, cjlast, cjold, cjratio, ss, rr, h0_forced, rtol, atol;
   int kk, kused, knew, phase, ns, maxord;
   int nst;
 };
@@ -101,8 +101,15 @@ template <class M>
 __device__ inline void set_ewt(CellLDS<M>& S, double rtol, double atol) {
   PL_MODEL(M);
   const int lane = lane_id();
-  PL_VEC(n) S.ewt[n] = 1.0 / (rtol * fabs(S.phi[0][n]) + atol);
+  if constexpr (M::EWT_LDS) { PL_VEC(n) S.ewt[n] = 1.0 / (rtol * fabs(S.phi[0][n]) + atol); }
   PL_SYNC();
+}
+// error weight of entry n: IDA evaluates ewt from phi[0] = y_n at the start of every step; phi[0] does not change until the step is
+// completed, so models that do not keep the vector in LDS recompute the identical value where it is used
+template <class M>
+__device__ __forceinline__ double ewt_of(const CellLDS<M>& S, const IdaScalars& I, int n) {
+  if constexpr (M::EWT_LDS) return S.ewt[n];
+  else return 1.0 / (I.rtol * fabs(S.phi[0][n]) + I.atol);
 }
 
 template <class M>
@@ -205,7 +212,7 @@ __device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaS
       PL_TIC();
       const double sc = (I.cjratio != 1.0) ? -2.0 / (1.0 + I.cjratio) : -1.0;
       double s = 0.0;
-      PL_VEC(n) { const double d = S.delta[n] * sc; S.ee[n] += d; const double p = d * S.ewt[n]; s += p * p; }
+      PL_VEC(n) { const double d = S.delta[n] * sc; S.ee[n] += d; const double p = d * ewt_of(S, I, n); s += p * p; }
       const double delnrm = sqrt(wave_sum(s) / NST);
       PL_SYNC();
       ret = 2;
@@ -234,7 +241,7 @@ __device__ inline int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, do
   const int kk = I.kk;
   double s0 = 0, s1 = 0, s2 = 0;
   PL_VEC(n) {
-    const double w = S.ewt[n], e = S.ee[n];
+    const double w = ewt_of(S, I, n), e = S.ee[n];
     double p = e * w; s0 += p * p;
     if (kk > 1) { const double d1 = S.phi[kk][n] + e; p = d1 * w; s1 += p * p;
       if (kk > 2) { const double d2 = d1 + S.phi[kk - 1][n]; p = d2 * w; s2 += p * p; } }
@@ -278,7 +285,7 @@ __device__ inline void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double er
     else if (I.kk + 1 >= I.ns || kdiff == 1) action = 2;
     if (action == 0) {
       double s = 0.0;
-      PL_VEC(n) { const double p = (S.ee[n] - S.phi[I.kk + 1][n]) * S.ewt[n]; s += p * p; }
+      PL_VEC(n) { const double p = (S.ee[n] - S.phi[I.kk + 1][n]) * ewt_of(S, I, n); s += p * p; }
       const double enorm = sqrt(wave_sum(s) / NST); err_kp1 = enorm / (I.kk + 2);
       const double terr_k = (I.kk + 1) * err_k, terr_kp1 = (I.kk + 2) * err_kp1;
       if (I.kk == 1) action = (terr_kp1 >= 0.5 * terr_k) ? 2 : 3;
@@ -336,13 +343,16 @@ __device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, Ida
   PL_MODEL(M);
   const int lane = lane_id();
   const double uround = 2.220446049250313e-16;
+  I.rtol = o.reltol; I.atol = o.abstol;
   if (I.nst == 0) {
     set_ewt(S, o.reltol, o.abstol);
     const double tdist = fabs(tstop - I.tn);
     double hh = I.h0_forced != 0.0 ? I.h0_forced : o.init_step;
     if (hh == 0.0) {
       hh = 0.001 * tdist;
-      const double ypnorm = wrms<M>(S.phi[1], S.ewt);
+      double sy = 0.0;
+      PL_VEC(n) { const double pq = S.phi[1][n] * ewt_of(S, I, n); sy += pq * pq; }
+      const double ypnorm = sqrt(wave_sum(sy) / NST);
       if (ypnorm > 0.5 / hh) hh = 0.5 / ypnorm;
     }
     if ((I.tn + hh - tstop) * hh > 0.0) hh = (tstop - I.tn) * (1.0 - 4.0 * uround);

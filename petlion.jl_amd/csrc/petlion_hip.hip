@@ -19,6 +19,14 @@
 
 using namespace pl;
 
+// Every kernel runs at most one wavefront per SIMD (LDS: >= 40 kB per single-wave workgroup), so the compiler may use the whole
+// 512-entry register file of a lane (256 VGPR + 256 AGPR) instead of spilling to scratch.
+#ifndef PL_WAVE_EMU
+#define PL_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
+#else
+#define PL_ONE_WAVE_PER_SIMD
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------------------
@@ -31,7 +39,7 @@ template <class M> __device__ __forceinline__ void store_vec(double* __restrict_
   _Pragma("unroll") for (int k__ = 0, n = lane; k__ < M::NTRIP; k__++, n += WAVE) if (n < M::NST) dst[n] = src[n];
 }
 
-template <class M> __global__ __launch_bounds__(64) void k_initial_guess(const Tables* tb, int n_cells, const double* theta, const double* SOC, double* Y) {
+template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_initial_guess(const Tables* tb, int n_cells, const double* theta, const double* SOC, double* Y) {
   __shared__ CellLDS<M> S;
   constexpr int NST = M::NST;
   LaneRegs R;
@@ -42,7 +50,7 @@ template <class M> __global__ __launch_bounds__(64) void k_initial_guess(const T
   store_vec<M>(Y + (size_t)cell * NST, S.yy);
 }
 
-template <class M> __global__ __launch_bounds__(64) void k_residual(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_residual(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                  int mode, double value, double* F) {
   __shared__ CellLDS<M> S;
   constexpr int NST = M::NST;
@@ -56,7 +64,7 @@ template <class M> __global__ __launch_bounds__(64) void k_residual(const Tables
   store_vec<M>(F + (size_t)cell * NST, S.delta);
 }
 
-template <class M> __global__ __launch_bounds__(64) void k_jacobian(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_jacobian(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                  double cj, int mode, double* nz) {
   __shared__ CellLDS<M> S;
   constexpr int NST = M::NST;
@@ -73,7 +81,7 @@ template <class M> __global__ __launch_bounds__(64) void k_jacobian(const Tables
   for (int k = lane_id(); k < nnz; k += WAVE) out[k] = jac_entry(S, tb, code[k], cj);
 }
 
-template <class M> __global__ __launch_bounds__(64) void k_linear_solve(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_linear_solve(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                      double cj, int mode, double* b) {
   __shared__ CellLDS<M> S;
   constexpr int NST = M::NST;
@@ -89,7 +97,7 @@ template <class M> __global__ __launch_bounds__(64) void k_linear_solve(const Ta
   store_vec<M>(b + (size_t)cell * NST, S.delta);
 }
 
-template <class M> __global__ __launch_bounds__(64) void k_init_consistent(const Tables* tb, int n_cells, const double* theta, int mode, double value,
+template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_init_consistent(const Tables* tb, int n_cells, const double* theta, int mode, double value,
                                                         double reltol_init, double* Y, double* YP, int* status, int* iters) {
   __shared__ CellLDS<M> S;
   constexpr int NST = M::NST;
@@ -112,7 +120,7 @@ struct IntegrateArgs {
   plh_outputs out; double* scratch;   // scratch: [n_cells][2][NST]
 };
 
-template <class M> __global__ __launch_bounds__(64) void k_integrate(IntegrateArgs a) {
+template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_integrate(IntegrateArgs a) {
   __shared__ CellLDS<M> S;
   constexpr int NST = M::NST;
   LaneRegs R;
