@@ -25,6 +25,7 @@ constexpr int WAVE = 64;
 constexpr int NP = 10, NS = 10, NN = 10, NR = 10, NE = NP + NS + NN, NJ = NP + NN;
 constexpr int O_CE = 0, O_CS = NE, N_CECS = O_CS + NJ * NR;      // c_e and c_s_avg lead every layout (reference src/external.jl:275-365)
 constexpr int NA = 10, NZ = 10, NT = NA + NE + NZ;               // current collectors; temperature nodes a|p|s|n|z
+constexpr int MAXORD = 5;
 
 // Model traits: state layout  Y = [ c_e | c_s_avg | T (thermal) | film, SOH (SEI) || j | Phi_e | Phi_s | j_s (SEI) | I ]  and closures.
 template <int CHEM_, bool SEI_, bool THERMAL_ = false> struct ModelT {
@@ -32,6 +33,7 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false> struct ModelT {
   static constexpr bool SEI = SEI_;
   static constexpr bool THERMAL = THERMAL_;
   static constexpr bool EWT_LDS = !(SEI_ || THERMAL_);   // error weights kept in LDS (else recomputed from phi[0] where used: LDS diet)
+  static constexpr int PHI_LDS = THERMAL_ ? 4 : MAXORD + 1;   // BDF history vectors kept in LDS; the higher orders live in registers (LDS diet)
   static constexpr int NB = THERMAL_ ? 4 : 3;        // node block size of the block-Thomas solve: (c_e, Phi_e, Phi_s[, T])
   static constexpr int O_T = N_CECS;
   static constexpr int O_FILM = N_CECS + (THERMAL_ ? NT : 0), O_SOH = O_FILM + NN;
@@ -44,7 +46,6 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false> struct ModelT {
 using ModelLcoIso = ModelT<PLH_CHEM_LCO_LIC6, false>;
 #define PL_MODEL(M) [[maybe_unused]] constexpr int O_J = M::O_J, O_PE = M::O_PE, O_PS = M::O_PS, O_I = M::O_I, NST = M::NST, NDIFF = M::NDIFF, NTRIP = M::NTRIP, \
                                        O_FILM = M::O_FILM, O_SOH = M::O_SOH, O_JS = M::O_JS
-constexpr int MAXORD = 5;
 constexpr double FAR = 96485.3321233;      // reference src/structures.jl:10
 constexpr double RGAS = 8.31446261815324;  // reference src/structures.jl:11
 constexpr double TREF = 298.15;
@@ -97,7 +98,8 @@ template <> struct SeiPool<true> {
 template <bool TH> struct ThermalPool {};
 template <> struct ThermalPool<true> {
   // heat-conduction stencil of residuals_T! (residuals.jl:299-489), already divided by rho*Cp:  aL T[it-1] + aD T[it] + aU T[it+1] + aC
-  double aL[NT], aD[NT], aU[NT], aC[NT], rc[NT], wT[NT];   // rc = 1/(rho Cp); wT = temperature_weighting w_i / L (aux...jl:649-679)
+  double aL[NT], aD[NT], aU[NT], wT5[5];                    // wT5 = temperature_weighting w_i / L per section a|p|s|n|z (aux...jl:649-679)
+  double aC2[2], rc5[5];                                    // constant term of the two convective end rows; 1/(rho Cp) per section a|p|s|n|z
   double qI[2], qIJ[2];                                    // collector rows: Joule heat qI * I^2 ; qIJ = d(row)/dI at the last Jacobian pass
   double kapP[NJ], dkapP[NJ];                              // per-particle D_s(T)/Rp^2 and its T derivative
   // Jacobian partials that exist only with temperature
@@ -107,33 +109,33 @@ template <> struct ThermalPool<true> {
   double TJ[NJ], Tcs[NJ];                                  // T rows x (j, c_s surface)
   double TX2[4][3];                                        // out-of-band T-row entries: rows of nodes 0, 9, 20, 29 x (c_e, Phi_e, Phi_s) of nodes 2, 7, 22, 27
   // particle resolvent in spectral form (per particle: kappa differs with T)
-  double rdiag[NJ][NR], AinvE[NJ][NR], AinvQ[NJ][NR], Wc[NJ][NR];
+  double AinvE[NJ][NR], AinvQ[NJ][NR];                     // A^-1 e_last, A^-1 q (AinvQ doubles as the store of W c between the Jacobian pass and the factorisation)
+  double kapF[NJ];                                         // kappa at the last factorisation (the resolvent is applied in spectral form)
   // node-local elimination
-  double tq[NE][4], phi4[NE][4], colI4[NE][4];
+  double tq[NE][4], phi4[NE][4], colI4[NE][2];           // colI4: (Phi_s, T) components of the column of I (the others are zero)
   // collector chains (tridiagonal scalar systems)
   double cP[2][NA], cM[2][NA], zc[2][NA], zI[2][NA], zb[2][NA];
   // Woodbury and border
   double Z[4][NE][4], Cinv[16], x2[NE][4], vB[NE][4];
-  double vcoll[2][NA];
-  double bord[4];                                          // [0] d2 = d - v.x2, [1] d (direct I entry of the control row), [2..3] spare
+  double bord[2];                                          // [0] d2 = d - v.x2, [1] d (direct I entry of the control row)
   double cjf;
 };
 
 template <class M> struct CellLDS {
-  double phi[MAXORD + 1][M::NPAD];
+  double phi[M::PHI_LDS][M::NPAD];
   double ewt[M::EWT_LDS ? M::NPAD : 2], yy[M::NPAD], yp[M::NPAD], ee[M::NPAD], delta[M::NPAD];
   // structured Jacobian pool (cj not included)
   double ceL[NE], ceD[NE], ceU[NE], ceJ[NE];
   double peL[NE], peD[NE], peU[NE], pcL[NE], pcD[NE], pcU[NE], peJ[NE];
   double gce[NJ], gcs[NJ], gpe[NJ], gps[NJ], psJ[NJ];
   // eliminated system
-  double dj[NJ], nphi[NE][3];      // j pivot; phi_c = omega . A_ux[:,c] (node block D[r][c] -= t_r phi_c, t = (ceJ, peJ, psJ))
-  double colI[NE][3];              // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
+  double dj[NJ], nphi[M::THERMAL ? 1 : NE][3];      // j pivot; phi_c = omega . A_ux[:,c] (node block D[r][c] -= t_r phi_c, t = (ceJ, peJ, psJ))
+  double colI[M::THERMAL ? 1 : NE][3];              // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
   double Dinv[NE][M::NB * M::NB], LD[NE][M::NB * M::NB];   // Thomas factors: D'^-1 and L D'^-1(prev)
   double LDmid[M::NB * M::NB];                             // closing block of the twisted factorisation
-  double Ainv[2][NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
-  double Mr[NR * NR];               // radial operator (copy of Tables::M)
-  double x2[NE][3];
+  double Ainv[2][M::THERMAL ? 1 : NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
+  double Mr[M::THERMAL ? 1 : NR * NR];               // radial operator (copy of Tables::M)
+  double x2[M::THERMAL ? 1 : NE][3];
   double ctrlJ[2], bord;           // P-mode control row at the last Jacobian pass (I*I1C, V*I1C); border pivot d - v.x2
   double w9[NJ];
   double sig[2];
@@ -143,7 +145,9 @@ template <class M> struct CellLDS {
   // wave-uniform BDF coefficient arrays (dynamically indexed by the order -> LDS, not registers/scratch)
   double ida_psi[MAXORD + 1], ida_alpha[MAXORD + 1], ida_beta[MAXORD + 1], ida_sigma[MAXORD + 1], ida_gamma[MAXORD + 1];
   double ida_out[4];
+#ifdef PL_PHASE_TIMERS
   long long cyc[8];    // per-phase cycle sums (profiling build only)
+#endif
   const Tables* tb;    // model tables (set by cell_setup)
   long long cnt[10];   // device counters (n_steps, n_res, n_jac, n_fact, n_solve, n_newton, n_errfail, n_convfail, sum_kp2, n_init_iters)
   CellConst cc;
@@ -387,7 +391,7 @@ __device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       S.sei.cjf = 0.0;
     }
   }
-  for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->M[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; }
+  if constexpr (!M::THERMAL) { for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->M[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
   for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
   PL_SYNC();
   if constexpr (M::THERMAL) thermal_setup(S, tb, th);

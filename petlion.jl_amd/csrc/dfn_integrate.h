@@ -17,6 +17,7 @@ namespace pl {
 
 struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live in CellLDS (S.ida_*)
   double tn, hh, hused, cj, cjlast, cjold, cjratio, ss, rr, h0_forced, rtol, atol;
+  double ph[2][6];   // per-lane entries of the BDF history vectors that are not kept in LDS (models with M::PHI_LDS < 6): [j - PHI_LDS][trip]
   int kk, kused, knew, phase, ns, maxord;
   int nst;
 };
@@ -28,6 +29,10 @@ __device__ __forceinline__ void cnt_add(Counters& c, int k, long long v = 1) { i
 
 // lane-strided sweep over the N state entries: exactly 5 trips (301 = 4*64 + 45), fully unrolled so that the LDS loads of all
 // trips are issued back to back (one latency instead of five); only the last trip is predicated.
+// BDF history access inside a PL_VEC loop (k__ = compile-time trip index): vectors j < M::PHI_LDS are LDS arrays, the rest registers in I.ph
+#define PHI_RD(j, n) ((M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? S.phi[(M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? (j) : 0][n] : I.ph[(j) - M::PHI_LDS][k__])
+#define PHI_WR(j, n, v) do { if (M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) S.phi[(M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? (j) : 0][n] = (v); \
+                             else if ((j) == M::PHI_LDS) I.ph[0][k__] = (v); else I.ph[1][k__] = (v); } while (0)
 #define PL_VEC(n) _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (k__ < NST / WAVE || n < NST)
 
 template <class M>
@@ -94,6 +99,7 @@ __device__ inline void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0
   I.cjratio = 1.0; I.ss = 20.0; I.phase = 0; I.ns = 0; I.h0_forced = 0.0; I.cj = 0.0; I.cjlast = 0.0; I.cjold = 0.0; I.rr = 0.0; I.knew = 0;
   if (lane <= MAXORD) { S.ida_psi[lane] = 0; S.ida_alpha[lane] = 0; S.ida_beta[lane] = 0; S.ida_sigma[lane] = 0; S.ida_gamma[lane] = 0; }
   PL_VEC(n) { S.phi[0][n] = y0[n]; S.phi[1][n] = yp0[n]; }
+  for (int q = 0; q < 6; q++) { I.ph[0][q] = 0.0; I.ph[1][q] = 0.0; }
   PL_SYNC();
 }
 
@@ -150,7 +156,7 @@ __device__ inline double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
   I.cjlast = I.cj; I.cj = -alphas / hh;
   const double ak = S.ida_alpha[kk];
   double ck = fabs(ak + alphas - alpha0); if (ck < ak) ck = ak;
-  for (int m = I.ns; m <= kk; m++) { const double b = S.ida_beta[m]; PL_VEC(n) S.phi[m][n] *= b; }
+  for (int m = I.ns; m <= kk; m++) { const double b = S.ida_beta[m]; PL_VEC(n) PHI_WR(m, n, PHI_RD(m, n) * b); }
   I.tn += hh;
   PL_SYNC();
   return ck;
@@ -163,7 +169,7 @@ __device__ inline void form_iterate(CellLDS<M>& S, const IdaScalars& I) {
   const int lane = lane_id();
   PL_VEC(n) {
     double a = S.phi[0][n], b = 0.0;
-    for (int j = 1; j <= I.kk; j++) { const double p = S.phi[j][n]; a += p; b += S.ida_gamma[j] * p; }
+    for (int j = 1; j <= I.kk; j++) { const double p = PHI_RD(j, n); a += p; b += S.ida_gamma[j] * p; }
     const double e = S.ee[n];
     S.yy[n] = a + e; S.yp[n] = b + I.cj * e;
   }
@@ -243,8 +249,8 @@ __device__ inline int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, do
   PL_VEC(n) {
     const double w = ewt_of(S, I, n), e = S.ee[n];
     double p = e * w; s0 += p * p;
-    if (kk > 1) { const double d1 = S.phi[kk][n] + e; p = d1 * w; s1 += p * p;
-      if (kk > 2) { const double d2 = d1 + S.phi[kk - 1][n]; p = d2 * w; s2 += p * p; } }
+    if (kk > 1) { const double d1 = PHI_RD(kk, n) + e; p = d1 * w; s1 += p * p;
+      if (kk > 2) { const double d2 = d1 + PHI_RD(kk - 1, n); p = d2 * w; s2 += p * p; } }
   }
   const double enorm_k = sqrt(wave_sum(s0) / NST);
   err_k = S.ida_sigma[kk] * enorm_k; const double terr_k = (kk + 1) * err_k;
@@ -265,7 +271,7 @@ __device__ inline void ida_restore(CellLDS<M>& S, IdaScalars& I, double saved_t)
   const int lane = lane_id();
   I.tn = saved_t;
   if (lane == 0) for (int j = 1; j <= I.kk; j++) S.ida_psi[j - 1] = S.ida_psi[j] - I.hh;
-  if (I.ns <= I.kk) for (int j = I.ns; j <= I.kk; j++) { const double b = 1.0 / S.ida_beta[j]; PL_VEC(n) S.phi[j][n] *= b; }
+  if (I.ns <= I.kk) for (int j = I.ns; j <= I.kk; j++) { const double b = 1.0 / S.ida_beta[j]; PL_VEC(n) PHI_WR(j, n, PHI_RD(j, n) * b); }
   PL_SYNC();
 }
 
@@ -285,7 +291,7 @@ __device__ inline void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double er
     else if (I.kk + 1 >= I.ns || kdiff == 1) action = 2;
     if (action == 0) {
       double s = 0.0;
-      PL_VEC(n) { const double p = (S.ee[n] - S.phi[I.kk + 1][n]) * ewt_of(S, I, n); s += p * p; }
+      PL_VEC(n) { const double p = (S.ee[n] - PHI_RD(I.kk + 1, n)) * ewt_of(S, I, n); s += p * p; }
       const double enorm = sqrt(wave_sum(s) / NST); err_kp1 = enorm / (I.kk + 2);
       const double terr_k = (I.kk + 1) * err_k, terr_kp1 = (I.kk + 2) * err_kp1;
       if (I.kk == 1) action = (terr_kp1 >= 0.5 * terr_k) ? 2 : 3;
@@ -301,9 +307,9 @@ __device__ inline void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double er
   const int ku = I.kused;
   PL_VEC(n) {
     const double e = S.ee[n];
-    if (ku < I.maxord) S.phi[ku + 1][n] = e;
-    double acc = S.phi[ku][n] + e; S.phi[ku][n] = acc;
-    for (int j = ku - 1; j >= 0; j--) { acc += S.phi[j][n]; S.phi[j][n] = acc; }
+    if (ku < I.maxord) PHI_WR(ku + 1, n, e);
+    double acc = PHI_RD(ku, n) + e; PHI_WR(ku, n, acc);
+    for (int j = ku - 1; j >= 0; j--) { acc += PHI_RD(j, n); PHI_WR(j, n, acc); }
   }
   PL_SYNC();
 }
@@ -325,7 +331,7 @@ __device__ inline void ida_get_solution(CellLDS<M>& S, const IdaScalars& I, doub
   PL_GS_STEP(1, rp0, rp1, c1, d0) PL_GS_STEP(2, rp1, rp2, c2, d1) PL_GS_STEP(3, rp2, rp3, c3, d2) PL_GS_STEP(4, rp3, rp4, c4, d3) PL_GS_STEP(5, rp4, rp5, c5, d4)
 #undef PL_GS_STEP
   PL_VEC(n) {
-    const double p1 = S.phi[1][n], p2 = S.phi[2][n], p3 = S.phi[3][n], p4 = S.phi[4][n], p5 = S.phi[5][n];
+    const double p1 = S.phi[1][n], p2 = S.phi[2][n], p3 = S.phi[3][n], p4 = PHI_RD(4, n), p5 = PHI_RD(5, n);
     double s = S.phi[0][n] + c1 * p1, sp = d0 * p1;
     if (kord >= 2) { s += c2 * p2; sp += d1 * p2; }
     if (kord >= 3) { s += c3 * p3; sp += d2 * p3; }
@@ -414,7 +420,7 @@ __device__ __forceinline__ double cellV(const double* Y) { return Y[M::O_PS] - Y
 // calc_T_avg / temperature_weighting (aux...jl:649-679): wave-uniform, every lane must call it
 template <class M>
 __device__ __forceinline__ double cellTavg(const CellLDS<M>& S, const double* Y) {
-  if constexpr (M::THERMAL) { const int lane = lane_id(); return wave_sum(lane < NT ? S.th.wT[lane] * Y[M::O_T + lane] : 0.0); }
+  if constexpr (M::THERMAL) { const int lane = lane_id(); return wave_sum(lane < NT ? S.th.wT5[tsec_of(lane)] * Y[M::O_T + lane] : 0.0); }
   else return S.cc.T0;
 }
 

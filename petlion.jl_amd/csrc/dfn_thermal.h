@@ -109,8 +109,11 @@ __device__ inline void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ t
     if (it == 0) { aD -= hc / h; aC = hc * Tamb / h; }                   // convective BCs at the two outer faces
     if (it == NT - 1) { aD -= hc / h; aC = hc * Tamb / h; }
     const double rc = 1.0 / rcp[k];
-    TP.aL[it] = aL * rc; TP.aD[it] = aD * rc; TP.aU[it] = aU * rc; TP.aC[it] = aC * rc; TP.rc[it] = rc;
-    TP.wT[it] = h / (la + (c.h[0] * NP + c.h[1] * NS + c.h[2] * NN) + lz);
+    TP.aL[it] = aL * rc; TP.aD[it] = aD * rc; TP.aU[it] = aU * rc;
+    if (it == 0) TP.aC2[0] = aC * rc;
+    if (it == NT - 1) TP.aC2[1] = aC * rc;
+    if (loc == 0) TP.rc5[k] = rc;
+    if (loc == 0) TP.wT5[k] = h / (la + (c.h[0] * NP + c.h[1] * NS + c.h[2] * NN) + lz);
     if (it == 0) TP.qI[0] = c.I1C * c.I1C / th[ix[K_sig_a]] * rc;
     if (it == NT - 1) TP.qI[1] = c.I1C * c.I1C / th[ix[K_sig_z]] * rc;
   }
@@ -206,7 +209,7 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
   const double dPe = em * pe_p + e0 * pe + ep * pe_n + e2 * pe_2;
   const double dce = em * ce_p + e0 * ce + ep * ce_n + e2 * ce_2;
   const double dPs = sm * ps_p + s0 * ps + sp * ps_n + s2 * ps_2;
-  const double rc = TP.rc[it];
+  const double rc = TP.rc5[tsec_of(it)];
   const double Faj = elec ? FAR * a * jv : 0.0;
   if (WANT_RES) {
     if (act) {
@@ -225,23 +228,24 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
       // residuals_T!, residuals.jl:299-489 ; heat sources aux...jl:344-518
       const double qrr = Faj * (T * dUdT + eta);
       const double qohm = K * dPe * dPe + cKfac * K * T * (dce / ce) * dPe + (elec ? sg * dPs * dPs : 0.0);
-      Fo[O_T + it] = TP.aL[it] * Tl + TP.aD[it] * T + TP.aU[it] * Tr + TP.aC[it] + (qrr + qohm) * rc - ypT;
+      Fo[O_T + it] = TP.aL[it] * Tl + TP.aD[it] * T + TP.aU[it] * Tr + (qrr + qohm) * rc - ypT;
     }
     if (lane >= 32 && lane < 32 + NA + NZ) {                                          // current-collector rows
       const int k = lane - 32, ic = k < NA ? k : NA + NE + (k - NA);
       const double Tc = Y[O_T + ic], Tcl = ic > 0 ? Y[O_T + ic - 1] : 0.0, Tcr = ic < NT - 1 ? Y[O_T + ic + 1] : 0.0;
-      Fo[O_T + ic] = TP.aL[ic] * Tcl + TP.aD[ic] * Tc + TP.aU[ic] * Tcr + TP.aC[ic] + TP.qI[k < NA ? 0 : 1] * yI * yI - YP[O_T + ic];
+      const double aC = ic == 0 ? TP.aC2[0] : (ic == NT - 1 ? TP.aC2[1] : 0.0);
+      Fo[O_T + ic] = TP.aL[ic] * Tcl + TP.aD[ic] * Tc + TP.aU[ic] * Tcr + aC + TP.qI[k < NA ? 0 : 1] * yI * yI - YP[O_T + ic];
     }
     if (mode == PLH_MODE_I || mode == PLH_MODE_V || mode == PLH_MODE_P || mode == PLH_MODE_ETA_P) {   // scalar_residual!, scalar_residual.jl:167-172
       const double Vc = Y[O_PS] - Y[O_PS + NJ - 1];
       if (lane == 0) Fo[O_I] = mode == PLH_MODE_I ? yI - value : (mode == PLH_MODE_V ? Vc - value : (mode == PLH_MODE_P ? yI * cI1C * Vc - value
                                                                   : Y[O_PS + NP] - Y[O_PE + NP + NS] - value));
     } else if (mode == PLH_MODE_DT) {                                                  // constant_temperature: value - sum w_i YP[T_i] / L
-      const double sT = wave_sum(lane < NT ? TP.wT[lane] * YP[O_T + lane] : 0.0);
+      const double sT = wave_sum(lane < NT ? TP.wT5[tsec_of(lane)] * YP[O_T + lane] : 0.0);
       if (lane == 0) Fo[O_I] = value - sT;
     } else {                                                                           // algebraic twin: YP_T -> rhs_T(Y), scalar_residual.jl:347-372
       PL_SYNC();
-      const double sT = wave_sum(lane < NT ? TP.wT[lane] * (Fo[O_T + lane] + YP[O_T + lane]) : 0.0);
+      const double sT = wave_sum(lane < NT ? TP.wT5[tsec_of(lane)] * (Fo[O_T + lane] + YP[O_T + lane]) : 0.0);
       if (lane == 0) Fo[O_I] = value - sT;
     }
   }
@@ -317,7 +321,7 @@ __device__ inline void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__
   auto& TP = S.th;
   const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
   double Mrow[NR], Wrow[NR];
-  for (int k = 0; k < NR; k++) { Mrow[k] = S.Mr[r * NR + k]; if (WANT_JAC) Wrow[k] = tb->W[r * NR + k]; }
+  for (int k = 0; k < NR; k++) { Mrow[k] = tb->M[r * NR + k]; if (WANT_JAC) Wrow[k] = tb->W[r * NR + k]; }
 #pragma unroll
   for (int pass = 0; pass < 4; pass++) {
     const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
@@ -326,7 +330,7 @@ __device__ inline void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__
     for (int k = 0; k < NR; k++) { const double v = Y[O_CS + p * NR + k]; acc += Mrow[k] * v; if (WANT_JAC) wc += Wrow[k] * v; }
     double rhs = TP.kapP[p] * acc;
     if (r == NR - 1) rhs += (p < NP ? c.bj_p : c.bj_n) * Y[O_J + p];
-    if (lane < 60 && p0 < NJ) { Fo[O_CS + p * NR + r] = rhs - YP[O_CS + p * NR + r]; if (WANT_JAC) TP.Wc[p][r] = wc; }
+    if (lane < 60 && p0 < NJ) { Fo[O_CS + p * NR + r] = rhs - YP[O_CS + p * NR + r]; if (WANT_JAC) TP.AinvQ[p][r] = wc; }
   }
 }
 
@@ -472,19 +476,20 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
   const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
   // 1. particle resolvents in spectral form
   if (!alg_only) {
-    const double lam_r = tb->LAM[r];
-    for (int pass = 0; pass < 4; pass++) {
-      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
-      if (lane < 60 && p0 < NJ) TP.rdiag[p][r] = 1.0 / (TP.kapP[p] * lam_r - cj);
-    }
-    PL_SYNC();
+    if (lane < NJ) TP.kapF[lane] = TP.kapP[lane];
     double Vrow[NR], wl[NR], lm[NR];
     for (int m = 0; m < NR; m++) { Vrow[m] = tb->V[r * NR + m]; wl[m] = tb->W[m * NR + NR - 1]; lm[m] = tb->LAM[m]; }
+    double ae[4], aq[4];
     for (int pass = 0; pass < 4; pass++) {
       const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
-      double ae = 0.0, aq = 0.0;
-      for (int m = 0; m < NR; m++) { const double f = Vrow[m] * TP.rdiag[p][m]; ae += f * wl[m]; aq += f * lm[m] * TP.Wc[p][m]; }
-      if (lane < 60 && p0 < NJ) { TP.AinvE[p][r] = ae; TP.AinvQ[p][r] = aq * TP.dkapP[p]; }
+      const double kp = TP.kapP[p];
+      ae[pass] = 0.0; aq[pass] = 0.0;
+      for (int m = 0; m < NR; m++) { const double f = Vrow[m] / (kp * lm[m] - cj); ae[pass] += f * wl[m]; aq[pass] += f * lm[m] * TP.AinvQ[p][m]; }   // AinvQ still holds W c
+    }
+    PL_SYNC();                                             // every lane has read W c before it is overwritten
+    for (int pass = 0; pass < 4; pass++) {
+      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
+      if (lane < 60 && p0 < NJ) { TP.AinvE[p][r] = ae[pass]; TP.AinvQ[p][r] = aq[pass] * TP.dkapP[p]; }
     }
     // 2. collector chains: (aL, aD - cj, aU) x = rhs by the Thomas algorithm, lane 62 = Al, lane 63 = Cu.  Two fixed right-hand
     //    sides: the coupling to T of the neighbouring cell node (Al: last row, through aU; Cu: first row, through aL) and the column of I
@@ -533,7 +538,7 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     }
     TP.tq[i][0] = t0; TP.tq[i][1] = t1; TP.tq[i][2] = t2; TP.tq[i][3] = t3;
     TP.phi4[i][0] = p0; TP.phi4[i][1] = p1; TP.phi4[i][2] = p2; TP.phi4[i][3] = p3;
-    TP.colI4[i][0] = 0.0; TP.colI4[i][1] = 0.0; TP.colI4[i][2] = cI2; TP.colI4[i][3] = cI3;
+    TP.colI4[i][0] = cI2; TP.colI4[i][1] = cI3;
   }
   if (lane == 0) TP.cjf = cj;
   PL_SYNC();
@@ -620,24 +625,24 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     else if (mode == PLH_MODE_P) { if (lane == 0) v2 = S.ctrlJ[0]; if (lane == NE - 1) v2 = -S.ctrlJ[0]; dI = S.ctrlJ[1]; }
     else if (mode == PLH_MODE_ETA_P) { if (lane == NP + NS) { v2 = 1.0; v1 = -1.0; } }
     else if (mode == PLH_MODE_DT) {
-      if (lane < NE) v3 = -cj * TP.wT[NA + ln];
+      if (lane < NE) v3 = -cj * TP.wT5[tsec_of(NA + ln)];
       // collector part: sum_k vc_k dT_k with dT = zb - zc dT_end - zI xI
       double vc = 0.0, vi = 0.0;
       for (int k = 0; k < NA; k++) {
-        if (lane == 0) { vc += TP.wT[k] * TP.zc[0][k]; vi += TP.wT[k] * TP.zI[0][k]; }
-        if (lane == NE - 1) { vc += TP.wT[NA + NE + k] * TP.zc[1][k]; vi += TP.wT[NA + NE + k] * TP.zI[1][k]; }
+        if (lane == 0) { vc += TP.wT5[tsec_of(k)] * TP.zc[0][k]; vi += TP.wT5[tsec_of(k)] * TP.zI[0][k]; }
+        if (lane == NE - 1) { vc += TP.wT5[tsec_of(NA + NE + k)] * TP.zc[1][k]; vi += TP.wT5[tsec_of(NA + NE + k)] * TP.zI[1][k]; }
       }
       v3 -= -cj * vc;                                       // -(-cj w) zc
       dI = wave_sum((lane == 0 || lane == NE - 1) ? cj * vi : 0.0);   // -(-cj w) zI
     } else {                                                // PL_MODE_DT_TWIN: -(sum_i w_i d rhs_T,i / d y_alg)
       // T row i depends on Phi_e, Phi_s of nodes i-1, i, i+1 (TeL/D/U, TsL/D/U), on j_i (TJ) and, for the four one-sided stencils, on a second neighbour
-      const double wi = lane < NE ? TP.wT[NA + ln] : 0.0;
+      const double wi = lane < NE ? TP.wT5[tsec_of(NA + ln)] : 0.0;
       const double eU = shift_up1(lane < NE ? wi * TP.TeU[ln] : 0.0), eL = shift_down1(lane < NE ? wi * TP.TeL[ln] : 0.0);
       const double sU = shift_up1(lane < NE ? wi * TP.TsU[ln] : 0.0), sL = shift_down1(lane < NE ? wi * TP.TsL[ln] : 0.0);
       if (lane < NE) {
         v1 = -(eU + wi * TP.TeD[ln] + (lane < NE - 1 ? eL : 0.0));
         v2 = -(sU + wi * TP.TsD[ln] + (lane < NE - 1 ? sL : 0.0));
-        for (int k = 0; k < 4; k++) if (lane == wb_src_node(k)) { const double wr = TP.wT[NA + wb_row_node(k)]; v1 -= wr * TP.TX2[k][1]; v2 -= wr * TP.TX2[k][2]; }
+        for (int k = 0; k < 4; k++) if (lane == wb_src_node(k)) { const double wr = TP.wT5[tsec_of(NA + wb_row_node(k))]; v1 -= wr * TP.TX2[k][1]; v2 -= wr * TP.TX2[k][2]; }
         const int sc = sec_of(ln);
         if (sc != 1) {                                     // j eliminated: v_x -= v_j phi
           const int jx = sc == 0 ? ln : ln - NS;
@@ -647,7 +652,7 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
         }
       }
       // the collector rows depend on I only (Joule heat): -(sum_k w_k) d rhs_k/dI
-      dI = -(NA * TP.wT[0] * TP.qIJ[0] + NZ * TP.wT[NT - 1] * TP.qIJ[1]);
+      dI = -(NA * TP.wT5[tsec_of(0)] * TP.qIJ[0] + NZ * TP.wT5[tsec_of(NT - 1)] * TP.qIJ[1]);
     }
     if (lane < NE) { TP.vB[ln][0] = v0; TP.vB[ln][1] = v1; TP.vB[ln][2] = v2; TP.vB[ln][3] = v3; }
   }
@@ -681,7 +686,7 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
   // 6b. border: x2 = B^-1 (column of I) and the pivot d - v.x2
   if (mode != PLH_MODE_I) {
     double ra[1][4] = {{0.0, 0.0, 0.0, 0.0}};
-    if (act) for (int cc = 0; cc < 4; cc++) ra[0][cc] = TP.colI4[i][cc];
+    if (act) { ra[0][2] = TP.colI4[i][0]; ra[0][3] = TP.colI4[i][1]; }
     thermal_sweeps<1>(S, alg_only, ra);
     if (!alg_only) { double s[4]; wb_dots(S, ra[0], s); wb_apply(S, ra[0], s); }
     if (act) for (int cc = 0; cc < 4; cc++) TP.x2[i][cc] = ra[0][cc];
@@ -703,11 +708,12 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
   if (!alg_only) {
     double Wrow[NR], Vrow[NR];
     for (int k = 0; k < NR; k++) { Wrow[k] = tb->W[r * NR + k]; Vrow[k] = tb->V[r * NR + k]; }
+    const double lam_r = tb->LAM[r];
     for (int pass = 0; pass < 4; pass++) {
       const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
       double y = 0.0;
       for (int k = 0; k < NR; k++) y += Wrow[k] * b[O_CS + p * NR + k];
-      if (lane < 60 && p0 < NJ) TP.Wc[p][r] = y * TP.rdiag[p][r];      // Wc is free between a factorisation and the next Jacobian pass
+      if (lane < 60 && p0 < NJ) S.yy[O_CS + p * NR + r] = y / (TP.kapF[p] * lam_r - TP.cjf);   // S.yy is dead between a residual and the next form_iterate
     }
     if (lane >= 62) {
       const int q = lane - 62, base = q == 0 ? 0 : NA + NE;
@@ -720,7 +726,7 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
     for (int pass = 0; pass < 4; pass++) {
       const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
       double w = 0.0;
-      for (int m = 0; m < NR; m++) w += Vrow[m] * TP.Wc[p][m];
+      for (int m = 0; m < NR; m++) w += Vrow[m] * S.yy[O_CS + p * NR + m];
       if (lane < 60 && p0 < NJ && r == NR - 1) S.w9[p] = w;
       R.wreg[pass] = w;
     }
@@ -753,7 +759,7 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
   double xI = 0.0;
   if (mode == PLH_MODE_I) {
     xI = b[O_I];
-    if (act) for (int cc = 0; cc < 4; cc++) y[cc] -= TP.colI4[i][cc] * xI;
+    if (act) { y[2] -= TP.colI4[i][0] * xI; y[3] -= TP.colI4[i][1] * xI; }
   }
   // c. block-Thomas sweeps + Woodbury correction
   {
@@ -772,7 +778,7 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
       else vy += TP.vB[i][0] * y[0];
     }
     if (mode == PLH_MODE_DT) {                                          // collector T's in the control row: -cj w_k zb_k
-      if (lane >= 32 && lane < 32 + NA + NZ) { const int k = lane - 32, q = k < NA ? 0 : 1, kk = k < NA ? k : k - NA; vy += -TP.cjf * TP.wT[q == 0 ? kk : NA + NE + kk] * TP.zb[q][kk]; }
+      if (lane >= 32 && lane < 32 + NA + NZ) { const int k = lane - 32, q = k < NA ? 0 : 1, kk = k < NA ? k : k - NA; vy += -TP.cjf * TP.wT5[tsec_of(q == 0 ? kk : NA + NE + kk)] * TP.zb[q][kk]; }
     }
     const double vsum = wave_sum(vy);
     xI = (bI - vsum) / TP.bord[0];
@@ -851,7 +857,7 @@ __device__ inline double thermal_jac_entry(const CellLDS<M>& S, const Tables* __
     case TT_T_CS: return TP.Tcs[a];
     case TT_T_X2: return TP.TX2[a][bb];
     case TT_T_I: return TP.qIJ[a];
-    case TT_CTRL_T: return -cj * TP.wT[a];
+    case TT_CTRL_T: return -cj * TP.wT5[tsec_of(a)];
   }
   return iso_jac_entry(S, tb, w, cj);
 }

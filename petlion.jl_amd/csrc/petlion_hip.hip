@@ -128,7 +128,9 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   if (cell >= a.n_cells) return;
   cell_setup(S, R, a.tb, a.theta + (size_t)cell * a.tb->P);
   Counters cnt; cnt.cnt = S.cnt; if (lane_id() < 10) S.cnt[lane_id()] = 0;
+#ifdef PL_PHASE_TIMERS
   if (lane_id() < 8) S.cyc[lane_id()] = 0;
+#endif
   PL_SYNC();
   PL_TIC();
   CellOut co;
@@ -144,7 +146,11 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   PL_SYNC();
   if (lane_id() == 0 && a.out.counters) {
     plh_counters* c = a.out.counters + cell;
+#ifdef PL_PHASE_TIMERS
     for (int k = 0; k < 8; k++) c->cyc[k] = S.cyc[k];
+#else
+    for (int k = 0; k < 8; k++) c->cyc[k] = 0;
+#endif
     c->n_steps = S.cnt[C_STEPS]; c->n_res = S.cnt[C_RES]; c->n_jac = S.cnt[C_JAC]; c->n_fact = S.cnt[C_FACT]; c->n_solve = S.cnt[C_SOLVE];
     c->n_newton = S.cnt[C_NEWTON]; c->n_errfail = S.cnt[C_ERRFAIL]; c->n_convfail = S.cnt[C_CONVFAIL]; c->sum_kp2 = S.cnt[C_SUMKP2]; c->n_init_iters = S.cnt[C_INIT];
   }
