@@ -178,3 +178,59 @@ def check_power_and_plating_modes(p, O, pkg):
 
 def test_power_and_plating_overpotential_modes(emu_model, O, pkg):
     check_power_and_plating_modes(emu_model, O, pkg)
+
+
+def check_stop_conditions(p, O, pkg):
+    """every boundary_stop_condition of the reference (src/checks.jl:31-224; flags 1..11) fires on the same step and back-interpolates to the
+    same point as the oracle; plus check_bounds = false, interp_final = false and the output-buffer guard."""
+    th = p.theta_vector()
+    cases = [
+        ("V_min", [{"I": -2.0, "V_min": 3.6}], 1.0, 1),
+        ("V_max", [{"I": 1.0, "V_max": 3.95}], 0.3, 2),
+        ("SOC_min", [{"I": -1.0, "SOC_min": 0.6}], 1.0, 3),
+        ("SOC_max", [{"I": 1.0, "SOC_max": 0.5}], 0.2, 4),
+        ("c_s_n_max", [{"I": 2.0, "c_s_n_max": 0.6}], 0.2, 6),
+        ("I_max", [{"V": 4.05, "I_max": 2.5, "tf": 600.0}], 0.6, None),      # fires only if the voltage step demands more than I_max
+        ("I_min", [{"I": 1.0, "tf": 600.0}, {"V": "hold", "I_min": 0.3}], 0.3, 8),
+        ("c_e_min", [{"I": -3.0, "c_e_min": 600.0}], 1.0, 9),
+        ("η_plating_min", [{"I": 3.0, "η_plating_min": 0.02}], 0.2, 11),
+    ]
+    if p.aging:
+        cases.append(("dfilm_max", [{"I": 1.0, "tf": 200.0}, {"I": 3.0, "dfilm_max": 2e-15}], 0.3, 10))
+    for name, proto, soc, flag in cases:
+        ens = pkg.simulate_ensemble(p, th[None, :], proto, SOC=soc)
+        ro = O.simulate(p.variant, th, soc, parity.runs_to_oracle(O, p, pkg, proto))
+        got = int(ens.run_info[0, -1]["flag"])
+        assert got == ro["runs"][-1]["flag"], (name, got, ro["runs"][-1])
+        if flag is not None:
+            assert got == flag, (name, got)
+        if len(proto) == 1:
+            parity.compare_trajectory(ens, 0, ro, rtol_state=1e-5)      # identical decisions; state floor of DESIGN.md section 5
+        else:
+            assert abs(ens.run_info[0, -1]["t_end"] - ro["runs"][-1]["t_end"]) <= 2e-3 * ro["runs"][-1]["t_end"], name
+    # check_bounds = false: runs to tf whatever the states do (flag 0); interp_final = false: the last point is the overshooting step
+    o = pkg.Opts(); o.check_bounds = False
+    ens = pkg.simulate_ensemble(p, th[None, :], [{"I": -1.0, "tf": 500.0, "V_min": 4.0}], SOC=1.0, opts=o)
+    ro = O.simulate(p.variant, th, 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0, "tf": 500.0, "V_min": 4.0}]), opts=O.default_opts(check_bounds=0))
+    assert ens.run_info[0, 0]["flag"] == 0 == ro["runs"][0]["flag"] and abs(ens.run_info[0, 0]["t_end"] - 500.0) < 1e-9
+    o = pkg.Opts(); o.interp_final = False
+    ens = pkg.simulate_ensemble(p, th[None, :], [{"I": -1.0, "V_min": 3.8}], SOC=1.0, opts=o)
+    ro = O.simulate(p.variant, th, 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0, "V_min": 3.8}]), opts=O.default_opts(interp_final=0))
+    assert ens.run_info[0, 0]["flag"] == 1 and ens.run_info[0, 0]["V"] < 3.8 and abs(ens.run_info[0, 0]["t_end"] - ro["runs"][0]["t_end"]) < 1e-5 * ro["runs"][0]["t_end"]
+    # output buffers smaller than the trajectory: the cell reports PLH_ERR_OUTPUT_FULL (-14) instead of writing out of bounds
+    ens = pkg.simulate_ensemble(p, th[None, :], [{"I": -1.0}], SOC=1.0, max_points=16)
+    assert ens.run_info[0, 0]["flag"] == -14 and int(ens.n_pts[0]) == 16
+
+
+def test_every_stop_condition(emu_model, O, pkg):
+    check_stop_conditions(emu_model, O, pkg)
+
+
+def test_dfilm_stop_condition(emu_model_sei, O, pkg):
+    p = emu_model_sei
+    th = p.theta_vector()
+    proto = [{"I": 1.0, "tf": 200.0}, {"I": 3.0, "dfilm_max": 2e-15}]
+    ens = pkg.simulate_ensemble(p, th[None, :], proto, SOC=0.3)
+    ro = O.simulate(p.variant, th, 0.3, parity.runs_to_oracle(O, p, pkg, proto))
+    assert int(ens.run_info[0, -1]["flag"]) == ro["runs"][-1]["flag"] == 10          # "Above max. film growth rate", checks.jl:203-224
+    assert abs(ens.run_info[0, -1]["t_end"] - ro["runs"][-1]["t_end"]) < 1e-6 * ro["runs"][-1]["t_end"]

@@ -247,3 +247,9 @@ def test_power_and_plating_overpotential_modes(hip_model, hip_model_thermal, hip
     import test_device_source_emu as te
     te.check_power_and_plating_modes(hip_model, O, pkg)
     te.check_power_and_plating_modes(hip_model_thermal, O, pkg)
+
+
+def test_every_stop_condition(hip_model, hip_model_sei, O, pkg):
+    import test_device_source_emu as te
+    te.check_stop_conditions(hip_model, O, pkg)
+    te.check_stop_conditions(hip_model_sei, O, pkg)
