@@ -133,7 +133,7 @@ def state_rel_err(Y, Yo):
     for name, a, e in sections_for(len(Yo)):
         # a field that is identically zero in exact arithmetic (j_s while not charging, I at rest) holds only solver round-off
         # (~1e-23 in the oracle's sparse LU, exactly 0 on the device): floor its scale well below any physical magnitude
-        floor = {"j_s": 1e-15, "j": 1e-12, "I": 1e-9, "film": 1e-14}.get(name, 1e-300)
+        floor = {"j_s": 1e-13, "j": 1e-12, "I": 1e-9, "film": 1e-14}.get(name, 1e-300)
         worst = max(worst, np.abs(Y[a:e] - Yo[a:e]).max() / max(np.abs(Yo[a:e]).max(), floor))
     return worst
 
