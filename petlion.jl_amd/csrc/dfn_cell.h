@@ -149,7 +149,6 @@ template <class M> struct CellLDS {
   long long cyc[8];    // per-phase cycle sums (profiling build only)
 #endif
   const Tables* tb;    // model tables (set by cell_setup)
-  long long cnt[10];   // device counters (n_steps, n_res, n_jac, n_fact, n_solve, n_newton, n_errfail, n_convfail, sum_kp2, n_init_iters)
   CellConst cc;
 };
 

@@ -22,10 +22,10 @@ struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live 
   int nst;
 };
 
-// device counters live in LDS (S.cnt), incremented by lane 0; indices:
+// device counters: wave-uniform registers (every call site uses a compile-time index), written out once at the end; indices:
 enum Cnt { C_STEPS, C_RES, C_JAC, C_FACT, C_SOLVE, C_NEWTON, C_ERRFAIL, C_CONVFAIL, C_SUMKP2, C_INIT };
-struct Counters { long long* cnt; };
-__device__ __forceinline__ void cnt_add(Counters& c, int k, long long v = 1) { if (lane_id() == 0) c.cnt[k] += v; }
+struct Counters { int v[10]; };
+__device__ __forceinline__ void cnt_add(Counters& c, int k, int v = 1) { c.v[k] += v; }
 
 // lane-strided sweep over the N state entries: exactly 5 trips (301 = 4*64 + 45), fully unrolled so that the LDS loads of all
 // trips are issued back to back (one latency instead of five); only the last trip is predicated.
@@ -515,7 +515,7 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     }
   };
   for (int r = 0; r < n_runs; r++) {
-    const plh_run& run = runs[r];
+    const plh_run run = runs[r];                                        // by value: one load per run instead of scalar loads in every step (the compiler cannot hoist them past the global stores)
     const int mode = run.mode;
     const bool new_run = !have_prev;
     double t0;

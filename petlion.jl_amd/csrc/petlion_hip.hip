@@ -107,12 +107,12 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec<M>(S.yy, Y + (size_t)cell * NST);
   PL_SYNC();
-  Counters cnt; cnt.cnt = S.cnt; if (lane_id() < 10) S.cnt[lane_id()] = 0;
+  Counters cnt; for (int k = 0; k < 10; k++) cnt.v[k] = 0;
   PL_SYNC();
   const int rc = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, reltol_init, cnt);
   store_vec<M>(Y + (size_t)cell * NST, S.yy); store_vec<M>(YP + (size_t)cell * NST, S.yp);
   PL_SYNC();
-  if (lane_id() == 0) { if (status) status[cell] = rc; if (iters) iters[cell] = (int)S.cnt[C_INIT]; }
+  if (lane_id() == 0) { if (status) status[cell] = rc; if (iters) iters[cell] = cnt.v[C_INIT]; }
 }
 
 struct IntegrateArgs {
@@ -127,7 +127,7 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   const int cell = blockIdx.x;
   if (cell >= a.n_cells) return;
   cell_setup(S, R, a.tb, a.theta + (size_t)cell * a.tb->P);
-  Counters cnt; cnt.cnt = S.cnt; if (lane_id() < 10) S.cnt[lane_id()] = 0;
+  Counters cnt; for (int k = 0; k < 10; k++) cnt.v[k] = 0;
 #ifdef PL_PHASE_TIMERS
   if (lane_id() < 8) S.cyc[lane_id()] = 0;
 #endif
@@ -151,8 +151,8 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
 #else
     for (int k = 0; k < 8; k++) c->cyc[k] = 0;
 #endif
-    c->n_steps = S.cnt[C_STEPS]; c->n_res = S.cnt[C_RES]; c->n_jac = S.cnt[C_JAC]; c->n_fact = S.cnt[C_FACT]; c->n_solve = S.cnt[C_SOLVE];
-    c->n_newton = S.cnt[C_NEWTON]; c->n_errfail = S.cnt[C_ERRFAIL]; c->n_convfail = S.cnt[C_CONVFAIL]; c->sum_kp2 = S.cnt[C_SUMKP2]; c->n_init_iters = S.cnt[C_INIT];
+    c->n_steps = cnt.v[C_STEPS]; c->n_res = cnt.v[C_RES]; c->n_jac = cnt.v[C_JAC]; c->n_fact = cnt.v[C_FACT]; c->n_solve = cnt.v[C_SOLVE];
+    c->n_newton = cnt.v[C_NEWTON]; c->n_errfail = cnt.v[C_ERRFAIL]; c->n_convfail = cnt.v[C_CONVFAIL]; c->sum_kp2 = cnt.v[C_SUMKP2]; c->n_init_iters = cnt.v[C_INIT];
   }
 }
 
