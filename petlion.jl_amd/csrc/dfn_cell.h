@@ -149,6 +149,7 @@ template <class M> struct CellLDS {
   long long cyc[8];    // per-phase cycle sums (profiling build only)
 #endif
   const Tables* tb;    // model tables (set by cell_setup)
+  plh_run runc;        // the run being integrated (copied from HBM once per run)
   CellConst cc;
 };
 

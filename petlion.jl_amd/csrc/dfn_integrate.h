@@ -515,7 +515,11 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     }
   };
   for (int r = 0; r < n_runs; r++) {
-    const plh_run run = runs[r];                                        // by value: one load per run instead of scalar loads in every step (the compiler cannot hoist them past the global stores)
+    // the run descriptor is staged in LDS once per run: reading it from global memory in every step costs ~1.4 k cycles per step (scalar
+    // loads that cannot be hoisted past the global stores), and a by-value register copy proved fragile under register pressure
+    if (lane == 0) S.runc = runs[r];
+    PL_SYNC();
+    const plh_run& run = S.runc;
     const int mode = run.mode;
     const bool new_run = !have_prev;
     double t0;

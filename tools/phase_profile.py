@@ -38,3 +38,4 @@ tot = cyc[:, 7].mean()
 for k, nm in enumerate(names):
     print("  %-11s %10.0f cyc  %5.1f%%" % (nm, cyc[:, k].mean(), 100 * cyc[:, k].mean() / tot))
 print("  per call: residual %.0f  jac+factor %.0f  solve %.0f" % (cyc[:, 0].mean() / (c["n_res"].mean() - c["n_jac"].mean()), cyc[:, 1].mean() / c["n_jac"].mean(), cyc[:, 2].mean() / c["n_newton"].mean()))
+print("  flags per run:", [dict(zip(*np.unique(ens.run_info["flag"][:, k], return_counts=True))) for k in range(ens.run_info.shape[1])])
