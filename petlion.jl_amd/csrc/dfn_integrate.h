@@ -17,6 +17,7 @@ namespace pl {
 
 struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live in CellLDS (S.ida_*)
   double tn, hh, hused, cj, cjlast, cjold, cjratio, ss, rr, h0_forced, rtol, atol;
+  double ew[6];      // per-lane error weights of this step for models that do not keep the vector in LDS (M::EWT_LDS == false)
   double ph[2][6];   // per-lane entries of the BDF history vectors that are not kept in LDS (models with M::PHI_LDS < 6): [j - PHI_LDS][trip]
   int kk, kused, knew, phase, ns, maxord;
   int nst;
@@ -103,20 +104,16 @@ __device__ inline void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0
   PL_SYNC();
 }
 
+// error weights: IDA evaluates ewt from phi[0] = y_n at the start of every step.  Kept in LDS (S.ewt) or, for the LDS-lean models, in
+// six registers per lane (I.ew[trip]); EWT(n) reads it inside a PL_VEC loop.
 template <class M>
-__device__ inline void set_ewt(CellLDS<M>& S, double rtol, double atol) {
+__device__ inline void set_ewt(CellLDS<M>& S, IdaScalars& I, double rtol, double atol) {
   PL_MODEL(M);
   const int lane = lane_id();
-  if constexpr (M::EWT_LDS) { PL_VEC(n) S.ewt[n] = 1.0 / (rtol * fabs(S.phi[0][n]) + atol); }
+  PL_VEC(n) { const double w = 1.0 / (rtol * fabs(S.phi[0][n]) + atol); if constexpr (M::EWT_LDS) S.ewt[n] = w; else I.ew[k__] = w; }
   PL_SYNC();
 }
-// error weight of entry n: IDA evaluates ewt from phi[0] = y_n at the start of every step; phi[0] does not change until the step is
-// completed, so models that do not keep the vector in LDS recompute the identical value where it is used
-template <class M>
-__device__ __forceinline__ double ewt_of(const CellLDS<M>& S, const IdaScalars& I, int n) {
-  if constexpr (M::EWT_LDS) return S.ewt[n];
-  else return 1.0 / (I.rtol * fabs(S.phi[0][n]) + I.atol);
-}
+#define EWT(n) (M::EWT_LDS ? S.ewt[M::EWT_LDS ? (n) : 0] : I.ew[k__])
 
 template <class M>
 __device__ inline double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
@@ -218,7 +215,7 @@ __device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaS
       PL_TIC();
       const double sc = (I.cjratio != 1.0) ? -2.0 / (1.0 + I.cjratio) : -1.0;
       double s = 0.0;
-      PL_VEC(n) { const double d = S.delta[n] * sc; S.ee[n] += d; const double p = d * ewt_of(S, I, n); s += p * p; }
+      PL_VEC(n) { const double d = S.delta[n] * sc; S.ee[n] += d; const double p = d * EWT(n); s += p * p; }
       const double delnrm = sqrt(wave_sum(s) / NST);
       PL_SYNC();
       ret = 2;
@@ -247,7 +244,7 @@ __device__ inline int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, do
   const int kk = I.kk;
   double s0 = 0, s1 = 0, s2 = 0;
   PL_VEC(n) {
-    const double w = ewt_of(S, I, n), e = S.ee[n];
+    const double w = EWT(n), e = S.ee[n];
     double p = e * w; s0 += p * p;
     if (kk > 1) { const double d1 = PHI_RD(kk, n) + e; p = d1 * w; s1 += p * p;
       if (kk > 2) { const double d2 = d1 + PHI_RD(kk - 1, n); p = d2 * w; s2 += p * p; } }
@@ -291,7 +288,7 @@ __device__ inline void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double er
     else if (I.kk + 1 >= I.ns || kdiff == 1) action = 2;
     if (action == 0) {
       double s = 0.0;
-      PL_VEC(n) { const double p = (S.ee[n] - PHI_RD(I.kk + 1, n)) * ewt_of(S, I, n); s += p * p; }
+      PL_VEC(n) { const double p = (S.ee[n] - PHI_RD(I.kk + 1, n)) * EWT(n); s += p * p; }
       const double enorm = sqrt(wave_sum(s) / NST); err_kp1 = enorm / (I.kk + 2);
       const double terr_k = (I.kk + 1) * err_k, terr_kp1 = (I.kk + 2) * err_kp1;
       if (I.kk == 1) action = (terr_kp1 >= 0.5 * terr_k) ? 2 : 3;
@@ -351,13 +348,13 @@ __device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, Ida
   const double uround = 2.220446049250313e-16;
   I.rtol = o.reltol; I.atol = o.abstol;
   if (I.nst == 0) {
-    set_ewt(S, o.reltol, o.abstol);
+    set_ewt(S, I, o.reltol, o.abstol);
     const double tdist = fabs(tstop - I.tn);
     double hh = I.h0_forced != 0.0 ? I.h0_forced : o.init_step;
     if (hh == 0.0) {
       hh = 0.001 * tdist;
       double sy = 0.0;
-      PL_VEC(n) { const double pq = S.phi[1][n] * ewt_of(S, I, n); sy += pq * pq; }
+      PL_VEC(n) { const double pq = S.phi[1][n] * EWT(n); sy += pq * pq; }
       const double ypnorm = sqrt(wave_sum(sy) / NST);
       if (ypnorm > 0.5 / hh) hh = 0.5 / ypnorm;
     }
@@ -369,7 +366,7 @@ __device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, Ida
     const double troundoff = 100.0 * uround * (fabs(I.tn) + fabs(I.hh));
     if (fabs(I.tn - tstop) <= troundoff) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; return 0; }
     if ((I.tn + I.hh - tstop) * I.hh > 0.0) I.hh = (tstop - I.tn) * (1.0 - 4.0 * uround);
-    set_ewt(S, o.reltol, o.abstol);
+    set_ewt(S, I, o.reltol, o.abstol);
   }
   const double saved_t = I.tn; int ncf = 0, nef = 0; double err_k = 0, err_km1 = 0;
   if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; PL_SYNC(); }
