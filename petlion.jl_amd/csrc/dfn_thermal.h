@@ -657,20 +657,17 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     if (lane < NE) { TP.vB[ln][0] = v0; TP.vB[ln][1] = v1; TP.vB[ln][2] = v2; TP.vB[ln][3] = v3; }
   }
   PL_SYNC();
-  // 5. Woodbury columns Z = Bb^-1 E (E = unit vectors at the T rows of nodes 0, 9, 20, 29) and the capacitance matrix
+  // 5. Woodbury columns Z = Bb^-1 E (E = unit vectors at the T rows of nodes 0, 9, 20, 29), the capacitance matrix, and the border
+  //    x2 = B^-1 (column of I): five right-hand sides in ONE pass of the sweeps (latency-bound: the extra ILP is almost free)
+  double xb[4] = {0.0, 0.0, 0.0, 0.0};
   if (!alg_only) {
-    double rz[4][4];
+    double rz[5][4];
     for (int k = 0; k < 4; k++) { for (int cc = 0; cc < 4; cc++) rz[k][cc] = 0.0; if (nd == wb_row_node(k)) rz[k][3] = 1.0; }
-    {
-      double ra[2][4];
-      for (int h2 = 0; h2 < 2; h2++) {
-        for (int q = 0; q < 2; q++) for (int cc = 0; cc < 4; cc++) ra[q][cc] = rz[h2 * 2 + q][cc];
-        thermal_sweeps<2>(S, alg_only, ra);
-        for (int q = 0; q < 2; q++) for (int cc = 0; cc < 4; cc++) rz[h2 * 2 + q][cc] = ra[q][cc];
-      }
-    }
+    for (int cc = 0; cc < 4; cc++) rz[4][cc] = 0.0;
+    if (act) { rz[4][2] = TP.colI4[i][0]; rz[4][3] = TP.colI4[i][1]; }
+    thermal_sweeps<5>(S, alg_only, rz);
     if (act) for (int k = 0; k < 4; k++) for (int cc = 0; cc < 4; cc++) TP.Z[k][i][cc] = rz[k][cc];
-    // C = I + Vw^T Z  (4x4), inverted redundantly by every lane, stored by lane 0
+    // C = I + Vw^T Z  (4x4), inverted redundantly by every lane
     double C[16], Ci[16];
     for (int k = 0; k < 4; k++) {
       double s[4]; wb_dots(S, rz[k], s);                    // column k of Vw^T Z
@@ -678,19 +675,23 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     }
     inv4(C, Ci);
     if (lane < 16) TP.Cinv[lane] = Ci[lane];
+    for (int cc = 0; cc < 4; cc++) xb[cc] = rz[4][cc];
   } else {
     if (lane < 16) TP.Cinv[lane] = (lane % 5 == 0) ? 1.0 : 0.0;
     if (act) for (int k = 0; k < 4; k++) for (int cc = 0; cc < 4; cc++) TP.Z[k][i][cc] = 0.0;
+    if (mode != PLH_MODE_I) {
+      double ra[1][4] = {{0.0, 0.0, 0.0, 0.0}};
+      if (act) { ra[0][2] = TP.colI4[i][0]; ra[0][3] = TP.colI4[i][1]; }
+      thermal_sweeps<1>(S, alg_only, ra);
+      for (int cc = 0; cc < 4; cc++) xb[cc] = ra[0][cc];
+    }
   }
   PL_SYNC();
-  // 6b. border: x2 = B^-1 (column of I) and the pivot d - v.x2
+  // 6b. border: x2 (Woodbury-corrected) and the pivot d - v.x2
   if (mode != PLH_MODE_I) {
-    double ra[1][4] = {{0.0, 0.0, 0.0, 0.0}};
-    if (act) { ra[0][2] = TP.colI4[i][0]; ra[0][3] = TP.colI4[i][1]; }
-    thermal_sweeps<1>(S, alg_only, ra);
-    if (!alg_only) { double s[4]; wb_dots(S, ra[0], s); wb_apply(S, ra[0], s); }
-    if (act) for (int cc = 0; cc < 4; cc++) TP.x2[i][cc] = ra[0][cc];
-    const double vx = wave_sum(act ? TP.vB[i][1] * ra[0][1] + TP.vB[i][2] * ra[0][2] + TP.vB[i][3] * ra[0][3] + (mode == PL_MODE_DT_TWIN ? 0.0 : TP.vB[i][0] * ra[0][0]) : 0.0);
+    if (!alg_only) { double s[4]; wb_dots(S, xb, s); wb_apply(S, xb, s); }
+    if (act) for (int cc = 0; cc < 4; cc++) TP.x2[i][cc] = xb[cc];
+    const double vx = wave_sum(act ? TP.vB[i][1] * xb[1] + TP.vB[i][2] * xb[2] + TP.vB[i][3] * xb[3] + (mode == PL_MODE_DT_TWIN ? 0.0 : TP.vB[i][0] * xb[0]) : 0.0);
     if (lane == 0) { TP.bord[0] = dI - vx; TP.bord[1] = dI; }
   } else if (lane == 0) { TP.bord[0] = 1.0; TP.bord[1] = 1.0; }
   PL_SYNC();
