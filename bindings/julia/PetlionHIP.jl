@@ -120,6 +120,17 @@ function J_full!(nzval::Vector{Float64}, m::Model, Y, YP, γ, θ; mode = :I)
                 m.h, 1, θ, Y, YP, γ, MODE[mode], nzval, PLH_HOST, C_NULL), "plh_jacobian")
     nzval
 end
+"J_y_alg! (generate_functions.jl:318-325): the block J[N_diff+1:N-1, N_diff+1:N] of the full Jacobian at γ = 0, in the CSC order of that block"
+function J_alg!(nzval::Vector{Float64}, m::Model, Y, YP, θ; mode = :I)
+    cp, ri = jac_pattern(m; mode = mode)
+    full = J_full!(zeros(length(ri)), m, Y, YP, 0.0, θ; mode = mode)
+    k = 0
+    for c in m.N_diff+1:m.N, q in cp[c]+1:cp[c+1]        # cp, ri are 0-based
+        r = ri[q] + 1
+        (r > m.N_diff && r < m.N) && (k += 1; nzval[k] = full[q])
+    end
+    nzval
+end
 function initial_guess!(out::Vector{Float64}, m::Model, SOC, θ)
     check(ccall((:plh_initial_guess, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cvoid}), m.h, 1, θ, SOC, out, PLH_HOST, C_NULL), "plh_initial_guess")
     out

@@ -44,6 +44,21 @@ def check_keys_and_pattern(p, O):
         ocp, ori, _ = O.jacobian(VARIANT, th, np.ones(N), np.zeros(N), 1.0, mode, 0.0)
         assert len(ri) == nnz_expect
         assert np.array_equal(cp, ocp) and np.array_equal(ri, ori)
+    check_alg_block_pattern(p, O)
+
+
+def check_alg_block_pattern(p, O):
+    """seam 1's J_y_alg! (generate_functions.jl:318-325) is the block J[N_diff:N-1, N_diff:N] of the full Jacobian at gamma = 0: its pattern,
+    extracted from plh_jac_pattern, must equal the one the oracle's symbolic pipeline produced for J_y_alg (245 nz for C1 with the CC row)."""
+    meta = O.meta(p.variant)
+    Nd, N = p.N.diff, p.N.tot
+    cp, ri = p.jac_pattern(0)
+    acp, ari = [0], []
+    for c in range(Nd, N):
+        rows = [int(r) - Nd for r in ri[cp[c]:cp[c + 1]] if r >= Nd and r < N - 1]     # generated rows only (the control row is separate)
+        ari += rows; acp.append(len(ari))
+    assert acp == list(meta["alg_colptr"]) and ari == list(meta["alg_rowval"])
+    assert len(ari) == meta["nnz_alg"]
 
 
 def check_evaluators(p, O, n_cells=3):
