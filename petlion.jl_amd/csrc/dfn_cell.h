@@ -76,6 +76,7 @@ struct CellConst {
   double T0, fRT, Kfac, I1C, tplus, JI0, JI29, ce0;
   double thmin_p, thmax_p, thmin_n, thmax_n;
   double R_SEI, rkag, Mrho, i0F, wexp, Uref;   // SEI: R_SEI, 1/k_n_aging, M_n/rho_n, i_0_jside/F, w, Uref_s
+  double rh[3], reps[3], rd_ps, rd_sn, beta_ps, beta_sn, rsg_p, rsg_n, rcm_p, rcm_n;   // reciprocals / interface weights used by every node pass
   double EaKp, EaKn, EaDp, EaDn;               // thermal: activation energies / R (kp, kn, kap_p, kap_n then hold the T_ref values)
   double r2h[3], qps_r, qps_l, qsn_r, qsn_l;   // thermal: gradient-stencil factors 1/(2h), 2/(3hp+hs), 2/(hp+3hs), 2/(3hs+hn), 2/(hs+3hn)
   int iso_ref;   // T0 == TREF exactly (temperature_switch, reference custom_functions.jl:1)
@@ -360,6 +361,10 @@ __device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     c.JI0 = c.I1C * c.h[0] / c.sig_p;                       // d(Phi_s row of first p node)/dI
     c.JI29 = -c.I1C * c.h[2] / c.sig_n;                     // d(Phi_s row of last n node)/dI
     c.ce0 = th[ix[K_c_e0]];
+    for (int q = 0; q < 3; q++) { c.rh[q] = 1.0 / c.h[q]; c.reps[q] = 1.0 / c.eps[q]; }
+    c.rd_ps = 1.0 / (c.h[0] / 2 + c.h[1] / 2); c.rd_sn = 1.0 / (c.h[1] / 2 + c.h[2] / 2);
+    c.beta_ps = (c.h[0] / 2) / (c.h[1] / 2 + c.h[0] / 2); c.beta_sn = (c.h[1] / 2) / (c.h[2] / 2 + c.h[1] / 2);
+    c.rsg_p = 1.0 / c.sig_p; c.rsg_n = 1.0 / c.sig_n; c.rcm_p = 1.0 / c.cmaxp; c.rcm_n = 1.0 / c.cmaxn;
     S.kapv[0] = c.kap_p; S.kapv[1] = c.kap_n;
     S.tb = tb;
     c.R_SEI = c.rkag = c.Mrho = c.i0F = c.wexp = c.Uref = 0.0;
@@ -453,6 +458,9 @@ __device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const doubl
   const double h = sc == 0 ? h0 : (sc == 1 ? h1 : h2);
   const double epsc = sc == 0 ? e0 : (sc == 1 ? e1 : e2);
   const double bfc = sc == 0 ? bf0 : (sc == 1 ? bf1 : bf2);
+  // divisions by per-cell constants are multiplications by reciprocals formed once in cell_setup (an fp64 division costs ~80 cycles of
+  // dependent latency on gfx950; the results differ from the reference's by one rounding, far below the 1e-12 residual parity bar)
+  const double rh = c.rh[sc], reps = c.reps[sc];
   double K, dK; keff(ce, cT0, K, dK);
   K *= bfc; dK *= bfc;
   double D, dD;
@@ -461,17 +469,18 @@ __device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const doubl
   const double ce_n = shift_down1(ce), pe_n = shift_down1(pe), K_n = shift_down1(K), dK_n = shift_down1(dK), D_n = shift_down1(D);
   const double dD_n = (WANT_JAC && M::CHEM != PLH_CHEM_LCO_LIC6) ? shift_down1(dD) : 0.0;
   // edge i : geometry (numerical_tools.jl:106-215)
-  double beta = 0.5, dist = h;
-  if (i == NP - 1) { beta = (h0 / 2) / (h1 / 2 + h0 / 2); dist = h0 / 2 + h1 / 2; }
-  if (i == NP + NS - 1) { beta = (h1 / 2) / (h2 / 2 + h1 / 2); dist = h1 / 2 + h2 / 2; }
+  double beta = 0.5, rdist = rh;
+  if (i == NP - 1) { beta = c.beta_ps; rdist = c.rd_ps; }
+  if (i == NP + NS - 1) { beta = c.beta_sn; rdist = c.rd_sn; }
   const bool edge = i < NE - 1;
-  const double denK = beta * K_n + (1 - beta) * K, Kh = K * K_n / denK;
-  const double denD = beta * D_n + (1 - beta) * D, Dh = D * D_n / denD;
-  const double denC = beta * ce_n + (1 - beta) * ce, cb = ce * ce_n / denC;
-  const double Tb = cT0 * cT0 / (beta * cT0 + (1 - beta) * cT0);
-  const double dc = (ce_n - ce) / dist;
-  const double w = Kh / dist;
-  const double g = Kh * Tb * dc / cb;
+  const double rdenK = 1.0 / (beta * K_n + (1 - beta) * K), Kh = K * K_n * rdenK;
+  const double rdenD = 1.0 / (beta * D_n + (1 - beta) * D), Dh = D * D_n * rdenD;
+  const double rdenC = 1.0 / (beta * ce_n + (1 - beta) * ce), cb = ce * ce_n * rdenC;
+  const double Tb = cT0;                                   // harmonic mean of equal temperatures
+  const double rcb = 1.0 / cb;
+  const double dc = (ce_n - ce) * rdist;
+  const double w = Kh * rdist;
+  const double g = Kh * Tb * dc * rcb;
   double E = edge ? w * (pe - pe_n) + cKfac * g : 0.0;   // Phi_e-row edge flux
   double Nf = edge ? Dh * dc : 0.0;                        // c_e-row edge flux
   const double E_p = shift_up1(E), Nf_p = shift_up1(Nf);
@@ -484,13 +493,14 @@ __device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const doubl
   const double cmax = sc == 0 ? ccmp : ccmn;
   const double kk = sc == 0 ? ckp : ckn;
   const double sg = sc == 0 ? csg_p : csg_n;
+  const double rsg = sc == 0 ? c.rsg_p : c.rsg_n, rcm = sc == 0 ? c.rcm_p : c.rcm_n;
   double U = 0, dU = 0;
   if (M::CHEM == PLH_CHEM_LCO_LIC6) {
-    if (sc == 0) ocv_lco(cs / cmax, cT0, ciso, U, dU);
-    else if (sc == 2) ocv_lic6(cs / cmax, cT0, ciso, U, dU);
+    if (sc == 0) ocv_lco(cs * rcm, cT0, ciso, U, dU);
+    else if (sc == 2) ocv_lic6(cs * rcm, cT0, ciso, U, dU);
   } else {
-    if (sc == 0) ocv_nmc(cs / cmax, U, dU);
-    else if (sc == 2) ocv_lic6_nmc(cs / cmax, U, dU);
+    if (sc == 0) ocv_nmc(cs * rcm, U, dU);
+    else if (sc == 2) ocv_lic6_nmc(cs * rcm, U, dU);
   }
   const double jt = jv + js;                             // j_total (aux...jl:160-178) drives the c_e / Phi_e / Phi_s sources
   const double eta = (M::SEI && sc == 2) ? ps - pe - U - FAR * jv * Rfilm : ps - pe - U;
@@ -503,7 +513,7 @@ __device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const doubl
   if (WANT_RES) {
     if (act) {
       const double src = elec ? (1 - ctplus) * 1.0 * a * jt : 0.0;
-      Fo[O_CE + i] = ((Nf - Nm) / h + src) / epsc - ypce;                 // residuals_c_e!, residuals.jl:6-106
+      Fo[O_CE + i] = ((Nf - Nm) * rh + src) * reps - ypce;                 // residuals_c_e!, residuals.jl:6-106
       Fo[O_PE + i] = (i < NE - 1) ? (E - Em - (elec ? h * FAR * a * jt : 0.0)) : pe;   // residuals_Φ_e!, residuals.jl:554-654
       if (elec) {
         Fo[O_J + jx] = 2.0 * kk * sq * sh - jv;                                        // residuals_j!, residuals.jl:491-517
@@ -512,7 +522,7 @@ __device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const doubl
         const double Idens = yI * cI1C;
         if (i == 0) f += -Idens * h;
         if (i == NE - 1) f += Idens * h;
-        Fo[O_PS + jx] = lap - f / sg;                                                  // residuals_Φ_s!, residuals.jl:656-703
+        Fo[O_PS + jx] = lap - f * rsg;                                                  // residuals_Φ_s!, residuals.jl:656-703
       }
     }
     if constexpr (M::SEI) {
@@ -535,24 +545,24 @@ __device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const doubl
   if (WANT_JAC) {
     if (lane == 0) { S.ctrlJ[0] = yI * cI1C; S.ctrlJ[1] = (Y[O_PS] - Y[O_PS + NJ - 1]) * cI1C; }   // scalar_jacobian! of method_P
     // edge derivatives
-    const double dKh_a = dK * beta * K_n * K_n / (denK * denK), dKh_b = dK_n * (1 - beta) * K * K / (denK * denK);
-    const double dcb_a = beta * ce_n * ce_n / (denC * denC), dcb_b = (1 - beta) * ce * ce / (denC * denC);
-    const double Tq = Tb / dist;
-    const double dg_a = Tq * (dKh_a * (ce_n - ce) / cb - Kh / cb - Kh * (ce_n - ce) * dcb_a / (cb * cb));
-    const double dg_b = Tq * (dKh_b * (ce_n - ce) / cb + Kh / cb - Kh * (ce_n - ce) * dcb_b / (cb * cb));
-    double Ea = edge ? (pe - pe_n) * dKh_a / dist + cKfac * dg_a : 0.0;
-    double Eb = edge ? (pe - pe_n) * dKh_b / dist + cKfac * dg_b : 0.0;
+    const double dKh_a = dK * beta * K_n * K_n * (rdenK * rdenK), dKh_b = dK_n * (1 - beta) * K * K * (rdenK * rdenK);
+    const double dcb_a = beta * ce_n * ce_n * (rdenC * rdenC), dcb_b = (1 - beta) * ce * ce * (rdenC * rdenC);
+    const double Tq = Tb * rdist;
+    const double dg_a = Tq * (dKh_a * (ce_n - ce) * rcb - Kh * rcb - Kh * (ce_n - ce) * dcb_a * (rcb * rcb));
+    const double dg_b = Tq * (dKh_b * (ce_n - ce) * rcb + Kh * rcb - Kh * (ce_n - ce) * dcb_b * (rcb * rcb));
+    double Ea = edge ? (pe - pe_n) * dKh_a * rdist + cKfac * dg_a : 0.0;
+    double Eb = edge ? (pe - pe_n) * dKh_b * rdist + cKfac * dg_b : 0.0;
     double we = edge ? w : 0.0;
     // N = Dh (c_{i+1} - c_i)/dist ; Dh = harmonic mean of D_i, D_{i+1} (dD/dc = 0 for D_eff_linear)
-    const double dDh_a = dD * beta * D_n * D_n / (denD * denD), dDh_b = dD_n * (1 - beta) * D * D / (denD * denD);
-    double Na = edge ? (dDh_a * (ce_n - ce) - Dh) / dist : 0.0, Nb = edge ? (dDh_b * (ce_n - ce) + Dh) / dist : 0.0;
+    const double dDh_a = dD * beta * D_n * D_n * (rdenD * rdenD), dDh_b = dD_n * (1 - beta) * D * D * (rdenD * rdenD);
+    double Na = edge ? (dDh_a * (ce_n - ce) - Dh) * rdist : 0.0, Nb = edge ? (dDh_b * (ce_n - ce) + Dh) * rdist : 0.0;
     const double Ea_p = shift_up1(Ea), Eb_p = shift_up1(Eb), we_p = shift_up1(we), Na_p = shift_up1(Na), Nb_p = shift_up1(Nb);
     if (act) {
-      const double he = h * epsc;
-      S.ceL[i] = i > 0 ? -Na_p / he : 0.0;
-      S.ceD[i] = (Na - (i > 0 ? Nb_p : 0.0)) / he;
-      S.ceU[i] = Nb / he;
-      S.ceJ[i] = elec ? (1 - ctplus) * a / epsc : 0.0;
+      const double rhe = rh * reps;
+      S.ceL[i] = i > 0 ? -Na_p * rhe : 0.0;
+      S.ceD[i] = (Na - (i > 0 ? Nb_p : 0.0)) * rhe;
+      S.ceU[i] = Nb * rhe;
+      S.ceJ[i] = elec ? (1 - ctplus) * a * reps : 0.0;
       if (i < NE - 1) {
         S.peL[i] = i > 0 ? -we_p : 0.0; S.peD[i] = (i > 0 ? we_p : 0.0) + we; S.peU[i] = -we;
         S.pcL[i] = i > 0 ? -Ea_p : 0.0; S.pcD[i] = Ea - (i > 0 ? Eb_p : 0.0); S.pcU[i] = Eb;
@@ -565,10 +575,10 @@ __device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const doubl
         const double pos = arg > 0.0 ? 1.0 : 0.0;
         const double inv_sq = pos > 0 ? 1.0 / sq : 0.0;
         S.gce[jx] = kk * sh * cs * (cmax - cs) * inv_sq;
-        S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * ch * cfRT * (-dU / cmax));
+        S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * ch * cfRT * (-dU * rcm));
         S.gps[jx] = 2.0 * kk * sq * ch * cfRT;
         S.gpe[jx] = -S.gps[jx];
-        S.psJ[jx] = -h * h * a * FAR / sg;
+        S.psJ[jx] = -h * h * a * FAR * rsg;
         if constexpr (M::SEI) {
           if (sc == 2) {
             S.sei.jjJ[ks] = -1.0 - S.gps[jx] * FAR * Rfilm;  // d(j row)/dj: eta_n carries -F j R_film
