@@ -773,12 +773,14 @@ __device__ inline void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
   // 1. particle resolvent rows: (kappa M - cj I)^-1 = V diag(1/(kappa lam - cj)) W
   if (!alg_only) {
     const int r = lane % NR;
+    // the 20 reciprocals 1/(kappa lam_m - cj) are formed by 20 lanes in parallel and passed through S.w9 (free outside the solves)
+    if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * tb->LAM[r] - cj);
+    PL_SYNC();
     for (int el = 0; el < 2; el++) {
-      const double kap = el == 0 ? c.kap_p : c.kap_n;
       double acc[NR];
       for (int k = 0; k < NR; k++) acc[k] = 0.0;
       for (int m = 0; m < NR; m++) {
-        const double f = tb->V[r * NR + m] / (kap * tb->LAM[m] - cj);
+        const double f = tb->V[r * NR + m] * S.w9[el * NR + m];
         for (int k = 0; k < NR; k++) acc[k] += f * tb->W[m * NR + k];
       }
       if (lane < NR) for (int k = 0; k < NR; k++) S.Ainv[el][r * NR + k] = acc[k];
@@ -820,8 +822,9 @@ __device__ inline void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       }
       if (!local3) {
         const double d = -1.0 - schur;
-        S.dj[jx] = d;
-        ph0 = alg_only ? 0.0 : S.gce[jx] / d; ph1 = S.gpe[jx] / d; ph2 = S.gps[jx] / d;
+        const double rd = 1.0 / d;
+        S.dj[jx] = rd;                                     // the reciprocal pivot: the solves multiply
+        ph0 = alg_only ? 0.0 : S.gce[jx] * rd; ph1 = S.gpe[jx] * rd; ph2 = S.gps[jx] * rd;
       }
     }
     S.nphi[i][0] = ph0; S.nphi[i][1] = ph1; S.nphi[i][2] = ph2;
@@ -952,7 +955,7 @@ __device__ inline void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode
           local3 = true;
         }
       }
-      if (!local3) beta = bjp / S.dj[jx];
+      if (!local3) beta = bjp * S.dj[jx];
       if (!alg_only) r0 -= S.ceJ[i] * beta;
       r1 -= S.peJ[i] * beta; r2 -= S.psJ[jx] * beta;
       if (mode == PLH_MODE_I) {             // control row: 1 * x_I = b_I
@@ -999,7 +1002,7 @@ __device__ inline void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode
           local3 = true;
         }
       }
-      if (!local3) b[O_J + jx] = v0 / S.dj[jx];
+      if (!local3) b[O_J + jx] = v0 * S.dj[jx];
     }
   }
   if constexpr (M::SEI) {                   // SOH row: sum_k sohw_k dj_s,k - cj dSOH = b_SOH (decoupled from everything else)

@@ -42,7 +42,7 @@ __device__ __forceinline__ double wrms(const double* v, const double* w) {
   const int lane = lane_id();
   double s = 0.0;
   PL_VEC(n) { const double p = v[n] * w[n]; s += p * p; }
-  return sqrt(wave_sum(s) / NST);
+  return sqrt(wave_sum(s) * (1.0 / NST));
 }
 
 // ---- consistent initialisation (newtons_method!) : Y (LDS, in/out), YP (LDS, out).  returns 0 / PLH_ERR_INIT ----
@@ -149,7 +149,8 @@ __device__ inline double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
     PL_SYNC();
   }
   double alphas = 0.0, alpha0 = 0.0;
-  for (int m = 0; m < kk; m++) { alphas -= 1.0 / (m + 1); alpha0 -= S.ida_alpha[m]; }
+  { const double rinv[MAXORD + 1] = {1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6};     // (compile-time quotients: identical values, no runtime division)
+    for (int m = 0; m < kk; m++) { alphas -= (m == 0 ? rinv[0] : m == 1 ? rinv[1] : m == 2 ? rinv[2] : m == 3 ? rinv[3] : rinv[4]); alpha0 -= S.ida_alpha[m]; } }
   I.cjlast = I.cj; I.cj = -alphas / hh;
   const double ak = S.ida_alpha[kk];
   double ck = fabs(ak + alphas - alpha0); if (ck < ak) ck = ak;
@@ -216,7 +217,7 @@ __device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaS
       const double sc = (I.cjratio != 1.0) ? -2.0 / (1.0 + I.cjratio) : -1.0;
       double s = 0.0;
       PL_VEC(n) { const double d = S.delta[n] * sc; S.ee[n] += d; const double p = d * EWT(n); s += p * p; }
-      const double delnrm = sqrt(wave_sum(s) / NST);
+      const double delnrm = sqrt(wave_sum(s) * (1.0 / NST));
       PL_SYNC();
       ret = 2;
       if (m == 0) { oldnrm = delnrm; if (delnrm <= toldel) ret = 0; }
@@ -249,13 +250,13 @@ __device__ inline int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, do
     if (kk > 1) { const double d1 = PHI_RD(kk, n) + e; p = d1 * w; s1 += p * p;
       if (kk > 2) { const double d2 = d1 + PHI_RD(kk - 1, n); p = d2 * w; s2 += p * p; } }
   }
-  const double enorm_k = sqrt(wave_sum(s0) / NST);
+  const double enorm_k = sqrt(wave_sum(s0) * (1.0 / NST));
   err_k = S.ida_sigma[kk] * enorm_k; const double terr_k = (kk + 1) * err_k;
   I.knew = kk; err_km1 = 0.0;
   if (kk > 1) {
-    const double enorm_km1 = sqrt(wave_sum(s1) / NST); err_km1 = S.ida_sigma[kk - 1] * enorm_km1; const double terr_km1 = kk * err_km1;
+    const double enorm_km1 = sqrt(wave_sum(s1) * (1.0 / NST)); err_km1 = S.ida_sigma[kk - 1] * enorm_km1; const double terr_km1 = kk * err_km1;
     if (kk > 2) {
-      const double enorm_km2 = sqrt(wave_sum(s2) / NST); const double err_km2 = S.ida_sigma[kk - 2] * enorm_km2; const double terr_km2 = (kk - 1) * err_km2;
+      const double enorm_km2 = sqrt(wave_sum(s2) * (1.0 / NST)); const double err_km2 = S.ida_sigma[kk - 2] * enorm_km2; const double terr_km2 = (kk - 1) * err_km2;
       if ((terr_km1 > terr_km2 ? terr_km1 : terr_km2) <= terr_k) I.knew = kk - 1;
     } else if (terr_km1 <= 0.5 * terr_k) I.knew = kk - 1;
   }
@@ -289,7 +290,7 @@ __device__ inline void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double er
     if (action == 0) {
       double s = 0.0;
       PL_VEC(n) { const double p = (S.ee[n] - PHI_RD(I.kk + 1, n)) * EWT(n); s += p * p; }
-      const double enorm = sqrt(wave_sum(s) / NST); err_kp1 = enorm / (I.kk + 2);
+      const double enorm = sqrt(wave_sum(s) * (1.0 / NST)); err_kp1 = enorm / (I.kk + 2);
       const double terr_k = (I.kk + 1) * err_k, terr_kp1 = (I.kk + 2) * err_kp1;
       if (I.kk == 1) action = (terr_kp1 >= 0.5 * terr_k) ? 2 : 3;
       else { const double terr_km1 = I.kk * err_km1;
@@ -355,7 +356,7 @@ __device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, Ida
       hh = 0.001 * tdist;
       double sy = 0.0;
       PL_VEC(n) { const double pq = S.phi[1][n] * EWT(n); sy += pq * pq; }
-      const double ypnorm = sqrt(wave_sum(sy) / NST);
+      const double ypnorm = sqrt(wave_sum(sy) * (1.0 / NST));
       if (ypnorm > 0.5 / hh) hh = 0.5 / ypnorm;
     }
     if ((I.tn + hh - tstop) * hh > 0.0) hh = (tstop - I.tn) * (1.0 - 4.0 * uround);

@@ -526,8 +526,9 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
       const double bj = sc == 0 ? c.bj_p : c.bj_n;
       const double sig = alg_only ? 0.0 : TP.AinvE[jx][NR - 1], tau = alg_only ? 0.0 : TP.AinvQ[jx][NR - 1];
       const double d = -1.0 - S.gcs[jx] * sig * bj;
-      S.dj[jx] = d;
-      p0 = alg_only ? 0.0 : S.gce[jx] / d; p1 = S.gpe[jx] / d; p2 = S.gps[jx] / d; p3 = alg_only ? 0.0 : (TP.gT[jx] - S.gcs[jx] * tau) / d;
+      const double rd = 1.0 / d;
+      S.dj[jx] = rd;
+      p0 = alg_only ? 0.0 : S.gce[jx] * rd; p1 = S.gpe[jx] * rd; p2 = S.gps[jx] * rd; p3 = alg_only ? 0.0 : (TP.gT[jx] - S.gcs[jx] * tau) * rd;
       t0 = alg_only ? 0.0 : S.ceJ[i]; t1 = S.peJ[i]; t2 = S.psJ[jx]; t3 = alg_only ? 0.0 : TP.TJ[jx] - TP.Tcs[jx] * sig * bj;
       if (i == 0) cI2 = c.JI0;
       if (i == NE - 1) cI2 = c.JI29;
@@ -749,7 +750,7 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
       const double bjp = b[O_J + jx] - S.gcs[jx] * w9;
       y[2] = b[O_PS + jx];
       if (!alg_only) y[3] -= TP.Tcs[jx] * w9;
-      beta = bjp / S.dj[jx];
+      beta = bjp * S.dj[jx];
       for (int cc = 0; cc < 4; cc++) y[cc] -= TP.tq[i][cc] * beta;
     }
     if (!alg_only) {

