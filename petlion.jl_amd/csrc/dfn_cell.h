@@ -76,7 +76,7 @@ struct CellConst {
   double T0, fRT, Kfac, I1C, tplus, JI0, JI29, ce0;
   double thmin_p, thmax_p, thmin_n, thmax_n;
   double R_SEI, rkag, Mrho, i0F, wexp, Uref;   // SEI: R_SEI, 1/k_n_aging, M_n/rho_n, i_0_jside/F, w, Uref_s
-  double rh[3], reps[3], rd_ps, rd_sn, beta_ps, beta_sn, rsg_p, rsg_n, rcm_p, rcm_n;   // reciprocals / interface weights used by every node pass
+  double rh[3], reps[3], rd_ps, rd_sn, beta_ps, beta_sn, rsg_p, rsg_n, rcm_p, rcm_n, Dh_ps, Dh_sn;   // reciprocals / interface weights used by every node pass
   double EaKp, EaKn, EaDp, EaDn;               // thermal: activation energies / R (kp, kn, kap_p, kap_n then hold the T_ref values)
   double r2h[3], qps_r, qps_l, qsn_r, qsn_l;   // thermal: gradient-stencil factors 1/(2h), 2/(3hp+hs), 2/(hp+3hs), 2/(3hs+hn), 2/(hs+3hn)
   int iso_ref;   // T0 == TREF exactly (temperature_switch, reference custom_functions.jl:1)
@@ -365,6 +365,7 @@ __device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     c.rd_ps = 1.0 / (c.h[0] / 2 + c.h[1] / 2); c.rd_sn = 1.0 / (c.h[1] / 2 + c.h[2] / 2);
     c.beta_ps = (c.h[0] / 2) / (c.h[1] / 2 + c.h[0] / 2); c.beta_sn = (c.h[1] / 2) / (c.h[2] / 2 + c.h[1] / 2);
     c.rsg_p = 1.0 / c.sig_p; c.rsg_n = 1.0 / c.sig_n; c.rcm_p = 1.0 / c.cmaxp; c.rcm_n = 1.0 / c.cmaxn;
+    c.Dh_ps = hmean(c.beta_ps, c.Dc[0], c.Dc[1]); c.Dh_sn = hmean(c.beta_sn, c.Dc[1], c.Dc[2]);   // D_eff_linear: constant edge means
     S.kapv[0] = c.kap_p; S.kapv[1] = c.kap_n;
     S.tb = tb;
     c.R_SEI = c.rkag = c.Mrho = c.i0F = c.wexp = c.Uref = 0.0;
@@ -474,10 +475,12 @@ __device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const doubl
   if (i == NP + NS - 1) { beta = c.beta_sn; rdist = c.rd_sn; }
   const bool edge = i < NE - 1;
   const double rdenK = 1.0 / (beta * K_n + (1 - beta) * K), Kh = K * K_n * rdenK;
-  const double rdenD = 1.0 / (beta * D_n + (1 - beta) * D), Dh = D * D_n * rdenD;
-  const double rdenC = 1.0 / (beta * ce_n + (1 - beta) * ce), cb = ce * ce_n * rdenC;
+  double rdenD = 0.0, Dh;
+  if (M::CHEM == PLH_CHEM_LCO_LIC6) Dh = (i == NP - 1) ? c.Dh_ps : ((i == NP + NS - 1) ? c.Dh_sn : D);   // constant D: no division
+  else { rdenD = 1.0 / (beta * D_n + (1 - beta) * D); Dh = D * D_n * rdenD; }
+  const double denC = beta * ce_n + (1 - beta) * ce;
+  const double rcb = denC / (ce * ce_n);                   // 1 / (harmonic mean of c_e at the edge)
   const double Tb = cT0;                                   // harmonic mean of equal temperatures
-  const double rcb = 1.0 / cb;
   const double dc = (ce_n - ce) * rdist;
   const double w = Kh * rdist;
   const double g = Kh * Tb * dc * rcb;
@@ -546,6 +549,7 @@ __device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const doubl
     if (lane == 0) { S.ctrlJ[0] = yI * cI1C; S.ctrlJ[1] = (Y[O_PS] - Y[O_PS + NJ - 1]) * cI1C; }   // scalar_jacobian! of method_P
     // edge derivatives
     const double dKh_a = dK * beta * K_n * K_n * (rdenK * rdenK), dKh_b = dK_n * (1 - beta) * K * K * (rdenK * rdenK);
+    const double rdenC = 1.0 / denC;
     const double dcb_a = beta * ce_n * ce_n * (rdenC * rdenC), dcb_b = (1 - beta) * ce * ce * (rdenC * rdenC);
     const double Tq = Tb * rdist;
     const double dg_a = Tq * (dKh_a * (ce_n - ce) * rcb - Kh * rcb - Kh * (ce_n - ce) * dcb_a * (rcb * rcb));

@@ -150,18 +150,20 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
   const double D = c.Dc[sc];                                            // D_eff_linear: no c_e / T dependence (custom_functions.jl:59-69)
   const double ce_n = shift_down1(ce), pe_n = shift_down1(pe), K_n = shift_down1(K), dKc_n = shift_down1(dKc), dKT_n = shift_down1(dKT), T_n = shift_down1(T);
   const double ce_p = shift_up1(ce), pe_p = shift_up1(pe);
-  double beta = 0.5, dist = h;
-  if (i == NP - 1) { beta = (h0 / 2) / (h1 / 2 + h0 / 2); dist = h0 / 2 + h1 / 2; }
-  if (i == NP + NS - 1) { beta = (h1 / 2) / (h2 / 2 + h1 / 2); dist = h1 / 2 + h2 / 2; }
+  // reciprocals of per-cell constants come from cell_setup (see iso_node_pass)
+  const double rh = c.rh[sc], reps = c.reps[sc];
+  double beta = 0.5, rdist = rh;
+  if (i == NP - 1) { beta = c.beta_ps; rdist = c.rd_ps; }
+  if (i == NP + NS - 1) { beta = c.beta_sn; rdist = c.rd_sn; }
   const bool edge = i < NE - 1;
-  const double denK = beta * K_n + (1 - beta) * K, Kh = K * K_n / denK;
+  const double rdenK = 1.0 / (beta * K_n + (1 - beta) * K), Kh = K * K_n * rdenK;
   const double D_n = shift_down1(D);
-  const double denD = beta * D_n + (1 - beta) * D, Dhm = D * D_n / denD;    // differs from D only at the p|s and s|n interfaces
-  const double denC = beta * ce_n + (1 - beta) * ce, cb = ce * ce_n / denC;
-  const double denT = beta * T_n + (1 - beta) * T, Tb = T * T_n / denT;
-  const double dc = (ce_n - ce) / dist;
-  const double w = Kh / dist;
-  const double g = Kh * Tb * dc / cb;
+  const double Dhm = (i == NP - 1) ? c.Dh_ps : ((i == NP + NS - 1) ? c.Dh_sn : D);   // constant edge means of D_eff_linear (cell_setup)
+  const double denC = beta * ce_n + (1 - beta) * ce, rcb = denC / (ce * ce_n);
+  const double rdenT = 1.0 / (beta * T_n + (1 - beta) * T), Tb = T * T_n * rdenT;
+  const double dc = (ce_n - ce) * rdist;
+  const double w = Kh * rdist;
+  const double g = Kh * Tb * dc * rcb;
   const double E = edge ? w * (pe - pe_n) + cKfac * g : 0.0;
   const double Nf = edge ? Dhm * dc : 0.0;
   const double E_p = shift_up1(E), Nf_p = shift_up1(Nf);
@@ -178,8 +180,9 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
   const double kap = (sc == 0 ? c.kap_p : c.kap_n) * exp(-EaD * dinv);
   if (act && elec) { TP.kapP[jx] = kap; if (WANT_JAC) TP.dkapP[jx] = kap * EaD * rT * rT; }
   double U = 0, dU = 0, dUdT = 0, ddUdT = 0;
-  if (sc == 0) ocv_lco_T(cs / cmax, T, U, dU, dUdT, ddUdT);
-  else if (sc == 2) ocv_lic6_T(cs / cmax, T, U, dU, dUdT, ddUdT);
+  const double rcm = sc == 0 ? c.rcm_p : c.rcm_n, rsg = sc == 0 ? c.rsg_p : c.rsg_n;
+  if (sc == 0) ocv_lco_T(cs * rcm, T, U, dU, dUdT, ddUdT);
+  else if (sc == 2) ocv_lic6_T(cs * rcm, T, U, dU, dUdT, ddUdT);
   const double eta = ps - pe - U;
   const double arg = ce * cs * (cmax - cs);
   const double sq = sqrt(arg > 0.0 ? arg : 0.0);
@@ -214,7 +217,7 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
   if (WANT_RES) {
     if (act) {
       const double src = elec ? (1 - ctplus) * 1.0 * a * jv : 0.0;
-      Fo[O_CE + i] = ((Nf - Nm) / h + src) / epsc - ypce;                 // residuals_c_e!, residuals.jl:6-106
+      Fo[O_CE + i] = ((Nf - Nm) * rh + src) * reps - ypce;                 // residuals_c_e!, residuals.jl:6-106
       Fo[O_PE + i] = (i < NE - 1) ? (E - Em - (elec ? h * FAR * a * jv : 0.0)) : pe;   // residuals_Φ_e!, residuals.jl:554-654
       if (elec) {
         Fo[O_J + jx] = 2.0 * kk * sq * sh - jv;                                        // residuals_j!, residuals.jl:491-517
@@ -223,7 +226,7 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
         const double Idens = yI * cI1C;
         if (i == 0) f += -Idens * h;
         if (i == NE - 1) f += Idens * h;
-        Fo[O_PS + jx] = lap - f / sg;                                                  // residuals_Φ_s!, residuals.jl:656-703
+        Fo[O_PS + jx] = lap - f * rsg;                                                  // residuals_Φ_s!, residuals.jl:656-703
       }
       // residuals_T!, residuals.jl:299-489 ; heat sources aux...jl:344-518
       const double qrr = Faj * (T * dUdT + eta);
@@ -252,28 +255,29 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
   if (WANT_JAC) {
     if (lane == 0) { TP.qIJ[0] = 2.0 * TP.qI[0] * yI; TP.qIJ[1] = 2.0 * TP.qI[1] * yI; }   // d(collector row)/dI (Joule heat ~ I^2)
     if (lane == 0) { S.ctrlJ[0] = yI * cI1C; S.ctrlJ[1] = (Y[O_PS] - Y[O_PS + NJ - 1]) * cI1C; }   // scalar_jacobian! of method_P
-    const double dKh_a = beta * K_n * K_n / (denK * denK), dKh_b = (1 - beta) * K * K / (denK * denK);   // dKh/dK_i, dKh/dK_{i+1}
-    const double dcb_a = beta * ce_n * ce_n / (denC * denC), dcb_b = (1 - beta) * ce * ce / (denC * denC);
-    const double dTb_a = beta * T_n * T_n / (denT * denT), dTb_b = (1 - beta) * T * T / (denT * denT);
-    const double Tq = Tb / dist;
+    const double dKh_a = beta * K_n * K_n * (rdenK * rdenK), dKh_b = (1 - beta) * K * K * (rdenK * rdenK);   // dKh/dK_i, dKh/dK_{i+1}
+    const double rdenC = 1.0 / denC;
+    const double dcb_a = beta * ce_n * ce_n * (rdenC * rdenC), dcb_b = (1 - beta) * ce * ce * (rdenC * rdenC);
+    const double dTb_a = beta * T_n * T_n * (rdenT * rdenT), dTb_b = (1 - beta) * T * T * (rdenT * rdenT);
+    const double Tq = Tb * rdist;
     const double dcn = ce_n - ce;
-    const double dg_a = Tq * (dKh_a * dKc * dcn / cb - Kh / cb - Kh * dcn * dcb_a / (cb * cb));
-    const double dg_b = Tq * (dKh_b * dKc_n * dcn / cb + Kh / cb - Kh * dcn * dcb_b / (cb * cb));
-    const double Ea = edge ? (pe - pe_n) * dKh_a * dKc / dist + cKfac * dg_a : 0.0;
-    const double Eb = edge ? (pe - pe_n) * dKh_b * dKc_n / dist + cKfac * dg_b : 0.0;
-    const double gq = dc / cb;                                                         // g = Kh Tb gq
-    const double ETa = edge ? (pe - pe_n) * dKh_a * dKT / dist + cKfac * gq * (dKh_a * dKT * Tb + Kh * dTb_a) : 0.0;
-    const double ETb = edge ? (pe - pe_n) * dKh_b * dKT_n / dist + cKfac * gq * (dKh_b * dKT_n * Tb + Kh * dTb_b) : 0.0;
+    const double dg_a = Tq * (dKh_a * dKc * dcn * rcb - Kh * rcb - Kh * dcn * dcb_a * (rcb * rcb));
+    const double dg_b = Tq * (dKh_b * dKc_n * dcn * rcb + Kh * rcb - Kh * dcn * dcb_b * (rcb * rcb));
+    const double Ea = edge ? (pe - pe_n) * dKh_a * dKc * rdist + cKfac * dg_a : 0.0;
+    const double Eb = edge ? (pe - pe_n) * dKh_b * dKc_n * rdist + cKfac * dg_b : 0.0;
+    const double gq = dc * rcb;                                                         // g = Kh Tb gq
+    const double ETa = edge ? (pe - pe_n) * dKh_a * dKT * rdist + cKfac * gq * (dKh_a * dKT * Tb + Kh * dTb_a) : 0.0;
+    const double ETb = edge ? (pe - pe_n) * dKh_b * dKT_n * rdist + cKfac * gq * (dKh_b * dKT_n * Tb + Kh * dTb_b) : 0.0;
     const double we = edge ? w : 0.0;
-    const double Na = edge ? -Dhm / dist : 0.0, Nb = edge ? Dhm / dist : 0.0;
+    const double Na = edge ? -Dhm * rdist : 0.0, Nb = edge ? Dhm * rdist : 0.0;
     const double Ea_p = shift_up1(Ea), Eb_p = shift_up1(Eb), we_p = shift_up1(we), Na_p = shift_up1(Na), Nb_p = shift_up1(Nb);
     const double ETa_p = shift_up1(ETa), ETb_p = shift_up1(ETb);
     if (act) {
-      const double he = h * epsc;
-      S.ceL[i] = i > 0 ? -Na_p / he : 0.0;
-      S.ceD[i] = (Na - (i > 0 ? Nb_p : 0.0)) / he;
-      S.ceU[i] = Nb / he;
-      S.ceJ[i] = elec ? (1 - ctplus) * a / epsc : 0.0;
+      const double rhe = rh * reps;
+      S.ceL[i] = i > 0 ? -Na_p * rhe : 0.0;
+      S.ceD[i] = (Na - (i > 0 ? Nb_p : 0.0)) * rhe;
+      S.ceU[i] = Nb * rhe;
+      S.ceJ[i] = elec ? (1 - ctplus) * a * reps : 0.0;
       if (i < NE - 1) {
         S.peL[i] = i > 0 ? -we_p : 0.0; S.peD[i] = (i > 0 ? we_p : 0.0) + we; S.peU[i] = -we;
         S.pcL[i] = i > 0 ? -Ea_p : 0.0; S.pcD[i] = Ea - (i > 0 ? Eb_p : 0.0); S.pcU[i] = Eb;
@@ -287,13 +291,13 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
         const double pos = arg > 0.0 ? 1.0 : 0.0;
         const double inv_sq = pos > 0 ? 1.0 / sq : 0.0;
         S.gce[jx] = kk * sh * cs * (cmax - cs) * inv_sq;
-        S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * chh * fRT * (-dU / cmax));
+        S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * chh * fRT * (-dU * rcm));
         S.gps[jx] = 2.0 * kk * sq * chh * fRT;
         S.gpe[jx] = -S.gps[jx];
         TP.gT[jx] = 2.0 * kk * sq * (EaK * rT * rT * sh + chh * (-xx * rT - fRT * dUdT));
-        S.psJ[jx] = -h * h * a * FAR / sg;
+        S.psJ[jx] = -h * h * a * FAR * rsg;
         TP.TJ[jx] = rc * FAR * a * (T * dUdT + eta);
-        TP.Tcs[jx] = rc * Faj * (T * ddUdT - dU) / cmax;
+        TP.Tcs[jx] = rc * Faj * (T * ddUdT - dU) * rcm;
       }
       // T row: couplings to (c_e, Phi_e, Phi_s, T) of nodes i-1, i, i+1 (+ the second neighbour at the four one-sided stencils)
       const double qPe = 2.0 * K * dPe + cKfac * K * T * (dce / ce);               // dQ/d(dPe)
