@@ -165,12 +165,15 @@ template <class M>
 __device__ inline void form_iterate(CellLDS<M>& S, const IdaScalars& I) {
   PL_MODEL(M);
   const int lane = lane_id();
-  PL_VEC(n) {
-    double a = S.phi[0][n], b = 0.0;
-    for (int j = 1; j <= I.kk; j++) { const double p = PHI_RD(j, n); a += p; b += S.ida_gamma[j] * p; }
-    const double e = S.ee[n];
-    S.yy[n] = a + e; S.yp[n] = b + I.cj * e;
+  // history vector outermost, the lane's trips innermost: the LDS loads of one order are issued back to back (a runtime-bounded inner
+  // loop over the orders would expose one LDS round trip per order and trip); same summation order as before
+  double a[NTRIP], b[NTRIP];
+  PL_VEC(n) { a[k__] = S.phi[0][n]; b[k__] = 0.0; }
+  _Pragma("unroll") for (int j = 1; j <= MAXORD; j++) if (j <= I.kk) {
+    const double g = S.ida_gamma[j];
+    PL_VEC(n) { const double p = PHI_RD(j, n); a[k__] += p; b[k__] += g * p; }
   }
+  PL_VEC(n) { const double e = S.ee[n]; S.yy[n] = a[k__] + e; S.yp[n] = b[k__] + I.cj * e; }
   PL_SYNC();
 }
 
@@ -303,11 +306,12 @@ __device__ inline void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double er
     I.hh = hnew;
   }
   const int ku = I.kused;
-  PL_VEC(n) {
-    const double e = S.ee[n];
-    if (ku < I.maxord) PHI_WR(ku + 1, n, e);
-    double acc = PHI_RD(ku, n) + e; PHI_WR(ku, n, acc);
-    for (int j = ku - 1; j >= 0; j--) { acc += PHI_RD(j, n); PHI_WR(j, n, acc); }
+  {   // phi update (running sums from the top order down), orders outermost / trips innermost as in form_iterate
+    double acc[NTRIP];
+    PL_VEC(n) { const double e = S.ee[n]; if (ku < I.maxord) PHI_WR(ku + 1, n, e); acc[k__] = PHI_RD(ku, n) + e; PHI_WR(ku, n, acc[k__]); }
+    _Pragma("unroll") for (int j = MAXORD - 1; j >= 0; j--) if (j < ku) {
+      PL_VEC(n) { acc[k__] += PHI_RD(j, n); PHI_WR(j, n, acc[k__]); }
+    }
   }
   PL_SYNC();
 }
