@@ -499,25 +499,28 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     //    sides: the coupling to T of the neighbouring cell node (Al: last row, through aU; Cu: first row, through aL) and the column of I
     if (lane >= 62) {
       const int q = lane - 62, base = q == 0 ? 0 : NA + NE;
-      double cp[NA], fc[NA], fi[NA];
+      // (all LDS operands are loaded up front and all results stored at the end: loads interleaved with stores inside the serial
+      //  recurrence would cost one LDS round trip per chain node)
+      double aLv[NA], aDv[NA], aUv[NA], cp[NA], cm[NA], fc[NA], fi[NA], xcv[NA], xiv[NA];
+      for (int k = 0; k < NA; k++) { aLv[k] = TP.aL[base + k]; aDv[k] = TP.aD[base + k]; aUv[k] = TP.aU[base + k]; }
+      const double qij = TP.qIJ[q];
       for (int k = 0; k < NA; k++) {
-        const int ic = base + k;
-        const double rcpl = (q == 0 && k == NA - 1) ? TP.aU[ic] : ((q == 1 && k == 0) ? TP.aL[ic] : 0.0);
-        if (k == 0) { TP.cM[q][0] = 0.0; cp[0] = 1.0 / (TP.aD[ic] - cj); fc[0] = rcpl; fi[0] = TP.qIJ[q]; }
+        const double rcpl = (q == 0 && k == NA - 1) ? aUv[k] : ((q == 1 && k == 0) ? aLv[k] : 0.0);
+        if (k == 0) { cm[0] = 0.0; cp[0] = 1.0 / (aDv[0] - cj); fc[0] = rcpl; fi[0] = qij; }
         else {
-          const double mlt = TP.aL[ic] * cp[k - 1];
-          TP.cM[q][k] = mlt;
-          cp[k] = 1.0 / ((TP.aD[ic] - cj) - mlt * TP.aU[ic - 1]);
-          fc[k] = rcpl - mlt * fc[k - 1]; fi[k] = TP.qIJ[q] - mlt * fi[k - 1];
+          const double mlt = aLv[k] * cp[k - 1];
+          cm[k] = mlt;
+          cp[k] = 1.0 / ((aDv[k] - cj) - mlt * aUv[k - 1]);
+          fc[k] = rcpl - mlt * fc[k - 1]; fi[k] = qij - mlt * fi[k - 1];
         }
-        TP.cP[q][k] = cp[k];
       }
       double xc = 0.0, xi = 0.0;
       for (int k = NA - 1; k >= 0; k--) {
-        const double up = k < NA - 1 ? TP.aU[base + k] : 0.0;
+        const double up = k < NA - 1 ? aUv[k] : 0.0;
         xc = (fc[k] - up * xc) * cp[k]; xi = (fi[k] - up * xi) * cp[k];
-        TP.zc[q][k] = xc; TP.zI[q][k] = xi;
+        xcv[k] = xc; xiv[k] = xi;
       }
+      for (int k = 0; k < NA; k++) { TP.cM[q][k] = cm[k]; TP.cP[q][k] = cp[k]; TP.zc[q][k] = xcv[k]; TP.zI[q][k] = xiv[k]; }
     }
   }
   PL_SYNC();
@@ -723,10 +726,12 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
     }
     if (lane >= 62) {
       const int q = lane - 62, base = q == 0 ? 0 : NA + NE;
-      double f[NA];
-      for (int k = 0; k < NA; k++) f[k] = b[O_T + base + k] - (k > 0 ? TP.cM[q][k] * f[k - 1] : 0.0);
+      double f[NA], bv[NA], cm[NA], au[NA], cpv[NA], xv[NA];
+      for (int k = 0; k < NA; k++) { bv[k] = b[O_T + base + k]; cm[k] = TP.cM[q][k]; au[k] = TP.aU[base + k]; cpv[k] = TP.cP[q][k]; }   // loads first
+      for (int k = 0; k < NA; k++) f[k] = bv[k] - (k > 0 ? cm[k] * f[k - 1] : 0.0);
       double x = 0.0;
-      for (int k = NA - 1; k >= 0; k--) { x = (f[k] - (k < NA - 1 ? TP.aU[base + k] * x : 0.0)) * TP.cP[q][k]; TP.zb[q][k] = x; }
+      for (int k = NA - 1; k >= 0; k--) { x = (f[k] - (k < NA - 1 ? au[k] * x : 0.0)) * cpv[k]; xv[k] = x; }
+      for (int k = 0; k < NA; k++) TP.zb[q][k] = xv[k];                                                                                  // stores last
     }
     PL_SYNC();
     for (int pass = 0; pass < 4; pass++) {
