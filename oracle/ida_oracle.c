@@ -275,7 +275,7 @@ static int splu_setup(splu* f, const int* cp, const int* ri, const double* ax) {
 /* public structs                                                                                               */
 /* ------------------------------------------------------------------------------------------------------------ */
 enum { ORC_MODE_I = 0, ORC_MODE_V = 1, ORC_MODE_DT = 2, ORC_MODE_P = 3, ORC_MODE_ETAP = 4, ORC_NMODES = 5 };
-enum { ORC_VAL_CONST = 0, ORC_VAL_HOLD = 1, ORC_VAL_REST = 2 };
+enum { ORC_VAL_CONST = 0, ORC_VAL_HOLD = 1, ORC_VAL_REST = 2, ORC_VAL_TABLE = 3 };
 
 typedef struct {   /* reference boundary_stop_conditions, src/structures.jl:237-250 ; NaN disables a bound */
   double V_max, V_min, SOC_max, SOC_min, T_max, c_s_n_max, I_max, I_min, eta_plating_min, c_e_min, dfilm_max;
@@ -287,6 +287,9 @@ typedef struct {   /* one run of a protocol = one simulate()/simulate!() call */
   double value;    /* C-rate / V / K/s */
   double tf;       /* run length in local time (reference default 1e6) */
   orc_bounds bounds;
+  /* ORC_VAL_TABLE: the input is a function of the run-local time (reference run_function, structures.jl), given as a piecewise-linear
+     table; a repeated knot time is a jump (right-continuous); beyond the last knot the last value holds */
+  int n_tab; const double* tab_t; const double* tab_v;
 } orc_run;
 
 typedef struct {   /* reference options_simulation, src/structures.jl:266-285 */
@@ -296,6 +299,7 @@ typedef struct {   /* reference options_simulation, src/structures.jl:266-285 */
   int max_order;      /* 5 */
   int jac_every_step; /* 0 = IDA policy (default); 1 = refresh each step (ablation) */
   double init_step;   /* 0 = automatic; > 0 = IDASetInitStep */
+  int n_tdiscon; double tdiscon[16];   /* opts.tdiscon: known discontinuities of a function input (structures.jl:279) */
 } orc_opts;
 
 typedef struct {
@@ -327,6 +331,7 @@ typedef struct {
   int *acp, *ari; double* aax; int annz; int* abase_map; int an_ctrl; int actrl_pos[64]; int actrl_col[64];
   double *tmp_nz, *w;
   double I1C;
+  const orc_run* frun;   /* != NULL: the control value is frun's table evaluated at the current time */
   splu lu, alu;
   orc_counters* cnt;
 } evalb;
@@ -359,6 +364,16 @@ static void build_pattern(int N, int rows_base, const int* bcp, const int* bri, 
 }
 
 static int find_key(const orc_model* m, const char* k);
+/* value of a tabulated input at run-local time t (scalar_residual.jl:169-170: method(Y,p) - run.func(t,Y,YP,p)) */
+static double tab_eval(const orc_run* r, double t) {
+  const int n = r->n_tab; const double* tt = r->tab_t; const double* vv = r->tab_v;
+  if (n <= 0) return 0.0;
+  if (t < tt[0]) return vv[0];
+  int k = 0; for (int q = 1; q < n; q++) if (tt[q] <= t) k = q;      /* last knot with t_k <= t */
+  if (k == n - 1) return vv[n - 1];
+  const double dt = tt[k + 1] - tt[k];
+  return dt > 0.0 ? vv[k] + (vv[k + 1] - vv[k]) * ((t - tt[k]) / dt) : vv[k + 1];
+}
 /* calc_I1C, reference auxiliary_states_and_coefficients.jl:632-647 */
 static double calc_I1C_c(const orc_model* m, const double* th) {
   const char* nm[10] = {"ϵ_fp", "ϵ_p", "ϵ_fn", "ϵ_n", "l_p", "l_n", "c_max_p", "c_max_n", "θ_min_p", "θ_max_p"};
@@ -506,8 +521,10 @@ static void ida_alloc(ida_t* I, int N) {
 static void ida_free(ida_t* I) { for (int j = 0; j < MXORDP1; j++) free(I->phi[j]); free(I->ewt); free(I->yy); free(I->yp); free(I->ee); free(I->delta); free(I->ypred); free(I->yppred); free(I->tmp); }
 
 /* IDAReInit(mem, 0.0, Y0, YP0) + IDASStolerances (reference src/model_evaluation.jl:247-251) */
-static void ida_reinit(ida_t* I, evalb* e, const orc_opts* o, const double* y0, const double* yp0) {
-  I->e = e; I->o = o; I->tn = 0.0; I->nst = 0; I->kk = 0; I->kused = 0; I->hused = 0.0; I->hh = 0.0;
+static void ida_reinit_at(ida_t* I, evalb* e, const orc_opts* o, const double* y0, const double* yp0, double t_start);
+static void ida_reinit(ida_t* I, evalb* e, const orc_opts* o, const double* y0, const double* yp0) { ida_reinit_at(I, e, o, y0, yp0, 0.0); }
+static void ida_reinit_at(ida_t* I, evalb* e, const orc_opts* o, const double* y0, const double* yp0, double t_start) {
+  I->e = e; I->o = o; I->tn = t_start; I->nst = 0; I->kk = 0; I->kused = 0; I->hused = 0.0; I->hh = 0.0;
   I->maxord = o->max_order > 0 ? o->max_order : 5; I->epsNewt = 0.33; I->toldel = 0.0001 * I->epsNewt; I->uround = 2.220446049250313e-16;
   I->cjratio = 1.0; I->ss = 20.0; I->tstopset = 0; I->phase = 0; I->ns = 0; I->h0_forced = 0.0;
   memcpy(I->phi[0], y0, I->N * sizeof(double)); memcpy(I->phi[1], yp0, I->N * sizeof(double));
@@ -539,6 +556,7 @@ static double ida_set_coeffs(ida_t* I) {
 /* nonlinear solve: IDANls + SUNNonlinSol_Newton + idaNlsConvTest + IDALs scaling.  returns 0 ok, >0 recoverable, <0 fatal */
 static int ida_nls(ida_t* I) {
   evalb* e = I->e; int N = I->N; orc_counters* cnt = e->cnt;
+  if (e->frun) e->value = tab_eval(e->frun, I->tn);     /* every residual of this step is evaluated at t = tn */
   int callLSetup = 0;
   if (I->nst == 0) { I->cjold = I->cj; I->ss = 20.0; callLSetup = 1; }
   else {
@@ -823,6 +841,14 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
     } else t0 = nextafter(t_global, INFINITY);       /* initial_time, model_evaluation.jl:112 */
     /* initial_current! (input_methods.jl:11-74) */
     double value = run->value;
+    const int is_tab = run->value_kind == ORC_VAL_TABLE;
+    if (is_tab) {                                /* run_function: initial_current! (input_methods.jl:28-34, 65-76, 104-107, 143-153) */
+      value = tab_eval(run, 0.0);
+      if (mode == ORC_MODE_I) Y[M.o_I] = value;
+      else if (mode == ORC_MODE_P) Y[M.o_I] = value / (calc_V(&M, Y) * calc_I1C_c(&M, theta));
+      else if (mode == ORC_MODE_V || mode == ORC_MODE_ETAP) { if (have_prev) Y[M.o_I] = prev_I; else { double OCV = calc_V(&M, Y); Y[M.o_I] = value > OCV ? 1.0 : -1.0; } }
+      else { rc = -103; break; }
+    } else
     if (mode == ORC_MODE_I) {
       if (run->value_kind == ORC_VAL_HOLD) value = have_prev ? prev_I : 0.0;
       else if (run->value_kind == ORC_VAL_REST) value = 0.0;
@@ -842,16 +868,20 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       if (have_prev) Y[M.o_I] = prev_I; else Y[M.o_I] = 1.0;      /* input_methods.jl:171-176 */
     }
     if (!ev_ok[mode]) { if (evalb_init(&ev[mode], &M, theta, mode, value, cnt) != 0) { rc = -102; break; } ev_ok[mode] = 1; }
-    evalb* e = &ev[mode]; e->value = value; e->th = theta; e->cnt = cnt;
+    evalb* e = &ev[mode]; e->value = value; e->th = theta; e->cnt = cnt; e->frun = is_tab ? run : NULL;
     if (M.thermal) M.dT_weights(e->w, theta);
     int ierr = newtons_method(e, Y, YP, opts, c_e0);
     orc_runinfo* ri = &info[r]; memset(ri, 0, sizeof(*ri)); ri->flag = -1;
     if (ierr != 0) { ri->flag = ierr; ri->t_end = t_global; rc = 1; break; }
     ida_reinit(Ip, e, opts, Y, YP);
     /* tstops (postfix_integrator!, model_evaluation.jl:288-310): {1.0 if continuation} U {tf} */
-    double tstops[2]; int nts = 0, its = 0;
-    if (!new_run && run->tf > 1.0) tstops[nts++] = 1.0;
+    double tstops[20]; int nts = 0, its = 0;
+    for (int q = 0; q < opts->n_tdiscon && q < 16; q++) tstops[nts++] = opts->tdiscon[q] - opts->reltol / 2;     /* model_evaluation.jl:295-297 */
+    if (!new_run) tstops[nts++] = 1.0;
     tstops[nts++] = run->tf;
+    for (int a = 1; a < nts; a++) { double v = tstops[a]; int b = a - 1; while (b >= 0 && tstops[b] > v) { tstops[b + 1] = tstops[b]; b--; } tstops[b + 1] = v; }   /* sort! */
+    { int first = 0; while (first < nts && tstops[first] <= 0.0) first++; if (first) { for (int a = first; a < nts; a++) tstops[a - first] = tstops[a]; nts -= first; } }
+    { int w_ = 0; for (int a = 0; a < nts; a++) if (tstops[a] <= run->tf) tstops[w_++] = tstops[a]; nts = w_; }   /* stops beyond tf are never reached */
     prev_vals pv = {1.0, -1, -1, -1, -1, -1, -1, -1, -1};
     int flag = -1;
     /* set_vars! at t=0 of a new solution: a continuation run does not add a point (t0 = nextfloat(t_end)) ...
@@ -871,7 +901,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
           ida_reinit(Ip, e, opts, Y, YP); Ip->h0_forced = opts->reltol; iter++; t = tprev; continue; }
         flag = sf; break;
       }
-      if (tret >= tstops[its] && its + 1 < nts) its++;
+      while (tret >= tstops[its] && its + 1 < nts) its++;
       iter++; t = tret;
       /* calc_SOC trapezoid (scalar_residual.jl:103-111) */
       double SOC_new = SOC + 0.5 * ((t + t0) - t_prev_saved) * (Y[M.o_I] + Yprev[M.o_I]) / 3600.0;
@@ -879,9 +909,18 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       SAVE(t + t0, Y, SOC);
       check_stop(&M, e, run, opts, t, run->tf, Y, YP, SOC, &pv, &flag, c_max_n);
       /* check_solve (checks.jl:226-249) */
-      if (t == tprev) { flag = ORC_ERR_STALL; break; }
+      if (!is_tab && t == tprev) { flag = ORC_ERR_STALL; break; }              /* (run_function has no stall test, checks.jl:251-269) */
       if (iter == opts->maxiters) { flag = ORC_ERR_MAXITERS; break; }
       if (flag == -1) { memcpy(Yprev, Y, N * sizeof(double)); memcpy(YPprev, YP, N * sizeof(double)); t_prev_saved = t + t0; }
+      if (flag == -1 && is_tab && t - tprev < 1e-3 * opts->reltol) {          /* check_reinitialization!, checks.jl:341-364 */
+        const double t_new = t + opts->reltol, v_old = e->value, v_new = tab_eval(run, t_new);
+        const double big = fmax(fabs(v_old), fabs(v_new));
+        if (!(fabs(v_old - v_new) <= fmax(opts->abstol, opts->reltol * big))) {
+          e->value = v_new;
+          if (newtons_method(e, Y, YP, opts, c_e0) != 0) { flag = ORC_ERR_INIT; break; }
+          ida_reinit_at(Ip, e, opts, Y, YP, t_new);
+        }
+      }
     }
     /* --- exit_simulation! / interp_final_points! (model_evaluation.jl:335-382) --- */
     double t_end = t + t0;

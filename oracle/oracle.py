@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETAP = 0, 1, 2, 3, 4
-VAL_CONST, VAL_HOLD, VAL_REST = 0, 1, 2
+VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE = 0, 1, 2, 3
 NAN = math.nan
 
 BOUND_FIELDS = ["V_max", "V_min", "SOC_max", "SOC_min", "T_max", "c_s_n_max", "I_max", "I_min", "eta_plating_min",
@@ -26,13 +26,14 @@ class Bounds(C.Structure):
 
 
 class Run(C.Structure):
-    _fields_ = [("mode", C.c_int), ("value_kind", C.c_int), ("value", C.c_double), ("tf", C.c_double), ("bounds", Bounds)]
+    _fields_ = [("mode", C.c_int), ("value_kind", C.c_int), ("value", C.c_double), ("tf", C.c_double), ("bounds", Bounds),
+                ("n_tab", C.c_int), ("tab_t", C.POINTER(C.c_double)), ("tab_v", C.POINTER(C.c_double))]
 
 
 class Opts(C.Structure):
     _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("abstol_init", C.c_double), ("reltol_init", C.c_double),
                 ("maxiters", C.c_int), ("check_bounds", C.c_int), ("interp_final", C.c_int), ("max_order", C.c_int),
-                ("jac_every_step", C.c_int), ("init_step", C.c_double)]
+                ("jac_every_step", C.c_int), ("init_step", C.c_double), ("n_tdiscon", C.c_int), ("tdiscon", C.c_double * 16)]
 
 
 class RunInfo(C.Structure):
@@ -78,10 +79,15 @@ def default_bounds(cathode="LCO", **over):
 
 def default_opts(**over):
     d = dict(abstol=1e-6, reltol=1e-3, maxiters=10000, check_bounds=1, interp_final=1, max_order=5, jac_every_step=0, init_step=0.0)
+    tdiscon = list(over.pop("tdiscon", []))
     d.update(over)
     d.setdefault("abstol_init", d["abstol"])
     d.setdefault("reltol_init", d["reltol"])
-    return Opts(**d)
+    o = Opts(**d)
+    o.n_tdiscon = len(tdiscon)
+    for k, v in enumerate(tdiscon):
+        o.tdiscon[k] = float(v)
+    return o
 
 
 def _dp(a):
@@ -105,12 +111,17 @@ def simulate(variant, theta, SOC0, runs, opts=None, max_out=20000, Y_init=None):
     N = m["N"]
     opts = opts or default_opts()
     arr = (Run * len(runs))()
+    keep = []
     for k, r in enumerate(runs):
         arr[k].mode = r.get("mode", MODE_I)
         arr[k].value_kind = r.get("value_kind", VAL_CONST)
         arr[k].value = r.get("value", 0.0)
         arr[k].tf = r.get("tf", 1e6)
         arr[k].bounds = r.get("bounds") or default_bounds()
+        if r.get("table") is not None:        # (t, v) arrays: piecewise-linear input in run-local time
+            tt = np.ascontiguousarray(r["table"][0], dtype=np.float64); vv = np.ascontiguousarray(r["table"][1], dtype=np.float64)
+            keep.append((tt, vv))
+            arr[k].value_kind = VAL_TABLE; arr[k].n_tab = len(tt); arr[k].tab_t = _dp(tt); arr[k].tab_v = _dp(vv)
     theta = np.ascontiguousarray(theta, dtype=np.float64)
     out = {k: np.zeros(max_out) for k in ("t", "V", "I", "SOC", "T")}
     n_out = C.c_int(0)

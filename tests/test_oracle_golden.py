@@ -174,3 +174,19 @@ def test_nmc_sei_variant(O):
     film = ro["Y"][230:240]
     assert 0 < 1 - SOH < 1e-5 and (film > 0).all() and film.max() < 1e-9     # SOH after the first pulse ~ 1 - 1.3e-6
     assert abs(ro["runs"][1]["SOC"] - 0.05) < 1e-6
+
+
+def test_function_inputs_notebook(O):
+    """reference examples/variable_input_functions.ipynb: time-dependent current (a step with and without tdiscon, two ramps) given here as
+    piecewise-linear tables (run_function: scalar_residual.jl:169-170, tstops of tdiscon model_evaluation.jl:295-297, checks.jl:251-269,341-364)"""
+    th = O.theta_vector("lco_iso")
+    I1C = 29.23                                       # printed to 2 decimals in the notebooks; the exact value is pinned in test_I1C
+    for key in ("func_step_no_tdiscon", "func_step_tdiscon", "func_ramp_100", "func_ramp_10"):
+        k = G["runs"][key]
+        ro = O.simulate("lco_iso", th, k["SOC0"], [dict(mode=O.MODE_I, table=k["table"], tf=k["tf"])], opts=O.default_opts(tdiscon=k["tdiscon"]))
+        r = ro["runs"][0]
+        assert r["flag"] == k["flag"] and abs(r["t_end"] - k["t_end"]) < 1e-9
+        assert abs(r["I"] - k["I_end"]) < 1e-12 and abs(r["V"] - k["V_end"]) < k["tol"]["V_abs"], (key, r["V"])
+        assert abs(r["SOC"] - k["SOC_end"]) < 1e-4
+        P = r["I"] * G["I1C_LCO"]["value"] * r["V"]     # calc_P = I * I1C * V (scalar_residual.jl:87)
+        assert abs(P - k["P_end"]) <= k["tol"]["P_rel"] * k["P_end"], (key, P)
