@@ -16,7 +16,7 @@ const lib = get(ENV, "PETLION_HIP_LIB", joinpath(@__DIR__, "..", "..", "petlion.
 
 const PLH_HOST = Cint(0)
 const MODE = Dict(:I => Cint(0), :V => Cint(1), :dT => Cint(2), :P => Cint(3), :η_p => Cint(4))
-const VAL_CONST, VAL_HOLD, VAL_REST = Cint(0), Cint(1), Cint(2)
+const VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE = Cint(0), Cint(1), Cint(2), Cint(3)
 
 struct ModelDesc
     chemistry::Cint; N_p::Cint; N_s::Cint; N_n::Cint; N_a::Cint; N_z::Cint; N_r_p::Cint; N_r_n::Cint
@@ -28,10 +28,12 @@ struct Bounds      # boundary_stop_conditions, src/structures.jl:237-250
 end
 struct Run
     mode::Cint; value_kind::Cint; value::Cdouble; tf::Cdouble; bounds::Bounds
+    n_tab::Cint; tab_t::Ptr{Cdouble}; tab_v::Ptr{Cdouble}     # VAL_TABLE: piecewise-linear input in run-local time (host arrays)
 end
 struct Opts
     abstol::Cdouble; reltol::Cdouble; abstol_init::Cdouble; reltol_init::Cdouble
     maxiters::Cint; check_bounds::Cint; interp_final::Cint; max_order::Cint; jac_every_step::Cint; init_step::Cdouble
+    n_tdiscon::Cint; tdiscon::NTuple{16,Cdouble}
 end
 struct RunInfo
     flag::Cint; iterations::Cint; t_end::Cdouble; V::Cdouble; I::Cdouble; SOC::Cdouble; T_avg::Cdouble
@@ -73,9 +75,14 @@ bounds_of(b; kw...) = Bounds((get(kw, f, getfield(b, f)) for f in (:V_max, :V_mi
 function make_run(p, step::NamedTuple)
     name = first(k for k in keys(step) if haskey(MODE, k))
     x = step[name]
-    kind, val = x === :hold ? (VAL_HOLD, 0.0) : x === :rest ? (VAL_REST, 0.0) : (VAL_CONST, Float64(x))
     kw = Dict(k => Float64(v) for (k, v) in pairs(step) if k ∉ (name, :tf))
-    Run(MODE[name], kind, val, Float64(get(step, :tf, 1e6)), bounds_of(p.bounds; kw...))
+    b = bounds_of(p.bounds; kw...)
+    tf = Float64(get(step, :tf, 1e6))
+    if x isa Tuple{Vector{Float64},Vector{Float64}}      # (t, values): a tabulated I(t) / V(t) / P(t); the caller keeps the two vectors alive (GC.@preserve)
+        return Run(MODE[name], VAL_TABLE, x[2][1], tf, b, length(x[1]), pointer(x[1]), pointer(x[2]))
+    end
+    kind, val = x === :hold ? (VAL_HOLD, 0.0) : x === :rest ? (VAL_REST, 0.0) : (VAL_CONST, Float64(x))
+    Run(MODE[name], kind, val, tf, b, 0, C_NULL, C_NULL)
 end
 
 """
@@ -89,7 +96,9 @@ function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.o
     n = size(Θ, 1)
     runs = [make_run(p, s) for s in protocol]
     o = p.opts
-    opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0))
+    td = Float64.(o.tdiscon); length(td) <= 16 || error("at most 16 tdiscon entries")
+    opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0,
+                    length(td), ntuple(k -> k <= length(td) ? td[k] : 0.0, 16)))
     Θt = permutedims(Θ)                                   # column-major n_theta × n_cells == row-major cells
     soc = SOC isa Number ? fill(Float64(SOC), n) : Vector{Float64}(SOC)
     t = zeros(max_pts, n); V = similar(t); I = similar(t); S = similar(t)

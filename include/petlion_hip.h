@@ -48,6 +48,7 @@ extern "C" {
 #define PLH_VAL_CONST 0
 #define PLH_VAL_HOLD 1  /* :hold  -- the value reached at the end of the previous run */
 #define PLH_VAL_REST 2  /* :rest  -- I = 0, all bound checks skipped (src/checks.jl:12,388) */
+#define PLH_VAL_TABLE 3   /* time-dependent input from plh_run.tab_t / tab_v */
 
 /* per-cell status beyond the reference's exit flags */
 #define PLH_FLAG_RUNNING (-1)
@@ -80,6 +81,10 @@ typedef struct {
   double value;
   double tf;       /* run length in run-local time; reference default 1e6 (model_evaluation.jl:13) */
   plh_bounds bounds;
+  /* PLH_VAL_TABLE: the input is a function of the run-local time (reference run_function: I = t -> ..., scalar_residual.jl:169-170) given as a
+     piecewise-linear table; a repeated knot time is a jump (right-continuous), the last value holds beyond the last knot.  The arrays are HOST
+     memory like the protocol itself (plh_integrate stages them).  List jump times in plh_opts.tdiscon as with the reference's `tdiscon`. */
+  int n_tab; const double* tab_t; const double* tab_v;
 } plh_run;
 
 /* reference options_simulation (src/structures.jl:266-285), the numerical subset */
@@ -90,6 +95,7 @@ typedef struct {
   int max_order;                                     /* BDF order cap, 5 */
   int jac_every_step;                                /* 0: IDA's Jacobian-reuse policy */
   double init_step;                                  /* 0: IDA's automatic h0 = 0.5/||y'||_wrms; >0: IDASetInitStep (src/checks.jl:231) */
+  int n_tdiscon; double tdiscon[16];                 /* opts.tdiscon (src/structures.jl:279): tstops at tdiscon - reltol/2 (model_evaluation.jl:295-297) */
 } plh_opts;
 
 /* per-cell, per-run summary == run_info + the printed summary (src/structures.jl:40-44, 678-746) */

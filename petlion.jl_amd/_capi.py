@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libpetlion_hip.so")
 
 PLH_HOST, PLH_DEVICE = 0, 1
 MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETA_P = 0, 1, 2, 3, 4
-VAL_CONST, VAL_HOLD, VAL_REST = 0, 1, 2
+VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE = 0, 1, 2, 3
 CHEM_LCO, CHEM_NMC = 0, 1
 FLAG_RUNNING, ERR_INIT, ERR_STALL, ERR_MAXITERS, ERR_OUTPUT_FULL = -1, -11, -12, -13, -14
 
@@ -34,13 +34,14 @@ class Bounds(C.Structure):
 
 
 class Run(C.Structure):
-    _fields_ = [("mode", C.c_int), ("value_kind", C.c_int), ("value", C.c_double), ("tf", C.c_double), ("bounds", Bounds)]
+    _fields_ = [("mode", C.c_int), ("value_kind", C.c_int), ("value", C.c_double), ("tf", C.c_double), ("bounds", Bounds),
+                ("n_tab", C.c_int), ("tab_t", C.POINTER(C.c_double)), ("tab_v", C.POINTER(C.c_double))]
 
 
 class Opts(C.Structure):
     _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("abstol_init", C.c_double), ("reltol_init", C.c_double),
                 ("maxiters", C.c_int), ("check_bounds", C.c_int), ("interp_final", C.c_int), ("max_order", C.c_int),
-                ("jac_every_step", C.c_int), ("init_step", C.c_double)]
+                ("jac_every_step", C.c_int), ("init_step", C.c_double), ("n_tdiscon", C.c_int), ("tdiscon", C.c_double * 16)]
 
 
 class RunInfo(C.Structure):

@@ -112,7 +112,18 @@ def _make_run(p, name, inp, tf, bounds):
         else:
             raise ValueError("Unsupported input symbol.")
     elif callable(inp):
-        raise NotImplementedError("function inputs are outside this round's scope (SURVEY.md 8f item 1)")
+        raise NotImplementedError("Julia-style closures cannot cross the C ABI: pass the input as a piecewise-linear table (t, values) in run-local "
+                                  "time and list its jumps in opts.tdiscon (reference run_function / tdiscon)")
+    elif isinstance(inp, (tuple, list)) and len(inp) == 2 and np.ndim(inp[0]) == 1:
+        if name == "dT":
+            raise ValueError("time-dependent dT inputs are not defined by the reference")
+        tt = np.ascontiguousarray(inp[0], dtype=np.float64); vv = np.ascontiguousarray(inp[1], dtype=np.float64)
+        if tt.shape != vv.shape or tt.size < 1 or (np.diff(tt) < 0).any():
+            raise ValueError("table input: (t, v) arrays of equal length with non-decreasing times")
+        r.value_kind, r.value = cap.VAL_TABLE, float(vv[0])
+        r.n_tab = tt.size
+        r.tab_t = tt.ctypes.data_as(C.POINTER(C.c_double)); r.tab_v = vv.ctypes.data_as(C.POINTER(C.c_double))
+        r._keep = (tt, vv)                              # keep the arrays alive as long as the run descriptor
     else:
         r.value_kind, r.value = cap.VAL_CONST, float(inp)
     r.tf = float(tf)
@@ -122,9 +133,16 @@ def _make_run(p, name, inp, tf, bounds):
 
 
 def _opts_struct(o):
-    return cap.Opts(o.abstol, o.reltol, o.abstol if o.abstol_init is None else o.abstol_init,
-                    o.reltol if o.reltol_init is None else o.reltol_init, int(o.maxiters), int(bool(o.check_bounds)),
-                    int(bool(o.interp_final)), int(o.max_order), int(bool(o.jac_every_step)), float(o.init_step))
+    s = cap.Opts(o.abstol, o.reltol, o.abstol if o.abstol_init is None else o.abstol_init,
+                 o.reltol if o.reltol_init is None else o.reltol_init, int(o.maxiters), int(bool(o.check_bounds)),
+                 int(bool(o.interp_final)), int(o.max_order), int(bool(o.jac_every_step)), float(o.init_step))
+    td = list(getattr(o, "tdiscon", []) or [])
+    if len(td) > 16:
+        raise ValueError("at most 16 tdiscon entries")
+    s.n_tdiscon = len(td)
+    for k, v in enumerate(td):
+        s.tdiscon[k] = float(v)
+    return s
 
 
 class RunResult:

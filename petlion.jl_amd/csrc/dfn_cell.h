@@ -140,12 +140,10 @@ template <class M> struct CellLDS {
   double ctrlJ[2], bord;           // P-mode control row at the last Jacobian pass (I*I1C, V*I1C); border pivot d - v.x2
   double w9[NJ];
   double sig[2];
-  double kapv[2];
   SeiPool<M::SEI> sei;
   ThermalPool<M::THERMAL> th;
   // wave-uniform BDF coefficient arrays (dynamically indexed by the order -> LDS, not registers/scratch)
   double ida_psi[MAXORD + 1], ida_alpha[MAXORD + 1], ida_beta[MAXORD + 1], ida_sigma[MAXORD + 1], ida_gamma[MAXORD + 1];
-  double ida_out[4];
 #ifdef PL_PHASE_TIMERS
   long long cyc[8];    // per-phase cycle sums (profiling build only)
 #endif
@@ -366,7 +364,6 @@ __device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     c.beta_ps = (c.h[0] / 2) / (c.h[1] / 2 + c.h[0] / 2); c.beta_sn = (c.h[1] / 2) / (c.h[2] / 2 + c.h[1] / 2);
     c.rsg_p = 1.0 / c.sig_p; c.rsg_n = 1.0 / c.sig_n; c.rcm_p = 1.0 / c.cmaxp; c.rcm_n = 1.0 / c.cmaxn;
     c.Dh_ps = hmean(c.beta_ps, c.Dc[0], c.Dc[1]); c.Dh_sn = hmean(c.beta_sn, c.Dc[1], c.Dc[2]);   // D_eff_linear: constant edge means
-    S.kapv[0] = c.kap_p; S.kapv[1] = c.kap_n;
     S.tb = tb;
     c.R_SEI = c.rkag = c.Mrho = c.i0F = c.wexp = c.Uref = 0.0;
     c.EaKp = c.EaKn = c.EaDp = c.EaDn = 0.0;

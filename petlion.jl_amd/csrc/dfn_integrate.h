@@ -46,9 +46,15 @@ __device__ __forceinline__ double wrms(const double* v, const double* w) {
 }
 
 // ---- consistent initialisation (newtons_method!) : Y (LDS, in/out), YP (LDS, out).  returns 0 / PLH_ERR_INIT ----
+// Returns the number of Newton iterations (>= 1) or PLH_ERR_INIT.  cell_simulate has exactly ONE call site (the re-initialisation of a
+// function input loops back to it): a second inlined copy costs 4-5 % of the step loop in instruction-cache misses, and a real call
+// spills the ~100 live registers of the step loop.
 template <class M>
-__device__ inline int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
-                                           int mode, double value, double reltol_init, Counters& cnt) {
+__device__ inline int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
+                                                      int mode, double value, double reltol_init) {
+  LaneRegs R;                                                        // (the algebraic solves do not touch the particle registers)
+  for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
+  int iters = 0;
   PL_MODEL(M);
   const int lane = lane_id();
   PL_VEC(n) YP[n] = 0.0;
@@ -61,7 +67,7 @@ __device__ inline int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tab
     PL_SYNC();
     cell_factor(S, R, tb, 0.0, mode, true);
     cell_solve(S, R, res, mode, true);
-    cnt_add(cnt, C_RES); cnt_add(cnt, C_JAC); cnt_add(cnt, C_FACT); cnt_add(cnt, C_SOLVE); cnt_add(cnt, C_INIT);
+    iters++;
     double s = 0.0;
     for (int n = NDIFF + lane; n < NST; n += WAVE) { const double d = res[n]; Y[n] -= d; s += d * d; }
     const double nrm = sqrt(wave_sum(s));
@@ -72,7 +78,6 @@ __device__ inline int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tab
   if (!ok) return PLH_ERR_INIT;
   // YP_diff = rhs_diff(Y)   (R_diff with YP = 0)
   cell_residual(S, R, Y, YP, res, mode == PL_MODE_DT_TWIN ? PLH_MODE_DT : mode, value);
-  cnt_add(cnt, C_RES);
   for (int n = lane; n < NDIFF; n += WAVE) YP[n] = res[n];
   PL_SYNC();
   // finite-difference estimate of the algebraic derivatives (model_evaluation.jl:462-477)
@@ -85,18 +90,26 @@ __device__ inline int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tab
   cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
   PL_SYNC();
   cell_solve(S, R, res, mode, true);
-  cnt_add(cnt, C_RES); cnt_add(cnt, C_SOLVE);
   for (int n = NDIFF + lane; n < NST; n += WAVE) YP[n] = -res[n] / dt;
   PL_SYNC();
+  return iters;
+}
+template <class M>
+__device__ __forceinline__ int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
+                                                    int mode, double value, double reltol_init, Counters& cnt) {
+  (void)R;
+  const int it = cell_init_consistent_impl(S, tb, Y, YP, res, Ytmp, mode, value, reltol_init);
+  if (it < 0) { cnt_add(cnt, C_INIT, 100); return it; }
+  cnt_add(cnt, C_RES, it + 2); cnt_add(cnt, C_JAC, it); cnt_add(cnt, C_FACT, it); cnt_add(cnt, C_SOLVE, it + 1); cnt_add(cnt, C_INIT, it);
   return 0;
 }
 
 // ---- IDA pieces ----
 template <class M>
-__device__ inline void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0, const double* yp0, int maxord) {
+__device__ inline void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0, const double* yp0, int maxord, double t_start = 0.0) {
   PL_MODEL(M);
   const int lane = lane_id();
-  I.tn = 0.0; I.nst = 0; I.kk = 0; I.kused = 0; I.hused = 0.0; I.hh = 0.0; I.maxord = maxord;
+  I.tn = t_start; I.nst = 0; I.kk = 0; I.kused = 0; I.hused = 0.0; I.hh = 0.0; I.maxord = maxord;
   I.cjratio = 1.0; I.ss = 20.0; I.phase = 0; I.ns = 0; I.h0_forced = 0.0; I.cj = 0.0; I.cjlast = 0.0; I.cjold = 0.0; I.rr = 0.0; I.knew = 0;
   if (lane <= MAXORD) { S.ida_psi[lane] = 0; S.ida_alpha[lane] = 0; S.ida_beta[lane] = 0; S.ida_sigma[lane] = 0; S.ida_gamma[lane] = 0; }
   PL_VEC(n) { S.phi[0][n] = y0[n]; S.phi[1][n] = yp0[n]; }
@@ -344,10 +357,30 @@ __device__ inline void ida_get_solution(CellLDS<M>& S, const IdaScalars& I, doub
   PL_SYNC();
 }
 
+// value of a tabulated input at run-local time t (reference run_function: method(Y,p) - run.func(t,Y,YP,p), scalar_residual.jl:169-170);
+// wave-uniform: every lane walks the (small) table in HBM through scalar loads
+__device__ inline double tab_eval(const plh_run& r, double t) {
+  const int n = r.n_tab; const double* tt = r.tab_t; const double* vv = r.tab_v;
+  if (n <= 0) return 0.0;
+  if (t < tt[0]) return vv[0];
+  int k = 0; for (int q = 1; q < n; q++) if (tt[q] <= t) k = q;      // last knot with t_k <= t (a repeated knot time is a jump, right-continuous)
+  if (k == n - 1) return vv[n - 1];
+  const double dt = tt[k + 1] - tt[k];
+  return dt > 0.0 ? vv[k] + (vv[k + 1] - vv[k]) * ((t - tt[k]) / dt) : vv[k + 1];
+}
+// next tstop after run-local time t: the sorted set {tdiscon - reltol/2} U {1.0 if continuation} U {tf} of postfix_integrator!
+// (model_evaluation.jl:288-310) walked without storing it
+__device__ inline double next_tstop(const plh_opts& o, double t, bool continuation, double tf) {
+  double best = tf;
+  if (continuation && 1.0 > t && 1.0 < best) best = 1.0;
+  for (int q = 0; q < o.n_tdiscon && q < 16; q++) { const double s = o.tdiscon[q] - o.reltol / 2; if (s > t && s > 0.0 && s < best) best = s; }
+  return best;
+}
+
 // one IDASolve(ONE_STEP_TSTOP) call: advances, returns y(tret), y'(tret) in S.yy / S.yp.  0 ok, <0 failure
-template <class M>
-__device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, double tstop, double& tret, int mode, double value,
-                               const plh_opts& o, Counters& cnt) {
+template <bool TAB, class M>
+__device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, double tstop, double& tret, int mode, double& value,
+                               const plh_opts& o, Counters& cnt, const plh_run* frun = nullptr) {
   PL_MODEL(M);
   const int lane = lane_id();
   const double uround = 2.220446049250313e-16;
@@ -377,6 +410,7 @@ __device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, Ida
   if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; PL_SYNC(); }
   for (;;) {
     double ck; { PL_TIC(); ck = ida_set_coeffs(S, I); PL_TOC(S, PH_STEPCTL); }
+    if constexpr (TAB) { if (frun) value = tab_eval(*frun, I.tn); }                           // every residual of this step attempt is evaluated at t = tn
     const int nflag = ida_nls(S, R, tb, I, mode, value, o.jac_every_step, cnt);
     int errfail = 0;
     if (nflag == 0) { PL_TIC(); errfail = ida_test_error(S, I, ck, err_k, err_km1); PL_TOC(S, PH_STEPCTL); }
@@ -490,7 +524,9 @@ struct CellOut {
 
 // the whole protocol for one cell.  Yprev/YPprev: per-cell scratch in HBM holding the previous accepted point (needed only for
 // the back-interpolation at the end of a run; written with coalesced fire-and-forget stores every step).
-template <class M>
+// TAB = the protocol contains time-dependent (tabulated) inputs / tdiscon: a separate instantiation, so that constant-input protocols (the
+// benchmark path) carry none of that code (its mere presence costs ~5 % of the step loop in registers and instruction cache)
+template <bool TAB, class M>
 __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
                                      const CellOut& out, int* n_pts_out, plh_run_info* info, Counters& cnt, double* Yfin, double* YPfin,
                                      double* Yprev, double* YPprev) {
@@ -530,6 +566,14 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     else t0 = nextafter(t_global, 1e300);                               // initial_time, model_evaluation.jl:112
     // initial_current! (input_methods.jl:11-74)
     double value = run.value, Iguess;
+    const bool is_tab = TAB && run.value_kind == PLH_VAL_TABLE;
+    if (is_tab) {                                                       // run_function: initial_current!, input_methods.jl:28-34, 65-76, 104-107, 143-153
+      value = tab_eval(run, 0.0);
+      if (mode == PLH_MODE_I) Iguess = value;
+      else if (mode == PLH_MODE_P) Iguess = value / (cellV<M>(S.yy) * S.cc.I1C);
+      else if (have_prev) Iguess = prev_I;
+      else { const double OCV = cellV<M>(S.yy); Iguess = value > OCV ? 1.0 : -1.0; }
+    } else
     if (mode == PLH_MODE_I) {
       if (run.value_kind == PLH_VAL_HOLD) value = have_prev ? prev_I : 0.0;
       else if (run.value_kind == PLH_VAL_REST) value = 0.0;
@@ -554,24 +598,32 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     if (lane == 0) S.yy[O_I] = Iguess;
     PL_SYNC();
     int flag = PLH_FLAG_RUNNING;
-    int ierr; { PL_TIC(); ierr = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, o.reltol_init, cnt); PL_TOC(S, PH_INIT); }
     plh_run_info ri; ri.flag = PLH_FLAG_RUNNING; ri.iterations = 0; ri.t_end = t_global; ri.V = 0; ri.I = 0; ri.SOC = SOC; ri.T_avg = T0;
-    if (ierr != 0) { ri.flag = ierr; if (lane == 0) info[r] = ri; for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; info[q] = z; } break; }
-    ida_reinit(S, I, S.yy, S.yp, o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD);
-    // tstops = {1.0 if continuation} U {tf}   (postfix_integrator!, model_evaluation.jl:288-310)
-    const bool two_stops = !new_run && run.tf > 1.0;
-    int its = 0; const int nts = two_stops ? 2 : 1;
+    // tstops = {tdiscon - reltol/2} U {1.0 if continuation} U {tf}   (postfix_integrator!, model_evaluation.jl:288-310)
+    const bool continuation = !new_run;
     PrevVals pv; pv.frac = 1.0; pv.V = -1; pv.SOC = -1; pv.I = -1; pv.c_s_n = -1; pv.c_e_min = -1; pv.eta_pl = -1; pv.dfilm = -1; pv.T = -1;
-    save_pt(nout, t0, S.yy, SOC); nout++;
-    check_stop(S, run, o, 0.0, run.tf, S.yy, S.yp, SOC, pv, flag);
-    PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
-    PL_SYNC();
     double tprev = 0.0, t = 0.0, t_prev_saved = t0; int iter = 1; bool stalled_once = false;
-    double I_prev_pt = S.yy[O_I];
+    double I_prev_pt = 0.0, t_restart = 0.0;
+    bool first_init = true, again = false, init_failed = false;
+    do {                                                                // (re)initialise -> integrate ; loops only for check_reinitialization!
+    again = false;
+    int ierr; { PL_TIC(); ierr = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, o.reltol_init, cnt); PL_TOC(S, PH_INIT); }
+    if (ierr != 0) { if (first_init) init_failed = true; else flag = ierr; ri.flag = ierr; break; }
+    ida_reinit(S, I, S.yy, S.yp, first_init ? (o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD) : I.maxord, t_restart);
+    if (first_init) {
+      first_init = false;
+      save_pt(nout, t0, S.yy, SOC); nout++;
+      check_stop(S, run, o, 0.0, run.tf, S.yy, S.yp, SOC, pv, flag);
+      PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
+      PL_SYNC();
+      I_prev_pt = S.yy[O_I];
+    }
     while (flag == PLH_FLAG_RUNNING) {
       double tret = t; tprev = t;
-      const double tstop_now = (two_stops && its == 0) ? 1.0 : run.tf;
-      const int sf = ida_step(S, R, tb, I, tstop_now, tret, mode, value, o, cnt);
+      double tstop_now;
+      if constexpr (TAB) tstop_now = next_tstop(o, t, continuation, run.tf);
+      else tstop_now = (continuation && run.tf > 1.0 && t < 1.0) ? 1.0 : run.tf;
+      const int sf = ida_step<TAB>(S, R, tb, I, tstop_now, tret, mode, value, o, cnt, is_tab ? &run : nullptr);
       if (sf != 0) {
         if (I.nst == 0 && !stalled_once) {                              // check_solve, checks.jl:227-237
           stalled_once = true;
@@ -581,22 +633,30 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
         }
         flag = sf; break;
       }
-      if (tret >= tstop_now && its + 1 < nts) its++;
       iter++; t = tret;
       PL_TIC();
       const double SOC_new = SOC + 0.5 * ((t + t0) - t_prev_saved) * (S.yy[O_I] + I_prev_pt) / 3600.0;   // calc_SOC, scalar_residual.jl:103-111
       SOC = SOC_new;
       save_pt(nout, t + t0, S.yy, SOC); nout++;
       check_stop(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
-      if (t == tprev) { flag = PLH_ERR_STALL; break; }
+      if (!is_tab && t == tprev) { flag = PLH_ERR_STALL; break; }      // (run_function has no stall test, checks.jl:251-269)
       if (iter == o.maxiters) { flag = PLH_ERR_MAXITERS; break; }
       if (nout >= out.max_pts && out.max_pts > 0 && flag == PLH_FLAG_RUNNING) { flag = PLH_ERR_OUTPUT_FULL; break; }
       if (flag == PLH_FLAG_RUNNING) {
         PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }      // fire-and-forget: read back only when a bound fires
         t_prev_saved = t + t0; I_prev_pt = S.yy[O_I];
+        if constexpr (TAB) if (is_tab && t - tprev < 1e-3 * o.reltol) {                    // check_reinitialization!, checks.jl:341-364
+          const double t_new = t + o.reltol, v_new = tab_eval(run, t_new);
+          const double big = fabs(value) > fabs(v_new) ? fabs(value) : fabs(v_new);
+          const double tolv = o.abstol > o.reltol * big ? o.abstol : o.reltol * big;
+          if (!(fabs(value - v_new) <= tolv)) { value = v_new; t_restart = t_new; again = true; }
+        }
       }
       PL_TOC(S, PH_OUTPUT);
+      if (again) break;                                                 // back to the consistent initialisation at t_restart
     }
+    } while (TAB && again && flag == PLH_FLAG_RUNNING);
+    if (init_failed) { if (lane == 0) info[r] = ri; for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; info[q] = z; } break; }
     double t_end = t + t0;
     if (flag > 0 && o.interp_final && t > 1.0) {                        // interp_final_points!, model_evaluation.jl:369-382
       const double fr = pv.frac;

@@ -120,7 +120,7 @@ struct IntegrateArgs {
   plh_outputs out; double* scratch;   // scratch: [n_cells][2][NST]
 };
 
-template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_integrate(IntegrateArgs a) {
+template <class M, bool TAB> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_integrate(IntegrateArgs a) {
   __shared__ CellLDS<M> S;
   constexpr int NST = M::NST;
   LaneRegs R;
@@ -138,7 +138,7 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   co.max_pts = a.out.max_pts;
   co.t = a.out.t ? a.out.t + off : nullptr; co.V = a.out.V ? a.out.V + off : nullptr; co.I = a.out.I ? a.out.I + off : nullptr;
   co.SOC = a.out.SOC ? a.out.SOC + off : nullptr; co.T = a.out.T_avg ? a.out.T_avg + off : nullptr;
-  cell_simulate(S, R, a.tb, a.SOC0[cell], a.Y_init ? a.Y_init + (size_t)cell * NST : nullptr, a.t_init ? a.t_init[cell] : 0.0, a.n_runs, a.runs, a.opts, co, a.out.n_pts ? a.out.n_pts + cell : nullptr,
+  cell_simulate<TAB>(S, R, a.tb, a.SOC0[cell], a.Y_init ? a.Y_init + (size_t)cell * NST : nullptr, a.t_init ? a.t_init[cell] : 0.0, a.n_runs, a.runs, a.opts, co, a.out.n_pts ? a.out.n_pts + cell : nullptr,
                 a.out.run_info + (size_t)cell * a.n_runs, cnt,
                 a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
                 a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST);
@@ -541,7 +541,12 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   if (n <= 0 || !theta || !SOC0 || n_runs <= 0 || !runs || !opts || !out || !out->run_info) return fail(PLH_E_ARG, "bad argument");
   for (int r = 0; r < n_runs; r++) {
     CHECK_MODE(runs[r].mode);
-    if (runs[r].value_kind < 0 || runs[r].value_kind > 2) return fail(PLH_E_ARG, "bad value_kind");
+    if (runs[r].value_kind < 0 || runs[r].value_kind > PLH_VAL_TABLE) return fail(PLH_E_ARG, "bad value_kind");
+    if (runs[r].value_kind == PLH_VAL_TABLE) {
+      if (runs[r].n_tab < 1 || !runs[r].tab_t || !runs[r].tab_v) return fail(PLH_E_ARG, "PLH_VAL_TABLE needs n_tab >= 1 and both table arrays");
+      if (runs[r].mode == PLH_MODE_DT) return fail(PLH_E_UNSUPPORTED, "time-dependent dT inputs are not defined by the reference");
+      for (int k = 1; k < runs[r].n_tab; k++) if (!(runs[r].tab_t[k] >= runs[r].tab_t[k - 1])) return fail(PLH_E_ARG, "table times must be non-decreasing");
+    }
     if (!(runs[r].tf > 0)) return fail(PLH_E_ARG, "run length tf must be positive");
   }
   if (out->max_pts < 0) return fail(PLH_E_ARG, "max_pts");
@@ -558,7 +563,17 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   a.Y_init = s.in(Y_init, (size_t)n * m->N); a.t_init = s.in(t_init, n);
   // the protocol is always host memory
   if (m->runs_cap < n_runs) { if (m->d_runs) hipFree(m->d_runs); HIPCHK(hipMalloc((void**)&m->d_runs, n_runs * sizeof(plh_run))); m->runs_cap = n_runs; }
-  HIPCHK(hipMemcpyAsync(m->d_runs, runs, n_runs * sizeof(plh_run), hipMemcpyHostToDevice, s.st));
+  std::vector<plh_run> hruns(runs, runs + n_runs);                    // tables are host arrays: stage them and patch the device copies
+  for (int r = 0; r < n_runs; r++) {
+    if (hruns[r].value_kind == PLH_VAL_TABLE) {
+      Stage hs(PLH_HOST, stream);
+      const double* dt_ = hs.in(runs[r].tab_t, runs[r].n_tab); const double* dv_ = hs.in(runs[r].tab_v, runs[r].n_tab);
+      if (!dt_ || !dv_) return fail(PLH_E_HIP, "hipMalloc failed (input table)");
+      hruns[r].tab_t = dt_; hruns[r].tab_v = dv_;
+      s.tmp.insert(s.tmp.end(), hs.tmp.begin(), hs.tmp.end()); hs.tmp.clear();     // freed with the call's other staging buffers
+    } else { hruns[r].n_tab = 0; hruns[r].tab_t = nullptr; hruns[r].tab_v = nullptr; }
+  }
+  HIPCHK(hipMemcpy(m->d_runs, hruns.data(), n_runs * sizeof(plh_run), hipMemcpyHostToDevice));
   a.runs = m->d_runs;
   const size_t np = (size_t)n * out->max_pts;
   a.out = *out;
@@ -567,7 +582,10 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   a.out.Y_final = s.buf(out->Y_final, (size_t)n * m->N, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * m->N, false);
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
   hipEventRecord(m->ev0, s.st);
-  PL_DISPATCH(m, PL_LAUNCH(k_integrate<M>, n, WAVE, s.st, a));
+  bool tabular = opts->n_tdiscon > 0;
+  for (int r = 0; r < n_runs; r++) tabular = tabular || runs[r].value_kind == PLH_VAL_TABLE;
+  if (tabular) PL_DISPATCH(m, PL_LAUNCH((k_integrate<M, true>), n, WAVE, s.st, a));
+  else PL_DISPATCH(m, PL_LAUNCH((k_integrate<M, false>), n, WAVE, s.st, a));
   hipEventRecord(m->ev1, s.st);
   m->timed = true;
   FINISH(s);

@@ -102,7 +102,7 @@ class Opts:
         self.verbose = False
         self.interp_final = True
         self.tstops = []
-        self.tdiscon = []
+        self.tdiscon = []           # known discontinuities of a time-dependent input (run-local times), reference opts.tdiscon
         self.interp_bc = "interpolate"
         # build-specific knobs (not in the reference)
         self.max_order = 5

@@ -136,7 +136,10 @@ def runs_to_oracle(O, p, pkg, protocol):
     out = []
     for r in runs:
         b = O.Bounds(**{f: getattr(r.bounds, f) for f in O.BOUND_FIELDS})
-        out.append(dict(mode=r.mode, value_kind=r.value_kind, value=r.value, tf=r.tf, bounds=b))
+        d = dict(mode=r.mode, value_kind=r.value_kind, value=r.value, tf=r.tf, bounds=b)
+        if r.value_kind == 3:       # PLH_VAL_TABLE
+            d["table"] = (np.array(r._keep[0]), np.array(r._keep[1]))
+        out.append(d)
     return out
 
 

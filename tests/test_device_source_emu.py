@@ -2,6 +2,7 @@
 (tests/wave_emu): the same C ABI, the same kernels, 64 emulated lanes.  The GPU versions of these checks are in
 test_gpu_parity.py; this file is what keeps the device code testable in a container without a GPU."""
 import numpy as np
+import pytest
 
 import parity
 
@@ -235,3 +236,29 @@ def test_dfilm_stop_condition(emu_model_sei, O, pkg):
     ro = O.simulate(p.variant, th, 0.3, parity.runs_to_oracle(O, p, pkg, proto))
     assert int(ens.run_info[0, -1]["flag"]) == ro["runs"][-1]["flag"] == 10          # "Above max. film growth rate", checks.jl:203-224
     assert abs(ens.run_info[0, -1]["t_end"] - ro["runs"][-1]["t_end"]) < 1e-6 * ro["runs"][-1]["t_end"]
+
+
+def check_function_inputs(p, O, pkg):
+    """time-dependent inputs (reference run_function: `simulate(p, tf, I = t -> ...)`) as piecewise-linear tables, `tdiscon` tstops and
+    check_reinitialization! (model_evaluation.jl:295-297, checks.jl:251-269, 341-364); the first four cases are the notebook's
+    (examples/variable_input_functions.ipynb), whose printed results pin the oracle in tests/test_oracle_golden.py."""
+    th = p.theta_vector()
+    tt = np.linspace(0, 10, 201)
+    cases = [("step_td", [{"I": ([0, 100, 100, 200], [1, 1, 0.5, 0.5]), "tf": 200.0}], 0.0, [100.0], True),
+             ("step", [{"I": ([0, 100, 100, 200], [1, 1, 0.5, 0.5]), "tf": 200.0}], 0.0, [], False),      # the jump is crossed by step-size collapse
+             ("ramp", [{"I": ([0, 100], [0, 1.0]), "tf": 100.0}], 0.0, [], True),
+             ("ramp10", [{"I": ([0, 100], [0, 10.0]), "tf": 100.0}], 0.0, [], False),   # same steps; one Newton stop test sits on its threshold (2 extra iterations)
+             ("P_sin", [{"P": (tt, 29.23 * np.sin(tt)), "tf": 10.0}], 0.5, [], False),      # starts from zero power: the first steps are set by round-off
+             ("V_cos", [{"V": (tt, 3.9 + 0.05 * np.cos(tt)), "tf": 10.0}], 0.5, [], True),
+             ("cc_then_drive", [{"I": -1.0, "tf": 300.0}, {"I": ([0, 50, 50, 120, 120, 200], [-1, -2, 0.5, 0.5, -1.5, -1.5]), "tf": 200.0}], 1.0, [50.0, 120.0], True)]
+    for name, proto, soc, td, same in cases:
+        o = pkg.Opts(); o.tdiscon = td
+        ens = pkg.simulate_ensemble(p, th[None, :], proto, SOC=soc, opts=o)
+        ro = O.simulate(p.variant, th, soc, parity.runs_to_oracle(O, p, pkg, proto), opts=O.default_opts(tdiscon=td))
+        parity.compare_trajectory(ens, 0, ro, rtol_state=5e-6, same_decisions=same)
+    with pytest.raises(NotImplementedError):
+        pkg.make_protocol(p, [{"I": lambda t: 1.0}])
+
+
+def test_function_inputs(emu_model, O, pkg):
+    check_function_inputs(emu_model, O, pkg)

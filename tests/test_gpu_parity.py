@@ -253,3 +253,28 @@ def test_every_stop_condition(hip_model, hip_model_sei, O, pkg):
     import test_device_source_emu as te
     te.check_stop_conditions(hip_model, O, pkg)
     te.check_stop_conditions(hip_model_sei, O, pkg)
+
+
+def test_function_inputs_and_drive_cycle_ensemble(hip_model, O, pkg):
+    """tabulated time-dependent inputs on the GPU: the notebook cases, then a 512-cell ensemble on a piecewise-linear drive cycle with jumps"""
+    import test_device_source_emu as te
+    p = hip_model
+    te.check_function_inputs(p, O, pkg)
+    n = 512
+    rng = np.random.default_rng(11)
+    Th = pkg.theta_matrix(p, n, {"D_sp": p.θ["D_sp"] * 2.0 ** (2 * rng.random(n) - 1), "k_n": p.θ["k_n"] * 2.0 ** (2 * rng.random(n) - 1)})
+    knots_t = [0, 60, 60, 150, 150, 240, 240, 400, 400, 600]
+    knots_v = [-1, -1, -3, -3, 0.5, 2.0, -0.5, -0.5, -2, -1]
+    proto = [{"I": (knots_t, knots_v), "tf": 600.0}]
+    o = pkg.Opts(); o.tdiscon = [60.0, 150.0, 240.0, 400.0]
+    ens = pkg.simulate_ensemble(p, Th, proto, SOC=0.9, opts=o)
+    assert (ens.run_info["flag"][:, 0] == 0).all() and np.abs(ens.run_info["t_end"][:, 0] - 600.0).max() < 1e-9
+    # SOC bookkeeping: the reference's trapezoid over the accepted points; the first step after each jump straddles it (tstop at tdiscon - reltol/2)
+    exact = 0.9 + np.trapezoid(knots_v, knots_t) / 3600.0
+    assert np.abs(ens.run_info["SOC"][:, 0] - exact).max() < 1e-4
+    for i in (0, 255, 511):
+        ro = O.simulate(p.variant, Th[i], 0.9, parity.runs_to_oracle(O, p, pkg, proto), opts=O.default_opts(tdiscon=o.tdiscon))
+        # four jumps crossed by step-size collapse: the step sequences may differ, so states agree at the integration tolerance (reltol 1e-3)
+        parity.compare_trajectory(ens, i, ro, rtol_state=5e-3, same_decisions=False)
+        assert abs(int(ens.run_info[i, 0]["iterations"]) - ro["runs"][0]["iterations"]) <= 0.1 * ro["runs"][0]["iterations"]
+        assert abs(ens.run_info[i, 0]["SOC"] - ro["runs"][0]["SOC"]) < 1e-5 and abs(ens.run_info[i, 0]["V"] - ro["runs"][0]["V"]) < 5e-4
