@@ -278,3 +278,52 @@ def test_function_inputs_and_drive_cycle_ensemble(hip_model, O, pkg):
         parity.compare_trajectory(ens, i, ro, rtol_state=5e-3, same_decisions=False)
         assert abs(int(ens.run_info[i, 0]["iterations"]) - ro["runs"][0]["iterations"]) <= 0.1 * ro["runs"][0]["iterations"]
         assert abs(ens.run_info[i, 0]["SOC"] - ro["runs"][0]["SOC"]) < 1e-5 and abs(ens.run_info[i, 0]["V"] - ro["runs"][0]["V"]) < 5e-4
+
+
+def test_c5_full_protocol_1024_cells(hip_model_nmc_sei, O, pkg):
+    """config C5 at its per-GPU size: 1024 NMC + SEI cells, GITT 20 x {1C for 180 s ; rest 7200 s} (GITT.ipynb:64-73), jittered kinetics.
+    Size-independent properties over the whole shard + two cells against the oracle."""
+    p = hip_model_nmc_sei
+    n = 1024
+    rng = np.random.default_rng(5)
+    Th = pkg.theta_matrix(p, n, {k: p.θ[k] * 2.0 ** (2 * rng.random(n) - 1) for k in ("D_sp", "D_sn", "k_p", "k_n")})
+    proto = []
+    for _ in range(20):
+        proto += [{"I": 1.0, "tf": 180.0}, {"I": "rest", "tf": 7200.0}]
+    ens = pkg.simulate_ensemble(p, Th, proto, SOC=0.0, max_points=4096)
+    fl = ens.run_info["flag"]
+    assert (fl >= 0).all()                                              # no solver failure anywhere
+    assert np.isin(fl[:, 0::2], (0, 2, 4)).all() and (fl[:, 1::2] == 0).all()      # pulses end on tf (or V_max / SOC_max late), rests on tf
+    full = (fl[:, :-2] == 0).all(axis=1)                                # (the 20th pulse reaches SOC = 1: it may stop on SOC_max instead of tf)
+    assert full.mean() > 0.5                                            # cells with slow kinetics hit V_max = 4.2 V in late pulses (reference semantics kept)
+    soc = ens.run_info["SOC"]
+    assert np.abs(soc[full, -3] - 19 * 180 / 3600).max() < 1e-6         # coulomb counting: 19 complete pulses of 180 s at 1C
+    assert (soc[full, -1] > 0.95).all() and (soc[full, -1] < 1.0 + 1e-3).all()          # the last pulse ends on V_max or SOC_max
+    assert (np.diff(soc[:, 0::2], axis=1) > 0).all() and np.abs(soc[:, 1::2] - soc[:, 0::2]).max() < 1e-12   # SOC rises in pulses, frozen in rests
+    film, soh = ens.Y[:, 230:240], ens.Y[:, 240]
+    assert (film > 0).all() and (soh < 1.0).all() and (soh > 1 - 1e-3).all()
+    t_end = ens.run_info["t_end"][full, -1]
+    assert (t_end > 20 * 7380.0 - 180.0).all() and (t_end < 20 * 7380.0 + 1e-3).all()
+    for i in (0, 777):
+        ro = O.simulate(p.variant, Th[i], 0.0, parity.runs_to_oracle(O, p, pkg, proto), max_out=20000)
+        assert [r["flag"] for r in ro["runs"]] == [int(f) for f in fl[i]]
+        assert abs(ens.run_info[i, -1]["V"] - ro["runs"][-1]["V"]) < 1e-5 and abs(soh[i] - ro["Y"][240]) < 1e-9
+        assert np.abs(film[i] - ro["Y"][230:240]).max() < 1e-3 * ro["Y"][230:240].max()
+
+
+def test_c3_full_size_4096_cells_properties(hip_model_thermal, pkg):
+    """config C3 at full size: 4096 thermal cells, CC-CT-CV with T_amb / h_cell jitter: every cell finishes, the CT legs hold the limit."""
+    import test_device_source_emu as te
+    p = hip_model_thermal
+    n = 4096
+    rng = np.random.default_rng(3)
+    Th = pkg.theta_matrix(p, n, {"T_amb": 298.15 + 5 * (rng.random(n) - 0.5), "h_cell": 2.0 ** (2 * rng.random(n) - 1)})
+    ens = pkg.simulate_ensemble(p, Th, te.CC_CT_CV, SOC=0.0, max_points=1024)
+    fl = ens.run_info["flag"]
+    assert (fl >= 0).all() and np.isin(fl[:, 0], (5, 2)).all() and (fl[:, 1] == 2).all() and np.isin(fl[:, 2], (4, 8)).all()
+    hot = fl[:, 0] == 5
+    assert np.abs(ens.run_info["T_avg"][hot, 0] - 313.15).max() < 1e-6 and np.abs(ens.run_info["T_avg"][hot, 1] - 313.15).max() < 1e-3
+    assert np.abs(ens.run_info["V"][:, 1] - 4.1).max() < 1e-9 and np.abs(ens.run_info["V"][:, 2] - 4.1).max() < 1e-6   # CT ends on V_max, CV holds it
+    assert (ens.run_info["SOC"][:, 2] > 0.9).all() and (ens.run_info["SOC"][:, 2] <= 1.0 + 2e-3).all()
+    T = ens.Y[:, 230:280]
+    assert (T > 290).all() and (T < 320).all()
