@@ -95,7 +95,7 @@ template <> struct SeiPool<true> {
 // pools of the thermal model (temperature = true; functions in dfn_thermal.h).  T lives on NT = 50 nodes (a | p | s | n | z); the
 // 30 cell-sandwich nodes carry T as the 4th unknown of the block-Thomas node block, the two collector chains are eliminated
 // onto their neighbours, and the four T rows whose one-sided gradient stencils reach a second neighbour (nodes 0, 9, 20, 29)
-// are handled as a rank-4 Woodbury update of the block-tridiagonal matrix.
+// are folded into the twisted elimination (modified neighbour blocks, two right-hand-side shares): see thermal_sweeps.
 template <bool TH> struct ThermalPool {};
 template <> struct ThermalPool<true> {
   // heat-conduction stencil of residuals_T! (residuals.jl:299-489), already divided by rho*Cp:  aL T[it-1] + aD T[it] + aU T[it+1] + aC
@@ -117,7 +117,8 @@ template <> struct ThermalPool<true> {
   // collector chains (tridiagonal scalar systems)
   double cP[2][NA], cM[2][NA], zc[2][NA], zI[2][NA], zb[2][NA];
   // Woodbury and border
-  double Z[4][NE][4], Cinv[16], x2[NE][4], vB[NE][4];
+  double x2[NE][4], vB[NE][4];
+  double qfar[2][4];                                       // q = (far T-row entry of node 9 / 20) . D'^-1 of node 7 / 22 (right-hand-side share)
   double bord[2];                                          // [0] d2 = d - v.x2, [1] d (direct I entry of the control row)
   double cjf;
 };

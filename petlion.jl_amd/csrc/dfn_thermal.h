@@ -412,15 +412,47 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
       G[rr * 4 + 3] = d1 * u.pt + d3 * u.Tt;
     }
   }
+  // ---- the four T rows with a second-neighbour entry (one-sided stencils at nodes 0, 9, 20, 29) inside the twisted elimination ----
+  // "far ahead" (node 0 -> node 2, node 29 -> node 27): eliminating x_0 puts -LD_1[:,3] (x) w into U_1, so node 1's (node 28's)
+  // back-substitution block is G - (Dinv C[:,3]) (x) w, and x_0 (x_29) gets -Dinv[:,3] (w . x_2) after the sweep.
+  // "far behind" (node 9 -> node 7, node 20 -> node 22): the source is already eliminated, its share q . y_src leaves the right-hand side
+  // after stage 7 (q and the modified L_9 / U_20 come from the factorisation).
+  const auto& TPs = S.th;
+  const bool far_ahead_nb = !alg_only && (nd == 1 || nd == NE - 2), far_ahead = !alg_only && (nd == 0 || nd == NE - 1);
+  const bool far_behind = !alg_only && (nd == NP - 1 || nd == NP + NS);
+  const int fk = (nd == 0 || nd == 1) ? 0 : 3;
+  const double w0 = TPs.TX2[fk][0], w1 = TPs.TX2[fk][1], w2 = TPs.TX2[fk][2];
+  if (far_ahead_nb) {
+    for (int rr = 0; rr < 4; rr++) {
+      const double t = Di[rr * 4] * C[3] + Di[rr * 4 + 1] * C[7] + Di[rr * 4 + 2] * C[11] + Di[rr * 4 + 3] * C[15];
+      G[rr * 4 + 0] -= t * w0; G[rr * 4 + 1] -= t * w1; G[rr * 4 + 2] -= t * w2;
+    }
+  }
+  double qf[4] = {0.0, 0.0, 0.0, 0.0};
+  if (far_behind) for (int k = 0; k < 4; k++) qf[k] = TPs.qfar[nd == NP - 1 ? 0 : 1][k];
   double y[NRHS][4];
   for (int q = 0; q < NRHS; q++) for (int k = 0; k < 4; k++) { if (!act) r[q][k] = 0.0; y[q][k] = r[q][k]; }
+  constexpr int FAR_STAGE = NP - 3;                          // = 7: nodes 7 and 22 are final after 7 stages of their chains
+#pragma unroll 1
+  for (int seg = 0; seg < 2; seg++) {
+    const int lo = seg == 0 ? 1 : FAR_STAGE + 1, hi = seg == 0 ? FAR_STAGE + 1 : TW_MID;
 #pragma unroll 2
-  for (int itr = 1; itr < TW_MID; itr++) {
+    for (int itr = lo; itr < hi; itr++) {
 #pragma unroll
-    for (int q = 0; q < NRHS; q++) {
-      const double p0 = shift_up1(y[q][0]), p1 = shift_up1(y[q][1]), p2 = shift_up1(y[q][2]), p3 = shift_up1(y[q][3]);
+      for (int q = 0; q < NRHS; q++) {
+        const double p0 = shift_up1(y[q][0]), p1 = shift_up1(y[q][1]), p2 = shift_up1(y[q][2]), p3 = shift_up1(y[q][3]);
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) y[q][rr] = r[q][rr] - (C[rr * 4] * p0 + C[rr * 4 + 1] * p1 + C[rr * 4 + 2] * p2 + C[rr * 4 + 3] * p3);
+        for (int rr = 0; rr < 4; rr++) y[q][rr] = r[q][rr] - (C[rr * 4] * p0 + C[rr * 4 + 1] * p1 + C[rr * 4 + 2] * p2 + C[rr * 4 + 3] * p3);
+      }
+    }
+    if (seg == 0) {                                         // right-hand side of nodes 9 / 20: minus q . y(node 7 / 22)
+#pragma unroll
+      for (int q = 0; q < NRHS; q++) {
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const double a7 = lane_bcast(y[q][k], tw_lane(NP - 3)), a22 = lane_bcast(y[q][k], tw_lane(NP + NS + 2)); d += qf[k] * (nd == NP - 1 ? a7 : a22); }
+        r[q][3] -= d;                                       // (qf = 0 everywhere else)
+      }
     }
   }
   double z[NRHS][4];
@@ -444,32 +476,20 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
       for (int rr = 0; rr < 4; rr++) r[q][rr] = z[q][rr] - (G[rr * 4] * q0 + G[rr * 4 + 1] * q1 + G[rr * 4 + 2] * q2 + G[rr * 4 + 3] * q3);
     }
   }
-}
-
-// rows of the Woodbury update: node (lane) and column weights of the four out-of-band T-row entries
-__device__ __forceinline__ int wb_src_node(int k) { return k == 0 ? 2 : (k == 1 ? NP - 3 : (k == 2 ? NP + NS + 2 : NE - 3)); }
-__device__ __forceinline__ int wb_row_node(int k) { return k == 0 ? 0 : (k == 1 ? NP - 1 : (k == 2 ? NP + NS : NE - 1)); }
-
-// s_k = (out-of-band row k) . y   for the solution held one node per lane
-template <class M>
-__device__ __forceinline__ void wb_dots(const CellLDS<M>& S, const double* y, double* s) {
-  const auto& TP = S.th;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int src = wb_src_node(k);
-    s[k] = TP.TX2[k][0] * lane_bcast(y[0], tw_lane(src)) + TP.TX2[k][1] * lane_bcast(y[1], tw_lane(src)) + TP.TX2[k][2] * lane_bcast(y[2], tw_lane(src));
+  for (int q = 0; q < NRHS; q++) {                          // x_0 -= Dinv_0[:,3] (w . x_2) ; x_29 -= Dinv_29[:,3] (w . x_27)
+    const double a0 = lane_bcast(r[q][0], tw_lane(2)), a1 = lane_bcast(r[q][1], tw_lane(2)), a2 = lane_bcast(r[q][2], tw_lane(2));
+    const double b0 = lane_bcast(r[q][0], tw_lane(NE - 3)), b1 = lane_bcast(r[q][1], tw_lane(NE - 3)), b2 = lane_bcast(r[q][2], tw_lane(NE - 3));
+    if (far_ahead) {
+      const double wx = nd == 0 ? w0 * a0 + w1 * a1 + w2 * a2 : w0 * b0 + w1 * b1 + w2 * b2;
+      for (int rr = 0; rr < 4; rr++) r[q][rr] -= Di[rr * 4 + 3] * wx;
+    }
   }
 }
-// y -= Z C^-1 s
-template <class M>
-__device__ __forceinline__ void wb_apply(const CellLDS<M>& S, double* y, const double* s) {
-  const auto& TP = S.th;
-  const int nd = tw_node(lane_id());
-  const int i = nd >= 0 ? nd : 0;
-  double m[4];
-  for (int a = 0; a < 4; a++) m[a] = TP.Cinv[a * 4] * s[0] + TP.Cinv[a * 4 + 1] * s[1] + TP.Cinv[a * 4 + 2] * s[2] + TP.Cinv[a * 4 + 3] * s[3];
-  for (int cc = 0; cc < 4; cc++) y[cc] -= TP.Z[0][i][cc] * m[0] + TP.Z[1][i][cc] * m[1] + TP.Z[2][i][cc] * m[2] + TP.Z[3][i][cc] * m[3];
-}
+
+// nodes of the four T rows with a second-neighbour entry, and the node that entry refers to
+__device__ __forceinline__ int wb_src_node(int k) { return k == 0 ? 2 : (k == 1 ? NP - 3 : (k == 2 ? NP + NS + 2 : NE - 3)); }
+__device__ __forceinline__ int wb_row_node(int k) { return k == 0 ? 0 : (k == 1 ? NP - 1 : (k == 2 ? NP + NS : NE - 1)); }
 
 template <class M>
 __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
@@ -581,6 +601,10 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     const OffBlk b = top ? upper_blk(S, nb, alg_only) : lower_blk(S, nb, alg_only);
     if (!act) { a.ce = a.pc = a.pe = a.pt = a.s = a.Tc = a.Te = a.Ts = a.Tt = 0.0; }
     for (int k = 0; k < 16; k++) Dn[k] = D[k];
+    // second-neighbour T-row entries (see thermal_sweeps): nodes 2 / 27 see U_1 / L_28 modified by -fv (x) fw ; nodes 9 / 20 get a modified
+    // lower / upper block once the factor of node 7 / 22 is final
+    double fv[4] = {0.0, 0.0, 0.0, 0.0}, fw[3] = {0.0, 0.0, 0.0};
+    constexpr int FAR_STAGE = NP - 3;
     inv4(D, Dinv);
 #pragma unroll 1
     for (int itr = 1; itr < TW_MID; itr++) {
@@ -599,7 +623,38 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
         Dn[rr * 4 + 2] = D[rr * 4 + 2] - (a2 * b.s + a3 * b.Ts);
         Dn[rr * 4 + 3] = D[rr * 4 + 3] - (a1 * b.pt + a3 * b.Tt);
       }
+      if (nd == 2 || nd == NE - 3) {
+        for (int rr = 0; rr < 4; rr++) {
+          const double t = LDm[rr * 4] * fv[0] + LDm[rr * 4 + 1] * fv[1] + LDm[rr * 4 + 2] * fv[2] + LDm[rr * 4 + 3] * fv[3];
+          Dn[rr * 4 + 0] += t * fw[0]; Dn[rr * 4 + 1] += t * fw[1]; Dn[rr * 4 + 2] += t * fw[2];
+        }
+      }
       inv4(Dn, Dinv);
+      if (itr == 1 && !alg_only) {                          // LD_1 (UD_28) is final: its T column modifies U_1 (L_28) as seen by node 2 (27)
+        for (int k = 0; k < 4; k++) {
+          const double c1 = lane_bcast(LDm[4 * k + 3], tw_lane(1)), c28 = lane_bcast(LDm[4 * k + 3], tw_lane(NE - 2));
+          if (nd == 2) fv[k] = c1;
+          if (nd == NE - 3) fv[k] = c28;
+        }
+        if (nd == 2) for (int cc = 0; cc < 3; cc++) fw[cc] = TP.TX2[0][cc];
+        if (nd == NE - 3) for (int cc = 0; cc < 3; cc++) fw[cc] = TP.TX2[3][cc];
+      }
+      if (itr == FAR_STAGE && !alg_only) {                  // the factor of node 7 (22) is final: fold node 9's (20's) entry on it into L_9 (U_20)
+        double q7[4] = {0.0, 0.0, 0.0, 0.0}, q22[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int cc = 0; cc < 3; cc++) for (int k = 0; k < 4; k++) {
+          const double d7 = lane_bcast(Dinv[cc * 4 + k], tw_lane(NP - 3)), d22 = lane_bcast(Dinv[cc * 4 + k], tw_lane(NP + NS + 2));
+          q7[k] += TP.TX2[1][cc] * d7; q22[k] += TP.TX2[2][cc] * d22;
+        }
+        if (nd == NP - 1 || nd == NP + NS) {
+          const double* q = nd == NP - 1 ? q7 : q22;
+          const OffBlk e = nd == NP - 1 ? upper_blk(S, NP - 3, alg_only) : lower_blk(S, NP + NS + 2, alg_only);
+          a.Tc -= q[0] * e.ce + q[1] * e.pc + q[3] * e.Tc;
+          a.Te -= q[1] * e.pe + q[3] * e.Te;
+          a.Ts -= q[2] * e.s + q[3] * e.Ts;
+          a.Tt -= q[1] * e.pt + q[3] * e.Tt;
+          for (int k = 0; k < 4; k++) TP.qfar[nd == NP - 1 ? 0 : 1][k] = q[k];
+        }
+      }
     }
     {   // closing node TW_MID: D'' = D'_mid - L_mid D'^-1_{mid-1} U_{mid-1}
       double P[16], L2[16], Dm[16], Dmi[16];
@@ -665,41 +720,14 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     if (lane < NE) { TP.vB[ln][0] = v0; TP.vB[ln][1] = v1; TP.vB[ln][2] = v2; TP.vB[ln][3] = v3; }
   }
   PL_SYNC();
-  // 5. Woodbury columns Z = Bb^-1 E (E = unit vectors at the T rows of nodes 0, 9, 20, 29), the capacitance matrix, and the border
-  //    x2 = B^-1 (column of I): five right-hand sides in ONE pass of the sweeps (latency-bound: the extra ILP is almost free)
-  double xb[4] = {0.0, 0.0, 0.0, 0.0};
-  if (!alg_only) {
-    double rz[5][4];
-    for (int k = 0; k < 4; k++) { for (int cc = 0; cc < 4; cc++) rz[k][cc] = 0.0; if (nd == wb_row_node(k)) rz[k][3] = 1.0; }
-    for (int cc = 0; cc < 4; cc++) rz[4][cc] = 0.0;
-    if (act) { rz[4][2] = TP.colI4[i][0]; rz[4][3] = TP.colI4[i][1]; }
-    thermal_sweeps<5>(S, alg_only, rz);
-    if (act) for (int k = 0; k < 4; k++) for (int cc = 0; cc < 4; cc++) TP.Z[k][i][cc] = rz[k][cc];
-    // C = I + Vw^T Z  (4x4), inverted redundantly by every lane
-    double C[16], Ci[16];
-    for (int k = 0; k < 4; k++) {
-      double s[4]; wb_dots(S, rz[k], s);                    // column k of Vw^T Z
-      for (int a = 0; a < 4; a++) C[a * 4 + k] = s[a] + (a == k ? 1.0 : 0.0);
-    }
-    inv4(C, Ci);
-    if (lane < 16) TP.Cinv[lane] = Ci[lane];
-    for (int cc = 0; cc < 4; cc++) xb[cc] = rz[4][cc];
-  } else {
-    if (lane < 16) TP.Cinv[lane] = (lane % 5 == 0) ? 1.0 : 0.0;
-    if (act) for (int k = 0; k < 4; k++) for (int cc = 0; cc < 4; cc++) TP.Z[k][i][cc] = 0.0;
-    if (mode != PLH_MODE_I) {
-      double ra[1][4] = {{0.0, 0.0, 0.0, 0.0}};
-      if (act) { ra[0][2] = TP.colI4[i][0]; ra[0][3] = TP.colI4[i][1]; }
-      thermal_sweeps<1>(S, alg_only, ra);
-      for (int cc = 0; cc < 4; cc++) xb[cc] = ra[0][cc];
-    }
-  }
   PL_SYNC();
-  // 6b. border: x2 (Woodbury-corrected) and the pivot d - v.x2
+  // 5. border: x2 = B^-1 (column of I) and the pivot d - v.x2
   if (mode != PLH_MODE_I) {
-    if (!alg_only) { double s[4]; wb_dots(S, xb, s); wb_apply(S, xb, s); }
-    if (act) for (int cc = 0; cc < 4; cc++) TP.x2[i][cc] = xb[cc];
-    const double vx = wave_sum(act ? TP.vB[i][1] * xb[1] + TP.vB[i][2] * xb[2] + TP.vB[i][3] * xb[3] + (mode == PL_MODE_DT_TWIN ? 0.0 : TP.vB[i][0] * xb[0]) : 0.0);
+    double ra[1][4] = {{0.0, 0.0, 0.0, 0.0}};
+    if (act) { ra[0][2] = TP.colI4[i][0]; ra[0][3] = TP.colI4[i][1]; }
+    thermal_sweeps<1>(S, alg_only, ra);
+    if (act) for (int cc = 0; cc < 4; cc++) TP.x2[i][cc] = ra[0][cc];
+    const double vx = wave_sum(act ? TP.vB[i][1] * ra[0][1] + TP.vB[i][2] * ra[0][2] + TP.vB[i][3] * ra[0][3] + (mode == PL_MODE_DT_TWIN ? 0.0 : TP.vB[i][0] * ra[0][0]) : 0.0);
     if (lane == 0) { TP.bord[0] = dI - vx; TP.bord[1] = dI; }
   } else if (lane == 0) { TP.bord[0] = 1.0; TP.bord[1] = 1.0; }
   PL_SYNC();
@@ -777,7 +805,6 @@ __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* _
     double ra[1][4] = {{y[0], y[1], y[2], y[3]}};
     thermal_sweeps<1>(S, alg_only, ra);
     for (int cc = 0; cc < 4; cc++) y[cc] = ra[0][cc];
-    if (!alg_only) { double s[4]; wb_dots(S, y, s); wb_apply(S, y, s); }
   }
   // d. border
   if (mode != PLH_MODE_I) {
