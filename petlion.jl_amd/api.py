@@ -175,6 +175,48 @@ class Solution:
     def isempty(self):
         return len(self.results) == 0
 
+    def __call__(self, t, interp_bc="interpolate", k=3):
+        """sol(t): the reference's post-interpolation of a solution (src/save_outputs.jl:74-133).  Every requested time is assigned to the run whose
+        tspan contains it (first match; before the first run -> run 1, otherwise the last run), each run's saved points get an interpolating spline
+        of degree min(k, points) -- Dierckx `Spline1D(t, x; k, bc)` with s = 0, i.e. FITPACK curfit/splev, which is exactly what
+        scipy.interpolate.splrep/splev call -- evaluated with bc = "nearest" (interp_bc = "interpolate") or "extrapolate"."""
+        from scipy.interpolate import splev, splrep
+        if interp_bc not in ("interpolate", "extrapolate"):
+            raise ValueError("Invalid interp_bc method.")
+        tq = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        spans = [r.tspan for r in self.results]
+        which = np.full(tq.shape, len(spans) - 1)
+        for q, tv in enumerate(tq):
+            if tv < spans[0][0]:
+                which[q] = 0
+                continue
+            for i, (a, b) in enumerate(spans):
+                if a <= tv <= b:
+                    which[q] = i
+                    break
+        out = Solution()
+        out.t = tq
+        out.results = [self.results[i] for i in sorted(set(which.tolist()))]
+        out.Y, out.YP, out.counters = self.Y, self.YP, self.counters
+        start = np.concatenate([[0], np.cumsum([r.iterations for r in self.results])])
+        for name in ("V", "I", "SOC", "P"):
+            x = getattr(self, name)
+            y = np.zeros_like(tq)
+            for i in set(which.tolist()):
+                pts = slice(int(start[i]), int(start[i + 1]))
+                n = int(start[i + 1] - start[i])
+                kk = min(k, n)
+                if kk >= n:
+                    kk = max(1, n - 1)          # FITPACK needs more points than the degree
+                sel = which == i
+                if n < 2:
+                    y[sel] = x[pts][0]
+                    continue
+                tck = splrep(self.t[pts], x[pts], k=kk, s=0)
+                y[sel] = splev(tq[sel], tck, ext=3 if interp_bc == "interpolate" else 0)
+            setattr(out, name, y)
+        return out
+
     def __repr__(self):
         if self.isempty():
             return "PETLION simulation (empty)"

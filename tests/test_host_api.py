@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "notebook_kats.json"), encoding="utf-8"))
 
@@ -58,3 +59,28 @@ def test_input_validation(emu_model, pkg):
         pkg.simulate(emu_model, V="rest")
     with pytest.raises(TypeError):
         pkg.simulate(emu_model, I=1, not_an_option=3)
+
+
+def test_solution_call_interpolates_like_the_reference(emu_model, pkg):
+    """sol(t) (reference src/save_outputs.jl:74-133): per-run interpolating cubic splines (FITPACK, as Dierckx.jl), nearest / extrapolate ends"""
+    p = emu_model
+    sol = pkg.simulate(p, 1200.0, I=2.0, SOC=0.0, V_max=4.1)
+    sol = pkg.simulate_b(sol, p, 600.0, V="hold")
+    k1 = sol.results[0].iterations
+    # the spline interpolates the saved points of both runs exactly
+    s = sol(sol.t)
+    assert np.abs(s.V - sol.V).max() < 1e-10 and np.abs(s.I - sol.I).max() < 1e-10 and np.abs(s.SOC - sol.SOC).max() < 1e-12
+    # between two saved points of the CC leg the interpolant stays within the bracket of a smooth, monotone V(t)
+    tm = 0.5 * (sol.t[10] + sol.t[11])
+    vm = sol(tm).V[0]
+    assert min(sol.V[10], sol.V[11]) - 1e-4 < vm < max(sol.V[10], sol.V[11]) + 1e-4
+    # each time is evaluated on the spline of its own run: the current is 2C just before the switch and below 2C in the CV leg
+    t_sw = sol.results[0].tspan[1]
+    assert abs(sol(t_sw - 1.0).I[0] - 2.0) < 1e-9 and sol(t_sw + 50.0).I[0] < 2.0
+    assert len(sol(np.array([t_sw - 1.0, t_sw + 50.0])).results) == 2 and k1 > 3
+    # interp_bc: beyond the end "interpolate" holds the last value, "extrapolate" continues the cubic
+    t_end = sol.t[-1]
+    assert abs(sol(t_end + 100.0).V[0] - sol.V[-1]) < 1e-12
+    assert abs(sol(t_end + 100.0, interp_bc="extrapolate").I[0] - sol.I[-1]) > 1e-6
+    with pytest.raises(ValueError):
+        sol(1.0, interp_bc="bogus")
