@@ -45,6 +45,7 @@ end
 struct Outputs
     max_pts::Cint; t::Ptr{Cdouble}; V::Ptr{Cdouble}; I::Ptr{Cdouble}; SOC::Ptr{Cdouble}; T_avg::Ptr{Cdouble}
     n_pts::Ptr{Cint}; Y_final::Ptr{Cdouble}; YP_final::Ptr{Cdouble}; run_info::Ptr{RunInfo}; counters::Ptr{Counters}
+    Y_all::Ptr{Cdouble}
 end
 
 lasterror() = unsafe_string(ccall((:plh_last_error, lib), Cstring, ()))
@@ -67,6 +68,16 @@ mutable struct Model
 end
 
 key_index(m::Model, k::Symbol) = findfirst(==(k), m.θ_keys)
+"p.ind of the device layout: state name => 1-based index range into Y (reference state_indices, src/external.jl:275-365)"
+function state_indices(m::Model)
+    d = Dict{Symbol,UnitRange{Int}}()
+    for i in 0:ccall((:plh_n_sections, lib), Cint, (Ptr{Cvoid},), m.h)-1
+        nm = Ref{Cstring}(); a = Ref{Cint}(); l = Ref{Cint}()
+        check(ccall((:plh_section, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cstring}, Ref{Cint}, Ref{Cint}), m.h, i, nm, a, l), "plh_section")
+        d[Symbol(unsafe_string(nm[]))] = (a[]+1):(a[]+l[])
+    end
+    d
+end
 "n_cells × n_theta matrix (row = one cell's θ_tot, update_θ! order of src/generate_functions.jl:364-372)"
 theta_matrix(m::Model, p, n_cells) = repeat(permutedims([Float64(p.θ[k]) for k in m.θ_keys]), n_cells, 1)
 
@@ -92,7 +103,8 @@ end
 `[(I = 2, tf = 1800, V_max = 4.1), (V = :hold, I_min = 1/20)]`.  Θ is n_cells × n_theta (row-major is what the C side wants, so
 the transposed copy is passed).
 """
-function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.opts.SOC, max_pts = 2048, Y_init = nothing, t_init = nothing)
+function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.opts.SOC, max_pts = 2048, Y_init = nothing, t_init = nothing,
+                           outputs = p.opts.outputs)
     n = size(Θ, 1)
     runs = [make_run(p, s) for s in protocol]
     o = p.opts
@@ -104,15 +116,20 @@ function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.o
     t = zeros(max_pts, n); V = similar(t); I = similar(t); S = similar(t)
     npts = zeros(Cint, n); Y = zeros(m.N, n); YP = zeros(m.N, n)
     info = Matrix{RunInfo}(undef, length(runs), n); cnt = Vector{Counters}(undef, n)
-    GC.@preserve t V I S npts Y YP info cnt begin
-        out = Ref(Outputs(max_pts, pointer(t), pointer(V), pointer(I), pointer(S), C_NULL, pointer(npts), pointer(Y), pointer(YP), pointer(info), pointer(cnt)))
+    outs = outputs isa Symbol ? (outputs,) : outputs
+    keep_Y = any(x -> x ∈ (:all, :Y, :c_e, :c_s_avg, :T, :film, :SOH, :j, :j_s, :Φ_e, :Φ_s), outs)     # solution_states_logic, src/outputs.jl:107-131
+    Tavg = p.numerics.temperature ? zeros(max_pts, n) : Float64[]
+    Yall = keep_Y ? zeros(m.N, max_pts, n) : Float64[]                  # sol.Y of every cell: Yall[:, k, i] = state after step k of cell i
+    GC.@preserve t V I S npts Y YP info cnt Tavg Yall begin
+        out = Ref(Outputs(max_pts, pointer(t), pointer(V), pointer(I), pointer(S), isempty(Tavg) ? C_NULL : pointer(Tavg), pointer(npts), pointer(Y), pointer(YP),
+                          pointer(info), pointer(cnt), keep_Y ? pointer(Yall) : C_NULL))
         rc = ccall((:plh_integrate, lib), Cint,
                    (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Run}, Ref{Opts}, Ref{Outputs}, Cint, Ptr{Cvoid}),
                    m.h, n, Θt, soc, Y_init === nothing ? C_NULL : pointer(Y_init), t_init === nothing ? C_NULL : pointer(t_init),
                    length(runs), runs, opts, out, PLH_HOST, C_NULL)
         check(rc, "plh_integrate")
     end
-    (t = t, V = V, I = I, SOC = S, n_pts = npts, Y = Y, YP = YP, run_info = info, counters = cnt,
+    (t = t, V = V, I = I, SOC = S, T_avg = Tavg, Y_all = Yall, n_pts = npts, Y = Y, YP = YP, run_info = info, counters = cnt,
      flag = [info[end, i].flag for i in 1:n], t_end = [info[end, i].t_end for i in 1:n])
 end
 

@@ -122,6 +122,7 @@ typedef struct {
   double *Y_final, *YP_final;        /* [n_cells][n_states] */
   plh_run_info* run_info;            /* [n_cells][n_runs] */
   plh_counters* counters;            /* [n_cells] */
+  double* Y_all;                     /* [n_cells][max_pts][N] or NULL: every saved state vector (reference outputs = :all / sol.Y; 2.4 kB per point) */
 } plh_outputs;
 
 /* ---- model handle: replaces petlion()'s generated-function bundle p.funcs (src/structures.jl:315-334) ---- */
@@ -132,6 +133,10 @@ int plh_n_diff(plh_model_t m);       /* p.N.diff */
 int plh_n_theta(plh_model_t m);      /* length(θ_keys), src/generate_functions.jl:327-363 */
 const char* plh_theta_key(plh_model_t m, int i);   /* UTF-8 names identical to the reference Symbols, sorted like θ_keys */
 double plh_theta_default(plh_model_t m, int i);    /* chemistry defaults, src/params.jl */
+/* p.ind (reference state_indices, src/external.jl:275-365): the named sections of the state vector in storage order, differential states
+ * first.  Names are the reference's Symbols (c_e, c_s_avg, T, film, SOH, j, Φ_e, Φ_s, j_s, I); start is 0-based. */
+int plh_n_sections(plh_model_t m);
+int plh_section(plh_model_t m, int i, const char** name, int* start, int* len);
 /* CSC pattern (0-based) of the full N x N Jacobian for a mode == [J_y_sp ; scalar row] of
  * _get_jacobian_combined (src/physics_equations/scalar_residual.jl:500-522).  colptr/rowval may be NULL to query nnz. */
 int plh_jac_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval);

@@ -803,7 +803,7 @@ static int find_key(const orc_model* m, const char* k) { for (int i = 0; i < m->
  * Outputs one row per saved point (t=0 of a new solution and every accepted step; the last point of a run is
  * replaced by the back-interpolated one), like the reference's default outputs (:t,:V) plus I, SOC, T_avg.
  */
-typedef struct { orc_model M; evalb ev[ORC_NMODES]; int ev_ok[ORC_NMODES]; ida_t I; int ida_ok; } orc_ctx;
+typedef struct { orc_model M; evalb ev[ORC_NMODES]; int ev_ok[ORC_NMODES]; ida_t I; int ida_ok; double* out_Y; } orc_ctx;
 
 static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_runs, const orc_run* runs, const orc_opts* opts,
                  int max_out, double* out_t, double* out_V, double* out_I, double* out_SOC, double* out_T, int* n_out,
@@ -823,7 +823,8 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       if (out_V) { out_V[nout] = calc_V(&M, (Y_)); } \
       if (out_I) { out_I[nout] = (Y_)[M.o_I]; } \
       if (out_SOC) { out_SOC[nout] = (SOC_); } \
-      if (out_T) { out_T[nout] = calc_Tavg(&M, ev[run->mode].w, (Y_), T0); } } \
+      if (out_T) { out_T[nout] = calc_Tavg(&M, ev[run->mode].w, (Y_), T0); } \
+      if (ctx->out_Y) { memcpy(ctx->out_Y + (size_t)nout * N, (Y_), N * sizeof(double)); } }   /* outputs = :all (sol.Y, save_outputs.jl:11-40) */ \
     nout++; } while (0)
 #define REPLACE_LAST(tt_, Y_, SOC_) do { nout--; SAVE(tt_, Y_, SOC_); } while (0)
   for (int r = 0; r < n_runs; r++) {
@@ -954,6 +955,18 @@ int orc_simulate(const char* variant, const double* theta, double SOC0, int n_ru
                  double* Y_final, double* YP_final, orc_runinfo* info, orc_counters* counters, const double* Y_init) {
   orc_ctx* ctx = (orc_ctx*)calloc(1, sizeof(orc_ctx));
   if (get_model(variant, &ctx->M) != 0) { free(ctx); return -100; }
+  int rc = simulate_core(ctx, theta, SOC0, n_runs, runs, opts, max_out, out_t, out_V, out_I, out_SOC, out_T, n_out, Y_final, YP_final, info, counters, Y_init);
+  ctx_free(ctx); free(ctx);
+  return rc;
+}
+
+/* orc_simulate + every saved state vector (outputs = :all): out_Y is [max_out][N] */
+int orc_simulate_all(const char* variant, const double* theta, double SOC0, int n_runs, const orc_run* runs, const orc_opts* opts,
+                 int max_out, double* out_t, double* out_V, double* out_I, double* out_SOC, double* out_T, double* out_Y, int* n_out,
+                 double* Y_final, double* YP_final, orc_runinfo* info, orc_counters* counters, const double* Y_init) {
+  orc_ctx* ctx = (orc_ctx*)calloc(1, sizeof(orc_ctx));
+  if (get_model(variant, &ctx->M) != 0) { free(ctx); return -100; }
+  ctx->out_Y = out_Y;
   int rc = simulate_core(ctx, theta, SOC0, n_runs, runs, opts, max_out, out_t, out_V, out_I, out_SOC, out_T, n_out, Y_final, YP_final, info, counters, Y_init);
   ctx_free(ctx); free(ctx);
   return rc;

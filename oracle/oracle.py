@@ -103,7 +103,7 @@ def theta_vector(variant, overrides=None):
     return th
 
 
-def simulate(variant, theta, SOC0, runs, opts=None, max_out=20000, Y_init=None):
+def simulate(variant, theta, SOC0, runs, opts=None, max_out=20000, Y_init=None, keep_Y=False):
     """runs: list of dicts(mode, value, value_kind, tf, bounds=Bounds).  Returns dict with per-point outputs, final
     state, per-run info and counters."""
     L = lib()
@@ -130,11 +130,14 @@ def simulate(variant, theta, SOC0, runs, opts=None, max_out=20000, Y_init=None):
     info = (RunInfo * len(runs))()
     cnt = Counters()
     yi = None if Y_init is None else _dp(np.ascontiguousarray(Y_init, dtype=np.float64))
-    rc = L.orc_simulate(variant.encode(), _dp(theta), C.c_double(SOC0), len(runs), arr, C.byref(opts), max_out,
-                        _dp(out["t"]), _dp(out["V"]), _dp(out["I"]), _dp(out["SOC"]), _dp(out["T"]), C.byref(n_out),
-                        _dp(Yf), _dp(YPf), info, C.byref(cnt), yi)
+    Yall = np.zeros((max_out, N)) if keep_Y else None
+    rc = L.orc_simulate_all(variant.encode(), _dp(theta), C.c_double(SOC0), len(runs), arr, C.byref(opts), max_out,
+                            _dp(out["t"]), _dp(out["V"]), _dp(out["I"]), _dp(out["SOC"]), _dp(out["T"]), None if Yall is None else _dp(Yall),
+                            C.byref(n_out), _dp(Yf), _dp(YPf), info, C.byref(cnt), yi)
     n = min(n_out.value, max_out)
     res = {k: v[:n].copy() for k, v in out.items()}
+    if keep_Y:
+        res["Y_all"] = Yall[:n].copy()
     res.update(rc=rc, Y=Yf, YP=YPf,
                runs=[dict(flag=i.flag, iterations=i.iterations, t_end=i.t_end, V=i.V, I=i.I, SOC=i.SOC, T_avg=i.T_avg) for i in info],
                counters={f: getattr(cnt, f) for f, _ in Counters._fields_})

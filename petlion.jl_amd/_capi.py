@@ -60,7 +60,7 @@ class CountersS(C.Structure):
 class Outputs(C.Structure):
     _fields_ = [("max_pts", C.c_int), ("t", C.c_void_p), ("V", C.c_void_p), ("I", C.c_void_p), ("SOC", C.c_void_p),
                 ("T_avg", C.c_void_p), ("n_pts", C.c_void_p), ("Y_final", C.c_void_p), ("YP_final", C.c_void_p),
-                ("run_info", C.c_void_p), ("counters", C.c_void_p)]
+                ("run_info", C.c_void_p), ("counters", C.c_void_p), ("Y_all", C.c_void_p)]
 
 
 RUN_INFO_DTYPE = np.dtype([("flag", np.int32), ("iterations", np.int32), ("t_end", np.float64), ("V", np.float64),
@@ -69,7 +69,7 @@ COUNTERS_DTYPE = np.dtype([(f, np.int64) for f in COUNTER_FIELDS] + [("cyc", np.
 assert RUN_INFO_DTYPE.itemsize == C.sizeof(RunInfo) and COUNTERS_DTYPE.itemsize == C.sizeof(CountersS)
 
 EXPORTS = ["plh_model_create", "plh_model_destroy", "plh_n_states", "plh_n_diff", "plh_n_theta", "plh_theta_key",
-           "plh_theta_default", "plh_jac_pattern", "plh_last_error", "plh_initial_guess", "plh_residual", "plh_jacobian",
+           "plh_theta_default", "plh_n_sections", "plh_section", "plh_jac_pattern", "plh_last_error", "plh_initial_guess", "plh_residual", "plh_jacobian",
            "plh_linear_solve", "plh_init_consistent", "plh_integrate", "plh_last_kernel_ms"]
 
 
@@ -98,7 +98,8 @@ def load(path=None):
     lib.plh_last_kernel_ms.argtypes = [C.c_void_p]
     lib.plh_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]
     lib.plh_model_destroy.argtypes = [C.c_void_p]
-    for f in ("plh_n_states", "plh_n_diff", "plh_n_theta"):
+    lib.plh_section.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for f in ("plh_n_states", "plh_n_diff", "plh_n_theta", "plh_n_sections"):
         getattr(lib, f).argtypes = [C.c_void_p]
     lib.plh_jac_pattern.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
     vp, i, d = C.c_void_p, C.c_int, C.c_double

@@ -53,6 +53,11 @@ class Model:
         self.N.diff = self._lib.plh_n_diff(h)
         self.N.alg = self.N.tot - self.N.diff
         self.θ_keys = [self._lib.plh_theta_key(h, i).decode("utf-8") for i in range(self._lib.plh_n_theta(h))]
+        self.ind = {}                       # p.ind: state name -> slice into Y (reference state_indices, src/external.jl:275-365)
+        for i in range(self._lib.plh_n_sections(h)):
+            nm, a, ln = C.c_char_p(), C.c_int(), C.c_int()
+            cap.check(self._lib, self._lib.plh_section(h, i, C.byref(nm), C.byref(a), C.byref(ln)), "plh_section")
+            self.ind[nm.value.decode("utf-8")] = slice(a.value, a.value + ln.value)
         self.variant = "%s_%s%s" % (cathode.lower(), "thermal" if self.temperature else "iso", "_sei" if aging else "")   # matching oracle variant (tests)
 
     theta = property(lambda self: self.θ)
@@ -166,11 +171,23 @@ class Solution:
         self.P = np.zeros(0)
         self.Y = None          # last state vector (sol.Y[end])
         self.YP = None
+        self.T_avg = None      # [points] with temperature = true
+        self.Y_all = None      # [points, N] when the run was made with outputs = "all" / a state name (sol.Y of the reference)
+        self._ind = None
         self.results = []
         self.counters = None
 
     def __len__(self):
         return len(self.t)
+
+    def __getattr__(self, name):
+        # sol.c_e, sol.T, sol.j, sol.Φ_e ... : per-step state sections, available when the states were kept (outputs = "all")
+        ind = self.__dict__.get("_ind")
+        if ind and name in ind:
+            if self.__dict__.get("Y_all") is None:
+                raise AttributeError("%s was not saved: run with outputs='all' (or outputs=(%r,))" % (name, name))
+            return self.Y_all[:, ind[name]]
+        raise AttributeError(name)
 
     def isempty(self):
         return len(self.results) == 0
@@ -198,10 +215,12 @@ class Solution:
         out.t = tq
         out.results = [self.results[i] for i in sorted(set(which.tolist()))]
         out.Y, out.YP, out.counters = self.Y, self.YP, self.counters
+        out._ind = self._ind
         start = np.concatenate([[0], np.cumsum([r.iterations for r in self.results])])
-        for name in ("V", "I", "SOC", "P"):
+        names = ["V", "I", "SOC", "P"] + (["T_avg"] if self.T_avg is not None else []) + (["Y_all"] if self.Y_all is not None else [])
+        for name in names:
             x = getattr(self, name)
-            y = np.zeros_like(tq)
+            y = np.zeros(tq.shape + x.shape[1:])
             for i in set(which.tolist()):
                 pts = slice(int(start[i]), int(start[i + 1]))
                 n = int(start[i + 1] - start[i])
@@ -212,8 +231,12 @@ class Solution:
                 if n < 2:
                     y[sel] = x[pts][0]
                     continue
-                tck = splrep(self.t[pts], x[pts], k=kk, s=0)
-                y[sel] = splev(tq[sel], tck, ext=3 if interp_bc == "interpolate" else 0)
+                ext = 3 if interp_bc == "interpolate" else 0
+                if x.ndim == 1:
+                    y[sel] = splev(tq[sel], splrep(self.t[pts], x[pts], k=kk, s=0), ext=ext)
+                else:                           # VectorOfArray fields: one spline per state (save_outputs.jl:104-119)
+                    for c in range(x.shape[1]):
+                        y[sel, c] = splev(tq[sel], splrep(self.t[pts], x[pts, c], k=kk, s=0), ext=ext)
             setattr(out, name, y)
         return out
 
@@ -242,6 +265,15 @@ def _split_kwargs(p, kw):
     return inputs, bounds, kw
 
 
+_STATE_OUTPUTS = ("Y", "c_e", "c_s_avg", "T", "film", "SOH", "j", "j_s", "Φ_e", "Φ_s")
+
+
+def _wants_states(p, outputs):
+    """outputs = :all or any per-node state asks for the state vector of every step (solution_states_logic, src/outputs.jl:107-131)."""
+    outs = (outputs,) if isinstance(outputs, str) else tuple(outputs or ())
+    return "all" in outs or any(x in _STATE_OUTPUTS for x in outs)
+
+
 def simulate(p, tf=1e6, *, sol=None, SOC=None, **kw):
     """simulate(p, tf; I=..|V=..|dT=.., SOC, abstol, reltol, ..., V_max, V_min, ...) for ONE cell (n_cells = 1 ensemble)."""
     inputs, bounds, rest = _split_kwargs(p, kw)
@@ -254,14 +286,23 @@ def simulate(p, tf=1e6, *, sol=None, SOC=None, **kw):
     (name, inp), = inputs.items()
     new = sol is None or sol.isempty()
     sol = Solution() if sol is None else sol
+    keep_Y = _wants_states(p, o.outputs) or sol.Y_all is not None
     soc0 = (p.opts.SOC if SOC is None else SOC) if new else sol.SOC[-1]
     ens = _integrate(p, p.theta_vector()[None, :], np.array([soc0]), [_make_run(p, name, inp, tf, bounds)], o,
-                     Y_init=None if new else sol.Y[None, :], t_init=None if new else np.array([sol.t[-1]]))
+                     Y_init=None if new else sol.Y[None, :], t_init=None if new else np.array([sol.t[-1]]), keep_Y=keep_Y)
     n = int(ens["n_pts"][0])
     I1C = calc_I1C(p.θ)
     for fld in ("t", "V", "I", "SOC"):
         setattr(sol, fld, np.concatenate([getattr(sol, fld), ens[fld][0, :n]]))
     sol.P = sol.I * I1C * sol.V                                   # calc_P, scalar_residual.jl:87
+    sol._ind = p.ind
+    if "T_avg" in ens:
+        sol.T_avg = np.concatenate([sol.T_avg if sol.T_avg is not None else np.zeros(0), ens["T_avg"][0, :n]])
+    if keep_Y:
+        prev = sol.Y_all if sol.Y_all is not None else np.zeros((0, p.N.tot))
+        if prev.shape[0] != len(sol.t) - n:
+            raise ValueError("the solution being continued was not saved with outputs='all'")
+        sol.Y_all = np.concatenate([prev, ens["Y_all"][0, :n]])
     sol.Y, sol.YP = ens["Y"][0].copy(), ens["YP"][0].copy()
     ri = ens["run_info"][0, 0]
     if ri["flag"] < 0:
@@ -277,7 +318,7 @@ def simulate_b(sol, p, tf=1e6, **kw):
     return simulate(p, tf, sol=sol, **kw)
 
 
-def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, stream=None, max_points=None):
+def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, stream=None, max_points=None, keep_Y=False):
     """one plh_integrate call; numpy in / numpy out (host pointers) or torch device tensors (device=True)."""
     lib, h = p._lib, p._h
     n = theta.shape[0]
@@ -307,6 +348,13 @@ def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, 
         kind = cap.PLH_HOST
     out.t, out.V, out.I, out.SOC = cap.ptr(bufs["t"]), cap.ptr(bufs["V"]), cap.ptr(bufs["I"]), cap.ptr(bufs["SOC"])
     out.T_avg = None
+    out.Y_all = None
+    if p.temperature:                   # per-step average temperature (calc_T_avg) only exists with temperature = true
+        bufs["T_avg"] = mk(n, mp) if device else np.zeros((n, mp))
+        out.T_avg = cap.ptr(bufs["T_avg"])
+    if keep_Y:                          # outputs = :all : every saved state vector
+        bufs["Y_all"] = mk(n, mp, N) if device else np.zeros((n, mp, N))
+        out.Y_all = cap.ptr(bufs["Y_all"])
     out.n_pts, out.Y_final, out.YP_final = cap.ptr(bufs["n_pts"]), cap.ptr(bufs["Y"]), cap.ptr(bufs["YP"])
     out.run_info, out.counters = cap.ptr(bufs["run_info"]), cap.ptr(bufs["counters"])
     cap.check(lib, lib.plh_integrate(h, n, cap.ptr(theta), cap.ptr(SOC0), cap.ptr(Y_init), cap.ptr(t_init), len(runs), arr,
@@ -323,6 +371,8 @@ class EnsembleSolution:
         self.t, self.V, self.I, self.SOC = bufs["t"], bufs["V"], bufs["I"], bufs["SOC"]
         self.n_pts = bufs["n_pts"]
         self.Y, self.YP = bufs["Y"], bufs["YP"]
+        self.T_avg = bufs.get("T_avg")          # [cell, point] with temperature = true
+        self.Y_all = bufs.get("Y_all")          # [cell, point, state] with outputs = "all"
         self.run_info = bufs["run_info"]
         self.counters = bufs["counters"]
         self.run_names = run_names
@@ -341,6 +391,11 @@ class EnsembleSolution:
         s.t, s.V, s.I, s.SOC = self.t[i, :n].copy(), self.V[i, :n].copy(), self.I[i, :n].copy(), self.SOC[i, :n].copy()
         s.P = s.I * calc_I1C(self.p.θ) * s.V
         s.Y, s.YP = self.Y[i].copy(), self.YP[i].copy()
+        s._ind = self.p.ind
+        if self.T_avg is not None:
+            s.T_avg = self.T_avg[i, :n].copy()
+        if self.Y_all is not None:
+            s.Y_all = self.Y_all[i, :n].copy()
         t0 = 0.0
         for k, nm in enumerate(self.run_names):
             ri = self.run_info[i, k]
@@ -366,11 +421,12 @@ def make_protocol(p, protocol):
     return runs, names
 
 
-def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, stream=None, max_points=None):
+def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, stream=None, max_points=None, outputs=None):
     """Integrate an ensemble of independent cells on this process's GPU.
 
     Theta: [n_cells, n_theta] array in `p.θ_keys` order (numpy = host memory; torch CUDA tensor with device=True = already in HBM).
     protocol: list of run dicts (see make_protocol) shared by all cells.  SOC: scalar or [n_cells] initial SOC.
+    outputs: "all" (or any state name) also returns every saved state vector as ens.Y_all [cell, point, state] -- 8 N bytes per point.
     """
     runs, names = make_protocol(p, protocol)
     o = opts or p.opts
@@ -381,7 +437,8 @@ def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, 
         soc0 = soc if hasattr(soc, "device") else torch.full((n,), float(soc), dtype=torch.float64, device=Theta.device)
     else:
         soc0 = np.full(n, float(soc)) if np.isscalar(soc) else np.asarray(soc, dtype=np.float64)
-    bufs = _integrate(p, Theta, soc0, runs, o, device=device, stream=stream, max_points=max_points)
+    bufs = _integrate(p, Theta, soc0, runs, o, device=device, stream=stream, max_points=max_points,
+                      keep_Y=_wants_states(p, o.outputs if outputs is None else outputs))
     if device:
         bufs["run_info"] = bufs["run_info"].cpu().numpy().view(cap.RUN_INFO_DTYPE).reshape(n, len(runs))
         bufs["counters"] = bufs["counters"].cpu().numpy().view(cap.COUNTERS_DTYPE).reshape(n)

@@ -518,7 +518,7 @@ __device__ inline void check_stop(const CellLDS<M>& S, const plh_run& run, const
 }
 
 struct CellOut {
-  double *t, *V, *I, *SOC, *T;
+  double *t, *V, *I, *SOC, *T, *Yall;
   int max_pts;
 };
 
@@ -544,6 +544,7 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
   }
   auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
     const double Tav = (M::THERMAL && out.T) ? cellTavg<M>(S, Y) : T0;
+    if constexpr (TAB) if (out.Yall && idx < out.max_pts) { PL_VEC(n) out.Yall[(size_t)idx * NST + n] = Y[n]; }      // outputs = :all
     if (lane == 0 && idx < out.max_pts) {
       if (out.t) out.t[idx] = tt;
       if (out.V) out.V[idx] = cellV<M>(Y);

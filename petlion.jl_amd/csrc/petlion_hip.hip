@@ -138,6 +138,7 @@ template <class M, bool TAB> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SI
   co.max_pts = a.out.max_pts;
   co.t = a.out.t ? a.out.t + off : nullptr; co.V = a.out.V ? a.out.V + off : nullptr; co.I = a.out.I ? a.out.I + off : nullptr;
   co.SOC = a.out.SOC ? a.out.SOC + off : nullptr; co.T = a.out.T_avg ? a.out.T_avg + off : nullptr;
+  co.Yall = a.out.Y_all ? a.out.Y_all + off * NST : nullptr;
   cell_simulate<TAB>(S, R, a.tb, a.SOC0[cell], a.Y_init ? a.Y_init + (size_t)cell * NST : nullptr, a.t_init ? a.t_init[cell] : 0.0, a.n_runs, a.runs, a.opts, co, a.out.n_pts ? a.out.n_pts + cell : nullptr,
                 a.out.run_info + (size_t)cell * a.n_runs, cnt,
                 a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
@@ -417,6 +418,19 @@ template <class M> static int build_patterns(plh_model_s* m) {
   return 0;
 }
 
+struct SectionInfo { const char* name; int start, len; };
+template <class M>
+static int sections_of(SectionInfo* o) {
+  int k = 0;
+  o[k++] = {"c_e", O_CE, NE}; o[k++] = {"c_s_avg", O_CS, NJ * NR};
+  if (M::THERMAL) o[k++] = {"T", M::O_T, NT};
+  if (M::SEI) { o[k++] = {"film", M::O_FILM, NN}; o[k++] = {"SOH", M::O_SOH, 1}; }
+  o[k++] = {"j", M::O_J, NJ}; o[k++] = {"Φ_e", M::O_PE, NE}; o[k++] = {"Φ_s", M::O_PS, NJ};
+  if (M::SEI) o[k++] = {"j_s", M::O_JS, NN};
+  o[k++] = {"I", M::O_I, 1};
+  return k;
+}
+
 extern "C" {
 
 const char* plh_last_error(void) { return g_err.c_str(); }
@@ -472,6 +486,15 @@ int plh_n_diff(plh_model_t m) { return m ? m->Nd : PLH_E_ARG; }
 int plh_n_theta(plh_model_t m) { return m ? m->P : PLH_E_ARG; }
 const char* plh_theta_key(plh_model_t m, int i) { return (m && i >= 0 && i < m->P) ? m->key_names[i] : nullptr; }
 double plh_theta_default(plh_model_t m, int i) { return (m && i >= 0 && i < m->P) ? m->key_defaults[i] : NAN; }
+
+int plh_n_sections(plh_model_t m) { if (!m) return PLH_E_ARG; SectionInfo s[12]; int n = 0; PL_DISPATCH(m, n = sections_of<M>(s)); return n; }
+int plh_section(plh_model_t m, int i, const char** name, int* start, int* len) {
+  if (!m) return fail(PLH_E_ARG, "null model");
+  SectionInfo s[12]; int n = 0; PL_DISPATCH(m, n = sections_of<M>(s));
+  if (i < 0 || i >= n) return fail(PLH_E_ARG, "section index out of range");
+  if (name) *name = s[i].name; if (start) *start = s[i].start; if (len) *len = s[i].len;
+  return 0;
+}
 
 int plh_jac_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval) {
   if (!m || !nnz) return fail(PLH_E_ARG, "null argument");
@@ -579,10 +602,11 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   a.out = *out;
   a.out.t = s.buf(out->t, np, false); a.out.V = s.buf(out->V, np, false); a.out.I = s.buf(out->I, np, false);
   a.out.SOC = s.buf(out->SOC, np, false); a.out.T_avg = s.buf(out->T_avg, np, false); a.out.n_pts = s.buf(out->n_pts, n, false);
+  a.out.Y_all = s.buf(out->Y_all, np * m->N, false);
   a.out.Y_final = s.buf(out->Y_final, (size_t)n * m->N, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * m->N, false);
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
   hipEventRecord(m->ev0, s.st);
-  bool tabular = opts->n_tdiscon > 0;
+  bool tabular = opts->n_tdiscon > 0 || out->Y_all;     // the general instantiation also carries the per-step state dump (outputs = :all)
   for (int r = 0; r < n_runs; r++) tabular = tabular || runs[r].value_kind == PLH_VAL_TABLE;
   if (tabular) PL_DISPATCH(m, PL_LAUNCH((k_integrate<M, true>), n, WAVE, s.st, a));
   else PL_DISPATCH(m, PL_LAUNCH((k_integrate<M, false>), n, WAVE, s.st, a));
@@ -590,7 +614,7 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   m->timed = true;
   FINISH(s);
   s.back(out->t, a.out.t, np); s.back(out->V, a.out.V, np); s.back(out->I, a.out.I, np); s.back(out->SOC, a.out.SOC, np);
-  s.back(out->T_avg, a.out.T_avg, np); s.back(out->n_pts, a.out.n_pts, n);
+  s.back(out->T_avg, a.out.T_avg, np); s.back(out->n_pts, a.out.n_pts, n); s.back(out->Y_all, a.out.Y_all, np * m->N);
   s.back(out->Y_final, a.out.Y_final, (size_t)n * m->N); s.back(out->YP_final, a.out.YP_final, (size_t)n * m->N);
   s.back(out->run_info, a.out.run_info, (size_t)n * n_runs); s.back(out->counters, a.out.counters, n);
   return 0;

@@ -262,3 +262,42 @@ def check_function_inputs(p, O, pkg):
 
 def test_function_inputs(emu_model, O, pkg):
     check_function_inputs(emu_model, O, pkg)
+
+
+def check_outputs_all(p, O, pkg, proto, soc):
+    """outputs = :all (reference solution_states_logic, src/outputs.jl:107-131; set_vars!, src/save_outputs.jl:11-40): every saved state vector
+    comes back as Y_all[cell, point, state] with the named sections of p.ind, plus T_avg per point when temperature = true."""
+    th = p.theta_vector()
+    ens = pkg.simulate_ensemble(p, np.tile(th, (2, 1)), proto, SOC=soc, outputs="all")
+    ref = pkg.simulate_ensemble(p, np.tile(th, (2, 1)), proto, SOC=soc)
+    n = int(ens.n_pts[0])
+    assert ref.Y_all is None and np.array_equal(ref.t[:, :n], ens.t[:, :n]) and np.array_equal(ref.Y, ens.Y)       # asking for the states changes nothing else
+    ro = O.simulate(p.variant, th, soc, parity.runs_to_oracle(O, p, pkg, proto), keep_Y=True)
+    parity.compare_trajectory(ens, 0, ro, rtol_state=1e-6)
+    assert n == len(ro["t"]) and ens.Y_all.shape == (2, ens.t.shape[1], p.N.tot)
+    assert np.array_equal(ens.Y_all[0, n - 1], ens.Y[0]) and np.array_equal(ens.Y_all[0, :n], ens.Y_all[1, :n])
+    for name, sl in p.ind.items():
+        a, b = ens.Y_all[0, :n, sl], ro["Y_all"][:, sl]
+        floor = {"j_s": 1e-13, "film": 1e-14}.get(name, 1e-300)
+        assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max() + floor, name                              # 1e-6 relative per section, every step
+    s = ens[0]
+    assert np.array_equal(s.Φ_s[:, 0] - s.Φ_s[:, -1], s.V) and np.array_equal(s.I, s.Y_all[:, p.ind["I"]][:, 0]) and s.c_e.shape == (n, 30)
+    if p.temperature:
+        assert np.abs(ens.T_avg[0, :n] - ro["T"]).max() < 1e-6 * 300 and s.T.shape == (n, 50)
+    else:
+        assert ens.T_avg is None
+        with pytest.raises(AttributeError):
+            s.T
+    # the single-cell API: outputs keyword, continuation keeps the states, sol(t) interpolates them
+    sol = pkg.simulate(p, proto[0].get("tf", 1e6), SOC=soc, outputs="all", **{k: v for k, v in proto[0].items() if k != "tf"})
+    assert np.array_equal(sol.Y_all, ens.Y_all[0, :len(sol.t)][:len(sol.t)]) or len(proto) > 1
+    mid = sol(0.5 * (sol.t[1] + sol.t[2]))
+    assert mid.Y_all.shape == (1, p.N.tot) and abs((mid.Φ_s[0, 0] - mid.Φ_s[0, -1]) - mid.V[0]) < 1e-9
+
+
+def test_outputs_all_states_per_step(emu_model, O, pkg):
+    check_outputs_all(emu_model, O, pkg, [{"I": -1.0, "tf": 400.0}], 1.0)
+
+
+def test_outputs_all_thermal(emu_model_thermal, O, pkg):
+    check_outputs_all(emu_model_thermal, O, pkg, [{"I": 3.0, "tf": 150.0}], 0.1)

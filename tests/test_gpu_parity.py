@@ -327,3 +327,10 @@ def test_c3_full_size_4096_cells_properties(hip_model_thermal, pkg):
     assert (ens.run_info["SOC"][:, 2] > 0.9).all() and (ens.run_info["SOC"][:, 2] <= 1.0 + 2e-3).all()
     T = ens.Y[:, 230:280]
     assert (T > 290).all() and (T < 320).all()
+
+
+def test_outputs_all_states_per_step(hip_model, hip_model_thermal, O, pkg):
+    """outputs = :all on the GPU: per-step state vectors and (thermal) per-step T_avg against the oracle, section by section at 1e-6"""
+    import test_device_source_emu as te
+    te.check_outputs_all(hip_model, O, pkg, [{"I": -1.0, "tf": 400.0}], 1.0)
+    te.check_outputs_all(hip_model_thermal, O, pkg, [{"I": 3.0, "tf": 150.0}], 0.1)
