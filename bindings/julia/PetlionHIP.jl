@@ -56,7 +56,7 @@ mutable struct Model
     N::Int; N_diff::Int; θ_keys::Vector{Symbol}
     function Model(p)   # p::PETLION.model -- reads only p.N and p.numerics
         N = p.N
-        chem = p.numerics.cathode == PETLION.LCO ? 0 : 1
+        chem = Symbol(p.numerics.cathode) == :LCO ? 0 : 1      # function name of the cathode system, as in strings_directory_func
         d = Ref(ModelDesc(chem, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, p.numerics.temperature == true, p.numerics.aging == :SEI, 8))
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:plh_model_create, lib), Cint, (Ref{ModelDesc}, Ref{Ptr{Cvoid}}), d, h), "plh_model_create")

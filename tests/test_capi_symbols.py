@@ -42,3 +42,34 @@ def test_unsupported_options_are_refused(pkg):
         pkg.petlion("LFP")
     with pytest.raises(NotImplementedError):
         pkg.petlion(pkg.LCO, aging="R_film")
+
+
+def test_julia_binding_matches_header(pkg):
+    """bindings/julia/*.jl cannot be executed here (no Julia): check statically that every `:plh_*` symbol they ccall is declared in the header and
+    that the Julia mirror structs have as many fields as the C structs they alias (a missing field would shift every later pointer)."""
+    jl = "".join(open(os.path.join(ROOT, "bindings", "julia", f)).read() for f in ("PetlionHIP.jl", "SavedModelWriter.jl"))
+    used = set(re.findall(r":(plh_[a-z_0-9]+)", jl))
+    assert used and used <= set(declared_symbols()), used - set(declared_symbols())
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "petlion_hip.h")).read(), flags=re.S)
+
+    def c_fields(name):
+        body = re.search(r"typedef struct \{([^}]*)\} %s;" % name, hdr).group(1)
+        n = 0
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                n += len(decl.split(","))
+        return n
+
+    def jl_fields(name):
+        body = re.search(r"struct %s\b[^\n]*\n(.*?)\nend" % name, jl, flags=re.S).group(1)
+        body = re.sub(r"#.*", "", body)
+        return len(re.findall(r"::", body))
+
+    for cname, jname in (("plh_model_desc", "ModelDesc"), ("plh_bounds", "Bounds"), ("plh_run", "Run"), ("plh_opts", "Opts"),
+                         ("plh_run_info", "RunInfo"), ("plh_counters", "Counters"), ("plh_outputs", "Outputs")):
+        assert c_fields(cname) == jl_fields(jname), (cname, c_fields(cname), jl_fields(jname))
+    # the ctypes mirrors used by the tests follow the same rule
+    cap = pkg._capi
+    for cname, st in (("plh_model_desc", cap.ModelDesc), ("plh_run", cap.Run), ("plh_opts", cap.Opts), ("plh_outputs", cap.Outputs)):
+        assert c_fields(cname) == len(st._fields_), cname
