@@ -55,6 +55,24 @@ def algorithmic_bytes(counters, n_pts):
     return float(b.sum())
 
 
+def usable_cores():
+    """cores this process can actually run on: the affinity mask, capped by the cgroup CPU quota (a container on a 256-core host may own 8)"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +210,43 @@ def main():
                                    "sample": "%d of the same C2 trajectories (1C discharge, identical params), run back to back on one host core by the "
                                              "oracle (plain-C IDA/KLU-style port, oracle/ida_oracle.c); %.1f s; host has %d cores; reference publishes "
                                              "2.616 ms/trajectory on an unspecified laptop (examples/getting_started.ipynb:183-192)" % (n_cpu, dt, os.cpu_count())}
+            # the same sample on every host core at once ("1 thread and all host cores"): one oracle context per thread, ctypes drops the GIL
+            from concurrent.futures import ThreadPoolExecutor
+            cores = usable_cores()
+            chunk, deadline = max(10, int(0.25 / per)), time.perf_counter() + 0.6 * args.cpu_seconds
+
+            def worker(_):
+                done = 0
+                while time.perf_counter() < deadline:            # time-bounded: chunks of ~0.25 s until the deadline
+                    assert O.run_batch("lco_iso", th, 1.0, runs, chunk)[0] == chunk
+                    done += chunk
+                return done
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                n_all = sum(ex.map(worker, range(cores)))
+            dt_all = time.perf_counter() - t1
+            out["cpu_baseline_all_cores"] = {"value": n_all / dt_all, "unit": "trajectories/s", "cores": cores, "kind": "port",
+                                             "sample": "%d of the same trajectories on %d oracle threads (the cores this process may use: affinity / cgroup quota; "
+                                                       "the machine reports %d logical cores); %.1f s; %.1fx the one-core rate" % (n_all, cores, os.cpu_count(), dt_all, n_all / dt_all / out["cpu_baseline"]["value"])}
+            # the same launch through host pointers (PLH_HOST: H2D of Theta, D2H of every output array) -- the PCIe-inclusive rate, never `value`
+            Th_host = pkg.theta_matrix(p, n_local)
+            pkg.simulate_ensemble(p, Th_host, protocol, SOC=1.0, max_points=256)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                pkg.simulate_ensemble(p, Th_host, protocol, SOC=1.0, max_points=256)
+            out["host_pointer_rate"] = {"value": 5 * n_local / (time.perf_counter() - t1), "unit": "trajectories/s",
+                                        "note": "plh_integrate with PLH_HOST pointers: pageable-memory staging of Theta in and t/V/I/SOC[256]/Y/YP/run_info/counters out per call"}
+            # measured device-to-device copy bandwidth of this box (read + write bytes), the second peak SURVEY 8(d) asks to quote
+            a = torch.empty(1 << 28, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
+            b.copy_(a); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                b.copy_(a)
+            e1.record(); torch.cuda.synchronize()
+            copy_gbps = 10 * 2 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            out["roofline"]["measured_copy_peak"] = copy_gbps
+            out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / copy_gbps
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
