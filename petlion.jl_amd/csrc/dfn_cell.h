@@ -33,7 +33,8 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false> struct ModelT {
   static constexpr bool SEI = SEI_;
   static constexpr bool THERMAL = THERMAL_;
   static constexpr bool EWT_LDS = !(SEI_ || THERMAL_);   // error weights kept in LDS (else recomputed from phi[0] where used: LDS diet)
-  static constexpr int PHI_LDS = THERMAL_ ? 4 : MAXORD + 1;   // BDF history vectors kept in LDS; the higher orders live in registers (LDS diet)
+  static constexpr int PHI_LDS = THERMAL_ ? 2 : MAXORD + 1;
+  static constexpr bool EE_LDS = !THERMAL_;          // accumulated Newton correction in LDS (else in registers, I.ee: LDS diet -> four thermal cells per CU)   // BDF history vectors kept in LDS; the higher orders live in registers (LDS diet)
   static constexpr int NB = THERMAL_ ? 4 : 3;        // node block size of the block-Thomas solve: (c_e, Phi_e, Phi_s[, T])
   static constexpr int O_T = N_CECS;
   static constexpr int O_FILM = N_CECS + (THERMAL_ ? NT : 0), O_SOH = O_FILM + NN;
@@ -125,7 +126,7 @@ template <> struct ThermalPool<true> {
 
 template <class M> struct CellLDS {
   double phi[M::PHI_LDS][M::NPAD];
-  double ewt[M::EWT_LDS ? M::NPAD : 2], yy[M::NPAD], yp[M::NPAD], ee[M::NPAD], delta[M::NPAD];
+  double ewt[M::EWT_LDS ? M::NPAD : 2], yy[M::NPAD], yp[M::NPAD], ee[M::EE_LDS ? M::NPAD : 2], delta[M::NPAD];
   // structured Jacobian pool (cj not included)
   double ceL[NE], ceD[NE], ceU[NE], ceJ[NE];
   double peL[NE], peD[NE], peU[NE], pcL[NE], pcD[NE], pcU[NE], peJ[NE];

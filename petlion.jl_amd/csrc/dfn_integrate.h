@@ -18,7 +18,8 @@ namespace pl {
 struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live in CellLDS (S.ida_*)
   double tn, hh, hused, cj, cjlast, cjold, cjratio, ss, rr, h0_forced, rtol, atol;
   double ew[6];      // per-lane error weights of this step for models that do not keep the vector in LDS (M::EWT_LDS == false)
-  double ph[2][6];   // per-lane entries of the BDF history vectors that are not kept in LDS (models with M::PHI_LDS < 6): [j - PHI_LDS][trip]
+  double ph[4][6];
+  double ee[6];      // accumulated Newton correction of the step (models with !M::EE_LDS)   // per-lane entries of the BDF history vectors that are not kept in LDS (models with M::PHI_LDS < 6): [j - PHI_LDS][trip]
   int kk, kused, knew, phase, ns, maxord;
   int nst;
 };
@@ -31,9 +32,12 @@ __device__ __forceinline__ void cnt_add(Counters& c, int k, int v = 1) { c.v[k] 
 // lane-strided sweep over the N state entries: exactly 5 trips (301 = 4*64 + 45), fully unrolled so that the LDS loads of all
 // trips are issued back to back (one latency instead of five); only the last trip is predicated.
 // BDF history access inside a PL_VEC loop (k__ = compile-time trip index): vectors j < M::PHI_LDS are LDS arrays, the rest registers in I.ph
-#define PHI_RD(j, n) ((M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? S.phi[(M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? (j) : 0][n] : I.ph[(j) - M::PHI_LDS][k__])
+#define PHI_RD(j, n) ((M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? S.phi[(M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? (j) : 0][n] : ((j) == M::PHI_LDS ? I.ph[0][k__] : ((j) == M::PHI_LDS + 1 ? I.ph[1][k__] : ((j) == M::PHI_LDS + 2 ? I.ph[2][k__] : I.ph[3][k__]))))
 #define PHI_WR(j, n, v) do { if (M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) S.phi[(M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? (j) : 0][n] = (v); \
-                             else if ((j) == M::PHI_LDS) I.ph[0][k__] = (v); else I.ph[1][k__] = (v); } while (0)
+                             else if ((j) == M::PHI_LDS) I.ph[0][k__] = (v); else if ((j) == M::PHI_LDS + 1) I.ph[1][k__] = (v); \
+                             else if ((j) == M::PHI_LDS + 2) I.ph[2][k__] = (v); else I.ph[3][k__] = (v); } while (0)
+// accumulated correction ee inside a PL_VEC loop
+#define EE(n) (*(M::EE_LDS ? &S.ee[M::EE_LDS ? (n) : 0] : &I.ee[k__]))
 #define PL_VEC(n) _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (k__ < NST / WAVE || n < NST)
 
 template <class M>
@@ -113,7 +117,7 @@ __device__ inline void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0
   I.cjratio = 1.0; I.ss = 20.0; I.phase = 0; I.ns = 0; I.h0_forced = 0.0; I.cj = 0.0; I.cjlast = 0.0; I.cjold = 0.0; I.rr = 0.0; I.knew = 0;
   if (lane <= MAXORD) { S.ida_psi[lane] = 0; S.ida_alpha[lane] = 0; S.ida_beta[lane] = 0; S.ida_sigma[lane] = 0; S.ida_gamma[lane] = 0; }
   PL_VEC(n) { S.phi[0][n] = y0[n]; S.phi[1][n] = yp0[n]; }
-  for (int q = 0; q < 6; q++) { I.ph[0][q] = 0.0; I.ph[1][q] = 0.0; }
+  for (int q = 0; q < 6; q++) { I.ph[0][q] = 0.0; I.ph[1][q] = 0.0; I.ph[2][q] = 0.0; I.ph[3][q] = 0.0; }
   PL_SYNC();
 }
 
@@ -175,7 +179,7 @@ __device__ inline double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
 
 // yy = ypred + ee, yp = yppred + cj ee with the predictor re-summed from phi (no separate predictor storage)
 template <class M>
-__device__ inline void form_iterate(CellLDS<M>& S, const IdaScalars& I) {
+__device__ inline void form_iterate(CellLDS<M>& S, IdaScalars& I) {
   PL_MODEL(M);
   const int lane = lane_id();
   // history vector outermost, the lane's trips innermost: the LDS loads of one order are issued back to back (a runtime-bounded inner
@@ -186,7 +190,7 @@ __device__ inline void form_iterate(CellLDS<M>& S, const IdaScalars& I) {
     const double g = S.ida_gamma[j];
     PL_VEC(n) { const double p = PHI_RD(j, n); a[k__] += p; b[k__] += g * p; }
   }
-  PL_VEC(n) { const double e = S.ee[n]; S.yy[n] = a[k__] + e; S.yp[n] = b[k__] + I.cj * e; }
+  PL_VEC(n) { const double e = EE(n); S.yy[n] = a[k__] + e; S.yp[n] = b[k__] + I.cj * e; }
   PL_SYNC();
 }
 
@@ -205,7 +209,7 @@ __device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaS
     if (I.cj != I.cjlast) I.ss = 100.0;
     if (jac_every_step) callLSetup = 1;
   }
-  PL_VEC(n) S.ee[n] = 0.0;
+  PL_VEC(n) EE(n) = 0.0;
   PL_SYNC();
   int jcur = 0, ret = 0;
   for (;;) {
@@ -232,7 +236,7 @@ __device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaS
       PL_TIC();
       const double sc = (I.cjratio != 1.0) ? -2.0 / (1.0 + I.cjratio) : -1.0;
       double s = 0.0;
-      PL_VEC(n) { const double d = S.delta[n] * sc; S.ee[n] += d; const double p = d * EWT(n); s += p * p; }
+      PL_VEC(n) { const double d = S.delta[n] * sc; EE(n) += d; const double p = d * EWT(n); s += p * p; }
       const double delnrm = sqrt(wave_sum(s) * (1.0 / NST));
       PL_SYNC();
       ret = 2;
@@ -247,7 +251,7 @@ __device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaS
       { PL_TIC(); form_iterate(S, I); PL_TOC(S, PH_NEWTVEC); }
       { PL_TIC(); cell_residual(S, R, S.yy, S.yp, S.delta, mode, value); cnt_add(cnt, C_RES); PL_TOC(S, PH_RES); }
     }
-    if (ret > 0 && !jcur) { callLSetup = 1; PL_VEC(n) S.ee[n] = 0.0; PL_SYNC(); continue; }
+    if (ret > 0 && !jcur) { callLSetup = 1; PL_VEC(n) EE(n) = 0.0; PL_SYNC(); continue; }
     break;
   }
   form_iterate(S, I);
@@ -261,7 +265,7 @@ __device__ inline int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, do
   const int kk = I.kk;
   double s0 = 0, s1 = 0, s2 = 0;
   PL_VEC(n) {
-    const double w = EWT(n), e = S.ee[n];
+    const double w = EWT(n), e = EE(n);
     double p = e * w; s0 += p * p;
     if (kk > 1) { const double d1 = PHI_RD(kk, n) + e; p = d1 * w; s1 += p * p;
       if (kk > 2) { const double d2 = d1 + PHI_RD(kk - 1, n); p = d2 * w; s2 += p * p; } }
@@ -305,7 +309,7 @@ __device__ inline void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double er
     else if (I.kk + 1 >= I.ns || kdiff == 1) action = 2;
     if (action == 0) {
       double s = 0.0;
-      PL_VEC(n) { const double p = (S.ee[n] - PHI_RD(I.kk + 1, n)) * EWT(n); s += p * p; }
+      PL_VEC(n) { const double p = (EE(n) - PHI_RD(I.kk + 1, n)) * EWT(n); s += p * p; }
       const double enorm = sqrt(wave_sum(s) * (1.0 / NST)); err_kp1 = enorm / (I.kk + 2);
       const double terr_k = (I.kk + 1) * err_k, terr_kp1 = (I.kk + 2) * err_kp1;
       if (I.kk == 1) action = (terr_kp1 >= 0.5 * terr_k) ? 2 : 3;
@@ -321,7 +325,7 @@ __device__ inline void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double er
   const int ku = I.kused;
   {   // phi update (running sums from the top order down), orders outermost / trips innermost as in form_iterate
     double acc[NTRIP];
-    PL_VEC(n) { const double e = S.ee[n]; if (ku < I.maxord) PHI_WR(ku + 1, n, e); acc[k__] = PHI_RD(ku, n) + e; PHI_WR(ku, n, acc[k__]); }
+    PL_VEC(n) { const double e = EE(n); if (ku < I.maxord) PHI_WR(ku + 1, n, e); acc[k__] = PHI_RD(ku, n) + e; PHI_WR(ku, n, acc[k__]); }
     _Pragma("unroll") for (int j = MAXORD - 1; j >= 0; j--) if (j < ku) {
       PL_VEC(n) { acc[k__] += PHI_RD(j, n); PHI_WR(j, n, acc[k__]); }
     }
@@ -346,7 +350,7 @@ __device__ inline void ida_get_solution(CellLDS<M>& S, const IdaScalars& I, doub
   PL_GS_STEP(1, rp0, rp1, c1, d0) PL_GS_STEP(2, rp1, rp2, c2, d1) PL_GS_STEP(3, rp2, rp3, c3, d2) PL_GS_STEP(4, rp3, rp4, c4, d3) PL_GS_STEP(5, rp4, rp5, c5, d4)
 #undef PL_GS_STEP
   PL_VEC(n) {
-    const double p1 = S.phi[1][n], p2 = S.phi[2][n], p3 = S.phi[3][n], p4 = PHI_RD(4, n), p5 = PHI_RD(5, n);
+    const double p1 = S.phi[1][n], p2 = PHI_RD(2, n), p3 = PHI_RD(3, n), p4 = PHI_RD(4, n), p5 = PHI_RD(5, n);
     double s = S.phi[0][n] + c1 * p1, sp = d0 * p1;
     if (kord >= 2) { s += c2 * p2; sp += d1 * p2; }
     if (kord >= 3) { s += c3 * p3; sp += d2 * p3; }
@@ -608,7 +612,7 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     bool first_init = true, again = false, init_failed = false;
     do {                                                                // (re)initialise -> integrate ; loops only for check_reinitialization!
     again = false;
-    int ierr; { PL_TIC(); ierr = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, o.reltol_init, cnt); PL_TOC(S, PH_INIT); }
+    int ierr; { PL_TIC(); ierr = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, M::EE_LDS ? S.ee : S.phi[1], mode, value, o.reltol_init, cnt); PL_TOC(S, PH_INIT); }
     if (ierr != 0) { if (first_init) init_failed = true; else flag = ierr; ri.flag = ierr; break; }
     ida_reinit(S, I, S.yy, S.yp, first_init ? (o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD) : I.maxord, t_restart);
     if (first_init) {

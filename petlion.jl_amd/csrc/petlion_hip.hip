@@ -91,7 +91,7 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec<M>(S.yy, Y + (size_t)cell * NST); load_vec<M>(S.yp, YP + (size_t)cell * NST); load_vec<M>(S.delta, b + (size_t)cell * NST);
   PL_SYNC();
-  cell_res_jac(S, R, S.yy, S.yp, S.ee, mode, 0.0);
+  cell_res_jac(S, R, S.yy, S.yp, S.phi[1], mode, 0.0);
   cell_factor(S, R, tb, cj, mode, false);
   cell_solve(S, R, S.delta, mode, false);
   store_vec<M>(b + (size_t)cell * NST, S.delta);
@@ -109,7 +109,7 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   PL_SYNC();
   Counters cnt; for (int k = 0; k < 10; k++) cnt.v[k] = 0;
   PL_SYNC();
-  const int rc = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.ee, mode, value, reltol_init, cnt);
+  const int rc = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, reltol_init, cnt);
   store_vec<M>(Y + (size_t)cell * NST, S.yy); store_vec<M>(YP + (size_t)cell * NST, S.yp);
   PL_SYNC();
   if (lane_id() == 0) { if (status) status[cell] = rc; if (iters) iters[cell] = cnt.v[C_INIT]; }
