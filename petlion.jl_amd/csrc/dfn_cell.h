@@ -32,9 +32,9 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false> struct ModelT {
   static constexpr int CHEM = CHEM_;                 // PLH_CHEM_LCO_LIC6 / PLH_CHEM_NMC_LIC6
   static constexpr bool SEI = SEI_;
   static constexpr bool THERMAL = THERMAL_;
-  static constexpr bool EWT_LDS = !(SEI_ || THERMAL_);   // error weights kept in LDS (else recomputed from phi[0] where used: LDS diet)
-  static constexpr int PHI_LDS = THERMAL_ ? 2 : MAXORD + 1;
-  static constexpr bool EE_LDS = !THERMAL_;          // accumulated Newton correction in LDS (else in registers, I.ee: LDS diet -> four thermal cells per CU)   // BDF history vectors kept in LDS; the higher orders live in registers (LDS diet)
+  // LDS diet: the error weights and the accumulated Newton correction live in registers (IdaScalars::ew / ee: they are only touched by the
+  // lane-strided vector phases), and so do the BDF history vectors of order >= PHI_LDS
+  static constexpr int PHI_LDS = THERMAL_ ? 2 : MAXORD + 1;   // thermal: 40.7 kB -> four cells per CU
   static constexpr int NB = THERMAL_ ? 4 : 3;        // node block size of the block-Thomas solve: (c_e, Phi_e, Phi_s[, T])
   static constexpr int O_T = N_CECS;
   static constexpr int O_FILM = N_CECS + (THERMAL_ ? NT : 0), O_SOH = O_FILM + NN;
@@ -126,7 +126,7 @@ template <> struct ThermalPool<true> {
 
 template <class M> struct CellLDS {
   double phi[M::PHI_LDS][M::NPAD];
-  double ewt[M::EWT_LDS ? M::NPAD : 2], yy[M::NPAD], yp[M::NPAD], ee[M::EE_LDS ? M::NPAD : 2], delta[M::NPAD];
+  double yy[M::NPAD], yp[M::NPAD], delta[M::NPAD];
   // structured Jacobian pool (cj not included)
   double ceL[NE], ceD[NE], ceU[NE], ceJ[NE];
   double peL[NE], peD[NE], peU[NE], pcL[NE], pcD[NE], pcU[NE], peJ[NE];

@@ -17,9 +17,9 @@ namespace pl {
 
 struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live in CellLDS (S.ida_*)
   double tn, hh, hused, cj, cjlast, cjold, cjratio, ss, rr, h0_forced, rtol, atol;
-  double ew[6];      // per-lane error weights of this step for models that do not keep the vector in LDS (M::EWT_LDS == false)
+  double ew[6];      // per-lane error weights of this step
   double ph[4][6];
-  double ee[6];      // accumulated Newton correction of the step (models with !M::EE_LDS)   // per-lane entries of the BDF history vectors that are not kept in LDS (models with M::PHI_LDS < 6): [j - PHI_LDS][trip]
+  double ee[6];      // per-lane accumulated Newton correction of the step   // per-lane entries of the BDF history vectors that are not kept in LDS (models with M::PHI_LDS < 6): [j - PHI_LDS][trip]
   int kk, kused, knew, phase, ns, maxord;
   int nst;
 };
@@ -37,7 +37,7 @@ __device__ __forceinline__ void cnt_add(Counters& c, int k, int v = 1) { c.v[k] 
                              else if ((j) == M::PHI_LDS) I.ph[0][k__] = (v); else if ((j) == M::PHI_LDS + 1) I.ph[1][k__] = (v); \
                              else if ((j) == M::PHI_LDS + 2) I.ph[2][k__] = (v); else I.ph[3][k__] = (v); } while (0)
 // accumulated correction ee inside a PL_VEC loop
-#define EE(n) (*(M::EE_LDS ? &S.ee[M::EE_LDS ? (n) : 0] : &I.ee[k__]))
+#define EE(n) I.ee[k__]
 #define PL_VEC(n) _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (k__ < NST / WAVE || n < NST)
 
 template <class M>
@@ -121,16 +121,16 @@ __device__ inline void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0
   PL_SYNC();
 }
 
-// error weights: IDA evaluates ewt from phi[0] = y_n at the start of every step.  Kept in LDS (S.ewt) or, for the LDS-lean models, in
-// six registers per lane (I.ew[trip]); EWT(n) reads it inside a PL_VEC loop.
+// error weights: IDA evaluates ewt from phi[0] = y_n at the start of every step.  Kept in six registers per lane (I.ew[trip]); EWT(n) reads
+// it inside a PL_VEC loop.
 template <class M>
 __device__ inline void set_ewt(CellLDS<M>& S, IdaScalars& I, double rtol, double atol) {
   PL_MODEL(M);
   const int lane = lane_id();
-  PL_VEC(n) { const double w = 1.0 / (rtol * fabs(S.phi[0][n]) + atol); if constexpr (M::EWT_LDS) S.ewt[n] = w; else I.ew[k__] = w; }
+  PL_VEC(n) { const double w = 1.0 / (rtol * fabs(S.phi[0][n]) + atol); I.ew[k__] = w; }
   PL_SYNC();
 }
-#define EWT(n) (M::EWT_LDS ? S.ewt[M::EWT_LDS ? (n) : 0] : I.ew[k__])
+#define EWT(n) I.ew[k__]
 
 template <class M>
 __device__ inline double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
@@ -612,7 +612,7 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     bool first_init = true, again = false, init_failed = false;
     do {                                                                // (re)initialise -> integrate ; loops only for check_reinitialization!
     again = false;
-    int ierr; { PL_TIC(); ierr = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, M::EE_LDS ? S.ee : S.phi[1], mode, value, o.reltol_init, cnt); PL_TOC(S, PH_INIT); }
+    int ierr; { PL_TIC(); ierr = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt); PL_TOC(S, PH_INIT); }
     if (ierr != 0) { if (first_init) init_failed = true; else flag = ierr; ri.flag = ierr; break; }
     ida_reinit(S, I, S.yy, S.yp, first_init ? (o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD) : I.maxord, t_restart);
     if (first_init) {
