@@ -35,6 +35,7 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false> struct ModelT {
   // LDS diet: the error weights and the accumulated Newton correction live in registers (IdaScalars::ew / ee: they are only touched by the
   // lane-strided vector phases), and so do the BDF history vectors of order >= PHI_LDS
   static constexpr int PHI_LDS = THERMAL_ ? 2 : MAXORD + 1;   // thermal: 40.7 kB -> four cells per CU
+  static constexpr bool PRED_REGS = !THERMAL_ && !SEI_;       // predictor (y, y') of the step kept in registers across the Newton iteration (else re-summed from phi)
   static constexpr int NB = THERMAL_ ? 4 : 3;        // node block size of the block-Thomas solve: (c_e, Phi_e, Phi_s[, T])
   static constexpr int O_T = N_CECS;
   static constexpr int O_FILM = N_CECS + (THERMAL_ ? NT : 0), O_SOH = O_FILM + NN;
@@ -170,6 +171,14 @@ __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
 #define PL_SYNC() __syncthreads()
 #else
 #define PL_SYNC() __asm__ volatile("" ::: "memory")
+#endif
+
+// Emulator only: with PL_EMU_POISON=1 in the environment the LDS block starts as garbage (on the GPU it holds whatever the previous workgroup
+// left there; the emulator's static storage would hide a read of never-written LDS behind zeros).  tests/wave_emu poisons the lane stacks too.
+#ifdef PL_WAVE_EMU
+#define PL_EMU_POISON(S_) do { if (getenv("PL_EMU_POISON")) { if (lane_id() == 0) memset((void*)&(S_), 0x7f, sizeof(S_)); __syncthreads(); } } while (0)
+#else
+#define PL_EMU_POISON(S_) do {} while (0)
 #endif
 
 // optional per-phase cycle accounting (profiling build: -DPL_PHASE_TIMERS)

@@ -19,7 +19,8 @@ struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live 
   double tn, hh, hused, cj, cjlast, cjold, cjratio, ss, rr, h0_forced, rtol, atol;
   double ew[6];      // per-lane error weights of this step
   double ph[4][6];
-  double ee[6];      // per-lane accumulated Newton correction of the step   // per-lane entries of the BDF history vectors that are not kept in LDS (models with M::PHI_LDS < 6): [j - PHI_LDS][trip]
+  double ee[6];      // per-lane accumulated Newton correction of the step
+  double pa[6], pb[6];   // predictor y_n(0), y'_n(0) of the step (models with M::PRED_REGS)   // per-lane entries of the BDF history vectors that are not kept in LDS (models with M::PHI_LDS < 6): [j - PHI_LDS][trip]
   int kk, kused, knew, phase, ns, maxord;
   int nst;
 };
@@ -179,9 +180,14 @@ __device__ inline double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
 
 // yy = ypred + ee, yp = yppred + cj ee with the predictor re-summed from phi (no separate predictor storage)
 template <class M>
-__device__ inline void form_iterate(CellLDS<M>& S, IdaScalars& I) {
+__device__ inline void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
   PL_MODEL(M);
   const int lane = lane_id();
+  if (M::PRED_REGS && !first) {          // the predictor of this step is already in registers
+    PL_VEC(n) { const double e = EE(n); S.yy[n] = I.pa[k__] + e; S.yp[n] = I.pb[k__] + I.cj * e; }
+    PL_SYNC();
+    return;
+  }
   // history vector outermost, the lane's trips innermost: the LDS loads of one order are issued back to back (a runtime-bounded inner
   // loop over the orders would expose one LDS round trip per order and trip); same summation order as before
   double a[NTRIP], b[NTRIP];
@@ -190,7 +196,7 @@ __device__ inline void form_iterate(CellLDS<M>& S, IdaScalars& I) {
     const double g = S.ida_gamma[j];
     PL_VEC(n) { const double p = PHI_RD(j, n); a[k__] += p; b[k__] += g * p; }
   }
-  PL_VEC(n) { const double e = EE(n); S.yy[n] = a[k__] + e; S.yp[n] = b[k__] + I.cj * e; }
+  PL_VEC(n) { const double e = EE(n); S.yy[n] = a[k__] + e; S.yp[n] = b[k__] + I.cj * e; if (M::PRED_REGS) { I.pa[k__] = a[k__]; I.pb[k__] = b[k__]; } }
   PL_SYNC();
 }
 
@@ -211,15 +217,18 @@ __device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaS
   }
   PL_VEC(n) EE(n) = 0.0;
   PL_SYNC();
-  int jcur = 0, ret = 0;
-  for (;;) {
-    { PL_TIC(); form_iterate(S, I); PL_TOC(S, PH_NEWTVEC); }
+  // One loop, one site per phase (form_iterate, residual + Jacobian + factorisation, residual, solve): every device function is inlined into the
+  // kernel, so each extra call site would be another copy of the node pass in the instruction stream of the hot loop.
+  int jcur = 0, ret = 0, m = 0; bool done = false; double oldnrm = 0.0;
+  for (bool first = true;; first = false) {
+    { PL_TIC(); form_iterate(S, I, first); PL_TOC(S, PH_NEWTVEC); }
+    if (done) break;                                      // the iterate (yy, yp) now includes the last correction
     if (callLSetup) {
       PL_TIC();
       cell_res_jac(S, R, S.yy, S.yp, S.delta, mode, value);
       cell_factor(S, R, tb, I.cj, mode, false);
       cnt_add(cnt, C_RES); cnt_add(cnt, C_JAC); cnt_add(cnt, C_FACT);
-      I.cjold = I.cj; I.cjratio = 1.0; I.ss = 20.0; jcur = 1;
+      I.cjold = I.cj; I.cjratio = 1.0; I.ss = 20.0; jcur = 1; callLSetup = 0;
       PL_TOC(S, PH_JACFACT);
     } else {
       PL_TIC();
@@ -227,34 +236,26 @@ __device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaS
       cnt_add(cnt, C_RES);
       PL_TOC(S, PH_RES);
     }
-    int m = 0; double oldnrm = 0.0;
-    for (;;) {
-      cnt_add(cnt, C_NEWTON); cnt_add(cnt, C_SOLVE);
-      { PL_TIC();
-      cell_solve(S, R, S.delta, mode, false);           // x = J^-1 F ; the Newton correction is -x
-      PL_TOC(S, PH_SOLVE); }
-      PL_TIC();
-      const double sc = (I.cjratio != 1.0) ? -2.0 / (1.0 + I.cjratio) : -1.0;
-      double s = 0.0;
-      PL_VEC(n) { const double d = S.delta[n] * sc; EE(n) += d; const double p = d * EWT(n); s += p * p; }
-      const double delnrm = sqrt(wave_sum(s) * (1.0 / NST));
-      PL_SYNC();
-      ret = 2;
-      if (m == 0) { oldnrm = delnrm; if (delnrm <= toldel) ret = 0; }
-      else { const double q = delnrm / oldnrm; const double rate = (m == 1) ? q : pow(q, 1.0 / m); if (rate > 0.9) ret = 1; else I.ss = rate / (1.0 - rate); }
-      if (ret == 2 && I.ss * delnrm <= epsNewt) ret = 0;
-      if (!(delnrm == delnrm)) ret = 1;
-      PL_TOC(S, PH_NEWTVEC);
-      if (ret == 0) { jcur = 0; break; }
-      if (ret != 2) break;
-      m++; if (m >= 4) { ret = 1; break; }
-      { PL_TIC(); form_iterate(S, I); PL_TOC(S, PH_NEWTVEC); }
-      { PL_TIC(); cell_residual(S, R, S.yy, S.yp, S.delta, mode, value); cnt_add(cnt, C_RES); PL_TOC(S, PH_RES); }
-    }
-    if (ret > 0 && !jcur) { callLSetup = 1; PL_VEC(n) EE(n) = 0.0; PL_SYNC(); continue; }
-    break;
+    cnt_add(cnt, C_NEWTON); cnt_add(cnt, C_SOLVE);
+    { PL_TIC();
+    cell_solve(S, R, S.delta, mode, false);           // x = J^-1 F ; the Newton correction is -x
+    PL_TOC(S, PH_SOLVE); }
+    PL_TIC();
+    const double sc = (I.cjratio != 1.0) ? -2.0 / (1.0 + I.cjratio) : -1.0;
+    double s = 0.0;
+    PL_VEC(n) { const double d = S.delta[n] * sc; EE(n) += d; const double p = d * EWT(n); s += p * p; }
+    const double delnrm = sqrt(wave_sum(s) * (1.0 / NST));
+    PL_SYNC();
+    ret = 2;
+    if (m == 0) { oldnrm = delnrm; if (delnrm <= toldel) ret = 0; }
+    else { const double q = delnrm / oldnrm; const double rate = (m == 1) ? q : pow(q, 1.0 / m); if (rate > 0.9) ret = 1; else I.ss = rate / (1.0 - rate); }
+    if (ret == 2 && I.ss * delnrm <= epsNewt) ret = 0;
+    if (!(delnrm == delnrm)) ret = 1;
+    PL_TOC(S, PH_NEWTVEC);
+    if (ret == 2) { m++; if (m < 4) continue; ret = 1; }  // another iteration with the same matrix
+    if (ret == 1 && !jcur) { callLSetup = 1; m = 0; PL_VEC(n) EE(n) = 0.0; PL_SYNC(); continue; }   // failed with a stale Jacobian: refresh and restart
+    done = true;                                            // converged (0) or failed with a current Jacobian (1)
   }
-  form_iterate(S, I);
   return ret;
 }
 

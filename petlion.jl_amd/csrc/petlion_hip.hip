@@ -41,6 +41,7 @@ template <class M> __device__ __forceinline__ void store_vec(double* __restrict_
 
 template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_initial_guess(const Tables* tb, int n_cells, const double* theta, const double* SOC, double* Y) {
   __shared__ CellLDS<M> S;
+  PL_EMU_POISON(S);
   constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;
@@ -53,6 +54,7 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
 template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_residual(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                  int mode, double value, double* F) {
   __shared__ CellLDS<M> S;
+  PL_EMU_POISON(S);
   constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;
@@ -67,6 +69,7 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
 template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_jacobian(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                  double cj, int mode, double* nz) {
   __shared__ CellLDS<M> S;
+  PL_EMU_POISON(S);
   constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;
@@ -84,6 +87,7 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
 template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_linear_solve(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                      double cj, int mode, double* b) {
   __shared__ CellLDS<M> S;
+  PL_EMU_POISON(S);
   constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;
@@ -100,6 +104,7 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
 template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_init_consistent(const Tables* tb, int n_cells, const double* theta, int mode, double value,
                                                         double reltol_init, double* Y, double* YP, int* status, int* iters) {
   __shared__ CellLDS<M> S;
+  PL_EMU_POISON(S);
   constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;
@@ -122,6 +127,7 @@ struct IntegrateArgs {
 
 template <class M, bool TAB> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_integrate(IntegrateArgs a) {
   __shared__ CellLDS<M> S;
+  PL_EMU_POISON(S);
   constexpr int NST = M::NST;
   LaneRegs R;
   const int cell = blockIdx.x;

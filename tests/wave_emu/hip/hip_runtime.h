@@ -52,14 +52,20 @@ inline void run_block(unsigned b, unsigned grid, const std::function<void()>& bo
   const size_t STK = 1 << 20;
   if (s.stacks.empty()) for (int l = 0; l < LANES; l++) s.stacks.push_back((char*)malloc(STK));
   s.body = body; s.block = b; s.grid = grid;
+  static const bool poison = getenv("PL_EMU_POISON") != nullptr;     // uninitialised locals read garbage instead of a recycled stack
   for (int l = 0; l < LANES; l++) {
+    if (poison) memset(s.stacks[l], 0x7f, STK);
     s.done[l] = false; getcontext(&s.lane_ctx[l]);
     s.lane_ctx[l].uc_stack.ss_sp = s.stacks[l]; s.lane_ctx[l].uc_stack.ss_size = STK; s.lane_ctx[l].uc_link = &s.main_ctx;
     makecontext(&s.lane_ctx[l], (void (*)())lane_entry, 0);
   }
   for (;;) {
     int alive = 0;
-    for (int l = 0; l < LANES; l++) if (!s.done[l]) { alive++; s.cur = l; swapcontext(&s.main_ctx, &s.lane_ctx[l]); }
+    // PL_EMU_ORDER=reverse runs the lanes 63..0 between sync points: a cross-lane LDS hand-over that lacks a sync point (= a compiler
+    // barrier on the GPU, where nothing else stops the compiler from moving the load above the store) then reads stale data in one of the
+    // two orders, so the tests are run in both
+    static const bool rev = getenv("PL_EMU_ORDER") && !strcmp(getenv("PL_EMU_ORDER"), "reverse");
+    for (int q = 0; q < LANES; q++) { const int l = rev ? LANES - 1 - q : q; if (!s.done[l]) { alive++; s.cur = l; swapcontext(&s.main_ctx, &s.lane_ctx[l]); } }
     if (!alive) break;
   }
 }

@@ -13,7 +13,7 @@ src = os.path.join(ROOT, "petlion.jl_amd", "csrc", "petlion_hip.hip")
 csrc = os.path.dirname(src)
 newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc))
 if not os.path.exists(lib) or os.path.getmtime(lib) < newest:
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-pass-failed", "-mllvm", "-amdgpu-function-calls=false",
                            "-DPL_PHASE_TIMERS", src, "-o", lib])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 which = sys.argv[2] if len(sys.argv) > 2 else "iso"
