@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpetlion_hip.so")
+LIB_PATH = os.environ.get("PETLION_HIP_LIB") or os.path.join(HERE, "libpetlion_hip.so")     # the override is for build experiments (tools/opt_level_check.sh)
 
 PLH_HOST, PLH_DEVICE = 0, 1
 MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETA_P = 0, 1, 2, 3, 4
