@@ -1,6 +1,8 @@
 """CPU-side checks of the DEVICE SOURCE (petlion.jl_amd/csrc/*.h, *.hip) through the test-only lock-step wave emulator
 (tests/wave_emu): the same C ABI, the same kernels, 64 emulated lanes.  The GPU versions of these checks are in
 test_gpu_parity.py; this file is what keeps the device code testable in a container without a GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -301,3 +303,16 @@ def test_outputs_all_states_per_step(emu_model, O, pkg):
 
 def test_outputs_all_thermal(emu_model_thermal, O, pkg):
     check_outputs_all(emu_model_thermal, O, pkg, [{"I": 3.0, "tf": 150.0}], 0.1)
+
+
+def test_emulator_hostile_modes():
+    """The same device-source tests with the emulator's LDS block and lane stacks starting as garbage (PL_EMU_POISON: on the GPU LDS holds what the
+    previous workgroup left) and the lanes run 63..0 between sync points (PL_EMU_ORDER=reverse: a cross-lane LDS hand-over that lacks a sync point --
+    on the GPU only a compiler barrier keeps the load below the store -- reads stale data in one of the two orders).  The environment is read once
+    per process, hence the subprocess."""
+    import subprocess, sys
+    env = dict(os.environ, PL_EMU_POISON="1", PL_EMU_ORDER="reverse")
+    sel = "cc_discharge_trajectory or lco_sei_aging or outputs_all_thermal or power_and_plating"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", sel, "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
