@@ -29,6 +29,7 @@ end
 struct Run
     mode::Cint; value_kind::Cint; value::Cdouble; tf::Cdouble; bounds::Bounds
     n_tab::Cint; tab_t::Ptr{Cdouble}; tab_v::Ptr{Cdouble}     # VAL_TABLE: piecewise-linear input in run-local time (host arrays)
+    value_cell::Ptr{Cdouble}; tf_cell::Ptr{Cdouble}           # per-cell input value / run length ([n_cells] host arrays) or C_NULL
 end
 struct Opts
     abstol::Cdouble; reltol::Cdouble; abstol_init::Cdouble; reltol_init::Cdouble
@@ -90,10 +91,11 @@ function make_run(p, step::NamedTuple)
     b = bounds_of(p.bounds; kw...)
     tf = Float64(get(step, :tf, 1e6))
     if x isa Tuple{Vector{Float64},Vector{Float64}}      # (t, values): a tabulated I(t) / V(t) / P(t); the caller keeps the two vectors alive (GC.@preserve)
-        return Run(MODE[name], VAL_TABLE, x[2][1], tf, b, length(x[1]), pointer(x[1]), pointer(x[2]))
+        return Run(MODE[name], VAL_TABLE, x[2][1], tf, b, length(x[1]), pointer(x[1]), pointer(x[2]), C_NULL, C_NULL)
     end
+    x isa Vector{Float64} && return Run(MODE[name], VAL_CONST, x[1], tf, b, 0, C_NULL, C_NULL, pointer(x), C_NULL)   # one value per cell (caller keeps x alive)
     kind, val = x === :hold ? (VAL_HOLD, 0.0) : x === :rest ? (VAL_REST, 0.0) : (VAL_CONST, Float64(x))
-    Run(MODE[name], kind, val, tf, b, 0, C_NULL, C_NULL)
+    Run(MODE[name], kind, val, tf, b, 0, C_NULL, C_NULL, C_NULL, C_NULL)
 end
 
 """

@@ -85,6 +85,9 @@ typedef struct {
      piecewise-linear table; a repeated knot time is a jump (right-continuous), the last value holds beyond the last knot.  The arrays are HOST
      memory like the protocol itself (plh_integrate stages them).  List jump times in plh_opts.tdiscon as with the reference's `tdiscon`. */
   int n_tab; const double* tab_t; const double* tab_v;
+  /* ensemble axis of the protocol itself: per-cell input value (PLH_VAL_CONST only, e.g. a C-rate sweep) and per-cell run length, [n_cells] HOST
+     arrays staged by plh_integrate; NULL = every cell uses `value` / `tf`.  (New: the reference runs one cell per simulate() call.) */
+  const double* value_cell; const double* tf_cell;
 } plh_run;
 
 /* reference options_simulation (src/structures.jl:266-285), the numerical subset */

@@ -129,9 +129,18 @@ def _make_run(p, name, inp, tf, bounds):
         r.n_tab = tt.size
         r.tab_t = tt.ctypes.data_as(C.POINTER(C.c_double)); r.tab_v = vv.ctypes.data_as(C.POINTER(C.c_double))
         r._keep = (tt, vv)                              # keep the arrays alive as long as the run descriptor
+    elif isinstance(inp, np.ndarray) and inp.ndim == 1:                       # one constant input per cell (ensemble axis of the protocol)
+        vv = np.ascontiguousarray(inp, dtype=np.float64)
+        r.value_kind, r.value = cap.VAL_CONST, float(vv[0])
+        r.value_cell = vv.ctypes.data_as(C.POINTER(C.c_double))
+        r._keep = (vv,)
     else:
         r.value_kind, r.value = cap.VAL_CONST, float(inp)
-    r.tf = float(tf)
+    if isinstance(tf, np.ndarray):                                            # one run length per cell
+        tt_ = np.ascontiguousarray(tf, dtype=np.float64)
+        r.tf = float(tt_[0]); r.tf_cell = tt_.ctypes.data_as(C.POINTER(C.c_double)); r._keep_tf = tt_
+    else:
+        r.tf = float(tf)
     for f in cap.BOUND_FIELDS:
         setattr(r.bounds, f, getattr(bounds, "η_plating_min" if f == "eta_plating_min" else f))
     return r
@@ -405,9 +414,10 @@ class EnsembleSolution:
         return s
 
 
-def make_protocol(p, protocol):
+def make_protocol(p, protocol, n_cells=None):
     """protocol: list of dicts like {"I": 2, "tf": 1800, "V_max": 4.1} / {"V": "hold", "I_min": 1/20} -- each dict is the
-    keyword set of one simulate()/simulate!() call."""
+    keyword set of one simulate()/simulate!() call.  An input value or `tf` given as a 1-D numpy array of length n_cells is applied cell by cell
+    (a C-rate sweep is `{"I": -np.linspace(0.5, 3, n)}`)."""
     runs, names = [], []
     for step in protocol:
         step = dict(step)
@@ -416,6 +426,9 @@ def make_protocol(p, protocol):
         if rest:
             raise TypeError("unknown protocol keys %r" % list(rest))
         (name, inp), = inputs.items()
+        for what, arr in (("input", inp), ("tf", tf)):
+            if isinstance(arr, np.ndarray) and (n_cells is None or arr.shape != (n_cells,)):
+                raise ValueError("per-cell %s: expected a 1-D array of length n_cells" % what)
         runs.append(_make_run(p, name, inp, tf, bounds))
         names.append(name)
     return runs, names
@@ -428,9 +441,9 @@ def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, 
     protocol: list of run dicts (see make_protocol) shared by all cells.  SOC: scalar or [n_cells] initial SOC.
     outputs: "all" (or any state name) also returns every saved state vector as ens.Y_all [cell, point, state] -- 8 N bytes per point.
     """
-    runs, names = make_protocol(p, protocol)
-    o = opts or p.opts
     n = Theta.shape[0]
+    runs, names = make_protocol(p, protocol, n)
+    o = opts or p.opts
     soc = p.opts.SOC if SOC is None else SOC
     if device:
         import torch

@@ -534,7 +534,7 @@ struct CellOut {
 template <bool TAB, class M>
 __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
                                      const CellOut& out, int* n_pts_out, plh_run_info* info, Counters& cnt, double* Yfin, double* YPfin,
-                                     double* Yprev, double* YPprev) {
+                                     double* Yprev, double* YPprev, int cell) {
   PL_MODEL(M);
   const int lane = lane_id();
   IdaScalars I;
@@ -561,7 +561,7 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
   for (int r = 0; r < n_runs; r++) {
     // the run descriptor is staged in LDS once per run: reading it from global memory in every step costs ~1.4 k cycles per step (scalar
     // loads that cannot be hoisted past the global stores), and a by-value register copy proved fragile under register pressure
-    if (lane == 0) S.runc = runs[r];
+    if (lane == 0) { S.runc = runs[r]; if (S.runc.value_cell) S.runc.value = S.runc.value_cell[cell]; if (S.runc.tf_cell) S.runc.tf = S.runc.tf_cell[cell]; }
     PL_SYNC();
     const plh_run& run = S.runc;
     const int mode = run.mode;

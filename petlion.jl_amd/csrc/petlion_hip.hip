@@ -148,7 +148,7 @@ template <class M, bool TAB> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SI
   cell_simulate<TAB>(S, R, a.tb, a.SOC0[cell], a.Y_init ? a.Y_init + (size_t)cell * NST : nullptr, a.t_init ? a.t_init[cell] : 0.0, a.n_runs, a.runs, a.opts, co, a.out.n_pts ? a.out.n_pts + cell : nullptr,
                 a.out.run_info + (size_t)cell * a.n_runs, cnt,
                 a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
-                a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST);
+                a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell);
   PL_TOC(S, PH_TOTAL);
   PL_SYNC();
   if (lane_id() == 0 && a.out.counters) {
@@ -577,6 +577,8 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
       for (int k = 1; k < runs[r].n_tab; k++) if (!(runs[r].tab_t[k] >= runs[r].tab_t[k - 1])) return fail(PLH_E_ARG, "table times must be non-decreasing");
     }
     if (!(runs[r].tf > 0)) return fail(PLH_E_ARG, "run length tf must be positive");
+    if (runs[r].value_cell && runs[r].value_kind != PLH_VAL_CONST) return fail(PLH_E_ARG, "value_cell needs PLH_VAL_CONST");
+    if (runs[r].tf_cell) for (int c = 0; c < n; c++) if (!(runs[r].tf_cell[c] > 0)) return fail(PLH_E_ARG, "run length tf_cell must be positive");
   }
   if (out->max_pts < 0) return fail(PLH_E_ARG, "max_pts");
   if ((Y_init == nullptr) != (t_init == nullptr)) return fail(PLH_E_ARG, "Y_init and t_init must be given together");
@@ -601,6 +603,12 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
       hruns[r].tab_t = dt_; hruns[r].tab_v = dv_;
       s.tmp.insert(s.tmp.end(), hs.tmp.begin(), hs.tmp.end()); hs.tmp.clear();     // freed with the call's other staging buffers
     } else { hruns[r].n_tab = 0; hruns[r].tab_t = nullptr; hruns[r].tab_v = nullptr; }
+    if (runs[r].value_cell || runs[r].tf_cell) {                       // per-cell protocol values: host arrays like the protocol
+      Stage hs(PLH_HOST, stream);
+      if (runs[r].value_cell) { hruns[r].value_cell = hs.in(runs[r].value_cell, n); if (!hruns[r].value_cell) return fail(PLH_E_HIP, "hipMalloc failed (value_cell)"); }
+      if (runs[r].tf_cell) { hruns[r].tf_cell = hs.in(runs[r].tf_cell, n); if (!hruns[r].tf_cell) return fail(PLH_E_HIP, "hipMalloc failed (tf_cell)"); }
+      s.tmp.insert(s.tmp.end(), hs.tmp.begin(), hs.tmp.end()); hs.tmp.clear();
+    }
   }
   HIPCHK(hipMemcpy(m->d_runs, hruns.data(), n_runs * sizeof(plh_run), hipMemcpyHostToDevice));
   a.runs = m->d_runs;

@@ -131,12 +131,14 @@ def check_init(p, O, V0_expected=2.863495104606893):
     return V0
 
 
-def runs_to_oracle(O, p, pkg, protocol):
-    runs, _ = pkg.make_protocol(p, protocol)
+def runs_to_oracle(O, p, pkg, protocol, cell=None, n_cells=None):
+    """the protocol as oracle run dicts; with per-cell inputs (arrays of length n_cells) the values of cell `cell`"""
+    runs, _ = pkg.make_protocol(p, protocol, n_cells)
     out = []
     for r in runs:
         b = O.Bounds(**{f: getattr(r.bounds, f) for f in O.BOUND_FIELDS})
-        d = dict(mode=r.mode, value_kind=r.value_kind, value=r.value, tf=r.tf, bounds=b)
+        d = dict(mode=r.mode, value_kind=r.value_kind, value=r.value_cell[cell] if r.value_cell else r.value,
+                 tf=r.tf_cell[cell] if r.tf_cell else r.tf, bounds=b)
         if r.value_kind == 3:       # PLH_VAL_TABLE
             d["table"] = (np.array(r._keep[0]), np.array(r._keep[1]))
         out.append(d)

@@ -305,6 +305,28 @@ def test_outputs_all_thermal(emu_model_thermal, O, pkg):
     check_outputs_all(emu_model_thermal, O, pkg, [{"I": 3.0, "tf": 150.0}], 0.1)
 
 
+def check_per_cell_protocol(p, O, pkg, n=6):
+    """per-cell input values and run lengths (plh_run.value_cell / tf_cell): a C-rate sweep followed by rests of different lengths, every cell
+    against the oracle run with that cell's values at 1e-6 (same step decisions)"""
+    th = p.theta_vector()
+    rates = -np.linspace(0.5, 3.0, n)
+    rests = np.linspace(30.0, 300.0, n)
+    proto = [{"I": rates, "tf": 600.0}, {"I": "rest", "tf": rests}]
+    ens = pkg.simulate_ensemble(p, np.tile(th, (n, 1)), proto, SOC=1.0)
+    for i in range(n):
+        ro = O.simulate(p.variant, th, 1.0, parity.runs_to_oracle(O, p, pkg, proto, cell=i, n_cells=n))
+        parity.compare_trajectory(ens, i, ro, rtol_state=1e-6)
+        assert abs(ens.run_info[i, 0]["I"] - rates[i]) < 1e-12 and abs(ens.run_info[i, 1]["t_end"] - ens.run_info[i, 0]["t_end"] - rests[i]) < 1e-6
+    with pytest.raises(ValueError):
+        pkg.simulate_ensemble(p, np.tile(th, (n, 1)), [{"I": rates[:-1]}], SOC=1.0)
+    with pytest.raises(pkg._capi.PetlionHipError):
+        pkg.simulate_ensemble(p, np.tile(th, (n, 1)), [{"I": -1.0, "tf": np.zeros(n)}], SOC=1.0)
+
+
+def test_per_cell_protocol_values(emu_model, O, pkg):
+    check_per_cell_protocol(emu_model, O, pkg, n=4)
+
+
 def test_emulator_hostile_modes():
     """The same device-source tests with the emulator's LDS block and lane stacks starting as garbage (PL_EMU_POISON: on the GPU LDS holds what the
     previous workgroup left) and the lanes run 63..0 between sync points (PL_EMU_ORDER=reverse: a cross-lane LDS hand-over that lacks a sync point --
