@@ -598,9 +598,12 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     // a = left block (L_n top / U_n bottom), b = right block (U_{n-1} top / L_{n+1} bottom); zero at the chain heads and in idle lanes
     OffBlk a = top ? lower_blk(S, i, alg_only) : upper_blk(S, i, alg_only);
     const int nb = top ? (i > 0 ? i - 1 : 0) : (i < NE - 1 ? i + 1 : NE - 1);
-    const OffBlk b = top ? upper_blk(S, nb, alg_only) : lower_blk(S, nb, alg_only);
     if (!act) { a.ce = a.pc = a.pe = a.pt = a.s = a.Tc = a.Te = a.Ts = a.Tt = 0.0; }
     for (int k = 0; k < 16; k++) Dn[k] = D[k];
+    // register diet for the sweep (every device function is inlined: ~80 integrator values are live around this loop): the node's own block D and
+    // the neighbour's off-diagonal block b are re-read from LDS in every stage instead of being held in 50 registers (D parks in S.LD[i], which is
+    // only written at the end)
+    if (act) for (int k = 0; k < 16; k++) S.LD[i][k] = D[k];
     // second-neighbour T-row entries (see thermal_sweeps): nodes 2 / 27 see U_1 / L_28 modified by -fv (x) fw ; nodes 9 / 20 get a modified
     // lower / upper block once the factor of node 7 / 22 is final
     double fv[4] = {0.0, 0.0, 0.0, 0.0}, fw[3] = {0.0, 0.0, 0.0};
@@ -608,7 +611,10 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     inv4(D, Dinv);
 #pragma unroll 1
     for (int itr = 1; itr < TW_MID; itr++) {
-      double P[16];
+      PL_SYNC();                                            // (also keeps the reloads below inside the loop)
+      const OffBlk b = top ? upper_blk(S, nb, alg_only) : lower_blk(S, nb, alg_only);
+      double P[16], D[16];
+      for (int k = 0; k < 16; k++) D[k] = S.LD[i][k];
       for (int k = 0; k < 16; k++) P[k] = shift_up1(Dinv[k]);
       for (int k = 0; k < 4; k++) {
         LDm[k] = a.ce * P[k];
