@@ -10,6 +10,10 @@
 #include <string>
 #include <vector>
 
+#ifndef PL_WAVE_EMU
+#include <dlfcn.h>
+#endif
+
 #include "dfn_integrate.h"
 #include "radial_tables_nr10.h"
 
@@ -244,6 +248,11 @@ struct plh_model_s {
   double* scratch = nullptr; size_t scratch_cells = 0;
   plh_run* d_runs = nullptr; int runs_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
+  // thermal models: plh_integrate is served by the sibling library (same source, built at -O2: the -O3 pipeline over-unrolls the 4x4 block code of
+  // the thermal kernels, C3 97 k -> 115 k trajectories/s); absent sibling = this library's own kernels
+  void* sib_lib = nullptr; plh_model_t sib = nullptr; bool sib_last = false;
+  int (*sib_integrate)(plh_model_t, int, const double*, const double*, const double*, const double*, int, const plh_run*, const plh_opts*, const plh_outputs*, int, void*) = nullptr;
+  double (*sib_kernel_ms)(plh_model_t) = nullptr; void (*sib_destroy)(plh_model_t) = nullptr; const char* (*sib_error)(void) = nullptr;
 };
 
 // decode word of the structural Jacobian entry (r, c), 0 if structurally zero
@@ -398,11 +407,18 @@ struct Stage {
 
 
 // instantiated model variants
-#define PL_DISPATCH(m, ...) do { switch ((m)->variant) { \
+// (PL_ONLY_THERMAL: the sibling library libpetlion_hip_thermal.so instantiates the thermal variant only, see plh_model_create)
+#ifdef PL_ONLY_THERMAL
+#define PL_DISPATCH_ISOTHERMAL(...)
+#else
+#define PL_DISPATCH_ISOTHERMAL(...) \
     case V_LCO_ISO: { using M = ModelT<PLH_CHEM_LCO_LIC6, false>; __VA_ARGS__; } break; \
     case V_NMC_ISO: { using M = ModelT<PLH_CHEM_NMC_LIC6, false>; __VA_ARGS__; } break; \
     case V_LCO_SEI: { using M = ModelT<PLH_CHEM_LCO_LIC6, true>; __VA_ARGS__; } break; \
-    case V_NMC_SEI: { using M = ModelT<PLH_CHEM_NMC_LIC6, true>; __VA_ARGS__; } break; \
+    case V_NMC_SEI: { using M = ModelT<PLH_CHEM_NMC_LIC6, true>; __VA_ARGS__; } break;
+#endif
+#define PL_DISPATCH(m, ...) do { switch ((m)->variant) { \
+    PL_DISPATCH_ISOTHERMAL(__VA_ARGS__) \
     case V_LCO_THERMAL: { using M = ModelT<PLH_CHEM_LCO_LIC6, false, true>; __VA_ARGS__; } break; \
     default: return fail(PLH_E_UNSUPPORTED, "model variant not instantiated"); } } while (0)
 
@@ -472,12 +488,34 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   if (hipMalloc((void**)&m->d_tb, sizeof(Tables)) != hipSuccess) { delete m; return fail(PLH_E_HIP, "hipMalloc failed"); }
   hipMemcpy(m->d_tb, &tb, sizeof(Tables), hipMemcpyHostToDevice);
   hipEventCreate(&m->ev0); hipEventCreate(&m->ev1);
+#if defined(PL_THERMAL_SIBLING) && !defined(PL_WAVE_EMU)
+  if (d->temperature && !getenv("PETLION_HIP_NO_SIBLING")) {
+    Dl_info self;
+    if (dladdr((void*)&plh_model_create, &self) && self.dli_fname) {
+      std::string path(self.dli_fname);
+      const size_t slash = path.find_last_of('/');
+      path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + PL_THERMAL_SIBLING;
+      if (void* lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL)) {
+        auto create = (int (*)(const plh_model_desc*, plh_model_t*))dlsym(lib, "plh_model_create");
+        m->sib_integrate = (decltype(m->sib_integrate))dlsym(lib, "plh_integrate");
+        m->sib_kernel_ms = (decltype(m->sib_kernel_ms))dlsym(lib, "plh_last_kernel_ms");
+        m->sib_destroy = (decltype(m->sib_destroy))dlsym(lib, "plh_model_destroy");
+        m->sib_error = (decltype(m->sib_error))dlsym(lib, "plh_last_error");
+        if (create && m->sib_integrate && m->sib_kernel_ms && m->sib_destroy && m->sib_error && create(d, &m->sib) == 0) m->sib_lib = lib;
+        else { m->sib = nullptr; dlclose(lib); }
+      }
+    }
+  }
+#endif
   *out = m;
   return 0;
 }
 
 void plh_model_destroy(plh_model_t m) {
   if (!m) return;
+#ifndef PL_WAVE_EMU
+  if (m->sib) { m->sib_destroy(m->sib); dlclose(m->sib_lib); }
+#endif
   for (int k = 0; k < PLH_N_MODES; k++) if (m->d_code[k]) hipFree(m->d_code[k]);
   if (m->d_tb) hipFree(m->d_tb);
   if (m->scratch) hipFree(m->scratch);
@@ -567,6 +605,12 @@ int plh_init_consistent(plh_model_t m, int n, const double* theta, int mode, dou
 int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0, const double* Y_init, const double* t_init, int n_runs,
                   const plh_run* runs, const plh_opts* opts, const plh_outputs* out, int kind, void* stream) {
   CHECK_MODEL(m);
+  if (m->sib) {                                           // thermal: the sibling library's kernels (see plh_model_s)
+    const int rc = m->sib_integrate(m->sib, n, theta, SOC0, Y_init, t_init, n_runs, runs, opts, out, kind, stream);
+    m->sib_last = true;
+    return rc == 0 ? 0 : fail(rc, m->sib_error());
+  }
+  m->sib_last = false;
   if (n <= 0 || !theta || !SOC0 || n_runs <= 0 || !runs || !opts || !out || !out->run_info) return fail(PLH_E_ARG, "bad argument");
   for (int r = 0; r < n_runs; r++) {
     CHECK_MODE(runs[r].mode);
@@ -635,6 +679,7 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
 }
 
 double plh_last_kernel_ms(plh_model_t m) {
+  if (m && m->sib && m->sib_last) return m->sib_kernel_ms(m->sib);
   if (!m || !m->timed) return -1.0;
   if (hipEventSynchronize(m->ev1) != hipSuccess) return -1.0;
   float ms = -1.f;

@@ -12,6 +12,6 @@ if [ "$1" = build ]; then
   wait
 else
   for o in 1 2; do
-    echo "== -O$o"; PETLION_HIP_LIB=$R/petlion.jl_amd/libpetlion_hip_O$o.so python -m pytest $R/tests -m gpu -q 2>&1 | tail -3
+    echo "== -O$o"; PETLION_HIP_NO_SIBLING=1 PETLION_HIP_LIB=$R/petlion.jl_amd/libpetlion_hip_O$o.so python -m pytest $R/tests -m gpu -q 2>&1 | tail -3
   done
 fi
