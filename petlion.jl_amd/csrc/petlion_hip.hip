@@ -417,9 +417,16 @@ struct Stage {
     case V_LCO_SEI: { using M = ModelT<PLH_CHEM_LCO_LIC6, true>; __VA_ARGS__; } break; \
     case V_NMC_SEI: { using M = ModelT<PLH_CHEM_NMC_LIC6, true>; __VA_ARGS__; } break;
 #endif
+#ifdef PL_ONLY_LCO_ISO     /* build experiments (tools/flag_search.sh): one variant, short compile */
+#undef PL_DISPATCH_ISOTHERMAL
+#define PL_DISPATCH_ISOTHERMAL(...) case V_LCO_ISO: { using M = ModelT<PLH_CHEM_LCO_LIC6, false>; __VA_ARGS__; } break;
+#define PL_DISPATCH_THERMAL(...)
+#else
+#define PL_DISPATCH_THERMAL(...) case V_LCO_THERMAL: { using M = ModelT<PLH_CHEM_LCO_LIC6, false, true>; __VA_ARGS__; } break;
+#endif
 #define PL_DISPATCH(m, ...) do { switch ((m)->variant) { \
     PL_DISPATCH_ISOTHERMAL(__VA_ARGS__) \
-    case V_LCO_THERMAL: { using M = ModelT<PLH_CHEM_LCO_LIC6, false, true>; __VA_ARGS__; } break; \
+    PL_DISPATCH_THERMAL(__VA_ARGS__) \
     default: return fail(PLH_E_UNSUPPORTED, "model variant not instantiated"); } } while (0)
 
 template <class M> static int build_patterns(plh_model_s* m) {
