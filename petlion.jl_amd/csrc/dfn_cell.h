@@ -733,12 +733,15 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only
   const int nd = tw_node(lane);
   const bool act = nd >= 0, top = lane < TW_MID;
   const int i = act ? nd : 0;
+  // every load is unconditional (i is a valid node in every lane) and masked afterwards: a guarded load `act ? S.x[i] : 0` compiles to one
+  // exec-masked branch per element, which serialises the loads of this prologue
   double C[9], Di[9], G[9], Lm[9];
-  for (int k = 0; k < 9; k++) { C[k] = act ? S.LD[i][k] : 0.0; Di[k] = act ? S.Dinv[i][k] : 0.0; Lm[k] = nd == TW_MID ? S.LDmid[k] : 0.0; }
+  for (int k = 0; k < 9; k++) { const double c = S.LD[i][k], d = S.Dinv[i][k], l = S.LDmid[k]; C[k] = act ? c : 0.0; Di[k] = act ? d : 0.0; Lm[k] = nd == TW_MID ? l : 0.0; }
   {   // back-substitution block: top x_n = z_n - Dinv U_n x_{n+1}; bottom x_n = z_n - Dinv L_n x_{n-1}; node TW_MID is closed (G = 0)
     const bool z = !act || nd == TW_MID;
-    const double v00 = (alg_only || z) ? 0.0 : (top ? S.ceU[i] : S.ceL[i]), v10 = (alg_only || z) ? 0.0 : (top ? S.pcU[i] : S.pcL[i]);
-    const double v11 = z ? 0.0 : (top ? S.peU[i] : S.peL[i]);
+    const double ceu = S.ceU[i], cel = S.ceL[i], pcu = S.pcU[i], pcl = S.pcL[i], peu = S.peU[i], pel = S.peL[i];
+    const double v00 = (alg_only || z) ? 0.0 : (top ? ceu : cel), v10 = (alg_only || z) ? 0.0 : (top ? pcu : pcl);
+    const double v11 = z ? 0.0 : (top ? peu : pel);
     const double v22 = z ? 0.0 : (top ? u22_of(i) : l22_of(i));
     for (int rr = 0; rr < 3; rr++) {
       G[rr * 3 + 0] = Di[rr * 3 + 0] * v00 + Di[rr * 3 + 1] * v10;
@@ -855,10 +858,13 @@ __device__ inline void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     // a = left block (L_n for top, U_n for bottom), b = right block (U_{n-1} for top, L_{n+1} for bottom); zero at the two chain heads
     const bool head = !act || nd == 0 || nd == NE - 1;
     const int nb = top ? (i > 0 ? i - 1 : 0) : (i < NE - 1 ? i + 1 : NE - 1);
-    const double a00 = (alg_only || head) ? 0.0 : (top ? S.ceL[i] : S.ceU[i]), a10 = (alg_only || head) ? 0.0 : (top ? S.pcL[i] : S.pcU[i]);
-    const double a11 = head ? 0.0 : (top ? S.peL[i] : S.peU[i]), a22 = head ? 0.0 : (top ? l22_of(i) : u22_of(i));
-    const double b00 = (alg_only || head) ? 0.0 : (top ? S.ceU[nb] : S.ceL[nb]), b10 = (alg_only || head) ? 0.0 : (top ? S.pcU[nb] : S.pcL[nb]);
-    const double b11 = head ? 0.0 : (top ? S.peU[nb] : S.peL[nb]), b22 = a22;
+    // unconditional loads, masked afterwards (see thomas_sweeps)
+    const double ceLi = S.ceL[i], ceUi = S.ceU[i], pcLi = S.pcL[i], pcUi = S.pcU[i], peLi = S.peL[i], peUi = S.peU[i];
+    const double ceLn = S.ceL[nb], ceUn = S.ceU[nb], pcLn = S.pcL[nb], pcUn = S.pcU[nb], peLn = S.peL[nb], peUn = S.peU[nb];
+    const double a00 = (alg_only || head) ? 0.0 : (top ? ceLi : ceUi), a10 = (alg_only || head) ? 0.0 : (top ? pcLi : pcUi);
+    const double a11 = head ? 0.0 : (top ? peLi : peUi), a22 = head ? 0.0 : (top ? l22_of(i) : u22_of(i));
+    const double b00 = (alg_only || head) ? 0.0 : (top ? ceUn : ceLn), b10 = (alg_only || head) ? 0.0 : (top ? pcUn : pcLn);
+    const double b11 = head ? 0.0 : (top ? peUn : peLn), b22 = a22;
     for (int k = 0; k < 9; k++) { LDm[k] = 0.0; Dn[k] = D[k]; }
     inv3(D, Dinv);
 #pragma unroll 1
