@@ -120,11 +120,16 @@ def main():
     # ---- ensemble scatter (RCCL, outside the timed region): rank 0 owns Theta ----
     if world > 1:
         mine = torch.empty(n_local, len(p.θ_keys), dtype=torch.float64, device=cdev)
-        if rank == 0:
-            full = torch.from_numpy(pkg.theta_matrix(p, n_total)).to(cdev)
-            dist.scatter(mine, [c.contiguous() for c in full.chunk(world, dim=0)], src=0)
-        else:
-            dist.scatter(mine, None, src=0)
+        try:
+            if rank == 0:
+                full = torch.from_numpy(pkg.theta_matrix(p, n_total)).to(cdev)
+                dist.scatter(mine, [c.contiguous() for c in full.chunk(world, dim=0)], src=0)
+            else:
+                dist.scatter(mine, None, src=0)
+        except (RuntimeError, NotImplementedError):      # a backend without scatter: broadcast the matrix, keep the own block
+            full = torch.from_numpy(pkg.theta_matrix(p, n_total)).to(cdev) if rank == 0 else torch.empty(n_total, len(p.θ_keys), dtype=torch.float64, device=cdev)
+            dist.broadcast(full, src=0)
+            mine = full[rank * n_local:(rank + 1) * n_local].clone()
         Theta = mine.to(dev)
     else:
         Theta = torch.from_numpy(pkg.theta_matrix(p, n_local)).to(dev)
@@ -161,8 +166,12 @@ def main():
     summ = pd.summarize(ens)
     if world > 1:
         mine_s = torch.from_numpy(summ).to(cdev)
-        parts = [torch.empty_like(mine_s) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine_s, parts, dst=0)
+        try:
+            parts = [torch.empty_like(mine_s) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine_s, parts, dst=0)
+        except (RuntimeError, NotImplementedError):      # a backend without gather
+            parts = [torch.empty_like(mine_s) for _ in range(world)]
+            dist.all_gather(parts, mine_s)
         if rank == 0:
             allsum = torch.cat(parts).cpu().numpy()
             assert (allsum[:, 0] == 3).all()
