@@ -235,6 +235,7 @@ static const VariantInfo VARIANTS[V_COUNT] = {
     {PLH_CHEM_LCO_LIC6, 0, 1, 56, KEYS_LCO_THERMAL, DEFAULTS_LCO_THERMAL},
 };
 
+struct StageBlock { void* p; size_t bytes; bool busy; };
 struct plh_model_s {
   plh_model_desc desc;
   int variant = 0;                 // index into the instantiated ModelT<> list (PL_DISPATCH)
@@ -248,6 +249,27 @@ struct plh_model_s {
   double* scratch = nullptr; size_t scratch_cells = 0;
   plh_run* d_runs = nullptr; int runs_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
+  // device staging blocks of the host-pointer (PLH_HOST) path, kept between calls: a repeated call with the same shapes does no hipMalloc / hipFree
+  std::vector<StageBlock> stage_cache;
+  void* grab(size_t bytes) {
+    int best = -1;
+    for (size_t k = 0; k < stage_cache.size(); k++)
+      if (!stage_cache[k].busy && stage_cache[k].bytes >= bytes && (best < 0 || stage_cache[k].bytes < stage_cache[best].bytes)) best = (int)k;
+    if (best >= 0 && stage_cache[best].bytes <= 2 * bytes + 4096) { stage_cache[best].busy = true; return stage_cache[best].p; }
+    void* d = nullptr; if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) return nullptr;
+    stage_cache.push_back({d, bytes, true}); return d;
+  }
+  void release(void* p) { for (auto& b : stage_cache) if (b.p == p) b.busy = false; }
+  // pinned host bounce buffer for the device-to-host copies of the PLH_HOST path: hipMemcpy into fresh pageable pages (a caller that allocates
+  // its output arrays per call) costs ~10x the DMA time in page pinning; DMA into this buffer + memcpy does not
+  void* pin = nullptr; size_t pin_bytes = 0;
+  void* pinned(size_t bytes) {
+    if (bytes <= pin_bytes) return pin;
+    if (pin) hipHostFree(pin);
+    pin = nullptr; pin_bytes = 0;
+    if (hipHostMalloc(&pin, bytes, hipHostMallocDefault) != hipSuccess) { pin = nullptr; return nullptr; }
+    pin_bytes = bytes; return pin;
+  }
   // thermal models: plh_integrate is served by the sibling library (same source, built at -O2: the -O3 pipeline over-unrolls the 4x4 block code of
   // the thermal kernels, C3 97 k -> 115 k trajectories/s); absent sibling = this library's own kernels
   void* sib_lib = nullptr; plh_model_t sib = nullptr; bool sib_last = false;
@@ -385,20 +407,25 @@ static unsigned classify(const Tables& tb, int mode, int r, int c) {
 // ---- staging helpers: host arrays are copied through temporary device buffers ----
 struct Stage {
   std::vector<void*> tmp;
-  int kind; hipStream_t st;
-  Stage(int k, void* s) : kind(k), st((hipStream_t)s) {}
-  ~Stage() { for (void* p : tmp) hipFree(p); }
+  plh_model_s* m; int kind; hipStream_t st;
+  Stage(plh_model_s* mm, int k, void* s) : m(mm), kind(k), st((hipStream_t)s) {}
+  ~Stage() { for (void* p : tmp) m->release(p); }
   template <class T> const T* in(const T* p, size_t n) {
     if (!p || kind == PLH_DEVICE) return p;
-    void* d = nullptr; if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return nullptr;
+    void* d = m->grab(n * sizeof(T)); if (!d) return nullptr;
     tmp.push_back(d); hipMemcpy(d, p, n * sizeof(T), hipMemcpyHostToDevice); return (const T*)d;
   }
   template <class T> T* buf(T* p, size_t n, bool copy_in) {
     if (!p || kind == PLH_DEVICE) return p;
-    void* d = nullptr; if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return nullptr;
+    void* d = m->grab(n * sizeof(T)); if (!d) return nullptr;
     tmp.push_back(d); if (copy_in) hipMemcpy(d, p, n * sizeof(T), hipMemcpyHostToDevice); return (T*)d;
   }
-  template <class T> void back(T* host, const T* dev, size_t n) { if (host && kind != PLH_DEVICE) hipMemcpy(host, dev, n * sizeof(T), hipMemcpyDeviceToHost); }
+  template <class T> void back(T* host, const T* dev, size_t n) {
+    if (!host || kind == PLH_DEVICE) return;
+    void* pb = n * sizeof(T) >= (64u << 10) ? m->pinned(n * sizeof(T)) : nullptr;
+    if (pb) { hipMemcpy(pb, dev, n * sizeof(T), hipMemcpyDeviceToHost); memcpy(host, pb, n * sizeof(T)); }
+    else hipMemcpy(host, dev, n * sizeof(T), hipMemcpyDeviceToHost);
+  }
 };
 #define CHECK_MODEL(m) do { if (!(m)) return fail(PLH_E_ARG, "null model"); } while (0)
 #define CHECK_MODE(mode) do { if ((mode) != PLH_MODE_I && (mode) != PLH_MODE_V && (mode) != PLH_MODE_P && (mode) != PLH_MODE_ETA_P && !((mode) == PLH_MODE_DT && m->desc.temperature)) \
@@ -527,6 +554,8 @@ void plh_model_destroy(plh_model_t m) {
   if (m->d_tb) hipFree(m->d_tb);
   if (m->scratch) hipFree(m->scratch);
   if (m->d_runs) hipFree(m->d_runs);
+  for (auto& b : m->stage_cache) hipFree(b.p);
+  if (m->pin) hipHostFree(m->pin);
   if (m->ev0) hipEventDestroy(m->ev0);
   if (m->ev1) hipEventDestroy(m->ev1);
   delete m;
@@ -558,7 +587,7 @@ int plh_jac_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval)
 
 int plh_initial_guess(plh_model_t m, int n, const double* theta, const double* SOC, double* Y, int kind, void* stream) {
   CHECK_MODEL(m); if (n <= 0 || !theta || !SOC || !Y) return fail(PLH_E_ARG, "bad argument");
-  Stage s(kind, stream);
+  Stage s(m, kind, stream);
   const double* th = s.in(theta, (size_t)n * m->P); const double* so = s.in(SOC, n); double* y = s.buf(Y, (size_t)n * m->N, false);
   PL_DISPATCH(m, PL_LAUNCH(k_initial_guess<M>, n, WAVE, s.st, m->d_tb, n, th, so, y));
   FINISH(s); s.back(Y, y, (size_t)n * m->N);
@@ -567,7 +596,7 @@ int plh_initial_guess(plh_model_t m, int n, const double* theta, const double* S
 
 int plh_residual(plh_model_t m, int n, const double* theta, const double* Y, const double* YP, int mode, double value, double* F, int kind, void* stream) {
   CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP || !F) return fail(PLH_E_ARG, "bad argument");
-  Stage s(kind, stream);
+  Stage s(m, kind, stream);
   const double* th = s.in(theta, (size_t)n * m->P); const double* y = s.in(Y, (size_t)n * m->N); const double* yp = s.in(YP, (size_t)n * m->N);
   double* f = s.buf(F, (size_t)n * m->N, false);
   PL_DISPATCH(m, PL_LAUNCH(k_residual<M>, n, WAVE, s.st, m->d_tb, n, th, y, yp, mode, value, f));
@@ -577,7 +606,7 @@ int plh_residual(plh_model_t m, int n, const double* theta, const double* Y, con
 
 int plh_jacobian(plh_model_t m, int n, const double* theta, const double* Y, const double* YP, double cj, int mode, double* nzval, int kind, void* stream) {
   CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP || !nzval) return fail(PLH_E_ARG, "bad argument");
-  Stage s(kind, stream);
+  Stage s(m, kind, stream);
   const size_t nnz = m->rowval[mode].size();
   const double* th = s.in(theta, (size_t)n * m->P); const double* y = s.in(Y, (size_t)n * m->N); const double* yp = s.in(YP, (size_t)n * m->N);
   double* z = s.buf(nzval, (size_t)n * nnz, false);
@@ -588,7 +617,7 @@ int plh_jacobian(plh_model_t m, int n, const double* theta, const double* Y, con
 
 int plh_linear_solve(plh_model_t m, int n, const double* theta, const double* Y, const double* YP, double cj, int mode, double* b, int kind, void* stream) {
   CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP || !b) return fail(PLH_E_ARG, "bad argument");
-  Stage s(kind, stream);
+  Stage s(m, kind, stream);
   const double* th = s.in(theta, (size_t)n * m->P); const double* y = s.in(Y, (size_t)n * m->N); const double* yp = s.in(YP, (size_t)n * m->N);
   double* bb = s.buf(b, (size_t)n * m->N, true);
   PL_DISPATCH(m, PL_LAUNCH(k_linear_solve<M>, n, WAVE, s.st, m->d_tb, n, th, y, yp, cj, mode, bb));
@@ -599,7 +628,7 @@ int plh_linear_solve(plh_model_t m, int n, const double* theta, const double* Y,
 int plh_init_consistent(plh_model_t m, int n, const double* theta, int mode, double value, double reltol_init, double* Y, double* YP, int* status,
                         int* iters, int kind, void* stream) {
   CHECK_MODEL(m); CHECK_MODE(mode); if (n <= 0 || !theta || !Y || !YP) return fail(PLH_E_ARG, "bad argument");
-  Stage s(kind, stream);
+  Stage s(m, kind, stream);
   const double* th = s.in(theta, (size_t)n * m->P);
   double* y = s.buf(Y, (size_t)n * m->N, true); double* yp = s.buf(YP, (size_t)n * m->N, false);
   int* st = s.buf(status, n, false); int* it = s.buf(iters, n, false);
@@ -633,7 +662,7 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   }
   if (out->max_pts < 0) return fail(PLH_E_ARG, "max_pts");
   if ((Y_init == nullptr) != (t_init == nullptr)) return fail(PLH_E_ARG, "Y_init and t_init must be given together");
-  Stage s(kind, stream);
+  Stage s(m, kind, stream);
   if (m->scratch_cells < (size_t)n) {
     if (m->scratch) hipFree(m->scratch);
     HIPCHK(hipMalloc((void**)&m->scratch, (size_t)n * 2 * m->N * sizeof(double)));
@@ -648,14 +677,14 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   std::vector<plh_run> hruns(runs, runs + n_runs);                    // tables are host arrays: stage them and patch the device copies
   for (int r = 0; r < n_runs; r++) {
     if (hruns[r].value_kind == PLH_VAL_TABLE) {
-      Stage hs(PLH_HOST, stream);
+      Stage hs(m, PLH_HOST, stream);
       const double* dt_ = hs.in(runs[r].tab_t, runs[r].n_tab); const double* dv_ = hs.in(runs[r].tab_v, runs[r].n_tab);
       if (!dt_ || !dv_) return fail(PLH_E_HIP, "hipMalloc failed (input table)");
       hruns[r].tab_t = dt_; hruns[r].tab_v = dv_;
       s.tmp.insert(s.tmp.end(), hs.tmp.begin(), hs.tmp.end()); hs.tmp.clear();     // freed with the call's other staging buffers
     } else { hruns[r].n_tab = 0; hruns[r].tab_t = nullptr; hruns[r].tab_v = nullptr; }
     if (runs[r].value_cell || runs[r].tf_cell) {                       // per-cell protocol values: host arrays like the protocol
-      Stage hs(PLH_HOST, stream);
+      Stage hs(m, PLH_HOST, stream);
       if (runs[r].value_cell) { hruns[r].value_cell = hs.in(runs[r].value_cell, n); if (!hruns[r].value_cell) return fail(PLH_E_HIP, "hipMalloc failed (value_cell)"); }
       if (runs[r].tf_cell) { hruns[r].tf_cell = hs.in(runs[r].tf_cell, n); if (!hruns[r].tf_cell) return fail(PLH_E_HIP, "hipMalloc failed (tf_cell)"); }
       s.tmp.insert(s.tmp.end(), hs.tmp.begin(), hs.tmp.end()); hs.tmp.clear();
