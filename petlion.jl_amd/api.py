@@ -368,7 +368,10 @@ def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, 
     out.run_info, out.counters = cap.ptr(bufs["run_info"]), cap.ptr(bufs["counters"])
     cap.check(lib, lib.plh_integrate(h, n, cap.ptr(theta), cap.ptr(SOC0), cap.ptr(Y_init), cap.ptr(t_init), len(runs), arr,
                                      C.byref(os_), C.byref(out), kind, stream), "plh_integrate")
-    bufs["kernel_ms"] = lib.plh_last_kernel_ms(h)
+    if device:
+        bufs["kernel_ms"] = lambda: lib.plh_last_kernel_ms(h)     # evaluated on access: the launch is asynchronous on `stream`
+    else:
+        bufs["kernel_ms"] = lib.plh_last_kernel_ms(h)
     return bufs
 
 
@@ -382,10 +385,31 @@ class EnsembleSolution:
         self.Y, self.YP = bufs["Y"], bufs["YP"]
         self.T_avg = bufs.get("T_avg")          # [cell, point] with temperature = true
         self.Y_all = bufs.get("Y_all")          # [cell, point, state] with outputs = "all"
-        self.run_info = bufs["run_info"]
-        self.counters = bufs["counters"]
+        self._run_info = bufs["run_info"]
+        self._counters = bufs["counters"]
         self.run_names = run_names
-        self.kernel_ms = bufs.get("kernel_ms", -1.0)
+        self._kernel_ms = bufs.get("kernel_ms", -1.0)
+
+    # With device=True the launch is asynchronous: the per-cell summaries stay in HBM until they are looked at (the first access synchronises),
+    # so a host loop can enqueue launches back to back.
+    @property
+    def run_info(self):
+        if not isinstance(self._run_info, np.ndarray):
+            self._run_info = self._run_info.cpu().numpy().view(cap.RUN_INFO_DTYPE).reshape(self.t.shape[0], len(self.run_names))
+        return self._run_info
+
+    @property
+    def counters(self):
+        if not isinstance(self._counters, np.ndarray):
+            self._counters = self._counters.cpu().numpy().view(cap.COUNTERS_DTYPE).reshape(self.t.shape[0])
+        return self._counters
+
+    @property
+    def kernel_ms(self):
+        """duration of the integrate kernel of the handle's LAST launch (HIP events on the launch stream)"""
+        if callable(self._kernel_ms):
+            self._kernel_ms = self._kernel_ms()
+        return self._kernel_ms
 
     @property
     def n_cells(self):
@@ -452,9 +476,6 @@ def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, 
         soc0 = np.full(n, float(soc)) if np.isscalar(soc) else np.asarray(soc, dtype=np.float64)
     bufs = _integrate(p, Theta, soc0, runs, o, device=device, stream=stream, max_points=max_points,
                       keep_Y=_wants_states(p, o.outputs if outputs is None else outputs))
-    if device:
-        bufs["run_info"] = bufs["run_info"].cpu().numpy().view(cap.RUN_INFO_DTYPE).reshape(n, len(runs))
-        bufs["counters"] = bufs["counters"].cpu().numpy().view(cap.COUNTERS_DTYPE).reshape(n)
     return EnsembleSolution(p, bufs, names)
 
 

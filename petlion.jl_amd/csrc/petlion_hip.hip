@@ -248,6 +248,7 @@ struct plh_model_s {
   unsigned* d_code[PLH_N_MODES] = {};
   double* scratch = nullptr; size_t scratch_cells = 0;
   plh_run* d_runs = nullptr; int runs_cap = 0;
+  std::vector<plh_run> runs_on_device;   // the protocol currently in d_runs (a repeated launch with the same protocol uploads nothing and does not synchronise)
   hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
   // device staging blocks of the host-pointer (PLH_HOST) path, kept between calls: a repeated call with the same shapes does no hipMalloc / hipFree
   std::vector<StageBlock> stage_cache;
@@ -690,7 +691,15 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
       s.tmp.insert(s.tmp.end(), hs.tmp.begin(), hs.tmp.end()); hs.tmp.clear();
     }
   }
-  HIPCHK(hipMemcpy(m->d_runs, hruns.data(), n_runs * sizeof(plh_run), hipMemcpyHostToDevice));
+  {
+    bool plain = true;                                               // no staged arrays behind the descriptors
+    for (int r = 0; r < n_runs; r++) plain = plain && !hruns[r].tab_t && !hruns[r].value_cell && !hruns[r].tf_cell;
+    const bool same = plain && (int)m->runs_on_device.size() == n_runs && memcmp(m->runs_on_device.data(), hruns.data(), n_runs * sizeof(plh_run)) == 0;
+    if (!same) {
+      HIPCHK(hipMemcpy(m->d_runs, hruns.data(), n_runs * sizeof(plh_run), hipMemcpyHostToDevice));
+      if (plain) m->runs_on_device = hruns; else m->runs_on_device.clear();
+    }
+  }
   a.runs = m->d_runs;
   const size_t np = (size_t)n * out->max_pts;
   a.out = *out;
