@@ -691,11 +691,12 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
       s.tmp.insert(s.tmp.end(), hs.tmp.begin(), hs.tmp.end()); hs.tmp.clear();
     }
   }
+  bool plain = true;                                                 // no staged arrays behind the descriptors
   {
-    bool plain = true;                                               // no staged arrays behind the descriptors
     for (int r = 0; r < n_runs; r++) plain = plain && !hruns[r].tab_t && !hruns[r].value_cell && !hruns[r].tf_cell;
     const bool same = plain && (int)m->runs_on_device.size() == n_runs && memcmp(m->runs_on_device.data(), hruns.data(), n_runs * sizeof(plh_run)) == 0;
     if (!same) {
+      HIPCHK(hipStreamSynchronize(s.st));                               // an earlier launch on this stream may still be reading d_runs
       HIPCHK(hipMemcpy(m->d_runs, hruns.data(), n_runs * sizeof(plh_run), hipMemcpyHostToDevice));
       if (plain) m->runs_on_device = hruns; else m->runs_on_device.clear();
     }
@@ -716,6 +717,7 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   hipEventRecord(m->ev1, s.st);
   m->timed = true;
   FINISH(s);
+  if (!plain && kind == PLH_DEVICE) HIPCHK(hipStreamSynchronize(s.st));   // staged tables / per-cell values are released below: the kernel must be done with them
   s.back(out->t, a.out.t, np); s.back(out->V, a.out.V, np); s.back(out->I, a.out.I, np); s.back(out->SOC, a.out.SOC, np);
   s.back(out->T_avg, a.out.T_avg, np); s.back(out->n_pts, a.out.n_pts, n); s.back(out->Y_all, a.out.Y_all, np * m->N);
   s.back(out->Y_final, a.out.Y_final, (size_t)n * m->N); s.back(out->YP_final, a.out.YP_final, (size_t)n * m->N);
