@@ -357,3 +357,29 @@ def test_c_rate_sweep_per_cell_inputs(hip_model, O, pkg):
     # monotone up to the integration tolerance (the stop time is back-interpolated linearly over the last step: O(reltol) scatter between neighbours)
     assert (np.diff(cap) <= 2e-3).all() and (np.diff(cap[::64]) <= 1e-9).all() and cap[0] > 0.999 and cap[-1] < 0.9
     assert np.abs(ens.run_info["I"][ok, 0] + rates[ok]).max() < 1e-12
+
+
+def test_async_back_to_back_launches(hip_model, pkg):
+    """device pointers: launches are only enqueued; results of queued launches (same and different protocols, different parameters) are bitwise those of
+    launches that were synchronised one by one"""
+    import torch
+    p = hip_model
+    n = 512
+    rng = np.random.default_rng(5)
+    A = torch.from_numpy(pkg.theta_matrix(p, n, {"D_sp": p.θ["D_sp"] * 2.0 ** (2 * rng.random(n) - 1)})).cuda()
+    B = torch.from_numpy(pkg.theta_matrix(p, n, {"k_n": p.θ["k_n"] * 2.0 ** (2 * rng.random(n) - 1)})).cuda()
+    P1, P2 = [{"I": -1.0}], [{"I": -2.0, "tf": 600.0}, {"I": "rest", "tf": 300.0}]
+    sim = lambda Th, proto: pkg.simulate_ensemble(p, Th, proto, SOC=1.0, device=True, max_points=256)
+    ref = {}
+    for key, Th, proto in (("A1", A, P1), ("B1", B, P1), ("A2", A, P2)):
+        e = sim(Th, proto); torch.cuda.synchronize()
+        ref[key] = (e.Y.clone(), e.t.clone(), e.run_info.copy())
+    torch.cuda.synchronize()
+    queued = [("A1", sim(A, P1)), ("B1", sim(B, P1)), ("A2", sim(A, P2)), ("A1", sim(A, P1)), ("B1", sim(B, P1))]     # nothing read in between
+    torch.cuda.synchronize()
+    for key, e in queued:
+        Y, t, info = ref[key]
+        assert torch.equal(e.Y, Y) and np.array_equal(e.run_info["t_end"], info["t_end"]) and np.array_equal(e.run_info["flag"], info["flag"]), key
+        npt = e.n_pts.cpu().numpy()
+        tt, tr = e.t.cpu().numpy(), t.cpu().numpy()
+        assert all(np.array_equal(tt[i, :npt[i]], tr[i, :npt[i]]) for i in range(0, n, 37)), key
