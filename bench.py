@@ -107,7 +107,12 @@ def main():
             dist.init_process_group(backend)
 
     import __graft_entry__ as g
-    g.build_hip()
+    if world > 1:                                  # one rank per node builds (a no-op when the in-tree libraries are current), the others wait
+        if local_rank == 0:
+            g.build_hip()
+        dist.barrier()
+    else:
+        g.build_hip()
     import pkgload
     pkg = pkgload.load()
     from petlion_jl_amd import distributed as pd
