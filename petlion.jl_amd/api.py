@@ -348,8 +348,9 @@ def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, 
     else:
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         SOC0 = np.ascontiguousarray(SOC0, dtype=np.float64)
-        bufs = dict(t=np.zeros((n, mp)), V=np.zeros((n, mp)), I=np.zeros((n, mp)), SOC=np.zeros((n, mp)), n_pts=np.zeros(n, np.int32),
-                    Y=np.zeros((n, N)), YP=np.zeros((n, N)), run_info=np.zeros((n, len(runs)), cap.RUN_INFO_DTYPE),
+        # (np.empty: the library overwrites every array in full; only the first n_pts[i] entries of a per-point row are meaningful)
+        bufs = dict(t=np.empty((n, mp)), V=np.empty((n, mp)), I=np.empty((n, mp)), SOC=np.empty((n, mp)), n_pts=np.zeros(n, np.int32),
+                    Y=np.empty((n, N)), YP=np.empty((n, N)), run_info=np.zeros((n, len(runs)), cap.RUN_INFO_DTYPE),
                     counters=np.zeros(n, cap.COUNTERS_DTYPE))
         if Y_init is not None:
             Y_init = np.ascontiguousarray(Y_init, dtype=np.float64)
@@ -359,10 +360,10 @@ def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, 
     out.T_avg = None
     out.Y_all = None
     if p.temperature:                   # per-step average temperature (calc_T_avg) only exists with temperature = true
-        bufs["T_avg"] = mk(n, mp) if device else np.zeros((n, mp))
+        bufs["T_avg"] = mk(n, mp) if device else np.empty((n, mp))
         out.T_avg = cap.ptr(bufs["T_avg"])
     if keep_Y:                          # outputs = :all : every saved state vector
-        bufs["Y_all"] = mk(n, mp, N) if device else np.zeros((n, mp, N))
+        bufs["Y_all"] = mk(n, mp, N) if device else np.empty((n, mp, N))
         out.Y_all = cap.ptr(bufs["Y_all"])
     out.n_pts, out.Y_final, out.YP_final = cap.ptr(bufs["n_pts"]), cap.ptr(bufs["Y"]), cap.ptr(bufs["YP"])
     out.run_info, out.counters = cap.ptr(bufs["run_info"]), cap.ptr(bufs["counters"])
