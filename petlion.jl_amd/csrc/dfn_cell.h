@@ -181,6 +181,15 @@ __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
 #define PL_EMU_POISON(S_) do {} while (0)
 #endif
 
+// Mixed-precision study build (-DPL_FP32_FACTORS, tools/fp32_factor_study.py): the LDS-resident factors of the Newton matrix (block-Thomas D'^-1 and
+// L D'^-1, particle resolvents) are rounded to fp32 where they are stored -- what an fp32 LDS layout would hold -- while states, residuals and all
+// arithmetic stay fp64.  The product build stores them unrounded.
+#ifdef PL_FP32_FACTORS
+#define PL_F32(x) ((double)(float)(x))
+#else
+#define PL_F32(x) (x)
+#endif
+
 // optional per-phase cycle accounting (profiling build: -DPL_PHASE_TIMERS)
 enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_OUTPUT, PH_TOTAL };
 #if defined(PL_PHASE_TIMERS) && !defined(PL_WAVE_EMU)
@@ -798,7 +807,7 @@ __device__ inline void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
         const double f = tb->V[r * NR + m] * S.w9[el * NR + m];
         for (int k = 0; k < NR; k++) acc[k] += f * tb->W[m * NR + k];
       }
-      if (lane < NR) for (int k = 0; k < NR; k++) S.Ainv[el][r * NR + k] = acc[k];
+      if (lane < NR) for (int k = 0; k < NR; k++) S.Ainv[el][r * NR + k] = PL_F32(acc[k]);
       if (lane == NR - 1) S.sig[el] = acc[NR - 1];
     }
   }
@@ -895,9 +904,9 @@ __device__ inline void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
         Dm[rr * 3 + 2] = Dn[rr * 3 + 2] - L2[rr * 3 + 2] * e22;
       }
       inv3(Dm, Dmi);
-      if (nd == TW_MID) for (int k = 0; k < 9; k++) { Dinv[k] = Dmi[k]; S.LDmid[k] = L2[k]; }
+      if (nd == TW_MID) for (int k = 0; k < 9; k++) { Dinv[k] = Dmi[k]; S.LDmid[k] = PL_F32(L2[k]); }
     }
-    if (act) for (int k = 0; k < 9; k++) { S.Dinv[i][k] = Dinv[k]; S.LD[i][k] = LDm[k]; }
+    if (act) for (int k = 0; k < 9; k++) { S.Dinv[i][k] = PL_F32(Dinv[k]); S.LD[i][k] = PL_F32(LDm[k]); }
   }
   PL_SYNC();
   // 4. border vector for modes whose control row is not "I = value":  x2 = T^-1 (column of I)
