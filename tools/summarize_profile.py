@@ -13,10 +13,12 @@ con = sqlite3.connect(os.path.join(src, "trace", "trace_results.db")); cur = con
 L += ["## `rocprofv3 --kernel-trace --stats` : top kernels", "", "| kernel | calls | total (us) | average (us) | % |", "|---|---|---|---|---|"]
 for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 6"):
     L.append("| `%s` | %d | %.1f | %.1f | %.2f |" % (r[0][:70], r[1], r[2] / 1e3 if r[2] > 1e6 else r[2], r[3] / 1e3 if r[3] > 1e5 else r[3], r[4]))
-rows = cur.execute("select duration, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels where name like '%k_integrate%'").fetchall()
+rows = cur.execute("select duration, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels where name like '%k_integrate%' order by start").fetchall()
 d = [r[0] for r in rows]
 L += ["", "`k_integrate`: %d dispatches, duration min/avg/max = %.1f / %.1f / %.1f us; grid %d x wg %d; arch VGPR %s, AGPR %s, SGPR %s, LDS %s B, scratch %s B/lane"
-      % (len(d), min(d) / 1e3, sum(d) / len(d) / 1e3, max(d) / 1e3, rows[0][6], rows[0][7], rows[0][1], rows[0][2], rows[0][3], rows[0][4], rows[0][5]), ""]
+      % (len(d), min(d) / 1e3, sum(d) / len(d) / 1e3, max(d) / 1e3, rows[0][6], rows[0][7], rows[0][1], rows[0][2], rows[0][3], rows[0][4], rows[0][5]),
+      "", "Per dispatch in launch order (us): " + ", ".join("%.0f" % (x / 1e3) for x in d) + " -- the first launches of a process run slower (clock ramp); "
+      "the steady state (last three: %.0f us) is what `bench.py` times after its warm-up steps (`roofline.kernel_ms_avg`, HIP events on the launch stream)." % (sum(d[-3:]) / 3e3), ""]
 L += ["## PMC passes (per k_integrate launch = 1024 cells = 1024 wavefronts; averages over the dispatches of the run)", "", "| counter | value per launch | per wavefront |", "|---|---|---|"]
 vals = {}
 for dbf in sorted(glob.glob(os.path.join(src, "pmc*", "*.db"))):
