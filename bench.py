@@ -76,8 +76,8 @@ def usable_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--cells-per-gpu", type=int, default=CELLS_PER_GPU)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
