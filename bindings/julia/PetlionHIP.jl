@@ -21,6 +21,8 @@ const VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE = Cint(0), Cint(1), Cint(2), Cint
 struct ModelDesc
     chemistry::Cint; N_p::Cint; N_s::Cint; N_n::Cint; N_a::Cint; N_z::Cint; N_r_p::Cint; N_r_n::Cint
     temperature::Cint; aging_SEI::Cint; real_bytes::Cint
+    precision::Cint      # 0 = fp64, 1 = mixed (fp32 storage of the Newton-matrix factors)
+    device::Cint         # HIP device ordinal, -1 = current
 end
 struct Bounds      # boundary_stop_conditions, src/structures.jl:237-250
     V_max::Cdouble; V_min::Cdouble; SOC_max::Cdouble; SOC_min::Cdouble; T_max::Cdouble; c_s_n_max::Cdouble
@@ -34,7 +36,8 @@ end
 struct Opts
     abstol::Cdouble; reltol::Cdouble; abstol_init::Cdouble; reltol_init::Cdouble
     maxiters::Cint; check_bounds::Cint; interp_final::Cint; max_order::Cint; jac_every_step::Cint; init_step::Cdouble
-    n_tdiscon::Cint; tdiscon::NTuple{16,Cdouble}
+    n_tdiscon::Cint; tdiscon::Ptr{Cdouble}     # host array of any length (the caller keeps it alive across the call)
+    refine::Cint                                # iterative-refinement steps per linear solve (parity mode), 0 = off
 end
 struct RunInfo
     flag::Cint; iterations::Cint; t_end::Cdouble; V::Cdouble; I::Cdouble; SOC::Cdouble; T_avg::Cdouble
@@ -55,10 +58,10 @@ check(rc, what) = rc == 0 || error("$what failed ($rc): $(lasterror())")
 mutable struct Model
     h::Ptr{Cvoid}
     N::Int; N_diff::Int; θ_keys::Vector{Symbol}
-    function Model(p)   # p::PETLION.model -- reads only p.N and p.numerics
+    function Model(p; precision = 0, device = -1)   # p::PETLION.model -- reads only p.N and p.numerics
         N = p.N
         chem = Symbol(p.numerics.cathode) == :LCO ? 0 : 1      # function name of the cathode system, as in strings_directory_func
-        d = Ref(ModelDesc(chem, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, p.numerics.temperature == true, p.numerics.aging == :SEI, 8))
+        d = Ref(ModelDesc(chem, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, p.numerics.temperature == true, p.numerics.aging == :SEI, 8, precision, device))
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:plh_model_create, lib), Cint, (Ref{ModelDesc}, Ref{Ptr{Cvoid}}), d, h), "plh_model_create")
         n = ccall((:plh_n_theta, lib), Cint, (Ptr{Cvoid},), h[])
@@ -106,13 +109,13 @@ end
 the transposed copy is passed).
 """
 function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.opts.SOC, max_pts = 2048, Y_init = nothing, t_init = nothing,
-                           outputs = p.opts.outputs)
+                           outputs = p.opts.outputs, refine = 0)
     n = size(Θ, 1)
     runs = [make_run(p, s) for s in protocol]
     o = p.opts
-    td = Float64.(o.tdiscon); length(td) <= 16 || error("at most 16 tdiscon entries")
+    td = Float64.(o.tdiscon)
     opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0,
-                    length(td), ntuple(k -> k <= length(td) ? td[k] : 0.0, 16)))
+                    length(td), isempty(td) ? C_NULL : pointer(td), refine))
     Θt = permutedims(Θ)                                   # column-major n_theta × n_cells == row-major cells
     soc = SOC isa Number ? fill(Float64(SOC), n) : Vector{Float64}(SOC)
     t = zeros(max_pts, n); V = similar(t); I = similar(t); S = similar(t)
@@ -122,7 +125,7 @@ function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.o
     keep_Y = any(x -> x ∈ (:all, :Y, :c_e, :c_s_avg, :T, :film, :SOH, :j, :j_s, :Φ_e, :Φ_s), outs)     # solution_states_logic, src/outputs.jl:107-131
     Tavg = p.numerics.temperature ? zeros(max_pts, n) : Float64[]
     Yall = keep_Y ? zeros(m.N, max_pts, n) : Float64[]                  # sol.Y of every cell: Yall[:, k, i] = state after step k of cell i
-    GC.@preserve t V I S npts Y YP info cnt Tavg Yall begin
+    GC.@preserve t V I S npts Y YP info cnt Tavg Yall td begin
         out = Ref(Outputs(max_pts, pointer(t), pointer(V), pointer(I), pointer(S), isempty(Tavg) ? C_NULL : pointer(Tavg), pointer(npts), pointer(Y), pointer(YP),
                           pointer(info), pointer(cnt), keep_Y ? pointer(Yall) : C_NULL))
         rc = ccall((:plh_integrate, lib), Cint,
@@ -141,8 +144,17 @@ function residual!(res::Vector{Float64}, m::Model, Y, YP, θ; mode = :I, value =
                 m.h, 1, θ, Y, YP, MODE[mode], value, res, PLH_HOST, C_NULL), "plh_residual")
     res
 end
-f_diff!(out, m::Model, Y, YP, θ) = (r = residual!(zeros(m.N), m, Y, YP, θ); out .= @view r[1:m.N_diff]; nothing)
-f_alg!(out, m::Model, Y, YP, θ) = (r = residual!(zeros(m.N), m, Y, YP, θ); out .= @view r[m.N_diff+1:m.N-1]; nothing)
+# f_diff!(out[N_diff], t, Y, YP, θ) / f_alg!(out[N_alg-1], t, Y, YP, θ): `out` may be a contiguous range view of `res` (scalar_residual.jl:559-560)
+function f_diff!(out, m::Model, Y, YP, θ)
+    check(ccall((:plh_residual_diff, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cvoid}),
+                m.h, 1, θ, Y, YP, out, PLH_HOST, C_NULL), "plh_residual_diff")
+    nothing
+end
+function f_alg!(out, m::Model, Y, YP, θ)
+    check(ccall((:plh_residual_alg, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cvoid}),
+                m.h, 1, θ, Y, YP, out, PLH_HOST, C_NULL), "plh_residual_alg")
+    nothing
+end
 function J_full!(nzval::Vector{Float64}, m::Model, Y, YP, γ, θ; mode = :I)
     check(ccall((:plh_jacobian, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cint, Ptr{Cdouble}, Cint, Ptr{Cvoid}),
                 m.h, 1, θ, Y, YP, γ, MODE[mode], nzval, PLH_HOST, C_NULL), "plh_jacobian")
@@ -150,14 +162,17 @@ function J_full!(nzval::Vector{Float64}, m::Model, Y, YP, γ, θ; mode = :I)
 end
 "J_y_alg! (generate_functions.jl:318-325): the block J[N_diff+1:N-1, N_diff+1:N] of the full Jacobian at γ = 0, in the CSC order of that block"
 function J_alg!(nzval::Vector{Float64}, m::Model, Y, YP, θ; mode = :I)
-    cp, ri = jac_pattern(m; mode = mode)
-    full = J_full!(zeros(length(ri)), m, Y, YP, 0.0, θ; mode = mode)
-    k = 0
-    for c in m.N_diff+1:m.N, q in cp[c]+1:cp[c+1]        # cp, ri are 0-based
-        r = ri[q] + 1
-        (r > m.N_diff && r < m.N) && (k += 1; nzval[k] = full[q])
-    end
+    check(ccall((:plh_jacobian_alg, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cvoid}),
+                m.h, 1, θ, Y, YP, MODE[mode], nzval, PLH_HOST, C_NULL), "plh_jacobian_alg")
     nzval
+end
+"0-based CSC pattern (colptr, rowval) of the J_y_alg block: N_alg columns, rows relative to N_diff"
+function jac_alg_pattern(m::Model; mode = :I)
+    nnz = Ref{Cint}(0)
+    ccall((:plh_jac_alg_pattern, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}, Ptr{Cint}, Ptr{Cint}), m.h, MODE[mode], nnz, C_NULL, C_NULL)
+    cp = zeros(Cint, m.N - m.N_diff + 1); ri = zeros(Cint, nnz[])
+    check(ccall((:plh_jac_alg_pattern, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}, Ptr{Cint}, Ptr{Cint}), m.h, MODE[mode], nnz, cp, ri), "plh_jac_alg_pattern")
+    cp, ri
 end
 function initial_guess!(out::Vector{Float64}, m::Model, SOC, θ)
     check(ccall((:plh_initial_guess, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cvoid}), m.h, 1, θ, SOC, out, PLH_HOST, C_NULL), "plh_initial_guess")
@@ -170,6 +185,39 @@ function jac_pattern(m::Model; mode = :I)
     cp = zeros(Cint, m.N + 1); ri = zeros(Cint, nnz[])
     check(ccall((:plh_jac_pattern, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}, Ptr{Cint}, Ptr{Cint}), m.h, MODE[mode], nnz, cp, ri), "plh_jac_pattern")
     cp, ri
+end
+
+# ---- multi-GPU: one Julia process per GPU (Distributed.jl / MPI.jl workers), RCCL inside the library for the ensemble scatter / gather ----
+#     id = myid() == root ? PetlionHIP.unique_id() : nothing          # 128 bytes, handed to the other workers by the host's own means
+#     comm = PetlionHIP.Comm(n_ranks, rank, id; device = rank)        # every worker
+#     info, cnt, ms = PetlionHIP.ensemble_run(comm, m, p, Θ, protocol; SOC = 1.0, partition = :cyclic)    # Θ significant on rank 0
+unique_id() = (id = zeros(UInt8, 128); check(ccall((:plh_comm_unique_id, lib), Cint, (Ptr{UInt8},), id), "plh_comm_unique_id"); id)
+mutable struct Comm
+    h::Ptr{Cvoid}
+    function Comm(n_ranks, rank, id::Vector{UInt8}; device = -1)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:plh_comm_create, lib), Cint, (Cint, Cint, Ptr{UInt8}, Cint, Ref{Ptr{Cvoid}}), n_ranks, rank, id, device, h), "plh_comm_create")
+        c = new(h[]); finalizer(x -> ccall((:plh_comm_destroy, lib), Cvoid, (Ptr{Cvoid},), x.h), c)
+    end
+end
+comm_rank(c::Comm) = ccall((:plh_comm_rank, lib), Cint, (Ptr{Cvoid},), c.h)
+comm_size(c::Comm) = ccall((:plh_comm_size, lib), Cint, (Ptr{Cvoid},), c.h)
+function ensemble_run(c::Comm, m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.opts.SOC, partition = :block, n_cells = size(Θ, 1), refine = 0)
+    runs = [make_run(p, s) for s in protocol]
+    o = p.opts; td = Float64.(o.tdiscon)
+    root = comm_rank(c) == 0
+    Θt = root ? permutedims(Θ) : zeros(0, 0)
+    soc = root ? (SOC isa Number ? fill(Float64(SOC), n_cells) : Vector{Float64}(SOC)) : Float64[]
+    info = Matrix{RunInfo}(undef, length(runs), root ? n_cells : 0); cnt = Vector{Counters}(undef, root ? n_cells : 0); ms = zeros(comm_size(c))
+    GC.@preserve td Θt soc info cnt ms begin
+        opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0,
+                        length(td), isempty(td) ? C_NULL : pointer(td), refine))
+        check(ccall((:plh_ensemble_run, lib), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Run}, Ref{Opts}, Cint, Ptr{RunInfo}, Ptr{Counters}, Ptr{Cdouble}, Ptr{Cdouble}),
+                    c.h, m.h, n_cells, root ? pointer(Θt) : C_NULL, root ? pointer(soc) : C_NULL, length(runs), runs, opts, partition === :cyclic ? 1 : 0,
+                    root ? pointer(info) : C_NULL, root ? pointer(cnt) : C_NULL, C_NULL, root ? pointer(ms) : C_NULL), "plh_ensemble_run")
+    end
+    info, cnt, ms
 end
 
 end # module

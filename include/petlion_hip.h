@@ -15,7 +15,9 @@
  *     using the reference's exit flags 0..11 (src/checks.jl:6,40,47,66,73,90,97,116,152,175,194,217) and negative codes
  *     for the reference's error() paths.
  *   - a handle is used by one host thread at a time (the reference model object is not re-entrant either,
- *     src/external.jl:135-139); different handles / GPUs may be used concurrently.
+ *     src/external.jl:135-139); different handles / GPUs may be used concurrently.  One handle may have launches in flight on several
+ *     streams: the per-launch device workspaces (previous-point scratch, protocol copy, staging blocks) are kept per stream.
+ *   - a handle is bound to one HIP device (plh_model_desc.device); every call switches to it and restores the caller's device.
  */
 #ifndef PETLION_HIP_H
 #define PETLION_HIP_H
@@ -26,6 +28,9 @@ extern "C" {
 
 #define PLH_HOST 0
 #define PLH_DEVICE 1
+#define PLH_HOST_ASYNC 2   /* plh_integrate only: the arrays are PINNED host memory from plh_host_alloc; the call enqueues the host-to-device copies, the kernel and
+                              the device-to-host copies on `stream` and returns -- the outputs are valid after plh_synchronize(m, stream).  Two streams and two
+                              buffer sets overlap one call's copies with the next call's kernel (the host-inclusive pipeline of bench.py). */
 
 #define PLH_E_ARG (-1)          /* invalid argument */
 #define PLH_E_UNSUPPORTED (-2)  /* model option outside the hot-path scope */
@@ -43,6 +48,10 @@ extern "C" {
 #define PLH_MODE_P 3   /* power, W/m^2:         Y[I] I1C (Phi_s[1] - Phi_s[end]) - value   (method_P, input_methods.jl:80-111) */
 #define PLH_MODE_ETA_P 4 /* plating overpotential, V: Phi_s.n[1] - Phi_e.n[1] - value     (method_η_p, input_methods.jl:113-152) */
 #define PLH_N_MODES 5
+
+/* plh_model_desc.precision */
+#define PLH_PREC_F64 0    /* everything fp64 (default; the parity configuration) */
+#define PLH_PREC_MIXED 1  /* block-Thomas factors and particle resolvents stored in fp32 in LDS; states, residuals, Jacobian entries, time, error control fp64 */
 
 /* how `value` is obtained (reference input_methods.jl:11-30,53-63; model_evaluation.jl:165-170) */
 #define PLH_VAL_CONST 0
@@ -66,7 +75,10 @@ typedef struct {
   int N_p, N_s, N_n, N_a, N_z, N_r_p, N_r_n;      /* reference defaults: 10 each */
   int temperature;                                /* 0/1 */
   int aging_SEI;                                  /* 0/1 */
-  int real_bytes;                                 /* 8 */
+  int real_bytes;                                 /* 8: states, residuals, time and tolerances are fp64 (the reference is Float64 everywhere) */
+  int precision;                                  /* PLH_PREC_* : storage precision of the LDS-resident Newton-matrix factors (config C5's fp32 leg) */
+  int device;                                     /* HIP device ordinal the handle binds to (every call of the handle runs there); -1 = the device that is
+                                                     current when plh_model_create is called */
 } plh_model_desc;
 
 /* reference boundary_stop_conditions (src/structures.jl:237-250); NaN disables a bound */
@@ -98,7 +110,11 @@ typedef struct {
   int max_order;                                     /* BDF order cap, 5 */
   int jac_every_step;                                /* 0: IDA's Jacobian-reuse policy */
   double init_step;                                  /* 0: IDA's automatic h0 = 0.5/||y'||_wrms; >0: IDASetInitStep (src/checks.jl:231) */
-  int n_tdiscon; double tdiscon[16];                 /* opts.tdiscon (src/structures.jl:279): tstops at tdiscon - reltol/2 (model_evaluation.jl:295-297) */
+  int n_tdiscon; const double* tdiscon;              /* opts.tdiscon (src/structures.jl:279), any length, HOST array like the protocol (staged by
+                                                        plh_integrate): tstops at tdiscon - reltol/2 (model_evaluation.jl:295-297) */
+  int refine;                                        /* 0 (default): plain structured solves.  n > 0: n steps of iterative refinement of every linear solve
+                                                        (init Newton and corrector) against the factored matrix -- the parity mode: the solution no longer
+                                                        depends on the elimination order (structured here, KLU's in the reference) beyond ~1e-13 */
 } plh_opts;
 
 /* per-cell, per-run summary == run_info + the printed summary (src/structures.jl:40-44, 678-746) */
@@ -143,7 +159,14 @@ int plh_section(plh_model_t m, int i, const char** name, int* start, int* len);
 /* CSC pattern (0-based) of the full N x N Jacobian for a mode == [J_y_sp ; scalar row] of
  * _get_jacobian_combined (src/physics_equations/scalar_residual.jl:500-522).  colptr/rowval may be NULL to query nnz. */
 int plh_jac_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval);
+/* CSC pattern (0-based, rows/columns relative to the block) of J_y_alg = J[N_diff : N-1, N_diff : N] at gamma = 0, the generated-function
+ * J_y_alg! of seam 1 (src/generate_functions.jl:318-325): N_alg columns, N_alg - 1 rows (the control row is not generated). */
+int plh_jac_alg_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval);
 const char* plh_last_error(void);
+/* sizeof / offsetof of every struct of this header as the library was compiled, for bindings that mirror them by hand (bindings/julia/PetlionHIP.jl,
+ * the ctypes mirror of the tests): out[] receives, per struct in declaration order (plh_model_desc, plh_bounds, plh_run, plh_opts, plh_run_info,
+ * plh_counters, plh_outputs): sizeof, number of fields, then the offset of each field.  Returns the number of ints written (or needed, if cap is short). */
+int plh_abi_layout(int* out, int cap);
 
 /* ---- batched evaluators (single-cell seam = n_cells 1, PLH_HOST) ---- */
 /* initial_guess!(out, SOC, θ, X_applied)  (src/states_definition.jl:80-121): Y[cell][N], Y[I] = 0 */
@@ -158,6 +181,17 @@ int plh_jacobian(plh_model_t m, int n_cells, const double* theta, const double* 
  * (src/model_evaluation.jl:271, 417-428): b[cell][N] in, x out in place */
 int plh_linear_solve(plh_model_t m, int n_cells, const double* theta, const double* Y, const double* YP, double cj, int mode,
                      double* b, int ptr_kind, void* stream);
+/* the same with n_refine steps of iterative refinement against the factored matrix (plh_opts.refine of the integrator as a stand-alone evaluator) */
+int plh_linear_solve_refined(plh_model_t m, int n_cells, const double* theta, const double* Y, const double* YP, double cj, int mode,
+                             double* b, int n_refine, int ptr_kind, void* stream);
+/* seam 1's split evaluators, with the argument lists of the five generated functions (src/generate_functions.jl:44-94, callers
+ * scalar_residual.jl:558-602): f_diff!(out[N_diff], t, Y, YP, θ), f_alg!(out[N_alg - 1], t, Y, YP, θ) (no control row, generate_functions.jl:254),
+ * J_y_alg!(nzval[nnz_alg], t, Y, YP, γ, θ) in the CSC order of plh_jac_alg_pattern.  J_y! is plh_jacobian minus the control row's entries
+ * (a stub gathers them through the pattern, bindings/julia/SavedModelWriter.jl). */
+int plh_residual_diff(plh_model_t m, int n_cells, const double* theta, const double* Y, const double* YP, double* out, int ptr_kind, void* stream);
+int plh_residual_alg(plh_model_t m, int n_cells, const double* theta, const double* Y, const double* YP, double* out, int ptr_kind, void* stream);
+int plh_jacobian_alg(plh_model_t m, int n_cells, const double* theta, const double* Y, const double* YP, int mode, double* nzval,
+                     int ptr_kind, void* stream);
 /* newtons_method! (src/model_evaluation.jl:430-480): Y in/out, YP out, status[cell] 0 or PLH_ERR_INIT, iters[cell] */
 int plh_init_consistent(plh_model_t m, int n_cells, const double* theta, int mode, double value, double reltol_init,
                         double* Y, double* YP, int* status, int* iters, int ptr_kind, void* stream);
@@ -173,6 +207,32 @@ int plh_integrate(plh_model_t m, int n_cells, const double* theta, const double*
 
 /* timing of the last plh_integrate kernel on its stream, measured with HIP events (ms); <0 if unavailable */
 double plh_last_kernel_ms(plh_model_t m);
+
+/* pinned host memory for PLH_HOST_ASYNC calls, and the completion point of everything the handle enqueued on `stream` */
+int plh_host_alloc(void** p, unsigned long long bytes);
+void plh_host_free(void* p);
+int plh_synchronize(plh_model_t m, void* stream);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI for the ensemble scatter / gather only ----
+ * A communicator joins n_ranks processes, each bound to one GPU.  Rank 0 obtains a 128-byte id with plh_comm_unique_id and hands it to the other
+ * ranks by whatever means the host has (MPI, Distributed.jl, a file); every rank then calls plh_comm_create(n_ranks, rank, id, device).
+ * plh_ensemble_run (collective: every rank calls it with the same protocol / options; theta, SOC0 and the output arrays are significant on rank 0
+ * only and are HOST memory):
+ *   1. ncclBroadcast of the ensemble shape, 2. scatter of the parameter rows from rank 0 (grouped ncclSend / ncclRecv; partition = contiguous blocks
+ *   cells[r n/G, (r+1) n/G) or cyclic cell mod G, which evens out step-count variance in randomised sweeps), 3. plh_integrate of the local shard on the
+ *   rank's GPU (no collective in the data path: cells are independent for the whole trajectory), 4. gather of the per-cell summaries (run_info,
+ *   counters, optionally the final states) to rank 0 in the caller's cell order.  rank_ms[n_ranks] (rank 0, may be NULL) receives every rank's
+ *   integrate-kernel time: the load-imbalance figure of a randomised sweep. */
+typedef struct plh_comm_s* plh_comm_t;
+#define PLH_PART_BLOCK 0
+#define PLH_PART_CYCLIC 1
+int plh_comm_unique_id(char id[128]);
+int plh_comm_create(int n_ranks, int rank, const char id[128], int device, plh_comm_t* out);
+void plh_comm_destroy(plh_comm_t c);
+int plh_comm_rank(plh_comm_t c);
+int plh_comm_size(plh_comm_t c);
+int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_cells_total, const double* theta, const double* SOC0, int n_runs, const plh_run* runs,
+                     const plh_opts* opts, int partition, plh_run_info* run_info, plh_counters* counters, double* Y_final, double* rank_ms);
 
 #ifdef __cplusplus
 }

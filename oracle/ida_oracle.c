@@ -299,7 +299,9 @@ typedef struct {   /* reference options_simulation, src/structures.jl:266-285 */
   int max_order;      /* 5 */
   int jac_every_step; /* 0 = IDA policy (default); 1 = refresh each step (ablation) */
   double init_step;   /* 0 = automatic; > 0 = IDASetInitStep */
-  int n_tdiscon; double tdiscon[16];   /* opts.tdiscon: known discontinuities of a function input (structures.jl:279) */
+  int n_tdiscon; const double* tdiscon;   /* opts.tdiscon: known discontinuities of a function input (structures.jl:279) */
+  int refine;         /* 0 = plain LU solves (default); n > 0 = n steps of iterative refinement of every linear solve against the matrix that
+                         was factored (parity mode: makes the solve independent of the elimination order to ~1e-13, see tools/solve_accuracy.py) */
 } orc_opts;
 
 typedef struct {
@@ -330,6 +332,7 @@ typedef struct {
   /* algebraic Jacobian CSC (N_alg x N_alg) */
   int *acp, *ari; double* aax; int annz; int* abase_map; int an_ctrl; int actrl_pos[64]; int actrl_col[64];
   double *tmp_nz, *w;
+  double *ax_f, *aax_f, *rtmp, *xtmp;   /* the matrices as last factored (iterative refinement), work vectors */
   double I1C;
   const orc_run* frun;   /* != NULL: the control value is frun's table evaluated at the current time */
   splu lu, alu;
@@ -396,6 +399,7 @@ static int evalb_init(evalb* e, const orc_model* m, const double* th, int mode, 
   build_pattern(Na, Na - 1, m->acolptr, m->arowval, Nd, e->an_ctrl, e->actrl_col, &e->acp, &e->ari, &e->annz, &e->abase_map, e->actrl_pos);
   e->ax = (double*)calloc(e->nnz, sizeof(double)); e->aax = (double*)calloc(e->annz, sizeof(double));
   e->tmp_nz = (double*)calloc(m->nnz + 64, sizeof(double)); e->w = (double*)calloc(N, sizeof(double));
+  e->ax_f = (double*)calloc(e->nnz, sizeof(double)); e->aax_f = (double*)calloc(e->annz, sizeof(double)); e->rtmp = (double*)calloc(N, sizeof(double)); e->xtmp = (double*)calloc(N, sizeof(double));
   if (m->thermal) m->dT_weights(e->w, th);
   e->I1C = calc_I1C_c(m, th);
   splu_init(&e->lu, N, e->cp, e->ri); splu_init(&e->alu, Na, e->acp, e->ari);
@@ -403,7 +407,7 @@ static int evalb_init(evalb* e, const orc_model* m, const double* th, int mode, 
 }
 static void evalb_free(evalb* e) {
   free(e->cp); free(e->ri); free(e->ax); free(e->base_map); free(e->acp); free(e->ari); free(e->aax); free(e->abase_map);
-  free(e->tmp_nz); free(e->w); splu_free(&e->lu); splu_free(&e->alu);
+  free(e->tmp_nz); free(e->w); free(e->ax_f); free(e->aax_f); free(e->rtmp); free(e->xtmp); splu_free(&e->lu); splu_free(&e->alu);
 }
 
 static double ctrl_residual(const evalb* e, const double* Y, const double* YP) {
@@ -461,6 +465,26 @@ static void J_alg(evalb* e, const double* Y, const double* YP) {
   if (e->cnt) e->cnt->n_jac++;
 }
 
+
+/* factor + remember the matrix; solve with `nref` steps of iterative refinement  x += A^-1 (b - A x)  against that matrix */
+static int lu_setup_keep(splu* f, int n, const int* cp, const int* ri, const double* ax, double* ax_keep) {
+  memcpy(ax_keep, ax, (size_t)cp[n] * sizeof(double));
+  return splu_setup(f, cp, ri, ax);
+}
+static void lu_solve_refined(const splu* f, int n, const int* cp, const int* ri, const double* ax_keep, double* b, double* r, double* x0, int nref) {
+  if (nref <= 0) { splu_solve(f, b); return; }
+  memcpy(r, b, n * sizeof(double));                 /* r = b (kept) */
+  splu_solve(f, b);                                 /* b = x */
+  for (int it = 0; it < nref; it++) {
+    memcpy(x0, b, n * sizeof(double));
+    /* b <- r - A x  (CSC) */
+    for (int i = 0; i < n; i++) b[i] = r[i];
+    for (int c = 0; c < n; c++) { const double xc = x0[c]; for (int p = cp[c]; p < cp[c + 1]; p++) b[ri[p]] -= ax_keep[p] * xc; }
+    splu_solve(f, b);
+    for (int i = 0; i < n; i++) b[i] += x0[i];
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* consistent initialisation: newtons_method!  (reference src/model_evaluation.jl:430-480)                      */
 /* ------------------------------------------------------------------------------------------------------------ */
@@ -471,9 +495,9 @@ static int newtons_method(evalb* e, double* Y, double* YP, const orc_opts* o, do
   int ok = 0;
   for (int iter = 1; iter <= 100; iter++) {
     R_alg(e, res, Y, YP); J_alg(e, Y, YP);
-    if (splu_setup(&e->alu, e->acp, e->ari, e->aax) != 0) { free(res); free(Ynew); return ORC_ERR_LINSOL; }
+    if (lu_setup_keep(&e->alu, Na, e->acp, e->ari, e->aax, e->aax_f) != 0) { free(res); free(Ynew); return ORC_ERR_LINSOL; }
     if (e->cnt) { e->cnt->n_fact++; e->cnt->n_solve++; e->cnt->n_init_iters++; }
-    splu_solve(&e->alu, res);
+    lu_solve_refined(&e->alu, Na, e->acp, e->ari, e->aax_f, res, e->rtmp, e->xtmp, o->refine);
     double nrm = 0.0;
     for (int i = 0; i < Na; i++) { Y[Nd + i] -= res[i]; nrm += res[i] * res[i]; }
     if (sqrt(nrm) < o->reltol_init) { ok = 1; break; }
@@ -486,7 +510,7 @@ static int newtons_method(evalb* e, double* Y, double* YP, const orc_opts* o, do
   double dt = fmax(10.0 * o->reltol_init, sqrt(nextafter(c_e0, INFINITY) - c_e0));
   for (int i = 0; i < N; i++) Ynew[i] = Y[i] + dt * YP[i];
   R_alg(e, res, Ynew, YP);
-  splu_solve(&e->alu, res);
+  lu_solve_refined(&e->alu, Na, e->acp, e->ari, e->aax_f, res, e->rtmp, e->xtmp, o->refine);
   if (e->cnt) e->cnt->n_solve++;
   for (int i = 0; i < Na; i++) YP[Nd + i] = -res[i] / dt;
   free(res); free(Ynew);
@@ -576,7 +600,7 @@ static int ida_nls(ida_t* I) {
     R_full(e, I->delta, I->yy, I->yp);
     if (callLSetup) {
       J_full(e, I->yy, I->yp, I->cj);
-      if (splu_setup(&e->lu, e->cp, e->ri, e->ax) != 0) return 1;     /* treat as recoverable */
+      if (lu_setup_keep(&e->lu, N, e->cp, e->ri, e->ax, e->ax_f) != 0) return 1;     /* treat as recoverable */
       if (cnt) cnt->n_fact++;
       I->cjold = I->cj; I->cjratio = 1.0; I->ss = 20.0; jcur = 1;
     }
@@ -584,7 +608,7 @@ static int ida_nls(ida_t* I) {
     for (;;) {
       if (cnt) { cnt->n_newton++; cnt->n_solve++; }
       for (int n = 0; n < N; n++) I->delta[n] = -I->delta[n];
-      splu_solve(&e->lu, I->delta);
+      lu_solve_refined(&e->lu, N, e->cp, e->ri, e->ax_f, I->delta, e->rtmp, e->xtmp, I->o->refine);
       if (I->cjratio != 1.0) { double s = 2.0 / (1.0 + I->cjratio); for (int n = 0; n < N; n++) I->delta[n] *= s; }
       for (int n = 0; n < N; n++) I->ee[n] += I->delta[n];
       double delnrm = wrms(N, I->delta, I->ewt);
@@ -876,8 +900,8 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
     if (ierr != 0) { ri->flag = ierr; ri->t_end = t_global; rc = 1; break; }
     ida_reinit(Ip, e, opts, Y, YP);
     /* tstops (postfix_integrator!, model_evaluation.jl:288-310): {1.0 if continuation} U {tf} */
-    double tstops[20]; int nts = 0, its = 0;
-    for (int q = 0; q < opts->n_tdiscon && q < 16; q++) tstops[nts++] = opts->tdiscon[q] - opts->reltol / 2;     /* model_evaluation.jl:295-297 */
+    double* tstops = (double*)malloc((opts->n_tdiscon + 4) * sizeof(double)); int nts = 0, its = 0;
+    for (int q = 0; q < opts->n_tdiscon; q++) tstops[nts++] = opts->tdiscon[q] - opts->reltol / 2;     /* model_evaluation.jl:295-297 */
     if (!new_run) tstops[nts++] = 1.0;
     tstops[nts++] = run->tf;
     for (int a = 1; a < nts; a++) { double v = tstops[a]; int b = a - 1; while (b >= 0 && tstops[b] > v) { tstops[b + 1] = tstops[b]; b--; } tstops[b + 1] = v; }   /* sort! */
@@ -1036,11 +1060,14 @@ int orc_init_consistent(const char* variant, const double* theta, int mode, doub
   evalb_free(&e); return rc;
 }
 /* solve J x = b with the KLU-like LU (used to cross-check the structured device solver) */
-int orc_linear_solve(const char* variant, const double* theta, int mode, double value, const double* Y, const double* YP, double cj, double* b) {
+int orc_linear_solve_refined(const char* variant, const double* theta, int mode, double value, const double* Y, const double* YP, double cj, double* b, int nref) {
   orc_model M; if (get_model(variant, &M) != 0) return -100;
   evalb e; if (evalb_init(&e, &M, theta, mode, value, NULL) != 0) return -102;
   J_full(&e, Y, YP, cj);
-  int rc = splu_setup(&e.lu, e.cp, e.ri, e.ax);
-  if (rc == 0) splu_solve(&e.lu, b);
+  int rc = lu_setup_keep(&e.lu, M.N, e.cp, e.ri, e.ax, e.ax_f);
+  if (rc == 0) lu_solve_refined(&e.lu, M.N, e.cp, e.ri, e.ax_f, b, e.rtmp, e.xtmp, nref);
   evalb_free(&e); return rc;
+}
+int orc_linear_solve(const char* variant, const double* theta, int mode, double value, const double* Y, const double* YP, double cj, double* b) {
+  return orc_linear_solve_refined(variant, theta, mode, value, Y, YP, cj, b, 0);
 }

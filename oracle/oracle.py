@@ -33,7 +33,8 @@ class Run(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("abstol_init", C.c_double), ("reltol_init", C.c_double),
                 ("maxiters", C.c_int), ("check_bounds", C.c_int), ("interp_final", C.c_int), ("max_order", C.c_int),
-                ("jac_every_step", C.c_int), ("init_step", C.c_double), ("n_tdiscon", C.c_int), ("tdiscon", C.c_double * 16)]
+                ("jac_every_step", C.c_int), ("init_step", C.c_double), ("n_tdiscon", C.c_int), ("tdiscon", C.POINTER(C.c_double)),
+                ("refine", C.c_int)]
 
 
 class RunInfo(C.Structure):
@@ -78,15 +79,15 @@ def default_bounds(cathode="LCO", **over):
 
 
 def default_opts(**over):
-    d = dict(abstol=1e-6, reltol=1e-3, maxiters=10000, check_bounds=1, interp_final=1, max_order=5, jac_every_step=0, init_step=0.0)
-    tdiscon = list(over.pop("tdiscon", []))
+    d = dict(abstol=1e-6, reltol=1e-3, maxiters=10000, check_bounds=1, interp_final=1, max_order=5, jac_every_step=0, init_step=0.0, refine=0)
+    tdiscon = np.ascontiguousarray(list(over.pop("tdiscon", [])), dtype=np.float64)
     d.update(over)
     d.setdefault("abstol_init", d["abstol"])
     d.setdefault("reltol_init", d["reltol"])
     o = Opts(**d)
-    o.n_tdiscon = len(tdiscon)
-    for k, v in enumerate(tdiscon):
-        o.tdiscon[k] = float(v)
+    o.n_tdiscon = tdiscon.size
+    o.tdiscon = _dp(tdiscon) if tdiscon.size else None
+    o._keep = tdiscon
     return o
 
 
@@ -190,12 +191,12 @@ def init_consistent(variant, theta, Y, mode=MODE_I, value=0.0, reltol_init=1e-3)
     return rc, Y, YP, it.value
 
 
-def linear_solve(variant, theta, Y, YP, cj, b, mode=MODE_I, value=0.0):
+def linear_solve(variant, theta, Y, YP, cj, b, mode=MODE_I, value=0.0, refine=0):
     L = lib()
     b = np.array(b, dtype=np.float64)
-    rc = L.orc_linear_solve(variant.encode(), _dp(np.ascontiguousarray(theta)), mode, C.c_double(value),
-                            _dp(np.ascontiguousarray(Y, dtype=np.float64)), _dp(np.ascontiguousarray(YP, dtype=np.float64)),
-                            C.c_double(cj), _dp(b))
+    rc = L.orc_linear_solve_refined(variant.encode(), _dp(np.ascontiguousarray(theta)), mode, C.c_double(value),
+                                    _dp(np.ascontiguousarray(Y, dtype=np.float64)), _dp(np.ascontiguousarray(YP, dtype=np.float64)),
+                                    C.c_double(cj), _dp(b), int(refine))
     assert rc == 0, rc
     return b
 

@@ -14,7 +14,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PETLION_HIP_LIB") or os.path.join(HERE, "libpetlion_hip.so")     # the override is for build experiments (tools/opt_level_check.sh)
 
-PLH_HOST, PLH_DEVICE = 0, 1
+PLH_HOST, PLH_DEVICE, PLH_HOST_ASYNC = 0, 1, 2
+PREC_F64, PREC_MIXED = 0, 1
+PART_BLOCK, PART_CYCLIC = 0, 1
 MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETA_P = 0, 1, 2, 3, 4
 VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE = 0, 1, 2, 3
 CHEM_LCO, CHEM_NMC = 0, 1
@@ -26,7 +28,7 @@ BOUND_FIELDS = ["V_max", "V_min", "SOC_max", "SOC_min", "T_max", "c_s_n_max", "I
 
 class ModelDesc(C.Structure):
     _fields_ = [(f, C.c_int) for f in ["chemistry", "N_p", "N_s", "N_n", "N_a", "N_z", "N_r_p", "N_r_n", "temperature",
-                                      "aging_SEI", "real_bytes"]]
+                                      "aging_SEI", "real_bytes", "precision", "device"]]
 
 
 class Bounds(C.Structure):
@@ -42,7 +44,8 @@ class Run(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("abstol_init", C.c_double), ("reltol_init", C.c_double),
                 ("maxiters", C.c_int), ("check_bounds", C.c_int), ("interp_final", C.c_int), ("max_order", C.c_int),
-                ("jac_every_step", C.c_int), ("init_step", C.c_double), ("n_tdiscon", C.c_int), ("tdiscon", C.c_double * 16)]
+                ("jac_every_step", C.c_int), ("init_step", C.c_double), ("n_tdiscon", C.c_int), ("tdiscon", C.POINTER(C.c_double)),
+                ("refine", C.c_int)]
 
 
 class RunInfo(C.Structure):
@@ -70,8 +73,10 @@ COUNTERS_DTYPE = np.dtype([(f, np.int64) for f in COUNTER_FIELDS] + [("cyc", np.
 assert RUN_INFO_DTYPE.itemsize == C.sizeof(RunInfo) and COUNTERS_DTYPE.itemsize == C.sizeof(CountersS)
 
 EXPORTS = ["plh_model_create", "plh_model_destroy", "plh_n_states", "plh_n_diff", "plh_n_theta", "plh_theta_key",
-           "plh_theta_default", "plh_n_sections", "plh_section", "plh_jac_pattern", "plh_last_error", "plh_initial_guess", "plh_residual", "plh_jacobian",
-           "plh_linear_solve", "plh_init_consistent", "plh_integrate", "plh_last_kernel_ms"]
+           "plh_theta_default", "plh_n_sections", "plh_section", "plh_jac_pattern", "plh_jac_alg_pattern", "plh_last_error", "plh_abi_layout",
+           "plh_initial_guess", "plh_residual", "plh_jacobian", "plh_linear_solve", "plh_linear_solve_refined", "plh_residual_diff", "plh_residual_alg",
+           "plh_jacobian_alg", "plh_init_consistent", "plh_integrate", "plh_last_kernel_ms", "plh_host_alloc", "plh_host_free", "plh_synchronize",
+           "plh_comm_unique_id", "plh_comm_create", "plh_comm_destroy", "plh_comm_rank", "plh_comm_size", "plh_ensemble_run"]
 
 
 class PetlionHipError(RuntimeError):
@@ -103,11 +108,28 @@ def load(path=None):
     for f in ("plh_n_states", "plh_n_diff", "plh_n_theta", "plh_n_sections"):
         getattr(lib, f).argtypes = [C.c_void_p]
     lib.plh_jac_pattern.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    lib.plh_jac_alg_pattern.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    lib.plh_abi_layout.argtypes = [C.c_void_p, C.c_int]
     vp, i, d = C.c_void_p, C.c_int, C.c_double
     lib.plh_initial_guess.argtypes = [vp, i, vp, vp, vp, i, vp]
     lib.plh_residual.argtypes = [vp, i, vp, vp, vp, i, d, vp, i, vp]
     lib.plh_jacobian.argtypes = [vp, i, vp, vp, vp, d, i, vp, i, vp]
     lib.plh_linear_solve.argtypes = [vp, i, vp, vp, vp, d, i, vp, i, vp]
+    lib.plh_linear_solve_refined.argtypes = [vp, i, vp, vp, vp, d, i, vp, i, i, vp]
+    lib.plh_residual_diff.argtypes = [vp, i, vp, vp, vp, vp, i, vp]
+    lib.plh_residual_alg.argtypes = [vp, i, vp, vp, vp, vp, i, vp]
+    lib.plh_jacobian_alg.argtypes = [vp, i, vp, vp, vp, i, vp, i, vp]
+    lib.plh_host_alloc.argtypes = [C.POINTER(vp), C.c_ulonglong]
+    lib.plh_host_free.argtypes = [vp]
+    lib.plh_host_free.restype = None
+    lib.plh_synchronize.argtypes = [vp, vp]
+    lib.plh_comm_unique_id.argtypes = [C.c_char_p]
+    lib.plh_comm_create.argtypes = [i, i, C.c_char_p, i, C.POINTER(vp)]
+    lib.plh_comm_destroy.argtypes = [vp]
+    lib.plh_comm_destroy.restype = None
+    lib.plh_comm_rank.argtypes = [vp]
+    lib.plh_comm_size.argtypes = [vp]
+    lib.plh_ensemble_run.argtypes = [vp, vp, i, vp, vp, i, C.POINTER(Run), C.POINTER(Opts), i, vp, vp, vp, vp]
     lib.plh_init_consistent.argtypes = [vp, i, vp, i, d, d, vp, vp, vp, vp, i, vp]
     lib.plh_integrate.argtypes = [vp, i, vp, vp, vp, vp, i, C.POINTER(Run), C.POINTER(Opts), C.POINTER(Outputs), i, vp]
     _cache[path] = lib

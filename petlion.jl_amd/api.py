@@ -30,7 +30,7 @@ class _N:
 class Model:
     """The reference's `model` struct, reduced to the data contracts of the hot path (src/structures.jl:336-345)."""
 
-    def __init__(self, cathode, N, temperature, aging, lib_path=None):
+    def __init__(self, cathode, N, temperature, aging, lib_path=None, precision="f64", device=-1):
         if cathode not in (LCO, NMC):
             raise NotImplementedError("chemistry %r is outside the hot-path scope (LCO and NMC are built)" % (cathode,))
         self.cathode = cathode
@@ -45,7 +45,11 @@ class Model:
         self.bounds = bounds_LCO() if cathode == LCO else bounds_NMC()
         self.opts = Opts()
         self._lib = cap.load(lib_path)
-        desc = cap.ModelDesc(cap.CHEM_LCO if cathode == LCO else cap.CHEM_NMC, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, int(self.temperature), int(bool(aging)), 8)
+        if precision not in ("f64", "mixed"):
+            raise ValueError("precision: 'f64' or 'mixed' (fp32 storage of the Newton-matrix factors, everything else fp64)")
+        self.precision = precision
+        desc = cap.ModelDesc(cap.CHEM_LCO if cathode == LCO else cap.CHEM_NMC, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, int(self.temperature), int(bool(aging)), 8,
+                             cap.PREC_MIXED if precision == "mixed" else cap.PREC_F64, int(device))
         h = C.c_void_p()
         cap.check(self._lib, self._lib.plh_model_create(C.byref(desc), C.byref(h)), "plh_model_create")
         self._h = h
@@ -88,12 +92,12 @@ class Model:
 
 def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_r_n=10, temperature=False,
             solid_diffusion="Fickian", Fickian_method="finite_difference", aging=False, jacobian="symbolic", SOC=1.0,
-            _lib_path=None):
+            precision="f64", device=-1, _lib_path=None):
     """petlion(cathode; kwargs...) -- reference src/params.jl:119-174.  `jacobian` is accepted and ignored (the device
     Jacobian is hand-derived); unsupported structural options raise."""
     if solid_diffusion != "Fickian" or Fickian_method != "finite_difference":
         raise NotImplementedError("only Fickian finite-difference solid diffusion is in the hot-path scope (SURVEY.md 8a)")
-    p = Model(cathode, _N(p=N_p, s=N_s, n=N_n, a=N_a, z=N_z, r_p=N_r_p, r_n=N_r_n), temperature, aging, _lib_path)
+    p = Model(cathode, _N(p=N_p, s=N_s, n=N_n, a=N_a, z=N_z, r_p=N_r_p, r_n=N_r_n), temperature, aging, _lib_path, precision, device)
     p.opts.SOC = SOC
     return p
 
@@ -150,12 +154,11 @@ def _opts_struct(o):
     s = cap.Opts(o.abstol, o.reltol, o.abstol if o.abstol_init is None else o.abstol_init,
                  o.reltol if o.reltol_init is None else o.reltol_init, int(o.maxiters), int(bool(o.check_bounds)),
                  int(bool(o.interp_final)), int(o.max_order), int(bool(o.jac_every_step)), float(o.init_step))
-    td = list(getattr(o, "tdiscon", []) or [])
-    if len(td) > 16:
-        raise ValueError("at most 16 tdiscon entries")
-    s.n_tdiscon = len(td)
-    for k, v in enumerate(td):
-        s.tdiscon[k] = float(v)
+    td = np.ascontiguousarray(list(getattr(o, "tdiscon", []) or []), dtype=np.float64)
+    s.n_tdiscon = td.size
+    s.tdiscon = td.ctypes.data_as(C.POINTER(C.c_double)) if td.size else None
+    s._keep = td                                     # the array must outlive the struct
+    s.refine = int(getattr(o, "refine", 0))
     return s
 
 

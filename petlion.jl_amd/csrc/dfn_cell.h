@@ -17,6 +17,7 @@
 // also compiles against tests/wave_emu (a test-only lock-step wave emulator used for CPU debugging).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "../../include/petlion_hip.h"
 
 namespace pl {
@@ -28,10 +29,16 @@ constexpr int NA = 10, NZ = 10, NT = NA + NE + NZ;               // current coll
 constexpr int MAXORD = 5;
 
 // Model traits: state layout  Y = [ c_e | c_s_avg | T (thermal) | film, SOH (SEI) || j | Phi_e | Phi_s | j_s (SEI) | I ]  and closures.
-template <int CHEM_, bool SEI_, bool THERMAL_ = false> struct ModelT {
+template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false> struct ModelT {
   static constexpr int CHEM = CHEM_;                 // PLH_CHEM_LCO_LIC6 / PLH_CHEM_NMC_LIC6
   static constexpr bool SEI = SEI_;
   static constexpr bool THERMAL = THERMAL_;
+  // PLH_PREC_MIXED (config C5's reduced-precision leg): the LDS-resident factors of the Newton matrix -- block-Thomas D'^-1, L D'^-1 and the particle
+  // resolvents -- are STORED in fp32; states, residuals, Jacobian partials, time, error control and all arithmetic stay fp64.  Pure fp32 is not offered: the
+  // reltol-1e-3 Newton iteration would still converge, but SOH (1 - 1e-6 per pulse), film (1e-14 m) and t (41 h at 1e-6 s steps) are below fp32 resolution
+  // (tools/fp32_study.py).
+  static constexpr bool MIXED = MIXED_;
+  using fact_t = typename std::conditional<MIXED_, float, double>::type;
   // LDS diet: the error weights and the accumulated Newton correction live in registers (IdaScalars::ew / ee: they are only touched by the
   // lane-strided vector phases), and so do the BDF history vectors of order >= PHI_LDS
   static constexpr int PHI_LDS = THERMAL_ ? 2 : MAXORD + 1;   // thermal: 40.7 kB -> four cells per CU
@@ -70,6 +77,9 @@ struct Tables {
   int P;
   int nnz[PLH_N_MODES];                                 // full-Jacobian nnz per mode
   const unsigned* csc_code[PLH_N_MODES];                          // per mode: decode word of every CSC entry
+  // the same entries in row-major (CSR) order: row pointers, decode words, column indices -- used by the matrix-vector product of the
+  // iterative-refinement mode (plh_opts.refine) and by nothing else
+  const int* csr_ptr[PLH_N_MODES]; const unsigned* csr_code[PLH_N_MODES]; const unsigned short* csr_col[PLH_N_MODES];
 };
 
 struct CellConst {
@@ -98,8 +108,9 @@ template <> struct SeiPool<true> {
 // 30 cell-sandwich nodes carry T as the 4th unknown of the block-Thomas node block, the two collector chains are eliminated
 // onto their neighbours, and the four T rows whose one-sided gradient stencils reach a second neighbour (nodes 0, 9, 20, 29)
 // are folded into the twisted elimination (modified neighbour blocks, two right-hand-side shares): see thermal_sweeps.
-template <bool TH> struct ThermalPool {};
-template <> struct ThermalPool<true> {
+template <bool TH, bool MIXED = false> struct ThermalPool {};
+template <bool MIXED> struct ThermalPool<true, MIXED> {
+  double Dpark[MIXED ? NE * 16 : 1];                       // mixed precision: fp64 parking of the node's own block during the factor sweep (fp64 variant: parks in LD)
   // heat-conduction stencil of residuals_T! (residuals.jl:299-489), already divided by rho*Cp:  aL T[it-1] + aD T[it] + aU T[it+1] + aC
   double aL[NT], aD[NT], aU[NT], wT5[5];                    // wT5 = temperature_weighting w_i / L per section a|p|s|n|z (aux...jl:649-679)
   double aC2[2], rc5[5];                                    // constant term of the two convective end rows; 1/(rho Cp) per section a|p|s|n|z
@@ -135,16 +146,16 @@ template <class M> struct CellLDS {
   // eliminated system
   double dj[NJ], nphi[M::THERMAL ? 1 : NE][3];      // j pivot; phi_c = omega . A_ux[:,c] (node block D[r][c] -= t_r phi_c, t = (ceJ, peJ, psJ))
   double colI[M::THERMAL ? 1 : NE][3];              // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
-  double Dinv[NE][M::NB * M::NB], LD[NE][M::NB * M::NB];   // Thomas factors: D'^-1 and L D'^-1(prev)
-  double LDmid[M::NB * M::NB];                             // closing block of the twisted factorisation
-  double Ainv[2][M::THERMAL ? 1 : NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
+  typename M::fact_t Dinv[NE][M::NB * M::NB], LD[NE][M::NB * M::NB];   // Thomas factors: D'^-1 and L D'^-1(prev)
+  typename M::fact_t LDmid[M::NB * M::NB];                             // closing block of the twisted factorisation
+  typename M::fact_t Ainv[2][M::THERMAL ? 1 : NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
   double Mr[M::THERMAL ? 1 : NR * NR];               // radial operator (copy of Tables::M)
   double x2[M::THERMAL ? 1 : NE][3];
   double ctrlJ[2], bord;           // P-mode control row at the last Jacobian pass (I*I1C, V*I1C); border pivot d - v.x2
   double w9[NJ];
   double sig[2];
   SeiPool<M::SEI> sei;
-  ThermalPool<M::THERMAL> th;
+  ThermalPool<M::THERMAL, M::MIXED> th;
   // wave-uniform BDF coefficient arrays (dynamically indexed by the order -> LDS, not registers/scratch)
   double ida_psi[MAXORD + 1], ida_alpha[MAXORD + 1], ida_beta[MAXORD + 1], ida_sigma[MAXORD + 1], ida_gamma[MAXORD + 1];
 #ifdef PL_PHASE_TIMERS
@@ -181,14 +192,8 @@ __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
 #define PL_EMU_POISON(S_) do {} while (0)
 #endif
 
-// Mixed-precision study build (-DPL_FP32_FACTORS, tools/fp32_factor_study.py): the LDS-resident factors of the Newton matrix (block-Thomas D'^-1 and
-// L D'^-1, particle resolvents) are rounded to fp32 where they are stored -- what an fp32 LDS layout would hold -- while states, residuals and all
-// arithmetic stay fp64.  The product build stores them unrounded.
-#ifdef PL_FP32_FACTORS
-#define PL_F32(x) ((double)(float)(x))
-#else
-#define PL_F32(x) (x)
-#endif
+// store into a factor array (fp32 in the mixed-precision variants, see ModelT::MIXED)
+#define PL_F32(x) ((typename M::fact_t)(x))
 
 // optional per-phase cycle accounting (profiling build: -DPL_PHASE_TIMERS)
 enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_OUTPUT, PH_TOTAL };
@@ -326,7 +331,7 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
 template <bool WANT_JAC, class M> __device__ inline void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const double* Y, const double* YP, double* Fo);
 template <class M> __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only);
 template <class M> __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, int mode, bool alg_only);
-template <class M> __device__ inline double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj);
+template <bool FROZEN = false, class M> __device__ inline double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj);
 constexpr int PL_MODE_DT_TWIN = 16;   // dT control row with YP_T replaced by rhs_T(Y): the consistent-initialisation form (scalar_residual.jl:347-372)
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1125,10 +1130,54 @@ __device__ inline void cell_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mod
   if constexpr (M::THERMAL) thermal_solve(S, R, S.tb, b, mode, alg_only);
   else iso_solve(S, R, b, mode, alg_only);
 }
-template <class M>
+// FROZEN = the entry as it went into the last factorisation (thermal: the per-node kappa(T) and the T column of the particle rows are rebuilt from what
+// thermal_factor kept; every other pool entry is only written by Jacobian passes anyway)
+template <bool FROZEN = false, class M>
 __device__ inline double jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
-  if constexpr (M::THERMAL) return thermal_jac_entry(S, tb, w, cj);
+  if constexpr (M::THERMAL) return thermal_jac_entry<FROZEN>(S, tb, w, cj);
   else return iso_jac_entry(S, tb, w, cj);
+}
+
+// J x = b with `nref` steps of iterative refinement  x += J^-1 (b - J x)  against the matrix of the last factorisation (cjf = its cj): the parity mode
+// plh_opts.refine.  The structured elimination (cell_solve) and a sparse LU (KLU in the reference, the oracle's LU) order their operations differently,
+// so their solutions of the ill-conditioned Newton systems (cond ~1e15, badly row-scaled) differ by 1e-12 .. 3e-9 (tools/solve_accuracy.py); one
+// refinement step with the fp64 residual makes both solutions agree with the exact one to ~1e-13 and with each other.  The product b - J x walks the
+// Jacobian in row-major order through the same decode words as the CSC export (plh_jacobian), so it is generic over the model variants.
+// b: LDS vector (in: right-hand side, out: solution); bsave: a free LDS vector.  alg_only: rows/columns >= NDIFF of the consistent-initialisation Newton
+// (the dT twin row has no exported entries: its residual is taken as zero, i.e. the row is not refined).
+template <class M>
+__device__ inline void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, double* bsave, double cjf, int mode, bool alg_only, int nref) {
+  PL_MODEL(M);
+  const int lane = lane_id();
+  const bool twin = mode == PL_MODE_DT_TWIN;
+  const int jm = twin ? PLH_MODE_DT : mode;
+  const int* __restrict__ ptr = tb->csr_ptr[jm]; const unsigned* __restrict__ code = tb->csr_code[jm]; const unsigned short* __restrict__ col = tb->csr_col[jm];
+  const double cj = alg_only ? 0.0 : cjf;
+  double xr[NTRIP];
+  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (n < NST) bsave[n] = b[n];
+  PL_SYNC();
+  for (int it = 0; it <= nref; it++) {
+    if (it > 0) {
+      double rr[NTRIP];
+      _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) {
+        xr[k__] = 0.0; rr[k__] = 0.0;
+        if (n < NST && (!alg_only || n >= NDIFF)) {
+          xr[k__] = b[n];
+          double s = 0.0;
+          for (int k = ptr[n]; k < ptr[n + 1]; k++) { const int c = col[k]; if (!alg_only || c >= NDIFF) s += jac_entry<true>(S, tb, code[k], cj) * b[c]; }
+          rr[k__] = (twin && n == O_I) ? 0.0 : bsave[n] - s;
+        }
+      }
+      PL_SYNC();
+      _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (n < NST && (!alg_only || n >= NDIFF)) b[n] = rr[k__];
+      PL_SYNC();
+    }
+    cell_solve(S, R, b, mode, alg_only);
+    if (it > 0) {
+      _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (n < NST && (!alg_only || n >= NDIFF)) b[n] += xr[k__];
+      PL_SYNC();
+    }
+  }
 }
 
 }  // namespace pl

@@ -54,9 +54,9 @@ __device__ __forceinline__ double wrms(const double* v, const double* w) {
 // Returns the number of Newton iterations (>= 1) or PLH_ERR_INIT.  cell_simulate has exactly ONE call site (the re-initialisation of a
 // function input loops back to it): a second inlined copy costs 4-5 % of the step loop in instruction-cache misses, and a real call
 // spills the ~100 live registers of the step loop.
-template <class M>
+template <bool GEN, class M>
 __device__ inline int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
-                                                      int mode, double value, double reltol_init) {
+                                                      int mode, double value, double reltol_init, double* bsave = nullptr, int nref = 0) {
   LaneRegs R;                                                        // (the algebraic solves do not touch the particle registers)
   for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
   int iters = 0;
@@ -71,7 +71,8 @@ __device__ inline int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb,
     cell_node_pass<true, true>(S, Y, YP, res, mode, value);      // R_alg + J_alg partials (differential rows ignored)
     PL_SYNC();
     cell_factor(S, R, tb, 0.0, mode, true);
-    cell_solve(S, R, res, mode, true);
+    if (GEN && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref);     // (general instantiation only: plh_opts.refine)
+    else cell_solve(S, R, res, mode, true);
     iters++;
     double s = 0.0;
     for (int n = NDIFF + lane; n < NST; n += WAVE) { const double d = res[n]; Y[n] -= d; s += d * d; }
@@ -94,16 +95,17 @@ __device__ inline int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb,
   PL_SYNC();
   cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
   PL_SYNC();
-  cell_solve(S, R, res, mode, true);
+  if (GEN && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref);
+  else cell_solve(S, R, res, mode, true);
   for (int n = NDIFF + lane; n < NST; n += WAVE) YP[n] = -res[n] / dt;
   PL_SYNC();
   return iters;
 }
-template <class M>
+template <bool GEN = false, class M>
 __device__ __forceinline__ int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
-                                                    int mode, double value, double reltol_init, Counters& cnt) {
+                                                    int mode, double value, double reltol_init, Counters& cnt, double* bsave = nullptr, int nref = 0) {
   (void)R;
-  const int it = cell_init_consistent_impl(S, tb, Y, YP, res, Ytmp, mode, value, reltol_init);
+  const int it = cell_init_consistent_impl<GEN>(S, tb, Y, YP, res, Ytmp, mode, value, reltol_init, bsave, nref);
   if (it < 0) { cnt_add(cnt, C_INIT, 100); return it; }
   cnt_add(cnt, C_RES, it + 2); cnt_add(cnt, C_JAC, it); cnt_add(cnt, C_FACT, it); cnt_add(cnt, C_SOLVE, it + 1); cnt_add(cnt, C_INIT, it);
   return 0;
@@ -201,8 +203,8 @@ __device__ inline void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = t
 }
 
 // IDANls + Newton + convergence test.  0 ok, 1 recoverable failure
-template <class M>
-__device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, int mode, double value, int jac_every_step, Counters& cnt) {
+template <bool GEN, class M>
+__device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, int mode, double value, int jac_every_step, Counters& cnt, int nref) {
   PL_MODEL(M);
   const int lane = lane_id();
   const double epsNewt = 0.33, toldel = 0.0001 * epsNewt;
@@ -238,7 +240,8 @@ __device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaS
     }
     cnt_add(cnt, C_NEWTON); cnt_add(cnt, C_SOLVE);
     { PL_TIC();
-    cell_solve(S, R, S.delta, mode, false);           // x = J^-1 F ; the Newton correction is -x
+    if (GEN && nref > 0) cell_solve_refined(S, R, tb, S.delta, S.yp, I.cjold, mode, false, nref);   // (S.yp is dead until the next form_iterate; cjold = cj of the factors)
+    else cell_solve(S, R, S.delta, mode, false);           // x = J^-1 F ; the Newton correction is -x
     PL_TOC(S, PH_SOLVE); }
     PL_TIC();
     const double sc = (I.cjratio != 1.0) ? -2.0 / (1.0 + I.cjratio) : -1.0;
@@ -368,7 +371,9 @@ __device__ inline double tab_eval(const plh_run& r, double t) {
   const int n = r.n_tab; const double* tt = r.tab_t; const double* vv = r.tab_v;
   if (n <= 0) return 0.0;
   if (t < tt[0]) return vv[0];
-  int k = 0; for (int q = 1; q < n; q++) if (tt[q] <= t) k = q;      // last knot with t_k <= t (a repeated knot time is a jump, right-continuous)
+  int lo = 0, hi = n;                                                  // last knot with t_k <= t (a repeated knot time is a jump, right-continuous):
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tt[mid] <= t) lo = mid; else hi = mid; }   // bisection, O(log n) loads per evaluation (drive cycles)
+  const int k = lo;
   if (k == n - 1) return vv[n - 1];
   const double dt = tt[k + 1] - tt[k];
   return dt > 0.0 ? vv[k] + (vv[k + 1] - vv[k]) * ((t - tt[k]) / dt) : vv[k + 1];
@@ -378,7 +383,13 @@ __device__ inline double tab_eval(const plh_run& r, double t) {
 __device__ inline double next_tstop(const plh_opts& o, double t, bool continuation, double tf) {
   double best = tf;
   if (continuation && 1.0 > t && 1.0 < best) best = 1.0;
-  for (int q = 0; q < o.n_tdiscon && q < 16; q++) { const double s = o.tdiscon[q] - o.reltol / 2; if (s > t && s > 0.0 && s < best) best = s; }
+  if (o.n_tdiscon > 0) {                                               // o.tdiscon is sorted ascending (plh_integrate stages a sorted copy): first entry with tdiscon - reltol/2 > max(t, 0)
+    const double lim = (t > 0.0 ? t : 0.0) + o.reltol / 2;
+    int lo = -1, hi = o.n_tdiscon;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (o.tdiscon[mid] > lim) hi = mid; else lo = mid; }
+    // (start one entry early: the bisection compares tdiscon > t + reltol/2, the test below tdiscon - reltol/2 > t)
+    for (int q = hi > 0 ? hi - 1 : 0; q < o.n_tdiscon; q++) { const double s = o.tdiscon[q] - o.reltol / 2; if (s > t && s > 0.0) { if (s < best) best = s; break; } }
+  }
   return best;
 }
 
@@ -416,7 +427,7 @@ __device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, Ida
   for (;;) {
     double ck; { PL_TIC(); ck = ida_set_coeffs(S, I); PL_TOC(S, PH_STEPCTL); }
     if constexpr (TAB) { if (frun) value = tab_eval(*frun, I.tn); }                           // every residual of this step attempt is evaluated at t = tn
-    const int nflag = ida_nls(S, R, tb, I, mode, value, o.jac_every_step, cnt);
+    const int nflag = ida_nls<TAB>(S, R, tb, I, mode, value, o.jac_every_step, cnt, o.refine);
     int errfail = 0;
     if (nflag == 0) { PL_TIC(); errfail = ida_test_error(S, I, ck, err_k, err_km1); PL_TOC(S, PH_STEPCTL); }
     if (nflag != 0 || errfail) {
@@ -613,7 +624,7 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
     bool first_init = true, again = false, init_failed = false;
     do {                                                                // (re)initialise -> integrate ; loops only for check_reinitialization!
     again = false;
-    int ierr; { PL_TIC(); ierr = cell_init_consistent(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt); PL_TOC(S, PH_INIT); }
+    int ierr; { PL_TIC(); ierr = cell_init_consistent<TAB>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt, S.phi[0], o.refine); PL_TOC(S, PH_INIT); }
     if (ierr != 0) { if (first_init) init_failed = true; else flag = ierr; ri.flag = ierr; break; }
     ida_reinit(S, I, S.yy, S.yp, first_init ? (o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD) : I.maxord, t_restart);
     if (first_init) {
@@ -635,7 +646,12 @@ __device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* t
           stalled_once = true;
           PL_VEC(n) { S.yy[n] = Yprev[n]; S.yp[n] = YPprev[n]; }
           PL_SYNC();
-          ida_reinit(S, I, S.yy, S.yp, I.maxord); I.h0_forced = o.reltol; iter++; t = tprev; continue;
+          ida_reinit(S, I, S.yy, S.yp, I.maxord); I.h0_forced = o.reltol; iter++; t = tprev;
+          // the reference's solve! has already pushed this (repeated) point and run the stop checks when check_solve shortens the first step
+          // (model_evaluation.jl:319-327, checks.jl:227-231): run.info.iterations stays equal to the number of saved points of the run
+          save_pt(nout, t + t0, S.yy, SOC); nout++;
+          check_stop(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
+          continue;
         }
         flag = sf; break;
       }

@@ -603,7 +603,9 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     // register diet for the sweep (every device function is inlined: ~80 integrator values are live around this loop): the node's own block D and
     // the neighbour's off-diagonal block b are re-read from LDS in every stage instead of being held in 50 registers (D parks in S.LD[i], which is
     // only written at the end)
-    if (act) for (int k = 0; k < 16; k++) S.LD[i][k] = D[k];
+    double* park;
+    if constexpr (M::MIXED) park = &S.th.Dpark[i * 16]; else park = &S.LD[i][0];      // (fp32 factor storage cannot hold the fp64 block)
+    if (act) for (int k = 0; k < 16; k++) park[k] = D[k];
     // second-neighbour T-row entries (see thermal_sweeps): nodes 2 / 27 see U_1 / L_28 modified by -fv (x) fw ; nodes 9 / 20 get a modified
     // lower / upper block once the factor of node 7 / 22 is final
     double fv[4] = {0.0, 0.0, 0.0, 0.0}, fw[3] = {0.0, 0.0, 0.0};
@@ -614,7 +616,7 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
       PL_SYNC();                                            // (also keeps the reloads below inside the loop)
       const OffBlk b = top ? upper_blk(S, nb, alg_only) : lower_blk(S, nb, alg_only);
       double P[16], D[16];
-      for (int k = 0; k < 16; k++) D[k] = S.LD[i][k];
+      for (int k = 0; k < 16; k++) D[k] = park[k];
       for (int k = 0; k < 16; k++) P[k] = shift_up1(Dinv[k]);
       for (int k = 0; k < 4; k++) {
         LDm[k] = a.ce * P[k];
@@ -680,9 +682,9 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
         Dm[rr * 4 + 3] = Dn[rr * 4 + 3] - (a1 * e.pt + a3 * e.Tt);
       }
       inv4(Dm, Dmi);
-      if (nd == TW_MID) for (int k = 0; k < 16; k++) { Dinv[k] = Dmi[k]; S.LDmid[k] = L2[k]; }
+      if (nd == TW_MID) for (int k = 0; k < 16; k++) { Dinv[k] = Dmi[k]; S.LDmid[k] = PL_F32(L2[k]); }
     }
-    if (act) for (int k = 0; k < 16; k++) { S.Dinv[i][k] = Dinv[k]; S.LD[i][k] = LDm[k]; }
+    if (act) for (int k = 0; k < 16; k++) { S.Dinv[i][k] = PL_F32(Dinv[k]); S.LD[i][k] = PL_F32(LDm[k]); }
   }
   // 6a. control row over the node unknowns (computed in the lane = node layout: the twin needs neighbour shifts), stored in TP.vB
   double dI = 0.0;
@@ -869,16 +871,20 @@ namespace pl {
 enum JTT { TT_CS_T = 64, TT_J_T, TT_PE_TL, TT_PE_TD, TT_PE_TU, TT_T_TL, TT_T_TD, TT_T_TU, TT_T_CL, TT_T_CD, TT_T_CU, TT_T_EL, TT_T_ED, TT_T_EU,
            TT_T_SL, TT_T_SD, TT_T_SU, TT_T_J, TT_T_CS, TT_T_X2, TT_T_I, TT_CTRL_T };
 
-template <class M>
+template <bool FROZEN, class M>
 __device__ inline double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
   PL_MODEL(M);
   const int t = w >> 24, a = (w >> 16) & 255, bb = (w >> 8) & 255, cc = w & 255;
   const auto& TP = S.th;
   switch (t) {
-    case JT_CS_CS: return TP.kapP[a] * tb->M[bb * NR + cc] - (bb == cc ? cj : 0.0);
-    case TT_CS_T: {                                      // d(kappa_p(T) (M c)_r)/dT ; evaluated at the state in S.yy
+    case JT_CS_CS: return (FROZEN ? TP.kapF[a] : TP.kapP[a]) * tb->M[bb * NR + cc] - (bb == cc ? cj : 0.0);   // (kapP follows every residual pass, kapF is the factored one)
+    case TT_CS_T: {                                      // d(kappa_p(T) (M c)_r)/dT
       double acc = 0.0;
-      for (int k = 0; k < NR; k++) acc += tb->M[bb * NR + k] * S.yy[O_CS + a * NR + k];
+      if (FROZEN) {                                      // q = kappa' M c of the last factorisation, rebuilt from A^-1 q: q = (kappa M - cj I) (A^-1 q)
+        for (int k = 0; k < NR; k++) acc += (TP.kapF[a] * tb->M[bb * NR + k] - (bb == k ? TP.cjf : 0.0)) * TP.AinvQ[a][k];
+        return acc;
+      }
+      for (int k = 0; k < NR; k++) acc += tb->M[bb * NR + k] * S.yy[O_CS + a * NR + k];      // evaluated at the state in S.yy (plh_jacobian)
       return TP.dkapP[a] * acc;
     }
     case TT_J_T: return TP.gT[a];

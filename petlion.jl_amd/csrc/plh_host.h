@@ -1,0 +1,47 @@
+// plh_host.h -- what the host side of the C ABI (petlion_hip.hip) and the per-variant kernel translation units (variant_tu.hip) share.
+//
+// Every model variant (chemistry x aging x temperature x factor precision) is ONE template instantiation ModelT<...> of the device source and is
+// compiled in its own translation unit (-DPL_VARIANT=<id>): the variants build in parallel, each with the optimisation level that suits its kernels,
+// and link into the one library libpetlion_hip.so.  The host side reaches a variant only through its VariantOps table.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dfn_cell.h"
+
+// id, chemistry, SEI aging, temperature, mixed precision (fp32 storage of the Newton-matrix factors)
+#define PL_VARIANT_LIST(X)                                  \
+  X(0, PLH_CHEM_LCO_LIC6, false, false, false)              \
+  X(1, PLH_CHEM_NMC_LIC6, false, false, false)              \
+  X(2, PLH_CHEM_LCO_LIC6, true, false, false)               \
+  X(3, PLH_CHEM_NMC_LIC6, true, false, false)               \
+  X(4, PLH_CHEM_LCO_LIC6, false, true, false)               \
+  X(5, PLH_CHEM_LCO_LIC6, false, false, true)               \
+  X(6, PLH_CHEM_NMC_LIC6, true, false, true)                \
+  X(7, PLH_CHEM_LCO_LIC6, false, true, true)
+constexpr int PL_N_VARIANTS = 8;
+
+struct IntegrateArgs {
+  const pl::Tables* tb; int n_cells; const double* theta; const double* SOC0; const double* Y_init; const double* t_init; int n_runs; const plh_run* runs; plh_opts opts;
+  plh_outputs out; double* scratch;   // scratch: [n_cells][2][NST]
+};
+
+struct SectionInfo { const char* name; int start, len; };
+
+struct VariantOps {
+  int id, chem, sei, thermal, mixed;
+  int N, Nd;
+  size_t lds_bytes;                                                                  // sizeof(CellLDS<M>): LDS per cell (= per workgroup)
+  unsigned (*classify)(const pl::Tables& tb, int mode, int r, int c);              // decode word of the structural Jacobian entry (r, c), 0 if structurally zero
+  int (*sections)(SectionInfo* out);
+  void (*initial_guess)(hipStream_t st, const pl::Tables* tb, int n, const double* theta, const double* SOC, double* Y);
+  void (*residual)(hipStream_t st, const pl::Tables* tb, int n, const double* theta, const double* Y, const double* YP, int mode, double value, double* F, int row0, int nrows);
+  void (*jacobian)(hipStream_t st, const pl::Tables* tb, int n, const double* theta, const double* Y, const double* YP, double cj, int mode, double* nz, const int* sel, int nsel);
+  void (*linear_solve)(hipStream_t st, const pl::Tables* tb, int n, const double* theta, const double* Y, const double* YP, double cj, int mode, double* b, int nref);
+  void (*init_consistent)(hipStream_t st, const pl::Tables* tb, int n, const double* theta, int mode, double value, double reltol_init, double* Y, double* YP, int* status,
+                          int* iters, int nref);
+  void (*integrate)(hipStream_t st, const IntegrateArgs& a, bool general);
+};
+
+// one definition per variant translation unit (nullptr-returning stubs do not exist: a missing variant is a link error)
+#define PL_DECLARE_OPS(ID, CHEM, SEI, TH, MIX) const VariantOps* plh_variant_ops_##ID();
+PL_VARIANT_LIST(PL_DECLARE_OPS)
+#undef PL_DECLARE_OPS

@@ -108,6 +108,7 @@ class Opts:
         self.max_order = 5
         self.jac_every_step = False
         self.init_step = 0.0        # 0 = IDA's automatic initial step; > 0 = IDASetInitStep
+        self.refine = 0             # n > 0: n steps of iterative refinement of every linear solve (parity mode, plh_opts.refine)
         self.max_points = 2048      # capacity of the per-cell output buffers
 
 

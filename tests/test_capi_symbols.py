@@ -73,3 +73,56 @@ def test_julia_binding_matches_header(pkg):
     cap = pkg._capi
     for cname, st in (("plh_model_desc", cap.ModelDesc), ("plh_run", cap.Run), ("plh_opts", cap.Opts), ("plh_outputs", cap.Outputs)):
         assert c_fields(cname) == len(st._fields_), cname
+
+
+JL_SIZES = {"Cint": (4, 4), "Cdouble": (8, 8), "Clonglong": (8, 8)}
+
+
+def _jl_layout(jl, name, known):
+    """(size, align, [field offsets]) of a Julia `struct` of isbits fields under the C layout rules Julia uses for ccall."""
+    body = re.search(r"struct %s\b[^\n]*\n(.*?)\nend" % name, jl, flags=re.S).group(1)
+    body = re.sub(r"#.*", "", body)
+    off, offs, amax = 0, [], 1
+    for ty in re.findall(r"::\s*([A-Za-z_]+(?:\{[^;\n]*?\})?)\s*(?:;|\n|$)", body):
+        m = re.match(r"NTuple\{(\d+),\s*(\w+)\}", ty)
+        if ty.startswith("Ptr{") or ty == "Cstring":
+            sz, al = 8, 8
+        elif m:
+            esz, al = JL_SIZES[m.group(2)]
+            sz = int(m.group(1)) * esz
+        elif ty in JL_SIZES:
+            sz, al = JL_SIZES[ty]
+        else:
+            sz, al, _ = known[ty]
+        off = (off + al - 1) // al * al
+        offs.append(off)
+        off += sz
+        amax = max(amax, al)
+    return (off + amax - 1) // amax * amax, amax, offs
+
+
+def test_struct_layouts_match_the_compiled_library(pkg):
+    """plh_abi_layout() reports sizeof/offsetof of every struct as compiled into the library; the hand-written mirrors -- the Julia structs of
+    bindings/julia/PetlionHIP.jl (laid out here by C rules from their field types) and the ctypes structs of the Python host -- must agree field by field."""
+    import __graft_entry__ as g
+    g.build_hip()
+    lib = pkg._capi.load()
+    n = lib.plh_abi_layout(None, 0)
+    buf = (C.c_int * n)()
+    assert lib.plh_abi_layout(buf, n) == n
+    vals, k, layouts = list(buf), 0, []
+    for _ in range(7):
+        size, nf = vals[k], vals[k + 1]
+        layouts.append((size, vals[k + 2:k + 2 + nf])); k += 2 + nf
+    assert k == n
+    jl = open(os.path.join(ROOT, "bindings", "julia", "PetlionHIP.jl")).read()
+    known = {}
+    cap = pkg._capi
+    ct = {"ModelDesc": cap.ModelDesc, "Bounds": cap.Bounds, "Run": cap.Run, "Opts": cap.Opts, "RunInfo": cap.RunInfo, "Counters": cap.CountersS, "Outputs": cap.Outputs}
+    for (size, offs), jname in zip(layouts, ("ModelDesc", "Bounds", "Run", "Opts", "RunInfo", "Counters", "Outputs")):
+        jsize, jal, joffs = _jl_layout(jl, jname, known)
+        known[jname] = (jsize, jal, joffs)
+        assert (jsize, joffs) == (size, list(offs)), (jname, jsize, size, joffs, list(offs))
+        st = ct[jname]
+        assert C.sizeof(st) == size and [getattr(st, f).offset for f, _ in st._fields_] == list(offs), jname
+    assert pkg._capi.RUN_INFO_DTYPE.itemsize == layouts[4][0] and pkg._capi.COUNTERS_DTYPE.itemsize == layouts[5][0]

@@ -383,23 +383,3 @@ def test_async_back_to_back_launches(hip_model, pkg):
         npt = e.n_pts.cpu().numpy()
         tt, tr = e.t.cpu().numpy(), t.cpu().numpy()
         assert all(np.array_equal(tt[i, :npt[i]], tr[i, :npt[i]]) for i in range(0, n, 37)), key
-
-
-def test_thermal_sibling_library_agrees_with_main_library(hip_model_thermal, pkg):
-    """temperature = true models integrate through libpetlion_hip_thermal.so (same source, -O2); the main library's own thermal kernels (-O3,
-    PETLION_HIP_NO_SIBLING=1) must give the same trajectories: equal flags and step counts, states to 1e-9"""
-    import os
-    import test_device_source_emu as te
-    p = hip_model_thermal
-    os.environ["PETLION_HIP_NO_SIBLING"] = "1"
-    try:
-        q = pkg.petlion(pkg.LCO, temperature=True)
-    finally:
-        del os.environ["PETLION_HIP_NO_SIBLING"]
-    n = 64
-    rng = np.random.default_rng(9)
-    Th = pkg.theta_matrix(p, n, {"T_amb": 298.15 + 5 * (rng.random(n) - 0.5), "h_cell": 2.0 ** (2 * rng.random(n) - 1)})
-    a = pkg.simulate_ensemble(p, Th, te.CC_CT_CV[:1], SOC=0.0)
-    b = pkg.simulate_ensemble(q, Th, te.CC_CT_CV[:1], SOC=0.0)
-    assert np.array_equal(a.run_info["flag"], b.run_info["flag"]) and np.array_equal(a.run_info["iterations"], b.run_info["iterations"])
-    assert np.abs(a.Y - b.Y).max() <= 1e-9 * np.abs(b.Y).max() and np.abs(a.run_info["t_end"] - b.run_info["t_end"]).max() < 1e-7
