@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- ensemble DFN full-discharge throughput on N MI355X (BASELINE.json metric), one process per GPU.
+"""bench.py -- ensemble DFN trajectory throughput on N MI355X (BASELINE.json metric), one process per GPU.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W [--config C2|C3|C4|C5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" = one pass of the hot path over one batch = ONE plh_integrate launch that integrates this rank's shard of the
-ensemble from t = 0 to the stop condition (consistent initialisation + every BDF/Newton step + stop/back-interpolation).
-Workload at every N: config C2 of BASELINE.json per GPU ("Batch of 1024 LCO isothermal 1C CC discharges (identical params)
-on one MI355X, fp64") -- weak scaling: 1024 cells per GPU, so N GPUs integrate N*1024 cells per step (the C4 sharding
-pattern: independent cells, contiguous blocks, no data-path collective).
-Parameters are resident in HBM before the timed region; RCCL is used only outside it (scatter of the parameter rows before,
-gather of the per-cell summaries after) -- that is the whole communication the path has.
+A "step" = one pass of the hot path over one batch = ONE plh_integrate launch that integrates this rank's shard of the ensemble through its whole
+protocol (consistent initialisation + every BDF/Newton step + stop tests / back-interpolation).  The default workload at every N is config C2 of
+BASELINE.json per GPU ("Batch of 1024 LCO isothermal 1C CC discharges (identical params) on one MI355X, fp64") -- weak scaling, independent cells,
+contiguous blocks, no data-path collective.  --config selects C3 (4096 thermal cells, CC-CT-CV), C4 (8192 jittered cells per GPU, the shard of the
+65 536-cell sweep) or C5 (1024 NMC + SEI cells, 20 GITT pulses); their inputs are SURVEY.md 8(d)'s (petlion.jl_amd/configs.py).
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement), including
-  "roofline":     algorithmic HBM bytes per launch (SURVEY.md 8(d) byte model x the device counters) / the integrate
-                  kernel's average duration measured with HIP events on its stream, vs the 8 TB/s HBM3E peak;
-  "cpu_baseline": the oracle (plain-C port of the reference path) timed on one host core on a bounded sample.
+`value` is the rate with the parameters already resident in HBM (the contract of this benchmark).  The same JSON line also carries
+  "roofline":       algorithmic HBM bytes per launch (SURVEY.md 8(d) byte model x the device counters) / the integrate kernel's average duration
+                    (HIP events on its stream) vs the 8 TB/s HBM3E peak -- the metric BASELINE.json names.  The kernel is LDS-resident: its measured HBM
+                    traffic ("traffic", rocprofv3 PMC) is a fraction of a percent of the model bytes, so "frac" is an equivalent-streaming rate, not HBM
+                    utilisation; "hbm_utilisation" is the real one and "limiter" names what bounds the kernel;
+  "cpu_baseline":   the oracle (plain-C port of the reference path) on one host core and on all usable cores, bounded sample of the same workload;
+  "host_inclusive": SURVEY 8(d)'s measurement shape -- parameters start in (pinned) host memory, per-cell summaries and sampled outputs end there --
+                    as a double-buffered PLH_HOST_ASYNC pipeline: median over >= 10 calls;
+  N > 1 only, "ensemble_run": the C4 sweep (8192 cells per GPU) through plh_ensemble_run (RCCL scatter -> integrate -> gather inside the C ABI),
+                    block and cyclic partitions, with the per-rank kernel times (load imbalance).
 """
 import argparse
 import json
@@ -28,35 +32,36 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CELLS_PER_GPU = 1024
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# SURVEY.md 8(d) byte model for C1/C2/C4: N=301, P=35, Z=2139, L=4335 (fp64, w = 8 B)
-W, N_ST, P_TH, Z_NNZ, L_LU = 8, 301, 35, 2139, 4335
-N_ALG, Z_ALG = 71, 245
-B_RES = W * (2 * N_ST + P_TH) + W * N_ST
-B_JAC = W * (2 * N_ST + P_TH) + W * Z_NNZ
-B_FACT = W * Z_NNZ + W * L_LU
-B_SOLVE = W * (L_LU + N_ST) + W * N_ST
-B_STEP1 = 2 * W * N_ST                      # x (k+2) per step
-B_RES_A, B_JAC_A, B_FACT_A, B_SOLVE_A = W * (2 * N_ST + P_TH) + W * N_ALG, W * (2 * N_ST + P_TH) + W * Z_ALG, 2 * W * Z_ALG, W * (Z_ALG + 2 * N_ALG)
-B_PT = 4 * W                                # t, V, I, SOC per saved point
+W = 8                            # fp64 word
+# SURVEY.md 8(d) byte-model constants per config: states N, theta entries P, nnz(J) Z, nnz(L+U) L, algebraic block N_alg / Z_alg, scalars per saved point
+CONFIGS = {
+    "C2": dict(N=301, P=35, Z=2139, L=4335, NA=71, ZA=245, SC=4, cells=1024, variant="lco_iso", model=dict(cathode="LCO"),
+               text="BASELINE.json configs[1] (C2): batch of %d LCO isothermal 1C CC discharges (identical params) per GPU, 301 DAEs/cell, reltol 1e-3 / abstol 1e-6, SOC 1 -> SOC_min"),
+    "C3": dict(N=351, P=56, Z=2883, L=7761, NA=71, ZA=245, SC=5, cells=4096, variant="lco_thermal", model=dict(cathode="LCO", temperature=True),
+               text="BASELINE.json configs[2] (C3): %d LCO cells with temperature = true per GPU, CC-CT-CV fast charge (I = 4C -> dT = hold at 40 C -> V = hold), T_amb / h_cell jitter (seed 3), 351 DAEs/cell"),
+    "C4": dict(N=301, P=35, Z=2139, L=4335, NA=71, ZA=245, SC=4, cells=8192, variant="lco_iso", model=dict(cathode="LCO"),
+               text="BASELINE.json configs[3] (C4): %d cells per GPU of the LCO parameter sweep (7 log-uniform factors, seed 4), 1C discharge, 301 DAEs/cell"),
+    "C5": dict(N=322, P=39, Z=2269, L=4985, NA=81, ZA=314, SC=4, cells=1024, variant="nmc_iso_sei", model=dict(cathode="NMC", aging="SEI"),
+               text="BASELINE.json configs[4] (C5): %d NMC cells with aging = SEI per GPU, GITT 20 x {1C 180 s ; rest 7200 s}, parameter jitter (seed 5), 322 DAEs/cell (fp64 leg)"),
+}
 
 
-def algorithmic_bytes(counters, n_pts):
-    """sum over cells of the SURVEY 8(d) model; init-Newton evaluations are costed at the algebraic-block sizes."""
-    c = {k: counters[k].astype(np.float64) for k in counters.dtype.names}
-    ni = c["n_init_iters"]
-    n_res_main = c["n_res"] - ni - 2.0          # init: one R_alg per iteration + R_diff + the shifted R_alg
-    n_jac_main = c["n_jac"] - ni
-    n_fact_main = c["n_fact"] - ni
-    n_solve_main = c["n_solve"] - ni - 1.0
-    b = (n_res_main * B_RES + n_jac_main * B_JAC + n_fact_main * B_FACT + n_solve_main * B_SOLVE + c["sum_kp2"] * B_STEP1
-         + (ni + 2.0) * B_RES_A + ni * (B_JAC_A + B_FACT_A) + (ni + 1.0) * B_SOLVE_A + n_pts.astype(np.float64) * B_PT)
+def algorithmic_bytes(c, counters, n_pts):
+    """sum over cells of the SURVEY 8(d) streaming model; init-Newton evaluations are costed at the algebraic-block sizes."""
+    N, P, Z, L, NA, ZA = c["N"], c["P"], c["Z"], c["L"], c["NA"], c["ZA"]
+    B_RES, B_JAC, B_FACT, B_SOLVE, B_STEP1 = W * (2 * N + P) + W * N, W * (2 * N + P) + W * Z, W * Z + W * L, W * (L + N) + W * N, 2 * W * N
+    B_RES_A, B_JAC_A, B_FACT_A, B_SOLVE_A = W * (2 * N + P) + W * NA, W * (2 * N + P) + W * ZA, 2 * W * ZA, W * (ZA + 2 * NA)
+    k = {f: counters[f].astype(np.float64) for f in counters.dtype.names if f != "cyc"}
+    ni = k["n_init_iters"]
+    n_init_runs = np.maximum(1.0, np.round((k["n_res"] - k["n_newton"] - ni) / 2.0))     # every (re)initialisation: its Newton residuals + R_diff + the shifted R_alg
+    b = ((k["n_res"] - ni - 2.0 * n_init_runs) * B_RES + (k["n_jac"] - ni) * B_JAC + (k["n_fact"] - ni) * B_FACT + (k["n_solve"] - ni - n_init_runs) * B_SOLVE
+         + k["sum_kp2"] * B_STEP1 + (ni + 2.0 * n_init_runs) * B_RES_A + ni * (B_JAC_A + B_FACT_A) + (ni + n_init_runs) * B_SOLVE_A + n_pts.astype(np.float64) * c["SC"] * W)
     return float(b.sum())
 
 
 def usable_cores():
-    """cores this process can actually run on: the affinity mask, capped by the cgroup CPU quota (a container on a 256-core host may own 8)"""
+    """cores this process can actually run on: the affinity mask, capped by the cgroup CPU quota (a container on a 256-core host may own 16)"""
     n = len(os.sched_getaffinity(0))
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
@@ -73,15 +78,92 @@ def usable_cores():
     return n
 
 
+def cpu_baseline(cfg_name, c, p, pkg, inp, seconds):
+    """the oracle on one host core, then on every usable core, on a bounded sample of the same workload"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
+    from oracle import oracle as O
+    runs = parity.runs_to_oracle(O, p, pkg, inp["protocol"])
+    th = np.ascontiguousarray(inp["theta"][:64])
+    t1 = time.perf_counter(); ok, _, _ = O.run_batch(c["variant"], th, inp["SOC"], runs, 4); per = (time.perf_counter() - t1) / 4
+    n_cpu = max(8, int(seconds / per))
+    t1 = time.perf_counter(); ok, tsum, _ = O.run_batch(c["variant"], th, inp["SOC"], runs, n_cpu); dt = time.perf_counter() - t1
+    assert ok == n_cpu, (ok, n_cpu)
+    one = {"value": n_cpu / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
+           "sample": "%d trajectories of this workload (its first 64 parameter sets, cyclically) run back to back on one host core by the oracle (plain-C IDA/KLU-style port of "
+                     "the reference path, oracle/ida_oracle.c); %.1f s; host reports %d logical cores; reference publishes 2.616 ms per 1C discharge on an unspecified laptop "
+                     "(examples/getting_started.ipynb:183-192)" % (n_cpu, dt, os.cpu_count())}
+    from concurrent.futures import ThreadPoolExecutor
+    cores = usable_cores()
+    chunk, deadline = max(2, int(0.25 / per)), time.perf_counter() + 0.6 * seconds
+
+    def worker(_):
+        done = 0
+        while time.perf_counter() < deadline:            # time-bounded: chunks of ~0.25 s until the deadline (ctypes drops the GIL)
+            assert O.run_batch(c["variant"], th, inp["SOC"], runs, chunk)[0] == chunk
+            done += chunk
+        return done
+    t1 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        n_all = sum(ex.map(worker, range(cores)))
+    dt_all = time.perf_counter() - t1
+    allc = {"value": n_all / dt_all, "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "sample": "%d of the same trajectories on %d oracle threads (the cores this process may use: affinity / cgroup quota); %.1f s; %.1fx the one-core rate"
+                      % (n_all, cores, dt_all, n_all / dt_all / one["value"])}
+    return one, allc
+
+
+def host_inclusive(pkg, p, inp, n_local, kernel_ms, calls=12):
+    """wall time of the batched call with Theta starting in host memory and the per-cell summaries + sampled outputs (t, V per saved point) ending there:
+    a depth-2 PLH_HOST_ASYNC pipeline over pinned buffers; per-call time = interval between successive completions, median of `calls`."""
+    import torch
+    pipe = pkg.api.HostPipeline(p, n_local, inp["protocol"], SOC=inp["SOC"], max_points=inp["max_points"], depth=2)
+    Th = inp["theta"]
+    for k in range(4):                                   # warm-up: staging blocks, per-stream workspaces
+        pipe.submit(k % 2, Th)
+    pipe.wait(0); pipe.wait(1)
+    torch.cuda.synchronize()
+    done = []
+    t0 = time.perf_counter()
+    for k in range(calls + 2):
+        slot = k % 2
+        if k >= 2:
+            b = pipe.wait(slot); done.append(time.perf_counter())
+            assert (b["run_info"]["flag"] >= 0).all()
+        if k < calls:
+            pipe.submit(slot, Th)
+    total = done[-1] - t0
+    iv = np.diff(np.array([t0] + done))
+    steady = iv[2:] if len(iv) > 4 else iv               # the first completions include the pipeline fill
+    ms_med = 1e3 * float(np.median(steady))
+    # the same call made synchronously through pageable memory (PLH_HOST: what an unprepared host does)
+    pkg.simulate_ensemble(p, Th, inp["protocol"], SOC=inp["SOC"], max_points=inp["max_points"])
+    ts = []
+    for _ in range(5):
+        t1 = time.perf_counter(); pkg.simulate_ensemble(p, Th, inp["protocol"], SOC=inp["SOC"], max_points=inp["max_points"]); ts.append(time.perf_counter() - t1)
+    pipe.close()
+    return {"value": n_local / (ms_med * 1e-3), "unit": "trajectories/s", "ms_per_call_median": ms_med, "calls": calls, "aggregate_value": calls * n_local / total,
+            "fraction_of_kernel_rate": kernel_ms / ms_med,
+            "what": "H2D of Theta (pinned), kernel, D2H of run_info + counters + n_pts + t, V [%d points] per cell; two calls in flight on two streams (PLH_HOST_ASYNC)" % inp["max_points"],
+            "synchronous_pageable": {"value": n_local / float(np.median(ts)), "ms_per_call_median": 1e3 * float(np.median(ts)),
+                                     "what": "one blocking PLH_HOST call at a time through freshly allocated pageable numpy arrays, all outputs (t, V, I, SOC, Y, YP, ...): "
+                                             "staging H2D, kernel, D2H through the pinned bounce buffer, memcpy; its spread between runs (r01: 221 k vs 341 k traj/s) is the page-fault "
+                                             "cost of first-touch output arrays, which depends on the allocator state of the calling process"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--cells-per-gpu", type=int, default=CELLS_PER_GPU)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--cells-per-gpu", type=int, default=0)
+    ap.add_argument("--precision", default="f64", choices=("f64", "mixed"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-inclusive pipeline, the copy-bandwidth probe and (N > 1) the plh_ensemble_run leg")
     args = ap.parse_args()
+    c = CONFIGS[args.config]
 
     import torch
     import torch.distributed as dist
@@ -107,7 +189,7 @@ def main():
             dist.init_process_group(backend)
 
     import __graft_entry__ as g
-    if world > 1:                                  # one rank per node builds (a no-op when the in-tree libraries are current), the others wait
+    if world > 1:                                  # one rank per node builds (a no-op when the in-tree library is current), the others wait
         if local_rank == 0:
             g.build_hip()
         dist.barrier()
@@ -117,31 +199,18 @@ def main():
     pkg = pkgload.load()
     from petlion_jl_amd import distributed as pd
 
-    p = pkg.petlion(pkg.LCO)
-    n_local = args.cells_per_gpu
+    mk = dict(c["model"]); cathode = mk.pop("cathode")
+    p = pkg.petlion(getattr(pkg, cathode), precision=args.precision, device=local_dev, **mk)
+    n_local = args.cells_per_gpu or c["cells"]
     n_total = n_local * world
-    protocol = [{"I": -1.0}]                       # simulate(p, I=-1, SOC=1): full 1C discharge to the stop condition
-
-    # ---- ensemble scatter (RCCL, outside the timed region): rank 0 owns Theta ----
-    if world > 1:
-        mine = torch.empty(n_local, len(p.θ_keys), dtype=torch.float64, device=cdev)
-        try:
-            if rank == 0:
-                full = torch.from_numpy(pkg.theta_matrix(p, n_total)).to(cdev)
-                dist.scatter(mine, [c.contiguous() for c in full.chunk(world, dim=0)], src=0)
-            else:
-                dist.scatter(mine, None, src=0)
-        except (RuntimeError, NotImplementedError):      # a backend without scatter: broadcast the matrix, keep the own block
-            full = torch.from_numpy(pkg.theta_matrix(p, n_total)).to(cdev) if rank == 0 else torch.empty(n_total, len(p.θ_keys), dtype=torch.float64, device=cdev)
-            dist.broadcast(full, src=0)
-            mine = full[rank * n_local:(rank + 1) * n_local].clone()
-        Theta = mine.to(dev)
-    else:
-        Theta = torch.from_numpy(pkg.theta_matrix(p, n_local)).to(dev)
+    # this rank's shard: the inputs are a counter-based function of the global cell index (petlion.jl_amd/configs.py), so no scatter is needed to build them
+    make = getattr(pkg.configs, args.config.lower())
+    inp = make(p, n_local) if args.config == "C2" else make(p, n_local, first=rank * n_local)
+    Theta = torch.from_numpy(np.ascontiguousarray(inp["theta"])).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        return pkg.simulate_ensemble(p, Theta, protocol, SOC=1.0, device=True, stream=stream, max_points=256)
+        return pkg.simulate_ensemble(p, Theta, inp["protocol"], SOC=inp["SOC"], device=True, stream=stream, max_points=inp["max_points"])
 
     for _ in range(args.warmup):
         ens = step()
@@ -167,93 +236,90 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
-    # ---- per-cell results: correctness guard + counters (gather of summaries, outside the timed region) ----
-    flags = ens.run_info["flag"][:, 0]
-    assert (flags == 3).all(), "every C2 cell must end on SOC_min (flag 3), got %r" % np.unique(flags)
-    assert np.abs(ens.run_info["t_end"][:, 0] - 3600.0).max() < 1e-5
-    summ = pd.summarize(ens)
-    if world > 1:
-        mine_s = torch.from_numpy(summ).to(cdev)
-        try:
-            parts = [torch.empty_like(mine_s) for _ in range(world)] if rank == 0 else None
-            dist.gather(mine_s, parts, dst=0)
-        except (RuntimeError, NotImplementedError):      # a backend without gather
-            parts = [torch.empty_like(mine_s) for _ in range(world)]
-            dist.all_gather(parts, mine_s)
-        if rank == 0:
-            allsum = torch.cat(parts).cpu().numpy()
-            assert (allsum[:, 0] == 3).all()
-    bytes_launch = algorithmic_bytes(ens.counters, ens.n_pts.cpu().numpy())
+    # ---- per-cell results: correctness guard + counters (outside the timed region) ----
+    flags = ens.run_info["flag"]
+    assert (flags >= 0).all(), "solver failure in %d cells" % int((flags < 0).sum())
+    if args.config == "C2":
+        assert (flags[:, 0] == 3).all(), "every C2 cell must end on SOC_min (flag 3), got %r" % np.unique(flags)
+        assert np.abs(ens.run_info["t_end"][:, 0] - 3600.0).max() < 1e-5
+    bytes_launch = algorithmic_bytes(c, ens.counters, ens.n_pts.cpu().numpy())
     kavg_ms = e0.elapsed_time(e1) / args.steps     # average launch duration over the timed region (HIP events on the launch stream)
     klast_ms = float(ens.kernel_ms)                # the library's own event pair around the last launch
+    kms = torch.tensor([kavg_ms], dtype=torch.float64, device=cdev)
+    if world > 1:
+        allk = [torch.zeros_like(kms) for _ in range(world)]
+        dist.all_gather(allk, kms)
+        rank_kernel_ms = [float(x.item()) for x in allk]
+    else:
+        rank_kernel_ms = [kavg_ms]
 
-    # measured HBM traffic per launch: PMC counters cannot be collected from inside the timed process, so the value is the one
-    # committed under profiles/ for this exact workload (same command under rocprofv3 --pmc, see tools/prof.sh); null otherwise
+    # measured HBM traffic per launch: PMC counters cannot be collected from inside the timed process, so the value is the one committed under profiles/ for this
+    # exact workload (same command under rocprofv3 --pmc, tools/prof.sh); null otherwise
     traffic = None
     try:
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-        if cands:
-            tj = json.load(open(cands[-1]))
-            if tj.get("cells_per_launch") == n_local and tj.get("workload") == "C2":
-                traffic = float(tj["hbm_bytes_per_launch"])
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic*.json")), reverse=True):
+            tj = json.load(open(f))
+            if tj.get("cells_per_launch") == n_local and tj.get("workload") == args.config and tj.get("precision", "f64") == args.precision:
+                traffic = float(tj["hbm_bytes_per_launch"]); break
     except Exception:
         traffic = None
+
+    # ---- N > 1: the C4 sweep through the C ABI's own multi-GPU entry (RCCL scatter -> integrate -> gather), block and cyclic partitions ----
+    ens_run = None
+    if world > 1 and not args.no_extras and backend == "nccl":
+        p4 = p if args.config in ("C2", "C4") and args.precision == "f64" else pkg.petlion(pkg.LCO, device=local_dev)
+        uid = torch.zeros(128, dtype=torch.uint8, device=cdev)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(pd.RcclComm.unique_id(p4._lib)), dtype=torch.uint8).to(cdev)
+        dist.broadcast(uid, src=0)
+        comm = pd.RcclComm(p4._lib, world, rank, bytes(uid.cpu().numpy().tobytes()), device=local_dev)
+        n4 = 8192 * world
+        Th4 = pkg.configs.c4(p4, n4)["theta"] if rank == 0 else None
+        ens_run = {}
+        for part in ("block", "cyclic"):
+            pd.ensemble_run_capi(comm, p4, Th4, [{"I": -1.0}], 1.0, n_cells=n4, partition=part)          # warm-up (RCCL channels, staging blocks)
+            dist.barrier(); t1 = time.perf_counter()
+            res = pd.ensemble_run_capi(comm, p4, Th4, [{"I": -1.0}], 1.0, n_cells=n4, partition=part)
+            dist.barrier(); dt = time.perf_counter() - t1
+            if rank == 0:
+                info, cnt, _, ms = res
+                assert np.isin(info["flag"][:, 0], (1, 3)).all()
+                ens_run[part] = {"wall_ms": 1e3 * dt, "trajectories_per_s_host_to_host": n4 / dt, "rank_kernel_ms": [float(x) for x in ms],
+                                 "kernel_ms_spread": float(ms.max() / ms.min()), "steps_per_cell_mean": float(cnt["n_steps"].mean())}
+        if rank == 0:
+            ens_run["what"] = ("plh_ensemble_run over %d ranks: %d C4 cells (8192 per GPU) from rank 0's host memory -- ncclBroadcast of the shape, grouped ncclSend/ncclRecv scatter of "
+                               "Theta, one plh_integrate per rank, gather of run_info / counters / Y_final to rank 0; wall time includes the host-side permutation and copies" % (world, n4))
+        comm.close()
+
     if rank == 0:
         traj_s = n_total * args.steps / elapsed
+        achieved = bytes_launch / (kavg_ms * 1e-3) / 1e9
         out = {
-            "metric": "DFN full-discharge trajectories/sec (ensemble)", "value": traj_s, "unit": "trajectories/s",
+            "metric": "DFN full-discharge trajectories/sec (ensemble)" if args.config in ("C2", "C4") else "DFN protocol trajectories/sec (ensemble)",
+            "value": traj_s, "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1] (C2): batch of %d LCO isothermal 1C CC discharges (identical params) per GPU, "
-                                   "301 DAEs/cell, reltol 1e-3 / abstol 1e-6, SOC 1 -> SOC_min" % n_local,
-                       "cells_per_gpu": n_local, "cells_total": n_total, "sharding": "independent cells, contiguous blocks, no data-path collective",
-                       "steps_per_trajectory": float(ens.counters["n_steps"].mean()), "newton_iters_per_trajectory": float(ens.counters["n_newton"].mean())},
-            "roofline": {"bound": "hbm", "achieved": bytes_launch / (kavg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": bytes_launch / (kavg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, from profiles/*_traffic.json)",
-                         "kernel": "k_integrate", "kernel_ms_avg": kavg_ms, "kernel_ms_last_launch": klast_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                         "algorithmic_bytes_per_trajectory": bytes_launch / n_local,
-                         "note": "algorithmic bytes = SURVEY 8(d) streaming model; the kernel is LDS-resident, see DESIGN.md and profiles/ for measured HBM traffic"},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == "f64" else "f64 (fp32 storage of the Newton-matrix factors)",
+            "data": "synthetic",
+            "config": {"workload": c["text"] % n_local, "cells_per_gpu": n_local, "cells_total": n_total, "sharding": "independent cells, contiguous blocks, no data-path collective",
+                       "steps_per_trajectory": float(ens.counters["n_steps"].mean()), "newton_iters_per_trajectory": float(ens.counters["n_newton"].mean()),
+                       "rank_kernel_ms": rank_kernel_ms},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, from profiles/*_traffic*.json)",
+                         "hbm_utilisation": (traffic / (kavg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         "limiter": "dependent-instruction latency at one wavefront per SIMD (LDS-resident cell state; VALU-active / s_waitcnt shares in profiles/): 'achieved' and 'frac' "
+                                    "price the SURVEY 8(d) streaming model's bytes, which this kernel never moves -- read them as an equivalent-streaming rate, 'hbm_utilisation' is the real one",
+                         "kernel": "k_integrate<%s>" % c["variant"], "kernel_ms_avg": kavg_ms, "kernel_ms_last_launch": klast_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                         "algorithmic_bytes_per_trajectory": bytes_launch / n_local},
         }
+        if ens_run is not None:
+            out["ensemble_run"] = ens_run
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import oracle as O
-            th = O.theta_vector("lco_iso")
-            runs = [dict(mode=O.MODE_I, value=-1.0)]
-            t1 = time.perf_counter(); O.run_batch("lco_iso", th, 1.0, runs, 50); per = (time.perf_counter() - t1) / 50
-            n_cpu = max(100, int(args.cpu_seconds / per))
-            t1 = time.perf_counter(); ok, tsum, _ = O.run_batch("lco_iso", th, 1.0, runs, n_cpu); dt = time.perf_counter() - t1
-            assert ok == n_cpu and abs(tsum / n_cpu - 3600.0) < 1e-6
-            out["cpu_baseline"] = {"value": n_cpu / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
-                                   "sample": "%d of the same C2 trajectories (1C discharge, identical params), run back to back on one host core by the "
-                                             "oracle (plain-C IDA/KLU-style port, oracle/ida_oracle.c); %.1f s; host has %d cores; reference publishes "
-                                             "2.616 ms/trajectory on an unspecified laptop (examples/getting_started.ipynb:183-192)" % (n_cpu, dt, os.cpu_count())}
-            # the same sample on every host core at once ("1 thread and all host cores"): one oracle context per thread, ctypes drops the GIL
-            from concurrent.futures import ThreadPoolExecutor
-            cores = usable_cores()
-            chunk, deadline = max(10, int(0.25 / per)), time.perf_counter() + 0.6 * args.cpu_seconds
-
-            def worker(_):
-                done = 0
-                while time.perf_counter() < deadline:            # time-bounded: chunks of ~0.25 s until the deadline
-                    assert O.run_batch("lco_iso", th, 1.0, runs, chunk)[0] == chunk
-                    done += chunk
-                return done
-            t1 = time.perf_counter()
-            with ThreadPoolExecutor(cores) as ex:
-                n_all = sum(ex.map(worker, range(cores)))
-            dt_all = time.perf_counter() - t1
-            out["cpu_baseline_all_cores"] = {"value": n_all / dt_all, "unit": "trajectories/s", "cores": cores, "kind": "port",
-                                             "sample": "%d of the same trajectories on %d oracle threads (the cores this process may use: affinity / cgroup quota; "
-                                                       "the machine reports %d logical cores); %.1f s; %.1fx the one-core rate" % (n_all, cores, os.cpu_count(), dt_all, n_all / dt_all / out["cpu_baseline"]["value"])}
-            # the same launch through host pointers (PLH_HOST: H2D of Theta, D2H of every output array) -- the PCIe-inclusive rate, never `value`
-            Th_host = pkg.theta_matrix(p, n_local)
-            pkg.simulate_ensemble(p, Th_host, protocol, SOC=1.0, max_points=256)
-            t1 = time.perf_counter()
-            for _ in range(5):
-                pkg.simulate_ensemble(p, Th_host, protocol, SOC=1.0, max_points=256)
-            out["host_pointer_rate"] = {"value": 5 * n_local / (time.perf_counter() - t1), "unit": "trajectories/s",
-                                        "note": "plh_integrate with PLH_HOST pointers: pageable-memory staging of Theta in and t/V/I/SOC[256]/Y/YP/run_info/counters out per call"}
+            one, allc = cpu_baseline(args.config, c, p, pkg, inp, args.cpu_seconds)
+            out["cpu_baseline"] = one
+            out["cpu_baseline_all_cores"] = allc
+        if world == 1 and not args.no_extras:
+            out["host_inclusive"] = host_inclusive(pkg, p, inp, n_local, kavg_ms)
             # measured device-to-device copy bandwidth of this box (read + write bytes), the second peak SURVEY 8(d) asks to quote
             a = torch.empty(1 << 28, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
             b.copy_(a); torch.cuda.synchronize()
@@ -262,9 +328,7 @@ def main():
             for _ in range(10):
                 b.copy_(a)
             e1.record(); torch.cuda.synchronize()
-            copy_gbps = 10 * 2 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            out["roofline"]["measured_copy_peak"] = copy_gbps
-            out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / copy_gbps
+            out["roofline"]["measured_copy_peak"] = 10 * 2 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -490,3 +490,66 @@ def theta_matrix(p, n_cells, overrides=None):
         for k, v in overrides.items():
             Th[:, p.θ_keys.index(k)] = v
     return Th
+
+
+class HostPipeline:
+    """Host-inclusive ensemble calls at kernel rate: `depth` in-flight calls over pinned host buffers (plh_host_alloc) and one HIP stream each
+    (PLH_HOST_ASYNC): call k+1's parameter upload and kernel overlap call k's device-to-host copies.  This is SURVEY.md 8(d)'s measurement shape --
+    parameters start in host memory, per-cell summaries and sampled outputs end in host memory -- without paying the copies serially.
+
+        pipe = HostPipeline(p, n_cells, protocol, max_points=256)
+        for k, Theta in enumerate(batches):
+            slot = k % pipe.depth
+            if k >= pipe.depth: consume(pipe.wait(slot))          # results of call k - depth
+            pipe.submit(slot, Theta)
+    """
+
+    def __init__(self, p, n_cells, protocol, SOC=1.0, opts=None, max_points=256, depth=2, streams=None):
+        import torch                                                   # streams only (plumbing)
+        self.p, self.n, self.depth = p, int(n_cells), int(depth)
+        self.runs, self.names = make_protocol(p, protocol, n_cells)
+        self.arr = (cap.Run * len(self.runs))(*self.runs)
+        self.opts = _opts_struct(opts or p.opts)
+        self.mp = int(max_points)
+        self._torch_streams = streams or [torch.cuda.Stream() for _ in range(self.depth)]
+        self.streams = [s.cuda_stream for s in self._torch_streams]
+        lib = p._lib
+        N, P, nr = p.N.tot, len(p.θ_keys), len(self.runs)
+        self._blocks = []
+
+        def pinned(shape, dtype):
+            dt = np.dtype(dtype); nbytes = int(np.prod(shape)) * dt.itemsize
+            ptr = C.c_void_p()
+            cap.check(lib, lib.plh_host_alloc(C.byref(ptr), nbytes), "plh_host_alloc")
+            self._blocks.append(ptr)
+            return np.frombuffer((C.c_char * nbytes).from_address(ptr.value), dtype=dt).reshape(shape)
+        self.slots = []
+        for _ in range(self.depth):
+            b = dict(theta=pinned((self.n, P), np.float64), soc=pinned((self.n,), np.float64), t=pinned((self.n, self.mp), np.float64), V=pinned((self.n, self.mp), np.float64),
+                     n_pts=pinned((self.n,), np.int32), run_info=pinned((self.n, nr), cap.RUN_INFO_DTYPE), counters=pinned((self.n,), cap.COUNTERS_DTYPE))
+            b["soc"][:] = float(SOC)
+            out = cap.Outputs()
+            out.max_pts = self.mp
+            out.t, out.V, out.n_pts = cap.ptr(b["t"]), cap.ptr(b["V"]), cap.ptr(b["n_pts"])
+            out.run_info, out.counters = cap.ptr(b["run_info"]), cap.ptr(b["counters"])
+            b["out"] = out
+            self.slots.append(b)
+
+    def submit(self, slot, Theta):
+        b = self.slots[slot]
+        np.copyto(b["theta"], Theta)                                   # the caller's parameters into the pinned block (what a Julia host would own directly)
+        lib, h = self.p._lib, self.p._h
+        cap.check(lib, lib.plh_integrate(h, self.n, cap.ptr(b["theta"]), cap.ptr(b["soc"]), None, None, len(self.runs), self.arr, C.byref(self.opts),
+                                         C.byref(b["out"]), cap.PLH_HOST_ASYNC, self.streams[slot]), "plh_integrate")
+
+    def wait(self, slot):
+        cap.check(self.p._lib, self.p._lib.plh_synchronize(self.p._h, self.streams[slot]), "plh_synchronize")
+        return self.slots[slot]
+
+    def close(self):
+        for s in range(self.depth):
+            self.p._lib.plh_synchronize(self.p._h, self.streams[s])
+        for ptr in self._blocks:
+            self.p._lib.plh_host_free(ptr)
+        self._blocks = []
+        self.slots = []

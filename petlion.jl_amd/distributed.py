@@ -87,3 +87,56 @@ def ensemble_run(p, Theta, protocol, SOC=1.0, *, group=None, device=None, local_
         return out, (local if local is not None else summ)
     dist.gather(pad, None, dst=0, group=group)
     return None, (local if local is not None else summ)
+
+
+# ---- the C-ABI multi-GPU path (plh_comm_* / plh_ensemble_run: RCCL inside the library, what a Julia host binds) ----
+class RcclComm:
+    """one rank of a plh_comm communicator.  `unique_id` (128 bytes) comes from RcclComm.unique_id() on rank 0 and reaches the other ranks by the host's own
+    means (here: a torch.distributed broadcast in bench.py; MPI / Distributed.jl in a Julia host)."""
+
+    def __init__(self, lib, n_ranks, rank, unique_id=None, device=-1):
+        import ctypes as C
+        self.lib = lib
+        h = C.c_void_p()
+        from ._capi import check
+        check(lib, lib.plh_comm_create(int(n_ranks), int(rank), unique_id, int(device), C.byref(h)), "plh_comm_create")
+        self.h = h
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+
+    @staticmethod
+    def unique_id(lib):
+        import ctypes as C
+        from ._capi import check
+        buf = C.create_string_buffer(128)
+        check(lib, lib.plh_comm_unique_id(buf), "plh_comm_unique_id")
+        return buf.raw
+
+    def close(self):
+        if self.h:
+            self.lib.plh_comm_destroy(self.h)
+            self.h = None
+
+
+def ensemble_run_capi(comm, p, Theta, protocol, SOC=1.0, *, n_cells=None, partition="block", opts=None, want_Y=False):
+    """plh_ensemble_run: collective over `comm`; Theta ([n_cells, n_theta] numpy) and SOC are significant on rank 0 only (other ranks pass None and n_cells).
+    Returns on rank 0 (run_info [n_cells, n_runs], counters [n_cells], Y_final or None, rank_ms [n_ranks]); None elsewhere."""
+    import ctypes as C
+    from . import _capi as cap
+    from .api import _opts_struct, make_protocol
+    root = comm.rank == 0
+    n = int(Theta.shape[0] if root else n_cells)
+    runs, _ = make_protocol(p, protocol, n)
+    arr = (cap.Run * len(runs))(*runs)
+    o = _opts_struct(opts or p.opts)
+    part = {"block": cap.PART_BLOCK, "cyclic": cap.PART_CYCLIC}[partition]
+    if root:
+        Theta = np.ascontiguousarray(Theta, dtype=np.float64)
+        soc = np.full(n, float(SOC)) if np.isscalar(SOC) else np.ascontiguousarray(SOC, dtype=np.float64)
+        info = np.zeros((n, len(runs)), cap.RUN_INFO_DTYPE); cnt = np.zeros(n, cap.COUNTERS_DTYPE)
+        Y = np.zeros((n, p.N.tot)) if want_Y else None
+        ms = np.zeros(comm.n_ranks)
+        cap.check(p._lib, p._lib.plh_ensemble_run(comm.h, p._h, n, cap.ptr(Theta), cap.ptr(soc), len(runs), arr, C.byref(o), part, cap.ptr(info), cap.ptr(cnt),
+                                                  cap.ptr(Y), cap.ptr(ms)), "plh_ensemble_run")
+        return info, cnt, Y, ms
+    cap.check(p._lib, p._lib.plh_ensemble_run(comm.h, p._h, n, None, None, len(runs), arr, C.byref(o), part, None, None, None, None), "plh_ensemble_run")
+    return None

@@ -8,26 +8,9 @@ import parity
 pytestmark = pytest.mark.gpu
 
 
-def splitmix_u01(seed, cell, k):
-    """counter-based RNG of SURVEY.md 8(d): splitmix64(seed ^ cell*0x9E3779B97F4A7C15 ^ k) -> [0,1)"""
-    M = (1 << 64) - 1
-    z = (seed ^ (cell * 0x9E3779B97F4A7C15) ^ k) & M
-    z = (z + 0x9E3779B97F4A7C15) & M
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
-    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
-    z = z ^ (z >> 31)
-    return (z >> 11) / float(1 << 53)
-
-
-SWEEP_KEYS = ("D_sp", "D_sn", "D_p", "D_s", "D_n", "k_p", "k_n")      # config C4, SURVEY.md 8(d)
-
-
-def sweep_theta(pkg, p, n, seed=4):
-    over = {}
-    for k, key in enumerate(SWEEP_KEYS):
-        u = np.array([splitmix_u01(seed, c, k) for c in range(n)])
-        over[key] = p.θ[key] * 2.0 ** (2 * u - 1)
-    return pkg.theta_matrix(p, n, over)
+def sweep_theta(pkg, p, n, seed=4, first=0):
+    """config C4 / C5 inputs: splitmix64 stream, seven log-uniform factors -- petlion.jl_amd/configs.py"""
+    return pkg.configs.sweep_theta(p, first + np.arange(n), seed)
 
 
 def test_native_library_is_the_hip_build(hip_model, pkg):
@@ -76,52 +59,91 @@ def test_c2_1024_identical_cells(hip_model, O, pkg):
     parity.compare_trajectory(host, n - 1, ro, rtol_state=1e-6)
 
 
-def sweep_check(pkg, p, O, n, opts=None, oopts=None):
-    """per-cell parity of a C4-style sweep: returns (n_same_decisions, sorted state errors of the same-decision cells)."""
-    Th = sweep_theta(pkg, p, n)
+def sweep_check(pkg, p, O, n, opts=None, oopts_kw=None, cells=None):
+    """per-cell parity of a C4-style sweep against the oracle.  Returns per cell (same_decisions, state error, reproducibility floor of the cell)."""
+    cells = np.arange(n) if cells is None else np.asarray(cells)
+    Th = pkg.configs.sweep_theta(p, cells, 4)
     ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0, opts=opts)
-    errs, n_same = [], 0
-    for i in range(n):
-        ro = O.simulate("lco_iso", Th[i], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}]), opts=oopts)
-        assert ens.run_info[i, 0]["flag"] == ro["runs"][0]["flag"]
+    runs = parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}])
+    out = []
+    for i in range(len(cells)):
+        ro, band = parity.oracle_noise_band(O, "lco_iso", Th[i], 1.0, runs, oopts_kw)
+        assert ens.run_info[i, 0]["flag"] == ro["runs"][0]["flag"], (cells[i], ens.run_info[i, 0], ro["runs"][0])
         same = ens.run_info[i, 0]["iterations"] == ro["runs"][0]["iterations"] and all(
             ens.counters[i][f] == ro["counters"][f] for f in ("n_steps", "n_res", "n_jac", "n_newton", "n_errfail", "n_convfail"))
-        rel = parity.state_rel_err(ens.Y[i], ro["Y"])
-        if same:
-            n_same += 1
-            errs.append(rel)
-        else:   # a razor's-edge accept/reject or order decision flipped: agreement to the integration tolerance only
-            assert rel <= 2e-3, (i, rel)
-        assert abs(ens.run_info[i, 0]["t_end"] - ro["runs"][0]["t_end"]) <= 1e-6 * ro["runs"][0]["t_end"] if ro["runs"][0]["flag"] == 3 else True
-    return n_same, np.sort(np.array(errs))
+        if ro["runs"][0]["flag"] == 3:                  # SOC_min: the stop time is exact whatever the step grid
+            assert abs(ens.run_info[i, 0]["t_end"] - ro["runs"][0]["t_end"]) <= 1e-6 * ro["runs"][0]["t_end"]
+        out.append((bool(same), parity.state_rel_err(ens.Y[i], ro["Y"]), band))
+    return out
+
+
+def assert_within_floor(rows, what):
+    """EVERY cell: final state within 1e-6 (north star) or, where the reference algorithm itself is not reproducible to 1e-6, within 10x the cell's own
+    reproducibility floor (the spread of the oracle under last-bit perturbations of one intermediate vector, parity.oracle_noise_band)"""
+    bad = [(i, e, b) for i, (_, e, b) in enumerate(rows) if not e <= max(1e-6, 10.0 * b)]
+    assert not bad, (what, bad[:5])
+    e = np.sort([r[1] for r in rows])
+    print("%s: %d/%d identical decisions; state err median %.1e, p90 %.1e, max %.1e; cells above 1e-6: %d (all within 10x their reproducibility floor)"
+          % (what, sum(r[0] for r in rows), len(rows), np.median(e), e[int(0.9 * len(e))], e[-1], int((e > 1e-6).sum())))
 
 
 def test_c4_parameter_sweep_subset_vs_oracle(hip_model, O, pkg):
-    """config C4 inputs (seed 4, 7-parameter log-uniform jitter), first 48 cells, default options, against the oracle.
+    """config C4 inputs (seed 4, 7-parameter log-uniform jitter), first 48 cells, default options, against the oracle -- every cell, no percentiles.
 
-    Tolerance structure (DESIGN.md 'Reproducibility floor of the reference algorithm'): the step/order/Newton decisions
-    must be identical; the end states then agree to 1e-6 (section-scaled) in the typical cell.  The tail above 1e-6 is NOT a
-    kernel error: the reference's finite-difference estimate of the initial algebraic derivatives turns the 1e-12 rounding
-    difference between two equivalent residual formulas into a ~1e-6 relative difference of the automatic first step
-    h0 = 0.5/||y'||, i.e. a ~1e-6 time shift of the whole step grid, which the linear back-interpolation at the discharge
-    knee magnifies in a few cells.  With h0 pinned (next test) the same cells agree to 1e-9..1e-8."""
-    n = 48
-    n_same, errs = sweep_check(pkg, hip_model, O, n)
-    assert n_same >= n - 2, n_same
-    assert np.median(errs) <= 1e-6, np.median(errs)
-    assert errs[int(0.75 * len(errs))] <= 1e-6 and errs[-1] <= 1e-4, errs[-5:]
-    print("C4 subset, default h0: %d/%d identical decisions; state err median %.1e, p75 %.1e, max %.1e" % (n_same, n, np.median(errs), errs[int(0.75 * len(errs))], errs[-1]))
+    Criterion per cell: state error <= 1e-6, or <= 10x the cell's own reproducibility floor.  Why a floor exists (measured, tools/solve_accuracy.py and
+    DESIGN.md 5): newtons_method! estimates YP_alg by a difference quotient with dt = 0.01 of a Newton update whose fp64 noise is ~1e-11 of Phi_e; that is
+    1e-6 relative in YP_Phi_e, which dominates ||y'||_wrms, so IDA's h0 = 0.5/||y'|| -- and with it the whole step grid, t_k ~ (2^k - 1) h0 -- moves by ~1e-6
+    relative between ANY two fp64 implementations of the reference algorithm (the oracle against itself with one vector perturbed in the last bit
+    shows the same spread); the linear back-interpolation over the last (~200 s) step turns that time shift into up to 1e-4 at the voltage knee.  The
+    linear solver is not the source: the structured solve is closer to an extended-precision solution than the sparse LU (test_linear_solver_accuracy)."""
+    rows = sweep_check(pkg, hip_model, O, 48)
+    assert sum(r[0] for r in rows) >= 46, [i for i, r in enumerate(rows) if not r[0]]
+    assert_within_floor(rows, "C4 subset, default options")
+    assert np.median([r[1] for r in rows]) <= 1e-6
 
 
 def test_c4_parameter_sweep_pinned_initial_step(hip_model, O, pkg):
-    """same cells with IDA's init_step pinned in both implementations (IDASetInitStep): isolates the kernel arithmetic from the
-    h0 noise.  1e-6 relative is met by >= 90 % of the cells, the median is below 1e-7."""
-    n = 48
+    """same cells with IDA's init_step pinned in both implementations (IDASetInitStep): removes the h0 noise; the median drops below 1e-7"""
     o = pkg.Opts(); o.init_step = 1e-2
-    n_same, errs = sweep_check(pkg, hip_model, O, n, opts=o, oopts=O.default_opts(init_step=1e-2))
-    assert n_same >= n - 2, n_same
-    assert np.median(errs) <= 1e-7 and errs[int(0.9 * len(errs))] <= 1e-6 and errs[-1] <= 1e-4, (np.median(errs), errs[-6:])
-    print("C4 subset, pinned h0: %d/%d identical decisions; state err median %.1e, p90 %.1e, max %.1e" % (n_same, n, np.median(errs), errs[int(0.9 * len(errs))], errs[-1]))
+    rows = sweep_check(pkg, hip_model, O, 48, opts=o, oopts_kw=dict(init_step=1e-2))
+    assert_within_floor(rows, "C4 subset, pinned h0")
+    assert np.median([r[1] for r in rows]) <= 1e-7 and max(r[1] for r in rows) <= 1e-4
+
+
+def test_c4_refinement_mode(hip_model, O, pkg):
+    """plh_opts.refine = 1 (one step of iterative refinement of every linear solve, in the device and in the oracle): the solves then agree to 1e-11
+    (test_linear_solver_accuracy) -- and the trajectory deviations do not shrink, which is the evidence that the solver is not what limits parity"""
+    o = pkg.Opts(); o.refine = 1
+    rows = sweep_check(pkg, hip_model, O, 24, opts=o, oopts_kw=dict(refine=1))
+    assert sum(r[0] for r in rows) >= 23
+    assert_within_floor(rows, "C4 subset, refine = 1")
+
+
+def test_linear_solver_accuracy(hip_model, hip_model_sei, hip_model_thermal, O):
+    """device structured solve and oracle sparse LU against an 80-bit extended-precision solution of the same systems"""
+    for p in (hip_model, hip_model_sei, hip_model_thermal):
+        r0, r1 = parity.check_solver_accuracy(p, O)
+        print("%s: plain solves: device %.1e / oracle %.1e from the truth (max); refined: %.1e / %.1e, device vs oracle %.1e"
+              % (p.variant, r0[:, 0].max(), r0[:, 1].max(), r1[:, 0].max(), r1[:, 1].max(), r1[:, 2].max()))
+
+
+def test_accuracy_against_tight_tolerance(hip_model, O, pkg):
+    """is the device as ACCURATE as the reference path?  48 C4 cells to a fixed t = 2400 s (so all runs end at the same time): device and oracle at the
+    default tolerances against the oracle at reltol 1e-8 / abstol 1e-10 -- the device's error must not exceed the oracle's by more than 10 % in any cell"""
+    n = 48
+    Th = sweep_theta(pkg, hip_model, n)
+    proto = [{"I": -1.0, "tf": 2400.0}]
+    ens = pkg.simulate_ensemble(hip_model, Th, proto, SOC=1.0)
+    runs = parity.runs_to_oracle(O, hip_model, pkg, proto)
+    ratios = []
+    for i in range(n):
+        ro = O.simulate("lco_iso", Th[i], 1.0, runs)
+        rt = O.simulate("lco_iso", Th[i], 1.0, runs, opts=O.default_opts(reltol=1e-8, abstol=1e-10), max_out=200000)
+        assert ens.run_info[i, 0]["flag"] == ro["runs"][0]["flag"] == rt["runs"][0]["flag"] == 0
+        e_dev, e_orc = parity.state_rel_err(ens.Y[i], rt["Y"]), parity.state_rel_err(ro["Y"], rt["Y"])
+        assert e_dev <= 1.1 * e_orc + 1e-9, (i, e_dev, e_orc)
+        ratios.append(e_dev / e_orc)
+    print("accuracy vs reltol 1e-8: device error / oracle error in [%.4f, %.4f] over %d cells" % (min(ratios), max(ratios), n))
 
 
 def test_c4_full_shard_properties(hip_model, pkg):
@@ -146,6 +168,34 @@ def test_c4_full_shard_properties(hip_model, pkg):
     # sharding property: the same cells integrated as two half-batches give bitwise the same answers
     half = pkg.simulate_ensemble(p, torch.from_numpy(Th[: n // 2]).cuda(), [{"I": -1.0}], SOC=1.0, device=True, max_points=512)
     assert (half.Y.cpu().numpy() == ens.Y.cpu().numpy()[: n // 2]).all()
+
+
+def test_c4_full_size_65536_cells(hip_model, O, pkg):
+    """config C4 at its full size in ONE launch (65 536 cells = what 8 GPUs share): properties of every trajectory, and 256 cells (every 256th) against
+    the oracle with the per-cell reproducibility criterion"""
+    import torch
+    p = hip_model
+    n = 65536
+    Th = sweep_theta(pkg, p, n)
+    ens = pkg.simulate_ensemble(p, torch.from_numpy(Th).cuda(), [{"I": -1.0}], SOC=1.0, device=True, max_points=256)
+    torch.cuda.synchronize()
+    flags, tend = ens.run_info["flag"][:, 0], ens.run_info["t_end"][:, 0]
+    assert np.isin(flags, (1, 3)).all(), np.unique(flags)
+    assert np.abs(tend[flags == 3] - 3600.0).max() < 1e-6 and (tend[flags == 1] < 3600.0).all()
+    soc_end = ens.run_info["SOC"][:, 0]
+    assert np.abs(soc_end - (1.0 - tend / 3600.0)).max() < 1e-9                    # coulomb counting closes in every cell
+    assert (ens.counters["n_steps"] > 30).all() and (ens.counters["n_steps"] < 400).all() and (ens.counters["n_convfail"] <= 3).all()
+    Y = ens.Y.cpu().numpy()
+    # the 8 192-cell shard of rank 3 of 8 integrated on its own gives bitwise the same answers
+    shard = pkg.simulate_ensemble(p, torch.from_numpy(Th[3 * 8192:4 * 8192]).cuda(), [{"I": -1.0}], SOC=1.0, device=True, max_points=256)
+    assert (shard.Y.cpu().numpy() == Y[3 * 8192:4 * 8192]).all()
+    runs = parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}])
+    rows = []
+    for i in range(0, n, 256):
+        ro, band = parity.oracle_noise_band(O, "lco_iso", Th[i], 1.0, runs, seeds=4)
+        assert flags[i] == ro["runs"][0]["flag"], i
+        rows.append((ens.run_info[i, 0]["iterations"] == ro["runs"][0]["iterations"], parity.state_rel_err(Y[i], ro["Y"]), band))
+    assert_within_floor(rows, "C4, 65 536 cells, every 256th against the oracle")
 
 
 def test_cc_cv_protocol(hip_model, O, pkg):
@@ -200,9 +250,8 @@ def test_c5_nmc_sei_gitt_ensemble(hip_model_nmc_sei, O, pkg):
     p = hip_model_nmc_sei
     te.check_sei_model(p, O, pkg)
     n = 512
-    rng = np.random.default_rng(5)
-    Th = pkg.theta_matrix(p, n, {"k_n": p.θ["k_n"] * 2.0 ** (2 * rng.random(n) - 1), "D_sn": p.θ["D_sn"] * 2.0 ** (2 * rng.random(n) - 1),
-                                 "i_0_jside": p.θ["i_0_jside"] * 2.0 ** (2 * rng.random(n) - 1)})
+    Th = sweep_theta(pkg, p, n, seed=5)                                  # the C5 jitter ...
+    Th[:, p.θ_keys.index("i_0_jside")] *= 2.0 ** (2 * pkg.configs.splitmix_u01(5, np.arange(n), 7) - 1)     # ... plus the side-reaction exchange current
     proto = []
     for _ in range(3):
         proto += [{"I": 1.0, "tf": 240.0}, {"I": "rest", "tf": 360.0}]
@@ -228,8 +277,7 @@ def test_c3_thermal_cc_ct_cv_ensemble(hip_model_thermal, O, pkg):
     import test_device_source_emu as te
     p = hip_model_thermal
     n = 256
-    rng = np.random.default_rng(3)
-    Th = pkg.theta_matrix(p, n, {"T_amb": 298.15 + 5 * (rng.random(n) - 0.5), "h_cell": 2.0 ** (2 * rng.random(n) - 1)})
+    Th = pkg.configs.c3(p, n)["theta"]                                   # splitmix64 stream, seed 3
     Th[0] = p.theta_vector()
     te.check_thermal_model(p, O, pkg, Th=Th, cells=(0, 1, 100, 255))
     ens = pkg.simulate_ensemble(p, Th, te.CC_CT_CV, SOC=0.0)
@@ -285,11 +333,8 @@ def test_c5_full_protocol_1024_cells(hip_model_nmc_sei, O, pkg):
     Size-independent properties over the whole shard + two cells against the oracle."""
     p = hip_model_nmc_sei
     n = 1024
-    rng = np.random.default_rng(5)
-    Th = pkg.theta_matrix(p, n, {k: p.θ[k] * 2.0 ** (2 * rng.random(n) - 1) for k in ("D_sp", "D_sn", "k_p", "k_n")})
-    proto = []
-    for _ in range(20):
-        proto += [{"I": 1.0, "tf": 180.0}, {"I": "rest", "tf": 7200.0}]
+    cfg = pkg.configs.c5(p, n)                                           # SURVEY 8(d): seed 5, the seven-parameter jitter (the NMC system has four of the keys)
+    Th, proto = cfg["theta"], cfg["protocol"]
     ens = pkg.simulate_ensemble(p, Th, proto, SOC=0.0, max_points=4096)
     fl = ens.run_info["flag"]
     assert (fl >= 0).all()                                              # no solver failure anywhere
@@ -316,8 +361,9 @@ def test_c3_full_size_4096_cells_properties(hip_model_thermal, pkg):
     import test_device_source_emu as te
     p = hip_model_thermal
     n = 4096
-    rng = np.random.default_rng(3)
-    Th = pkg.theta_matrix(p, n, {"T_amb": 298.15 + 5 * (rng.random(n) - 0.5), "h_cell": 2.0 ** (2 * rng.random(n) - 1)})
+    cfg = pkg.configs.c3(p, n)
+    Th = cfg["theta"]
+    assert cfg["protocol"] == te.CC_CT_CV
     ens = pkg.simulate_ensemble(p, Th, te.CC_CT_CV, SOC=0.0, max_points=1024)
     fl = ens.run_info["flag"]
     assert (fl >= 0).all() and np.isin(fl[:, 0], (5, 2)).all() and (fl[:, 1] == 2).all() and np.isin(fl[:, 2], (4, 8)).all()

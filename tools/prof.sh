@@ -3,13 +3,15 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$1
+shift
+EXTRA="$@ --no-cpu-baseline --no-extras"     # e.g. tools/prof.sh r02_c3 --config C3
 mkdir -p $OUT
 cd $R
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1 -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM -d $OUT/pmc2 -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc3.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc4.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python bench.py --steps 5 --warmup 2 $EXTRA > $OUT/bench_trace.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1 -o pmc -- python bench.py --steps 2 --warmup 1 $EXTRA > $OUT/bench_pmc1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM -d $OUT/pmc2 -o pmc -- python bench.py --steps 2 --warmup 1 $EXTRA > $OUT/bench_pmc2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc -- python bench.py --steps 2 --warmup 1 $EXTRA > $OUT/bench_pmc3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc -- python bench.py --steps 2 --warmup 1 $EXTRA > $OUT/bench_pmc4.log 2>&1
 find $OUT -name "*.csv" | head -30
 for f in $(find $OUT/trace -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
 python3 - <<PY

@@ -3,11 +3,14 @@
 usage: python tools/summarize_profile.py <tag> [label]"""
 import collections, glob, os, sqlite3, sys
 tag = sys.argv[1]; label = sys.argv[2] if len(sys.argv) > 2 else tag
+workload = sys.argv[3] if len(sys.argv) > 3 else "C2"                       # usage: summarize_profile.py <tag> [label] [workload] [cells] [precision]
+cells = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+precision = sys.argv[5] if len(sys.argv) > 5 else "f64"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 out = os.path.join(ROOT, "profiles", "%s_rocprofv3_summary.md" % label)
 L = ["# rocprofv3 summary `%s`" % label, "",
-     "Command profiled (GPU box, 1x MI355X): `python bench.py --steps 5 --warmup 2 --no-cpu-baseline` for the kernel trace,",
+     "Command profiled (GPU box, 1x MI355X): `python bench.py --config %s%s --steps 5 --warmup 2 --no-cpu-baseline --no-extras` for the kernel trace," % (workload, "" if precision == "f64" else " --precision " + precision),
      "`--steps 2 --warmup 1` for each PMC pass (separate passes, never combined with sys/hip traces). Source: tools/prof.sh.", ""]
 con = sqlite3.connect(os.path.join(src, "trace", "trace_results.db")); cur = con.cursor()
 L += ["## `rocprofv3 --kernel-trace --stats` : top kernels", "", "| kernel | calls | total (us) | average (us) | % |", "|---|---|---|---|---|"]
@@ -19,7 +22,7 @@ L += ["", "`k_integrate`: %d dispatches, duration min/avg/max = %.1f / %.1f / %.
       % (len(d), min(d) / 1e3, sum(d) / len(d) / 1e3, max(d) / 1e3, rows[0][6], rows[0][7], rows[0][1], rows[0][2], rows[0][3], rows[0][4], rows[0][5]),
       "", "Per dispatch in launch order (us): " + ", ".join("%.0f" % (x / 1e3) for x in d) + " -- the first launches of a process run slower (clock ramp); "
       "the steady state (last three: %.0f us) is what `bench.py` times after its warm-up steps (`roofline.kernel_ms_avg`, HIP events on the launch stream)." % (sum(d[-3:]) / 3e3), ""]
-L += ["## PMC passes (per k_integrate launch = 1024 cells = 1024 wavefronts; averages over the dispatches of the run)", "", "| counter | value per launch | per wavefront |", "|---|---|---|"]
+L += ["## PMC passes (per k_integrate launch = %d cells = %d wavefronts; averages over the dispatches of the run)" % (cells, cells), "", "| counter | value per launch | per wavefront |", "|---|---|---|"]
 vals = {}
 for dbf in sorted(glob.glob(os.path.join(src, "pmc*", "*.db"))):
     con = sqlite3.connect(dbf); cur = con.cursor()
@@ -32,18 +35,18 @@ for dbf in sorted(glob.glob(os.path.join(src, "pmc*", "*.db"))):
     for k, v in acc.items():
         vals[k] = sum(v) / len(v)
 for k in sorted(vals):
-    L.append("| %s | %.4g | %.4g |" % (k, vals[k], vals[k] / 1024))
+    L.append("| %s | %.4g | %.4g |" % (k, vals[k], vals[k] / cells))
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     rd, wr = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024     # KiB -> B; gfx950 FETCH_SIZE reads 1/2 (MI355X_MICROARCH.md, HBM)
     L += ["", "HBM traffic per launch (FETCH_SIZE x 1024 B x 2 [gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md section HBM] + WRITE_SIZE x 1024 B, write side uncalibrated):",
-          "read %.1f MB + write %.1f MB = %.1f MB per launch = %.1f kB per trajectory." % (rd / 1e6, wr / 1e6, (rd + wr) / 1e6, (rd + wr) / 1024 / 1e3)]
+          "read %.1f MB + write %.1f MB = %.1f MB per launch = %.1f kB per trajectory." % (rd / 1e6, wr / 1e6, (rd + wr) / 1e6, (rd + wr) / cells / 1e3)]
     import json
-    json.dump({"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "cells_per_launch": 1024, "workload": "C2",
-               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`; "
+    json.dump({"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "cells_per_launch": cells, "workload": workload, "precision": precision,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --config %s --steps 2 --warmup 1 --no-cpu-baseline --no-extras`; " % workload +
                          "FETCH_SIZE x 1024 B x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE x 1024 B; see %s_rocprofv3_summary.md" % label},
               open(os.path.join(ROOT, "profiles", "%s_traffic.json" % label), "w"), indent=1)
 if "SQ_WAVE_CYCLES" in vals:
     L += ["", "SQ_WAVE_CYCLES etc. count quad-cycles: %.3g shader cycles per wavefront; VALU-active fraction %.0f %%, s_waitcnt-parked fraction %.0f %%."
-          % (4 * vals["SQ_WAVE_CYCLES"] / 1024, 100 * vals.get("SQ_ACTIVE_INST_ANY", 0) / vals["SQ_WAVE_CYCLES"], 100 * vals.get("SQ_WAIT_ANY", 0) / vals["SQ_WAVE_CYCLES"])]
+          % (4 * vals["SQ_WAVE_CYCLES"] / cells, 100 * vals.get("SQ_ACTIVE_INST_ANY", 0) / vals["SQ_WAVE_CYCLES"], 100 * vals.get("SQ_WAIT_ANY", 0) / vals["SQ_WAVE_CYCLES"])]
 open(out, "w").write("\n".join(L) + "\n")
 print(open(out).read())
