@@ -152,6 +152,7 @@ int plh_n_diff(plh_model_t m);       /* p.N.diff */
 int plh_n_theta(plh_model_t m);      /* length(θ_keys), src/generate_functions.jl:327-363 */
 const char* plh_theta_key(plh_model_t m, int i);   /* UTF-8 names identical to the reference Symbols, sorted like θ_keys */
 double plh_theta_default(plh_model_t m, int i);    /* chemistry defaults, src/params.jl */
+int plh_lds_bytes(plh_model_t m);    /* LDS held by one cell (= one workgroup) of this variant: 160 kB / this = resident cells per CU */
 /* p.ind (reference state_indices, src/external.jl:275-365): the named sections of the state vector in storage order, differential states
  * first.  Names are the reference's Symbols (c_e, c_s_avg, T, film, SOH, j, Φ_e, Φ_s, j_s, I); start is 0-based. */
 int plh_n_sections(plh_model_t m);

@@ -302,10 +302,11 @@ typedef struct {   /* reference options_simulation, src/structures.jl:266-285 */
   int n_tdiscon; const double* tdiscon;   /* opts.tdiscon: known discontinuities of a function input (structures.jl:279) */
   int refine;         /* 0 = plain LU solves (default); n > 0 = n steps of iterative refinement of every linear solve against the matrix that
                          was factored (parity mode: makes the solve independent of the elimination order to ~1e-13, see tools/solve_accuracy.py) */
-  /* reproducibility probe (tests only): the shifted state Y + dt YP of the finite-difference estimate of the algebraic derivatives
-     (model_evaluation.jl:462-477) is multiplied entry by entry by 1 + fd_perturb * u_i, u_i in [-1, 1) from splitmix64(perturb_seed, i).  With
-     fd_perturb = 2.2e-16 this is a last-bit perturbation of ONE intermediate vector of the reference algorithm: the spread of the results over a few
-     seeds is the reproducibility floor any second fp64 implementation of the same algorithm (another sparse LU, another summation order) sits in. */
+  /* reproducibility probe (tests only): the algebraic residual of the finite-difference estimate of the algebraic derivatives
+     (model_evaluation.jl:462-477) gets an evaluation-rounding-sized perturbation, res_i += fd_perturb * u_i * sum_c |J_ic Y_c|, u_i in [-1, 1) from
+     splitmix64(perturb_seed, i).  With fd_perturb = 2.2e-16 this is what two correct fp64 evaluations of the same row differ by (another summation
+     order, products formed before or after a difference); the spread of the results over a few seeds is the reproducibility floor any second fp64
+     implementation of the reference algorithm sits in. */
   double fd_perturb; int perturb_seed;
 } orc_opts;
 
@@ -514,12 +515,20 @@ static int newtons_method(evalb* e, double* Y, double* YP, const orc_opts* o, do
   /* finite-difference estimate of YP_alg (model_evaluation.jl:462-477) */
   double dt = fmax(10.0 * o->reltol_init, sqrt(nextafter(c_e0, INFINITY) - c_e0));
   for (int i = 0; i < N; i++) Ynew[i] = Y[i] + dt * YP[i];
-  if (o->fd_perturb != 0.0) for (int i = 0; i < N; i++) {
-    uint64_t z = ((uint64_t)o->perturb_seed * 0x9E3779B97F4A7C15ull) ^ (uint64_t)i; z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-    Ynew[i] *= 1.0 + o->fd_perturb * (2.0 * ((double)(z >> 11) / 9007199254740992.0) - 1.0);
-  }
   R_alg(e, res, Ynew, YP);
+  if (o->fd_perturb != 0.0) {
+    /* reproducibility probe: res_i += fd_perturb * u_i * sum_c |J_ic Y_c| -- an evaluation-rounding-sized perturbation of every algebraic row (each
+       row is a sum of terms of that magnitude; two correct fp64 evaluations of it differ by a few ulps of the largest term) */
+    const int Na_ = N - Nd;
+    double* term = (double*)calloc(Na_, sizeof(double));
+    for (int c = 0; c < Na_; c++) for (int q = e->acp[c]; q < e->acp[c + 1]; q++) term[e->ari[q]] += fabs(e->aax_f[q] * Ynew[Nd + c]);
+    for (int i = 0; i < Na_; i++) {
+      uint64_t z = ((uint64_t)o->perturb_seed * 0x9E3779B97F4A7C15ull) ^ (uint64_t)i; z += 0x9E3779B97F4A7C15ull;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+      res[i] += o->fd_perturb * term[i] * (2.0 * ((double)(z >> 11) / 9007199254740992.0) - 1.0);
+    }
+    free(term);
+  }
   lu_solve_refined(&e->alu, Na, e->acp, e->ari, e->aax_f, res, e->rtmp, e->xtmp, o->refine);
   if (e->cnt) e->cnt->n_solve++;
   for (int i = 0; i < Na; i++) YP[Nd + i] = -res[i] / dt;

@@ -56,6 +56,7 @@ class Model:
         self.N.tot = self._lib.plh_n_states(h)
         self.N.diff = self._lib.plh_n_diff(h)
         self.N.alg = self.N.tot - self.N.diff
+        self.lds_bytes = self._lib.plh_lds_bytes(h)            # LDS per cell of this variant
         self.θ_keys = [self._lib.plh_theta_key(h, i).decode("utf-8") for i in range(self._lib.plh_n_theta(h))]
         self.ind = {}                       # p.ind: state name -> slice into Y (reference state_indices, src/external.jl:275-365)
         for i in range(self._lib.plh_n_sections(h)):

@@ -342,6 +342,7 @@ int plh_n_diff(plh_model_t m) { return m ? m->Nd : PLH_E_ARG; }
 int plh_n_theta(plh_model_t m) { return m ? m->P : PLH_E_ARG; }
 const char* plh_theta_key(plh_model_t m, int i) { return (m && i >= 0 && i < m->P) ? m->key_names[i] : nullptr; }
 double plh_theta_default(plh_model_t m, int i) { return (m && i >= 0 && i < m->P) ? m->key_defaults[i] : NAN; }
+int plh_lds_bytes(plh_model_t m) { return m ? (int)m->ops->lds_bytes : PLH_E_ARG; }
 
 int plh_n_sections(plh_model_t m) { if (!m) return PLH_E_ARG; SectionInfo s[12]; return m->ops->sections(s); }
 int plh_section(plh_model_t m, int i, const char** name, int* start, int* len) {

@@ -429,3 +429,44 @@ def test_async_back_to_back_launches(hip_model, pkg):
         npt = e.n_pts.cpu().numpy()
         tt, tr = e.t.cpu().numpy(), t.cpu().numpy()
         assert all(np.array_equal(tt[i, :npt[i]], tr[i, :npt[i]]) for i in range(0, n, 37)), key
+
+
+def test_c5_mixed_precision_leg(hip_model_nmc_sei, pkg):
+    """config C5's reduced-precision leg (BASELINE configs[4], SURVEY 8(d): "run in fp64 and fp32, report max rel. deviation of V(t), SOH(t_end), film(t_end)"):
+    the mixed-precision instantiation (precision = "mixed": fp32 storage of the block-Thomas factors and particle resolvents, everything else fp64 -- pure fp32
+    cannot resolve SOH, film or t, tools/fp32_study.py) against the fp64 instantiation on the C5 inputs."""
+    p64 = hip_model_nmc_sei
+    pmx = pkg.petlion(pkg.NMC, aging="SEI", precision="mixed")
+    assert pmx.lds_bytes < p64.lds_bytes
+    n = 512
+    cfg = pkg.configs.c5(p64, n)
+    a = pkg.simulate_ensemble(p64, cfg["theta"], cfg["protocol"], SOC=cfg["SOC"], max_points=cfg["max_points"])
+    b = pkg.simulate_ensemble(pmx, cfg["theta"], cfg["protocol"], SOC=cfg["SOC"], max_points=cfg["max_points"])
+    assert (a.run_info["flag"] >= 0).all() and np.array_equal(a.run_info["flag"], b.run_info["flag"])           # no solver failure, identical exit flags
+    same = np.ones(n, bool)
+    for f in ("n_steps", "n_res", "n_jac", "n_newton", "n_errfail", "n_convfail"):
+        same &= a.counters[f] == b.counters[f]
+    assert same.mean() >= 0.95                                          # fp32 factor storage leaves the step / order / Newton decisions of nearly every cell untouched
+    ind = p64.ind
+    soh = lambda e: e.Y[:, ind["SOH"]][:, 0]
+    film = lambda e: e.Y[:, ind["film"]]
+    dV = np.abs(a.run_info["V"] - b.run_info["V"]) / np.abs(a.run_info["V"])
+    dsoh, dfilm = np.abs(soh(a) - soh(b)) / soh(a), np.abs(film(a) - film(b)).max(axis=1) / np.abs(film(a)).max(axis=1)
+    # cells with identical decisions: deviations at the level of the fp32 rounding of a converged modified-Newton iteration; all cells: the integration tolerance
+    assert dV[same].max() <= 1e-6 and dsoh[same].max() <= 1e-10 and dfilm[same].max() <= 1e-6, (dV[same].max(), dsoh[same].max(), dfilm[same].max())
+    assert dV.max() <= 2e-3 and dsoh.max() <= 1e-6 and dfilm.max() <= 2e-3, (dV.max(), dsoh.max(), dfilm.max())
+    print("C5 mixed vs fp64, %d cells: identical decisions in %d; max rel deviation V(run ends) %.1e (%.1e over identical-decision cells), SOH(t_end) %.1e (%.1e), film(t_end) %.1e (%.1e); "
+          "kernel %.1f ms vs %.1f ms; LDS %d B vs %d B per cell"
+          % (n, same.sum(), dV.max(), dV[same].max(), dsoh.max(), dsoh[same].max(), dfilm.max(), dfilm[same].max(), b.kernel_ms, a.kernel_ms, pmx.lds_bytes, p64.lds_bytes))
+
+
+def test_mixed_precision_variants_exist_and_refuse_cleanly(pkg):
+    for kw in (dict(cathode=pkg.LCO), dict(cathode=pkg.LCO, temperature=True)):
+        c = dict(kw); cathode = c.pop("cathode")
+        p = pkg.petlion(cathode, precision="mixed", **c)
+        ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 4), [{"I": -1.0, "tf": 600.0}], SOC=1.0)
+        q = pkg.petlion(cathode, **c)
+        ref = pkg.simulate_ensemble(q, pkg.theta_matrix(q, 4), [{"I": -1.0, "tf": 600.0}], SOC=1.0)
+        assert np.array_equal(ens.run_info["flag"], ref.run_info["flag"]) and parity.state_rel_err(ens.Y[0], ref.Y[0]) < 1e-6
+    with pytest.raises(pkg._capi.PetlionHipError):
+        pkg.petlion(pkg.NMC, precision="mixed")                        # NMC without aging is not instantiated in mixed precision: refused, no silent fp64
