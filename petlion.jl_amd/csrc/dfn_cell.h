@@ -22,6 +22,18 @@
 
 namespace pl {
 
+// Every device function is inlined into its kernel.  The product build does it late (`inline` here + -mllvm -amdgpu-function-calls=false: the AMDGPU
+// always-inline pass after the function-level optimisations; 0 B of scratch in the isothermal integrate kernel); tools/experiments/build_modes.py also builds
+// "early" (-DPL_DEV='__device__ __forceinline__', no flag) and, through PL_DEV_FACTOR, the thermal factorisation as a real function (-DPL_FACTOR_CALL).
+#ifndef PL_DEV
+#define PL_DEV __device__ inline
+#endif
+#if defined(PL_FACTOR_CALL) && !defined(PL_WAVE_EMU)
+#define PL_DEV_FACTOR __device__ __attribute__((noinline))
+#else
+#define PL_DEV_FACTOR PL_DEV
+#endif
+
 constexpr int WAVE = 64;
 constexpr int NP = 10, NS = 10, NN = 10, NR = 10, NE = NP + NS + NN, NJ = NP + NN;
 constexpr int O_CE = 0, O_CS = NE, N_CECS = O_CS + NJ * NR;      // c_e and c_s_avg lead every layout (reference src/external.jl:275-365)
@@ -198,11 +210,28 @@ __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
 // optional per-phase cycle accounting (profiling build: -DPL_PHASE_TIMERS)
 enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_OUTPUT, PH_TOTAL };
 #if defined(PL_PHASE_TIMERS) && !defined(PL_WAVE_EMU)
-#define PL_TIC() const long long pl_t0__ = (long long)__builtin_readcyclecounter()
-#define PL_TOC(S_, ph) do { if (lane_id() == 0) (S_).cyc[ph] += (long long)__builtin_readcyclecounter() - pl_t0__; } while (0)
+#define PL_TIC_() long long pl_t0__ = (long long)__builtin_readcyclecounter()
+#define PL_TOC_(S_, ph) do { if (lane_id() == 0) (S_).cyc[ph] += (long long)__builtin_readcyclecounter() - pl_t0__; } while (0)
 #else
+#define PL_TIC_() do {} while (0)
+#define PL_TOC_(S_, ph) do {} while (0)
+#endif
+// -DPL_PHASE_DETAIL (with PL_PHASE_TIMERS): the seven phase slots are re-used for the sub-phases of the Jacobian refresh (PL_TICD / PL_TOCD below); the
+// coarse phases are then not recorded (slot 7 stays the total)
+#ifdef PL_PHASE_DETAIL
 #define PL_TIC() do {} while (0)
 #define PL_TOC(S_, ph) do {} while (0)
+#define PL_TIC_TOTAL() PL_TIC_()
+#define PL_TOC_TOTAL(S_) PL_TOC_(S_, PH_TOTAL)
+#define PL_TICD() PL_TIC_()
+#define PL_TOCD(S_, slot) do { const long long now__ = (long long)__builtin_readcyclecounter(); if (lane_id() == 0) (S_).cyc[slot] += now__ - pl_t0__; pl_t0__ = now__; } while (0)   /* lap timer */
+#else
+#define PL_TIC() PL_TIC_()
+#define PL_TOC(S_, ph) PL_TOC_(S_, ph)
+#define PL_TIC_TOTAL() do {} while (0)
+#define PL_TOC_TOTAL(S_) PL_TOC_(S_, PH_TOTAL)
+#define PL_TICD() do {} while (0)
+#define PL_TOCD(S_, slot) do {} while (0)
 #endif
 __host__ __device__ __forceinline__ int sec_of(int i) { return i < NP ? 0 : (i < NP + NS ? 1 : 2); }
 // ---- cross-lane primitives.  gfx950: DPP moves (probed on hardware, tools/probes/dpp_probe.hip: wave_shr:1 / wave_shl:1 shift
@@ -325,20 +354,20 @@ __device__ __forceinline__ void sinh_cosh(double x, double& sh, double& ch) {
 __device__ __forceinline__ double hmean(double beta, double a, double b) { return a * b / (beta * b + (1.0 - beta) * a); }
 
 // thermal-model counterparts (dfn_thermal.h); the generic entry points below dispatch to them when M::THERMAL
-template <class M> __device__ inline void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th);
+template <class M> PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th);
 template <bool WANT_RES, bool WANT_JAC, class M>
-__device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value);
-template <bool WANT_JAC, class M> __device__ inline void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const double* Y, const double* YP, double* Fo);
-template <class M> __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only);
-template <class M> __device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, int mode, bool alg_only);
-template <bool FROZEN = false, class M> __device__ inline double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj);
+PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value);
+template <bool WANT_JAC, class M> PL_DEV void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const double* Y, const double* YP, double* Fo);
+template <class M> PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only);
+template <class M> PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, int mode, bool alg_only);
+template <bool FROZEN = false, class M> PL_DEV double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj);
 constexpr int PL_MODE_DT_TWIN = 16;   // dT control row with YP_T replaced by rhs_T(Y): the consistent-initialisation form (scalar_residual.jl:347-372)
 
 // ------------------------------------------------------------------------------------------------------------------
 // per-cell constants from theta (build_auxiliary_states!, reference aux...jl:6-52, and the Arrhenius closures)
 // ------------------------------------------------------------------------------------------------------------------
 template <class M>
-__device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, const double* __restrict__ th) {
+PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, const double* __restrict__ th) {
   PL_MODEL(M);
   const int lane = lane_id();
   if (lane == 0) {
@@ -427,7 +456,7 @@ __device__ inline void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __re
 
 // initial_guess!, reference src/states_definition.jl:80-121
 template <class M>
-__device__ inline void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) {
+PL_DEV void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) {
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -454,7 +483,7 @@ __device__ inline void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) 
 // node pass shared by the residual and the Jacobian partials.  Lane i < 30 owns control volume i and edge i (i|i+1).
 // ------------------------------------------------------------------------------------------------------------------
 template <bool WANT_RES, bool WANT_JAC, class M>
-__device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
+PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -630,7 +659,7 @@ __device__ inline void iso_node_pass(CellLDS<M>& S, const double* Y, const doubl
 
 // c_s rows (residuals_c_s_avg!, Fickian FDM, residuals.jl:128-180): lane -> (particle = pass*6 + lane/10, row = lane%10)
 template <class M>
-__device__ inline void iso_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
+PL_DEV void iso_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -667,18 +696,18 @@ __device__ inline void iso_cs_rows(CellLDS<M>& S, const LaneRegs& R, const doubl
 
 // ---- generic entry points: dispatch to the isothermal or the thermal implementation ----
 template <bool WANT_RES, bool WANT_JAC, class M>
-__device__ inline void cell_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
+PL_DEV void cell_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
   if constexpr (M::THERMAL) thermal_node_pass<WANT_RES, WANT_JAC>(S, Y, YP, Fo, mode, value);
   else iso_node_pass<WANT_RES, WANT_JAC>(S, Y, YP, Fo, mode, value);
 }
 template <bool WANT_JAC = false, class M>
-__device__ inline void cell_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
+PL_DEV void cell_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
   if constexpr (M::THERMAL) thermal_cs_rows<WANT_JAC>(S, S.tb, Y, YP, Fo);
   else iso_cs_rows(S, R, Y, YP, Fo);
 }
 // full residual F(Y, YP) -> Fo (all three are LDS vectors)
 template <class M>
-__device__ inline void cell_residual(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo, int mode, double value) {
+PL_DEV void cell_residual(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo, int mode, double value) {
   cell_node_pass<true, false>(S, Y, YP, Fo, mode, value);
   if constexpr (M::THERMAL) PL_SYNC();                      // the particle rows read the per-node D_s(T) written by the node pass
   cell_cs_rows<false>(S, R, Y, YP, Fo);
@@ -686,10 +715,10 @@ __device__ inline void cell_residual(CellLDS<M>& S, const LaneRegs& R, const dou
 }
 // residual + Jacobian partials in one pass (the Newton-matrix refresh of the corrector)
 template <class M>
-__device__ inline void cell_res_jac(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo, int mode, double value) {
-  cell_node_pass<true, true>(S, Y, YP, Fo, mode, value);
+PL_DEV void cell_res_jac(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo, int mode, double value) {
+  { PL_TICD(); cell_node_pass<true, true>(S, Y, YP, Fo, mode, value); PL_TOCD(S, 0); }
   if constexpr (M::THERMAL) PL_SYNC();
-  cell_cs_rows<true>(S, R, Y, YP, Fo);
+  { PL_TICD(); cell_cs_rows<true>(S, R, Y, YP, Fo); PL_TOCD(S, 1); }
   PL_SYNC();
 }
 
@@ -795,7 +824,7 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only
 // factor the Newton matrix at the Jacobian partials currently in S (cell_node_pass<.,true> must have run).
 // mode selects the control row; alg_only = the 71x71 algebraic block of the consistent-initialisation Newton.
 template <class M>
-__device__ inline void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
+PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -930,7 +959,7 @@ __device__ inline void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
 
 // solve J x = b in place (b is an LDS vector of NST entries).  alg_only: only rows/cols NDIFF.. are touched.
 template <class M>
-__device__ inline void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_only) {
+PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_only) {
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -1065,7 +1094,7 @@ enum JT { JT_CE_L = 1, JT_CE_D, JT_CE_U, JT_CE_J, JT_CS_CS, JT_CS_J, JT_J_CE, JT
           JT_CTRL_P1, JT_CTRL_M1,
           JT_CTRL_PA, JT_CTRL_PB, JT_CTRL_PI, JT_CE_JS, JT_PE_JS, JT_PS_JS, JT_J_F, JT_F_JS, JT_F_F, JT_SOH_JS, JT_SOH_SOH, JT_JS_PS, JT_JS_PE, JT_JS_J, JT_JS_JS, JT_JS_F, JT_JS_I };
 template <class M>
-__device__ inline double iso_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
+PL_DEV double iso_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
   PL_MODEL(M);
   const int t = w >> 24, a = (w >> 16) & 255, bb = (w >> 8) & 255, cc = w & 255;
   const CellConst& c = S.cc;
@@ -1121,19 +1150,19 @@ __device__ inline double iso_jac_entry(const CellLDS<M>& S, const Tables* __rest
 }
 
 template <class M>
-__device__ inline void cell_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
+PL_DEV void cell_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
   if constexpr (M::THERMAL) thermal_factor(S, R, tb, cj, mode, alg_only);
   else iso_factor(S, R, tb, cj, mode, alg_only);
 }
 template <class M>
-__device__ inline void cell_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_only) {
+PL_DEV void cell_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_only) {
   if constexpr (M::THERMAL) thermal_solve(S, R, S.tb, b, mode, alg_only);
   else iso_solve(S, R, b, mode, alg_only);
 }
 // FROZEN = the entry as it went into the last factorisation (thermal: the per-node kappa(T) and the T column of the particle rows are rebuilt from what
 // thermal_factor kept; every other pool entry is only written by Jacobian passes anyway)
 template <bool FROZEN = false, class M>
-__device__ inline double jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
+PL_DEV double jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
   if constexpr (M::THERMAL) return thermal_jac_entry<FROZEN>(S, tb, w, cj);
   else return iso_jac_entry(S, tb, w, cj);
 }
@@ -1146,7 +1175,7 @@ __device__ inline double jac_entry(const CellLDS<M>& S, const Tables* __restrict
 // b: LDS vector (in: right-hand side, out: solution); bsave: a free LDS vector.  alg_only: rows/columns >= NDIFF of the consistent-initialisation Newton
 // (the dT twin row has no exported entries: its residual is taken as zero, i.e. the row is not refined).
 template <class M>
-__device__ inline void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, double* bsave, double cjf, int mode, bool alg_only, int nref) {
+PL_DEV void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, double* bsave, double cjf, int mode, bool alg_only, int nref) {
   PL_MODEL(M);
   const int lane = lane_id();
   const bool twin = mode == PL_MODE_DT_TWIN;

@@ -55,7 +55,7 @@ __device__ __forceinline__ double wrms(const double* v, const double* w) {
 // function input loops back to it): a second inlined copy costs 4-5 % of the step loop in instruction-cache misses, and a real call
 // spills the ~100 live registers of the step loop.
 template <bool GEN, class M>
-__device__ inline int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
+PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
                                                       int mode, double value, double reltol_init, double* bsave = nullptr, int nref = 0) {
   LaneRegs R;                                                        // (the algebraic solves do not touch the particle registers)
   for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
@@ -113,7 +113,7 @@ __device__ __forceinline__ int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, 
 
 // ---- IDA pieces ----
 template <class M>
-__device__ inline void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0, const double* yp0, int maxord, double t_start = 0.0) {
+PL_DEV void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0, const double* yp0, int maxord, double t_start = 0.0) {
   PL_MODEL(M);
   const int lane = lane_id();
   I.tn = t_start; I.nst = 0; I.kk = 0; I.kused = 0; I.hused = 0.0; I.hh = 0.0; I.maxord = maxord;
@@ -127,7 +127,7 @@ __device__ inline void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0
 // error weights: IDA evaluates ewt from phi[0] = y_n at the start of every step.  Kept in six registers per lane (I.ew[trip]); EWT(n) reads
 // it inside a PL_VEC loop.
 template <class M>
-__device__ inline void set_ewt(CellLDS<M>& S, IdaScalars& I, double rtol, double atol) {
+PL_DEV void set_ewt(CellLDS<M>& S, IdaScalars& I, double rtol, double atol) {
   PL_MODEL(M);
   const int lane = lane_id();
   PL_VEC(n) { const double w = 1.0 / (rtol * fabs(S.phi[0][n]) + atol); I.ew[k__] = w; }
@@ -136,7 +136,7 @@ __device__ inline void set_ewt(CellLDS<M>& S, IdaScalars& I, double rtol, double
 #define EWT(n) I.ew[k__]
 
 template <class M>
-__device__ inline double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
+PL_DEV double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
   PL_MODEL(M);
   const int lane = lane_id();
   const int kk = I.kk; const double hh = I.hh;
@@ -182,7 +182,7 @@ __device__ inline double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
 
 // yy = ypred + ee, yp = yppred + cj ee with the predictor re-summed from phi (no separate predictor storage)
 template <class M>
-__device__ inline void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
+PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
   PL_MODEL(M);
   const int lane = lane_id();
   if (M::PRED_REGS && !first) {          // the predictor of this step is already in registers
@@ -204,7 +204,7 @@ __device__ inline void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = t
 
 // IDANls + Newton + convergence test.  0 ok, 1 recoverable failure
 template <bool GEN, class M>
-__device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, int mode, double value, int jac_every_step, Counters& cnt, int nref) {
+PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, int mode, double value, int jac_every_step, Counters& cnt, int nref) {
   PL_MODEL(M);
   const int lane = lane_id();
   const double epsNewt = 0.33, toldel = 0.0001 * epsNewt;
@@ -263,7 +263,7 @@ __device__ inline int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaS
 }
 
 template <class M>
-__device__ inline int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, double& err_k, double& err_km1) {
+PL_DEV int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, double& err_k, double& err_km1) {
   PL_MODEL(M);
   const int lane = lane_id();
   const int kk = I.kk;
@@ -288,7 +288,7 @@ __device__ inline int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, do
 }
 
 template <class M>
-__device__ inline void ida_restore(CellLDS<M>& S, IdaScalars& I, double saved_t) {
+PL_DEV void ida_restore(CellLDS<M>& S, IdaScalars& I, double saved_t) {
   PL_MODEL(M);
   const int lane = lane_id();
   I.tn = saved_t;
@@ -298,7 +298,7 @@ __device__ inline void ida_restore(CellLDS<M>& S, IdaScalars& I, double saved_t)
 }
 
 template <class M>
-__device__ inline void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double err_km1) {
+PL_DEV void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double err_km1) {
   PL_MODEL(M);
   const int lane = lane_id();
   I.nst++;
@@ -339,7 +339,7 @@ __device__ inline void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double er
 
 // IDAGetSolution(t): y -> yo, y' -> ypo (LDS vectors)
 template <class M>
-__device__ inline void ida_get_solution(CellLDS<M>& S, const IdaScalars& I, double t, double* yo, double* ypo) {
+PL_DEV void ida_get_solution(CellLDS<M>& S, const IdaScalars& I, double t, double* yo, double* ypo) {
   PL_MODEL(M);
   const int lane = lane_id();
   int kord = I.kused; if (kord == 0) kord = 1;
@@ -367,7 +367,7 @@ __device__ inline void ida_get_solution(CellLDS<M>& S, const IdaScalars& I, doub
 
 // value of a tabulated input at run-local time t (reference run_function: method(Y,p) - run.func(t,Y,YP,p), scalar_residual.jl:169-170);
 // wave-uniform: every lane walks the (small) table in HBM through scalar loads
-__device__ inline double tab_eval(const plh_run& r, double t) {
+PL_DEV double tab_eval(const plh_run& r, double t) {
   const int n = r.n_tab; const double* tt = r.tab_t; const double* vv = r.tab_v;
   if (n <= 0) return 0.0;
   if (t < tt[0]) return vv[0];
@@ -380,7 +380,7 @@ __device__ inline double tab_eval(const plh_run& r, double t) {
 }
 // next tstop after run-local time t: the sorted set {tdiscon - reltol/2} U {1.0 if continuation} U {tf} of postfix_integrator!
 // (model_evaluation.jl:288-310) walked without storing it
-__device__ inline double next_tstop(const plh_opts& o, double t, bool continuation, double tf) {
+PL_DEV double next_tstop(const plh_opts& o, double t, bool continuation, double tf) {
   double best = tf;
   if (continuation && 1.0 > t && 1.0 < best) best = 1.0;
   if (o.n_tdiscon > 0) {                                               // o.tdiscon is sorted ascending (plh_integrate stages a sorted copy): first entry with tdiscon - reltol/2 > max(t, 0)
@@ -395,7 +395,7 @@ __device__ inline double next_tstop(const plh_opts& o, double t, bool continuati
 
 // one IDASolve(ONE_STEP_TSTOP) call: advances, returns y(tret), y'(tret) in S.yy / S.yp.  0 ok, <0 failure
 template <bool TAB, class M>
-__device__ inline int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, double tstop, double& tret, int mode, double& value,
+PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, double tstop, double& tret, int mode, double& value,
                                const plh_opts& o, Counters& cnt, const plh_run* frun = nullptr) {
   PL_MODEL(M);
   const int lane = lane_id();
@@ -477,7 +477,7 @@ __device__ __forceinline__ double cellTavg(const CellLDS<M>& S, const double* Y)
 }
 
 template <class M>
-__device__ inline void check_stop(const CellLDS<M>& S, const plh_run& run, const plh_opts& o, double t, double tf, const double* Y, const double* YP,
+PL_DEV void check_stop(const CellLDS<M>& S, const plh_run& run, const plh_opts& o, double t, double tf, const double* Y, const double* YP,
                                   double SOC, PrevVals& pv, int& flag) {
   PL_MODEL(M);
   const double eps = t < 1.0 ? o.reltol : 0.0;
@@ -543,7 +543,7 @@ struct CellOut {
 // TAB = the protocol contains time-dependent (tabulated) inputs / tdiscon: a separate instantiation, so that constant-input protocols (the
 // benchmark path) carry none of that code (its mere presence costs ~5 % of the step loop in registers and instruction cache)
 template <bool TAB, class M>
-__device__ inline void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
+PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
                                      const CellOut& out, int* n_pts_out, plh_run_info* info, Counters& cnt, double* Yfin, double* YPfin,
                                      double* Yprev, double* YPprev, int cell) {
   PL_MODEL(M);

@@ -74,7 +74,7 @@ __device__ __forceinline__ int tsec_of(int it) { return it < NA ? 0 : (it < NA +
 // constants of the heat equation (lanes 0..49 own one T node each)
 // ------------------------------------------------------------------------------------------------------------------
 template <class M>
-__device__ inline void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th) {
+PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th) {
   static_assert(M::CHEM == PLH_CHEM_LCO_LIC6 && !M::SEI, "temperature = true is instantiated for LCO/LiC6 without aging");
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -126,7 +126,7 @@ __device__ inline void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ t
 // node pass: lanes 0..29 own control volume i / edge i of the cell sandwich; lanes 32..51 own the 20 collector T rows
 // ------------------------------------------------------------------------------------------------------------------
 template <bool WANT_RES, bool WANT_JAC, class M>
-__device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
+PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
   PL_MODEL(M);
   constexpr int O_T = M::O_T;
   const int lane = lane_id();
@@ -318,7 +318,7 @@ __device__ inline void thermal_node_pass(CellLDS<M>& S, const double* Y, const d
 
 // c_s rows with per-particle kappa(T) (residuals_c_s_avg!, residuals.jl:128-180); WANT_JAC also stores W c (needed for the T column)
 template <bool WANT_JAC, class M>
-__device__ inline void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const double* Y, const double* YP, double* Fo) {
+PL_DEV void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const double* Y, const double* YP, double* Fo) {
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -492,12 +492,13 @@ __device__ __forceinline__ int wb_src_node(int k) { return k == 0 ? 2 : (k == 1 
 __device__ __forceinline__ int wb_row_node(int k) { return k == 0 ? 0 : (k == 1 ? NP - 1 : (k == 2 ? NP + NS : NE - 1)); }
 
 template <class M>
-__device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
+PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double cj, int mode, bool alg_only) {
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
   auto& TP = S.th;
   const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
+  PL_TICD();
   // 1. particle resolvents in spectral form
   if (!alg_only) {
     if (lane < NJ) TP.kapF[lane] = TP.kapP[lane];
@@ -544,6 +545,7 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     }
   }
   PL_SYNC();
+  PL_TOCD(S, 2);
   // 3. node-local elimination of j (and the particle / collector Schur complements)
   if (lane < NE) {
     const int i = lane, sc = sec_of(i);
@@ -570,6 +572,7 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
   }
   if (lane == 0) TP.cjf = cj;
   PL_SYNC();
+  PL_TOCD(S, 3);
   // 4. twisted block-Thomas factorisation with 4x4 blocks (lane layout and recurrences as in iso_factor step 3)
   const int nd = tw_node(lane);
   const bool act = nd >= 0, top = lane < TW_MID;
@@ -686,6 +689,7 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     }
     if (act) for (int k = 0; k < 16; k++) { S.Dinv[i][k] = PL_F32(Dinv[k]); S.LD[i][k] = PL_F32(LDm[k]); }
   }
+  PL_TOCD(S, 4);
   // 6a. control row over the node unknowns (computed in the lane = node layout: the twin needs neighbour shifts), stored in TP.vB
   double dI = 0.0;
   {
@@ -739,10 +743,11 @@ __device__ inline void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* 
     if (lane == 0) { TP.bord[0] = dI - vx; TP.bord[1] = dI; }
   } else if (lane == 0) { TP.bord[0] = 1.0; TP.bord[1] = 1.0; }
   PL_SYNC();
+  PL_TOCD(S, 5);
 }
 
 template <class M>
-__device__ inline void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, int mode, bool alg_only) {
+PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, int mode, bool alg_only) {
   PL_MODEL(M);
   constexpr int O_T = M::O_T;
   const int lane = lane_id();
@@ -872,7 +877,7 @@ enum JTT { TT_CS_T = 64, TT_J_T, TT_PE_TL, TT_PE_TD, TT_PE_TU, TT_T_TL, TT_T_TD,
            TT_T_SL, TT_T_SD, TT_T_SU, TT_T_J, TT_T_CS, TT_T_X2, TT_T_I, TT_CTRL_T };
 
 template <bool FROZEN, class M>
-__device__ inline double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
+PL_DEV double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
   PL_MODEL(M);
   const int t = w >> 24, a = (w >> 16) & 255, bb = (w >> 8) & 255, cc = w & 255;
   const auto& TP = S.th;

@@ -89,7 +89,7 @@ static VariantInfo variant_keys(int chem, int sei, int thermal) {
 }
 static const VariantOps* variant_ops(int id) {
   switch (id) {
-#define PL_OPS_CASE(ID, CHEM, SEI, TH, MIX) case ID: return plh_variant_ops_##ID();
+#define PL_OPS_CASE(ID, CHEM, SEI, TH, MIX) case ID: return plh_variant_ops_##ID ? plh_variant_ops_##ID() : nullptr;
     PL_VARIANT_LIST(PL_OPS_CASE)
 #undef PL_OPS_CASE
   }

@@ -130,7 +130,7 @@ template <class M, bool TAB> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SI
   if (lane_id() < 8) S.cyc[lane_id()] = 0;
 #endif
   PL_SYNC();
-  PL_TIC();
+  PL_TIC(); PL_TIC_TOTAL();
   CellOut co;
   const size_t off = (size_t)cell * a.out.max_pts;
   co.max_pts = a.out.max_pts;
@@ -141,7 +141,7 @@ template <class M, bool TAB> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SI
                 a.out.run_info + (size_t)cell * a.n_runs, cnt,
                 a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
                 a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell);
-  PL_TOC(S, PH_TOTAL);
+  PL_TOC_TOTAL(S);
   PL_SYNC();
   if (lane_id() == 0 && a.out.counters) {
     plh_counters* c = a.out.counters + cell;

@@ -41,7 +41,8 @@ struct VariantOps {
   void (*integrate)(hipStream_t st, const IntegrateArgs& a, bool general);
 };
 
-// one definition per variant translation unit (nullptr-returning stubs do not exist: a missing variant is a link error)
-#define PL_DECLARE_OPS(ID, CHEM, SEI, TH, MIX) const VariantOps* plh_variant_ops_##ID();
+// one definition per variant translation unit.  Weak: an experiment build may link a subset of the variants (tools/), plh_model_create then refuses the
+// missing ones with PLH_E_UNSUPPORTED; the product build links all of them (tests/test_capi_symbols.py checks that every variant can be created)
+#define PL_DECLARE_OPS(ID, CHEM, SEI, TH, MIX) const VariantOps* plh_variant_ops_##ID() __attribute__((weak));
 PL_VARIANT_LIST(PL_DECLARE_OPS)
 #undef PL_DECLARE_OPS

@@ -8,15 +8,13 @@ sys.path.insert(0, ROOT)
 import pkgload
 pkg = pkgload.load()
 import torch
-lib = os.path.join(ROOT, "petlion.jl_amd", "libpetlion_hip_prof.so")
-src = os.path.join(ROOT, "petlion.jl_amd", "csrc", "petlion_hip.hip")
-csrc = os.path.dirname(src)
-newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc))
-if not os.path.exists(lib) or os.path.getmtime(lib) < newest:
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-pass-failed", "-mllvm", "-amdgpu-function-calls=false",
-                           "-DPL_PHASE_TIMERS", src, "-o", lib])
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-which = sys.argv[2] if len(sys.argv) > 2 else "iso"
+import __graft_entry__ as g
+detail = "--detail" in sys.argv
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+which = args[1] if len(args) > 1 else "iso"
+variant = {"iso": 0, "thermal": 4, "sei": 3}[which]
+lib = g.build_hip(extra_flags=["-DPL_PHASE_TIMERS"] + (["-DPL_PHASE_DETAIL"] if detail else []), lib=os.path.join(ROOT, "petlion.jl_amd", "_exp", "libplh_prof_%s%s.so" % (which, "_d" if detail else "")), variants=[variant])
+n = int(args[0]) if args else 1024
 if which == "thermal":
     p = pkg.petlion(pkg.LCO, temperature=True, _lib_path=lib)
     kw = dict(T_max=313.15, V_max=4.1, I_max=4.0, I_min=1 / 20)
@@ -31,11 +29,16 @@ Th = torch.from_numpy(pkg.theta_matrix(p, n)).cuda()
 for _ in range(3):
     ens = pkg.simulate_ensemble(p, Th, proto, SOC=soc, device=True, max_points=1024)
 names = ["residual", "jac+factor", "solve", "newton-vec", "step-ctl", "init", "output", "TOTAL"]
+if detail:
+    names = ["jac: node pass", "jac: particle rows", "factor: resolvents+collectors", "factor: node-local elimination", "factor: block sweep", "factor: control row+border", "-", "TOTAL"]
 cyc = ens.counters["cyc"].astype(np.float64)
 c = ens.counters
 print("kernel %.3f ms for %d cells; per cell: steps %.0f res %.0f jac %.0f solves %.0f" % (ens.kernel_ms, n, c["n_steps"].mean(), c["n_res"].mean(), c["n_jac"].mean(), c["n_solve"].mean()))
 tot = cyc[:, 7].mean()
 for k, nm in enumerate(names):
     print("  %-11s %10.0f cyc  %5.1f%%" % (nm, cyc[:, k].mean(), 100 * cyc[:, k].mean() / tot))
-print("  per call: residual %.0f  jac+factor %.0f  solve %.0f" % (cyc[:, 0].mean() / (c["n_res"].mean() - c["n_jac"].mean()), cyc[:, 1].mean() / c["n_jac"].mean(), cyc[:, 2].mean() / c["n_newton"].mean()))
+if detail:
+    print("  per Jacobian refresh:", ", ".join("%s %.0f" % (nm, cyc[:, k].mean() / c["n_jac"].mean()) for k, nm in enumerate(names[:6])))
+else:
+  print("  per call: residual %.0f  jac+factor %.0f  solve %.0f" % (cyc[:, 0].mean() / (c["n_res"].mean() - c["n_jac"].mean()), cyc[:, 1].mean() / c["n_jac"].mean(), cyc[:, 2].mean() / c["n_newton"].mean()))
 print("  flags per run:", [dict(zip(*np.unique(ens.run_info["flag"][:, k], return_counts=True))) for k in range(ens.run_info.shape[1])])
