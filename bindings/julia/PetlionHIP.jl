@@ -23,6 +23,7 @@ struct ModelDesc
     temperature::Cint; aging_SEI::Cint; real_bytes::Cint
     precision::Cint      # 0 = fp64, 1 = mixed (fp32 storage of the Newton-matrix factors)
     device::Cint         # HIP device ordinal, -1 = current
+    solid_diffusion::Cint; thermodynamic_factor::Cint; rxn::Cint     # 0 Fickian FDM / 1 quadratic / 2 polynomial ; 0 linear / 1 nonlinear ; 0 BV / 1 MHC
 end
 struct Bounds      # boundary_stop_conditions, src/structures.jl:237-250
     V_max::Cdouble; V_min::Cdouble; SOC_max::Cdouble; SOC_min::Cdouble; T_max::Cdouble; c_s_n_max::Cdouble
@@ -61,7 +62,9 @@ mutable struct Model
     function Model(p; precision = 0, device = -1)   # p::PETLION.model -- reads only p.N and p.numerics
         N = p.N
         chem = Symbol(p.numerics.cathode) == :LCO ? 0 : 1      # function name of the cathode system, as in strings_directory_func
-        d = Ref(ModelDesc(chem, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, p.numerics.temperature == true, p.numerics.aging == :SEI, 8, precision, device))
+        d = Ref(ModelDesc(chem, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, p.numerics.temperature == true, p.numerics.aging == :SEI, 8, precision, device,
+                          Dict(:Fickian => 0, :quadratic => 1, :polynomial => 2)[p.numerics.solid_diffusion],
+                          p.numerics.thermodynamic_factor === PETLION_thermodynamic_factor_nonlinear(p) ? 1 : 0, p.numerics.rxn_p === PETLION_rxn_MHC(p) ? 1 : 0))
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:plh_model_create, lib), Cint, (Ref{ModelDesc}, Ref{Ptr{Cvoid}}), d, h), "plh_model_create")
         n = ccall((:plh_n_theta, lib), Cint, (Ptr{Cvoid},), h[])
@@ -70,6 +73,10 @@ mutable struct Model
         finalizer(x -> ccall((:plh_model_destroy, lib), Cvoid, (Ptr{Cvoid},), x.h), m)
     end
 end
+
+# the reference stores the closures themselves in p.numerics (src/params.jl:286); they are compared by identity with the two non-default ones the device instantiates
+PETLION_thermodynamic_factor_nonlinear(p) = getfield(parentmodule(typeof(p)), :thermodynamic_factor)
+PETLION_rxn_MHC(p) = getfield(parentmodule(typeof(p)), :rxn_MHC)
 
 key_index(m::Model, k::Symbol) = findfirst(==(k), m.θ_keys)
 "p.ind of the device layout: state name => 1-based index range into Y (reference state_indices, src/external.jl:275-365)"

@@ -49,6 +49,16 @@ extern "C" {
 #define PLH_MODE_ETA_P 4 /* plating overpotential, V: Phi_s.n[1] - Phi_e.n[1] - value     (method_η_p, input_methods.jl:113-152) */
 #define PLH_N_MODES 5
 
+/* plh_model_desc.solid_diffusion / thermodynamic_factor / rxn: the model options of petlion(...; solid_diffusion, thermodynamic_factor, rxn_p, rxn_n)
+ * (reference src/params.jl:140-172; equations: residuals.jl:108-127,237-258, aux...jl:193-248, custom_functions.jl:177-203, 212-298) */
+#define PLH_SD_FICKIAN 0     /* :Fickian with Fickian_method = :finite_difference (N_r radial nodes per particle) */
+#define PLH_SD_QUADRATIC 1   /* :quadratic  -- one volume-averaged concentration per particle, c_s* = c_avg - Rp/(5 D_s) j */
+#define PLH_SD_POLYNOMIAL 2  /* :polynomial -- c_avg and the flux moment Q per particle (Subramanian et al.) */
+#define PLH_TF_LINEAR 0      /* thermodynamic_factor_linear: nu = 1 */
+#define PLH_TF_NONLINEAR 1   /* thermodynamic_factor: nu(c_e, T) = 0.601 - 0.24 (c_e/1000)^0.5 + 0.982 (1 - 0.0052 (T - 293)) (c_e/1000)^1.5 */
+#define PLH_RXN_BV 0         /* rxn_BV in both electrodes */
+#define PLH_RXN_MHC 1        /* rxn_MHC in both electrodes (Marcus-Hush-Chidsey; theta gains λ_MHC_p, λ_MHC_n) */
+
 /* plh_model_desc.precision */
 #define PLH_PREC_F64 0    /* everything fp64 (default; the parity configuration) */
 #define PLH_PREC_MIXED 1  /* block-Thomas factors and particle resolvents stored in fp32 in LDS; states, residuals, Jacobian entries, time, error control fp64 */
@@ -79,6 +89,9 @@ typedef struct {
   int precision;                                  /* PLH_PREC_* : storage precision of the LDS-resident Newton-matrix factors (config C5's fp32 leg) */
   int device;                                     /* HIP device ordinal the handle binds to (every call of the handle runs there); -1 = the device that is
                                                      current when plh_model_create is called */
+  int solid_diffusion;                            /* PLH_SD_* */
+  int thermodynamic_factor;                       /* PLH_TF_* */
+  int rxn;                                        /* PLH_RXN_* */
 } plh_model_desc;
 
 /* reference boundary_stop_conditions (src/structures.jl:237-250); NaN disables a bound */

@@ -47,6 +47,11 @@ VARIANTS = {
     "lco_iso_sei": dict(cathode="LCO", temperature=False, aging=True),
     "nmc_iso_sei": dict(cathode="NMC", temperature=False, aging=True),
     "nmc_iso": dict(cathode="NMC", temperature=False, aging=False),
+    # SURVEY 8(f).4 model variants (one option each on the LCO isothermal model)
+    "lco_iso_quad": dict(cathode="LCO", solid_diffusion="quadratic"),
+    "lco_iso_poly": dict(cathode="LCO", solid_diffusion="polynomial"),
+    "lco_iso_nu": dict(cathode="LCO", thermodynamic_factor="nonlinear"),
+    "lco_iso_mhc": dict(cathode="LCO", rxn="MHC"),
 }
 
 
@@ -96,6 +101,8 @@ def generate(name, verbose=True):
 
     ysym = {s: i for i, s in enumerate(Y)}
     ypsym = {s: i for i, s in enumerate(YP)}
+    aux = getattr(ops, "aux_defs", {})                    # named intermediates (dfn_model.SymOps.aux): chain rule below, substituted back before printing
+    daux = {a: {t: sp.diff(e, t) for t in e.free_symbols if t in ysym} for a, e in aux.items()}
     # sparse Jacobian, column-major (CSC) like the reference's SparseMatrixCSC
     entries = {}   # (row, col) -> expr
     for r, e in enumerate(res):
@@ -109,6 +116,14 @@ def generate(name, verbose=True):
                 d = sp.diff(e, s)
                 if d != 0:
                     entries[(r, ypsym[s])] = entries.get((r, ypsym[s]), 0) + cj * d
+            elif s in aux:
+                d = sp.diff(e, s)
+                if d != 0:
+                    for t, dt in daux[s].items():
+                        entries[(r, ysym[t])] = entries.get((r, ysym[t]), 0) + d * dt
+    if aux:
+        res = [e.xreplace(aux) for e in res]
+        entries = {k: sp.sympify(v).xreplace(aux) for k, v in entries.items()}
     cols = [[] for _ in range(N)]
     for (r, c) in entries:
         cols[c].append(r)
@@ -138,7 +153,7 @@ def generate(name, verbose=True):
     L = []
     L.append("/* GENERATED by oracle/codegen.py from oracle/dfn_model.py -- ORACLE (test infrastructure), do not edit.")
     L.append(" * variant %s: N=%d N_diff=%d nnz(J_y)=%d nnz(J_y_alg)=%d P=%d */" % (name, N, Nd, Z, len(a_rowval), P))
-    L.append("#include <math.h>\n")
+    L.append("#include <math.h>\n#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n")
     pre = "orc_" + name
     L.append("const int %s_N = %d, %s_NDIFF = %d, %s_NNZ = %d, %s_NNZ_ALG = %d, %s_P = %d;" % (pre, N, pre, Nd, pre, Z, pre, len(a_rowval), pre, P))
     L.append("const int %s_colptr[%d] = {%s};" % (pre, N + 1, ",".join(map(str, colptr))))

@@ -44,6 +44,11 @@ class FloatOps:
     def exp(self, x): return self._cm(x).exp(x)
     def sinh(self, x): return self._cm(x).sinh(x)
     def atan(self, x): return self._cm(x).atan(x)
+    def log(self, x): return self._cm(x).log(x)
+    def erf(self, x):
+        if isinstance(x, complex):       # first-order continuation (complex-step checks only)
+            return math.erf(x.real) + 1j * x.imag * 2.0 / math.sqrt(math.pi) * math.exp(-x.real ** 2)
+        return math.erf(x)
     def pow(self, x, y):
         return x ** y
     def relu(self, x, minval=0.0):   # max(minval, x)  (sqrt_ReLU argument, custom_functions.jl:210)
@@ -59,6 +64,7 @@ class FloatOps:
         ar = a.real if isinstance(a, complex) else a
         return x if ar > b else y
     def const(self, v): return v
+    def aux(self, name, expr): return expr         # (symbolic tracing names this intermediate; plain evaluation just uses its value)
 
 
 class SymOps:
@@ -70,6 +76,8 @@ class SymOps:
     def exp(self, x): return self.sp.exp(x)
     def sinh(self, x): return self.sp.sinh(x)
     def atan(self, x): return self.sp.atan(x)
+    def log(self, x): return self.sp.log(x)
+    def erf(self, x): return self.sp.erf(x)
     def pow(self, x, y): return self.sp.Pow(x, y)
     def relu(self, x, minval=0.0):
         return self.sp.Piecewise((x, x > minval), (self.sp.Float(minval), True))
@@ -80,6 +88,14 @@ class SymOps:
     def where_gt(self, a, b, x, y):
         return self.sp.Piecewise((x, a > b), (y, True))
     def const(self, v): return self.sp.Float(v)
+    def aux(self, name, expr):
+        """name an intermediate (the surface concentration of the quadratic / polynomial particle models): the residual is traced in terms of the new
+        symbol, codegen applies the chain rule -- differentiating the OCV polynomials through a nested expression is what makes sympy crawl"""
+        if not hasattr(self, "aux_defs"):
+            self.aux_defs = {}
+        sym = self.sp.Symbol(name, real=True)
+        self.aux_defs[sym] = self.sp.sympify(expr)
+        return sym
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -191,9 +207,12 @@ def fd_second_order(n):
 # ----------------------------------------------------------------------------------------------------------------
 class Layout:
     """0-based index ranges.  reference src/external.jl:275-365."""
-    def __init__(self, Np=10, Ns=10, Nn=10, Na=10, Nz=10, Nrp=10, Nrn=10, temperature=False, aging=False):
+    def __init__(self, Np=10, Ns=10, Nn=10, Na=10, Nz=10, Nrp=10, Nrn=10, temperature=False, aging=False, solid_diffusion="Fickian"):
+        if solid_diffusion != "Fickian":               # one volume-averaged concentration per particle (c_s_indices, aux...jl:696-703)
+            Nrp = Nrn = 1
         self.Np, self.Ns, self.Nn, self.Na, self.Nz, self.Nrp, self.Nrn = Np, Ns, Nn, Na, Nz, Nrp, Nrn
         self.temperature, self.aging = bool(temperature), bool(aging)
+        self.solid_diffusion = solid_diffusion
         o = 0
         self.c_e = (o, o + Np + Ns + Nn); o = self.c_e[1]
         self.c_s = (o, o + Np * Nrp + Nn * Nrn); o = self.c_s[1]
@@ -204,6 +223,9 @@ class Layout:
         if aging:
             self.film = (o, o + Nn); o = self.film[1]
             self.SOH = (o, o + 1); o = self.SOH[1]
+        self.Q = None
+        if solid_diffusion == "polynomial":            # Q is active only for the polynomial approximation (states_definition.jl:60-67)
+            self.Q = (o, o + Np + Nn); o = self.Q[1]
         self.N_diff = o
         self.j = (o, o + Np + Nn); o = self.j[1]
         self.Phi_e = (o, o + Np + Ns + Nn); o = self.Phi_e[1]
@@ -216,9 +238,13 @@ class Layout:
 
 
 class Model:
-    def __init__(self, cathode="LCO", temperature=False, aging=False, **Nkw):
+    def __init__(self, cathode="LCO", temperature=False, aging=False, solid_diffusion="Fickian", thermodynamic_factor="linear", rxn="BV", **Nkw):
+        """solid_diffusion: "Fickian" (finite difference), "quadratic", "polynomial" (params.jl:140); thermodynamic_factor: "linear" (nu = 1) or
+        "nonlinear" (custom_functions.jl:177-203); rxn: "BV" or "MHC" for both electrodes (custom_functions.jl:212-298)"""
+        assert solid_diffusion in ("Fickian", "quadratic", "polynomial") and thermodynamic_factor in ("linear", "nonlinear") and rxn in ("BV", "MHC")
         self.cathode = cathode
-        self.lay = Layout(temperature=temperature, aging=aging, **Nkw)
+        self.solid_diffusion, self.thermodynamic_factor, self.rxn = solid_diffusion, thermodynamic_factor, rxn
+        self.lay = Layout(temperature=temperature, aging=aging, solid_diffusion=solid_diffusion, **Nkw)
         self.theta = theta_LCO() if cathode == "LCO" else theta_NMC()
         if cathode == "NMC" and temperature:
             raise ValueError("the reference NMC chemistry defines no thermal parameters (params.jl:295-367)")
@@ -226,8 +252,9 @@ class Model:
 
     @property
     def name(self):
-        return "%s_%s%s" % (self.cathode.lower(), "thermal" if self.lay.temperature else "iso",
-                            "_sei" if self.lay.aging else "")
+        return "%s_%s%s%s%s%s" % (self.cathode.lower(), "thermal" if self.lay.temperature else "iso", "_sei" if self.lay.aging else "",
+                                  {"Fickian": "", "quadratic": "_quad", "polynomial": "_poly"}[self.solid_diffusion],
+                                  "_nu" if self.thermodynamic_factor == "nonlinear" else "", "_mhc" if self.rxn == "MHC" else "")
 
 
 def harmonic_mean(beta, x1, x2):
@@ -342,6 +369,24 @@ def rxn_BV(ops, c_s_star, c_e, T, eta, k, c_max):
     return 2.0 * k * ops.sqrt(ops.relu(c_e * c_s_star * (c_max - c_s_star), 0.0)) * ops.sinh(0.5 * F_CONST * eta / (R_CONST * T))
 
 
+def rxn_MHC(ops, c_s_star, c_e, T, eta, k, lam, c_max, c_e0):
+    """custom_functions.jl:241-298, the alpha = 0.5 branch that is taken (Zeng, Smith, Bai, Bazant 2014): Marcus-Hush-Chidsey kinetics in the uniformly
+    valid approximation; eta_f = F eta/(R T) + log_ReLU(c_e/c_e0 / (c_s*/c_max); minval = 1e-4)"""
+    eta_hat = eta * (F_CONST / (R_CONST * T))
+    theta_i = c_s_star / c_max
+    ce_hat = c_e / c_e0
+    eta_f = eta_hat + ops.log(ops.relu(ce_hat / theta_i, 1e-4))
+    a = 1.0 + ops.sqrt(lam)
+    k0 = k / ((1.0 - ops.erf((lam - ops.sqrt(a)) / (2.0 * ops.sqrt(lam)))) / 2.0)
+    coeff = k0 * (1.0 - ops.erf((lam - ops.sqrt(a + eta_f ** 2)) / (2.0 * ops.sqrt(lam))))
+    return coeff * (1.0 / (1.0 + ops.exp(-eta_f)) * c_e0 * c_s_star - 1.0 / (1.0 + ops.exp(eta_f)) * c_e * c_max) * ops.sqrt((1.0 - c_s_star / c_max) / c_e0)
+
+
+def thermodynamic_factor_nonlinear(ops, c_e, T):
+    """custom_functions.jl:191: 0.601 - 0.24 (c_e/1000)^0.5 + 0.982 (1 - 0.0052 (T - 293)) (c_e/1000)^1.5"""
+    return 0.601 - 0.24 * ops.pow(c_e / 1000.0, 0.5) + 0.982 * (1.0 - 0.0052 * (T - 293.0)) * ops.pow(c_e / 1000.0, 1.5)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # the residual
 # ----------------------------------------------------------------------------------------------------------------
@@ -395,9 +440,21 @@ def residual(model, ops, Y, YP, th, mode=MODE_I, value=0.0, with_control=True):
     if aging:
         for i in range(Nn):
             jt[Np + i] = jt[Np + i] + j_s[i]
-    # surface concentrations (aux...jl:193-211): last radial node of each particle
-    cs_star_p = [c_s[(i + 1) * Nrp - 1] for i in range(Np)]
-    cs_star_n = [c_s[Np * Nrp + (i + 1) * Nrn - 1] for i in range(Nn)]
+    Dsp = [th["D_sp"] * arrhenius(ops, th["Ea_D_sp"], T_p[i], thermal) for i in range(Np)]
+    Dsn = [th["D_sn"] * arrhenius(ops, th["Ea_D_sn"], T_n[i], thermal) for i in range(Nn)]
+    sd = model.solid_diffusion
+    if sd == "polynomial":
+        Qs = Y[lay.Q[0]:lay.Q[1]]
+    # surface concentrations (build_c_s_star!, aux...jl:193-248)
+    if sd == "Fickian":                                  # last radial node of each particle
+        cs_star_p = [c_s[(i + 1) * Nrp - 1] for i in range(Np)]
+        cs_star_n = [c_s[Np * Nrp + (i + 1) * Nrn - 1] for i in range(Nn)]
+    elif sd == "quadratic":                              # c_avg - Rp/(5 D_s) j   (aux...jl:212-230)
+        cs_star_p = [ops.aux("csp%d" % i, c_s[i] - (th["Rp_p"] / (Dsp[i] * 5)) * j[i]) for i in range(Np)]
+        cs_star_n = [ops.aux("csn%d" % i, c_s[Np + i] - (th["Rp_n"] / (Dsn[i] * 5)) * j[Np + i]) for i in range(Nn)]
+    else:                                                # c_avg + Rp/(35 D_s) (-j + 8 D_s Q)   (aux...jl:231-248)
+        cs_star_p = [ops.aux("csp%d" % i, c_s[i] + (th["Rp_p"] / (Dsp[i] * 35)) * (-j[i] + 8 * Dsp[i] * Qs[i])) for i in range(Np)]
+        cs_star_n = [ops.aux("csn%d" % i, c_s[Np + i] + (th["Rp_n"] / (Dsn[i] * 35)) * (-j[Np + i] + 8 * Dsn[i] * Qs[Np + i])) for i in range(Nn)]
     # OCV (aux...jl:250-270)
     ocv_p = OCV_LCO if model.cathode == "LCO" else OCV_NMC
     ocv_n = OCV_LiC6 if model.cathode == "LCO" else OCV_LiC6_with_NMC
@@ -425,11 +482,12 @@ def residual(model, ops, Y, YP, th, mode=MODE_I, value=0.0, with_control=True):
         Dp = [ops.pow(eps_p, bp) * D_eff_fn(ops, c_e[i], T_p[i]) for i in range(Np)]
         Ds = [ops.pow(eps_s, bs) * D_eff_fn(ops, c_e[Np + i], T_s[i]) for i in range(Ns)]
         Dn = [ops.pow(eps_n, bn) * D_eff_fn(ops, c_e[Np + Ns + i], T_n[i]) for i in range(Nn)]
-    Dsp = [th["D_sp"] * arrhenius(ops, th["Ea_D_sp"], T_p[i], thermal) for i in range(Np)]
-    Dsn = [th["D_sn"] * arrhenius(ops, th["Ea_D_sn"], T_n[i], thermal) for i in range(Nn)]
 
     hp, hs, hn = th["l_p"] / Np, th["l_s"] / Ns, th["l_n"] / Nn     # Δx*l per section
-    nu = 1.0                                                          # thermodynamic_factor_linear, custom_functions.jl:177
+    if model.thermodynamic_factor == "linear":                        # thermodynamic_factor_linear, custom_functions.jl:177
+        nu = [1.0] * Ne
+    else:                                                             # thermodynamic_factor, custom_functions.jl:191-203
+        nu = [thermodynamic_factor_nonlinear(ops, c_e[i], (T_p + T_s + T_n)[i]) for i in range(Ne)]
 
     # --- residuals_c_e! (residuals.jl:6-106) ---
     Dp_e, Ds_e, Dn_e = interpolate_electrolyte_grid(Dp, Ds, Dn, th, lay)
@@ -464,9 +522,9 @@ def residual(model, ops, Y, YP, th, mode=MODE_I, value=0.0, with_control=True):
     rhs[i] = (first_n * c_e[i - 1] - (first_n + second_n) * c_e[i] + second_n * c_e[i + 1]) / hn
     tp = th["t₊"]
     for i in range(Np):
-        rhs[i] = rhs[i] + (1 - tp) * nu * a_p * jt[i]
+        rhs[i] = rhs[i] + (1 - tp) * nu[i] * a_p * jt[i]
     for i in range(Nn):
-        rhs[Np + Ns + i] = rhs[Np + Ns + i] + (1 - tp) * nu * a_n * jt[Np + i]
+        rhs[Np + Ns + i] = rhs[Np + Ns + i] + (1 - tp) * nu[Np + Ns + i] * a_n * jt[Np + i]
     eps_cv = [eps_p] * Np + [eps_s] * Ns + [eps_n] * Nn
     for i in range(Ne):
         res[lay.c_e[0] + i] = rhs[i] / eps_cv[i] - YP[lay.c_e[0] + i]
@@ -486,23 +544,41 @@ def residual(model, ops, Y, YP, th, mode=MODE_I, value=0.0, with_control=True):
             out.append((Dse / Rp ** 2) * (d2[k] + 2.0 / r * d1[k]))
         return out
     o = lay.c_s[0]
-    for i in range(Np):
-        rows = particle_rows(c_s[i * Nrp:(i + 1) * Nrp], j[i], th["Rp_p"], Dsp[i], Nrp)
-        for k in range(Nrp):
-            res[o + i * Nrp + k] = rows[k] - YP[o + i * Nrp + k]
-    o = lay.c_s[0] + Np * Nrp
-    for i in range(Nn):
-        rows = particle_rows(c_s[Np * Nrp + i * Nrn:Np * Nrp + (i + 1) * Nrn], j[Np + i], th["Rp_n"], Dsn[i], Nrn)
-        for k in range(Nrn):
-            res[o + i * Nrn + k] = rows[k] - YP[o + i * Nrn + k]
+    if sd == "Fickian":
+        for i in range(Np):
+            rows = particle_rows(c_s[i * Nrp:(i + 1) * Nrp], j[i], th["Rp_p"], Dsp[i], Nrp)
+            for k in range(Nrp):
+                res[o + i * Nrp + k] = rows[k] - YP[o + i * Nrp + k]
+        o = lay.c_s[0] + Np * Nrp
+        for i in range(Nn):
+            rows = particle_rows(c_s[Np * Nrp + i * Nrn:Np * Nrp + (i + 1) * Nrn], j[Np + i], th["Rp_n"], Dsn[i], Nrn)
+            for k in range(Nrn):
+                res[o + i * Nrn + k] = rows[k] - YP[o + i * Nrn + k]
+    else:                                                # quadratic / polynomial approximation (residuals.jl:108-127): d c_avg/dt = -3 j / Rp
+        for i in range(Np):
+            res[o + i] = -3 * j[i] / th["Rp_p"] - YP[o + i]
+        for i in range(Nn):
+            res[o + Np + i] = -3 * j[Np + i] / th["Rp_n"] - YP[o + Np + i]
+    if sd == "polynomial":                               # residuals_Q! (residuals.jl:237-258)
+        o = lay.Q[0]
+        for i in range(Np):
+            res[o + i] = (-Dsp[i] * Qs[i] - 45 / 2 * j[i]) / th["Rp_p"] ** 2 - YP[o + i]
+        for i in range(Nn):
+            res[o + Np + i] = (-Dsn[i] * Qs[Np + i] - 45 / 2 * j[Np + i]) / th["Rp_n"] ** 2 - YP[o + Np + i]
 
     # --- residuals_j! (residuals.jl:491-517) ---
     for i in range(Np):
         k = th["k_p"] * arrhenius(ops, th["Ea_k_p"], T_p[i], thermal)
-        res[lay.j[0] + i] = rxn_BV(ops, cs_star_p[i], c_e[i], T_p[i], eta_p[i], k, th["c_max_p"]) - j[i]
+        if model.rxn == "MHC":
+            res[lay.j[0] + i] = rxn_MHC(ops, cs_star_p[i], c_e[i], T_p[i], eta_p[i], k, th["λ_MHC_p"], th["c_max_p"], th["c_e₀"]) - j[i]
+        else:
+            res[lay.j[0] + i] = rxn_BV(ops, cs_star_p[i], c_e[i], T_p[i], eta_p[i], k, th["c_max_p"]) - j[i]
     for i in range(Nn):
         k = th["k_n"] * arrhenius(ops, th["Ea_k_n"], T_n[i], thermal)
-        res[lay.j[0] + Np + i] = rxn_BV(ops, cs_star_n[i], c_e[Np + Ns + i], T_n[i], eta_n[i], k, th["c_max_n"]) - j[Np + i]
+        if model.rxn == "MHC":
+            res[lay.j[0] + Np + i] = rxn_MHC(ops, cs_star_n[i], c_e[Np + Ns + i], T_n[i], eta_n[i], k, th["λ_MHC_n"], th["c_max_n"], th["c_e₀"]) - j[Np + i]
+        else:
+            res[lay.j[0] + Np + i] = rxn_BV(ops, cs_star_n[i], c_e[Np + Ns + i], T_n[i], eta_n[i], k, th["c_max_n"]) - j[Np + i]
 
     # --- residuals_Φ_e! (residuals.jl:554-654) ---
     Kp_e, Ks_e, Kn_e = interpolate_electrolyte_grid(Kp, Ks, Kn, th, lay)
@@ -534,13 +610,13 @@ def residual(model, ops, Y, YP, th, mode=MODE_I, value=0.0, with_control=True):
     cbp, cbs, cbn = interpolate_edges(c_e, th, lay)
     Tb_p, Tb_s, Tb_n = interpolate_edges(T[Na:Na + Ne], th, lay)
     fxp, fxs, fxn = edge_fluxes(c_e, th, lay)
-    Kfac = 2 * R * (1 - tp) * nu / F
+    Kfac = [2 * R * (1 - tp) * nu[i] / F for i in range(Ne - 1)]     # nu of the LEFT control volume of each edge (residuals.jl:626-629)
     g = ([Kp_e[i] * Tb_p[i] * fxp[i] / cbp[i] for i in range(Np)]
          + [Ks_e[i] * Tb_s[i] * fxs[i] / cbs[i] for i in range(Ns)]
          + [Kn_e[i] * Tb_n[i] * fxn[i] / cbn[i] for i in range(Nn - 1)])       # Ne-1 edges
     f = [None] * Ne
     for i in range(Ne - 1):
-        f[i] = -Kfac * (g[i] - (g[i - 1] if i > 0 else 0.0))
+        f[i] = -Kfac[i] * (g[i] - (g[i - 1] if i > 0 else 0.0))
     f[Ne - 1] = 0.0
     for i in range(Np):
         f[i] = f[i] + hp * F * a_p * jt[i]
@@ -625,15 +701,15 @@ def residual(model, ops, Y, YP, th, mode=MODE_I, value=0.0, with_control=True):
         for i in range(Np):
             q_rev = F * a_p * jt[i] * T_p[i] * dU_p[i]
             q_rxn = F * a_p * jt[i] * eta_p[i]
-            q_ohm = (Kp[i] * dPe_p[i] ** 2 + 2 * R * Kp[i] * T_p[i] * (1 - tp) * nu / F * (dce_p[i] / ce_p[i]) * dPe_p[i]
+            q_ohm = (Kp[i] * dPe_p[i] ** 2 + 2 * R * Kp[i] * T_p[i] * (1 - tp) * nu[i] / F * (dce_p[i] / ce_p[i]) * dPe_p[i]
                      + sig_p * dPs_p[i] ** 2)
             Q[Na + i] = q_rev + q_rxn + q_ohm
         for i in range(Ns):
-            Q[Na + Np + i] = Ks[i] * dPe_s[i] ** 2 + 2 * R * Ks[i] * T_s[i] * (1 - tp) * nu / F * (dce_s[i] / ce_s[i]) * dPe_s[i]
+            Q[Na + Np + i] = Ks[i] * dPe_s[i] ** 2 + 2 * R * Ks[i] * T_s[i] * (1 - tp) * nu[Np + i] / F * (dce_s[i] / ce_s[i]) * dPe_s[i]
         for i in range(Nn):
             q_rev = F * a_n * jt[Np + i] * T_n[i] * dU_n[i]
             q_rxn = F * a_n * jt[Np + i] * eta_n[i]
-            q_ohm = (Kn[i] * dPe_n[i] ** 2 + 2 * R * Kn[i] * T_n[i] * (1 - tp) * nu / F * (dce_n[i] / ce_n[i]) * dPe_n[i]
+            q_ohm = (Kn[i] * dPe_n[i] ** 2 + 2 * R * Kn[i] * T_n[i] * (1 - tp) * nu[Np + Ns + i] / F * (dce_n[i] / ce_n[i]) * dPe_n[i]
                      + sig_n * dPs_n[i] ** 2)
             Q[Na + Np + Ns + i] = q_rev + q_rxn + q_ohm
         NT = Na + Ne + Nz

@@ -54,7 +54,7 @@ typedef struct {
   fjac_t jac, jac_alg;
   fig_t initial_guess;
   /* layout (0-based), reference src/external.jl:275-365 */
-  int Np, Ns, Nn, Na, Nz, Nrp, Nrn, thermal, aging;
+  int Np, Ns, Nn, Na, Nz, Nrp, Nrn, thermal, aging, has_Q;
   int o_ce, o_cs, o_T, o_film, o_SOH, o_j, o_pe, o_ps, o_js, o_I;
   /* thermal extras */
   int nnz_twin; const int* twin_cols; fres_t dT_twin; fjac_t dT_twin_jac; void (*dT_weights)(double*, const double*);
@@ -90,9 +90,22 @@ DECL_VARIANT(nmc_iso_sei)
 #ifdef ORC_HAVE_nmc_iso
 DECL_VARIANT(nmc_iso)
 #endif
+#ifdef ORC_HAVE_lco_iso_quad
+DECL_VARIANT(lco_iso_quad)
+#endif
+#ifdef ORC_HAVE_lco_iso_poly
+DECL_VARIANT(lco_iso_poly)
+#endif
+#ifdef ORC_HAVE_lco_iso_nu
+DECL_VARIANT(lco_iso_nu)
+#endif
+#ifdef ORC_HAVE_lco_iso_mhc
+DECL_VARIANT(lco_iso_mhc)
+#endif
 
 static void set_layout(orc_model* m, int thermal, int aging) {
-  m->Np = m->Ns = m->Nn = m->Na = m->Nz = m->Nrp = m->Nrn = 10;
+  m->Np = m->Ns = m->Nn = m->Na = m->Nz = 10;
+  if (m->Nrp == 0) m->Nrp = m->Nrn = 10;      /* (1 for the quadratic / polynomial solid-diffusion approximations: one c_s_avg per particle) */
   m->thermal = thermal; m->aging = aging;
   int o = 0;
   m->o_ce = o; o += m->Np + m->Ns + m->Nn;
@@ -100,6 +113,7 @@ static void set_layout(orc_model* m, int thermal, int aging) {
   m->o_T = -1; m->o_film = -1; m->o_SOH = -1; m->o_js = -1;
   if (thermal) { m->o_T = o; o += m->Na + m->Np + m->Ns + m->Nn + m->Nz; }
   if (aging) { m->o_film = o; o += m->Nn; m->o_SOH = o; o += 1; }
+  if (m->has_Q) o += m->Np + m->Nn;            /* Q, polynomial approximation only (states_definition.jl:60-67) */
   m->o_j = o; o += m->Np + m->Nn;
   m->o_pe = o; o += m->Np + m->Ns + m->Nn;
   m->o_ps = o; o += m->Np + m->Nn;
@@ -112,7 +126,8 @@ static void set_layout(orc_model* m, int thermal, int aging) {
   (m)->rowval = orc_##v##_rowval; (m)->acolptr = orc_##v##_alg_colptr; (m)->arowval = orc_##v##_alg_rowval; \
   (m)->theta_keys = orc_##v##_theta_keys; (m)->f_diff = orc_##v##_f_diff; (m)->f_alg = orc_##v##_f_alg; \
   (m)->jac = orc_##v##_jac; (m)->jac_alg = orc_##v##_jac_alg; (m)->initial_guess = orc_##v##_initial_guess; \
-  set_layout(m, th_, ag_); } while (0)
+  (m)->Nrp = (m)->Nrn = 0; (m)->has_Q = 0; set_layout(m, th_, ag_); } while (0)
+#define FILL_VARIANT_SD(m, v, nr_, q_) do { FILL_VARIANT(m, v, 0, 0); (m)->Nrp = (m)->Nrn = nr_; (m)->has_Q = q_; set_layout(m, 0, 0); } while (0)
 
 static int get_model(const char* name, orc_model* m) {
 #ifdef ORC_HAVE_lco_iso
@@ -132,6 +147,18 @@ static int get_model(const char* name, orc_model* m) {
 #endif
 #ifdef ORC_HAVE_nmc_iso
   if (!strcmp(name, "nmc_iso")) { FILL_VARIANT(m, nmc_iso, 0, 0); return 0; }
+#endif
+#ifdef ORC_HAVE_lco_iso_quad
+  if (!strcmp(name, "lco_iso_quad")) { FILL_VARIANT_SD(m, lco_iso_quad, 1, 0); return 0; }
+#endif
+#ifdef ORC_HAVE_lco_iso_poly
+  if (!strcmp(name, "lco_iso_poly")) { FILL_VARIANT_SD(m, lco_iso_poly, 1, 1); return 0; }
+#endif
+#ifdef ORC_HAVE_lco_iso_nu
+  if (!strcmp(name, "lco_iso_nu")) { FILL_VARIANT(m, lco_iso_nu, 0, 0); return 0; }
+#endif
+#ifdef ORC_HAVE_lco_iso_mhc
+  if (!strcmp(name, "lco_iso_mhc")) { FILL_VARIANT(m, lco_iso_mhc, 0, 0); return 0; }
 #endif
   return -1;
 }

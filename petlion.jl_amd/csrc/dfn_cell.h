@@ -36,13 +36,20 @@ namespace pl {
 
 constexpr int WAVE = 64;
 constexpr int NP = 10, NS = 10, NN = 10, NR = 10, NE = NP + NS + NN, NJ = NP + NN;
-constexpr int O_CE = 0, O_CS = NE, N_CECS = O_CS + NJ * NR;      // c_e and c_s_avg lead every layout (reference src/external.jl:275-365)
+constexpr int O_CE = 0, O_CS = NE;                                 // c_e and c_s_avg lead every layout (reference src/external.jl:275-365)
 constexpr int NA = 10, NZ = 10, NT = NA + NE + NZ;               // current collectors; temperature nodes a|p|s|n|z
 constexpr int MAXORD = 5;
 
 // Model traits: state layout  Y = [ c_e | c_s_avg | T (thermal) | film, SOH (SEI) || j | Phi_e | Phi_s | j_s (SEI) | I ]  and closures.
-template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false> struct ModelT {
+// SD_: solid diffusion -- PLH_SD_FICKIAN (9th-order finite differences, N_r nodes per particle), PLH_SD_QUADRATIC, PLH_SD_POLYNOMIAL (one volume-averaged
+//      concentration per particle, the polynomial variant with the extra state Q: residuals.jl:108-127, 237-258, aux...jl:212-248)
+// TF_: thermodynamic factor -- 0 linear (nu = 1), 1 nonlinear nu(c_e, T) (custom_functions.jl:177-203);  RXN_: 0 Butler-Volmer, 1 Marcus-Hush-Chidsey (:212-298)
+template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false, int SD_ = 0, int TF_ = 0, int RXN_ = 0> struct ModelT {
   static constexpr int CHEM = CHEM_;                 // PLH_CHEM_LCO_LIC6 / PLH_CHEM_NMC_LIC6
+  static constexpr int SD = SD_, TF = TF_, RXN = RXN_;
+  static_assert(SD_ == 0 || (!SEI_ && !THERMAL_), "the quadratic / polynomial particle models are instantiated for the isothermal models without aging");
+  static constexpr int NCS = SD_ == 0 ? NJ * NR : NJ;    // entries of c_s_avg
+  static constexpr int N_CECS = O_CS + NCS;
   static constexpr bool SEI = SEI_;
   static constexpr bool THERMAL = THERMAL_;
   // PLH_PREC_MIXED (config C5's reduced-precision leg): the LDS-resident factors of the Newton matrix -- block-Thomas D'^-1, L D'^-1 and the particle
@@ -58,7 +65,8 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false> stru
   static constexpr int NB = THERMAL_ ? 4 : 3;        // node block size of the block-Thomas solve: (c_e, Phi_e, Phi_s[, T])
   static constexpr int O_T = N_CECS;
   static constexpr int O_FILM = N_CECS + (THERMAL_ ? NT : 0), O_SOH = O_FILM + NN;
-  static constexpr int NDIFF = SEI_ ? O_SOH + 1 : O_FILM;
+  static constexpr int O_Q = SEI_ ? O_SOH + 1 : O_FILM;              // Q (polynomial approximation only) closes the differential block
+  static constexpr int NDIFF = O_Q + (SD_ == 2 ? NJ : 0);
   static constexpr int O_J = NDIFF, O_PE = O_J + NJ, O_PS = O_PE + NE, O_JS = O_PS + NJ, O_I = SEI_ ? O_JS + NN : O_PS + NJ;
   static constexpr int NST = O_I + 1, NALG = NST - NDIFF;
   static constexpr int NPAD = NST + (NST & 1);
@@ -66,7 +74,7 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false> stru
 };
 using ModelLcoIso = ModelT<PLH_CHEM_LCO_LIC6, false>;
 #define PL_MODEL(M) [[maybe_unused]] constexpr int O_J = M::O_J, O_PE = M::O_PE, O_PS = M::O_PS, O_I = M::O_I, NST = M::NST, NDIFF = M::NDIFF, NTRIP = M::NTRIP, \
-                                       O_FILM = M::O_FILM, O_SOH = M::O_SOH, O_JS = M::O_JS
+                                       O_FILM = M::O_FILM, O_SOH = M::O_SOH, O_JS = M::O_JS, N_CECS = M::N_CECS, O_Q = M::O_Q
 constexpr double FAR = 96485.3321233;      // reference src/structures.jl:10
 constexpr double RGAS = 8.31446261815324;  // reference src/structures.jl:11
 constexpr double TREF = 298.15;
@@ -78,7 +86,7 @@ enum Key { K_D_n, K_D_p, K_D_s, K_D_sn, K_D_sp, K_Ea_D_sn, K_Ea_D_sp, K_Ea_k_n, 
            K_tplus, K_w, K_th_max_n, K_th_max_p, K_th_min_n, K_th_min_p, K_rho_n, K_sig_n, K_sig_p, K_eps_fn, K_eps_fp, K_eps_n, K_eps_p,
            K_eps_s,
            K_Cp_a, K_Cp_n, K_Cp_p, K_Cp_s, K_Cp_z, K_T_amb, K_h_cell, K_l_a, K_l_z, K_lam_a, K_lam_n, K_lam_p, K_lam_s, K_lam_z,
-           K_rho_a, K_rho_p, K_rho_s, K_rho_z, K_sig_a, K_sig_z, K_COUNT };
+           K_rho_a, K_rho_p, K_rho_s, K_rho_z, K_sig_a, K_sig_z, K_lam_MHC_n, K_lam_MHC_p, K_COUNT };
 
 // read-only model tables in device memory
 struct Tables {
@@ -103,6 +111,9 @@ struct CellConst {
   double rh[3], reps[3], rd_ps, rd_sn, beta_ps, beta_sn, rsg_p, rsg_n, rcm_p, rcm_n, Dh_ps, Dh_sn;   // reciprocals / interface weights used by every node pass
   double EaKp, EaKn, EaDp, EaDn;               // thermal: activation energies / R (kp, kn, kap_p, kap_n then hold the T_ref values)
   double r2h[3], qps_r, qps_l, qsn_r, qsn_l;   // thermal: gradient-stencil factors 1/(2h), 2/(3hp+hs), 2/(hp+3hs), 2/(3hs+hn), 2/(hs+3hn)
+  // quadratic / polynomial particle models: c_s* = c_avg + csj j (+ csq Q);  d c_avg/dt = csr j;  dQ/dt = -kappa Q + qj j   (index 0 = p, 1 = n)
+  double csj[2], csq[2], csr[2], qj[2];
+  double lam[2], mhc_k0[2], rce0;   // MHC: lambda per electrode, k_i / ((1 - erf((lambda - sqrt(1 + sqrt(lambda))) / (2 sqrt(lambda)))) / 2), 1 / c_e0
   int iso_ref;   // T0 == TREF exactly (temperature_switch, reference custom_functions.jl:1)
 };
 
@@ -160,8 +171,9 @@ template <class M> struct CellLDS {
   double colI[M::THERMAL ? 1 : NE][3];              // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
   typename M::fact_t Dinv[NE][M::NB * M::NB], LD[NE][M::NB * M::NB];   // Thomas factors: D'^-1 and L D'^-1(prev)
   typename M::fact_t LDmid[M::NB * M::NB];                             // closing block of the twisted factorisation
-  typename M::fact_t Ainv[2][M::THERMAL ? 1 : NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
-  double Mr[M::THERMAL ? 1 : NR * NR];               // radial operator (copy of Tables::M)
+  typename M::fact_t Ainv[2][(M::THERMAL || M::SD != 0) ? 1 : NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
+  double Mr[(M::THERMAL || M::SD != 0) ? 1 : NR * NR];               // radial operator (copy of Tables::M)
+  double resp[M::SD != 0 ? NJ : 1], rcjf[M::SD != 0 ? 2 : 1][2];    // quadratic / polynomial particles: d c_s* / d j after eliminating c_avg (and Q); 1/cj and 1/(-kappa - cj) of the factorisation
   double x2[M::THERMAL ? 1 : NE][3];
   double ctrlJ[2], bord;           // P-mode control row at the last Jacobian pass (I*I1C, V*I1C); border pivot d - v.x2
   double w9[NJ];
@@ -391,6 +403,7 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     c.a_p = 3 * esp / Rp_p; c.a_n = 3 * esn / Rp_n;         // build_a!, aux...jl:124-139
     c.sig_p = th[ix[K_sig_p]] * esp; c.sig_n = th[ix[K_sig_n]] * esn;
     const double T0 = th[ix[K_T0]];
+    c.ce0 = th[ix[K_c_e0]];
     c.T0 = T0; c.iso_ref = (T0 == TREF);
     double arr_kp = 1.0, arr_kn = 1.0, arr_dp = 1.0, arr_dn = 1.0;   // temperature_switch, custom_functions.jl:1,16-31,44-57
     if (!c.iso_ref && !M::THERMAL) {   // with temperature = true the Arrhenius factors are evaluated per node from T(x)
@@ -412,7 +425,6 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     c.I1C = (FAR / 3600.0) * (qa < qb ? qa : qb);           // calc_I1C, aux...jl:632-647
     c.JI0 = c.I1C * c.h[0] / c.sig_p;                       // d(Phi_s row of first p node)/dI
     c.JI29 = -c.I1C * c.h[2] / c.sig_n;                     // d(Phi_s row of last n node)/dI
-    c.ce0 = th[ix[K_c_e0]];
     for (int q = 0; q < 3; q++) { c.rh[q] = 1.0 / c.h[q]; c.reps[q] = 1.0 / c.eps[q]; }
     c.rd_ps = 1.0 / (c.h[0] / 2 + c.h[1] / 2); c.rd_sn = 1.0 / (c.h[1] / 2 + c.h[2] / 2);
     c.beta_ps = (c.h[0] / 2) / (c.h[1] / 2 + c.h[0] / 2); c.beta_sn = (c.h[1] / 2) / (c.h[2] / 2 + c.h[1] / 2);
@@ -421,6 +433,19 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     S.tb = tb;
     c.R_SEI = c.rkag = c.Mrho = c.i0F = c.wexp = c.Uref = 0.0;
     c.EaKp = c.EaKn = c.EaDp = c.EaDn = 0.0;
+    {   // quadratic / polynomial particle models (aux...jl:212-248, residuals.jl:108-127, 237-258); D_s_eff = D_s * Arrhenius factor
+      const double Dsp = th[ix[K_D_sp]] * arr_dp, Dsn = th[ix[K_D_sn]] * arr_dn;
+      const double den = M::SD == 2 ? 35.0 : 5.0;
+      c.csj[0] = -Rp_p / (Dsp * den); c.csj[1] = -Rp_n / (Dsn * den);
+      c.csq[0] = M::SD == 2 ? (Rp_p / (Dsp * 35.0)) * (8.0 * Dsp) : 0.0; c.csq[1] = M::SD == 2 ? (Rp_n / (Dsn * 35.0)) * (8.0 * Dsn) : 0.0;
+      c.csr[0] = -3.0 / Rp_p; c.csr[1] = -3.0 / Rp_n;
+      c.qj[0] = -(45.0 / 2.0) / (Rp_p * Rp_p); c.qj[1] = -(45.0 / 2.0) / (Rp_n * Rp_n);
+    }
+    c.lam[0] = c.lam[1] = 1.0; c.mhc_k0[0] = c.mhc_k0[1] = 0.0; c.rce0 = 1.0 / c.ce0;
+    if constexpr (M::RXN == 1) {
+      c.lam[0] = th[ix[K_lam_MHC_p]]; c.lam[1] = th[ix[K_lam_MHC_n]];
+      for (int q = 0; q < 2; q++) { const double l = c.lam[q], a1 = 1.0 + sqrt(l); c.mhc_k0[q] = (q == 0 ? c.kp : c.kn) / ((1.0 - erf((l - sqrt(a1)) / (2.0 * sqrt(l)))) / 2.0); }
+    }
     if constexpr (M::THERMAL) {
       c.iso_ref = 0;                                        // the temperature_switch always takes the exp branch (custom_functions.jl:1)
       c.EaKp = th[ix[K_Ea_k_p]] / RGAS; c.EaKn = th[ix[K_Ea_k_n]] / RGAS; c.EaDp = th[ix[K_Ea_D_sp]] / RGAS; c.EaDn = th[ix[K_Ea_D_sn]] / RGAS;
@@ -448,7 +473,7 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
       S.sei.cjf = 0.0;
     }
   }
-  if constexpr (!M::THERMAL) { for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->M[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
+  if constexpr (!M::THERMAL && M::SD == 0) { for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->M[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
   for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
   PL_SYNC();
   if constexpr (M::THERMAL) thermal_setup(S, tb, th);
@@ -468,7 +493,7 @@ PL_DEV void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) {
   _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (n < NST) {
     double v = 0.0;
     if (n < O_CS) v = c.ce0;
-    else if (n < O_CS + NP * NR) v = csp;
+    else if (n < O_CS + (M::SD == 0 ? NP * NR : NP)) v = csp;
     else if (n < N_CECS) v = csn;
     else if (M::THERMAL && n < M::O_T + NT) v = c.T0;
     else if (n >= O_PS && n < O_PS + NP) v = Up;
@@ -494,7 +519,15 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   const int jx = sc == 0 ? i : i - NS;                 // index into j / Phi_s / particles
   // ---- every LDS operand of this pass is loaded here, up front (one latency instead of one stall per use) ----
   const double ce = Y[O_CE + i], pe = Y[O_PE + i];
-  const double jv_l = Y[O_J + jx], ps_l = Y[O_PS + jx], cs_l = Y[O_CS + jx * NR + NR - 1], yI = Y[O_I];
+  const int el = sc == 2 ? 1 : 0;                      // electrode index of the per-electrode constants
+  const double jv_l = Y[O_J + jx], ps_l = Y[O_PS + jx], yI = Y[O_I];
+  // surface concentration: the last radial node (Fickian FDM) or c_avg + csj j (+ csq Q) (quadratic / polynomial, build_c_s_star!, aux...jl:193-248)
+  double cs_l, cavg_l = 0.0, q_l = 0.0;
+  if constexpr (M::SD == 0) cs_l = Y[O_CS + jx * NR + NR - 1];
+  else {
+    cavg_l = Y[O_CS + jx]; if (M::SD == 2) q_l = Y[O_Q + jx];
+    cs_l = cavg_l + c.csj[el] * jv_l + c.csq[el] * q_l;
+  }
   const double ypce = WANT_RES ? YP[O_CE + i] : 0.0;
   // SEI (anode nodes): side-reaction flux j_s, film thickness, film resistance R_film = R_SEI + film/k_n_aging (aux...jl:272-300)
   const int ks = (M::SEI && sc == 2) ? i - (NP + NS) : 0;
@@ -515,6 +548,12 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   const double rh = c.rh[sc], reps = c.reps[sc];
   double K, dK; keff(ce, cT0, K, dK);
   K *= bfc; dK *= bfc;
+  double nu = 1.0, dnu = 0.0;                          // thermodynamic factor of this control volume (custom_functions.jl:177-203)
+  if constexpr (M::TF == 1) {
+    const double x = ce * 1e-3, sx = sqrt(x), tfac = 0.982 * (1.0 - 0.0052 * (cT0 - 293.0));
+    nu = 0.601 - 0.24 * sx + tfac * x * sx;
+    dnu = (-0.12 / sx + 1.5 * tfac * sx) * 1e-3;
+  }
   double D, dD;
   if (M::CHEM == PLH_CHEM_LCO_LIC6) { D = sc == 0 ? dc0 : (sc == 1 ? dc1 : dc2); dD = 0.0; }
   else { deff_nmc(ce, cT0, D, dD); D *= bfc; dD *= bfc; }
@@ -535,10 +574,14 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   const double dc = (ce_n - ce) * rdist;
   const double w = Kh * rdist;
   const double g = Kh * Tb * dc * rcb;
-  double E = edge ? w * (pe - pe_n) + cKfac * g : 0.0;   // Phi_e-row edge flux
+  // Phi_e-row edge flux.  With nu = 1 the concentration part is a flux too (E = w dPhi + Kfac g); with nu(c_e) the reference weights BOTH edges of row i
+  // with the row's own nu_i (K[i] (g_i - g_{i-1}), residuals.jl:626-645), so g is differenced separately
+  const double gE = edge ? g : 0.0;
+  double E = edge ? (M::TF == 1 ? w * (pe - pe_n) : w * (pe - pe_n) + cKfac * g) : 0.0;
   double Nf = edge ? Dh * dc : 0.0;                        // c_e-row edge flux
   const double E_p = shift_up1(E), Nf_p = shift_up1(Nf);
-  const double Em = i > 0 ? E_p : 0.0, Nm = i > 0 ? Nf_p : 0.0;
+  const double g_p = M::TF == 1 ? shift_up1(gE) : 0.0;
+  const double Em = i > 0 ? E_p : 0.0, Nm = i > 0 ? Nf_p : 0.0, gm = i > 0 ? g_p : 0.0;
   // electrode quantities
   const double a = sc == 0 ? ca_p : ca_n;
   const double jv = elec ? jv_l : 0.0;
@@ -561,16 +604,43 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   const double arg = ce * cs * (cmax - cs);
   const double sq = sqrt(arg > 0.0 ? arg : 0.0);
   const double xx = cfRT * eta;
-  double sh, chh; sinh_cosh(xx, sh, chh);
+  double sh = 0.0, chh = 0.0;
+  // reaction rate j_calc and its partials with respect to (c_e, c_s*, eta): Butler-Volmer (rxn_BV) or Marcus-Hush-Chidsey (rxn_MHC, custom_functions.jl:241-298)
+  double jc = 0.0, jc_ce = 0.0, jc_cs = 0.0, jc_eta = 0.0;
+  if constexpr (M::RXN == 0) sinh_cosh(xx, sh, chh);
+  else {
+    const double lam = c.lam[el], sl = sqrt(lam), a1 = 1.0 + sl, k0 = c.mhc_k0[el], ce0 = c.ce0, rce0 = c.rce0;
+    const double th_i = cs * rcm, ratio = ce * rce0 / th_i;                      // c_e_hat / theta_i
+    const bool lin = ratio > 1e-4;                                               // log_ReLU(.; minval = 1e-4)
+    const double ef = 2.0 * cfRT * eta + log(lin ? ratio : 1e-4);               // eta_f = F eta/(R T) + log(...)
+    const double sr = sqrt(a1 + ef * ef), zz = (lam - sr) / (2.0 * sl);
+    const double co = k0 * (1.0 - erf(zz));                                      // coeff_rd_ox
+    const double dco = k0 * 1.1283791670955126 * exp(-zz * zz) * ef / (2.0 * sl * sr);   // d coeff / d eta_f  (2/sqrt(pi) e^{-z^2} * (eta_f / sr) / (2 sqrt(lambda)))
+    const double em = exp(-ef), fo = 1.0 / (1.0 + em), fr = 1.0 - fo;            // 1/(1 + e^{-eta_f}), 1/(1 + e^{+eta_f})
+    const double brk = fo * ce0 * cs - fr * ce * cmax;
+    const double sarg = (1.0 - th_i) * rce0, sq2 = sqrt(sarg > 0.0 ? sarg : 0.0);   // sqrt_ReLU((1 - c_s*/c_max)/c_e0)
+    const double dfo = fo * fr;                                                    // d fo / d eta_f = - d fr / d eta_f
+    jc = co * brk * sq2;
+    const double djc_ef = (dco * brk + co * dfo * (ce0 * cs + ce * cmax)) * sq2;
+    const double def_ce = lin ? 1.0 / ce : 0.0, def_cs = lin ? -1.0 / cs : 0.0;
+    jc_eta = djc_ef * 2.0 * cfRT;
+    jc_ce = djc_ef * def_ce + co * (-fr * cmax) * sq2;
+    jc_cs = djc_ef * def_cs + co * (fo * ce0) * sq2 + (sq2 > 0.0 ? co * brk * (-rcm * rce0) / (2.0 * sq2) : 0.0);
+  }
   const double ps_p = shift_up1(ps), ps_n = shift_down1(ps);
   const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
   if (WANT_RES) {
     if (act) {
-      const double src = elec ? (1 - ctplus) * 1.0 * a * jt : 0.0;
+      const double src = elec ? (1 - ctplus) * nu * a * jt : 0.0;
       Fo[O_CE + i] = ((Nf - Nm) * rh + src) * reps - ypce;                 // residuals_c_e!, residuals.jl:6-106
-      Fo[O_PE + i] = (i < NE - 1) ? (E - Em - (elec ? h * FAR * a * jt : 0.0)) : pe;   // residuals_Φ_e!, residuals.jl:554-654
+      const double dE = M::TF == 1 ? (E - Em) + cKfac * nu * (gE - gm) : E - Em;
+      Fo[O_PE + i] = (i < NE - 1) ? (dE - (elec ? h * FAR * a * jt : 0.0)) : pe;      // residuals_Φ_e!, residuals.jl:554-654
       if (elec) {
-        Fo[O_J + jx] = 2.0 * kk * sq * sh - jv;                                        // residuals_j!, residuals.jl:491-517
+        Fo[O_J + jx] = (M::RXN == 0 ? 2.0 * kk * sq * sh : jc) - jv;                    // residuals_j!, residuals.jl:491-517
+        if constexpr (M::SD != 0) {                                                    // residuals_c_s_avg! (quadratic / polynomial), residuals_Q!
+          Fo[O_CS + jx] = c.csr[el] * jv - YP[O_CS + jx];
+          if (M::SD == 2) Fo[O_Q + jx] = -(el == 0 ? c.kap_p : c.kap_n) * q_l + c.qj[el] * jv - YP[O_Q + jx];
+        }
         double lap = first ? (-ps + ps_n) : (last ? (ps_p - ps) : (ps_p - 2 * ps + ps_n));
         double f = h * h * a * FAR * jt;
         const double Idens = yI * cI1C;
@@ -605,8 +675,10 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
     const double Tq = Tb * rdist;
     const double dg_a = Tq * (dKh_a * (ce_n - ce) * rcb - Kh * rcb - Kh * (ce_n - ce) * dcb_a * (rcb * rcb));
     const double dg_b = Tq * (dKh_b * (ce_n - ce) * rcb + Kh * rcb - Kh * (ce_n - ce) * dcb_b * (rcb * rcb));
-    double Ea = edge ? (pe - pe_n) * dKh_a * rdist + cKfac * dg_a : 0.0;
-    double Eb = edge ? (pe - pe_n) * dKh_b * rdist + cKfac * dg_b : 0.0;
+    double Ea = edge ? (pe - pe_n) * dKh_a * rdist + (M::TF == 1 ? 0.0 : cKfac * dg_a) : 0.0;
+    double Eb = edge ? (pe - pe_n) * dKh_b * rdist + (M::TF == 1 ? 0.0 : cKfac * dg_b) : 0.0;
+    const double Ga = (M::TF == 1 && edge) ? dg_a : 0.0, Gb = (M::TF == 1 && edge) ? dg_b : 0.0;     // d g / d c_e (left, right) of this edge
+    const double Ga_p = M::TF == 1 ? shift_up1(Ga) : 0.0, Gb_p = M::TF == 1 ? shift_up1(Gb) : 0.0;
     double we = edge ? w : 0.0;
     // N = Dh (c_{i+1} - c_i)/dist ; Dh = harmonic mean of D_i, D_{i+1} (dD/dc = 0 for D_eff_linear)
     const double dDh_a = dD * beta * D_n * D_n * (rdenD * rdenD), dDh_b = dD_n * (1 - beta) * D * D * (rdenD * rdenD);
@@ -615,12 +687,16 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
     if (act) {
       const double rhe = rh * reps;
       S.ceL[i] = i > 0 ? -Na_p * rhe : 0.0;
-      S.ceD[i] = (Na - (i > 0 ? Nb_p : 0.0)) * rhe;
+      S.ceD[i] = (Na - (i > 0 ? Nb_p : 0.0)) * rhe + ((M::TF == 1 && elec) ? (1 - ctplus) * dnu * a * jt * reps : 0.0);
       S.ceU[i] = Nb * rhe;
-      S.ceJ[i] = elec ? (1 - ctplus) * a * reps : 0.0;
+      S.ceJ[i] = elec ? (1 - ctplus) * nu * a * reps : 0.0;
       if (i < NE - 1) {
         S.peL[i] = i > 0 ? -we_p : 0.0; S.peD[i] = (i > 0 ? we_p : 0.0) + we; S.peU[i] = -we;
         S.pcL[i] = i > 0 ? -Ea_p : 0.0; S.pcD[i] = Ea - (i > 0 ? Eb_p : 0.0); S.pcU[i] = Eb;
+        if constexpr (M::TF == 1) {                        // + Kfac nu_i (g_i - g_{i-1}) with nu_i = nu(c_e,i)
+          const double kn = cKfac * nu;
+          S.pcL[i] += i > 0 ? -kn * Ga_p : 0.0; S.pcD[i] += kn * (Ga - (i > 0 ? Gb_p : 0.0)) + cKfac * dnu * (gE - gm); S.pcU[i] += kn * Gb;
+        }
         S.peJ[i] = elec ? -h * FAR * a : 0.0;
       } else {
         S.peL[i] = 0; S.peD[i] = 1.0; S.peU[i] = 0; S.pcL[i] = 0; S.pcD[i] = 0; S.pcU[i] = 0; S.peJ[i] = 0;
@@ -629,9 +705,15 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
         const double ch = chh;
         const double pos = arg > 0.0 ? 1.0 : 0.0;
         const double inv_sq = pos > 0 ? 1.0 / sq : 0.0;
-        S.gce[jx] = kk * sh * cs * (cmax - cs) * inv_sq;
-        S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * ch * cfRT * (-dU * rcm));
-        S.gps[jx] = 2.0 * kk * sq * ch * cfRT;
+        if constexpr (M::RXN == 0) {
+          S.gce[jx] = kk * sh * cs * (cmax - cs) * inv_sq;
+          S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * ch * cfRT * (-dU * rcm));
+          S.gps[jx] = 2.0 * kk * sq * ch * cfRT;
+        } else {                                           // eta = Phi_s - Phi_e - U(c_s*/c_max)
+          S.gce[jx] = jc_ce;
+          S.gcs[jx] = jc_cs + jc_eta * (-dU * rcm);
+          S.gps[jx] = jc_eta;
+        }
         S.gpe[jx] = -S.gps[jx];
         S.psJ[jx] = -h * h * a * FAR * rsg;
         if constexpr (M::SEI) {
@@ -703,7 +785,7 @@ PL_DEV void cell_node_pass(CellLDS<M>& S, const double* Y, const double* YP, dou
 template <bool WANT_JAC = false, class M>
 PL_DEV void cell_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
   if constexpr (M::THERMAL) thermal_cs_rows<WANT_JAC>(S, S.tb, Y, YP, Fo);
-  else iso_cs_rows(S, R, Y, YP, Fo);
+  else if constexpr (M::SD == 0) iso_cs_rows(S, R, Y, YP, Fo);        // (quadratic / polynomial: the particle rows are node-local, written by the node pass)
 }
 // full residual F(Y, YP) -> Fo (all three are LDS vectors)
 template <class M>
@@ -829,6 +911,9 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
   const int lane = lane_id();
   const CellConst& c = S.cc;
   // 1. particle resolvent rows: (kappa M - cj I)^-1 = V diag(1/(kappa lam - cj)) W
+  if constexpr (M::SD != 0) {
+    if (lane < 2) { S.rcjf[lane][0] = alg_only ? 0.0 : -1.0 / cj; S.rcjf[lane][1] = alg_only ? 0.0 : 1.0 / (-(lane == 0 ? c.kap_p : c.kap_n) - cj); }   // -1/cj, 1/(-kappa - cj)
+  } else
   if (!alg_only) {
     const int r = lane % NR;
     // the 20 reciprocals 1/(kappa lam_m - cj) are formed by 20 lanes in parallel and passed through S.w9 (free outside the solves)
@@ -856,7 +941,13 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     if (sc != 1) {
       const int jx = sc == 0 ? i : i - NS;
       const double bj = sc == 0 ? c.bj_p : c.bj_n;
-      const double schur = alg_only ? 0.0 : S.gcs[jx] * S.sig[sc == 0 ? 0 : 1] * bj;
+      double schur;
+      if constexpr (M::SD == 0) schur = alg_only ? 0.0 : S.gcs[jx] * S.sig[sc == 0 ? 0 : 1] * bj;
+      else {   // d c_s*/d j with c_avg (and Q) eliminated:  -cj dc + csr dj = b_c ,  (-kappa - cj) dQ + qj dj = b_Q ,  c_s* = c + csj j + csq Q
+        const int el = sc == 0 ? 0 : 1;
+        const double resp = alg_only ? c.csj[el] : c.csj[el] + c.csr[el] * (1.0 / cj) - c.csq[el] * c.qj[el] * (1.0 / (-(el == 0 ? c.kap_p : c.kap_n) - cj));
+        S.resp[jx] = resp; schur = -S.gcs[jx] * resp;
+      }
       if (i == 0) cI2 = c.JI0;
       if (i == NE - 1) cI2 = c.JI29;
       bool local3 = false;
@@ -965,6 +1056,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   const CellConst& c = S.cc;
   const int r = lane % NR, g = lane / NR;
   // a. particle partial solutions  w = A^-1 b_cs : four independent accumulation chains (pass = particles pass*6 .. pass*6+5)
+  if constexpr (M::SD == 0)
   if (!alg_only) {
     const int gg = lane < 60 ? g : 5;
     int pp[4]; double w[4];
@@ -995,6 +1087,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   PL_SYNC();
   // b. fold c_s and j elimination into the node right-hand sides
   double bjp = 0.0, bjs = 0.0, bfl = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0;
+  [[maybe_unused]] double bca = 0.0, bq = 0.0;       // right-hand sides of the c_avg / Q rows of this node (quadratic / polynomial particles)
   int jx = 0; bool elec = false, sei_node = false;
   const int nd = tw_node(lane);                 // node of this lane in the twisted layout of thomas_sweeps (-1: idle)
   if (nd >= 0) {
@@ -1003,7 +1096,12 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
     sei_node = M::SEI && sc == 2;
     double r0 = alg_only ? 0.0 : b[O_CE + i], r1 = b[O_PE + i], r2 = 0.0;
     if (elec) {
-      bjp = b[O_J + jx] - (alg_only ? 0.0 : S.gcs[jx] * S.w9[jx]);
+      if constexpr (M::SD == 0) bjp = b[O_J + jx] - (alg_only ? 0.0 : S.gcs[jx] * S.w9[jx]);
+      else {   // particular part of c_s*: dc = b_c (-1/cj), dQ = b_Q / (-kappa - cj)
+        const int el = sc == 0 ? 0 : 1;
+        bca = alg_only ? 0.0 : b[O_CS + jx]; bq = (alg_only || M::SD != 2) ? 0.0 : b[O_Q + jx];
+        bjp = b[O_J + jx] - S.gcs[jx] * (bca * S.rcjf[el][0] + c.csq[el] * bq * S.rcjf[el][1]);
+      }
       r2 = b[O_PS + jx];
       double beta;                          // omega . b_u : what the eliminated local unknowns feed back into the node rows
       bool local3 = false;
@@ -1064,6 +1162,14 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
         }
       }
       if (!local3) b[O_J + jx] = v0 * S.dj[jx];
+      if constexpr (M::SD != 0) {
+        if (!alg_only) {
+          const int el = sec_of(i) == 0 ? 0 : 1;
+          const double dj = v0 * S.dj[jx];
+          b[O_CS + jx] = (bca - c.csr[el] * dj) * S.rcjf[el][0];                       // dc = (csr dj - b_c)/cj
+          if (M::SD == 2) b[O_Q + jx] = (bq - c.qj[el] * dj) * S.rcjf[el][1];        // dQ = (b_Q - qj dj)/(-kappa - cj)
+        }
+      }
     }
   }
   if constexpr (M::SEI) {                   // SOH row: sum_k sohw_k dj_s,k - cj dSOH = b_SOH (decoupled from everything else)
@@ -1073,6 +1179,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   if (lane == 0) b[O_I] = xI;
   PL_SYNC();
   // f. particles:  dc = w - (A^-1 e_last) * bj * dj
+  if constexpr (M::SD == 0)
   if (!alg_only) {
     for (int pass = 0; pass < 4; pass++) {
       const int p = pass * 6 + g;
@@ -1092,7 +1199,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
 enum JT { JT_CE_L = 1, JT_CE_D, JT_CE_U, JT_CE_J, JT_CS_CS, JT_CS_J, JT_J_CE, JT_J_CS, JT_J_J, JT_J_PE, JT_J_PS,
           JT_PE_CL, JT_PE_CD, JT_PE_CU, JT_PE_L, JT_PE_D, JT_PE_U, JT_PE_J, JT_PS_L, JT_PS_D, JT_PS_U, JT_PS_J, JT_PS_I,
           JT_CTRL_P1, JT_CTRL_M1,
-          JT_CTRL_PA, JT_CTRL_PB, JT_CTRL_PI, JT_CE_JS, JT_PE_JS, JT_PS_JS, JT_J_F, JT_F_JS, JT_F_F, JT_SOH_JS, JT_SOH_SOH, JT_JS_PS, JT_JS_PE, JT_JS_J, JT_JS_JS, JT_JS_F, JT_JS_I };
+          JT_CTRL_PA, JT_CTRL_PB, JT_CTRL_PI, JT_CSA_D, JT_Q_Q, JT_Q_J, JT_J_Q, JT_CE_JS, JT_PE_JS, JT_PS_JS, JT_J_F, JT_F_JS, JT_F_F, JT_SOH_JS, JT_SOH_SOH, JT_JS_PS, JT_JS_PE, JT_JS_J, JT_JS_JS, JT_JS_F, JT_JS_I };
 template <class M>
 PL_DEV double iso_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsigned w, double cj) {
   PL_MODEL(M);
@@ -1104,10 +1211,16 @@ PL_DEV double iso_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, 
     case JT_CE_U: return S.ceU[a];
     case JT_CE_J: return S.ceJ[a];
     case JT_CS_CS: return (a < NP ? c.kap_p : c.kap_n) * tb->M[bb * NR + cc] - (bb == cc ? cj : 0.0);
-    case JT_CS_J: return a < NP ? c.bj_p : c.bj_n;
+    case JT_CS_J: if constexpr (M::SD != 0) return c.csr[a < NP ? 0 : 1]; else return a < NP ? c.bj_p : c.bj_n;
+    case JT_CSA_D: return -cj;
+    case JT_Q_Q: return -(a < NP ? c.kap_p : c.kap_n) - cj;
+    case JT_Q_J: return c.qj[a < NP ? 0 : 1];
+    case JT_J_Q: return S.gcs[a] * c.csq[a < NP ? 0 : 1];
     case JT_J_CE: return S.gce[a];
     case JT_J_CS: return S.gcs[a];
-    case JT_J_J: if constexpr (M::SEI) { if (a >= NP) return S.sei.jjJ[a - NP]; } return -1.0;
+    case JT_J_J: if constexpr (M::SEI) { if (a >= NP) return S.sei.jjJ[a - NP]; }
+                 if constexpr (M::SD != 0) return -1.0 + S.gcs[a] * c.csj[a < NP ? 0 : 1];
+                 return -1.0;
     case JT_J_PE: return S.gpe[a];
     case JT_J_PS: return S.gps[a];
     case JT_PE_CL: return S.pcL[a];

@@ -511,7 +511,7 @@ PL_DEV void check_stop(const CellLDS<M>& S, const plh_run& run, const plh_opts& 
     }
   }
   if (b.c_s_n_max == b.c_s_n_max) {                                                     // check_stop_c_s_surf, checks.jl:141-161
-    double cm = -1e300; for (int i = 0; i < NN; i++) { const double v = Y[O_CS + NP * NR + (i + 1) * NR - 1]; cm = v > cm ? v : cm; }
+    double cm = -1e300; for (int i = 0; i < NN; i++) { const double v = M::SD == 0 ? Y[O_CS + NP * NR + (i + 1) * NR - 1] : Y[O_CS + NP + i]; cm = v > cm ? v : cm; }     // (c_s_n_maximum, checks.jl:125-139)
     const double lim = b.c_s_n_max * S.cc.cmaxn;
     if (Ic > 0 && cm - lim > eps) { const double f = (pv.c_s_n - lim) / (pv.c_s_n - cm); if (f < pv.frac) { pv.frac = f; flag = 6; } }
     pv.c_s_n = cm;

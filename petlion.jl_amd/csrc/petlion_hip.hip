@@ -35,7 +35,7 @@ static const char* const KEY_ENUM_NAMES[K_COUNT] = {
     "brugg_n", "brugg_p", "brugg_s", "c_e₀", "c_max_n", "c_max_p", "i_0_jside", "k_n", "k_n_aging", "k_p", "l_n", "l_p", "l_s",
     "t₊", "w", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "ρ_n", "σ_n", "σ_p", "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s",
     "Cp_a", "Cp_n", "Cp_p", "Cp_s", "Cp_z", "T_amb", "h_cell", "l_a", "l_z", "λ_a", "λ_n", "λ_p", "λ_s", "λ_z",
-    "ρ_a", "ρ_p", "ρ_s", "ρ_z", "σ_a", "σ_z"};
+    "ρ_a", "ρ_p", "ρ_s", "ρ_z", "σ_a", "σ_z", "λ_MHC_n", "λ_MHC_p"};
 // per variant: the sorted theta_keys the reference's generated functions would receive (generate_functions.jl:327-363, 387) and
 // the chemistry defaults (reference src/params.jl:5-117, 176-226 LCO/LiC6; 295-367, 436-452 NMC/LiC6_NMC)
 static const char* const KEYS_LCO_ISO[] = {
@@ -80,16 +80,26 @@ static const double DEFAULTS_LCO_THERMAL[] = {
     25 + 273.15, 25 + 273.15, 4.0, 4.0, 4.0, 1000.0, 30555.0, 51554.0, 1.0, 5.0310e-11, 2.334e-11, 10e-6, 88e-6, 80e-6, 25e-6, 10e-6,
     0.364, 0.85510, 0.49550, 0.01429, 0.99174, 237.0, 1.7, 2.1, 0.16, 401.0, 2700.0, 2500.0, 2500.0, 1100.0, 8940.0,
     3.55e7, 100.0, 100.0, 5.96e7, 0.0326, 0.025, 0.485, 0.385, 0.724};
+// rxn = MHC adds the reorganisation energies λ_MHC_p, λ_MHC_n (reference src/params.jl:16,67)
+static const char* const KEYS_LCO_MHC[] = {
+    "D_n", "D_p", "D_s", "D_sn", "D_sp", "Ea_D_sn", "Ea_D_sp", "Ea_k_n", "Ea_k_p", "Rp_n", "Rp_p", "T₀", "brugg_n", "brugg_p", "brugg_s",
+    "c_e₀", "c_max_n", "c_max_p", "k_n", "k_p", "l_n", "l_p", "l_s", "t₊", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "λ_MHC_n", "λ_MHC_p", "σ_n", "σ_p",
+    "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s"};
+static const double DEFAULTS_LCO_MHC[] = {
+    7.5e-10, 7.5e-10, 7.5e-10, 3.9e-14, 1e-14, 5000.0, 5000.0, 5000.0, 5000.0, 2e-6, 2e-6, 25 + 273.15, 4.0, 4.0, 4.0,
+    1000.0, 30555.0, 51554.0, 5.0310e-11, 2.334e-11, 88e-6, 80e-6, 25e-6, 0.364, 0.85510, 0.49550, 0.01429, 0.99174, 6.26e-20, 6.26e-20, 100.0, 100.0,
+    0.0326, 0.025, 0.485, 0.385, 0.724};
 struct VariantInfo { int nkeys; const char* const* keys; const double* defaults; };
 // parameter set of a variant: by (chemistry, SEI, temperature); the mixed-precision variants share their fp64 sibling's
-static VariantInfo variant_keys(int chem, int sei, int thermal) {
+static VariantInfo variant_keys(int chem, int sei, int thermal, int rxn) {
+  if (rxn == PLH_RXN_MHC) return {37, KEYS_LCO_MHC, DEFAULTS_LCO_MHC};
   if (thermal) return {56, KEYS_LCO_THERMAL, DEFAULTS_LCO_THERMAL};
   if (chem == PLH_CHEM_LCO_LIC6) return sei ? VariantInfo{42, KEYS_LCO_SEI, DEFAULTS_LCO_SEI} : VariantInfo{35, KEYS_LCO_ISO, DEFAULTS_LCO_ISO};
   return sei ? VariantInfo{39, KEYS_NMC_SEI, DEFAULTS_NMC_SEI} : VariantInfo{32, KEYS_NMC_ISO, DEFAULTS_NMC_ISO};
 }
 static const VariantOps* variant_ops(int id) {
   switch (id) {
-#define PL_OPS_CASE(ID, CHEM, SEI, TH, MIX) case ID: return plh_variant_ops_##ID ? plh_variant_ops_##ID() : nullptr;
+#define PL_OPS_CASE(ID, CHEM, SEI, TH, MIX, SD, TF, RXN) case ID: return plh_variant_ops_##ID ? plh_variant_ops_##ID() : nullptr;
     PL_VARIANT_LIST(PL_OPS_CASE)
 #undef PL_OPS_CASE
   }
@@ -277,15 +287,19 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   if (d->real_bytes != 8) return fail(PLH_E_UNSUPPORTED, "states, residuals and time are fp64 (real_bytes = 8); reduced precision is selected with precision = PLH_PREC_MIXED");
   if (d->precision != PLH_PREC_F64 && d->precision != PLH_PREC_MIXED) return fail(PLH_E_ARG, "precision must be PLH_PREC_F64 or PLH_PREC_MIXED");
   if (d->chemistry != PLH_CHEM_LCO_LIC6 && d->chemistry != PLH_CHEM_NMC_LIC6) return fail(PLH_E_UNSUPPORTED, "unknown chemistry");
+  if (d->solid_diffusion < 0 || d->solid_diffusion > PLH_SD_POLYNOMIAL || d->thermodynamic_factor < 0 || d->thermodynamic_factor > 1 || d->rxn < 0 || d->rxn > 1)
+    return fail(PLH_E_ARG, "solid_diffusion / thermodynamic_factor / rxn out of range");
   const VariantOps* ops = nullptr;
   for (int v = 0; v < PL_N_VARIANTS; v++) {
     const VariantOps* o = variant_ops(v);
-    if (o && o->chem == d->chemistry && o->sei == (d->aging_SEI ? 1 : 0) && o->thermal == (d->temperature ? 1 : 0) && o->mixed == (d->precision == PLH_PREC_MIXED ? 1 : 0)) ops = o;
+    if (o && o->chem == d->chemistry && o->sei == (d->aging_SEI ? 1 : 0) && o->thermal == (d->temperature ? 1 : 0) && o->mixed == (d->precision == PLH_PREC_MIXED ? 1 : 0) &&
+        o->sd == d->solid_diffusion && o->tf == d->thermodynamic_factor && o->rxn == d->rxn) ops = o;
   }
-  if (!ops) return fail(PLH_E_UNSUPPORTED, "this chemistry / temperature / aging / precision combination is not instantiated on the device (built in fp64: LCO and NMC "
-                                           "isothermal with or without SEI aging, LCO with temperature; mixed precision: LCO isothermal, NMC + SEI, LCO with temperature)");
+  if (!ops) return fail(PLH_E_UNSUPPORTED, "this chemistry / temperature / aging / precision / model-option combination is not instantiated on the device (built in fp64: LCO and NMC "
+                                           "isothermal with or without SEI aging, LCO with temperature; LCO isothermal with ONE of: quadratic or polynomial solid diffusion, the nonlinear "
+                                           "thermodynamic factor, MHC kinetics; mixed precision: LCO isothermal, NMC + SEI, LCO with temperature)");
   if (d->temperature && (d->N_a != NA || d->N_z != NZ)) return fail(PLH_E_UNSUPPORTED, "discretisation: only N_a = N_z = 10 is instantiated");
-  if (d->N_p != NP || d->N_s != NS || d->N_n != NN || d->N_r_p != NR || d->N_r_n != NR)
+  if (d->N_p != NP || d->N_s != NS || d->N_n != NN || (d->solid_diffusion == PLH_SD_FICKIAN && (d->N_r_p != NR || d->N_r_n != NR)))
     return fail(PLH_E_UNSUPPORTED, "discretisation: only N_p = N_s = N_n = N_r_p = N_r_n = 10 is instantiated");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(PLH_E_HIP, "no HIP device visible: the product path has no CPU fallback");
@@ -304,7 +318,7 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   memcpy(tb.M, PL_RADIAL_M, sizeof(tb.M)); memcpy(tb.LAM, PL_RADIAL_LAM, sizeof(tb.LAM));
   memcpy(tb.V, PL_RADIAL_V, sizeof(tb.V)); memcpy(tb.W, PL_RADIAL_W, sizeof(tb.W));
   tb.BJ = PL_RADIAL_BJ_FACTOR; tb.chem = d->chemistry;
-  const VariantInfo vi = variant_keys(ops->chem, ops->sei, ops->thermal);
+  const VariantInfo vi = variant_keys(ops->chem, ops->sei, ops->thermal, ops->rxn);
   m->P = vi.nkeys; m->key_names = vi.keys; m->key_defaults = vi.defaults;
   tb.P = m->P;
   for (int k = 0; k < K_COUNT; k++) {
@@ -374,9 +388,10 @@ int plh_abi_layout(int* out, int cap) {
   std::vector<int> v;
 #define PL_S(T, NF) v.push_back((int)sizeof(T)); v.push_back(NF);
 #define PL_F(T, f) v.push_back((int)offsetof(T, f));
-  PL_S(plh_model_desc, 13) PL_F(plh_model_desc, chemistry) PL_F(plh_model_desc, N_p) PL_F(plh_model_desc, N_s) PL_F(plh_model_desc, N_n) PL_F(plh_model_desc, N_a)
+  PL_S(plh_model_desc, 16) PL_F(plh_model_desc, chemistry) PL_F(plh_model_desc, N_p) PL_F(plh_model_desc, N_s) PL_F(plh_model_desc, N_n) PL_F(plh_model_desc, N_a)
   PL_F(plh_model_desc, N_z) PL_F(plh_model_desc, N_r_p) PL_F(plh_model_desc, N_r_n) PL_F(plh_model_desc, temperature) PL_F(plh_model_desc, aging_SEI)
-  PL_F(plh_model_desc, real_bytes) PL_F(plh_model_desc, precision) PL_F(plh_model_desc, device)
+  PL_F(plh_model_desc, real_bytes) PL_F(plh_model_desc, precision) PL_F(plh_model_desc, device) PL_F(plh_model_desc, solid_diffusion)
+  PL_F(plh_model_desc, thermodynamic_factor) PL_F(plh_model_desc, rxn)
   PL_S(plh_bounds, 11) PL_F(plh_bounds, V_max) PL_F(plh_bounds, V_min) PL_F(plh_bounds, SOC_max) PL_F(plh_bounds, SOC_min) PL_F(plh_bounds, T_max) PL_F(plh_bounds, c_s_n_max)
   PL_F(plh_bounds, I_max) PL_F(plh_bounds, I_min) PL_F(plh_bounds, eta_plating_min) PL_F(plh_bounds, c_e_min) PL_F(plh_bounds, dfilm_max)
   PL_S(plh_run, 10) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, tab_t)

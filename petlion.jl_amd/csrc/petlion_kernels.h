@@ -229,6 +229,10 @@ unsigned classify(const Tables& tb, int mode, int r, int c) {
     if (M::SEI && sc == 2 && c == O_JS + (i - NP - NS)) return W(JT_CE_JS, i, 0, 0);
     return 0;
   }
+  if constexpr (M::SD != 0) {                       // quadratic / polynomial particles: c_avg row (and Q row) per electrode node
+    if (r >= O_CS && r < N_CECS) { const int p = r - O_CS; if (c == r) return W(JT_CSA_D, p, 0, 0); if (c == O_J + p) return W(JT_CS_J, p, 0, 0); return 0; }
+    if (M::SD == 2 && r >= O_Q && r < O_Q + NJ) { const int p = r - O_Q; if (c == r) return W(JT_Q_Q, p, 0, 0); if (c == O_J + p) return W(JT_Q_J, p, 0, 0); return 0; }
+  }
   if (r < N_CECS) {                                 // c_s row (p, rr)
     const int p = (r - O_CS) / NR, rr = (r - O_CS) % NR;
     if (c >= O_CS && c < N_CECS && (c - O_CS) / NR == p) { const int cc = (c - O_CS) % NR; return (tb.M[rr * NR + cc] != 0.0 || rr == cc) ? W(JT_CS_CS, p, rr, cc) : 0; }
@@ -245,7 +249,8 @@ unsigned classify(const Tables& tb, int mode, int r, int c) {
     const int jx = r - O_J, nd = node_of_j(jx);
     if (M::SEI && jx >= NP && c == O_FILM + jx - NP) return W(JT_J_F, jx - NP, 0, 0);
     if (c == O_CE + nd) return W(JT_J_CE, jx, 0, 0);
-    if (c == O_CS + jx * NR + NR - 1) return W(JT_J_CS, jx, 0, 0);
+    if (c == (M::SD == 0 ? O_CS + jx * NR + NR - 1 : O_CS + jx)) return W(JT_J_CS, jx, 0, 0);
+    if (M::SD == 2 && c == O_Q + jx) return W(JT_J_Q, jx, 0, 0);
     if (c == r) return W(JT_J_J, jx, 0, 0);
     if (c == O_PE + nd) return W(JT_J_PE, jx, 0, 0);
     if (c == O_PS + jx) return W(JT_J_PS, jx, 0, 0);
@@ -285,9 +290,10 @@ unsigned classify(const Tables& tb, int mode, int r, int c) {
 template <class M>
 int sections_of(SectionInfo* o) {
   int k = 0;
-  o[k++] = {"c_e", O_CE, NE}; o[k++] = {"c_s_avg", O_CS, NJ * NR};
+  o[k++] = {"c_e", O_CE, NE}; o[k++] = {"c_s_avg", O_CS, M::NCS};
   if (M::THERMAL) o[k++] = {"T", M::O_T, NT};
   if (M::SEI) { o[k++] = {"film", M::O_FILM, NN}; o[k++] = {"SOH", M::O_SOH, 1}; }
+  if (M::SD == 2) o[k++] = {"Q", M::O_Q, NJ};
   o[k++] = {"j", M::O_J, NJ}; o[k++] = {"Φ_e", M::O_PE, NE}; o[k++] = {"Φ_s", M::O_PS, NJ};
   if (M::SEI) o[k++] = {"j_s", M::O_JS, NN};
   o[k++] = {"I", M::O_I, 1};
@@ -319,7 +325,7 @@ template <class M> struct OpsOf {
     else PL_LAUNCH((k_integrate<M, false>), a.n_cells, WAVE, st, a);
   }
   static const VariantOps* table(int id) {
-    static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::MIXED ? 1 : 0, M::NST, M::NDIFF, sizeof(CellLDS<M>), &classify<M>, &sections_of<M>,
+    static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::MIXED ? 1 : 0, M::SD, M::TF, M::RXN, M::NST, M::NDIFF, sizeof(CellLDS<M>), &classify<M>, &sections_of<M>,
                                    &initial_guess, &residual, &jacobian, &linear_solve, &init_consistent, &integrate};
     return &ops;
   }

@@ -6,27 +6,19 @@
 #error "compile with -DPL_VARIANT=<id>"
 #endif
 
-#define PL_DEFINE_OPS(ID, CHEM, SEI, TH, MIX) \
-  const VariantOps* plh_variant_ops_##ID() { return pl::OpsOf<pl::ModelT<CHEM, SEI, TH, MIX>>::table(ID); }
+#define PL_DEFINE_OPS(ID, CHEM, SEI, TH, MIX, SD, TF, RXN) \
+  const VariantOps* plh_variant_ops_##ID() { return pl::OpsOf<pl::ModelT<CHEM, SEI, TH, MIX, SD, TF, RXN>>::table(ID); }
 
-#if PL_VARIANT == 0
-PL_DEFINE_OPS(0, PLH_CHEM_LCO_LIC6, false, false, false)
-#elif PL_VARIANT == 1
-PL_DEFINE_OPS(1, PLH_CHEM_NMC_LIC6, false, false, false)
-#elif PL_VARIANT == 2
-PL_DEFINE_OPS(2, PLH_CHEM_LCO_LIC6, true, false, false)
-#elif PL_VARIANT == 3
-PL_DEFINE_OPS(3, PLH_CHEM_NMC_LIC6, true, false, false)
-#elif PL_VARIANT == 4
-PL_DEFINE_OPS(4, PLH_CHEM_LCO_LIC6, false, true, false)
-#elif PL_VARIANT == 5
-PL_DEFINE_OPS(5, PLH_CHEM_LCO_LIC6, false, false, true)
-#elif PL_VARIANT == 6
-PL_DEFINE_OPS(6, PLH_CHEM_NMC_LIC6, true, false, true)
-#elif PL_VARIANT == 7
-PL_DEFINE_OPS(7, PLH_CHEM_LCO_LIC6, false, true, true)
-#elif PL_VARIANT == -1   /* every variant in one translation unit (the test-only wave-emulator build) */
+// the variant selected by -DPL_VARIANT (or all of them for PL_VARIANT == -1: the test-only wave-emulator build is one translation unit)
+#define PL_V(ID, CHEM, SEI, TH, MIX, SD, TF, RXN) template <> struct pl::VariantSel<ID> { using M = pl::ModelT<CHEM, SEI, TH, MIX, SD, TF, RXN>; };
+namespace pl { template <int ID> struct VariantSel; }
+PL_VARIANT_LIST(PL_V)
+#undef PL_V
+
+#if PL_VARIANT == -1
 PL_VARIANT_LIST(PL_DEFINE_OPS)
 #else
-#error "unknown PL_VARIANT"
+#define PL_ONE_(ID) const VariantOps* plh_variant_ops_##ID() { return pl::OpsOf<pl::VariantSel<ID>::M>::table(ID); }
+#define PL_ONE(ID) PL_ONE_(ID)
+PL_ONE(PL_VARIANT)
 #endif

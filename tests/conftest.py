@@ -85,3 +85,19 @@ def emu_model_thermal(pkg):
 @pytest.fixture(scope="session")
 def hip_model_thermal(pkg, hip_model):
     return pkg.petlion(pkg.LCO, temperature=True)
+
+
+F4_OPTIONS = {"quad": dict(solid_diffusion="quadratic"), "poly": dict(solid_diffusion="polynomial"), "nu": dict(thermodynamic_factor="nonlinear"),
+              "mhc": dict(rxn_p="MHC", rxn_n="MHC")}
+
+
+@pytest.fixture(scope="session")
+def emu_models_f4(pkg):
+    """SURVEY 8(f).4 model variants on the wave emulator: quadratic / polynomial solid diffusion, nonlinear thermodynamic factor, MHC kinetics"""
+    import build_emu
+    return {k: pkg.petlion(pkg.LCO, _lib_path=build_emu.build(), **kw) for k, kw in F4_OPTIONS.items()}
+
+
+@pytest.fixture(scope="session")
+def hip_models_f4(pkg, hip_model):
+    return {k: pkg.petlion(pkg.LCO, **kw) for k, kw in F4_OPTIONS.items()}

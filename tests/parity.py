@@ -11,8 +11,12 @@ SECTIONS_SEI = [("c_e", 0, 30), ("c_s", 30, 230), ("film", 230, 240), ("SOH", 24
 SECTIONS_THERMAL = [("c_e", 0, 30), ("c_s", 30, 230), ("T", 230, 280), ("j", 280, 300), ("Phi_e", 300, 330), ("Phi_s", 330, 350), ("I", 350, 351)]
 
 
+SECTIONS_QUAD = [("c_e", 0, 30), ("c_s", 30, 50), ("j", 50, 70), ("Phi_e", 70, 100), ("Phi_s", 100, 120), ("I", 120, 121)]
+SECTIONS_POLY = [("c_e", 0, 30), ("c_s", 30, 50), ("Q", 50, 70), ("j", 70, 90), ("Phi_e", 90, 120), ("Phi_s", 120, 140), ("I", 140, 141)]
+
+
 def sections_for(n_states):
-    return {322: SECTIONS_SEI, 351: SECTIONS_THERMAL}.get(n_states, SECTIONS)
+    return {322: SECTIONS_SEI, 351: SECTIONS_THERMAL, 121: SECTIONS_QUAD, 141: SECTIONS_POLY}.get(n_states, SECTIONS)
 
 
 def realistic_states(O, th, n, seed=0, variant="lco_iso"):
@@ -38,7 +42,13 @@ def check_keys_and_pattern(p, O):
     assert np.array_equal(p.theta_vector(), np.array(meta["theta_default"]))
     th = p.theta_vector()
     N = p.N.tot
-    Z = 2883 if p.temperature else (2269 if p.aging else 2139)   # Z = 2139 in CC mode (+130 with SEI; 2883 thermal)
+    Z = meta["nnz"] + 1                                          # Z = 2139 in CC mode (+130 with SEI; 2883 thermal); 519 / 579 quadratic / polynomial
+    if p.variant in ("lco_iso", "nmc_iso", "lco_iso_nu", "lco_iso_mhc"):
+        assert Z == 2139
+    if p.variant.endswith("_sei"):
+        assert Z == 2269
+    if p.temperature:
+        assert Z == 2883
     for mode, nnz_expect in ((0, Z), (1, Z + 1), (3, Z + 2), (4, Z + 1)) + (((2, 2932),) if p.temperature else ()):
         cp, ri = p.jac_pattern(mode)
         ocp, ori, _ = O.jacobian(VARIANT, th, np.ones(N), np.zeros(N), 1.0, mode, 0.0)

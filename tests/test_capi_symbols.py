@@ -37,7 +37,9 @@ def test_fails_loudly_without_gpu(pkg):
 
 def test_unsupported_options_are_refused(pkg):
     with pytest.raises(NotImplementedError):
-        pkg.petlion(pkg.LCO, solid_diffusion="polynomial")
+        pkg.petlion(pkg.LCO, Fickian_method="spectral")
+    with pytest.raises(NotImplementedError):
+        pkg.petlion(pkg.LCO, rxn_p="MHC")                     # rxn_n must follow (one kinetics for both electrodes is what is instantiated)
     with pytest.raises(NotImplementedError):
         pkg.petlion("LFP")
     with pytest.raises(NotImplementedError):

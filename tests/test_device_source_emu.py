@@ -353,3 +353,37 @@ def test_emulator_hostile_modes():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", sel, "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def check_f4_variant(p, O, pkg, tag, n_traj=2, rtol_state=2e-5):
+    """one SURVEY 8(f).4 model variant: key order and CSC pattern identical to the oracle's symbolic pipeline, residual 1e-12 / Jacobian 1e-9 / solve 1e-8,
+    consistent initialisation, and 1C discharges with identical solver decisions (final state within the reproducibility floor discussed in test_gpu_parity.py)"""
+    parity.check_keys_and_pattern(p, O)
+    if tag == "mhc":                                        # the reference default lambda = 6.26e-20 saturates the erf: also exercise a dimensionless lambda where it matters
+        p.θ["λ_MHC_p"], p.θ["λ_MHC_n"] = 8.0, 6.0
+    parity.check_evaluators(p, O, n_cells=3)
+    parity.check_init(p, O, None)
+    Th = pkg.theta_matrix(p, n_traj, {"D_sp": np.linspace(1.0, 0.7, n_traj) * p.θ["D_sp"]})
+    ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0)
+    for i in range(n_traj):
+        ro = O.simulate(p.variant, Th[i], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}]))
+        parity.compare_trajectory(ens, i, ro, rtol_state=rtol_state)
+    return ens
+
+
+def test_f4_quadratic_and_polynomial_solid_diffusion(emu_models_f4, O, pkg):
+    """residuals_c_s_avg! / residuals_Q! / build_c_s_star! of the quadratic and polynomial approximations (residuals.jl:108-127, 237-258; aux...jl:212-248)"""
+    eq = check_f4_variant(emu_models_f4["quad"], O, pkg, "quad")
+    ep = check_f4_variant(emu_models_f4["poly"], O, pkg, "poly")
+    assert emu_models_f4["quad"].N.tot == 121 and emu_models_f4["poly"].N.tot == 141 and "Q" in emu_models_f4["poly"].ind
+    assert eq.run_info[0, 0]["flag"] == 3 and ep.run_info[0, 0]["flag"] == 1          # the polynomial surface concentration reaches the knee earlier: V_min
+
+
+def test_f4_nonlinear_thermodynamic_factor(emu_models_f4, O, pkg):
+    """thermodynamic_factor(c_e, T) (custom_functions.jl:191-203) in the c_e source and, with the row's own nu_i on both edges, in the Phi_e rows (residuals.jl:95-98, 626-645)"""
+    check_f4_variant(emu_models_f4["nu"], O, pkg, "nu")
+
+
+def test_f4_mhc_kinetics(emu_models_f4, O, pkg):
+    """rxn_MHC (custom_functions.jl:241-298): evaluators at lambda = 8 / 6 (the erf matters) and trajectories"""
+    check_f4_variant(emu_models_f4["mhc"], O, pkg, "mhc")

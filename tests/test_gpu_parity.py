@@ -470,3 +470,20 @@ def test_mixed_precision_variants_exist_and_refuse_cleanly(pkg):
         assert np.array_equal(ens.run_info["flag"], ref.run_info["flag"]) and parity.state_rel_err(ens.Y[0], ref.Y[0]) < 1e-6
     with pytest.raises(pkg._capi.PetlionHipError):
         pkg.petlion(pkg.NMC, precision="mixed")                        # NMC without aging is not instantiated in mixed precision: refused, no silent fp64
+
+
+def test_f4_model_variants(hip_models_f4, O, pkg):
+    """SURVEY 8(f).4 on the GPU: quadratic / polynomial solid diffusion, nonlinear thermodynamic factor, MHC kinetics -- evaluator parity, consistent
+    initialisation, trajectories with identical decisions; then a 1024-cell C4-style sweep per variant (properties)"""
+    import test_device_source_emu as te
+    import torch
+    for tag, p in hip_models_f4.items():
+        te.check_f4_variant(p, O, pkg, tag, n_traj=4)
+        n = 1024
+        Th = pkg.configs.sweep_theta(p, np.arange(n), 4)
+        ens = pkg.simulate_ensemble(p, torch.from_numpy(Th).cuda(), [{"I": -1.0}], SOC=1.0, device=True, max_points=512)
+        torch.cuda.synchronize()
+        fl, tend = ens.run_info["flag"][:, 0], ens.run_info["t_end"][:, 0]
+        assert np.isin(fl, (1, 3)).all(), (tag, np.unique(fl))
+        assert np.abs(tend[fl == 3] - 3600.0).max(initial=0.0) < 1e-6 and np.abs(ens.run_info["SOC"][:, 0] - (1.0 - tend / 3600.0)).max() < 1e-9
+        print("%s: N = %d, LDS %d B/cell, 1024-cell sweep kernel %.2f ms (%.0f trajectories/s), flags %s" % (p.variant, p.N.tot, p.lds_bytes, ens.kernel_ms, n / ens.kernel_ms * 1e3, dict(zip(*np.unique(fl, return_counts=True)))))
