@@ -153,10 +153,15 @@ def check_thermal_model(p, O, pkg, Th=None, cells=(0,)):
         # default options (Jacobian reuse): the step sequences may differ within the integration tolerance; the reference's
         # linear back-interpolation over the last step then moves the stop time by O(h^2)
         ro = O.simulate(p.variant, Th[i], 0.0, parity.runs_to_oracle(O, p, pkg, CC_CT_CV))
+        # the hold legs (dT = :hold, V = :hold) start from set points and predictor histories that carry the rounding noise of the legs before them: the oracle's own
+        # spread under evaluation-rounding-sized perturbations (orc_opts.fd_perturb, see test_gpu_parity.py) bounds what a second implementation can reproduce
+        pert = [O.simulate(p.variant, Th[i], 0.0, parity.runs_to_oracle(O, p, pkg, CC_CT_CV), opts=O.default_opts(fd_perturb=2.2e-16, perturb_seed=sd)) for sd in (1, 2, 3, 4)]
         for k, rr in enumerate(ro["runs"]):
             info = ens.run_info[i, k]
-            assert info["flag"] == rr["flag"] and abs(int(info["iterations"]) - rr["iterations"]) <= max(2, 0.15 * rr["iterations"]), (i, k, info, rr)
-            assert abs(info["t_end"] - rr["t_end"]) <= (2e-3 if k < 2 else 1e-2) * rr["t_end"] and abs(info["I"] - rr["I"]) <= 3e-2 * abs(rr["I"]), (i, k, info, rr)
+            it_band = max(abs(q["runs"][k]["iterations"] - rr["iterations"]) for q in pert)
+            te_band = max(abs(q["runs"][k]["t_end"] - rr["t_end"]) for q in pert)
+            assert info["flag"] == rr["flag"] and abs(int(info["iterations"]) - rr["iterations"]) <= max(2, 0.15 * rr["iterations"], 3 * it_band), (i, k, info, rr, it_band)
+            assert abs(info["t_end"] - rr["t_end"]) <= max((2e-3 if k < 2 else 1e-2) * rr["t_end"], 3 * te_band) and abs(info["I"] - rr["I"]) <= 3e-2 * abs(rr["I"]), (i, k, info, rr)
             assert abs(info["T_avg"] - rr["T_avg"]) < (2e-2 if k < 2 else 0.2) and abs(info["SOC"] - rr["SOC"]) < 2e-3
         if ro["runs"][0]["flag"] == 5:
             assert abs(ens.run_info[i, 1]["T_avg"] - 313.15) < 1e-4                                    # the CT leg holds 40 C
