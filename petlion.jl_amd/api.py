@@ -303,6 +303,15 @@ def simulate(p, tf=1e6, *, sol=None, SOC=None, **kw):
             raise TypeError("unknown keyword %r" % k)
         setattr(o, k, v)
     (name, inp), = inputs.items()
+    if len(getattr(o, "tstops", []) or []) > 0:
+        raise NotImplementedError("tstops: the device places tstops at tf, at 1 s of a continuation run and at tdiscon - reltol/2 (model_evaluation.jl:288-310); user tstops are not wired through")
+    # simulate(p, tf::Vector): run to tf[end], then post-interpolate onto tf (model_evaluation.jl:79-80, 148-149)
+    tf_interp = None
+    if isinstance(tf, (list, tuple, np.ndarray)):
+        tf_interp = np.asarray(tf, dtype=np.float64)
+        if tf_interp.ndim != 1 or tf_interp.size == 0:
+            raise ValueError("tf must be a number or a non-empty vector of times")
+        tf = float(tf_interp[-1])
     new = sol is None or sol.isempty()
     sol = Solution() if sol is None else sol
     keep_Y = _wants_states(p, o.outputs) or sol.Y_all is not None
@@ -310,6 +319,9 @@ def simulate(p, tf=1e6, *, sol=None, SOC=None, **kw):
     ens = _integrate(p, p.theta_vector()[None, :], np.array([soc0]), [_make_run(p, name, inp, tf, bounds)], o,
                      Y_init=None if new else sol.Y[None, :], t_init=None if new else np.array([sol.t[-1]]), keep_Y=keep_Y)
     n = int(ens["n_pts"][0])
+    ri = ens["run_info"][0, 0]
+    if ri["flag"] < 0:                                                # the reference's error() paths: `sol` is left untouched
+        raise RuntimeError(EXIT_REASONS.get(int(ri["flag"]), "error"))
     I1C = calc_I1C(p.θ)
     for fld in ("t", "V", "I", "SOC"):
         setattr(sol, fld, np.concatenate([getattr(sol, fld), ens[fld][0, :n]]))
@@ -323,12 +335,11 @@ def simulate(p, tf=1e6, *, sol=None, SOC=None, **kw):
             raise ValueError("the solution being continued was not saved with outputs='all'")
         sol.Y_all = np.concatenate([prev, ens["Y_all"][0, :n]])
     sol.Y, sol.YP = ens["Y"][0].copy(), ens["YP"][0].copy()
-    ri = ens["run_info"][0, 0]
-    if ri["flag"] < 0:
-        raise RuntimeError(EXIT_REASONS.get(int(ri["flag"]), "error"))      # the reference's error() paths
     t_start = ens["t"][0, 0]
     sol.results.append(RunResult(name, (t_start, ri["t_end"]), ri["flag"], ri["iterations"], ri))
     sol.counters = ens["counters"][0]
+    if tf_interp is not None:
+        return sol(tf_interp, interp_bc=o.interp_bc)
     return sol
 
 
@@ -380,6 +391,13 @@ def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, 
     cap.check(lib, lib.plh_integrate(h, n, cap.ptr(theta), cap.ptr(SOC0), cap.ptr(Y_init), cap.ptr(t_init), len(runs), arr,
                                      C.byref(os_), C.byref(out), kind, stream), "plh_integrate")
     if device:
+        if stream is not None and int(stream) != torch.cuda.current_stream(dev).cuda_stream:
+            # the buffers were allocated on torch's current stream but the kernel runs on `stream`: tell the caching allocator, or it may hand the
+            # memory out again while the kernel still writes it
+            ext = torch.cuda.ExternalStream(int(stream), device=dev)
+            for v in list(bufs.values()) + [theta, SOC0]:
+                if hasattr(v, "record_stream"):
+                    v.record_stream(ext)
         bufs["kernel_ms"] = lambda: lib.plh_last_kernel_ms(h)     # evaluated on access: the launch is asynchronous on `stream`
     else:
         bufs["kernel_ms"] = lib.plh_last_kernel_ms(h)
@@ -430,16 +448,17 @@ class EnsembleSolution:
         return self.run_info["flag"]
 
     def __getitem__(self, i):
+        host = lambda x: (x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)).copy()      # device=True results are torch tensors in HBM
         s = Solution()
         n = int(self.n_pts[i])
-        s.t, s.V, s.I, s.SOC = self.t[i, :n].copy(), self.V[i, :n].copy(), self.I[i, :n].copy(), self.SOC[i, :n].copy()
+        s.t, s.V, s.I, s.SOC = host(self.t[i, :n]), host(self.V[i, :n]), host(self.I[i, :n]), host(self.SOC[i, :n])
         s.P = s.I * calc_I1C(self.p.θ) * s.V
-        s.Y, s.YP = self.Y[i].copy(), self.YP[i].copy()
+        s.Y, s.YP = host(self.Y[i]), host(self.YP[i])
         s._ind = self.p.ind
         if self.T_avg is not None:
-            s.T_avg = self.T_avg[i, :n].copy()
+            s.T_avg = host(self.T_avg[i, :n])
         if self.Y_all is not None:
-            s.Y_all = self.Y_all[i, :n].copy()
+            s.Y_all = host(self.Y_all[i, :n])
         t0 = 0.0
         for k, nm in enumerate(self.run_names):
             ri = self.run_info[i, k]

@@ -122,7 +122,7 @@ template <bool SEI> struct SeiPool {};
 template <> struct SeiPool<true> {
   double jjJ[NN], jjF[NN];                                          // d(j row)/d(j, film)
   double jsPS[NN], jsPE[NN], jsJ[NN], jsJS[NN], jsF[NN], jsI[NN];   // d(j_s row)/d(Phi_s, Phi_e, j, j_s, film, I)
-  double Wl[NN][9];                                                 // inverse of the node-local (j, j_s, film) block
+  double Wl[9][NN];                                                 // inverse of the node-local (j, j_s, film) block
   double sohw[NN];                                                  // d(rhs_SOH)/d j_s: trapezoid + end-extrapolation weights
   double cjf;                                                       // cj of the current factorisation
 };
@@ -149,11 +149,11 @@ template <bool MIXED> struct ThermalPool<true, MIXED> {
   double AinvE[NJ][NR], AinvQ[NJ][NR];                     // A^-1 e_last, A^-1 q (AinvQ doubles as the store of W c between the Jacobian pass and the factorisation)
   double kapF[NJ];                                         // kappa at the last factorisation (the resolvent is applied in spectral form)
   // node-local elimination
-  double tq[NE][4], phi4[NE][4], colI4[NE][2];           // colI4: (Phi_s, T) components of the column of I (the others are zero)
+  double tq[4][NE], phi4[4][NE], colI4[2][NE];           // colI4: (Phi_s, T) components of the column of I (the others are zero)
   // collector chains (tridiagonal scalar systems)
   double cP[2][NA], cM[2][NA], zc[2][NA], zI[2][NA], zb[2][NA];
   // Woodbury and border
-  double x2[NE][4], vB[NE][4];
+  double x2[4][NE], vB[4][NE];
   double qfar[2][4];                                       // q = (far T-row entry of node 9 / 20) . D'^-1 of node 7 / 22 (right-hand-side share)
   double bord[2];                                          // [0] d2 = d - v.x2, [1] d (direct I entry of the control row)
   double cjf;
@@ -167,14 +167,16 @@ template <class M> struct CellLDS {
   double peL[NE], peD[NE], peU[NE], pcL[NE], pcD[NE], pcU[NE], peJ[NE];
   double gce[NJ], gcs[NJ], gpe[NJ], gps[NJ], psJ[NJ];
   // eliminated system
-  double dj[NJ], nphi[M::THERMAL ? 1 : NE][3];      // j pivot; phi_c = omega . A_ux[:,c] (node block D[r][c] -= t_r phi_c, t = (ceJ, peJ, psJ))
-  double colI[M::THERMAL ? 1 : NE][3];              // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
-  typename M::fact_t Dinv[NE][M::NB * M::NB], LD[NE][M::NB * M::NB];   // Thomas factors: D'^-1 and L D'^-1(prev)
+  // (per-node small blocks are stored structure-of-arrays, [element][node]: the lanes of a wave own one node each, so element k of all nodes is
+  //  one conflict-free LDS access; [node][element] with a row of 16 doubles puts every lane on the same bank)
+  double dj[NJ], nphi[3][M::THERMAL ? 1 : NE];      // j pivot; phi_c = omega . A_ux[:,c] (node block D[r][c] -= t_r phi_c, t = (ceJ, peJ, psJ))
+  double colI[3][M::THERMAL ? 1 : NE];              // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
+  typename M::fact_t Dinv[M::NB * M::NB][NE], LD[M::NB * M::NB][NE];   // Thomas factors: D'^-1 and L D'^-1(prev)
   typename M::fact_t LDmid[M::NB * M::NB];                             // closing block of the twisted factorisation
   typename M::fact_t Ainv[2][(M::THERMAL || M::SD != 0) ? 1 : NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
   double Mr[(M::THERMAL || M::SD != 0) ? 1 : NR * NR];               // radial operator (copy of Tables::M)
   double resp[M::SD != 0 ? NJ : 1], rcjf[M::SD != 0 ? 2 : 1][2];    // quadratic / polynomial particles: d c_s* / d j after eliminating c_avg (and Q); 1/cj and 1/(-kappa - cj) of the factorisation
-  double x2[M::THERMAL ? 1 : NE][3];
+  double x2[3][M::THERMAL ? 1 : NE];
   double ctrlJ[2], bord;           // P-mode control row at the last Jacobian pass (I*I1C, V*I1C); border pivot d - v.x2
   double w9[NJ];
   double sig[2];
@@ -829,7 +831,7 @@ __device__ __forceinline__ void node_block(const CellLDS<M>& S, int i, double cj
   if (elec) {
     const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
     D[8] = (first || last) ? -1.0 : -2.0;
-    const double gc = S.nphi[i][0], ge = S.nphi[i][1], gs = S.nphi[i][2];      // phi (already zero in column c_e when alg_only)
+    const double gc = S.nphi[0][i], ge = S.nphi[1][i], gs = S.nphi[2][i];      // phi (already zero in column c_e when alg_only)
     const double fs = alg_only ? 0.0 : S.ceJ[i], fp = S.peJ[i], fq = S.psJ[jx];
     D[0] -= fs * gc; D[1] -= fs * ge; D[2] -= fs * gs;
     D[3] -= fp * gc; D[4] -= fp * ge; D[5] -= fp * gs;
@@ -861,7 +863,7 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only
   // every load is unconditional (i is a valid node in every lane) and masked afterwards: a guarded load `act ? S.x[i] : 0` compiles to one
   // exec-masked branch per element, which serialises the loads of this prologue
   double C[9], Di[9], G[9], Lm[9];
-  for (int k = 0; k < 9; k++) { const double c = S.LD[i][k], d = S.Dinv[i][k], l = S.LDmid[k]; C[k] = act ? c : 0.0; Di[k] = act ? d : 0.0; Lm[k] = nd == TW_MID ? l : 0.0; }
+  for (int k = 0; k < 9; k++) { const double c = S.LD[k][i], d = S.Dinv[k][i], l = S.LDmid[k]; C[k] = act ? c : 0.0; Di[k] = act ? d : 0.0; Lm[k] = nd == TW_MID ? l : 0.0; }
   {   // back-substitution block: top x_n = z_n - Dinv U_n x_{n+1}; bottom x_n = z_n - Dinv L_n x_{n-1}; node TW_MID is closed (G = 0)
     const bool z = !act || nd == TW_MID;
     const double ceu = S.ceU[i], cel = S.ceL[i], pcu = S.pcU[i], pcl = S.pcL[i], peu = S.peU[i], pel = S.peL[i];
@@ -959,7 +961,7 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
           A[3] = S.sei.jsJ[k]; A[4] = S.sei.jsJS[k]; A[5] = alg_only ? 0.0 : S.sei.jsF[k];
           A[6] = 0.0; A[7] = alg_only ? 0.0 : -c.Mrho; A[8] = alg_only ? 1.0 : -cj;
           inv3(A, Wm);
-          for (int q = 0; q < 9; q++) S.sei.Wl[k][q] = Wm[q];
+          for (int q = 0; q < 9; q++) S.sei.Wl[q][k] = Wm[q];
           const double w0 = Wm[0] + Wm[3], w1 = Wm[1] + Wm[4];
           ph0 = alg_only ? 0.0 : w0 * S.gce[jx];
           ph1 = w0 * S.gpe[jx] + w1 * S.sei.jsPE[k];
@@ -976,8 +978,8 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
         ph0 = alg_only ? 0.0 : S.gce[jx] * rd; ph1 = S.gpe[jx] * rd; ph2 = S.gps[jx] * rd;
       }
     }
-    S.nphi[i][0] = ph0; S.nphi[i][1] = ph1; S.nphi[i][2] = ph2;
-    S.colI[i][0] = cI0; S.colI[i][1] = cI1; S.colI[i][2] = cI2;
+    S.nphi[0][i] = ph0; S.nphi[1][i] = ph1; S.nphi[2][i] = ph2;
+    S.colI[0][i] = cI0; S.colI[1][i] = cI1; S.colI[2][i] = cI2;
   }
   if constexpr (M::SEI) { if (lane == 0) S.sei.cjf = cj; }
   PL_SYNC();
@@ -1031,16 +1033,16 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
       inv3(Dm, Dmi);
       if (nd == TW_MID) for (int k = 0; k < 9; k++) { Dinv[k] = Dmi[k]; S.LDmid[k] = PL_F32(L2[k]); }
     }
-    if (act) for (int k = 0; k < 9; k++) { S.Dinv[i][k] = PL_F32(Dinv[k]); S.LD[i][k] = PL_F32(LDm[k]); }
+    if (act) for (int k = 0; k < 9; k++) { S.Dinv[k][i] = PL_F32(Dinv[k]); S.LD[k][i] = PL_F32(LDm[k]); }
   }
   PL_SYNC();
   // 4. border vector for modes whose control row is not "I = value":  x2 = T^-1 (column of I)
   if (mode != PLH_MODE_I) {
     const int nd = tw_node(lane);
     const int il = nd >= 0 ? nd : 0;
-    double r0 = nd >= 0 ? S.colI[il][0] : 0.0, r1 = nd >= 0 ? S.colI[il][1] : 0.0, r2 = nd >= 0 ? S.colI[il][2] : 0.0;
+    double r0 = nd >= 0 ? S.colI[0][il] : 0.0, r1 = nd >= 0 ? S.colI[1][il] : 0.0, r2 = nd >= 0 ? S.colI[2][il] : 0.0;
     thomas_sweeps(S, alg_only, r0, r1, r2);
-    if (nd >= 0) { S.x2[nd][0] = r0; S.x2[nd][1] = r1; S.x2[nd][2] = r2; }
+    if (nd >= 0) { S.x2[0][nd] = r0; S.x2[1][nd] = r1; S.x2[2][nd] = r2; }
     // border pivot d - v.x2 of the control row (v, d): V: Phi_s[1] - Phi_s[end]; P: I I1C (same) with d = V I1C; eta_p: Phi_s.n[1] - Phi_e.n[1]
     const double vx = (mode == PLH_MODE_ETA_P) ? lane_bcast(r2, tw_lane(NP + NS)) - lane_bcast(r1, tw_lane(NP + NS)) : lane_bcast(r2, tw_lane(0)) - lane_bcast(r2, tw_lane(NE - 1));
     if (lane == 0) S.bord = (mode == PLH_MODE_P) ? S.ctrlJ[1] - S.ctrlJ[0] * vx : -vx;
@@ -1109,7 +1111,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
         if (sc == 2) {
           const int k = i - (NP + NS);
           bjs = b[O_JS + k]; bfl = alg_only ? 0.0 : b[O_FILM + k];
-          const double* Wm = S.sei.Wl[k];
+          double Wm[9]; for (int q = 0; q < 9; q++) Wm[q] = S.sei.Wl[q][k];
           beta = (Wm[0] + Wm[3]) * bjp + (Wm[1] + Wm[4]) * bjs + (Wm[2] + Wm[5]) * bfl;
           local3 = true;
         }
@@ -1119,7 +1121,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
       r1 -= S.peJ[i] * beta; r2 -= S.psJ[jx] * beta;
       if (mode == PLH_MODE_I) {             // control row: 1 * x_I = b_I
         const double bI = b[O_I];
-        r0 -= S.colI[i][0] * bI; r1 -= S.colI[i][1] * bI; r2 -= S.colI[i][2] * bI;
+        r0 -= S.colI[0][i] * bI; r1 -= S.colI[1][i] * bI; r2 -= S.colI[2][i] * bI;
       }
     }
     m0 = r0; m1 = r1; m2 = r2;
@@ -1134,7 +1136,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
     double vm = (mode == PLH_MODE_ETA_P) ? lane_bcast(m2, tw_lane(NP + NS)) - lane_bcast(m1, tw_lane(NP + NS)) : lane_bcast(m2, tw_lane(0)) - lane_bcast(m2, tw_lane(NE - 1));
     if (mode == PLH_MODE_P) vm *= S.ctrlJ[0];
     xI = (b[O_I] - vm) / S.bord;
-    if (nd >= 0) { mx[0] -= xI * S.x2[nd][0]; mx[1] -= xI * S.x2[nd][1]; mx[2] -= xI * S.x2[nd][2]; }
+    if (nd >= 0) { mx[0] -= xI * S.x2[0][nd]; mx[1] -= xI * S.x2[1][nd]; mx[2] -= xI * S.x2[2][nd]; }
   }
   PL_SYNC();
   // e. back-substitute the node-local unknowns (j; with SEI also j_s and film), write node unknowns
@@ -1151,7 +1153,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
       if constexpr (M::SEI) {
         if (sei_node) {
           const int k = i - (NP + NS);
-          const double* Wm = S.sei.Wl[k];
+          double Wm[9]; for (int q = 0; q < 9; q++) Wm[q] = S.sei.Wl[q][k];
           const double v1 = bjs - S.sei.jsPE[k] * mx[1] - S.sei.jsPS[k] * mx[2] - S.sei.jsI[k] * xI;
           b[O_J + jx] = Wm[0] * v0 + Wm[1] * v1 + Wm[2] * bfl;
           djs = Wm[3] * v0 + Wm[4] * v1 + Wm[5] * bfl;

@@ -399,19 +399,10 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
   const int nd = tw_node(lane);
   const bool act = nd >= 0, top = lane < TW_MID;
   const int i = act ? nd : 0;
-  double C[16], Di[16], G[16], Lm[16];
-  for (int k = 0; k < 16; k++) { C[k] = act ? S.LD[i][k] : 0.0; Di[k] = act ? S.Dinv[i][k] : 0.0; Lm[k] = nd == TW_MID ? S.LDmid[k] : 0.0; }
-  {
-    OffBlk u = top ? upper_blk(S, i, alg_only) : lower_blk(S, i, alg_only);     // back-substitution block (zero for the closing node)
-    if (!act || nd == TW_MID) { u.ce = u.pc = u.pe = u.pt = u.s = u.Tc = u.Te = u.Ts = u.Tt = 0.0; }
-    for (int rr = 0; rr < 4; rr++) {       // G = Dinv U
-      const double d0 = Di[rr * 4], d1 = Di[rr * 4 + 1], d2 = Di[rr * 4 + 2], d3 = Di[rr * 4 + 3];
-      G[rr * 4 + 0] = d0 * u.ce + d1 * u.pc + d3 * u.Tc;
-      G[rr * 4 + 1] = d1 * u.pe + d3 * u.Te;
-      G[rr * 4 + 2] = d2 * u.s + d3 * u.Ts;
-      G[rr * 4 + 3] = d1 * u.pt + d3 * u.Tt;
-    }
-  }
+  // register diet: C (forward sweep), then Lm (closing), then G (backward sweep) are formed one after the other, so that at most two of the 4x4 blocks
+  // are live at a time next to the integrator's per-lane state (the three at once were half of the register file); PL_SYNC keeps the loads where they are
+  double C[16], Di[16];
+  for (int k = 0; k < 16; k++) { C[k] = act ? S.LD[k][i] : 0.0; Di[k] = act ? S.Dinv[k][i] : 0.0; }
   // ---- the four T rows with a second-neighbour entry (one-sided stencils at nodes 0, 9, 20, 29) inside the twisted elimination ----
   // "far ahead" (node 0 -> node 2, node 29 -> node 27): eliminating x_0 puts -LD_1[:,3] (x) w into U_1, so node 1's (node 28's)
   // back-substitution block is G - (Dinv C[:,3]) (x) w, and x_0 (x_29) gets -Dinv[:,3] (w . x_2) after the sweep.
@@ -422,12 +413,7 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
   const bool far_behind = !alg_only && (nd == NP - 1 || nd == NP + NS);
   const int fk = (nd == 0 || nd == 1) ? 0 : 3;
   const double w0 = TPs.TX2[fk][0], w1 = TPs.TX2[fk][1], w2 = TPs.TX2[fk][2];
-  if (far_ahead_nb) {
-    for (int rr = 0; rr < 4; rr++) {
-      const double t = Di[rr * 4] * C[3] + Di[rr * 4 + 1] * C[7] + Di[rr * 4 + 2] * C[11] + Di[rr * 4 + 3] * C[15];
-      G[rr * 4 + 0] -= t * w0; G[rr * 4 + 1] -= t * w1; G[rr * 4 + 2] -= t * w2;
-    }
-  }
+  const double cT[4] = {C[3], C[7], C[11], C[15]};        // T column of LD (outlives C: the far-ahead correction of G)
   double qf[4] = {0.0, 0.0, 0.0, 0.0};
   if (far_behind) for (int k = 0; k < 4; k++) qf[k] = TPs.qfar[nd == NP - 1 ? 0 : 1][k];
   double y[NRHS][4];
@@ -455,6 +441,9 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
       }
     }
   }
+  PL_SYNC();
+  double Lm[16];
+  for (int k = 0; k < 16; k++) { const double l = S.LDmid[k]; Lm[k] = nd == TW_MID ? l : 0.0; }
   double z[NRHS][4];
 #pragma unroll
   for (int q = 0; q < NRHS; q++) {
@@ -466,6 +455,25 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) { const double gz = lane_bcast(z[q][rr], tw_lane(TW_MID)); if (lane == TW_MID) z[q][rr] = gz; }   // ghost of the closing node
     for (int k = 0; k < 4; k++) r[q][k] = z[q][k];
+  }
+  PL_SYNC();
+  double G[16];
+  {
+    OffBlk u = top ? upper_blk(S, i, alg_only) : lower_blk(S, i, alg_only);     // back-substitution block (zero for the closing node)
+    if (!act || nd == TW_MID) { u.ce = u.pc = u.pe = u.pt = u.s = u.Tc = u.Te = u.Ts = u.Tt = 0.0; }
+    for (int rr = 0; rr < 4; rr++) {       // G = Dinv U
+      const double d0 = Di[rr * 4], d1 = Di[rr * 4 + 1], d2 = Di[rr * 4 + 2], d3 = Di[rr * 4 + 3];
+      G[rr * 4 + 0] = d0 * u.ce + d1 * u.pc + d3 * u.Tc;
+      G[rr * 4 + 1] = d1 * u.pe + d3 * u.Te;
+      G[rr * 4 + 2] = d2 * u.s + d3 * u.Ts;
+      G[rr * 4 + 3] = d1 * u.pt + d3 * u.Tt;
+    }
+    if (far_ahead_nb) {
+      for (int rr = 0; rr < 4; rr++) {
+        const double t = Di[rr * 4] * cT[0] + Di[rr * 4 + 1] * cT[1] + Di[rr * 4 + 2] * cT[2] + Di[rr * 4 + 3] * cT[3];
+        G[rr * 4 + 0] -= t * w0; G[rr * 4 + 1] -= t * w1; G[rr * 4 + 2] -= t * w2;
+      }
+    }
   }
 #pragma unroll 2
   for (int itr = 0; itr < TW_MID; itr++) {
@@ -566,9 +574,9 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       if (i == 0) cI3 = -TP.aL[NA] * TP.zI[0][NA - 1];
       if (i == NE - 1) cI3 = -TP.aU[NA + NE - 1] * TP.zI[1][0];
     }
-    TP.tq[i][0] = t0; TP.tq[i][1] = t1; TP.tq[i][2] = t2; TP.tq[i][3] = t3;
-    TP.phi4[i][0] = p0; TP.phi4[i][1] = p1; TP.phi4[i][2] = p2; TP.phi4[i][3] = p3;
-    TP.colI4[i][0] = cI2; TP.colI4[i][1] = cI3;
+    TP.tq[0][i] = t0; TP.tq[1][i] = t1; TP.tq[2][i] = t2; TP.tq[3][i] = t3;
+    TP.phi4[0][i] = p0; TP.phi4[1][i] = p1; TP.phi4[2][i] = p2; TP.phi4[3][i] = p3;
+    TP.colI4[0][i] = cI2; TP.colI4[1][i] = cI3;
   }
   if (lane == 0) TP.cjf = cj;
   PL_SYNC();
@@ -596,7 +604,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     if (elec) {
       const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
       D[10] = (first || last) ? -1.0 : -2.0;
-      for (int rr = 0; rr < 4; rr++) for (int cc = 0; cc < 4; cc++) D[rr * 4 + cc] -= TP.tq[i][rr] * TP.phi4[i][cc];
+      for (int rr = 0; rr < 4; rr++) for (int cc = 0; cc < 4; cc++) D[rr * 4 + cc] -= TP.tq[rr][i] * TP.phi4[cc][i];
     }
     // a = left block (L_n top / U_n bottom), b = right block (U_{n-1} top / L_{n+1} bottom); zero at the chain heads and in idle lanes
     OffBlk a = top ? lower_blk(S, i, alg_only) : upper_blk(S, i, alg_only);
@@ -607,8 +615,8 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     // the neighbour's off-diagonal block b are re-read from LDS in every stage instead of being held in 50 registers (D parks in S.LD[i], which is
     // only written at the end)
     double* park;
-    if constexpr (M::MIXED) park = &S.th.Dpark[i * 16]; else park = &S.LD[i][0];      // (fp32 factor storage cannot hold the fp64 block)
-    if (act) for (int k = 0; k < 16; k++) park[k] = D[k];
+    if constexpr (M::MIXED) park = &S.th.Dpark[i]; else park = &S.LD[0][i];      // (fp32 factor storage cannot hold the fp64 block)
+    if (act) for (int k = 0; k < 16; k++) park[k * NE] = D[k];      // (element k of node i at [k * NE + i]: the structure-of-arrays layout of the factor arrays)
     // second-neighbour T-row entries (see thermal_sweeps): nodes 2 / 27 see U_1 / L_28 modified by -fv (x) fw ; nodes 9 / 20 get a modified
     // lower / upper block once the factor of node 7 / 22 is final
     double fv[4] = {0.0, 0.0, 0.0, 0.0}, fw[3] = {0.0, 0.0, 0.0};
@@ -617,16 +625,20 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
 #pragma unroll 1
     for (int itr = 1; itr < TW_MID; itr++) {
       PL_SYNC();                                            // (also keeps the reloads below inside the loop)
-      const OffBlk b = top ? upper_blk(S, nb, alg_only) : lower_blk(S, nb, alg_only);
-      double P[16], D[16];
-      for (int k = 0; k < 16; k++) D[k] = park[k];
-      for (int k = 0; k < 16; k++) P[k] = shift_up1(Dinv[k]);
-      for (int k = 0; k < 4; k++) {
-        LDm[k] = a.ce * P[k];
-        LDm[4 + k] = a.pc * P[k] + a.pe * P[4 + k] + a.pt * P[12 + k];
-        LDm[8 + k] = a.s * P[8 + k];
-        LDm[12 + k] = a.Tc * P[k] + a.Te * P[4 + k] + a.Ts * P[8 + k] + a.Tt * P[12 + k];
+      {
+        double P[16];
+        for (int k = 0; k < 16; k++) P[k] = shift_up1(Dinv[k]);
+        for (int k = 0; k < 4; k++) {
+          LDm[k] = a.ce * P[k];
+          LDm[4 + k] = a.pc * P[k] + a.pe * P[4 + k] + a.pt * P[12 + k];
+          LDm[8 + k] = a.s * P[8 + k];
+          LDm[12 + k] = a.Tc * P[k] + a.Te * P[4 + k] + a.Ts * P[8 + k] + a.Tt * P[12 + k];
+        }
       }
+      PL_SYNC();                                            // (the node's own block and the neighbour's off-diagonal block are fetched only now: P is dead)
+      const OffBlk b = top ? upper_blk(S, nb, alg_only) : lower_blk(S, nb, alg_only);
+      double D[16];
+      for (int k = 0; k < 16; k++) D[k] = park[k * NE];
       for (int rr = 0; rr < 4; rr++) {
         const double a0 = LDm[rr * 4], a1 = LDm[rr * 4 + 1], a2 = LDm[rr * 4 + 2], a3 = LDm[rr * 4 + 3];
         Dn[rr * 4 + 0] = D[rr * 4 + 0] - (a0 * b.ce + a1 * b.pc + a3 * b.Tc);
@@ -687,7 +699,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       inv4(Dm, Dmi);
       if (nd == TW_MID) for (int k = 0; k < 16; k++) { Dinv[k] = Dmi[k]; S.LDmid[k] = PL_F32(L2[k]); }
     }
-    if (act) for (int k = 0; k < 16; k++) { S.Dinv[i][k] = PL_F32(Dinv[k]); S.LD[i][k] = PL_F32(LDm[k]); }
+    if (act) for (int k = 0; k < 16; k++) { S.Dinv[k][i] = PL_F32(Dinv[k]); S.LD[k][i] = PL_F32(LDm[k]); }
   }
   PL_TOCD(S, 4);
   // 6a. control row over the node unknowns (computed in the lane = node layout: the twin needs neighbour shifts), stored in TP.vB
@@ -722,24 +734,24 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
         if (sc != 1) {                                     // j eliminated: v_x -= v_j phi
           const int jx = sc == 0 ? ln : ln - NS;
           const double vj = -wi * TP.TJ[jx];
-          v1 -= vj * TP.phi4[ln][1]; v2 -= vj * TP.phi4[ln][2];
+          v1 -= vj * TP.phi4[1][ln]; v2 -= vj * TP.phi4[2][ln];
           v0 = vj;                                         // kept for the right-hand side (b_I -= v_j beta); slot 0 is free in the algebraic system
         }
       }
       // the collector rows depend on I only (Joule heat): -(sum_k w_k) d rhs_k/dI
       dI = -(NA * TP.wT5[tsec_of(0)] * TP.qIJ[0] + NZ * TP.wT5[tsec_of(NT - 1)] * TP.qIJ[1]);
     }
-    if (lane < NE) { TP.vB[ln][0] = v0; TP.vB[ln][1] = v1; TP.vB[ln][2] = v2; TP.vB[ln][3] = v3; }
+    if (lane < NE) { TP.vB[0][ln] = v0; TP.vB[1][ln] = v1; TP.vB[2][ln] = v2; TP.vB[3][ln] = v3; }
   }
   PL_SYNC();
   PL_SYNC();
   // 5. border: x2 = B^-1 (column of I) and the pivot d - v.x2
   if (mode != PLH_MODE_I) {
     double ra[1][4] = {{0.0, 0.0, 0.0, 0.0}};
-    if (act) { ra[0][2] = TP.colI4[i][0]; ra[0][3] = TP.colI4[i][1]; }
+    if (act) { ra[0][2] = TP.colI4[0][i]; ra[0][3] = TP.colI4[1][i]; }
     thermal_sweeps<1>(S, alg_only, ra);
-    if (act) for (int cc = 0; cc < 4; cc++) TP.x2[i][cc] = ra[0][cc];
-    const double vx = wave_sum(act ? TP.vB[i][1] * ra[0][1] + TP.vB[i][2] * ra[0][2] + TP.vB[i][3] * ra[0][3] + (mode == PL_MODE_DT_TWIN ? 0.0 : TP.vB[i][0] * ra[0][0]) : 0.0);
+    if (act) for (int cc = 0; cc < 4; cc++) TP.x2[cc][i] = ra[0][cc];
+    const double vx = wave_sum(act ? TP.vB[1][i] * ra[0][1] + TP.vB[2][i] * ra[0][2] + TP.vB[3][i] * ra[0][3] + (mode == PL_MODE_DT_TWIN ? 0.0 : TP.vB[0][i] * ra[0][0]) : 0.0);
     if (lane == 0) { TP.bord[0] = dI - vx; TP.bord[1] = dI; }
   } else if (lane == 0) { TP.bord[0] = 1.0; TP.bord[1] = 1.0; }
   PL_SYNC();
@@ -801,7 +813,7 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
       y[2] = b[O_PS + jx];
       if (!alg_only) y[3] -= TP.Tcs[jx] * w9;
       beta = bjp * S.dj[jx];
-      for (int cc = 0; cc < 4; cc++) y[cc] -= TP.tq[i][cc] * beta;
+      for (int cc = 0; cc < 4; cc++) y[cc] -= TP.tq[cc][i] * beta;
     }
     if (!alg_only) {
       if (i == 0) y[3] -= TP.aL[NA] * TP.zb[0][NA - 1];
@@ -811,7 +823,7 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
   double xI = 0.0;
   if (mode == PLH_MODE_I) {
     xI = b[O_I];
-    if (act) { y[2] -= TP.colI4[i][0] * xI; y[3] -= TP.colI4[i][1] * xI; }
+    if (act) { y[2] -= TP.colI4[0][i] * xI; y[3] -= TP.colI4[1][i] * xI; }
   }
   // c. block-Thomas sweeps + Woodbury correction
   {
@@ -824,16 +836,16 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
     double bI = b[O_I];
     double vy = 0.0;
     if (act) {
-      vy = TP.vB[i][1] * y[1] + TP.vB[i][2] * y[2] + TP.vB[i][3] * y[3];
-      if (mode == PL_MODE_DT_TWIN) vy += TP.vB[i][0] * beta;           // v_j (b_j'/d): the eliminated j part of the twin row
-      else vy += TP.vB[i][0] * y[0];
+      vy = TP.vB[1][i] * y[1] + TP.vB[2][i] * y[2] + TP.vB[3][i] * y[3];
+      if (mode == PL_MODE_DT_TWIN) vy += TP.vB[0][i] * beta;           // v_j (b_j'/d): the eliminated j part of the twin row
+      else vy += TP.vB[0][i] * y[0];
     }
     if (mode == PLH_MODE_DT) {                                          // collector T's in the control row: -cj w_k zb_k
       if (lane >= 32 && lane < 32 + NA + NZ) { const int k = lane - 32, q = k < NA ? 0 : 1, kk = k < NA ? k : k - NA; vy += -TP.cjf * TP.wT5[tsec_of(q == 0 ? kk : NA + NE + kk)] * TP.zb[q][kk]; }
     }
     const double vsum = wave_sum(vy);
     xI = (bI - vsum) / TP.bord[0];
-    if (act) for (int cc = 0; cc < 4; cc++) y[cc] -= xI * TP.x2[i][cc];
+    if (act) for (int cc = 0; cc < 4; cc++) y[cc] -= xI * TP.x2[cc][i];
   }
   PL_SYNC();
   // e. write node unknowns, back-substitute j and the collectors
@@ -842,7 +854,7 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
     b[O_PE + i] = y[1];
     if (elec) {
       b[O_PS + jx] = y[2];
-      b[O_J + jx] = beta - (TP.phi4[i][0] * y[0] + TP.phi4[i][1] * y[1] + TP.phi4[i][2] * y[2] + TP.phi4[i][3] * y[3]);
+      b[O_J + jx] = beta - (TP.phi4[0][i] * y[0] + TP.phi4[1][i] * y[1] + TP.phi4[2][i] * y[2] + TP.phi4[3][i] * y[3]);
     }
   }
   if (lane == 0) b[O_I] = xI;

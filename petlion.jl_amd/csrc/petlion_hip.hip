@@ -648,7 +648,7 @@ int plh_comm_create(int n_ranks, int rank, const char id[128], int device, plh_c
   c->device = device;
   DeviceGuard guard(device);
   if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(PLH_E_HIP, "hipStreamCreate failed"); }
-  if (n_ranks > 1) {
+  if (id) {        // (a one-rank communicator with an id still initialises RCCL: the collective path then runs end to end on a single GPU)
     ncclUniqueId u; memcpy(&u, id, 128);
     const ncclResult_t r = ncclCommInitRank(&c->comm, n_ranks, u, rank);
     if (r != ncclSuccess) { hipStreamDestroy(c->st); delete c; return fail(PLH_E_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
@@ -713,7 +713,7 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
   // 1. shape check: everybody must describe the same ensemble (ncclBroadcast from rank 0)
   long long meta[4] = {n_total, n_runs, partition, P};
 #ifndef PL_WAVE_EMU
-  if (G > 1) {
+  if (c->comm) {
     long long root_meta[4];
     if (root) HIPCHK(hipMemcpy(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice));
     NCCLCHK(ncclBroadcast(d_meta, d_meta, 4, ncclInt64, 0, c->comm, st));
@@ -733,7 +733,7 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
     HIPCHK(hipMemcpy(d_soc, soc.data(), soc.size() * sizeof(double), hipMemcpyHostToDevice));
   }
 #ifndef PL_WAVE_EMU
-  if (G > 1) {
+  if (c->comm && G > 1) {
     NCCLCHK(ncclGroupStart());
     if (root) { for (int r = 1; r < G; r++) if (off[r + 1] > off[r]) { NCCLCHK(ncclSend(d_th + (size_t)off[r] * P, (size_t)(off[r + 1] - off[r]) * P, ncclDouble, r, c->comm, st));
                                                                       NCCLCHK(ncclSend(d_soc + off[r], (size_t)(off[r + 1] - off[r]), ncclDouble, r, c->comm, st)); } }
@@ -753,7 +753,7 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
   // 4. gather of the per-cell summaries to rank 0 (rank-contiguous order), then back to the caller's cell order
   HIPCHK(hipMemcpy(d_ms + me, &ms, sizeof(double), hipMemcpyHostToDevice));
 #ifndef PL_WAVE_EMU
-  if (G > 1) {
+  if (c->comm && G > 1) {
     const size_t bi = (size_t)n_runs * sizeof(plh_run_info), bc = sizeof(plh_counters);
     NCCLCHK(ncclGroupStart());
     if (root) for (int r = 1; r < G; r++) {

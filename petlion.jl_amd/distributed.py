@@ -73,6 +73,8 @@ def ensemble_run(p, Theta, protocol, SOC=1.0, *, group=None, device=None, local_
             summ = np.asarray(local_integrate(mine[:m].cpu().numpy(), SOC), dtype=np.float64)
         else:
             from .api import simulate_ensemble
+            if mine.device.type != "cuda":                  # a CPU group (gloo) carries host tensors: move the shard to this rank's GPU (there is no CPU integrator)
+                mine = mine.cuda()
             local = simulate_ensemble(p, mine[:m].contiguous(), protocol, SOC=SOC, device=True)
             summ = summarize(local)
     else:

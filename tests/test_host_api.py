@@ -84,3 +84,25 @@ def test_solution_call_interpolates_like_the_reference(emu_model, pkg):
     assert abs(sol(t_end + 100.0, interp_bc="extrapolate").I[0] - sol.I[-1]) > 1e-6
     with pytest.raises(ValueError):
         sol(1.0, interp_bc="bogus")
+
+
+def test_simulate_vector_tf_and_failed_run_leave_sol_untouched(emu_model, pkg):
+    """simulate(p, tf::Vector) runs to tf[end] and post-interpolates onto tf (model_evaluation.jl:79-80); a failed run raises before `sol` is modified"""
+    import numpy as np
+    p = emu_model
+    sol = pkg.simulate(p, [0.0, 100.0, 250.0, 600.0], I=-1, SOC=1)
+    assert np.array_equal(sol.t, [0.0, 100.0, 250.0, 600.0]) and len(sol.V) == 4 and sol.V[0] > sol.V[-1]
+    full = pkg.simulate(p, 600.0, I=-1, SOC=1)
+    assert abs(sol.V[-1] - full.V[-1]) < 1e-9 and abs(sol.V[1] - np.interp(100.0, full.t, full.V)) < 2e-3
+    n0 = len(full.t)
+    try:
+        pkg.simulate_b(full, p, 100.0, I=-1, maxiters=3)              # "Reached max iterations" -> RuntimeError
+        assert False, "expected a RuntimeError"
+    except RuntimeError:
+        pass
+    assert len(full.t) == n0 and len(full.results) == 1
+    try:
+        pkg.simulate(p, 100.0, I=-1, tstops=[50.0])
+        assert False
+    except NotImplementedError:
+        pass
