@@ -227,8 +227,14 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
     if (done) break;                                      // the iterate (yy, yp) now includes the last correction
     if (callLSetup) {
       PL_TIC();
+#ifndef PL_EXP_NO_JAC
       cell_res_jac(S, R, S.yy, S.yp, S.delta, mode, value);
+#else
+      cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
+#endif
+#ifndef PL_EXP_NO_FACTOR
       cell_factor(S, R, tb, I.cj, mode, false);
+#endif
       cnt_add(cnt, C_RES); cnt_add(cnt, C_JAC); cnt_add(cnt, C_FACT);
       I.cjold = I.cj; I.cjratio = 1.0; I.ss = 20.0; jcur = 1; callLSetup = 0;
       PL_TOC(S, PH_JACFACT);
@@ -240,8 +246,10 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
     }
     cnt_add(cnt, C_NEWTON); cnt_add(cnt, C_SOLVE);
     { PL_TIC();
+#ifndef PL_EXP_NO_SOLVE
     if (GEN && nref > 0) cell_solve_refined(S, R, tb, S.delta, S.yp, I.cjold, mode, false, nref);   // (S.yp is dead until the next form_iterate; cjold = cj of the factors)
     else cell_solve(S, R, S.delta, mode, false);           // x = J^-1 F ; the Newton correction is -x
+#endif
     PL_TOC(S, PH_SOLVE); }
     PL_TIC();
     const double sc = (I.cjratio != 1.0) ? -2.0 / (1.0 + I.cjratio) : -1.0;

@@ -15,7 +15,7 @@ namespace pl {
 
 // Every kernel runs at most one wavefront per SIMD (LDS: >= 40 kB per single-wave workgroup), so the compiler may use the whole
 // 512-entry register file of a lane (256 VGPR + 256 AGPR) instead of spilling to scratch.
-#ifndef PL_WAVE_EMU
+#if !defined(PL_WAVE_EMU) && !defined(PL_NO_WAVES_ATTR)      /* (PL_NO_WAVES_ATTR: experiment builds of tools/experiments/build_modes.py) */
 #define PL_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 #else
 #define PL_ONE_WAVE_PER_SIMD

@@ -484,6 +484,13 @@ def test_f4_model_variants(hip_models_f4, O, pkg):
         ens = pkg.simulate_ensemble(p, torch.from_numpy(Th).cuda(), [{"I": -1.0}], SOC=1.0, device=True, max_points=512)
         torch.cuda.synchronize()
         fl, tend = ens.run_info["flag"][:, 0], ens.run_info["t_end"][:, 0]
-        assert np.isin(fl, (1, 3)).all(), (tag, np.unique(fl))
-        assert np.abs(tend[fl == 3] - 3600.0).max(initial=0.0) < 1e-6 and np.abs(ens.run_info["SOC"][:, 0] - (1.0 - tend / 3600.0)).max() < 1e-9
+        ok = np.isin(fl, (1, 3))
+        # IDA gives up on a few jittered cells of the polynomial model where the voltage knee meets a step-size collapse (the reference's "Model failed to
+        # converge" error): the device must fail on the cells the oracle fails on, at the same time -- never on others
+        assert (~ok).sum() <= 0.02 * n and (fl[~ok] == -12).all(), (tag, np.unique(fl))
+        runs = parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}])
+        for i in np.flatnonzero(~ok):
+            ro = O.simulate(p.variant, Th[i], 1.0, runs)
+            assert ro["runs"][0]["flag"] < 0 and abs(ro["runs"][0]["t_end"] - tend[i]) < 1e-3 * tend[i], (tag, i, ro["runs"][0], tend[i])
+        assert np.abs(tend[fl == 3] - 3600.0).max(initial=0.0) < 1e-6 and np.abs(ens.run_info["SOC"][ok, 0] - (1.0 - tend[ok] / 3600.0)).max() < 1e-9
         print("%s: N = %d, LDS %d B/cell, 1024-cell sweep kernel %.2f ms (%.0f trajectories/s), flags %s" % (p.variant, p.N.tot, p.lds_bytes, ens.kernel_ms, n / ens.kernel_ms * 1e3, dict(zip(*np.unique(fl, return_counts=True)))))

@@ -19,6 +19,11 @@ BUILDS = [  # tag, variants, {variant: opt}, extra flags, perf config, pytest -k
     ("th_early_O3", [4], {4: "-O3"}, EARLY, "c3", "c3_thermal"),
     ("th_fcall_O2", [4], {4: "-O2"}, EARLY + ["-DPL_FACTOR_CALL"], "c3", "c3_thermal"),
     ("th_fcall_O3", [4], {4: "-O3"}, EARLY + ["-DPL_FACTOR_CALL"], "c3", "c3_thermal"),
+    # the r01 failure mode -- device functions left to the inliner's heuristics (real s_swappc calls inside k_integrate)
+    ("iso_calls_O2", [0], {0: "-O2"}, ["-DPL_DEV=__device__ inline"], "c2", "c2_1024 or evaluators or consistent"),
+    ("iso_calls_O3", [0], {0: "-O3"}, ["-DPL_DEV=__device__ inline"], "c2", "c2_1024 or evaluators or consistent"),
+    ("iso_calls_O2_noattr", [0], {0: "-O2"}, ["-DPL_DEV=__device__ inline", "-DPL_NO_WAVES_ATTR"], "c2", "c2_1024 or evaluators or consistent"),
+    ("iso_calls_O2_noinl", [0], {0: "-O2"}, ["-DPL_DEV=__device__ __attribute__((noinline))"], "c2", "c2_1024 or evaluators or consistent"),
 ]
 sel = sys.argv[1:]
 builds = [b for b in BUILDS if not sel or b[0] in sel]
