@@ -61,7 +61,7 @@ mutable struct Model
     N::Int; N_diff::Int; θ_keys::Vector{Symbol}
     function Model(p; precision = 0, device = -1)   # p::PETLION.model -- reads only p.N and p.numerics
         N = p.N
-        chem = Symbol(p.numerics.cathode) == :LCO ? 0 : 1      # function name of the cathode system, as in strings_directory_func
+        chem = Dict(:LCO => 0, :NMC => 1, :NMC_LGM50 => 2)[Symbol(p.numerics.cathode)]      # function name of the cathode system, as in strings_directory_func
         d = Ref(ModelDesc(chem, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, p.numerics.temperature == true, p.numerics.aging == :SEI, 8, precision, device,
                           Dict(:Fickian => 0, :quadratic => 1, :polynomial => 2)[p.numerics.solid_diffusion],
                           p.numerics.thermodynamic_factor === PETLION_thermodynamic_factor_nonlinear(p) ? 1 : 0, p.numerics.rxn_p === PETLION_rxn_MHC(p) ? 1 : 0))

@@ -97,7 +97,7 @@ function install(cathode = PETLION.LCO; libpath = PetlionHIP.lib, kwargs...)
     θ_keys = copy(m.θ_keys)                                   # update_θ! fills θ_tot in this order (generate_functions.jl:364-372)
 
     n = p0.N
-    desc = (Symbol(p0.numerics.cathode) == :LCO ? 0 : 1, n.p, n.s, n.n, n.a, n.z, n.r_p, n.r_n,
+    desc = (Dict(:LCO => 0, :NMC => 1, :NMC_LGM50 => 2)[Symbol(p0.numerics.cathode)], n.p, n.s, n.n, n.a, n.z, n.r_p, n.r_n,
             Int(p0.numerics.temperature == true), Int(p0.numerics.aging == :SEI), 8, 0, -1,     # fp64, current device
             Dict(:Fickian => 0, :quadratic => 1, :polynomial => 2)[p0.numerics.solid_diffusion],
             Int(p0.numerics.thermodynamic_factor === PETLION.thermodynamic_factor), Int(p0.numerics.rxn_p === PETLION.rxn_MHC))

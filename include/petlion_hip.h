@@ -36,9 +36,10 @@ extern "C" {
 #define PLH_E_UNSUPPORTED (-2)  /* model option outside the hot-path scope */
 #define PLH_E_HIP (-3)          /* HIP runtime failure (no GPU, out of memory, launch failure) */
 
-/* chemistries: reference src/params.jl:5-289 (LCO + LiC6), 295-507 (NMC + LiC6_NMC) */
+/* chemistries: reference src/params.jl:5-289 (LCO + LiC6), 295-507 (NMC + LiC6_NMC), 514-849 (NMC_LGM50 + LiC6_LGM50) */
 #define PLH_CHEM_LCO_LIC6 0
 #define PLH_CHEM_NMC_LIC6 1
+#define PLH_CHEM_LGM50 2      /* NMC_LGM50 + LiC6_LGM50 (Chen et al. 2020), reference src/params.jl:514-849: own OCVs, D_eff(c_e), K_eff(c_e) */
 
 /* operating modes = the control row of the DAE (reference src/physics_equations/input_methods.jl:9,40,182-189,
  * src/physics_equations/scalar_residual.jl:167-172) */

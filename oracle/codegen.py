@@ -52,6 +52,7 @@ VARIANTS = {
     "lco_iso_poly": dict(cathode="LCO", solid_diffusion="polynomial"),
     "lco_iso_nu": dict(cathode="LCO", thermodynamic_factor="nonlinear"),
     "lco_iso_mhc": dict(cathode="LCO", rxn="MHC"),
+    "lgm50_iso": dict(cathode="LGM50"),                  # NMC_LGM50 + LiC6_LGM50 (Chen et al. 2020), reference src/params.jl:514-849
 }
 
 

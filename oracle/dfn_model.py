@@ -44,6 +44,7 @@ class FloatOps:
     def exp(self, x): return self._cm(x).exp(x)
     def sinh(self, x): return self._cm(x).sinh(x)
     def atan(self, x): return self._cm(x).atan(x)
+    def tanh(self, x): return self._cm(x).tanh(x)
     def log(self, x): return self._cm(x).log(x)
     def erf(self, x):
         if isinstance(x, complex):       # first-order continuation (complex-step checks only)
@@ -76,6 +77,7 @@ class SymOps:
     def exp(self, x): return self.sp.exp(x)
     def sinh(self, x): return self.sp.sinh(x)
     def atan(self, x): return self.sp.atan(x)
+    def tanh(self, x): return self.sp.tanh(x)
     def log(self, x): return self.sp.log(x)
     def erf(self, x): return self.sp.erf(x)
     def pow(self, x, y): return self.sp.Pow(x, y)
@@ -145,12 +147,29 @@ def theta_NMC():
     return th
 
 
+def theta_LGM50():
+    """NMC_LGM50 cathode + LiC6_LGM50 anode + system_LGM50_NMC_LiC6 (Chen et al. 2020): reference src/params.jl:514-560, 576-625, 776-801.  Only the entries the
+    isothermal Fickian model reads matter here; the thermal ones are listed for completeness."""
+    th = OrderedDict()
+    th["D_sp"] = 4e-15; th["k_p"] = 3.5445802224420315e-11; th["λ_MHC_p"] = 0.0; th["θ_min_p"] = 0.8395; th["θ_max_p"] = 17038.0 / 63104.0
+    th["l_p"] = 75.6e-6; th["σ_p"] = 0.18; th["ϵ_p"] = 0.335; th["ϵ_fp"] = 0.0; th["brugg_p"] = 1.5
+    th["c_max_p"] = 63104.0; th["Rp_p"] = 5.22e-06; th["Ea_D_sp"] = 0.0; th["Ea_k_p"] = 17800.0
+    th["D_sn"] = 3.3e-14; th["k_n"] = 6.716046737258585e-12; th["λ_MHC_n"] = 0.0; th["θ_max_n"] = 29866.0 / 33133; th["θ_min_n"] = 0.0481727
+    th["l_n"] = 85.2e-6; th["σ_n"] = 215.0; th["ϵ_n"] = 0.25; th["ϵ_fn"] = 0.0; th["brugg_n"] = 1.5
+    th["c_max_n"] = 33133.0; th["Rp_n"] = 5.86e-6; th["Ea_D_sn"] = 3.03e4; th["Ea_k_n"] = 35000.0
+    th["D_e"] = 8.794e-11; th["l_s"] = 12e-6; th["ϵ_s"] = 0.47; th["brugg_s"] = 1.5; th["t₊"] = 0.2594
+    th["c_e₀"] = 1000.0; th["T₀"] = 25 + 273.15; th["T_amb"] = 25 + 273.15
+    return th
+
+
 BOUNDS_DEFAULT = {
     # reference src/params.jl:233-252 (LCO) and 456-475 (NMC); NaN = disabled
     "LCO": dict(V_min=2.5, V_max=4.3, SOC_min=0.0, SOC_max=1.0, T_max=55 + 273.15, c_s_n_max=math.nan,
                 I_max=math.nan, I_min=math.nan, η_plating_min=math.nan, c_e_min=math.nan, dfilm_max=math.nan),
     "NMC": dict(V_min=2.8, V_max=4.2, SOC_min=0.0, SOC_max=1.0, T_max=math.nan, c_s_n_max=math.nan,
                 I_max=math.nan, I_min=math.nan, η_plating_min=math.nan, c_e_min=math.nan, dfilm_max=math.nan),
+    "LGM50": dict(V_min=2.5, V_max=4.2, SOC_min=0.0, SOC_max=1.0, T_max=55 + 273.15, c_s_n_max=math.nan,      # params.jl:803-813
+                  I_max=math.nan, I_min=math.nan, η_plating_min=math.nan, c_e_min=math.nan, dfilm_max=math.nan),
 }
 
 
@@ -245,7 +264,9 @@ class Model:
         self.cathode = cathode
         self.solid_diffusion, self.thermodynamic_factor, self.rxn = solid_diffusion, thermodynamic_factor, rxn
         self.lay = Layout(temperature=temperature, aging=aging, solid_diffusion=solid_diffusion, **Nkw)
-        self.theta = theta_LCO() if cathode == "LCO" else theta_NMC()
+        self.theta = {"LCO": theta_LCO, "NMC": theta_NMC, "LGM50": theta_LGM50}[cathode]()
+        if cathode in ("NMC", "LGM50") and (temperature or aging):
+            raise ValueError("LGM50 is built isothermal without aging")
         if cathode == "NMC" and temperature:
             raise ValueError("the reference NMC chemistry defines no thermal parameters (params.jl:295-367)")
         self.bounds = dict(BOUNDS_DEFAULT[cathode])
@@ -364,6 +385,28 @@ def OCV_LiC6_with_NMC(ops, x, T, thermal):
     return U, 0.0
 
 
+def OCV_NMC_LGM50(ops, x, T, thermal):
+    """params.jl:563-572 (dU/dT = 0)"""
+    return (-0.8090 * x + 4.4875 - 0.0428 * ops.tanh(18.5138 * (x - 0.5542)) - 17.7326 * ops.tanh(15.7890 * (x - 0.3117))
+            + 17.5842 * ops.tanh(15.9308 * (x - 0.3120))), 0.0
+
+
+def OCV_LiC6_LGM50(ops, x, T, thermal):
+    """params.jl:627-636 (dU/dT = 0)"""
+    return (1.9793 * ops.exp(-39.3631 * x) + 0.15561 - 0.0909 * ops.tanh(29.8538 * (x - 0.1234)) - 0.04478 * ops.tanh(14.9159 * (x - 0.2769))
+            - 0.0205 * ops.tanh(30.4444 * (x - 0.6103)) - 0.09259 * ops.tanh(17.08 * (x - 1))), 0.0
+
+
+def D_eff_LGM50_fn(D_e, c):
+    """params.jl:646"""
+    return D_e * ((c / 1000) ** 2 - 4.516715942688196 * (c / 1000) + 5.5287696156470325)
+
+
+def K_eff_LGM50_fn(ops, c):
+    """params.jl:660"""
+    return 0.1297 * (c / 1000) ** 3 - 2.51 * ops.pow(c / 1000, 1.5) + 3.329 * (c / 1000)
+
+
 def rxn_BV(ops, c_s_star, c_e, T, eta, k, c_max):
     """custom_functions.jl:212-231 (alpha = 0.5 branch, sqrt = sqrt_ReLU)"""
     return 2.0 * k * ops.sqrt(ops.relu(c_e * c_s_star * (c_max - c_s_star), 0.0)) * ops.sinh(0.5 * F_CONST * eta / (R_CONST * T))
@@ -456,8 +499,8 @@ def residual(model, ops, Y, YP, th, mode=MODE_I, value=0.0, with_control=True):
         cs_star_p = [ops.aux("csp%d" % i, c_s[i] + (th["Rp_p"] / (Dsp[i] * 35)) * (-j[i] + 8 * Dsp[i] * Qs[i])) for i in range(Np)]
         cs_star_n = [ops.aux("csn%d" % i, c_s[Np + i] + (th["Rp_n"] / (Dsn[i] * 35)) * (-j[Np + i] + 8 * Dsn[i] * Qs[Np + i])) for i in range(Nn)]
     # OCV (aux...jl:250-270)
-    ocv_p = OCV_LCO if model.cathode == "LCO" else OCV_NMC
-    ocv_n = OCV_LiC6 if model.cathode == "LCO" else OCV_LiC6_with_NMC
+    ocv_p = {"LCO": OCV_LCO, "NMC": OCV_NMC, "LGM50": OCV_NMC_LGM50}[model.cathode]
+    ocv_n = {"LCO": OCV_LiC6, "NMC": OCV_LiC6_with_NMC, "LGM50": OCV_LiC6_LGM50}[model.cathode]
     U_p, dU_p, U_n, dU_n = [], [], [], []
     for i in range(Np):
         u, d = ocv_p(ops, cs_star_p[i] / th["c_max_p"], T_p[i], thermal); U_p.append(u); dU_p.append(d)
@@ -471,10 +514,19 @@ def residual(model, ops, Y, YP, th, mode=MODE_I, value=0.0, with_control=True):
         eta_n = [eta_n[i] - F * j[Np + i] * R_film[i] for i in range(Nn)]
     # K_eff, D_eff, D_s_eff (aux...jl:302-342) with the porosity substitution of aux...jl:141-158
     bp, bs, bn = th["brugg_p"], th["brugg_s"], th["brugg_n"]
-    Kp = [ops.pow(eps_p, bp) * K_eff_fn(c_e[i], T_p[i]) for i in range(Np)]
-    Ks = [ops.pow(eps_s, bs) * K_eff_fn(c_e[Np + i], T_s[i]) for i in range(Ns)]
-    Kn = [ops.pow(eps_n, bn) * K_eff_fn(c_e[Np + Ns + i], T_n[i]) for i in range(Nn)]
-    if model.cathode == "LCO":                          # D_eff_linear, custom_functions.jl:59-69
+    if model.cathode == "LGM50":                        # K_eff_LGM50, params.jl:660-672
+        Kp = [ops.pow(eps_p, bp) * K_eff_LGM50_fn(ops, c_e[i]) for i in range(Np)]
+        Ks = [ops.pow(eps_s, bs) * K_eff_LGM50_fn(ops, c_e[Np + i]) for i in range(Ns)]
+        Kn = [ops.pow(eps_n, bn) * K_eff_LGM50_fn(ops, c_e[Np + Ns + i]) for i in range(Nn)]
+    else:
+        Kp = [ops.pow(eps_p, bp) * K_eff_fn(c_e[i], T_p[i]) for i in range(Np)]
+        Ks = [ops.pow(eps_s, bs) * K_eff_fn(c_e[Np + i], T_s[i]) for i in range(Ns)]
+        Kn = [ops.pow(eps_n, bn) * K_eff_fn(c_e[Np + Ns + i], T_n[i]) for i in range(Nn)]
+    if model.cathode == "LGM50":                        # D_eff_LGM50, params.jl:646-658
+        Dp = [ops.pow(eps_p, bp) * D_eff_LGM50_fn(th["D_e"], c_e[i]) for i in range(Np)]
+        Ds = [ops.pow(eps_s, bs) * D_eff_LGM50_fn(th["D_e"], c_e[Np + i]) for i in range(Ns)]
+        Dn = [ops.pow(eps_n, bn) * D_eff_LGM50_fn(th["D_e"], c_e[Np + Ns + i]) for i in range(Nn)]
+    elif model.cathode == "LCO":                        # D_eff_linear, custom_functions.jl:59-69
         Dp = [th["D_p"] * ops.pow(eps_p, bp)] * Np
         Ds = [th["D_s"] * ops.pow(eps_s, bs)] * Ns
         Dn = [th["D_n"] * ops.pow(eps_n, bn)] * Nn
@@ -784,8 +836,8 @@ def initial_guess_generic(model, ops, SOC, th):
             Y[i] = th["T₀"]
     if lay.aging:
         Y[lay.SOH[0]] = 1.0
-    ocv_p = OCV_LCO if model.cathode == "LCO" else OCV_NMC
-    ocv_n = OCV_LiC6 if model.cathode == "LCO" else OCV_LiC6_with_NMC
+    ocv_p = {"LCO": OCV_LCO, "NMC": OCV_NMC, "LGM50": OCV_NMC_LGM50}[model.cathode]
+    ocv_n = {"LCO": OCV_LiC6, "NMC": OCV_LiC6_with_NMC, "LGM50": OCV_LiC6_LGM50}[model.cathode]
     Up = ocv_p(ops, csp / th["c_max_p"], th["T₀"], lay.temperature)[0]
     Un = ocv_n(ops, csn / th["c_max_n"], th["T₀"], lay.temperature)[0]
     for i in range(lay.Np):

@@ -90,6 +90,9 @@ DECL_VARIANT(nmc_iso_sei)
 #ifdef ORC_HAVE_nmc_iso
 DECL_VARIANT(nmc_iso)
 #endif
+#ifdef ORC_HAVE_lgm50_iso
+DECL_VARIANT(lgm50_iso)
+#endif
 #ifdef ORC_HAVE_lco_iso_quad
 DECL_VARIANT(lco_iso_quad)
 #endif
@@ -147,6 +150,9 @@ static int get_model(const char* name, orc_model* m) {
 #endif
 #ifdef ORC_HAVE_nmc_iso
   if (!strcmp(name, "nmc_iso")) { FILL_VARIANT(m, nmc_iso, 0, 0); return 0; }
+#endif
+#ifdef ORC_HAVE_lgm50_iso
+  if (!strcmp(name, "lgm50_iso")) { FILL_VARIANT(m, lgm50_iso, 0, 0); return 0; }
 #endif
 #ifdef ORC_HAVE_lco_iso_quad
   if (!strcmp(name, "lco_iso_quad")) { FILL_VARIANT_SD(m, lco_iso_quad, 1, 0); return 0; }

@@ -19,7 +19,7 @@ PREC_F64, PREC_MIXED = 0, 1
 PART_BLOCK, PART_CYCLIC = 0, 1
 MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETA_P = 0, 1, 2, 3, 4
 VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE = 0, 1, 2, 3
-CHEM_LCO, CHEM_NMC = 0, 1
+CHEM_LCO, CHEM_NMC, CHEM_LGM50 = 0, 1, 2
 FLAG_RUNNING, ERR_INIT, ERR_STALL, ERR_MAXITERS, ERR_OUTPUT_FULL = -1, -11, -12, -13, -14
 
 BOUND_FIELDS = ["V_max", "V_min", "SOC_max", "SOC_min", "T_max", "c_s_n_max", "I_max", "I_min", "eta_plating_min",

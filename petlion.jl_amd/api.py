@@ -16,10 +16,11 @@ import math
 import numpy as np
 
 from . import _capi as cap
-from .params import EXIT_REASONS, Bounds, Opts, bounds_LCO, bounds_NMC, calc_I1C, theta_LCO, theta_NMC
+from .params import EXIT_REASONS, Bounds, Opts, bounds_LCO, bounds_LGM50, bounds_NMC, calc_I1C, theta_LCO, theta_LGM50, theta_NMC
 
 LCO = "LCO"
 NMC = "NMC"
+NMC_LGM50 = "LGM50"
 
 
 class _N:
@@ -31,8 +32,8 @@ class Model:
     """The reference's `model` struct, reduced to the data contracts of the hot path (src/structures.jl:336-345)."""
 
     def __init__(self, cathode, N, temperature, aging, lib_path=None, precision="f64", device=-1, solid_diffusion="Fickian", thermodynamic_factor="linear", rxn="BV"):
-        if cathode not in (LCO, NMC):
-            raise NotImplementedError("chemistry %r is outside the hot-path scope (LCO and NMC are built)" % (cathode,))
+        if cathode not in (LCO, NMC, NMC_LGM50):
+            raise NotImplementedError("chemistry %r is outside the hot-path scope (LCO, NMC and NMC_LGM50 are built)" % (cathode,))
         self.cathode = cathode
         self.N = N
         self.temperature = bool(temperature)
@@ -40,15 +41,15 @@ class Model:
             raise NotImplementedError("aging=%r: the reference knows false and :SEI (src/params.jl:119-174)" % (aging,))
         aging = "SEI" if aging in (True, "SEI") else False
         self.aging = aging
-        self.θ = theta_LCO() if cathode == LCO else theta_NMC()
+        self.θ = {LCO: theta_LCO, NMC: theta_NMC, NMC_LGM50: theta_LGM50}[cathode]()
         self.θ["I1C"] = calc_I1C(self.θ)
-        self.bounds = bounds_LCO() if cathode == LCO else bounds_NMC()
+        self.bounds = {LCO: bounds_LCO, NMC: bounds_NMC, NMC_LGM50: bounds_LGM50}[cathode]()
         self.opts = Opts()
         self._lib = cap.load(lib_path)
         if precision not in ("f64", "mixed"):
             raise ValueError("precision: 'f64' or 'mixed' (fp32 storage of the Newton-matrix factors, everything else fp64)")
         self.precision = precision
-        desc = cap.ModelDesc(cap.CHEM_LCO if cathode == LCO else cap.CHEM_NMC, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, int(self.temperature), int(bool(aging)), 8,
+        desc = cap.ModelDesc({LCO: cap.CHEM_LCO, NMC: cap.CHEM_NMC, NMC_LGM50: cap.CHEM_LGM50}[cathode], N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, int(self.temperature), int(bool(aging)), 8,
                              cap.PREC_MIXED if precision == "mixed" else cap.PREC_F64, int(device),
                              {"Fickian": 0, "quadratic": 1, "polynomial": 2}[solid_diffusion], {"linear": 0, "nonlinear": 1}[thermodynamic_factor], {"BV": 0, "MHC": 1}[rxn])
         self.solid_diffusion, self.thermodynamic_factor, self.rxn = solid_diffusion, thermodynamic_factor, rxn

@@ -86,7 +86,7 @@ enum Key { K_D_n, K_D_p, K_D_s, K_D_sn, K_D_sp, K_Ea_D_sn, K_Ea_D_sp, K_Ea_k_n, 
            K_tplus, K_w, K_th_max_n, K_th_max_p, K_th_min_n, K_th_min_p, K_rho_n, K_sig_n, K_sig_p, K_eps_fn, K_eps_fp, K_eps_n, K_eps_p,
            K_eps_s,
            K_Cp_a, K_Cp_n, K_Cp_p, K_Cp_s, K_Cp_z, K_T_amb, K_h_cell, K_l_a, K_l_z, K_lam_a, K_lam_n, K_lam_p, K_lam_s, K_lam_z,
-           K_rho_a, K_rho_p, K_rho_s, K_rho_z, K_sig_a, K_sig_z, K_lam_MHC_n, K_lam_MHC_p, K_COUNT };
+           K_rho_a, K_rho_p, K_rho_s, K_rho_z, K_sig_a, K_sig_z, K_lam_MHC_n, K_lam_MHC_p, K_D_e, K_COUNT };
 
 // read-only model tables in device memory
 struct Tables {
@@ -113,6 +113,7 @@ struct CellConst {
   double r2h[3], qps_r, qps_l, qsn_r, qsn_l;   // thermal: gradient-stencil factors 1/(2h), 2/(3hp+hs), 2/(hp+3hs), 2/(3hs+hn), 2/(hs+3hn)
   // quadratic / polynomial particle models: c_s* = c_avg + csj j (+ csq Q);  d c_avg/dt = csr j;  dQ/dt = -kappa Q + qj j   (index 0 = p, 1 = n)
   double csj[2], csq[2], csr[2], qj[2];
+  double De;     // LGM50: electrolyte diffusivity scale D_e
   double lam[2], mhc_k0[2], rce0;   // MHC: lambda per electrode, k_i / ((1 - erf((lambda - sqrt(1 + sqrt(lambda))) / (2 sqrt(lambda)))) / 2), 1 / c_e0
   int iso_ref;   // T0 == TREF exactly (temperature_switch, reference custom_functions.jl:1)
 };
@@ -355,6 +356,28 @@ __device__ __forceinline__ void deff_nmc(double c, double T, double& D, double& 
   dD = D * LN10 * (-54.0 * 5e-3 / (u * u) - 0.22e-3);
 }
 
+// LGM50 closures (reference src/params.jl:563-572, 627-636, 646, 660; dU/dT = 0)
+PL_DEV void ocv_nmc_lgm50(double x, double& U, double& dUdx) {
+  const double t1 = tanh(18.5138 * (x - 0.5542)), t2 = tanh(15.7890 * (x - 0.3117)), t3 = tanh(15.9308 * (x - 0.3120));
+  U = -0.8090 * x + 4.4875 - 0.0428 * t1 - 17.7326 * t2 + 17.5842 * t3;
+  dUdx = -0.8090 - 0.0428 * 18.5138 * (1.0 - t1 * t1) - 17.7326 * 15.7890 * (1.0 - t2 * t2) + 17.5842 * 15.9308 * (1.0 - t3 * t3);
+}
+PL_DEV void ocv_lic6_lgm50(double x, double& U, double& dUdx) {
+  const double e1 = exp(-39.3631 * x), t1 = tanh(29.8538 * (x - 0.1234)), t2 = tanh(14.9159 * (x - 0.2769)), t3 = tanh(30.4444 * (x - 0.6103)), t4 = tanh(17.08 * (x - 1.0));
+  U = 1.9793 * e1 + 0.15561 - 0.0909 * t1 - 0.04478 * t2 - 0.0205 * t3 - 0.09259 * t4;
+  dUdx = -39.3631 * 1.9793 * e1 - 0.0909 * 29.8538 * (1.0 - t1 * t1) - 0.04478 * 14.9159 * (1.0 - t2 * t2) - 0.0205 * 30.4444 * (1.0 - t3 * t3) - 0.09259 * 17.08 * (1.0 - t4 * t4);
+}
+PL_DEV void deff_lgm50(double c, double De, double& D, double& dD) {
+  const double x = c * 1e-3;
+  D = De * (x * x - 4.516715942688196 * x + 5.5287696156470325);
+  dD = De * (2.0 * x - 4.516715942688196) * 1e-3;
+}
+PL_DEV void keff_lgm50(double c, double& K, double& dK) {
+  const double x = c * 1e-3, sx = sqrt(x);
+  K = 0.1297 * x * x * x - 2.51 * x * sx + 3.329 * x;
+  dK = (3.0 * 0.1297 * x * x - 1.5 * 2.51 * sx + 3.329) * 1e-3;
+}
+
 // sinh and cosh from ONE expm1 and one division (ocml's sinh alone costs ~670 cycles of dependent latency on gfx950):
 //   u = e^x - 1 ;  sinh x = (u + u/(u+1))/2 ,  cosh x = sinh x + 1/(u+1)   -- accurate for small |x| as well (no cancellation)
 __device__ __forceinline__ void sinh_cosh(double x, double& sh, double& ch) {
@@ -400,7 +423,8 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     c.bf[2] = pow(c.eps[2], th[ix[K_brugg_n]]);
     if (M::CHEM == PLH_CHEM_LCO_LIC6) {                     // D_eff_linear, custom_functions.jl:59-69
       c.Dc[0] = th[ix[K_D_p]] * c.bf[0]; c.Dc[1] = th[ix[K_D_s]] * c.bf[1]; c.Dc[2] = th[ix[K_D_n]] * c.bf[2];
-    } else { c.Dc[0] = c.Dc[1] = c.Dc[2] = 0.0; }           // NMC: D_eff(c_e, T) per control volume (node pass)
+    } else { c.Dc[0] = c.Dc[1] = c.Dc[2] = 0.0; }           // NMC, LGM50: D_eff(c_e[, T]) per control volume (node pass)
+    c.De = M::CHEM == PLH_CHEM_LGM50 ? th[ix[K_D_e]] : 0.0;
     const double Rp_p = th[ix[K_Rp_p]], Rp_n = th[ix[K_Rp_n]];
     c.a_p = 3 * esp / Rp_p; c.a_n = 3 * esn / Rp_n;         // build_a!, aux...jl:124-139
     c.sig_p = th[ix[K_sig_p]] * esp; c.sig_n = th[ix[K_sig_n]] * esn;
@@ -491,6 +515,7 @@ PL_DEV void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) {
   const double csn = c.cmaxn * (SOC * (c.thmax_n - c.thmin_n) + c.thmin_n);
   double Up, Un, d;
   if (M::CHEM == PLH_CHEM_LCO_LIC6) { ocv_lco(csp / c.cmaxp, c.T0, c.iso_ref, Up, d); ocv_lic6(csn / c.cmaxn, c.T0, c.iso_ref, Un, d); }
+  else if (M::CHEM == PLH_CHEM_LGM50) { ocv_nmc_lgm50(csp / c.cmaxp, Up, d); ocv_lic6_lgm50(csn / c.cmaxn, Un, d); }
   else { ocv_nmc(csp / c.cmaxp, Up, d); ocv_lic6_nmc(csn / c.cmaxn, Un, d); }
   _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (n < NST) {
     double v = 0.0;
@@ -548,7 +573,8 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   // divisions by per-cell constants are multiplications by reciprocals formed once in cell_setup (an fp64 division costs ~80 cycles of
   // dependent latency on gfx950; the results differ from the reference's by one rounding, far below the 1e-12 residual parity bar)
   const double rh = c.rh[sc], reps = c.reps[sc];
-  double K, dK; keff(ce, cT0, K, dK);
+ double K, dK;
+  if (M::CHEM == PLH_CHEM_LGM50) keff_lgm50(ce, K, dK); else keff(ce, cT0, K, dK);
   K *= bfc; dK *= bfc;
   double nu = 1.0, dnu = 0.0;                          // thermodynamic factor of this control volume (custom_functions.jl:177-203)
   if constexpr (M::TF == 1) {
@@ -558,6 +584,7 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   }
   double D, dD;
   if (M::CHEM == PLH_CHEM_LCO_LIC6) { D = sc == 0 ? dc0 : (sc == 1 ? dc1 : dc2); dD = 0.0; }
+  else if (M::CHEM == PLH_CHEM_LGM50) { deff_lgm50(ce, c.De, D, dD); D *= bfc; dD *= bfc; }
   else { deff_nmc(ce, cT0, D, dD); D *= bfc; dD *= bfc; }
   const double ce_n = shift_down1(ce), pe_n = shift_down1(pe), K_n = shift_down1(K), dK_n = shift_down1(dK), D_n = shift_down1(D);
   const double dD_n = (WANT_JAC && M::CHEM != PLH_CHEM_LCO_LIC6) ? shift_down1(dD) : 0.0;
@@ -597,6 +624,9 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   if (M::CHEM == PLH_CHEM_LCO_LIC6) {
     if (sc == 0) ocv_lco(cs * rcm, cT0, ciso, U, dU);
     else if (sc == 2) ocv_lic6(cs * rcm, cT0, ciso, U, dU);
+  } else if (M::CHEM == PLH_CHEM_LGM50) {
+    if (sc == 0) ocv_nmc_lgm50(cs * rcm, U, dU);
+    else if (sc == 2) ocv_lic6_lgm50(cs * rcm, U, dU);
   } else {
     if (sc == 0) ocv_nmc(cs * rcm, U, dU);
     else if (sc == 2) ocv_lic6_nmc(cs * rcm, U, dU);

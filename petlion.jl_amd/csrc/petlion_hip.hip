@@ -35,7 +35,7 @@ static const char* const KEY_ENUM_NAMES[K_COUNT] = {
     "brugg_n", "brugg_p", "brugg_s", "c_e₀", "c_max_n", "c_max_p", "i_0_jside", "k_n", "k_n_aging", "k_p", "l_n", "l_p", "l_s",
     "t₊", "w", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "ρ_n", "σ_n", "σ_p", "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s",
     "Cp_a", "Cp_n", "Cp_p", "Cp_s", "Cp_z", "T_amb", "h_cell", "l_a", "l_z", "λ_a", "λ_n", "λ_p", "λ_s", "λ_z",
-    "ρ_a", "ρ_p", "ρ_s", "ρ_z", "σ_a", "σ_z", "λ_MHC_n", "λ_MHC_p"};
+    "ρ_a", "ρ_p", "ρ_s", "ρ_z", "σ_a", "σ_z", "λ_MHC_n", "λ_MHC_p", "D_e"};
 // per variant: the sorted theta_keys the reference's generated functions would receive (generate_functions.jl:327-363, 387) and
 // the chemistry defaults (reference src/params.jl:5-117, 176-226 LCO/LiC6; 295-367, 436-452 NMC/LiC6_NMC)
 static const char* const KEYS_LCO_ISO[] = {
@@ -89,9 +89,17 @@ static const double DEFAULTS_LCO_MHC[] = {
     7.5e-10, 7.5e-10, 7.5e-10, 3.9e-14, 1e-14, 5000.0, 5000.0, 5000.0, 5000.0, 2e-6, 2e-6, 25 + 273.15, 4.0, 4.0, 4.0,
     1000.0, 30555.0, 51554.0, 5.0310e-11, 2.334e-11, 88e-6, 80e-6, 25e-6, 0.364, 0.85510, 0.49550, 0.01429, 0.99174, 6.26e-20, 6.26e-20, 100.0, 100.0,
     0.0326, 0.025, 0.485, 0.385, 0.724};
+// NMC_LGM50 + LiC6_LGM50 + system_LGM50_NMC_LiC6 (Chen et al. 2020): reference src/params.jl:514-560, 576-625, 776-801
+static const char* const KEYS_LGM50_ISO[] = {
+    "D_e", "D_sn", "D_sp", "Ea_D_sn", "Ea_D_sp", "Ea_k_n", "Ea_k_p", "Rp_n", "Rp_p", "T₀", "brugg_n", "brugg_p", "brugg_s", "c_e₀", "c_max_n", "c_max_p",
+    "k_n", "k_p", "l_n", "l_p", "l_s", "t₊", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "σ_n", "σ_p", "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s"};
+static const double DEFAULTS_LGM50_ISO[] = {
+    8.794e-11, 3.3e-14, 4e-15, 3.03e4, 0.0, 35000.0, 17800.0, 5.86e-6, 5.22e-06, 25 + 273.15, 1.5, 1.5, 1.5, 1000.0, 33133.0, 63104.0,
+    6.716046737258585e-12, 3.5445802224420315e-11, 85.2e-6, 75.6e-6, 12e-6, 0.2594, 29866.0 / 33133, 17038.0 / 63104.0, 0.0481727, 0.8395, 215.0, 0.18, 0.0, 0.0, 0.25, 0.335, 0.47};
 struct VariantInfo { int nkeys; const char* const* keys; const double* defaults; };
 // parameter set of a variant: by (chemistry, SEI, temperature); the mixed-precision variants share their fp64 sibling's
 static VariantInfo variant_keys(int chem, int sei, int thermal, int rxn) {
+  if (chem == PLH_CHEM_LGM50) return {33, KEYS_LGM50_ISO, DEFAULTS_LGM50_ISO};
   if (rxn == PLH_RXN_MHC) return {37, KEYS_LCO_MHC, DEFAULTS_LCO_MHC};
   if (thermal) return {56, KEYS_LCO_THERMAL, DEFAULTS_LCO_THERMAL};
   if (chem == PLH_CHEM_LCO_LIC6) return sei ? VariantInfo{42, KEYS_LCO_SEI, DEFAULTS_LCO_SEI} : VariantInfo{35, KEYS_LCO_ISO, DEFAULTS_LCO_ISO};
@@ -286,7 +294,7 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   if (!d || !out) return fail(PLH_E_ARG, "null argument");
   if (d->real_bytes != 8) return fail(PLH_E_UNSUPPORTED, "states, residuals and time are fp64 (real_bytes = 8); reduced precision is selected with precision = PLH_PREC_MIXED");
   if (d->precision != PLH_PREC_F64 && d->precision != PLH_PREC_MIXED) return fail(PLH_E_ARG, "precision must be PLH_PREC_F64 or PLH_PREC_MIXED");
-  if (d->chemistry != PLH_CHEM_LCO_LIC6 && d->chemistry != PLH_CHEM_NMC_LIC6) return fail(PLH_E_UNSUPPORTED, "unknown chemistry");
+  if (d->chemistry != PLH_CHEM_LCO_LIC6 && d->chemistry != PLH_CHEM_NMC_LIC6 && d->chemistry != PLH_CHEM_LGM50) return fail(PLH_E_UNSUPPORTED, "unknown chemistry");
   if (d->solid_diffusion < 0 || d->solid_diffusion > PLH_SD_POLYNOMIAL || d->thermodynamic_factor < 0 || d->thermodynamic_factor > 1 || d->rxn < 0 || d->rxn > 1)
     return fail(PLH_E_ARG, "solid_diffusion / thermodynamic_factor / rxn out of range");
   const VariantOps* ops = nullptr;
@@ -296,7 +304,7 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
         o->sd == d->solid_diffusion && o->tf == d->thermodynamic_factor && o->rxn == d->rxn) ops = o;
   }
   if (!ops) return fail(PLH_E_UNSUPPORTED, "this chemistry / temperature / aging / precision / model-option combination is not instantiated on the device (built in fp64: LCO and NMC "
-                                           "isothermal with or without SEI aging, LCO with temperature; LCO isothermal with ONE of: quadratic or polynomial solid diffusion, the nonlinear "
+                                           "isothermal with or without SEI aging, LGM50 isothermal, LCO with temperature; LCO isothermal with ONE of: quadratic or polynomial solid diffusion, the nonlinear "
                                            "thermodynamic factor, MHC kinetics; mixed precision: LCO isothermal, NMC + SEI, LCO with temperature)");
   if (d->temperature && (d->N_a != NA || d->N_z != NZ)) return fail(PLH_E_UNSUPPORTED, "discretisation: only N_a = N_z = 10 is instantiated");
   if (d->N_p != NP || d->N_s != NS || d->N_n != NN || (d->solid_diffusion == PLH_SD_FICKIAN && (d->N_r_p != NR || d->N_r_n != NR)))

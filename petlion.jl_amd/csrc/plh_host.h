@@ -20,8 +20,9 @@
   X(8, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_QUADRATIC, PLH_TF_LINEAR, PLH_RXN_BV)        \
   X(9, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_POLYNOMIAL, PLH_TF_LINEAR, PLH_RXN_BV)       \
   X(10, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_NONLINEAR, PLH_RXN_BV)      \
-  X(11, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_MHC)
-constexpr int PL_N_VARIANTS = 12;
+  X(11, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_MHC)       \
+  X(12, PLH_CHEM_LGM50, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV)
+constexpr int PL_N_VARIANTS = 13;
 
 struct IntegrateArgs {
   const pl::Tables* tb; int n_cells; const double* theta; const double* SOC0; const double* Y_init; const double* t_init; int n_runs; const plh_run* runs; plh_opts opts;

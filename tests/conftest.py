@@ -88,16 +88,16 @@ def hip_model_thermal(pkg, hip_model):
 
 
 F4_OPTIONS = {"quad": dict(solid_diffusion="quadratic"), "poly": dict(solid_diffusion="polynomial"), "nu": dict(thermodynamic_factor="nonlinear"),
-              "mhc": dict(rxn_p="MHC", rxn_n="MHC")}
+              "mhc": dict(rxn_p="MHC", rxn_n="MHC"), "lgm50": dict(cathode="LGM50")}
 
 
 @pytest.fixture(scope="session")
 def emu_models_f4(pkg):
     """SURVEY 8(f).4 model variants on the wave emulator: quadratic / polynomial solid diffusion, nonlinear thermodynamic factor, MHC kinetics"""
     import build_emu
-    return {k: pkg.petlion(pkg.LCO, _lib_path=build_emu.build(), **kw) for k, kw in F4_OPTIONS.items()}
+    return {k: pkg.petlion(kw.get("cathode", pkg.LCO), _lib_path=build_emu.build(), **{a: b for a, b in kw.items() if a != "cathode"}) for k, kw in F4_OPTIONS.items()}
 
 
 @pytest.fixture(scope="session")
 def hip_models_f4(pkg, hip_model):
-    return {k: pkg.petlion(pkg.LCO, **kw) for k, kw in F4_OPTIONS.items()}
+    return {k: pkg.petlion(kw.get("cathode", pkg.LCO), **{a: b for a, b in kw.items() if a != "cathode"}) for k, kw in F4_OPTIONS.items()}

@@ -43,6 +43,8 @@ def test_unsupported_options_are_refused(pkg):
     with pytest.raises(NotImplementedError):
         pkg.petlion("LFP")
     with pytest.raises(NotImplementedError):
+        pkg.petlion(pkg.LCO, solid_diffusion="Fickian", Fickian_method="spectral")
+    with pytest.raises(NotImplementedError):
         pkg.petlion(pkg.LCO, aging="R_film")
 
 

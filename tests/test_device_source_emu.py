@@ -392,3 +392,11 @@ def test_f4_nonlinear_thermodynamic_factor(emu_models_f4, O, pkg):
 def test_f4_mhc_kinetics(emu_models_f4, O, pkg):
     """rxn_MHC (custom_functions.jl:241-298): evaluators at lambda = 8 / 6 (the erf matters) and trajectories"""
     check_f4_variant(emu_models_f4["mhc"], O, pkg, "mhc")
+
+
+def test_f4_lgm50_chemistry(emu_models_f4, O, pkg):
+    """NMC_LGM50 + LiC6_LGM50 (Chen et al. 2020, reference src/params.jl:514-849): tanh OCVs, D_eff(c_e) and K_eff(c_e) closures, 33 parameters"""
+    p = emu_models_f4["lgm50"]
+    assert "D_e" in p.θ_keys and "D_p" not in p.θ_keys and len(p.θ_keys) == 33
+    ens = check_f4_variant(p, O, pkg, "lgm50")
+    assert ens.run_info[0, 0]["flag"] == 1 and 3500.0 < ens.run_info[0, 0]["t_end"] < 3600.0          # a 1C discharge ends on V_min = 2.5 V shortly before 1 h
