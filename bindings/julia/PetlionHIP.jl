@@ -24,6 +24,7 @@ struct ModelDesc
     precision::Cint      # 0 = fp64, 1 = mixed (fp32 storage of the Newton-matrix factors)
     device::Cint         # HIP device ordinal, -1 = current
     solid_diffusion::Cint; thermodynamic_factor::Cint; rxn::Cint     # 0 Fickian FDM / 1 quadratic / 2 polynomial ; 0 linear / 1 nonlinear ; 0 BV / 1 MHC
+    waves_per_cell::Cint  # 1 (default) or 2 wavefronts per cell
 end
 struct Bounds      # boundary_stop_conditions, src/structures.jl:237-250
     V_max::Cdouble; V_min::Cdouble; SOC_max::Cdouble; SOC_min::Cdouble; T_max::Cdouble; c_s_n_max::Cdouble
@@ -59,12 +60,12 @@ check(rc, what) = rc == 0 || error("$what failed ($rc): $(lasterror())")
 mutable struct Model
     h::Ptr{Cvoid}
     N::Int; N_diff::Int; θ_keys::Vector{Symbol}
-    function Model(p; precision = 0, device = -1)   # p::PETLION.model -- reads only p.N and p.numerics
+    function Model(p; precision = 0, device = -1, waves_per_cell = 1)   # p::PETLION.model -- reads only p.N and p.numerics
         N = p.N
         chem = Dict(:LCO => 0, :NMC => 1, :NMC_LGM50 => 2)[Symbol(p.numerics.cathode)]      # function name of the cathode system, as in strings_directory_func
         d = Ref(ModelDesc(chem, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, p.numerics.temperature == true, p.numerics.aging == :SEI, 8, precision, device,
                           Dict(:Fickian => 0, :quadratic => 1, :polynomial => 2)[p.numerics.solid_diffusion],
-                          p.numerics.thermodynamic_factor === PETLION_thermodynamic_factor_nonlinear(p) ? 1 : 0, p.numerics.rxn_p === PETLION_rxn_MHC(p) ? 1 : 0))
+                          p.numerics.thermodynamic_factor === PETLION_thermodynamic_factor_nonlinear(p) ? 1 : 0, p.numerics.rxn_p === PETLION_rxn_MHC(p) ? 1 : 0, waves_per_cell))
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:plh_model_create, lib), Cint, (Ref{ModelDesc}, Ref{Ptr{Cvoid}}), d, h), "plh_model_create")
         n = ccall((:plh_n_theta, lib), Cint, (Ptr{Cvoid},), h[])

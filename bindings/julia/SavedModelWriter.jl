@@ -28,15 +28,15 @@ const RESIDUAL_SIG = "(Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble
 const JACOBIAN_SIG = "(Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cint, Ptr{Cdouble}, Cint, Ptr{Cvoid})"
 
 "text shared by the five files: open the library, create the handle for the same structural options"
-function prelude(libpath, desc::NTuple{16,Int})
+function prelude(libpath, desc::NTuple{17,Int})
     """
     let
         dl = Base.Libc.Libdl.dlopen($(repr(abspath(libpath))))
         sym(s) = Base.Libc.Libdl.dlsym(dl, s)
         lasterr() = unsafe_string(ccall(sym(:plh_last_error), Cstring, ()))
-        desc = Ref{NTuple{16,Cint}}(Cint.($(desc)))          # plh_model_desc: sixteen ints (include/petlion_hip.h)
+        desc = Ref{NTuple{17,Cint}}(Cint.($(desc)))          # plh_model_desc: seventeen ints (include/petlion_hip.h)
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        ccall(sym(:plh_model_create), Cint, (Ref{NTuple{16,Cint}}, Ref{Ptr{Cvoid}}), desc, h) == 0 || error("plh_model_create: " * lasterr())
+        ccall(sym(:plh_model_create), Cint, (Ref{NTuple{17,Cint}}, Ref{Ptr{Cvoid}}), desc, h) == 0 || error("plh_model_create: " * lasterr())
         N = Int(ccall(sym(:plh_n_states), Cint, (Ptr{Cvoid},), h[])); Nd = Int(ccall(sym(:plh_n_diff), Cint, (Ptr{Cvoid},), h[]))
         f_res = sym(:plh_residual); f_jac = sym(:plh_jacobian); f_guess = sym(:plh_initial_guess)
         buf = zeros(N)
@@ -100,7 +100,7 @@ function install(cathode = PETLION.LCO; libpath = PetlionHIP.lib, kwargs...)
     desc = (Dict(:LCO => 0, :NMC => 1, :NMC_LGM50 => 2)[Symbol(p0.numerics.cathode)], n.p, n.s, n.n, n.a, n.z, n.r_p, n.r_n,
             Int(p0.numerics.temperature == true), Int(p0.numerics.aging == :SEI), 8, 0, -1,     # fp64, current device
             Dict(:Fickian => 0, :quadratic => 1, :polynomial => 2)[p0.numerics.solid_diffusion],
-            Int(p0.numerics.thermodynamic_factor === PETLION.thermodynamic_factor), Int(p0.numerics.rxn_p === PETLION.rxn_MHC))
+            Int(p0.numerics.thermodynamic_factor === PETLION.thermodynamic_factor), Int(p0.numerics.rxn_p === PETLION.rxn_MHC), 1)
     pre = prelude(libpath, desc)
     dir = PETLION.strings_directory_func(p0; create_dir = true) * "/"
     write(dir * "info.txt", PETLION.model_info(p0))

@@ -93,6 +93,8 @@ typedef struct {
   int solid_diffusion;                            /* PLH_SD_* */
   int thermodynamic_factor;                       /* PLH_TF_* */
   int rxn;                                        /* PLH_RXN_* */
+  int waves_per_cell;                             /* 0 or 1: one wavefront integrates one cell (every variant); 2: two wavefronts per cell -- wave 1 owns the particle rows and
+                                                     runs next to wave 0's finite-volume work (LCO isothermal Fickian fp64 only).  Same algorithm, same results to rounding. */
 } plh_model_desc;
 
 /* reference boundary_stop_conditions (src/structures.jl:237-250); NaN disables a bound */

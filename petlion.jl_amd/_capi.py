@@ -28,7 +28,7 @@ BOUND_FIELDS = ["V_max", "V_min", "SOC_max", "SOC_min", "T_max", "c_s_n_max", "I
 
 class ModelDesc(C.Structure):
     _fields_ = [(f, C.c_int) for f in ["chemistry", "N_p", "N_s", "N_n", "N_a", "N_z", "N_r_p", "N_r_n", "temperature",
-                                      "aging_SEI", "real_bytes", "precision", "device", "solid_diffusion", "thermodynamic_factor", "rxn"]]
+                                      "aging_SEI", "real_bytes", "precision", "device", "solid_diffusion", "thermodynamic_factor", "rxn", "waves_per_cell"]]
 
 
 class Bounds(C.Structure):

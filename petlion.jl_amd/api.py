@@ -31,7 +31,7 @@ class _N:
 class Model:
     """The reference's `model` struct, reduced to the data contracts of the hot path (src/structures.jl:336-345)."""
 
-    def __init__(self, cathode, N, temperature, aging, lib_path=None, precision="f64", device=-1, solid_diffusion="Fickian", thermodynamic_factor="linear", rxn="BV"):
+    def __init__(self, cathode, N, temperature, aging, lib_path=None, precision="f64", device=-1, solid_diffusion="Fickian", thermodynamic_factor="linear", rxn="BV", waves_per_cell=1):
         if cathode not in (LCO, NMC, NMC_LGM50):
             raise NotImplementedError("chemistry %r is outside the hot-path scope (LCO, NMC and NMC_LGM50 are built)" % (cathode,))
         self.cathode = cathode
@@ -51,7 +51,8 @@ class Model:
         self.precision = precision
         desc = cap.ModelDesc({LCO: cap.CHEM_LCO, NMC: cap.CHEM_NMC, NMC_LGM50: cap.CHEM_LGM50}[cathode], N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, int(self.temperature), int(bool(aging)), 8,
                              cap.PREC_MIXED if precision == "mixed" else cap.PREC_F64, int(device),
-                             {"Fickian": 0, "quadratic": 1, "polynomial": 2}[solid_diffusion], {"linear": 0, "nonlinear": 1}[thermodynamic_factor], {"BV": 0, "MHC": 1}[rxn])
+                             {"Fickian": 0, "quadratic": 1, "polynomial": 2}[solid_diffusion], {"linear": 0, "nonlinear": 1}[thermodynamic_factor], {"BV": 0, "MHC": 1}[rxn], int(waves_per_cell))
+        self.waves_per_cell = int(waves_per_cell)
         self.solid_diffusion, self.thermodynamic_factor, self.rxn = solid_diffusion, thermodynamic_factor, rxn
         h = C.c_void_p()
         cap.check(self._lib, self._lib.plh_model_create(C.byref(desc), C.byref(h)), "plh_model_create")
@@ -98,14 +99,14 @@ class Model:
 
 def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_r_n=10, temperature=False,
             solid_diffusion="Fickian", Fickian_method="finite_difference", aging=False, jacobian="symbolic", SOC=1.0,
-            thermodynamic_factor="linear", rxn_p="BV", rxn_n="BV", precision="f64", device=-1, _lib_path=None):
+            thermodynamic_factor="linear", rxn_p="BV", rxn_n="BV", precision="f64", device=-1, waves_per_cell=1, _lib_path=None):
     """petlion(cathode; kwargs...) -- reference src/params.jl:119-174.  `jacobian` is accepted and ignored (the device
     Jacobian is hand-derived); unsupported structural options raise."""
     if solid_diffusion not in ("Fickian", "quadratic", "polynomial") or (solid_diffusion == "Fickian" and Fickian_method != "finite_difference"):
         raise NotImplementedError("solid diffusion: Fickian (finite_difference), quadratic and polynomial are built; the BETA spectral method is not (SURVEY.md 8f)")
     if thermodynamic_factor not in ("linear", "nonlinear") or rxn_p not in ("BV", "MHC") or rxn_n != rxn_p:
         raise NotImplementedError("thermodynamic_factor: linear / nonlinear; rxn_p = rxn_n in (BV, MHC)")
-    p = Model(cathode, _N(p=N_p, s=N_s, n=N_n, a=N_a, z=N_z, r_p=N_r_p, r_n=N_r_n), temperature, aging, _lib_path, precision, device, solid_diffusion, thermodynamic_factor, rxn_p)
+    p = Model(cathode, _N(p=N_p, s=N_s, n=N_n, a=N_a, z=N_z, r_p=N_r_p, r_n=N_r_n), temperature, aging, _lib_path, precision, device, solid_diffusion, thermodynamic_factor, rxn_p, waves_per_cell)
     p.opts.SOC = SOC
     return p
 

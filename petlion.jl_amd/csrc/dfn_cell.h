@@ -44,9 +44,15 @@ constexpr int MAXORD = 5;
 // SD_: solid diffusion -- PLH_SD_FICKIAN (9th-order finite differences, N_r nodes per particle), PLH_SD_QUADRATIC, PLH_SD_POLYNOMIAL (one volume-averaged
 //      concentration per particle, the polynomial variant with the extra state Q: residuals.jl:108-127, 237-258, aux...jl:212-248)
 // TF_: thermodynamic factor -- 0 linear (nu = 1), 1 nonlinear nu(c_e, T) (custom_functions.jl:177-203);  RXN_: 0 Butler-Volmer, 1 Marcus-Hush-Chidsey (:212-298)
-template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false, int SD_ = 0, int TF_ = 0, int RXN_ = 0> struct ModelT {
+// W2_: two wavefronts per cell (a 128-thread workgroup; isothermal Fickian models): wave 1 owns the particle rows -- c_s residual rows, particle resolvents, particle
+//      partial solves and back-substitution, and the c_s entries of every vector phase -- and runs them next to wave 0's node pass / elimination / sweeps; the two waves of
+//      a cell share its LDS block and meet at s_barrier (PL_XSYNC).  Two waves per SIMD also means 256 registers per wave instead of 512.
+template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false, int SD_ = 0, int TF_ = 0, int RXN_ = 0, int W2_ = 0> struct ModelT {
   static constexpr int CHEM = CHEM_;                 // PLH_CHEM_LCO_LIC6 / PLH_CHEM_NMC_LIC6
   static constexpr int SD = SD_, TF = TF_, RXN = RXN_;
+  static constexpr bool W2 = W2_ != 0;
+  static constexpr int NWAVES = W2_ ? 2 : 1;
+  static_assert(W2_ == 0 || (SD_ == 0 && !SEI_ && !THERMAL_), "two waves per cell: isothermal Fickian models without aging");
   static_assert(SD_ == 0 || (!SEI_ && !THERMAL_), "the quadratic / polynomial particle models are instantiated for the isothermal models without aging");
   static constexpr int NCS = SD_ == 0 ? NJ * NR : NJ;    // entries of c_s_avg
   static constexpr int N_CECS = O_CS + NCS;
@@ -70,7 +76,9 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false, int 
   static constexpr int O_J = NDIFF, O_PE = O_J + NJ, O_PS = O_PE + NE, O_JS = O_PS + NJ, O_I = SEI_ ? O_JS + NN : O_PS + NJ;
   static constexpr int NST = O_I + 1, NALG = NST - NDIFF;
   static constexpr int NPAD = NST + (NST & 1);
-  static constexpr int NTRIP = (NST + WAVE - 1) / WAVE;
+  // trips of a lane through a state vector: one wave strides the whole vector; with two waves, wave 1 strides the NCS particle entries (4 trips), wave 0 the
+  // other NST - NCS entries (2 trips) -- see vrow / vok
+  static constexpr int NTRIP = W2_ ? (NCS + WAVE - 1) / WAVE : (NST + WAVE - 1) / WAVE;
 };
 using ModelLcoIso = ModelT<PLH_CHEM_LCO_LIC6, false>;
 #define PL_MODEL(M) [[maybe_unused]] constexpr int O_J = M::O_J, O_PE = M::O_PE, O_PS = M::O_PS, O_I = M::O_I, NST = M::NST, NDIFF = M::NDIFF, NTRIP = M::NTRIP, \
@@ -181,6 +189,7 @@ template <class M> struct CellLDS {
   double ctrlJ[2], bord;           // P-mode control row at the last Jacobian pass (I*I1C, V*I1C); border pivot d - v.x2
   double w9[NJ];
   double sig[2];
+  double red[M::W2 ? 16 : 1];      // two waves per cell: partial sums of the cross-wave reductions (ring of 4 x 2 waves x up to 2... see block_sum)
   SeiPool<M::SEI> sei;
   ThermalPool<M::THERMAL, M::MIXED> th;
   // wave-uniform BDF coefficient arrays (dynamically indexed by the order -> LDS, not registers/scratch)
@@ -198,7 +207,8 @@ struct LaneRegs {
   double wreg[4];       // particle partial solutions kept across the Thomas phase
 };
 
-__device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
+__device__ __forceinline__ int lane_id() { return (int)threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ int wave_id() { return (int)threadIdx.x >> 6; }     // 0 for the one-wave kernels; 0 / 1 for M::W2
 
 // Phase separator between LDS producers and consumers.  A workgroup here is exactly ONE wavefront, and the LDS instructions of one
 // wave execute in program order, so no s_barrier is needed -- and __syncthreads() would cost a workgroup-scope fence that also
@@ -206,15 +216,26 @@ __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
 // a compiler barrier (the compiler still inserts the lgkmcnt waits that real data dependences need); the lock-step emulator
 // yields to the other lanes.
 #ifdef PL_WAVE_EMU
-#define PL_SYNC() __syncthreads()
+#define PL_SYNC() wave_emu::yield()
 #else
 #define PL_SYNC() __asm__ volatile("" ::: "memory")
 #endif
+// Hand-over between the two waves of a cell (M::W2): a real workgroup barrier; for the one-wave models it is PL_SYNC.  (`M` must be in scope.)
+#define PL_XSYNC() do { if constexpr (M::W2) __syncthreads(); else PL_SYNC(); } while (0)
+// row of the state vector a lane handles in trip k of a vector phase, and whether that trip is live
+template <class M> __device__ __forceinline__ int vrow(int k, int lane, int wv) {
+  if constexpr (!M::W2) return lane + WAVE * k;
+  else { const int m = lane + WAVE * k; return wv ? O_CS + m : (m < O_CS ? m : m + M::NCS); }
+}
+template <class M> __device__ __forceinline__ bool vok(int k, int lane, int wv) {
+  if constexpr (!M::W2) return k < M::NST / WAVE || lane + WAVE * k < M::NST;
+  else return lane + WAVE * k < (wv ? M::NCS : M::NST - M::NCS);
+}
 
 // Emulator only: with PL_EMU_POISON=1 in the environment the LDS block starts as garbage (on the GPU it holds whatever the previous workgroup
 // left there; the emulator's static storage would hide a read of never-written LDS behind zeros).  tests/wave_emu poisons the lane stacks too.
 #ifdef PL_WAVE_EMU
-#define PL_EMU_POISON(S_) do { if (getenv("PL_EMU_POISON")) { if (lane_id() == 0) memset((void*)&(S_), 0x7f, sizeof(S_)); __syncthreads(); } } while (0)
+#define PL_EMU_POISON(S_) do { if (getenv("PL_EMU_POISON")) { if (threadIdx.x == 0) memset((void*)&(S_), 0x7f, sizeof(S_)); __syncthreads(); } } while (0)
 #else
 #define PL_EMU_POISON(S_) do {} while (0)
 #endif
@@ -226,7 +247,7 @@ __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
 enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_OUTPUT, PH_TOTAL };
 #if defined(PL_PHASE_TIMERS) && !defined(PL_WAVE_EMU)
 #define PL_TIC_() long long pl_t0__ = (long long)__builtin_readcyclecounter()
-#define PL_TOC_(S_, ph) do { if (lane_id() == 0) (S_).cyc[ph] += (long long)__builtin_readcyclecounter() - pl_t0__; } while (0)
+#define PL_TOC_(S_, ph) do { if (threadIdx.x == 0) (S_).cyc[ph] += (long long)__builtin_readcyclecounter() - pl_t0__; } while (0)
 #else
 #define PL_TIC_() do {} while (0)
 #define PL_TOC_(S_, ph) do {} while (0)
@@ -239,7 +260,7 @@ enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_O
 #define PL_TIC_TOTAL() PL_TIC_()
 #define PL_TOC_TOTAL(S_) PL_TOC_(S_, PH_TOTAL)
 #define PL_TICD() PL_TIC_()
-#define PL_TOCD(S_, slot) do { const long long now__ = (long long)__builtin_readcyclecounter(); if (lane_id() == 0) (S_).cyc[slot] += now__ - pl_t0__; pl_t0__ = now__; } while (0)   /* lap timer */
+#define PL_TOCD(S_, slot) do { const long long now__ = (long long)__builtin_readcyclecounter(); if (threadIdx.x == 0) (S_).cyc[slot] += now__ - pl_t0__; pl_t0__ = now__; } while (0)   /* lap timer */
 #else
 #define PL_TIC() PL_TIC_()
 #define PL_TOC(S_, ph) PL_TOC_(S_, ph)
@@ -277,6 +298,28 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
 }
 #endif
+
+// sum over all lanes of the cell: one wave, or (M::W2) both waves through two LDS slots and two barriers (every thread of the workgroup must call it)
+template <class M, class LDS> __device__ __forceinline__ double block_sum(LDS& S, double v) {
+  const double s = wave_sum(v);
+  if constexpr (!M::W2) return s;
+  else {
+    if (lane_id() == 0) S.red[wave_id()] = s;
+    __syncthreads();
+    const double r = S.red[0] + S.red[1];
+    __syncthreads();
+    return r;
+  }
+}
+template <class M, class LDS> __device__ __forceinline__ void block_sum3(LDS& S, double& a, double& b, double& c) {
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  if constexpr (M::W2) {
+    if (lane_id() == 0) { S.red[wave_id() * 4] = a; S.red[wave_id() * 4 + 1] = b; S.red[wave_id() * 4 + 2] = c; }
+    __syncthreads();
+    a = S.red[0] + S.red[4]; b = S.red[1] + S.red[5]; c = S.red[2] + S.red[6];
+    __syncthreads();
+  }
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // closures (reference src/physics_equations/custom_functions.jl)
@@ -407,7 +450,7 @@ template <class M>
 PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, const double* __restrict__ th) {
   PL_MODEL(M);
   const int lane = lane_id();
-  if (lane == 0) {
+  if (lane == 0 && wave_id() == 0) {
     CellConst& c = S.cc;
     const int* ix = tb->thidx;
     const double lp = th[ix[K_l_p]], ls = th[ix[K_l_s]], ln = th[ix[K_l_n]];
@@ -499,9 +542,9 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
       S.sei.cjf = 0.0;
     }
   }
-  if constexpr (!M::THERMAL && M::SD == 0) { for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->M[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
+  if constexpr (!M::THERMAL && M::SD == 0) { if (wave_id() == M::NWAVES - 1) for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->M[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
   for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
-  PL_SYNC();
+  PL_XSYNC();
   if constexpr (M::THERMAL) thermal_setup(S, tb, th);
 }
 
@@ -517,7 +560,7 @@ PL_DEV void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) {
   if (M::CHEM == PLH_CHEM_LCO_LIC6) { ocv_lco(csp / c.cmaxp, c.T0, c.iso_ref, Up, d); ocv_lic6(csn / c.cmaxn, c.T0, c.iso_ref, Un, d); }
   else if (M::CHEM == PLH_CHEM_LGM50) { ocv_nmc_lgm50(csp / c.cmaxp, Up, d); ocv_lic6_lgm50(csn / c.cmaxn, Un, d); }
   else { ocv_nmc(csp / c.cmaxp, Up, d); ocv_lic6_nmc(csn / c.cmaxn, Un, d); }
-  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (n < NST) {
+  _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wave_id()); vok<M>(k__, lane, wave_id())) {
     double v = 0.0;
     if (n < O_CS) v = c.ce0;
     else if (n < O_CS + (M::SD == 0 ? NP * NR : NP)) v = csp;
@@ -528,7 +571,7 @@ PL_DEV void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) {
     else if (M::SEI && n == O_SOH) v = 1.0;               // film = 0, SOH = 1, j_s = 0 (states_definition.jl:80-121)
     Y[n] = v;
   }
-  PL_SYNC();
+  PL_XSYNC();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -537,6 +580,7 @@ PL_DEV void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) {
 template <bool WANT_RES, bool WANT_JAC, class M>
 PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
   PL_MODEL(M);
+  if constexpr (M::W2) { if (wave_id() != 0) return; }       // two waves per cell: the finite-volume rows belong to wave 0
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const int i = lane < NE ? lane : NE - 1;
@@ -775,6 +819,7 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
 template <class M>
 PL_DEV void iso_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
   PL_MODEL(M);
+  if constexpr (M::W2) { if (wave_id() != 1) return; }       // two waves per cell: the particle rows belong to wave 1
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
@@ -825,7 +870,7 @@ PL_DEV void cell_residual(CellLDS<M>& S, const LaneRegs& R, const double* Y, con
   cell_node_pass<true, false>(S, Y, YP, Fo, mode, value);
   if constexpr (M::THERMAL) PL_SYNC();                      // the particle rows read the per-node D_s(T) written by the node pass
   cell_cs_rows<false>(S, R, Y, YP, Fo);
-  PL_SYNC();
+  PL_SYNC();                                                // (two waves per cell: every wave has written its own rows of Fo; whoever reads across waves synchronises first)
 }
 // residual + Jacobian partials in one pass (the Newton-matrix refresh of the corrector)
 template <class M>
@@ -946,7 +991,7 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
   if constexpr (M::SD != 0) {
     if (lane < 2) { S.rcjf[lane][0] = alg_only ? 0.0 : -1.0 / cj; S.rcjf[lane][1] = alg_only ? 0.0 : 1.0 / (-(lane == 0 ? c.kap_p : c.kap_n) - cj); }   // -1/cj, 1/(-kappa - cj)
   } else
-  if (!alg_only) {
+  if (!alg_only && (!M::W2 || wave_id() == 1)) {          // (two waves per cell: the resolvents are wave 1's, next to wave 0's Jacobian node pass)
     const int r = lane % NR;
     // the 20 reciprocals 1/(kappa lam_m - cj) are formed by 20 lanes in parallel and passed through S.w9 (free outside the solves)
     if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * tb->LAM[r] - cj);
@@ -962,7 +1007,8 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
       if (lane == NR - 1) S.sig[el] = acc[NR - 1];
     }
   }
-  PL_SYNC();
+  PL_XSYNC();
+  if constexpr (M::W2) { if (wave_id() != 0) return; }    // two waves per cell: the node-local elimination, the block factorisation and the border are wave 0's
   // 2. node-local elimination.  Without SEI the local unknown is j (pivot d = -1 - gcs sigma bj after the particle Schur complement);
   //    with SEI the anode nodes eliminate u = (j, j_s, film) through the inverse W of their 3x3 local block.  Both cases reduce to
   //    D[r][c] -= t_r phi_c with t = (ceJ, peJ, psJ) (j and j_s enter the node rows only through j_total) and phi = omega . A_ux,
@@ -1089,7 +1135,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   const int r = lane % NR, g = lane / NR;
   // a. particle partial solutions  w = A^-1 b_cs : four independent accumulation chains (pass = particles pass*6 .. pass*6+5)
   if constexpr (M::SD == 0)
-  if (!alg_only) {
+  if (!alg_only && (!M::W2 || wave_id() == 1)) {
     const int gg = lane < 60 ? g : 5;
     int pp[4]; double w[4];
 #pragma unroll
@@ -1116,7 +1162,8 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
       R.wreg[pass] = w[pass];
     }
   }
-  PL_SYNC();
+  PL_XSYNC();
+  if (!M::W2 || wave_id() == 0) {                       // b .. e: wave 0 (two waves per cell)
   // b. fold c_s and j elimination into the node right-hand sides
   double bjp = 0.0, bjs = 0.0, bfl = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0;
   [[maybe_unused]] double bca = 0.0, bq = 0.0;       // right-hand sides of the c_avg / Q rows of this node (quadratic / polynomial particles)
@@ -1209,10 +1256,11 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
     if (lane == 0 && !alg_only) b[O_SOH] = (sd - b[O_SOH]) / S.sei.cjf;
   }
   if (lane == 0) b[O_I] = xI;
-  PL_SYNC();
+  }
+  PL_XSYNC();
   // f. particles:  dc = w - (A^-1 e_last) * bj * dj
   if constexpr (M::SD == 0)
-  if (!alg_only) {
+  if (!alg_only && (!M::W2 || wave_id() == 1)) {
     for (int pass = 0; pass < 4; pass++) {
       const int p = pass * 6 + g;
       if (lane < 60 && p < NJ) {
@@ -1328,27 +1376,30 @@ PL_DEV void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restr
   const int* __restrict__ ptr = tb->csr_ptr[jm]; const unsigned* __restrict__ code = tb->csr_code[jm]; const unsigned short* __restrict__ col = tb->csr_col[jm];
   const double cj = alg_only ? 0.0 : cjf;
   double xr[NTRIP];
-  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (n < NST) bsave[n] = b[n];
-  PL_SYNC();
+  const int wv = wave_id();
+  _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv)) bsave[n] = b[n];
+  PL_XSYNC();
   for (int it = 0; it <= nref; it++) {
     if (it > 0) {
       double rr[NTRIP];
-      _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) {
+      PL_XSYNC();                                          // the solution of the previous pass is complete in b (both waves)
+      _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) {
+        const int n = vrow<M>(k__, lane, wv);
         xr[k__] = 0.0; rr[k__] = 0.0;
-        if (n < NST && (!alg_only || n >= NDIFF)) {
+        if (vok<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) {
           xr[k__] = b[n];
           double s = 0.0;
           for (int k = ptr[n]; k < ptr[n + 1]; k++) { const int c = col[k]; if (!alg_only || c >= NDIFF) s += jac_entry<true>(S, tb, code[k], cj) * b[c]; }
           rr[k__] = (twin && n == O_I) ? 0.0 : bsave[n] - s;
         }
       }
-      PL_SYNC();
-      _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (n < NST && (!alg_only || n >= NDIFF)) b[n] = rr[k__];
-      PL_SYNC();
+      PL_XSYNC();
+      _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) b[n] = rr[k__];
+      PL_XSYNC();
     }
     cell_solve(S, R, b, mode, alg_only);
     if (it > 0) {
-      _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (n < NST && (!alg_only || n >= NDIFF)) b[n] += xr[k__];
+      _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) b[n] += xr[k__];
       PL_SYNC();
     }
   }

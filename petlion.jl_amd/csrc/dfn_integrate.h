@@ -39,7 +39,7 @@ __device__ __forceinline__ void cnt_add(Counters& c, int k, int v = 1) { c.v[k] 
                              else if ((j) == M::PHI_LDS + 2) I.ph[2][k__] = (v); else I.ph[3][k__] = (v); } while (0)
 // accumulated correction ee inside a PL_VEC loop
 #define EE(n) I.ee[k__]
-#define PL_VEC(n) _Pragma("unroll") for (int k__ = 0, n = lane; k__ < NTRIP; k__++, n += WAVE) if (k__ < NST / WAVE || n < NST)
+#define PL_VEC(n) _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wave_id()); vok<M>(k__, lane, wave_id()))
 
 template <class M>
 __device__ __forceinline__ double wrms(const double* v, const double* w) {
@@ -47,7 +47,7 @@ __device__ __forceinline__ double wrms(const double* v, const double* w) {
   const int lane = lane_id();
   double s = 0.0;
   PL_VEC(n) { const double p = v[n] * w[n]; s += p * p; }
-  return sqrt(wave_sum(s) * (1.0 / NST));
+  return sqrt(wave_sum(s) * (1.0 / NST));      // (one-wave models only; unused by the integrator)
 }
 
 // ---- consistent initialisation (newtons_method!) : Y (LDS, in/out), YP (LDS, out).  returns 0 / PLH_ERR_INIT ----
@@ -63,7 +63,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   PL_MODEL(M);
   const int lane = lane_id();
   PL_VEC(n) YP[n] = 0.0;
-  PL_SYNC();
+  PL_XSYNC();
   // the dT control row contains YP_T; the algebraic system uses its twin with YP_T -> rhs_T(Y) (scalar_residual.jl:347-372)
   if (M::THERMAL && mode == PLH_MODE_DT) mode = PL_MODE_DT_TWIN;
   int ok = 0;
@@ -75,16 +75,16 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
     else cell_solve(S, R, res, mode, true);
     iters++;
     double s = 0.0;
-    for (int n = NDIFF + lane; n < NST; n += WAVE) { const double d = res[n]; Y[n] -= d; s += d * d; }
-    const double nrm = sqrt(wave_sum(s));
-    PL_SYNC();
+    if (!M::W2 || wave_id() == 0) for (int n = NDIFF + lane; n < NST; n += WAVE) { const double d = res[n]; Y[n] -= d; s += d * d; }      // (the algebraic rows are wave 0's)
+    const double nrm = sqrt(block_sum<M>(S, s));
+    PL_XSYNC();
     if (nrm < reltol_init) { ok = 1; break; }
     if (!(nrm == nrm)) break;
   }
   if (!ok) return PLH_ERR_INIT;
   // YP_diff = rhs_diff(Y)   (R_diff with YP = 0)
   cell_residual(S, R, Y, YP, res, mode == PL_MODE_DT_TWIN ? PLH_MODE_DT : mode, value);
-  for (int n = lane; n < NDIFF; n += WAVE) YP[n] = res[n];
+  PL_VEC(n) if (n < NDIFF) YP[n] = res[n];
   PL_SYNC();
   // finite-difference estimate of the algebraic derivatives (model_evaluation.jl:462-477)
   const double ce0 = S.cc.ce0;
@@ -92,13 +92,13 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   double dt = sqrt(epsce);
   if (10.0 * reltol_init > dt) dt = 10.0 * reltol_init;
   PL_VEC(n) Ytmp[n] = Y[n] + dt * YP[n];
-  PL_SYNC();
+  PL_XSYNC();
   cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
   PL_SYNC();
   if (GEN && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref);
   else cell_solve(S, R, res, mode, true);
-  for (int n = NDIFF + lane; n < NST; n += WAVE) YP[n] = -res[n] / dt;
-  PL_SYNC();
+  if (!M::W2 || wave_id() == 0) for (int n = NDIFF + lane; n < NST; n += WAVE) YP[n] = -res[n] / dt;
+  PL_XSYNC();
   return iters;
 }
 template <bool GEN = false, class M>
@@ -118,10 +118,10 @@ PL_DEV void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0, const dou
   const int lane = lane_id();
   I.tn = t_start; I.nst = 0; I.kk = 0; I.kused = 0; I.hused = 0.0; I.hh = 0.0; I.maxord = maxord;
   I.cjratio = 1.0; I.ss = 20.0; I.phase = 0; I.ns = 0; I.h0_forced = 0.0; I.cj = 0.0; I.cjlast = 0.0; I.cjold = 0.0; I.rr = 0.0; I.knew = 0;
-  if (lane <= MAXORD) { S.ida_psi[lane] = 0; S.ida_alpha[lane] = 0; S.ida_beta[lane] = 0; S.ida_sigma[lane] = 0; S.ida_gamma[lane] = 0; }
+  if (lane <= MAXORD && wave_id() == 0) { S.ida_psi[lane] = 0; S.ida_alpha[lane] = 0; S.ida_beta[lane] = 0; S.ida_sigma[lane] = 0; S.ida_gamma[lane] = 0; }
   PL_VEC(n) { S.phi[0][n] = y0[n]; S.phi[1][n] = yp0[n]; }
   for (int q = 0; q < 6; q++) { I.ph[0][q] = 0.0; I.ph[1][q] = 0.0; I.ph[2][q] = 0.0; I.ph[3][q] = 0.0; }
-  PL_SYNC();
+  PL_XSYNC();
 }
 
 // error weights: IDA evaluates ewt from phi[0] = y_n at the start of every step.  Kept in six registers per lane (I.ew[trip]); EWT(n) reads
@@ -154,10 +154,10 @@ PL_DEV double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
     const double q = i > 0 ? pn_im1 / po_im1 : 1.0;
     const double al_prev = i > 1 ? hh / pn_im1 : 1.0;
     const double g = i > 0 ? al_prev / hh : 0.0;
+    PL_XSYNC();
+    if (lane <= kk && wave_id() == 0) { S.ida_psi[lane] = pn_i; S.ida_alpha[lane] = al; S.ida_beta[lane] = q; S.ida_gamma[lane] = g; }
     PL_SYNC();
-    if (lane <= kk) { S.ida_psi[lane] = pn_i; S.ida_alpha[lane] = al; S.ida_beta[lane] = q; S.ida_gamma[lane] = g; }
-    PL_SYNC();
-    if (lane == 0) {
+    if (lane == 0 && wave_id() == 0) {
       double b = 1.0, sg = 1.0, gm = 0.0;
       S.ida_sigma[0] = 1.0;
       for (int m = 1; m <= kk; m++) {
@@ -166,7 +166,7 @@ PL_DEV double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
         gm += S.ida_gamma[m]; S.ida_gamma[m] = gm;
       }
     }
-    PL_SYNC();
+    PL_XSYNC();
   }
   double alphas = 0.0, alpha0 = 0.0;
   { const double rinv[MAXORD + 1] = {1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6};     // (compile-time quotients: identical values, no runtime division)
@@ -187,7 +187,7 @@ PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
   const int lane = lane_id();
   if (M::PRED_REGS && !first) {          // the predictor of this step is already in registers
     PL_VEC(n) { const double e = EE(n); S.yy[n] = I.pa[k__] + e; S.yp[n] = I.pb[k__] + I.cj * e; }
-    PL_SYNC();
+    PL_XSYNC();
     return;
   }
   // history vector outermost, the lane's trips innermost: the LDS loads of one order are issued back to back (a runtime-bounded inner
@@ -199,7 +199,7 @@ PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
     PL_VEC(n) { const double p = PHI_RD(j, n); a[k__] += p; b[k__] += g * p; }
   }
   PL_VEC(n) { const double e = EE(n); S.yy[n] = a[k__] + e; S.yp[n] = b[k__] + I.cj * e; if (M::PRED_REGS) { I.pa[k__] = a[k__]; I.pb[k__] = b[k__]; } }
-  PL_SYNC();
+  PL_XSYNC();
 }
 
 // IDANls + Newton + convergence test.  0 ok, 1 recoverable failure
@@ -255,7 +255,7 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
     const double sc = (I.cjratio != 1.0) ? -2.0 / (1.0 + I.cjratio) : -1.0;
     double s = 0.0;
     PL_VEC(n) { const double d = S.delta[n] * sc; EE(n) += d; const double p = d * EWT(n); s += p * p; }
-    const double delnrm = sqrt(wave_sum(s) * (1.0 / NST));
+    const double delnrm = sqrt(block_sum<M>(S, s) * (1.0 / NST));
     PL_SYNC();
     ret = 2;
     if (m == 0) { oldnrm = delnrm; if (delnrm <= toldel) ret = 0; }
@@ -282,13 +282,14 @@ PL_DEV int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, double& err_k
     if (kk > 1) { const double d1 = PHI_RD(kk, n) + e; p = d1 * w; s1 += p * p;
       if (kk > 2) { const double d2 = d1 + PHI_RD(kk - 1, n); p = d2 * w; s2 += p * p; } }
   }
-  const double enorm_k = sqrt(wave_sum(s0) * (1.0 / NST));
+  block_sum3<M>(S, s0, s1, s2);                         // (all three at once: one pair of barriers with two waves per cell)
+  const double enorm_k = sqrt(s0 * (1.0 / NST));
   err_k = S.ida_sigma[kk] * enorm_k; const double terr_k = (kk + 1) * err_k;
   I.knew = kk; err_km1 = 0.0;
   if (kk > 1) {
-    const double enorm_km1 = sqrt(wave_sum(s1) * (1.0 / NST)); err_km1 = S.ida_sigma[kk - 1] * enorm_km1; const double terr_km1 = kk * err_km1;
+    const double enorm_km1 = sqrt(s1 * (1.0 / NST)); err_km1 = S.ida_sigma[kk - 1] * enorm_km1; const double terr_km1 = kk * err_km1;
     if (kk > 2) {
-      const double enorm_km2 = sqrt(wave_sum(s2) * (1.0 / NST)); const double err_km2 = S.ida_sigma[kk - 2] * enorm_km2; const double terr_km2 = (kk - 1) * err_km2;
+      const double enorm_km2 = sqrt(s2 * (1.0 / NST)); const double err_km2 = S.ida_sigma[kk - 2] * enorm_km2; const double terr_km2 = (kk - 1) * err_km2;
       if ((terr_km1 > terr_km2 ? terr_km1 : terr_km2) <= terr_k) I.knew = kk - 1;
     } else if (terr_km1 <= 0.5 * terr_k) I.knew = kk - 1;
   }
@@ -300,9 +301,9 @@ PL_DEV void ida_restore(CellLDS<M>& S, IdaScalars& I, double saved_t) {
   PL_MODEL(M);
   const int lane = lane_id();
   I.tn = saved_t;
-  if (lane == 0) for (int j = 1; j <= I.kk; j++) S.ida_psi[j - 1] = S.ida_psi[j] - I.hh;
+  if (lane == 0 && wave_id() == 0) for (int j = 1; j <= I.kk; j++) S.ida_psi[j - 1] = S.ida_psi[j] - I.hh;
   if (I.ns <= I.kk) for (int j = I.ns; j <= I.kk; j++) { const double b = 1.0 / S.ida_beta[j]; PL_VEC(n) PHI_WR(j, n, PHI_RD(j, n) * b); }
-  PL_SYNC();
+  PL_XSYNC();
 }
 
 template <class M>
@@ -322,7 +323,7 @@ PL_DEV void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double
     if (action == 0) {
       double s = 0.0;
       PL_VEC(n) { const double p = (EE(n) - PHI_RD(I.kk + 1, n)) * EWT(n); s += p * p; }
-      const double enorm = sqrt(wave_sum(s) * (1.0 / NST)); err_kp1 = enorm / (I.kk + 2);
+      const double enorm = sqrt(block_sum<M>(S, s) * (1.0 / NST)); err_kp1 = enorm / (I.kk + 2);
       const double terr_k = (I.kk + 1) * err_k, terr_kp1 = (I.kk + 2) * err_kp1;
       if (I.kk == 1) action = (terr_kp1 >= 0.5 * terr_k) ? 2 : 3;
       else { const double terr_km1 = I.kk * err_km1;
@@ -370,7 +371,7 @@ PL_DEV void ida_get_solution(CellLDS<M>& S, const IdaScalars& I, double t, doubl
     if (kord >= 5) { s += c5 * p5; sp += d4 * p5; }
     yo[n] = s; ypo[n] = sp;
   }
-  PL_SYNC();
+  PL_XSYNC();
 }
 
 // value of a tabulated input at run-local time t (reference run_function: method(Y,p) - run.func(t,Y,YP,p), scalar_residual.jl:169-170);
@@ -417,7 +418,7 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
       hh = 0.001 * tdist;
       double sy = 0.0;
       PL_VEC(n) { const double pq = S.phi[1][n] * EWT(n); sy += pq * pq; }
-      const double ypnorm = sqrt(wave_sum(sy) * (1.0 / NST));
+      const double ypnorm = sqrt(block_sum<M>(S, sy) * (1.0 / NST));
       if (ypnorm > 0.5 / hh) hh = 0.5 / ypnorm;
     }
     if ((I.tn + hh - tstop) * hh > 0.0) hh = (tstop - I.tn) * (1.0 - 4.0 * uround);
@@ -431,7 +432,7 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
     set_ewt(S, I, o.reltol, o.abstol);
   }
   const double saved_t = I.tn; int ncf = 0, nef = 0; double err_k = 0, err_km1 = 0;
-  if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; PL_SYNC(); }
+  if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0 && wave_id() == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; PL_XSYNC(); }
   for (;;) {
     double ck; { PL_TIC(); ck = ida_set_coeffs(S, I); PL_TOC(S, PH_STEPCTL); }
     if constexpr (TAB) { if (frun) value = tab_eval(*frun, I.tn); }                           // every residual of this step attempt is evaluated at t = tn
@@ -455,7 +456,7 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
       }
       const double tscale = fabs(I.tn) > 1.0 ? fabs(I.tn) : 1.0;
       if (fabs(I.hh) < 1e-14 * tscale) return PLH_ERR_STALL;
-      if (I.nst == 0) { if (lane == 0) S.ida_psi[0] = I.hh; const double rr = I.rr; PL_VEC(n) S.phi[1][n] *= rr; PL_SYNC(); }
+      if (I.nst == 0) { if (lane == 0 && wave_id() == 0) S.ida_psi[0] = I.hh; const double rr = I.rr; PL_VEC(n) S.phi[1][n] *= rr; PL_XSYNC(); }
       continue;
     }
     break;
@@ -563,13 +564,13 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
   const double T0 = S.cc.T0;
   if (Yinit) {                                                          // simulate!(sol, ...): continue from sol.Y[end]
     PL_VEC(n) S.yy[n] = Yinit[n];
-    PL_SYNC();
+    PL_XSYNC();
     have_prev = true; t_global = t_init; prev_V = cellV<M>(S.yy); prev_I = S.yy[O_I]; prev_etap = S.yy[O_PS + NP] - S.yy[O_PE + NP + NS];
   }
   auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
     const double Tav = (M::THERMAL && out.T) ? cellTavg<M>(S, Y) : T0;
     if constexpr (TAB) if (out.Yall && idx < out.max_pts) { PL_VEC(n) out.Yall[(size_t)idx * NST + n] = Y[n]; }      // outputs = :all
-    if (lane == 0 && idx < out.max_pts) {
+    if (lane == 0 && wave_id() == 0 && idx < out.max_pts) {
       if (out.t) out.t[idx] = tt;
       if (out.V) out.V[idx] = cellV<M>(Y);
       if (out.I) out.I[idx] = Y[O_I];
@@ -580,8 +581,9 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
   for (int r = 0; r < n_runs; r++) {
     // the run descriptor is staged in LDS once per run: reading it from global memory in every step costs ~1.4 k cycles per step (scalar
     // loads that cannot be hoisted past the global stores), and a by-value register copy proved fragile under register pressure
-    if (lane == 0) { S.runc = runs[r]; if (S.runc.value_cell) S.runc.value = S.runc.value_cell[cell]; if (S.runc.tf_cell) S.runc.tf = S.runc.tf_cell[cell]; }
-    PL_SYNC();
+    PL_XSYNC();                                                       // (the other wave may still be reading the previous run's descriptor)
+    if (lane == 0 && wave_id() == 0) { S.runc = runs[r]; if (S.runc.value_cell) S.runc.value = S.runc.value_cell[cell]; if (S.runc.tf_cell) S.runc.tf = S.runc.tf_cell[cell]; }
+    PL_XSYNC();
     const plh_run& run = S.runc;
     const int mode = run.mode;
     const bool new_run = !have_prev;
@@ -619,9 +621,9 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       if (run.value_kind == PLH_VAL_HOLD) value = 0.0;
       Iguess = have_prev ? prev_I : 1.0;                                // input_methods.jl:171-176
     }
-    PL_SYNC();
-    if (lane == 0) S.yy[O_I] = Iguess;
-    PL_SYNC();
+    PL_XSYNC();
+    if (lane == 0 && wave_id() == 0) S.yy[O_I] = Iguess;
+    PL_XSYNC();
     int flag = PLH_FLAG_RUNNING;
     plh_run_info ri; ri.flag = PLH_FLAG_RUNNING; ri.iterations = 0; ri.t_end = t_global; ri.V = 0; ri.I = 0; ri.SOC = SOC; ri.T_avg = T0;
     // tstops = {tdiscon - reltol/2} U {1.0 if continuation} U {tf}   (postfix_integrator!, model_evaluation.jl:288-310)
@@ -653,7 +655,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
         if (I.nst == 0 && !stalled_once) {                              // check_solve, checks.jl:227-237
           stalled_once = true;
           PL_VEC(n) { S.yy[n] = Yprev[n]; S.yp[n] = YPprev[n]; }
-          PL_SYNC();
+          PL_XSYNC();
           ida_reinit(S, I, S.yy, S.yp, I.maxord); I.h0_forced = o.reltol; iter++; t = tprev;
           // the reference's solve! has already pushed this (repeated) point and run the stop checks when check_solve shortens the first step
           // (model_evaluation.jl:319-327, checks.jl:227-231): run.info.iterations stays equal to the number of saved points of the run
@@ -691,21 +693,21 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     if (flag > 0 && o.interp_final && t > 1.0) {                        // interp_final_points!, model_evaluation.jl:369-382
       const double fr = pv.frac;
       const double ti = fr * (t - tprev) + tprev;
-      PL_SYNC();
+      PL_XSYNC();
       PL_VEC(n) { S.yy[n] = fr * (S.yy[n] - Yprev[n]) + Yprev[n]; S.yp[n] = fr * (S.yp[n] - YPprev[n]) + YPprev[n]; }
-      PL_SYNC();
+      PL_XSYNC();
       SOC = SOC + 0.5 * ((ti + t0) - (t + t0)) * (S.yy[O_I] + S.yy[O_I]) / 3600.0;
       t_end = ti + t0;
       save_pt(nout - 1, t_end, S.yy, SOC);
     }
     ri.flag = flag; ri.iterations = iter; ri.t_end = t_end; ri.V = cellV<M>(S.yy); ri.I = S.yy[O_I]; ri.SOC = SOC; ri.T_avg = cellTavg<M>(S, S.yy);
-    if (lane == 0) info[r] = ri;
+    if (lane == 0 && wave_id() == 0) info[r] = ri;
     t_global = t_end; have_prev = true; prev_V = ri.V; prev_I = ri.I; prev_etap = S.yy[O_PS + NP] - S.yy[O_PE + NP + NS];
     if (flag < 0) { for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; z.iterations = 0; info[q] = z; } break; }
-    PL_SYNC();
+    PL_XSYNC();
   }
-  if (lane == 0 && n_pts_out) *n_pts_out = nout < out.max_pts ? nout : out.max_pts;
-  PL_SYNC();
+  if (lane == 0 && wave_id() == 0 && n_pts_out) *n_pts_out = nout < out.max_pts ? nout : out.max_pts;
+  PL_XSYNC();
   if (Yfin) PL_VEC(n) Yfin[n] = S.yy[n];
   if (YPfin) PL_VEC(n) YPfin[n] = S.yp[n];
 }

@@ -107,7 +107,7 @@ static VariantInfo variant_keys(int chem, int sei, int thermal, int rxn) {
 }
 static const VariantOps* variant_ops(int id) {
   switch (id) {
-#define PL_OPS_CASE(ID, CHEM, SEI, TH, MIX, SD, TF, RXN) case ID: return plh_variant_ops_##ID ? plh_variant_ops_##ID() : nullptr;
+#define PL_OPS_CASE(ID, CHEM, SEI, TH, MIX, SD, TF, RXN, W2) case ID: return plh_variant_ops_##ID ? plh_variant_ops_##ID() : nullptr;
     PL_VARIANT_LIST(PL_OPS_CASE)
 #undef PL_OPS_CASE
   }
@@ -297,11 +297,12 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   if (d->chemistry != PLH_CHEM_LCO_LIC6 && d->chemistry != PLH_CHEM_NMC_LIC6 && d->chemistry != PLH_CHEM_LGM50) return fail(PLH_E_UNSUPPORTED, "unknown chemistry");
   if (d->solid_diffusion < 0 || d->solid_diffusion > PLH_SD_POLYNOMIAL || d->thermodynamic_factor < 0 || d->thermodynamic_factor > 1 || d->rxn < 0 || d->rxn > 1)
     return fail(PLH_E_ARG, "solid_diffusion / thermodynamic_factor / rxn out of range");
+  if (d->waves_per_cell < 0 || d->waves_per_cell > 2) return fail(PLH_E_ARG, "waves_per_cell must be 0, 1 or 2");
   const VariantOps* ops = nullptr;
   for (int v = 0; v < PL_N_VARIANTS; v++) {
     const VariantOps* o = variant_ops(v);
     if (o && o->chem == d->chemistry && o->sei == (d->aging_SEI ? 1 : 0) && o->thermal == (d->temperature ? 1 : 0) && o->mixed == (d->precision == PLH_PREC_MIXED ? 1 : 0) &&
-        o->sd == d->solid_diffusion && o->tf == d->thermodynamic_factor && o->rxn == d->rxn) ops = o;
+        o->sd == d->solid_diffusion && o->tf == d->thermodynamic_factor && o->rxn == d->rxn && o->w2 == (d->waves_per_cell == 2 ? 1 : 0)) ops = o;
   }
   if (!ops) return fail(PLH_E_UNSUPPORTED, "this chemistry / temperature / aging / precision / model-option combination is not instantiated on the device (built in fp64: LCO and NMC "
                                            "isothermal with or without SEI aging, LGM50 isothermal, LCO with temperature; LCO isothermal with ONE of: quadratic or polynomial solid diffusion, the nonlinear "
@@ -396,10 +397,10 @@ int plh_abi_layout(int* out, int cap) {
   std::vector<int> v;
 #define PL_S(T, NF) v.push_back((int)sizeof(T)); v.push_back(NF);
 #define PL_F(T, f) v.push_back((int)offsetof(T, f));
-  PL_S(plh_model_desc, 16) PL_F(plh_model_desc, chemistry) PL_F(plh_model_desc, N_p) PL_F(plh_model_desc, N_s) PL_F(plh_model_desc, N_n) PL_F(plh_model_desc, N_a)
+  PL_S(plh_model_desc, 17) PL_F(plh_model_desc, chemistry) PL_F(plh_model_desc, N_p) PL_F(plh_model_desc, N_s) PL_F(plh_model_desc, N_n) PL_F(plh_model_desc, N_a)
   PL_F(plh_model_desc, N_z) PL_F(plh_model_desc, N_r_p) PL_F(plh_model_desc, N_r_n) PL_F(plh_model_desc, temperature) PL_F(plh_model_desc, aging_SEI)
   PL_F(plh_model_desc, real_bytes) PL_F(plh_model_desc, precision) PL_F(plh_model_desc, device) PL_F(plh_model_desc, solid_diffusion)
-  PL_F(plh_model_desc, thermodynamic_factor) PL_F(plh_model_desc, rxn)
+  PL_F(plh_model_desc, thermodynamic_factor) PL_F(plh_model_desc, rxn) PL_F(plh_model_desc, waves_per_cell)
   PL_S(plh_bounds, 11) PL_F(plh_bounds, V_max) PL_F(plh_bounds, V_min) PL_F(plh_bounds, SOC_max) PL_F(plh_bounds, SOC_min) PL_F(plh_bounds, T_max) PL_F(plh_bounds, c_s_n_max)
   PL_F(plh_bounds, I_max) PL_F(plh_bounds, I_min) PL_F(plh_bounds, eta_plating_min) PL_F(plh_bounds, c_e_min) PL_F(plh_bounds, dfilm_max)
   PL_S(plh_run, 10) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, tab_t)

@@ -16,7 +16,7 @@ namespace pl {
 // Every kernel runs at most one wavefront per SIMD (LDS: >= 40 kB per single-wave workgroup), so the compiler may use the whole
 // 512-entry register file of a lane (256 VGPR + 256 AGPR) instead of spilling to scratch.
 #if !defined(PL_WAVE_EMU) && !defined(PL_NO_WAVES_ATTR)      /* (PL_NO_WAVES_ATTR: experiment builds of tools/experiments/build_modes.py) */
-#define PL_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
+#define PL_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(M::NWAVES, M::NWAVES)))    /* one cell per SIMD: one wave (512 registers) or, M::W2, its two waves (256 each) */
 #else
 #define PL_ONE_WAVE_PER_SIMD
 #endif
@@ -25,15 +25,15 @@ namespace pl {
 // kernels
 // ---------------------------------------------------------------------------------------------------------------------
 template <class M> __device__ __forceinline__ void load_vec(double* dst, const double* __restrict__ src) {
-  const int lane = lane_id();
-  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < M::NTRIP; k__++, n += WAVE) if (n < M::NST) dst[n] = src[n];
+  const int lane = lane_id(), wv = wave_id();
+  _Pragma("unroll") for (int k__ = 0; k__ < M::NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv)) dst[n] = src[n];
 }
 template <class M> __device__ __forceinline__ void store_vec(double* __restrict__ dst, const double* src) {
-  const int lane = lane_id();
-  _Pragma("unroll") for (int k__ = 0, n = lane; k__ < M::NTRIP; k__++, n += WAVE) if (n < M::NST) dst[n] = src[n];
+  const int lane = lane_id(), wv = wave_id();
+  _Pragma("unroll") for (int k__ = 0; k__ < M::NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv)) dst[n] = src[n];
 }
 
-template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_initial_guess(const Tables* tb, int n_cells, const double* theta, const double* SOC, double* Y) {
+template <class M> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WAVE_PER_SIMD void k_initial_guess(const Tables* tb, int n_cells, const double* theta, const double* SOC, double* Y) {
   __shared__ CellLDS<M> S;
   PL_EMU_POISON(S);
   constexpr int NST = M::NST;
@@ -46,7 +46,7 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
 }
 
 // F[cell][nrows] = rows row0 .. row0+nrows-1 of the residual (the whole vector, or the f_diff! / f_alg! slices of seam 1)
-template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_residual(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+template <class M> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WAVE_PER_SIMD void k_residual(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                  int mode, double value, double* F, int row0, int nrows) {
   __shared__ CellLDS<M> S;
   PL_EMU_POISON(S);
@@ -56,12 +56,13 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec<M>(S.yy, Y + (size_t)cell * NST); load_vec<M>(S.yp, YP + (size_t)cell * NST);
-  PL_SYNC();
+  PL_XSYNC();
   cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
-  for (int n = lane_id(); n < nrows; n += WAVE) F[(size_t)cell * nrows + n] = S.delta[row0 + n];
+  PL_XSYNC();
+  for (int n = (int)threadIdx.x; n < nrows; n += WAVE * M::NWAVES) F[(size_t)cell * nrows + n] = S.delta[row0 + n];
 }
 
-template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_jacobian(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+template <class M> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WAVE_PER_SIMD void k_jacobian(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                  double cj, int mode, double* nz, const int* sel, int nsel) {
   __shared__ CellLDS<M> S;
   PL_EMU_POISON(S);
@@ -71,15 +72,16 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec<M>(S.yy, Y + (size_t)cell * NST); load_vec<M>(S.yp, YP + (size_t)cell * NST);
-  PL_SYNC();
+  PL_XSYNC();
   cell_res_jac(S, R, S.yy, S.yp, S.delta, mode, 0.0);
+  PL_XSYNC();
   const int nnz = sel ? nsel : tb->nnz[mode];             // sel: positions (in the CSC order of the mode) of the entries to export, e.g. the J_y_alg! block
   const unsigned* code = tb->csc_code[mode];
   double* out = nz + (size_t)cell * nnz;
-  for (int k = lane_id(); k < nnz; k += WAVE) out[k] = jac_entry(S, tb, code[sel ? sel[k] : k], cj);
+  for (int k = (int)threadIdx.x; k < nnz; k += WAVE * M::NWAVES) out[k] = jac_entry(S, tb, code[sel ? sel[k] : k], cj);
 }
 
-template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_linear_solve(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
+template <class M> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WAVE_PER_SIMD void k_linear_solve(const Tables* tb, int n_cells, const double* theta, const double* Y, const double* YP,
                                                      double cj, int mode, double* b, int nref) {
   __shared__ CellLDS<M> S;
   PL_EMU_POISON(S);
@@ -89,7 +91,7 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec<M>(S.yy, Y + (size_t)cell * NST); load_vec<M>(S.yp, YP + (size_t)cell * NST); load_vec<M>(S.delta, b + (size_t)cell * NST);
-  PL_SYNC();
+  PL_XSYNC();
   cell_res_jac(S, R, S.yy, S.yp, S.phi[1], mode, 0.0);
   cell_factor(S, R, tb, cj, mode, false);
   if (nref > 0) cell_solve_refined(S, R, tb, S.delta, S.phi[0], cj, mode, false, nref);
@@ -97,7 +99,7 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   store_vec<M>(b + (size_t)cell * NST, S.delta);
 }
 
-template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_init_consistent(const Tables* tb, int n_cells, const double* theta, int mode, double value,
+template <class M> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WAVE_PER_SIMD void k_init_consistent(const Tables* tb, int n_cells, const double* theta, int mode, double value,
                                                         double reltol_init, double* Y, double* YP, int* status, int* iters, int nref) {
   __shared__ CellLDS<M> S;
   PL_EMU_POISON(S);
@@ -107,17 +109,17 @@ template <class M> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_
   if (cell >= n_cells) return;
   cell_setup(S, R, tb, theta + (size_t)cell * tb->P);
   load_vec<M>(S.yy, Y + (size_t)cell * NST);
-  PL_SYNC();
+  PL_XSYNC();
   Counters cnt; for (int k = 0; k < 10; k++) cnt.v[k] = 0;
   PL_SYNC();
   const int rc = cell_init_consistent<true>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, reltol_init, cnt, S.phi[0], nref);
   store_vec<M>(Y + (size_t)cell * NST, S.yy); store_vec<M>(YP + (size_t)cell * NST, S.yp);
   PL_SYNC();
-  if (lane_id() == 0) { if (status) status[cell] = rc; if (iters) iters[cell] = cnt.v[C_INIT]; }
+  if (threadIdx.x == 0) { if (status) status[cell] = rc; if (iters) iters[cell] = cnt.v[C_INIT]; }
 }
 
 
-template <class M, bool TAB> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SIMD void k_integrate(IntegrateArgs a) {
+template <class M, bool TAB> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WAVE_PER_SIMD void k_integrate(IntegrateArgs a) {
   __shared__ CellLDS<M> S;
   PL_EMU_POISON(S);
   constexpr int NST = M::NST;
@@ -127,9 +129,9 @@ template <class M, bool TAB> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SI
   cell_setup(S, R, a.tb, a.theta + (size_t)cell * a.tb->P);
   Counters cnt; for (int k = 0; k < 10; k++) cnt.v[k] = 0;
 #ifdef PL_PHASE_TIMERS
-  if (lane_id() < 8) S.cyc[lane_id()] = 0;
+  if (threadIdx.x < 8) S.cyc[threadIdx.x] = 0;
 #endif
-  PL_SYNC();
+  PL_XSYNC();
   PL_TIC(); PL_TIC_TOTAL();
   CellOut co;
   const size_t off = (size_t)cell * a.out.max_pts;
@@ -143,7 +145,7 @@ template <class M, bool TAB> __global__ __launch_bounds__(64) PL_ONE_WAVE_PER_SI
                 a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell);
   PL_TOC_TOTAL(S);
   PL_SYNC();
-  if (lane_id() == 0 && a.out.counters) {
+  if (threadIdx.x == 0 && a.out.counters) {
     plh_counters* c = a.out.counters + cell;
 #ifdef PL_PHASE_TIMERS
     for (int k = 0; k < 8; k++) c->cyc[k] = S.cyc[k];
@@ -305,27 +307,27 @@ int sections_of(SectionInfo* o) {
 // ---------------------------------------------------------------------------------------------------------------------
 template <class M> struct OpsOf {
   static void initial_guess(hipStream_t st, const Tables* tb, int n, const double* theta, const double* SOC, double* Y) {
-    PL_LAUNCH(k_initial_guess<M>, n, WAVE, st, tb, n, theta, SOC, Y);
+    PL_LAUNCH(k_initial_guess<M>, n, WAVE * M::NWAVES, st, tb, n, theta, SOC, Y);
   }
   static void residual(hipStream_t st, const Tables* tb, int n, const double* theta, const double* Y, const double* YP, int mode, double value, double* F, int row0, int nrows) {
-    PL_LAUNCH(k_residual<M>, n, WAVE, st, tb, n, theta, Y, YP, mode, value, F, row0, nrows);
+    PL_LAUNCH(k_residual<M>, n, WAVE * M::NWAVES, st, tb, n, theta, Y, YP, mode, value, F, row0, nrows);
   }
   static void jacobian(hipStream_t st, const Tables* tb, int n, const double* theta, const double* Y, const double* YP, double cj, int mode, double* nz, const int* sel, int nsel) {
-    PL_LAUNCH(k_jacobian<M>, n, WAVE, st, tb, n, theta, Y, YP, cj, mode, nz, sel, nsel);
+    PL_LAUNCH(k_jacobian<M>, n, WAVE * M::NWAVES, st, tb, n, theta, Y, YP, cj, mode, nz, sel, nsel);
   }
   static void linear_solve(hipStream_t st, const Tables* tb, int n, const double* theta, const double* Y, const double* YP, double cj, int mode, double* b, int nref) {
-    PL_LAUNCH(k_linear_solve<M>, n, WAVE, st, tb, n, theta, Y, YP, cj, mode, b, nref);
+    PL_LAUNCH(k_linear_solve<M>, n, WAVE * M::NWAVES, st, tb, n, theta, Y, YP, cj, mode, b, nref);
   }
   static void init_consistent(hipStream_t st, const Tables* tb, int n, const double* theta, int mode, double value, double reltol_init, double* Y, double* YP, int* status,
                               int* iters, int nref) {
-    PL_LAUNCH(k_init_consistent<M>, n, WAVE, st, tb, n, theta, mode, value, reltol_init, Y, YP, status, iters, nref);
+    PL_LAUNCH(k_init_consistent<M>, n, WAVE * M::NWAVES, st, tb, n, theta, mode, value, reltol_init, Y, YP, status, iters, nref);
   }
   static void integrate(hipStream_t st, const IntegrateArgs& a, bool general) {
-    if (general) PL_LAUNCH((k_integrate<M, true>), a.n_cells, WAVE, st, a);
-    else PL_LAUNCH((k_integrate<M, false>), a.n_cells, WAVE, st, a);
+    if (general) PL_LAUNCH((k_integrate<M, true>), a.n_cells, WAVE * M::NWAVES, st, a);
+    else PL_LAUNCH((k_integrate<M, false>), a.n_cells, WAVE * M::NWAVES, st, a);
   }
   static const VariantOps* table(int id) {
-    static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::MIXED ? 1 : 0, M::SD, M::TF, M::RXN, M::NST, M::NDIFF, sizeof(CellLDS<M>), &classify<M>, &sections_of<M>,
+    static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::MIXED ? 1 : 0, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, sizeof(CellLDS<M>), &classify<M>, &sections_of<M>,
                                    &initial_guess, &residual, &jacobian, &linear_solve, &init_consistent, &integrate};
     return &ops;
   }

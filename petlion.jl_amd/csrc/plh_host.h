@@ -7,22 +7,24 @@
 #include <hip/hip_runtime.h>
 #include "dfn_cell.h"
 
-// id, chemistry, SEI aging, temperature, mixed precision (fp32 storage of the Newton-matrix factors), solid diffusion, thermodynamic factor, reaction kinetics
+// id, chemistry, SEI aging, temperature, mixed precision (fp32 storage of the Newton-matrix factors), solid diffusion, thermodynamic factor, reaction kinetics,
+// two waves per cell
 #define PL_VARIANT_LIST(X)                                                                         \
-  X(0, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV)          \
-  X(1, PLH_CHEM_NMC_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV)          \
-  X(2, PLH_CHEM_LCO_LIC6, true, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV)           \
-  X(3, PLH_CHEM_NMC_LIC6, true, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV)           \
-  X(4, PLH_CHEM_LCO_LIC6, false, true, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV)           \
-  X(5, PLH_CHEM_LCO_LIC6, false, false, true, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV)           \
-  X(6, PLH_CHEM_NMC_LIC6, true, false, true, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV)            \
-  X(7, PLH_CHEM_LCO_LIC6, false, true, true, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV)            \
-  X(8, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_QUADRATIC, PLH_TF_LINEAR, PLH_RXN_BV)        \
-  X(9, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_POLYNOMIAL, PLH_TF_LINEAR, PLH_RXN_BV)       \
-  X(10, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_NONLINEAR, PLH_RXN_BV)      \
-  X(11, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_MHC)       \
-  X(12, PLH_CHEM_LGM50, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV)
-constexpr int PL_N_VARIANTS = 13;
+  X(0, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)          \
+  X(1, PLH_CHEM_NMC_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)          \
+  X(2, PLH_CHEM_LCO_LIC6, true, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)           \
+  X(3, PLH_CHEM_NMC_LIC6, true, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)           \
+  X(4, PLH_CHEM_LCO_LIC6, false, true, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)           \
+  X(5, PLH_CHEM_LCO_LIC6, false, false, true, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)           \
+  X(6, PLH_CHEM_NMC_LIC6, true, false, true, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)            \
+  X(7, PLH_CHEM_LCO_LIC6, false, true, true, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)            \
+  X(8, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_QUADRATIC, PLH_TF_LINEAR, PLH_RXN_BV, 0)        \
+  X(9, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_POLYNOMIAL, PLH_TF_LINEAR, PLH_RXN_BV, 0)       \
+  X(10, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_NONLINEAR, PLH_RXN_BV, 0)      \
+  X(11, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_MHC, 0)       \
+  X(12, PLH_CHEM_LGM50, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)            \
+  X(13, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 1)
+constexpr int PL_N_VARIANTS = 14;
 
 struct IntegrateArgs {
   const pl::Tables* tb; int n_cells; const double* theta; const double* SOC0; const double* Y_init; const double* t_init; int n_runs; const plh_run* runs; plh_opts opts;
@@ -32,7 +34,7 @@ struct IntegrateArgs {
 struct SectionInfo { const char* name; int start, len; };
 
 struct VariantOps {
-  int id, chem, sei, thermal, mixed, sd, tf, rxn;
+  int id, chem, sei, thermal, mixed, sd, tf, rxn, w2;
   int N, Nd;
   size_t lds_bytes;                                                                  // sizeof(CellLDS<M>): LDS per cell (= per workgroup)
   unsigned (*classify)(const pl::Tables& tb, int mode, int r, int c);              // decode word of the structural Jacobian entry (r, c), 0 if structurally zero
@@ -48,6 +50,6 @@ struct VariantOps {
 
 // one definition per variant translation unit.  Weak: an experiment build may link a subset of the variants (tools/), plh_model_create then refuses the
 // missing ones with PLH_E_UNSUPPORTED; the product build links all of them (tests/test_capi_symbols.py checks that every variant can be created)
-#define PL_DECLARE_OPS(ID, CHEM, SEI, TH, MIX, SD, TF, RXN) const VariantOps* plh_variant_ops_##ID() __attribute__((weak));
+#define PL_DECLARE_OPS(ID, CHEM, SEI, TH, MIX, SD, TF, RXN, W2) const VariantOps* plh_variant_ops_##ID() __attribute__((weak));
 PL_VARIANT_LIST(PL_DECLARE_OPS)
 #undef PL_DECLARE_OPS

@@ -6,11 +6,11 @@
 #error "compile with -DPL_VARIANT=<id>"
 #endif
 
-#define PL_DEFINE_OPS(ID, CHEM, SEI, TH, MIX, SD, TF, RXN) \
-  const VariantOps* plh_variant_ops_##ID() { return pl::OpsOf<pl::ModelT<CHEM, SEI, TH, MIX, SD, TF, RXN>>::table(ID); }
+#define PL_DEFINE_OPS(ID, CHEM, SEI, TH, MIX, SD, TF, RXN, W2) \
+  const VariantOps* plh_variant_ops_##ID() { return pl::OpsOf<pl::ModelT<CHEM, SEI, TH, MIX, SD, TF, RXN, W2>>::table(ID); }
 
 // the variant selected by -DPL_VARIANT (or all of them for PL_VARIANT == -1: the test-only wave-emulator build is one translation unit)
-#define PL_V(ID, CHEM, SEI, TH, MIX, SD, TF, RXN) template <> struct pl::VariantSel<ID> { using M = pl::ModelT<CHEM, SEI, TH, MIX, SD, TF, RXN>; };
+#define PL_V(ID, CHEM, SEI, TH, MIX, SD, TF, RXN, W2) template <> struct pl::VariantSel<ID> { using M = pl::ModelT<CHEM, SEI, TH, MIX, SD, TF, RXN, W2>; };
 namespace pl { template <int ID> struct VariantSel; }
 PL_VARIANT_LIST(PL_V)
 #undef PL_V

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel time / throughput of the BASELINE.json configs on one GPU (kernel time by the library's HIP events, Theta resident).
-   python tools/perf_configs.py [c2|c3|c4|c5|all ...] [--reps K] [--cells N] [--precision f64|mixed]
+   python tools/perf_configs.py [c2|c3|c4|c5|all ...] [--reps K] [--cells N] [--precision f64|mixed] [--waves 1|2]
 PETLION_HIP_LIB=<path> selects an experiment build of the library (tools/experiments/)."""
 import argparse, os, sys
 import numpy as np
@@ -35,12 +35,12 @@ def run(name, p, cfg, reps):
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("which", nargs="*", default=["all"]); ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--cells", type=int, default=0); ap.add_argument("--precision", default="f64")
+    ap.add_argument("--cells", type=int, default=0); ap.add_argument("--precision", default="f64"); ap.add_argument("--waves", type=int, default=1)
     a = ap.parse_args()
     which = list(MODELS) if "all" in a.which else a.which
     for w in which:
         mk = dict(MODELS[w]); c = mk.pop("c")
-        p = pkg.petlion(c, precision=a.precision, **mk)
+        p = pkg.petlion(c, precision=a.precision, waves_per_cell=a.waves, **mk)
         run(w, p, getattr(pkg.configs, w)(p, a.cells or CELLS[w]), a.reps)
 
 
