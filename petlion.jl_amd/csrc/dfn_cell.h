@@ -254,13 +254,25 @@ enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_O
 #endif
 // -DPL_PHASE_DETAIL (with PL_PHASE_TIMERS): the seven phase slots are re-used for the sub-phases of the Jacobian refresh (PL_TICD / PL_TOCD below); the
 // coarse phases are then not recorded (slot 7 stays the total)
+#if defined(PL_PHASE_DETAIL) && (PL_PHASE_DETAIL + 0 == 0)
+#undef PL_PHASE_DETAIL
+#define PL_PHASE_DETAIL 1
+#endif
 #ifdef PL_PHASE_DETAIL
 #define PL_TIC() do {} while (0)
 #define PL_TOC(S_, ph) do {} while (0)
 #define PL_TIC_TOTAL() PL_TIC_()
 #define PL_TOC_TOTAL(S_) PL_TOC_(S_, PH_TOTAL)
+#define PL_LAP_(S_, slot) do { const long long now__ = (long long)__builtin_readcyclecounter(); if (threadIdx.x == 0) (S_).cyc[slot] += now__ - pl_t0__; pl_t0__ = now__; } while (0)   /* lap timer */
+#if PL_PHASE_DETAIL == 1          /* sub-phases of the Jacobian refresh */
 #define PL_TICD() PL_TIC_()
-#define PL_TOCD(S_, slot) do { const long long now__ = (long long)__builtin_readcyclecounter(); if (threadIdx.x == 0) (S_).cyc[slot] += now__ - pl_t0__; pl_t0__ = now__; } while (0)   /* lap timer */
+#define PL_TOCD(S_, slot) PL_LAP_(S_, slot)
+#else
+#define PL_TICD() do {} while (0)
+#define PL_TOCD(S_, slot) do {} while (0)
+#endif
+#define PL_TICE(mode) long long pl_t0__ = (PL_PHASE_DETAIL == (mode)) ? (long long)__builtin_readcyclecounter() : 0   /* mode 2: solve + residual, mode 3: step control + output */
+#define PL_TOCE(S_, mode, slot) do { if (PL_PHASE_DETAIL == (mode)) PL_LAP_(S_, slot); } while (0)
 #else
 #define PL_TIC() PL_TIC_()
 #define PL_TOC(S_, ph) PL_TOC_(S_, ph)
@@ -268,6 +280,8 @@ enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_O
 #define PL_TOC_TOTAL(S_) PL_TOC_(S_, PH_TOTAL)
 #define PL_TICD() do {} while (0)
 #define PL_TOCD(S_, slot) do {} while (0)
+#define PL_TICE(mode) do {} while (0)
+#define PL_TOCE(S_, mode, slot) do {} while (0)
 #endif
 __host__ __device__ __forceinline__ int sec_of(int i) { return i < NP ? 0 : (i < NP + NS ? 1 : 2); }
 // ---- cross-lane primitives.  gfx950: DPP moves (probed on hardware, tools/probes/dpp_probe.hip: wave_shr:1 / wave_shl:1 shift
@@ -867,10 +881,13 @@ PL_DEV void cell_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, cons
 // full residual F(Y, YP) -> Fo (all three are LDS vectors)
 template <class M>
 PL_DEV void cell_residual(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo, int mode, double value) {
+  PL_TICE(2);
   cell_node_pass<true, false>(S, Y, YP, Fo, mode, value);
   if constexpr (M::THERMAL) PL_SYNC();                      // the particle rows read the per-node D_s(T) written by the node pass
+  PL_TOCE(S, 2, 5);
   cell_cs_rows<false>(S, R, Y, YP, Fo);
-  PL_SYNC();                                                // (two waves per cell: every wave has written its own rows of Fo; whoever reads across waves synchronises first)
+  PL_SYNC();
+  PL_TOCE(S, 2, 6);                                                // (two waves per cell: every wave has written its own rows of Fo; whoever reads across waves synchronises first)
 }
 // residual + Jacobian partials in one pass (the Newton-matrix refresh of the corrector)
 template <class M>
@@ -1133,6 +1150,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const int r = lane % NR, g = lane / NR;
+  PL_TICE(2);
   // a. particle partial solutions  w = A^-1 b_cs : four independent accumulation chains (pass = particles pass*6 .. pass*6+5)
   if constexpr (M::SD == 0)
   if (!alg_only && (!M::W2 || wave_id() == 1)) {
@@ -1163,6 +1181,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
     }
   }
   PL_XSYNC();
+  PL_TOCE(S, 2, 0);
   if (!M::W2 || wave_id() == 0) {                       // b .. e: wave 0 (two waves per cell)
   // b. fold c_s and j elimination into the node right-hand sides
   double bjp = 0.0, bjs = 0.0, bfl = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0;
@@ -1203,8 +1222,10 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
     }
     m0 = r0; m1 = r1; m2 = r2;
   }
+  PL_TOCE(S, 2, 1);
   // c. block-Thomas forward / backward substitution (systolic, registers + DPP)
   thomas_sweeps(S, alg_only, m0, m1, m2);
+  PL_TOCE(S, 2, 2);
   double mx[3] = {m0, m1, m2};
   // d. border: control row couples Phi_s[first] - Phi_s[last] (voltage mode)
   double xI;
@@ -1258,6 +1279,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   if (lane == 0) b[O_I] = xI;
   }
   PL_XSYNC();
+  PL_TOCE(S, 2, 3);
   // f. particles:  dc = w - (A^-1 e_last) * bj * dj
   if constexpr (M::SD == 0)
   if (!alg_only && (!M::W2 || wave_id() == 1)) {
@@ -1271,6 +1293,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
     }
   }
   PL_SYNC();
+  PL_TOCE(S, 2, 4);
 }
 
 

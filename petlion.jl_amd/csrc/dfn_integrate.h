@@ -434,11 +434,11 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
   const double saved_t = I.tn; int ncf = 0, nef = 0; double err_k = 0, err_km1 = 0;
   if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0 && wave_id() == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; PL_XSYNC(); }
   for (;;) {
-    double ck; { PL_TIC(); ck = ida_set_coeffs(S, I); PL_TOC(S, PH_STEPCTL); }
+    double ck; { PL_TIC(); PL_TICE(3); ck = ida_set_coeffs(S, I); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 0); }
     if constexpr (TAB) { if (frun) value = tab_eval(*frun, I.tn); }                           // every residual of this step attempt is evaluated at t = tn
     const int nflag = ida_nls<TAB>(S, R, tb, I, mode, value, o.jac_every_step, cnt, o.refine);
     int errfail = 0;
-    if (nflag == 0) { PL_TIC(); errfail = ida_test_error(S, I, ck, err_k, err_km1); PL_TOC(S, PH_STEPCTL); }
+    if (nflag == 0) { PL_TIC(); PL_TICE(3); errfail = ida_test_error(S, I, ck, err_k, err_km1); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 1); }
     if (nflag != 0 || errfail) {
       ida_restore(S, I, saved_t);
       I.phase = 1;
@@ -462,13 +462,14 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
     break;
   }
   cnt_add(cnt, C_STEPS); cnt_add(cnt, C_SUMKP2, I.kk + 2);
-  PL_TIC();
+  PL_TIC(); PL_TICE(3);
   ida_complete_step(S, I, err_k, err_km1);
+  PL_TOCE(S, 3, 2);
   const double troundoff = 100.0 * uround * (fabs(I.tn) + fabs(I.hh));
-  if (fabs(I.tn - tstop) <= troundoff) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; PL_TOC(S, PH_STEPCTL); return 0; }
+  if (fabs(I.tn - tstop) <= troundoff) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 3); return 0; }
   if ((I.tn + I.hh - tstop) * I.hh > 0.0) I.hh = (tstop - I.tn) * (1.0 - 4.0 * uround);
   ida_get_solution(S, I, I.tn, S.yy, S.yp); tret = I.tn;
-  PL_TOC(S, PH_STEPCTL);
+  PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 3);
   return 0;
 }
 
@@ -666,11 +667,13 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
         flag = sf; break;
       }
       iter++; t = tret;
-      PL_TIC();
+      PL_TIC(); PL_TICE(3);
       const double SOC_new = SOC + 0.5 * ((t + t0) - t_prev_saved) * (S.yy[O_I] + I_prev_pt) / 3600.0;   // calc_SOC, scalar_residual.jl:103-111
       SOC = SOC_new;
       save_pt(nout, t + t0, S.yy, SOC); nout++;
+      PL_TOCE(S, 3, 4);
       check_stop(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
+      PL_TOCE(S, 3, 5);
       if (!is_tab && t == tprev) { flag = PLH_ERR_STALL; break; }      // (run_function has no stall test, checks.jl:251-269)
       if (iter == o.maxiters) { flag = PLH_ERR_MAXITERS; break; }
       if (nout >= out.max_pts && out.max_pts > 0 && flag == PLH_FLAG_RUNNING) { flag = PLH_ERR_OUTPUT_FULL; break; }
@@ -684,7 +687,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
           if (!(fabs(value - v_new) <= tolv)) { value = v_new; t_restart = t_new; again = true; }
         }
       }
-      PL_TOC(S, PH_OUTPUT);
+      PL_TOC(S, PH_OUTPUT); PL_TOCE(S, 3, 6);
       if (again) break;                                                 // back to the consistent initialisation at t_restart
     }
     } while (TAB && again && flag == PLH_FLAG_RUNNING);

@@ -360,6 +360,34 @@ def test_emulator_hostile_modes():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def check_two_waves(pkg, O):
+    import build_emu
+    p = pkg.petlion(pkg.LCO, waves_per_cell=2, _lib_path=build_emu.build())
+    parity.check_keys_and_pattern(p, O)
+    parity.check_evaluators(p, O, n_cells=2)
+    parity.check_init(p, O)
+    Th = pkg.theta_matrix(p, 2, {"D_sp": np.array([1.0, 0.6]) * p.θ["D_sp"]})
+    ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0)
+    for i in range(2):
+        parity.compare_trajectory(ens, i, O.simulate("lco_iso", Th[i], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}])), rtol_state=1e-6)
+
+
+def test_two_waves_per_cell_variant(pkg, O):
+    """waves_per_cell = 2 (a 128-thread workgroup per cell, wave 1 owns the particle rows): same evaluators, initialisation and trajectory as the oracle"""
+    check_two_waves(pkg, O)
+
+
+@pytest.mark.parametrize("wave", ["0", "1"])
+def test_two_waves_per_cell_hostile_schedules(wave):
+    """the two-wave variant with one wave always run as far ahead of the other as the workgroup barriers allow (PL_EMU_WAVE: a cross-wave LDS hand-over that lacks a
+    barrier reads stale data under one of the two preferences), lanes in reverse order, LDS and stacks poisoned"""
+    import subprocess, sys
+    env = dict(os.environ, PL_EMU_POISON="1", PL_EMU_ORDER="reverse", PL_EMU_WAVE=wave)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "two_waves_per_cell_variant", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def check_f4_variant(p, O, pkg, tag, n_traj=2, rtol_state=2e-5):
     """one SURVEY 8(f).4 model variant: key order and CSC pattern identical to the oracle's symbolic pipeline, residual 1e-12 / Jacobian 1e-9 / solve 1e-8,
     consistent initialisation, and 1C discharges with identical solver decisions (final state within the reproducibility floor discussed in test_gpu_parity.py)"""

@@ -497,3 +497,21 @@ def test_f4_model_variants(hip_models_f4, O, pkg):
                    (ro["counters"]["n_convfail"] >= 2 and abs(ro["runs"][0]["t_end"] - tend[i]) < 1e-2 * tend[i]), (tag, i, ro["runs"][0], tend[i])
         assert np.abs(tend[fl == 3] - 3600.0).max(initial=0.0) < 1e-6 and np.abs(ens.run_info["SOC"][ok, 0] - (1.0 - tend[ok] / 3600.0)).max() < 1e-9
         print("%s: N = %d, LDS %d B/cell, 1024-cell sweep kernel %.2f ms (%.0f trajectories/s), flags %s" % (p.variant, p.N.tot, p.lds_bytes, ens.kernel_ms, n / ens.kernel_ms * 1e3, dict(zip(*np.unique(fl, return_counts=True)))))
+
+
+def test_two_waves_per_cell_variant(hip_model, O, pkg):
+    """waves_per_cell = 2 (128-thread workgroup per cell; VERDICT r01 item 4's experiment, kept as an option): oracle parity of evaluators / initialisation /
+    trajectories, and the same decisions as the one-wave kernel on 512 cells of the C4 sweep (the two kernels differ only in the association of the norms)"""
+    import torch
+    p2 = pkg.petlion(pkg.LCO, waves_per_cell=2)
+    parity.check_evaluators(p2, O, n_cells=4)
+    parity.check_init(p2, O)
+    cfg = pkg.configs.c4(hip_model, 512)
+    Thd = torch.from_numpy(np.ascontiguousarray(cfg["theta"])).cuda()
+    e1 = pkg.simulate_ensemble(hip_model, Thd, cfg["protocol"], SOC=cfg["SOC"], device=True, max_points=cfg["max_points"])
+    e2 = pkg.simulate_ensemble(p2, Thd, cfg["protocol"], SOC=cfg["SOC"], device=True, max_points=cfg["max_points"])
+    torch.cuda.synchronize()
+    assert np.array_equal(e1.run_info["flag"], e2.run_info["flag"]) and np.array_equal(e1.counters["n_steps"], e2.counters["n_steps"])
+    Y1, Y2 = e1.Y.cpu().numpy(), e2.Y.cpu().numpy()
+    assert max(parity.state_rel_err(Y2[i], Y1[i]) for i in range(512)) < 1e-9
+    print("two waves per cell: 512 C4 cells %.3f ms vs %.3f ms with one wave per cell" % (e2.kernel_ms, e1.kernel_ms))
