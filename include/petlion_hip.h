@@ -163,6 +163,11 @@ typedef struct {
 /* ---- model handle: replaces petlion()'s generated-function bundle p.funcs (src/structures.jl:315-334) ---- */
 int plh_model_create(const plh_model_desc* desc, plh_model_t* out);
 void plh_model_destroy(plh_model_t m);
+/* Other discretisations (reference src/params.jl:119-136: petlion(...; N_p, N_s, N_n, N_r_p, N_r_n, N_a, N_z)).  The kernels are compiled per grid, like the reference
+   generates and caches its functions per model (generate_functions.jl:44-94): the built-in ones for the default 10 / 10 / 10 / 10, any other grid with 2 <= N_p, N_s, N_n,
+   N_p + N_s + N_n <= 48, 10 <= N_r_p = N_r_n <= 16 as a library built from csrc/variant_tu.hip (petlion.jl_amd/grids.py) and registered here BEFORE
+   plh_model_create is called with those dimensions.  Registering the same path twice is a no-op; the library stays loaded for the life of the process. */
+int plh_register_grid_library(const char* path);
 int plh_n_states(plh_model_t m);     /* p.N.tot  */
 int plh_n_diff(plh_model_t m);       /* p.N.diff */
 int plh_n_theta(plh_model_t m);      /* length(θ_keys), src/generate_functions.jl:327-363 */

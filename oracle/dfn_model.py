@@ -265,7 +265,7 @@ class Model:
         self.solid_diffusion, self.thermodynamic_factor, self.rxn = solid_diffusion, thermodynamic_factor, rxn
         self.lay = Layout(temperature=temperature, aging=aging, solid_diffusion=solid_diffusion, **Nkw)
         self.theta = {"LCO": theta_LCO, "NMC": theta_NMC, "LGM50": theta_LGM50}[cathode]()
-        if cathode in ("NMC", "LGM50") and (temperature or aging):
+        if cathode == "LGM50" and (temperature or aging):
             raise ValueError("LGM50 is built isothermal without aging")
         if cathode == "NMC" and temperature:
             raise ValueError("the reference NMC chemistry defines no thermal parameters (params.jl:295-367)")

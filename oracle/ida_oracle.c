@@ -93,6 +93,12 @@ DECL_VARIANT(nmc_iso)
 #ifdef ORC_HAVE_lgm50_iso
 DECL_VARIANT(lgm50_iso)
 #endif
+#ifdef ORC_HAVE_lco_iso_g12_7_9_11
+DECL_VARIANT(lco_iso_g12_7_9_11)
+#endif
+#ifdef ORC_HAVE_nmc_iso_sei_g6_5_8_13
+DECL_VARIANT(nmc_iso_sei_g6_5_8_13)
+#endif
 #ifdef ORC_HAVE_lco_iso_quad
 DECL_VARIANT(lco_iso_quad)
 #endif
@@ -107,7 +113,8 @@ DECL_VARIANT(lco_iso_mhc)
 #endif
 
 static void set_layout(orc_model* m, int thermal, int aging) {
-  m->Np = m->Ns = m->Nn = m->Na = m->Nz = 10;
+  if (m->Np == 0) m->Np = m->Ns = m->Nn = 10;   /* (another discretisation: FILL_VARIANT_GRID) */
+  m->Na = m->Nz = 10;
   if (m->Nrp == 0) m->Nrp = m->Nrn = 10;      /* (1 for the quadratic / polynomial solid-diffusion approximations: one c_s_avg per particle) */
   m->thermal = thermal; m->aging = aging;
   int o = 0;
@@ -130,6 +137,8 @@ static void set_layout(orc_model* m, int thermal, int aging) {
   (m)->theta_keys = orc_##v##_theta_keys; (m)->f_diff = orc_##v##_f_diff; (m)->f_alg = orc_##v##_f_alg; \
   (m)->jac = orc_##v##_jac; (m)->jac_alg = orc_##v##_jac_alg; (m)->initial_guess = orc_##v##_initial_guess; \
   (m)->Nrp = (m)->Nrn = 0; (m)->has_Q = 0; set_layout(m, th_, ag_); } while (0)
+#define FILL_VARIANT_GRID(m, v, ag_, np_, ns_, nn_, nr_) do { FILL_VARIANT(m, v, 0, ag_); (m)->Np = np_; (m)->Ns = ns_; (m)->Nn = nn_; (m)->Nrp = (m)->Nrn = nr_; \
+  set_layout(m, 0, ag_); } while (0)
 #define FILL_VARIANT_SD(m, v, nr_, q_) do { FILL_VARIANT(m, v, 0, 0); (m)->Nrp = (m)->Nrn = nr_; (m)->has_Q = q_; set_layout(m, 0, 0); } while (0)
 
 static int get_model(const char* name, orc_model* m) {
@@ -153,6 +162,12 @@ static int get_model(const char* name, orc_model* m) {
 #endif
 #ifdef ORC_HAVE_lgm50_iso
   if (!strcmp(name, "lgm50_iso")) { FILL_VARIANT(m, lgm50_iso, 0, 0); return 0; }
+#endif
+#ifdef ORC_HAVE_lco_iso_g12_7_9_11
+  if (!strcmp(name, "lco_iso_g12_7_9_11")) { FILL_VARIANT_GRID(m, lco_iso_g12_7_9_11, 0, 12, 7, 9, 11); return 0; }
+#endif
+#ifdef ORC_HAVE_nmc_iso_sei_g6_5_8_13
+  if (!strcmp(name, "nmc_iso_sei_g6_5_8_13")) { FILL_VARIANT_GRID(m, nmc_iso_sei_g6_5_8_13, 1, 6, 5, 8, 13); return 0; }
 #endif
 #ifdef ORC_HAVE_lco_iso_quad
   if (!strcmp(name, "lco_iso_quad")) { FILL_VARIANT_SD(m, lco_iso_quad, 1, 0); return 0; }

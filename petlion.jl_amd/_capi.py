@@ -72,7 +72,7 @@ RUN_INFO_DTYPE = np.dtype([("flag", np.int32), ("iterations", np.int32), ("t_end
 COUNTERS_DTYPE = np.dtype([(f, np.int64) for f in COUNTER_FIELDS] + [("cyc", np.int64, (8,))], align=True)
 assert RUN_INFO_DTYPE.itemsize == C.sizeof(RunInfo) and COUNTERS_DTYPE.itemsize == C.sizeof(CountersS)
 
-EXPORTS = ["plh_model_create", "plh_model_destroy", "plh_n_states", "plh_n_diff", "plh_n_theta", "plh_theta_key",
+EXPORTS = ["plh_model_create", "plh_model_destroy", "plh_register_grid_library", "plh_n_states", "plh_n_diff", "plh_n_theta", "plh_theta_key",
            "plh_theta_default", "plh_lds_bytes", "plh_n_sections", "plh_section", "plh_jac_pattern", "plh_jac_alg_pattern", "plh_last_error", "plh_abi_layout",
            "plh_initial_guess", "plh_residual", "plh_jacobian", "plh_linear_solve", "plh_linear_solve_refined", "plh_residual_diff", "plh_residual_alg",
            "plh_jacobian_alg", "plh_init_consistent", "plh_integrate", "plh_last_kernel_ms", "plh_host_alloc", "plh_host_free", "plh_synchronize",
@@ -104,6 +104,7 @@ def load(path=None):
     lib.plh_last_kernel_ms.argtypes = [C.c_void_p]
     lib.plh_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]
     lib.plh_model_destroy.argtypes = [C.c_void_p]
+    lib.plh_register_grid_library.argtypes = [C.c_char_p]
     lib.plh_section.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     for f in ("plh_n_states", "plh_n_diff", "plh_n_theta", "plh_n_sections", "plh_lds_bytes"):
         getattr(lib, f).argtypes = [C.c_void_p]

@@ -12,10 +12,12 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
 from . import _capi as cap
+from . import grids
 from .params import EXIT_REASONS, Bounds, Opts, bounds_LCO, bounds_LGM50, bounds_NMC, calc_I1C, theta_LCO, theta_LGM50, theta_NMC
 
 LCO = "LCO"
@@ -31,7 +33,7 @@ class _N:
 class Model:
     """The reference's `model` struct, reduced to the data contracts of the hot path (src/structures.jl:336-345)."""
 
-    def __init__(self, cathode, N, temperature, aging, lib_path=None, precision="f64", device=-1, solid_diffusion="Fickian", thermodynamic_factor="linear", rxn="BV", waves_per_cell=1):
+    def __init__(self, cathode, N, temperature, aging, lib_path=None, precision="f64", device=-1, solid_diffusion="Fickian", thermodynamic_factor="linear", rxn="BV", waves_per_cell=1, grid_lib=None):
         if cathode not in (LCO, NMC, NMC_LGM50):
             raise NotImplementedError("chemistry %r is outside the hot-path scope (LCO, NMC and NMC_LGM50 are built)" % (cathode,))
         self.cathode = cathode
@@ -54,6 +56,22 @@ class Model:
                              {"Fickian": 0, "quadratic": 1, "polynomial": 2}[solid_diffusion], {"linear": 0, "nonlinear": 1}[thermodynamic_factor], {"BV": 0, "MHC": 1}[rxn], int(waves_per_cell))
         self.waves_per_cell = int(waves_per_cell)
         self.solid_diffusion, self.thermodynamic_factor, self.rxn = solid_diffusion, thermodynamic_factor, rxn
+        # another discretisation than the built-in 10/10/10/10: its kernels are a library of their own, compiled on first use and cached (grids.py), registered before the
+        # handle is created (`grid_lib`: a library built elsewhere -- the tests' emulator build)
+        if N.r_p != N.r_n and solid_diffusion == "Fickian":
+            raise NotImplementedError("N_r_p != N_r_n: the device kernels use one radial grid for both electrodes")
+        g = grids.grid_tuple(N.p, N.s, N.n, N.r_p if solid_diffusion == "Fickian" else 10, N.a if self.temperature else 10, N.z if self.temperature else 10)
+        grids.check(g, thermal=self.temperature, sei=bool(aging))
+        if grid_lib is None and g != grids.DEFAULT:
+            if lib_path is not None:
+                raise ValueError("a non-default discretisation with an explicit library path needs grid_lib= as well")
+            vid = grids.variant_id({LCO: "LCO_LIC6", NMC: "NMC_LIC6", NMC_LGM50: "LGM50"}[cathode], bool(aging), self.temperature, precision == "mixed",
+                                   solid_diffusion.upper(), thermodynamic_factor.upper(), rxn, waves_per_cell == 2)
+            if vid is None:
+                raise NotImplementedError("this combination of model options is not instantiated on the device")
+            grid_lib = grids.library(g, [vid])
+        if grid_lib:                                     # (False: register nothing -- the tests' way to reach the C ABI's own refusal)
+            cap.check(self._lib, self._lib.plh_register_grid_library(os.fsencode(grid_lib)), "plh_register_grid_library")
         h = C.c_void_p()
         cap.check(self._lib, self._lib.plh_model_create(C.byref(desc), C.byref(h)), "plh_model_create")
         self._h = h
@@ -70,6 +88,8 @@ class Model:
         self.variant = "%s_%s%s%s%s%s" % (cathode.lower(), "thermal" if self.temperature else "iso", "_sei" if aging else "",          # matching oracle variant (tests)
                                           {"Fickian": "", "quadratic": "_quad", "polynomial": "_poly"}[solid_diffusion], "_nu" if thermodynamic_factor == "nonlinear" else "",
                                           "_mhc" if rxn == "MHC" else "")
+        if g != grids.DEFAULT:
+            self.variant += "_g%d_%d_%d_%d" % g[:4]
 
     theta = property(lambda self: self.θ)
 
@@ -99,14 +119,14 @@ class Model:
 
 def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_r_n=10, temperature=False,
             solid_diffusion="Fickian", Fickian_method="finite_difference", aging=False, jacobian="symbolic", SOC=1.0,
-            thermodynamic_factor="linear", rxn_p="BV", rxn_n="BV", precision="f64", device=-1, waves_per_cell=1, _lib_path=None):
+            thermodynamic_factor="linear", rxn_p="BV", rxn_n="BV", precision="f64", device=-1, waves_per_cell=1, _lib_path=None, _grid_lib=None):
     """petlion(cathode; kwargs...) -- reference src/params.jl:119-174.  `jacobian` is accepted and ignored (the device
     Jacobian is hand-derived); unsupported structural options raise."""
     if solid_diffusion not in ("Fickian", "quadratic", "polynomial") or (solid_diffusion == "Fickian" and Fickian_method != "finite_difference"):
         raise NotImplementedError("solid diffusion: Fickian (finite_difference), quadratic and polynomial are built; the BETA spectral method is not (SURVEY.md 8f)")
     if thermodynamic_factor not in ("linear", "nonlinear") or rxn_p not in ("BV", "MHC") or rxn_n != rxn_p:
         raise NotImplementedError("thermodynamic_factor: linear / nonlinear; rxn_p = rxn_n in (BV, MHC)")
-    p = Model(cathode, _N(p=N_p, s=N_s, n=N_n, a=N_a, z=N_z, r_p=N_r_p, r_n=N_r_n), temperature, aging, _lib_path, precision, device, solid_diffusion, thermodynamic_factor, rxn_p, waves_per_cell)
+    p = Model(cathode, _N(p=N_p, s=N_s, n=N_n, a=N_a, z=N_z, r_p=N_r_p, r_n=N_r_n), temperature, aging, _lib_path, precision, device, solid_diffusion, thermodynamic_factor, rxn_p, waves_per_cell, _grid_lib)
     p.opts.SOC = SOC
     return p
 

@@ -35,9 +35,37 @@ namespace pl {
 #endif
 
 constexpr int WAVE = 64;
-constexpr int NP = 10, NS = 10, NN = 10, NR = 10, NE = NP + NS + NN, NJ = NP + NN;
+// Discretisation (reference src/params.jl:119-136: N_p, N_s, N_n, N_r_p = N_r_n, N_a, N_z): compile-time constants of a translation unit.  The library's built-in
+// variants use the reference default, 10 everywhere; another grid is one more build of variant_tu.hip with -DPL_NP=.. -DPL_NS=.. (and `pl` renamed per grid, so that
+// the two builds can live in one process), loaded through plh_register_grid_library (petlion.jl_amd/grids.py drives it; DESIGN.md "other discretisations").
+#ifndef PL_NP
+#define PL_NP 10
+#endif
+#ifndef PL_NS
+#define PL_NS 10
+#endif
+#ifndef PL_NN
+#define PL_NN 10
+#endif
+#ifndef PL_NR
+#define PL_NR 10
+#endif
+#ifndef PL_NA
+#define PL_NA 10
+#endif
+#ifndef PL_NZ
+#define PL_NZ 10
+#endif
+constexpr int NP = PL_NP, NS = PL_NS, NN = PL_NN, NR = PL_NR, NE = NP + NS + NN, NJ = NP + NN;
 constexpr int O_CE = 0, O_CS = NE;                                 // c_e and c_s_avg lead every layout (reference src/external.jl:275-365)
-constexpr int NA = 10, NZ = 10, NT = NA + NE + NZ;               // current collectors; temperature nodes a|p|s|n|z
+constexpr int NA = PL_NA, NZ = PL_NZ, NT = NA + NE + NZ;         // current collectors; temperature nodes a|p|s|n|z
+constexpr bool GRID_DEFAULT = NP == 10 && NS == 10 && NN == 10 && NR == 10 && NA == 10 && NZ == 10;
+constexpr int NRMAX = 16;                                          // Tables has room for the radial operator of any supported N_r
+// lane maps: the node pass gives control volume i to lane i; the twisted block sweeps put nodes 0 .. NE/2-1 in lanes 0 .. and nodes NE-1 .. NE/2 in lanes 32 .. (tw_node);
+// the particle phases give lane l row l % NR of particle pass * CS_G + l / NR
+static_assert(NP >= 2 && NS >= 2 && NN >= 2 && NE <= 48, "2 <= N_p, N_s, N_n and N_p + N_s + N_n <= 48 (one lane per node, two 32-lane halves in the sweeps)");
+static_assert(NR >= 10 && NR <= NRMAX, "10 <= N_r <= 16 (the radial operator of N_r = 9 has complex eigenvalues: no spectral resolvent; tools/gen_radial_tables.py)");
+constexpr int CS_G = WAVE / NR, CS_LANES = CS_G * NR, CS_PASS = (NJ + CS_G - 1) / CS_G;     // particles per pass, lanes in use, passes (default grid: 6, 60, 4)
 constexpr int MAXORD = 5;
 
 // Model traits: state layout  Y = [ c_e | c_s_avg | T (thermal) | film, SOH (SEI) || j | Phi_e | Phi_s | j_s (SEI) | I ]  and closures.
@@ -98,7 +126,14 @@ enum Key { K_D_n, K_D_p, K_D_s, K_D_sn, K_D_sp, K_Ea_D_sn, K_Ea_D_sp, K_Ea_k_n, 
 
 // read-only model tables in device memory
 struct Tables {
-  double M[NR * NR], LAM[NR], V[NR * NR], W[NR * NR];   // radial operator and its eigen-decomposition
+  // radial operator M (N_r x N_r, row-major), its eigenvalues LAM and eigenvectors V, W = V^-1, packed back to back for THIS translation unit's N_r (so that the
+  // offsets the kernels see do not depend on the largest supported N_r: vector global loads carry a 13-bit immediate offset); the host side fills the block through
+  // the strides of the variant's own N_r (plh_model_create)
+  double RAD[3 * NRMAX * NRMAX + NRMAX];
+  __host__ __device__ const double* Mp() const { return RAD; }
+  __host__ __device__ const double* LAMp() const { return RAD + NR * NR; }
+  __host__ __device__ const double* Vp() const { return RAD + NR * NR + NR; }
+  __host__ __device__ const double* Wp() const { return RAD + 2 * NR * NR + NR; }
   double BJ;                                            // surface-row BC factor
   int thidx[K_COUNT];                                   // position of each key in the theta vector (-1: absent)
   int chem;
@@ -187,7 +222,7 @@ template <class M> struct CellLDS {
   double resp[M::SD != 0 ? NJ : 1], rcjf[M::SD != 0 ? 2 : 1][2];    // quadratic / polynomial particles: d c_s* / d j after eliminating c_avg (and Q); 1/cj and 1/(-kappa - cj) of the factorisation
   double x2[3][M::THERMAL ? 1 : NE];
   double ctrlJ[2], bord;           // P-mode control row at the last Jacobian pass (I*I1C, V*I1C); border pivot d - v.x2
-  double w9[NJ];
+  double w9[NJ > 2 * NR ? NJ : 2 * NR];
   double sig[2];
   double red[M::W2 ? 16 : 1];      // two waves per cell: partial sums of the cross-wave reductions (ring of 4 x 2 waves x up to 2... see block_sum)
   SeiPool<M::SEI> sei;
@@ -204,7 +239,7 @@ template <class M> struct CellLDS {
 
 // per-lane registers that persist across phases
 struct LaneRegs {
-  double wreg[4];       // particle partial solutions kept across the Thomas phase
+  double wreg[CS_PASS]; // particle partial solutions kept across the Thomas phase
 };
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x & (WAVE - 1); }
@@ -556,8 +591,8 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
       S.sei.cjf = 0.0;
     }
   }
-  if constexpr (!M::THERMAL && M::SD == 0) { if (wave_id() == M::NWAVES - 1) for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->M[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
-  for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
+  if constexpr (!M::THERMAL && M::SD == 0) { if (wave_id() == M::NWAVES - 1) for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->Mp()[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
+  for (int k = 0; k < CS_PASS; k++) R.wreg[k] = 0.0;
   PL_XSYNC();
   if constexpr (M::THERMAL) thermal_setup(S, tb, th);
 }
@@ -829,24 +864,24 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   }
 }
 
-// c_s rows (residuals_c_s_avg!, Fickian FDM, residuals.jl:128-180): lane -> (particle = pass*6 + lane/10, row = lane%10)
+// c_s rows (residuals_c_s_avg!, Fickian FDM, residuals.jl:128-180): lane -> (particle = pass*CS_G + lane/NR, row = lane%NR)   (default grid: 4 passes of 6 particles)
 template <class M>
 PL_DEV void iso_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
   PL_MODEL(M);
   if constexpr (M::W2) { if (wave_id() != 1) return; }       // two waves per cell: the particle rows belong to wave 1
   const int lane = lane_id();
   const CellConst& c = S.cc;
-  const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
+  const int r = lane % NR, g = lane < CS_LANES ? lane / NR : CS_G - 1;
   double Mrow[NR];
   for (int k = 0; k < NR; k++) Mrow[k] = S.Mr[r * NR + k];
-  // the four passes are independent: four accumulation chains side by side (particle index clamped so that every lane computes)
-  int pp[4]; double acc[4];
+  // the passes are independent: CS_PASS accumulation chains side by side (particle index clamped so that every lane computes)
+  int pp[CS_PASS]; double acc[CS_PASS];
 #pragma unroll
-  for (int pass = 0; pass < 4; pass++) { const int p = pass * 6 + g; pp[pass] = p < NJ ? p : NJ - 1; acc[pass] = 0.0; }
+  for (int pass = 0; pass < CS_PASS; pass++) { const int p = pass * CS_G + g; pp[pass] = p < NJ ? p : NJ - 1; acc[pass] = 0.0; }
   // issue every LDS load first (one latency), then the arithmetic
-  double v[4][NR], jv[4], ypv[4];
+  double v[CS_PASS][NR], jv[CS_PASS], ypv[CS_PASS];
 #pragma unroll
-  for (int pass = 0; pass < 4; pass++) {
+  for (int pass = 0; pass < CS_PASS; pass++) {
 #pragma unroll
     for (int k = 0; k < NR; k++) v[pass][k] = Y[O_CS + pp[pass] * NR + k];
     jv[pass] = Y[O_J + pp[pass]];
@@ -856,14 +891,14 @@ PL_DEV void iso_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const
 #pragma unroll
   for (int k = 0; k < NR; k++) {
 #pragma unroll
-    for (int pass = 0; pass < 4; pass++) acc[pass] += Mrow[k] * v[pass][k];
+    for (int pass = 0; pass < CS_PASS; pass++) acc[pass] += Mrow[k] * v[pass][k];
   }
 #pragma unroll
-  for (int pass = 0; pass < 4; pass++) {
-    const int p = pass * 6 + g;
+  for (int pass = 0; pass < CS_PASS; pass++) {
+    const int p = pass * CS_G + g;
     double rhs = (p < NP ? kap_p : kap_n) * acc[pass];
     if (r == NR - 1) rhs += (p < NP ? bj_p : bj_n) * jv[pass];
-    if (lane < 60 && p < NJ) Fo[O_CS + p * NR + r] = rhs - ypv[pass];
+    if (lane < CS_LANES && p < NJ) Fo[O_CS + p * NR + r] = rhs - ypv[pass];
   }
 }
 
@@ -938,6 +973,7 @@ __device__ __forceinline__ void node_block(const CellLDS<M>& S, int i, double cj
 // back-substitution runs the other way with wave_shl:1; lane 15 is a ghost that re-publishes node 15's solution for node 14.
 // Every lane re-evaluates its recurrence at every stage (idempotent once its predecessor is final), so there are no per-stage selects.
 constexpr int TW_MID = NE / 2, TW_BASE = 32;
+constexpr int TW_FWD = NE - TW_MID;       // forward stages + 1: the backward-eliminated half holds NE - TW_MID nodes (the closing one included; one more than the other half when NE is odd)
 __device__ __forceinline__ int tw_node(int lane) { return lane < TW_MID ? lane : ((lane >= TW_BASE && lane < TW_BASE + (NE - TW_MID)) ? NE - 1 - (lane - TW_BASE) : -1); }
 __host__ __device__ constexpr int tw_lane(int node) { return node < TW_MID ? node : TW_BASE + (NE - 1 - node); }
 __device__ __forceinline__ double l22_of(int n) { return (n > 0 && sec_of(n) != 1 && sec_of(n - 1) == sec_of(n)) ? 1.0 : 0.0; }   // Phi_s row n x Phi_s[n-1]
@@ -971,7 +1007,7 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only
   if (!act) { r0 = 0.0; r1 = 0.0; r2 = 0.0; }
   double y0 = r0, y1 = r1, y2 = r2;
 #pragma unroll 2
-  for (int it = 1; it < TW_MID; it++) {
+  for (int it = 1; it < TW_FWD; it++) {
     const double p0 = shift_up1(y0), p1 = shift_up1(y1), p2 = shift_up1(y2);
     y0 = r0 - (C[0] * p0 + C[1] * p1 + C[2] * p2);
     y1 = r1 - (C[3] * p0 + C[4] * p1 + C[5] * p2);
@@ -1010,15 +1046,15 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
   } else
   if (!alg_only && (!M::W2 || wave_id() == 1)) {          // (two waves per cell: the resolvents are wave 1's, next to wave 0's Jacobian node pass)
     const int r = lane % NR;
-    // the 20 reciprocals 1/(kappa lam_m - cj) are formed by 20 lanes in parallel and passed through S.w9 (free outside the solves)
-    if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * tb->LAM[r] - cj);
+    // the 2 N_r reciprocals 1/(kappa lam_m - cj) are formed by 2 N_r lanes in parallel and passed through S.w9 (free outside the solves)
+    if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * tb->LAMp()[r] - cj);
     PL_SYNC();
     for (int el = 0; el < 2; el++) {
       double acc[NR];
       for (int k = 0; k < NR; k++) acc[k] = 0.0;
       for (int m = 0; m < NR; m++) {
-        const double f = tb->V[r * NR + m] * S.w9[el * NR + m];
-        for (int k = 0; k < NR; k++) acc[k] += f * tb->W[m * NR + k];
+        const double f = tb->Vp()[r * NR + m] * S.w9[el * NR + m];
+        for (int k = 0; k < NR; k++) acc[k] += f * tb->Wp()[m * NR + k];
       }
       if (lane < NR) for (int k = 0; k < NR; k++) S.Ainv[el][r * NR + k] = PL_F32(acc[k]);
       if (lane == NR - 1) S.sig[el] = acc[NR - 1];
@@ -1097,7 +1133,7 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     for (int k = 0; k < 9; k++) { LDm[k] = 0.0; Dn[k] = D[k]; }
     inv3(D, Dinv);
 #pragma unroll 1
-    for (int it = 1; it < TW_MID; it++) {
+    for (int it = 1; it < TW_FWD; it++) {
       double P[9];
       for (int k = 0; k < 9; k++) P[k] = shift_up1(Dinv[k]);
       for (int k = 0; k < 3; k++) {
@@ -1154,29 +1190,36 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   // a. particle partial solutions  w = A^-1 b_cs : four independent accumulation chains (pass = particles pass*6 .. pass*6+5)
   if constexpr (M::SD == 0)
   if (!alg_only && (!M::W2 || wave_id() == 1)) {
-    const int gg = lane < 60 ? g : 5;
-    int pp[4]; double w[4];
+    const int gg = lane < CS_LANES ? g : CS_G - 1;
+    int pp[CS_PASS]; double w[CS_PASS];
 #pragma unroll
-    for (int pass = 0; pass < 4; pass++) { const int p = pass * 6 + gg; pp[pass] = p < NJ ? p : NJ - 1; w[pass] = 0.0; }
-    double AP[NR], AN[NR], bv[4][NR];
+    for (int pass = 0; pass < CS_PASS; pass++) { const int p = pass * CS_G + gg; pp[pass] = p < NJ ? p : NJ - 1; w[pass] = 0.0; }
+    double AP[NR], AN[NR], bv[CS_PASS][NR];
 #pragma unroll
     for (int k = 0; k < NR; k++) { AP[k] = S.Ainv[0][r * NR + k]; AN[k] = S.Ainv[1][r * NR + k]; }
 #pragma unroll
-    for (int pass = 0; pass < 4; pass++) {
+    for (int pass = 0; pass < CS_PASS; pass++) {
 #pragma unroll
       for (int k = 0; k < NR; k++) bv[pass][k] = b[O_CS + pp[pass] * NR + k];
     }
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-      w[0] += AP[k] * bv[0][k];                                   // pass 0: particles 0..5 (cathode)
-      w[1] += (pp[1] < NP ? AP[k] : AN[k]) * bv[1][k];            // pass 1: particles 6..11 (mixed)
-      w[2] += AN[k] * bv[2][k];                                   // passes 2,3: anode
-      w[3] += AN[k] * bv[3][k];
+      if constexpr (GRID_DEFAULT) {
+        w[0] += AP[k] * bv[0][k];                                   // pass 0: particles 0..5 (cathode)
+        w[1] += (pp[1] < NP ? AP[k] : AN[k]) * bv[1][k];            // pass 1: particles 6..11 (mixed)
+        w[2] += AN[k] * bv[2][k];                                   // passes 2,3: anode
+        w[3] += AN[k] * bv[3][k];
+      } else {
+        // a pass that lies entirely in one electrode takes that electrode's resolvent without a select (known per pass after unrolling)
+#pragma unroll
+        for (int pass = 0; pass < CS_PASS; pass++)
+          w[pass] += ((pass + 1) * CS_G <= NP ? AP[k] : (pass * CS_G >= NP ? AN[k] : (pp[pass] < NP ? AP[k] : AN[k]))) * bv[pass][k];
+      }
     }
 #pragma unroll
-    for (int pass = 0; pass < 4; pass++) {
-      const int p = pass * 6 + gg;
-      if (lane < 60 && p < NJ && r == NR - 1) S.w9[p] = w[pass];
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      const int p = pass * CS_G + gg;
+      if (lane < CS_LANES && p < NJ && r == NR - 1) S.w9[p] = w[pass];
       R.wreg[pass] = w[pass];
     }
   }
@@ -1283,9 +1326,9 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   // f. particles:  dc = w - (A^-1 e_last) * bj * dj
   if constexpr (M::SD == 0)
   if (!alg_only && (!M::W2 || wave_id() == 1)) {
-    for (int pass = 0; pass < 4; pass++) {
-      const int p = pass * 6 + g;
-      if (lane < 60 && p < NJ) {
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      const int p = pass * CS_G + g;
+      if (lane < CS_LANES && p < NJ) {
         const int el = p < NP ? 0 : 1;
         const double bj = el == 0 ? c.bj_p : c.bj_n;
         b[O_CS + p * NR + r] = R.wreg[pass] - S.Ainv[el][r * NR + NR - 1] * bj * b[O_J + p];
@@ -1313,7 +1356,7 @@ PL_DEV double iso_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, 
     case JT_CE_D: return S.ceD[a] - cj;
     case JT_CE_U: return S.ceU[a];
     case JT_CE_J: return S.ceJ[a];
-    case JT_CS_CS: return (a < NP ? c.kap_p : c.kap_n) * tb->M[bb * NR + cc] - (bb == cc ? cj : 0.0);
+    case JT_CS_CS: return (a < NP ? c.kap_p : c.kap_n) * tb->Mp()[bb * NR + cc] - (bb == cc ? cj : 0.0);
     case JT_CS_J: if constexpr (M::SD != 0) return c.csr[a < NP ? 0 : 1]; else return a < NP ? c.bj_p : c.bj_n;
     case JT_CSA_D: return -cj;
     case JT_Q_Q: return -(a < NP ? c.kap_p : c.kap_n) - cj;

@@ -15,12 +15,14 @@
 
 namespace pl {
 
+// most trips of a lane through a state vector over the variants of this grid (thermal: NT more states; SEI: 2 NN + 1 more; polynomial: NJ more); 6 on the default grid
+constexpr int NTRIP_MAX = (2 * NE + NJ * NR + 2 * NJ + 1 + (NT > 2 * NN + 1 ? NT : 2 * NN + 1) + WAVE - 1) / WAVE;
 struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live in CellLDS (S.ida_*)
   double tn, hh, hused, cj, cjlast, cjold, cjratio, ss, rr, h0_forced, rtol, atol;
-  double ew[6];      // per-lane error weights of this step
-  double ph[4][6];
-  double ee[6];      // per-lane accumulated Newton correction of the step
-  double pa[6], pb[6];   // predictor y_n(0), y'_n(0) of the step (models with M::PRED_REGS)   // per-lane entries of the BDF history vectors that are not kept in LDS (models with M::PHI_LDS < 6): [j - PHI_LDS][trip]
+  double ew[NTRIP_MAX];      // per-lane error weights of this step
+  double ph[4][NTRIP_MAX];
+  double ee[NTRIP_MAX];      // per-lane accumulated Newton correction of the step
+  double pa[NTRIP_MAX], pb[NTRIP_MAX];   // predictor y_n(0), y'_n(0) of the step (models with M::PRED_REGS)   // per-lane entries of the BDF history vectors that are not kept in LDS (models with M::PHI_LDS < 6): [j - PHI_LDS][trip]
   int kk, kused, knew, phase, ns, maxord;
   int nst;
 };
@@ -58,7 +60,7 @@ template <bool GEN, class M>
 PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
                                                       int mode, double value, double reltol_init, double* bsave = nullptr, int nref = 0) {
   LaneRegs R;                                                        // (the algebraic solves do not touch the particle registers)
-  for (int k = 0; k < 4; k++) R.wreg[k] = 0.0;
+  for (int k = 0; k < CS_PASS; k++) R.wreg[k] = 0.0;
   int iters = 0;
   PL_MODEL(M);
   const int lane = lane_id();
@@ -120,7 +122,7 @@ PL_DEV void ida_reinit(CellLDS<M>& S, IdaScalars& I, const double* y0, const dou
   I.cjratio = 1.0; I.ss = 20.0; I.phase = 0; I.ns = 0; I.h0_forced = 0.0; I.cj = 0.0; I.cjlast = 0.0; I.cjold = 0.0; I.rr = 0.0; I.knew = 0;
   if (lane <= MAXORD && wave_id() == 0) { S.ida_psi[lane] = 0; S.ida_alpha[lane] = 0; S.ida_beta[lane] = 0; S.ida_sigma[lane] = 0; S.ida_gamma[lane] = 0; }
   PL_VEC(n) { S.phi[0][n] = y0[n]; S.phi[1][n] = yp0[n]; }
-  for (int q = 0; q < 6; q++) { I.ph[0][q] = 0.0; I.ph[1][q] = 0.0; I.ph[2][q] = 0.0; I.ph[3][q] = 0.0; }
+  for (int q = 0; q < NTRIP_MAX; q++) { I.ph[0][q] = 0.0; I.ph[1][q] = 0.0; I.ph[2][q] = 0.0; I.ph[3][q] = 0.0; }
   PL_XSYNC();
 }
 

@@ -325,7 +325,7 @@ PL_DEV void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const 
   auto& TP = S.th;
   const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
   double Mrow[NR], Wrow[NR];
-  for (int k = 0; k < NR; k++) { Mrow[k] = tb->M[r * NR + k]; if (WANT_JAC) Wrow[k] = tb->W[r * NR + k]; }
+  for (int k = 0; k < NR; k++) { Mrow[k] = tb->Mp()[r * NR + k]; if (WANT_JAC) Wrow[k] = tb->Wp()[r * NR + k]; }
 #pragma unroll
   for (int pass = 0; pass < 4; pass++) {
     const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
@@ -511,7 +511,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
   if (!alg_only) {
     if (lane < NJ) TP.kapF[lane] = TP.kapP[lane];
     double Vrow[NR], wl[NR], lm[NR];
-    for (int m = 0; m < NR; m++) { Vrow[m] = tb->V[r * NR + m]; wl[m] = tb->W[m * NR + NR - 1]; lm[m] = tb->LAM[m]; }
+    for (int m = 0; m < NR; m++) { Vrow[m] = tb->Vp()[r * NR + m]; wl[m] = tb->Wp()[m * NR + NR - 1]; lm[m] = tb->LAMp()[m]; }
     double ae[4], aq[4];
     for (int pass = 0; pass < 4; pass++) {
       const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
@@ -769,8 +769,8 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
   // a. particle partial solutions w = A_p^-1 b_cs  (two mat-vecs through the spectral form); collector forward/backward substitution
   if (!alg_only) {
     double Wrow[NR], Vrow[NR];
-    for (int k = 0; k < NR; k++) { Wrow[k] = tb->W[r * NR + k]; Vrow[k] = tb->V[r * NR + k]; }
-    const double lam_r = tb->LAM[r];
+    for (int k = 0; k < NR; k++) { Wrow[k] = tb->Wp()[r * NR + k]; Vrow[k] = tb->Vp()[r * NR + k]; }
+    const double lam_r = tb->LAMp()[r];
     for (int pass = 0; pass < 4; pass++) {
       const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
       double y = 0.0;
@@ -894,14 +894,14 @@ PL_DEV double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ 
   const int t = w >> 24, a = (w >> 16) & 255, bb = (w >> 8) & 255, cc = w & 255;
   const auto& TP = S.th;
   switch (t) {
-    case JT_CS_CS: return (FROZEN ? TP.kapF[a] : TP.kapP[a]) * tb->M[bb * NR + cc] - (bb == cc ? cj : 0.0);   // (kapP follows every residual pass, kapF is the factored one)
+    case JT_CS_CS: return (FROZEN ? TP.kapF[a] : TP.kapP[a]) * tb->Mp()[bb * NR + cc] - (bb == cc ? cj : 0.0);   // (kapP follows every residual pass, kapF is the factored one)
     case TT_CS_T: {                                      // d(kappa_p(T) (M c)_r)/dT
       double acc = 0.0;
       if (FROZEN) {                                      // q = kappa' M c of the last factorisation, rebuilt from A^-1 q: q = (kappa M - cj I) (A^-1 q)
-        for (int k = 0; k < NR; k++) acc += (TP.kapF[a] * tb->M[bb * NR + k] - (bb == k ? TP.cjf : 0.0)) * TP.AinvQ[a][k];
+        for (int k = 0; k < NR; k++) acc += (TP.kapF[a] * tb->Mp()[bb * NR + k] - (bb == k ? TP.cjf : 0.0)) * TP.AinvQ[a][k];
         return acc;
       }
-      for (int k = 0; k < NR; k++) acc += tb->M[bb * NR + k] * S.yy[O_CS + a * NR + k];      // evaluated at the state in S.yy (plh_jacobian)
+      for (int k = 0; k < NR; k++) acc += tb->Mp()[bb * NR + k] * S.yy[O_CS + a * NR + k];      // evaluated at the state in S.yy (plh_jacobian)
       return TP.dkapP[a] * acc;
     }
     case TT_J_T: return TP.gT[a];

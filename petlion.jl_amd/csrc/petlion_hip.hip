@@ -12,8 +12,10 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <mutex>
+
 #include "plh_host.h"
-#include "radial_tables_nr10.h"
 
 #ifdef PL_WAVE_EMU
 // the test-only wave-emulator build is a single translation unit: every variant's kernels are compiled right here, no RCCL
@@ -112,6 +114,21 @@ static const VariantOps* variant_ops(int id) {
 #undef PL_OPS_CASE
   }
   return nullptr;
+}
+// libraries of variants compiled for other discretisations (plh_register_grid_library): kept loaded for the life of the process
+struct GridLib { std::string path; void* handle; int grid[6]; const VariantOps* (*ops)(int); };
+static std::vector<GridLib> g_grid_libs;
+static std::mutex g_grid_mutex;
+static bool desc_matches(const plh_model_desc* d, const VariantOps* o) {
+  return o->chem == d->chemistry && o->sei == (d->aging_SEI ? 1 : 0) && o->thermal == (d->temperature ? 1 : 0) && o->mixed == (d->precision == PLH_PREC_MIXED ? 1 : 0) &&
+         o->sd == d->solid_diffusion && o->tf == d->thermodynamic_factor && o->rxn == d->rxn && o->w2 == (d->waves_per_cell == 2 ? 1 : 0);
+}
+// N_a / N_z only exist with temperature = true, N_r only for Fickian diffusion (params.jl:119-136); an absent dimension matches anything
+static bool grid_matches(const plh_model_desc* d, const int* g) {
+  if (d->N_p != g[0] || d->N_s != g[1] || d->N_n != g[2]) return false;
+  if (d->solid_diffusion == PLH_SD_FICKIAN && (d->N_r_p != g[3] || d->N_r_n != g[3])) return false;
+  if (d->temperature && (d->N_a != g[4] || d->N_z != g[5])) return false;
+  return true;
 }
 
 // ---- per-handle state ----
@@ -299,17 +316,25 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
     return fail(PLH_E_ARG, "solid_diffusion / thermodynamic_factor / rxn out of range");
   if (d->waves_per_cell < 0 || d->waves_per_cell > 2) return fail(PLH_E_ARG, "waves_per_cell must be 0, 1 or 2");
   const VariantOps* ops = nullptr;
+  bool variant_exists = false;
   for (int v = 0; v < PL_N_VARIANTS; v++) {
     const VariantOps* o = variant_ops(v);
-    if (o && o->chem == d->chemistry && o->sei == (d->aging_SEI ? 1 : 0) && o->thermal == (d->temperature ? 1 : 0) && o->mixed == (d->precision == PLH_PREC_MIXED ? 1 : 0) &&
-        o->sd == d->solid_diffusion && o->tf == d->thermodynamic_factor && o->rxn == d->rxn && o->w2 == (d->waves_per_cell == 2 ? 1 : 0)) ops = o;
+    if (o && desc_matches(d, o)) { variant_exists = true; if (grid_matches(d, o->grid)) ops = o; }
   }
+  if (!ops) {                                            // another discretisation: a registered grid library
+    std::lock_guard<std::mutex> lk(g_grid_mutex);
+    for (const GridLib& gl : g_grid_libs) {
+      if (!grid_matches(d, gl.grid)) continue;
+      for (int v = 0; v < PL_N_VARIANTS && !ops; v++) { const VariantOps* o = gl.ops(v); if (o && desc_matches(d, o)) { variant_exists = true; ops = o; } }
+    }
+  }
+  if (!ops && variant_exists)
+    return fail(PLH_E_UNSUPPORTED, "discretisation: the library's built-in kernels are compiled for N_p = N_s = N_n = N_r_p = N_r_n = N_a = N_z = 10; another grid (2 <= N_p, N_s, N_n, "
+                                   "N_p + N_s + N_n <= 48, 10 <= N_r_p = N_r_n <= 16) is one more build of csrc/variant_tu.hip, registered with plh_register_grid_library() before "
+                                   "plh_model_create (petlion.jl_amd/grids.py does both; INTEGRATION.md)");
   if (!ops) return fail(PLH_E_UNSUPPORTED, "this chemistry / temperature / aging / precision / model-option combination is not instantiated on the device (built in fp64: LCO and NMC "
                                            "isothermal with or without SEI aging, LGM50 isothermal, LCO with temperature; LCO isothermal with ONE of: quadratic or polynomial solid diffusion, the nonlinear "
                                            "thermodynamic factor, MHC kinetics; mixed precision: LCO isothermal, NMC + SEI, LCO with temperature)");
-  if (d->temperature && (d->N_a != NA || d->N_z != NZ)) return fail(PLH_E_UNSUPPORTED, "discretisation: only N_a = N_z = 10 is instantiated");
-  if (d->N_p != NP || d->N_s != NS || d->N_n != NN || (d->solid_diffusion == PLH_SD_FICKIAN && (d->N_r_p != NR || d->N_r_n != NR)))
-    return fail(PLH_E_UNSUPPORTED, "discretisation: only N_p = N_s = N_n = N_r_p = N_r_n = 10 is instantiated");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(PLH_E_HIP, "no HIP device visible: the product path has no CPU fallback");
   int dev = d->device;
@@ -324,9 +349,11 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   m->desc = *d; m->desc.device = dev; m->device = dev; m->ops = ops;
   Tables& tb = m->h_tb;
   memset(&tb, 0, sizeof(tb));
-  memcpy(tb.M, PL_RADIAL_M, sizeof(tb.M)); memcpy(tb.LAM, PL_RADIAL_LAM, sizeof(tb.LAM));
-  memcpy(tb.V, PL_RADIAL_V, sizeof(tb.V)); memcpy(tb.W, PL_RADIAL_W, sizeof(tb.W));
-  tb.BJ = PL_RADIAL_BJ_FACTOR; tb.chem = d->chemistry;
+  { const int nr = ops->grid[3];                         // radial operator of the variant's N_r (packed N_r x N_r)
+    double* r = tb.RAD;                                  // (the variant's kernels read the block with their own N_r: Tables::Mp / LAMp / Vp / Wp)
+    memcpy(r, ops->rad_M, sizeof(double) * nr * nr); memcpy(r + nr * nr, ops->rad_LAM, sizeof(double) * nr);
+    memcpy(r + nr * nr + nr, ops->rad_V, sizeof(double) * nr * nr); memcpy(r + 2 * nr * nr + nr, ops->rad_W, sizeof(double) * nr * nr); }
+  tb.BJ = ops->rad_BJ; tb.chem = d->chemistry;
   const VariantInfo vi = variant_keys(ops->chem, ops->sei, ops->thermal, ops->rxn);
   m->P = vi.nkeys; m->key_names = vi.keys; m->key_defaults = vi.defaults;
   tb.P = m->P;
@@ -339,6 +366,29 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
     plh_model_destroy(m); return fail(PLH_E_HIP, "hipMalloc / hipMemcpy of the model tables failed");
   }
   *out = m;
+  return 0;
+}
+
+int plh_register_grid_library(const char* path) {
+  if (!path) return fail(PLH_E_ARG, "null path");
+  std::lock_guard<std::mutex> lk(g_grid_mutex);
+  for (const GridLib& gl : g_grid_libs) if (gl.path == path) return 0;
+  void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return fail(PLH_E_ARG, std::string("dlopen failed: ") + dlerror());
+  GridLib gl; gl.path = path; gl.handle = h;
+  gl.ops = (const VariantOps* (*)(int))dlsym(h, "plh_grid_variant_ops");
+  void (*dims)(int*) = (void (*)(int*))dlsym(h, "plh_grid_dims");
+  if (!gl.ops || !dims) { dlclose(h); return fail(PLH_E_ARG, "not a grid library: plh_grid_variant_ops / plh_grid_dims missing (build csrc/variant_tu.hip with -DPL_GRID_LIBRARY)"); }
+  dims(gl.grid);
+  int found = 0;
+  for (int v = 0; v < PL_N_VARIANTS; v++) {
+    const VariantOps* o = gl.ops(v);
+    if (!o) continue;
+    if (memcmp(o->grid, gl.grid, sizeof(gl.grid)) != 0 || o->id != v) { dlclose(h); return fail(PLH_E_ARG, "grid library: variant table does not match the library's own dimensions (stale build?)"); }
+    found++;
+  }
+  if (!found) { dlclose(h); return fail(PLH_E_ARG, "grid library holds no variant"); }
+  g_grid_libs.push_back(gl);
   return 0;
 }
 

@@ -237,7 +237,7 @@ unsigned classify(const Tables& tb, int mode, int r, int c) {
   }
   if (r < N_CECS) {                                 // c_s row (p, rr)
     const int p = (r - O_CS) / NR, rr = (r - O_CS) % NR;
-    if (c >= O_CS && c < N_CECS && (c - O_CS) / NR == p) { const int cc = (c - O_CS) % NR; return (tb.M[rr * NR + cc] != 0.0 || rr == cc) ? W(JT_CS_CS, p, rr, cc) : 0; }
+    if (c >= O_CS && c < N_CECS && (c - O_CS) / NR == p) { const int cc = (c - O_CS) % NR; return (tb.Mp()[rr * NR + cc] != 0.0 || rr == cc) ? W(JT_CS_CS, p, rr, cc) : 0; }
     if (rr == NR - 1 && c == O_J + p) return W(JT_CS_J, p, 0, 0);
     return 0;
   }
@@ -327,7 +327,8 @@ template <class M> struct OpsOf {
     else PL_LAUNCH((k_integrate<M, false>), a.n_cells, WAVE * M::NWAVES, st, a);
   }
   static const VariantOps* table(int id) {
-    static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::MIXED ? 1 : 0, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, sizeof(CellLDS<M>), &classify<M>, &sections_of<M>,
+    static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::MIXED ? 1 : 0, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, {NP, NS, NN, NR, NA, NZ},
+                                   PL_RADIAL_M, PL_RADIAL_LAM, PL_RADIAL_V, PL_RADIAL_W, PL_RADIAL_BJ_FACTOR, sizeof(CellLDS<M>), &classify<M>, &sections_of<M>,
                                    &initial_guess, &residual, &jacobian, &linear_solve, &init_consistent, &integrate};
     return &ops;
   }

@@ -36,6 +36,8 @@ struct SectionInfo { const char* name; int start, len; };
 struct VariantOps {
   int id, chem, sei, thermal, mixed, sd, tf, rxn, w2;
   int N, Nd;
+  int grid[6];                                                                       // N_p, N_s, N_n, N_r (= N_r_p = N_r_n), N_a, N_z this table was compiled for
+  const double *rad_M, *rad_LAM, *rad_V, *rad_W; double rad_BJ;                      // radial operator tables of this N_r (radial_tables.h), N_r x N_r packed
   size_t lds_bytes;                                                                  // sizeof(CellLDS<M>): LDS per cell (= per workgroup)
   unsigned (*classify)(const pl::Tables& tb, int mode, int r, int c);              // decode word of the structural Jacobian entry (r, c), 0 if structurally zero
   int (*sections)(SectionInfo* out);
@@ -53,3 +55,8 @@ struct VariantOps {
 #define PL_DECLARE_OPS(ID, CHEM, SEI, TH, MIX, SD, TF, RXN, W2) const VariantOps* plh_variant_ops_##ID() __attribute__((weak));
 PL_VARIANT_LIST(PL_DECLARE_OPS)
 #undef PL_DECLARE_OPS
+
+// A library of variants compiled for ANOTHER discretisation (variant_tu.hip with -DPL_NP=.. etc. and -DPL_GRID_LIBRARY; petlion.jl_amd/grids.py) exports these two
+// C symbols; plh_register_grid_library() loads it and consults its tables in plh_model_create.
+extern "C" const VariantOps* plh_grid_variant_ops(int id);     // nullptr: variant not built into this grid library
+extern "C" void plh_grid_dims(int* grid6);

@@ -1,10 +1,26 @@
 // variant_tu.hip -- one model variant's kernels: compile with -DPL_VARIANT=<id> (ids and template arguments: PL_VARIANT_LIST in plh_host.h).
 // All variants link into libpetlion_hip.so next to the host side of the C ABI (petlion_hip.hip).
+#include "radial_tables.h"
 #include "petlion_kernels.h"
 
-#ifndef PL_VARIANT
+#if !defined(PL_VARIANT) && !defined(PL_GRID_GLUE)
 #error "compile with -DPL_VARIANT=<id>"
 #endif
+
+#ifdef PL_GRID_GLUE
+// Glue object of a library of variants compiled for ANOTHER discretisation (petlion.jl_amd/grids.py): the variant objects of that library are this file compiled with
+// -DPL_VARIANT=<id> -DPL_NP=.. -DPL_NS=.. -DPL_NN=.. -DPL_NR=.. -DPL_NA=.. -DPL_NZ=.. (and -Dpl=<per-grid namespace>, hidden visibility), this object adds the two C
+// entry points plh_register_grid_library() looks for.  Variants that were not built into the library resolve to null (weak declarations in plh_host.h).
+extern "C" __attribute__((visibility("default"))) const VariantOps* plh_grid_variant_ops(int id) {
+  switch (id) {
+#define PL_OPS_CASE(ID, CHEM, SEI, TH, MIX, SD, TF, RXN, W2) case ID: return plh_variant_ops_##ID ? plh_variant_ops_##ID() : nullptr;
+    PL_VARIANT_LIST(PL_OPS_CASE)
+#undef PL_OPS_CASE
+  }
+  return nullptr;
+}
+extern "C" __attribute__((visibility("default"))) void plh_grid_dims(int* g) { g[0] = pl::NP; g[1] = pl::NS; g[2] = pl::NN; g[3] = pl::NR; g[4] = pl::NA; g[5] = pl::NZ; }
+#else
 
 #define PL_DEFINE_OPS(ID, CHEM, SEI, TH, MIX, SD, TF, RXN, W2) \
   const VariantOps* plh_variant_ops_##ID() { return pl::OpsOf<pl::ModelT<CHEM, SEI, TH, MIX, SD, TF, RXN, W2>>::table(ID); }
@@ -22,3 +38,4 @@ PL_VARIANT_LIST(PL_DEFINE_OPS)
 #define PL_ONE(ID) PL_ONE_(ID)
 PL_ONE(PL_VARIANT)
 #endif
+#endif  // PL_GRID_GLUE

@@ -1,0 +1,97 @@
+"""Kernels for discretisations other than the built-in one (reference src/params.jl:119-136: petlion(...; N_p, N_s, N_n, N_r_p, N_r_n, N_a, N_z)).
+
+The grid dimensions are compile-time constants of the device source (one lane per node, register-resident blocks, LDS arrays sized by the grid), so another grid is
+another build of csrc/variant_tu.hip -- the counterpart of the reference generating and caching its functions per model (generate_functions.jl:44-94, the
+`saved_models/` cache).  `library(grid, variant_id)` compiles (hipcc, gfx950; once, cached under petlion.jl_amd/_grids/) a shared library holding the requested
+model variants for that grid; Model.__init__ registers it with plh_register_grid_library() and then creates the handle as usual.
+
+Limits (static_asserts in csrc/dfn_cell.h): 2 <= N_p, N_s, N_n; N_p + N_s + N_n <= 48; 10 <= N_r_p = N_r_n <= 16; temperature = true keeps N_a = N_z = 10 and the default
+sandwich (the thermal elimination hard-wires its four second-neighbour rows).  No CPU fallback: without hipcc the build fails loudly."""
+import json
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+GRID_DIR = os.path.join(HERE, "_grids")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+DEFAULT = (10, 10, 10, 10, 10, 10)
+
+
+def variant_table():
+    """rows of PL_VARIANT_LIST (csrc/plh_host.h): id -> (chemistry, sei, thermal, mixed, sd, tf, rxn, w2) as the C spellings"""
+    txt = open(os.path.join(CSRC, "plh_host.h")).read()
+    rows = {}
+    for m in re.finditer(r"X\((\d+),\s*(\w+),\s*(\w+),\s*(\w+),\s*(\w+),\s*(\w+),\s*(\w+),\s*(\w+),\s*(\d+)\)", txt):
+        rows[int(m.group(1))] = m.groups()[1:]
+    return rows
+
+
+def variant_id(chemistry, sei, thermal, mixed, sd, tf, rxn, w2):
+    """id of the model variant with these options (the names are those of include/petlion_hip.h), None if it is not instantiated"""
+    want = ("PLH_CHEM_" + chemistry, "true" if sei else "false", "true" if thermal else "false", "true" if mixed else "false", "PLH_SD_" + sd, "PLH_TF_" + tf,
+            "PLH_RXN_" + rxn, str(int(w2)))
+    for k, row in variant_table().items():
+        if tuple(row) == want:
+            return k
+    return None
+
+
+def grid_tuple(N_p, N_s, N_n, N_r, N_a=10, N_z=10):
+    return (int(N_p), int(N_s), int(N_n), int(N_r), int(N_a), int(N_z))
+
+
+def check(grid, thermal=False, sei=False):
+    p, s, n, r, a, z = grid
+    if sei and n < 3:
+        raise ValueError("discretisation: aging = :SEI needs N_n >= 3 (the SOH row extrapolates j_s from three nodes, residuals.jl:278-297)")
+    if min(p, s, n) < 2 or p + s + n > 48:
+        raise ValueError("discretisation: 2 <= N_p, N_s, N_n and N_p + N_s + N_n <= 48 (one lane per node)")
+    if not 10 <= r <= 16:
+        raise ValueError("discretisation: 10 <= N_r_p = N_r_n <= 16 (radial operator tables: tools/gen_radial_tables.py)")
+    if thermal and grid != DEFAULT:
+        raise NotImplementedError("temperature = true is built for the default discretisation only")
+
+
+def defines(grid):
+    p, s, n, r, a, z = grid
+    tag = "g%d_%d_%d_%d_%d_%d" % grid
+    return tag, ["-DPL_NP=%d" % p, "-DPL_NS=%d" % s, "-DPL_NN=%d" % n, "-DPL_NR=%d" % r, "-DPL_NA=%d" % a, "-DPL_NZ=%d" % z, "-Dpl=pl_" + tag]
+
+
+def _sources_mtime():
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))] + [os.path.join(HERE, "..", "include", "petlion_hip.h")]
+    return max(os.path.getmtime(f) for f in files)
+
+
+def library(grid, variants, force=False):
+    """path of the grid library holding (at least) `variants` for `grid`, building it if it is missing, stale, or lacks one of them"""
+    check(grid, thermal=any(variant_table()[v][2] == "true" for v in variants))
+    tag, defs = defines(grid)
+    os.makedirs(GRID_DIR, exist_ok=True)
+    lib = os.path.join(GRID_DIR, "libplh_%s.so" % tag)
+    manifest = os.path.join(GRID_DIR, "libplh_%s.json" % tag)
+    have = []
+    if os.path.exists(lib) and os.path.exists(manifest) and os.path.getmtime(lib) >= _sources_mtime():
+        have = json.load(open(manifest))["variants"]
+    if not force and set(variants) <= set(have):
+        return lib
+    allv = sorted(set(have) | set(variants))
+    src = os.path.join(CSRC, "variant_tu.hip")
+    common = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-Wno-pass-failed"] + defs
+    jobs, objs = [], []
+    for v in allv:
+        o = os.path.join(GRID_DIR, "%s_v%d.o" % (tag, v))
+        objs.append(o)
+        # the build mode of the built-in isothermal kernels (__graft_entry__.py): -O3, every device function inlined late
+        jobs.append(subprocess.Popen(common + ["-mllvm", "-amdgpu-function-calls=false", "-O3", "-DPL_VARIANT=%d" % v, "-c", src, "-o", o]))
+    glue = os.path.join(GRID_DIR, "%s_glue.o" % tag)
+    jobs.append(subprocess.Popen(common + ["-O2", "-DPL_GRID_GLUE", "-c", src, "-o", glue]))
+    if any(j.wait() for j in jobs):
+        raise RuntimeError("hipcc failed building the kernels of discretisation %r" % (grid,))
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", glue] + objs + ["-o", lib])
+    json.dump({"grid": list(grid), "variants": allv}, open(manifest, "w"))
+    for o in objs + [glue]:
+        os.remove(o)
+    return lib

@@ -428,3 +428,103 @@ def test_f4_lgm50_chemistry(emu_models_f4, O, pkg):
     assert "D_e" in p.θ_keys and "D_p" not in p.θ_keys and len(p.θ_keys) == 33
     ens = check_f4_variant(p, O, pkg, "lgm50")
     assert ens.run_info[0, 0]["flag"] == 1 and 3500.0 < ens.run_info[0, 0]["t_end"] < 3600.0          # a 1C discharge ends on V_min = 2.5 V shortly before 1 h
+
+
+# ---- other discretisations (reference src/params.jl:119-136): the kernels of another grid are one more build of the same device source -------------------------
+def emu_grid_model(pkg, cathode, grid, variant_id, **kw):
+    import build_emu
+    g = tuple(grid) + (10, 10)
+    return pkg.petlion(cathode, N_p=grid[0], N_s=grid[1], N_n=grid[2], N_r_p=grid[3], N_r_n=grid[3], _lib_path=build_emu.build(), _grid_lib=build_emu.build_grid(g, [variant_id]), **kw)
+
+
+def check_grid_model(p, O, pkg, identical=True):
+    """a model on another grid against the oracle variant generated for that grid (oracle/codegen.py): theta keys and CSC pattern, residual 1e-12 / Jacobian 1e-9 /
+    solve 1e-8, consistent initialisation, two 1C discharges"""
+    parity.check_keys_and_pattern(p, O)
+    parity.check_evaluators(p, O, n_cells=2)
+    parity.check_init(p, O, None)
+    Th = pkg.theta_matrix(p, 2, {"D_sp": np.array([1.0, 0.6]) * p.θ["D_sp"]})
+    ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0)
+    for i in range(2):
+        ro = O.simulate(p.variant, Th[i], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}]))
+        if identical:
+            parity.compare_trajectory(ens, i, ro, rtol_state=1e-6)
+        else:   # a discharge that ends on the voltage knee: the stop time is reproducible to the floor discussed in test_gpu_parity.py, one Newton iteration may differ
+            assert ens.run_info[i, 0]["flag"] == ro["runs"][0]["flag"] and int(ens.counters[i]["n_steps"]) == ro["counters"]["n_steps"]
+            assert abs(int(ens.counters[i]["n_newton"]) - ro["counters"]["n_newton"]) <= 2
+            assert abs(ens.run_info[i, 0]["t_end"] - ro["runs"][0]["t_end"]) < 1e-7 * ro["runs"][0]["t_end"] and parity.state_rel_err(ens.Y[i], ro["Y"]) < 2e-6
+
+
+def test_other_discretisation_lco_12_7_9_11(pkg, O):
+    """N_p = 12, N_s = 7, N_n = 9, N_r = 11 (330 states): unequal sections, N_r != 10, six trips per lane"""
+    check_grid_model(emu_grid_model(pkg, pkg.LCO, (12, 7, 9, 11), 0), O, pkg)
+
+
+def test_other_discretisation_nmc_sei_6_5_8_13(pkg, O):
+    """NMC + SEI on N_p = 6, N_s = 5, N_n = 8, N_r = 13 (266 states): an odd number of nodes (the two halves of the twisted sweeps differ by one), four particles per pass"""
+    check_grid_model(emu_grid_model(pkg, pkg.NMC, (6, 5, 8, 13), 3, aging="SEI"), O, pkg, identical=False)
+
+
+def check_grid_self_consistency(p, pkg, dm, n_fd=6):
+    """grids without a generated oracle variant: the device residual against the oracle's PYTHON restatement evaluated directly (oracle/dfn_model.py, FloatOps), the
+    device Jacobian against central differences of the device residual, the device solve against a dense solve of the device Jacobian"""
+    lib, h, N = p._lib, p._h, p.N.tot
+    model = dm.Model(cathode="LCO", Np=p.N.p, Ns=p.N.s, Nn=p.N.n, Nrp=p.N.r_p, Nrn=p.N.r_n)
+    assert model.lay.N == N
+    th = p.theta_vector()[None, :].copy()
+    thd = dict(model.theta); thd.update(dict(zip(p.θ_keys, th[0])))
+    rng = np.random.default_rng(5)
+    Y = np.array([dm.initial_guess(model, 0.6, thd)]); Y[0, -1] = -1.0
+    Yd = np.zeros((1, N)); soc = np.array([0.6])
+    assert lib.plh_initial_guess(h, 1, th.ctypes.data, soc.ctypes.data, Yd.ctypes.data, 0, None) == 0
+    assert np.allclose(Yd[0, :-1], Y[0, :-1], rtol=1e-13, atol=0)
+    Y *= 1 + 1e-3 * rng.standard_normal(Y.shape); YP = 1e-4 * np.abs(Y) * rng.standard_normal(Y.shape)
+    for mode, val in ((0, -1.0), (1, 3.9)):
+        def F_of(y):
+            F = np.zeros((1, N)); y = np.ascontiguousarray(y)
+            assert lib.plh_residual(h, 1, th.ctypes.data, y.ctypes.data, YP.ctypes.data, mode, val, F.ctypes.data, 0, None) == 0
+            return F[0]
+        F = F_of(Y)
+        Fo = np.array([float(v) for v in dm.residual(model, dm.FloatOps(), list(Y[0]), list(YP[0]), thd, mode=mode, value=val)])
+        cp, ri = p.jac_pattern(mode)
+        def J_at(cj):
+            nz = np.zeros((1, len(ri)))
+            assert lib.plh_jacobian(h, 1, th.ctypes.data, Y.ctypes.data, YP.ctypes.data, cj, mode, nz.ctypes.data, 0, None) == 0
+            A = np.zeros((N, N))
+            for c in range(N):
+                A[ri[cp[c]:cp[c + 1]], c] = nz[0, cp[c]:cp[c + 1]]
+            return A
+        J0, cj = J_at(0.0), 0.37
+        A = J_at(cj)
+        term = np.abs(J0) @ np.abs(Y[0]) + np.abs(A - J0) @ np.abs(YP[0]) / cj + abs(val) * (np.arange(N) == N - 1)
+        assert (np.abs(F - Fo) <= 1e-11 * term + 1e-300).all(), (mode, np.flatnonzero(np.abs(F - Fo) > 1e-11 * term)[:6])
+        for _ in range(n_fd):                                   # J(cj = 0) v against the directional central difference of the residual
+            v = rng.standard_normal(N) * np.abs(Y[0]); eps = 1e-6
+            fd = (F_of(Y + eps * v) - F_of(Y - eps * v)) / (2 * eps)
+            assert (np.abs(J0 @ v - fd) <= 1e-6 * (np.abs(J0) @ np.abs(v)) + 1e-300).all(), mode
+        b = rng.standard_normal((1, N)); x = b.copy()
+        assert lib.plh_linear_solve(h, 1, th.ctypes.data, Y.ctypes.data, YP.ctypes.data, cj, mode, x.ctypes.data, 0, None) == 0
+        xo = np.linalg.solve(A, b[0])
+        for name, sl in p.ind.items():
+            assert np.abs(x[0, sl] - xo[sl]).max() <= 1e-7 * np.abs(xo[sl]).max() + 1e-300, (mode, name)
+
+
+@pytest.mark.parametrize("grid", [(2, 2, 2, 10), (16, 16, 16, 16), (5, 3, 20, 12)])
+def test_extreme_discretisations(pkg, grid):
+    """the smallest and the largest supported grids, and a lopsided one: evaluators self-consistent and equal to the oracle's Python restatement, and a 1C discharge that
+    reproduces the default grid's cell voltage to the discretisation error"""
+    from oracle import dfn_model as dm
+    p = emu_grid_model(pkg, pkg.LCO, grid, 0)
+    check_grid_self_consistency(p, pkg, dm)
+    ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 1), [{"I": -1.0, "tf": 600.0}], SOC=1.0)
+    assert ens.run_info[0, 0]["flag"] == 0 and abs(ens.run_info[0, 0]["t_end"] - 600.0) < 1e-9
+    # default grid: 3.945410 V after 600 s at 1C; 16/16/16/16: 3.945626; 5/3/20/12: 3.944614; two nodes per section: 3.935740 (10 mV of discretisation error)
+    assert abs(ens.run_info[0, 0]["V"] - 3.945410) < (1.5e-2 if min(grid[:3]) < 3 else 2e-3), ens.run_info[0, 0]["V"]
+
+
+def test_unsupported_discretisations_refuse(pkg, emu_model):
+    for kw in (dict(N_p=40, N_s=10, N_n=10), dict(N_r_p=9, N_r_n=9), dict(N_r_p=12, N_r_n=10), dict(N_p=1)):
+        with pytest.raises((ValueError, NotImplementedError)):
+            pkg.petlion(pkg.LCO, **kw)
+    with pytest.raises(pkg._capi.PetlionHipError, match="plh_register_grid_library"):       # the C ABI itself: an unregistered grid is refused with the way out in the message
+        pkg.petlion(pkg.LCO, N_p=11, _lib_path=emu_model._lib._name, _grid_lib=False)

@@ -15,9 +15,39 @@ def build(force=False):
     deps.append(os.path.join(HERE, "hip", "hip_runtime.h"))
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", HERE, SRC, "-o", OUT, "-Wno-unused-variable"]
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", HERE, SRC, "-o", OUT, "-Wno-unused-variable", "-ldl"]
     subprocess.check_call(cmd)
     return OUT
+
+
+def build_grid(grid, variants, force=False):
+    """emulator build of a grid library (petlion.jl_amd/grids.py builds the real one with hipcc): the listed variants of csrc/variant_tu.hip compiled for another
+    discretisation, to be registered into libpetlion_emu.so with plh_register_grid_library"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import pkgload
+    grids = pkgload.load().grids
+    tag, defs = grids.defines(grid)
+    out = os.path.join(HERE, "libplh_emu_%s_%s.so" % (tag, "_".join(str(v) for v in sorted(variants))))
+    src = os.path.join(os.path.dirname(SRC), "variant_tu.hip")
+    deps = [os.path.join(os.path.dirname(SRC), f) for f in os.listdir(os.path.dirname(SRC)) if f.endswith((".h", ".hip"))] + [os.path.join(HERE, "hip", "hip_runtime.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    common = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "c++", "-I", HERE, "-Wno-unused-variable"] + defs
+    objs = []
+    jobs = []
+    for v in sorted(variants):
+        o = out + ".v%d.o" % v
+        objs.append(o)
+        jobs.append(subprocess.Popen(common + ["-DPL_VARIANT=%d" % v, "-c", src, "-o", o]))
+    glue = out + ".glue.o"
+    jobs.append(subprocess.Popen(common + ["-DPL_GRID_GLUE", "-c", src, "-o", glue]))
+    if any(j.wait() for j in jobs):
+        raise RuntimeError("g++ failed")
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-Wl,-Bsymbolic", glue] + objs + ["-o", out])
+    for o in objs + [glue]:
+        os.remove(o)
+    return out
 
 
 if __name__ == "__main__":
