@@ -66,6 +66,8 @@ mutable struct Model
         d = Ref(ModelDesc(chem, N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, p.numerics.temperature == true, p.numerics.aging == :SEI, 8, precision, device,
                           Dict(:Fickian => 0, :quadratic => 1, :polynomial => 2)[p.numerics.solid_diffusion],
                           p.numerics.thermodynamic_factor === PETLION_thermodynamic_factor_nonlinear(p) ? 1 : 0, p.numerics.rxn_p === PETLION_rxn_MHC(p) ? 1 : 0, waves_per_cell))
+        grid = (N.p, N.s, N.n, N.r_p, p.numerics.temperature == true ? N.a : 10, p.numerics.temperature == true ? N.z : 10)
+        grid == (10, 10, 10, 10, 10, 10) || register_grid(grid_library(grid))     # another discretisation: its kernels are a library of their own (see grid_library)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:plh_model_create, lib), Cint, (Ref{ModelDesc}, Ref{Ptr{Cvoid}}), d, h), "plh_model_create")
         n = ccall((:plh_n_theta, lib), Cint, (Ptr{Cvoid},), h[])
@@ -74,6 +76,16 @@ mutable struct Model
         finalizer(x -> ccall((:plh_model_destroy, lib), Cvoid, (Ptr{Cvoid},), x.h), m)
     end
 end
+
+# Kernels of another discretisation (reference src/params.jl:119-136).  The grid dimensions are compile-time constants of the device source, so a grid is one more build
+# of csrc/variant_tu.hip -- the device-side counterpart of PETLION generating and caching functions per model (generate_functions.jl:44-94).  `grid_library` shells out to
+# the Python driver of that build (petlion.jl_amd/grids.py: hipcc, cached under petlion.jl_amd/_grids/), which prints the library path; PETLION_HIP_ROOT = the repository root.
+function grid_library(grid; variants = 0:12)
+    root = get(ENV, "PETLION_HIP_ROOT", joinpath(@__DIR__, "..", ".."))
+    code = "import pkgload; g = pkgload.load().grids; t = g.variant_table(); print(g.library($(grid), [v for v in $(collect(variants)) if t[v][2] == 'false']))"   # (isothermal variants)
+    strip(read(setenv(`python -c $code`; dir = root), String))
+end
+register_grid(path::AbstractString) = check(ccall((:plh_register_grid_library, lib), Cint, (Cstring,), path), "plh_register_grid_library")
 
 # the reference stores the closures themselves in p.numerics (src/params.jl:286); they are compared by identity with the two non-default ones the device instantiates
 PETLION_thermodynamic_factor_nonlinear(p) = getfield(parentmodule(typeof(p)), :thermodynamic_factor)

@@ -19,6 +19,10 @@ BUILDS = [  # tag, variants, {variant: opt}, extra flags, perf config, pytest -k
     ("th_early_O3", [4], {4: "-O3"}, EARLY, "c3", "c3_thermal"),
     ("th_fcall_O2", [4], {4: "-O2"}, EARLY + ["-DPL_FACTOR_CALL"], "c3", "c3_thermal"),
     ("th_fcall_O3", [4], {4: "-O3"}, EARLY + ["-DPL_FACTOR_CALL"], "c3", "c3_thermal"),
+    # fp64 division without the IEEE scale / fixup sequence (approximate-function lowering: rcp + two Newton steps + one correction); th_* the same for the thermal kernel
+    ("iso_afn", [0], {0: "-O3"}, LATE + ["-fapprox-func"], "c2 c4", "c2_1024 or evaluators"),
+    ("iso_afn_rcp", [0], {0: "-O3"}, LATE + ["-fapprox-func", "-freciprocal-math"], "c2 c4", "c2_1024 or evaluators"),
+    ("th_afn", [4], {4: "-O3"}, EARLY + ["-fapprox-func"], "c3", "c3_thermal"),
     # the r01 failure mode -- device functions left to the inliner's heuristics (real s_swappc calls inside k_integrate)
     ("iso_calls_O2", [0], {0: "-O2"}, ["-DPL_DEV=__device__ inline"], "c2", "c2_1024 or evaluators or consistent"),
     ("iso_calls_O3", [0], {0: "-O3"}, ["-DPL_DEV=__device__ inline"], "c2", "c2_1024 or evaluators or consistent"),
