@@ -41,6 +41,8 @@ __device__ __forceinline__ void cnt_add(Counters& c, int k, int v = 1) { c.v[k] 
                              else if ((j) == M::PHI_LDS + 2) I.ph[2][k__] = (v); else I.ph[3][k__] = (v); } while (0)
 // accumulated correction ee inside a PL_VEC loop
 #define EE(n) I.ee[k__]
+// some BDF history orders live in registers (thermal model): the step-control passes then index the history with compile-time orders under wave-uniform branches
+template <class M> constexpr bool PHI_REGS = M::PHI_LDS <= MAXORD;
 #define PL_VEC(n) _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wave_id()); vok<M>(k__, lane, wave_id()))
 
 template <class M>
@@ -144,8 +146,11 @@ PL_DEV double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
   const int kk = I.kk; const double hh = I.hh;
   if (hh != I.hused || kk != I.kused) I.ns = 0;
   I.ns = (I.ns + 1 < I.kused + 2) ? I.ns + 1 : I.kused + 2;
+  double alphas = 0.0, alpha0 = 0.0;
+  const double rinv[MAXORD + 1] = {1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6};     // (compile-time quotients: identical values, no runtime division)
   if (kk + 1 >= I.ns) {
-    // IDASetCoeffs recurrences; the divisions are done by lanes 0..kk in parallel, the (division-free) prefix products/sums by lane 0:
+    // IDASetCoeffs recurrences; the divisions are done by lanes 0..kk in parallel, the (division-free) prefix products / sums by every lane from register broadcasts
+    // (no LDS round trip per order), each lane m <= kk then stores entry m:
     //   psi_new[0] = h, psi_new[i] = psi_old[i-1] + h ; alpha[i] = h/psi_new[i] ; beta[i] = prod_{m<=i} psi_new[m-1]/psi_old[m-1] ;
     //   sigma[i] = i sigma[i-1] alpha[i] ; gamma[i] = gamma[i-1] + alpha[i-1]/h
     const int i = lane <= kk ? lane : 0;
@@ -156,27 +161,24 @@ PL_DEV double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
     const double q = i > 0 ? pn_im1 / po_im1 : 1.0;
     const double al_prev = i > 1 ? hh / pn_im1 : 1.0;
     const double g = i > 0 ? al_prev / hh : 0.0;
-    PL_XSYNC();
-    if (lane <= kk && wave_id() == 0) { S.ida_psi[lane] = pn_i; S.ida_alpha[lane] = al; S.ida_beta[lane] = q; S.ida_gamma[lane] = g; }
-    PL_SYNC();
-    if (lane == 0 && wave_id() == 0) {
-      double b = 1.0, sg = 1.0, gm = 0.0;
-      S.ida_sigma[0] = 1.0;
-      for (int m = 1; m <= kk; m++) {
-        b *= S.ida_beta[m]; S.ida_beta[m] = b;
-        sg = m * sg * S.ida_alpha[m]; S.ida_sigma[m] = sg;
-        gm += S.ida_gamma[m]; S.ida_gamma[m] = gm;
-      }
+    double bm = 1.0, sg = 1.0, gm = 0.0, myb = q, mys = 1.0, myg = g;
+    _Pragma("unroll") for (int m = 1; m <= MAXORD; m++) if (m <= kk) {
+      const double qm = lane_bcast(q, m), am = lane_bcast(al, m), gmm = lane_bcast(g, m);
+      bm *= qm; sg = m * sg * am; gm += gmm;
+      if (lane == m) { myb = bm; mys = sg; myg = gm; }
     }
+    _Pragma("unroll") for (int m = 0; m < MAXORD; m++) if (m < kk) { alphas -= rinv[m]; alpha0 -= lane_bcast(al, m); }
+    PL_XSYNC();                                      // (every lane has read the old psi)
+    if (lane <= kk && wave_id() == 0) { S.ida_psi[lane] = pn_i; S.ida_alpha[lane] = al; S.ida_beta[lane] = myb; S.ida_sigma[lane] = mys; S.ida_gamma[lane] = myg; }
     PL_XSYNC();
+  } else {
+    for (int m = 0; m < kk; m++) { alphas -= (m == 0 ? rinv[0] : m == 1 ? rinv[1] : m == 2 ? rinv[2] : m == 3 ? rinv[3] : rinv[4]); alpha0 -= S.ida_alpha[m]; }
   }
-  double alphas = 0.0, alpha0 = 0.0;
-  { const double rinv[MAXORD + 1] = {1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6};     // (compile-time quotients: identical values, no runtime division)
-    for (int m = 0; m < kk; m++) { alphas -= (m == 0 ? rinv[0] : m == 1 ? rinv[1] : m == 2 ? rinv[2] : m == 3 ? rinv[3] : rinv[4]); alpha0 -= S.ida_alpha[m]; } }
   I.cjlast = I.cj; I.cj = -alphas / hh;
   const double ak = S.ida_alpha[kk];
   double ck = fabs(ak + alphas - alpha0); if (ck < ak) ck = ak;
-  for (int m = I.ns; m <= kk; m++) { const double b = S.ida_beta[m]; PL_VEC(n) PHI_WR(m, n, PHI_RD(m, n) * b); }
+  // (IDASetCoeffs' rescaling phi[m] *= beta[m], m = ns .. kk, is done by the first form_iterate of the step, in the pass that sums the predictor anyway: same
+  //  products, one pass over the history less; ida_restore undoes it from the same beta / ns)
   I.tn += hh;
   PL_SYNC();
   return ck;
@@ -198,7 +200,10 @@ PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
   PL_VEC(n) { a[k__] = S.phi[0][n]; b[k__] = 0.0; }
   _Pragma("unroll") for (int j = 1; j <= MAXORD; j++) if (j <= I.kk) {
     const double g = S.ida_gamma[j];
-    PL_VEC(n) { const double p = PHI_RD(j, n); a[k__] += p; b[k__] += g * p; }
+    if (first && j >= I.ns) {            // the rescaling of IDASetCoeffs (see ida_set_coeffs)
+      const double bt = S.ida_beta[j];
+      PL_VEC(n) { const double p = PHI_RD(j, n) * bt; PHI_WR(j, n, p); a[k__] += p; b[k__] += g * p; }
+    } else PL_VEC(n) { const double p = PHI_RD(j, n); a[k__] += p; b[k__] += g * p; }
   }
   PL_VEC(n) { const double e = EE(n); S.yy[n] = a[k__] + e; S.yp[n] = b[k__] + I.cj * e; if (M::PRED_REGS) { I.pa[k__] = a[k__]; I.pb[k__] = b[k__]; } }
   PL_XSYNC();
@@ -278,11 +283,29 @@ PL_DEV int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, double& err_k
   const int lane = lane_id();
   const int kk = I.kk;
   double s0 = 0, s1 = 0, s2 = 0;
-  PL_VEC(n) {
-    const double w = EWT(n), e = EE(n);
-    double p = e * w; s0 += p * p;
-    if (kk > 1) { const double d1 = PHI_RD(kk, n) + e; p = d1 * w; s1 += p * p;
-      if (kk > 2) { const double d2 = d1 + PHI_RD(kk - 1, n); p = d2 * w; s2 += p * p; } }
+  // phi[kk], phi[kk-1] through a compile-time order index (wave-uniform branches): the history orders that live in registers (thermal model) are then read directly
+  // instead of through a select chain per element
+  // (with the whole history in LDS a runtime order is just an address, and the extra branches cost 2 % of the isothermal kernels: PHI_REGS selects the form)
+  if constexpr (PHI_REGS<M>) {
+    double pk[NTRIP], pkm1[NTRIP];
+    PL_VEC(n) { pk[k__] = 0.0; pkm1[k__] = 0.0; }
+    _Pragma("unroll") for (int j = 1; j <= MAXORD; j++) {
+      if (j == kk && kk > 1) { PL_VEC(n) pk[k__] = PHI_RD(j, n); }
+      else if (j == kk - 1 && kk > 2) { PL_VEC(n) pkm1[k__] = PHI_RD(j, n); }
+    }
+    PL_VEC(n) {
+      const double w = EWT(n), e = EE(n);
+      double p = e * w; s0 += p * p;
+      if (kk > 1) { const double d1 = pk[k__] + e; p = d1 * w; s1 += p * p;
+        if (kk > 2) { const double d2 = d1 + pkm1[k__]; p = d2 * w; s2 += p * p; } }
+    }
+  } else {
+    PL_VEC(n) {
+      const double w = EWT(n), e = EE(n);
+      double p = e * w; s0 += p * p;
+      if (kk > 1) { const double d1 = PHI_RD(kk, n) + e; p = d1 * w; s1 += p * p;
+        if (kk > 2) { const double d2 = d1 + PHI_RD(kk - 1, n); p = d2 * w; s2 += p * p; } }
+    }
   }
   block_sum3<M>(S, s0, s1, s2);                         // (all three at once: one pair of barriers with two waves per cell)
   const double enorm_k = sqrt(s0 * (1.0 / NST));
@@ -304,12 +327,20 @@ PL_DEV void ida_restore(CellLDS<M>& S, IdaScalars& I, double saved_t) {
   const int lane = lane_id();
   I.tn = saved_t;
   if (lane == 0 && wave_id() == 0) for (int j = 1; j <= I.kk; j++) S.ida_psi[j - 1] = S.ida_psi[j] - I.hh;
-  if (I.ns <= I.kk) for (int j = I.ns; j <= I.kk; j++) { const double b = 1.0 / S.ida_beta[j]; PL_VEC(n) PHI_WR(j, n, PHI_RD(j, n) * b); }
+  if constexpr (PHI_REGS<M>) {
+    _Pragma("unroll") for (int j = 0; j <= MAXORD; j++) if (j >= I.ns && j <= I.kk) { const double b = 1.0 / S.ida_beta[j]; PL_VEC(n) PHI_WR(j, n, PHI_RD(j, n) * b); }
+  } else {
+    if (I.ns <= I.kk) for (int j = I.ns; j <= I.kk; j++) { const double b = 1.0 / S.ida_beta[j]; PL_VEC(n) PHI_WR(j, n, PHI_RD(j, n) * b); }
+  }
   PL_XSYNC();
 }
 
+// IDACompleteStep.  Returns true when it has also produced the solution at the new time, y(tn) -> S.yy, y'(tn) -> S.yp: unless the step ended on tstop (the caller then
+// interpolates to tstop), IDAGetSolution(tn) is  y = phi[0]  and  y' = sum_j d_{j-1} phi[j]  (delt = 0 makes every c_j with j >= 1 vanish), i.e. by-products of the
+// running sums that update the history -- one pass over the history instead of two.  The coefficients d are formed by IDAGetSolution's own recurrence; y' is summed from the
+// top order down (IDAGetSolution sums upwards: last-bit differences in the REPORTED y' only -- the integrator continues from phi, not from y').
 template <class M>
-PL_DEV void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double err_km1) {
+PL_DEV bool ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double err_km1, double tstop) {
   PL_MODEL(M);
   const int lane = lane_id();
   I.nst++;
@@ -324,7 +355,9 @@ PL_DEV void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double
     else if (I.kk + 1 >= I.ns || kdiff == 1) action = 2;
     if (action == 0) {
       double s = 0.0;
-      PL_VEC(n) { const double p = (EE(n) - PHI_RD(I.kk + 1, n)) * EWT(n); s += p * p; }
+      if constexpr (PHI_REGS<M>) {
+        _Pragma("unroll") for (int j = 2; j <= MAXORD; j++) if (j == I.kk + 1) { PL_VEC(n) { const double p = (EE(n) - PHI_RD(j, n)) * EWT(n); s += p * p; } }
+      } else { PL_VEC(n) { const double p = (EE(n) - PHI_RD(I.kk + 1, n)) * EWT(n); s += p * p; } }
       const double enorm = sqrt(block_sum<M>(S, s) * (1.0 / NST)); err_kp1 = enorm / (I.kk + 2);
       const double terr_k = (I.kk + 1) * err_k, terr_kp1 = (I.kk + 2) * err_kp1;
       if (I.kk == 1) action = (terr_kp1 >= 0.5 * terr_k) ? 2 : 3;
@@ -338,14 +371,43 @@ PL_DEV void ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double
     I.hh = hnew;
   }
   const int ku = I.kused;
-  {   // phi update (running sums from the top order down), orders outermost / trips innermost as in form_iterate
-    double acc[NTRIP];
-    PL_VEC(n) { const double e = EE(n); if (ku < I.maxord) PHI_WR(ku + 1, n, e); acc[k__] = PHI_RD(ku, n) + e; PHI_WR(ku, n, acc[k__]); }
-    _Pragma("unroll") for (int j = MAXORD - 1; j >= 0; j--) if (j < ku) {
-      PL_VEC(n) { acc[k__] += PHI_RD(j, n); PHI_WR(j, n, acc[k__]); }
-    }
+  const bool at_tstop = fabs(I.tn - tstop) <= 100.0 * 2.220446049250313e-16 * (fabs(I.tn) + fabs(I.hh));     // (ida_step's test, with the step size chosen above)
+  // d_{j-1} of IDAGetSolution at t = tn (delt = 0: c_j = 0 for j >= 1, gam_j = psi[j-1] / psi[j]); the reciprocals of psi by lanes 0..ku in parallel as in ida_get_solution
+  double dc1 = 0, dc2 = 0, dc3 = 0, dc4 = 0, dc5 = 0;
+  if (!at_tstop) {
+    const double rp_mine = 1.0 / S.ida_psi[lane <= MAXORD ? lane : MAXORD];
+    const double rp0 = lane_bcast(rp_mine, 0), rp1 = lane_bcast(rp_mine, 1), rp2 = lane_bcast(rp_mine, 2), rp3 = lane_bcast(rp_mine, 3), rp4 = lane_bcast(rp_mine, 4),
+                 rp5 = lane_bcast(rp_mine, 5);
+    const double delt = 0.0;
+    double c = 1.0, d = 0.0, gam = delt * rp0;
+#define PL_GS_STEP(J, RPJM1, RPJ, DV) if (J <= ku) { d = d * gam + c * RPJM1; c = c * gam; gam = (delt + S.ida_psi[J - 1]) * RPJ; DV = d; }
+    PL_GS_STEP(1, rp0, rp1, dc1) PL_GS_STEP(2, rp1, rp2, dc2) PL_GS_STEP(3, rp2, rp3, dc3) PL_GS_STEP(4, rp3, rp4, dc4) PL_GS_STEP(5, rp4, rp5, dc5)
+#undef PL_GS_STEP
   }
-  PL_SYNC();
+  {   // phi update (running sums from the top order down), orders outermost / trips innermost as in form_iterate; y' accumulates d_{j-1} * (new phi[j]) on the way
+    double acc[NTRIP], sp[NTRIP];
+    const double dku = ku == 1 ? dc1 : ku == 2 ? dc2 : ku == 3 ? dc3 : ku == 4 ? dc4 : dc5;
+    // (the order index of every history access is a compile-time constant under a wave-uniform branch: direct register access for the orders kept in registers)
+    if constexpr (PHI_REGS<M>) {
+      _Pragma("unroll") for (int j = MAXORD; j >= 0; j--) {
+        if (j == ku + 1 && ku < I.maxord) { PL_VEC(n) PHI_WR(j, n, EE(n)); }
+        else if (j == ku) { PL_VEC(n) { acc[k__] = PHI_RD(j, n) + EE(n); PHI_WR(j, n, acc[k__]); sp[k__] = dku * acc[k__]; } }
+        else if (j < ku) {
+          const double dj = j == 1 ? dc1 : j == 2 ? dc2 : j == 3 ? dc3 : j == 4 ? dc4 : 0.0;       // (j = 0: phi[0] does not enter y')
+          PL_VEC(n) { acc[k__] += PHI_RD(j, n); PHI_WR(j, n, acc[k__]); if (j > 0) sp[k__] += dj * acc[k__]; }
+        }
+      }
+    } else {
+      PL_VEC(n) { const double e = EE(n); if (ku < I.maxord) PHI_WR(ku + 1, n, e); acc[k__] = PHI_RD(ku, n) + e; PHI_WR(ku, n, acc[k__]); sp[k__] = dku * acc[k__]; }
+      _Pragma("unroll") for (int j = MAXORD - 1; j >= 0; j--) if (j < ku) {
+        const double dj = j == 1 ? dc1 : j == 2 ? dc2 : j == 3 ? dc3 : j == 4 ? dc4 : 0.0;       // (j = 0: phi[0] does not enter y')
+        PL_VEC(n) { acc[k__] += PHI_RD(j, n); PHI_WR(j, n, acc[k__]); if (j > 0) sp[k__] += dj * acc[k__]; }
+      }
+    }
+    if (!at_tstop) { PL_VEC(n) { S.yy[n] = acc[k__]; S.yp[n] = sp[k__]; } }
+  }
+  PL_XSYNC();
+  return !at_tstop;
 }
 
 // IDAGetSolution(t): y -> yo, y' -> ypo (LDS vectors)
@@ -465,12 +527,11 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
   }
   cnt_add(cnt, C_STEPS); cnt_add(cnt, C_SUMKP2, I.kk + 2);
   PL_TIC(); PL_TICE(3);
-  ida_complete_step(S, I, err_k, err_km1);
+  const bool have_sol = ida_complete_step(S, I, err_k, err_km1, tstop);
   PL_TOCE(S, 3, 2);
-  const double troundoff = 100.0 * uround * (fabs(I.tn) + fabs(I.hh));
-  if (fabs(I.tn - tstop) <= troundoff) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 3); return 0; }
+  if (!have_sol) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 3); return 0; }      // the step ended on tstop (|tn - tstop| <= troundoff)
   if ((I.tn + I.hh - tstop) * I.hh > 0.0) I.hh = (tstop - I.tn) * (1.0 - 4.0 * uround);
-  ida_get_solution(S, I, I.tn, S.yy, S.yp); tret = I.tn;
+  tret = I.tn;                                                                      // y(tn), y'(tn) are in S.yy / S.yp (ida_complete_step)
   PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 3);
   return 0;
 }
