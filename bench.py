@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--precision", default="f64", choices=("f64", "mixed"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--leg-timeout", type=int, default=240, help="N > 1: watchdog of the plh_ensemble_run leg (seconds)")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-inclusive pipeline, the copy-bandwidth probe and (N > 1) the plh_ensemble_run leg")
     args = ap.parse_args()
     c = CONFIGS[args.config]
@@ -265,33 +266,7 @@ def main():
     except Exception:
         traffic = None
 
-    # ---- N > 1: the C4 sweep through the C ABI's own multi-GPU entry (RCCL scatter -> integrate -> gather), block and cyclic partitions ----
-    ens_run = None
-    if world > 1 and not args.no_extras and backend == "nccl":
-        p4 = p if args.config in ("C2", "C4") and args.precision == "f64" else pkg.petlion(pkg.LCO, device=local_dev)
-        uid = torch.zeros(128, dtype=torch.uint8, device=cdev)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(pd.RcclComm.unique_id(p4._lib)), dtype=torch.uint8).to(cdev)
-        dist.broadcast(uid, src=0)
-        comm = pd.RcclComm(p4._lib, world, rank, bytes(uid.cpu().numpy().tobytes()), device=local_dev)
-        n4 = 8192 * world
-        Th4 = pkg.configs.c4(p4, n4)["theta"] if rank == 0 else None
-        ens_run = {}
-        for part in ("block", "cyclic"):
-            pd.ensemble_run_capi(comm, p4, Th4, [{"I": -1.0}], 1.0, n_cells=n4, partition=part)          # warm-up (RCCL channels, staging blocks)
-            dist.barrier(); t1 = time.perf_counter()
-            res = pd.ensemble_run_capi(comm, p4, Th4, [{"I": -1.0}], 1.0, n_cells=n4, partition=part)
-            dist.barrier(); dt = time.perf_counter() - t1
-            if rank == 0:
-                info, cnt, _, ms = res
-                assert np.isin(info["flag"][:, 0], (1, 3)).all()
-                ens_run[part] = {"wall_ms": 1e3 * dt, "trajectories_per_s_host_to_host": n4 / dt, "rank_kernel_ms": [float(x) for x in ms],
-                                 "kernel_ms_spread": float(ms.max() / ms.min()), "steps_per_cell_mean": float(cnt["n_steps"].mean())}
-        if rank == 0:
-            ens_run["what"] = ("plh_ensemble_run over %d ranks: %d C4 cells (8192 per GPU) from rank 0's host memory -- ncclBroadcast of the shape, grouped ncclSend/ncclRecv scatter of "
-                               "Theta, one plh_integrate per rank, gather of run_info / counters / Y_final to rank 0; wall time includes the host-side permutation and copies" % (world, n4))
-        comm.close()
-
+    out = None
     if rank == 0:
         traj_s = n_total * args.steps / elapsed
         achieved = bytes_launch / (kavg_ms * 1e-3) / 1e9
@@ -312,8 +287,64 @@ def main():
                          "kernel": "k_integrate<%s>" % c["variant"], "kernel_ms_avg": kavg_ms, "kernel_ms_last_launch": klast_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "algorithmic_bytes_per_trajectory": bytes_launch / n_local},
         }
-        if ens_run is not None:
+
+    # ---- N > 1: the C4 sweep through the C ABI's own multi-GPU entry (RCCL scatter -> integrate -> gather), block and cyclic partitions ----
+    # The timed region above is complete and `out` holds the line; this extra leg must not be able to lose it: exceptions are caught on every rank (the ranks agree on
+    # success through an all_reduce), and a watchdog emits the line without the leg if a collective hangs.
+    if world > 1 and not args.no_extras and backend == "nccl":
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["ensemble_run"] = {"error": "plh_ensemble_run leg did not finish within %d s (watchdog)" % args.leg_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.leg_timeout, give_up); dog.daemon = True; dog.start()
+        ens_run, comm = {}, None
+
+        def all_ok(ok):
+            f = torch.tensor([1 if ok else 0], device=cdev); dist.all_reduce(f, op=dist.ReduceOp.MIN); return bool(f.item())
+        try:
+            p4 = p if args.config in ("C2", "C4") and args.precision == "f64" else pkg.petlion(pkg.LCO, device=local_dev)
+            uid = torch.zeros(128, dtype=torch.uint8, device=cdev)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(pd.RcclComm.unique_id(p4._lib)), dtype=torch.uint8).to(cdev)
+            dist.broadcast(uid, src=0)
+            err = None
+            try:
+                comm = pd.RcclComm(p4._lib, world, rank, bytes(uid.cpu().numpy().tobytes()), device=local_dev)
+            except Exception as e:                                   # noqa: BLE001
+                err = "plh_comm_create: %r" % (e,)
+            if not all_ok(err is None):
+                raise RuntimeError(err or "plh_comm_create failed on another rank")
+            n4 = 8192 * world
+            Th4 = pkg.configs.c4(p4, n4)["theta"] if rank == 0 else None
+            for part in ("block", "cyclic"):
+                pd.ensemble_run_capi(comm, p4, Th4, [{"I": -1.0}], 1.0, n_cells=n4, partition=part)          # warm-up (RCCL channels, staging blocks)
+                dist.barrier(); t1 = time.perf_counter()
+                res = pd.ensemble_run_capi(comm, p4, Th4, [{"I": -1.0}], 1.0, n_cells=n4, partition=part)
+                dist.barrier(); dt = time.perf_counter() - t1
+                if rank == 0:
+                    info, cnt, _, ms = res
+                    ens_run[part] = {"wall_ms": 1e3 * dt, "trajectories_per_s_host_to_host": n4 / dt, "rank_kernel_ms": [float(x) for x in ms],
+                                     "kernel_ms_spread": float(ms.max() / ms.min()), "steps_per_cell_mean": float(cnt["n_steps"].mean()),
+                                     "all_cells_finished": bool(np.isin(info["flag"][:, 0], (1, 3)).all())}
+            if rank == 0:
+                ens_run["what"] = ("plh_ensemble_run over %d ranks: %d C4 cells (8192 per GPU) from rank 0's host memory -- ncclBroadcast of the shape, grouped ncclSend/ncclRecv scatter of "
+                                   "Theta, one plh_integrate per rank, gather of run_info / counters / Y_final to rank 0; wall time includes the host-side permutation and copies" % (world, n4))
+        except Exception as e:                                       # noqa: BLE001
+            ens_run["error"] = repr(e)
+        finally:
+            dog.cancel()
+            try:
+                if comm is not None:
+                    comm.close()
+            except Exception:                                        # noqa: BLE001
+                pass
+        if rank == 0:
             out["ensemble_run"] = ens_run
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             one, allc = cpu_baseline(args.config, c, p, pkg, inp, args.cpu_seconds)
             out["cpu_baseline"] = one
