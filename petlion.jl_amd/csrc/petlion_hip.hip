@@ -378,7 +378,11 @@ int plh_register_grid_library(const char* path) {
   GridLib gl; gl.path = path; gl.handle = h;
   gl.ops = (const VariantOps* (*)(int))dlsym(h, "plh_grid_variant_ops");
   void (*dims)(int*) = (void (*)(int*))dlsym(h, "plh_grid_dims");
-  if (!gl.ops || !dims) { dlclose(h); return fail(PLH_E_ARG, "not a grid library: plh_grid_variant_ops / plh_grid_dims missing (build csrc/variant_tu.hip with -DPL_GRID_LIBRARY)"); }
+  void (*abi)(int*, int*, int*, int*) = (void (*)(int*, int*, int*, int*))dlsym(h, "plh_grid_abi");
+  if (!gl.ops || !dims || !abi) { dlclose(h); return fail(PLH_E_ARG, "not a grid library: plh_grid_variant_ops / plh_grid_dims / plh_grid_abi missing (petlion.jl_amd/grids.py builds one)"); }
+  { int v = 0, so = 0, sa = 0, st = 0; abi(&v, &so, &sa, &st);
+    if (v != PLH_HOST_ABI || so != (int)sizeof(VariantOps) || sa != (int)sizeof(IntegrateArgs) || st != (int)sizeof(Tables)) {
+      dlclose(h); return fail(PLH_E_ARG, "grid library was built against another version of the host interface (stale cache: rebuild it, grids.library(..., force=True))"); } }
   dims(gl.grid);
   int found = 0;
   for (int v = 0; v < PL_N_VARIANTS; v++) {

@@ -19,6 +19,9 @@ extern "C" __attribute__((visibility("default"))) const VariantOps* plh_grid_var
   }
   return nullptr;
 }
+extern "C" __attribute__((visibility("default"))) void plh_grid_abi(int* abi, int* so, int* sa, int* st) {
+  *abi = PLH_HOST_ABI; *so = (int)sizeof(VariantOps); *sa = (int)sizeof(IntegrateArgs); *st = (int)sizeof(pl::Tables);
+}
 extern "C" __attribute__((visibility("default"))) void plh_grid_dims(int* g) { g[0] = pl::NP; g[1] = pl::NS; g[2] = pl::NN; g[3] = pl::NR; g[4] = pl::NA; g[5] = pl::NZ; }
 #else
 

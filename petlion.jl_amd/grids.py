@@ -70,6 +70,13 @@ def library(grid, variants, force=False):
     check(grid, thermal=any(variant_table()[v][2] == "true" for v in variants))
     tag, defs = defines(grid)
     os.makedirs(GRID_DIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(GRID_DIR, "%s.lock" % tag), "w") as lock:        # one builder per grid at a time (the ranks of a multi-process job ask for the same library)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _library_locked(grid, variants, force, tag, defs)
+
+
+def _library_locked(grid, variants, force, tag, defs):
     lib = os.path.join(GRID_DIR, "libplh_%s.so" % tag)
     manifest = os.path.join(GRID_DIR, "libplh_%s.json" % tag)
     have = []
