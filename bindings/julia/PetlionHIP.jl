@@ -16,7 +16,7 @@ const lib = get(ENV, "PETLION_HIP_LIB", joinpath(@__DIR__, "..", "..", "petlion.
 
 const PLH_HOST = Cint(0)
 const MODE = Dict(:I => Cint(0), :V => Cint(1), :dT => Cint(2), :P => Cint(3), :η_p => Cint(4))
-const VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE = Cint(0), Cint(1), Cint(2), Cint(3)
+const VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE, VAL_EXPR = Cint(0), Cint(1), Cint(2), Cint(3), Cint(4)
 
 struct ModelDesc
     chemistry::Cint; N_p::Cint; N_s::Cint; N_n::Cint; N_a::Cint; N_z::Cint; N_r_p::Cint; N_r_n::Cint
@@ -107,6 +107,7 @@ theta_matrix(m::Model, p, n_cells) = repeat(permutedims([Float64(p.θ[k]) for k 
 
 bounds_of(b; kw...) = Bounds((get(kw, f, getfield(b, f)) for f in (:V_max, :V_min, :SOC_max, :SOC_min, :T_max, :c_s_n_max, :I_max, :I_min, :η_plating_min, :c_e_min, :dfilm_max))...)
 
+const KEEPALIVE = Any[]
 function make_run(p, step::NamedTuple)
     name = first(k for k in keys(step) if haskey(MODE, k))
     x = step[name]
@@ -116,9 +117,50 @@ function make_run(p, step::NamedTuple)
     if x isa Tuple{Vector{Float64},Vector{Float64}}      # (t, values): a tabulated I(t) / V(t) / P(t); the caller keeps the two vectors alive (GC.@preserve)
         return Run(MODE[name], VAL_TABLE, x[2][1], tf, b, length(x[1]), pointer(x[1]), pointer(x[2]), C_NULL, C_NULL)
     end
+    if x isa Function                                    # a closure input: its expression as a postfix program (closure_program below)
+        ops, args = closure_program(x, p)
+        push!(KEEPALIVE, (ops, args))                    # (the program arrays must outlive the call; emptied by simulate_ensemble when it returns)
+        return Run(MODE[name], VAL_EXPR, 0.0, tf, b, length(ops), pointer(ops), pointer(args), C_NULL, C_NULL)
+    end
     x isa Vector{Float64} && return Run(MODE[name], VAL_CONST, x[1], tf, b, 0, C_NULL, C_NULL, pointer(x), C_NULL)   # one value per cell (caller keeps x alive)
     kind, val = x === :hold ? (VAL_HOLD, 0.0) : x === :rest ? (VAL_REST, 0.0) : (VAL_CONST, Float64(x))
     Run(MODE[name], kind, val, tf, b, 0, C_NULL, C_NULL, C_NULL, C_NULL)
+end
+
+# Input closures `I = (t, Y, YP, p) -> ...` (input_methods.jl:159-176): PETLION itself traces them with Symbolics to differentiate the control row
+# (scalar_residual.jl:248-274); the same traced expression, walked in post-order, is the C ABI's postfix program (PLH_VAL_EXPR, PLH_OP_* of include/petlion_hip.h).
+# The Python host mirror does exactly this with operator overloading (petlion.jl_amd/closures.py, tested); this Julia version is its transliteration onto
+# SymbolicUtils' expression interface and has not been executed.
+const OPCODE = Dict(:+ => 5, :- => 6, :* => 7, :/ => 8, :sin => 10, :cos => 11, :exp => 12, :log => 13, :sqrt => 14, :^ => 15, :abs => 16, :min => 17, :max => 18,
+                    :< => 19, :<= => 20, :> => 21, :>= => 22, :ifelse => 23, :tanh => 24)
+function closure_program(f, p)
+    S = parentmodule(typeof(p)).Symbolics; SU = S.SymbolicUtils
+    θ_sym, Y, YP, t, SOC, I, γ, p_sym, θ_keys = parentmodule(typeof(p)).get_symbolic_vars(p; original_keys = p.cache.θ_keys)   # the tracers PETLION uses (scalar_residual.jl:251)
+    ex = S.value(parentmodule(typeof(p)).redefine_func(f)(t, Y, YP, p_sym))
+    index_of(v, vec) = findfirst(x -> isequal(S.value(x), v), vec)
+    ops = Float64[]; args = Float64[]
+    emit(op, a = 0.0) = (push!(ops, op); push!(args, a))
+    function walk(e)
+        if e isa Number
+            emit(0, Float64(e))
+        elseif !SU.istree(e)
+            isequal(e, S.value(t)) ? emit(1) :
+            (k = index_of(e, Y)) !== nothing ? emit(2, k - 1) :
+            (k = index_of(e, YP)) !== nothing ? emit(3, k - 1) :
+            (k = index_of(e, θ_sym)) !== nothing ? emit(4, k - 1) : error("input closure reads a symbol the device cannot resolve: $e")
+        else
+            op = nameof(SU.operation(e)); a = SU.arguments(e)
+            if op in (:+, :*) && length(a) > 2                    # n-ary sums / products: left fold
+                walk(a[1]); for x in a[2:end]; walk(x); emit(OPCODE[op]); end
+            elseif op === :- && length(a) == 1
+                walk(a[1]); emit(9)
+            else
+                foreach(walk, a); emit(OPCODE[op])
+            end
+        end
+    end
+    walk(ex)
+    ops, args
 end
 
 """

@@ -69,6 +69,40 @@ extern "C" {
 #define PLH_VAL_HOLD 1  /* :hold  -- the value reached at the end of the previous run */
 #define PLH_VAL_REST 2  /* :rest  -- I = 0, all bound checks skipped (src/checks.jl:12,388) */
 #define PLH_VAL_TABLE 3   /* time-dependent input from plh_run.tab_t / tab_v */
+#define PLH_VAL_EXPR 4    /* input = a closure f(t, Y, YP, theta) given as a postfix program (PLH_OP_*) in plh_run.tab_t (opcodes) / tab_v (operands) */
+/* Postfix programs for PLH_VAL_EXPR: the form in which a reference input closure `I = (t, Y, YP, p) -> ...` (scalar_residual.jl:169-170, input_methods.jl:159-176) crosses the
+   C ABI.  Instruction k is (opcode tab_t[k], operand tab_v[k]); the machine is a stack of at most 16 doubles, the program must leave exactly one value.  Operands: the constant
+   for CONST, a 0-based state index for Y / YP, a 0-based position in the model's theta_keys for THETA; unused otherwise.  The closure is evaluated with the current iterate inside
+   every residual evaluation of the run (also during the consistent initialisation), like run.func in scalar_residual!.  Its derivative with respect to Y is NOT put into the
+   Newton matrix -- the reference's own fallback for closures it cannot differentiate (scalar_residual.jl:248-274, _get_method_funcs_no_differentiation): the converged states
+   satisfy the same equations, the Newton iteration may take different steps than with the reference's symbolic derivative. */
+#define PLH_OP_CONST 0
+#define PLH_OP_T 1
+#define PLH_OP_Y 2
+#define PLH_OP_YP 3
+#define PLH_OP_THETA 4
+#define PLH_OP_ADD 5
+#define PLH_OP_SUB 6
+#define PLH_OP_MUL 7
+#define PLH_OP_DIV 8
+#define PLH_OP_NEG 9
+#define PLH_OP_SIN 10
+#define PLH_OP_COS 11
+#define PLH_OP_EXP 12
+#define PLH_OP_LOG 13
+#define PLH_OP_SQRT 14
+#define PLH_OP_POW 15
+#define PLH_OP_ABS 16
+#define PLH_OP_MIN 17
+#define PLH_OP_MAX 18
+#define PLH_OP_LT 19      /* a b -> (a < b) as 1.0 / 0.0 ; LE, GT, GE alike */
+#define PLH_OP_LE 20
+#define PLH_OP_GT 21
+#define PLH_OP_GE 22
+#define PLH_OP_SELECT 23  /* c a b -> (c != 0 ? a : b)   (ifelse) */
+#define PLH_OP_TANH 24
+#define PLH_N_OPS 25
+#define PLH_EXPR_STACK 16
 
 /* per-cell status beyond the reference's exit flags */
 #define PLH_FLAG_RUNNING (-1)
@@ -112,6 +146,7 @@ typedef struct {
   /* PLH_VAL_TABLE: the input is a function of the run-local time (reference run_function: I = t -> ..., scalar_residual.jl:169-170) given as a
      piecewise-linear table; a repeated knot time is a jump (right-continuous), the last value holds beyond the last knot.  The arrays are HOST
      memory like the protocol itself (plh_integrate stages them).  List jump times in plh_opts.tdiscon as with the reference's `tdiscon`. */
+  /* PLH_VAL_EXPR: n_tab instructions, tab_t[k] = opcode (PLH_OP_*, stored as a double), tab_v[k] = operand (see above); HOST arrays, staged like a table. */
   int n_tab; const double* tab_t; const double* tab_v;
   /* ensemble axis of the protocol itself: per-cell input value (PLH_VAL_CONST only, e.g. a C-rate sweep) and per-cell run length, [n_cells] HOST
      arrays staged by plh_integrate; NULL = every cell uses `value` / `tf`.  (New: the reference runs one cell per simulate() call.) */

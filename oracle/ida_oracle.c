@@ -323,7 +323,11 @@ static int splu_setup(splu* f, const int* cp, const int* ri, const double* ax) {
 /* public structs                                                                                               */
 /* ------------------------------------------------------------------------------------------------------------ */
 enum { ORC_MODE_I = 0, ORC_MODE_V = 1, ORC_MODE_DT = 2, ORC_MODE_P = 3, ORC_MODE_ETAP = 4, ORC_NMODES = 5 };
-enum { ORC_VAL_CONST = 0, ORC_VAL_HOLD = 1, ORC_VAL_REST = 2, ORC_VAL_TABLE = 3 };
+enum { ORC_VAL_CONST = 0, ORC_VAL_HOLD = 1, ORC_VAL_REST = 2, ORC_VAL_TABLE = 3, ORC_VAL_EXPR = 4 };
+/* ORC_VAL_EXPR: the input closure run.func(t, Y, YP, p) (scalar_residual.jl:169-170) as a postfix program, instruction k = (opcode tab_t[k], operand tab_v[k]); the opcode
+   numbering is the C ABI's (include/petlion_hip.h PLH_OP_*), restated here: */
+enum { OP_CONST = 0, OP_T, OP_Y, OP_YP, OP_THETA, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SIN, OP_COS, OP_EXP, OP_LOG, OP_SQRT, OP_POW, OP_ABS, OP_MIN, OP_MAX,
+       OP_LT, OP_LE, OP_GT, OP_GE, OP_SELECT, OP_TANH };
 
 typedef struct {   /* reference boundary_stop_conditions, src/structures.jl:237-250 ; NaN disables a bound */
   double V_max, V_min, SOC_max, SOC_min, T_max, c_s_n_max, I_max, I_min, eta_plating_min, c_e_min, dfilm_max;
@@ -388,7 +392,8 @@ typedef struct {
   double *tmp_nz, *w;
   double *ax_f, *aax_f, *rtmp, *xtmp;   /* the matrices as last factored (iterative refinement), work vectors */
   double I1C;
-  const orc_run* frun;   /* != NULL: the control value is frun's table evaluated at the current time */
+  const orc_run* frun;   /* != NULL: the control value is frun's table / closure evaluated at the current time */
+  double t_fun;          /* run-local time of the residual evaluations (closure inputs) */
   splu lu, alu;
   orc_counters* cnt;
 } evalb;
@@ -431,6 +436,29 @@ static double tab_eval(const orc_run* r, double t) {
   const double dt = tt[k + 1] - tt[k];
   return dt > 0.0 ? vv[k] + (vv[k + 1] - vv[k]) * ((t - tt[k]) / dt) : vv[k + 1];
 }
+static double expr_eval(const orc_run* r, double t, const double* Y, const double* YP, const double* th) {
+  double st[64]; int sp = 0;
+  for (int k = 0; k < r->n_tab; k++) {
+    const int op = (int)r->tab_t[k]; const double a = r->tab_v[k];
+    switch (op) {
+      case OP_CONST: st[sp++] = a; break; case OP_T: st[sp++] = t; break; case OP_Y: st[sp++] = Y[(int)a]; break; case OP_YP: st[sp++] = YP[(int)a]; break;
+      case OP_THETA: st[sp++] = th[(int)a]; break;
+      case OP_NEG: st[sp - 1] = -st[sp - 1]; break; case OP_SIN: st[sp - 1] = sin(st[sp - 1]); break; case OP_COS: st[sp - 1] = cos(st[sp - 1]); break;
+      case OP_EXP: st[sp - 1] = exp(st[sp - 1]); break; case OP_LOG: st[sp - 1] = log(st[sp - 1]); break; case OP_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
+      case OP_ABS: st[sp - 1] = fabs(st[sp - 1]); break; case OP_TANH: st[sp - 1] = tanh(st[sp - 1]); break;
+      case OP_SELECT: { const double b = st[sp - 1], x = st[sp - 2], c = st[sp - 3]; sp -= 2; st[sp - 1] = c != 0.0 ? x : b; break; }
+      default: { const double y = st[sp - 1], x = st[sp - 2]; sp--; double v = 0.0;
+        switch (op) { case OP_ADD: v = x + y; break; case OP_SUB: v = x - y; break; case OP_MUL: v = x * y; break; case OP_DIV: v = x / y; break; case OP_POW: v = pow(x, y); break;
+                      case OP_MIN: v = x < y ? x : y; break; case OP_MAX: v = x > y ? x : y; break; case OP_LT: v = x < y; break; case OP_LE: v = x <= y; break;
+                      case OP_GT: v = x > y; break; case OP_GE: v = x >= y; break; }
+        st[sp - 1] = v; }
+    }
+  }
+  return st[0];
+}
+static double run_input(const orc_run* r, double t, const double* Y, const double* YP, const double* th) {
+  return r->value_kind == ORC_VAL_EXPR ? expr_eval(r, t, Y, YP, th) : tab_eval(r, t);
+}
 /* calc_I1C, reference auxiliary_states_and_coefficients.jl:632-647 */
 static double calc_I1C_c(const orc_model* m, const double* th) {
   const char* nm[10] = {"ϵ_fp", "ϵ_p", "ϵ_fn", "ϵ_n", "l_p", "l_n", "c_max_p", "c_max_n", "θ_min_p", "θ_max_p"};
@@ -464,7 +492,9 @@ static void evalb_free(evalb* e) {
   free(e->tmp_nz); free(e->w); free(e->ax_f); free(e->aax_f); free(e->rtmp); free(e->xtmp); splu_free(&e->lu); splu_free(&e->alu);
 }
 
-static double ctrl_residual(const evalb* e, const double* Y, const double* YP) {
+static double ctrl_residual(evalb* e, const double* Y, const double* YP) {
+  /* closure input: val = run.func(t, Y, YP, p) with the iterate, in every residual, and run.value[] = val (scalar_residual.jl:169-170) */
+  if (e->frun && e->frun->value_kind == ORC_VAL_EXPR) e->value = expr_eval(e->frun, e->t_fun, Y, YP, e->th);
   const orc_model* m = &e->m;
   if (e->mode == ORC_MODE_I) return Y[m->o_I] - e->value;                                         /* method_I */
   if (e->mode == ORC_MODE_V) return Y[m->o_ps] - Y[m->o_ps + m->Np + m->Nn - 1] - e->value;       /* method_V */
@@ -647,7 +677,7 @@ static double ida_set_coeffs(ida_t* I) {
 /* nonlinear solve: IDANls + SUNNonlinSol_Newton + idaNlsConvTest + IDALs scaling.  returns 0 ok, >0 recoverable, <0 fatal */
 static int ida_nls(ida_t* I) {
   evalb* e = I->e; int N = I->N; orc_counters* cnt = e->cnt;
-  if (e->frun) e->value = tab_eval(e->frun, I->tn);     /* every residual of this step is evaluated at t = tn */
+  if (e->frun) { e->value = run_input(e->frun, I->tn, I->phi[0], I->phi[1], e->th); e->t_fun = I->tn; }     /* every residual of this step is evaluated at t = tn */
   int callLSetup = 0;
   if (I->nst == 0) { I->cjold = I->cj; I->ss = 20.0; callLSetup = 1; }
   else {
@@ -933,9 +963,9 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
     } else t0 = nextafter(t_global, INFINITY);       /* initial_time, model_evaluation.jl:112 */
     /* initial_current! (input_methods.jl:11-74) */
     double value = run->value;
-    const int is_tab = run->value_kind == ORC_VAL_TABLE;
+    const int is_tab = run->value_kind == ORC_VAL_TABLE || run->value_kind == ORC_VAL_EXPR;
     if (is_tab) {                                /* run_function: initial_current! (input_methods.jl:28-34, 65-76, 104-107, 143-153) */
-      value = tab_eval(run, 0.0);
+      value = run_input(run, 0.0, Y, YP, theta);
       if (mode == ORC_MODE_I) Y[M.o_I] = value;
       else if (mode == ORC_MODE_P) Y[M.o_I] = value / (calc_V(&M, Y) * calc_I1C_c(&M, theta));
       else if (mode == ORC_MODE_V || mode == ORC_MODE_ETAP) { if (have_prev) Y[M.o_I] = prev_I; else { double OCV = calc_V(&M, Y); Y[M.o_I] = value > OCV ? 1.0 : -1.0; } }
@@ -960,7 +990,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       if (have_prev) Y[M.o_I] = prev_I; else Y[M.o_I] = 1.0;      /* input_methods.jl:171-176 */
     }
     if (!ev_ok[mode]) { if (evalb_init(&ev[mode], &M, theta, mode, value, cnt) != 0) { rc = -102; break; } ev_ok[mode] = 1; }
-    evalb* e = &ev[mode]; e->value = value; e->th = theta; e->cnt = cnt; e->frun = is_tab ? run : NULL;
+    evalb* e = &ev[mode]; e->value = value; e->th = theta; e->cnt = cnt; e->frun = is_tab ? run : NULL; e->t_fun = 0.0;
     if (M.thermal) M.dT_weights(e->w, theta);
     int ierr = newtons_method(e, Y, YP, opts, c_e0);
     orc_runinfo* ri = &info[r]; memset(ri, 0, sizeof(*ri)); ri->flag = -1;
@@ -1005,10 +1035,10 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       if (iter == opts->maxiters) { flag = ORC_ERR_MAXITERS; break; }
       if (flag == -1) { memcpy(Yprev, Y, N * sizeof(double)); memcpy(YPprev, YP, N * sizeof(double)); t_prev_saved = t + t0; }
       if (flag == -1 && is_tab && t - tprev < 1e-3 * opts->reltol) {          /* check_reinitialization!, checks.jl:341-364 */
-        const double t_new = t + opts->reltol, v_old = e->value, v_new = tab_eval(run, t_new);
+        const double t_new = t + opts->reltol, v_old = e->value, v_new = run_input(run, t_new, Y, YP, theta);
         const double big = fmax(fabs(v_old), fabs(v_new));
         if (!(fabs(v_old - v_new) <= fmax(opts->abstol, opts->reltol * big))) {
-          e->value = v_new;
+          e->value = v_new; e->t_fun = t_new;
           if (newtons_method(e, Y, YP, opts, c_e0) != 0) { flag = ORC_ERR_INIT; break; }
           ida_reinit_at(Ip, e, opts, Y, YP, t_new);
         }

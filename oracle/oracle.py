@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETAP = 0, 1, 2, 3, 4
-VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE = 0, 1, 2, 3
+VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE, VAL_EXPR = 0, 1, 2, 3, 4
 NAN = math.nan
 
 BOUND_FIELDS = ["V_max", "V_min", "SOC_max", "SOC_min", "T_max", "c_s_n_max", "I_max", "I_min", "eta_plating_min",
@@ -123,6 +123,10 @@ def simulate(variant, theta, SOC0, runs, opts=None, max_out=20000, Y_init=None, 
             tt = np.ascontiguousarray(r["table"][0], dtype=np.float64); vv = np.ascontiguousarray(r["table"][1], dtype=np.float64)
             keep.append((tt, vv))
             arr[k].value_kind = VAL_TABLE; arr[k].n_tab = len(tt); arr[k].tab_t = _dp(tt); arr[k].tab_v = _dp(vv)
+        if r.get("expr") is not None:         # (opcodes, operands): closure input as a postfix program (ORC_VAL_EXPR)
+            oo = np.ascontiguousarray(r["expr"][0], dtype=np.float64); aa = np.ascontiguousarray(r["expr"][1], dtype=np.float64)
+            keep.append((oo, aa))
+            arr[k].value_kind = VAL_EXPR; arr[k].n_tab = len(oo); arr[k].tab_t = _dp(oo); arr[k].tab_v = _dp(aa)
     theta = np.ascontiguousarray(theta, dtype=np.float64)
     out = {k: np.zeros(max_out) for k in ("t", "V", "I", "SOC", "T")}
     n_out = C.c_int(0)

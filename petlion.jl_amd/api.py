@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 from . import _capi as cap
-from . import grids
+from . import closures, grids
 from .params import EXIT_REASONS, Bounds, Opts, bounds_LCO, bounds_LGM50, bounds_NMC, calc_I1C, theta_LCO, theta_LGM50, theta_NMC
 
 LCO = "LCO"
@@ -150,8 +150,15 @@ def _make_run(p, name, inp, tf, bounds):
         else:
             raise ValueError("Unsupported input symbol.")
     elif callable(inp):
-        raise NotImplementedError("Julia-style closures cannot cross the C ABI: pass the input as a piecewise-linear table (t, values) in run-local "
-                                  "time and list its jumps in opts.tdiscon (reference run_function / tdiscon)")
+        # a closure cannot cross the C ABI, its expression can: traced once into a postfix program (closures.py; PLH_VAL_EXPR).  A closure that branches on t or Y in Python
+        # cannot be traced (closures.TraceError says how to rewrite it); a piecewise-linear table (t, values) + opts.tdiscon remains the other way in.
+        if name == "dT":
+            raise ValueError("function inputs for dT are not defined by the reference")
+        ops, args = closures.trace(inp, p)
+        r.value_kind, r.value = cap.VAL_EXPR, 0.0
+        r.n_tab = ops.size
+        r.tab_t = ops.ctypes.data_as(C.POINTER(C.c_double)); r.tab_v = args.ctypes.data_as(C.POINTER(C.c_double))
+        r._keep = (ops, args)
     elif isinstance(inp, (tuple, list)) and len(inp) == 2 and np.ndim(inp[0]) == 1:
         if name == "dT":
             raise ValueError("time-dependent dT inputs are not defined by the reference")

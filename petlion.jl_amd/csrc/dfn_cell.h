@@ -235,6 +235,9 @@ template <class M> struct CellLDS {
   const Tables* tb;    // model tables (set by cell_setup)
   plh_run runc;        // the run being integrated (copied from HBM once per run)
   CellConst cc;
+  // closure inputs (PLH_VAL_EXPR; general instantiation only; kept last so that nothing else moves): the cell's theta row in HBM and the interpreter's value stack
+  const double* theta_row;
+  double xstk[PLH_EXPR_STACK * M::NWAVES];      // (one stack per wave)
 };
 
 // per-lane registers that persist across phases

@@ -58,9 +58,11 @@ __device__ __forceinline__ double wrms(const double* v, const double* w) {
 // Returns the number of Newton iterations (>= 1) or PLH_ERR_INIT.  cell_simulate has exactly ONE call site (the re-initialisation of a
 // function input loops back to it): a second inlined copy costs 4-5 % of the step loop in instruction-cache misses, and a real call
 // spills the ~100 live registers of the step loop.
+template <class M> PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP);     // closure inputs (PLH_VAL_EXPR), defined below
+// `frun` (general instantiation only): the run when its input is a closure of the state -- re-evaluated with the iterate before every residual evaluation, at run-local time t_fun
 template <bool GEN, class M>
 PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
-                                                      int mode, double value, double reltol_init, double* bsave = nullptr, int nref = 0) {
+                                                      int mode, double value, double reltol_init, double* bsave = nullptr, int nref = 0, const plh_run* frun = nullptr, double t_fun = 0.0) {
   LaneRegs R;                                                        // (the algebraic solves do not touch the particle registers)
   for (int k = 0; k < CS_PASS; k++) R.wreg[k] = 0.0;
   int iters = 0;
@@ -72,6 +74,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   if (M::THERMAL && mode == PLH_MODE_DT) mode = PL_MODE_DT_TWIN;
   int ok = 0;
   for (int iter = 1; iter <= 100; iter++) {
+    if constexpr (GEN) { if (frun) value = expr_eval(S, *frun, t_fun, Y, YP); }
     cell_node_pass<true, true>(S, Y, YP, res, mode, value);      // R_alg + J_alg partials (differential rows ignored)
     PL_SYNC();
     cell_factor(S, R, tb, 0.0, mode, true);
@@ -87,6 +90,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   }
   if (!ok) return PLH_ERR_INIT;
   // YP_diff = rhs_diff(Y)   (R_diff with YP = 0)
+  if constexpr (GEN) { if (frun) value = expr_eval(S, *frun, t_fun, Y, YP); }
   cell_residual(S, R, Y, YP, res, mode == PL_MODE_DT_TWIN ? PLH_MODE_DT : mode, value);
   PL_VEC(n) if (n < NDIFF) YP[n] = res[n];
   PL_SYNC();
@@ -97,6 +101,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   if (10.0 * reltol_init > dt) dt = 10.0 * reltol_init;
   PL_VEC(n) Ytmp[n] = Y[n] + dt * YP[n];
   PL_XSYNC();
+  if constexpr (GEN) { if (frun) value = expr_eval(S, *frun, t_fun, Ytmp, YP); }
   cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
   PL_SYNC();
   if (GEN && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref);
@@ -107,9 +112,10 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
 }
 template <bool GEN = false, class M>
 __device__ __forceinline__ int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
-                                                    int mode, double value, double reltol_init, Counters& cnt, double* bsave = nullptr, int nref = 0) {
+                                                    int mode, double value, double reltol_init, Counters& cnt, double* bsave = nullptr, int nref = 0,
+                                                    const plh_run* frun = nullptr, double t_fun = 0.0) {
   (void)R;
-  const int it = cell_init_consistent_impl<GEN>(S, tb, Y, YP, res, Ytmp, mode, value, reltol_init, bsave, nref);
+  const int it = cell_init_consistent_impl<GEN>(S, tb, Y, YP, res, Ytmp, mode, value, reltol_init, bsave, nref, frun, t_fun);
   if (it < 0) { cnt_add(cnt, C_INIT, 100); return it; }
   cnt_add(cnt, C_RES, it + 2); cnt_add(cnt, C_JAC, it); cnt_add(cnt, C_FACT, it); cnt_add(cnt, C_SOLVE, it + 1); cnt_add(cnt, C_INIT, it);
   return 0;
@@ -211,7 +217,10 @@ PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
 
 // IDANls + Newton + convergence test.  0 ok, 1 recoverable failure
 template <bool GEN, class M>
-PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, int mode, double value, int jac_every_step, Counters& cnt, int nref) {
+PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, int mode, double value, int jac_every_step, Counters& cnt, int nref, const plh_run* xrun = nullptr,
+                   double* xvalue = nullptr) {
+  // (xrun / xvalue: a closure input is re-evaluated inside every residual and leaves the value of its last evaluation behind -- run.value[] of scalar_residual.jl:170 -- for
+  //  check_reinitialization!)
   PL_MODEL(M);
   const int lane = lane_id();
   const double epsNewt = 0.33, toldel = 0.0001 * epsNewt;
@@ -232,6 +241,7 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
   for (bool first = true;; first = false) {
     { PL_TIC(); form_iterate(S, I, first); PL_TOC(S, PH_NEWTVEC); }
     if (done) break;                                      // the iterate (yy, yp) now includes the last correction
+    if constexpr (GEN) { if (xrun) { value = expr_eval(S, *xrun, I.tn, S.yy, S.yp); *xvalue = value; } }       // closure input: run.func(t, Y, YP, p) inside every residual (scalar_residual.jl:169-170)
     if (callLSetup) {
       PL_TIC();
 #ifndef PL_EXP_NO_JAC
@@ -451,6 +461,39 @@ PL_DEV double tab_eval(const plh_run& r, double t) {
   const double dt = tt[k + 1] - tt[k];
   return dt > 0.0 ? vv[k] + (vv[k + 1] - vv[k]) * ((t - tt[k]) / dt) : vv[k + 1];
 }
+// value of a closure input (PLH_VAL_EXPR): a postfix program over t, Y, YP, theta (include/petlion_hip.h); wave-uniform, every lane runs it (scalar loads of the program,
+// broadcast LDS reads of the states).  The value stack is an LDS array -- every lane stores the same value at the same address -- because a runtime-indexed private array
+// would live in scratch memory, once per inlined copy of this function.
+template <class M>
+PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP) {
+  double* st = S.xstk + PLH_EXPR_STACK * wave_id(); const double* th = S.theta_row; int sp = 0;
+  for (int k = 0; k < r.n_tab; k++) {
+    const int op = (int)r.tab_t[k]; const double a = r.tab_v[k];
+    if (op <= PLH_OP_THETA) {
+      double v;
+      switch (op) { case PLH_OP_CONST: v = a; break; case PLH_OP_T: v = t; break; case PLH_OP_Y: v = Y[(int)a]; break; case PLH_OP_YP: v = YP[(int)a]; break; default: v = th[(int)a]; }
+      st[sp++] = v;
+    } else if (op == PLH_OP_SELECT) { const double b = st[sp - 1], x = st[sp - 2], c = st[sp - 3]; sp -= 2; st[sp - 1] = c != 0.0 ? x : b; }
+    else if (op == PLH_OP_NEG || op == PLH_OP_SIN || op == PLH_OP_COS || op == PLH_OP_EXP || op == PLH_OP_LOG || op == PLH_OP_SQRT || op == PLH_OP_ABS || op == PLH_OP_TANH) {
+      const double x = st[sp - 1]; double v;
+      switch (op) { case PLH_OP_NEG: v = -x; break; case PLH_OP_SIN: v = sin(x); break; case PLH_OP_COS: v = cos(x); break; case PLH_OP_EXP: v = exp(x); break;
+                    case PLH_OP_LOG: v = log(x); break; case PLH_OP_SQRT: v = sqrt(x); break; case PLH_OP_ABS: v = fabs(x); break; default: v = tanh(x); }
+      st[sp - 1] = v;
+    } else {
+      const double y = st[sp - 1], x = st[sp - 2]; sp--; double v;
+      switch (op) { case PLH_OP_ADD: v = x + y; break; case PLH_OP_SUB: v = x - y; break; case PLH_OP_MUL: v = x * y; break; case PLH_OP_DIV: v = x / y; break;
+                    case PLH_OP_POW: v = pow(x, y); break; case PLH_OP_MIN: v = x < y ? x : y; break; case PLH_OP_MAX: v = x > y ? x : y; break;
+                    case PLH_OP_LT: v = x < y ? 1.0 : 0.0; break; case PLH_OP_LE: v = x <= y ? 1.0 : 0.0; break; case PLH_OP_GT: v = x > y ? 1.0 : 0.0; break; default: v = x >= y ? 1.0 : 0.0; }
+      st[sp - 1] = v;
+    }
+  }
+  return st[0];
+}
+// input of a run_function run at run-local time t with the iterate (Y, YP): table or closure
+template <class M>
+PL_DEV double run_input(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP) {
+  return r.value_kind == PLH_VAL_EXPR ? expr_eval(S, r, t, Y, YP) : tab_eval(r, t);
+}
 // next tstop after run-local time t: the sorted set {tdiscon - reltol/2} U {1.0 if continuation} U {tf} of postfix_integrator!
 // (model_evaluation.jl:288-310) walked without storing it
 PL_DEV double next_tstop(const plh_opts& o, double t, bool continuation, double tf) {
@@ -499,8 +542,8 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
   if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0 && wave_id() == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; PL_XSYNC(); }
   for (;;) {
     double ck; { PL_TIC(); PL_TICE(3); ck = ida_set_coeffs(S, I); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 0); }
-    if constexpr (TAB) { if (frun) value = tab_eval(*frun, I.tn); }                           // every residual of this step attempt is evaluated at t = tn
-    const int nflag = ida_nls<TAB>(S, R, tb, I, mode, value, o.jac_every_step, cnt, o.refine);
+    if constexpr (TAB) { if (frun) value = run_input(S, *frun, I.tn, S.yy, S.yp); }                           // every residual of this step attempt is evaluated at t = tn
+    const int nflag = ida_nls<TAB>(S, R, tb, I, mode, value, o.jac_every_step, cnt, o.refine, (TAB && frun && frun->value_kind == PLH_VAL_EXPR) ? frun : nullptr, &value);
     int errfail = 0;
     if (nflag == 0) { PL_TIC(); PL_TICE(3); errfail = ida_test_error(S, I, ck, err_k, err_km1); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 1); }
     if (nflag != 0 || errfail) {
@@ -657,9 +700,9 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     else t0 = nextafter(t_global, 1e300);                               // initial_time, model_evaluation.jl:112
     // initial_current! (input_methods.jl:11-74)
     double value = run.value, Iguess;
-    const bool is_tab = TAB && run.value_kind == PLH_VAL_TABLE;
+    const bool is_tab = TAB && (run.value_kind == PLH_VAL_TABLE || run.value_kind == PLH_VAL_EXPR);      // run_function
     if (is_tab) {                                                       // run_function: initial_current!, input_methods.jl:28-34, 65-76, 104-107, 143-153
-      value = tab_eval(run, 0.0);
+      value = run_input(S, run, 0.0, S.yy, S.yp);
       if (mode == PLH_MODE_I) Iguess = value;
       else if (mode == PLH_MODE_P) Iguess = value / (cellV<M>(S.yy) * S.cc.I1C);
       else if (have_prev) Iguess = prev_I;
@@ -698,7 +741,8 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     bool first_init = true, again = false, init_failed = false;
     do {                                                                // (re)initialise -> integrate ; loops only for check_reinitialization!
     again = false;
-    int ierr; { PL_TIC(); ierr = cell_init_consistent<TAB>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt, S.phi[0], o.refine); PL_TOC(S, PH_INIT); }
+    int ierr; { PL_TIC(); ierr = cell_init_consistent<TAB>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt, S.phi[0], o.refine,
+                                                                       (TAB && run.value_kind == PLH_VAL_EXPR) ? &run : nullptr, t_restart); PL_TOC(S, PH_INIT); }
     if (ierr != 0) { if (first_init) init_failed = true; else flag = ierr; ri.flag = ierr; break; }
     ida_reinit(S, I, S.yy, S.yp, first_init ? (o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD) : I.maxord, t_restart);
     if (first_init) {
@@ -744,7 +788,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
         PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }      // fire-and-forget: read back only when a bound fires
         t_prev_saved = t + t0; I_prev_pt = S.yy[O_I];
         if constexpr (TAB) if (is_tab && t - tprev < 1e-3 * o.reltol) {                    // check_reinitialization!, checks.jl:341-364
-          const double t_new = t + o.reltol, v_new = tab_eval(run, t_new);
+          const double t_new = t + o.reltol, v_new = run_input(S, run, t_new, S.yy, S.yp);
           const double big = fabs(value) > fabs(v_new) ? fabs(value) : fabs(v_new);
           const double tolv = o.abstol > o.reltol * big ? o.abstol : o.reltol * big;
           if (!(fabs(value - v_new) <= tolv)) { value = v_new; t_restart = t_new; again = true; }

@@ -563,7 +563,25 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   if (n <= 0 || !theta || !SOC0 || n_runs <= 0 || !runs || !opts || !out || !out->run_info) return fail(PLH_E_ARG, "bad argument");
   for (int r = 0; r < n_runs; r++) {
     CHECK_MODE(runs[r].mode);
-    if (runs[r].value_kind < 0 || runs[r].value_kind > PLH_VAL_TABLE) return fail(PLH_E_ARG, "bad value_kind");
+    if (runs[r].value_kind < 0 || runs[r].value_kind > PLH_VAL_EXPR) return fail(PLH_E_ARG, "bad value_kind");
+    if (runs[r].value_kind == PLH_VAL_EXPR) {                     // closure input as a postfix program: check it here, the device interpreter trusts it
+      if (runs[r].n_tab < 1 || !runs[r].tab_t || !runs[r].tab_v) return fail(PLH_E_ARG, "PLH_VAL_EXPR needs n_tab >= 1 and both program arrays");
+      if (runs[r].mode == PLH_MODE_DT) return fail(PLH_E_UNSUPPORTED, "function inputs for dT are not defined by the reference");
+      int sp = 0;
+      for (int k = 0; k < runs[r].n_tab; k++) {
+        const double opd = runs[r].tab_t[k]; const int op = (int)opd; const double a = runs[r].tab_v[k];
+        if (!(opd == (double)op) || op < 0 || op >= PLH_N_OPS) return fail(PLH_E_ARG, "PLH_VAL_EXPR: unknown opcode");
+        int pop = 2, idx_max = -1;
+        if (op <= PLH_OP_THETA) pop = 0; else if (op == PLH_OP_SELECT) pop = 3;
+        else if (op == PLH_OP_NEG || op == PLH_OP_SIN || op == PLH_OP_COS || op == PLH_OP_EXP || op == PLH_OP_LOG || op == PLH_OP_SQRT || op == PLH_OP_ABS || op == PLH_OP_TANH) pop = 1;
+        if (op == PLH_OP_Y || op == PLH_OP_YP) idx_max = m->N; else if (op == PLH_OP_THETA) idx_max = m->P;
+        if (idx_max >= 0 && !(a == (double)(int)a && a >= 0 && a < idx_max)) return fail(PLH_E_ARG, "PLH_VAL_EXPR: state / theta index out of range");
+        if (sp < pop) return fail(PLH_E_ARG, "PLH_VAL_EXPR: stack underflow");
+        sp += 1 - pop;
+        if (sp > PLH_EXPR_STACK) return fail(PLH_E_ARG, "PLH_VAL_EXPR: more than 16 values on the stack");
+      }
+      if (sp != 1) return fail(PLH_E_ARG, "PLH_VAL_EXPR: the program must leave exactly one value");
+    }
     if (runs[r].value_kind == PLH_VAL_TABLE) {
       if (runs[r].n_tab < 1 || !runs[r].tab_t || !runs[r].tab_v) return fail(PLH_E_ARG, "PLH_VAL_TABLE needs n_tab >= 1 and both table arrays");
       if (runs[r].mode == PLH_MODE_DT) return fail(PLH_E_UNSUPPORTED, "time-dependent dT inputs are not defined by the reference");
@@ -610,7 +628,7 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   }
   std::vector<plh_run> hruns(runs, runs + n_runs);                    // tables are host arrays: stage them and patch the device copies
   for (int r = 0; r < n_runs; r++) {
-    if (hruns[r].value_kind == PLH_VAL_TABLE) {
+    if (hruns[r].value_kind == PLH_VAL_TABLE || hruns[r].value_kind == PLH_VAL_EXPR) {
       hruns[r].tab_t = s.in_host(runs[r].tab_t, runs[r].n_tab); hruns[r].tab_v = s.in_host(runs[r].tab_v, runs[r].n_tab);
     } else { hruns[r].n_tab = 0; hruns[r].tab_t = nullptr; hruns[r].tab_v = nullptr; }
     if (runs[r].value_cell) hruns[r].value_cell = s.in_host(runs[r].value_cell, n);       // per-cell protocol values: host arrays like the protocol
@@ -638,7 +656,7 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   CHECK_STAGE(s);                                                     // a failed staging allocation must never reach the kernel as a NULL ("not requested") output
   hipEventRecord(cx.ev0, s.st);
   bool general = opts->n_tdiscon > 0 || out->Y_all || opts->refine > 0;     // the general instantiation also carries the per-step state dump (outputs = :all) and the refinement mode
-  for (int r = 0; r < n_runs; r++) general = general || runs[r].value_kind == PLH_VAL_TABLE;
+  for (int r = 0; r < n_runs; r++) general = general || runs[r].value_kind == PLH_VAL_TABLE || runs[r].value_kind == PLH_VAL_EXPR;
   m->ops->integrate(s.st, a, general);
   hipEventRecord(cx.ev1, s.st);
   cx.timed = true; m->last = &cx;

@@ -127,6 +127,7 @@ template <class M, bool TAB> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE
   const int cell = blockIdx.x;
   if (cell >= a.n_cells) return;
   cell_setup(S, R, a.tb, a.theta + (size_t)cell * a.tb->P);
+  if constexpr (TAB) { if (threadIdx.x == 0) S.theta_row = a.theta + (size_t)cell * a.tb->P; }     // closure inputs read theta again (general instantiation only)
   Counters cnt; for (int k = 0; k < 10; k++) cnt.v[k] = 0;
 #ifdef PL_PHASE_TIMERS
   if (threadIdx.x < 8) S.cyc[threadIdx.x] = 0;

@@ -167,6 +167,8 @@ def runs_to_oracle(O, p, pkg, protocol, cell=None, n_cells=None):
                  tf=r.tf_cell[cell] if r.tf_cell else r.tf, bounds=b)
         if r.value_kind == 3:       # PLH_VAL_TABLE
             d["table"] = (np.array(r._keep[0]), np.array(r._keep[1]))
+        if r.value_kind == 4:       # PLH_VAL_EXPR
+            d["expr"] = (np.array(r._keep[0]), np.array(r._keep[1]))
         out.append(d)
     return out
 

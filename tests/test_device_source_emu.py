@@ -278,8 +278,49 @@ def check_function_inputs(p, O, pkg):
         ens = pkg.simulate_ensemble(p, th[None, :], proto, SOC=soc, opts=o)
         ro = O.simulate(p.variant, th, soc, parity.runs_to_oracle(O, p, pkg, proto), opts=O.default_opts(tdiscon=td))
         parity.compare_trajectory(ens, 0, ro, rtol_state=5e-6, same_decisions=same)
-    with pytest.raises(NotImplementedError):
-        pkg.make_protocol(p, [{"I": lambda t: 1.0}])
+    check_closure_inputs(p, O, pkg)
+
+
+def check_closure_inputs(p, O, pkg):
+    """input closures `I = (t, Y, YP, p) -> ...` traced into the C ABI's postfix programs (PLH_VAL_EXPR; petlion.jl_amd/closures.py): the notebook's P = sin(t) and
+    V = 3.5 + 0.1 cos(t) (examples/variable_input_functions.ipynb) evaluated exactly instead of through a sampled table, a ramp whose slope is a model parameter of the cell, a
+    step written with where() + tdiscon, and closures of the STATE (a current that tapers with the cell voltage; one that reads YP).  The oracle runs the same programs
+    (ORC_VAL_EXPR): same decisions, state 5e-6."""
+    cl = pkg.closures
+    th = p.theta_vector()
+    P1 = 29.23                                                     # (1C power scale of this cell, W/m^2: the notebook's sin(t) is in the reference's power unit)
+    cases = [("P_sin", [{"P": lambda t: P1 * cl.sin(t), "tf": 10.0}], 0.5, [], False),
+             ("V_cos", [{"V": lambda t: 3.9 + 0.05 * np.cos(t), "tf": 10.0}], 0.5, [], True),
+             ("ramp_theta", [{"I": lambda t, q: q.θ["t₊"] * t / 36.4, "tf": 100.0}], 0.0, [], True),          # slope from a theta entry of the cell (0.364 / 36.4 = 1/100)
+             ("step_where", [{"I": lambda t: cl.where(t < 100, 1.0, 0.5), "tf": 200.0}], 0.0, [100.0], True),
+             ("taper_V", [{"I": lambda t, Y, q: -cl.minimum(1.0, cl.maximum(0.05, (cl.calc_V(Y, q) - 3.0) * 2.0)), "tf": 4000.0, "V_min": 3.05}], 1.0, [], True),
+             # (a closure of YP enters the Newton matrix scaled by cj = O(1/h); without its derivative -- see include/petlion_hip.h -- only a weak dependence converges)
+             ("reads_YP", [{"I": lambda t, Y, YP, q: -1.0 + 1e-7 * YP[q.ind["c_e"].start], "tf": 300.0}], 1.0, [], True)]
+    for name, proto, soc, td, same in cases:
+        o = pkg.Opts(); o.tdiscon = td
+        ens = pkg.simulate_ensemble(p, th[None, :], proto, SOC=soc, opts=o)
+        runs = parity.runs_to_oracle(O, p, pkg, proto)
+        assert runs[0]["value_kind"] == 4
+        ro = O.simulate(p.variant, th, soc, runs, opts=O.default_opts(tdiscon=td))
+        assert ens.run_info[0, 0]["flag"] == ro["runs"][0]["flag"] >= 0, (name, ens.run_info[0, 0], ro["runs"][0])
+        parity.compare_trajectory(ens, 0, ro, rtol_state=5e-6, same_decisions=same)
+    # the exact closure and its 201-point table agree to the table's interpolation error
+    tt = np.linspace(0, 10, 201)
+    e1 = pkg.simulate_ensemble(p, th[None, :], [{"V": lambda t: 3.9 + 0.05 * np.cos(t), "tf": 10.0}], SOC=0.5)
+    e2 = pkg.simulate_ensemble(p, th[None, :], [{"V": (tt, 3.9 + 0.05 * np.cos(tt)), "tf": 10.0}], SOC=0.5)
+    assert abs(e1.run_info[0, 0]["V"] - (3.9 + 0.05 * np.cos(10.0))) < 1e-5 and abs(e1.run_info[0, 0]["I"] - e2.run_info[0, 0]["I"]) < 2e-3 * abs(e2.run_info[0, 0]["I"])
+    # per-cell parameters reach the closure: two cells with different t_plus get different ramps
+    Th = pkg.theta_matrix(p, 2, {"t₊": np.array([0.364, 0.182])})
+    e3 = pkg.simulate_ensemble(p, Th, [{"I": lambda t, q: q.θ["t₊"] * t / 36.4, "tf": 100.0}], SOC=0.0)
+    assert abs(e3.run_info[0, 0]["I"] - 1.0) < 1e-9 and abs(e3.run_info[1, 0]["I"] - 0.5) < 1e-9
+    # what cannot be traced says so
+    with pytest.raises(cl.TraceError, match="where"):
+        pkg.make_protocol(p, [{"I": lambda t: 1.0 if t < 100 else 0.5}])
+    import math
+    with pytest.raises(cl.TraceError, match="numpy"):
+        pkg.make_protocol(p, [{"I": lambda t: math.sin(t)}])
+    with pytest.raises(ValueError):
+        pkg.make_protocol(p, [{"dT": lambda t: 0.0}])
 
 
 def test_function_inputs(emu_model, O, pkg):
