@@ -218,7 +218,12 @@ template <class M> struct CellLDS {
   typename M::fact_t Dinv[M::NB * M::NB][NE], LD[M::NB * M::NB][NE];   // Thomas factors: D'^-1 and L D'^-1(prev)
   typename M::fact_t LDmid[M::NB * M::NB];                             // closing block of the twisted factorisation
   typename M::fact_t Ainv[2][(M::THERMAL || M::SD != 0) ? 1 : NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
-  double Mr[(M::THERMAL || M::SD != 0) ? 1 : NR * NR];               // radial operator (copy of Tables::M)
+  // radial operator (copy of Tables::M) followed by
+  // its eigen-decomposition (copies of Tables::V, W, LAM): the resolvents are rebuilt from them at every Jacobian refresh, and reading the tables from HBM there cost
+  // 9.7 k cycles per refresh (two dependent rounds of global / scalar loads); from LDS, with the 2 N_r^2 entries spread over the wave, 1 k
+  // (one array, so that the models without it -- thermal: 40 952 of the 40 960 B that four cells per CU allow -- pay 8 bytes, not 32)
+  double Mr[(M::THERMAL || M::SD != 0) ? 1 : 3 * NR * NR + NR];
+  static constexpr int OFF_VR = NR * NR, OFF_WR = 2 * NR * NR, OFF_LAMR = 3 * NR * NR;
   double resp[M::SD != 0 ? NJ : 1], rcjf[M::SD != 0 ? 2 : 1][2];    // quadratic / polynomial particles: d c_s* / d j after eliminating c_avg (and Q); 1/cj and 1/(-kappa - cj) of the factorisation
   double x2[3][M::THERMAL ? 1 : NE];
   double ctrlJ[2], bord;           // P-mode control row at the last Jacobian pass (I*I1C, V*I1C); border pivot d - v.x2
@@ -594,7 +599,9 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
       S.sei.cjf = 0.0;
     }
   }
-  if constexpr (!M::THERMAL && M::SD == 0) { if (wave_id() == M::NWAVES - 1) for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->Mp()[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
+  if constexpr (!M::THERMAL && M::SD == 0) { if (wave_id() == M::NWAVES - 1) {
+    for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->Mp()[k]; S.Mr[S.OFF_VR + k] = tb->Vp()[k]; S.Mr[S.OFF_WR + k] = tb->Wp()[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; }
+    if (lane < NR) S.Mr[S.OFF_LAMR + lane] = tb->LAMp()[lane]; } }
   for (int k = 0; k < CS_PASS; k++) R.wreg[k] = 0.0;
   PL_XSYNC();
   if constexpr (M::THERMAL) thermal_setup(S, tb, th);
@@ -1043,6 +1050,7 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
   PL_MODEL(M);
   const int lane = lane_id();
   const CellConst& c = S.cc;
+  PL_TICD();
   // 1. particle resolvent rows: (kappa M - cj I)^-1 = V diag(1/(kappa lam - cj)) W
   if constexpr (M::SD != 0) {
     if (lane < 2) { S.rcjf[lane][0] = alg_only ? 0.0 : -1.0 / cj; S.rcjf[lane][1] = alg_only ? 0.0 : 1.0 / (-(lane == 0 ? c.kap_p : c.kap_n) - cj); }   // -1/cj, 1/(-kappa - cj)
@@ -1050,21 +1058,27 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
   if (!alg_only && (!M::W2 || wave_id() == 1)) {          // (two waves per cell: the resolvents are wave 1's, next to wave 0's Jacobian node pass)
     const int r = lane % NR;
     // the 2 N_r reciprocals 1/(kappa lam_m - cj) are formed by 2 N_r lanes in parallel and passed through S.w9 (free outside the solves)
-    if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * tb->LAMp()[r] - cj);
+    if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * S.Mr[S.OFF_LAMR + r] - cj);
     PL_SYNC();
-    for (int el = 0; el < 2; el++) {
-      double acc[NR];
-      for (int k = 0; k < NR; k++) acc[k] = 0.0;
-      for (int m = 0; m < NR; m++) {
-        const double f = tb->Vp()[r * NR + m] * S.w9[el * NR + m];
-        for (int k = 0; k < NR; k++) acc[k] += f * tb->Wp()[m * NR + k];
-      }
-      if (lane < NR) for (int k = 0; k < NR; k++) S.Ainv[el][r * NR + k] = PL_F32(acc[k]);
-      if (lane == NR - 1) S.sig[el] = acc[NR - 1];
+    // entry (row, k) of electrode el = sum_m V[row][m] w_el[m] W[m][k], m ascending; lanes 0..31 build the cathode's resolvent, 32..63 the anode's, RS_KG lanes per row with
+    // RS_KW columns each (N_r = 10: 3 lanes x 4 columns)
+    constexpr int RS_KG = 32 / NR, RS_KW = (NR + RS_KG - 1) / RS_KG;
+    const int el = lane >> 5, q = lane & 31, row = q / RS_KG < NR ? q / RS_KG : NR - 1, k0 = (q % RS_KG) * RS_KW;
+    const bool act = q < NR * RS_KG;
+    double acc[RS_KW];
+    for (int kk = 0; kk < RS_KW; kk++) acc[kk] = 0.0;
+    for (int m = 0; m < NR; m++) {
+      const double f = S.Mr[S.OFF_VR + row * NR + m] * S.w9[el * NR + m];
+      for (int kk = 0; kk < RS_KW; kk++) acc[kk] += f * S.Mr[S.OFF_WR + m * NR + (k0 + kk < NR ? k0 + kk : NR - 1)];
+    }
+    if (act) for (int kk = 0; kk < RS_KW; kk++) if (k0 + kk < NR) {
+      S.Ainv[el][row * NR + k0 + kk] = PL_F32(acc[kk]);
+      if (row == NR - 1 && k0 + kk == NR - 1) S.sig[el] = acc[kk];
     }
   }
   PL_XSYNC();
   if constexpr (M::W2) { if (wave_id() != 0) return; }    // two waves per cell: the node-local elimination, the block factorisation and the border are wave 0's
+  PL_TOCD(S, 2);
   // 2. node-local elimination.  Without SEI the local unknown is j (pivot d = -1 - gcs sigma bj after the particle Schur complement);
   //    with SEI the anode nodes eliminate u = (j, j_s, film) through the inverse W of their 3x3 local block.  Both cases reduce to
   //    D[r][c] -= t_r phi_c with t = (ceJ, peJ, psJ) (j and j_s enter the node rows only through j_total) and phi = omega . A_ux,
@@ -1115,6 +1129,7 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
   }
   if constexpr (M::SEI) { if (lane == 0) S.sei.cjf = cj; }
   PL_SYNC();
+  PL_TOCD(S, 3);
   // 3. twisted block-Thomas factorisation (lane layout of thomas_sweeps): top nodes D'_n = D_n - L_n D'^-1_{n-1} U_{n-1}, bottom nodes
   //    D'_n = D_n - U_n D'^-1_{n+1} L_{n+1}; with the mirrored layout both read "a P b" with P = the factor of the lane below.
   {
@@ -1168,6 +1183,7 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     if (act) for (int k = 0; k < 9; k++) { S.Dinv[k][i] = PL_F32(Dinv[k]); S.LD[k][i] = PL_F32(LDm[k]); }
   }
   PL_SYNC();
+  PL_TOCD(S, 4);
   // 4. border vector for modes whose control row is not "I = value":  x2 = T^-1 (column of I)
   if (mode != PLH_MODE_I) {
     const int nd = tw_node(lane);
@@ -1180,6 +1196,7 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     if (lane == 0) S.bord = (mode == PLH_MODE_P) ? S.ctrlJ[1] - S.ctrlJ[0] * vx : -vx;
     PL_SYNC();
   }
+  PL_TOCD(S, 5);
 }
 
 // solve J x = b in place (b is an LDS vector of NST entries).  alg_only: only rows/cols NDIFF.. are touched.

@@ -328,6 +328,10 @@ template <class M> struct OpsOf {
     else PL_LAUNCH((k_integrate<M, false>), a.n_cells, WAVE * M::NWAVES, st, a);
   }
   static const VariantOps* table(int id) {
+#if !defined(PL_PHASE_TIMERS) && !defined(PL_WAVE_EMU)
+    // four cells per CU (160 kB of LDS, one wave per SIMD) is what every built-in kernel is tuned for: one byte over 40 960 drops the CU to three cells (-25 %)
+    static_assert(!GRID_DEFAULT || sizeof(CellLDS<M>) <= 40960, "built-in variant: LDS per cell above 40 960 B, only three cells per CU would be resident");
+#endif
     static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::MIXED ? 1 : 0, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, {NP, NS, NN, NR, NA, NZ},
                                    PL_RADIAL_M, PL_RADIAL_LAM, PL_RADIAL_V, PL_RADIAL_W, PL_RADIAL_BJ_FACTOR, sizeof(CellLDS<M>), &classify<M>, &sections_of<M>,
                                    &initial_guess, &residual, &jacobian, &linear_solve, &init_consistent, &integrate};
