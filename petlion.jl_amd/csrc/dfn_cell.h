@@ -1067,7 +1067,7 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     const bool act = q < NR * RS_KG;
     double acc[RS_KW];
     for (int kk = 0; kk < RS_KW; kk++) acc[kk] = 0.0;
-    for (int m = 0; m < NR; m++) {
+    _Pragma("unroll 2") for (int m = 0; m < NR; m++) {            // (fully unrolled, the 60 operands of the sums are all live at once: 132 B/lane of scratch in the integrate kernel)
       const double f = S.Mr[S.OFF_VR + row * NR + m] * S.w9[el * NR + m];
       for (int kk = 0; kk < RS_KW; kk++) acc[kk] += f * S.Mr[S.OFF_WR + m * NR + (k0 + kk < NR ? k0 + kk : NR - 1)];
     }
