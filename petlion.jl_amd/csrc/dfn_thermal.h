@@ -76,6 +76,9 @@ __device__ __forceinline__ int tsec_of(int it) { return it < NA ? 0 : (it < NA +
 template <class M>
 PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th) {
   static_assert(M::CHEM == PLH_CHEM_LCO_LIC6 && !M::SEI, "temperature = true is instantiated for LCO/LiC6 without aging");
+  // Other grids are not offered with temperature = true: the elimination assumes N_p = N_n (the two T rows with a far-behind entry become final at the same stage of their
+  // chains), the collector chains N_a = N_z, and the thermal Jacobian decode N_r = 10 -- measured: N_s alone may change, anything else fails the solve / Jacobian self-checks
+  static_assert(!M::THERMAL || GRID_DEFAULT || (NP == 10 && NN == 10 && NR == 10 && NA == 10 && NZ == 10), "temperature = true: only N_s may differ from the default discretisation");
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const int* ix = tb->thidx;
@@ -87,8 +90,9 @@ PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const do
     const double lam[5] = {th[ix[K_lam_a]], th[ix[K_lam_p]], th[ix[K_lam_s]], th[ix[K_lam_n]], th[ix[K_lam_z]]};
     const double rcp[5] = {th[ix[K_rho_a]] * th[ix[K_Cp_a]], th[ix[K_rho_p]] * th[ix[K_Cp_p]], th[ix[K_rho_s]] * th[ix[K_Cp_s]],
                            th[ix[K_rho_n]] * th[ix[K_Cp_n]], th[ix[K_rho_z]] * th[ix[K_Cp_z]]};
-    const int loc = it - k * 10;                         // every section has 10 nodes
-    const bool first = loc == 0, last = loc == 9;
+    const int sec_start = k == 0 ? 0 : k == 1 ? NA : k == 2 ? NA + NP : k == 3 ? NA + NP + NS : NA + NE, sec_len = k == 0 ? NA : k == 1 ? NP : k == 2 ? NS : k == 3 ? NN : NZ;
+    const int loc = it - sec_start;
+    const bool first = loc == 0, last = loc == sec_len - 1;
     const double h = hh[k], lm = lam[k];
     double aL = first ? 0.0 : lm / (h * h), aU = last ? 0.0 : lm / (h * h), aD = -(aL + aU), aC = 0.0;
     if (last && k < 4) {                                  // left CV of an interface (residuals.jl:354-439)
@@ -421,7 +425,7 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
   constexpr int FAR_STAGE = NP - 3;                          // = 7: nodes 7 and 22 are final after 7 stages of their chains
 #pragma unroll 1
   for (int seg = 0; seg < 2; seg++) {
-    const int lo = seg == 0 ? 1 : FAR_STAGE + 1, hi = seg == 0 ? FAR_STAGE + 1 : TW_MID;
+    const int lo = seg == 0 ? 1 : FAR_STAGE + 1, hi = seg == 0 ? FAR_STAGE + 1 : TW_FWD;
 #pragma unroll 2
     for (int itr = lo; itr < hi; itr++) {
 #pragma unroll
@@ -623,7 +627,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     constexpr int FAR_STAGE = NP - 3;
     inv4(D, Dinv);
 #pragma unroll 1
-    for (int itr = 1; itr < TW_MID; itr++) {
+    for (int itr = 1; itr < TW_FWD; itr++) {
       PL_SYNC();                                            // (also keeps the reloads below inside the loop)
       {
         double P[16];
