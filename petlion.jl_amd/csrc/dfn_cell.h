@@ -1346,13 +1346,17 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   // f. particles:  dc = w - (A^-1 e_last) * bj * dj
   if constexpr (M::SD == 0)
   if (!alg_only && (!M::W2 || wave_id() == 1)) {
+    // unconditional loads with clamped indices first (one LDS latency), guarded stores last: a load inside `if (lane < ..)` is one exec-masked round trip per pass
+    const int gg = lane < CS_LANES ? g : CS_G - 1;
+    const double aP = S.Ainv[0][r * NR + NR - 1] * c.bj_p, aN = S.Ainv[1][r * NR + NR - 1] * c.bj_n;
+    double dj[CS_PASS];
+#pragma unroll
+    for (int pass = 0; pass < CS_PASS; pass++) { const int p = pass * CS_G + gg; dj[pass] = b[O_J + (p < NJ ? p : NJ - 1)]; }
+#pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) {
-      const int p = pass * CS_G + g;
-      if (lane < CS_LANES && p < NJ) {
-        const int el = p < NP ? 0 : 1;
-        const double bj = el == 0 ? c.bj_p : c.bj_n;
-        b[O_CS + p * NR + r] = R.wreg[pass] - S.Ainv[el][r * NR + NR - 1] * bj * b[O_J + p];
-      }
+      const int p = pass * CS_G + gg;
+      const double v = R.wreg[pass] - (p < NP ? aP : aN) * dj[pass];
+      if (lane < CS_LANES && p < NJ) b[O_CS + p * NR + r] = v;
     }
   }
   PL_SYNC();
