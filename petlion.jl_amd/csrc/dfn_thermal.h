@@ -336,9 +336,11 @@ PL_DEV void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const 
     double acc = 0.0, wc = 0.0;
 #pragma unroll
     for (int k = 0; k < NR; k++) { const double v = Y[O_CS + p * NR + k]; acc += Mrow[k] * v; if (WANT_JAC) wc += Wrow[k] * v; }
+    // (every load unconditional -- p is clamped --, only the stores guarded: a load under `if` is one exec-masked LDS round trip of its own)
+    const double jv = Y[O_J + p], ypv = YP[O_CS + p * NR + r];
     double rhs = TP.kapP[p] * acc;
-    if (r == NR - 1) rhs += (p < NP ? c.bj_p : c.bj_n) * Y[O_J + p];
-    if (lane < 60 && p0 < NJ) { Fo[O_CS + p * NR + r] = rhs - YP[O_CS + p * NR + r]; if (WANT_JAC) TP.AinvQ[p][r] = wc; }
+    if (r == NR - 1) rhs += (p < NP ? c.bj_p : c.bj_n) * jv;
+    if (lane < 60 && p0 < NJ) { Fo[O_CS + p * NR + r] = rhs - ypv; if (WANT_JAC) TP.AinvQ[p][r] = wc; }
   }
 }
 
@@ -872,13 +874,19 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
   PL_SYNC();
   // f. particles: dc = w - A^-1 e_last bj dj - A^-1 q dT
   if (!alg_only) {
+    // (unconditional clamped loads first, guarded stores last -- see iso_solve)
+    double ae[4], aq[4], dj[4], dT[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1, nd = p < NP ? p : p + NS;
+      ae[pass] = TP.AinvE[p][r]; aq[pass] = TP.AinvQ[p][r]; dj[pass] = b[O_J + p]; dT[pass] = b[O_T + NA + nd];
+    }
+#pragma unroll
     for (int pass = 0; pass < 4; pass++) {
       const int p = pass * 6 + g;
-      if (lane < 60 && p < NJ) {
-        const double bj = p < NP ? c.bj_p : c.bj_n;
-        const int nd = p < NP ? p : p + NS;
-        b[O_CS + p * NR + r] = R.wreg[pass] - TP.AinvE[p][r] * bj * b[O_J + p] - TP.AinvQ[p][r] * b[O_T + NA + nd];
-      }
+      const double bj = p < NP ? c.bj_p : c.bj_n;
+      const double v = R.wreg[pass] - ae[pass] * bj * dj[pass] - aq[pass] * dT[pass];
+      if (lane < 60 && p < NJ) b[O_CS + p * NR + r] = v;
     }
   }
   PL_SYNC();
