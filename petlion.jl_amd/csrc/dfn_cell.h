@@ -1251,6 +1251,29 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   [[maybe_unused]] double bca = 0.0, bq = 0.0;       // right-hand sides of the c_avg / Q rows of this node (quadratic / polynomial particles)
   int jx = 0; bool elec = false, sei_node = false;
   const int nd = tw_node(lane);                 // node of this lane in the twisted layout of thomas_sweeps (-1: idle)
+  if constexpr (M::SD == 0 && !M::SEI) {       // (measured: +1.5 % on the isothermal kernels, -2 % with SEI, whose integrate kernel is already spilling: selected per model)
+    // every LDS operand of this phase is loaded unconditionally, with indices clamped into range for the lanes / nodes that do not use it, and selected afterwards:
+    // loads under the nested `if`s (node lane? electrode node? current mode?) were three dependent LDS round trips
+    const int i = nd >= 0 ? nd : 0, sc = sec_of(i);
+    elec = nd >= 0 && sc != 1; jx = sc == 0 ? i : (sc == 2 ? i - NS : 0);
+    const double l_ce = b[O_CE + i], l_pe = b[O_PE + i], l_j = b[O_J + jx], l_ps = b[O_PS + jx], l_bI = b[O_I];
+    const double l_gcs = S.gcs[jx], l_w9 = S.w9[jx], l_dj = S.dj[jx], l_ceJ = S.ceJ[i], l_peJ = S.peJ[i], l_psJ = S.psJ[jx];
+    const double l_c0 = S.colI[0][i], l_c1 = S.colI[1][i], l_c2 = S.colI[2][i];
+    if (nd >= 0) {
+      double r0 = alg_only ? 0.0 : l_ce, r1 = l_pe, r2 = 0.0;
+      if (elec) {
+        bjp = l_j - (alg_only ? 0.0 : l_gcs * l_w9);
+        r2 = l_ps;
+        const double beta = bjp * l_dj;       // omega . b_u : what the eliminated local unknown j feeds back into the node rows
+        if (!alg_only) r0 -= l_ceJ * beta;
+        r1 -= l_peJ * beta; r2 -= l_psJ * beta;
+        if (mode == PLH_MODE_I) {             // control row: 1 * x_I = b_I
+          r0 -= l_c0 * l_bI; r1 -= l_c1 * l_bI; r2 -= l_c2 * l_bI;
+        }
+      }
+      m0 = r0; m1 = r1; m2 = r2;
+    }
+  } else
   if (nd >= 0) {
     const int i = nd, sc = sec_of(i);
     elec = sc != 1; jx = sc == 0 ? i : i - NS;
