@@ -106,3 +106,34 @@ def test_simulate_vector_tf_and_failed_run_leave_sol_untouched(emu_model, pkg):
         assert False
     except NotImplementedError:
         pass
+
+
+def test_closure_tracer_programs(pkg, emu_model):
+    """petlion.jl_amd/closures.py: a closure traced into the C ABI's postfix program evaluates to the closure's own value (host-side interpreter), respects the 16-slot stack,
+    and refuses what cannot be traced"""
+    import math
+    cl = pkg.closures
+    p = emu_model
+    th = p.theta_vector()
+    rng = np.random.default_rng(3)
+    Y = rng.random(p.N.tot) + 0.5; YP = rng.standard_normal(p.N.tot)
+    ps = p.ind["Φ_s"]
+    cases = [(lambda t: 1.5 * cl.sin(t) + cl.cos(2 * t) ** 2, lambda t: 1.5 * math.sin(t) + math.cos(2 * t) ** 2),
+             (lambda t, q: q.θ["t₊"] * t / (1 + cl.exp(-t)), lambda t: th[p.θ_keys.index("t₊")] * t / (1 + math.exp(-t))),
+             (lambda t: cl.where(t < 3, 1.0, cl.where(t >= 5, -2.0, cl.sqrt(t))), lambda t: 1.0 if t < 3 else (-2.0 if t >= 5 else math.sqrt(t))),
+             (lambda t, Y_, q: -cl.minimum(1.0, cl.maximum(0.05, (cl.calc_V(Y_, q) - 0.1) * 2.0)), lambda t: -min(1.0, max(0.05, (Y[ps.start] - Y[ps.stop - 1] - 0.1) * 2.0))),
+             (lambda t, Y_, YP_, q: abs(YP_[3]) * cl.tanh(Y_[-1]) - cl.log(Y_[0] + t), lambda t: abs(YP[3]) * math.tanh(Y[-1]) - math.log(Y[0] + t))]
+    for f, ref in cases:
+        prog = cl.trace(f, p)
+        for t in (0.0, 2.5, 4.0, 7.0):
+            assert abs(cl.evaluate(prog, t, Y, YP, th) - ref(t)) <= 1e-14 * max(1.0, abs(ref(t)))
+    deep = lambda t: t + (t + (t + (t + (t + (t + (t + (t + (t + (t + (t + (t + (t + (t + (t + (t + (t + t))))))))))))))))     # right-nested: 18 operands on the stack
+    with pytest.raises(cl.TraceError, match="stack"):
+        cl.trace(deep, p)
+    assert cl.trace(lambda t: ((((t + t) + t) + t) + t), p)[0].size == 9                                                   # left-nested sums need two slots
+    with pytest.raises(cl.TraceError):
+        cl.trace(lambda t: 1.0 if t < 1 else 2.0, p)
+    with pytest.raises(cl.TraceError):
+        cl.trace(lambda t, q: q.θ["I1C"] * t, p)
+    with pytest.raises(cl.TraceError):
+        cl.trace(lambda a, b, c, d, e: a, p)
