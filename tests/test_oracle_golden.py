@@ -190,3 +190,21 @@ def test_function_inputs_notebook(O):
         assert abs(r["SOC"] - k["SOC_end"]) < 1e-4
         P = r["I"] * G["I1C_LCO"]["value"] * r["V"]     # calc_P = I * I1C * V (scalar_residual.jl:87)
         assert abs(P - k["P_end"]) <= k["tol"]["P_rel"] * k["P_end"], (key, P)
+
+
+def test_function_inputs_notebook_as_closures(O):
+    """the same notebook cases with the input given as the closure itself -- `I_fun1(t) = t < 100 ? 1 : 0.5`, `I_ramp(t, p) = p.θ[:ramp_val] * t` -- in the postfix-program form of
+    the C ABI (ORC_VAL_EXPR): the oracle's closure path reproduces the reference's printed results like its table path does"""
+    th = O.theta_vector("lco_iso")
+    OP = dict(CONST=0, T=1, MUL=7, LT=19, SELECT=23)
+    step = ([OP["T"], OP["CONST"], OP["LT"], OP["CONST"], OP["CONST"], OP["SELECT"]], [0, 100.0, 0, 1.0, 0.5, 0])            # ifelse(t < 100, 1, 0.5)
+    ramp = lambda slope: ([OP["CONST"], OP["T"], OP["MUL"]], [slope, 0, 0])                                                    # ramp_val * t
+    for key, prog in (("func_step_no_tdiscon", step), ("func_step_tdiscon", step), ("func_ramp_100", ramp(1 / 100)), ("func_ramp_10", ramp(1 / 10))):
+        k = G["runs"][key]
+        ro = O.simulate("lco_iso", th, k["SOC0"], [dict(mode=O.MODE_I, expr=prog, tf=k["tf"])], opts=O.default_opts(tdiscon=k["tdiscon"]))
+        r = ro["runs"][0]
+        assert r["flag"] == k["flag"] and abs(r["t_end"] - k["t_end"]) < 1e-9
+        assert abs(r["I"] - k["I_end"]) < 1e-12 and abs(r["V"] - k["V_end"]) < k["tol"]["V_abs"], (key, r["V"])
+        assert abs(r["SOC"] - k["SOC_end"]) < 1e-4
+        P = r["I"] * G["I1C_LCO"]["value"] * r["V"]
+        assert abs(P - k["P_end"]) <= k["tol"]["P_rel"] * k["P_end"], (key, P)
