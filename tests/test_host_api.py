@@ -137,3 +137,17 @@ def test_closure_tracer_programs(pkg, emu_model):
         cl.trace(lambda t, q: q.θ["I1C"] * t, p)
     with pytest.raises(cl.TraceError):
         cl.trace(lambda a, b, c, d, e: a, p)
+
+
+def test_register_grid_library_refusals(pkg, emu_model):
+    """plh_register_grid_library: a missing file and a library that is not a grid library are refused with a message, registering the same grid library twice is a no-op"""
+    import build_emu
+    lib = emu_model._lib
+    assert lib.plh_register_grid_library(b"/nonexistent/libplh_g1.so") != 0 and b"dlopen" in lib.plh_last_error()
+    assert lib.plh_register_grid_library(os.fsencode(lib._name)) != 0 and b"not a grid library" in lib.plh_last_error()
+    gl = os.fsencode(build_emu.build_grid((12, 7, 9, 11, 10, 10), [0]))
+    assert lib.plh_register_grid_library(gl) == 0 and lib.plh_register_grid_library(gl) == 0
+    p = pkg.petlion(pkg.LCO, N_p=12, N_s=7, N_n=9, N_r_p=11, N_r_n=11, _lib_path=lib._name, _grid_lib=False)      # already registered: found without registering again
+    assert p.N.tot == 330
+    with pytest.raises(pkg._capi.PetlionHipError, match="not instantiated|discretisation"):                          # a variant the grid library does not hold
+        pkg.petlion(pkg.NMC, N_p=12, N_s=7, N_n=9, N_r_p=11, N_r_n=11, _lib_path=lib._name, _grid_lib=False)
