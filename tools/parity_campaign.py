@@ -103,3 +103,8 @@ IDA's h0 = 0.5/||y'|| and the whole step grid; legs that start from a :hold set 
 their step sequences decorrelate -- in the oracle against itself exactly as in the device against the oracle.  The linear solver is NOT the source: against an extended-
 precision solution the structured device solve is as accurate as the sparse LU or better (profiles/r02_solver_accuracy.md), and refining both solves changes nothing
 (tests/test_gpu_parity.py::test_c4_refinement_mode).  At equal TIME the voltage curves agree to the column "max V(t) dev." -- inside reltol = 1e-3.""")
+print("""
+Oracle pinning (say it with every report): the oracle is a restatement, not the reference.  It is pinned on the reference's notebook outputs for LCO isothermal and LCO thermal
+(tests/test_oracle_golden.py: I1C bit-exact, V(t=0) 1e-11, ten run summaries 1e-3 .. 1e-5, the function-input cases through both the table and the closure path); the NMC and
+SEI rows of this table (all of config C5) compare the device with an oracle that has NO reference vector behind it -- equations restated from the source only.
+""")
