@@ -40,6 +40,7 @@ struct Opts
     maxiters::Cint; check_bounds::Cint; interp_final::Cint; max_order::Cint; jac_every_step::Cint; init_step::Cdouble
     n_tdiscon::Cint; tdiscon::Ptr{Cdouble}     # host array of any length (the caller keeps it alive across the call)
     refine::Cint                                # iterative-refinement steps per linear solve (parity mode), 0 = off
+    n_tstops::Cint; tstops::Ptr{Cdouble}       # opts.tstops (run-local times the integrator must hit; src/model_evaluation.jl:292-294), host array
 end
 struct RunInfo
     flag::Cint; iterations::Cint; t_end::Cdouble; V::Cdouble; I::Cdouble; SOC::Cdouble; T_avg::Cdouble
@@ -175,9 +176,9 @@ function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.o
     n = size(Θ, 1)
     runs = [make_run(p, s) for s in protocol]
     o = p.opts
-    td = Float64.(o.tdiscon)
+    td = Float64.(o.tdiscon); ts = Float64.(o.tstops)
     opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0,
-                    length(td), isempty(td) ? C_NULL : pointer(td), refine))
+                    length(td), isempty(td) ? C_NULL : pointer(td), refine, length(ts), isempty(ts) ? C_NULL : pointer(ts)))
     Θt = permutedims(Θ)                                   # column-major n_theta × n_cells == row-major cells
     soc = SOC isa Number ? fill(Float64(SOC), n) : Vector{Float64}(SOC)
     t = zeros(max_pts, n); V = similar(t); I = similar(t); S = similar(t)
@@ -187,7 +188,7 @@ function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.o
     keep_Y = any(x -> x ∈ (:all, :Y, :c_e, :c_s_avg, :T, :film, :SOH, :j, :j_s, :Φ_e, :Φ_s), outs)     # solution_states_logic, src/outputs.jl:107-131
     Tavg = p.numerics.temperature ? zeros(max_pts, n) : Float64[]
     Yall = keep_Y ? zeros(m.N, max_pts, n) : Float64[]                  # sol.Y of every cell: Yall[:, k, i] = state after step k of cell i
-    GC.@preserve t V I S npts Y YP info cnt Tavg Yall td begin
+    GC.@preserve t V I S npts Y YP info cnt Tavg Yall td ts begin
         out = Ref(Outputs(max_pts, pointer(t), pointer(V), pointer(I), pointer(S), isempty(Tavg) ? C_NULL : pointer(Tavg), pointer(npts), pointer(Y), pointer(YP),
                           pointer(info), pointer(cnt), keep_Y ? pointer(Yall) : C_NULL))
         rc = ccall((:plh_integrate, lib), Cint,
@@ -266,14 +267,14 @@ comm_rank(c::Comm) = ccall((:plh_comm_rank, lib), Cint, (Ptr{Cvoid},), c.h)
 comm_size(c::Comm) = ccall((:plh_comm_size, lib), Cint, (Ptr{Cvoid},), c.h)
 function ensemble_run(c::Comm, m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.opts.SOC, partition = :block, n_cells = size(Θ, 1), refine = 0)
     runs = [make_run(p, s) for s in protocol]
-    o = p.opts; td = Float64.(o.tdiscon)
+    o = p.opts; td = Float64.(o.tdiscon); ts = Float64.(o.tstops)
     root = comm_rank(c) == 0
     Θt = root ? permutedims(Θ) : zeros(0, 0)
     soc = root ? (SOC isa Number ? fill(Float64(SOC), n_cells) : Vector{Float64}(SOC)) : Float64[]
     info = Matrix{RunInfo}(undef, length(runs), root ? n_cells : 0); cnt = Vector{Counters}(undef, root ? n_cells : 0); ms = zeros(comm_size(c))
-    GC.@preserve td Θt soc info cnt ms begin
+    GC.@preserve td ts Θt soc info cnt ms begin
         opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0,
-                        length(td), isempty(td) ? C_NULL : pointer(td), refine))
+                        length(td), isempty(td) ? C_NULL : pointer(td), refine, length(ts), isempty(ts) ? C_NULL : pointer(ts)))
         check(ccall((:plh_ensemble_run, lib), Cint,
                     (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Run}, Ref{Opts}, Cint, Ptr{RunInfo}, Ptr{Counters}, Ptr{Cdouble}, Ptr{Cdouble}),
                     c.h, m.h, n_cells, root ? pointer(Θt) : C_NULL, root ? pointer(soc) : C_NULL, length(runs), runs, opts, partition === :cyclic ? 1 : 0,

@@ -166,6 +166,8 @@ typedef struct {
   int refine;                                        /* 0 (default): plain structured solves.  n > 0: n steps of iterative refinement of every linear solve
                                                         (init Newton and corrector) against the factored matrix -- the parity mode: the solution no longer
                                                         depends on the elimination order (structured here, KLU's in the reference) beyond ~1e-13 */
+  int n_tstops; const double* tstops;                /* opts.tstops (src/structures.jl:278, model_evaluation.jl:292-294): times, in run-local time, the integrator must hit
+                                                        exactly (a saved point lands on each); any length, HOST array staged like tdiscon; applies to every run of the protocol */
 } plh_opts;
 
 /* per-cell, per-run summary == run_info + the printed summary (src/structures.jl:40-44, 678-746) */
@@ -279,7 +281,9 @@ int plh_synchronize(plh_model_t m, void* stream);
  *   cells[r n/G, (r+1) n/G) or cyclic cell mod G, which evens out step-count variance in randomised sweeps), 3. plh_integrate of the local shard on the
  *   rank's GPU (no collective in the data path: cells are independent for the whole trajectory), 4. gather of the per-cell summaries (run_info,
  *   counters, optionally the final states) to rank 0 in the caller's cell order.  rank_ms[n_ranks] (rank 0, may be NULL) receives every rank's
- *   integrate-kernel time: the load-imbalance figure of a randomised sweep. */
+ *   integrate-kernel time: the load-imbalance figure of a randomised sweep.
+ * Per-cell protocol arrays (plh_run.value_cell / tf_cell) belong to the protocol: n_cells_total entries indexed by the GLOBAL cell, the same on every rank; each rank
+ * integrates with its own shard of them.  An error on any rank (arguments, staging, its plh_integrate) is agreed on between the phases: every rank returns non-zero. */
 typedef struct plh_comm_s* plh_comm_t;
 #define PLH_PART_BLOCK 0
 #define PLH_PART_CYCLIC 1

@@ -360,6 +360,7 @@ typedef struct {   /* reference options_simulation, src/structures.jl:266-285 */
      order, products formed before or after a difference); the spread of the results over a few seeds is the reproducibility floor any second fp64
      implementation of the reference algorithm sits in. */
   double fd_perturb; int perturb_seed;
+  int n_tstops; const double* tstops;     /* opts.tstops: user stop times in run-local time, appended to the integrator's tstops (model_evaluation.jl:292-294) */
 } orc_opts;
 
 typedef struct {
@@ -997,7 +998,8 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
     if (ierr != 0) { ri->flag = ierr; ri->t_end = t_global; rc = 1; break; }
     ida_reinit(Ip, e, opts, Y, YP);
     /* tstops (postfix_integrator!, model_evaluation.jl:288-310): {1.0 if continuation} U {tf} */
-    double* tstops = (double*)malloc((opts->n_tdiscon + 4) * sizeof(double)); int nts = 0, its = 0;
+    double* tstops = (double*)malloc((opts->n_tdiscon + opts->n_tstops + 4) * sizeof(double)); int nts = 0, its = 0;
+    for (int q = 0; q < opts->n_tstops; q++) tstops[nts++] = opts->tstops[q];                          /* model_evaluation.jl:292-294 */
     for (int q = 0; q < opts->n_tdiscon; q++) tstops[nts++] = opts->tdiscon[q] - opts->reltol / 2;     /* model_evaluation.jl:295-297 */
     if (!new_run) tstops[nts++] = 1.0;
     tstops[nts++] = run->tf;
@@ -1045,6 +1047,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       }
     }
     /* --- exit_simulation! / interp_final_points! (model_evaluation.jl:335-382) --- */
+    free(tstops);
     double t_end = t + t0;
     if (flag > 0 && opts->interp_final && t > 1.0) {
       double fr = pv.frac;

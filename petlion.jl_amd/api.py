@@ -117,11 +117,17 @@ class Model:
         return cp, ri
 
 
-def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_r_n=10, temperature=False,
+def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_r_n=10, temperature=None,
             solid_diffusion="Fickian", Fickian_method="finite_difference", aging=False, jacobian="symbolic", SOC=1.0,
             thermodynamic_factor="linear", rxn_p="BV", rxn_n="BV", precision="f64", device=-1, waves_per_cell=1, _lib_path=None, _grid_lib=None):
     """petlion(cathode; kwargs...) -- reference src/params.jl:119-174.  `jacobian` is accepted and ignored (the device
     Jacobian is hand-derived); unsupported structural options raise."""
+    if temperature is None:
+        # the reference's LGM50 system defaults to temperature = true (src/params.jl, system_LGM50_NMC_LiC6 kwargs); only its isothermal variant is instantiated on the
+        # device, so the choice must be explicit there instead of silently different physics
+        if cathode == NMC_LGM50:
+            raise NotImplementedError("petlion(NMC_LGM50): the reference default is temperature=true, which is not instantiated on the device; pass temperature=False explicitly")
+        temperature = False
     if solid_diffusion not in ("Fickian", "quadratic", "polynomial") or (solid_diffusion == "Fickian" and Fickian_method != "finite_difference"):
         raise NotImplementedError("solid diffusion: Fickian (finite_difference), quadratic and polynomial are built; the BETA spectral method is not (SURVEY.md 8f)")
     if thermodynamic_factor not in ("linear", "nonlinear") or rxn_p not in ("BV", "MHC") or rxn_n != rxn_p:
@@ -193,8 +199,11 @@ def _opts_struct(o):
     td = np.ascontiguousarray(list(getattr(o, "tdiscon", []) or []), dtype=np.float64)
     s.n_tdiscon = td.size
     s.tdiscon = td.ctypes.data_as(C.POINTER(C.c_double)) if td.size else None
-    s._keep = td                                     # the array must outlive the struct
     s.refine = int(getattr(o, "refine", 0))
+    ts = np.ascontiguousarray(list(getattr(o, "tstops", []) or []), dtype=np.float64)      # opts.tstops (run-local times; model_evaluation.jl:292-294)
+    s.n_tstops = ts.size
+    s.tstops = ts.ctypes.data_as(C.POINTER(C.c_double)) if ts.size else None
+    s._keep = (td, ts)                               # the arrays must outlive the struct
     return s
 
 
@@ -332,8 +341,6 @@ def simulate(p, tf=1e6, *, sol=None, SOC=None, **kw):
             raise TypeError("unknown keyword %r" % k)
         setattr(o, k, v)
     (name, inp), = inputs.items()
-    if len(getattr(o, "tstops", []) or []) > 0:
-        raise NotImplementedError("tstops: the device places tstops at tf, at 1 s of a continuation run and at tdiscon - reltol/2 (model_evaluation.jl:288-310); user tstops are not wired through")
     # simulate(p, tf::Vector): run to tf[end], then post-interpolate onto tf (model_evaluation.jl:79-80, 148-149)
     tf_interp = None
     if isinstance(tf, (list, tuple, np.ndarray)):

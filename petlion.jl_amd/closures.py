@@ -59,6 +59,11 @@ class X:
     def __le__(self, o): return self._bin("LE", o)
     def __gt__(self, o): return self._bin("GT", o)
     def __ge__(self, o): return self._bin("GE", o)
+    # == / != as (a <= b) * (a >= b) and 1 - that (no EQ opcode is needed); without these Python falls back to identity comparison and the closure would be traced
+    # with a CONSTANT branch
+    def __eq__(self, o): return self._bin("LE", o)._bin("MUL", self._bin("GE", o))
+    def __ne__(self, o): return X.lift(1.0)._bin("SUB", self.__eq__(o))
+    __hash__ = object.__hash__
 
     def __bool__(self):
         raise TraceError("the closure branches on a traced value (if / and / or / min() / max() on t, Y, ...): write the branch as where(cond, a, b), or pass the input as a table")

@@ -494,11 +494,17 @@ template <class M>
 PL_DEV double run_input(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP) {
   return r.value_kind == PLH_VAL_EXPR ? expr_eval(S, r, t, Y, YP) : tab_eval(r, t);
 }
-// next tstop after run-local time t: the sorted set {tdiscon - reltol/2} U {1.0 if continuation} U {tf} of postfix_integrator!
+// next tstop after run-local time t: the sorted set opts.tstops U {tdiscon - reltol/2} U {1.0 if continuation} U {tf} of postfix_integrator!
 // (model_evaluation.jl:288-310) walked without storing it
 PL_DEV double next_tstop(const plh_opts& o, double t, bool continuation, double tf) {
   double best = tf;
   if (continuation && 1.0 > t && 1.0 < best) best = 1.0;
+  if (o.n_tstops > 0) {                                                // user tstops (model_evaluation.jl:292-294; sorted device copy): first entry > max(t, 0)
+    const double lim = t > 0.0 ? t : 0.0;
+    int lo = -1, hi = o.n_tstops;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (o.tstops[mid] > lim) hi = mid; else lo = mid; }
+    if (hi < o.n_tstops && o.tstops[hi] < best) best = o.tstops[hi];
+  }
   if (o.n_tdiscon > 0) {                                               // o.tdiscon is sorted ascending (plh_integrate stages a sorted copy): first entry with tdiscon - reltol/2 > max(t, 0)
     const double lim = (t > 0.0 ? t : 0.0) + o.reltol / 2;
     int lo = -1, hi = o.n_tdiscon;

@@ -139,7 +139,9 @@ struct StreamCtx {
   double* scratch = nullptr; size_t scratch_cells = 0;     // [n_cells][2][N]: previous accepted point of every cell (back-interpolation)
   plh_run* d_runs = nullptr; int runs_cap = 0;
   std::vector<plh_run> runs_on_device;                       // the protocol currently in d_runs (a repeated launch with the same protocol uploads nothing and does not synchronise)
-  double* d_tdiscon = nullptr; int tdiscon_cap = 0; std::vector<double> tdiscon_on_device;
+  // sorted device copies of opts.tdiscon / opts.tstops, kept per stream (re-uploaded only when they change)
+  struct TimeList { double* d = nullptr; int cap = 0; std::vector<double> on_device; };
+  TimeList tdiscon, tstops;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
   std::vector<void*> pending;                               // staging blocks of PLH_HOST_ASYNC launches: released by plh_synchronize
 };
@@ -404,7 +406,8 @@ void plh_model_destroy(plh_model_t m) {
   for (StreamCtx* c : m->streams) {
     if (c->scratch) hipFree(c->scratch);
     if (c->d_runs) hipFree(c->d_runs);
-    if (c->d_tdiscon) hipFree(c->d_tdiscon);
+    if (c->tdiscon.d) hipFree(c->tdiscon.d);
+    if (c->tstops.d) hipFree(c->tstops.d);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     delete c;
@@ -459,8 +462,9 @@ int plh_abi_layout(int* out, int cap) {
   PL_F(plh_bounds, I_max) PL_F(plh_bounds, I_min) PL_F(plh_bounds, eta_plating_min) PL_F(plh_bounds, c_e_min) PL_F(plh_bounds, dfilm_max)
   PL_S(plh_run, 10) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, tab_t)
   PL_F(plh_run, tab_v) PL_F(plh_run, value_cell) PL_F(plh_run, tf_cell)
-  PL_S(plh_opts, 13) PL_F(plh_opts, abstol) PL_F(plh_opts, reltol) PL_F(plh_opts, abstol_init) PL_F(plh_opts, reltol_init) PL_F(plh_opts, maxiters) PL_F(plh_opts, check_bounds)
+  PL_S(plh_opts, 15) PL_F(plh_opts, abstol) PL_F(plh_opts, reltol) PL_F(plh_opts, abstol_init) PL_F(plh_opts, reltol_init) PL_F(plh_opts, maxiters) PL_F(plh_opts, check_bounds)
   PL_F(plh_opts, interp_final) PL_F(plh_opts, max_order) PL_F(plh_opts, jac_every_step) PL_F(plh_opts, init_step) PL_F(plh_opts, n_tdiscon) PL_F(plh_opts, tdiscon) PL_F(plh_opts, refine)
+  PL_F(plh_opts, n_tstops) PL_F(plh_opts, tstops)
   PL_S(plh_run_info, 7) PL_F(plh_run_info, flag) PL_F(plh_run_info, iterations) PL_F(plh_run_info, t_end) PL_F(plh_run_info, V) PL_F(plh_run_info, I) PL_F(plh_run_info, SOC)
   PL_F(plh_run_info, T_avg)
   PL_S(plh_counters, 11) PL_F(plh_counters, n_steps) PL_F(plh_counters, n_res) PL_F(plh_counters, n_jac) PL_F(plh_counters, n_fact) PL_F(plh_counters, n_solve)
@@ -594,6 +598,8 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   if (out->max_pts < 0) return fail(PLH_E_ARG, "max_pts");
   if ((Y_init == nullptr) != (t_init == nullptr)) return fail(PLH_E_ARG, "Y_init and t_init must be given together");
   if (opts->n_tdiscon < 0 || (opts->n_tdiscon > 0 && !opts->tdiscon)) return fail(PLH_E_ARG, "tdiscon");
+  if (opts->n_tstops < 0 || (opts->n_tstops > 0 && !opts->tstops)) return fail(PLH_E_ARG, "tstops");
+  for (int k = 0; k < opts->n_tstops; k++) if (!(opts->tstops[k] == opts->tstops[k])) return fail(PLH_E_ARG, "tstops must not contain NaN");
   if (opts->refine < 0 || opts->refine > 4) return fail(PLH_E_ARG, "refine must be 0 .. 4");
   DeviceGuard guard(m->device);
   Stage s(m, kind, stream);
@@ -608,19 +614,23 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   a.tb = m->d_tb; a.n_cells = n; a.n_runs = n_runs; a.opts = *opts; a.scratch = cx.scratch;
   a.theta = s.in(theta, (size_t)n * m->P); a.SOC0 = s.in(SOC0, n);
   a.Y_init = s.in(Y_init, (size_t)n * m->N); a.t_init = s.in(t_init, n);
-  // tdiscon: a sorted device copy, kept per stream (re-uploaded only when it changes)
-  a.opts.tdiscon = nullptr;
-  if (opts->n_tdiscon > 0) {
-    std::vector<double> td(opts->tdiscon, opts->tdiscon + opts->n_tdiscon);
+  // tdiscon / tstops: sorted device copies, kept per stream (re-uploaded only when they change)
+  auto time_list = [&](StreamCtx::TimeList& tl, const double* src, int cnt, const double** dst) -> int {
+    *dst = nullptr;
+    if (cnt <= 0) return 0;
+    std::vector<double> td(src, src + cnt);
     std::sort(td.begin(), td.end());
-    if (td != cx.tdiscon_on_device) {
+    if (td != tl.on_device) {
       HIPCHK(hipStreamSynchronize(cx.st));
-      if (cx.tdiscon_cap < (int)td.size()) { if (cx.d_tdiscon) hipFree(cx.d_tdiscon); cx.d_tdiscon = nullptr; cx.tdiscon_cap = 0; HIPCHK(hipMalloc((void**)&cx.d_tdiscon, td.size() * sizeof(double))); cx.tdiscon_cap = (int)td.size(); }
-      HIPCHK(hipMemcpy(cx.d_tdiscon, td.data(), td.size() * sizeof(double), hipMemcpyHostToDevice));
-      cx.tdiscon_on_device = td;
+      if (tl.cap < (int)td.size()) { if (tl.d) hipFree(tl.d); tl.d = nullptr; tl.cap = 0; HIPCHK(hipMalloc((void**)&tl.d, td.size() * sizeof(double))); tl.cap = (int)td.size(); }
+      HIPCHK(hipMemcpy(tl.d, td.data(), td.size() * sizeof(double), hipMemcpyHostToDevice));
+      tl.on_device = td;
     }
-    a.opts.tdiscon = cx.d_tdiscon;
-  }
+    *dst = tl.d;
+    return 0;
+  };
+  if (int rc = time_list(cx.tdiscon, opts->tdiscon, opts->n_tdiscon, &a.opts.tdiscon)) return rc;
+  if (int rc = time_list(cx.tstops, opts->tstops, opts->n_tstops, &a.opts.tstops)) return rc;
   // the protocol is always host memory
   if (cx.runs_cap < n_runs) {
     if (cx.d_runs) { HIPCHK(hipStreamSynchronize(cx.st)); hipFree(cx.d_runs); cx.d_runs = nullptr; cx.runs_cap = 0; cx.runs_on_device.clear(); }
@@ -655,7 +665,7 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
   CHECK_STAGE(s);                                                     // a failed staging allocation must never reach the kernel as a NULL ("not requested") output
   hipEventRecord(cx.ev0, s.st);
-  bool general = opts->n_tdiscon > 0 || out->Y_all || opts->refine > 0;     // the general instantiation also carries the per-step state dump (outputs = :all) and the refinement mode
+  bool general = opts->n_tdiscon > 0 || opts->n_tstops > 0 || out->Y_all || opts->refine > 0;     // the general instantiation also carries the per-step state dump (outputs = :all) and the refinement mode
   for (int r = 0; r < n_runs; r++) general = general || runs[r].value_kind == PLH_VAL_TABLE || runs[r].value_kind == PLH_VAL_EXPR;
   m->ops->integrate(s.st, a, general);
   hipEventRecord(cx.ev1, s.st);
@@ -765,11 +775,10 @@ static inline long long shard_cell(long long n, int G, int r, long long k, int p
 int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* theta, const double* SOC0, int n_runs, const plh_run* runs,
                      const plh_opts* opts, int partition, plh_run_info* run_info, plh_counters* counters, double* Y_final, double* rank_ms) {
   CHECK_MODEL(m);
+  // (misuse that every rank sees alike -- all ranks pass the same shape, protocol and options -- returns at once; everything that can differ between ranks is agreed on below)
   if (!c || n_total <= 0 || n_runs <= 0 || !runs || !opts) return fail(PLH_E_ARG, "bad argument");
   if (partition != PLH_PART_BLOCK && partition != PLH_PART_CYCLIC) return fail(PLH_E_ARG, "partition must be PLH_PART_BLOCK or PLH_PART_CYCLIC");
   const int G = c->n_ranks, me = c->rank; const bool root = me == 0;
-  if (root && (!theta || !SOC0 || !run_info)) return fail(PLH_E_ARG, "rank 0 needs theta, SOC0 and run_info");
-  if (m->device != c->device) return fail(PLH_E_ARG, "the model handle and the communicator must be bound to the same device");
   DeviceGuard guard(m->device);
   const int P = m->P, N = m->N;
   const long long cnt = shard_count(n_total, G, me);
@@ -782,6 +791,7 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
 #endif
   // device blocks (cached in the handle): root holds the whole permuted ensemble, the others their shard
   Stage s(m, PLH_DEVICE, st);
+  struct SyncFirst { hipStream_t st; ~SyncFirst() { hipStreamSynchronize(st); } } sync_first{st};     // (destroyed before `s`: no staging block is released while a collective that targets it is still enqueued)
   const size_t rows = root ? (size_t)n_total : (size_t)(cnt > 0 ? cnt : 1);
   double* d_th = (double*)s.dev_block(rows * P * sizeof(double));
   double* d_soc = (double*)s.dev_block(rows * sizeof(double));
@@ -790,7 +800,26 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
   double* d_Y = (double*)s.dev_block(rows * N * sizeof(double));
   long long* d_meta = (long long*)s.dev_block(8 * sizeof(long long));
   double* d_ms = (double*)s.dev_block((size_t)G * sizeof(double));
-  CHECK_STAGE(s);
+  // A return that only ONE rank takes would leave the others blocked in the next ncclSend / ncclRecv: before every phase the ranks agree on a status (all-reduce of the
+  // most negative return code) and leave together.
+  auto agree = [&](int rc, const char* where) -> int {
+#ifndef PL_WAVE_EMU
+    if (c->comm && G > 1 && d_meta) {
+      int all = rc;
+      if (hipMemcpy(d_meta + 4, &all, sizeof(int), hipMemcpyHostToDevice) != hipSuccess || ncclAllReduce(d_meta + 4, d_meta + 4, 1, ncclInt, ncclMin, c->comm, st) != ncclSuccess ||
+          hipStreamSynchronize(st) != hipSuccess || hipMemcpy(&all, d_meta + 4, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        return rc != 0 ? rc : fail(PLH_E_HIP, std::string("plh_ensemble_run: status exchange failed (") + where + ")");
+      if (rc == 0 && all != 0) return fail(all, std::string("plh_ensemble_run: another rank failed (") + where + "); see its plh_last_error()");
+    }
+#endif
+    (void)where;
+    return rc;
+  };
+  int rc0 = 0;
+  if (s.bad) rc0 = fail(PLH_E_HIP, s.why);
+  else if (root && (!theta || !SOC0 || !run_info)) rc0 = fail(PLH_E_ARG, "rank 0 needs theta, SOC0 and run_info");
+  else if (m->device != c->device) rc0 = fail(PLH_E_ARG, "the model handle and the communicator must be bound to the same device");
+  if (int rc = agree(rc0, "arguments / staging")) return rc;
   // 1. shape check: everybody must describe the same ensemble (ncclBroadcast from rank 0)
   long long meta[4] = {n_total, n_runs, partition, P};
 #ifndef PL_WAVE_EMU
@@ -800,9 +829,24 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
     NCCLCHK(ncclBroadcast(d_meta, d_meta, 4, ncclInt64, 0, c->comm, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMemcpy(root_meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost));
-    if (memcmp(root_meta, meta, sizeof(meta)) != 0) return fail(PLH_E_ARG, "plh_ensemble_run: this rank's (n_cells_total, n_runs, partition, model) differ from rank 0's");
+    rc0 = memcmp(root_meta, meta, sizeof(meta)) != 0 ? fail(PLH_E_ARG, "plh_ensemble_run: this rank's (n_cells_total, n_runs, partition, model) differ from rank 0's") : 0;
+    if (int rc = agree(rc0, "ensemble shape")) return rc;
   }
 #endif
+  // per-cell protocol arrays (plh_run.value_cell / tf_cell) are indexed by the GLOBAL cell: n_cells_total entries, the same on every rank like the rest of the protocol.
+  // plh_integrate indexes them by the LOCAL cell, so each rank hands it its own shard of them, in shard order.
+  std::vector<plh_run> lruns(runs, runs + n_runs);
+  std::vector<std::vector<double>> shard_vals;
+  for (int r = 0; r < n_runs; r++) {
+    for (int which = 0; which < 2; which++) {
+      const double* src = which == 0 ? runs[r].value_cell : runs[r].tf_cell;
+      if (!src) continue;
+      std::vector<double> v((size_t)(cnt > 0 ? cnt : 1));
+      for (long long k = 0; k < cnt; k++) v[k] = src[shard_cell(n_total, G, me, k, partition)];
+      shard_vals.push_back(std::move(v));
+      (which == 0 ? lruns[r].value_cell : lruns[r].tf_cell) = shard_vals.back().data();
+    }
+  }
   // 2. scatter of the parameter rows (rank 0 permutes them into rank-contiguous order first)
   if (root) {
     std::vector<double> th((size_t)n_total * P), soc(n_total);
@@ -827,10 +871,10 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
   if (cnt > 0) {
     plh_outputs o; memset(&o, 0, sizeof(o));
     o.max_pts = 0; o.run_info = d_info; o.counters = d_cnt; o.Y_final = d_Y;
-    const int rc = plh_integrate(m, (int)cnt, d_th, d_soc, nullptr, nullptr, n_runs, runs, opts, &o, PLH_DEVICE, st);
-    if (rc != 0) return rc;
-    ms = plh_last_kernel_ms(m);
+    rc0 = plh_integrate(m, (int)cnt, d_th, d_soc, nullptr, nullptr, n_runs, lruns.data(), opts, &o, PLH_DEVICE, st);
+    if (rc0 == 0) ms = plh_last_kernel_ms(m);
   }
+  if (int rc = agree(rc0, "plh_integrate")) return rc;
   // 4. gather of the per-cell summaries to rank 0 (rank-contiguous order), then back to the caller's cell order
   HIPCHK(hipMemcpy(d_ms + me, &ms, sizeof(double), hipMemcpyHostToDevice));
 #ifndef PL_WAVE_EMU

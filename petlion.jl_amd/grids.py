@@ -77,14 +77,22 @@ def library(grid, variants, force=False):
 
 
 def _library_locked(grid, variants, force, tag, defs):
-    lib = os.path.join(GRID_DIR, "libplh_%s.so" % tag)
-    manifest = os.path.join(GRID_DIR, "libplh_%s.json" % tag)
-    have = []
-    if os.path.exists(lib) and os.path.exists(manifest) and os.path.getmtime(lib) >= _sources_mtime():
+    # The file name carries the variant ids it holds: a library is never rebuilt in place under a path that plh_register_grid_library may already have dlopen'ed in this
+    # process (registering a known path is a no-op) -- a second model on the same grid with another variant gets a NEW file holding the union, registered next to the first.
+    import glob
+    fresh, have_best = _sources_mtime(), []
+    for manifest in sorted(glob.glob(os.path.join(GRID_DIR, "libplh_%s_v*.json" % tag))):
+        lib = manifest[:-5] + ".so"
+        if not os.path.exists(lib) or os.path.getmtime(lib) < fresh:
+            continue
         have = json.load(open(manifest))["variants"]
-    if not force and set(variants) <= set(have):
-        return lib
-    allv = sorted(set(have) | set(variants))
+        if not force and set(variants) <= set(have):
+            return lib
+        if len(have) > len(have_best):
+            have_best = have
+    allv = sorted(set(have_best) | set(variants))
+    stem = os.path.join(GRID_DIR, "libplh_%s_v%s" % (tag, "_".join(str(v) for v in allv)))
+    lib, manifest = stem + ".so", stem + ".json"
     src = os.path.join(CSRC, "variant_tu.hip")
     common = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-Wno-pass-failed"] + defs
     jobs, objs = [], []
@@ -97,7 +105,9 @@ def _library_locked(grid, variants, force, tag, defs):
     jobs.append(subprocess.Popen(common + ["-O2", "-DPL_GRID_GLUE", "-c", src, "-o", glue]))
     if any(j.wait() for j in jobs):
         raise RuntimeError("hipcc failed building the kernels of discretisation %r" % (grid,))
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", glue] + objs + ["-o", lib])
+    tmp = lib + ".tmp%d" % os.getpid()                      # (a forced rebuild replaces the file atomically: a process that has the old one mapped keeps its inode)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", glue] + objs + ["-o", tmp])
+    os.replace(tmp, lib)
     json.dump({"grid": list(grid), "variants": allv}, open(manifest, "w"))
     for o in objs + [glue]:
         os.remove(o)

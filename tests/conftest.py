@@ -88,7 +88,7 @@ def hip_model_thermal(pkg, hip_model):
 
 
 F4_OPTIONS = {"quad": dict(solid_diffusion="quadratic"), "poly": dict(solid_diffusion="polynomial"), "nu": dict(thermodynamic_factor="nonlinear"),
-              "mhc": dict(rxn_p="MHC", rxn_n="MHC"), "lgm50": dict(cathode="LGM50")}
+              "mhc": dict(rxn_p="MHC", rxn_n="MHC"), "lgm50": dict(cathode="LGM50", temperature=False)}
 
 
 @pytest.fixture(scope="session")

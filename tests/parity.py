@@ -293,3 +293,92 @@ def oracle_noise_band(O, variant, th, soc, runs, opts_kw=None, seeds=6, eps=2.2e
         rk = O.simulate(variant, th, soc, runs, opts=O.default_opts(fd_perturb=eps, perturb_seed=seed, **kw))
         band = max(band, state_rel_err(rk["Y"], r0["Y"]))
     return r0, band
+
+
+# ---- tight-tolerance parity: the regime where the reproducibility floor of the default tolerances vanishes (VERDICT r02 "next" 1) ----
+TIGHT = dict(reltol=1e-8, abstol=1e-10)
+
+
+def _tight_tstops(ro, runs, sample_dt, fine_dt=0.05, fine_span=1.0):
+    """run-local stop times (opts.tstops, model_evaluation.jl:292-294) of the second pass: a coarse grid over the longest leg -- the equal times at which the two
+    trajectories are compared -- and a fine grid around the run-local end time of every leg that ended on a BOUND in the first pass.  The reference replaces the
+    last point of such a run by a LINEAR interpolation between the last two accepted points (interp_final_points!, model_evaluation.jl:369-382): its end state
+    depends on where those two points fall (h^2 y''/8: 1e-5 of Phi_s at a voltage knee with the ~5 s steps of reltol 1e-8, and the step grids of two
+    implementations do differ at tight tolerances); the fine grid makes both bracket the crossing within the same 0.05 s."""
+    ts, t0, longest = [], 0.0, 0.0
+    for rr in ro["runs"]:
+        loc = rr["t_end"] - t0
+        longest = max(longest, loc)
+        if rr["flag"] > 0:
+            ts.append(loc + np.arange(-fine_span, fine_span + fine_dt / 2, fine_dt))
+        t0 = rr["t_end"]
+    ts.append(np.arange(sample_dt, longest + fine_span, sample_dt))
+    ts = np.unique(np.round(np.concatenate(ts), 9))
+    return ts[ts > 1.5]                  # (a continuation run has its own tstop at 1 s)
+
+
+def _quad_interp(tk, Yk, t):
+    """Lagrange interpolation through three points (rows of Yk at times tk) at time t"""
+    (a, b, c) = tk
+    return Yk[0] * ((t - b) * (t - c) / ((a - b) * (a - c))) + Yk[1] * ((t - a) * (t - c) / ((b - a) * (b - c))) + Yk[2] * ((t - a) * (t - b) / ((c - a) * (c - b)))
+
+
+def tight_compare(pkg, p, O, th, soc, protocol, sample_dt=50.0, tol=None, max_points=40000, extra_opts=None):
+    """ONE cell, device and oracle BOTH at reltol 1e-8 / abstol 1e-10 (`tol`).  Pass 1 (oracle alone) locates the leg ends; pass 2 runs both with the same opts.tstops
+    (_tight_tstops) and outputs = :all.  Every deviation is relative to the scale of its field over the whole trajectory (max |field| over the oracle's saved points).
+    Returns
+      traj     max over the common stop times and the state sections of |Y_dev(t) - Y_orc(t)| / scale        (state trajectories at equal times)
+      V        max over the common stop times of |V_dev - V_orc| / |V_orc|
+      legs     per run: (flag_dev, flag_orc, t_end_dev, t_end_orc, end-state deviation), the last one measured against the oracle's trajectory at the DEVICE's own end
+               time (quadratic interpolation of the oracle's saved states on the fine stop grid): the end state of a run cannot be compared at unequal times
+      n_times  number of common stop times"""
+    tol = dict(tol or TIGHT)
+    runs = runs_to_oracle(O, p, pkg, protocol)
+    okw = dict(maxiters=1000000, **tol, **(extra_opts or {}))
+    r1 = O.simulate(p.variant, th, soc, runs, opts=O.default_opts(**okw), max_out=max_points)
+    assert min(r["flag"] for r in r1["runs"]) >= 0, ("the oracle itself fails on this protocol at the tight tolerances", r1["runs"])
+    ts = _tight_tstops(r1, runs, sample_dt)
+    ro = O.simulate(p.variant, th, soc, runs, opts=O.default_opts(tstops=ts, **okw), max_out=max_points, keep_Y=True)
+    assert min(r["flag"] for r in ro["runs"]) >= 0, ("the oracle itself fails on this protocol at the tight tolerances (second pass)", ro["runs"])
+    o = pkg.Opts(); o.reltol = tol["reltol"]; o.abstol = tol["abstol"]; o.maxiters = 1000000; o.tstops = list(ts)
+    for k, v in (extra_opts or {}).items():
+        setattr(o, k, v)
+    ens = pkg.simulate_ensemble(p, np.ascontiguousarray(th[None, :]), protocol, SOC=soc, opts=o, max_points=max_points, outputs="all")
+    info = ens.run_info[0]
+    n = int(ens.n_pts[0])
+    assert n < max_points and len(ro["t"]) < max_points, "output buffers too small for the tight-tolerance run"
+    td, Vd, Yd = np.asarray(ens.t[0, :n]), np.asarray(ens.V[0, :n]), np.asarray(ens.Y_all[0, :n])
+    to, Vo, Yo = ro["t"], ro["V"], ro["Y_all"]
+    secs = sections_for(Yo.shape[1])
+    scale = {name: max(np.abs(Yo[:, a:e]).max(), 1e-300) for name, a, e in secs}
+    # saved points of run k: [start[k], start[k+1])   (run.info.iterations = points of the run)
+    sd = np.concatenate([[0], np.cumsum([int(x) for x in info["iterations"]])]); so = np.concatenate([[0], np.cumsum([r["iterations"] for r in ro["runs"]])])
+    traj, dV, ntimes, legs = 0.0, 0.0, 0, []
+    t0d = t0o = 0.0
+    for k, rr in enumerate(ro["runs"]):
+        a_d, e_d, a_o, e_o = int(sd[k]), int(sd[k + 1]), int(so[k]), int(so[k + 1])
+        # run-local times of the accepted points (the last point of a run that ended on a bound is the back-interpolated one: not on the grid)
+        ld, lo = td[a_d:e_d] - td[a_d], to[a_o:e_o] - to[a_o]
+        common, ia, ib = np.intersect1d(np.round(ld[:-1], 6), np.round(lo[:-1], 6), return_indices=True)
+        on_grid = np.isin(common, np.round(ts, 6))
+        ia, ib = ia[on_grid] + a_d, ib[on_grid] + a_o
+        for name, a, e in secs:
+            if len(ia):
+                traj = max(traj, float(np.abs(Yd[ia, a:e] - Yo[ib, a:e]).max() / scale[name]))
+        if len(ia):
+            dV = max(dV, float((np.abs(Vd[ia] - Vo[ib]) / np.abs(Vo[ib])).max()))
+        ntimes += len(ia)
+        # end state of the run against the oracle's trajectory at the device's own end time
+        te_d, te_o = float(info[k]["t_end"]), rr["t_end"]
+        Yend = Yd[e_d - 1]
+        if int(info[k]["flag"]) == 0 or e_o - a_o < 5:
+            Yref = Yo[e_o - 1]
+        else:
+            loc = te_d - td[a_d]                                       # device's end in run-local time
+            grid = lo[:-1]
+            j = int(np.clip(np.searchsorted(grid, loc), 2, len(grid) - 1))
+            idx = [j - 2, j - 1, j] if j == len(grid) - 1 or abs(grid[j - 1] - loc) < abs(grid[j] - loc) or j + 1 >= len(grid) else [j - 1, j, j + 1]
+            Yref = _quad_interp(grid[idx], Yo[a_o:e_o][idx], loc)
+        end_err = max(float(np.abs(Yend[a:e] - Yref[a:e]).max() / scale[name]) for name, a, e in secs)
+        legs.append((int(info[k]["flag"]), rr["flag"], te_d, te_o, end_err))
+    return dict(traj=traj, V=dV, legs=legs, n_times=ntimes, steps=(int(ens.counters[0]["n_steps"]), ro["counters"]["n_steps"]), kernel_ms=ens.kernel_ms)

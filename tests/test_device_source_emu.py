@@ -388,6 +388,32 @@ def test_per_cell_protocol_values(emu_model, O, pkg):
     check_per_cell_protocol(emu_model, O, pkg, n=4)
 
 
+def check_user_tstops(p, O, pkg, soc=1.0, proto=None):
+    """opts.tstops (reference src/model_evaluation.jl:292-294: appended to the integrator's tstops, run-local times): the integrator hits every stop exactly -- a saved
+    point lands on each one inside the run -- and the trajectory keeps the oracle's decisions (same step / Newton counters, states at 1e-6)"""
+    proto = proto or [{"I": -1.0, "tf": 900.0}, {"I": "rest", "tf": 300.0}]
+    stops = [400.0, 37.25, 250.5, 250.5, 899.0, 1200.0, -3.0, 0.0]          # unsorted, duplicated, one beyond tf of either run, non-positive ones (dropped like the reference does)
+    # (init_step pinned in both: a stop clips the step before it to tstop - t_n, which turns the 1e-6 relative h0 noise of the step grid, DESIGN.md 5, into 1e-3 of that step)
+    o = pkg.Opts(); o.tstops = stops; o.init_step = 1e-3
+    ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 2), proto, SOC=soc, opts=o)
+    ro = O.simulate(p.variant, p.theta_vector(), soc, parity.runs_to_oracle(O, p, pkg, proto), opts=O.default_opts(tstops=stops, init_step=1e-3))
+    parity.compare_trajectory(ens, 1, ro, rtol_state=1e-6)
+    n = int(ens.n_pts[0]); t = ens.t[0, :n]
+    k1 = int(ens.run_info[0, 0]["iterations"])
+    for st in (37.25, 250.5, 400.0, 899.0):
+        assert (t[:k1] == st).sum() == 1, st                                   # exactly, once, in run 1
+    loc2 = t[k1:] - t[k1]
+    for st in (37.25, 250.5):
+        assert np.abs(loc2 - st).min() < 1e-9 * 900.0, st                     # run 2 (local time restarts at nextfloat(t_end)): 37.25 and 250.5 again; 400 is beyond its tf
+    assert np.abs(loc2 - 400.0).min() > 1.0
+    plain = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 1), proto, SOC=soc)
+    assert parity.state_rel_err(plain.Y[0], ens.Y[0]) < 2e-2 and int(plain.n_pts[0]) < n     # the stops cost steps, the solution stays within the integration tolerance
+
+
+def test_user_tstops(emu_model, O, pkg):
+    check_user_tstops(emu_model, O, pkg)
+
+
 def test_emulator_hostile_modes():
     """The same device-source tests with the emulator's LDS block and lane stacks starting as garbage (PL_EMU_POISON: on the GPU LDS holds what the
     previous workgroup left) and the lanes run 63..0 between sync points (PL_EMU_ORDER=reverse: a cross-lane LDS hand-over that lacks a sync point --

@@ -40,3 +40,36 @@ def test_ensemble_run_two_ranks_nccl(tmp_path):
     for part in ("block", "cyclic"):
         assert np.array_equal(d[part + "_Y"], d["ref_Y"]) and np.array_equal(d[part + "_t_end"], d["ref_t_end"])      # bitwise: the shard a cell lands in does not matter
         assert (d[part + "_ms"] > 0).all() and len(d[part + "_ms"]) == 2
+
+
+def test_bench_spawns_its_own_ranks_and_the_rank_logic_runs(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher spawns its two ranks itself (torch.distributed.run on 127.0.0.1) and rank 0 prints the one JSON line -- the path an
+    8-GPU driver run takes if it starts bench.py plainly.  BENCH_BACKEND=gloo lets both ranks share the one GPU of this box (RCCL refuses two ranks per device); the
+    RCCL path itself is test_ensemble_run_* above and the driver's multi-GPU run."""
+    import json
+    env = dict(os.environ, BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["cells_total"] == 2048 and len(d["config"]["rank_kernel_ms"]) == 2 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_ensemble_run_per_cell_protocol_values(hip_model, pkg):
+    """per-cell protocol arrays (value_cell / tf_cell) through plh_ensemble_run are indexed by the GLOBAL cell: with the cyclic partition of one rank the
+    shard order equals the caller's, and the results must equal plh_integrate's on the same per-cell protocol"""
+    from petlion_jl_amd import distributed as pd
+    p = hip_model
+    n = 96
+    rates = -np.linspace(0.5, 3.0, n); tfs = np.linspace(300.0, 900.0, n)
+    proto = [{"I": rates, "tf": tfs}]
+    Th = pkg.configs.c4(p, n)["theta"]
+    ref = pkg.simulate_ensemble(p, Th, proto, SOC=1.0)
+    comm = pd.RcclComm(p._lib, 1, 0, pd.RcclComm.unique_id(p._lib))
+    for part in ("block", "cyclic"):
+        info, cnt, Y, ms = pd.ensemble_run_capi(comm, p, Th, proto, 1.0, partition=part, want_Y=True)
+        assert np.array_equal(Y, ref.Y) and np.array_equal(info["t_end"][:, 0], ref.run_info["t_end"][:, 0]) and np.array_equal(info["I"][:, 0], rates)
+    comm.close()

@@ -540,3 +540,58 @@ def test_other_discretisations(pkg, O, hip_model):
     # the handles of different grids coexist with the built-in one
     ens = pkg.simulate_ensemble(hip_model, pkg.theta_matrix(hip_model, 1), [{"I": -1.0, "tf": 600.0}], SOC=1.0)
     assert abs(ens.run_info[0, 0]["V"] - 3.945410) < 1e-5
+
+
+def test_user_tstops_on_gpu(hip_model, hip_model_thermal, hip_model_nmc_sei, O, pkg):
+    """opts.tstops (model_evaluation.jl:292-294) on the GPU, three models"""
+    import test_device_source_emu as te
+    te.check_user_tstops(hip_model, O, pkg)
+    te.check_user_tstops(hip_model_thermal, O, pkg, soc=0.1, proto=[{"I": 2.0, "tf": 900.0}, {"I": "rest", "tf": 300.0}])
+    te.check_user_tstops(hip_model_nmc_sei, O, pkg, soc=0.1, proto=[{"I": 1.0, "tf": 900.0}, {"I": "rest", "tf": 300.0}])
+
+
+def test_seam1_cache_writer_and_split_exports_on_gpu(hip_model, hip_model_sei, hip_model_thermal, hip_model_nmc, O):
+    """SURVEY 8(f).2 on the hardware: the index construction of bindings/julia/SavedModelWriter.jl replayed against the HIP library (tests/test_seam1_cache_writer.py does
+    it on the emulator build), including the split exports plh_residual_diff / plh_residual_alg / plh_jacobian_alg the generated-function stubs call"""
+    import test_seam1_cache_writer as ts
+    for p in (hip_model, hip_model_sei, hip_model_thermal, hip_model_nmc):
+        ts.check_variant(p, O)
+
+
+def test_split_exports_batched_on_gpu(hip_model_thermal, O):
+    """plh_residual_diff / _alg and plh_jacobian_alg on a batch with differing parameters, host pointers, against the oracle's f_diff! / f_alg! / J_y_alg! rows"""
+    import ctypes as C
+    p = hip_model_thermal
+    N, Nd = p.N.tot, p.N.diff
+    n = 7
+    th = p.theta_vector()
+    Y, YP = parity.realistic_states(O, th, n, variant=p.variant)
+    Th = np.tile(th, (n, 1)); Th[:, p.θ_keys.index("h_cell")] *= np.linspace(0.5, 2.0, n); Th = np.ascontiguousarray(Th)
+    Fd, Fa = np.zeros((n, Nd)), np.zeros((n, N - Nd - 1))
+    assert p._lib.plh_residual_diff(p._h, n, Th.ctypes.data, Y.ctypes.data, YP.ctypes.data, Fd.ctypes.data, 0, None) == 0
+    assert p._lib.plh_residual_alg(p._h, n, Th.ctypes.data, Y.ctypes.data, YP.ctypes.data, Fa.ctypes.data, 0, None) == 0
+    nnz = C.c_int(0)
+    assert p._lib.plh_jac_alg_pattern(p._h, 0, C.byref(nnz), None, None) == 0
+    nz = np.zeros((n, nnz.value))
+    assert p._lib.plh_jacobian_alg(p._h, n, Th.ctypes.data, Y.ctypes.data, YP.ctypes.data, 0, nz.ctypes.data, 0, None) == 0
+    for i in range(n):
+        Fo = O.residual(p.variant, Th[i], Y[i], YP[i], 0, 0.0)
+        scale = np.abs(Fo).max()
+        assert np.abs(Fd[i] - Fo[:Nd]).max() <= 1e-9 * max(scale, 1.0) and np.abs(Fa[i] - Fo[Nd:N - 1]).max() <= 1e-9 * max(np.abs(Fo[Nd:N - 1]).max(), 1e-3)
+        cp, ri, onz = O.jacobian(p.variant, Th[i], Y[i], YP[i], 0.0, 0, 0.0)
+        blk = [onz[q] for c in range(Nd, N) for q in range(cp[c], cp[c + 1]) if Nd <= ri[q] < N - 1]
+        assert len(blk) == nnz.value and np.abs(nz[i] - np.array(blk)).max() <= 1e-9 * np.abs(blk).max()
+
+
+def test_two_variants_on_one_non_default_grid(pkg, O):
+    """a second model on the SAME non-default grid with another variant, in one process (the grid library used to be rebuilt in place under a path that was
+    already registered): LCO Fickian, then quadratic diffusion (N_r forced to 10: same grid tag), then the first one again"""
+    import torch
+    kw = dict(N_p=7, N_s=6, N_n=8)
+    a = pkg.petlion(pkg.LCO, **kw)
+    b = pkg.petlion(pkg.LCO, solid_diffusion="quadratic", **kw)
+    c = pkg.petlion(pkg.LCO, **kw)
+    for p in (a, b, c):
+        ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 4), [{"I": -1.0, "tf": 600.0}], SOC=1.0)
+        assert (ens.run_info["flag"][:, 0] == 0).all()
+    assert a.N.tot == c.N.tot != b.N.tot

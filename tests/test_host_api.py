@@ -101,11 +101,8 @@ def test_simulate_vector_tf_and_failed_run_leave_sol_untouched(emu_model, pkg):
     except RuntimeError:
         pass
     assert len(full.t) == n0 and len(full.results) == 1
-    try:
-        pkg.simulate(p, 100.0, I=-1, tstops=[50.0])
-        assert False
-    except NotImplementedError:
-        pass
+    s2 = pkg.simulate(p, 100.0, I=-1, tstops=[50.0])                  # opts.tstops (model_evaluation.jl:292-294): a saved point lands exactly on the stop
+    assert (s2.t == 50.0).sum() == 1 and s2.t[-1] == 100.0
 
 
 def test_closure_tracer_programs(pkg, emu_model):
@@ -122,7 +119,10 @@ def test_closure_tracer_programs(pkg, emu_model):
              (lambda t, q: q.θ["t₊"] * t / (1 + cl.exp(-t)), lambda t: th[p.θ_keys.index("t₊")] * t / (1 + math.exp(-t))),
              (lambda t: cl.where(t < 3, 1.0, cl.where(t >= 5, -2.0, cl.sqrt(t))), lambda t: 1.0 if t < 3 else (-2.0 if t >= 5 else math.sqrt(t))),
              (lambda t, Y_, q: -cl.minimum(1.0, cl.maximum(0.05, (cl.calc_V(Y_, q) - 0.1) * 2.0)), lambda t: -min(1.0, max(0.05, (Y[ps.start] - Y[ps.stop - 1] - 0.1) * 2.0))),
-             (lambda t, Y_, YP_, q: abs(YP_[3]) * cl.tanh(Y_[-1]) - cl.log(Y_[0] + t), lambda t: abs(YP[3]) * math.tanh(Y[-1]) - math.log(Y[0] + t))]
+             (lambda t, Y_, YP_, q: abs(YP_[3]) * cl.tanh(Y_[-1]) - cl.log(Y_[0] + t), lambda t: abs(YP[3]) * math.tanh(Y[-1]) - math.log(Y[0] + t)),
+             # == / != on traced values (they used to fall back to Python identity and trace a constant branch)
+             (lambda t: cl.where(t == 4.0, 10.0, 1.0) + cl.where(t != 2.5, 0.5, 0.25), lambda t: (10.0 if t == 4.0 else 1.0) + (0.5 if t != 2.5 else 0.25)),
+             (lambda t, Y_, q: cl.where(Y_[0] != 0, t, -t) * (t == t), lambda t: t)]
     for f, ref in cases:
         prog = cl.trace(f, p)
         for t in (0.0, 2.5, 4.0, 7.0):
