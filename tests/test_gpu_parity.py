@@ -547,7 +547,7 @@ def test_user_tstops_on_gpu(hip_model, hip_model_thermal, hip_model_nmc_sei, O, 
     import test_device_source_emu as te
     te.check_user_tstops(hip_model, O, pkg)
     te.check_user_tstops(hip_model_thermal, O, pkg, soc=0.1, proto=[{"I": 2.0, "tf": 900.0}, {"I": "rest", "tf": 300.0}])
-    te.check_user_tstops(hip_model_nmc_sei, O, pkg, soc=0.1, proto=[{"I": 1.0, "tf": 900.0}, {"I": "rest", "tf": 300.0}])
+    te.check_user_tstops(hip_model_nmc_sei, O, pkg, soc=0.1, proto=[{"I": 1.0, "tf": 900.0}, {"I": "rest", "tf": 300.0}], rtol_state=1e-3, same_decisions=False)      # (NMC + SEI: the stops re-scale the step grid, the sequences differ: states at the integration tolerance)
 
 
 def test_seam1_cache_writer_and_split_exports_on_gpu(hip_model, hip_model_sei, hip_model_thermal, hip_model_nmc, O):
