@@ -41,6 +41,7 @@ struct Opts
     n_tdiscon::Cint; tdiscon::Ptr{Cdouble}     # host array of any length (the caller keeps it alive across the call)
     refine::Cint                                # iterative-refinement steps per linear solve (parity mode), 0 = off
     n_tstops::Cint; tstops::Ptr{Cdouble}       # opts.tstops (run-local times the integrator must hit; src/model_evaluation.jl:292-294), host array
+    yp_alg_zero::Cint                           # 1: start the integrator with YP_alg = 0 (step history of the example notebooks' package version), 0 = today's source
 end
 struct RunInfo
     flag::Cint; iterations::Cint; t_end::Cdouble; V::Cdouble; I::Cdouble; SOC::Cdouble; T_avg::Cdouble
@@ -178,7 +179,7 @@ function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.o
     o = p.opts
     td = Float64.(o.tdiscon); ts = Float64.(o.tstops)
     opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0,
-                    length(td), isempty(td) ? C_NULL : pointer(td), refine, length(ts), isempty(ts) ? C_NULL : pointer(ts)))
+                    length(td), isempty(td) ? C_NULL : pointer(td), refine, length(ts), isempty(ts) ? C_NULL : pointer(ts), 0))
     Θt = permutedims(Θ)                                   # column-major n_theta × n_cells == row-major cells
     soc = SOC isa Number ? fill(Float64(SOC), n) : Vector{Float64}(SOC)
     t = zeros(max_pts, n); V = similar(t); I = similar(t); S = similar(t)
@@ -274,7 +275,7 @@ function ensemble_run(c::Comm, m::Model, p, Θ::Matrix{Float64}, protocol; SOC =
     info = Matrix{RunInfo}(undef, length(runs), root ? n_cells : 0); cnt = Vector{Counters}(undef, root ? n_cells : 0); ms = zeros(comm_size(c))
     GC.@preserve td ts Θt soc info cnt ms begin
         opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0,
-                        length(td), isempty(td) ? C_NULL : pointer(td), refine, length(ts), isempty(ts) ? C_NULL : pointer(ts)))
+                        length(td), isempty(td) ? C_NULL : pointer(td), refine, length(ts), isempty(ts) ? C_NULL : pointer(ts), 0))
         check(ccall((:plh_ensemble_run, lib), Cint,
                     (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Run}, Ref{Opts}, Cint, Ptr{RunInfo}, Ptr{Counters}, Ptr{Cdouble}, Ptr{Cdouble}),
                     c.h, m.h, n_cells, root ? pointer(Θt) : C_NULL, root ? pointer(soc) : C_NULL, length(runs), runs, opts, partition === :cyclic ? 1 : 0,

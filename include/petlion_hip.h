@@ -168,6 +168,10 @@ typedef struct {
                                                         depends on the elimination order (structured here, KLU's in the reference) beyond ~1e-13 */
   int n_tstops; const double* tstops;                /* opts.tstops (src/structures.jl:278, model_evaluation.jl:292-294): times, in run-local time, the integrator must hit
                                                         exactly (a saved point lands on each); any length, HOST array staged like tdiscon; applies to every run of the protocol */
+  int yp_alg_zero;                                   /* 0 (default): newtons_method! hands the integrator its finite-difference estimate of the algebraic derivatives
+                                                        (src/model_evaluation.jl:462-477).  1: the integrator starts with YP_alg = 0, as the package version that produced the
+                                                        reference's example notebooks did -- with it the printed step history of examples/model_inputs_and_outputs.ipynb
+                                                        (121 saved points, sol.V[1:13], sol.c_e[1:5]) is reproduced to 1e-8 (tests/golden/notebook_kats.json) */
 } plh_opts;
 
 /* per-cell, per-run summary == run_info + the printed summary (src/structures.jl:40-44, 678-746) */

@@ -361,6 +361,9 @@ typedef struct {   /* reference options_simulation, src/structures.jl:266-285 */
      implementation of the reference algorithm sits in. */
   double fd_perturb; int perturb_seed;
   int n_tstops; const double* tstops;     /* opts.tstops: user stop times in run-local time, appended to the integrator's tstops (model_evaluation.jl:292-294) */
+  /* bounded experiment on the step history of the reference's notebook (tests/test_oracle_golden.py::test_step_history_of_the_2C_charge_notebook): 1 = the integrator is
+     started with YP_alg = 0, i.e. without newtons_method!'s finite-difference estimate of the algebraic derivatives (model_evaluation.jl:462-477) */
+  int exp_yp_alg_zero;
 } orc_opts;
 
 typedef struct {
@@ -996,6 +999,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
     int ierr = newtons_method(e, Y, YP, opts, c_e0);
     orc_runinfo* ri = &info[r]; memset(ri, 0, sizeof(*ri)); ri->flag = -1;
     if (ierr != 0) { ri->flag = ierr; ri->t_end = t_global; rc = 1; break; }
+    if (opts->exp_yp_alg_zero) for (int n = M.Nd; n < N; n++) YP[n] = 0.0;
     ida_reinit(Ip, e, opts, Y, YP);
     /* tstops (postfix_integrator!, model_evaluation.jl:288-310): {1.0 if continuation} U {tf} */
     double* tstops = (double*)malloc((opts->n_tdiscon + opts->n_tstops + 4) * sizeof(double)); int nts = 0, its = 0;

@@ -45,7 +45,7 @@ class Opts(C.Structure):
     _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("abstol_init", C.c_double), ("reltol_init", C.c_double),
                 ("maxiters", C.c_int), ("check_bounds", C.c_int), ("interp_final", C.c_int), ("max_order", C.c_int),
                 ("jac_every_step", C.c_int), ("init_step", C.c_double), ("n_tdiscon", C.c_int), ("tdiscon", C.POINTER(C.c_double)),
-                ("refine", C.c_int), ("n_tstops", C.c_int), ("tstops", C.POINTER(C.c_double))]
+                ("refine", C.c_int), ("n_tstops", C.c_int), ("tstops", C.POINTER(C.c_double)), ("yp_alg_zero", C.c_int)]
 
 
 class RunInfo(C.Structure):

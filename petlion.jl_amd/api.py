@@ -204,6 +204,7 @@ def _opts_struct(o):
     s.n_tstops = ts.size
     s.tstops = ts.ctypes.data_as(C.POINTER(C.c_double)) if ts.size else None
     s._keep = (td, ts)                               # the arrays must outlive the struct
+    s.yp_alg_zero = int(bool(getattr(o, "yp_alg_zero", False)))
     return s
 
 

@@ -750,6 +750,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     int ierr; { PL_TIC(); ierr = cell_init_consistent<TAB>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt, S.phi[0], o.refine,
                                                                        (TAB && run.value_kind == PLH_VAL_EXPR) ? &run : nullptr, t_restart); PL_TOC(S, PH_INIT); }
     if (ierr != 0) { if (first_init) init_failed = true; else flag = ierr; ri.flag = ierr; break; }
+    if constexpr (TAB) { if (o.yp_alg_zero) { PL_VEC(n) if (n >= NDIFF) S.yp[n] = 0.0; PL_XSYNC(); } }     // plh_opts.yp_alg_zero (general instantiation only)
     ida_reinit(S, I, S.yy, S.yp, first_init ? (o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD) : I.maxord, t_restart);
     if (first_init) {
       first_init = false;
@@ -791,7 +792,9 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       if (iter == o.maxiters) { flag = PLH_ERR_MAXITERS; break; }
       if (nout >= out.max_pts && out.max_pts > 0 && flag == PLH_FLAG_RUNNING) { flag = PLH_ERR_OUTPUT_FULL; break; }
       if (flag == PLH_FLAG_RUNNING) {
+#ifndef PL_EXP_NO_PREV      /* (experiment build: upper bound of what the per-step previous-point copy costs; results of runs that end on a bound are then wrong) */
         PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }      // fire-and-forget: read back only when a bound fires
+#endif
         t_prev_saved = t + t0; I_prev_pt = S.yy[O_I];
         if constexpr (TAB) if (is_tab && t - tprev < 1e-3 * o.reltol) {                    // check_reinitialization!, checks.jl:341-364
           const double t_new = t + o.reltol, v_new = run_input(S, run, t_new, S.yy, S.yp);

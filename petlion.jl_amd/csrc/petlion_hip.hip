@@ -462,9 +462,9 @@ int plh_abi_layout(int* out, int cap) {
   PL_F(plh_bounds, I_max) PL_F(plh_bounds, I_min) PL_F(plh_bounds, eta_plating_min) PL_F(plh_bounds, c_e_min) PL_F(plh_bounds, dfilm_max)
   PL_S(plh_run, 10) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, tab_t)
   PL_F(plh_run, tab_v) PL_F(plh_run, value_cell) PL_F(plh_run, tf_cell)
-  PL_S(plh_opts, 15) PL_F(plh_opts, abstol) PL_F(plh_opts, reltol) PL_F(plh_opts, abstol_init) PL_F(plh_opts, reltol_init) PL_F(plh_opts, maxiters) PL_F(plh_opts, check_bounds)
+  PL_S(plh_opts, 16) PL_F(plh_opts, abstol) PL_F(plh_opts, reltol) PL_F(plh_opts, abstol_init) PL_F(plh_opts, reltol_init) PL_F(plh_opts, maxiters) PL_F(plh_opts, check_bounds)
   PL_F(plh_opts, interp_final) PL_F(plh_opts, max_order) PL_F(plh_opts, jac_every_step) PL_F(plh_opts, init_step) PL_F(plh_opts, n_tdiscon) PL_F(plh_opts, tdiscon) PL_F(plh_opts, refine)
-  PL_F(plh_opts, n_tstops) PL_F(plh_opts, tstops)
+  PL_F(plh_opts, n_tstops) PL_F(plh_opts, tstops) PL_F(plh_opts, yp_alg_zero)
   PL_S(plh_run_info, 7) PL_F(plh_run_info, flag) PL_F(plh_run_info, iterations) PL_F(plh_run_info, t_end) PL_F(plh_run_info, V) PL_F(plh_run_info, I) PL_F(plh_run_info, SOC)
   PL_F(plh_run_info, T_avg)
   PL_S(plh_counters, 11) PL_F(plh_counters, n_steps) PL_F(plh_counters, n_res) PL_F(plh_counters, n_jac) PL_F(plh_counters, n_fact) PL_F(plh_counters, n_solve)
@@ -665,7 +665,7 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
   CHECK_STAGE(s);                                                     // a failed staging allocation must never reach the kernel as a NULL ("not requested") output
   hipEventRecord(cx.ev0, s.st);
-  bool general = opts->n_tdiscon > 0 || opts->n_tstops > 0 || out->Y_all || opts->refine > 0;     // the general instantiation also carries the per-step state dump (outputs = :all) and the refinement mode
+  bool general = opts->n_tdiscon > 0 || opts->n_tstops > 0 || out->Y_all || opts->refine > 0 || opts->yp_alg_zero != 0;     // the general instantiation also carries the per-step state dump (outputs = :all) and the refinement mode
   for (int r = 0; r < n_runs; r++) general = general || runs[r].value_kind == PLH_VAL_TABLE || runs[r].value_kind == PLH_VAL_EXPR;
   m->ops->integrate(s.st, a, general);
   hipEventRecord(cx.ev1, s.st);

@@ -125,6 +125,7 @@ class Opts:
         self.jac_every_step = False
         self.init_step = 0.0        # 0 = IDA's automatic initial step; > 0 = IDASetInitStep
         self.refine = 0             # n > 0: n steps of iterative refinement of every linear solve (parity mode, plh_opts.refine)
+        self.yp_alg_zero = False    # True: start the integrator with YP_alg = 0 (the package version of the reference's example notebooks; plh_opts.yp_alg_zero)
         self.max_points = 2048      # capacity of the per-cell output buffers
 
 

@@ -414,6 +414,23 @@ def test_user_tstops(emu_model, O, pkg):
     check_user_tstops(emu_model, O, pkg)
 
 
+def check_notebook_step_history_device(p, pkg):
+    """the printed step history of examples/model_inputs_and_outputs.ipynb (SUNDIALS IDA + KLU output: 121 points, sol.V[1:13], sol.c_e[1:5]) through the host API and
+    the device integrator with opts.yp_alg_zero (tests/test_oracle_golden.py::check_notebook_step_history has the story)"""
+    import test_oracle_golden as tg
+
+    def sim(z):
+        sol = pkg.simulate(p, I=2, SOC=0, V_max=4.1, outputs=("t", "V", "c_e"), yp_alg_zero=z)
+        pkg.simulate_b(sol, p, V="hold", outputs=("t", "V", "c_e"), yp_alg_zero=z)
+        runs = [dict(flag=r.flag, iterations=r.iterations, t_end=float(r.info["t_end"]), I=float(r.info["I"]), SOC=float(r.info["SOC"])) for r in sol.results]
+        return dict(t=sol.t, V=sol.V, c_e=sol.c_e, runs=runs)
+    tg.check_notebook_step_history(sim, exact_hold_leg=False)
+
+
+def test_notebook_step_history_on_the_device_source(emu_model, pkg):
+    check_notebook_step_history_device(emu_model, pkg)
+
+
 def test_emulator_hostile_modes():
     """The same device-source tests with the emulator's LDS block and lane stacks starting as garbage (PL_EMU_POISON: on the GPU LDS holds what the
     previous workgroup left) and the lanes run 63..0 between sync points (PL_EMU_ORDER=reverse: a cross-lane LDS hand-over that lacks a sync point --

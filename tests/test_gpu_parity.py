@@ -595,3 +595,9 @@ def test_two_variants_on_one_non_default_grid(pkg, O):
         ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 4), [{"I": -1.0, "tf": 600.0}], SOC=1.0)
         assert (ens.run_info["flag"][:, 0] == 0).all()
     assert a.N.tot == c.N.tot != b.N.tot
+
+
+def test_notebook_step_history_on_gpu(hip_model, pkg):
+    """the reference notebook's printed IDA step history (121 points, V[1:13] to 1e-8, c_e[1:5] to 1e-7) reproduced by the HIP integrator (opts.yp_alg_zero)"""
+    import test_device_source_emu as te
+    te.check_notebook_step_history_device(hip_model, pkg)

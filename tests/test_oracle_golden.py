@@ -90,6 +90,43 @@ def test_notebook_runs(O):
     assert abs(ro["V"][0] - G["V_first13_2C_charge"]["values"][0]) < 1e-10
 
 
+def check_notebook_step_history(sim, exact_hold_leg=True):
+    """`sim(yp_alg_zero)` -> dict(t, V, c_e [points, 30], runs) of `simulate(p, I=2, SOC=0, V_max=4.1); simulate!(sol, p, V=:hold)` with outputs (:t, :V, :c_e).
+    The reference's notebook prints the STEP HISTORY of that pair of runs as SUNDIALS IDA + KLU produced it: 121 saved points, sol.V[1:13] and the last 12, the leading and
+    trailing ten entries of sol.c_e[1:5].  Started with YP_alg = 0 -- the one thing today's source does differently, it adds the finite-difference estimate of
+    model_evaluation.jl:462-477 -- the IDA restatement reproduces every printed digit that an independent fp64 implementation can (2.5e-9 V after twelve steps):
+    h0 = 0.5/||y'||_wrms = 6.10 ms, an error-test failure on the first attempt (x0.60), then IDA's order and step selection, step for step."""
+    r = sim(True)
+    k = G["V_first13_2C_charge"]
+    assert [q["flag"] for q in r["runs"]] == [2, 4] and r["runs"][0]["iterations"] == 84
+    if exact_hold_leg:
+        assert len(r["t"]) == k["n_points_total"] == 121 and r["runs"][1]["iterations"] == 37
+    else:       # (a second implementation: the hold leg restarts from a back-interpolated state, its step sequence is reproducible to +-2 steps -- DESIGN.md 5)
+        assert abs(len(r["t"]) - 121) <= 2
+    assert np.abs(r["V"][:13] - np.array(k["values"])).max() < 1e-8 and np.abs(r["V"][-12:] - np.array(k["last12_CC_CV"])).max() < 1e-9
+    assert np.abs(1e3 * r["t"][:13] - np.array(k["inferred_step_times_ms"])).max() < 1e-3
+    for j, pr in enumerate(G["c_e_first5_saved_profiles"]["profiles"]):
+        assert np.abs(r["c_e"][j, :10] - pr["first10"]).max() < 1e-7 and np.abs(r["c_e"][j, 20:30] - pr["last10"]).max() < 1e-7, j
+    kc, kv = G["runs"]["charge_2C_to_4p1"], G["runs"]["cv_hold_after_2C"]
+    lim = 5e-3 if exact_hold_leg else 1.0
+    assert abs(r["runs"][0]["t_end"] - kc["t_end"]) < 5e-3 and abs(r["runs"][1]["t_end"] - kv["t_end"]) < lim        # printed with two decimals: 1388.68 s, 2440.61 s
+    assert abs(r["runs"][1]["I"] - kv["I_end"]) < (5e-5 if exact_hold_leg else 2e-3) and abs(r["runs"][1]["SOC"] - 1.0001) < 5e-5
+    # with today's source (YP_alg estimated) the first step is 1.30 ms instead: another step history, the same solution within the integration tolerance
+    r0 = sim(False)
+    assert abs(len(r0["t"]) - 121) <= 8 and abs(r0["V"][0] - k["values"][0]) < 1e-10 and abs(1e3 * r0["t"][1] - 1.3035) < 1e-3
+
+
+def test_step_history_of_the_2C_charge_notebook(O):
+    """examples/model_inputs_and_outputs.ipynb cells 6-12 (lines 152-164, 236-240)"""
+    th = O.theta_vector("lco_iso")
+    runs = [dict(mode=O.MODE_I, value=2.0, tf=1e6, bounds=O.default_bounds(V_max=4.1)), dict(mode=O.MODE_V, value_kind=O.VAL_HOLD, tf=1e6, bounds=O.default_bounds(V_max=4.1))]
+
+    def sim(z):
+        r = O.simulate("lco_iso", th, 0.0, runs, opts=O.default_opts(exp_yp_alg_zero=int(z)), keep_Y=True)
+        return dict(t=r["t"], V=r["V"], c_e=r["Y_all"][:, :30], runs=r["runs"])
+    check_notebook_step_history(sim)
+
+
 def test_tolerance_tightening_converges(O):
     """accuracy is proven by tightening: the end state converges with first order in reltol or better"""
     th = O.theta_vector("lco_iso")
