@@ -165,6 +165,39 @@ def spawn_ranks(n):
         raise SystemExit(rc)
 
 
+def general_path(pkg, p, inp, Theta, n_local, kernel_ms, reps=5):
+    """what a call pays for the features beyond constant inputs -- each runs in the smallest k_integrate instantiation that has it (GenFlag, csrc/dfn_integrate.h):
+    kernel time of the same workload with the feature switched on, relative to the plain kernel of the timed region"""
+    import torch
+    proto = inp["protocol"]
+    first = dict(proto[0])
+    if "I" not in first or isinstance(first["I"], str):
+        return None
+    Ival, tf = float(first["I"]), float(first.get("tf", 1e6))
+    tab = dict(first); tab["I"] = ([0.0, 1e7], [Ival, Ival])                         # the same constant current as a table / as a closure of t and the state
+    clo = dict(first); clo["I"] = lambda t, Y, P_: Ival + 0.0 * t + 0.0 * Y[0]
+    cases = [("stop times (opts.tstops; one stop beyond every run, so that the step sequence is the plain one)", proto, dict(tstops=[1e7]), None),
+             ("state dump (outputs = :all)", proto, {}, "all"),
+             ("table input", [tab] + proto[1:], {}, None),
+             ("closure input", [clo] + proto[1:], {}, None),
+             ("refine = 1", proto, dict(refine=1), None)]
+    out = {}
+    for name, pr, okw, outputs in cases:
+        o = pkg.Opts()
+        for k, v in okw.items():
+            setattr(o, k, v)
+        ms = []
+        for r in range(reps + 1):
+            ens = pkg.simulate_ensemble(p, Theta, pr, SOC=inp["SOC"], device=True, opts=o, max_points=inp["max_points"], outputs=outputs)
+            torch.cuda.synchronize()
+            if r:
+                ms.append(float(ens.kernel_ms))
+        assert (ens.run_info["flag"] >= 0).all(), name
+        out[name] = {"kernel_ms": float(np.mean(ms)), "trajectories_per_s": n_local / (np.mean(ms) * 1e-3), "vs_plain_kernel": kernel_ms / float(np.mean(ms))}
+        del ens
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -368,6 +401,7 @@ def main():
             out["cpu_baseline_all_cores"] = allc
         if world == 1 and not args.no_extras:
             out["host_inclusive"] = host_inclusive(pkg, p, inp, n_local, kavg_ms)
+            out["general_path"] = general_path(pkg, p, inp, Theta, n_local, kavg_ms)
             # measured device-to-device copy bandwidth of this box (read + write bytes), the second peak SURVEY 8(d) asks to quote
             a = torch.empty(1 << 28, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
             b.copy_(a); torch.cuda.synchronize()

@@ -195,7 +195,8 @@ template <bool MIXED> struct ThermalPool<true, MIXED> {
   // node-local elimination
   double tq[4][NE], phi4[4][NE], colI4[2][NE];           // colI4: (Phi_s, T) components of the column of I (the others are zero)
   // collector chains (tridiagonal scalar systems)
-  double cP[2][NA], cM[2][NA], zc[2][NA], zI[2][NA], zb[2][NA];
+  static constexpr int NC = NA > NZ ? NA : NZ;
+  double cP[2][NC], cM[2][NC], zc[2][NC], zI[2][NC], zb[2][NC];
   // Woodbury and border
   double x2[4][NE], vB[4][NE];
   double qfar[2][4];                                       // q = (far T-row entry of node 9 / 20) . D'^-1 of node 7 / 22 (right-hand-side share)

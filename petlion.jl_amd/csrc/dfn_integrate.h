@@ -27,6 +27,15 @@ struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live 
   int nst;
 };
 
+// Feature flags of the integrate kernel's instantiations.  The step loop keeps ~60 per-lane values live next to the cell's LDS block, and code that is merely PRESENT in it costs
+// registers and instruction cache whether it runs or not -- so each call pays only for what it asks for (plh_integrate picks the instantiation):
+//   0                      constant / hold / rest inputs, per-step scalars out                                   (the benchmark path)
+//   GF_STOPS               + opts.tstops / tdiscon stop times, the per-step state dump (outputs = :all), yp_alg_zero
+//   GF_STOPS | GF_FUNC     + inputs that are functions of time given as tables (run_function), check_reinitialization!
+//   ... | GF_EXPR          + closure inputs of (t, Y, YP, theta): the postfix interpreter inside every residual evaluation
+//   ... | GF_REFINE        + iterative refinement of every linear solve (plh_opts.refine, the parity diagnostic)
+enum GenFlag { GF_STOPS = 1, GF_FUNC = 2, GF_EXPR = 4, GF_REFINE = 8 };
+
 // device counters: wave-uniform registers (every call site uses a compile-time index), written out once at the end; indices:
 enum Cnt { C_STEPS, C_RES, C_JAC, C_FACT, C_SOLVE, C_NEWTON, C_ERRFAIL, C_CONVFAIL, C_SUMKP2, C_INIT };
 struct Counters { int v[10]; };
@@ -60,7 +69,7 @@ __device__ __forceinline__ double wrms(const double* v, const double* w) {
 // spills the ~100 live registers of the step loop.
 template <class M> PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP);     // closure inputs (PLH_VAL_EXPR), defined below
 // `frun` (general instantiation only): the run when its input is a closure of the state -- re-evaluated with the iterate before every residual evaluation, at run-local time t_fun
-template <bool GEN, class M>
+template <int F, class M>
 PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
                                                       int mode, double value, double reltol_init, double* bsave = nullptr, int nref = 0, const plh_run* frun = nullptr, double t_fun = 0.0) {
   LaneRegs R;                                                        // (the algebraic solves do not touch the particle registers)
@@ -74,11 +83,11 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   if (M::THERMAL && mode == PLH_MODE_DT) mode = PL_MODE_DT_TWIN;
   int ok = 0;
   for (int iter = 1; iter <= 100; iter++) {
-    if constexpr (GEN) { if (frun) value = expr_eval(S, *frun, t_fun, Y, YP); }
+    if constexpr ((F & GF_EXPR) != 0) { if (frun) value = expr_eval(S, *frun, t_fun, Y, YP); }
     cell_node_pass<true, true>(S, Y, YP, res, mode, value);      // R_alg + J_alg partials (differential rows ignored)
     PL_SYNC();
     cell_factor(S, R, tb, 0.0, mode, true);
-    if (GEN && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref);     // (general instantiation only: plh_opts.refine)
+    if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref);     // (GF_REFINE instantiations only: plh_opts.refine)
     else cell_solve(S, R, res, mode, true);
     iters++;
     double s = 0.0;
@@ -90,7 +99,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   }
   if (!ok) return PLH_ERR_INIT;
   // YP_diff = rhs_diff(Y)   (R_diff with YP = 0)
-  if constexpr (GEN) { if (frun) value = expr_eval(S, *frun, t_fun, Y, YP); }
+  if constexpr ((F & GF_EXPR) != 0) { if (frun) value = expr_eval(S, *frun, t_fun, Y, YP); }
   cell_residual(S, R, Y, YP, res, mode == PL_MODE_DT_TWIN ? PLH_MODE_DT : mode, value);
   PL_VEC(n) if (n < NDIFF) YP[n] = res[n];
   PL_SYNC();
@@ -101,21 +110,21 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   if (10.0 * reltol_init > dt) dt = 10.0 * reltol_init;
   PL_VEC(n) Ytmp[n] = Y[n] + dt * YP[n];
   PL_XSYNC();
-  if constexpr (GEN) { if (frun) value = expr_eval(S, *frun, t_fun, Ytmp, YP); }
+  if constexpr ((F & GF_EXPR) != 0) { if (frun) value = expr_eval(S, *frun, t_fun, Ytmp, YP); }
   cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
   PL_SYNC();
-  if (GEN && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref);
+  if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref);
   else cell_solve(S, R, res, mode, true);
   if (!M::W2 || wave_id() == 0) for (int n = NDIFF + lane; n < NST; n += WAVE) YP[n] = -res[n] / dt;
   PL_XSYNC();
   return iters;
 }
-template <bool GEN = false, class M>
+template <int F = 0, class M>
 __device__ __forceinline__ int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
                                                     int mode, double value, double reltol_init, Counters& cnt, double* bsave = nullptr, int nref = 0,
                                                     const plh_run* frun = nullptr, double t_fun = 0.0) {
   (void)R;
-  const int it = cell_init_consistent_impl<GEN>(S, tb, Y, YP, res, Ytmp, mode, value, reltol_init, bsave, nref, frun, t_fun);
+  const int it = cell_init_consistent_impl<F>(S, tb, Y, YP, res, Ytmp, mode, value, reltol_init, bsave, nref, frun, t_fun);
   if (it < 0) { cnt_add(cnt, C_INIT, 100); return it; }
   cnt_add(cnt, C_RES, it + 2); cnt_add(cnt, C_JAC, it); cnt_add(cnt, C_FACT, it); cnt_add(cnt, C_SOLVE, it + 1); cnt_add(cnt, C_INIT, it);
   return 0;
@@ -216,7 +225,7 @@ PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
 }
 
 // IDANls + Newton + convergence test.  0 ok, 1 recoverable failure
-template <bool GEN, class M>
+template <int F, class M>
 PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, int mode, double value, int jac_every_step, Counters& cnt, int nref, const plh_run* xrun = nullptr,
                    double* xvalue = nullptr) {
   // (xrun / xvalue: a closure input is re-evaluated inside every residual and leaves the value of its last evaluation behind -- run.value[] of scalar_residual.jl:170 -- for
@@ -241,7 +250,7 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
   for (bool first = true;; first = false) {
     { PL_TIC(); form_iterate(S, I, first); PL_TOC(S, PH_NEWTVEC); }
     if (done) break;                                      // the iterate (yy, yp) now includes the last correction
-    if constexpr (GEN) { if (xrun) { value = expr_eval(S, *xrun, I.tn, S.yy, S.yp); *xvalue = value; } }       // closure input: run.func(t, Y, YP, p) inside every residual (scalar_residual.jl:169-170)
+    if constexpr ((F & GF_EXPR) != 0) { if (xrun) { value = expr_eval(S, *xrun, I.tn, S.yy, S.yp); *xvalue = value; } }       // closure input: run.func(t, Y, YP, p) inside every residual (scalar_residual.jl:169-170)
     if (callLSetup) {
       PL_TIC();
 #ifndef PL_EXP_NO_JAC
@@ -264,7 +273,7 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
     cnt_add(cnt, C_NEWTON); cnt_add(cnt, C_SOLVE);
     { PL_TIC();
 #ifndef PL_EXP_NO_SOLVE
-    if (GEN && nref > 0) cell_solve_refined(S, R, tb, S.delta, S.yp, I.cjold, mode, false, nref);   // (S.yp is dead until the next form_iterate; cjold = cj of the factors)
+    if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, S.delta, S.yp, I.cjold, mode, false, nref);   // (S.yp is dead until the next form_iterate; cjold = cj of the factors)
     else cell_solve(S, R, S.delta, mode, false);           // x = J^-1 F ; the Newton correction is -x
 #endif
     PL_TOC(S, PH_SOLVE); }
@@ -490,9 +499,10 @@ PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double*
   return st[0];
 }
 // input of a run_function run at run-local time t with the iterate (Y, YP): table or closure
-template <class M>
+template <int F, class M>
 PL_DEV double run_input(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP) {
-  return r.value_kind == PLH_VAL_EXPR ? expr_eval(S, r, t, Y, YP) : tab_eval(r, t);
+  if constexpr ((F & GF_EXPR) != 0) return r.value_kind == PLH_VAL_EXPR ? expr_eval(S, r, t, Y, YP) : tab_eval(r, t);
+  else return tab_eval(r, t);
 }
 // next tstop after run-local time t: the sorted set opts.tstops U {tdiscon - reltol/2} U {1.0 if continuation} U {tf} of postfix_integrator!
 // (model_evaluation.jl:288-310) walked without storing it
@@ -516,7 +526,7 @@ PL_DEV double next_tstop(const plh_opts& o, double t, bool continuation, double 
 }
 
 // one IDASolve(ONE_STEP_TSTOP) call: advances, returns y(tret), y'(tret) in S.yy / S.yp.  0 ok, <0 failure
-template <bool TAB, class M>
+template <int F, class M>
 PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, double tstop, double& tret, int mode, double& value,
                                const plh_opts& o, Counters& cnt, const plh_run* frun = nullptr) {
   PL_MODEL(M);
@@ -548,8 +558,8 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
   if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0 && wave_id() == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; PL_XSYNC(); }
   for (;;) {
     double ck; { PL_TIC(); PL_TICE(3); ck = ida_set_coeffs(S, I); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 0); }
-    if constexpr (TAB) { if (frun) value = run_input(S, *frun, I.tn, S.yy, S.yp); }                           // every residual of this step attempt is evaluated at t = tn
-    const int nflag = ida_nls<TAB>(S, R, tb, I, mode, value, o.jac_every_step, cnt, o.refine, (TAB && frun && frun->value_kind == PLH_VAL_EXPR) ? frun : nullptr, &value);
+    if constexpr ((F & GF_FUNC) != 0) { if (frun) value = run_input<F>(S, *frun, I.tn, S.yy, S.yp); }                           // every residual of this step attempt is evaluated at t = tn
+    const int nflag = ida_nls<F>(S, R, tb, I, mode, value, o.jac_every_step, cnt, o.refine, ((F & GF_EXPR) && frun && frun->value_kind == PLH_VAL_EXPR) ? frun : nullptr, &value);
     int errfail = 0;
     if (nflag == 0) { PL_TIC(); PL_TICE(3); errfail = ida_test_error(S, I, ck, err_k, err_km1); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 1); }
     if (nflag != 0 || errfail) {
@@ -662,9 +672,8 @@ struct CellOut {
 
 // the whole protocol for one cell.  Yprev/YPprev: per-cell scratch in HBM holding the previous accepted point (needed only for
 // the back-interpolation at the end of a run; written with coalesced fire-and-forget stores every step).
-// TAB = the protocol contains time-dependent (tabulated) inputs / tdiscon: a separate instantiation, so that constant-input protocols (the
-// benchmark path) carry none of that code (its mere presence costs ~5 % of the step loop in registers and instruction cache)
-template <bool TAB, class M>
+// F: feature flags (GenFlag): constant-input protocols (the benchmark path) carry none of the general code
+template <int F, class M>
 PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
                                      const CellOut& out, int* n_pts_out, plh_run_info* info, Counters& cnt, double* Yfin, double* YPfin,
                                      double* Yprev, double* YPprev, int cell) {
@@ -682,7 +691,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
   }
   auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
     const double Tav = (M::THERMAL && out.T) ? cellTavg<M>(S, Y) : T0;
-    if constexpr (TAB) if (out.Yall && idx < out.max_pts) { PL_VEC(n) out.Yall[(size_t)idx * NST + n] = Y[n]; }      // outputs = :all
+    if constexpr ((F & GF_STOPS) != 0) if (out.Yall && idx < out.max_pts) { PL_VEC(n) out.Yall[(size_t)idx * NST + n] = Y[n]; }      // outputs = :all
     if (lane == 0 && wave_id() == 0 && idx < out.max_pts) {
       if (out.t) out.t[idx] = tt;
       if (out.V) out.V[idx] = cellV<M>(Y);
@@ -706,9 +715,9 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     else t0 = nextafter(t_global, 1e300);                               // initial_time, model_evaluation.jl:112
     // initial_current! (input_methods.jl:11-74)
     double value = run.value, Iguess;
-    const bool is_tab = TAB && (run.value_kind == PLH_VAL_TABLE || run.value_kind == PLH_VAL_EXPR);      // run_function
+    const bool is_tab = (F & GF_FUNC) && (run.value_kind == PLH_VAL_TABLE || run.value_kind == PLH_VAL_EXPR);      // run_function
     if (is_tab) {                                                       // run_function: initial_current!, input_methods.jl:28-34, 65-76, 104-107, 143-153
-      value = run_input(S, run, 0.0, S.yy, S.yp);
+      value = run_input<F>(S, run, 0.0, S.yy, S.yp);
       if (mode == PLH_MODE_I) Iguess = value;
       else if (mode == PLH_MODE_P) Iguess = value / (cellV<M>(S.yy) * S.cc.I1C);
       else if (have_prev) Iguess = prev_I;
@@ -747,10 +756,10 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     bool first_init = true, again = false, init_failed = false;
     do {                                                                // (re)initialise -> integrate ; loops only for check_reinitialization!
     again = false;
-    int ierr; { PL_TIC(); ierr = cell_init_consistent<TAB>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt, S.phi[0], o.refine,
-                                                                       (TAB && run.value_kind == PLH_VAL_EXPR) ? &run : nullptr, t_restart); PL_TOC(S, PH_INIT); }
+    int ierr; { PL_TIC(); ierr = cell_init_consistent<F>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt, S.phi[0], o.refine,
+                                                                       ((F & GF_EXPR) && run.value_kind == PLH_VAL_EXPR) ? &run : nullptr, t_restart); PL_TOC(S, PH_INIT); }
     if (ierr != 0) { if (first_init) init_failed = true; else flag = ierr; ri.flag = ierr; break; }
-    if constexpr (TAB) { if (o.yp_alg_zero) { PL_VEC(n) if (n >= NDIFF) S.yp[n] = 0.0; PL_XSYNC(); } }     // plh_opts.yp_alg_zero (general instantiation only)
+    if constexpr ((F & GF_STOPS) != 0) { if (o.yp_alg_zero) { PL_VEC(n) if (n >= NDIFF) S.yp[n] = 0.0; PL_XSYNC(); } }     // plh_opts.yp_alg_zero
     ida_reinit(S, I, S.yy, S.yp, first_init ? (o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD) : I.maxord, t_restart);
     if (first_init) {
       first_init = false;
@@ -763,9 +772,9 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     while (flag == PLH_FLAG_RUNNING) {
       double tret = t; tprev = t;
       double tstop_now;
-      if constexpr (TAB) tstop_now = next_tstop(o, t, continuation, run.tf);
+      if constexpr ((F & GF_STOPS) != 0) tstop_now = next_tstop(o, t, continuation, run.tf);
       else tstop_now = (continuation && run.tf > 1.0 && t < 1.0) ? 1.0 : run.tf;
-      const int sf = ida_step<TAB>(S, R, tb, I, tstop_now, tret, mode, value, o, cnt, is_tab ? &run : nullptr);
+      const int sf = ida_step<F>(S, R, tb, I, tstop_now, tret, mode, value, o, cnt, is_tab ? &run : nullptr);
       if (sf != 0) {
         if (I.nst == 0 && !stalled_once) {                              // check_solve, checks.jl:227-237
           stalled_once = true;
@@ -796,8 +805,8 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
         PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }      // fire-and-forget: read back only when a bound fires
 #endif
         t_prev_saved = t + t0; I_prev_pt = S.yy[O_I];
-        if constexpr (TAB) if (is_tab && t - tprev < 1e-3 * o.reltol) {                    // check_reinitialization!, checks.jl:341-364
-          const double t_new = t + o.reltol, v_new = run_input(S, run, t_new, S.yy, S.yp);
+        if constexpr ((F & GF_FUNC) != 0) if (is_tab && t - tprev < 1e-3 * o.reltol) {                    // check_reinitialization!, checks.jl:341-364
+          const double t_new = t + o.reltol, v_new = run_input<F>(S, run, t_new, S.yy, S.yp);
           const double big = fabs(value) > fabs(v_new) ? fabs(value) : fabs(v_new);
           const double tolv = o.abstol > o.reltol * big ? o.abstol : o.reltol * big;
           if (!(fabs(value - v_new) <= tolv)) { value = v_new; t_restart = t_new; again = true; }
@@ -806,7 +815,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       PL_TOC(S, PH_OUTPUT); PL_TOCE(S, 3, 6);
       if (again) break;                                                 // back to the consistent initialisation at t_restart
     }
-    } while (TAB && again && flag == PLH_FLAG_RUNNING);
+    } while ((F & GF_FUNC) && again && flag == PLH_FLAG_RUNNING);
     if (init_failed) { if (lane == 0) info[r] = ri; for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; info[q] = z; } break; }
     double t_end = t + t0;
     if (flag > 0 && o.interp_final && t > 1.0) {                        // interp_final_points!, model_evaluation.jl:369-382

@@ -76,9 +76,11 @@ __device__ __forceinline__ int tsec_of(int it) { return it < NA ? 0 : (it < NA +
 template <class M>
 PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th) {
   static_assert(M::CHEM == PLH_CHEM_LCO_LIC6 && !M::SEI, "temperature = true is instantiated for LCO/LiC6 without aging");
-  // Other grids are not offered with temperature = true: the elimination assumes N_p = N_n (the two T rows with a far-behind entry become final at the same stage of their
-  // chains), the collector chains N_a = N_z, and the thermal Jacobian decode N_r = 10 -- measured: N_s alone may change, anything else fails the solve / Jacobian self-checks
-  static_assert(!M::THERMAL || GRID_DEFAULT || (NP == 10 && NN == 10 && NR == 10 && NA == 10 && NZ == 10), "temperature = true: only N_s may differ from the default discretisation");
+  // Discretisations with temperature = true (reference src/params.jl:119-136 takes any N_p, N_s, N_n, N_a, N_z, N_r).  What the elimination needs: each electrode inside its
+  // own half of the twisted sweeps (the T rows of nodes N_p - 1 and N_p + N_s reach back to a second neighbour that must already be final in the same chain), at least four
+  // nodes per electrode (those rows' one-sided stencils), one lane per temperature node and per collector row.
+  static_assert(!M::THERMAL || (NP >= 4 && NN >= 4 && NP <= TW_MID && NN < NE - TW_MID && NA >= 2 && NZ >= 2 && NA + NZ <= 30 && NT <= WAVE),
+                "temperature = true: 4 <= N_p <= (N_p + N_s + N_n) / 2, 4 <= N_n < (N_p + N_s + N_n + 1) / 2, 2 <= N_a, N_z, N_a + N_z <= 30, N_a + N_p + N_s + N_n + N_z <= 64");
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const int* ix = tb->thidx;
@@ -327,12 +329,12 @@ PL_DEV void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const 
   const int lane = lane_id();
   const CellConst& c = S.cc;
   auto& TP = S.th;
-  const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
+  const int r = lane % NR, g = lane < CS_LANES ? lane / NR : CS_G - 1;
   double Mrow[NR], Wrow[NR];
   for (int k = 0; k < NR; k++) { Mrow[k] = tb->Mp()[r * NR + k]; if (WANT_JAC) Wrow[k] = tb->Wp()[r * NR + k]; }
 #pragma unroll
-  for (int pass = 0; pass < 4; pass++) {
-    const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
+  for (int pass = 0; pass < CS_PASS; pass++) {
+    const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
     double acc = 0.0, wc = 0.0;
 #pragma unroll
     for (int k = 0; k < NR; k++) { const double v = Y[O_CS + p * NR + k]; acc += Mrow[k] * v; if (WANT_JAC) wc += Wrow[k] * v; }
@@ -340,7 +342,7 @@ PL_DEV void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const 
     const double jv = Y[O_J + p], ypv = YP[O_CS + p * NR + r];
     double rhs = TP.kapP[p] * acc;
     if (r == NR - 1) rhs += (p < NP ? c.bj_p : c.bj_n) * jv;
-    if (lane < 60 && p0 < NJ) { Fo[O_CS + p * NR + r] = rhs - ypv; if (WANT_JAC) TP.AinvQ[p][r] = wc; }
+    if (lane < CS_LANES && p0 < NJ) { Fo[O_CS + p * NR + r] = rhs - ypv; if (WANT_JAC) TP.AinvQ[p][r] = wc; }
   }
 }
 
@@ -424,10 +426,13 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
   if (far_behind) for (int k = 0; k < 4; k++) qf[k] = TPs.qfar[nd == NP - 1 ? 0 : 1][k];
   double y[NRHS][4];
   for (int q = 0; q < NRHS; q++) for (int k = 0; k < 4; k++) { if (!act) r[q][k] = 0.0; y[q][k] = r[q][k]; }
-  constexpr int FAR_STAGE = NP - 3;                          // = 7: nodes 7 and 22 are final after 7 stages of their chains
+  // nodes N_p - 3 (top chain) and N_p + N_s + 2 (bottom chain) are final after FAR_T = N_p - 3 and FAR_B = N_n - 3 stages of their chains (7 and 7 on the default
+  // grid: one interruption of the stage loop serves both; two when N_p != N_n)
+  constexpr int FAR_T = NP - 3, FAR_B = NN - 3, FAR_LO = FAR_T < FAR_B ? FAR_T : FAR_B, FAR_HI = FAR_T < FAR_B ? FAR_B : FAR_T;
+  constexpr int NSEG = FAR_LO == FAR_HI ? 2 : 3;
 #pragma unroll 1
-  for (int seg = 0; seg < 2; seg++) {
-    const int lo = seg == 0 ? 1 : FAR_STAGE + 1, hi = seg == 0 ? FAR_STAGE + 1 : TW_FWD;
+  for (int seg = 0; seg < NSEG; seg++) {
+    const int lo = seg == 0 ? 1 : (seg == 1 ? FAR_LO + 1 : FAR_HI + 1), hi = seg == 0 ? FAR_LO + 1 : ((seg == 1 && NSEG == 3) ? FAR_HI + 1 : TW_FWD);
 #pragma unroll 2
     for (int itr = lo; itr < hi; itr++) {
 #pragma unroll
@@ -437,13 +442,15 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
         for (int rr = 0; rr < 4; rr++) y[q][rr] = r[q][rr] - (C[rr * 4] * p0 + C[rr * 4 + 1] * p1 + C[rr * 4 + 2] * p2 + C[rr * 4 + 3] * p3);
       }
     }
-    if (seg == 0) {                                         // right-hand side of nodes 9 / 20: minus q . y(node 7 / 22)
+    if (seg < NSEG - 1) {                                   // right-hand side of node N_p - 1 / N_p + N_s: minus q . y(node N_p - 3 / N_p + N_s + 2), once that y is final
+      const int stage = seg == 0 ? FAR_LO : FAR_HI;
+      const bool mine = (nd == NP - 1 && stage == FAR_T) || (nd == NP + NS && stage == FAR_B);
 #pragma unroll
       for (int q = 0; q < NRHS; q++) {
         double d = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; k++) { const double a7 = lane_bcast(y[q][k], tw_lane(NP - 3)), a22 = lane_bcast(y[q][k], tw_lane(NP + NS + 2)); d += qf[k] * (nd == NP - 1 ? a7 : a22); }
-        r[q][3] -= d;                                       // (qf = 0 everywhere else)
+        if (mine) r[q][3] -= d;                             // (qf = 0 in every other lane)
       }
     }
   }
@@ -511,24 +518,24 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
   const int lane = lane_id();
   const CellConst& c = S.cc;
   auto& TP = S.th;
-  const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
+  const int r = lane % NR, g = lane < CS_LANES ? lane / NR : CS_G - 1;
   PL_TICD();
   // 1. particle resolvents in spectral form
   if (!alg_only) {
     if (lane < NJ) TP.kapF[lane] = TP.kapP[lane];
     double Vrow[NR], wl[NR], lm[NR];
     for (int m = 0; m < NR; m++) { Vrow[m] = tb->Vp()[r * NR + m]; wl[m] = tb->Wp()[m * NR + NR - 1]; lm[m] = tb->LAMp()[m]; }
-    double ae[4], aq[4];
-    for (int pass = 0; pass < 4; pass++) {
-      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
+    double ae[CS_PASS], aq[CS_PASS];
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
       const double kp = TP.kapP[p];
       ae[pass] = 0.0; aq[pass] = 0.0;
       for (int m = 0; m < NR; m++) { const double f = Vrow[m] / (kp * lm[m] - cj); ae[pass] += f * wl[m]; aq[pass] += f * lm[m] * TP.AinvQ[p][m]; }   // AinvQ still holds W c
     }
     PL_SYNC();                                             // every lane has read W c before it is overwritten
-    for (int pass = 0; pass < 4; pass++) {
-      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
-      if (lane < 60 && p0 < NJ) { TP.AinvE[p][r] = ae[pass]; TP.AinvQ[p][r] = aq[pass] * TP.dkapP[p]; }
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
+      if (lane < CS_LANES && p0 < NJ) { TP.AinvE[p][r] = ae[pass]; TP.AinvQ[p][r] = aq[pass] * TP.dkapP[p]; }
     }
     // 2. collector chains: (aL, aD - cj, aU) x = rhs by the Thomas algorithm, lane 62 = Al, lane 63 = Cu.  Two fixed right-hand
     //    sides: the coupling to T of the neighbouring cell node (Al: last row, through aU; Cu: first row, through aL) and the column of I
@@ -536,10 +543,12 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       const int q = lane - 62, base = q == 0 ? 0 : NA + NE;
       // (all LDS operands are loaded up front and all results stored at the end: loads interleaved with stores inside the serial
       //  recurrence would cost one LDS round trip per chain node)
-      double aLv[NA], aDv[NA], aUv[NA], cp[NA], cm[NA], fc[NA], fi[NA], xcv[NA], xiv[NA];
-      for (int k = 0; k < NA; k++) { aLv[k] = TP.aL[base + k]; aDv[k] = TP.aD[base + k]; aUv[k] = TP.aU[base + k]; }
+      constexpr int NC = NA > NZ ? NA : NZ;
+      const int nq = q == 0 ? NA : NZ;                      // chain length: aluminium N_a, copper N_z
+      double aLv[NC], aDv[NC], aUv[NC], cp[NC], cm[NC], fc[NC], fi[NC], xcv[NC], xiv[NC];
+      for (int k = 0; k < NC; k++) if (k < nq) { aLv[k] = TP.aL[base + k]; aDv[k] = TP.aD[base + k]; aUv[k] = TP.aU[base + k]; }
       const double qij = TP.qIJ[q];
-      for (int k = 0; k < NA; k++) {
+      for (int k = 0; k < NC; k++) if (k < nq) {
         const double rcpl = (q == 0 && k == NA - 1) ? aUv[k] : ((q == 1 && k == 0) ? aLv[k] : 0.0);
         if (k == 0) { cm[0] = 0.0; cp[0] = 1.0 / (aDv[0] - cj); fc[0] = rcpl; fi[0] = qij; }
         else {
@@ -550,12 +559,12 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
         }
       }
       double xc = 0.0, xi = 0.0;
-      for (int k = NA - 1; k >= 0; k--) {
-        const double up = k < NA - 1 ? aUv[k] : 0.0;
+      for (int k = NC - 1; k >= 0; k--) if (k < nq) {
+        const double up = k < nq - 1 ? aUv[k] : 0.0;
         xc = (fc[k] - up * xc) * cp[k]; xi = (fi[k] - up * xi) * cp[k];
         xcv[k] = xc; xiv[k] = xi;
       }
-      for (int k = 0; k < NA; k++) { TP.cM[q][k] = cm[k]; TP.cP[q][k] = cp[k]; TP.zc[q][k] = xcv[k]; TP.zI[q][k] = xiv[k]; }
+      for (int k = 0; k < NC; k++) if (k < nq) { TP.cM[q][k] = cm[k]; TP.cP[q][k] = cp[k]; TP.zc[q][k] = xcv[k]; TP.zI[q][k] = xiv[k]; }
     }
   }
   PL_SYNC();
@@ -626,7 +635,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     // second-neighbour T-row entries (see thermal_sweeps): nodes 2 / 27 see U_1 / L_28 modified by -fv (x) fw ; nodes 9 / 20 get a modified
     // lower / upper block once the factor of node 7 / 22 is final
     double fv[4] = {0.0, 0.0, 0.0, 0.0}, fw[3] = {0.0, 0.0, 0.0};
-    constexpr int FAR_STAGE = NP - 3;
+    constexpr int FAR_T = NP - 3, FAR_B = NN - 3;          // stage after which the factor of node N_p - 3 (top chain) / N_p + N_s + 2 (bottom chain) is final
     inv4(D, Dinv);
 #pragma unroll 1
     for (int itr = 1; itr < TW_FWD; itr++) {
@@ -668,13 +677,13 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
         if (nd == 2) for (int cc = 0; cc < 3; cc++) fw[cc] = TP.TX2[0][cc];
         if (nd == NE - 3) for (int cc = 0; cc < 3; cc++) fw[cc] = TP.TX2[3][cc];
       }
-      if (itr == FAR_STAGE && !alg_only) {                  // the factor of node 7 (22) is final: fold node 9's (20's) entry on it into L_9 (U_20)
+      if ((itr == FAR_T || itr == FAR_B) && !alg_only) {    // the factor of node N_p - 3 (N_p + N_s + 2) is final: fold node N_p - 1's (N_p + N_s's) entry on it into its L (U)
         double q7[4] = {0.0, 0.0, 0.0, 0.0}, q22[4] = {0.0, 0.0, 0.0, 0.0};
         for (int cc = 0; cc < 3; cc++) for (int k = 0; k < 4; k++) {
           const double d7 = lane_bcast(Dinv[cc * 4 + k], tw_lane(NP - 3)), d22 = lane_bcast(Dinv[cc * 4 + k], tw_lane(NP + NS + 2));
           q7[k] += TP.TX2[1][cc] * d7; q22[k] += TP.TX2[2][cc] * d22;
         }
-        if (nd == NP - 1 || nd == NP + NS) {
+        if ((nd == NP - 1 && itr == FAR_T) || (nd == NP + NS && itr == FAR_B)) {
           const double* q = nd == NP - 1 ? q7 : q22;
           const OffBlk e = nd == NP - 1 ? upper_blk(S, NP - 3, alg_only) : lower_blk(S, NP + NS + 2, alg_only);
           a.Tc -= q[0] * e.ce + q[1] * e.pc + q[3] * e.Tc;
@@ -721,10 +730,8 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       if (lane < NE) v3 = -cj * TP.wT5[tsec_of(NA + ln)];
       // collector part: sum_k vc_k dT_k with dT = zb - zc dT_end - zI xI
       double vc = 0.0, vi = 0.0;
-      for (int k = 0; k < NA; k++) {
-        if (lane == 0) { vc += TP.wT5[tsec_of(k)] * TP.zc[0][k]; vi += TP.wT5[tsec_of(k)] * TP.zI[0][k]; }
-        if (lane == NE - 1) { vc += TP.wT5[tsec_of(NA + NE + k)] * TP.zc[1][k]; vi += TP.wT5[tsec_of(NA + NE + k)] * TP.zI[1][k]; }
-      }
+      if (lane == 0) for (int k = 0; k < NA; k++) { vc += TP.wT5[tsec_of(k)] * TP.zc[0][k]; vi += TP.wT5[tsec_of(k)] * TP.zI[0][k]; }
+      if (lane == NE - 1) for (int k = 0; k < NZ; k++) { vc += TP.wT5[tsec_of(NA + NE + k)] * TP.zc[1][k]; vi += TP.wT5[tsec_of(NA + NE + k)] * TP.zI[1][k]; }
       v3 -= -cj * vc;                                       // -(-cj w) zc
       dI = wave_sum((lane == 0 || lane == NE - 1) ? cj * vi : 0.0);   // -(-cj w) zI
     } else {                                                // PL_MODE_DT_TWIN: -(sum_i w_i d rhs_T,i / d y_alg)
@@ -771,33 +778,35 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
   const int lane = lane_id();
   const CellConst& c = S.cc;
   auto& TP = S.th;
-  const int r = lane % NR, g = lane < 60 ? lane / NR : 5;
+  const int r = lane % NR, g = lane < CS_LANES ? lane / NR : CS_G - 1;
   // a. particle partial solutions w = A_p^-1 b_cs  (two mat-vecs through the spectral form); collector forward/backward substitution
   if (!alg_only) {
     double Wrow[NR], Vrow[NR];
     for (int k = 0; k < NR; k++) { Wrow[k] = tb->Wp()[r * NR + k]; Vrow[k] = tb->Vp()[r * NR + k]; }
     const double lam_r = tb->LAMp()[r];
-    for (int pass = 0; pass < 4; pass++) {
-      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
       double y = 0.0;
       for (int k = 0; k < NR; k++) y += Wrow[k] * b[O_CS + p * NR + k];
-      if (lane < 60 && p0 < NJ) S.yy[O_CS + p * NR + r] = y / (TP.kapF[p] * lam_r - TP.cjf);   // S.yy is dead between a residual and the next form_iterate
+      if (lane < CS_LANES && p0 < NJ) S.yy[O_CS + p * NR + r] = y / (TP.kapF[p] * lam_r - TP.cjf);   // S.yy is dead between a residual and the next form_iterate
     }
     if (lane >= 62) {
       const int q = lane - 62, base = q == 0 ? 0 : NA + NE;
-      double f[NA], bv[NA], cm[NA], au[NA], cpv[NA], xv[NA];
-      for (int k = 0; k < NA; k++) { bv[k] = b[O_T + base + k]; cm[k] = TP.cM[q][k]; au[k] = TP.aU[base + k]; cpv[k] = TP.cP[q][k]; }   // loads first
-      for (int k = 0; k < NA; k++) f[k] = bv[k] - (k > 0 ? cm[k] * f[k - 1] : 0.0);
+      constexpr int NC = NA > NZ ? NA : NZ;
+      const int nq = q == 0 ? NA : NZ;
+      double f[NC], bv[NC], cm[NC], au[NC], cpv[NC], xv[NC];
+      for (int k = 0; k < NC; k++) if (k < nq) { bv[k] = b[O_T + base + k]; cm[k] = TP.cM[q][k]; au[k] = TP.aU[base + k]; cpv[k] = TP.cP[q][k]; }   // loads first
+      for (int k = 0; k < NC; k++) if (k < nq) f[k] = bv[k] - (k > 0 ? cm[k] * f[k - 1] : 0.0);
       double x = 0.0;
-      for (int k = NA - 1; k >= 0; k--) { x = (f[k] - (k < NA - 1 ? au[k] * x : 0.0)) * cpv[k]; xv[k] = x; }
-      for (int k = 0; k < NA; k++) TP.zb[q][k] = xv[k];                                                                                  // stores last
+      for (int k = NC - 1; k >= 0; k--) if (k < nq) { x = (f[k] - (k < nq - 1 ? au[k] * x : 0.0)) * cpv[k]; xv[k] = x; }
+      for (int k = 0; k < NC; k++) if (k < nq) TP.zb[q][k] = xv[k];                                                                     // stores last
     }
     PL_SYNC();
-    for (int pass = 0; pass < 4; pass++) {
-      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1;
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
       double w = 0.0;
       for (int m = 0; m < NR; m++) w += Vrow[m] * S.yy[O_CS + p * NR + m];
-      if (lane < 60 && p0 < NJ && r == NR - 1) S.w9[p] = w;
+      if (lane < CS_LANES && p0 < NJ && r == NR - 1) S.w9[p] = w;
       R.wreg[pass] = w;
     }
   }
@@ -875,18 +884,18 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
   // f. particles: dc = w - A^-1 e_last bj dj - A^-1 q dT
   if (!alg_only) {
     // (unconditional clamped loads first, guarded stores last -- see iso_solve)
-    double ae[4], aq[4], dj[4], dT[4];
+    double ae[CS_PASS], aq[CS_PASS], dj[CS_PASS], dT[CS_PASS];
 #pragma unroll
-    for (int pass = 0; pass < 4; pass++) {
-      const int p0 = pass * 6 + g, p = p0 < NJ ? p0 : NJ - 1, nd = p < NP ? p : p + NS;
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1, nd = p < NP ? p : p + NS;
       ae[pass] = TP.AinvE[p][r]; aq[pass] = TP.AinvQ[p][r]; dj[pass] = b[O_J + p]; dT[pass] = b[O_T + NA + nd];
     }
 #pragma unroll
-    for (int pass = 0; pass < 4; pass++) {
-      const int p = pass * 6 + g;
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      const int p = pass * CS_G + g;
       const double bj = p < NP ? c.bj_p : c.bj_n;
       const double v = R.wreg[pass] - ae[pass] * bj * dj[pass] - aq[pass] * dT[pass];
-      if (lane < 60 && p < NJ) b[O_CS + p * NR + r] = v;
+      if (lane < CS_LANES && p < NJ) b[O_CS + p * NR + r] = v;
     }
   }
   PL_SYNC();

@@ -665,9 +665,12 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
   CHECK_STAGE(s);                                                     // a failed staging allocation must never reach the kernel as a NULL ("not requested") output
   hipEventRecord(cx.ev0, s.st);
-  bool general = opts->n_tdiscon > 0 || opts->n_tstops > 0 || out->Y_all || opts->refine > 0 || opts->yp_alg_zero != 0;     // the general instantiation also carries the per-step state dump (outputs = :all) and the refinement mode
-  for (int r = 0; r < n_runs; r++) general = general || runs[r].value_kind == PLH_VAL_TABLE || runs[r].value_kind == PLH_VAL_EXPR;
-  m->ops->integrate(s.st, a, general);
+  // the instantiation that has the features this call asks for (GenFlag, dfn_integrate.h): 1 = stop times / state dump, 2 = table inputs, 4 = closure inputs, 8 = refinement
+  int features = 0;
+  if (opts->n_tdiscon > 0 || opts->n_tstops > 0 || out->Y_all || opts->yp_alg_zero != 0) features |= 1;
+  for (int r = 0; r < n_runs; r++) { if (runs[r].value_kind == PLH_VAL_TABLE) features |= 1 | 2; if (runs[r].value_kind == PLH_VAL_EXPR) features |= 1 | 2 | 4; }
+  if (opts->refine > 0) features |= 1 | 2 | 4 | 8;
+  m->ops->integrate(s.st, a, features);
   hipEventRecord(cx.ev1, s.st);
   cx.timed = true; m->last = &cx;
   FINISH(s);

