@@ -56,6 +56,8 @@ VARIANTS = {
     # other discretisations (reference src/params.jl:119-136); the name suffix is _g<N_p>_<N_s>_<N_n>_<N_r>
     "lco_iso_g12_7_9_11": dict(cathode="LCO", Np=12, Ns=7, Nn=9, Nrp=11, Nrn=11),
     "nmc_iso_sei_g6_5_8_13": dict(cathode="NMC", aging=True, Np=6, Ns=5, Nn=8, Nrp=13, Nrn=13),
+    # temperature = true on another grid: _g<N_p>_<N_s>_<N_n>_<N_r>_<N_a>_<N_z>
+    "lco_thermal_g8_6_7_11_5_7": dict(cathode="LCO", temperature=True, Np=8, Ns=6, Nn=7, Nrp=11, Nrn=11, Na=5, Nz=7),
 }
 
 

@@ -81,6 +81,9 @@ DECL_VARIANT(lco_iso)
 #ifdef ORC_HAVE_lco_thermal
 DECL_VARIANT(lco_thermal) DECL_THERMAL(lco_thermal)
 #endif
+#ifdef ORC_HAVE_lco_thermal_g8_6_7_11_5_7
+DECL_VARIANT(lco_thermal_g8_6_7_11_5_7) DECL_THERMAL(lco_thermal_g8_6_7_11_5_7)
+#endif
 #ifdef ORC_HAVE_lco_iso_sei
 DECL_VARIANT(lco_iso_sei)
 #endif
@@ -114,7 +117,7 @@ DECL_VARIANT(lco_iso_mhc)
 
 static void set_layout(orc_model* m, int thermal, int aging) {
   if (m->Np == 0) m->Np = m->Ns = m->Nn = 10;   /* (another discretisation: FILL_VARIANT_GRID) */
-  m->Na = m->Nz = 10;
+  if (m->Na == 0) m->Na = m->Nz = 10;           /* (FILL_THERMAL_GRID sets the collector discretisation) */
   if (m->Nrp == 0) m->Nrp = m->Nrn = 10;      /* (1 for the quadratic / polynomial solid-diffusion approximations: one c_s_avg per particle) */
   m->thermal = thermal; m->aging = aging;
   int o = 0;
@@ -139,6 +142,9 @@ static void set_layout(orc_model* m, int thermal, int aging) {
   (m)->Nrp = (m)->Nrn = 0; (m)->has_Q = 0; set_layout(m, th_, ag_); } while (0)
 #define FILL_VARIANT_GRID(m, v, ag_, np_, ns_, nn_, nr_) do { FILL_VARIANT(m, v, 0, ag_); (m)->Np = np_; (m)->Ns = ns_; (m)->Nn = nn_; (m)->Nrp = (m)->Nrn = nr_; \
   set_layout(m, 0, ag_); } while (0)
+#define FILL_THERMAL_GRID(m, v, np_, ns_, nn_, nr_, na_, nz_) do { FILL_VARIANT(m, v, 1, 0); (m)->Np = np_; (m)->Ns = ns_; (m)->Nn = nn_; (m)->Nrp = (m)->Nrn = nr_; \
+  (m)->Na = na_; (m)->Nz = nz_; set_layout(m, 1, 0); (m)->nnz_twin = orc_##v##_NNZ_DT_TWIN; (m)->twin_cols = orc_##v##_dT_twin_cols; \
+  (m)->dT_twin = orc_##v##_dT_twin; (m)->dT_twin_jac = orc_##v##_dT_twin_jac; (m)->dT_weights = orc_##v##_dT_weights; } while (0)
 #define FILL_VARIANT_SD(m, v, nr_, q_) do { FILL_VARIANT(m, v, 0, 0); (m)->Nrp = (m)->Nrn = nr_; (m)->has_Q = q_; set_layout(m, 0, 0); } while (0)
 
 static int get_model(const char* name, orc_model* m) {
@@ -150,6 +156,9 @@ static int get_model(const char* name, orc_model* m) {
     m->nnz_twin = orc_lco_thermal_NNZ_DT_TWIN; m->twin_cols = orc_lco_thermal_dT_twin_cols;
     m->dT_twin = orc_lco_thermal_dT_twin; m->dT_twin_jac = orc_lco_thermal_dT_twin_jac; m->dT_weights = orc_lco_thermal_dT_weights;
     return 0; }
+#endif
+#ifdef ORC_HAVE_lco_thermal_g8_6_7_11_5_7
+  if (!strcmp(name, "lco_thermal_g8_6_7_11_5_7")) { FILL_THERMAL_GRID(m, lco_thermal_g8_6_7_11_5_7, 8, 6, 7, 11, 5, 7); return 0; }
 #endif
 #ifdef ORC_HAVE_lco_iso_sei
   if (!strcmp(name, "lco_iso_sei")) { FILL_VARIANT(m, lco_iso_sei, 0, 1); return 0; }

@@ -89,7 +89,7 @@ class Model:
                                           {"Fickian": "", "quadratic": "_quad", "polynomial": "_poly"}[solid_diffusion], "_nu" if thermodynamic_factor == "nonlinear" else "",
                                           "_mhc" if rxn == "MHC" else "")
         if g != grids.DEFAULT:
-            self.variant += "_g%d_%d_%d_%d" % g[:4]
+            self.variant += "_g%d_%d_%d_%d" % g[:4] + ("_%d_%d" % g[4:] if self.temperature else "")
 
     theta = property(lambda self: self.θ)
 

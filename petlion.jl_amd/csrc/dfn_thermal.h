@@ -77,10 +77,11 @@ template <class M>
 PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th) {
   static_assert(M::CHEM == PLH_CHEM_LCO_LIC6 && !M::SEI, "temperature = true is instantiated for LCO/LiC6 without aging");
   // Discretisations with temperature = true (reference src/params.jl:119-136 takes any N_p, N_s, N_n, N_a, N_z, N_r).  What the elimination needs: each electrode inside its
-  // own half of the twisted sweeps (the T rows of nodes N_p - 1 and N_p + N_s reach back to a second neighbour that must already be final in the same chain), at least four
-  // nodes per electrode (those rows' one-sided stencils), one lane per temperature node and per collector row.
-  static_assert(!M::THERMAL || (NP >= 4 && NN >= 4 && NP <= TW_MID && NN < NE - TW_MID && NA >= 2 && NZ >= 2 && NA + NZ <= 30 && NT <= WAVE),
-                "temperature = true: 4 <= N_p <= (N_p + N_s + N_n) / 2, 4 <= N_n < (N_p + N_s + N_n + 1) / 2, 2 <= N_a, N_z, N_a + N_z <= 30, N_a + N_p + N_s + N_n + N_z <= 64");
+  // own half of the twisted sweeps (the T rows of nodes N_p - 1 and N_p + N_s reach back to a second neighbour that must already be final in the same chain), at least five
+  // nodes per electrode (that second neighbour must not be the node next to the chain head, whose off-diagonal block the head's own one-sided stencil modifies), one lane per
+  // temperature node and per collector row.
+  static_assert(!M::THERMAL || (NP >= 5 && NN >= 5 && NP <= TW_MID && NN < NE - TW_MID && NA >= 2 && NZ >= 2 && NA + NZ <= 30 && NT <= WAVE),
+                "temperature = true: 5 <= N_p <= (N_p + N_s + N_n) / 2, 5 <= N_n < (N_p + N_s + N_n + 1) / 2, 2 <= N_a, N_z, N_a + N_z <= 30, N_a + N_p + N_s + N_n + N_z <= 64");
   const int lane = lane_id();
   const CellConst& c = S.cc;
   const int* ix = tb->thidx;

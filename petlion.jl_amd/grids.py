@@ -6,7 +6,7 @@ another build of csrc/variant_tu.hip -- the counterpart of the reference generat
 model variants for that grid; Model.__init__ registers it with plh_register_grid_library() and then creates the handle as usual.
 
 Limits (static_asserts in csrc/dfn_cell.h / dfn_thermal.h): 2 <= N_p, N_s, N_n; N_p + N_s + N_n <= 48; 10 <= N_r_p = N_r_n <= 16; with temperature = true additionally
-4 <= N_p <= N/2, 4 <= N_n < (N + 1)/2 for N = N_p + N_s + N_n (each electrode inside its own half of the twisted sweeps: the T rows of its last / first node reach back to a
+5 <= N_p <= N/2, 5 <= N_n < (N + 1)/2 for N = N_p + N_s + N_n (each electrode inside its own half of the twisted sweeps: the T rows of its last / first node reach back to a
 second neighbour), 2 <= N_a, N_z, N_a + N_z <= 30, N_a + N + N_z <= 64.  No CPU fallback: without hipcc the build fails loudly."""
 import json
 import os
@@ -53,8 +53,8 @@ def check(grid, thermal=False, sei=False):
         raise ValueError("discretisation: 10 <= N_r_p = N_r_n <= 16 (radial operator tables: tools/gen_radial_tables.py)")
     if thermal:
         ne, mid = p + s + n, (p + s + n) // 2
-        if not (4 <= p <= mid and 4 <= n < ne - mid and a >= 2 and z >= 2 and a + z <= 30 and a + ne + z <= 64):
-            raise NotImplementedError("discretisation with temperature = true: 4 <= N_p <= (N_p + N_s + N_n) / 2, 4 <= N_n < (N_p + N_s + N_n + 1) / 2 (each electrode inside its "
+        if not (5 <= p <= mid and 5 <= n < ne - mid and a >= 2 and z >= 2 and a + z <= 30 and a + ne + z <= 64):
+            raise NotImplementedError("discretisation with temperature = true: 5 <= N_p <= (N_p + N_s + N_n) / 2, 5 <= N_n < (N_p + N_s + N_n + 1) / 2 (each electrode inside its "
                                       "own half of the twisted block sweeps), 2 <= N_a, N_z, N_a + N_z <= 30, N_a + N_p + N_s + N_n + N_z <= 64 (one lane per temperature node)")
 
 

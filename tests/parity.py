@@ -15,10 +15,10 @@ SECTIONS_QUAD = [("c_e", 0, 30), ("c_s", 30, 50), ("j", 50, 70), ("Phi_e", 70, 1
 SECTIONS_POLY = [("c_e", 0, 30), ("c_s", 30, 50), ("Q", 50, 70), ("j", 70, 90), ("Phi_e", 90, 120), ("Phi_s", 120, 140), ("I", 140, 141)]
 
 
-def grid_sections(Np, Ns, Nn, Nr, sei=False):
-    """state sections of an isothermal Fickian model on another discretisation (reference state layout, src/external.jl:275-365)"""
+def grid_sections(Np, Ns, Nn, Nr, sei=False, thermal=None):
+    """state sections of a Fickian model on another discretisation (reference state layout, src/external.jl:275-365); thermal = (N_a, N_z) with temperature = true"""
     out, o = [], 0
-    for name, n in (("c_e", Np + Ns + Nn), ("c_s", (Np + Nn) * Nr)) + ((("film", Nn), ("SOH", 1)) if sei else ()) + (("j", Np + Nn), ("Phi_e", Np + Ns + Nn), ("Phi_s", Np + Nn)) + \
+    for name, n in (("c_e", Np + Ns + Nn), ("c_s", (Np + Nn) * Nr)) + ((("T", thermal[0] + Np + Ns + Nn + thermal[1]),) if thermal else ()) + ((("film", Nn), ("SOH", 1)) if sei else ()) + (("j", Np + Nn), ("Phi_e", Np + Ns + Nn), ("Phi_s", Np + Nn)) + \
                    ((("j_s", Nn),) if sei else ()) + (("I", 1),):
         out.append((name, o, o + n)); o += n
     return out
@@ -26,7 +26,7 @@ def grid_sections(Np, Ns, Nn, Nr, sei=False):
 
 # (keyed by the number of states: every model the tests build has its own)
 SECTION_TABLES = {301: SECTIONS, 322: SECTIONS_SEI, 351: SECTIONS_THERMAL, 121: SECTIONS_QUAD, 141: SECTIONS_POLY,
-                  330: grid_sections(12, 7, 9, 11), 266: grid_sections(6, 5, 8, 13, sei=True)}
+                  330: grid_sections(12, 7, 9, 11), 266: grid_sections(6, 5, 8, 13, sei=True), 271: grid_sections(8, 6, 7, 11, thermal=(5, 7))}
 
 
 def sections_for(n_states):
@@ -61,9 +61,10 @@ def check_keys_and_pattern(p, O):
         assert Z == 2139
     if p.variant in ("lco_iso_sei", "nmc_iso_sei"):
         assert Z == 2269
-    if p.temperature:
+    if p.variant == "lco_thermal":
         assert Z == 2883
-    for mode, nnz_expect in ((0, Z), (1, Z + 1), (3, Z + 2), (4, Z + 1)) + (((2, 2932),) if p.temperature else ()):
+    nT = (p.ind["T"].stop - p.ind["T"].start) if p.temperature else 0      # the dT control row has one entry per temperature node (2883 - 1 + 50 = 2932 on the default grid)
+    for mode, nnz_expect in ((0, Z), (1, Z + 1), (3, Z + 2), (4, Z + 1)) + (((2, Z - 1 + nT),) if p.temperature else ()):
         cp, ri = p.jac_pattern(mode)
         ocp, ori, _ = O.jacobian(VARIANT, th, np.ones(N), np.zeros(N), 1.0, mode, 0.0)
         assert len(ri) == nnz_expect

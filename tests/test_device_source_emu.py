@@ -516,9 +516,10 @@ def test_f4_lgm50_chemistry(emu_models_f4, O, pkg):
 
 # ---- other discretisations (reference src/params.jl:119-136): the kernels of another grid are one more build of the same device source -------------------------
 def emu_grid_model(pkg, cathode, grid, variant_id, **kw):
+    """grid = (N_p, N_s, N_n, N_r) or, with temperature = true, (N_p, N_s, N_n, N_r, N_a, N_z)"""
     import build_emu
-    g = tuple(grid) + (10, 10)
-    return pkg.petlion(cathode, N_p=grid[0], N_s=grid[1], N_n=grid[2], N_r_p=grid[3], N_r_n=grid[3], _lib_path=build_emu.build(), _grid_lib=build_emu.build_grid(g, [variant_id]), **kw)
+    g = tuple(grid) + (10, 10) if len(grid) == 4 else tuple(grid)
+    return pkg.petlion(cathode, N_p=g[0], N_s=g[1], N_n=g[2], N_r_p=g[3], N_r_n=g[3], N_a=g[4], N_z=g[5], _lib_path=build_emu.build(), _grid_lib=build_emu.build_grid(g, [variant_id]), **kw)
 
 
 def check_grid_model(p, O, pkg, identical=True):
@@ -544,6 +545,36 @@ def test_other_discretisation_lco_12_7_9_11(pkg, O):
     check_grid_model(emu_grid_model(pkg, pkg.LCO, (12, 7, 9, 11), 0), O, pkg)
 
 
+def check_thermal_grid_model(p, O, pkg):
+    """temperature = true on another grid (N_p != N_n, N_a != N_z, N_r != 10) against the oracle variant generated for it: pattern, evaluators in every mode incl. dT,
+    consistent initialisation, a 1C discharge with identical decisions, and the CC-CT-CV protocol (CC leg at 1e-6, hold legs at the default-tolerance floor)"""
+    check_grid_model(p, O, pkg)
+    ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 1), CC_CT_CV, SOC=0.0)
+    ro = O.simulate(p.variant, p.theta_vector(), 0.0, parity.runs_to_oracle(O, p, pkg, CC_CT_CV))
+    fl = [int(f) for f in ens.run_info[0]["flag"]]
+    assert fl == [r["flag"] for r in ro["runs"]] == [5, 2, 4]
+    assert int(ens.run_info[0, 0]["iterations"]) == ro["runs"][0]["iterations"] and abs(ens.run_info[0, 0]["t_end"] - ro["runs"][0]["t_end"]) < 1e-6 * ro["runs"][0]["t_end"]
+    for k in (1, 2):
+        assert abs(ens.run_info[0, k]["t_end"] - ro["runs"][k]["t_end"]) < (2e-3, 1e-2)[k - 1] * ro["runs"][k]["t_end"], k
+
+
+def test_other_discretisation_thermal_8_6_7_11_5_7(pkg, O):
+    """LCO with temperature = true on N_p = 8, N_s = 6, N_n = 7, N_r = 11, N_a = 5, N_z = 7 (271 states): the two far-behind T rows become final at different stages of their
+    chains, the collector chains have different lengths, five particles per pass"""
+    check_thermal_grid_model(emu_grid_model(pkg, pkg.LCO, (8, 6, 7, 11, 5, 7), 4, temperature=True), O, pkg)
+
+
+@pytest.mark.parametrize("grid", [(5, 9, 5, 10, 2, 3), (9, 4, 6, 12, 12, 4), (12, 8, 12, 10, 10, 10)])
+def test_thermal_extreme_discretisations(pkg, grid):
+    """temperature = true at the limits of what the elimination takes (five nodes per electrode, an electrode filling its half of the sweeps, two-node collectors, an odd
+    number of nodes): evaluators self-consistent and equal to the oracle's Python restatement in the I, V and dT modes, and the CC-CT-CV protocol runs through"""
+    from oracle import dfn_model as dm
+    p = emu_grid_model(pkg, pkg.LCO, grid, 4, temperature=True)
+    check_grid_self_consistency(p, pkg, dm)
+    ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 1), CC_CT_CV, SOC=0.0)
+    assert [int(f) for f in ens.run_info[0]["flag"]] == [5, 2, 4] and abs(ens.run_info[0, 1]["T_avg"] - 313.15) < 1e-3
+
+
 def test_other_discretisation_nmc_sei_6_5_8_13(pkg, O):
     """NMC + SEI on N_p = 6, N_s = 5, N_n = 8, N_r = 13 (266 states): an odd number of nodes (the two halves of the twisted sweeps differ by one), four particles per pass"""
     check_grid_model(emu_grid_model(pkg, pkg.NMC, (6, 5, 8, 13), 3, aging="SEI"), O, pkg, identical=False)
@@ -553,7 +584,7 @@ def check_grid_self_consistency(p, pkg, dm, n_fd=6):
     """grids without a generated oracle variant: the device residual against the oracle's PYTHON restatement evaluated directly (oracle/dfn_model.py, FloatOps), the
     device Jacobian against central differences of the device residual, the device solve against a dense solve of the device Jacobian"""
     lib, h, N = p._lib, p._h, p.N.tot
-    model = dm.Model(cathode="LCO", Np=p.N.p, Ns=p.N.s, Nn=p.N.n, Nrp=p.N.r_p, Nrn=p.N.r_n)
+    model = dm.Model(cathode="LCO", temperature=p.temperature, Np=p.N.p, Ns=p.N.s, Nn=p.N.n, Nrp=p.N.r_p, Nrn=p.N.r_n, **(dict(Na=p.N.a, Nz=p.N.z) if p.temperature else {}))
     assert model.lay.N == N
     th = p.theta_vector()[None, :].copy()
     thd = dict(model.theta); thd.update(dict(zip(p.θ_keys, th[0])))
@@ -563,7 +594,9 @@ def check_grid_self_consistency(p, pkg, dm, n_fd=6):
     assert lib.plh_initial_guess(h, 1, th.ctypes.data, soc.ctypes.data, Yd.ctypes.data, 0, None) == 0
     assert np.allclose(Yd[0, :-1], Y[0, :-1], rtol=1e-13, atol=0)
     Y *= 1 + 1e-3 * rng.standard_normal(Y.shape); YP = 1e-4 * np.abs(Y) * rng.standard_normal(Y.shape)
-    for mode, val in ((0, -1.0), (1, 3.9)):
+    if p.temperature:                                           # a temperature profile with gradients, so that every conduction / heat-source term is exercised
+        Y[0, p.ind["T"]] += 3.0 * np.sin(np.linspace(0.0, 3.0, p.ind["T"].stop - p.ind["T"].start))
+    for mode, val in ((0, -1.0), (1, 3.9)) + (((2, 0.01),) if p.temperature else ()):
         def F_of(y):
             F = np.zeros((1, N)); y = np.ascontiguousarray(y)
             assert lib.plh_residual(h, 1, th.ctypes.data, y.ctypes.data, YP.ctypes.data, mode, val, F.ctypes.data, 0, None) == 0
@@ -607,7 +640,8 @@ def test_extreme_discretisations(pkg, grid):
 
 
 def test_unsupported_discretisations_refuse(pkg, emu_model):
-    for kw in (dict(N_p=40, N_s=10, N_n=10), dict(N_r_p=9, N_r_n=9), dict(N_r_p=12, N_r_n=10), dict(N_p=1)):
+    for kw in (dict(N_p=40, N_s=10, N_n=10), dict(N_r_p=9, N_r_n=9), dict(N_r_p=12, N_r_n=10), dict(N_p=1), dict(temperature=True, N_p=4), dict(temperature=True, N_p=20, N_s=4, N_n=6),
+               dict(temperature=True, N_a=20, N_z=20)):
         with pytest.raises((ValueError, NotImplementedError)):
             pkg.petlion(pkg.LCO, **kw)
     with pytest.raises(pkg._capi.PetlionHipError, match="plh_register_grid_library"):       # the C ABI itself: an unregistered grid is refused with the way out in the message

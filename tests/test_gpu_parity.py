@@ -526,6 +526,7 @@ def test_other_discretisations(pkg, O, hip_model):
     from oracle import dfn_model as dm
     te.check_grid_model(pkg.petlion(pkg.LCO, N_p=12, N_s=7, N_n=9, N_r_p=11, N_r_n=11), O, pkg)
     te.check_grid_model(pkg.petlion(pkg.NMC, aging="SEI", N_p=6, N_s=5, N_n=8, N_r_p=13, N_r_n=13), O, pkg, identical=False)
+    te.check_thermal_grid_model(pkg.petlion(pkg.LCO, temperature=True, N_p=8, N_s=6, N_n=7, N_r_p=11, N_r_n=11, N_a=5, N_z=7), O, pkg)      # temperature = true off the default grid
     n = 1024
     for grid in ((2, 2, 2, 10), (16, 16, 16, 16), (5, 3, 20, 12)):
         p = pkg.petlion(pkg.LCO, N_p=grid[0], N_s=grid[1], N_n=grid[2], N_r_p=grid[3], N_r_n=grid[3])
