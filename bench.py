@@ -113,10 +113,11 @@ def cpu_baseline(cfg_name, c, p, pkg, inp, seconds):
     return one, allc
 
 
-def host_inclusive(pkg, p, inp, n_local, kernel_ms, calls=12):
+def host_inclusive(pkg, p, inp, n_local, kernel_ms, calls=None):
     """wall time of the batched call with Theta starting in host memory and the per-cell summaries + sampled outputs (t, V per saved point) ending there:
-    a depth-2 PLH_HOST_ASYNC pipeline over pinned buffers; per-call time = interval between successive completions, median of `calls`."""
+    a depth-2 PLH_HOST_ASYNC pipeline over pinned buffers; per-call time = interval between successive completions, median of `calls` (>= 12, and enough for >= 0.5 s)."""
     import torch
+    calls = calls or int(min(600, max(12, np.ceil(600.0 / max(kernel_ms, 1e-3)))))
     pipe = pkg.api.HostPipeline(p, n_local, inp["protocol"], SOC=inp["SOC"], max_points=inp["max_points"], depth=2)
     Th = inp["theta"]
     for k in range(4):                                   # warm-up: staging blocks, per-stream workspaces
@@ -201,8 +202,8 @@ def general_path(pkg, p, inp, Theta, n_local, kernel_ms, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400, help="timed launches (default: 0.6 s of C2 launches; the kernel needs 1.5 ms)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--cells-per-gpu", type=int, default=0)
     ap.add_argument("--precision", default="f64", choices=("f64", "mixed"))

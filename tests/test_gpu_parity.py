@@ -602,3 +602,29 @@ def test_notebook_step_history_on_gpu(hip_model, pkg):
     """the reference notebook's printed IDA step history (121 points, V[1:13] to 1e-8, c_e[1:5] to 1e-7) reproduced by the HIP integrator (opts.yp_alg_zero)"""
     import test_device_source_emu as te
     te.check_notebook_step_history_device(hip_model, pkg)
+
+
+def test_c5_full_size_8192_cells_properties(hip_model_nmc_sei, pkg):
+    """config C5 at its FULL size in one launch (8192 NMC + SEI cells, the 20-pulse GITT protocol; 8 GPUs share it as 1024-cell shards): size-independent properties of every
+    trajectory, and the 1024-cell shard of rank 5 integrated on its own gives bitwise the same answers"""
+    import torch
+    p = hip_model_nmc_sei
+    n = 8192
+    cfg = pkg.configs.c5(p, n)
+    Th = torch.from_numpy(np.ascontiguousarray(cfg["theta"])).cuda()
+    ens = pkg.simulate_ensemble(p, Th, cfg["protocol"], SOC=0.0, device=True, max_points=cfg["max_points"])
+    torch.cuda.synchronize()
+    fl, soc = ens.run_info["flag"], ens.run_info["SOC"]
+    assert (fl >= 0).all()                                              # no solver failure in any of the 8192 x 40 runs
+    assert np.isin(fl[:, 0::2], (0, 2, 4)).all() and (fl[:, 1::2] == 0).all()
+    full = (fl[:, :-2] == 0).all(axis=1)
+    assert full.mean() > 0.5 and np.abs(soc[full, -3] - 19 * 180 / 3600).max() < 1e-6      # coulomb counting over 19 complete pulses
+    assert (np.diff(soc[:, 0::2], axis=1) > 0).all() and np.abs(soc[:, 1::2] - soc[:, 0::2]).max() < 1e-12
+    Y = ens.Y.cpu().numpy()
+    film, soh = Y[:, p.ind["film"]], Y[:, p.ind["SOH"]][:, 0]
+    assert (film > 0).all() and (soh < 1.0).all() and (soh > 1 - 1e-3).all()
+    steps = ens.counters["n_steps"]
+    print("C5 at 8192 cells: kernel %.1f ms (%.0f protocols/s), steps per cell %d .. %d, %d cells complete all 20 pulses" % (ens.kernel_ms, n / ens.kernel_ms * 1e3, steps.min(), steps.max(), int(full.sum())))
+    shard = pkg.simulate_ensemble(p, Th[5 * 1024:6 * 1024], cfg["protocol"], SOC=0.0, device=True, max_points=cfg["max_points"])
+    torch.cuda.synchronize()
+    assert (shard.Y.cpu().numpy() == Y[5 * 1024:6 * 1024]).all()
