@@ -53,6 +53,7 @@ VARIANTS = {
     "lco_iso_nu": dict(cathode="LCO", thermodynamic_factor="nonlinear"),
     "lco_iso_mhc": dict(cathode="LCO", rxn="MHC"),
     "lgm50_iso": dict(cathode="LGM50"),                  # NMC_LGM50 + LiC6_LGM50 (Chen et al. 2020), reference src/params.jl:514-849
+    "lgm50_thermal": dict(cathode="LGM50", temperature=True),      # ... with temperature = true, the reference default of that chemistry (params.jl:695)
     # other discretisations (reference src/params.jl:119-136); the name suffix is _g<N_p>_<N_s>_<N_n>_<N_r>
     "lco_iso_g12_7_9_11": dict(cathode="LCO", Np=12, Ns=7, Nn=9, Nrp=11, Nrn=11),
     "nmc_iso_sei_g6_5_8_13": dict(cathode="NMC", aging=True, Np=6, Ns=5, Nn=8, Nrp=13, Nrn=13),

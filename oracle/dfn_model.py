@@ -159,6 +159,11 @@ def theta_LGM50():
     th["c_max_n"] = 33133.0; th["Rp_n"] = 5.86e-6; th["Ea_D_sn"] = 3.03e4; th["Ea_k_n"] = 35000.0
     th["D_e"] = 8.794e-11; th["l_s"] = 12e-6; th["ϵ_s"] = 0.47; th["brugg_s"] = 1.5; th["t₊"] = 0.2594
     th["c_e₀"] = 1000.0; th["T₀"] = 25 + 273.15; th["T_amb"] = 25 + 273.15
+    # heat equation (temperature = true is the reference default of this chemistry): params.jl:531-533 (cathode), 593-595 (anode), 779-800 (system)
+    th["λ_p"] = 2.1; th["ρ_p"] = 3262.0; th["Cp_p"] = 700.0; th["λ_n"] = 1.7; th["ρ_n"] = 1657.0; th["Cp_n"] = 700.0
+    th["l_a"] = 16e-6; th["l_z"] = 12e-6; th["σ_a"] = 36.914e6; th["σ_z"] = 58.41e6
+    th["λ_s"] = 0.16; th["λ_a"] = 237.0; th["λ_z"] = 401.0; th["ρ_s"] = 397.0; th["ρ_a"] = 2700.0; th["ρ_z"] = 8960.0
+    th["Cp_s"] = 700.0; th["Cp_a"] = 897.0; th["Cp_z"] = 385.0; th["h_cell"] = 1.0
     return th
 
 
@@ -265,8 +270,8 @@ class Model:
         self.solid_diffusion, self.thermodynamic_factor, self.rxn = solid_diffusion, thermodynamic_factor, rxn
         self.lay = Layout(temperature=temperature, aging=aging, solid_diffusion=solid_diffusion, **Nkw)
         self.theta = {"LCO": theta_LCO, "NMC": theta_NMC, "LGM50": theta_LGM50}[cathode]()
-        if cathode == "LGM50" and (temperature or aging):
-            raise ValueError("LGM50 is built isothermal without aging")
+        if cathode == "LGM50" and aging:
+            raise ValueError("LGM50 is built without aging (its SEI / stress parameters belong to aging models the reference marks unused)")
         if cathode == "NMC" and temperature:
             raise ValueError("the reference NMC chemistry defines no thermal parameters (params.jl:295-367)")
         self.bounds = dict(BOUNDS_DEFAULT[cathode])

@@ -123,11 +123,7 @@ def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_
     """petlion(cathode; kwargs...) -- reference src/params.jl:119-174.  `jacobian` is accepted and ignored (the device
     Jacobian is hand-derived); unsupported structural options raise."""
     if temperature is None:
-        # the reference's LGM50 system defaults to temperature = true (src/params.jl, system_LGM50_NMC_LiC6 kwargs); only its isothermal variant is instantiated on the
-        # device, so the choice must be explicit there instead of silently different physics
-        if cathode == NMC_LGM50:
-            raise NotImplementedError("petlion(NMC_LGM50): the reference default is temperature=true, which is not instantiated on the device; pass temperature=False explicitly")
-        temperature = False
+        temperature = cathode == NMC_LGM50       # the reference's defaults: system_LGM50_NMC_LiC6 has temperature = true (src/params.jl:695), LCO / NMC false (139, 389)
     if solid_diffusion not in ("Fickian", "quadratic", "polynomial") or (solid_diffusion == "Fickian" and Fickian_method != "finite_difference"):
         raise NotImplementedError("solid diffusion: Fickian (finite_difference), quadratic and polynomial are built; the BETA spectral method is not (SURVEY.md 8f)")
     if thermodynamic_factor not in ("linear", "nonlinear") or rxn_p not in ("BV", "MHC") or rxn_n != rxn_p:

@@ -75,7 +75,7 @@ __device__ __forceinline__ int tsec_of(int it) { return it < NA ? 0 : (it < NA +
 // ------------------------------------------------------------------------------------------------------------------
 template <class M>
 PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th) {
-  static_assert(M::CHEM == PLH_CHEM_LCO_LIC6 && !M::SEI, "temperature = true is instantiated for LCO/LiC6 without aging");
+  static_assert((M::CHEM == PLH_CHEM_LCO_LIC6 || M::CHEM == PLH_CHEM_LGM50) && !M::SEI, "temperature = true is instantiated for LCO/LiC6 and NMC_LGM50/LiC6_LGM50 without aging");
   // Discretisations with temperature = true (reference src/params.jl:119-136 takes any N_p, N_s, N_n, N_a, N_z, N_r).  What the elimination needs: each electrode inside its
   // own half of the twisted sweeps (the T rows of nodes N_p - 1 and N_p + N_s reach back to a second neighbour that must already be final in the same chain), at least five
   // nodes per electrode (that second neighbour must not be the node next to the chain head, whose off-diagonal block the head's own one-sided stencil modifies), one lane per
@@ -152,9 +152,13 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
   const double h = sc == 0 ? h0 : (sc == 1 ? h1 : h2);
   const double epsc = c.eps[sc], bfc = c.bf[sc];
   const double cKfac = c.Kfac, ctplus = c.tplus, cI1C = c.I1C;
-  double K, dKc, dKT; keff_T(ce, T, K, dKc, dKT);
+  constexpr bool LGM = M::CHEM == PLH_CHEM_LGM50;                       // K_eff_LGM50(c_e), D_eff_LGM50(c_e), tanh OCVs with dU/dT = 0 (reference src/params.jl:563-672)
+  double K, dKc, dKT;
+  if constexpr (LGM) { keff_lgm50(ce, K, dKc); dKT = 0.0; } else keff_T(ce, T, K, dKc, dKT);
   K *= bfc; dKc *= bfc; dKT *= bfc;
-  const double D = c.Dc[sc];                                            // D_eff_linear: no c_e / T dependence (custom_functions.jl:59-69)
+  double D, dD = 0.0;
+  if constexpr (LGM) { deff_lgm50(ce, c.De, D, dD); D *= bfc; dD *= bfc; }
+  else D = c.Dc[sc];                                                    // D_eff_linear: no c_e / T dependence (custom_functions.jl:59-69)
   const double ce_n = shift_down1(ce), pe_n = shift_down1(pe), K_n = shift_down1(K), dKc_n = shift_down1(dKc), dKT_n = shift_down1(dKT), T_n = shift_down1(T);
   const double ce_p = shift_up1(ce), pe_p = shift_up1(pe);
   // reciprocals of per-cell constants come from cell_setup (see iso_node_pass)
@@ -165,7 +169,10 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
   const bool edge = i < NE - 1;
   const double rdenK = 1.0 / (beta * K_n + (1 - beta) * K), Kh = K * K_n * rdenK;
   const double D_n = shift_down1(D);
-  const double Dhm = (i == NP - 1) ? c.Dh_ps : ((i == NP + NS - 1) ? c.Dh_sn : D);   // constant edge means of D_eff_linear (cell_setup)
+  const double dD_n = (WANT_JAC && LGM) ? shift_down1(dD) : 0.0;
+  double rdenD = 0.0, Dhm;
+  if constexpr (LGM) { rdenD = 1.0 / (beta * D_n + (1 - beta) * D); Dhm = D * D_n * rdenD; }     // harmonic edge mean of D_eff(c_e)
+  else Dhm = (i == NP - 1) ? c.Dh_ps : ((i == NP + NS - 1) ? c.Dh_sn : D);   // constant edge means of D_eff_linear (cell_setup)
   const double denC = beta * ce_n + (1 - beta) * ce, rcb = denC / (ce * ce_n);
   const double rdenT = 1.0 / (beta * T_n + (1 - beta) * T), Tb = T * T_n * rdenT;
   const double dc = (ce_n - ce) * rdist;
@@ -188,8 +195,13 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
   if (act && elec) { TP.kapP[jx] = kap; if (WANT_JAC) TP.dkapP[jx] = kap * EaD * rT * rT; }
   double U = 0, dU = 0, dUdT = 0, ddUdT = 0;
   const double rcm = sc == 0 ? c.rcm_p : c.rcm_n, rsg = sc == 0 ? c.rsg_p : c.rsg_n;
-  if (sc == 0) ocv_lco_T(cs * rcm, T, U, dU, dUdT, ddUdT);
-  else if (sc == 2) ocv_lic6_T(cs * rcm, T, U, dU, dUdT, ddUdT);
+  if constexpr (LGM) {
+    if (sc == 0) ocv_nmc_lgm50(cs * rcm, U, dU);
+    else if (sc == 2) ocv_lic6_lgm50(cs * rcm, U, dU);
+  } else {
+    if (sc == 0) ocv_lco_T(cs * rcm, T, U, dU, dUdT, ddUdT);
+    else if (sc == 2) ocv_lic6_T(cs * rcm, T, U, dU, dUdT, ddUdT);
+  }
   const double eta = ps - pe - U;
   const double arg = ce * cs * (cmax - cs);
   const double sq = sqrt(arg > 0.0 ? arg : 0.0);
@@ -276,7 +288,8 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
     const double ETa = edge ? (pe - pe_n) * dKh_a * dKT * rdist + cKfac * gq * (dKh_a * dKT * Tb + Kh * dTb_a) : 0.0;
     const double ETb = edge ? (pe - pe_n) * dKh_b * dKT_n * rdist + cKfac * gq * (dKh_b * dKT_n * Tb + Kh * dTb_b) : 0.0;
     const double we = edge ? w : 0.0;
-    const double Na = edge ? -Dhm * rdist : 0.0, Nb = edge ? Dhm * rdist : 0.0;
+    const double dDh_a = LGM ? dD * beta * D_n * D_n * (rdenD * rdenD) : 0.0, dDh_b = LGM ? dD_n * (1 - beta) * D * D * (rdenD * rdenD) : 0.0;
+    const double Na = edge ? (dDh_a * (ce_n - ce) - Dhm) * rdist : 0.0, Nb = edge ? (dDh_b * (ce_n - ce) + Dhm) * rdist : 0.0;
     const double Ea_p = shift_up1(Ea), Eb_p = shift_up1(Eb), we_p = shift_up1(we), Na_p = shift_up1(Na), Nb_p = shift_up1(Nb);
     const double ETa_p = shift_up1(ETa), ETb_p = shift_up1(ETb);
     if (act) {
@@ -780,6 +793,7 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
   const CellConst& c = S.cc;
   auto& TP = S.th;
   const int r = lane % NR, g = lane < CS_LANES ? lane / NR : CS_G - 1;
+  PL_TICE(2);
   // a. particle partial solutions w = A_p^-1 b_cs  (two mat-vecs through the spectral form); collector forward/backward substitution
   if (!alg_only) {
     double Wrow[NR], Vrow[NR];
@@ -812,6 +826,7 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
     }
   }
   PL_SYNC();
+  PL_TOCE(S, 2, 0);
   // b. node right-hand sides
   const int nd = tw_node(lane);                   // twisted lane layout of thermal_sweeps
   const bool act = nd >= 0;
@@ -841,12 +856,14 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
     xI = b[O_I];
     if (act) { y[2] -= TP.colI4[0][i] * xI; y[3] -= TP.colI4[1][i] * xI; }
   }
+  PL_TOCE(S, 2, 1);
   // c. block-Thomas sweeps + Woodbury correction
   {
     double ra[1][4] = {{y[0], y[1], y[2], y[3]}};
     thermal_sweeps<1>(S, alg_only, ra);
     for (int cc = 0; cc < 4; cc++) y[cc] = ra[0][cc];
   }
+  PL_TOCE(S, 2, 2);
   // d. border
   if (mode != PLH_MODE_I) {
     double bI = b[O_I];
@@ -882,6 +899,7 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
     }
   }
   PL_SYNC();
+  PL_TOCE(S, 2, 3);
   // f. particles: dc = w - A^-1 e_last bj dj - A^-1 q dT
   if (!alg_only) {
     // (unconditional clamped loads first, guarded stores last -- see iso_solve)
@@ -900,6 +918,7 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
     }
   }
   PL_SYNC();
+  PL_TOCE(S, 2, 4);
 }
 
 }  // namespace pl

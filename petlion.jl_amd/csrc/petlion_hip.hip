@@ -98,10 +98,15 @@ static const char* const KEYS_LGM50_ISO[] = {
 static const double DEFAULTS_LGM50_ISO[] = {
     8.794e-11, 3.3e-14, 4e-15, 3.03e4, 0.0, 35000.0, 17800.0, 5.86e-6, 5.22e-06, 25 + 273.15, 1.5, 1.5, 1.5, 1000.0, 33133.0, 63104.0,
     6.716046737258585e-12, 3.5445802224420315e-11, 85.2e-6, 75.6e-6, 12e-6, 0.2594, 29866.0 / 33133, 17038.0 / 63104.0, 0.0481727, 0.8395, 215.0, 0.18, 0.0, 0.0, 0.25, 0.335, 0.47};
+// ... with temperature = true, the reference default of this chemistry (params.jl:695): + the heat-equation parameters (params.jl:531-533, 593-595, 779-800)
+static const char* const KEYS_LGM50_THERMAL[] = {
+    "Cp_a", "Cp_n", "Cp_p", "Cp_s", "Cp_z", "D_e", "D_sn", "D_sp", "Ea_D_sn", "Ea_D_sp", "Ea_k_n", "Ea_k_p", "Rp_n", "Rp_p", "T_amb", "T₀", "brugg_n", "brugg_p", "brugg_s", "c_e₀", "c_max_n", "c_max_p", "h_cell", "k_n", "k_p", "l_a", "l_n", "l_p", "l_s", "l_z", "t₊", "θ_max_n", "θ_max_p", "θ_min_n", "θ_min_p", "λ_a", "λ_n", "λ_p", "λ_s", "λ_z", "ρ_a", "ρ_n", "ρ_p", "ρ_s", "ρ_z", "σ_a", "σ_n", "σ_p", "σ_z", "ϵ_fn", "ϵ_fp", "ϵ_n", "ϵ_p", "ϵ_s"};
+static const double DEFAULTS_LGM50_THERMAL[] = {
+    897.0, 700.0, 700.0, 700.0, 385.0, 8.794e-11, 3.3e-14, 4e-15, 30300.0, 0.0, 35000.0, 17800.0, 5.86e-06, 5.22e-06, 298.15, 298.15, 1.5, 1.5, 1.5, 1000.0, 33133.0, 63104.0, 1.0, 6.716046737258585e-12, 3.5445802224420315e-11, 1.6e-05, 8.52e-05, 7.56e-05, 1.2e-05, 1.2e-05, 0.2594, 0.9013973983641687, 0.2699987322515213, 0.0481727, 0.8395, 237.0, 1.7, 2.1, 0.16, 401.0, 2700.0, 1657.0, 3262.0, 397.0, 8960.0, 36914000.0, 215.0, 0.18, 58410000.0, 0.0, 0.0, 0.25, 0.335, 0.47};
 struct VariantInfo { int nkeys; const char* const* keys; const double* defaults; };
 // parameter set of a variant: by (chemistry, SEI, temperature); the mixed-precision variants share their fp64 sibling's
 static VariantInfo variant_keys(int chem, int sei, int thermal, int rxn) {
-  if (chem == PLH_CHEM_LGM50) return {33, KEYS_LGM50_ISO, DEFAULTS_LGM50_ISO};
+  if (chem == PLH_CHEM_LGM50) return thermal ? VariantInfo{54, KEYS_LGM50_THERMAL, DEFAULTS_LGM50_THERMAL} : VariantInfo{33, KEYS_LGM50_ISO, DEFAULTS_LGM50_ISO};
   if (rxn == PLH_RXN_MHC) return {37, KEYS_LCO_MHC, DEFAULTS_LCO_MHC};
   if (thermal) return {56, KEYS_LCO_THERMAL, DEFAULTS_LCO_THERMAL};
   if (chem == PLH_CHEM_LCO_LIC6) return sei ? VariantInfo{42, KEYS_LCO_SEI, DEFAULTS_LCO_SEI} : VariantInfo{35, KEYS_LCO_ISO, DEFAULTS_LCO_ISO};
@@ -335,7 +340,7 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
                                    "N_p + N_s + N_n <= 48, 10 <= N_r_p = N_r_n <= 16) is one more build of csrc/variant_tu.hip, registered with plh_register_grid_library() before "
                                    "plh_model_create (petlion.jl_amd/grids.py does both; INTEGRATION.md)");
   if (!ops) return fail(PLH_E_UNSUPPORTED, "this chemistry / temperature / aging / precision / model-option combination is not instantiated on the device (built in fp64: LCO and NMC "
-                                           "isothermal with or without SEI aging, LGM50 isothermal, LCO with temperature; LCO isothermal with ONE of: quadratic or polynomial solid diffusion, the nonlinear "
+                                           "isothermal with or without SEI aging, LGM50 isothermal and with temperature, LCO with temperature; LCO isothermal with ONE of: quadratic or polynomial solid diffusion, the nonlinear "
                                            "thermodynamic factor, MHC kinetics; mixed precision: LCO isothermal, NMC + SEI, LCO with temperature)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(PLH_E_HIP, "no HIP device visible: the product path has no CPU fallback");

@@ -23,8 +23,9 @@
   X(10, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_NONLINEAR, PLH_RXN_BV, 0)      \
   X(11, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_MHC, 0)       \
   X(12, PLH_CHEM_LGM50, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)            \
-  X(13, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 1)
-constexpr int PL_N_VARIANTS = 14;
+  X(13, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 1)          \
+  X(14, PLH_CHEM_LGM50, false, true, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)
+constexpr int PL_N_VARIANTS = 15;
 
 struct IntegrateArgs {
   const pl::Tables* tb; int n_cells; const double* theta; const double* SOC0; const double* Y_init; const double* t_init; int n_runs; const plh_run* runs; plh_opts opts;
@@ -61,5 +62,5 @@ PL_VARIANT_LIST(PL_DECLARE_OPS)
 extern "C" const VariantOps* plh_grid_variant_ops(int id);     // nullptr: variant not built into this grid library
 extern "C" void plh_grid_dims(int* grid6);
 // what a grid library was compiled against: bump PLH_HOST_ABI whenever VariantOps / IntegrateArgs / Tables change, so that a stale cached library is refused, not misread
-constexpr int PLH_HOST_ABI = 2;
+constexpr int PLH_HOST_ABI = 3;
 extern "C" void plh_grid_abi(int* abi, int* sizeof_ops, int* sizeof_args, int* sizeof_tables);

@@ -83,13 +83,16 @@ def bounds_LCO():
 
 
 def theta_LGM50():
-    """NMC_LGM50 + LiC6_LGM50 + system_LGM50_NMC_LiC6 (Chen et al. 2020), reference src/params.jl:514-560, 576-625, 776-801 (the entries the isothermal model reads)"""
+    """NMC_LGM50 + LiC6_LGM50 + system_LGM50_NMC_LiC6 (Chen et al. 2020), reference src/params.jl:514-560, 576-625, 776-801"""
     th = OrderedDict()
     th.update({"D_sp": 4e-15, "k_p": 3.5445802224420315e-11, "λ_MHC_p": 0.0, "θ_min_p": 0.8395, "θ_max_p": 17038.0 / 63104.0, "l_p": 75.6e-6, "σ_p": 0.18, "ϵ_p": 0.335,
                "ϵ_fp": 0.0, "brugg_p": 1.5, "c_max_p": 63104.0, "Rp_p": 5.22e-06, "Ea_D_sp": 0.0, "Ea_k_p": 17800.0})
     th.update({"D_sn": 3.3e-14, "k_n": 6.716046737258585e-12, "λ_MHC_n": 0.0, "θ_max_n": 29866.0 / 33133, "θ_min_n": 0.0481727, "l_n": 85.2e-6, "σ_n": 215.0, "ϵ_n": 0.25,
                "ϵ_fn": 0.0, "brugg_n": 1.5, "c_max_n": 33133.0, "Rp_n": 5.86e-6, "Ea_D_sn": 3.03e4, "Ea_k_n": 35000.0})
     th.update({"D_e": 8.794e-11, "l_s": 12e-6, "ϵ_s": 0.47, "brugg_s": 1.5, "t₊": 0.2594, "c_e₀": 1000.0, "T₀": 25 + 273.15, "T_amb": 25 + 273.15})
+    # heat equation (temperature = true is this chemistry's default in the reference): src/params.jl:531-533, 593-595, 779-800
+    th.update({"λ_p": 2.1, "ρ_p": 3262.0, "Cp_p": 700.0, "λ_n": 1.7, "ρ_n": 1657.0, "Cp_n": 700.0, "l_a": 16e-6, "l_z": 12e-6, "σ_a": 36.914e6, "σ_z": 58.41e6,
+               "λ_s": 0.16, "λ_a": 237.0, "λ_z": 401.0, "ρ_s": 397.0, "ρ_a": 2700.0, "ρ_z": 8960.0, "Cp_s": 700.0, "Cp_a": 897.0, "Cp_z": 385.0, "h_cell": 1.0})
     return th
 
 

@@ -87,6 +87,17 @@ def hip_model_thermal(pkg, hip_model):
     return pkg.petlion(pkg.LCO, temperature=True)
 
 
+@pytest.fixture(scope="session")
+def emu_model_lgm50_thermal(pkg):
+    import build_emu
+    return pkg.petlion(pkg.NMC_LGM50, _lib_path=build_emu.build())          # (temperature = true is this chemistry's default)
+
+
+@pytest.fixture(scope="session")
+def hip_model_lgm50_thermal(pkg, hip_model):
+    return pkg.petlion(pkg.NMC_LGM50)
+
+
 F4_OPTIONS = {"quad": dict(solid_diffusion="quadratic"), "poly": dict(solid_diffusion="polynomial"), "nu": dict(thermodynamic_factor="nonlinear"),
               "mhc": dict(rxn_p="MHC", rxn_n="MHC"), "lgm50": dict(cathode="LGM50", temperature=False)}
 

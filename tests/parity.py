@@ -86,7 +86,7 @@ def check_alg_block_pattern(p, O):
     assert len(ari) == meta["nnz_alg"]
 
 
-def check_evaluators(p, O, n_cells=3):
+def check_evaluators(p, O, n_cells=3, solve_tol=1e-8):
     VARIANT = p.variant
     lib, h = p._lib, p._h
     th = p.theta_vector()
@@ -133,7 +133,7 @@ def check_evaluators(p, O, n_cells=3):
             for name, a, e in sections_for(N):
                 # measured against an extended-precision solve (check_solver_accuracy): both solvers are within 3e-9 of the truth (isothermal: the
                 # structured solve 1e-11, the oracle's LU 3e-9); thermal 2e-9 each = the conditioning floor of the fp64 Jacobian entries themselves
-                assert np.abs(x[i, a:e] - xo[a:e]).max() <= 1e-8 * (np.abs(xo[a:e]).max() + 1e-300), (mode, i, name)
+                assert np.abs(x[i, a:e] - xo[a:e]).max() <= solve_tol * (np.abs(xo[a:e]).max() + 1e-300), (mode, i, name)
 
 
 def check_init(p, O, V0_expected=2.863495104606893):

@@ -175,6 +175,37 @@ def test_lco_thermal_cc_ct_cv(emu_model_thermal, O, pkg):
     check_thermal_model(emu_model_thermal, O, pkg)
 
 
+def check_lgm50_thermal(p, O, pkg):
+    """NMC_LGM50 + LiC6_LGM50 with temperature = true -- the reference's DEFAULT configuration of that chemistry (src/params.jl:695): K_eff(c_e), D_eff(c_e) per control volume,
+    tanh OCVs with dU/dT = 0, Arrhenius k and D_s per node; 54 parameters.  Oracle variant lgm50_thermal (equations only: the reference holds no vector for this chemistry)."""
+    assert p.temperature and p.variant == "lgm50_thermal" and len(p.θ_keys) == 54
+    parity.check_keys_and_pattern(p, O)
+    # (the solve is compared with the oracle's sparse LU at 1e-7 here and with an 80-bit solution below: on this chemistry -- sigma_p = 0.18 S/m -- the ORACLE's LU is the
+    #  less accurate of the two, 1.9e-8 from the truth in the V mode where the structured solve is within 3e-10)
+    parity.check_evaluators(p, O, n_cells=3, solve_tol=1e-7)
+    rows = np.array([r[3:] for r in parity.solver_accuracy_rows(p, O, n_states=2, modes=((0, -1.0), (1, 3.9), (2, 0.01)))])
+    assert rows[:, 0].max() <= 2e-9, rows[:, 0].max()
+    parity.check_init(p, O, None)
+    Th = pkg.theta_matrix(p, 2, {"h_cell": np.array([1.0, 5.0]) * p.θ["h_cell"]})
+    ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0)
+    for i in range(2):
+        ro = O.simulate(p.variant, Th[i], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}]))
+        parity.compare_trajectory(ens, i, ro, rtol_state=2e-6)
+    assert ens.run_info[0, 0]["T_avg"] > 305.0                               # a 1C discharge heats this cell by ~9 K (sigma_p = 0.18 S/m)
+    kw = dict(T_max=313.15, V_max=4.2, I_min=1 / 20)
+    proto = [dict(I=2.0, **kw), dict(dT="hold", **kw), dict(V="hold", **kw)]
+    ens = pkg.simulate_ensemble(p, Th[:1], proto, SOC=0.0)
+    ro = O.simulate(p.variant, Th[0], 0.0, parity.runs_to_oracle(O, p, pkg, proto))
+    assert [int(f) for f in ens.run_info[0]["flag"]] == [r["flag"] for r in ro["runs"]] == [5, 2, 8]
+    assert int(ens.run_info[0, 0]["iterations"]) == ro["runs"][0]["iterations"] and abs(ens.run_info[0, 0]["t_end"] - ro["runs"][0]["t_end"]) < 1e-6 * ro["runs"][0]["t_end"]
+    for k in (1, 2):
+        assert abs(ens.run_info[0, k]["t_end"] - ro["runs"][k]["t_end"]) < (2e-3, 1e-2)[k - 1] * ro["runs"][k]["t_end"], k
+
+
+def test_lgm50_with_temperature(emu_model_lgm50_thermal, O, pkg):
+    check_lgm50_thermal(emu_model_lgm50_thermal, O, pkg)
+
+
 def check_power_and_plating_modes(p, O, pkg):
     """constant / held power `P` and plating overpotential `η_p` (reference input_methods.jl:80-152, scalar_residual.jl:189-225): single runs
     with identical step decisions at 1e-6; chained :hold / :rest legs with a fresh Jacobian every step and IDA's first step pinned (reproducibility floor)."""

@@ -79,8 +79,10 @@ def sweep_check(pkg, p, O, n, opts=None, oopts_kw=None, cells=None):
 
 def assert_within_floor(rows, what):
     """EVERY cell: final state within 1e-6 (north star) or, where the reference algorithm itself is not reproducible to 1e-6, within 10x the cell's own
-    reproducibility floor (the spread of the oracle under last-bit perturbations of one intermediate vector, parity.oracle_noise_band)"""
-    bad = [(i, e, b) for i, (_, e, b) in enumerate(rows) if not e <= max(1e-6, 10.0 * b)]
+    reproducibility floor (the spread of the oracle under last-bit perturbations of one intermediate vector, parity.oracle_noise_band), and never more than 1e-4"""
+    # (the floor's licence is capped: a perturbed oracle re-run that flips a solver decision can show a spread of 1e-2 and more, which must not excuse the device -- 1e-4 is the
+    #  largest deviation the h0 -> step grid -> back-interpolation chain produces in a cell whose decisions are intact, DESIGN.md 5)
+    bad = [(i, e, b) for i, (_, e, b) in enumerate(rows) if not e <= max(1e-6, min(10.0 * b, 1e-4))]
     assert not bad, (what, bad[:5])
     e = np.sort([r[1] for r in rows])
     print("%s: %d/%d identical decisions; state err median %.1e, p90 %.1e, max %.1e; cells above 1e-6: %d (all within 10x their reproducibility floor)"
@@ -628,3 +630,20 @@ def test_c5_full_size_8192_cells_properties(hip_model_nmc_sei, pkg):
     shard = pkg.simulate_ensemble(p, Th[5 * 1024:6 * 1024], cfg["protocol"], SOC=0.0, device=True, max_points=cfg["max_points"])
     torch.cuda.synchronize()
     assert (shard.Y.cpu().numpy() == Y[5 * 1024:6 * 1024]).all()
+
+
+def test_lgm50_with_temperature_on_gpu(hip_model_lgm50_thermal, O, pkg):
+    """the reference's default NMC_LGM50 configuration (temperature = true): evaluators / initialisation / trajectories against the oracle, then a 1024-cell sweep"""
+    import torch
+    import test_device_source_emu as te
+    p = hip_model_lgm50_thermal
+    te.check_lgm50_thermal(p, O, pkg)
+    n = 1024
+    Th = pkg.configs.sweep_theta(p, np.arange(n), 4)
+    ens = pkg.simulate_ensemble(p, torch.from_numpy(Th).cuda(), [{"I": -1.0}], SOC=1.0, device=True, max_points=512)
+    torch.cuda.synchronize()
+    fl, tend = ens.run_info["flag"][:, 0], ens.run_info["t_end"][:, 0]
+    assert np.isin(fl, (1, 3, 5)).all(), np.unique(fl)
+    assert np.abs(ens.run_info["SOC"][:, 0] - (1.0 - tend / 3600.0)).max() < 1e-9
+    print("lgm50_thermal: 1024-cell sweep kernel %.2f ms (%.0f trajectories/s), flags %s, T_avg at the end %.1f .. %.1f K" % (ens.kernel_ms, n / ens.kernel_ms * 1e3, dict(zip(*np.unique(fl, return_counts=True))),
+          ens.run_info["T_avg"][:, 0].min(), ens.run_info["T_avg"][:, 0].max()))
