@@ -53,6 +53,9 @@ VARIANTS = {
     "lco_iso_nu": dict(cathode="LCO", thermodynamic_factor="nonlinear"),
     "lco_iso_mhc": dict(cathode="LCO", rxn="MHC"),
     "lgm50_iso": dict(cathode="LGM50"),                  # NMC_LGM50 + LiC6_LGM50 (Chen et al. 2020), reference src/params.jl:514-849
+    # the LCO thermal model with the heat-conduction stencil evaluated on temperature differences (dfn_model.Model.t_conduction): same equations, 1e4 x less rounding in the
+    # sum of the T rows that the dT control row and its twin form -- the tight-tolerance counterpart of the device's evaluation
+    "lco_thermal_tdiff": dict(cathode="LCO", temperature=True, t_conduction="difference"),
     "lgm50_thermal": dict(cathode="LGM50", temperature=True),      # ... with temperature = true, the reference default of that chemistry (params.jl:695)
     # other discretisations (reference src/params.jl:119-136); the name suffix is _g<N_p>_<N_s>_<N_n>_<N_r>
     "lco_iso_g12_7_9_11": dict(cathode="LCO", Np=12, Ns=7, Nn=9, Nrp=11, Nrn=11),
@@ -74,10 +77,12 @@ def theta_keys_for(model):
     return sorted(keys)
 
 
-def _emit_block(name, args, exprs, out_name, printer, lines):
-    """CSE + straight-line C for a list of expressions written to out_name[k]."""
+def _emit_block(name, args, exprs, out_name, printer, lines, pre_defs=()):
+    """CSE + straight-line C for a list of expressions written to out_name[k]; pre_defs = named intermediates that stay named (emitted first, as written)"""
     repl, red = sp.cse(exprs, symbols=sp.numbered_symbols("x"), optimizations=None, order="none")
     lines.append("void %s(%s)\n{" % (name, args))
+    for s, e in pre_defs:
+        lines.append("  const double %s = %s;" % (s, printer.doprint(e)))
     for s, e in repl:
         lines.append("  const double %s = %s;" % (s, printer.doprint(e)))
     for k, e in enumerate(red):
@@ -128,8 +133,13 @@ def generate(name, verbose=True):
                 if d != 0:
                     for t, dt in daux[s].items():
                         entries[(r, ysym[t])] = entries.get((r, ysym[t]), 0) + d * dt
+    # intermediates that stay named in the RESIDUAL code (dT_k: the temperature differences of Model.t_conduction = "difference" -- substituting them back would let sympy
+    # merge (T[k+1] - T[k]) - (T[k] - T[k-1]) into T[k-1] - 2 T[k] + T[k+1], the very cancellation they avoid); the Jacobian entries take all of them back
+    kept = {a: e for a, e in aux.items() if str(a).startswith("dT_")}
+    kept_defs = sorted(kept.items(), key=lambda ae: int(str(ae[0])[3:]))
     if aux:
-        res = [e.xreplace(aux) for e in res]
+        sub = {a: e for a, e in aux.items() if a not in kept}
+        res = [e.xreplace(sub) for e in res]
         entries = {k: sp.sympify(v).xreplace(aux) for k, v in entries.items()}
     cols = [[] for _ in range(N)]
     for (r, c) in entries:
@@ -169,7 +179,7 @@ def generate(name, verbose=True):
     L.append("const int %s_alg_rowval[%d] = {%s};" % (pre, max(1, len(a_rowval)), ",".join(map(str, a_rowval)) or "0"))
     L.append("const char* const %s_theta_keys[%d] = {%s};\n" % (pre, P, ",".join('"%s"' % k for k in keys)))
     sig = "double* out, const double* Y, const double* YP, const double* th"
-    _emit_block(pre + "_f_diff", sig, res[:Nd], "out", pr, L)
+    _emit_block(pre + "_f_diff", sig, res[:Nd], "out", pr, L, kept_defs)
     _emit_block(pre + "_f_alg", sig, res[Nd:], "out", pr, L)
     sigj = "double* nz, const double* Y, const double* YP, double cj, const double* th"
     _emit_block(pre + "_jac", sigj, nzexpr, "nz", pr, L)
@@ -188,14 +198,15 @@ def generate(name, verbose=True):
         rhsT = [res[lay.T[0] + i] + YP[lay.T[0] + i] for i in range(lay.T[1] - lay.T[0])]
         twin = -sum(w[i] * rhsT[i] for i in range(len(w))) / Ltot      # + value added by the caller
         tw_cols, tw_expr = [], []
+        twin_full = twin.xreplace(kept) if kept else twin
         for c in range(Nd, N):
-            d = sp.diff(twin, Y[c])
+            d = sp.diff(twin_full, Y[c])
             if d != 0:
                 tw_cols.append(c - Nd)
                 tw_expr.append(d)
         L.append("const int %s_NNZ_DT_TWIN = %d;" % (pre, len(tw_cols)))
         L.append("const int %s_dT_twin_cols[%d] = {%s};" % (pre, len(tw_cols), ",".join(map(str, tw_cols))))
-        _emit_block(pre + "_dT_twin", sig, [twin], "out", pr, L)
+        _emit_block(pre + "_dT_twin", sig, [twin], "out", pr, L, kept_defs)
         _emit_block(pre + "_dT_twin_jac", sigj, tw_expr, "nz", pr, L)
         L.append("void %s_dT_weights(double* w, const double* th)\n{" % pre)
         for i in range(len(w)):

@@ -262,11 +262,17 @@ class Layout:
 
 
 class Model:
-    def __init__(self, cathode="LCO", temperature=False, aging=False, solid_diffusion="Fickian", thermodynamic_factor="linear", rxn="BV", **Nkw):
+    def __init__(self, cathode="LCO", temperature=False, aging=False, solid_diffusion="Fickian", thermodynamic_factor="linear", rxn="BV", t_conduction="matrix", **Nkw):
         """solid_diffusion: "Fickian" (finite difference), "quadratic", "polynomial" (params.jl:140); thermodynamic_factor: "linear" (nu = 1) or
         "nonlinear" (custom_functions.jl:177-203); rxn: "BV" or "MHC" for both electrodes (custom_functions.jl:212-298)"""
         assert solid_diffusion in ("Fickian", "quadratic", "polynomial") and thermodynamic_factor in ("linear", "nonlinear") and rxn in ("BV", "MHC")
         self.cathode = cathode
+        # t_conduction: how the heat-conduction stencil of residuals_T! is EVALUATED -- "matrix": coefficients times temperatures, summed (what the reference's A_T * T generates:
+        # three terms of 6e6 K/s cancelling to 0.1 K/s, 1e-9 K/s of rounding per row); "difference": the same stencil on the differences of neighbouring temperatures (named
+        # intermediates dT_k = T[k+1] - T[k], exact to their own last bit).  Algebraically identical; the second form is what the device evaluates since r03, and the variant
+        # lco_thermal_tdiff exists so that the dT = :hold leg -- whose control row sums all fifty rows -- can be compared at tight tolerances (DESIGN.md 5).
+        assert t_conduction in ("matrix", "difference")
+        self.t_conduction = t_conduction
         self.solid_diffusion, self.thermodynamic_factor, self.rxn = solid_diffusion, thermodynamic_factor, rxn
         self.lay = Layout(temperature=temperature, aging=aging, solid_diffusion=solid_diffusion, **Nkw)
         self.theta = {"LCO": theta_LCO, "NMC": theta_NMC, "LGM50": theta_LGM50}[cathode]()
@@ -777,14 +783,16 @@ def residual(model, ops, Y, YP, th, mode=MODE_I, value=0.0, with_control=True):
         starts = [0, Na, Na + Np, Na + Np + Ns, Na + Ne]       # first CV of a,p,s,n,z
         ends = [Na - 1, Na + Np - 1, Na + Np + Ns - 1, Na + Ne - 1, NT - 1]
         AT = [None] * NT
+        diff_form = model.t_conduction == "difference"
+        dTk = [ops.aux("dT_%d" % k, T[k + 1] - T[k]) for k in range(NT - 1)] if diff_form else None
         for i in range(NT):
             # block_tridiag per section: Neumann corners (-1), interior (-2)
             first = i in starts; last = i in ends
             acc = 0.0
             if not first:
-                acc = acc + (T[i - 1] - T[i])
+                acc = acc + ((-dTk[i - 1]) if diff_form else (T[i - 1] - T[i]))
             if not last:
-                acc = acc + (T[i + 1] - T[i])
+                acc = acc + (dTk[i] if diff_form else (T[i + 1] - T[i]))
             AT[i] = lam[i] * acc / hT[i] ** 2
         # interfaces (residuals.jl:354-439): left CV = last of section k, right CV = first of section k+1
         for k in range(4):
@@ -795,9 +803,13 @@ def residual(model, ops, Y, YP, th, mode=MODE_I, value=0.0, with_control=True):
             den_ = hr / 2 + hl / 2
             last_l = lam[il] / hl
             first_r = lam_if / den_
-            AT[il] = (last_l * T[il - 1] - (last_l + first_r) * T[il] + first_r * T[il + 1]) / hl
             second_r = lam[ir] / hr
-            AT[ir] = (first_r * T[ir - 1] - (second_r + first_r) * T[ir] + second_r * T[ir + 1]) / hr
+            if diff_form:
+                AT[il] = (-last_l * dTk[il - 1] + first_r * dTk[il]) / hl
+                AT[ir] = (-first_r * dTk[ir - 1] + second_r * dTk[ir]) / hr
+            else:
+                AT[il] = (last_l * T[il - 1] - (last_l + first_r) * T[il] + first_r * T[il + 1]) / hl
+                AT[ir] = (first_r * T[ir - 1] - (second_r + first_r) * T[ir] + second_r * T[ir + 1]) / hr
         BC = [0.0] * NT
         BC[0] = th["h_cell"] * (th["T_amb"] - T[0]) / ha
         BC[NT - 1] = -th["h_cell"] * (T[NT - 1] - th["T_amb"]) / hz

@@ -87,6 +87,9 @@ DECL_VARIANT(lco_thermal_g8_6_7_11_5_7) DECL_THERMAL(lco_thermal_g8_6_7_11_5_7)
 #ifdef ORC_HAVE_lgm50_thermal
 DECL_VARIANT(lgm50_thermal) DECL_THERMAL(lgm50_thermal)
 #endif
+#ifdef ORC_HAVE_lco_thermal_tdiff
+DECL_VARIANT(lco_thermal_tdiff) DECL_THERMAL(lco_thermal_tdiff)
+#endif
 #ifdef ORC_HAVE_lco_iso_sei
 DECL_VARIANT(lco_iso_sei)
 #endif
@@ -158,6 +161,12 @@ static int get_model(const char* name, orc_model* m) {
   if (!strcmp(name, "lco_thermal")) { FILL_VARIANT(m, lco_thermal, 1, 0);
     m->nnz_twin = orc_lco_thermal_NNZ_DT_TWIN; m->twin_cols = orc_lco_thermal_dT_twin_cols;
     m->dT_twin = orc_lco_thermal_dT_twin; m->dT_twin_jac = orc_lco_thermal_dT_twin_jac; m->dT_weights = orc_lco_thermal_dT_weights;
+    return 0; }
+#endif
+#ifdef ORC_HAVE_lco_thermal_tdiff
+  if (!strcmp(name, "lco_thermal_tdiff")) { FILL_VARIANT(m, lco_thermal_tdiff, 1, 0);
+    m->nnz_twin = orc_lco_thermal_tdiff_NNZ_DT_TWIN; m->twin_cols = orc_lco_thermal_tdiff_dT_twin_cols;
+    m->dT_twin = orc_lco_thermal_tdiff_dT_twin; m->dT_twin_jac = orc_lco_thermal_tdiff_dT_twin_jac; m->dT_weights = orc_lco_thermal_tdiff_dT_weights;
     return 0; }
 #endif
 #ifdef ORC_HAVE_lgm50_thermal

@@ -158,6 +158,7 @@ struct CellConst {
   double csj[2], csq[2], csr[2], qj[2];
   double De;     // LGM50: electrolyte diffusivity scale D_e
   double lam[2], mhc_k0[2], rce0;   // MHC: lambda per electrode, k_i / ((1 - erf((lambda - sqrt(1 + sqrt(lambda))) / (2 sqrt(lambda)))) / 2), 1 / c_e0
+  double Tamb;   // thermal: ambient temperature (convective ends of the heat equation)
   int iso_ref;   // T0 == TREF exactly (temperature_switch, reference custom_functions.jl:1)
 };
 
@@ -180,7 +181,7 @@ template <bool MIXED> struct ThermalPool<true, MIXED> {
   double Dpark[MIXED ? NE * 16 : 1];                       // mixed precision: fp64 parking of the node's own block during the factor sweep (fp64 variant: parks in LD)
   // heat-conduction stencil of residuals_T! (residuals.jl:299-489), already divided by rho*Cp:  aL T[it-1] + aD T[it] + aU T[it+1] + aC
   double aL[NT], aD[NT], aU[NT], wT5[5];                    // wT5 = temperature_weighting w_i / L per section a|p|s|n|z (aux...jl:649-679)
-  double aC2[2], rc5[5];                                    // constant term of the two convective end rows; 1/(rho Cp) per section a|p|s|n|z
+  double aC2[2], rc5[5];                                    // convective coefficient h_cell / (h rho Cp) of the two end rows; 1/(rho Cp) per section a|p|s|n|z
   double qI[2], qIJ[2];                                    // collector rows: Joule heat qI * I^2 ; qIJ = d(row)/dI at the last Jacobian pass
   double kapP[NJ], dkapP[NJ];                              // per-particle D_s(T)/Rp^2 and its T derivative
   // Jacobian partials that exist only with temperature
@@ -559,7 +560,7 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     c.Dh_ps = hmean(c.beta_ps, c.Dc[0], c.Dc[1]); c.Dh_sn = hmean(c.beta_sn, c.Dc[1], c.Dc[2]);   // D_eff_linear: constant edge means
     S.tb = tb;
     c.R_SEI = c.rkag = c.Mrho = c.i0F = c.wexp = c.Uref = 0.0;
-    c.EaKp = c.EaKn = c.EaDp = c.EaDn = 0.0;
+    c.EaKp = c.EaKn = c.EaDp = c.EaDn = 0.0; c.Tamb = 0.0;
     {   // quadratic / polynomial particle models (aux...jl:212-248, residuals.jl:108-127, 237-258); D_s_eff = D_s * Arrhenius factor
       const double Dsp = th[ix[K_D_sp]] * arr_dp, Dsn = th[ix[K_D_sn]] * arr_dn;
       const double den = M::SD == 2 ? 35.0 : 5.0;
@@ -575,6 +576,7 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     }
     if constexpr (M::THERMAL) {
       c.iso_ref = 0;                                        // the temperature_switch always takes the exp branch (custom_functions.jl:1)
+      c.Tamb = th[ix[K_T_amb]];
       c.EaKp = th[ix[K_Ea_k_p]] / RGAS; c.EaKn = th[ix[K_Ea_k_n]] / RGAS; c.EaDp = th[ix[K_Ea_D_sp]] / RGAS; c.EaDn = th[ix[K_Ea_D_sn]] / RGAS;
       for (int q = 0; q < 3; q++) c.r2h[q] = 1.0 / (2.0 * c.h[q]);
       c.qps_r = 2.0 / (3 * c.h[0] + c.h[1]); c.qps_l = 2.0 / (c.h[0] + 3 * c.h[1]);

@@ -117,8 +117,8 @@ PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const do
     if (it == NT - 1) { aD -= hc / h; aC = hc * Tamb / h; }
     const double rc = 1.0 / rcp[k];
     TP.aL[it] = aL * rc; TP.aD[it] = aD * rc; TP.aU[it] = aU * rc;
-    if (it == 0) TP.aC2[0] = aC * rc;
-    if (it == NT - 1) TP.aC2[1] = aC * rc;
+    if (it == 0) TP.aC2[0] = hc / h * rc;                                 // (the end rows are evaluated as  aL (T_l - T) + aU (T_r - T) + aC2 (T_amb - T): see thermal_node_pass)
+    if (it == NT - 1) TP.aC2[1] = hc / h * rc;
     if (loc == 0) TP.rc5[k] = rc;
     if (loc == 0) TP.wT5[k] = h / (la + (c.h[0] * NP + c.h[1] * NS + c.h[2] * NN) + lz);
     if (it == 0) TP.qI[0] = c.I1C * c.I1C / th[ix[K_sig_a]] * rc;
@@ -250,13 +250,18 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
       // residuals_T!, residuals.jl:299-489 ; heat sources aux...jl:344-518
       const double qrr = Faj * (T * dUdT + eta);
       const double qohm = K * dPe * dPe + cKfac * K * T * (dce / ce) * dPe + (elec ? sg * dPs * dPs : 0.0);
-      Fo[O_T + it] = TP.aL[it] * Tl + TP.aD[it] * T + TP.aU[it] * Tr + (qrr + qohm) * rc - ypT;
+      // Conduction in DIFFERENCE form, aL (T_l - T) + aU (T_r - T)  (aD = -(aL + aU) on every interior row): the matrix form aL T_l + aD T + aU T_r of the reference
+      // (residuals.jl:299-489) sums three terms of 6e6 K/s that cancel to ~0.1 K/s, i.e. carries 1e-9 K/s of rounding per row -- harmless for the row itself, but the
+      // dT control row and its algebraic twin SUM the fifty rows (their conduction parts telescope to zero) and find the current from what is left: 1e-6 relative noise in I,
+      // which at reltol <= 1e-6 is what made the dT = :hold leg stall on the device more often than in the oracle.  Differences of neighbouring temperatures
+      // are exact to their own last bit, so the noise drops by T / dT ~ 1e4.
+      Fo[O_T + it] = TP.aL[it] * (Tl - T) + TP.aU[it] * (Tr - T) + (qrr + qohm) * rc - ypT;
     }
     if (lane >= 32 && lane < 32 + NA + NZ) {                                          // current-collector rows
       const int k = lane - 32, ic = k < NA ? k : NA + NE + (k - NA);
       const double Tc = Y[O_T + ic], Tcl = ic > 0 ? Y[O_T + ic - 1] : 0.0, Tcr = ic < NT - 1 ? Y[O_T + ic + 1] : 0.0;
-      const double aC = ic == 0 ? TP.aC2[0] : (ic == NT - 1 ? TP.aC2[1] : 0.0);
-      Fo[O_T + ic] = TP.aL[ic] * Tcl + TP.aD[ic] * Tc + TP.aU[ic] * Tcr + aC + TP.qI[k < NA ? 0 : 1] * yI * yI - YP[O_T + ic];
+      const double hcv = ic == 0 ? TP.aC2[0] : (ic == NT - 1 ? TP.aC2[1] : 0.0);      // convective end rows: h_cell (T_amb - T) / (h rho Cp)
+      Fo[O_T + ic] = TP.aL[ic] * (Tcl - Tc) + TP.aU[ic] * (Tcr - Tc) + hcv * (c.Tamb - Tc) + TP.qI[k < NA ? 0 : 1] * yI * yI - YP[O_T + ic];
     }
     if (mode == PLH_MODE_I || mode == PLH_MODE_V || mode == PLH_MODE_P || mode == PLH_MODE_ETA_P) {   // scalar_residual!, scalar_residual.jl:167-172
       const double Vc = Y[O_PS] - Y[O_PS + NJ - 1];

@@ -335,7 +335,7 @@ def _quad_interp(tk, Yk, t):
     return Yk[0] * ((t - b) * (t - c) / ((a - b) * (a - c))) + Yk[1] * ((t - a) * (t - c) / ((b - a) * (b - c))) + Yk[2] * ((t - a) * (t - b) / ((c - a) * (c - b)))
 
 
-def tight_compare(pkg, p, O, th, soc, protocol, sample_dt=50.0, tol=None, max_points=40000, extra_opts=None):
+def tight_compare(pkg, p, O, th, soc, protocol, sample_dt=50.0, tol=None, max_points=40000, extra_opts=None, variant=None):
     """ONE cell, device and oracle BOTH at reltol 1e-8 / abstol 1e-10 (`tol`).  Pass 1 (oracle alone) locates the leg ends; pass 2 runs both with the same opts.tstops
     (_tight_tstops) and outputs = :all.  Every deviation is relative to the scale of its field over the whole trajectory (max |field| over the oracle's saved points).
     Returns
@@ -347,11 +347,12 @@ def tight_compare(pkg, p, O, th, soc, protocol, sample_dt=50.0, tol=None, max_po
     tol = dict(tol or TIGHT)
     runs = runs_to_oracle(O, p, pkg, protocol)
     okw = dict(maxiters=120000, **tol, **(extra_opts or {}))
-    r1 = O.simulate(p.variant, th, soc, runs, opts=O.default_opts(**okw), max_out=max_points)
+    variant = variant or p.variant                       # (an oracle variant of the same model, e.g. lco_thermal_tdiff)
+    r1 = O.simulate(variant, th, soc, runs, opts=O.default_opts(**okw), max_out=max_points)
     if min(r["flag"] for r in r1["runs"]) < 0:
         raise RunFails("oracle", [(r["flag"], r["iterations"], r["t_end"]) for r in r1["runs"]])
     ts = _tight_tstops(r1, runs, sample_dt)
-    ro = O.simulate(p.variant, th, soc, runs, opts=O.default_opts(tstops=ts, **okw), max_out=max_points, keep_Y=True)
+    ro = O.simulate(variant, th, soc, runs, opts=O.default_opts(tstops=ts, **okw), max_out=max_points, keep_Y=True)
     if min(r["flag"] for r in ro["runs"]) < 0:
         raise RunFails("oracle", [(r["flag"], r["iterations"], r["t_end"]) for r in ro["runs"]])
     o = pkg.Opts(); o.reltol = tol["reltol"]; o.abstol = tol["abstol"]; o.maxiters = 120000; o.tstops = list(ts)
