@@ -340,6 +340,8 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov0(double v) {     /
 }
 __device__ __forceinline__ double shift_up1(double v) { return dpp_mov0<0x138>(v); }     // lane i <- lane i-1 (lane 0 <- 0)
 __device__ __forceinline__ double shift_down1(double v) { return dpp_mov0<0x130>(v); }   // lane i <- lane i+1 (lane 63 <- 0)
+__device__ __forceinline__ double row_up2(double v) { return dpp_mov0<0x112>(v); }        // lane i <- lane i-2 within its row of 16 lanes (row_shr:2; lanes 0, 1 of a row <- 0)
+__device__ __forceinline__ double row_down2(double v) { return dpp_mov0<0x102>(v); }      // lane i <- lane i+2 within its row of 16 lanes (row_shl:2; lanes 14, 15 of a row <- 0)
 __device__ __forceinline__ double lane_bcast(double v, int src) {                         // wave-uniform src
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
@@ -351,6 +353,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 #else
 __device__ __forceinline__ double shift_up1(double v) { const double r = __shfl_up(v, 1); return lane_id() == 0 ? 0.0 : r; }
 __device__ __forceinline__ double shift_down1(double v) { const double r = __shfl_down(v, 1); return lane_id() == WAVE - 1 ? 0.0 : r; }
+__device__ __forceinline__ double row_up2(double v) { const double r = __shfl_up(v, 2); return (lane_id() & 15) < 2 ? 0.0 : r; }
+__device__ __forceinline__ double row_down2(double v) { const double r = __shfl_down(v, 2); return (lane_id() & 15) > 13 ? 0.0 : r; }
 __device__ __forceinline__ double lane_bcast(double v, int src) { return __shfl(v, src); }
 __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 1; o < 16; o <<= 1) { const double r = __shfl_up(v, o); if ((lane_id() & 15) >= o) v += r; }
@@ -1018,7 +1022,35 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only
     }
   }
   if (!act) { r0 = 0.0; r1 = 0.0; r2 = 0.0; }
-  double y0 = r0, y1 = r1, y2 = r2;
+  // Both substitutions are first-order linear recurrences along a chain of lanes, y_n = r_n - C_n y_{n-1}: a DEPENDENT chain of DPP shift + three FMAs per stage, and at one wave
+  // per SIMD its latency, not its instruction count, is what a solve waits for (121 cycles per stage measured against 60 of issue).  One level of recursive doubling halves the chain:
+  //     y_n = (r_n - C_n r_{n-1}) + (C_n C_{n-1}) y_{n-2}
+  // -- the odd and the even nodes of a half then advance together, two lanes apart (row_shr:2 / row_shl:2: each half of the twisted layout sits inside one 16-lane DPP row), in
+  // ceil(n/2) stages.  The products C_n C_{n-1} and the shifted right-hand sides cost one parallel pre-pass (27 + 9 FMAs); they depend on the factors only, but there is no LDS left to
+  // keep them in.  (Grids whose halves do not fit a DPP row keep the one-lane recurrence.)
+#ifdef PL_EXP_NO_STRIDE2      /* (experiment build: the one-lane recurrence, for same-box A/B runs) */
+  constexpr bool STRIDE2 = false;
+#else
+  constexpr bool STRIDE2 = TW_FWD <= 15 && TW_MID <= 15;
+#endif
+  double y0, y1, y2;
+  if constexpr (STRIDE2) {
+    double P[9];
+    {
+      double Cs[9];
+      for (int k = 0; k < 9; k++) Cs[k] = shift_up1(C[k]);                     // C of the previous node of the chain
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) P[a * 3 + b] = C[a * 3] * Cs[b] + C[a * 3 + 1] * Cs[3 + b] + C[a * 3 + 2] * Cs[6 + b];
+      const double s0 = shift_up1(r0), s1 = shift_up1(r1), s2 = shift_up1(r2);
+      r0 -= C[0] * s0 + C[1] * s1 + C[2] * s2; r1 -= C[3] * s0 + C[4] * s1 + C[5] * s2; r2 -= C[6] * s0 + C[7] * s1 + C[8] * s2;
+    }
+    y0 = r0; y1 = r1; y2 = r2;
+    constexpr int NST2 = (TW_FWD - 1 + 1) / 2;                               // the last node of the longer half is TW_FWD - 1 steps from its head
+    _Pragma("unroll") for (int it = 0; it < NST2; it++) {
+      const double p0 = row_up2(y0), p1 = row_up2(y1), p2 = row_up2(y2);
+      y0 = r0 + (P[0] * p0 + P[1] * p1 + P[2] * p2); y1 = r1 + (P[3] * p0 + P[4] * p1 + P[5] * p2); y2 = r2 + (P[6] * p0 + P[7] * p1 + P[8] * p2);
+    }
+  } else {
+  y0 = r0; y1 = r1; y2 = r2;
   // the stage loops are fully unrolled for the models without aging (no loop bookkeeping between the DPP shifts: +2.7 % on C4, +0.9 % on C2); with SEI, whose integrate
   // kernel is already out of registers, that costs 1.8 %, so it keeps the loop unrolled by two
 #define PL_FWD_STAGE { const double p0 = shift_up1(y0), p1 = shift_up1(y1), p2 = shift_up1(y2); \
@@ -1026,6 +1058,7 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only
   if constexpr (M::SEI) { _Pragma("unroll 2") for (int it = 1; it < TW_FWD; it++) PL_FWD_STAGE }
   else { _Pragma("unroll") for (int it = 1; it < TW_FWD; it++) PL_FWD_STAGE }
 #undef PL_FWD_STAGE
+  }
   {   // closing node: y_mid -= (L_mid Dinv_{mid-1}) y_{mid-1}
     const double m0 = lane_bcast(y0, TW_MID - 1), m1 = lane_bcast(y1, TW_MID - 1), m2 = lane_bcast(y2, TW_MID - 1);
     y0 -= Lm[0] * m0 + Lm[1] * m1 + Lm[2] * m2; y1 -= Lm[3] * m0 + Lm[4] * m1 + Lm[5] * m2; y2 -= Lm[6] * m0 + Lm[7] * m1 + Lm[8] * m2;
@@ -1035,12 +1068,30 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only
     const double g0 = lane_bcast(z0, tw_lane(TW_MID)), g1 = lane_bcast(z1, tw_lane(TW_MID)), g2 = lane_bcast(z2, tw_lane(TW_MID));
     if (lane == TW_MID) { z0 = g0; z1 = g1; z2 = g2; }
   }
-  double x0 = z0, x1 = z1, x2 = z2;
+  double x0, x1, x2;
+  if constexpr (STRIDE2) {                                                    // x_n = (z_n - G_n z_{n+1}) + (G_n G_{n+1}) x_{n+2}  ("n+1" = the next lane of the chain)
+    double Q[9];
+    {
+      double Gs[9];
+      for (int k = 0; k < 9; k++) Gs[k] = shift_down1(G[k]);
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Q[a * 3 + b] = G[a * 3] * Gs[b] + G[a * 3 + 1] * Gs[3 + b] + G[a * 3 + 2] * Gs[6 + b];
+      const double s0 = shift_down1(z0), s1 = shift_down1(z1), s2 = shift_down1(z2);
+      z0 -= G[0] * s0 + G[1] * s1 + G[2] * s2; z1 -= G[3] * s0 + G[4] * s1 + G[5] * s2; z2 -= G[6] * s0 + G[7] * s1 + G[8] * s2;
+    }
+    x0 = z0; x1 = z1; x2 = z2;
+    constexpr int NST2 = (TW_MID + 1) / 2;                                    // lane 0 is TW_MID steps from the ghost of the closing node
+    _Pragma("unroll") for (int it = 0; it < NST2; it++) {
+      const double q0 = row_down2(x0), q1 = row_down2(x1), q2 = row_down2(x2);
+      x0 = z0 + (Q[0] * q0 + Q[1] * q1 + Q[2] * q2); x1 = z1 + (Q[3] * q0 + Q[4] * q1 + Q[5] * q2); x2 = z2 + (Q[6] * q0 + Q[7] * q1 + Q[8] * q2);
+    }
+  } else {
+  x0 = z0; x1 = z1; x2 = z2;
 #define PL_BWD_STAGE { const double q0 = shift_down1(x0), q1 = shift_down1(x1), q2 = shift_down1(x2); \
     x0 = z0 - (G[0] * q0 + G[1] * q1 + G[2] * q2); x1 = z1 - (G[3] * q0 + G[4] * q1 + G[5] * q2); x2 = z2 - (G[6] * q0 + G[7] * q1 + G[8] * q2); }
   if constexpr (M::SEI) { _Pragma("unroll 2") for (int it = 0; it < TW_MID; it++) PL_BWD_STAGE }
   else { _Pragma("unroll") for (int it = 0; it < TW_MID; it++) PL_BWD_STAGE }
 #undef PL_BWD_STAGE
+  }
   r0 = x0; r1 = x1; r2 = x2;
 }
 

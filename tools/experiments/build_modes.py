@@ -30,6 +30,9 @@ BUILDS = [  # tag, variants, {variant: opt}, extra flags, perf config, pytest -k
     ("iso_calls_O2_noinl", [0], {0: "-O2"}, ["-DPL_DEV=__device__ __attribute__((noinline))"], "c2", "c2_1024 or evaluators or consistent"),
     # r03: same-box A/B baselines and the cost of the per-step previous-point copy (upper bound: the copy removed)
     ("sei_late_O3", [3], {3: "-O3"}, LATE, "c5", "c5_nmc_sei"),
+    # r03: recursive doubling in the block sweeps of the solve (default) against the one-lane recurrence
+    ("iso_stride1", [0], {0: "-O3"}, LATE + ["-DPL_EXP_NO_STRIDE2"], "c2 c4", "evaluators"),
+    ("sei_stride1", [3], {3: "-O3"}, LATE + ["-DPL_EXP_NO_STRIDE2"], "c5", "evaluators"),
     ("iso_noprev", [0], {0: "-O3"}, LATE + ["-DPL_EXP_NO_PREV"], "c2 c4", "evaluators"),
     ("th_noprev", [4], {4: "-O3"}, EARLY + ["-DPL_EXP_NO_PREV"], "c3", "evaluators"),
     ("sei_noprev", [3], {3: "-O3"}, LATE + ["-DPL_EXP_NO_PREV"], "c5", "evaluators"),
