@@ -343,7 +343,7 @@ def tight_compare(pkg, p, O, th, soc, protocol, sample_dt=50.0, tol=None, max_po
       V        max over the common stop times of |V_dev - V_orc| / |V_orc|
       legs     per run: (flag_dev, flag_orc, t_end_dev, t_end_orc, end-state deviation), the last one measured against the oracle's trajectory at the DEVICE's own end
                time (quadratic interpolation of the oracle's saved states on the fine stop grid): the end state of a run cannot be compared at unequal times
-      n_times  number of common stop times"""
+      n_times  number of common stop times;   worst = (state section, run index, run-local time) of `traj`;   by_field[section] = [its part of `traj`, its scale]"""
     tol = dict(tol or TIGHT)
     runs = runs_to_oracle(O, p, pkg, protocol)
     okw = dict(maxiters=120000, **tol, **(extra_opts or {}))
@@ -370,7 +370,8 @@ def tight_compare(pkg, p, O, th, soc, protocol, sample_dt=50.0, tol=None, max_po
     scale = {name: max(np.abs(Yo[:, a:e]).max(), 1e-300) for name, a, e in secs}
     # saved points of run k: [start[k], start[k+1])   (run.info.iterations = points of the run)
     sd = np.concatenate([[0], np.cumsum([int(x) for x in info["iterations"]])]); so = np.concatenate([[0], np.cumsum([r["iterations"] for r in ro["runs"]])])
-    traj, dV, ntimes, legs = 0.0, 0.0, 0, []
+    traj, dV, ntimes, legs, worst = 0.0, 0.0, 0, [], None
+    by_field = {name: [0.0, float(scale[name])] for name, a, e in secs}
     t0d = t0o = 0.0
     for k, rr in enumerate(ro["runs"]):
         a_d, e_d, a_o, e_o = int(sd[k]), int(sd[k + 1]), int(so[k]), int(so[k + 1])
@@ -381,7 +382,10 @@ def tight_compare(pkg, p, O, th, soc, protocol, sample_dt=50.0, tol=None, max_po
         ia, ib = ia[on_grid] + a_d, ib[on_grid] + a_o
         for name, a, e in secs:
             if len(ia):
-                traj = max(traj, float(np.abs(Yd[ia, a:e] - Yo[ib, a:e]).max() / scale[name]))
+                dev = np.abs(Yd[ia, a:e] - Yo[ib, a:e]).max(axis=1) / scale[name]
+                by_field[name][0] = max(by_field[name][0], float(dev.max()))
+                if float(dev.max()) > traj:
+                    traj, worst = float(dev.max()), (name, k, float(ld[ia[int(dev.argmax())] - a_d]))      # (section, run, run-local time of the largest deviation)
         if len(ia):
             dV = max(dV, float((np.abs(Vd[ia] - Vo[ib]) / np.abs(Vo[ib])).max()))
         ntimes += len(ia)
@@ -398,4 +402,4 @@ def tight_compare(pkg, p, O, th, soc, protocol, sample_dt=50.0, tol=None, max_po
             Yref = _quad_interp(grid[idx], Yo[a_o:e_o][idx], loc)
         end_err = max(float(np.abs(Yend[a:e] - Yref[a:e]).max() / scale[name]) for name, a, e in secs)
         legs.append((int(info[k]["flag"]), rr["flag"], te_d, te_o, end_err))
-    return dict(tol=tol, traj=traj, V=dV, legs=legs, n_times=ntimes, steps=(int(ens.counters[0]["n_steps"]), ro["counters"]["n_steps"]), kernel_ms=ens.kernel_ms)
+    return dict(tol=tol, traj=traj, worst=worst, by_field=by_field, V=dV, legs=legs, n_times=ntimes, steps=(int(ens.counters[0]["n_steps"]), ro["counters"]["n_steps"]), kernel_ms=ens.kernel_ms)
