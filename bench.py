@@ -177,10 +177,13 @@ def general_path(pkg, p, inp, Theta, n_local, kernel_ms, reps=5):
     Ival, tf = float(first["I"]), float(first.get("tf", 1e6))
     tab = dict(first); tab["I"] = ([0.0, 1e7], [Ival, Ival])                         # the same constant current as a table / as a closure of t and the state
     clo = dict(first); clo["I"] = lambda t, Y, P_: Ival + 0.0 * t + 0.0 * Y[0]
+    ps = p.ind["Φ_s"]                                                                  # (a 1e-9 C-rate per volt dependence on the cell voltage: the same workload to 1e-9, with two derivative programs)
+    clo_y = dict(first); clo_y["I"] = lambda t, Y, P_: Ival + 1e-9 * (Y[ps.start] - Y[ps.stop - 1])
     cases = [("stop times (opts.tstops; one stop beyond every run, so that the step sequence is the plain one)", proto, dict(tstops=[1e7]), None),
              ("state dump (outputs = :all)", proto, {}, "all"),
              ("table input", [tab] + proto[1:], {}, None),
              ("closure input", [clo] + proto[1:], {}, None),
+             ("closure of the state with its derivative in the Newton matrix (general control row)", [clo_y] + proto[1:], {}, None),
              ("refine = 1", proto, dict(refine=1), None)]
     out = {}
     for name, pr, okw, outputs in cases:

@@ -34,6 +34,7 @@ struct Run
     mode::Cint; value_kind::Cint; value::Cdouble; tf::Cdouble; bounds::Bounds
     n_tab::Cint; tab_t::Ptr{Cdouble}; tab_v::Ptr{Cdouble}     # VAL_TABLE: piecewise-linear input in run-local time (host arrays)
     value_cell::Ptr{Cdouble}; tf_cell::Ptr{Cdouble}           # per-cell input value / run length ([n_cells] host arrays) or C_NULL
+    n_dcol::Cint; dcol::Ptr{Cint}; dofs::Ptr{Cint}            # VAL_EXPR of the state: derivative programs d f / d Y[dcol[k]] = instructions dofs[k]:dofs[k+1] of tab_t / tab_v (0 = none)
 end
 struct Opts
     abstol::Cdouble; reltol::Cdouble; abstol_init::Cdouble; reltol_init::Cdouble

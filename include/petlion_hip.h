@@ -73,9 +73,13 @@ extern "C" {
 /* Postfix programs for PLH_VAL_EXPR: the form in which a reference input closure `I = (t, Y, YP, p) -> ...` (scalar_residual.jl:169-170, input_methods.jl:159-176) crosses the
    C ABI.  Instruction k is (opcode tab_t[k], operand tab_v[k]); the machine is a stack of at most 16 doubles, the program must leave exactly one value.  Operands: the constant
    for CONST, a 0-based state index for Y / YP, a 0-based position in the model's theta_keys for THETA; unused otherwise.  The closure is evaluated with the current iterate inside
-   every residual evaluation of the run (also during the consistent initialisation), like run.func in scalar_residual!.  Its derivative with respect to Y is NOT put into the
-   Newton matrix -- the reference's own fallback for closures it cannot differentiate (scalar_residual.jl:248-274, _get_method_funcs_no_differentiation): the converged states
-   satisfy the same equations, the Newton iteration may take different steps than with the reference's symbolic derivative. */
+   every residual evaluation of the run (also during the consistent initialisation), like run.func in scalar_residual!.
+   Derivatives (plh_run.n_dcol / dcol / dofs): the reference differentiates a closure of the state symbolically and puts the row d(method - f)/dY into the Newton matrix
+   (differentiate_residual_func, scalar_residual.jl:276-416).  The caller does the same differentiation (it holds the expression) and passes, for each state column dcol[k]
+   the closure reads, a program for d f / d Y[dcol[k]]: instructions [dofs[k], dofs[k+1]) of the SAME tab_t / tab_v arrays (dofs[0] >= n_tab).  The device evaluates them at
+   every Jacobian refresh and solves with the general control row (one extra structured solve per factorisation, two dot products per solve).  n_dcol = 0 is the reference's
+   own fallback for closures it cannot differentiate (scalar_residual.jl:248-274, _get_method_funcs_no_differentiation): same converged states, other Newton steps -- it is
+   what a closure that reads YP gets here (the reference substitutes the differential equations for YP in its consistent-initialisation row, :335-362; not built). */
 #define PLH_OP_CONST 0
 #define PLH_OP_T 1
 #define PLH_OP_Y 2
@@ -103,6 +107,7 @@ extern "C" {
 #define PLH_OP_TANH 24
 #define PLH_N_OPS 25
 #define PLH_EXPR_STACK 16
+#define PLH_MAX_DCOL 60     /* most state columns a closure's derivative programs may name (plh_run.n_dcol) */
 
 /* per-cell status beyond the reference's exit flags */
 #define PLH_FLAG_RUNNING (-1)
@@ -151,6 +156,9 @@ typedef struct {
   /* ensemble axis of the protocol itself: per-cell input value (PLH_VAL_CONST only, e.g. a C-rate sweep) and per-cell run length, [n_cells] HOST
      arrays staged by plh_integrate; NULL = every cell uses `value` / `tf`.  (New: the reference runs one cell per simulate() call.) */
   const double* value_cell; const double* tf_cell;
+  /* PLH_VAL_EXPR of the state: derivative programs of the control row (see PLH_VAL_EXPR above); HOST arrays, dcol[n_dcol] 0-based state columns in ascending order,
+     dofs[n_dcol + 1] instruction offsets into tab_t / tab_v.  n_dcol = 0: no differentiation. */
+  int n_dcol; const int* dcol; const int* dofs;
 } plh_run;
 
 /* reference options_simulation (src/structures.jl:266-285), the numerical subset */

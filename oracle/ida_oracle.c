@@ -369,6 +369,9 @@ typedef struct {   /* one run of a protocol = one simulate()/simulate!() call */
   /* ORC_VAL_TABLE: the input is a function of the run-local time (reference run_function, structures.jl), given as a piecewise-linear
      table; a repeated knot time is a jump (right-continuous); beyond the last knot the last value holds */
   int n_tab; const double* tab_t; const double* tab_v;
+  /* ORC_VAL_EXPR of the state: the symbolic derivative of the closure, d f / d Y[dcol[k]] = instructions [dofs[k], dofs[k+1]) of the same arrays -- what the reference's
+     differentiate_residual_func (scalar_residual.jl:276-416) compiles into J_scalar_func; n_dcol = 0: _get_method_funcs_no_differentiation (:248-274) */
+  int n_dcol; const int* dcol; const int* dofs;
 } orc_run;
 
 typedef struct {   /* reference options_simulation, src/structures.jl:266-285 */
@@ -417,9 +420,12 @@ typedef struct {
   const double* th;
   int mode; double value;
   /* full Jacobian CSC (N x N) = base rows + control row */
-  int *cp, *ri; double* ax; int nnz; int* base_map; int n_ctrl; int ctrl_pos[64]; int ctrl_col[64];
+  int *cp, *ri; double* ax; int nnz; int* base_map; int n_ctrl; int ctrl_pos[128]; int ctrl_col[128];
   /* algebraic Jacobian CSC (N_alg x N_alg) */
-  int *acp, *ari; double* aax; int annz; int* abase_map; int an_ctrl; int actrl_pos[64]; int actrl_col[64];
+  int *acp, *ari; double* aax; int annz; int* abase_map; int an_ctrl; int actrl_pos[128]; int actrl_col[128];
+  /* closure with derivative programs (drun->n_dcol > 0): the control row = the input method's own entries (the first n_base / an_base columns above) minus d f / d Y, whose
+     columns not already in the row follow them (scalar_residual.jl:300-303: J_sp_scalar[J_vec.nzind] .= 1); dpos[k] / adpos[k] = position of column dcol[k] (-1: not in the block) */
+  const orc_run* drun; int n_base, an_base; int dpos[64], adpos[64];
   double *tmp_nz, *w;
   double *ax_f, *aax_f, *rtmp, *xtmp;   /* the matrices as last factored (iterative refinement), work vectors */
   double I1C;
@@ -467,9 +473,9 @@ static double tab_eval(const orc_run* r, double t) {
   const double dt = tt[k + 1] - tt[k];
   return dt > 0.0 ? vv[k] + (vv[k + 1] - vv[k]) * ((t - tt[k]) / dt) : vv[k + 1];
 }
-static double expr_eval(const orc_run* r, double t, const double* Y, const double* YP, const double* th) {
+static double expr_eval_range(const orc_run* r, double t, const double* Y, const double* YP, const double* th, int k0, int k1) {
   double st[64]; int sp = 0;
-  for (int k = 0; k < r->n_tab; k++) {
+  for (int k = k0; k < k1; k++) {
     const int op = (int)r->tab_t[k]; const double a = r->tab_v[k];
     switch (op) {
       case OP_CONST: st[sp++] = a; break; case OP_T: st[sp++] = t; break; case OP_Y: st[sp++] = Y[(int)a]; break; case OP_YP: st[sp++] = YP[(int)a]; break;
@@ -487,6 +493,7 @@ static double expr_eval(const orc_run* r, double t, const double* Y, const doubl
   }
   return st[0];
 }
+static double expr_eval(const orc_run* r, double t, const double* Y, const double* YP, const double* th) { return expr_eval_range(r, t, Y, YP, th, 0, r->n_tab); }
 static double run_input(const orc_run* r, double t, const double* Y, const double* YP, const double* th) {
   return r->value_kind == ORC_VAL_EXPR ? expr_eval(r, t, Y, YP, th) : tab_eval(r, t);
 }
@@ -501,14 +508,24 @@ static double calc_I1C_c(const orc_model* m, const double* th) {
   return (96485.3321233 / 3600.0) * (a < b ? a : b);
 }
 
-static int evalb_init(evalb* e, const orc_model* m, const double* th, int mode, double value, orc_counters* cnt) {
+static int evalb_init_d(evalb* e, const orc_model* m, const double* th, int mode, double value, orc_counters* cnt, const orc_run* drun) {
   memset(e, 0, sizeof(*e));
-  e->m = *m; e->th = th; e->mode = mode; e->value = value; e->cnt = cnt;
+  e->m = *m; e->th = th; e->mode = mode; e->value = value; e->cnt = cnt; e->drun = drun;
   int N = m->N, Nd = m->Nd, Na = N - Nd;
   if (mode == ORC_MODE_DT && !m->thermal) return -1;
-  e->n_ctrl = ctrl_columns(m, mode, e->ctrl_col, 0);
+  e->n_ctrl = e->n_base = ctrl_columns(m, mode, e->ctrl_col, 0);
+  e->an_ctrl = e->an_base = ctrl_columns(m, mode, e->actrl_col, 1);
+  if (drun) {
+    if (drun->n_dcol > 64 || mode == ORC_MODE_DT) return -1;
+    for (int k = 0; k < drun->n_dcol; k++) {
+      const int c = drun->dcol[k]; int q;
+      for (q = 0; q < e->n_ctrl; q++) if (e->ctrl_col[q] == c) break;
+      if (q == e->n_ctrl) e->ctrl_col[e->n_ctrl++] = c;
+      e->dpos[k] = q; e->adpos[k] = -1;
+      if (c >= Nd) { for (q = 0; q < e->an_ctrl; q++) if (e->actrl_col[q] == c) break; if (q == e->an_ctrl) e->actrl_col[e->an_ctrl++] = c; e->adpos[k] = q; }
+    }
+  }
   build_pattern(N, N - 1, m->colptr, m->rowval, 0, e->n_ctrl, e->ctrl_col, &e->cp, &e->ri, &e->nnz, &e->base_map, e->ctrl_pos);
-  e->an_ctrl = ctrl_columns(m, mode, e->actrl_col, 1);
   build_pattern(Na, Na - 1, m->acolptr, m->arowval, Nd, e->an_ctrl, e->actrl_col, &e->acp, &e->ari, &e->annz, &e->abase_map, e->actrl_pos);
   e->ax = (double*)calloc(e->nnz, sizeof(double)); e->aax = (double*)calloc(e->annz, sizeof(double));
   e->tmp_nz = (double*)calloc(m->nnz + 64, sizeof(double)); e->w = (double*)calloc(N, sizeof(double));
@@ -517,6 +534,18 @@ static int evalb_init(evalb* e, const orc_model* m, const double* th, int mode, 
   e->I1C = calc_I1C_c(m, th);
   splu_init(&e->lu, N, e->cp, e->ri); splu_init(&e->alu, Na, e->acp, e->ari);
   return 0;
+}
+static int evalb_init(evalb* e, const orc_model* m, const double* th, int mode, double value, orc_counters* cnt) { return evalb_init_d(e, m, th, mode, value, cnt, NULL); }
+/* minus the closure's derivative programs into the control row (J_scalar_func of differentiate_residual_func); alg: the columns of the algebraic block only
+   (J_vec[N.diff+1:end], scalar_residual.jl:369-371) */
+static void ctrl_row_derivatives(const evalb* e, const double* Y, const double* YP, double* ax, const int* cpos, int n_base, int n_ctrl, int alg) {
+  const orc_run* r = e->drun;
+  if (!r) return;
+  for (int q = n_base; q < n_ctrl; q++) ax[cpos[q]] = 0.0;
+  for (int k = 0; k < r->n_dcol; k++) {
+    const int q = alg ? e->adpos[k] : e->dpos[k];
+    if (q >= 0) ax[cpos[q]] -= expr_eval_range(r, e->t_fun, Y, YP, e->th, r->dofs[k], r->dofs[k + 1]);
+  }
 }
 static void evalb_free(evalb* e) {
   free(e->cp); free(e->ri); free(e->ax); free(e->base_map); free(e->acp); free(e->ari); free(e->aax); free(e->abase_map);
@@ -567,6 +596,7 @@ static void J_full(evalb* e, const double* Y, const double* YP, double cj) {
   else if (e->mode == ORC_MODE_V) { e->ax[e->ctrl_pos[0]] = 1.0; e->ax[e->ctrl_pos[1]] = -1.0; }
   else if (e->mode == ORC_MODE_P || e->mode == ORC_MODE_ETAP) ctrl_row_P_etap(e, Y, e->ax, e->ctrl_pos);
   else for (int k = 0; k < e->n_ctrl; k++) e->ax[e->ctrl_pos[k]] = -cj * e->w[k];
+  ctrl_row_derivatives(e, Y, YP, e->ax, e->ctrl_pos, e->n_base, e->n_ctrl, 0);
   if (e->cnt) e->cnt->n_jac++;
 }
 static void J_alg(evalb* e, const double* Y, const double* YP) {
@@ -577,6 +607,7 @@ static void J_alg(evalb* e, const double* Y, const double* YP) {
   else if (e->mode == ORC_MODE_V) { e->aax[e->actrl_pos[0]] = 1.0; e->aax[e->actrl_pos[1]] = -1.0; }
   else if (e->mode == ORC_MODE_P || e->mode == ORC_MODE_ETAP) ctrl_row_P_etap(e, Y, e->aax, e->actrl_pos);
   else { m->dT_twin_jac(e->tmp_nz, Y, YP, 0.0, e->th); for (int k = 0; k < e->an_ctrl; k++) e->aax[e->actrl_pos[k]] = e->tmp_nz[k]; }
+  ctrl_row_derivatives(e, Y, YP, e->aax, e->actrl_pos, e->an_base, e->an_ctrl, 1);
   if (e->cnt) e->cnt->n_jac++;
 }
 
@@ -979,6 +1010,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       if (ctx->out_Y) { memcpy(ctx->out_Y + (size_t)nout * N, (Y_), N * sizeof(double)); } }   /* outputs = :all (sol.Y, save_outputs.jl:11-40) */ \
     nout++; } while (0)
 #define REPLACE_LAST(tt_, Y_, SOC_) do { nout--; SAVE(tt_, Y_, SOC_); } while (0)
+  evalb ev_der; int own_ev = 0;
   for (int r = 0; r < n_runs; r++) {
     const orc_run* run = &runs[r];
     int mode = run->mode;
@@ -1021,7 +1053,11 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       if (have_prev) Y[M.o_I] = prev_I; else Y[M.o_I] = 1.0;      /* input_methods.jl:171-176 */
     }
     if (!ev_ok[mode]) { if (evalb_init(&ev[mode], &M, theta, mode, value, cnt) != 0) { rc = -102; break; } ev_ok[mode] = 1; }
-    evalb* e = &ev[mode]; e->value = value; e->th = theta; e->cnt = cnt; e->frun = is_tab ? run : NULL; e->t_fun = 0.0;
+    evalb* e = &ev[mode];
+    /* a closure of the state with derivative programs has its own sparsity pattern: its own evaluator bundle */
+    if (own_ev) { evalb_free(&ev_der); own_ev = 0; }
+    if (run->value_kind == ORC_VAL_EXPR && run->n_dcol > 0) { if (evalb_init_d(&ev_der, &M, theta, mode, value, cnt, run) != 0) { rc = -102; break; } own_ev = 1; e = &ev_der; }
+    e->value = value; e->th = theta; e->cnt = cnt; e->frun = is_tab ? run : NULL; e->t_fun = 0.0;
     if (M.thermal) M.dT_weights(e->w, theta);
     int ierr = newtons_method(e, Y, YP, opts, c_e0);
     orc_runinfo* ri = &info[r]; memset(ri, 0, sizeof(*ri)); ri->flag = -1;
@@ -1096,6 +1132,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
     t_global = t_end; have_prev = 1; prev_V = ri->V; prev_I = ri->I; prev_etap = Y[M.o_ps + M.Np] - Y[M.o_pe + M.Np + M.Ns];
     if (flag < 0) { rc = 1; break; }
   }
+  if (own_ev) evalb_free(&ev_der);
   if (n_out) *n_out = nout;
   if (Y_final) memcpy(Y_final, Y, N * sizeof(double));
   if (YP_final) memcpy(YP_final, YP, N * sizeof(double));

@@ -27,7 +27,8 @@ class Bounds(C.Structure):
 
 class Run(C.Structure):
     _fields_ = [("mode", C.c_int), ("value_kind", C.c_int), ("value", C.c_double), ("tf", C.c_double), ("bounds", Bounds),
-                ("n_tab", C.c_int), ("tab_t", C.POINTER(C.c_double)), ("tab_v", C.POINTER(C.c_double))]
+                ("n_tab", C.c_int), ("tab_t", C.POINTER(C.c_double)), ("tab_v", C.POINTER(C.c_double)),
+                ("n_dcol", C.c_int), ("dcol", C.POINTER(C.c_int)), ("dofs", C.POINTER(C.c_int))]
 
 
 class Opts(C.Structure):
@@ -129,7 +130,11 @@ def simulate(variant, theta, SOC0, runs, opts=None, max_out=20000, Y_init=None, 
         if r.get("expr") is not None:         # (opcodes, operands): closure input as a postfix program (ORC_VAL_EXPR)
             oo = np.ascontiguousarray(r["expr"][0], dtype=np.float64); aa = np.ascontiguousarray(r["expr"][1], dtype=np.float64)
             keep.append((oo, aa))
-            arr[k].value_kind = VAL_EXPR; arr[k].n_tab = len(oo); arr[k].tab_t = _dp(oo); arr[k].tab_v = _dp(aa)
+            arr[k].value_kind = VAL_EXPR; arr[k].n_tab = len(oo) if r.get("n_main") is None else int(r["n_main"]); arr[k].tab_t = _dp(oo); arr[k].tab_v = _dp(aa)
+            if r.get("dcol") is not None:     # derivative programs of the control row: columns + instruction offsets into the same arrays (n_main = length of the main program)
+                dc = np.ascontiguousarray(r["dcol"], dtype=np.int32); do = np.ascontiguousarray(r["dofs"], dtype=np.int32)
+                keep.append((dc, do))
+                arr[k].n_dcol = len(dc); arr[k].dcol = dc.ctypes.data_as(C.POINTER(C.c_int)); arr[k].dofs = do.ctypes.data_as(C.POINTER(C.c_int))
     theta = np.ascontiguousarray(theta, dtype=np.float64)
     out = {k: np.zeros(max_out) for k in ("t", "V", "I", "SOC", "T")}
     n_out = C.c_int(0)

@@ -156,11 +156,22 @@ def _make_run(p, name, inp, tf, bounds):
         # cannot be traced (closures.TraceError says how to rewrite it); a piecewise-linear table (t, values) + opts.tdiscon remains the other way in.
         if name == "dT":
             raise ValueError("function inputs for dT are not defined by the reference")
-        ops, args = closures.trace(inp, p)
+        (ops, args), tree = closures.trace(inp, p, with_tree=True)
         r.value_kind, r.value = cap.VAL_EXPR, 0.0
         r.n_tab = ops.size
+        # a closure of Y: the entries d f / d Y[c] of the control row, as the reference's symbolic differentiation builds them (scalar_residual.jl:276-416); the programs ride
+        # behind the main one in the same arrays (plh_run.dcol / dofs)
+        der = closures.row_derivatives(tree)
+        keep = []
+        if der is not None:
+            dcol = np.ascontiguousarray(der[0], dtype=np.int32)
+            dofs = np.ascontiguousarray(np.cumsum([ops.size] + [q[0].size for q in der[1]]), dtype=np.int32)
+            ops = np.concatenate([ops] + [q[0] for q in der[1]]); args = np.concatenate([args] + [q[1] for q in der[1]])
+            r.n_dcol = dcol.size
+            r.dcol = dcol.ctypes.data_as(C.POINTER(C.c_int)); r.dofs = dofs.ctypes.data_as(C.POINTER(C.c_int))
+            keep = [dcol, dofs]
         r.tab_t = ops.ctypes.data_as(C.POINTER(C.c_double)); r.tab_v = args.ctypes.data_as(C.POINTER(C.c_double))
-        r._keep = (ops, args)
+        r._keep = (ops, args, *keep)
     elif isinstance(inp, (tuple, list)) and len(inp) == 2 and np.ndim(inp[0]) == 1:
         if name == "dT":
             raise ValueError("time-dependent dT inputs are not defined by the reference")

@@ -173,7 +173,101 @@ def compile_tree(x):
     return np.array(ops, dtype=np.float64), np.array(args, dtype=np.float64)
 
 
-def trace(f, p):
+def _is_const(x, v=None):
+    return x.op == "CONST" and (v is None or x.arg == v)
+
+
+def _add(a, b):
+    if a is None: return b
+    if b is None: return a
+    return a._bin("ADD", b)
+
+
+def _sub(a, b):
+    if b is None: return a
+    if a is None: return X("NEG", 0.0, (b,))
+    return a._bin("SUB", b)
+
+
+def _mul(a, b):
+    """a * b with a or b possibly None (= 0) and the unit factor folded"""
+    if a is None or b is None or _is_const(a, 0.0) or _is_const(b, 0.0): return None
+    if _is_const(a, 1.0): return b
+    if _is_const(b, 1.0): return a
+    return a._bin("MUL", b)
+
+
+def diff(x, kind, idx):
+    """d x / d Y[idx] (kind = "Y") or d x / d YP[idx] (kind = "YP") of a traced value as another traced value; None = identically zero.  The rules are the ones Symbolics
+    applies to the same closure in the reference (scalar_residual.jl:289-291, sparsejacobian of the traced control row): ifelse / min / max / abs differentiate branch-wise,
+    comparisons are constants."""
+    one = X("CONST", 1.0)
+    op, k = x.op, x.kids
+    if op in ("CONST", "T", "THETA"): return None
+    if op in ("Y", "YP"): return one if (op == kind and int(x.arg) == idx) else None
+    if op in ("LT", "LE", "GT", "GE"): return None
+    d = [diff(c, kind, idx) for c in k]
+    if all(v is None for v in d): return None
+    if op == "ADD": return _add(d[0], d[1])
+    if op == "SUB": return _sub(d[0], d[1])
+    if op == "NEG": return X("NEG", 0.0, (d[0],))
+    if op == "MUL": return _add(_mul(d[0], k[1]), _mul(k[0], d[1]))
+    if op == "DIV":                                                          # a' / b - (a / b) b' / b
+        t1 = None if d[0] is None else d[0]._bin("DIV", k[1])
+        t2 = None if d[1] is None else _mul(x, d[1])._bin("DIV", k[1])
+        return _sub(t1, t2)
+    if op == "SIN": return _mul(X("COS", 0.0, (k[0],)), d[0])
+    if op == "COS": return X("NEG", 0.0, (_mul(X("SIN", 0.0, (k[0],)), d[0]),))
+    if op == "EXP": return _mul(x, d[0])
+    if op == "LOG": return d[0]._bin("DIV", k[0])
+    if op == "SQRT": return d[0]._bin("DIV", X("CONST", 2.0)._bin("MUL", x))
+    if op == "TANH": return _mul(one._bin("SUB", x._bin("MUL", x)), d[0])
+    if op == "ABS": return X("SELECT", 0.0, (k[0]._bin("GE", 0.0), d[0], X("NEG", 0.0, (d[0],))))
+    if op == "POW":
+        out = None
+        if d[0] is not None:                                                 # b a^(b-1) a'
+            bm1 = X("CONST", k[1].arg - 1.0) if _is_const(k[1]) else k[1]._bin("SUB", 1.0)
+            out = _mul(_mul(k[1], k[0]._bin("POW", bm1)), d[0])
+        if d[1] is not None:                                                 # a^b log(a) b'
+            out = _add(out, _mul(_mul(x, X("LOG", 0.0, (k[0],))), d[1]))
+        return out
+    z = lambda v: X("CONST", 0.0) if v is None else v
+    if op == "MIN": return X("SELECT", 0.0, (k[0]._bin("LT", k[1]), z(d[0]), z(d[1])))
+    if op == "MAX": return X("SELECT", 0.0, (k[0]._bin("GT", k[1]), z(d[0]), z(d[1])))
+    if op == "SELECT": return X("SELECT", 0.0, (k[0], z(d[1]), z(d[2]))) if (d[1] is not None or d[2] is not None) else None
+    raise TraceError("no derivative rule for " + op)
+
+
+def _refs(x, kind, acc):
+    if x.op == kind:
+        acc.add(int(x.arg))
+    for c in x.kids:
+        _refs(c, kind, acc)
+    return acc
+
+
+def row_derivatives(x):
+    """what the reference's differentiate_residual_func (scalar_residual.jl:276-416) builds for a closure of the state: the entries d f / d Y[c] of the control row, as
+    (columns, [program per column]) -- or None when the closure reads YP (its consistent-initialisation form substitutes the differential equations for YP; not built
+    here) or a derivative does not fit the device interpreter's stack: the run then uses the reference's no-differentiation fallback (scalar_residual.jl:248-274)."""
+    x = X.lift(x)
+    cols = sorted(_refs(x, "Y", set()))
+    if not cols or _refs(x, "YP", set()):
+        return None
+    out_c, out_p = [], []
+    for c in cols:
+        d = diff(x, "Y", c)
+        if d is None:
+            continue
+        try:
+            out_p.append(compile_tree(d))
+        except TraceError:
+            return None
+        out_c.append(c)
+    return (out_c, out_p) if out_c else None
+
+
+def trace(f, p, with_tree=False):
     """postfix program of the input closure f for model p"""
     n = len(inspect.signature(f).parameters)
     t, Y, YP, P = X("T"), _StateVec("Y", p.N.tot), _StateVec("YP", p.N.tot), _P(p)
@@ -187,7 +281,7 @@ def trace(f, p):
         out = f(t, Y, YP, P)
     else:
         raise TraceError("Input function must have one to four arguments (t, Y, YP, p)")
-    return compile_tree(out)
+    return (compile_tree(out), X.lift(out)) if with_tree else compile_tree(out)
 
 
 def evaluate(prog, t, Y=None, YP=None, theta=None):

@@ -215,8 +215,8 @@ template <class M> struct CellLDS {
   // eliminated system
   // (per-node small blocks are stored structure-of-arrays, [element][node]: the lanes of a wave own one node each, so element k of all nodes is
   //  one conflict-free LDS access; [node][element] with a row of 16 doubles puts every lane on the same bank)
-  double dj[NJ], nphi[3][M::THERMAL ? 1 : NE];      // j pivot; phi_c = omega . A_ux[:,c] (node block D[r][c] -= t_r phi_c, t = (ceJ, peJ, psJ))
-  double colI[3][M::THERMAL ? 1 : NE];              // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
+  double dj[NJ], nphi[M::THERMAL ? 1 : 3][M::THERMAL ? 1 : NE];      // j pivot; phi_c = omega . A_ux[:,c] (node block D[r][c] -= t_r phi_c, t = (ceJ, peJ, psJ))
+  double colI[M::THERMAL ? 1 : 3][M::THERMAL ? 1 : NE];            // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
   typename M::fact_t Dinv[M::NB * M::NB][NE], LD[M::NB * M::NB][NE];   // Thomas factors: D'^-1 and L D'^-1(prev)
   typename M::fact_t LDmid[M::NB * M::NB];                             // closing block of the twisted factorisation
   typename M::fact_t Ainv[2][(M::THERMAL || M::SD != 0) ? 1 : NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
@@ -227,7 +227,7 @@ template <class M> struct CellLDS {
   double Mr[(M::THERMAL || M::SD != 0) ? 1 : 3 * NR * NR + NR];
   static constexpr int OFF_VR = NR * NR, OFF_WR = 2 * NR * NR, OFF_LAMR = 3 * NR * NR;
   double resp[M::SD != 0 ? NJ : 1], rcjf[M::SD != 0 ? 2 : 1][2];    // quadratic / polynomial particles: d c_s* / d j after eliminating c_avg (and Q); 1/cj and 1/(-kappa - cj) of the factorisation
-  double x2[3][M::THERMAL ? 1 : NE];
+  double x2[M::THERMAL ? 1 : 3][M::THERMAL ? 1 : NE];      // (the thermal model keeps its own in ThermalPool: one placeholder element here)
   double ctrlJ[2], bord;           // P-mode control row at the last Jacobian pass (I*I1C, V*I1C); border pivot d - v.x2
   double w9[NJ > 2 * NR ? NJ : 2 * NR];
   double sig[2];
@@ -1525,6 +1525,42 @@ PL_DEV double jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsi
   else return iso_jac_entry(S, tb, w, cj);
 }
 
+// General control row: a closure input of the state whose derivative programs are given (plh_run.n_dcol > 0; reference differentiate_residual_func,
+// scalar_residual.jl:276-416 puts d(method - f)/dY into the last row of the Newton matrix).  The row can touch any column, so it is handled as a BORDER of the
+// structured solve in current mode (whose control row is "x_I = b_I"):  with W = J_I^-1 e_I (the image of the I column, W[O_I] = 1; one extra solve per factorisation,
+// kept in HBM) and x0 the mode-I solve of the right-hand side with b_I = 0,   x_I = (b_I - g.x0) / (g.W),   x = x0 + x_I W.
+// Entry k of the row lives in lane k (gv); its column is one of the input method's own (bcol) or run->dcol[k - nb].  Built by gen_factor (dfn_integrate.h).
+struct GenRow {
+  const plh_run* run = nullptr;   // nullptr: the run has no derivative programs
+  double* W = nullptr;            // this cell's [NST] slice of IntegrateArgs.genW
+  double gv = 0.0, bord = 1.0;
+  int ng = 0, nb = 0, bc0 = 0, bc1 = 0, bc2 = 0;
+  __device__ __forceinline__ bool on() const { return run != nullptr; }
+  __device__ __forceinline__ int col(int k) const { return k >= nb ? run->dcol[k - nb] : (k == 0 ? bc0 : (k == 1 ? bc1 : bc2)); }
+  // g . b (wave-uniform; b an LDS vector)
+  __device__ __forceinline__ double dot(const double* b, int first_col) const {
+    double s = 0.0;
+    for (int k = 0; k < ng; k++) { const int c = col(k); const double v = lane_bcast(gv, k); if (c >= first_col) s += v * b[c]; }
+    return s;
+  }
+};
+template <class M>
+PL_DEV void gen_solve(CellLDS<M>& S, LaneRegs& R, double* b, bool alg_only, const GenRow& g) {
+  PL_MODEL(M);
+  const int lane = lane_id(), wv = wave_id();
+  PL_XSYNC();                                            // (two waves per cell: the control row of b is wave 0's, and nothing has synchronised since it was written)
+  const double rho = b[O_I];
+  PL_XSYNC();
+  if (lane == 0 && wv == 0) b[O_I] = 0.0;
+  PL_XSYNC();
+  cell_solve(S, R, b, PLH_MODE_I, alg_only);
+  PL_XSYNC();
+  const double xI = (rho - g.dot(b, alg_only ? NDIFF : 0)) / g.bord;
+  PL_XSYNC();
+  _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) b[n] += xI * g.W[n];
+  PL_XSYNC();
+}
+
 // J x = b with `nref` steps of iterative refinement  x += J^-1 (b - J x)  against the matrix of the last factorisation (cjf = its cj): the parity mode
 // plh_opts.refine.  The structured elimination (cell_solve) and a sparse LU (KLU in the reference, the oracle's LU) order their operations differently,
 // so their solutions of the ill-conditioned Newton systems (cond ~1e15, badly row-scaled) differ by 1e-12 .. 3e-9 (tools/solve_accuracy.py); one
@@ -1533,11 +1569,11 @@ PL_DEV double jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsi
 // b: LDS vector (in: right-hand side, out: solution); bsave: a free LDS vector.  alg_only: rows/columns >= NDIFF of the consistent-initialisation Newton
 // (the dT twin row has no exported entries: its residual is taken as zero, i.e. the row is not refined).
 template <class M>
-PL_DEV void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, double* bsave, double cjf, int mode, bool alg_only, int nref) {
+PL_DEV void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, double* b, double* bsave, double cjf, int mode, bool alg_only, int nref, const GenRow* g = nullptr) {
   PL_MODEL(M);
   const int lane = lane_id();
   const bool twin = mode == PL_MODE_DT_TWIN;
-  const int jm = twin ? PLH_MODE_DT : mode;
+  const int jm = g ? PLH_MODE_I : (twin ? PLH_MODE_DT : mode);       // (general control row: rows other than the last as exported for current mode, the last from g)
   const int* __restrict__ ptr = tb->csr_ptr[jm]; const unsigned* __restrict__ code = tb->csr_code[jm]; const unsigned short* __restrict__ col = tb->csr_col[jm];
   const double cj = alg_only ? 0.0 : cjf;
   double xr[NTRIP];
@@ -1548,6 +1584,7 @@ PL_DEV void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restr
     if (it > 0) {
       double rr[NTRIP];
       PL_XSYNC();                                          // the solution of the previous pass is complete in b (both waves)
+      const double gdot = g ? g->dot(b, alg_only ? NDIFF : 0) : 0.0;
       _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) {
         const int n = vrow<M>(k__, lane, wv);
         xr[k__] = 0.0; rr[k__] = 0.0;
@@ -1555,6 +1592,7 @@ PL_DEV void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restr
           xr[k__] = b[n];
           double s = 0.0;
           for (int k = ptr[n]; k < ptr[n + 1]; k++) { const int c = col[k]; if (!alg_only || c >= NDIFF) s += jac_entry<true>(S, tb, code[k], cj) * b[c]; }
+          if (g && n == O_I) s = gdot;
           rr[k__] = (twin && n == O_I) ? 0.0 : bsave[n] - s;
         }
       }
@@ -1562,7 +1600,7 @@ PL_DEV void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restr
       _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) b[n] = rr[k__];
       PL_XSYNC();
     }
-    cell_solve(S, R, b, mode, alg_only);
+    if (g) gen_solve(S, R, b, alg_only, *g); else cell_solve(S, R, b, mode, alg_only);
     if (it > 0) {
       _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) b[n] += xr[k__];
       PL_SYNC();

@@ -63,15 +63,95 @@ __device__ __forceinline__ double wrms(const double* v, const double* w) {
   return sqrt(wave_sum(s) * (1.0 / NST));      // (one-wave models only; unused by the integrator)
 }
 
+// value of a tabulated input at run-local time t (reference run_function: method(Y,p) - run.func(t,Y,YP,p), scalar_residual.jl:169-170);
+// wave-uniform: every lane walks the (small) table in HBM through scalar loads
+PL_DEV double tab_eval(const plh_run& r, double t) {
+  const int n = r.n_tab; const double* tt = r.tab_t; const double* vv = r.tab_v;
+  if (n <= 0) return 0.0;
+  if (t < tt[0]) return vv[0];
+  int lo = 0, hi = n;                                                  // last knot with t_k <= t (a repeated knot time is a jump, right-continuous):
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tt[mid] <= t) lo = mid; else hi = mid; }   // bisection, O(log n) loads per evaluation (drive cycles)
+  const int k = lo;
+  if (k == n - 1) return vv[n - 1];
+  const double dt = tt[k + 1] - tt[k];
+  return dt > 0.0 ? vv[k] + (vv[k + 1] - vv[k]) * ((t - tt[k]) / dt) : vv[k + 1];
+}
+// value of a closure input (PLH_VAL_EXPR): a postfix program over t, Y, YP, theta (include/petlion_hip.h); wave-uniform, every lane runs it (scalar loads of the program,
+// broadcast LDS reads of the states).  The value stack is an LDS array -- every lane stores the same value at the same address -- because a runtime-indexed private array
+// would live in scratch memory, once per inlined copy of this function.
+template <class M>
+PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP, int k0 = 0, int k1 = -1) {      // instructions [k0, k1); default: the main program
+  double* st = S.xstk + PLH_EXPR_STACK * wave_id(); const double* th = S.theta_row; int sp = 0;
+  if (k1 < 0) k1 = r.n_tab;
+  for (int k = k0; k < k1; k++) {
+    const int op = (int)r.tab_t[k]; const double a = r.tab_v[k];
+    if (op <= PLH_OP_THETA) {
+      double v;
+      switch (op) { case PLH_OP_CONST: v = a; break; case PLH_OP_T: v = t; break; case PLH_OP_Y: v = Y[(int)a]; break; case PLH_OP_YP: v = YP[(int)a]; break; default: v = th[(int)a]; }
+      st[sp++] = v;
+    } else if (op == PLH_OP_SELECT) { const double b = st[sp - 1], x = st[sp - 2], c = st[sp - 3]; sp -= 2; st[sp - 1] = c != 0.0 ? x : b; }
+    else if (op == PLH_OP_NEG || op == PLH_OP_SIN || op == PLH_OP_COS || op == PLH_OP_EXP || op == PLH_OP_LOG || op == PLH_OP_SQRT || op == PLH_OP_ABS || op == PLH_OP_TANH) {
+      const double x = st[sp - 1]; double v;
+      switch (op) { case PLH_OP_NEG: v = -x; break; case PLH_OP_SIN: v = sin(x); break; case PLH_OP_COS: v = cos(x); break; case PLH_OP_EXP: v = exp(x); break;
+                    case PLH_OP_LOG: v = log(x); break; case PLH_OP_SQRT: v = sqrt(x); break; case PLH_OP_ABS: v = fabs(x); break; default: v = tanh(x); }
+      st[sp - 1] = v;
+    } else {
+      const double y = st[sp - 1], x = st[sp - 2]; sp--; double v;
+      switch (op) { case PLH_OP_ADD: v = x + y; break; case PLH_OP_SUB: v = x - y; break; case PLH_OP_MUL: v = x * y; break; case PLH_OP_DIV: v = x / y; break;
+                    case PLH_OP_POW: v = pow(x, y); break; case PLH_OP_MIN: v = x < y ? x : y; break; case PLH_OP_MAX: v = x > y ? x : y; break;
+                    case PLH_OP_LT: v = x < y ? 1.0 : 0.0; break; case PLH_OP_LE: v = x <= y ? 1.0 : 0.0; break; case PLH_OP_GT: v = x > y ? 1.0 : 0.0; break; default: v = x >= y ? 1.0 : 0.0; }
+      st[sp - 1] = v;
+    }
+  }
+  return st[0];
+}
+// input of a run_function run at run-local time t with the iterate (Y, YP): table or closure
+template <int F, class M>
+PL_DEV double run_input(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP) {
+  if constexpr ((F & GF_EXPR) != 0) return r.value_kind == PLH_VAL_EXPR ? expr_eval(S, r, t, Y, YP) : tab_eval(r, t);
+  else return tab_eval(r, t);
+}
+// Jacobian refresh of a run with a general control row (GenRow, dfn_cell.h): factor in current mode, evaluate the row at (t, Y, YP) -- the input method's own entries
+// (scalar_jacobian!, scalar_residual.jl:174-202) and minus the closure's derivative programs --, one solve for W = J_I^-1 e_I into the free LDS vector `tmp`, border pivot g.W.
+// alg_only: the algebraic block of the consistent initialisation (columns >= NDIFF of the row, J_vec[N.diff+1:end], scalar_residual.jl:369-371).
+template <class M>
+PL_DEV void gen_factor(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double cj, int mode, bool alg_only, GenRow& g, double t, const double* Y, const double* YP, double* tmp) {
+  PL_MODEL(M);
+  const int lane = lane_id();
+  const plh_run& r = *g.run;
+  double b0, b1 = 0.0, b2 = 0.0;
+  if (mode == PLH_MODE_I) { g.nb = 1; g.bc0 = O_I; b0 = 1.0; }
+  else if (mode == PLH_MODE_V) { g.nb = 2; g.bc0 = O_PS; g.bc1 = O_PS + NJ - 1; b0 = 1.0; b1 = -1.0; }
+  else if (mode == PLH_MODE_P) { g.nb = 3; g.bc0 = O_PS; g.bc1 = O_PS + NJ - 1; g.bc2 = O_I; b0 = Y[O_I] * S.cc.I1C; b1 = -b0; b2 = (Y[O_PS] - Y[O_PS + NJ - 1]) * S.cc.I1C; }
+  else { g.nb = 2; g.bc0 = O_PE + NP + NS; g.bc1 = O_PS + NP; b0 = -1.0; b1 = 1.0; }                      // eta_p
+  g.ng = g.nb + r.n_dcol;
+  double gv = 0.0;
+  for (int k = 0; k < g.ng; k++) {
+    double v = k >= g.nb ? -expr_eval(S, r, t, Y, YP, r.dofs[k - g.nb], r.dofs[k - g.nb + 1]) : (k == 0 ? b0 : (k == 1 ? b1 : b2));
+    if (alg_only && g.col(k) < NDIFF) v = 0.0;
+    if (lane == k) gv = v;
+  }
+  g.gv = gv;
+  cell_factor(S, R, tb, cj, PLH_MODE_I, alg_only);
+  PL_XSYNC();
+  PL_VEC(n) tmp[n] = n == O_I ? 1.0 : 0.0;
+  PL_XSYNC();
+  cell_solve(S, R, tmp, PLH_MODE_I, alg_only);
+  PL_XSYNC();
+  PL_VEC(n) g.W[n] = tmp[n];
+  g.bord = g.dot(tmp, alg_only ? NDIFF : 0);
+  PL_XSYNC();
+}
+
 // ---- consistent initialisation (newtons_method!) : Y (LDS, in/out), YP (LDS, out).  returns 0 / PLH_ERR_INIT ----
 // Returns the number of Newton iterations (>= 1) or PLH_ERR_INIT.  cell_simulate has exactly ONE call site (the re-initialisation of a
 // function input loops back to it): a second inlined copy costs 4-5 % of the step loop in instruction-cache misses, and a real call
 // spills the ~100 live registers of the step loop.
-template <class M> PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP);     // closure inputs (PLH_VAL_EXPR), defined below
 // `frun` (general instantiation only): the run when its input is a closure of the state -- re-evaluated with the iterate before every residual evaluation, at run-local time t_fun
 template <int F, class M>
 PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
-                                                      int mode, double value, double reltol_init, double* bsave = nullptr, int nref = 0, const plh_run* frun = nullptr, double t_fun = 0.0) {
+                                                      int mode, double value, double reltol_init, double* bsave = nullptr, int nref = 0, const plh_run* frun = nullptr, double t_fun = 0.0,
+                                                      GenRow* g = nullptr) {
   LaneRegs R;                                                        // (the algebraic solves do not touch the particle registers)
   for (int k = 0; k < CS_PASS; k++) R.wreg[k] = 0.0;
   int iters = 0;
@@ -86,8 +166,12 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
     if constexpr ((F & GF_EXPR) != 0) { if (frun) value = expr_eval(S, *frun, t_fun, Y, YP); }
     cell_node_pass<true, true>(S, Y, YP, res, mode, value);      // R_alg + J_alg partials (differential rows ignored)
     PL_SYNC();
-    cell_factor(S, R, tb, 0.0, mode, true);
-    if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref);     // (GF_REFINE instantiations only: plh_opts.refine)
+    bool gen = false;
+    if constexpr ((F & GF_EXPR) != 0) gen = g && g->on();
+    if constexpr ((F & GF_EXPR) != 0) { if (gen) gen_factor(S, R, tb, 0.0, mode, true, *g, t_fun, Y, YP, Ytmp); }        // (Ytmp is free until the Newton iteration is over)
+    if (!gen) cell_factor(S, R, tb, 0.0, mode, true);
+    if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref, gen ? g : nullptr);     // (GF_REFINE instantiations only: plh_opts.refine)
+    else if (gen) gen_solve(S, R, res, true, *g);
     else cell_solve(S, R, res, mode, true);
     iters++;
     double s = 0.0;
@@ -113,7 +197,10 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   if constexpr ((F & GF_EXPR) != 0) { if (frun) value = expr_eval(S, *frun, t_fun, Ytmp, YP); }
   cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
   PL_SYNC();
-  if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref);
+  bool gen = false;
+  if constexpr ((F & GF_EXPR) != 0) gen = g && g->on();
+  if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref, gen ? g : nullptr);
+  else if (gen) gen_solve(S, R, res, true, *g);
   else cell_solve(S, R, res, mode, true);
   if (!M::W2 || wave_id() == 0) for (int n = NDIFF + lane; n < NST; n += WAVE) YP[n] = -res[n] / dt;
   PL_XSYNC();
@@ -122,9 +209,9 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
 template <int F = 0, class M>
 __device__ __forceinline__ int cell_init_consistent(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double* Y, double* YP, double* res, double* Ytmp,
                                                     int mode, double value, double reltol_init, Counters& cnt, double* bsave = nullptr, int nref = 0,
-                                                    const plh_run* frun = nullptr, double t_fun = 0.0) {
+                                                    const plh_run* frun = nullptr, double t_fun = 0.0, GenRow* g = nullptr) {
   (void)R;
-  const int it = cell_init_consistent_impl<F>(S, tb, Y, YP, res, Ytmp, mode, value, reltol_init, bsave, nref, frun, t_fun);
+  const int it = cell_init_consistent_impl<F>(S, tb, Y, YP, res, Ytmp, mode, value, reltol_init, bsave, nref, frun, t_fun, g);
   if (it < 0) { cnt_add(cnt, C_INIT, 100); return it; }
   cnt_add(cnt, C_RES, it + 2); cnt_add(cnt, C_JAC, it); cnt_add(cnt, C_FACT, it); cnt_add(cnt, C_SOLVE, it + 1); cnt_add(cnt, C_INIT, it);
   return 0;
@@ -227,7 +314,7 @@ PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
 // IDANls + Newton + convergence test.  0 ok, 1 recoverable failure
 template <int F, class M>
 PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, int mode, double value, int jac_every_step, Counters& cnt, int nref, const plh_run* xrun = nullptr,
-                   double* xvalue = nullptr) {
+                   double* xvalue = nullptr, GenRow* g = nullptr) {
   // (xrun / xvalue: a closure input is re-evaluated inside every residual and leaves the value of its last evaluation behind -- run.value[] of scalar_residual.jl:170 -- for
   //  check_reinitialization!)
   PL_MODEL(M);
@@ -259,7 +346,9 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
       cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
 #endif
 #ifndef PL_EXP_NO_FACTOR
-      cell_factor(S, R, tb, I.cj, mode, false);
+      bool genf = false;
+      if constexpr ((F & GF_EXPR) != 0) { if (g && g->on()) { genf = true; gen_factor(S, R, tb, I.cj, mode, false, *g, I.tn, S.yy, S.yp, S.yp); } }   // (S.yp is dead until the next form_iterate; the row is evaluated before W overwrites it)
+      if (!genf) cell_factor(S, R, tb, I.cj, mode, false);
 #endif
       cnt_add(cnt, C_RES); cnt_add(cnt, C_JAC); cnt_add(cnt, C_FACT);
       I.cjold = I.cj; I.cjratio = 1.0; I.ss = 20.0; jcur = 1; callLSetup = 0;
@@ -273,7 +362,10 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
     cnt_add(cnt, C_NEWTON); cnt_add(cnt, C_SOLVE);
     { PL_TIC();
 #ifndef PL_EXP_NO_SOLVE
-    if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, S.delta, S.yp, I.cjold, mode, false, nref);   // (S.yp is dead until the next form_iterate; cjold = cj of the factors)
+    bool gens = false;
+    if constexpr ((F & GF_EXPR) != 0) gens = g && g->on();
+    if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, S.delta, S.yp, I.cjold, mode, false, nref, gens ? g : nullptr);   // (S.yp is dead until the next form_iterate; cjold = cj of the factors)
+    else if (gens) gen_solve(S, R, S.delta, false, *g);
     else cell_solve(S, R, S.delta, mode, false);           // x = J^-1 F ; the Newton correction is -x
 #endif
     PL_TOC(S, PH_SOLVE); }
@@ -457,53 +549,6 @@ PL_DEV void ida_get_solution(CellLDS<M>& S, const IdaScalars& I, double t, doubl
   PL_XSYNC();
 }
 
-// value of a tabulated input at run-local time t (reference run_function: method(Y,p) - run.func(t,Y,YP,p), scalar_residual.jl:169-170);
-// wave-uniform: every lane walks the (small) table in HBM through scalar loads
-PL_DEV double tab_eval(const plh_run& r, double t) {
-  const int n = r.n_tab; const double* tt = r.tab_t; const double* vv = r.tab_v;
-  if (n <= 0) return 0.0;
-  if (t < tt[0]) return vv[0];
-  int lo = 0, hi = n;                                                  // last knot with t_k <= t (a repeated knot time is a jump, right-continuous):
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tt[mid] <= t) lo = mid; else hi = mid; }   // bisection, O(log n) loads per evaluation (drive cycles)
-  const int k = lo;
-  if (k == n - 1) return vv[n - 1];
-  const double dt = tt[k + 1] - tt[k];
-  return dt > 0.0 ? vv[k] + (vv[k + 1] - vv[k]) * ((t - tt[k]) / dt) : vv[k + 1];
-}
-// value of a closure input (PLH_VAL_EXPR): a postfix program over t, Y, YP, theta (include/petlion_hip.h); wave-uniform, every lane runs it (scalar loads of the program,
-// broadcast LDS reads of the states).  The value stack is an LDS array -- every lane stores the same value at the same address -- because a runtime-indexed private array
-// would live in scratch memory, once per inlined copy of this function.
-template <class M>
-PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP) {
-  double* st = S.xstk + PLH_EXPR_STACK * wave_id(); const double* th = S.theta_row; int sp = 0;
-  for (int k = 0; k < r.n_tab; k++) {
-    const int op = (int)r.tab_t[k]; const double a = r.tab_v[k];
-    if (op <= PLH_OP_THETA) {
-      double v;
-      switch (op) { case PLH_OP_CONST: v = a; break; case PLH_OP_T: v = t; break; case PLH_OP_Y: v = Y[(int)a]; break; case PLH_OP_YP: v = YP[(int)a]; break; default: v = th[(int)a]; }
-      st[sp++] = v;
-    } else if (op == PLH_OP_SELECT) { const double b = st[sp - 1], x = st[sp - 2], c = st[sp - 3]; sp -= 2; st[sp - 1] = c != 0.0 ? x : b; }
-    else if (op == PLH_OP_NEG || op == PLH_OP_SIN || op == PLH_OP_COS || op == PLH_OP_EXP || op == PLH_OP_LOG || op == PLH_OP_SQRT || op == PLH_OP_ABS || op == PLH_OP_TANH) {
-      const double x = st[sp - 1]; double v;
-      switch (op) { case PLH_OP_NEG: v = -x; break; case PLH_OP_SIN: v = sin(x); break; case PLH_OP_COS: v = cos(x); break; case PLH_OP_EXP: v = exp(x); break;
-                    case PLH_OP_LOG: v = log(x); break; case PLH_OP_SQRT: v = sqrt(x); break; case PLH_OP_ABS: v = fabs(x); break; default: v = tanh(x); }
-      st[sp - 1] = v;
-    } else {
-      const double y = st[sp - 1], x = st[sp - 2]; sp--; double v;
-      switch (op) { case PLH_OP_ADD: v = x + y; break; case PLH_OP_SUB: v = x - y; break; case PLH_OP_MUL: v = x * y; break; case PLH_OP_DIV: v = x / y; break;
-                    case PLH_OP_POW: v = pow(x, y); break; case PLH_OP_MIN: v = x < y ? x : y; break; case PLH_OP_MAX: v = x > y ? x : y; break;
-                    case PLH_OP_LT: v = x < y ? 1.0 : 0.0; break; case PLH_OP_LE: v = x <= y ? 1.0 : 0.0; break; case PLH_OP_GT: v = x > y ? 1.0 : 0.0; break; default: v = x >= y ? 1.0 : 0.0; }
-      st[sp - 1] = v;
-    }
-  }
-  return st[0];
-}
-// input of a run_function run at run-local time t with the iterate (Y, YP): table or closure
-template <int F, class M>
-PL_DEV double run_input(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP) {
-  if constexpr ((F & GF_EXPR) != 0) return r.value_kind == PLH_VAL_EXPR ? expr_eval(S, r, t, Y, YP) : tab_eval(r, t);
-  else return tab_eval(r, t);
-}
 // next tstop after run-local time t: the sorted set opts.tstops U {tdiscon - reltol/2} U {1.0 if continuation} U {tf} of postfix_integrator!
 // (model_evaluation.jl:288-310) walked without storing it
 PL_DEV double next_tstop(const plh_opts& o, double t, bool continuation, double tf) {
@@ -528,7 +573,7 @@ PL_DEV double next_tstop(const plh_opts& o, double t, bool continuation, double 
 // one IDASolve(ONE_STEP_TSTOP) call: advances, returns y(tret), y'(tret) in S.yy / S.yp.  0 ok, <0 failure
 template <int F, class M>
 PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, double tstop, double& tret, int mode, double& value,
-                               const plh_opts& o, Counters& cnt, const plh_run* frun = nullptr) {
+                               const plh_opts& o, Counters& cnt, const plh_run* frun = nullptr, GenRow* g = nullptr) {
   PL_MODEL(M);
   const int lane = lane_id();
   const double uround = 2.220446049250313e-16;
@@ -559,7 +604,7 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
   for (;;) {
     double ck; { PL_TIC(); PL_TICE(3); ck = ida_set_coeffs(S, I); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 0); }
     if constexpr ((F & GF_FUNC) != 0) { if (frun) value = run_input<F>(S, *frun, I.tn, S.yy, S.yp); }                           // every residual of this step attempt is evaluated at t = tn
-    const int nflag = ida_nls<F>(S, R, tb, I, mode, value, o.jac_every_step, cnt, o.refine, ((F & GF_EXPR) && frun && frun->value_kind == PLH_VAL_EXPR) ? frun : nullptr, &value);
+    const int nflag = ida_nls<F>(S, R, tb, I, mode, value, o.jac_every_step, cnt, o.refine, ((F & GF_EXPR) && frun && frun->value_kind == PLH_VAL_EXPR) ? frun : nullptr, &value, g);
     int errfail = 0;
     if (nflag == 0) { PL_TIC(); PL_TICE(3); errfail = ida_test_error(S, I, ck, err_k, err_km1); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 1); }
     if (nflag != 0 || errfail) {
@@ -676,7 +721,7 @@ struct CellOut {
 template <int F, class M>
 PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
                                      const CellOut& out, int* n_pts_out, plh_run_info* info, Counters& cnt, double* Yfin, double* YPfin,
-                                     double* Yprev, double* YPprev, int cell) {
+                                     double* Yprev, double* YPprev, int cell, double* genW = nullptr) {
   PL_MODEL(M);
   const int lane = lane_id();
   IdaScalars I;
@@ -746,6 +791,8 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     PL_XSYNC();
     if (lane == 0 && wave_id() == 0) S.yy[O_I] = Iguess;
     PL_XSYNC();
+    GenRow grow;                                                        // closure of the state with derivative programs: general control row (dfn_cell.h)
+    if constexpr ((F & GF_EXPR) != 0) { if (run.value_kind == PLH_VAL_EXPR && run.n_dcol > 0 && genW) { grow.run = &run; grow.W = genW; } }
     int flag = PLH_FLAG_RUNNING;
     plh_run_info ri; ri.flag = PLH_FLAG_RUNNING; ri.iterations = 0; ri.t_end = t_global; ri.V = 0; ri.I = 0; ri.SOC = SOC; ri.T_avg = T0;
     // tstops = {tdiscon - reltol/2} U {1.0 if continuation} U {tf}   (postfix_integrator!, model_evaluation.jl:288-310)
@@ -757,7 +804,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     do {                                                                // (re)initialise -> integrate ; loops only for check_reinitialization!
     again = false;
     int ierr; { PL_TIC(); ierr = cell_init_consistent<F>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt, S.phi[0], o.refine,
-                                                                       ((F & GF_EXPR) && run.value_kind == PLH_VAL_EXPR) ? &run : nullptr, t_restart); PL_TOC(S, PH_INIT); }
+                                                                       ((F & GF_EXPR) && run.value_kind == PLH_VAL_EXPR) ? &run : nullptr, t_restart, &grow); PL_TOC(S, PH_INIT); }
     if (ierr != 0) { if (first_init) init_failed = true; else flag = ierr; ri.flag = ierr; break; }
     if constexpr ((F & GF_STOPS) != 0) { if (o.yp_alg_zero) { PL_VEC(n) if (n >= NDIFF) S.yp[n] = 0.0; PL_XSYNC(); } }     // plh_opts.yp_alg_zero
     ida_reinit(S, I, S.yy, S.yp, first_init ? (o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD) : I.maxord, t_restart);
@@ -774,7 +821,10 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       double tstop_now;
       if constexpr ((F & GF_STOPS) != 0) tstop_now = next_tstop(o, t, continuation, run.tf);
       else tstop_now = (continuation && run.tf > 1.0 && t < 1.0) ? 1.0 : run.tf;
-      const int sf = ida_step<F>(S, R, tb, I, tstop_now, tret, mode, value, o, cnt, is_tab ? &run : nullptr);
+      // two waves per cell: both evaluate the stop checks, SOC and I_prev_pt from S.yy redundantly; the wave that is ahead must not start overwriting S.yy (predictor of
+      // the next step) while the other still reads the accepted point -- with a varying current its SOC, hence its stop flag, would differ
+      if constexpr (M::W2) __syncthreads();
+      const int sf = ida_step<F>(S, R, tb, I, tstop_now, tret, mode, value, o, cnt, is_tab ? &run : nullptr, &grow);
       if (sf != 0) {
         if (I.nst == 0 && !stalled_once) {                              // check_solve, checks.jl:227-237
           stalled_once = true;
@@ -821,6 +871,9 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     if (flag > 0 && o.interp_final && t > 1.0) {                        // interp_final_points!, model_evaluation.jl:369-382
       const double fr = pv.frac;
       const double ti = fr * (t - tprev) + tprev;
+#ifdef PL_DBG_W2
+      if (lane == 0) printf("DBG wave %d flag %d fr %.17g t %.17g tprev %.17g yy0 %.17g prev0 %.17g\n", wave_id(), flag, fr, t, tprev, S.yy[vrow<M>(0, 0, wave_id())], Yprev[vrow<M>(0, 0, wave_id())]);
+#endif
       PL_XSYNC();
       PL_VEC(n) { S.yy[n] = fr * (S.yy[n] - Yprev[n]) + Yprev[n]; S.yp[n] = fr * (S.yp[n] - YPprev[n]) + YPprev[n]; }
       PL_XSYNC();

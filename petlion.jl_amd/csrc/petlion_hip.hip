@@ -142,6 +142,7 @@ struct StageBlock { void* p; size_t bytes; bool busy; };
 struct StreamCtx {
   hipStream_t st = nullptr;
   double* scratch = nullptr; size_t scratch_cells = 0;     // [n_cells][2][N]: previous accepted point of every cell (back-interpolation)
+  double* genW = nullptr; size_t genW_cells = 0;           // [n_cells][N]: border vector of the general control row (closure inputs with derivative programs)
   plh_run* d_runs = nullptr; int runs_cap = 0;
   std::vector<plh_run> runs_on_device;                       // the protocol currently in d_runs (a repeated launch with the same protocol uploads nothing and does not synchronise)
   // sorted device copies of opts.tdiscon / opts.tstops, kept per stream (re-uploaded only when they change)
@@ -410,6 +411,7 @@ void plh_model_destroy(plh_model_t m) {
   if (m->d_tb) hipFree(m->d_tb);
   for (StreamCtx* c : m->streams) {
     if (c->scratch) hipFree(c->scratch);
+    if (c->genW) hipFree(c->genW);
     if (c->d_runs) hipFree(c->d_runs);
     if (c->tdiscon.d) hipFree(c->tdiscon.d);
     if (c->tstops.d) hipFree(c->tstops.d);
@@ -465,8 +467,8 @@ int plh_abi_layout(int* out, int cap) {
   PL_F(plh_model_desc, thermodynamic_factor) PL_F(plh_model_desc, rxn) PL_F(plh_model_desc, waves_per_cell)
   PL_S(plh_bounds, 11) PL_F(plh_bounds, V_max) PL_F(plh_bounds, V_min) PL_F(plh_bounds, SOC_max) PL_F(plh_bounds, SOC_min) PL_F(plh_bounds, T_max) PL_F(plh_bounds, c_s_n_max)
   PL_F(plh_bounds, I_max) PL_F(plh_bounds, I_min) PL_F(plh_bounds, eta_plating_min) PL_F(plh_bounds, c_e_min) PL_F(plh_bounds, dfilm_max)
-  PL_S(plh_run, 10) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, tab_t)
-  PL_F(plh_run, tab_v) PL_F(plh_run, value_cell) PL_F(plh_run, tf_cell)
+  PL_S(plh_run, 13) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, tab_t)
+  PL_F(plh_run, tab_v) PL_F(plh_run, value_cell) PL_F(plh_run, tf_cell) PL_F(plh_run, n_dcol) PL_F(plh_run, dcol) PL_F(plh_run, dofs)
   PL_S(plh_opts, 16) PL_F(plh_opts, abstol) PL_F(plh_opts, reltol) PL_F(plh_opts, abstol_init) PL_F(plh_opts, reltol_init) PL_F(plh_opts, maxiters) PL_F(plh_opts, check_bounds)
   PL_F(plh_opts, interp_final) PL_F(plh_opts, max_order) PL_F(plh_opts, jac_every_step) PL_F(plh_opts, init_step) PL_F(plh_opts, n_tdiscon) PL_F(plh_opts, tdiscon) PL_F(plh_opts, refine)
   PL_F(plh_opts, n_tstops) PL_F(plh_opts, tstops) PL_F(plh_opts, yp_alg_zero)
@@ -576,20 +578,33 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
     if (runs[r].value_kind == PLH_VAL_EXPR) {                     // closure input as a postfix program: check it here, the device interpreter trusts it
       if (runs[r].n_tab < 1 || !runs[r].tab_t || !runs[r].tab_v) return fail(PLH_E_ARG, "PLH_VAL_EXPR needs n_tab >= 1 and both program arrays");
       if (runs[r].mode == PLH_MODE_DT) return fail(PLH_E_UNSUPPORTED, "function inputs for dT are not defined by the reference");
-      int sp = 0;
-      for (int k = 0; k < runs[r].n_tab; k++) {
-        const double opd = runs[r].tab_t[k]; const int op = (int)opd; const double a = runs[r].tab_v[k];
-        if (!(opd == (double)op) || op < 0 || op >= PLH_N_OPS) return fail(PLH_E_ARG, "PLH_VAL_EXPR: unknown opcode");
-        int pop = 2, idx_max = -1;
-        if (op <= PLH_OP_THETA) pop = 0; else if (op == PLH_OP_SELECT) pop = 3;
-        else if (op == PLH_OP_NEG || op == PLH_OP_SIN || op == PLH_OP_COS || op == PLH_OP_EXP || op == PLH_OP_LOG || op == PLH_OP_SQRT || op == PLH_OP_ABS || op == PLH_OP_TANH) pop = 1;
-        if (op == PLH_OP_Y || op == PLH_OP_YP) idx_max = m->N; else if (op == PLH_OP_THETA) idx_max = m->P;
-        if (idx_max >= 0 && !(a == (double)(int)a && a >= 0 && a < idx_max)) return fail(PLH_E_ARG, "PLH_VAL_EXPR: state / theta index out of range");
-        if (sp < pop) return fail(PLH_E_ARG, "PLH_VAL_EXPR: stack underflow");
-        sp += 1 - pop;
-        if (sp > PLH_EXPR_STACK) return fail(PLH_E_ARG, "PLH_VAL_EXPR: more than 16 values on the stack");
+      auto check_program = [&](int k0, int k1) -> int {
+        int sp = 0;
+        for (int k = k0; k < k1; k++) {
+          const double opd = runs[r].tab_t[k]; const int op = (int)opd; const double a = runs[r].tab_v[k];
+          if (!(opd == (double)op) || op < 0 || op >= PLH_N_OPS) return fail(PLH_E_ARG, "PLH_VAL_EXPR: unknown opcode");
+          int pop = 2, idx_max = -1;
+          if (op <= PLH_OP_THETA) pop = 0; else if (op == PLH_OP_SELECT) pop = 3;
+          else if (op == PLH_OP_NEG || op == PLH_OP_SIN || op == PLH_OP_COS || op == PLH_OP_EXP || op == PLH_OP_LOG || op == PLH_OP_SQRT || op == PLH_OP_ABS || op == PLH_OP_TANH) pop = 1;
+          if (op == PLH_OP_Y || op == PLH_OP_YP) idx_max = m->N; else if (op == PLH_OP_THETA) idx_max = m->P;
+          if (idx_max >= 0 && !(a == (double)(int)a && a >= 0 && a < idx_max)) return fail(PLH_E_ARG, "PLH_VAL_EXPR: state / theta index out of range");
+          if (sp < pop) return fail(PLH_E_ARG, "PLH_VAL_EXPR: stack underflow");
+          sp += 1 - pop;
+          if (sp > PLH_EXPR_STACK) return fail(PLH_E_ARG, "PLH_VAL_EXPR: more than 16 values on the stack");
+        }
+        if (sp != 1) return fail(PLH_E_ARG, "PLH_VAL_EXPR: the program must leave exactly one value");
+        return 0;
+      };
+      if (int rc = check_program(0, runs[r].n_tab)) return rc;
+      if (runs[r].n_dcol < 0 || runs[r].n_dcol > PLH_MAX_DCOL) return fail(PLH_E_ARG, "PLH_VAL_EXPR: n_dcol out of range (0 .. 60)");
+      if (runs[r].n_dcol > 0) {                                      // derivative programs of the control row, behind the main program in the same arrays
+        if (!runs[r].dcol || !runs[r].dofs || runs[r].dofs[0] < runs[r].n_tab) return fail(PLH_E_ARG, "PLH_VAL_EXPR: n_dcol > 0 needs dcol, dofs and dofs[0] >= n_tab");
+        for (int k = 0; k < runs[r].n_dcol; k++) {
+          if (runs[r].dcol[k] < 0 || runs[r].dcol[k] >= m->N || (k > 0 && runs[r].dcol[k] <= runs[r].dcol[k - 1])) return fail(PLH_E_ARG, "PLH_VAL_EXPR: dcol must be ascending state columns");
+          if (runs[r].dofs[k + 1] <= runs[r].dofs[k]) return fail(PLH_E_ARG, "PLH_VAL_EXPR: dofs must be increasing");
+          if (int rc = check_program(runs[r].dofs[k], runs[r].dofs[k + 1])) return rc;
+        }
       }
-      if (sp != 1) return fail(PLH_E_ARG, "PLH_VAL_EXPR: the program must leave exactly one value");
     }
     if (runs[r].value_kind == PLH_VAL_TABLE) {
       if (runs[r].n_tab < 1 || !runs[r].tab_t || !runs[r].tab_v) return fail(PLH_E_ARG, "PLH_VAL_TABLE needs n_tab >= 1 and both table arrays");
@@ -615,8 +630,15 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
     HIPCHK(hipMalloc((void**)&cx.scratch, (size_t)n * 2 * m->N * sizeof(double)));
     cx.scratch_cells = n;
   }
+  bool need_genW = false;
+  for (int r = 0; r < n_runs; r++) need_genW = need_genW || (runs[r].value_kind == PLH_VAL_EXPR && runs[r].n_dcol > 0);
+  if (need_genW && cx.genW_cells < (size_t)n) {
+    if (cx.genW) { HIPCHK(hipStreamSynchronize(cx.st)); hipFree(cx.genW); cx.genW = nullptr; cx.genW_cells = 0; }
+    HIPCHK(hipMalloc((void**)&cx.genW, (size_t)n * m->N * sizeof(double)));
+    cx.genW_cells = n;
+  }
   IntegrateArgs a;
-  a.tb = m->d_tb; a.n_cells = n; a.n_runs = n_runs; a.opts = *opts; a.scratch = cx.scratch;
+  a.tb = m->d_tb; a.n_cells = n; a.n_runs = n_runs; a.opts = *opts; a.scratch = cx.scratch; a.genW = need_genW ? cx.genW : nullptr;
   a.theta = s.in(theta, (size_t)n * m->P); a.SOC0 = s.in(SOC0, n);
   a.Y_init = s.in(Y_init, (size_t)n * m->N); a.t_init = s.in(t_init, n);
   // tdiscon / tstops: sorted device copies, kept per stream (re-uploaded only when they change)
@@ -644,8 +666,12 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   std::vector<plh_run> hruns(runs, runs + n_runs);                    // tables are host arrays: stage them and patch the device copies
   for (int r = 0; r < n_runs; r++) {
     if (hruns[r].value_kind == PLH_VAL_TABLE || hruns[r].value_kind == PLH_VAL_EXPR) {
-      hruns[r].tab_t = s.in_host(runs[r].tab_t, runs[r].n_tab); hruns[r].tab_v = s.in_host(runs[r].tab_v, runs[r].n_tab);
-    } else { hruns[r].n_tab = 0; hruns[r].tab_t = nullptr; hruns[r].tab_v = nullptr; }
+      const bool der = hruns[r].value_kind == PLH_VAL_EXPR && runs[r].n_dcol > 0;
+      const int len = der ? runs[r].dofs[runs[r].n_dcol] : runs[r].n_tab;
+      hruns[r].tab_t = s.in_host(runs[r].tab_t, len); hruns[r].tab_v = s.in_host(runs[r].tab_v, len);
+      if (der) { hruns[r].dcol = s.in_host(runs[r].dcol, runs[r].n_dcol); hruns[r].dofs = s.in_host(runs[r].dofs, runs[r].n_dcol + 1); }
+      else { hruns[r].n_dcol = 0; hruns[r].dcol = nullptr; hruns[r].dofs = nullptr; }
+    } else { hruns[r].n_tab = 0; hruns[r].tab_t = nullptr; hruns[r].tab_v = nullptr; hruns[r].n_dcol = 0; hruns[r].dcol = nullptr; hruns[r].dofs = nullptr; }
     if (runs[r].value_cell) hruns[r].value_cell = s.in_host(runs[r].value_cell, n);       // per-cell protocol values: host arrays like the protocol
     if (runs[r].tf_cell) hruns[r].tf_cell = s.in_host(runs[r].tf_cell, n);
   }

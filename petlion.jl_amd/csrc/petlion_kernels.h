@@ -149,7 +149,7 @@ template <class M, int F> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WA
   cell_simulate<F>(S, R, a.tb, a.SOC0[cell], a.Y_init ? a.Y_init + (size_t)cell * NST : nullptr, a.t_init ? a.t_init[cell] : 0.0, a.n_runs, a.runs, a.opts, co, a.out.n_pts ? a.out.n_pts + cell : nullptr,
                 a.out.run_info + (size_t)cell * a.n_runs, cnt,
                 a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
-                a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell);
+                a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell, a.genW ? a.genW + (size_t)cell * NST : nullptr);
   PL_TOC_TOTAL(S);
   PL_SYNC();
   if (threadIdx.x == 0 && a.out.counters) {

@@ -170,6 +170,8 @@ def runs_to_oracle(O, p, pkg, protocol, cell=None, n_cells=None):
             d["table"] = (np.array(r._keep[0]), np.array(r._keep[1]))
         if r.value_kind == 4:       # PLH_VAL_EXPR
             d["expr"] = (np.array(r._keep[0]), np.array(r._keep[1]))
+            if r.n_dcol > 0:              # derivative programs of a closure of the state (behind the main program in the same arrays)
+                d["n_main"] = int(r.n_tab); d["dcol"] = np.array(r._keep[2]); d["dofs"] = np.array(r._keep[3])
         out.append(d)
     return out
 

@@ -325,16 +325,36 @@ def check_closure_inputs(p, O, pkg):
              ("ramp_theta", [{"I": lambda t, q: q.θ["t₊"] * t / 36.4, "tf": 100.0}], 0.0, [], True),          # slope from a theta entry of the cell (0.364 / 36.4 = 1/100)
              ("step_where", [{"I": lambda t: cl.where(t < 100, 1.0, 0.5), "tf": 200.0}], 0.0, [100.0], True),
              ("taper_V", [{"I": lambda t, Y, q: -cl.minimum(1.0, cl.maximum(0.05, (cl.calc_V(Y, q) - 3.0) * 2.0)), "tf": 4000.0, "V_min": 3.05}], 1.0, [], True),
-             # (a closure of YP enters the Newton matrix scaled by cj = O(1/h); without its derivative -- see include/petlion_hip.h -- only a weak dependence converges)
+             # closures of the state: their symbolic derivative goes into the control row of the Newton matrix (scalar_residual.jl:276-416; closures.row_derivatives ->
+             # plh_run.dcol / dofs): a current that depends on a DIFFERENTIAL state, a voltage set-point that depends on the current (without the derivative the control row
+             # has no I entry left to pivot on), a power that follows the voltage through tanh
+             ("I_of_ce", [{"I": lambda t, Y, q: -1.0 + 2e-4 * (Y[q.ind["c_e"].start] - 1000.0), "tf": 600.0}], 1.0, [], True),
+             ("V_of_I", [{"V": lambda t, Y, q: 4.0 - 0.05 * cl.calc_I(Y, q), "tf": 300.0}], 0.5, [], True),
+             ("P_tanh", [{"P": lambda t, Y, q: -29.0 * cl.tanh(2.0 * (cl.calc_V(Y, q) - 3.2)), "tf": 600.0}], 1.0, [], True),
+             # (a closure of YP keeps the reference's no-differentiation fallback here -- include/petlion_hip.h -- : it enters the Newton matrix scaled by cj = O(1/h), so only a
+             #  weak dependence converges)
              ("reads_YP", [{"I": lambda t, Y, YP, q: -1.0 + 1e-7 * YP[q.ind["c_e"].start], "tf": 300.0}], 1.0, [], True)]
+    n_der = {"taper_V": 2, "I_of_ce": 1, "V_of_I": 1, "P_tanh": 2}
     for name, proto, soc, td, same in cases:
         o = pkg.Opts(); o.tdiscon = td
         ens = pkg.simulate_ensemble(p, th[None, :], proto, SOC=soc, opts=o)
         runs = parity.runs_to_oracle(O, p, pkg, proto)
-        assert runs[0]["value_kind"] == 4
+        assert runs[0]["value_kind"] == 4 and len(runs[0].get("dcol", ())) == n_der.get(name, 0)
         ro = O.simulate(p.variant, th, soc, runs, opts=O.default_opts(tdiscon=td))
         assert ens.run_info[0, 0]["flag"] == ro["runs"][0]["flag"] >= 0, (name, ens.run_info[0, 0], ro["runs"][0])
         parity.compare_trajectory(ens, 0, ro, rtol_state=5e-6, same_decisions=same)
+        if name in ("taper_V", "V_of_I"):
+            # the derivative is what the reference algorithm uses: without it (its fallback for closures it cannot differentiate) the same run takes other Newton steps --
+            # 92 steps instead of 85 through the taper -- or cannot be initialised at all (V = f(I): singular control row)
+            for r in runs:
+                r.pop("dcol")
+            r0 = O.simulate(p.variant, th, soc, runs, opts=O.default_opts(tdiscon=td))
+            assert (r0["runs"][0]["flag"] < 0) if name == "V_of_I" else (r0["counters"]["n_steps"] != ro["counters"]["n_steps"])
+            # with iterative refinement (the general row takes part in the residual product)
+            o.refine = 1
+            e1 = pkg.simulate_ensemble(p, th[None, :], proto, SOC=soc, opts=o)
+            r1 = O.simulate(p.variant, th, soc, parity.runs_to_oracle(O, p, pkg, proto), opts=O.default_opts(tdiscon=td, refine=1))
+            parity.compare_trajectory(e1, 0, r1, rtol_state=5e-6, same_decisions=True)
     # the exact closure and its 201-point table agree to the table's interpolation error
     tt = np.linspace(0, 10, 201)
     e1 = pkg.simulate_ensemble(p, th[None, :], [{"V": lambda t: 3.9 + 0.05 * np.cos(t), "tf": 10.0}], SOC=0.5)
@@ -352,6 +372,28 @@ def check_closure_inputs(p, O, pkg):
         pkg.make_protocol(p, [{"I": lambda t: math.sin(t)}])
     with pytest.raises(ValueError):
         pkg.make_protocol(p, [{"dT": lambda t: 0.0}])
+
+
+def check_closure_derivatives_other_models(p_th, p_sei, O, pkg):
+    """closures of the state with the thermal model (a charge current that backs off with the temperature of the separator's middle node; a CV set-point with a
+    temperature coefficient) and with SEI aging (a charge current that backs off as the film grows): the general control row through the 4x4-block thermal solve and the
+    3-unknown node-local elimination of the SEI electrode, same decisions as the oracle's sparse LU of the merged pattern"""
+    cl = pkg.closures
+    for p, soc, protos in ((p_th, 0.2, [[{"I": lambda t, Y, q: 3.0 - 0.08 * (Y[q.ind["T"].start + 20] - 298.15), "tf": 400.0}],
+                                       [{"I": 2.0, "tf": 100.0}, {"V": lambda t, Y, q: 4.0 + 1e-3 * (Y[q.ind["T"].start + 20] - 298.15) - 0.02 * cl.calc_I(Y, q), "tf": 200.0}]]),
+                           (p_sei, 0.1, [[{"I": lambda t, Y, q: 1.0 - 2e7 * Y[q.ind["film"].start + 3], "tf": 900.0}]])):
+        th = p.theta_vector()
+        for proto in protos:
+            ens = pkg.simulate_ensemble(p, th[None, :], proto, SOC=soc)
+            runs = parity.runs_to_oracle(O, p, pkg, proto)
+            assert len(runs[-1]["dcol"]) >= 1
+            ro = O.simulate(p.variant, th, soc, runs)
+            assert ens.run_info[0, -1]["flag"] == ro["runs"][-1]["flag"] >= 0, (ens.run_info[0], ro["runs"])
+            parity.compare_trajectory(ens, 0, ro, rtol_state=5e-6, same_decisions=True)
+
+
+def test_closure_derivatives_thermal_and_sei(emu_model_thermal, emu_model_sei, O, pkg):
+    check_closure_derivatives_other_models(emu_model_thermal, emu_model_sei, O, pkg)
 
 
 def test_function_inputs(emu_model, O, pkg):
@@ -485,6 +527,11 @@ def check_two_waves(pkg, O):
     ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0)
     for i in range(2):
         parity.compare_trajectory(ens, i, O.simulate("lco_iso", Th[i], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}])), rtol_state=1e-6)
+    # a closure of the state with derivative programs: the general control row reads across the two waves (also under the hostile schedules below)
+    cl = pkg.closures
+    taper = [{"I": lambda t, Y, q: -cl.minimum(1.0, cl.maximum(0.05, (cl.calc_V(Y, q) - 3.0) * 2.0)), "tf": 4000.0, "V_min": 3.05}]
+    ens = pkg.simulate_ensemble(p, Th[:1], taper, SOC=1.0)
+    parity.compare_trajectory(ens, 0, O.simulate("lco_iso", Th[0], 1.0, parity.runs_to_oracle(O, p, pkg, taper)), rtol_state=5e-6)
 
 
 def test_two_waves_per_cell_variant(pkg, O):

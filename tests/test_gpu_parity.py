@@ -305,6 +305,33 @@ def test_every_stop_condition(hip_model, hip_model_sei, O, pkg):
     te.check_stop_conditions(hip_model_sei, O, pkg)
 
 
+def test_closure_derivatives_on_gpu(hip_model_thermal, hip_model_sei, O, pkg):
+    """closures of the state: their symbolic derivatives in the control row of the Newton matrix (reference scalar_residual.jl:276-416; plh_run.dcol / dofs, GenRow in
+    csrc/dfn_cell.h) with the thermal and SEI models, and through the two-waves-per-cell kernel (the LCO isothermal cases run in
+    test_function_inputs_and_drive_cycle_ensemble); then a 256-cell ensemble whose closure reads a per-cell parameter: same flags and end states as cell-by-cell runs"""
+    import test_device_source_emu as te
+    te.check_closure_derivatives_other_models(hip_model_thermal, hip_model_sei, O, pkg)
+    p2 = pkg.petlion(pkg.LCO, waves_per_cell=2)
+    te.check_closure_inputs(p2, O, pkg)
+    p = pkg.petlion(pkg.LCO)
+    cl = pkg.closures
+    n = 256
+    rng = np.random.default_rng(21)
+    Th = pkg.theta_matrix(p, n, {"t₊": 0.364 * (0.8 + 0.4 * rng.random(n)), "D_sp": p.θ["D_sp"] * 2.0 ** (2 * rng.random(n) - 1)})
+    proto = [{"I": lambda t, Y, q: -cl.minimum(1.0, cl.maximum(0.05, (cl.calc_V(Y, q) - 3.0) * 2.0 * q.θ["t₊"] / 0.364)), "tf": 4000.0, "V_min": 3.05}]
+    ens = pkg.simulate_ensemble(p, Th, proto, SOC=1.0)
+    assert (ens.run_info["flag"] >= 0).all()
+    same = 0
+    for c in range(0, n, 32):
+        one = pkg.simulate_ensemble(p, Th[c:c + 1], proto, SOC=1.0)
+        assert one.run_info[0, 0]["flag"] == ens.run_info[c, 0]["flag"] and np.array_equal(one.Y[0], ens.Y[c])
+        ro = O.simulate(p.variant, Th[c], 1.0, parity.runs_to_oracle(O, p, pkg, proto))
+        same += int(ens.counters[c]["n_steps"]) == ro["counters"]["n_steps"] and int(ens.counters[c]["n_jac"]) == ro["counters"]["n_jac"]
+        parity.compare_trajectory(ens, c, ro, rtol_state=2e-3, same_decisions=False)
+    assert same >= 6, same
+    print("closure with derivative programs, %d cells: kernel %.2f ms; identical step / Jacobian counts as the oracle in %d of 8 cells" % (n, ens.kernel_ms, same))
+
+
 def test_function_inputs_and_drive_cycle_ensemble(hip_model, O, pkg):
     """tabulated time-dependent inputs on the GPU: the notebook cases, then a 512-cell ensemble on a piecewise-linear drive cycle with jumps"""
     import test_device_source_emu as te

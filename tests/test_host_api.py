@@ -139,6 +139,36 @@ def test_closure_tracer_programs(pkg, emu_model):
         cl.trace(lambda a, b, c, d, e: a, p)
 
 
+def test_closure_symbolic_derivatives(pkg, emu_model):
+    """closures.row_derivatives: the programs for d f / d Y[c] (what the reference's Symbolics differentiation of the closure supplies to the Newton matrix,
+    scalar_residual.jl:289-303) against central differences of the closure's own program, every rule of the table; closures of YP or of t only get none"""
+    cl = pkg.closures
+    p = emu_model
+    th = p.theta_vector()
+    rng = np.random.default_rng(5)
+    Y = rng.random(p.N.tot) + 0.5; YP = rng.standard_normal(p.N.tot)
+    fs = [lambda t, Y_, q: Y_[0] * Y_[1] / (Y_[2] + t) - 3.0 * Y_[0] ** 2.5 + 2.0 ** Y_[3] + Y_[4] ** Y_[5],
+          lambda t, Y_, q: cl.sin(Y_[0] * t) * cl.cos(Y_[1]) + cl.exp(-Y_[2]) * cl.log(Y_[3] + 1.0) + cl.sqrt(Y_[4]) * cl.tanh(Y_[5] - 1.0),
+          lambda t, Y_, q: -cl.minimum(1.0, cl.maximum(0.05, (cl.calc_V(Y_, q) + 0.2) * 2.0)) + abs(Y_[7] - 1.0) * q.θ["t₊"],
+          lambda t, Y_, q: cl.where(Y_[0] > Y_[1], Y_[0] * Y_[2], Y_[1] / Y_[2]) - (-Y_[3]) + cl.minimum(Y_[4], Y_[5] * Y_[5])]
+    for f in fs:
+        prog, tree = cl.trace(f, p, with_tree=True)
+        cols, progs = cl.row_derivatives(tree)
+        assert cols == sorted(cols) and len(cols) >= 3
+        for c, dp in zip(cols, progs):
+            h = 1e-6
+            Yp, Ym = Y.copy(), Y.copy(); Yp[c] += h; Ym[c] -= h
+            fd = (cl.evaluate(prog, 1.3, Yp, YP, th) - cl.evaluate(prog, 1.3, Ym, YP, th)) / (2 * h)
+            an = cl.evaluate(dp, 1.3, Y, YP, th)
+            assert abs(an - fd) <= 1e-7 * max(1.0, abs(fd)), (c, an, fd)
+    assert cl.row_derivatives(cl.trace(lambda t: cl.sin(t), p, with_tree=True)[1]) is None
+    assert cl.row_derivatives(cl.trace(lambda t, Y_, YP_, q: Y_[0] + YP_[1], p, with_tree=True)[1]) is None          # reads YP: the reference's fallback path here
+    # the run descriptor carries them: columns ascending, programs behind the main one
+    (run,), _ = pkg.make_protocol(p, [{"I": lambda t, Y_, q: -0.5 * cl.calc_V(Y_, q), "tf": 10.0}])
+    ps = p.ind["Φ_s"]
+    assert run.n_dcol == 2 and [run.dcol[0], run.dcol[1]] == [ps.start, ps.stop - 1] and run.dofs[0] == run.n_tab
+
+
 def test_register_grid_library_refusals(pkg, emu_model):
     """plh_register_grid_library: a missing file and a library that is not a grid library are refused with a message, registering the same grid library twice is a no-op"""
     import build_emu
