@@ -48,7 +48,10 @@ extern "C" {
 #define PLH_MODE_DT 2  /* dT_avg/dt, K/s:       value - sum_i w_i YP[T_i] / L     (temperature models only) */
 #define PLH_MODE_P 3   /* power, W/m^2:         Y[I] I1C (Phi_s[1] - Phi_s[end]) - value   (method_P, input_methods.jl:80-111) */
 #define PLH_MODE_ETA_P 4 /* plating overpotential, V: Phi_s.n[1] - Phi_e.n[1] - value     (method_η_p, input_methods.jl:113-152) */
-#define PLH_N_MODES 5
+#define PLH_N_MODES 5   /* the modes above: the ones with an exported Jacobian pattern (plh_jac_pattern, plh_residual, ...) */
+#define PLH_MODE_RES 5 /* user-defined control residual (reference method_res, input_methods.jl:155-175; run_residual, scalar_residual.jl:172):  value - f(t, Y, theta) = 0 with
+                          the closure f as PLH_VAL_EXPR and its derivative programs (n_dcol >= 1: the reference always differentiates this row, scalar_residual.jl:262-274);
+                          plh_integrate / plh_ensemble_run only.  Closures of YP (the dc_s_*, dc_e_* modes are such) are not supported. */
 
 /* plh_model_desc.solid_diffusion / thermodynamic_factor / rxn: the model options of petlion(...; solid_diffusion, thermodynamic_factor, rxn_p, rxn_n)
  * (reference src/params.jl:140-172; equations: residuals.jl:108-127,237-258, aux...jl:193-248, custom_functions.jl:177-203, 212-298) */

@@ -349,7 +349,9 @@ static int splu_setup(splu* f, const int* cp, const int* ri, const double* ax) {
 /* ------------------------------------------------------------------------------------------------------------ */
 /* public structs                                                                                               */
 /* ------------------------------------------------------------------------------------------------------------ */
-enum { ORC_MODE_I = 0, ORC_MODE_V = 1, ORC_MODE_DT = 2, ORC_MODE_P = 3, ORC_MODE_ETAP = 4, ORC_NMODES = 5 };
+enum { ORC_MODE_I = 0, ORC_MODE_V = 1, ORC_MODE_DT = 2, ORC_MODE_P = 3, ORC_MODE_ETAP = 4,
+       ORC_MODE_RES = 5,   /* method_res (input_methods.jl:155-175): res[end] = theta[:_residual_val] - run.func(t, Y, YP, p) (run_residual, scalar_residual.jl:172), a closure with derivative programs */
+       ORC_NMODES = 6 };
 enum { ORC_VAL_CONST = 0, ORC_VAL_HOLD = 1, ORC_VAL_REST = 2, ORC_VAL_TABLE = 3, ORC_VAL_EXPR = 4 };
 /* ORC_VAL_EXPR: the input closure run.func(t, Y, YP, p) (scalar_residual.jl:169-170) as a postfix program, instruction k = (opcode tab_t[k], operand tab_v[k]); the opcode
    numbering is the C ABI's (include/petlion_hip.h PLH_OP_*), restated here: */
@@ -556,6 +558,7 @@ static double ctrl_residual(evalb* e, const double* Y, const double* YP) {
   /* closure input: val = run.func(t, Y, YP, p) with the iterate, in every residual, and run.value[] = val (scalar_residual.jl:169-170) */
   if (e->frun && e->frun->value_kind == ORC_VAL_EXPR) e->value = expr_eval(e->frun, e->t_fun, Y, YP, e->th);
   const orc_model* m = &e->m;
+  if (e->mode == ORC_MODE_RES) return e->frun->value - e->value;                                  /* run_residual: _residual_val - f */
   if (e->mode == ORC_MODE_I) return Y[m->o_I] - e->value;                                         /* method_I */
   if (e->mode == ORC_MODE_V) return Y[m->o_ps] - Y[m->o_ps + m->Np + m->Nn - 1] - e->value;       /* method_V */
   if (e->mode == ORC_MODE_P) return Y[m->o_I] * e->I1C * (Y[m->o_ps] - Y[m->o_ps + m->Np + m->Nn - 1]) - e->value;   /* method_P = calc_P, scalar_residual.jl:87 */
@@ -595,7 +598,7 @@ static void J_full(evalb* e, const double* Y, const double* YP, double cj) {
   if (e->mode == ORC_MODE_I) e->ax[e->ctrl_pos[0]] = 1.0;
   else if (e->mode == ORC_MODE_V) { e->ax[e->ctrl_pos[0]] = 1.0; e->ax[e->ctrl_pos[1]] = -1.0; }
   else if (e->mode == ORC_MODE_P || e->mode == ORC_MODE_ETAP) ctrl_row_P_etap(e, Y, e->ax, e->ctrl_pos);
-  else for (int k = 0; k < e->n_ctrl; k++) e->ax[e->ctrl_pos[k]] = -cj * e->w[k];
+  else if (e->mode == ORC_MODE_DT) for (int k = 0; k < e->n_ctrl; k++) e->ax[e->ctrl_pos[k]] = -cj * e->w[k];
   ctrl_row_derivatives(e, Y, YP, e->ax, e->ctrl_pos, e->n_base, e->n_ctrl, 0);
   if (e->cnt) e->cnt->n_jac++;
 }
@@ -606,7 +609,7 @@ static void J_alg(evalb* e, const double* Y, const double* YP) {
   if (e->mode == ORC_MODE_I) e->aax[e->actrl_pos[0]] = 1.0;
   else if (e->mode == ORC_MODE_V) { e->aax[e->actrl_pos[0]] = 1.0; e->aax[e->actrl_pos[1]] = -1.0; }
   else if (e->mode == ORC_MODE_P || e->mode == ORC_MODE_ETAP) ctrl_row_P_etap(e, Y, e->aax, e->actrl_pos);
-  else { m->dT_twin_jac(e->tmp_nz, Y, YP, 0.0, e->th); for (int k = 0; k < e->an_ctrl; k++) e->aax[e->actrl_pos[k]] = e->tmp_nz[k]; }
+  else if (e->mode == ORC_MODE_DT) { m->dT_twin_jac(e->tmp_nz, Y, YP, 0.0, e->th); for (int k = 0; k < e->an_ctrl; k++) e->aax[e->actrl_pos[k]] = e->tmp_nz[k]; }
   ctrl_row_derivatives(e, Y, YP, e->aax, e->actrl_pos, e->an_base, e->an_ctrl, 1);
   if (e->cnt) e->cnt->n_jac++;
 }
@@ -1032,6 +1035,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       if (mode == ORC_MODE_I) Y[M.o_I] = value;
       else if (mode == ORC_MODE_P) Y[M.o_I] = value / (calc_V(&M, Y) * calc_I1C_c(&M, theta));
       else if (mode == ORC_MODE_V || mode == ORC_MODE_ETAP) { if (have_prev) Y[M.o_I] = prev_I; else { double OCV = calc_V(&M, Y); Y[M.o_I] = value > OCV ? 1.0 : -1.0; } }
+      else if (mode == ORC_MODE_RES) { if (run->n_dcol < 1) { rc = -103; break; } Y[M.o_I] = have_prev ? prev_I : 1.0; }      /* input_methods.jl:171-176 */
       else { rc = -103; break; }
     } else
     if (mode == ORC_MODE_I) {

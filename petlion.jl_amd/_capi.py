@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("PETLION_HIP_LIB") or os.path.join(HERE, "libpetlion_h
 PLH_HOST, PLH_DEVICE, PLH_HOST_ASYNC = 0, 1, 2
 PREC_F64, PREC_MIXED = 0, 1
 PART_BLOCK, PART_CYCLIC = 0, 1
-MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETA_P = 0, 1, 2, 3, 4
+MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETA_P, MODE_RES = 0, 1, 2, 3, 4, 5
 VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE, VAL_EXPR = 0, 1, 2, 3, 4
 CHEM_LCO, CHEM_NMC, CHEM_LGM50 = 0, 1, 2
 FLAG_RUNNING, ERR_INIT, ERR_STALL, ERR_MAXITERS, ERR_OUTPUT_FULL = -1, -11, -12, -13, -14

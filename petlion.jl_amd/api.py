@@ -134,14 +134,21 @@ def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-_INPUTS = ("I", "V", "dT", "P", "η_p")
-_MODE = {"I": cap.MODE_I, "V": cap.MODE_V, "dT": cap.MODE_DT, "P": cap.MODE_P, "η_p": cap.MODE_ETA_P}
+_INPUTS = ("I", "V", "dT", "P", "η_p", "res")
+_MODE = {"I": cap.MODE_I, "V": cap.MODE_V, "dT": cap.MODE_DT, "P": cap.MODE_P, "η_p": cap.MODE_ETA_P, "res": cap.MODE_RES}
 _BOUND_KW = Bounds.FIELDS
 
 
 def _make_run(p, name, inp, tf, bounds):
     r = cap.Run()
     r.mode = _MODE[name]
+    res_x = 0.0
+    if name == "res":
+        # user-defined control residual (reference input_methods.jl:155-175, custom_res!, model_evaluation.jl:155-172): res = f  ->  0 - f = 0;  res = (x, f)  ->  x - f = 0
+        if isinstance(inp, (tuple, list)) and len(inp) == 2 and callable(inp[1]) and not callable(inp[0]):
+            res_x, inp = float(inp[0]), inp[1]
+        if not callable(inp):
+            raise ValueError("res = f or res = (x, f) with a closure f(t, Y, p)")
     if isinstance(inp, str):
         if inp == "hold":
             r.value_kind, r.value = cap.VAL_HOLD, 0.0
@@ -172,6 +179,11 @@ def _make_run(p, name, inp, tf, bounds):
             keep = [dcol, dofs]
         r.tab_t = ops.ctypes.data_as(C.POINTER(C.c_double)); r.tab_v = args.ctypes.data_as(C.POINTER(C.c_double))
         r._keep = (ops, args, *keep)
+        if name == "res":
+            if der is None:
+                raise ValueError("res: the closure must read the state Y (and not YP: the reference substitutes the differential equations for YP in the "
+                                 "consistent-initialisation row, which this build does not do -- so no dc_s_* / dc_e_* modes either)")
+            r.value = res_x
     elif isinstance(inp, (tuple, list)) and len(inp) == 2 and np.ndim(inp[0]) == 1:
         if name == "dT":
             raise ValueError("time-dependent dT inputs are not defined by the reference")

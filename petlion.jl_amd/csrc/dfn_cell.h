@@ -805,7 +805,8 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
     if (lane == 0) {                                                                   // scalar_residual!, scalar_residual.jl:167-172
       const double Vc = Y[O_PS] - Y[O_PS + NJ - 1];
       Fo[O_I] = mode == PLH_MODE_I ? yI - value : (mode == PLH_MODE_V ? Vc - value : (mode == PLH_MODE_P ? yI * cI1C * Vc - value   // method_P
-                                                   : Y[O_PS + NP] - Y[O_PE + NP + NS] - value));                                    // method_η_p
+                                                   : (mode == PLH_MODE_RES ? -value                                                  // method_res = 0: `value` is f - x (closure_input)
+                                                   : Y[O_PS + NP] - Y[O_PE + NP + NS] - value)));                                   // method_η_p
     }
   }
   if (WANT_JAC) {

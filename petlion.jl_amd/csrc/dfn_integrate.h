@@ -105,10 +105,17 @@ PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double*
   }
   return st[0];
 }
+// value of the closure of a run as the control residual uses it: method(Y) - f for the input modes; for PLH_MODE_RES (method_res = 0; run_residual,
+// scalar_residual.jl:172: res = theta[:_residual_val] - f) the row is -(f - x) with x = plh_run.value
+template <class M>
+PL_DEV double closure_input(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP) {
+  const double f = expr_eval(S, r, t, Y, YP);
+  return r.mode == PLH_MODE_RES ? f - r.value : f;
+}
 // input of a run_function run at run-local time t with the iterate (Y, YP): table or closure
 template <int F, class M>
 PL_DEV double run_input(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP) {
-  if constexpr ((F & GF_EXPR) != 0) return r.value_kind == PLH_VAL_EXPR ? expr_eval(S, r, t, Y, YP) : tab_eval(r, t);
+  if constexpr ((F & GF_EXPR) != 0) return r.value_kind == PLH_VAL_EXPR ? closure_input(S, r, t, Y, YP) : tab_eval(r, t);
   else return tab_eval(r, t);
 }
 // Jacobian refresh of a run with a general control row (GenRow, dfn_cell.h): factor in current mode, evaluate the row at (t, Y, YP) -- the input method's own entries
@@ -122,6 +129,7 @@ PL_DEV void gen_factor(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double cj, 
   double b0, b1 = 0.0, b2 = 0.0;
   if (mode == PLH_MODE_I) { g.nb = 1; g.bc0 = O_I; b0 = 1.0; }
   else if (mode == PLH_MODE_V) { g.nb = 2; g.bc0 = O_PS; g.bc1 = O_PS + NJ - 1; b0 = 1.0; b1 = -1.0; }
+  else if (mode == PLH_MODE_RES) { g.nb = 0; b0 = 0.0; }                                                    // method_res = 0: the row is the closure's alone
   else if (mode == PLH_MODE_P) { g.nb = 3; g.bc0 = O_PS; g.bc1 = O_PS + NJ - 1; g.bc2 = O_I; b0 = Y[O_I] * S.cc.I1C; b1 = -b0; b2 = (Y[O_PS] - Y[O_PS + NJ - 1]) * S.cc.I1C; }
   else { g.nb = 2; g.bc0 = O_PE + NP + NS; g.bc1 = O_PS + NP; b0 = -1.0; b1 = 1.0; }                      // eta_p
   g.ng = g.nb + r.n_dcol;
@@ -163,7 +171,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   if (M::THERMAL && mode == PLH_MODE_DT) mode = PL_MODE_DT_TWIN;
   int ok = 0;
   for (int iter = 1; iter <= 100; iter++) {
-    if constexpr ((F & GF_EXPR) != 0) { if (frun) value = expr_eval(S, *frun, t_fun, Y, YP); }
+    if constexpr ((F & GF_EXPR) != 0) { if (frun) value = closure_input(S, *frun, t_fun, Y, YP); }
     cell_node_pass<true, true>(S, Y, YP, res, mode, value);      // R_alg + J_alg partials (differential rows ignored)
     PL_SYNC();
     bool gen = false;
@@ -183,7 +191,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   }
   if (!ok) return PLH_ERR_INIT;
   // YP_diff = rhs_diff(Y)   (R_diff with YP = 0)
-  if constexpr ((F & GF_EXPR) != 0) { if (frun) value = expr_eval(S, *frun, t_fun, Y, YP); }
+  if constexpr ((F & GF_EXPR) != 0) { if (frun) value = closure_input(S, *frun, t_fun, Y, YP); }
   cell_residual(S, R, Y, YP, res, mode == PL_MODE_DT_TWIN ? PLH_MODE_DT : mode, value);
   PL_VEC(n) if (n < NDIFF) YP[n] = res[n];
   PL_SYNC();
@@ -194,7 +202,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   if (10.0 * reltol_init > dt) dt = 10.0 * reltol_init;
   PL_VEC(n) Ytmp[n] = Y[n] + dt * YP[n];
   PL_XSYNC();
-  if constexpr ((F & GF_EXPR) != 0) { if (frun) value = expr_eval(S, *frun, t_fun, Ytmp, YP); }
+  if constexpr ((F & GF_EXPR) != 0) { if (frun) value = closure_input(S, *frun, t_fun, Ytmp, YP); }
   cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
   PL_SYNC();
   bool gen = false;
@@ -337,7 +345,7 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
   for (bool first = true;; first = false) {
     { PL_TIC(); form_iterate(S, I, first); PL_TOC(S, PH_NEWTVEC); }
     if (done) break;                                      // the iterate (yy, yp) now includes the last correction
-    if constexpr ((F & GF_EXPR) != 0) { if (xrun) { value = expr_eval(S, *xrun, I.tn, S.yy, S.yp); *xvalue = value; } }       // closure input: run.func(t, Y, YP, p) inside every residual (scalar_residual.jl:169-170)
+    if constexpr ((F & GF_EXPR) != 0) { if (xrun) { value = closure_input(S, *xrun, I.tn, S.yy, S.yp); *xvalue = value; } }       // closure input: run.func(t, Y, YP, p) inside every residual (scalar_residual.jl:169-170)
     if (callLSetup) {
       PL_TIC();
 #ifndef PL_EXP_NO_JAC
@@ -765,6 +773,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       value = run_input<F>(S, run, 0.0, S.yy, S.yp);
       if (mode == PLH_MODE_I) Iguess = value;
       else if (mode == PLH_MODE_P) Iguess = value / (cellV<M>(S.yy) * S.cc.I1C);
+      else if (mode == PLH_MODE_RES) Iguess = have_prev ? prev_I : 1.0;                                  // input_methods.jl:171-176 (res_I_guess = nothing)
       else if (have_prev) Iguess = prev_I;
       else { const double OCV = cellV<M>(S.yy); Iguess = value > OCV ? 1.0 : -1.0; }
     } else

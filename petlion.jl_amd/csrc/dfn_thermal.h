@@ -263,10 +263,10 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
       const double hcv = ic == 0 ? TP.aC2[0] : (ic == NT - 1 ? TP.aC2[1] : 0.0);      // convective end rows: h_cell (T_amb - T) / (h rho Cp)
       Fo[O_T + ic] = TP.aL[ic] * (Tcl - Tc) + TP.aU[ic] * (Tcr - Tc) + hcv * (c.Tamb - Tc) + TP.qI[k < NA ? 0 : 1] * yI * yI - YP[O_T + ic];
     }
-    if (mode == PLH_MODE_I || mode == PLH_MODE_V || mode == PLH_MODE_P || mode == PLH_MODE_ETA_P) {   // scalar_residual!, scalar_residual.jl:167-172
+    if (mode == PLH_MODE_I || mode == PLH_MODE_V || mode == PLH_MODE_P || mode == PLH_MODE_ETA_P || mode == PLH_MODE_RES) {   // scalar_residual!, scalar_residual.jl:167-172
       const double Vc = Y[O_PS] - Y[O_PS + NJ - 1];
       if (lane == 0) Fo[O_I] = mode == PLH_MODE_I ? yI - value : (mode == PLH_MODE_V ? Vc - value : (mode == PLH_MODE_P ? yI * cI1C * Vc - value
-                                                                  : Y[O_PS + NP] - Y[O_PE + NP + NS] - value));
+                                                                  : (mode == PLH_MODE_RES ? -value : Y[O_PS + NP] - Y[O_PE + NP + NS] - value)));
     } else if (mode == PLH_MODE_DT) {                                                  // constant_temperature: value - sum w_i YP[T_i] / L
       const double sT = wave_sum(lane < NT ? TP.wT5[tsec_of(lane)] * YP[O_T + lane] : 0.0);
       if (lane == 0) Fo[O_I] = value - sT;

@@ -573,7 +573,10 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   if (kind != PLH_HOST && kind != PLH_DEVICE && kind != PLH_HOST_ASYNC) return fail(PLH_E_ARG, "bad ptr_kind");
   if (n <= 0 || !theta || !SOC0 || n_runs <= 0 || !runs || !opts || !out || !out->run_info) return fail(PLH_E_ARG, "bad argument");
   for (int r = 0; r < n_runs; r++) {
-    CHECK_MODE(runs[r].mode);
+    if (runs[r].mode == PLH_MODE_RES) {                          // user-defined control residual: a closure of Y with its derivative programs
+      if (runs[r].value_kind != PLH_VAL_EXPR || runs[r].n_dcol < 1)
+        return fail(PLH_E_UNSUPPORTED, "PLH_MODE_RES needs a PLH_VAL_EXPR closure of the state with derivative programs (n_dcol >= 1; closures of YP are not supported)");
+    } else CHECK_MODE(runs[r].mode);
     if (runs[r].value_kind < 0 || runs[r].value_kind > PLH_VAL_EXPR) return fail(PLH_E_ARG, "bad value_kind");
     if (runs[r].value_kind == PLH_VAL_EXPR) {                     // closure input as a postfix program: check it here, the device interpreter trusts it
       if (runs[r].n_tab < 1 || !runs[r].tab_t || !runs[r].tab_v) return fail(PLH_E_ARG, "PLH_VAL_EXPR needs n_tab >= 1 and both program arrays");

@@ -396,6 +396,38 @@ def test_closure_derivatives_thermal_and_sei(emu_model_thermal, emu_model_sei, O
     check_closure_derivatives_other_models(emu_model_thermal, emu_model_sei, O, pkg)
 
 
+def check_res_mode(p, p_th, O, pkg):
+    """the user-defined control residual, `simulate(p, tf; res = (x, f))` (reference input_methods.jl:155-175, run_residual: x - f(t, Y, p) = 0 as the last row, always
+    differentiated): "V + 0.05 I = 4" written as a residual gives the run of the V = 4 - 0.05 I closure; a residual on the temperature of one node (thermal model) and
+    one that ties the current to a DIFFERENTIAL state run with the oracle's decisions; what is not built (closures of YP, i.e. also dc_s_* / dc_e_*) is refused"""
+    cl = pkg.closures
+    th = p.theta_vector()
+    res = [{"res": (4.0, lambda t, Y, q: cl.calc_V(Y, q) + 0.05 * cl.calc_I(Y, q)), "tf": 300.0}]
+    asV = [{"V": lambda t, Y, q: 4.0 - 0.05 * cl.calc_I(Y, q), "tf": 300.0}]
+    e1, e2 = pkg.simulate_ensemble(p, th[None, :], res, SOC=0.5), pkg.simulate_ensemble(p, th[None, :], asV, SOC=0.5)
+    assert e1.run_info[0, 0]["flag"] == e2.run_info[0, 0]["flag"] == 0 and abs(e1.run_info[0, 0]["V"] + 0.05 * e1.run_info[0, 0]["I"] - 4.0) < 1e-9
+    assert parity.state_rel_err(e1.Y[0], e2.Y[0]) < 2e-5 and int(e1.counters[0]["n_steps"]) == int(e2.counters[0]["n_steps"])
+    cases = [(p, 0.5, res), (p, 1.0, [{"I": -1.0, "tf": 200.0}, {"res": lambda t, Y, q: cl.calc_I(Y, q) + 1.0 - 3e-4 * (Y[q.ind["c_e"].start] - 1000.0), "tf": 400.0}])]
+    if p_th is not None:
+        cases.append((p_th, 0.2, [{"I": 3.0, "tf": 150.0}, {"res": (0.0, lambda t, Y, q: Y[q.ind["T"].start + 20] - 302.0 + 2.0 * cl.calc_I(Y, q)), "tf": 300.0}]))
+    for pm, soc, proto in cases:
+        thm = pm.theta_vector()
+        ens = pkg.simulate_ensemble(pm, thm[None, :], proto, SOC=soc)
+        runs = parity.runs_to_oracle(O, pm, pkg, proto)
+        assert runs[-1]["mode"] == 5 and len(runs[-1]["dcol"]) >= 1
+        ro = O.simulate(pm.variant, thm, soc, runs)
+        assert ens.run_info[0, -1]["flag"] == ro["runs"][-1]["flag"] >= 0, (ens.run_info[0], ro["runs"])
+        parity.compare_trajectory(ens, 0, ro, rtol_state=5e-6, same_decisions=True)
+    with pytest.raises(ValueError, match="YP"):
+        pkg.make_protocol(p, [{"res": lambda t, Y, YP, q: YP[0] - 1.0}])
+    with pytest.raises(ValueError):
+        pkg.make_protocol(p, [{"res": 1.0}])
+
+
+def test_res_mode(emu_model, emu_model_thermal, O, pkg):
+    check_res_mode(emu_model, emu_model_thermal, O, pkg)
+
+
 def test_function_inputs(emu_model, O, pkg):
     check_function_inputs(emu_model, O, pkg)
 

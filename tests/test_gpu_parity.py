@@ -311,6 +311,7 @@ def test_closure_derivatives_on_gpu(hip_model_thermal, hip_model_sei, O, pkg):
     test_function_inputs_and_drive_cycle_ensemble); then a 256-cell ensemble whose closure reads a per-cell parameter: same flags and end states as cell-by-cell runs"""
     import test_device_source_emu as te
     te.check_closure_derivatives_other_models(hip_model_thermal, hip_model_sei, O, pkg)
+    te.check_res_mode(pkg.petlion(pkg.LCO), hip_model_thermal, O, pkg)            # the user-defined control residual (`res = (x, f)`), a closure row with no method part
     p2 = pkg.petlion(pkg.LCO, waves_per_cell=2)
     te.check_closure_inputs(p2, O, pkg)
     p = pkg.petlion(pkg.LCO)
