@@ -16,9 +16,9 @@ namespace pl {
 // Every kernel runs at most one wavefront per SIMD (LDS: >= 37 kB per single-wave workgroup), so the compiler may use the whole 512-entry register file of a lane.  It does:
 // hipcc -Rpass-analysis=kernel-resource-usage reports for the benchmark instantiation k_integrate<.., 0> (r03; rocprofv3's `accum_vgpr_count` shows 0 on this unified-file
 // part and is not the figure to read)
-//    LCO isothermal   256 VGPR + 242 AGPR, 112 VGPR spills (into AGPRs), 616 SGPR spills (into VGPR lanes),   0 B/lane of scratch
-//    NMC + SEI        256 VGPR + 256 AGPR, 126 VGPR spills,              677 SGPR spills,                   164 B/lane
-//    LCO thermal      256 VGPR + 256 AGPR, 358 VGPR spills,              666 SGPR spills,                   364 B/lane
+//    LCO isothermal   256 VGPR + 239 AGPR,  82 VGPR spills (into AGPRs), 633 SGPR spills (into VGPR lanes),   0 B/lane of scratch
+//    NMC + SEI        256 VGPR + 256 AGPR, 100 VGPR spills,              702 SGPR spills,                   180 B/lane
+//    LCO thermal      256 VGPR + 256 AGPR, 329 VGPR spills,              668 SGPR spills,                   368 B/lane
 // i.e. the arch-VGPR half is saturated everywhere and the AGPR half is the first spill level (v_accvgpr_read/write, one instruction each way); only what does not fit there
 // goes to scratch memory, and that traffic sits around the Jacobian refresh, not in the residual / solve loop.
 #if !defined(PL_WAVE_EMU) && !defined(PL_NO_WAVES_ATTR)      /* (PL_NO_WAVES_ATTR: experiment builds of tools/experiments/build_modes.py) */
