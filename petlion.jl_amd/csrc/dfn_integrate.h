@@ -880,9 +880,6 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     if (flag > 0 && o.interp_final && t > 1.0) {                        // interp_final_points!, model_evaluation.jl:369-382
       const double fr = pv.frac;
       const double ti = fr * (t - tprev) + tprev;
-#ifdef PL_DBG_W2
-      if (lane == 0) printf("DBG wave %d flag %d fr %.17g t %.17g tprev %.17g yy0 %.17g prev0 %.17g\n", wave_id(), flag, fr, t, tprev, S.yy[vrow<M>(0, 0, wave_id())], Yprev[vrow<M>(0, 0, wave_id())]);
-#endif
       PL_XSYNC();
       PL_VEC(n) { S.yy[n] = fr * (S.yy[n] - Yprev[n]) + Yprev[n]; S.yp[n] = fr * (S.yp[n] - YPprev[n]) + YPprev[n]; }
       PL_XSYNC();
