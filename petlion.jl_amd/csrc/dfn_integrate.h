@@ -34,7 +34,9 @@ struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live 
 //   GF_STOPS | GF_FUNC     + inputs that are functions of time given as tables (run_function), check_reinitialization!
 //   ... | GF_EXPR          + closure inputs of (t, Y, YP, theta): the postfix interpreter inside every residual evaluation
 //   ... | GF_REFINE        + iterative refinement of every linear solve (plh_opts.refine, the parity diagnostic)
-enum GenFlag { GF_STOPS = 1, GF_FUNC = 2, GF_EXPR = 4, GF_REFINE = 8 };
+//   ... | GF_GENROW        + a closure of the state with derivative programs: the general control row (GenRow, dfn_cell.h); separate from GF_EXPR because its
+//                           presence alone costs the plain-closure kernel 9 % (registers around the Newton loop)
+enum GenFlag { GF_STOPS = 1, GF_FUNC = 2, GF_EXPR = 4, GF_REFINE = 8, GF_GENROW = 16 };
 
 // device counters: wave-uniform registers (every call site uses a compile-time index), written out once at the end; indices:
 enum Cnt { C_STEPS, C_RES, C_JAC, C_FACT, C_SOLVE, C_NEWTON, C_ERRFAIL, C_CONVFAIL, C_SUMKP2, C_INIT };
@@ -175,8 +177,8 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
     cell_node_pass<true, true>(S, Y, YP, res, mode, value);      // R_alg + J_alg partials (differential rows ignored)
     PL_SYNC();
     bool gen = false;
-    if constexpr ((F & GF_EXPR) != 0) gen = g && g->on();
-    if constexpr ((F & GF_EXPR) != 0) { if (gen) gen_factor(S, R, tb, 0.0, mode, true, *g, t_fun, Y, YP, Ytmp); }        // (Ytmp is free until the Newton iteration is over)
+    if constexpr ((F & GF_GENROW) != 0) gen = g && g->on();
+    if constexpr ((F & GF_GENROW) != 0) { if (gen) gen_factor(S, R, tb, 0.0, mode, true, *g, t_fun, Y, YP, Ytmp); }        // (Ytmp is free until the Newton iteration is over)
     if (!gen) cell_factor(S, R, tb, 0.0, mode, true);
     if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref, gen ? g : nullptr);     // (GF_REFINE instantiations only: plh_opts.refine)
     else if (gen) gen_solve(S, R, res, true, *g);
@@ -206,7 +208,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
   PL_SYNC();
   bool gen = false;
-  if constexpr ((F & GF_EXPR) != 0) gen = g && g->on();
+  if constexpr ((F & GF_GENROW) != 0) gen = g && g->on();
   if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, res, bsave, 0.0, mode, true, nref, gen ? g : nullptr);
   else if (gen) gen_solve(S, R, res, true, *g);
   else cell_solve(S, R, res, mode, true);
@@ -355,7 +357,7 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
 #endif
 #ifndef PL_EXP_NO_FACTOR
       bool genf = false;
-      if constexpr ((F & GF_EXPR) != 0) { if (g && g->on()) { genf = true; gen_factor(S, R, tb, I.cj, mode, false, *g, I.tn, S.yy, S.yp, S.yp); } }   // (S.yp is dead until the next form_iterate; the row is evaluated before W overwrites it)
+      if constexpr ((F & GF_GENROW) != 0) { if (g && g->on()) { genf = true; gen_factor(S, R, tb, I.cj, mode, false, *g, I.tn, S.yy, S.yp, S.yp); } }   // (S.yp is dead until the next form_iterate; the row is evaluated before W overwrites it)
       if (!genf) cell_factor(S, R, tb, I.cj, mode, false);
 #endif
       cnt_add(cnt, C_RES); cnt_add(cnt, C_JAC); cnt_add(cnt, C_FACT);
@@ -371,7 +373,7 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
     { PL_TIC();
 #ifndef PL_EXP_NO_SOLVE
     bool gens = false;
-    if constexpr ((F & GF_EXPR) != 0) gens = g && g->on();
+    if constexpr ((F & GF_GENROW) != 0) gens = g && g->on();
     if ((F & GF_REFINE) && nref > 0) cell_solve_refined(S, R, tb, S.delta, S.yp, I.cjold, mode, false, nref, gens ? g : nullptr);   // (S.yp is dead until the next form_iterate; cjold = cj of the factors)
     else if (gens) gen_solve(S, R, S.delta, false, *g);
     else cell_solve(S, R, S.delta, mode, false);           // x = J^-1 F ; the Newton correction is -x
@@ -801,7 +803,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     if (lane == 0 && wave_id() == 0) S.yy[O_I] = Iguess;
     PL_XSYNC();
     GenRow grow;                                                        // closure of the state with derivative programs: general control row (dfn_cell.h)
-    if constexpr ((F & GF_EXPR) != 0) { if (run.value_kind == PLH_VAL_EXPR && run.n_dcol > 0 && genW) { grow.run = &run; grow.W = genW; } }
+    if constexpr ((F & GF_GENROW) != 0) { if (run.value_kind == PLH_VAL_EXPR && run.n_dcol > 0 && genW) { grow.run = &run; grow.W = genW; } }
     int flag = PLH_FLAG_RUNNING;
     plh_run_info ri; ri.flag = PLH_FLAG_RUNNING; ri.iterations = 0; ri.t_end = t_global; ri.V = 0; ri.I = 0; ri.SOC = SOC; ri.T_avg = T0;
     // tstops = {tdiscon - reltol/2} U {1.0 if continuation} U {tf}   (postfix_integrator!, model_evaluation.jl:288-310)

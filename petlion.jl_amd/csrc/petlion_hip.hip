@@ -699,10 +699,11 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
   CHECK_STAGE(s);                                                     // a failed staging allocation must never reach the kernel as a NULL ("not requested") output
   hipEventRecord(cx.ev0, s.st);
-  // the instantiation that has the features this call asks for (GenFlag, dfn_integrate.h): 1 = stop times / state dump, 2 = table inputs, 4 = closure inputs, 8 = refinement
+  // the instantiation that has the features this call asks for (GenFlag, dfn_integrate.h): 1 = stop times / state dump, 2 = table inputs, 4 = closure inputs, 8 = refinement, 16 = general control row
   int features = 0;
   if (opts->n_tdiscon > 0 || opts->n_tstops > 0 || out->Y_all || opts->yp_alg_zero != 0) features |= 1;
   for (int r = 0; r < n_runs; r++) { if (runs[r].value_kind == PLH_VAL_TABLE) features |= 1 | 2; if (runs[r].value_kind == PLH_VAL_EXPR) features |= 1 | 2 | 4; }
+  if (need_genW) features |= 16;                                     // closures with derivative programs: the general control row
   if (opts->refine > 0) features |= 1 | 2 | 4 | 8;
   m->ops->integrate(s.st, a, features);
   hipEventRecord(cx.ev1, s.st);

@@ -330,7 +330,8 @@ template <class M> struct OpsOf {
     PL_LAUNCH(k_init_consistent<M>, n, WAVE * M::NWAVES, st, tb, n, theta, mode, value, reltol_init, Y, YP, status, iters, nref);
   }
   static void integrate(hipStream_t st, const IntegrateArgs& a, int features) {     // features: GenFlag bits the call needs; the smallest instantiation that has them all
-    if (features & GF_REFINE) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR | GF_REFINE>), a.n_cells, WAVE * M::NWAVES, st, a);
+    if (features & GF_REFINE) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR | GF_GENROW | GF_REFINE>), a.n_cells, WAVE * M::NWAVES, st, a);
+    else if (features & GF_GENROW) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR | GF_GENROW>), a.n_cells, WAVE * M::NWAVES, st, a);
     else if (features & GF_EXPR) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR>), a.n_cells, WAVE * M::NWAVES, st, a);
     else if (features & GF_FUNC) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC>), a.n_cells, WAVE * M::NWAVES, st, a);
     else if (features & GF_STOPS) PL_LAUNCH((k_integrate<M, GF_STOPS>), a.n_cells, WAVE * M::NWAVES, st, a);
