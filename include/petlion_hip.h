@@ -49,6 +49,17 @@ extern "C" {
 #define PLH_MODE_P 3   /* power, W/m^2:         Y[I] I1C (Phi_s[1] - Phi_s[end]) - value   (method_P, input_methods.jl:80-111) */
 #define PLH_MODE_ETA_P 4 /* plating overpotential, V: Phi_s.n[1] - Phi_e.n[1] - value     (method_η_p, input_methods.jl:113-152) */
 #define PLH_N_MODES 5   /* the modes above: the ones with an exported Jacobian pattern (plh_jac_pattern, plh_residual, ...) */
+#define PLH_MODE_DSTATE 6 /* rate of change of ONE differential state held at value: value - YP[index] = 0 (reference dc_s_p_max / dc_s_p_min / dc_s_n_max / dc_s_n_min / dc_e_max /
+                            dc_e_min, input_methods.jl:190-247: state_deriv_func(ind) as a run_residual).  plh_run.dstate (PLH_DSTATE_*) says which state: chosen per cell from the
+                            state at the START of the run (the extreme surface concentration of an electrode / electrolyte concentration at the end of the previous run), so the run
+                            must continue a solution (not the first run of a protocol unless Y_init is given).  PLH_VAL_CONST or PLH_VAL_HOLD (= 0).  The consistent initialisation
+                            uses the row with YP[index] replaced by its differential equation (scalar_residual.jl:335-362).  plh_integrate / plh_ensemble_run only. */
+#define PLH_DSTATE_CS_P_MAX 1
+#define PLH_DSTATE_CS_P_MIN 2
+#define PLH_DSTATE_CS_N_MAX 3
+#define PLH_DSTATE_CS_N_MIN 4
+#define PLH_DSTATE_CE_MAX 5
+#define PLH_DSTATE_CE_MIN 6
 #define PLH_MODE_RES 5 /* user-defined control residual (reference method_res, input_methods.jl:155-175; run_residual, scalar_residual.jl:172):  value - f(t, Y, theta) = 0 with
                           the closure f as PLH_VAL_EXPR and its derivative programs (n_dcol >= 1: the reference always differentiates this row, scalar_residual.jl:262-274);
                           plh_integrate / plh_ensemble_run only.  Closures of YP (the dc_s_*, dc_e_* modes are such) are not supported. */
@@ -162,6 +173,7 @@ typedef struct {
   /* PLH_VAL_EXPR of the state: derivative programs of the control row (see PLH_VAL_EXPR above); HOST arrays, dcol[n_dcol] 0-based state columns in ascending order,
      dofs[n_dcol + 1] instruction offsets into tab_t / tab_v.  n_dcol = 0: no differentiation. */
   int n_dcol; const int* dcol; const int* dofs;
+  int dstate;      /* PLH_MODE_DSTATE: PLH_DSTATE_* ; 0 otherwise */
 } plh_run;
 
 /* reference options_simulation (src/structures.jl:266-285), the numerical subset */

@@ -351,7 +351,9 @@ static int splu_setup(splu* f, const int* cp, const int* ri, const double* ax) {
 /* ------------------------------------------------------------------------------------------------------------ */
 enum { ORC_MODE_I = 0, ORC_MODE_V = 1, ORC_MODE_DT = 2, ORC_MODE_P = 3, ORC_MODE_ETAP = 4,
        ORC_MODE_RES = 5,   /* method_res (input_methods.jl:155-175): res[end] = theta[:_residual_val] - run.func(t, Y, YP, p) (run_residual, scalar_residual.jl:172), a closure with derivative programs */
-       ORC_NMODES = 6 };
+       ORC_MODE_DSTATE = 6, /* x - YP[ind] = 0 with ind the extreme surface / electrolyte concentration at the start of the run (dc_s_p_max ... dc_e_min, input_methods.jl:190-247:
+                               state_deriv_func(ind) as a run_residual); orc_run.dstate = 1..6 in that order */
+       ORC_NMODES = 7 };
 enum { ORC_VAL_CONST = 0, ORC_VAL_HOLD = 1, ORC_VAL_REST = 2, ORC_VAL_TABLE = 3, ORC_VAL_EXPR = 4 };
 /* ORC_VAL_EXPR: the input closure run.func(t, Y, YP, p) (scalar_residual.jl:169-170) as a postfix program, instruction k = (opcode tab_t[k], operand tab_v[k]); the opcode
    numbering is the C ABI's (include/petlion_hip.h PLH_OP_*), restated here: */
@@ -374,6 +376,7 @@ typedef struct {   /* one run of a protocol = one simulate()/simulate!() call */
   /* ORC_VAL_EXPR of the state: the symbolic derivative of the closure, d f / d Y[dcol[k]] = instructions [dofs[k], dofs[k+1]) of the same arrays -- what the reference's
      differentiate_residual_func (scalar_residual.jl:276-416) compiles into J_scalar_func; n_dcol = 0: _get_method_funcs_no_differentiation (:248-274) */
   int n_dcol; const int* dcol; const int* dofs;
+  int dstate;      /* ORC_MODE_DSTATE: which state (1 c_s_p max, 2 c_s_p min, 3 c_s_n max, 4 c_s_n min, 5 c_e max, 6 c_e min) */
 } orc_run;
 
 typedef struct {   /* reference options_simulation, src/structures.jl:266-285 */
@@ -428,6 +431,9 @@ typedef struct {
   /* closure with derivative programs (drun->n_dcol > 0): the control row = the input method's own entries (the first n_base / an_base columns above) minus d f / d Y, whose
      columns not already in the row follow them (scalar_residual.jl:300-303: J_sp_scalar[J_vec.nzind] .= 1); dpos[k] / adpos[k] = position of column dcol[k] (-1: not in the block) */
   const orc_run* drun; int n_base, an_base; int dpos[64], adpos[64];
+  int dind;                /* ORC_MODE_DSTATE: the state whose derivative is held (-1 otherwise); its twin row takes the algebraic entries of row dind of the base Jacobian */
+  int n_tw; int tw_src[64]; /* positions of those entries in the base CSC values (the control-row entries actrl_pos[0..n_tw) of the algebraic block) */
+  double* tmp_diff;        /* N_diff work vector (f_diff for the twin) */
   double *tmp_nz, *w;
   double *ax_f, *aax_f, *rtmp, *xtmp;   /* the matrices as last factored (iterative refinement), work vectors */
   double I1C;
@@ -510,14 +516,21 @@ static double calc_I1C_c(const orc_model* m, const double* th) {
   return (96485.3321233 / 3600.0) * (a < b ? a : b);
 }
 
-static int evalb_init_d(evalb* e, const orc_model* m, const double* th, int mode, double value, orc_counters* cnt, const orc_run* drun) {
+static int evalb_init_x(evalb* e, const orc_model* m, const double* th, int mode, double value, orc_counters* cnt, const orc_run* drun, int dind) {
   memset(e, 0, sizeof(*e));
-  e->m = *m; e->th = th; e->mode = mode; e->value = value; e->cnt = cnt; e->drun = drun;
+  e->m = *m; e->th = th; e->mode = mode; e->value = value; e->cnt = cnt; e->drun = drun; e->dind = dind;
   int N = m->N, Nd = m->Nd, Na = N - Nd;
   if (mode == ORC_MODE_DT && !m->thermal) return -1;
   e->n_ctrl = e->n_base = ctrl_columns(m, mode, e->ctrl_col, 0);
   e->an_ctrl = e->an_base = ctrl_columns(m, mode, e->actrl_col, 1);
-  if (drun) {
+  if (mode == ORC_MODE_DSTATE) {          /* integration row: -cj at column dind; twin: row dind of dF/dY in the algebraic columns (scalar_residual.jl:335-362) */
+    if (dind < 0 || dind >= Nd) return -1;
+    e->ctrl_col[0] = dind; e->n_ctrl = e->n_base = 1;
+    e->n_tw = 0;
+    for (int c = Nd; c < N; c++) for (int q = m->colptr[c]; q < m->colptr[c + 1]; q++) if (m->rowval[q] == dind && e->n_tw < 64) { e->actrl_col[e->n_tw] = c; e->tw_src[e->n_tw] = q; e->n_tw++; }
+    e->an_ctrl = e->an_base = e->n_tw;
+  }
+  if (drun && mode != ORC_MODE_DSTATE) {
     if (drun->n_dcol > 64 || mode == ORC_MODE_DT) return -1;
     for (int k = 0; k < drun->n_dcol; k++) {
       const int c = drun->dcol[k]; int q;
@@ -530,13 +543,14 @@ static int evalb_init_d(evalb* e, const orc_model* m, const double* th, int mode
   build_pattern(N, N - 1, m->colptr, m->rowval, 0, e->n_ctrl, e->ctrl_col, &e->cp, &e->ri, &e->nnz, &e->base_map, e->ctrl_pos);
   build_pattern(Na, Na - 1, m->acolptr, m->arowval, Nd, e->an_ctrl, e->actrl_col, &e->acp, &e->ari, &e->annz, &e->abase_map, e->actrl_pos);
   e->ax = (double*)calloc(e->nnz, sizeof(double)); e->aax = (double*)calloc(e->annz, sizeof(double));
-  e->tmp_nz = (double*)calloc(m->nnz + 64, sizeof(double)); e->w = (double*)calloc(N, sizeof(double));
+  e->tmp_nz = (double*)calloc(m->nnz + 64, sizeof(double)); e->w = (double*)calloc(N, sizeof(double)); e->tmp_diff = (double*)calloc(Nd > 0 ? Nd : 1, sizeof(double));
   e->ax_f = (double*)calloc(e->nnz, sizeof(double)); e->aax_f = (double*)calloc(e->annz, sizeof(double)); e->rtmp = (double*)calloc(N, sizeof(double)); e->xtmp = (double*)calloc(N, sizeof(double));
   if (m->thermal) m->dT_weights(e->w, th);
   e->I1C = calc_I1C_c(m, th);
   splu_init(&e->lu, N, e->cp, e->ri); splu_init(&e->alu, Na, e->acp, e->ari);
   return 0;
 }
+static int evalb_init_d(evalb* e, const orc_model* m, const double* th, int mode, double value, orc_counters* cnt, const orc_run* drun) { return evalb_init_x(e, m, th, mode, value, cnt, drun, -1); }
 static int evalb_init(evalb* e, const orc_model* m, const double* th, int mode, double value, orc_counters* cnt) { return evalb_init_d(e, m, th, mode, value, cnt, NULL); }
 /* minus the closure's derivative programs into the control row (J_scalar_func of differentiate_residual_func); alg: the columns of the algebraic block only
    (J_vec[N.diff+1:end], scalar_residual.jl:369-371) */
@@ -551,7 +565,7 @@ static void ctrl_row_derivatives(const evalb* e, const double* Y, const double* 
 }
 static void evalb_free(evalb* e) {
   free(e->cp); free(e->ri); free(e->ax); free(e->base_map); free(e->acp); free(e->ari); free(e->aax); free(e->abase_map);
-  free(e->tmp_nz); free(e->w); free(e->ax_f); free(e->aax_f); free(e->rtmp); free(e->xtmp); splu_free(&e->lu); splu_free(&e->alu);
+  free(e->tmp_nz); free(e->w); free(e->tmp_diff); free(e->ax_f); free(e->aax_f); free(e->rtmp); free(e->xtmp); splu_free(&e->lu); splu_free(&e->alu);
 }
 
 static double ctrl_residual(evalb* e, const double* Y, const double* YP) {
@@ -559,6 +573,7 @@ static double ctrl_residual(evalb* e, const double* Y, const double* YP) {
   if (e->frun && e->frun->value_kind == ORC_VAL_EXPR) e->value = expr_eval(e->frun, e->t_fun, Y, YP, e->th);
   const orc_model* m = &e->m;
   if (e->mode == ORC_MODE_RES) return e->frun->value - e->value;                                  /* run_residual: _residual_val - f */
+  if (e->mode == ORC_MODE_DSTATE) return e->value - YP[e->dind];                                  /* state_deriv_func(ind): _residual_val - YP[ind] */
   if (e->mode == ORC_MODE_I) return Y[m->o_I] - e->value;                                         /* method_I */
   if (e->mode == ORC_MODE_V) return Y[m->o_ps] - Y[m->o_ps + m->Np + m->Nn - 1] - e->value;       /* method_V */
   if (e->mode == ORC_MODE_P) return Y[m->o_I] * e->I1C * (Y[m->o_ps] - Y[m->o_ps + m->Np + m->Nn - 1]) - e->value;   /* method_P = calc_P, scalar_residual.jl:87 */
@@ -579,6 +594,7 @@ static void R_alg(evalb* e, double* res /*N_alg*/, const double* Y, const double
   const orc_model* m = &e->m; int Na = m->N - m->Nd;
   m->f_alg(res, Y, YP, e->th);
   if (e->mode == ORC_MODE_DT) { double tw; m->dT_twin(&tw, Y, YP, e->th); res[Na - 1] = e->value + tw; }
+  else if (e->mode == ORC_MODE_DSTATE) { m->f_diff(e->tmp_diff, Y, YP, e->th); res[Na - 1] = e->value - (e->tmp_diff[e->dind] + YP[e->dind]); }   /* YP[ind] -> rhs_ind(Y) = F_ind + YP[ind] */
   else res[Na - 1] = ctrl_residual(e, Y, YP);
   if (e->cnt) e->cnt->n_res++;
 }
@@ -599,6 +615,7 @@ static void J_full(evalb* e, const double* Y, const double* YP, double cj) {
   else if (e->mode == ORC_MODE_V) { e->ax[e->ctrl_pos[0]] = 1.0; e->ax[e->ctrl_pos[1]] = -1.0; }
   else if (e->mode == ORC_MODE_P || e->mode == ORC_MODE_ETAP) ctrl_row_P_etap(e, Y, e->ax, e->ctrl_pos);
   else if (e->mode == ORC_MODE_DT) for (int k = 0; k < e->n_ctrl; k++) e->ax[e->ctrl_pos[k]] = -cj * e->w[k];
+  else if (e->mode == ORC_MODE_DSTATE) e->ax[e->ctrl_pos[0]] = -cj;
   ctrl_row_derivatives(e, Y, YP, e->ax, e->ctrl_pos, e->n_base, e->n_ctrl, 0);
   if (e->cnt) e->cnt->n_jac++;
 }
@@ -610,6 +627,7 @@ static void J_alg(evalb* e, const double* Y, const double* YP) {
   else if (e->mode == ORC_MODE_V) { e->aax[e->actrl_pos[0]] = 1.0; e->aax[e->actrl_pos[1]] = -1.0; }
   else if (e->mode == ORC_MODE_P || e->mode == ORC_MODE_ETAP) ctrl_row_P_etap(e, Y, e->aax, e->actrl_pos);
   else if (e->mode == ORC_MODE_DT) { m->dT_twin_jac(e->tmp_nz, Y, YP, 0.0, e->th); for (int k = 0; k < e->an_ctrl; k++) e->aax[e->actrl_pos[k]] = e->tmp_nz[k]; }
+  else if (e->mode == ORC_MODE_DSTATE) { m->jac(e->tmp_nz, Y, YP, 0.0, e->th); for (int k = 0; k < e->n_tw; k++) e->aax[e->actrl_pos[k]] = -e->tmp_nz[e->tw_src[k]]; }
   ctrl_row_derivatives(e, Y, YP, e->aax, e->actrl_pos, e->an_base, e->an_ctrl, 1);
   if (e->cnt) e->cnt->n_jac++;
 }
@@ -1009,11 +1027,11 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       if (out_V) { out_V[nout] = calc_V(&M, (Y_)); } \
       if (out_I) { out_I[nout] = (Y_)[M.o_I]; } \
       if (out_SOC) { out_SOC[nout] = (SOC_); } \
-      if (out_T) { out_T[nout] = calc_Tavg(&M, ev[run->mode].w, (Y_), T0); } \
+      if (out_T) { out_T[nout] = calc_Tavg(&M, cur_w, (Y_), T0); } \
       if (ctx->out_Y) { memcpy(ctx->out_Y + (size_t)nout * N, (Y_), N * sizeof(double)); } }   /* outputs = :all (sol.Y, save_outputs.jl:11-40) */ \
     nout++; } while (0)
 #define REPLACE_LAST(tt_, Y_, SOC_) do { nout--; SAVE(tt_, Y_, SOC_); } while (0)
-  evalb ev_der; int own_ev = 0;
+  evalb ev_der; int own_ev = 0; const double* cur_w = NULL;
   for (int r = 0; r < n_runs; r++) {
     const orc_run* run = &runs[r];
     int mode = run->mode;
@@ -1030,6 +1048,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
     /* initial_current! (input_methods.jl:11-74) */
     double value = run->value;
     const int is_tab = run->value_kind == ORC_VAL_TABLE || run->value_kind == ORC_VAL_EXPR;
+    const int is_fun = is_tab && mode != ORC_MODE_RES;      /* run_function; a `res` closure is a run_residual */
     if (is_tab) {                                /* run_function: initial_current! (input_methods.jl:28-34, 65-76, 104-107, 143-153) */
       value = run_input(run, 0.0, Y, YP, theta);
       if (mode == ORC_MODE_I) Y[M.o_I] = value;
@@ -1056,12 +1075,27 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       if (run->value_kind == ORC_VAL_HOLD) value = 0.0;
       if (have_prev) Y[M.o_I] = prev_I; else Y[M.o_I] = 1.0;      /* input_methods.jl:171-176 */
     }
-    if (!ev_ok[mode]) { if (evalb_init(&ev[mode], &M, theta, mode, value, cnt) != 0) { rc = -102; break; } ev_ok[mode] = 1; }
-    evalb* e = &ev[mode];
-    /* a closure of the state with derivative programs has its own sparsity pattern: its own evaluator bundle */
+    evalb* e = NULL;
+    /* a closure of the state with derivative programs, or the rate of a state chosen at run time, has its own sparsity pattern: its own evaluator bundle */
     if (own_ev) { evalb_free(&ev_der); own_ev = 0; }
+    if (mode == ORC_MODE_DSTATE) {
+      /* which state: the extreme surface / electrolyte concentration of sol.Y[end] (input_methods.jl:195-247; argmax / argmin return the first extreme) */
+      if (!have_prev || run->dstate < 1 || run->dstate > 6) { rc = -103; break; }
+      int first, count, stride;                     /* surface entry of particle i: the last of its N_r radial nodes (c_s_indices, aux...jl:688-716; N_r = 1: c_s_avg itself) */
+      if (run->dstate <= 2) { first = M.o_cs + M.Nrp - 1; count = M.Np; stride = M.Nrp; }
+      else if (run->dstate <= 4) { first = M.o_cs + M.Np * M.Nrp + M.Nrn - 1; count = M.Nn; stride = M.Nrn; }
+      else { first = M.o_ce; count = M.Np + M.Ns + M.Nn; stride = 1; }
+      int best = first; const int want_max = run->dstate & 1;
+      for (int q = 1; q < count; q++) { const int idx = first + q * stride; if (want_max ? Y[idx] > Y[best] : Y[idx] < Y[best]) best = idx; }
+      if (evalb_init_x(&ev_der, &M, theta, mode, value, cnt, NULL, best) != 0) { rc = -102; break; }
+      own_ev = 1; e = &ev_der;
+    } else {
+      if (!ev_ok[mode]) { if (evalb_init(&ev[mode], &M, theta, mode, value, cnt) != 0) { rc = -102; break; } ev_ok[mode] = 1; }
+      e = &ev[mode];
+    }
     if (run->value_kind == ORC_VAL_EXPR && run->n_dcol > 0) { if (evalb_init_d(&ev_der, &M, theta, mode, value, cnt, run) != 0) { rc = -102; break; } own_ev = 1; e = &ev_der; }
     e->value = value; e->th = theta; e->cnt = cnt; e->frun = is_tab ? run : NULL; e->t_fun = 0.0;
+    cur_w = e->w;
     if (M.thermal) M.dT_weights(e->w, theta);
     int ierr = newtons_method(e, Y, YP, opts, c_e0);
     orc_runinfo* ri = &info[r]; memset(ri, 0, sizeof(*ri)); ri->flag = -1;
@@ -1104,10 +1138,10 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
       SAVE(t + t0, Y, SOC);
       check_stop(&M, e, run, opts, t, run->tf, Y, YP, SOC, &pv, &flag, c_max_n);
       /* check_solve (checks.jl:226-249) */
-      if (!is_tab && t == tprev) { flag = ORC_ERR_STALL; break; }              /* (run_function has no stall test, checks.jl:251-269) */
+      if (!is_fun && t == tprev) { flag = ORC_ERR_STALL; break; }              /* (run_function has no stall test, checks.jl:251-269; run_residual has: checks.jl:226) */
       if (iter == opts->maxiters) { flag = ORC_ERR_MAXITERS; break; }
       if (flag == -1) { memcpy(Yprev, Y, N * sizeof(double)); memcpy(YPprev, YP, N * sizeof(double)); t_prev_saved = t + t0; }
-      if (flag == -1 && is_tab && t - tprev < 1e-3 * opts->reltol) {          /* check_reinitialization!, checks.jl:341-364 */
+      if (flag == -1 && is_fun && t - tprev < 1e-3 * opts->reltol) {          /* check_reinitialization!, checks.jl:341-364 */
         const double t_new = t + opts->reltol, v_old = e->value, v_new = run_input(run, t_new, Y, YP, theta);
         const double big = fmax(fabs(v_old), fabs(v_new));
         if (!(fabs(v_old - v_new) <= fmax(opts->abstol, opts->reltol * big))) {

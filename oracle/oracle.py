@@ -28,7 +28,7 @@ class Bounds(C.Structure):
 class Run(C.Structure):
     _fields_ = [("mode", C.c_int), ("value_kind", C.c_int), ("value", C.c_double), ("tf", C.c_double), ("bounds", Bounds),
                 ("n_tab", C.c_int), ("tab_t", C.POINTER(C.c_double)), ("tab_v", C.POINTER(C.c_double)),
-                ("n_dcol", C.c_int), ("dcol", C.POINTER(C.c_int)), ("dofs", C.POINTER(C.c_int))]
+                ("n_dcol", C.c_int), ("dcol", C.POINTER(C.c_int)), ("dofs", C.POINTER(C.c_int)), ("dstate", C.c_int)]
 
 
 class Opts(C.Structure):
@@ -123,6 +123,7 @@ def simulate(variant, theta, SOC0, runs, opts=None, max_out=20000, Y_init=None, 
         arr[k].value = r.get("value", 0.0)
         arr[k].tf = r.get("tf", 1e6)
         arr[k].bounds = r.get("bounds") or default_bounds()
+        arr[k].dstate = r.get("dstate", 0)
         if r.get("table") is not None:        # (t, v) arrays: piecewise-linear input in run-local time
             tt = np.ascontiguousarray(r["table"][0], dtype=np.float64); vv = np.ascontiguousarray(r["table"][1], dtype=np.float64)
             keep.append((tt, vv))

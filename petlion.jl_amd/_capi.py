@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("PETLION_HIP_LIB") or os.path.join(HERE, "libpetlion_h
 PLH_HOST, PLH_DEVICE, PLH_HOST_ASYNC = 0, 1, 2
 PREC_F64, PREC_MIXED = 0, 1
 PART_BLOCK, PART_CYCLIC = 0, 1
-MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETA_P, MODE_RES = 0, 1, 2, 3, 4, 5
+MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETA_P, MODE_RES, MODE_DSTATE = 0, 1, 2, 3, 4, 5, 6
+DSTATE = {"dc_s_p_max": 1, "dc_s_p_min": 2, "dc_s_n_max": 3, "dc_s_n_min": 4, "dc_e_max": 5, "dc_e_min": 6}
 VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE, VAL_EXPR = 0, 1, 2, 3, 4
 CHEM_LCO, CHEM_NMC, CHEM_LGM50 = 0, 1, 2
 FLAG_RUNNING, ERR_INIT, ERR_STALL, ERR_MAXITERS, ERR_OUTPUT_FULL = -1, -11, -12, -13, -14
@@ -39,7 +40,7 @@ class Run(C.Structure):
     _fields_ = [("mode", C.c_int), ("value_kind", C.c_int), ("value", C.c_double), ("tf", C.c_double), ("bounds", Bounds),
                 ("n_tab", C.c_int), ("tab_t", C.POINTER(C.c_double)), ("tab_v", C.POINTER(C.c_double)),
                 ("value_cell", C.POINTER(C.c_double)), ("tf_cell", C.POINTER(C.c_double)),
-                ("n_dcol", C.c_int), ("dcol", C.POINTER(C.c_int)), ("dofs", C.POINTER(C.c_int))]
+                ("n_dcol", C.c_int), ("dcol", C.POINTER(C.c_int)), ("dofs", C.POINTER(C.c_int)), ("dstate", C.c_int)]
 
 
 class Opts(C.Structure):

@@ -134,8 +134,9 @@ def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-_INPUTS = ("I", "V", "dT", "P", "η_p", "res")
+_INPUTS = ("I", "V", "dT", "P", "η_p", "res") + tuple(cap.DSTATE)
 _MODE = {"I": cap.MODE_I, "V": cap.MODE_V, "dT": cap.MODE_DT, "P": cap.MODE_P, "η_p": cap.MODE_ETA_P, "res": cap.MODE_RES}
+_MODE.update({k: cap.MODE_DSTATE for k in cap.DSTATE})       # dc_s_p_max, ..., dc_e_min (input_methods.jl:190-247): the rate of one differential state, chosen per cell at the start of the run
 _BOUND_KW = Bounds.FIELDS
 
 
@@ -143,6 +144,10 @@ def _make_run(p, name, inp, tf, bounds):
     r = cap.Run()
     r.mode = _MODE[name]
     res_x = 0.0
+    if name in cap.DSTATE:
+        r.dstate = cap.DSTATE[name]
+        if callable(inp) or isinstance(inp, (tuple, list)):
+            raise ValueError("%s takes a number or :hold" % name)
     if name == "res":
         # user-defined control residual (reference input_methods.jl:155-175, custom_res!, model_evaluation.jl:155-172): res = f  ->  0 - f = 0;  res = (x, f)  ->  x - f = 0
         if isinstance(inp, (tuple, list)) and len(inp) == 2 and callable(inp[1]) and not callable(inp[0]):

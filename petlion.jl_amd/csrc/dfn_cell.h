@@ -346,6 +346,7 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {               
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int lane_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }                       // wave-uniform src
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_mov0<0x111>(v); v += dpp_mov0<0x112>(v); v += dpp_mov0<0x114>(v); v += dpp_mov0<0x118>(v);   // row_shr 1,2,4,8: inclusive row scan
   return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
@@ -356,6 +357,7 @@ __device__ __forceinline__ double shift_down1(double v) { const double r = __shf
 __device__ __forceinline__ double row_up2(double v) { const double r = __shfl_up(v, 2); return (lane_id() & 15) < 2 ? 0.0 : r; }
 __device__ __forceinline__ double row_down2(double v) { const double r = __shfl_down(v, 2); return (lane_id() & 15) > 13 ? 0.0 : r; }
 __device__ __forceinline__ double lane_bcast(double v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ int lane_bcast_i(int v, int src) { return __shfl(v, src); }
 __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 1; o < 16; o <<= 1) { const double r = __shfl_up(v, o); if ((lane_id() & 15) >= o) v += r; }
   return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
@@ -1530,14 +1532,14 @@ PL_DEV double jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, unsi
 // scalar_residual.jl:276-416 puts d(method - f)/dY into the last row of the Newton matrix).  The row can touch any column, so it is handled as a BORDER of the
 // structured solve in current mode (whose control row is "x_I = b_I"):  with W = J_I^-1 e_I (the image of the I column, W[O_I] = 1; one extra solve per factorisation,
 // kept in HBM) and x0 the mode-I solve of the right-hand side with b_I = 0,   x_I = (b_I - g.x0) / (g.W),   x = x0 + x_I W.
-// Entry k of the row lives in lane k (gv); its column is one of the input method's own (bcol) or run->dcol[k - nb].  Built by gen_factor (dfn_integrate.h).
+// Entry k of the row lives in lane k (value gv, column gcol).  Built by gen_factor (dfn_integrate.h).
 struct GenRow {
-  const plh_run* run = nullptr;   // nullptr: the run has no derivative programs
+  const plh_run* run = nullptr;   // nullptr: the run has no general control row
   double* W = nullptr;            // this cell's [NST] slice of IntegrateArgs.genW
-  double gv = 0.0, bord = 1.0;
-  int ng = 0, nb = 0, bc0 = 0, bc1 = 0, bc2 = 0;
+  double gv = 0.0, bord = 1.0;    // lane k: value of entry k ; border pivot g . W
+  int gcol = 0, ng = 0;           // lane k: column of entry k ; number of entries (<= 64)
   __device__ __forceinline__ bool on() const { return run != nullptr; }
-  __device__ __forceinline__ int col(int k) const { return k >= nb ? run->dcol[k - nb] : (k == 0 ? bc0 : (k == 1 ? bc1 : bc2)); }
+  __device__ __forceinline__ int col(int k) const { return lane_bcast_i(gcol, k); }
   // g . b (wave-uniform; b an LDS vector)
   __device__ __forceinline__ double dot(const double* b, int first_col) const {
     double s = 0.0;

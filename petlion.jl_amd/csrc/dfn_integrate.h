@@ -111,6 +111,7 @@ PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double*
 // scalar_residual.jl:172: res = theta[:_residual_val] - f) the row is -(f - x) with x = plh_run.value
 template <class M>
 PL_DEV double closure_input(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP) {
+  if (r.mode == PLH_MODE_DSTATE) return YP[r.dstate] - r.value;      // state_deriv_func(ind) as the residual x - YP[ind] (r.dstate = the index once the run has started; r.value = x)
   const double f = expr_eval(S, r, t, Y, YP);
   return r.mode == PLH_MODE_RES ? f - r.value : f;
 }
@@ -128,20 +129,27 @@ PL_DEV void gen_factor(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double cj, 
   PL_MODEL(M);
   const int lane = lane_id();
   const plh_run& r = *g.run;
-  double b0, b1 = 0.0, b2 = 0.0;
-  if (mode == PLH_MODE_I) { g.nb = 1; g.bc0 = O_I; b0 = 1.0; }
-  else if (mode == PLH_MODE_V) { g.nb = 2; g.bc0 = O_PS; g.bc1 = O_PS + NJ - 1; b0 = 1.0; b1 = -1.0; }
-  else if (mode == PLH_MODE_RES) { g.nb = 0; b0 = 0.0; }                                                    // method_res = 0: the row is the closure's alone
-  else if (mode == PLH_MODE_P) { g.nb = 3; g.bc0 = O_PS; g.bc1 = O_PS + NJ - 1; g.bc2 = O_I; b0 = Y[O_I] * S.cc.I1C; b1 = -b0; b2 = (Y[O_PS] - Y[O_PS + NJ - 1]) * S.cc.I1C; }
-  else { g.nb = 2; g.bc0 = O_PE + NP + NS; g.bc1 = O_PS + NP; b0 = -1.0; b1 = 1.0; }                      // eta_p
-  g.ng = g.nb + r.n_dcol;
-  double gv = 0.0;
-  for (int k = 0; k < g.ng; k++) {
-    double v = k >= g.nb ? -expr_eval(S, r, t, Y, YP, r.dofs[k - g.nb], r.dofs[k - g.nb + 1]) : (k == 0 ? b0 : (k == 1 ? b1 : b2));
-    if (alg_only && g.col(k) < NDIFF) v = 0.0;
-    if (lane == k) gv = v;
+  double gv = 0.0; int gcol = 0, ng = 0;
+  auto entry = [&](int c, double v) { if (!(alg_only && c < NDIFF)) { if (lane == ng) { gv = v; gcol = c; } ng++; } };      // (wave-uniform c, v; entry k lives in lane k)
+  if (r.mode == PLH_MODE_DSTATE) {
+    // x - YP[ind] (state_deriv_func, input_methods.jl:190-247): the integration row is -cj at column ind; the consistent-initialisation row has YP[ind] replaced by the
+    // differential equation of that state (scalar_residual.jl:335-362), i.e. minus the entries of row ind of dF/dY in the algebraic columns -- walked through the
+    // decode words of the exported pattern (current mode's: the rows other than the last do not depend on the mode)
+    const int ind = r.dstate;
+    if (!alg_only) entry(ind, -cj);
+    else {
+      const int* __restrict__ ptr = tb->csr_ptr[PLH_MODE_I]; const unsigned* __restrict__ code = tb->csr_code[PLH_MODE_I]; const unsigned short* __restrict__ ccol = tb->csr_col[PLH_MODE_I];
+      for (int k = ptr[ind]; k < ptr[ind + 1]; k++) { const int c = ccol[k]; if (c >= NDIFF) entry(c, -jac_entry<false>(S, tb, code[k], 0.0)); }
+    }
+  } else {
+    if (mode == PLH_MODE_I) entry(O_I, 1.0);                                                                 // scalar_jacobian! of the input method (scalar_residual.jl:174-202)
+    else if (mode == PLH_MODE_V) { entry(O_PS, 1.0); entry(O_PS + NJ - 1, -1.0); }
+    else if (mode == PLH_MODE_P) { const double iI = Y[O_I] * S.cc.I1C; entry(O_PS, iI); entry(O_PS + NJ - 1, -iI); entry(O_I, (Y[O_PS] - Y[O_PS + NJ - 1]) * S.cc.I1C); }
+    else if (mode == PLH_MODE_ETA_P) { entry(O_PE + NP + NS, -1.0); entry(O_PS + NP, 1.0); }
+    // (PLH_MODE_RES: method_res = 0, the row is the closure's alone)
+    for (int k = 0; k < r.n_dcol; k++) entry(r.dcol[k], -expr_eval(S, r, t, Y, YP, r.dofs[k], r.dofs[k + 1]));
   }
-  g.gv = gv;
+  g.gv = gv; g.gcol = gcol; g.ng = ng;
   cell_factor(S, R, tb, cj, PLH_MODE_I, alg_only);
   PL_XSYNC();
   PL_VEC(n) tmp[n] = n == O_I ? 1.0 : 0.0;
@@ -171,9 +179,23 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   PL_XSYNC();
   // the dT control row contains YP_T; the algebraic system uses its twin with YP_T -> rhs_T(Y) (scalar_residual.jl:347-372)
   if (M::THERMAL && mode == PLH_MODE_DT) mode = PL_MODE_DT_TWIN;
+  // value of a closure input with the iterate; PLH_MODE_DSTATE (x - YP[ind]): YP[ind] is replaced by the differential equation of that state (the reference's
+  // consistent-initialisation form of a residual that contains YP, scalar_residual.jl:335-362): rhs_ind(Yv) = F_ind(Yv, YP) + YP[ind]
+  auto input_value = [&](const double* Yv) -> double {
+    if constexpr ((F & GF_GENROW) != 0) {
+      if (frun->mode == PLH_MODE_DSTATE) {
+        cell_residual(S, R, Yv, YP, res, PLH_MODE_RES, 0.0);
+        PL_XSYNC();
+        const double v = res[frun->dstate] + YP[frun->dstate] - frun->value;
+        PL_XSYNC();
+        return v;
+      }
+    }
+    return closure_input(S, *frun, t_fun, Yv, YP);
+  };
   int ok = 0;
   for (int iter = 1; iter <= 100; iter++) {
-    if constexpr ((F & GF_EXPR) != 0) { if (frun) value = closure_input(S, *frun, t_fun, Y, YP); }
+    if constexpr ((F & GF_EXPR) != 0) { if (frun) value = input_value(Y); }
     cell_node_pass<true, true>(S, Y, YP, res, mode, value);      // R_alg + J_alg partials (differential rows ignored)
     PL_SYNC();
     bool gen = false;
@@ -193,7 +215,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   }
   if (!ok) return PLH_ERR_INIT;
   // YP_diff = rhs_diff(Y)   (R_diff with YP = 0)
-  if constexpr ((F & GF_EXPR) != 0) { if (frun) value = closure_input(S, *frun, t_fun, Y, YP); }
+  if constexpr ((F & GF_EXPR) != 0) { if (frun) value = input_value(Y); }
   cell_residual(S, R, Y, YP, res, mode == PL_MODE_DT_TWIN ? PLH_MODE_DT : mode, value);
   PL_VEC(n) if (n < NDIFF) YP[n] = res[n];
   PL_SYNC();
@@ -204,7 +226,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
   if (10.0 * reltol_init > dt) dt = 10.0 * reltol_init;
   PL_VEC(n) Ytmp[n] = Y[n] + dt * YP[n];
   PL_XSYNC();
-  if constexpr ((F & GF_EXPR) != 0) { if (frun) value = closure_input(S, *frun, t_fun, Ytmp, YP); }
+  if constexpr ((F & GF_EXPR) != 0) { if (frun) value = input_value(Ytmp); }
   cell_node_pass<true, false>(S, Ytmp, YP, res, mode, value);
   PL_SYNC();
   bool gen = false;
@@ -613,8 +635,8 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
   if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0 && wave_id() == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; PL_XSYNC(); }
   for (;;) {
     double ck; { PL_TIC(); PL_TICE(3); ck = ida_set_coeffs(S, I); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 0); }
-    if constexpr ((F & GF_FUNC) != 0) { if (frun) value = run_input<F>(S, *frun, I.tn, S.yy, S.yp); }                           // every residual of this step attempt is evaluated at t = tn
-    const int nflag = ida_nls<F>(S, R, tb, I, mode, value, o.jac_every_step, cnt, o.refine, ((F & GF_EXPR) && frun && frun->value_kind == PLH_VAL_EXPR) ? frun : nullptr, &value, g);
+    if constexpr ((F & GF_FUNC) != 0) { if (frun && frun->mode != PLH_MODE_DSTATE) value = run_input<F>(S, *frun, I.tn, S.yy, S.yp); }                           // every residual of this step attempt is evaluated at t = tn
+    const int nflag = ida_nls<F>(S, R, tb, I, mode, value, o.jac_every_step, cnt, o.refine, ((F & GF_EXPR) && frun && (frun->value_kind == PLH_VAL_EXPR || frun->mode == PLH_MODE_DSTATE)) ? frun : nullptr, &value, g);
     int errfail = 0;
     if (nflag == 0) { PL_TIC(); PL_TICE(3); errfail = ida_test_error(S, I, ck, err_k, err_km1); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 1); }
     if (nflag != 0 || errfail) {
@@ -762,7 +784,23 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     if (lane == 0 && wave_id() == 0) { S.runc = runs[r]; if (S.runc.value_cell) S.runc.value = S.runc.value_cell[cell]; if (S.runc.tf_cell) S.runc.tf = S.runc.tf_cell[cell]; }
     PL_XSYNC();
     const plh_run& run = S.runc;
-    const int mode = run.mode;
+    // PLH_MODE_DSTATE (x - YP[ind] = 0) runs as a control residual with no method part (PLH_MODE_RES) whose "closure" is YP[ind] (closure_input, gen_factor)
+    const bool dstate = (F & GF_GENROW) && run.mode == PLH_MODE_DSTATE;
+    const int mode = dstate ? PLH_MODE_RES : run.mode;
+    if constexpr ((F & GF_GENROW) != 0) {
+      if (dstate) {      // which state: the extreme surface / electrolyte concentration of the state the run starts from (input_methods.jl:195-247; argmax / argmin: the first extreme)
+        const int kind = run.dstate;
+        constexpr int CSTR = M::SD == 0 ? NR : 1, CSURF = M::SD == 0 ? NR - 1 : 0;
+        const int first = kind <= PLH_DSTATE_CS_P_MIN ? O_CS + CSURF : (kind <= PLH_DSTATE_CS_N_MIN ? O_CS + NP * CSTR + CSURF : O_CE);
+        const int count = kind <= PLH_DSTATE_CS_P_MIN ? NP : (kind <= PLH_DSTATE_CS_N_MIN ? NN : NE), stride = kind <= PLH_DSTATE_CS_N_MIN ? CSTR : 1;
+        const bool want_max = (kind & 1) != 0;
+        int best = first; double bv = S.yy[first];
+        for (int q = 1; q < count; q++) { const double v = S.yy[first + q * stride]; if (want_max ? v > bv : v < bv) { bv = v; best = first + q * stride; } }
+        PL_XSYNC();
+        if (lane == 0 && wave_id() == 0) S.runc.dstate = best;
+        PL_XSYNC();
+      }
+    }
     const bool new_run = !have_prev;
     double t0;
     // S.yy holds the current state Y, S.yp the current YP between steps
@@ -771,6 +809,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     // initial_current! (input_methods.jl:11-74)
     double value = run.value, Iguess;
     const bool is_tab = (F & GF_FUNC) && (run.value_kind == PLH_VAL_TABLE || run.value_kind == PLH_VAL_EXPR);      // run_function
+    const bool is_fun = is_tab && run.mode != PLH_MODE_RES;              // run_function; a `res` closure is a run_residual (checks.jl:226: stall test, no check_reinitialization!)
     if (is_tab) {                                                       // run_function: initial_current!, input_methods.jl:28-34, 65-76, 104-107, 143-153
       value = run_input<F>(S, run, 0.0, S.yy, S.yp);
       if (mode == PLH_MODE_I) Iguess = value;
@@ -778,6 +817,10 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       else if (mode == PLH_MODE_RES) Iguess = have_prev ? prev_I : 1.0;                                  // input_methods.jl:171-176 (res_I_guess = nothing)
       else if (have_prev) Iguess = prev_I;
       else { const double OCV = cellV<M>(S.yy); Iguess = value > OCV ? 1.0 : -1.0; }
+    } else
+    if (dstate) {                                                       // run_residual: custom_res! (:hold -> 0), initial_current! (input_methods.jl:171-176)
+      if (run.value_kind == PLH_VAL_HOLD) { value = 0.0; if (lane == 0 && wave_id() == 0) S.runc.value = 0.0; }
+      Iguess = have_prev ? prev_I : 1.0;
     } else
     if (mode == PLH_MODE_I) {
       if (run.value_kind == PLH_VAL_HOLD) value = have_prev ? prev_I : 0.0;
@@ -803,7 +846,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     if (lane == 0 && wave_id() == 0) S.yy[O_I] = Iguess;
     PL_XSYNC();
     GenRow grow;                                                        // closure of the state with derivative programs: general control row (dfn_cell.h)
-    if constexpr ((F & GF_GENROW) != 0) { if (run.value_kind == PLH_VAL_EXPR && run.n_dcol > 0 && genW) { grow.run = &run; grow.W = genW; } }
+    if constexpr ((F & GF_GENROW) != 0) { if (((run.value_kind == PLH_VAL_EXPR && run.n_dcol > 0) || dstate) && genW) { grow.run = &run; grow.W = genW; } }
     int flag = PLH_FLAG_RUNNING;
     plh_run_info ri; ri.flag = PLH_FLAG_RUNNING; ri.iterations = 0; ri.t_end = t_global; ri.V = 0; ri.I = 0; ri.SOC = SOC; ri.T_avg = T0;
     // tstops = {tdiscon - reltol/2} U {1.0 if continuation} U {tf}   (postfix_integrator!, model_evaluation.jl:288-310)
@@ -815,7 +858,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     do {                                                                // (re)initialise -> integrate ; loops only for check_reinitialization!
     again = false;
     int ierr; { PL_TIC(); ierr = cell_init_consistent<F>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt, S.phi[0], o.refine,
-                                                                       ((F & GF_EXPR) && run.value_kind == PLH_VAL_EXPR) ? &run : nullptr, t_restart, &grow); PL_TOC(S, PH_INIT); }
+                                                                       ((F & GF_EXPR) && (run.value_kind == PLH_VAL_EXPR || dstate)) ? &run : nullptr, t_restart, &grow); PL_TOC(S, PH_INIT); }
     if (ierr != 0) { if (first_init) init_failed = true; else flag = ierr; ri.flag = ierr; break; }
     if constexpr ((F & GF_STOPS) != 0) { if (o.yp_alg_zero) { PL_VEC(n) if (n >= NDIFF) S.yp[n] = 0.0; PL_XSYNC(); } }     // plh_opts.yp_alg_zero
     ida_reinit(S, I, S.yy, S.yp, first_init ? (o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD) : I.maxord, t_restart);
@@ -835,7 +878,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       // two waves per cell: both evaluate the stop checks, SOC and I_prev_pt from S.yy redundantly; the wave that is ahead must not start overwriting S.yy (predictor of
       // the next step) while the other still reads the accepted point -- with a varying current its SOC, hence its stop flag, would differ
       if constexpr (M::W2) __syncthreads();
-      const int sf = ida_step<F>(S, R, tb, I, tstop_now, tret, mode, value, o, cnt, is_tab ? &run : nullptr, &grow);
+      const int sf = ida_step<F>(S, R, tb, I, tstop_now, tret, mode, value, o, cnt, (is_tab || dstate) ? &run : nullptr, &grow);
       if (sf != 0) {
         if (I.nst == 0 && !stalled_once) {                              // check_solve, checks.jl:227-237
           stalled_once = true;
@@ -858,7 +901,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       PL_TOCE(S, 3, 4);
       check_stop(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
       PL_TOCE(S, 3, 5);
-      if (!is_tab && t == tprev) { flag = PLH_ERR_STALL; break; }      // (run_function has no stall test, checks.jl:251-269)
+      if (!is_fun && t == tprev) { flag = PLH_ERR_STALL; break; }      // (run_function has no stall test, checks.jl:251-269; run_residual -- res, dT, d<state> -- has: checks.jl:226)
       if (iter == o.maxiters) { flag = PLH_ERR_MAXITERS; break; }
       if (nout >= out.max_pts && out.max_pts > 0 && flag == PLH_FLAG_RUNNING) { flag = PLH_ERR_OUTPUT_FULL; break; }
       if (flag == PLH_FLAG_RUNNING) {
@@ -866,7 +909,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
         PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }      // fire-and-forget: read back only when a bound fires
 #endif
         t_prev_saved = t + t0; I_prev_pt = S.yy[O_I];
-        if constexpr ((F & GF_FUNC) != 0) if (is_tab && t - tprev < 1e-3 * o.reltol) {                    // check_reinitialization!, checks.jl:341-364
+        if constexpr ((F & GF_FUNC) != 0) if (is_fun && t - tprev < 1e-3 * o.reltol) {                    // check_reinitialization!, checks.jl:341-364
           const double t_new = t + o.reltol, v_new = run_input<F>(S, run, t_new, S.yy, S.yp);
           const double big = fabs(value) > fabs(v_new) ? fabs(value) : fabs(v_new);
           const double tolv = o.abstol > o.reltol * big ? o.abstol : o.reltol * big;

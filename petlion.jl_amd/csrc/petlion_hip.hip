@@ -467,8 +467,8 @@ int plh_abi_layout(int* out, int cap) {
   PL_F(plh_model_desc, thermodynamic_factor) PL_F(plh_model_desc, rxn) PL_F(plh_model_desc, waves_per_cell)
   PL_S(plh_bounds, 11) PL_F(plh_bounds, V_max) PL_F(plh_bounds, V_min) PL_F(plh_bounds, SOC_max) PL_F(plh_bounds, SOC_min) PL_F(plh_bounds, T_max) PL_F(plh_bounds, c_s_n_max)
   PL_F(plh_bounds, I_max) PL_F(plh_bounds, I_min) PL_F(plh_bounds, eta_plating_min) PL_F(plh_bounds, c_e_min) PL_F(plh_bounds, dfilm_max)
-  PL_S(plh_run, 13) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, tab_t)
-  PL_F(plh_run, tab_v) PL_F(plh_run, value_cell) PL_F(plh_run, tf_cell) PL_F(plh_run, n_dcol) PL_F(plh_run, dcol) PL_F(plh_run, dofs)
+  PL_S(plh_run, 14) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, tab_t)
+  PL_F(plh_run, tab_v) PL_F(plh_run, value_cell) PL_F(plh_run, tf_cell) PL_F(plh_run, n_dcol) PL_F(plh_run, dcol) PL_F(plh_run, dofs) PL_F(plh_run, dstate)
   PL_S(plh_opts, 16) PL_F(plh_opts, abstol) PL_F(plh_opts, reltol) PL_F(plh_opts, abstol_init) PL_F(plh_opts, reltol_init) PL_F(plh_opts, maxiters) PL_F(plh_opts, check_bounds)
   PL_F(plh_opts, interp_final) PL_F(plh_opts, max_order) PL_F(plh_opts, jac_every_step) PL_F(plh_opts, init_step) PL_F(plh_opts, n_tdiscon) PL_F(plh_opts, tdiscon) PL_F(plh_opts, refine)
   PL_F(plh_opts, n_tstops) PL_F(plh_opts, tstops) PL_F(plh_opts, yp_alg_zero)
@@ -576,6 +576,10 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
     if (runs[r].mode == PLH_MODE_RES) {                          // user-defined control residual: a closure of Y with its derivative programs
       if (runs[r].value_kind != PLH_VAL_EXPR || runs[r].n_dcol < 1)
         return fail(PLH_E_UNSUPPORTED, "PLH_MODE_RES needs a PLH_VAL_EXPR closure of the state with derivative programs (n_dcol >= 1; closures of YP are not supported)");
+    } else if (runs[r].mode == PLH_MODE_DSTATE) {                // rate of one differential state held (dc_s_* / dc_e_*): continues a solution
+      if (runs[r].dstate < PLH_DSTATE_CS_P_MAX || runs[r].dstate > PLH_DSTATE_CE_MIN) return fail(PLH_E_ARG, "PLH_MODE_DSTATE: plh_run.dstate must be a PLH_DSTATE_* constant");
+      if (runs[r].value_kind != PLH_VAL_CONST && runs[r].value_kind != PLH_VAL_HOLD) return fail(PLH_E_ARG, "PLH_MODE_DSTATE takes a constant value or :hold");
+      if (r == 0 && !Y_init) return fail(PLH_E_ARG, "PLH_MODE_DSTATE chooses its state from the end of the previous run: it cannot be the first run of a new solution");
     } else CHECK_MODE(runs[r].mode);
     if (runs[r].value_kind < 0 || runs[r].value_kind > PLH_VAL_EXPR) return fail(PLH_E_ARG, "bad value_kind");
     if (runs[r].value_kind == PLH_VAL_EXPR) {                     // closure input as a postfix program: check it here, the device interpreter trusts it
@@ -634,7 +638,7 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
     cx.scratch_cells = n;
   }
   bool need_genW = false;
-  for (int r = 0; r < n_runs; r++) need_genW = need_genW || (runs[r].value_kind == PLH_VAL_EXPR && runs[r].n_dcol > 0);
+  for (int r = 0; r < n_runs; r++) need_genW = need_genW || (runs[r].value_kind == PLH_VAL_EXPR && runs[r].n_dcol > 0) || runs[r].mode == PLH_MODE_DSTATE;
   if (need_genW && cx.genW_cells < (size_t)n) {
     if (cx.genW) { HIPCHK(hipStreamSynchronize(cx.st)); hipFree(cx.genW); cx.genW = nullptr; cx.genW_cells = 0; }
     HIPCHK(hipMalloc((void**)&cx.genW, (size_t)n * m->N * sizeof(double)));
@@ -703,7 +707,7 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   int features = 0;
   if (opts->n_tdiscon > 0 || opts->n_tstops > 0 || out->Y_all || opts->yp_alg_zero != 0) features |= 1;
   for (int r = 0; r < n_runs; r++) { if (runs[r].value_kind == PLH_VAL_TABLE) features |= 1 | 2; if (runs[r].value_kind == PLH_VAL_EXPR) features |= 1 | 2 | 4; }
-  if (need_genW) features |= 16;                                     // closures with derivative programs: the general control row
+  if (need_genW) features |= 1 | 2 | 4 | 16;                                     // closures with derivative programs: the general control row
   if (opts->refine > 0) features |= 1 | 2 | 4 | 8;
   m->ops->integrate(s.st, a, features);
   hipEventRecord(cx.ev1, s.st);

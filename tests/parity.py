@@ -165,7 +165,7 @@ def runs_to_oracle(O, p, pkg, protocol, cell=None, n_cells=None):
     for r in runs:
         b = O.Bounds(**{f: getattr(r.bounds, f) for f in O.BOUND_FIELDS})
         d = dict(mode=r.mode, value_kind=r.value_kind, value=r.value_cell[cell] if r.value_cell else r.value,
-                 tf=r.tf_cell[cell] if r.tf_cell else r.tf, bounds=b)
+                 tf=r.tf_cell[cell] if r.tf_cell else r.tf, bounds=b, dstate=r.dstate)
         if r.value_kind == 3:       # PLH_VAL_TABLE
             d["table"] = (np.array(r._keep[0]), np.array(r._keep[1]))
         if r.value_kind == 4:       # PLH_VAL_EXPR

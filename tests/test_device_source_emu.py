@@ -428,6 +428,53 @@ def test_res_mode(emu_model, emu_model_thermal, O, pkg):
     check_res_mode(emu_model, emu_model_thermal, O, pkg)
 
 
+def check_dstate_modes(models, O, pkg):
+    """the rate of ONE differential state held: dc_s_p_max / dc_s_p_min / dc_s_n_max / dc_s_n_min / dc_e_max / dc_e_min (reference input_methods.jl:190-247: state_deriv_func(ind)
+    as a run_residual, ind = the extreme surface / electrolyte concentration at the end of the previous run; consistent initialisation with YP[ind] replaced by the differential
+    equation, scalar_residual.jl:335-362).  "Constant surface concentration" charging after a CC leg, on the isothermal, thermal, SEI and quadratic-diffusion models: the oracle's
+    decisions; the chosen state really is held; refusals."""
+    for p, soc, proto in models:
+        th = p.theta_vector()
+        ens = pkg.simulate_ensemble(p, th[None, :], proto, SOC=soc, outputs="all")
+        runs = parity.runs_to_oracle(O, p, pkg, proto)
+        assert runs[-1]["mode"] == 6 and runs[-1]["dstate"] >= 1
+        ro = O.simulate(p.variant, th, soc, runs, keep_Y=True)
+        assert ens.run_info[0, -1]["flag"] == ro["runs"][-1]["flag"] >= 0, (p.variant, ens.run_info[0], ro["runs"])
+        parity.compare_trajectory(ens, 0, ro, rtol_state=5e-6, same_decisions=True)
+        # the held state: its value moves at the requested rate over the last run (every saved point of it)
+        name = [k for k in proto[-1] if k.startswith("dc_")][0]
+        rate = 0.0 if proto[-1][name] == "hold" else float(proto[-1][name])
+        n = int(ens.n_pts[0]); k = int(ens.run_info[0, -1]["iterations"])
+        Yr, tr = ens.Y_all[0, n - k:n], ens.t[0, n - k:n]
+        sec = p.ind["c_e"] if "c_e" in name else p.ind["c_s_avg"]
+        cand = np.arange(sec.start, sec.stop)
+        if "c_s" in name:
+            nr = (sec.stop - sec.start) // (p.N.p + p.N.n)
+            surf = cand[nr - 1::nr]
+            cand = surf[:p.N.p] if "_p_" in name else surf[p.N.p:]
+        ind = cand[np.argmax(Yr[0, cand])] if name.endswith("max") else cand[np.argmin(Yr[0, cand])]
+        drift = Yr[:, ind] - (Yr[0, ind] + rate * (tr - tr[0]))
+        assert np.abs(drift).max() <= 2e-3 * max(1.0, abs(rate) * (tr[-1] - tr[0])) + 1e-6 * abs(Yr[0, ind]), (p.variant, name, np.abs(drift).max())
+    p = models[0][0]
+    with pytest.raises(RuntimeError, match="first run"):
+        pkg.simulate_ensemble(p, p.theta_vector()[None, :], [{"dc_s_n_max": 0.0, "tf": 10.0}], SOC=0.5)
+    with pytest.raises(ValueError):
+        pkg.make_protocol(p, [{"I": 1.0, "tf": 10.0}, {"dc_e_min": lambda t: 0.0}])
+
+
+def dstate_cases(p, p_th, p_sei, p_quad):
+    return [(p, 0.2, [{"I": 2.0, "tf": 300.0}, {"dc_s_n_max": 0.0, "tf": 300.0}]),
+            (p, 1.0, [{"I": -1.0, "tf": 600.0}, {"dc_e_max": "hold", "tf": 200.0}]),
+            (p, 0.2, [{"I": 2.0, "tf": 200.0}, {"dc_s_p_min": -0.5, "tf": 100.0}]),
+            (p_th, 0.2, [{"I": 3.0, "tf": 150.0}, {"dc_s_n_max": "hold", "tf": 200.0}]),
+            (p_sei, 0.1, [{"I": 1.0, "tf": 300.0}, {"dc_e_min": 0.0, "tf": 200.0}]),
+            (p_quad, 1.0, [{"I": -1.0, "tf": 300.0}, {"dc_s_p_max": 0.5, "tf": 100.0}, {"dc_s_n_min": "hold", "tf": 100.0}])]
+
+
+def test_dstate_modes(emu_model, emu_model_thermal, emu_model_sei, emu_models_f4, O, pkg):
+    check_dstate_modes(dstate_cases(emu_model, emu_model_thermal, emu_model_sei, emu_models_f4["quad"]), O, pkg)
+
+
 def test_function_inputs(emu_model, O, pkg):
     check_function_inputs(emu_model, O, pkg)
 

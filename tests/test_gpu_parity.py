@@ -305,13 +305,14 @@ def test_every_stop_condition(hip_model, hip_model_sei, O, pkg):
     te.check_stop_conditions(hip_model_sei, O, pkg)
 
 
-def test_closure_derivatives_on_gpu(hip_model_thermal, hip_model_sei, O, pkg):
+def test_closure_derivatives_on_gpu(hip_model_thermal, hip_model_sei, hip_models_f4, O, pkg):
     """closures of the state: their symbolic derivatives in the control row of the Newton matrix (reference scalar_residual.jl:276-416; plh_run.dcol / dofs, GenRow in
     csrc/dfn_cell.h) with the thermal and SEI models, and through the two-waves-per-cell kernel (the LCO isothermal cases run in
     test_function_inputs_and_drive_cycle_ensemble); then a 256-cell ensemble whose closure reads a per-cell parameter: same flags and end states as cell-by-cell runs"""
     import test_device_source_emu as te
     te.check_closure_derivatives_other_models(hip_model_thermal, hip_model_sei, O, pkg)
     te.check_res_mode(pkg.petlion(pkg.LCO), hip_model_thermal, O, pkg)            # the user-defined control residual (`res = (x, f)`), a closure row with no method part
+    te.check_dstate_modes(te.dstate_cases(pkg.petlion(pkg.LCO), hip_model_thermal, hip_model_sei, hip_models_f4["quad"]), O, pkg)     # dc_s_* / dc_e_*: the rate of one differential state held
     p2 = pkg.petlion(pkg.LCO, waves_per_cell=2)
     te.check_closure_inputs(p2, O, pkg)
     p = pkg.petlion(pkg.LCO)
