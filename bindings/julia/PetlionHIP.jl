@@ -34,8 +34,9 @@ struct Run
     mode::Cint; value_kind::Cint; value::Cdouble; tf::Cdouble; bounds::Bounds
     n_tab::Cint; tab_t::Ptr{Cdouble}; tab_v::Ptr{Cdouble}     # VAL_TABLE: piecewise-linear input in run-local time (host arrays)
     value_cell::Ptr{Cdouble}; tf_cell::Ptr{Cdouble}           # per-cell input value / run length ([n_cells] host arrays) or C_NULL
-    n_dcol::Cint; dcol::Ptr{Cint}; dofs::Ptr{Cint}            # VAL_EXPR of the state: derivative programs d f / d Y[dcol[k]] = instructions dofs[k]:dofs[k+1] of tab_t / tab_v (0 = none)
+    n_dcol::Cint                                              # VAL_EXPR of the state: number of derivative programs (0 = none)
     dstate::Cint                                              # MODE_DSTATE: which differential state's rate is held (PLH_DSTATE_*), 0 otherwise
+    dcol::Ptr{Cint}; dofs::Ptr{Cint}                          # d f / d Y[dcol[k]] = instructions dofs[k]:dofs[k+1] of tab_t / tab_v
 end
 struct Opts
     abstol::Cdouble; reltol::Cdouble; abstol_init::Cdouble; reltol_init::Cdouble
@@ -119,16 +120,16 @@ function make_run(p, step::NamedTuple)
     b = bounds_of(p.bounds; kw...)
     tf = Float64(get(step, :tf, 1e6))
     if x isa Tuple{Vector{Float64},Vector{Float64}}      # (t, values): a tabulated I(t) / V(t) / P(t); the caller keeps the two vectors alive (GC.@preserve)
-        return Run(MODE[name], VAL_TABLE, x[2][1], tf, b, length(x[1]), pointer(x[1]), pointer(x[2]), C_NULL, C_NULL, 0, C_NULL, C_NULL, 0)
+        return Run(MODE[name], VAL_TABLE, x[2][1], tf, b, length(x[1]), pointer(x[1]), pointer(x[2]), C_NULL, C_NULL, 0, 0, C_NULL, C_NULL)
     end
     if x isa Function                                    # a closure input: its expression as a postfix program (closure_program below)
         ops, args = closure_program(x, p)
         push!(KEEPALIVE, (ops, args))                    # (the program arrays must outlive the call; emptied by simulate_ensemble when it returns)
-        return Run(MODE[name], VAL_EXPR, 0.0, tf, b, length(ops), pointer(ops), pointer(args), C_NULL, C_NULL, 0, C_NULL, C_NULL, 0)   # n_dcol = 0: the derivative programs (Symbolics.derivative of the same expression per state column, as PETLION's differentiate_residual_func builds them) are produced by the Python mirror only so far
+        return Run(MODE[name], VAL_EXPR, 0.0, tf, b, length(ops), pointer(ops), pointer(args), C_NULL, C_NULL, 0, 0, C_NULL, C_NULL)   # n_dcol = 0: the derivative programs (Symbolics.derivative of the same expression per state column, as PETLION's differentiate_residual_func builds them) are produced by the Python mirror only so far
     end
-    x isa Vector{Float64} && return Run(MODE[name], VAL_CONST, x[1], tf, b, 0, C_NULL, C_NULL, pointer(x), C_NULL, 0, C_NULL, C_NULL, 0)   # one value per cell (caller keeps x alive)
+    x isa Vector{Float64} && return Run(MODE[name], VAL_CONST, x[1], tf, b, 0, C_NULL, C_NULL, pointer(x), C_NULL, 0, 0, C_NULL, C_NULL)   # one value per cell (caller keeps x alive)
     kind, val = x === :hold ? (VAL_HOLD, 0.0) : x === :rest ? (VAL_REST, 0.0) : (VAL_CONST, Float64(x))
-    Run(MODE[name], kind, val, tf, b, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL, C_NULL, 0)
+    Run(MODE[name], kind, val, tf, b, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, 0, C_NULL, C_NULL)
 end
 
 # Input closures `I = (t, Y, YP, p) -> ...` (input_methods.jl:159-176): PETLION itself traces them with Symbolics to differentiate the control row

@@ -172,8 +172,9 @@ typedef struct {
   const double* value_cell; const double* tf_cell;
   /* PLH_VAL_EXPR of the state: derivative programs of the control row (see PLH_VAL_EXPR above); HOST arrays, dcol[n_dcol] 0-based state columns in ascending order,
      dofs[n_dcol + 1] instruction offsets into tab_t / tab_v.  n_dcol = 0: no differentiation. */
-  int n_dcol; const int* dcol; const int* dofs;
+  int n_dcol;
   int dstate;      /* PLH_MODE_DSTATE: PLH_DSTATE_* ; 0 otherwise */
+  const int* dcol; const int* dofs;
 } plh_run;
 
 /* reference options_simulation (src/structures.jl:266-285), the numerical subset */

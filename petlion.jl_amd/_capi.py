@@ -40,7 +40,7 @@ class Run(C.Structure):
     _fields_ = [("mode", C.c_int), ("value_kind", C.c_int), ("value", C.c_double), ("tf", C.c_double), ("bounds", Bounds),
                 ("n_tab", C.c_int), ("tab_t", C.POINTER(C.c_double)), ("tab_v", C.POINTER(C.c_double)),
                 ("value_cell", C.POINTER(C.c_double)), ("tf_cell", C.POINTER(C.c_double)),
-                ("n_dcol", C.c_int), ("dcol", C.POINTER(C.c_int)), ("dofs", C.POINTER(C.c_int)), ("dstate", C.c_int)]
+                ("n_dcol", C.c_int), ("dstate", C.c_int), ("dcol", C.POINTER(C.c_int)), ("dofs", C.POINTER(C.c_int))]
 
 
 class Opts(C.Structure):

@@ -468,7 +468,7 @@ int plh_abi_layout(int* out, int cap) {
   PL_S(plh_bounds, 11) PL_F(plh_bounds, V_max) PL_F(plh_bounds, V_min) PL_F(plh_bounds, SOC_max) PL_F(plh_bounds, SOC_min) PL_F(plh_bounds, T_max) PL_F(plh_bounds, c_s_n_max)
   PL_F(plh_bounds, I_max) PL_F(plh_bounds, I_min) PL_F(plh_bounds, eta_plating_min) PL_F(plh_bounds, c_e_min) PL_F(plh_bounds, dfilm_max)
   PL_S(plh_run, 14) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, tab_t)
-  PL_F(plh_run, tab_v) PL_F(plh_run, value_cell) PL_F(plh_run, tf_cell) PL_F(plh_run, n_dcol) PL_F(plh_run, dcol) PL_F(plh_run, dofs) PL_F(plh_run, dstate)
+  PL_F(plh_run, tab_v) PL_F(plh_run, value_cell) PL_F(plh_run, tf_cell) PL_F(plh_run, n_dcol) PL_F(plh_run, dstate) PL_F(plh_run, dcol) PL_F(plh_run, dofs)
   PL_S(plh_opts, 16) PL_F(plh_opts, abstol) PL_F(plh_opts, reltol) PL_F(plh_opts, abstol_init) PL_F(plh_opts, reltol_init) PL_F(plh_opts, maxiters) PL_F(plh_opts, check_bounds)
   PL_F(plh_opts, interp_final) PL_F(plh_opts, max_order) PL_F(plh_opts, jac_every_step) PL_F(plh_opts, init_step) PL_F(plh_opts, n_tdiscon) PL_F(plh_opts, tdiscon) PL_F(plh_opts, refine)
   PL_F(plh_opts, n_tstops) PL_F(plh_opts, tstops) PL_F(plh_opts, yp_alg_zero)
