@@ -680,3 +680,39 @@ def test_lgm50_with_temperature_on_gpu(hip_model_lgm50_thermal, O, pkg):
     assert np.abs(ens.run_info["SOC"][:, 0] - (1.0 - tend / 3600.0)).max() < 1e-9
     print("lgm50_thermal: 1024-cell sweep kernel %.2f ms (%.0f trajectories/s), flags %s, T_avg at the end %.1f .. %.1f K" % (ens.kernel_ms, n / ens.kernel_ms * 1e3, dict(zip(*np.unique(fl, return_counts=True))),
           ens.run_info["T_avg"][:, 0].min(), ens.run_info["T_avg"][:, 0].max()))
+
+
+ALL_VARIANTS = [("LCO", {}), ("NMC", {}), ("LCO", dict(aging="SEI")), ("NMC", dict(aging="SEI")), ("LCO", dict(temperature=True)),
+                ("LCO", dict(precision="mixed")), ("NMC", dict(aging="SEI", precision="mixed")), ("LCO", dict(temperature=True, precision="mixed")),
+                ("LCO", dict(solid_diffusion="quadratic")), ("LCO", dict(solid_diffusion="polynomial")), ("LCO", dict(thermodynamic_factor="nonlinear")),
+                ("LCO", dict(rxn_p="MHC", rxn_n="MHC")), ("NMC_LGM50", dict(temperature=False)), ("LCO", dict(waves_per_cell=2)), ("NMC_LGM50", {})]
+
+
+def test_every_kernel_instantiation_of_every_variant(hip_model, pkg):
+    """every k_integrate<variant, F> of the library, F = plain / stops / tables / closures / general control row / refine (csrc/dfn_integrate.h GenFlag), runs the SAME 300 s 1C
+    discharge of 32 jittered cells -- as a constant, with a stop time beyond the run, as a table, as a closure of t, as a closure with a 1e-12 C/V dependence on the cell voltage, and
+    with one refinement step -- and must reproduce the plain kernel: flags and end times equal, SOC (exact for a constant current) to 1e-12, voltage to 1e-9 where the arithmetic is
+    the same (stops, table, closure: the input is the same number) and to the integration tolerance where it is not.  The guard DESIGN.md 5a asks for: a build whose register
+    allocation goes wrong in ONE instantiation (seen once: a garbage SOC accumulator in <LCO, tables>) fails here whatever the model."""
+    cl = pkg.closures
+    assert len(ALL_VARIANTS) == 15
+    n = 32
+    for chem, kw in ALL_VARIANTS:
+        p = pkg.petlion(getattr(pkg, chem), **kw)
+        Th = pkg.configs.sweep_theta(p, np.arange(n), 4) if chem == "LCO" and not kw.get("temperature") and "aging" not in kw else np.tile(p.theta_vector(), (n, 1))
+        ps = p.ind["Φ_s"]
+        base = pkg.simulate_ensemble(p, Th, [{"I": -1.0, "tf": 300.0}], SOC=1.0)
+        assert (base.run_info["flag"][:, 0] == 0).all() and np.abs(base.run_info["SOC"][:, 0] - (1.0 - 300.0 / 3600.0)).max() < 1e-12, (p.variant, base.run_info[0])
+        o_stop, o_ref = pkg.Opts(), pkg.Opts()
+        o_stop.tstops = [1e7]; o_ref.refine = 1
+        cases = [("stops", [{"I": -1.0, "tf": 300.0}], o_stop, 1e-12),
+                 ("table", [{"I": ([0.0, 1e7], [-1.0, -1.0]), "tf": 300.0}], None, 1e-9),
+                 ("closure", [{"I": lambda t: -1.0 + 0.0 * t, "tf": 300.0}], None, 1e-9),
+                 ("general row", [{"I": lambda t, Y, q: -1.0 + 1e-12 * (Y[ps.start] - Y[ps.stop - 1]), "tf": 300.0}], None, 2e-3),
+                 ("refine", [{"I": -1.0, "tf": 300.0}], o_ref, 2e-3)]
+        for name, proto, o, vtol in cases:
+            e = pkg.simulate_ensemble(p, Th, proto, SOC=1.0, opts=o)
+            assert np.array_equal(e.run_info["flag"], base.run_info["flag"]) and np.abs(e.run_info["t_end"] - base.run_info["t_end"]).max() == 0.0, (p.variant, name, e.run_info[0], base.run_info[0])
+            assert np.abs(e.run_info["SOC"] - base.run_info["SOC"]).max() < 1e-11 and np.abs(e.run_info["V"] - base.run_info["V"]).max() <= vtol, \
+                (p.variant, name, np.abs(e.run_info["SOC"] - base.run_info["SOC"]).max(), np.abs(e.run_info["V"] - base.run_info["V"]).max())
+            assert np.abs(e.SOC[:, 0] - 1.0).max() == 0.0, (p.variant, name)                  # (the first saved point: the accumulator starts from SOC0)
