@@ -90,10 +90,11 @@ extern "C" {
    every residual evaluation of the run (also during the consistent initialisation), like run.func in scalar_residual!.
    Derivatives (plh_run.n_dcol / dcol / dofs): the reference differentiates a closure of the state symbolically and puts the row d(method - f)/dY into the Newton matrix
    (differentiate_residual_func, scalar_residual.jl:276-416).  The caller does the same differentiation (it holds the expression) and passes, for each state column dcol[k]
-   the closure reads, a program for d f / d Y[dcol[k]]: instructions [dofs[k], dofs[k+1]) of the SAME tab_t / tab_v arrays (dofs[0] >= n_tab).  The device evaluates them at
-   every Jacobian refresh and solves with the general control row (one extra structured solve per factorisation, two dot products per solve).  n_dcol = 0 is the reference's
-   own fallback for closures it cannot differentiate (scalar_residual.jl:248-274, _get_method_funcs_no_differentiation): same converged states, other Newton steps -- it is
-   what a closure that reads YP gets here (the reference substitutes the differential equations for YP in its consistent-initialisation row, :335-362; not built). */
+   the closure reads, a program for d f / d Y[dcol[k]]: instructions [dofs[k], dofs[k+1]) of the SAME tab_t / tab_v arrays (dofs[0] >= n_tab).  A column dcol[k] = N + i
+   (N = n_states, i a DIFFERENTIAL state) is d f / d YP[i]: it enters the integration row times cj, and the consistent-initialisation row through the differential equation of
+   state i (YP[i] -> rhs_i(Y), as the reference substitutes there, scalar_residual.jl:335-362; the closure itself is then evaluated with YP = rhs(Y)).  The device evaluates the
+   programs at every Jacobian refresh and solves with the general control row (one extra structured solve per factorisation, two dot products per solve).  n_dcol = 0 is the
+   reference's own fallback for closures it cannot differentiate (scalar_residual.jl:248-274, _get_method_funcs_no_differentiation): same converged states, other Newton steps. */
 #define PLH_OP_CONST 0
 #define PLH_OP_T 1
 #define PLH_OP_Y 2
@@ -170,8 +171,8 @@ typedef struct {
   /* ensemble axis of the protocol itself: per-cell input value (PLH_VAL_CONST only, e.g. a C-rate sweep) and per-cell run length, [n_cells] HOST
      arrays staged by plh_integrate; NULL = every cell uses `value` / `tf`.  (New: the reference runs one cell per simulate() call.) */
   const double* value_cell; const double* tf_cell;
-  /* PLH_VAL_EXPR of the state: derivative programs of the control row (see PLH_VAL_EXPR above); HOST arrays, dcol[n_dcol] 0-based state columns in ascending order,
-     dofs[n_dcol + 1] instruction offsets into tab_t / tab_v.  n_dcol = 0: no differentiation. */
+  /* PLH_VAL_EXPR of the state: derivative programs of the control row (see PLH_VAL_EXPR above); HOST arrays, dcol[n_dcol] 0-based columns in ascending order (Y columns, then
+     N + i for YP of differential states), dofs[n_dcol + 1] instruction offsets into tab_t / tab_v.  n_dcol = 0: no differentiation. */
   int n_dcol;
   int dstate;      /* PLH_MODE_DSTATE: PLH_DSTATE_* ; 0 otherwise */
   const int* dcol; const int* dofs;

@@ -434,6 +434,9 @@ typedef struct {
   int dind;                /* ORC_MODE_DSTATE: the state whose derivative is held (-1 otherwise); its twin row takes the algebraic entries of row dind of the base Jacobian */
   int n_tw; int tw_src[64]; /* positions of those entries in the base CSC values (the control-row entries actrl_pos[0..n_tw) of the algebraic block) */
   double* tmp_diff;        /* N_diff work vector (f_diff for the twin) */
+  /* closure columns dcol[k] = N + i: d f / d YP[i] of a differential state i.  Integration row: times cj at column i.  Algebraic block (consistent initialisation): the closure is
+     evaluated with YP -> rhs(Y) and the column chains through row i of dF/dY (scalar_residual.jl:335-362): records (program k, source position in the base CSC values, control entry) */
+  int has_yp, n_yp; int yp_k[512], yp_src[512], yp_dst[512]; double* yp_sub;
   double *tmp_nz, *w;
   double *ax_f, *aax_f, *rtmp, *xtmp;   /* the matrices as last factored (iterative refinement), work vectors */
   double I1C;
@@ -533,7 +536,21 @@ static int evalb_init_x(evalb* e, const orc_model* m, const double* th, int mode
   if (drun && mode != ORC_MODE_DSTATE) {
     if (drun->n_dcol > 64 || mode == ORC_MODE_DT) return -1;
     for (int k = 0; k < drun->n_dcol; k++) {
-      const int c = drun->dcol[k]; int q;
+      int c = drun->dcol[k]; int q;
+      if (c >= N) {                       /* d f / d YP[i] */
+        const int i = c - N;
+        if (i >= Nd) return -1;
+        e->has_yp = 1;
+        for (q = 0; q < e->n_ctrl; q++) if (e->ctrl_col[q] == i) break;
+        if (q == e->n_ctrl) e->ctrl_col[e->n_ctrl++] = i;
+        e->dpos[k] = q; e->adpos[k] = -1;
+        for (int c2 = Nd; c2 < N; c2++) for (int src = m->colptr[c2]; src < m->colptr[c2 + 1]; src++) if (m->rowval[src] == i && e->n_yp < 512) {
+          int d; for (d = 0; d < e->an_ctrl; d++) if (e->actrl_col[d] == c2) break;
+          if (d == e->an_ctrl) e->actrl_col[e->an_ctrl++] = c2;
+          e->yp_k[e->n_yp] = k; e->yp_src[e->n_yp] = src; e->yp_dst[e->n_yp] = d; e->n_yp++;
+        }
+        continue;
+      }
       for (q = 0; q < e->n_ctrl; q++) if (e->ctrl_col[q] == c) break;
       if (q == e->n_ctrl) e->ctrl_col[e->n_ctrl++] = c;
       e->dpos[k] = q; e->adpos[k] = -1;
@@ -544,6 +561,7 @@ static int evalb_init_x(evalb* e, const orc_model* m, const double* th, int mode
   build_pattern(Na, Na - 1, m->acolptr, m->arowval, Nd, e->an_ctrl, e->actrl_col, &e->acp, &e->ari, &e->annz, &e->abase_map, e->actrl_pos);
   e->ax = (double*)calloc(e->nnz, sizeof(double)); e->aax = (double*)calloc(e->annz, sizeof(double));
   e->tmp_nz = (double*)calloc(m->nnz + 64, sizeof(double)); e->w = (double*)calloc(N, sizeof(double)); e->tmp_diff = (double*)calloc(Nd > 0 ? Nd : 1, sizeof(double));
+  e->yp_sub = (double*)calloc(N, sizeof(double));
   e->ax_f = (double*)calloc(e->nnz, sizeof(double)); e->aax_f = (double*)calloc(e->annz, sizeof(double)); e->rtmp = (double*)calloc(N, sizeof(double)); e->xtmp = (double*)calloc(N, sizeof(double));
   if (m->thermal) m->dT_weights(e->w, th);
   e->I1C = calc_I1C_c(m, th);
@@ -554,18 +572,32 @@ static int evalb_init_d(evalb* e, const orc_model* m, const double* th, int mode
 static int evalb_init(evalb* e, const orc_model* m, const double* th, int mode, double value, orc_counters* cnt) { return evalb_init_d(e, m, th, mode, value, cnt, NULL); }
 /* minus the closure's derivative programs into the control row (J_scalar_func of differentiate_residual_func); alg: the columns of the algebraic block only
    (J_vec[N.diff+1:end], scalar_residual.jl:369-371) */
-static void ctrl_row_derivatives(const evalb* e, const double* Y, const double* YP, double* ax, const int* cpos, int n_base, int n_ctrl, int alg) {
+static void ctrl_row_derivatives(const evalb* e, const double* Y, const double* YP, double cj, double* ax, const int* cpos, int n_base, int n_ctrl, int alg) {
   const orc_run* r = e->drun;
   if (!r) return;
+  const int N = e->m.N;
+  const double* YPe = YP;
+  if (alg && e->has_yp) {                  /* the closure with YP -> rhs(Y); row i of dF/dY at cj = 0 for the chain rule */
+    e->m.f_diff(e->tmp_diff, Y, YP, e->th);
+    for (int i = 0; i < N; i++) e->yp_sub[i] = i < e->m.Nd ? e->tmp_diff[i] + YP[i] : YP[i];
+    YPe = e->yp_sub;
+    e->m.jac(e->tmp_nz, Y, YP, 0.0, e->th);
+  }
   for (int q = n_base; q < n_ctrl; q++) ax[cpos[q]] = 0.0;
   for (int k = 0; k < r->n_dcol; k++) {
+    const double a = expr_eval_range(r, e->t_fun, Y, YPe, e->th, r->dofs[k], r->dofs[k + 1]);
+    if (r->dcol[k] >= N) {
+      if (!alg) ax[cpos[e->dpos[k]]] -= cj * a;
+      else for (int w = 0; w < e->n_yp; w++) if (e->yp_k[w] == k) ax[cpos[e->yp_dst[w]]] -= a * e->tmp_nz[e->yp_src[w]];
+      continue;
+    }
     const int q = alg ? e->adpos[k] : e->dpos[k];
-    if (q >= 0) ax[cpos[q]] -= expr_eval_range(r, e->t_fun, Y, YP, e->th, r->dofs[k], r->dofs[k + 1]);
+    if (q >= 0) ax[cpos[q]] -= a;
   }
 }
 static void evalb_free(evalb* e) {
   free(e->cp); free(e->ri); free(e->ax); free(e->base_map); free(e->acp); free(e->ari); free(e->aax); free(e->abase_map);
-  free(e->tmp_nz); free(e->w); free(e->tmp_diff); free(e->ax_f); free(e->aax_f); free(e->rtmp); free(e->xtmp); splu_free(&e->lu); splu_free(&e->alu);
+  free(e->tmp_nz); free(e->w); free(e->tmp_diff); free(e->yp_sub); free(e->ax_f); free(e->aax_f); free(e->rtmp); free(e->xtmp); splu_free(&e->lu); splu_free(&e->alu);
 }
 
 static double ctrl_residual(evalb* e, const double* Y, const double* YP) {
@@ -595,6 +627,11 @@ static void R_alg(evalb* e, double* res /*N_alg*/, const double* Y, const double
   m->f_alg(res, Y, YP, e->th);
   if (e->mode == ORC_MODE_DT) { double tw; m->dT_twin(&tw, Y, YP, e->th); res[Na - 1] = e->value + tw; }
   else if (e->mode == ORC_MODE_DSTATE) { m->f_diff(e->tmp_diff, Y, YP, e->th); res[Na - 1] = e->value - (e->tmp_diff[e->dind] + YP[e->dind]); }   /* YP[ind] -> rhs_ind(Y) = F_ind + YP[ind] */
+  else if (e->drun && e->has_yp) {          /* a closure of YP: YP -> rhs(Y) = F_diff(Y, YP) + YP in the consistent-initialisation row (scalar_residual.jl:335-362) */
+    m->f_diff(e->tmp_diff, Y, YP, e->th);
+    for (int i = 0; i < m->N; i++) e->yp_sub[i] = i < m->Nd ? e->tmp_diff[i] + YP[i] : YP[i];
+    res[Na - 1] = ctrl_residual(e, Y, e->yp_sub);
+  }
   else res[Na - 1] = ctrl_residual(e, Y, YP);
   if (e->cnt) e->cnt->n_res++;
 }
@@ -616,7 +653,7 @@ static void J_full(evalb* e, const double* Y, const double* YP, double cj) {
   else if (e->mode == ORC_MODE_P || e->mode == ORC_MODE_ETAP) ctrl_row_P_etap(e, Y, e->ax, e->ctrl_pos);
   else if (e->mode == ORC_MODE_DT) for (int k = 0; k < e->n_ctrl; k++) e->ax[e->ctrl_pos[k]] = -cj * e->w[k];
   else if (e->mode == ORC_MODE_DSTATE) e->ax[e->ctrl_pos[0]] = -cj;
-  ctrl_row_derivatives(e, Y, YP, e->ax, e->ctrl_pos, e->n_base, e->n_ctrl, 0);
+  ctrl_row_derivatives(e, Y, YP, cj, e->ax, e->ctrl_pos, e->n_base, e->n_ctrl, 0);
   if (e->cnt) e->cnt->n_jac++;
 }
 static void J_alg(evalb* e, const double* Y, const double* YP) {
@@ -628,7 +665,7 @@ static void J_alg(evalb* e, const double* Y, const double* YP) {
   else if (e->mode == ORC_MODE_P || e->mode == ORC_MODE_ETAP) ctrl_row_P_etap(e, Y, e->aax, e->actrl_pos);
   else if (e->mode == ORC_MODE_DT) { m->dT_twin_jac(e->tmp_nz, Y, YP, 0.0, e->th); for (int k = 0; k < e->an_ctrl; k++) e->aax[e->actrl_pos[k]] = e->tmp_nz[k]; }
   else if (e->mode == ORC_MODE_DSTATE) { m->jac(e->tmp_nz, Y, YP, 0.0, e->th); for (int k = 0; k < e->n_tw; k++) e->aax[e->actrl_pos[k]] = -e->tmp_nz[e->tw_src[k]]; }
-  ctrl_row_derivatives(e, Y, YP, e->aax, e->actrl_pos, e->an_base, e->an_ctrl, 1);
+  ctrl_row_derivatives(e, Y, YP, 0.0, e->aax, e->actrl_pos, e->an_base, e->an_ctrl, 1);
   if (e->cnt) e->cnt->n_jac++;
 }
 

@@ -173,7 +173,7 @@ def _make_run(p, name, inp, tf, bounds):
         r.n_tab = ops.size
         # a closure of Y: the entries d f / d Y[c] of the control row, as the reference's symbolic differentiation builds them (scalar_residual.jl:276-416); the programs ride
         # behind the main one in the same arrays (plh_run.dcol / dofs)
-        der = closures.row_derivatives(tree)
+        der = closures.row_derivatives(tree, p.N.tot, p.N.diff)
         keep = []
         if der is not None:
             dcol = np.ascontiguousarray(der[0], dtype=np.int32)
@@ -186,8 +186,7 @@ def _make_run(p, name, inp, tf, bounds):
         r._keep = (ops, args, *keep)
         if name == "res":
             if der is None:
-                raise ValueError("res: the closure must read the state Y (and not YP: the reference substitutes the differential equations for YP in the "
-                                 "consistent-initialisation row, which this build does not do -- so no dc_s_* / dc_e_* modes either)")
+                raise ValueError("res: the closure must read the state (Y, or YP of differential states)")
             r.value = res_x
     elif isinstance(inp, (tuple, list)) and len(inp) == 2 and np.ndim(inp[0]) == 1:
         if name == "dT":

@@ -246,24 +246,28 @@ def _refs(x, kind, acc):
     return acc
 
 
-def row_derivatives(x):
-    """what the reference's differentiate_residual_func (scalar_residual.jl:276-416) builds for a closure of the state: the entries d f / d Y[c] of the control row, as
-    (columns, [program per column]) -- or None when the closure reads YP (its consistent-initialisation form substitutes the differential equations for YP; not built
-    here) or a derivative does not fit the device interpreter's stack: the run then uses the reference's no-differentiation fallback (scalar_residual.jl:248-274)."""
+def row_derivatives(x, n_tot=None, n_diff=None):
+    """what the reference's differentiate_residual_func (scalar_residual.jl:276-416) builds for a closure of the state: the entries of the control row, as
+    (columns, [program per column]).  Column c < n_tot: d f / d Y[c]; column n_tot + i: d f / d YP[i] for a DIFFERENTIAL state i (the device multiplies it by cj in the
+    integration row and, in the consistent-initialisation row, chains it through the differential equation of state i, as the reference substitutes YP -> rhs there,
+    scalar_residual.jl:335-362).  None -- the reference's no-differentiation fallback (scalar_residual.jl:248-274) -- when the closure reads no state, reads YP of an
+    ALGEBRAIC state, or a derivative does not fit the device interpreter's stack."""
     x = X.lift(x)
     cols = sorted(_refs(x, "Y", set()))
-    if not cols or _refs(x, "YP", set()):
+    pcols = sorted(_refs(x, "YP", set()))
+    if pcols and (n_tot is None or n_diff is None or pcols[-1] >= n_diff):
         return None
     out_c, out_p = [], []
-    for c in cols:
-        d = diff(x, "Y", c)
-        if d is None:
-            continue
-        try:
-            out_p.append(compile_tree(d))
-        except TraceError:
-            return None
-        out_c.append(c)
+    for kind, cc in (("Y", cols), ("YP", pcols)):
+        for c in cc:
+            d = diff(x, kind, c)
+            if d is None:
+                continue
+            try:
+                out_p.append(compile_tree(d))
+            except TraceError:
+                return None
+            out_c.append(c if kind == "Y" else n_tot + c)
     return (out_c, out_p) if out_c else None
 
 

@@ -147,7 +147,19 @@ PL_DEV void gen_factor(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double cj, 
     else if (mode == PLH_MODE_P) { const double iI = Y[O_I] * S.cc.I1C; entry(O_PS, iI); entry(O_PS + NJ - 1, -iI); entry(O_I, (Y[O_PS] - Y[O_PS + NJ - 1]) * S.cc.I1C); }
     else if (mode == PLH_MODE_ETA_P) { entry(O_PE + NP + NS, -1.0); entry(O_PS + NP, 1.0); }
     // (PLH_MODE_RES: method_res = 0, the row is the closure's alone)
-    for (int k = 0; k < r.n_dcol; k++) entry(r.dcol[k], -expr_eval(S, r, t, Y, YP, r.dofs[k], r.dofs[k + 1]));
+    for (int k = 0; k < r.n_dcol; k++) {
+      const int c = r.dcol[k];
+      const double v = -expr_eval(S, r, t, Y, YP, r.dofs[k], r.dofs[k + 1]);
+      if (c < NST) entry(c, v);                                                                               // - d f / d Y[c]
+      else {                                                                                                    // - d f / d YP[i] of the differential state i = c - NST:
+        const int i = c - NST;
+        if (!alg_only) entry(i, cj * v);                                                                      //   times cj in the integration row;
+        else {                                                                                                  //   YP[i] -> rhs_i(Y) in the consistent-initialisation row: chain through row i of dF/dY
+          const int* __restrict__ ptr = tb->csr_ptr[PLH_MODE_I]; const unsigned* __restrict__ code = tb->csr_code[PLH_MODE_I]; const unsigned short* __restrict__ ccol = tb->csr_col[PLH_MODE_I];
+          for (int q = ptr[i]; q < ptr[i + 1]; q++) { const int c2 = ccol[q]; if (c2 >= NDIFF) entry(c2, v * jac_entry<false>(S, tb, code[q], 0.0)); }
+        }
+      }
+    }
   }
   g.gv = gv; g.gcol = gcol; g.ng = ng;
   cell_factor(S, R, tb, cj, PLH_MODE_I, alg_only);
@@ -187,6 +199,17 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
         cell_residual(S, R, Yv, YP, res, PLH_MODE_RES, 0.0);
         PL_XSYNC();
         const double v = res[frun->dstate] + YP[frun->dstate] - frun->value;
+        PL_XSYNC();
+        return v;
+      }
+    }
+    if constexpr ((F & GF_GENROW) != 0) {
+      if (frun->n_dcol > 0 && frun->dcol[frun->n_dcol - 1] >= NST) {      // the closure reads YP of differential states: evaluated with YP = rhs(Yv) = F_diff(Yv, YP) + YP
+        cell_residual(S, R, Yv, YP, res, PLH_MODE_RES, 0.0);
+        PL_XSYNC();
+        PL_VEC(n) if (n < NDIFF) res[n] += YP[n];
+        PL_XSYNC();
+        const double v = closure_input(S, *frun, t_fun, Yv, res);
         PL_XSYNC();
         return v;
       }

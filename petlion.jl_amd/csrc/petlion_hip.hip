@@ -607,7 +607,9 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
       if (runs[r].n_dcol > 0) {                                      // derivative programs of the control row, behind the main program in the same arrays
         if (!runs[r].dcol || !runs[r].dofs || runs[r].dofs[0] < runs[r].n_tab) return fail(PLH_E_ARG, "PLH_VAL_EXPR: n_dcol > 0 needs dcol, dofs and dofs[0] >= n_tab");
         for (int k = 0; k < runs[r].n_dcol; k++) {
-          if (runs[r].dcol[k] < 0 || runs[r].dcol[k] >= m->N || (k > 0 && runs[r].dcol[k] <= runs[r].dcol[k - 1])) return fail(PLH_E_ARG, "PLH_VAL_EXPR: dcol must be ascending state columns");
+          // columns 0 .. N-1: d f / d Y[c]; N + i: d f / d YP[i] of a differential state i
+          if (runs[r].dcol[k] < 0 || runs[r].dcol[k] >= m->N + m->ops->Nd || (k > 0 && runs[r].dcol[k] <= runs[r].dcol[k - 1]))
+            return fail(PLH_E_ARG, "PLH_VAL_EXPR: dcol must be ascending columns (0 .. N-1 for Y, N + i for YP of a differential state i)");
           if (runs[r].dofs[k + 1] <= runs[r].dofs[k]) return fail(PLH_E_ARG, "PLH_VAL_EXPR: dofs must be increasing");
           if (int rc = check_program(runs[r].dofs[k], runs[r].dofs[k + 1])) return rc;
         }

@@ -331,10 +331,12 @@ def check_closure_inputs(p, O, pkg):
              ("I_of_ce", [{"I": lambda t, Y, q: -1.0 + 2e-4 * (Y[q.ind["c_e"].start] - 1000.0), "tf": 600.0}], 1.0, [], True),
              ("V_of_I", [{"V": lambda t, Y, q: 4.0 - 0.05 * cl.calc_I(Y, q), "tf": 300.0}], 0.5, [], True),
              ("P_tanh", [{"P": lambda t, Y, q: -29.0 * cl.tanh(2.0 * (cl.calc_V(Y, q) - 3.2)), "tf": 600.0}], 1.0, [], True),
-             # (a closure of YP keeps the reference's no-differentiation fallback here -- include/petlion_hip.h -- : it enters the Newton matrix scaled by cj = O(1/h), so only a
-             #  weak dependence converges)
-             ("reads_YP", [{"I": lambda t, Y, YP, q: -1.0 + 1e-7 * YP[q.ind["c_e"].start], "tf": 300.0}], 1.0, [], True)]
-    n_der = {"taper_V": 2, "I_of_ce": 1, "V_of_I": 1, "P_tanh": 2}
+             # closures of YP (differential states): cj d f / d YP in the integration row, the chain through the differential equation in the consistent-initialisation row
+             # (scalar_residual.jl:335-362).  Without the derivative these runs stall in the oracle ("Model failed to converge"): the row enters scaled by cj = O(1/h)
+             ("reads_YP", [{"I": lambda t, Y, YP, q: -1.0 + 0.02 * YP[q.ind["c_e"].start], "tf": 300.0}], 1.0, [], True),
+             ("YP_and_Y", [{"I": lambda t, Y, YP, q: -1.0 + 1e-3 * YP[q.ind["c_s_avg"].start + 9] - 0.1 * (cl.calc_V(Y, q) - 4.0), "tf": 300.0}], 1.0, [], True),
+             ("res_of_YP", [{"res": (-0.5, lambda t, Y, YP, q: YP[q.ind["c_e"].start + 15] + 0.5 * cl.calc_I(Y, q)), "tf": 200.0}], 0.5, [], True)]
+    n_der = {"taper_V": 2, "I_of_ce": 1, "V_of_I": 1, "P_tanh": 2, "reads_YP": 1, "YP_and_Y": 3, "res_of_YP": 2}
     for name, proto, soc, td, same in cases:
         o = pkg.Opts(); o.tdiscon = td
         ens = pkg.simulate_ensemble(p, th[None, :], proto, SOC=soc, opts=o)
@@ -343,6 +345,10 @@ def check_closure_inputs(p, O, pkg):
         ro = O.simulate(p.variant, th, soc, runs, opts=O.default_opts(tdiscon=td))
         assert ens.run_info[0, 0]["flag"] == ro["runs"][0]["flag"] >= 0, (name, ens.run_info[0, 0], ro["runs"][0])
         parity.compare_trajectory(ens, 0, ro, rtol_state=5e-6, same_decisions=same)
+        if name == "reads_YP":
+            for r in runs:
+                r.pop("dcol")
+            assert O.simulate(p.variant, th, soc, runs, opts=O.default_opts(tdiscon=td))["runs"][0]["flag"] < 0
         if name in ("taper_V", "V_of_I"):
             # the derivative is what the reference algorithm uses: without it (its fallback for closures it cannot differentiate) the same run takes other Newton steps --
             # 92 steps instead of 85 through the taper -- or cannot be initialised at all (V = f(I): singular control row)
@@ -380,6 +386,8 @@ def check_closure_derivatives_other_models(p_th, p_sei, O, pkg):
     3-unknown node-local elimination of the SEI electrode, same decisions as the oracle's sparse LU of the merged pattern"""
     cl = pkg.closures
     for p, soc, protos in ((p_th, 0.2, [[{"I": lambda t, Y, q: 3.0 - 0.08 * (Y[q.ind["T"].start + 20] - 298.15), "tf": 400.0}],
+                                       [{"I": lambda t, Y, YP, q: 3.0 - 20.0 * YP[q.ind["T"].start + 20], "tf": 100.0}],          # a current that backs off with the heating RATE
+
                                        [{"I": 2.0, "tf": 100.0}, {"V": lambda t, Y, q: 4.0 + 1e-3 * (Y[q.ind["T"].start + 20] - 298.15) - 0.02 * cl.calc_I(Y, q), "tf": 200.0}]]),
                            (p_sei, 0.1, [[{"I": lambda t, Y, q: 1.0 - 2e7 * Y[q.ind["film"].start + 3], "tf": 900.0}]])):
         th = p.theta_vector()
@@ -418,8 +426,8 @@ def check_res_mode(p, p_th, O, pkg):
         ro = O.simulate(pm.variant, thm, soc, runs)
         assert ens.run_info[0, -1]["flag"] == ro["runs"][-1]["flag"] >= 0, (ens.run_info[0], ro["runs"])
         parity.compare_trajectory(ens, 0, ro, rtol_state=5e-6, same_decisions=True)
-    with pytest.raises(ValueError, match="YP"):
-        pkg.make_protocol(p, [{"res": lambda t, Y, YP, q: YP[0] - 1.0}])
+    with pytest.raises(ValueError, match="state"):
+        pkg.make_protocol(p, [{"res": lambda t, Y, YP, q: YP[p.N.diff + 1] - 1.0}])            # YP of an algebraic state: no differential equation to chain through
     with pytest.raises(ValueError):
         pkg.make_protocol(p, [{"res": 1.0}])
 

@@ -162,7 +162,13 @@ def test_closure_symbolic_derivatives(pkg, emu_model):
             an = cl.evaluate(dp, 1.3, Y, YP, th)
             assert abs(an - fd) <= 1e-7 * max(1.0, abs(fd)), (c, an, fd)
     assert cl.row_derivatives(cl.trace(lambda t: cl.sin(t), p, with_tree=True)[1]) is None
-    assert cl.row_derivatives(cl.trace(lambda t, Y_, YP_, q: Y_[0] + YP_[1], p, with_tree=True)[1]) is None          # reads YP: the reference's fallback path here
+    # a closure of YP: columns N + i for differential states i (the device chains them through the differential equations in the consistent initialisation); YP of an
+    # algebraic state has no such equation: the reference's fallback path
+    N, Nd = p.N.tot, p.N.diff
+    tree = cl.trace(lambda t, Y_, YP_, q: Y_[0] * YP_[1] + cl.sin(YP_[5]), p, with_tree=True)[1]
+    cols, progs = cl.row_derivatives(tree, N, Nd)
+    assert cols == [0, N + 1, N + 5] and abs(cl.evaluate(progs[1], 0.0, Y, YP, th) - Y[0]) < 1e-15 and abs(cl.evaluate(progs[2], 0.0, Y, YP, th) - np.cos(YP[5])) < 1e-15
+    assert cl.row_derivatives(cl.trace(lambda t, Y_, YP_, q: Y_[0] + YP_[Nd + 2], p, with_tree=True)[1], N, Nd) is None
     # the run descriptor carries them: columns ascending, programs behind the main one
     (run,), _ = pkg.make_protocol(p, [{"I": lambda t, Y_, q: -0.5 * cl.calc_V(Y_, q), "tf": 10.0}])
     ps = p.ind["Φ_s"]
