@@ -15,7 +15,8 @@ module PetlionHIP
 const lib = get(ENV, "PETLION_HIP_LIB", joinpath(@__DIR__, "..", "..", "petlion.jl_amd", "libpetlion_hip.so"))
 
 const PLH_HOST = Cint(0)
-const MODE = Dict(:I => Cint(0), :V => Cint(1), :dT => Cint(2), :P => Cint(3), :η_p => Cint(4))
+const DSTATE = Dict(:dc_s_p_max => Cint(1), :dc_s_p_min => Cint(2), :dc_s_n_max => Cint(3), :dc_s_n_min => Cint(4), :dc_e_max => Cint(5), :dc_e_min => Cint(6))   # PLH_DSTATE_* (input_methods.jl:190-247)
+const MODE = merge(Dict(:I => Cint(0), :V => Cint(1), :dT => Cint(2), :P => Cint(3), :η_p => Cint(4), :res => Cint(5)), Dict(k => Cint(6) for k in keys(DSTATE)))
 const VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE, VAL_EXPR = Cint(0), Cint(1), Cint(2), Cint(3), Cint(4)
 
 struct ModelDesc
@@ -122,10 +123,18 @@ function make_run(p, step::NamedTuple)
     if x isa Tuple{Vector{Float64},Vector{Float64}}      # (t, values): a tabulated I(t) / V(t) / P(t); the caller keeps the two vectors alive (GC.@preserve)
         return Run(MODE[name], VAL_TABLE, x[2][1], tf, b, length(x[1]), pointer(x[1]), pointer(x[2]), C_NULL, C_NULL, 0, 0, C_NULL, C_NULL)
     end
+    if haskey(DSTATE, name)                              # the rate of one differential state held (number or :hold); the device picks the state per cell
+        kind, val = x === :hold ? (VAL_HOLD, 0.0) : (VAL_CONST, Float64(x))
+        return Run(MODE[name], kind, val, tf, b, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, DSTATE[name], C_NULL, C_NULL)
+    end
+    res_x = 0.0
+    if name === :res && x isa Tuple                      # res = (x, f): x - f(t, Y, YP, p) = 0 (custom_res!, model_evaluation.jl:155-172)
+        res_x, x = Float64(x[1]), x[2]
+    end
     if x isa Function                                    # a closure input: its expression as a postfix program (closure_program below)
-        ops, args = closure_program(x, p)
-        push!(KEEPALIVE, (ops, args))                    # (the program arrays must outlive the call; emptied by simulate_ensemble when it returns)
-        return Run(MODE[name], VAL_EXPR, 0.0, tf, b, length(ops), pointer(ops), pointer(args), C_NULL, C_NULL, 0, 0, C_NULL, C_NULL)   # n_dcol = 0: the derivative programs (Symbolics.derivative of the same expression per state column, as PETLION's differentiate_residual_func builds them) are produced by the Python mirror only so far
+        ops, args, n_main, dcol, dofs = closure_program(x, p)
+        push!(KEEPALIVE, (ops, args, dcol, dofs))        # (the program arrays must outlive the call; emptied by simulate_ensemble when it returns)
+        return Run(MODE[name], VAL_EXPR, res_x, tf, b, n_main, pointer(ops), pointer(args), C_NULL, C_NULL, length(dcol), 0, isempty(dcol) ? C_NULL : pointer(dcol), isempty(dcol) ? C_NULL : pointer(dofs))
     end
     x isa Vector{Float64} && return Run(MODE[name], VAL_CONST, x[1], tf, b, 0, C_NULL, C_NULL, pointer(x), C_NULL, 0, 0, C_NULL, C_NULL)   # one value per cell (caller keeps x alive)
     kind, val = x === :hold ? (VAL_HOLD, 0.0) : x === :rest ? (VAL_REST, 0.0) : (VAL_CONST, Float64(x))
@@ -135,7 +144,7 @@ end
 # Input closures `I = (t, Y, YP, p) -> ...` (input_methods.jl:159-176): PETLION itself traces them with Symbolics to differentiate the control row
 # (scalar_residual.jl:248-274); the same traced expression, walked in post-order, is the C ABI's postfix program (PLH_VAL_EXPR, PLH_OP_* of include/petlion_hip.h).
 # The Python host mirror does exactly this with operator overloading (petlion.jl_amd/closures.py, tested); this Julia version is its transliteration onto
-# SymbolicUtils' expression interface and has not been executed.
+# SymbolicUtils' expression interface (derivative programs through Symbolics.derivative, as PETLION's differentiate_residual_func does) and has not been executed.
 const OPCODE = Dict(:+ => 5, :- => 6, :* => 7, :/ => 8, :sin => 10, :cos => 11, :exp => 12, :log => 13, :sqrt => 14, :^ => 15, :abs => 16, :min => 17, :max => 18,
                     :< => 19, :<= => 20, :> => 21, :>= => 22, :ifelse => 23, :tanh => 24)
 function closure_program(f, p)
@@ -165,7 +174,23 @@ function closure_program(f, p)
         end
     end
     walk(ex)
-    ops, args
+    n_main = length(ops)
+    # derivative programs of the control row (PETLION: sparsejacobian of the traced row with respect to Y and YP, scalar_residual.jl:289-291): one program per column the
+    # closure reads, behind the main program in the same arrays; column k-1 for Y[k], N + k - 1 for YP[k] of a differential state (include/petlion_hip.h, PLH_VAL_EXPR).
+    # A closure that reads YP of an algebraic state keeps PETLION's no-differentiation fallback (n_dcol = 0).
+    N = length(Y); Nd = p.N.diff
+    vars = S.get_variables(ex)
+    dcol = Cint[]; dofs = Cint[n_main]
+    reads_alg_yp = any(k -> any(v -> isequal(v, S.value(YP[k])), vars), Nd+1:N)
+    if !reads_alg_yp
+        for (vec, off) in ((Y, 0), (YP, N)), k in 1:(off == 0 ? N : Nd)
+            any(v -> isequal(v, S.value(vec[k])), vars) || continue
+            d = S.value(S.simplify(S.derivative(ex, vec[k])))
+            (d isa Number && iszero(d)) && continue
+            walk(d); push!(dcol, off + k - 1); push!(dofs, length(ops))
+        end
+    end
+    ops, args, n_main, dcol, dofs
 end
 
 """
