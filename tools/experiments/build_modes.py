@@ -33,6 +33,10 @@ BUILDS = [  # tag, variants, {variant: opt}, extra flags, perf config, pytest -k
     # r03: recursive doubling in the block sweeps of the solve (default) against the one-lane recurrence
     ("iso_stride1", [0], {0: "-O3"}, LATE + ["-DPL_EXP_NO_STRIDE2"], "c2 c4", "evaluators"),
     ("sei_stride1", [3], {3: "-O3"}, LATE + ["-DPL_EXP_NO_STRIDE2"], "c5", "evaluators"),
+    # r03: floating-point flags that keep IEEE results for finite data (no reassociation): does the compiler find anything?
+    ("iso_fz", [0], {0: "-O3"}, LATE + ["-fno-signed-zeros", "-fno-trapping-math"], "c2 c4", "evaluators"),
+    ("sei_fz", [3], {3: "-O3"}, LATE + ["-fno-signed-zeros", "-fno-trapping-math"], "c5", "evaluators"),
+    ("th_fz", [4], {4: "-O3"}, EARLY + ["-fno-signed-zeros", "-fno-trapping-math"], "c3", "evaluators"),
     ("iso_noprev", [0], {0: "-O3"}, LATE + ["-DPL_EXP_NO_PREV"], "c2 c4", "evaluators"),
     ("th_noprev", [4], {4: "-O3"}, EARLY + ["-DPL_EXP_NO_PREV"], "c3", "evaluators"),
     ("sei_noprev", [3], {3: "-O3"}, LATE + ["-DPL_EXP_NO_PREV"], "c5", "evaluators"),
