@@ -613,6 +613,17 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
           if (runs[r].dofs[k + 1] <= runs[r].dofs[k]) return fail(PLH_E_ARG, "PLH_VAL_EXPR: dofs must be increasing");
           if (int rc = check_program(runs[r].dofs[k], runs[r].dofs[k + 1])) return rc;
         }
+        // the general control row holds one entry per lane: the input method's own (<= 3), one per Y column, and for a YP column the algebraic entries of that state's row
+        // (consistent-initialisation form) -- counted on the exported pattern
+        int n_entries = 3, n_y = 0;
+        for (int k = 0; k < runs[r].n_dcol; k++) {
+          const int c = runs[r].dcol[k];
+          if (c < m->N) { n_y++; continue; }
+          int tw = 0;
+          for (int cc = m->ops->Nd; cc < m->N; cc++) for (int q = m->colptr[PLH_MODE_I][cc]; q < m->colptr[PLH_MODE_I][cc + 1]; q++) tw += m->rowval[PLH_MODE_I][q] == c - m->N;
+          n_entries += tw > 1 ? tw : 1;
+        }
+        if (n_entries + n_y > 64) return fail(PLH_E_UNSUPPORTED, "PLH_VAL_EXPR: the control row of this closure has more than 64 entries (columns read + Jacobian entries of the differential states whose YP it reads)");
       }
     }
     if (runs[r].value_kind == PLH_VAL_TABLE) {

@@ -400,7 +400,21 @@ def check_closure_derivatives_other_models(p_th, p_sei, O, pkg):
             parity.compare_trajectory(ens, 0, ro, rtol_state=5e-6, same_decisions=True)
 
 
+def check_control_row_capacity(p_th, pkg):
+    """the general control row has one entry per lane (64): a closure whose row would need more -- here the rate of the mean of thirty temperature nodes, each chaining through
+    the algebraic entries of its heat equation in the consistent initialisation -- is refused, not truncated"""
+    T0 = p_th.ind["T"].start
+    def mean_rate(t, Y, YP, q):
+        s = YP[T0 + 10]
+        for k in range(11, 40):
+            s = s + YP[T0 + k]
+        return 3.0 - s
+    with pytest.raises(RuntimeError, match="64 entries"):
+        pkg.simulate_ensemble(p_th, p_th.theta_vector()[None, :], [{"I": mean_rate, "tf": 10.0}], SOC=0.2)
+
+
 def test_closure_derivatives_thermal_and_sei(emu_model_thermal, emu_model_sei, O, pkg):
+    check_control_row_capacity(emu_model_thermal, pkg)
     check_closure_derivatives_other_models(emu_model_thermal, emu_model_sei, O, pkg)
 
 
