@@ -6,5 +6,5 @@ of include/petlion_hip.h.  There is no CPU compute path in this package.
 """
 from . import _capi, closures, configs, grids  # noqa: F401
 from .api import (LCO, NMC, NMC_LGM50, EnsembleSolution, Model, Solution, exit_reasons, final_exit_reason, make_protocol, petlion,  # noqa: F401
-                  simulate, simulate_b, simulate_ensemble, theta_matrix)
+                  selftest, simulate, simulate_b, simulate_ensemble, theta_matrix)
 from .params import EXIT_REASONS, Bounds, Opts, calc_I1C  # noqa: F401

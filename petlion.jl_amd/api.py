@@ -70,6 +70,7 @@ class Model:
             if vid is None:
                 raise NotImplementedError("this combination of model options is not instantiated on the device")
             grid_lib = grids.library(g, [vid])
+            self._grid_lib_built = grid_lib
         if grid_lib:                                     # (False: register nothing -- the tests' way to reach the C ABI's own refusal)
             cap.check(self._lib, self._lib.plh_register_grid_library(os.fsencode(grid_lib)), "plh_register_grid_library")
         h = C.c_void_p()
@@ -130,7 +131,59 @@ def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_
         raise NotImplementedError("thermodynamic_factor: linear / nonlinear; rxn_p = rxn_n in (BV, MHC)")
     p = Model(cathode, _N(p=N_p, s=N_s, n=N_n, a=N_a, z=N_z, r_p=N_r_p, r_n=N_r_n), temperature, aging, _lib_path, precision, device, solid_diffusion, thermodynamic_factor, rxn_p, waves_per_cell, _grid_lib)
     p.opts.SOC = SOC
+    _selftest_new_grid_library(p)
     return p
+
+
+def selftest(p, n_cells=2, tf=100.0):
+    """Power-on check of the kernels of ONE model variant: every k_integrate instantiation (plain / stop times / table / closure / general control row / refinement,
+    csrc/dfn_integrate.h GenFlag) runs the same 1C discharge and must reproduce the plain kernel -- flags and end times equal, SOC (exact for a constant current) to 1e-11,
+    the first saved SOC equal to SOC0, voltage to 1e-9 where the input is the same number.  Raises RuntimeError naming the instantiation.  It exists because a kernel of this size
+    sits at the register allocator's limits: one build was seen to start a run with a garbage SOC accumulator in one instantiation only; the built-in variants
+    are checked by the GPU test suite, a grid library compiled on the user's machine at first use is checked here."""
+    Th = np.tile(p.theta_vector(), (n_cells, 1))
+    ps = p.ind["Φ_s"]
+    base = simulate_ensemble(p, Th, [{"I": -1.0, "tf": tf}], SOC=1.0)
+    o_stop, o_ref = Opts(), Opts()
+    o_stop.tstops = [1e7]; o_ref.refine = 1
+    cases = [("stop times", [{"I": -1.0, "tf": tf}], o_stop, 1e-12), ("table input", [{"I": ([0.0, 1e7], [-1.0, -1.0]), "tf": tf}], None, 1e-9),
+             ("closure input", [{"I": lambda t: -1.0 + 0.0 * t, "tf": tf}], None, 1e-9),
+             ("general control row", [{"I": lambda t, Y, q: -1.0 + 1e-12 * (Y[ps.start] - Y[ps.stop - 1]), "tf": tf}], None, 2e-3), ("refinement", [{"I": -1.0, "tf": tf}], o_ref, 2e-3)]
+    bad = None
+    if not ((base.run_info["flag"][:, 0] == 0).all() and np.abs(base.run_info["SOC"][:, 0] - (1.0 - tf / 3600.0)).max() < 1e-11 and np.abs(base.SOC[:, 0] - 1.0).max() == 0.0):
+        bad = "plain"
+    for name, proto, o, vtol in cases:
+        if bad:
+            break
+        e = simulate_ensemble(p, Th, proto, SOC=1.0, opts=o)
+        if not (np.array_equal(e.run_info["flag"], base.run_info["flag"]) and np.abs(e.run_info["t_end"] - base.run_info["t_end"]).max() == 0.0
+                and np.abs(e.run_info["SOC"] - base.run_info["SOC"]).max() < 1e-11 and np.abs(e.run_info["V"] - base.run_info["V"]).max() <= vtol and np.abs(e.SOC[:, 0] - 1.0).max() == 0.0):
+            bad = name
+    if bad:
+        raise RuntimeError("kernel self-test failed: the %s instantiation of %s does not reproduce the plain kernel on a 1C discharge -- a miscompiled build "
+                           "(rebuild; see DESIGN.md 5a)" % (bad, p.variant))
+
+
+def _selftest_new_grid_library(p):
+    """a grid library compiled at first use (petlion.jl_amd/grids.py) is checked once per (library, variant) on the first machine with a GPU that loads it"""
+    lib = getattr(p, "_grid_lib_built", None)
+    if not lib:
+        return
+    marker = "%s.%s.selftest" % (lib, p.variant)
+    if os.path.exists(marker):
+        return
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return
+    except ImportError:
+        return
+    selftest(p)
+    try:
+        with open(marker, "w") as f:
+            f.write("ok\n")
+    except OSError:
+        pass
 
 
 # ---------------------------------------------------------------------------------------------------------------------

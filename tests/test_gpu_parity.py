@@ -1,5 +1,7 @@
 """GPU parity tests: the HIP path (through the C ABI, real MI355X) against the oracle on the same seeded inputs, plus
 size-independent properties at BASELINE.json's full sizes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -559,7 +561,11 @@ def test_other_discretisations(pkg, O, hip_model):
     import torch
     import test_device_source_emu as te
     from oracle import dfn_model as dm
-    te.check_grid_model(pkg.petlion(pkg.LCO, N_p=12, N_s=7, N_n=9, N_r_p=11, N_r_n=11), O, pkg)
+    p12 = pkg.petlion(pkg.LCO, N_p=12, N_s=7, N_n=9, N_r_p=11, N_r_n=11)
+    # (a grid library is checked once per variant by pkg.selftest -- every kernel instantiation against the plain one -- on the first GPU machine that loads it: the marker file)
+    assert os.path.exists("%s.%s.selftest" % (p12._grid_lib_built, p12.variant))
+    pkg.selftest(hip_model)
+    te.check_grid_model(p12, O, pkg)
     te.check_grid_model(pkg.petlion(pkg.NMC, aging="SEI", N_p=6, N_s=5, N_n=8, N_r_p=13, N_r_n=13), O, pkg, identical=False)
     te.check_thermal_grid_model(pkg.petlion(pkg.LCO, temperature=True, N_p=8, N_s=6, N_n=7, N_r_p=11, N_r_n=11, N_a=5, N_z=7), O, pkg)      # temperature = true off the default grid
     n = 1024

@@ -175,6 +175,27 @@ def test_closure_symbolic_derivatives(pkg, emu_model):
     assert run.n_dcol == 2 and [run.dcol[0], run.dcol[1]] == [ps.start, ps.stop - 1] and run.dofs[0] == run.n_tab
 
 
+def test_kernel_selftest(pkg, emu_model, emu_model_thermal):
+    """pkg.selftest: every kernel instantiation of a variant against its plain kernel (run automatically, once, for a grid library compiled at first use on a machine with a GPU)"""
+    pkg.selftest(emu_model)
+    pkg.selftest(emu_model_thermal, n_cells=1, tf=30.0)
+    class Broken:                                                       # a model whose runs come back with another SOC: the check must say which instantiation
+        pass
+    import petlion_jl_amd.api as api
+    real = api.simulate_ensemble
+    def fake(p, Th, proto, **kw):
+        e = real(p, Th, proto, **kw)
+        if isinstance(proto[0]["I"], tuple):
+            e.run_info["SOC"][:] += 1e-6
+        return e
+    api.simulate_ensemble = fake
+    try:
+        with pytest.raises(RuntimeError, match="table input"):
+            pkg.selftest(emu_model)
+    finally:
+        api.simulate_ensemble = real
+
+
 def test_register_grid_library_refusals(pkg, emu_model):
     """plh_register_grid_library: a missing file and a library that is not a grid library are refused with a message, registering the same grid library twice is a no-op"""
     import build_emu
