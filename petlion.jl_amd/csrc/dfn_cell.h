@@ -61,6 +61,9 @@ constexpr int O_CE = 0, O_CS = NE;                                 // c_e and c_
 constexpr int NA = PL_NA, NZ = PL_NZ, NT = NA + NE + NZ;         // current collectors; temperature nodes a|p|s|n|z
 constexpr bool GRID_DEFAULT = NP == 10 && NS == 10 && NN == 10 && NR == 10 && NA == 10 && NZ == 10;
 constexpr int NRMAX = 16;                                          // Tables has room for the radial operator of any supported N_r
+}  // namespace pl
+#include "radial_tables.h"      // PL_RADIAL_M / LAM / V / W: the radial operator of THIS translation unit's N_r as static const arrays -- device code may index them directly
+namespace pl {
 // lane maps: the node pass gives control volume i to lane i; the twisted block sweeps put nodes 0 .. NE/2-1 in lanes 0 .. and nodes NE-1 .. NE/2 in lanes 32 .. (tw_node);
 // the particle phases give lane l row l % NR of particle pass * CS_G + l / NR
 static_assert(NP >= 2 && NS >= 2 && NN >= 2 && NE <= 48, "2 <= N_p, N_s, N_n and N_p + N_s + N_n <= 48 (one lane per node, two 32-lane halves in the sweeps)");
@@ -318,6 +321,18 @@ enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_O
 #endif
 #define PL_TICE(mode) long long pl_t0__ = (PL_PHASE_DETAIL == (mode)) ? (long long)__builtin_readcyclecounter() : 0   /* mode 2: solve + residual, mode 3: step control + output */
 #define PL_TOCE(S_, mode, slot) do { if (PL_PHASE_DETAIL == (mode)) PL_LAP_(S_, slot); } while (0)
+#elif defined(PL_ASM_MARKS)      /* ISA inspection builds (tools/asm/): the timer positions become comment markers in the assembly (each one is also a compiler barrier) */
+#define PL_MARK_(txt) __asm__ volatile("; PLMARK " txt ::: "memory")
+#define PL_STR2_(x) #x
+#define PL_STR_(x) PL_STR2_(x)
+#define PL_TIC() PL_MARK_("tic")
+#define PL_TOC(S_, ph) PL_MARK_("toc " #ph)
+#define PL_TIC_TOTAL() do {} while (0)
+#define PL_TOC_TOTAL(S_) do {} while (0)
+#define PL_TICD() PL_MARK_("ticD")
+#define PL_TOCD(S_, slot) PL_MARK_("tocD " #slot)
+#define PL_TICE(mode) PL_MARK_("ticE " #mode)
+#define PL_TOCE(S_, mode, slot) PL_MARK_("tocE " #mode " " #slot)
 #else
 #define PL_TIC() PL_TIC_()
 #define PL_TOC(S_, ph) PL_TOC_(S_, ph)

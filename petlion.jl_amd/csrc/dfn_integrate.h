@@ -147,9 +147,20 @@ PL_DEV void gen_factor(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double cj, 
     else if (mode == PLH_MODE_P) { const double iI = Y[O_I] * S.cc.I1C; entry(O_PS, iI); entry(O_PS + NJ - 1, -iI); entry(O_I, (Y[O_PS] - Y[O_PS + NJ - 1]) * S.cc.I1C); }
     else if (mode == PLH_MODE_ETA_P) { entry(O_PE + NP + NS, -1.0); entry(O_PS + NP, 1.0); }
     // (PLH_MODE_RES: method_res = 0, the row is the closure's alone)
+    // Evaluation point of the derivative programs in the consistent initialisation: the closure itself is evaluated there with YP -> rhs(Y) = F_diff(Y, YP) + YP
+    // (input_value, cell_init_consistent_impl), so its partials are too -- for a closure nonlinear in YP (or with Y / YP cross terms) the row evaluated at the init's raw
+    // YP = 0 would be a different row (res = x - YP[i]^2 gives 2 YP[i] = 0: a zero border).  `tmp` is free until the W solve below.
+    const double* YPe = YP;
+    if (alg_only && r.n_dcol > 0 && r.dcol[r.n_dcol - 1] >= NST) {
+      cell_residual(S, R, Y, YP, tmp, PLH_MODE_RES, 0.0);
+      PL_XSYNC();
+      PL_VEC(n) tmp[n] = n < NDIFF ? tmp[n] + YP[n] : YP[n];
+      PL_XSYNC();
+      YPe = tmp;
+    }
     for (int k = 0; k < r.n_dcol; k++) {
       const int c = r.dcol[k];
-      const double v = -expr_eval(S, r, t, Y, YP, r.dofs[k], r.dofs[k + 1]);
+      const double v = -expr_eval(S, r, t, Y, YPe, r.dofs[k], r.dofs[k + 1]);
       if (c < NST) entry(c, v);                                                                               // - d f / d Y[c]
       else {                                                                                                    // - d f / d YP[i] of the differential state i = c - NST:
         const int i = c - NST;

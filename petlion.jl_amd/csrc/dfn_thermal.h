@@ -350,7 +350,9 @@ PL_DEV void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const 
   auto& TP = S.th;
   const int r = lane % NR, g = lane < CS_LANES ? lane / NR : CS_G - 1;
   double Mrow[NR], Wrow[NR];
-  for (int k = 0; k < NR; k++) { Mrow[k] = tb->Mp()[r * NR + k]; if (WANT_JAC) Wrow[k] = tb->Wp()[r * NR + k]; }
+  // (the radial operator is a compile-time table of this translation unit: global loads from a constant base, on their own counter -- through `tb`, a pointer that went
+  //  through LDS, they were FLAT loads, which also occupy the LDS counter and serialise against the LDS traffic of the pass)
+  for (int k = 0; k < NR; k++) { Mrow[k] = PL_RADIAL_M[r * NR + k]; if (WANT_JAC) Wrow[k] = PL_RADIAL_W[r * NR + k]; }
 #pragma unroll
   for (int pass = 0; pass < CS_PASS; pass++) {
     const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
@@ -543,7 +545,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
   if (!alg_only) {
     if (lane < NJ) TP.kapF[lane] = TP.kapP[lane];
     double Vrow[NR], wl[NR], lm[NR];
-    for (int m = 0; m < NR; m++) { Vrow[m] = tb->Vp()[r * NR + m]; wl[m] = tb->Wp()[m * NR + NR - 1]; lm[m] = tb->LAMp()[m]; }
+    for (int m = 0; m < NR; m++) { Vrow[m] = PL_RADIAL_V[r * NR + m]; wl[m] = PL_RADIAL_W[m * NR + NR - 1]; lm[m] = PL_RADIAL_LAM[m]; }
     double ae[CS_PASS], aq[CS_PASS];
     for (int pass = 0; pass < CS_PASS; pass++) {
       const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
@@ -802,8 +804,8 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
   // a. particle partial solutions w = A_p^-1 b_cs  (two mat-vecs through the spectral form); collector forward/backward substitution
   if (!alg_only) {
     double Wrow[NR], Vrow[NR];
-    for (int k = 0; k < NR; k++) { Wrow[k] = tb->Wp()[r * NR + k]; Vrow[k] = tb->Vp()[r * NR + k]; }
-    const double lam_r = tb->LAMp()[r];
+    for (int k = 0; k < NR; k++) { Wrow[k] = PL_RADIAL_W[r * NR + k]; Vrow[k] = PL_RADIAL_V[r * NR + k]; }
+    const double lam_r = PL_RADIAL_LAM[r];
     for (int pass = 0; pass < CS_PASS; pass++) {
       const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
       double y = 0.0;

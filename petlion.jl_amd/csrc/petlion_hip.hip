@@ -19,7 +19,10 @@
 
 #ifdef PL_WAVE_EMU
 // the test-only wave-emulator build is a single translation unit: every variant's kernels are compiled right here, no RCCL
+// (-DPL_VARIANT=<id>: a developer's quick build with that one variant; the others are then refused by plh_model_create)
+#ifndef PL_VARIANT
 #define PL_VARIANT -1
+#endif
 #include "variant_tu.hip"
 #else
 #include <rccl/rccl.h>

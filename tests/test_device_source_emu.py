@@ -335,8 +335,11 @@ def check_closure_inputs(p, O, pkg):
              # (scalar_residual.jl:335-362).  Without the derivative these runs stall in the oracle ("Model failed to converge"): the row enters scaled by cj = O(1/h)
              ("reads_YP", [{"I": lambda t, Y, YP, q: -1.0 + 0.02 * YP[q.ind["c_e"].start], "tf": 300.0}], 1.0, [], True),
              ("YP_and_Y", [{"I": lambda t, Y, YP, q: -1.0 + 1e-3 * YP[q.ind["c_s_avg"].start + 9] - 0.1 * (cl.calc_V(Y, q) - 4.0), "tf": 300.0}], 1.0, [], True),
-             ("res_of_YP", [{"res": (-0.5, lambda t, Y, YP, q: YP[q.ind["c_e"].start + 15] + 0.5 * cl.calc_I(Y, q)), "tf": 200.0}], 0.5, [], True)]
-    n_der = {"taper_V": 2, "I_of_ce": 1, "V_of_I": 1, "P_tanh": 2, "reads_YP": 1, "YP_and_Y": 3, "res_of_YP": 2}
+             ("res_of_YP", [{"res": (-0.5, lambda t, Y, YP, q: YP[q.ind["c_e"].start + 15] + 0.5 * cl.calc_I(Y, q)), "tf": 200.0}], 0.5, [], True),
+             # NONLINEAR in YP, with a Y / YP cross term: the derivative programs read YP themselves, so in the consistent initialisation they must be evaluated where the closure
+             # is -- at YP = rhs(Y) -- not at the init's raw YP = 0, where 2 YP[i] = 0 would leave the row without its chain entries
+             ("YP_squared", [{"I": lambda t, Y, YP, q: -1.0 + 0.5 * YP[q.ind["c_e"].start] * YP[q.ind["c_e"].start] + 1e-4 * YP[q.ind["c_e"].start + 29] * (Y[q.ind["c_e"].start] - 1000.0), "tf": 300.0}], 1.0, [], True)]
+    n_der = {"taper_V": 2, "I_of_ce": 1, "V_of_I": 1, "P_tanh": 2, "reads_YP": 1, "YP_and_Y": 3, "res_of_YP": 2, "YP_squared": 3}
     for name, proto, soc, td, same in cases:
         o = pkg.Opts(); o.tdiscon = td
         ens = pkg.simulate_ensemble(p, th[None, :], proto, SOC=soc, opts=o)

@@ -150,17 +150,20 @@ def test_rest_and_hold_semantics(O):
     assert abs(ro["runs"][1]["SOC"] - 1.0 * 180 / 3600) < 1e-6
 
 
-def test_thermal_cc_ct_cv_notebook(O):
+@pytest.mark.parametrize("variant", ["lco_thermal", "lco_thermal_tdiff"])
+def test_thermal_cc_ct_cv_notebook(O, variant):
     """reference examples/fast_charging_CC-CT-CV.ipynb: temperature=true, SOC0=0, T_max=40 C, V_max=4.1, I_max=4, I_min=1/20;
     simulate(p, I=4) -> simulate!(dT=:hold) -> simulate!(V=:hold).  Exercises the T rows, the heat sources, the dT control row and its
-    algebraic twin (scalar_residual.jl:347-372)."""
-    th = O.theta_vector("lco_thermal")
-    m = O.meta("lco_thermal")
+    algebraic twin (scalar_residual.jl:347-372).  Run through BOTH thermal oracle variants: `lco_thermal` restates the reference's matrix-form heat conduction
+    A_T * T (residuals.jl:299-489); `lco_thermal_tdiff` -- the variant the tight-tolerance GPU suite compares the device with -- evaluates the same stencil on
+    temperature differences.  The notebook's printed results pin both."""
+    th = O.theta_vector(variant)
+    m = O.meta(variant)
     assert m["N"] == 351 and m["nnz"] + 1 == 2883          # SURVEY.md App. D (C3, CC mode)
     b = O.default_bounds(T_max=313.15, V_max=4.1, I_max=4.0, I_min=1 / 20)
     runs = [dict(mode=O.MODE_I, value=4.0, bounds=b), dict(mode=O.MODE_DT, value_kind=O.VAL_HOLD, bounds=b),
             dict(mode=O.MODE_V, value_kind=O.VAL_HOLD, bounds=b)]
-    ro = O.simulate("lco_thermal", th, 0.0, runs)
+    ro = O.simulate(variant, th, 0.0, runs)
     assert ro["rc"] == 0
     for key, r in zip(("thermal_4C", "thermal_dT_hold", "thermal_V_hold"), ro["runs"]):
         k = G["runs"][key]
@@ -173,6 +176,53 @@ def test_thermal_cc_ct_cv_notebook(O):
         assert abs(r["SOC"] - k["SOC_end"]) < 2e-3
     assert abs(ro["runs"][0]["T_avg"] - 313.15) < 1e-6 and abs(ro["runs"][1]["T_avg"] - 313.15) < 1e-4     # CT leg holds 40 C
     assert abs(ro["runs"][2]["T_avg"] - (25.6963 + 273.15)) < 0.05
+
+
+def test_thermal_tdiff_variant_is_the_same_model(O):
+    """`lco_thermal_tdiff` (Model(t_conduction="difference")) against `lco_thermal` (the reference's matrix form) row by row on realistic states with a
+    non-trivial T(x): identical sizes / parameter keys / sparsity patterns in every mode; every residual row within 1e-12 of the magnitude of its terms (the two
+    forms differ by rounding only: aL T_l + aD T + aU T_r vs aL (T_l - T) + aU (T_r - T) with aD = -(aL + aU) [- h_cell / (h rho Cp) at the two ends]); every Jacobian
+    value within 1e-9; the consistent initialisation (incl. the dT twin) within 1e-10; and the default-tolerance CC-CT-CV trajectory with the same decisions."""
+    import parity
+    A, B = "lco_thermal", "lco_thermal_tdiff"
+    ma, mb = O.meta(A), O.meta(B)
+    for k in ("N", "N_diff", "nnz", "nnz_alg", "theta_keys", "theta_default", "alg_colptr", "alg_rowval"):
+        assert ma[k] == mb[k], k
+    th = O.theta_vector(A)
+    N = ma["N"]
+    Y, YP = parity.realistic_states(O, th, 4, seed=11, variant=A)
+    for mode, val in ((O.MODE_I, 3.0), (O.MODE_V, 3.9), (O.MODE_DT, 0.01), (O.MODE_P, 80.0)):
+        for i in range(len(Y)):
+            Fa, Fb = O.residual(A, th, Y[i], YP[i], mode, val), O.residual(B, th, Y[i], YP[i], mode, val)
+            cpa, ria, nza = O.jacobian(A, th, Y[i], YP[i], 0.0, mode, val)
+            cpb, rib, nzb = O.jacobian(B, th, Y[i], YP[i], 0.0, mode, val)
+            assert np.array_equal(cpa, cpb) and np.array_equal(ria, rib)
+            _, _, nz1 = O.jacobian(A, th, Y[i], YP[i], 1.0, mode, val)
+            term = np.zeros(N); term[-1] = abs(val)
+            for c in range(N):
+                sl = slice(cpa[c], cpa[c + 1])
+                np.add.at(term, ria[sl], np.abs(nza[sl] * Y[i, c]) + np.abs((nz1[sl] - nza[sl]) * YP[i, c]))
+            bad = np.abs(Fa - Fb) > 1e-12 * term + 1e-300
+            assert not bad.any(), (mode, i, np.nonzero(bad)[0][:5], np.abs(Fa - Fb)[bad][:5], term[bad][:5])
+            rel = np.abs(nza - nzb) / (np.abs(nza) + 1e-300)
+            assert rel.max() < 1e-9, (mode, i, rel.max())
+    # (dT = 0 from a uniform-temperature rest state would be I = 0 +- sqrt(rounding) -- the heat is quadratic in I --, so the twin is initialised at 0.02 K/s.  Its row SUMS the
+    #  fifty T rows: the matrix form's 1e-9 K/s of rounding per row is 1e-6 relative in the current it determines -- DESIGN.md 5 "tight tolerances" -- hence 3e-6 there)
+    for mode, val, tol in ((O.MODE_I, 4.0, 1e-10), (O.MODE_DT, 0.02, 3e-6)):
+        Yg = O.initial_guess(A, th, 0.3)
+        assert np.array_equal(Yg, O.initial_guess(B, th, 0.3))
+        (rca, Ya, YPa, ita), (rcb, Yb, YPb, itb) = O.init_consistent(A, th, Yg, mode, val), O.init_consistent(B, th, Yg, mode, val)
+        assert rca == rcb == 0 and ita == itb and parity.state_rel_err(Ya, Yb) < tol, (mode, parity.state_rel_err(Ya, Yb))
+    b = O.default_bounds(T_max=313.15, V_max=4.1, I_max=4.0, I_min=1 / 20)
+    runs = [dict(mode=O.MODE_I, value=4.0, bounds=b), dict(mode=O.MODE_DT, value_kind=O.VAL_HOLD, bounds=b), dict(mode=O.MODE_V, value_kind=O.VAL_HOLD, bounds=b)]
+    ra, rb = O.simulate(A, th, 0.0, runs), O.simulate(B, th, 0.0, runs)
+    assert [r["flag"] for r in ra["runs"]] == [r["flag"] for r in rb["runs"]]
+    # CC and CT legs: identical decisions (the V-hold leg is the "+-1 step" leg of DESIGN.md 5 for any two evaluations that differ in the last bit)
+    for k in range(2):
+        assert ra["runs"][k]["iterations"] == rb["runs"][k]["iterations"], (k, ra["runs"][k], rb["runs"][k])
+        # (the h0 floor of DESIGN.md 5 for two last-bit-different evaluations: 1e-6 on the CC leg, amplified by the restart from a held set point on the CT leg)
+        assert abs(ra["runs"][k]["t_end"] - rb["runs"][k]["t_end"]) <= (5e-6, 5e-5)[k] * ra["runs"][k]["t_end"]
+    assert abs(ra["runs"][2]["t_end"] - rb["runs"][2]["t_end"]) <= 2e-3 * ra["runs"][2]["t_end"]
 
 
 def test_thermal_jacobian_vs_complex_step(O):
