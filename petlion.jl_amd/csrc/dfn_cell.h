@@ -182,8 +182,10 @@ template <> struct SeiPool<true> {
 template <bool TH, bool MIXED = false> struct ThermalPool {};
 template <bool MIXED> struct ThermalPool<true, MIXED> {
   double Dpark[MIXED ? NE * 16 : 1];                       // mixed precision: fp64 parking of the node's own block during the factor sweep (fp64 variant: parks in LD)
-  // heat-conduction stencil of residuals_T! (residuals.jl:299-489), already divided by rho*Cp:  aL T[it-1] + aD T[it] + aU T[it+1] + aC
-  double aL[NT], aD[NT], aU[NT], wT5[5];                    // wT5 = temperature_weighting w_i / L per section a|p|s|n|z (aux...jl:649-679)
+  // heat-conduction stencil of residuals_T! (residuals.jl:299-489), already divided by rho*Cp:  aL T[it-1] + aD T[it] + aU T[it+1] + aC with aD = -(aL + aU) [- aC2 at the
+  // two convective ends] (thermal_aD: not stored -- r04's LDS diet: the 2.4 kB freed here hold the radial operator, which the particle phases otherwise fetched from global
+  // memory in every residual and every solve, at one wave per SIMD with nothing to hide that latency behind)
+  double aL[NT], aU[NT], wT5[5];                            // wT5 = temperature_weighting w_i / L per section a|p|s|n|z (aux...jl:649-679)
   double aC2[2], rc5[5];                                    // convective coefficient h_cell / (h rho Cp) of the two end rows; 1/(rho Cp) per section a|p|s|n|z
   double qI[2], qIJ[2];                                    // collector rows: Joule heat qI * I^2 ; qIJ = d(row)/dI at the last Jacobian pass
   double kapP[NJ], dkapP[NJ];                              // per-particle D_s(T)/Rp^2 and its T derivative
@@ -197,10 +199,12 @@ template <bool MIXED> struct ThermalPool<true, MIXED> {
   double AinvE[NJ][NR], AinvQ[NJ][NR];                     // A^-1 e_last, A^-1 q (AinvQ doubles as the store of W c between the Jacobian pass and the factorisation)
   double kapF[NJ];                                         // kappa at the last factorisation (the resolvent is applied in spectral form)
   // node-local elimination
-  double tq[4][NE], phi4[4][NE], colI4[2][NE];           // colI4: (Phi_s, T) components of the column of I (the others are zero)
+  // t_r phi_c of the eliminated j (D[r][c] -= t_r phi_c): t = (ceJ, peJ, psJ, tq3), phi = (gce, gpe, gps) dj and phi3 -- only the two T entries need storing
+  double tq3[NE], phi3[NE];
+  double cI4[4];                                           // column of I after the local elimination: (Phi_s, T) components at node 0 and at node NE - 1 (zero elsewhere)
   // collector chains (tridiagonal scalar systems)
   static constexpr int NC = NA > NZ ? NA : NZ;
-  double cP[2][NC], cM[2][NC], zc[2][NC], zI[2][NC], zb[2][NC];
+  double cP[2][NC], zc[2][NC], zI[2][NC];                  // (forward multipliers of the chains: aL[k] cP[k-1], formed where they are used; the chain solution of a solve stays in registers)
   // Woodbury and border
   double x2[4][NE], vB[4][NE];
   double qfar[2][4];                                       // q = (far T-row entry of node 9 / 20) . D'^-1 of node 7 / 22 (right-hand-side share)
@@ -208,9 +212,12 @@ template <bool MIXED> struct ThermalPool<true, MIXED> {
   double cjf;
 };
 
-template <class M> struct CellLDS {
-  double phi[M::PHI_LDS][M::NPAD];
-  double yy[M::NPAD], yp[M::NPAD], delta[M::NPAD];
+// 16-byte alignment of the block and of its vectors: with it the compiler can prove that an even-indexed pair of doubles is one aligned 16-byte access and uses ds_read_b128
+// (4 LDS-array cycles per wave-instruction, 256 B/clk) instead of ds_read2_b64 (8 cycles for the same 16 bytes per lane: MI355X_MICROARCH.md, LDS table).  The LDS array is
+// shared by the four cells of a CU; in the particle phases it, not the VALU, is what a cell waits for.
+template <class M> struct alignas(16) CellLDS {
+  alignas(16) double phi[M::PHI_LDS][M::NPAD];
+  alignas(16) double yy[M::NPAD], yp[M::NPAD], delta[M::NPAD];
   // structured Jacobian pool (cj not included)
   double ceL[NE], ceD[NE], ceU[NE], ceJ[NE];
   double peL[NE], peD[NE], peU[NE], pcL[NE], pcD[NE], pcU[NE], peJ[NE];
@@ -222,12 +229,12 @@ template <class M> struct CellLDS {
   double colI[M::THERMAL ? 1 : 3][M::THERMAL ? 1 : NE];            // column of I after the local elimination (Phi_s ends; + j_s coupling with SEI)
   typename M::fact_t Dinv[M::NB * M::NB][NE], LD[M::NB * M::NB][NE];   // Thomas factors: D'^-1 and L D'^-1(prev)
   typename M::fact_t LDmid[M::NB * M::NB];                             // closing block of the twisted factorisation
-  typename M::fact_t Ainv[2][(M::THERMAL || M::SD != 0) ? 1 : NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
+  alignas(16) typename M::fact_t Ainv[2][(M::THERMAL || M::SD != 0) ? 1 : NR * NR];          // particle resolvents (kappa M - cj I)^-1 for the p / n electrode (row-major)
   // radial operator (copy of Tables::M) followed by
   // its eigen-decomposition (copies of Tables::V, W, LAM): the resolvents are rebuilt from them at every Jacobian refresh, and reading the tables from HBM there cost
   // 9.7 k cycles per refresh (two dependent rounds of global / scalar loads); from LDS, with the 2 N_r^2 entries spread over the wave, 1 k
   // (one array, so that the models without it -- thermal: 40 952 of the 40 960 B that four cells per CU allow -- pay 8 bytes, not 32)
-  double Mr[(M::THERMAL || M::SD != 0) ? 1 : 3 * NR * NR + NR];
+  alignas(16) double Mr[M::SD != 0 ? 1 : (M::THERMAL ? 3 * NR * NR : 3 * NR * NR + NR)];      // (thermal: M, V, W; the eigenvalues are only read at a factorisation)
   static constexpr int OFF_VR = NR * NR, OFF_WR = 2 * NR * NR, OFF_LAMR = 3 * NR * NR;
   double resp[M::SD != 0 ? NJ : 1], rcjf[M::SD != 0 ? 2 : 1][2];    // quadratic / polynomial particles: d c_s* / d j after eliminating c_avg (and Q); 1/cj and 1/(-kappa - cj) of the factorisation
   double x2[M::THERMAL ? 1 : 3][M::THERMAL ? 1 : NE];      // (the thermal model keeps its own in ThermalPool: one placeholder element here)
@@ -253,7 +260,32 @@ template <class M> struct CellLDS {
 // per-lane registers that persist across phases
 struct LaneRegs {
   double wreg[CS_PASS]; // particle partial solutions kept across the Thomas phase
+  double rcp[CS_PASS];  // thermal model: 1 / (kappa_p lam_r - cj) of the last factorisation for this lane's (particle, radial mode) of each pass -- the spectral resolvent's diagonal
 };
+
+// An index the compiler must treat as opaque: `base + PL_OPAQUE_IDX(lane part)` keeps the lane-dependent part of an LDS address in ONE register and leaves the compile-time part to
+// the instruction's offset field.  Without it the constant parts of S.<array>[lane part + const] are folded into one large immediate per access, which ds_read2_b64's 8-bit
+// offsets cannot hold: the compiler then materialises a separate address (v_add / v_mad) for every pair of loads -- a quarter of the instructions of the particle phases.
+#ifdef PL_WAVE_EMU
+#define PL_OPAQUE_IDX(i) (i)
+typedef const double* lds_cptr;
+typedef double* lds_ptr;
+#define PL_LDS_BASE(p) (p)
+#define PL_LDS_BASE_A(A16, p) (p)
+#else
+__device__ __forceinline__ int pl_opaque_idx(int i) { __asm__("" : "+v"(i)); return i; }
+#define PL_OPAQUE_IDX(i) pl_opaque_idx(i)
+// The same for a whole LDS address: a 32-bit LDS pointer (address_space(3)) the compiler may not look into.  Accesses q[compile-time index] then use q's register plus
+// the instruction's offset field -- within the reach of ds_read2_b64 (2040 B) as long as the indices stay below 256.
+typedef const __attribute__((address_space(3))) double* lds_cptr;
+typedef __attribute__((address_space(3))) double* lds_ptr;
+__device__ __forceinline__ lds_cptr pl_lds_base(const double* p) { lds_cptr q = (lds_cptr)p; __asm__("" : "+v"(q)); return q; }
+__device__ __forceinline__ lds_ptr pl_lds_base(double* p) { lds_ptr q = (lds_ptr)p; __asm__("" : "+v"(q)); return q; }
+#define PL_LDS_BASE(p) pl_lds_base(p)
+// the same for an address the CALLER knows to be 16-byte aligned (A16 true; the asm hides that from the compiler): pairs q[2k], q[2k+1] then load as one ds_read_b128
+template <bool A16> __device__ __forceinline__ lds_cptr pl_lds_base_a(const double* p) { lds_cptr q = pl_lds_base(p); if constexpr (A16) __builtin_assume(((unsigned)(__UINTPTR_TYPE__)q & 15u) == 0u); return q; }
+#define PL_LDS_BASE_A(A16, p) pl_lds_base_a<A16>(p)
+#endif
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return (int)threadIdx.x >> 6; }     // 0 for the one-wave kernels; 0 / 1 for M::W2
@@ -321,7 +353,8 @@ enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_O
 #endif
 #define PL_TICE(mode) long long pl_t0__ = (PL_PHASE_DETAIL == (mode)) ? (long long)__builtin_readcyclecounter() : 0   /* mode 2: solve + residual, mode 3: step control + output */
 #define PL_TOCE(S_, mode, slot) do { if (PL_PHASE_DETAIL == (mode)) PL_LAP_(S_, slot); } while (0)
-#elif defined(PL_ASM_MARKS)      /* ISA inspection builds (tools/asm/): the timer positions become comment markers in the assembly (each one is also a compiler barrier) */
+#elif defined(PL_ASM_MARKS)
+#define PL_AMARK(txt) __asm__ volatile("; PLMARK " txt ::: "memory")      /* named positions for tools/asm/isa.py (nothing in every other build) */      /* ISA inspection builds (tools/asm/): the timer positions become comment markers in the assembly (each one is also a compiler barrier) */
 #define PL_MARK_(txt) __asm__ volatile("; PLMARK " txt ::: "memory")
 #define PL_STR2_(x) #x
 #define PL_STR_(x) PL_STR2_(x)
@@ -342,6 +375,9 @@ enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_O
 #define PL_TOCD(S_, slot) do {} while (0)
 #define PL_TICE(mode) do {} while (0)
 #define PL_TOCE(S_, mode, slot) do {} while (0)
+#endif
+#ifndef PL_AMARK
+#define PL_AMARK(txt) do {} while (0)
 #endif
 __host__ __device__ __forceinline__ int sec_of(int i) { return i < NP ? 0 : (i < NP + NS ? 1 : 2); }
 // ---- cross-lane primitives.  gfx950: DPP moves (probed on hardware, tools/probes/dpp_probe.hip: wave_shr:1 / wave_shl:1 shift
@@ -623,10 +659,10 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
       S.sei.cjf = 0.0;
     }
   }
-  if constexpr (!M::THERMAL && M::SD == 0) { if (wave_id() == M::NWAVES - 1) {
-    for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->Mp()[k]; S.Mr[S.OFF_VR + k] = tb->Vp()[k]; S.Mr[S.OFF_WR + k] = tb->Wp()[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; }
-    if (lane < NR) S.Mr[S.OFF_LAMR + lane] = tb->LAMp()[lane]; } }
-  for (int k = 0; k < CS_PASS; k++) R.wreg[k] = 0.0;
+  if constexpr (M::SD == 0) { if (wave_id() == M::NWAVES - 1) {
+    for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->Mp()[k]; S.Mr[S.OFF_VR + k] = tb->Vp()[k]; S.Mr[S.OFF_WR + k] = tb->Wp()[k]; if constexpr (!M::THERMAL) { S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
+    if constexpr (!M::THERMAL) { if (lane < NR) S.Mr[S.OFF_LAMR + lane] = tb->LAMp()[lane]; } } }
+  for (int k = 0; k < CS_PASS; k++) { R.wreg[k] = 0.0; R.rcp[k] = 0.0; }
   PL_XSYNC();
   if constexpr (M::THERMAL) thermal_setup(S, tb, th);
 }
@@ -1001,6 +1037,12 @@ __device__ __forceinline__ void node_block(const CellLDS<M>& S, int i, double cj
   }
 }
 
+// r - a.b and r + a.b for short dot products, written so that every term is ONE fused multiply-add onto the running value (r - (a0 b0 + a1 b1 + a2 b2) is a multiply, two
+// fmas and a subtraction: four dependent instructions where three do) -- the inner statement of every sweep stage
+#define PL_NMS3(r, a0, b0, a1, b1, a2, b2) ((((r) - (a0) * (b0)) - (a1) * (b1)) - (a2) * (b2))
+#define PL_PMS3(r, a0, b0, a1, b1, a2, b2) ((((r) + (a0) * (b0)) + (a1) * (b1)) + (a2) * (b2))
+#define PL_NMS4(r, a0, b0, a1, b1, a2, b2, a3, b3) (((((r) - (a0) * (b0)) - (a1) * (b1)) - (a2) * (b2)) - (a3) * (b3))
+
 // ---- twisted (two-ended) block-Thomas in a mirrored lane layout ----
 // Nodes 0..14 are eliminated forwards and live in lanes 0..14; nodes 29..15 are eliminated backwards and live in lanes 32..46 (node 29 in
 // lane 32), so BOTH halves run the same "take the value of the lane below" recurrence (one DPP wave_shr:1 per value and stage) and the
@@ -1059,27 +1101,27 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only
       for (int k = 0; k < 9; k++) Cs[k] = shift_up1(C[k]);                     // C of the previous node of the chain
       for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) P[a * 3 + b] = C[a * 3] * Cs[b] + C[a * 3 + 1] * Cs[3 + b] + C[a * 3 + 2] * Cs[6 + b];
       const double s0 = shift_up1(r0), s1 = shift_up1(r1), s2 = shift_up1(r2);
-      r0 -= C[0] * s0 + C[1] * s1 + C[2] * s2; r1 -= C[3] * s0 + C[4] * s1 + C[5] * s2; r2 -= C[6] * s0 + C[7] * s1 + C[8] * s2;
+      r0 = PL_NMS3(r0, C[0], s0, C[1], s1, C[2], s2); r1 = PL_NMS3(r1, C[3], s0, C[4], s1, C[5], s2); r2 = PL_NMS3(r2, C[6], s0, C[7], s1, C[8], s2);
     }
     y0 = r0; y1 = r1; y2 = r2;
     constexpr int NST2 = (TW_FWD - 1 + 1) / 2;                               // the last node of the longer half is TW_FWD - 1 steps from its head
     _Pragma("unroll") for (int it = 0; it < NST2; it++) {
       const double p0 = row_up2(y0), p1 = row_up2(y1), p2 = row_up2(y2);
-      y0 = r0 + (P[0] * p0 + P[1] * p1 + P[2] * p2); y1 = r1 + (P[3] * p0 + P[4] * p1 + P[5] * p2); y2 = r2 + (P[6] * p0 + P[7] * p1 + P[8] * p2);
+      y0 = PL_PMS3(r0, P[0], p0, P[1], p1, P[2], p2); y1 = PL_PMS3(r1, P[3], p0, P[4], p1, P[5], p2); y2 = PL_PMS3(r2, P[6], p0, P[7], p1, P[8], p2);
     }
   } else {
   y0 = r0; y1 = r1; y2 = r2;
   // the stage loops are fully unrolled for the models without aging (no loop bookkeeping between the DPP shifts: +2.7 % on C4, +0.9 % on C2); with SEI, whose integrate
   // kernel is already out of registers, that costs 1.8 %, so it keeps the loop unrolled by two
 #define PL_FWD_STAGE { const double p0 = shift_up1(y0), p1 = shift_up1(y1), p2 = shift_up1(y2); \
-    y0 = r0 - (C[0] * p0 + C[1] * p1 + C[2] * p2); y1 = r1 - (C[3] * p0 + C[4] * p1 + C[5] * p2); y2 = r2 - (C[6] * p0 + C[7] * p1 + C[8] * p2); }
+    y0 = PL_NMS3(r0, C[0], p0, C[1], p1, C[2], p2); y1 = PL_NMS3(r1, C[3], p0, C[4], p1, C[5], p2); y2 = PL_NMS3(r2, C[6], p0, C[7], p1, C[8], p2); }
   if constexpr (M::SEI) { _Pragma("unroll 2") for (int it = 1; it < TW_FWD; it++) PL_FWD_STAGE }
   else { _Pragma("unroll") for (int it = 1; it < TW_FWD; it++) PL_FWD_STAGE }
 #undef PL_FWD_STAGE
   }
   {   // closing node: y_mid -= (L_mid Dinv_{mid-1}) y_{mid-1}
     const double m0 = lane_bcast(y0, TW_MID - 1), m1 = lane_bcast(y1, TW_MID - 1), m2 = lane_bcast(y2, TW_MID - 1);
-    y0 -= Lm[0] * m0 + Lm[1] * m1 + Lm[2] * m2; y1 -= Lm[3] * m0 + Lm[4] * m1 + Lm[5] * m2; y2 -= Lm[6] * m0 + Lm[7] * m1 + Lm[8] * m2;
+    y0 = PL_NMS3(y0, Lm[0], m0, Lm[1], m1, Lm[2], m2); y1 = PL_NMS3(y1, Lm[3], m0, Lm[4], m1, Lm[5], m2); y2 = PL_NMS3(y2, Lm[6], m0, Lm[7], m1, Lm[8], m2);
   }
   double z0 = Di[0] * y0 + Di[1] * y1 + Di[2] * y2, z1 = Di[3] * y0 + Di[4] * y1 + Di[5] * y2, z2 = Di[6] * y0 + Di[7] * y1 + Di[8] * y2;
   {   // ghost of the closing node in lane TW_MID (its G is zero: it just holds x_mid for lane TW_MID-1)
@@ -1094,18 +1136,18 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only
       for (int k = 0; k < 9; k++) Gs[k] = shift_down1(G[k]);
       for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Q[a * 3 + b] = G[a * 3] * Gs[b] + G[a * 3 + 1] * Gs[3 + b] + G[a * 3 + 2] * Gs[6 + b];
       const double s0 = shift_down1(z0), s1 = shift_down1(z1), s2 = shift_down1(z2);
-      z0 -= G[0] * s0 + G[1] * s1 + G[2] * s2; z1 -= G[3] * s0 + G[4] * s1 + G[5] * s2; z2 -= G[6] * s0 + G[7] * s1 + G[8] * s2;
+      z0 = PL_NMS3(z0, G[0], s0, G[1], s1, G[2], s2); z1 = PL_NMS3(z1, G[3], s0, G[4], s1, G[5], s2); z2 = PL_NMS3(z2, G[6], s0, G[7], s1, G[8], s2);
     }
     x0 = z0; x1 = z1; x2 = z2;
     constexpr int NST2 = (TW_MID + 1) / 2;                                    // lane 0 is TW_MID steps from the ghost of the closing node
     _Pragma("unroll") for (int it = 0; it < NST2; it++) {
       const double q0 = row_down2(x0), q1 = row_down2(x1), q2 = row_down2(x2);
-      x0 = z0 + (Q[0] * q0 + Q[1] * q1 + Q[2] * q2); x1 = z1 + (Q[3] * q0 + Q[4] * q1 + Q[5] * q2); x2 = z2 + (Q[6] * q0 + Q[7] * q1 + Q[8] * q2);
+      x0 = PL_PMS3(z0, Q[0], q0, Q[1], q1, Q[2], q2); x1 = PL_PMS3(z1, Q[3], q0, Q[4], q1, Q[5], q2); x2 = PL_PMS3(z2, Q[6], q0, Q[7], q1, Q[8], q2);
     }
   } else {
   x0 = z0; x1 = z1; x2 = z2;
 #define PL_BWD_STAGE { const double q0 = shift_down1(x0), q1 = shift_down1(x1), q2 = shift_down1(x2); \
-    x0 = z0 - (G[0] * q0 + G[1] * q1 + G[2] * q2); x1 = z1 - (G[3] * q0 + G[4] * q1 + G[5] * q2); x2 = z2 - (G[6] * q0 + G[7] * q1 + G[8] * q2); }
+    x0 = PL_NMS3(z0, G[0], q0, G[1], q1, G[2], q2); x1 = PL_NMS3(z1, G[3], q0, G[4], q1, G[5], q2); x2 = PL_NMS3(z2, G[6], q0, G[7], q1, G[8], q2); }
   if constexpr (M::SEI) { _Pragma("unroll 2") for (int it = 0; it < TW_MID; it++) PL_BWD_STAGE }
   else { _Pragma("unroll") for (int it = 0; it < TW_MID; it++) PL_BWD_STAGE }
 #undef PL_BWD_STAGE
@@ -1230,7 +1272,7 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
         LDm[6 + k] = a22 * P[6 + k];
       }
       for (int rr = 0; rr < 3; rr++) {
-        Dn[rr * 3 + 0] = D[rr * 3 + 0] - (LDm[rr * 3 + 0] * b00 + LDm[rr * 3 + 1] * b10);
+        Dn[rr * 3 + 0] = (D[rr * 3 + 0] - LDm[rr * 3 + 0] * b00) - LDm[rr * 3 + 1] * b10;
         Dn[rr * 3 + 1] = D[rr * 3 + 1] - LDm[rr * 3 + 1] * b11;
         Dn[rr * 3 + 2] = D[rr * 3 + 2] - LDm[rr * 3 + 2] * b22;
       }
@@ -1243,7 +1285,7 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
       const double e00 = alg_only ? 0.0 : S.ceU[TW_MID - 1], e10 = alg_only ? 0.0 : S.pcU[TW_MID - 1], e11 = S.peU[TW_MID - 1], e22 = c22;
       for (int k = 0; k < 3; k++) { L2[k] = c00 * P[k]; L2[3 + k] = c10 * P[k] + c11 * P[3 + k]; L2[6 + k] = c22 * P[6 + k]; }
       for (int rr = 0; rr < 3; rr++) {
-        Dm[rr * 3 + 0] = Dn[rr * 3 + 0] - (L2[rr * 3 + 0] * e00 + L2[rr * 3 + 1] * e10);
+        Dm[rr * 3 + 0] = (Dn[rr * 3 + 0] - L2[rr * 3 + 0] * e00) - L2[rr * 3 + 1] * e10;
         Dm[rr * 3 + 1] = Dn[rr * 3 + 1] - L2[rr * 3 + 1] * e11;
         Dm[rr * 3 + 2] = Dn[rr * 3 + 2] - L2[rr * 3 + 2] * e22;
       }

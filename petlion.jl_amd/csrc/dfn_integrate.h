@@ -54,6 +54,11 @@ __device__ __forceinline__ void cnt_add(Counters& c, int k, int v = 1) { c.v[k] 
 #define EE(n) I.ee[k__]
 // some BDF history orders live in registers (thermal model): the step-control passes then index the history with compile-time orders under wave-uniform branches
 template <class M> constexpr bool PHI_REGS = M::PHI_LDS <= MAXORD;
+#ifdef PL_EXP_BRANCHY_PHI
+constexpr bool PL_BRANCHY_PHI = true;
+#else
+constexpr bool PL_BRANCHY_PHI = false;
+#endif
 #define PL_VEC(n) _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wave_id()); vok<M>(k__, lane, wave_id()))
 
 template <class M>
@@ -194,7 +199,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
                                                       int mode, double value, double reltol_init, double* bsave = nullptr, int nref = 0, const plh_run* frun = nullptr, double t_fun = 0.0,
                                                       GenRow* g = nullptr) {
   LaneRegs R;                                                        // (the algebraic solves do not touch the particle registers)
-  for (int k = 0; k < CS_PASS; k++) R.wreg[k] = 0.0;
+  for (int k = 0; k < CS_PASS; k++) { R.wreg[k] = 0.0; R.rcp[k] = 0.0; }
   int iters = 0;
   PL_MODEL(M);
   const int lane = lane_id();
@@ -357,6 +362,7 @@ template <class M>
 PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
   PL_MODEL(M);
   const int lane = lane_id();
+  PL_AMARK("form_iterate");
   if (M::PRED_REGS && !first) {          // the predictor of this step is already in registers
     PL_VEC(n) { const double e = EE(n); S.yy[n] = I.pa[k__] + e; S.yp[n] = I.pb[k__] + I.cj * e; }
     PL_XSYNC();
@@ -366,6 +372,22 @@ PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
   // loop over the orders would expose one LDS round trip per order and trip); same summation order as before
   double a[NTRIP], b[NTRIP];
   PL_VEC(n) { a[k__] = S.phi[0][n]; b[k__] = 0.0; }
+  if constexpr (PHI_REGS<M> && !PL_BRANCHY_PHI) {
+    // History orders that live in registers (thermal model): NO control flow around them.  A wave-uniform branch whose arm rewrites a register-resident order makes the
+    // compiler reconcile the whole register array at the join (hundreds of v_mov per call, r03: 12 cycles per instruction in the step-control phases); instead every order is
+    // processed with wave-uniform 0 / 1 factors -- p * 1.0, fma(0.0, p, a) and fma(1.0, p, a) are exact, so the sums are the ones of the branching form, bit for bit.
+    _Pragma("unroll") for (int j = 1; j <= MAXORD; j++) {
+      if (j < M::PHI_LDS) {                      // (orders kept in LDS: j <= kk always holds for them, kk >= 1)
+        const double g = S.ida_gamma[j];
+        if (first && j >= I.ns) { const double bt = S.ida_beta[j]; PL_VEC(n) { const double p = S.phi[j][n] * bt; S.phi[j][n] = p; a[k__] += p; b[k__] += g * p; } }
+        else PL_VEC(n) { const double p = S.phi[j][n]; a[k__] += p; b[k__] += g * p; }
+      } else {
+        const bool on = j <= I.kk;
+        const double m = on ? 1.0 : 0.0, mg = on ? S.ida_gamma[j <= MAXORD ? j : 0] : 0.0, bt = (on && first && j >= I.ns) ? S.ida_beta[j] : 1.0;
+        PL_VEC(n) { const double p = PHI_RD(j, n) * bt; PHI_WR(j, n, p); a[k__] += m * p; b[k__] += mg * p; }
+      }
+    }
+  } else
   _Pragma("unroll") for (int j = 1; j <= MAXORD; j++) if (j <= I.kk) {
     const double g = S.ida_gamma[j];
     if (first && j >= I.ns) {            // the rescaling of IDASetCoeffs (see ida_set_coeffs)
@@ -375,6 +397,7 @@ PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
   }
   PL_VEC(n) { const double e = EE(n); S.yy[n] = a[k__] + e; S.yp[n] = b[k__] + I.cj * e; if (M::PRED_REGS) { I.pa[k__] = a[k__]; I.pb[k__] = b[k__]; } }
   PL_XSYNC();
+  PL_AMARK("form_iterate end");
 }
 
 // IDANls + Newton + convergence test.  0 ok, 1 recoverable failure
@@ -459,6 +482,7 @@ PL_DEV int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, double& err_k
   PL_MODEL(M);
   const int lane = lane_id();
   const int kk = I.kk;
+  PL_AMARK("test_error");
   double s0 = 0, s1 = 0, s2 = 0;
   // phi[kk], phi[kk-1] through a compile-time order index (wave-uniform branches): the history orders that live in registers (thermal model) are then read directly
   // instead of through a select chain per element
@@ -495,6 +519,7 @@ PL_DEV int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, double& err_k
       if ((terr_km1 > terr_km2 ? terr_km1 : terr_km2) <= terr_k) I.knew = kk - 1;
     } else if (terr_km1 <= 0.5 * terr_k) I.knew = kk - 1;
   }
+  PL_AMARK("test_error end");
   return (ck * enorm_k > 1.0) ? 1 : 0;
 }
 
@@ -520,6 +545,7 @@ template <class M>
 PL_DEV bool ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double err_km1, double tstop) {
   PL_MODEL(M);
   const int lane = lane_id();
+  PL_AMARK("complete_step");
   I.nst++;
   const int kdiff = I.kk - I.kused; I.kused = I.kk; I.hused = I.hh;
   if (I.knew == I.kk - 1 || I.kk == I.maxord) I.phase = 1;
@@ -565,13 +591,35 @@ PL_DEV bool ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double
     double acc[NTRIP], sp[NTRIP];
     const double dku = ku == 1 ? dc1 : ku == 2 ? dc2 : ku == 3 ? dc3 : ku == 4 ? dc4 : dc5;
     // (the order index of every history access is a compile-time constant under a wave-uniform branch: direct register access for the orders kept in registers)
-    if constexpr (PHI_REGS<M>) {
+    if constexpr (PHI_REGS<M> && PL_BRANCHY_PHI) {      // (r03 form, kept for same-box A/B builds: tools/experiments/build_modes.py th_branchy)
       _Pragma("unroll") for (int j = MAXORD; j >= 0; j--) {
         if (j == ku + 1 && ku < I.maxord) { PL_VEC(n) PHI_WR(j, n, EE(n)); }
         else if (j == ku) { PL_VEC(n) { acc[k__] = PHI_RD(j, n) + EE(n); PHI_WR(j, n, acc[k__]); sp[k__] = dku * acc[k__]; } }
         else if (j < ku) {
           const double dj = j == 1 ? dc1 : j == 2 ? dc2 : j == 3 ? dc3 : j == 4 ? dc4 : 0.0;       // (j = 0: phi[0] does not enter y')
           PL_VEC(n) { acc[k__] += PHI_RD(j, n); PHI_WR(j, n, acc[k__]); if (j > 0) sp[k__] += dj * acc[k__]; }
+        }
+      }
+    } else if constexpr (PHI_REGS<M>) {
+      // branch-free over the register-resident orders (see form_iterate): the running sum starts as ee, order j joins it iff j <= ku (factor 1.0 / 0.0: exact), takes the
+      // sum back iff j <= ku, takes ee iff j = ku + 1 < = maxord, and enters y' with d_{j-1} (0 for the orders that are not part of the step: dc_j is 0 beyond ku)
+      (void)dku;
+      const bool grow = ku < I.maxord;
+      PL_VEC(n) { acc[k__] = EE(n); sp[k__] = 0.0; }
+      _Pragma("unroll") for (int j = MAXORD; j >= 0; j--) {
+        const double dj = j == 1 ? dc1 : j == 2 ? dc2 : j == 3 ? dc3 : j == 4 ? dc4 : j == 5 ? dc5 : 0.0;       // (j = 0: phi[0] does not enter y')
+        if (j < M::PHI_LDS) {                    // LDS orders 0 .. PHI_LDS - 1 <= ku: always part of the sum
+          PL_VEC(n) { acc[k__] += S.phi[j][n]; S.phi[j][n] = acc[k__]; if (j > 0) sp[k__] += dj * acc[k__]; }
+        } else {
+          const bool in = j <= ku, take_ee = grow && j == ku + 1;
+          const double m = in ? 1.0 : 0.0;
+          PL_VEC(n) {
+            const double ph = PHI_RD(j, n), e = EE(n);
+            const double an = acc[k__] + m * ph;           // (contracts to one fma on the GPU; m * ph is exact either way)
+            acc[k__] = an;
+            PHI_WR(j, n, in ? an : (take_ee ? e : ph));
+            sp[k__] += dj * an;
+          }
         }
       }
     } else {
@@ -584,6 +632,7 @@ PL_DEV bool ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double
     if (!at_tstop) { PL_VEC(n) { S.yy[n] = acc[k__]; S.yp[n] = sp[k__]; } }
   }
   PL_XSYNC();
+  PL_AMARK("complete_step end");
   return !at_tstop;
 }
 

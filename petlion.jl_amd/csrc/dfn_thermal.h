@@ -73,6 +73,13 @@ __device__ __forceinline__ int tsec_of(int it) { return it < NA ? 0 : (it < NA +
 // ------------------------------------------------------------------------------------------------------------------
 // constants of the heat equation (lanes 0..49 own one T node each)
 // ------------------------------------------------------------------------------------------------------------------
+// diagonal of the scaled heat-conduction stencil, aD = -(aL + aU) - (convective coefficient at the two outer faces): every interior and interface row of residuals_T!
+// conserves the conductive flux (residuals.jl:299-489), so the diagonal need not be stored (Jacobian entries only -- the residual uses the difference form)
+template <class TP_> __device__ __forceinline__ double thermal_aD(const TP_& TP, int it) {
+  const double e = it == 0 ? TP.aC2[0] : (it == NT - 1 ? TP.aC2[1] : 0.0);
+  return -(TP.aL[it] + TP.aU[it]) - e;
+}
+
 template <class M>
 PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th) {
   static_assert((M::CHEM == PLH_CHEM_LCO_LIC6 || M::CHEM == PLH_CHEM_LGM50) && !M::SEI, "temperature = true is instantiated for LCO/LiC6 and NMC_LGM50/LiC6_LGM50 without aging");
@@ -116,7 +123,8 @@ PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const do
     if (it == 0) { aD -= hc / h; aC = hc * Tamb / h; }                   // convective BCs at the two outer faces
     if (it == NT - 1) { aD -= hc / h; aC = hc * Tamb / h; }
     const double rc = 1.0 / rcp[k];
-    TP.aL[it] = aL * rc; TP.aD[it] = aD * rc; TP.aU[it] = aU * rc;
+    TP.aL[it] = aL * rc; TP.aU[it] = aU * rc;      // (aD: thermal_aD)
+    (void)aD;
     if (it == 0) TP.aC2[0] = hc / h * rc;                                 // (the end rows are evaluated as  aL (T_l - T) + aU (T_r - T) + aC2 (T_amb - T): see thermal_node_pass)
     if (it == NT - 1) TP.aC2[1] = hc / h * rc;
     if (loc == 0) TP.rc5[k] = rc;
@@ -350,9 +358,8 @@ PL_DEV void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const 
   auto& TP = S.th;
   const int r = lane % NR, g = lane < CS_LANES ? lane / NR : CS_G - 1;
   double Mrow[NR], Wrow[NR];
-  // (the radial operator is a compile-time table of this translation unit: global loads from a constant base, on their own counter -- through `tb`, a pointer that went
-  //  through LDS, they were FLAT loads, which also occupy the LDS counter and serialise against the LDS traffic of the pass)
-  for (int k = 0; k < NR; k++) { Mrow[k] = PL_RADIAL_M[r * NR + k]; if (WANT_JAC) Wrow[k] = PL_RADIAL_W[r * NR + k]; }
+  // (the radial operator from its LDS copy, as in the isothermal models: r03 fetched it from the table in global memory in every residual and every solve)
+  for (int k = 0; k < NR; k++) { Mrow[k] = S.Mr[r * NR + k]; if (WANT_JAC) Wrow[k] = S.Mr[S.OFF_WR + r * NR + k]; }
 #pragma unroll
   for (int pass = 0; pass < CS_PASS; pass++) {
     const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
@@ -399,24 +406,44 @@ __device__ __forceinline__ void inv4(const double* A, double* B) {
 // the sparse off-diagonal node blocks.  Lower block of node i (rows of i x unknowns of i-1) / upper block (rows of i x unknowns of i+1):
 //   [ ce 0 0 0 ; pc pe 0 pt ; 0 0 s 0 ; Tc Te Ts Tt ]
 struct OffBlk { double ce, pc, pe, pt, s, Tc, Te, Ts, Tt; };
+// (every LDS operand is loaded unconditionally -- i is a valid node in every lane -- and masked afterwards: `cond ? 0.0 : S.x[i]` compiles to one exec-masked branch with
+//  its own LDS round trip PER ELEMENT, which serialised the prologue of every solve: 16 + 16 + 9 dependent round trips in thermal_sweeps)
 template <class M> __device__ __forceinline__ OffBlk lower_blk(const CellLDS<M>& S, int i, bool alg_only) {
   OffBlk b; const auto& TP = S.th;
   const int sci = sec_of(i), scp = sec_of(i > 0 ? i - 1 : 0);
   const bool z = i == 0;
-  b.ce = (alg_only || z) ? 0.0 : S.ceL[i]; b.pc = (alg_only || z) ? 0.0 : S.pcL[i]; b.pe = z ? 0.0 : S.peL[i]; b.pt = (alg_only || z) ? 0.0 : TP.ptL[i];
-  b.s = (!z && sci != 1 && scp == sci) ? 1.0 : 0.0;
+  const double ce = S.ceL[i], pc = S.pcL[i], pe = S.peL[i], pt = TP.ptL[i], Tc = TP.TcL[i], Te = TP.TeL[i], Ts = TP.TsL[i], Tt = TP.aL[NA + i];
   const bool zt = alg_only || z;
-  b.Tc = zt ? 0.0 : TP.TcL[i]; b.Te = zt ? 0.0 : TP.TeL[i]; b.Ts = zt ? 0.0 : TP.TsL[i]; b.Tt = zt ? 0.0 : TP.aL[NA + i];
+  b.ce = zt ? 0.0 : ce; b.pc = zt ? 0.0 : pc; b.pe = z ? 0.0 : pe; b.pt = zt ? 0.0 : pt;
+  b.s = (!z && sci != 1 && scp == sci) ? 1.0 : 0.0;
+  b.Tc = zt ? 0.0 : Tc; b.Te = zt ? 0.0 : Te; b.Ts = zt ? 0.0 : Ts; b.Tt = zt ? 0.0 : Tt;
   return b;
 }
 template <class M> __device__ __forceinline__ OffBlk upper_blk(const CellLDS<M>& S, int i, bool alg_only) {
   OffBlk b; const auto& TP = S.th;
   const int sci = sec_of(i), scn = sec_of(i < NE - 1 ? i + 1 : NE - 1);
   const bool z = i == NE - 1;
-  b.ce = (alg_only || z) ? 0.0 : S.ceU[i]; b.pc = (alg_only || z) ? 0.0 : S.pcU[i]; b.pe = z ? 0.0 : S.peU[i]; b.pt = (alg_only || z) ? 0.0 : TP.ptU[i];
-  b.s = (!z && sci != 1 && scn == sci) ? 1.0 : 0.0;
+  const double ce = S.ceU[i], pc = S.pcU[i], pe = S.peU[i], pt = TP.ptU[i], Tc = TP.TcU[i], Te = TP.TeU[i], Ts = TP.TsU[i], Tt = TP.aU[NA + i];
   const bool zt = alg_only || z;
-  b.Tc = zt ? 0.0 : TP.TcU[i]; b.Te = zt ? 0.0 : TP.TeU[i]; b.Ts = zt ? 0.0 : TP.TsU[i]; b.Tt = zt ? 0.0 : TP.aU[NA + i];
+  b.ce = zt ? 0.0 : ce; b.pc = zt ? 0.0 : pc; b.pe = z ? 0.0 : pe; b.pt = zt ? 0.0 : pt;
+  b.s = (!z && sci != 1 && scn == sci) ? 1.0 : 0.0;
+  b.Tc = zt ? 0.0 : Tc; b.Te = zt ? 0.0 : Te; b.Ts = zt ? 0.0 : Ts; b.Tt = zt ? 0.0 : Tt;
+  return b;
+}
+// the block of node i on the side given per lane (top half: upper block, bottom half: lower block, or the other way round): ONE set of loads through a per-lane address
+template <class M> __device__ __forceinline__ OffBlk side_blk(const CellLDS<M>& S, int i, bool upper, bool alg_only) {
+  OffBlk b; const auto& TP = S.th;
+  const int sci = sec_of(i), scx = sec_of(upper ? (i < NE - 1 ? i + 1 : NE - 1) : (i > 0 ? i - 1 : 0));
+  const bool z = upper ? i == NE - 1 : i == 0;
+  // ceL / ceD / ceU ... are consecutive arrays of NE doubles: the upper block is the lower one 2 NE doubles further on (ceL, ceD, ceU; likewise pe, pc, pt, Tc, Te, Ts); aL -> aU: NT
+  const int o = upper ? 2 * NE : 0;
+  static_assert(sizeof(S.ceL) == NE * sizeof(double), "layout");
+  const double ce = (&S.ceL[0])[o + i], pc = (&S.pcL[0])[o + i], pe = (&S.peL[0])[o + i], pt = (&TP.ptL[0])[o + i], Tc = (&TP.TcL[0])[o + i], Te = (&TP.TeL[0])[o + i],
+               Ts = (&TP.TsL[0])[o + i], Tt = (&TP.aL[0])[(upper ? NT : 0) + NA + i];
+  const bool zt = alg_only || z;
+  b.ce = zt ? 0.0 : ce; b.pc = zt ? 0.0 : pc; b.pe = z ? 0.0 : pe; b.pt = zt ? 0.0 : pt;
+  b.s = (!z && sci != 1 && scx == sci) ? 1.0 : 0.0;
+  b.Tc = zt ? 0.0 : Tc; b.Te = zt ? 0.0 : Te; b.Ts = zt ? 0.0 : Ts; b.Tt = zt ? 0.0 : Tt;
   return b;
 }
 
@@ -431,7 +458,7 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
   // register diet: C (forward sweep), then Lm (closing), then G (backward sweep) are formed one after the other, so that at most two of the 4x4 blocks
   // are live at a time next to the integrator's per-lane state (the three at once were half of the register file); PL_SYNC keeps the loads where they are
   double C[16], Di[16];
-  for (int k = 0; k < 16; k++) { C[k] = act ? S.LD[k][i] : 0.0; Di[k] = act ? S.Dinv[k][i] : 0.0; }
+  for (int k = 0; k < 16; k++) { const double c = S.LD[k][i], d = S.Dinv[k][i]; C[k] = act ? c : 0.0; Di[k] = act ? d : 0.0; }
   // ---- the four T rows with a second-neighbour entry (one-sided stencils at nodes 0, 9, 20, 29) inside the twisted elimination ----
   // "far ahead" (node 0 -> node 2, node 29 -> node 27): eliminating x_0 puts -LD_1[:,3] (x) w into U_1, so node 1's (node 28's)
   // back-substitution block is G - (Dinv C[:,3]) (x) w, and x_0 (x_29) gets -Dinv[:,3] (w . x_2) after the sweep.
@@ -460,7 +487,7 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
       for (int q = 0; q < NRHS; q++) {
         const double p0 = shift_up1(y[q][0]), p1 = shift_up1(y[q][1]), p2 = shift_up1(y[q][2]), p3 = shift_up1(y[q][3]);
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) y[q][rr] = r[q][rr] - (C[rr * 4] * p0 + C[rr * 4 + 1] * p1 + C[rr * 4 + 2] * p2 + C[rr * 4 + 3] * p3);
+        for (int rr = 0; rr < 4; rr++) y[q][rr] = PL_NMS4(r[q][rr], C[rr * 4], p0, C[rr * 4 + 1], p1, C[rr * 4 + 2], p2, C[rr * 4 + 3], p3);
       }
     }
     if (seg < NSEG - 1) {                                   // right-hand side of node N_p - 1 / N_p + N_s: minus q . y(node N_p - 3 / N_p + N_s + 2), once that y is final
@@ -483,7 +510,7 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
   for (int q = 0; q < NRHS; q++) {
     const double m0 = lane_bcast(y[q][0], TW_MID - 1), m1 = lane_bcast(y[q][1], TW_MID - 1), m2 = lane_bcast(y[q][2], TW_MID - 1), m3 = lane_bcast(y[q][3], TW_MID - 1);
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) y[q][rr] -= Lm[rr * 4] * m0 + Lm[rr * 4 + 1] * m1 + Lm[rr * 4 + 2] * m2 + Lm[rr * 4 + 3] * m3;
+    for (int rr = 0; rr < 4; rr++) y[q][rr] = PL_NMS4(y[q][rr], Lm[rr * 4], m0, Lm[rr * 4 + 1], m1, Lm[rr * 4 + 2], m2, Lm[rr * 4 + 3], m3);
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) z[q][rr] = Di[rr * 4] * y[q][0] + Di[rr * 4 + 1] * y[q][1] + Di[rr * 4 + 2] * y[q][2] + Di[rr * 4 + 3] * y[q][3];
 #pragma unroll
@@ -493,7 +520,7 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
   PL_SYNC();
   double G[16];
   {
-    OffBlk u = top ? upper_blk(S, i, alg_only) : lower_blk(S, i, alg_only);     // back-substitution block (zero for the closing node)
+    OffBlk u = side_blk(S, i, top, alg_only);     // back-substitution block: upper for the top half, lower for the bottom half (zero for the closing node)
     if (!act || nd == TW_MID) { u.ce = u.pc = u.pe = u.pt = u.s = u.Tc = u.Te = u.Ts = u.Tt = 0.0; }
     for (int rr = 0; rr < 4; rr++) {       // G = Dinv U
       const double d0 = Di[rr * 4], d1 = Di[rr * 4 + 1], d2 = Di[rr * 4 + 2], d3 = Di[rr * 4 + 3];
@@ -515,7 +542,7 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
     for (int q = 0; q < NRHS; q++) {
       const double q0 = shift_down1(r[q][0]), q1 = shift_down1(r[q][1]), q2 = shift_down1(r[q][2]), q3 = shift_down1(r[q][3]);
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) r[q][rr] = z[q][rr] - (G[rr * 4] * q0 + G[rr * 4 + 1] * q1 + G[rr * 4 + 2] * q2 + G[rr * 4 + 3] * q3);
+      for (int rr = 0; rr < 4; rr++) r[q][rr] = PL_NMS4(z[q][rr], G[rr * 4], q0, G[rr * 4 + 1], q1, G[rr * 4 + 2], q2, G[rr * 4 + 3], q3);
     }
   }
 #pragma unroll
@@ -541,51 +568,67 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
   auto& TP = S.th;
   const int r = lane % NR, g = lane < CS_LANES ? lane / NR : CS_G - 1;
   PL_TICD();
-  // 1. particle resolvents in spectral form
+  // 1. particle resolvents in spectral form: A_p^-1 = V diag(1 / (kappa_p lam_m - cj)) W.  Lane (g, r) owns mode r of its particles and forms the reciprocals of ITS modes
+  //    only (CS_PASS divisions per lane; r03 divided inside the sums: N_r CS_PASS of them).  They stay in registers for the solves (R.rcp) and are shared with the other
+  //    lanes of the particle through the c_s section of S.yy, which is dead between a residual evaluation and the next form_iterate (thermal_solve uses it the same way).
   if (!alg_only) {
     if (lane < NJ) TP.kapF[lane] = TP.kapP[lane];
-    double Vrow[NR], wl[NR], lm[NR];
-    for (int m = 0; m < NR; m++) { Vrow[m] = PL_RADIAL_V[r * NR + m]; wl[m] = PL_RADIAL_W[m * NR + NR - 1]; lm[m] = PL_RADIAL_LAM[m]; }
-    double ae[CS_PASS], aq[CS_PASS];
+    const double lam_r = PL_RADIAL_LAM[r];
+    const int cs0 = PL_OPAQUE_IDX(g * NR + r);
+    double wc[CS_PASS];
+#pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) {
       const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
-      const double kp = TP.kapP[p];
-      ae[pass] = 0.0; aq[pass] = 0.0;
-      for (int m = 0; m < NR; m++) { const double f = Vrow[m] / (kp * lm[m] - cj); ae[pass] += f * wl[m]; aq[pass] += f * lm[m] * TP.AinvQ[p][m]; }   // AinvQ still holds W c
+      R.rcp[pass] = 1.0 / (TP.kapP[p] * lam_r - cj);
+      wc[pass] = (&TP.AinvQ[0][0])[(p0 < NJ ? pass * CS_G * NR : (NJ - 1 - g) * NR) + cs0];      // AinvQ still holds W c  (clamped like p)
     }
-    PL_SYNC();                                             // every lane has read W c before it is overwritten
+#pragma unroll
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      const int p0 = pass * CS_G + g;
+      if (lane < CS_LANES && p0 < NJ) { S.yy[O_CS + pass * CS_G * NR + cs0] = R.rcp[pass]; (&TP.AinvQ[0][0])[pass * CS_G * NR + cs0] = wc[pass] * R.rcp[pass]; }
+    }
+    PL_SYNC();
+    double VW[NR], VL[NR];                                  // V[r][m] W[m][last] and V[r][m] lam_m: the constant factors of the two sums
+    for (int m = 0; m < NR; m++) { const double v = S.Mr[S.OFF_VR + r * NR + m]; VW[m] = v * PL_RADIAL_W[m * NR + NR - 1]; VL[m] = v * PL_RADIAL_LAM[m]; }
+    double ae[CS_PASS], aq[CS_PASS];
+    const int pg0 = PL_OPAQUE_IDX(g * NR);
+#pragma unroll
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      const int p0 = pass * CS_G + g;
+      const int base = p0 < NJ ? pass * CS_G * NR + pg0 : (NJ - 1) * NR;
+      ae[pass] = 0.0; aq[pass] = 0.0;
+#pragma unroll
+      for (int m = 0; m < NR; m++) { ae[pass] += VW[m] * S.yy[O_CS + base + m]; aq[pass] += VL[m] * (&TP.AinvQ[0][0])[base + m]; }
+    }
+    PL_SYNC();                                             // every lane has read the shared reciprocals and W c / d before they are overwritten
+#pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) {
       const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
       if (lane < CS_LANES && p0 < NJ) { TP.AinvE[p][r] = ae[pass]; TP.AinvQ[p][r] = aq[pass] * TP.dkapP[p]; }
     }
-    // 2. collector chains: (aL, aD - cj, aU) x = rhs by the Thomas algorithm, lane 62 = Al, lane 63 = Cu.  Two fixed right-hand
-    //    sides: the coupling to T of the neighbouring cell node (Al: last row, through aU; Cu: first row, through aL) and the column of I
-    if (lane >= 62) {
-      const int q = lane - 62, base = q == 0 ? 0 : NA + NE;
-      // (all LDS operands are loaded up front and all results stored at the end: loads interleaved with stores inside the serial
-      //  recurrence would cost one LDS round trip per chain node)
+    // 2. collector chains: (aL, aD - cj, aU) x = rhs by the Thomas algorithm, lane 32 + k = collector node k (systolic DPP chains as in thermal_solve: one LDS load per
+    //    operand and lane).  Two fixed right-hand sides: the coupling to T of the neighbouring cell node (Al: last row, through aU; Cu: first row, through aL) and the column of I
+    {
+      const int ck = lane - 32;
+      const bool cact = ck >= 0 && ck < NA + NZ;
+      const int kq = cact ? ck : 0, q = kq < NA ? 0 : 1, kk = q == 0 ? kq : kq - NA, ic = q == 0 ? kk : NA + NE + kk, nq = q == 0 ? NA : NZ;
+      const double l_aL = TP.aL[ic], l_aU = TP.aU[ic], l_aD = thermal_aD(TP, ic), l_qij = TP.qIJ[q];
+      const bool head = !cact || kk == 0;
+      const double aLk = head ? 0.0 : l_aL, up = (cact && kk < nq - 1) ? l_aU : 0.0, dk = l_aD - cj, qij = cact ? l_qij : 0.0;
+      const double aU_prev = shift_up1(l_aU);
+      const double rcpl = !cact ? 0.0 : ((q == 0 && kk == NA - 1) ? l_aU : ((q == 1 && kk == 0) ? l_aL : 0.0));
       constexpr int NC = NA > NZ ? NA : NZ;
-      const int nq = q == 0 ? NA : NZ;                      // chain length: aluminium N_a, copper N_z
-      double aLv[NC], aDv[NC], aUv[NC], cp[NC], cm[NC], fc[NC], fi[NC], xcv[NC], xiv[NC];
-      for (int k = 0; k < NC; k++) if (k < nq) { aLv[k] = TP.aL[base + k]; aDv[k] = TP.aD[base + k]; aUv[k] = TP.aU[base + k]; }
-      const double qij = TP.qIJ[q];
-      for (int k = 0; k < NC; k++) if (k < nq) {
-        const double rcpl = (q == 0 && k == NA - 1) ? aUv[k] : ((q == 1 && k == 0) ? aLv[k] : 0.0);
-        if (k == 0) { cm[0] = 0.0; cp[0] = 1.0 / (aDv[0] - cj); fc[0] = rcpl; fi[0] = qij; }
-        else {
-          const double mlt = aLv[k] * cp[k - 1];
-          cm[k] = mlt;
-          cp[k] = 1.0 / ((aDv[k] - cj) - mlt * aUv[k - 1]);
-          fc[k] = rcpl - mlt * fc[k - 1]; fi[k] = qij - mlt * fi[k - 1];
-        }
+      double cp = 1.0 / dk, fc = rcpl, fi = qij;
+#pragma unroll 1
+      for (int st = 1; st < NC; st++) {
+        const double cpp = shift_up1(cp), fcp = shift_up1(fc), fip = shift_up1(fi);
+        const double mlt = aLk * cpp;
+        cp = 1.0 / (dk - mlt * aU_prev); fc = rcpl - mlt * fcp; fi = qij - mlt * fip;
       }
-      double xc = 0.0, xi = 0.0;
-      for (int k = NC - 1; k >= 0; k--) if (k < nq) {
-        const double up = k < nq - 1 ? aUv[k] : 0.0;
-        xc = (fc[k] - up * xc) * cp[k]; xi = (fi[k] - up * xi) * cp[k];
-        xcv[k] = xc; xiv[k] = xi;
-      }
-      for (int k = 0; k < NC; k++) if (k < nq) { TP.cM[q][k] = cm[k]; TP.cP[q][k] = cp[k]; TP.zc[q][k] = xcv[k]; TP.zI[q][k] = xiv[k]; }
+      double xc = fc * cp, xi = fi * cp;
+#pragma unroll
+      for (int st = 1; st < NC; st++) { const double xcn = shift_down1(xc), xin = shift_down1(xi); xc = (fc - up * xcn) * cp; xi = (fi - up * xin) * cp; }
+      if (cact) { TP.cP[q][kk] = cp; TP.zc[q][kk] = xc; TP.zI[q][kk] = xi; }
     }
   }
   PL_SYNC();
@@ -610,9 +653,10 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       if (i == 0) cI3 = -TP.aL[NA] * TP.zI[0][NA - 1];
       if (i == NE - 1) cI3 = -TP.aU[NA + NE - 1] * TP.zI[1][0];
     }
-    TP.tq[0][i] = t0; TP.tq[1][i] = t1; TP.tq[2][i] = t2; TP.tq[3][i] = t3;
-    TP.phi4[0][i] = p0; TP.phi4[1][i] = p1; TP.phi4[2][i] = p2; TP.phi4[3][i] = p3;
-    TP.colI4[0][i] = cI2; TP.colI4[1][i] = cI3;
+    (void)t0; (void)t1; (void)t2; (void)p0; (void)p1; (void)p2;      // (formed again where they are used, from ceJ / peJ / psJ and gce / gpe / gps, dj: thermal_tq / thermal_phi)
+    TP.tq3[i] = t3; TP.phi3[i] = p3;
+    if (i == 0) { TP.cI4[0] = cI2; TP.cI4[1] = cI3; }
+    if (i == NE - 1) { TP.cI4[2] = cI2; TP.cI4[3] = cI3; }
   }
   if (lane == 0) TP.cjf = cj;
   PL_SYNC();
@@ -630,7 +674,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     if (alg_only) { D[0] = 1.0; D[15] = 1.0; }
     else {
       D[0] = S.ceD[i] - cj; D[4] = S.pcD[i]; D[7] = TP.ptD[i];
-      D[12] = TP.TcD[i]; D[13] = TP.TeD[i]; D[14] = TP.TsD[i]; D[15] = TP.aD[NA + i] - cj + TP.TtD[i];
+      D[12] = TP.TcD[i]; D[13] = TP.TeD[i]; D[14] = TP.TsD[i]; D[15] = thermal_aD(TP, NA + i) - cj + TP.TtD[i];
       if (elec) D[15] -= TP.Tcs[jx] * TP.AinvQ[jx][NR - 1];
       if (i == 0) D[15] -= TP.aL[NA] * TP.zc[0][NA - 1];
       if (i == NE - 1) D[15] -= TP.aU[NA + NE - 1] * TP.zc[1][0];
@@ -640,7 +684,11 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     if (elec) {
       const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
       D[10] = (first || last) ? -1.0 : -2.0;
-      for (int rr = 0; rr < 4; rr++) for (int cc = 0; cc < 4; cc++) D[rr * 4 + cc] -= TP.tq[rr][i] * TP.phi4[cc][i];
+      {
+        const double rd = S.dj[jx];
+        const double tqv[4] = {alg_only ? 0.0 : S.ceJ[i], S.peJ[i], S.psJ[jx], TP.tq3[i]}, phv[4] = {alg_only ? 0.0 : S.gce[jx] * rd, S.gpe[jx] * rd, S.gps[jx] * rd, TP.phi3[i]};
+        for (int rr = 0; rr < 4; rr++) for (int cc = 0; cc < 4; cc++) D[rr * 4 + cc] -= tqv[rr] * phv[cc];
+      }
     }
     // a = left block (L_n top / U_n bottom), b = right block (U_{n-1} top / L_{n+1} bottom); zero at the chain heads and in idle lanes
     OffBlk a = top ? lower_blk(S, i, alg_only) : upper_blk(S, i, alg_only);
@@ -677,10 +725,10 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       for (int k = 0; k < 16; k++) D[k] = park[k * NE];
       for (int rr = 0; rr < 4; rr++) {
         const double a0 = LDm[rr * 4], a1 = LDm[rr * 4 + 1], a2 = LDm[rr * 4 + 2], a3 = LDm[rr * 4 + 3];
-        Dn[rr * 4 + 0] = D[rr * 4 + 0] - (a0 * b.ce + a1 * b.pc + a3 * b.Tc);
-        Dn[rr * 4 + 1] = D[rr * 4 + 1] - (a1 * b.pe + a3 * b.Te);
-        Dn[rr * 4 + 2] = D[rr * 4 + 2] - (a2 * b.s + a3 * b.Ts);
-        Dn[rr * 4 + 3] = D[rr * 4 + 3] - (a1 * b.pt + a3 * b.Tt);
+        Dn[rr * 4 + 0] = ((D[rr * 4 + 0] - a0 * b.ce) - a1 * b.pc) - a3 * b.Tc;
+        Dn[rr * 4 + 1] = (D[rr * 4 + 1] - a1 * b.pe) - a3 * b.Te;
+        Dn[rr * 4 + 2] = (D[rr * 4 + 2] - a2 * b.s) - a3 * b.Ts;
+        Dn[rr * 4 + 3] = (D[rr * 4 + 3] - a1 * b.pt) - a3 * b.Tt;
       }
       if (nd == 2 || nd == NE - 3) {
         for (int rr = 0; rr < 4; rr++) {
@@ -727,10 +775,10 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       }
       for (int rr = 0; rr < 4; rr++) {
         const double a0 = L2[rr * 4], a1 = L2[rr * 4 + 1], a2 = L2[rr * 4 + 2], a3 = L2[rr * 4 + 3];
-        Dm[rr * 4 + 0] = Dn[rr * 4 + 0] - (a0 * e.ce + a1 * e.pc + a3 * e.Tc);
-        Dm[rr * 4 + 1] = Dn[rr * 4 + 1] - (a1 * e.pe + a3 * e.Te);
-        Dm[rr * 4 + 2] = Dn[rr * 4 + 2] - (a2 * e.s + a3 * e.Ts);
-        Dm[rr * 4 + 3] = Dn[rr * 4 + 3] - (a1 * e.pt + a3 * e.Tt);
+        Dm[rr * 4 + 0] = ((Dn[rr * 4 + 0] - a0 * e.ce) - a1 * e.pc) - a3 * e.Tc;
+        Dm[rr * 4 + 1] = (Dn[rr * 4 + 1] - a1 * e.pe) - a3 * e.Te;
+        Dm[rr * 4 + 2] = (Dn[rr * 4 + 2] - a2 * e.s) - a3 * e.Ts;
+        Dm[rr * 4 + 3] = (Dn[rr * 4 + 3] - a1 * e.pt) - a3 * e.Tt;
       }
       inv4(Dm, Dmi);
       if (nd == TW_MID) for (int k = 0; k < 16; k++) { Dinv[k] = Dmi[k]; S.LDmid[k] = PL_F32(L2[k]); }
@@ -768,7 +816,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
         if (sc != 1) {                                     // j eliminated: v_x -= v_j phi
           const int jx = sc == 0 ? ln : ln - NS;
           const double vj = -wi * TP.TJ[jx];
-          v1 -= vj * TP.phi4[1][ln]; v2 -= vj * TP.phi4[2][ln];
+          v1 -= vj * (S.gpe[jx] * S.dj[jx]); v2 -= vj * (S.gps[jx] * S.dj[jx]);
           v0 = vj;                                         // kept for the right-hand side (b_I -= v_j beta); slot 0 is free in the algebraic system
         }
       }
@@ -782,7 +830,8 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
   // 5. border: x2 = B^-1 (column of I) and the pivot d - v.x2
   if (mode != PLH_MODE_I) {
     double ra[1][4] = {{0.0, 0.0, 0.0, 0.0}};
-    if (act) { ra[0][2] = TP.colI4[0][i]; ra[0][3] = TP.colI4[1][i]; }
+    if (nd == 0) { ra[0][2] = TP.cI4[0]; ra[0][3] = TP.cI4[1]; }
+    if (nd == NE - 1) { ra[0][2] = TP.cI4[2]; ra[0][3] = TP.cI4[3]; }
     thermal_sweeps<1>(S, alg_only, ra);
     if (act) for (int cc = 0; cc < 4; cc++) TP.x2[cc][i] = ra[0][cc];
     const double vx = wave_sum(act ? TP.vB[1][i] * ra[0][1] + TP.vB[2][i] * ra[0][2] + TP.vB[3][i] * ra[0][3] + (mode == PL_MODE_DT_TWIN ? 0.0 : TP.vB[0][i] * ra[0][0]) : 0.0);
@@ -801,67 +850,102 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
   auto& TP = S.th;
   const int r = lane % NR, g = lane < CS_LANES ? lane / NR : CS_G - 1;
   PL_TICE(2);
-  // a. particle partial solutions w = A_p^-1 b_cs  (two mat-vecs through the spectral form); collector forward/backward substitution
+  // a. particle partial solutions w = A_p^-1 b_cs  (two mat-vecs through the spectral form, the diagonal from R.rcp); collector forward/backward substitution
+  double zbk = 0.0;                                        // lane 32 + k: chain solution of collector node k (T^-1 b_T restricted to the chain)
   if (!alg_only) {
     double Wrow[NR], Vrow[NR];
-    for (int k = 0; k < NR; k++) { Wrow[k] = PL_RADIAL_W[r * NR + k]; Vrow[k] = PL_RADIAL_V[r * NR + k]; }
-    const double lam_r = PL_RADIAL_LAM[r];
+    for (int k = 0; k < NR; k++) { Wrow[k] = S.Mr[S.OFF_WR + r * NR + k]; Vrow[k] = S.Mr[S.OFF_VR + r * NR + k]; }
+    // (one address register per array for the lane's particle group; pass and column go into the offset fields.  The last pass may reach beyond the last particle: its
+    //  lanes read the last particle instead -- same values as a clamped index, selected per lane on the ADDRESS)
+    constexpr int LASTP = (CS_PASS - 1) * CS_G;             // first particle of the last pass
+    const bool over = LASTP + g >= NJ;
+    constexpr bool A16 = NR % 2 == 0 && O_CS % 2 == 0;      // particle rows start on 16-byte boundaries (b is one of the 16-byte aligned vectors of CellLDS)
+    const lds_cptr bg = PL_LDS_BASE_A(A16, (const double*)b + O_CS + g * NR), bl = PL_LDS_BASE_A(A16, (const double*)b + O_CS + (over ? NJ - 1 : LASTP + g) * NR);
+    double yv[CS_PASS];
+#pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) {
-      const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
+      const lds_cptr bb = pass == CS_PASS - 1 ? bl : bg + pass * CS_G * NR;
       double y = 0.0;
-      for (int k = 0; k < NR; k++) y += Wrow[k] * b[O_CS + p * NR + k];
-      if (lane < CS_LANES && p0 < NJ) S.yy[O_CS + p * NR + r] = y / (TP.kapF[p] * lam_r - TP.cjf);   // S.yy is dead between a residual and the next form_iterate
+#pragma unroll
+      for (int k = 0; k < NR; k++) y += Wrow[k] * bb[k];
+      yv[pass] = y * R.rcp[pass];
     }
-    if (lane >= 62) {
-      const int q = lane - 62, base = q == 0 ? 0 : NA + NE;
+    const lds_ptr yg = PL_LDS_BASE(S.yy + O_CS + g * NR + r);
+#pragma unroll
+    for (int pass = 0; pass < CS_PASS; pass++)
+      if (lane < CS_LANES && pass * CS_G + g < NJ) yg[pass * CS_G * NR] = yv[pass];   // S.yy is dead between a residual and the next form_iterate
+    {
+      // collector chains: lane 32 + k owns collector node k (aluminium 0 .. N_a - 1, then copper), the mapping of the residual rows and of phase e.  Both Thomas recurrences
+      // run as systolic DPP chains (every lane re-evaluates its stage until its predecessor is final, as in the block sweeps): ONE LDS load per operand and lane instead of
+      // the 4 N_a loads per lane of a single-lane recurrence -- the LDS array, shared by the four cells of the CU, is what the particle phases wait for -- and straight-line
+      // code the scheduler interleaves with the mat-vecs.  The chain heads have a zero multiplier, so the copper chain ignores the lane below it.
+      const int ck = lane - 32;
+      const bool cact = ck >= 0 && ck < NA + NZ;
+      const int kq = cact ? ck : 0, q = kq < NA ? 0 : 1, kk = q == 0 ? kq : kq - NA, ic = q == 0 ? kk : NA + NE + kk, nq = q == 0 ? NA : NZ;
+      const double l_bv = b[O_T + ic], l_aL = TP.aL[ic], l_aU = TP.aU[ic], l_cp = TP.cP[q][kk];
+      const double cp_prev = shift_up1(l_cp);
+      const double cm = (cact && kk > 0) ? l_aL * cp_prev : 0.0, up = (cact && kk < nq - 1) ? l_aU : 0.0, bv = cact ? l_bv : 0.0, cpk = cact ? l_cp : 0.0;
       constexpr int NC = NA > NZ ? NA : NZ;
-      const int nq = q == 0 ? NA : NZ;
-      double f[NC], bv[NC], cm[NC], au[NC], cpv[NC], xv[NC];
-      for (int k = 0; k < NC; k++) if (k < nq) { bv[k] = b[O_T + base + k]; cm[k] = TP.cM[q][k]; au[k] = TP.aU[base + k]; cpv[k] = TP.cP[q][k]; }   // loads first
-      for (int k = 0; k < NC; k++) if (k < nq) f[k] = bv[k] - (k > 0 ? cm[k] * f[k - 1] : 0.0);
-      double x = 0.0;
-      for (int k = NC - 1; k >= 0; k--) if (k < nq) { x = (f[k] - (k < nq - 1 ? au[k] * x : 0.0)) * cpv[k]; xv[k] = x; }
-      for (int k = 0; k < NC; k++) if (k < nq) TP.zb[q][k] = xv[k];                                                                     // stores last
+      double f = bv;
+#pragma unroll
+      for (int st = 1; st < NC; st++) { const double fp = shift_up1(f); f = bv - cm * fp; }
+      double x = f * cpk;
+#pragma unroll
+      for (int st = 1; st < NC; st++) { const double xn = shift_down1(x); x = (f - up * xn) * cpk; }
+      zbk = x;
     }
     PL_SYNC();
+    const lds_cptr yr = PL_LDS_BASE_A(A16, (const double*)S.yy + O_CS + g * NR), yl = PL_LDS_BASE_A(A16, (const double*)S.yy + O_CS + (over ? NJ - 1 : LASTP + g) * NR);
+#pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) {
-      const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
+      const int p0 = pass * CS_G + g;
+      const lds_cptr yb = pass == CS_PASS - 1 ? yl : yr + pass * CS_G * NR;
       double w = 0.0;
-      for (int m = 0; m < NR; m++) w += Vrow[m] * S.yy[O_CS + p * NR + m];
-      if (lane < CS_LANES && p0 < NJ && r == NR - 1) S.w9[p] = w;
+#pragma unroll
+      for (int m = 0; m < NR; m++) w += Vrow[m] * yb[m];
+      if (lane < CS_LANES && p0 < NJ && r == NR - 1) S.w9[p0] = w;
       R.wreg[pass] = w;
     }
   }
   PL_SYNC();
   PL_TOCE(S, 2, 0);
   // b. node right-hand sides
+  // (all LDS operands of phases b, d, e are loaded unconditionally up front -- clamped indices for the lanes / nodes that do not use them -- and selected afterwards: loads under
+  //  the nested `if`s (node lane? electrode node? current mode?) were dependent exec-masked round trips, see iso_solve)
   const int nd = tw_node(lane);                   // twisted lane layout of thermal_sweeps
   const bool act = nd >= 0;
   const int i = act ? nd : 0;
   const int sc = sec_of(i);
   const bool elec = act && sc != 1;
-  const int jx = sc == 0 ? i : i - NS;
+  const int jx = sc == 0 ? i : (sc == 2 ? i - NS : 0);
+  const double l_ce = b[O_CE + i], l_pe = b[O_PE + i], l_T = b[O_T + NA + i], l_j = b[O_J + jx], l_ps = b[O_PS + jx], l_bI = b[O_I];
+  const double l_w9 = S.w9[jx], l_gcs = S.gcs[jx], l_Tcs = TP.Tcs[jx], l_dj = S.dj[jx];
+  const double l_ceJ = S.ceJ[i], l_tq1 = S.peJ[i], l_tq2 = S.psJ[jx], l_tq3 = TP.tq3[i], l_tq0 = alg_only ? 0.0 : l_ceJ;
+  const double l_cI0 = i == 0 ? TP.cI4[0] : (i == NE - 1 ? TP.cI4[2] : 0.0), l_cI1 = i == 0 ? TP.cI4[1] : (i == NE - 1 ? TP.cI4[3] : 0.0);
+  const double l_zbA = lane_bcast(zbk, 32 + NA - 1), l_zbZ = lane_bcast(zbk, 32 + NA), l_aL = TP.aL[NA], l_aU = TP.aU[NA + NE - 1];
+  const double l_gce = S.gce[jx], l_gpe = S.gpe[jx], l_gps = S.gps[jx], l_ph3 = TP.phi3[i];
+  const double l_ph0 = alg_only ? 0.0 : l_gce * l_dj, l_ph1 = l_gpe * l_dj, l_ph2 = l_gps * l_dj;
   double beta = 0.0;
   double y[4] = {0.0, 0.0, 0.0, 0.0};
   if (act) {
-    y[0] = alg_only ? 0.0 : b[O_CE + i]; y[1] = b[O_PE + i]; y[2] = 0.0; y[3] = alg_only ? 0.0 : b[O_T + NA + i];
+    y[0] = alg_only ? 0.0 : l_ce; y[1] = l_pe; y[2] = 0.0; y[3] = alg_only ? 0.0 : l_T;
     if (elec) {
-      const double w9 = alg_only ? 0.0 : S.w9[jx];
-      const double bjp = b[O_J + jx] - S.gcs[jx] * w9;
-      y[2] = b[O_PS + jx];
-      if (!alg_only) y[3] -= TP.Tcs[jx] * w9;
-      beta = bjp * S.dj[jx];
-      for (int cc = 0; cc < 4; cc++) y[cc] -= TP.tq[cc][i] * beta;
+      const double w9 = alg_only ? 0.0 : l_w9;
+      const double bjp = l_j - l_gcs * w9;
+      y[2] = l_ps;
+      if (!alg_only) y[3] -= l_Tcs * w9;
+      beta = bjp * l_dj;
+      y[0] -= l_tq0 * beta; y[1] -= l_tq1 * beta; y[2] -= l_tq2 * beta; y[3] -= l_tq3 * beta;
     }
     if (!alg_only) {
-      if (i == 0) y[3] -= TP.aL[NA] * TP.zb[0][NA - 1];
-      if (i == NE - 1) y[3] -= TP.aU[NA + NE - 1] * TP.zb[1][0];
+      if (i == 0) y[3] -= l_aL * l_zbA;
+      if (i == NE - 1) y[3] -= l_aU * l_zbZ;
     }
   }
   double xI = 0.0;
   if (mode == PLH_MODE_I) {
-    xI = b[O_I];
-    if (act) { y[2] -= TP.colI4[0][i] * xI; y[3] -= TP.colI4[1][i] * xI; }
+    xI = l_bI;
+    if (act) { y[2] -= l_cI0 * xI; y[3] -= l_cI1 * xI; }
   }
   PL_TOCE(S, 2, 1);
   // c. block-Thomas sweeps + Woodbury correction
@@ -873,19 +957,22 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
   PL_TOCE(S, 2, 2);
   // d. border
   if (mode != PLH_MODE_I) {
-    double bI = b[O_I];
+    const double v0 = TP.vB[0][i], v1 = TP.vB[1][i], v2 = TP.vB[2][i], v3 = TP.vB[3][i];
+    const double x20 = TP.x2[0][i], x21 = TP.x2[1][i], x22 = TP.x2[2][i], x23 = TP.x2[3][i], bd = TP.bord[0];
     double vy = 0.0;
     if (act) {
-      vy = TP.vB[1][i] * y[1] + TP.vB[2][i] * y[2] + TP.vB[3][i] * y[3];
-      if (mode == PL_MODE_DT_TWIN) vy += TP.vB[0][i] * beta;           // v_j (b_j'/d): the eliminated j part of the twin row
-      else vy += TP.vB[0][i] * y[0];
+      vy = v1 * y[1] + v2 * y[2] + v3 * y[3];
+      if (mode == PL_MODE_DT_TWIN) vy += v0 * beta;           // v_j (b_j'/d): the eliminated j part of the twin row
+      else vy += v0 * y[0];
     }
     if (mode == PLH_MODE_DT) {                                          // collector T's in the control row: -cj w_k zb_k
-      if (lane >= 32 && lane < 32 + NA + NZ) { const int k = lane - 32, q = k < NA ? 0 : 1, kk = k < NA ? k : k - NA; vy += -TP.cjf * TP.wT5[tsec_of(q == 0 ? kk : NA + NE + kk)] * TP.zb[q][kk]; }
+      const int k = lane >= 32 && lane < 32 + NA + NZ ? lane - 32 : 0, q = k < NA ? 0 : 1, kk = k < NA ? k : k - NA;
+      const double wk = TP.wT5[tsec_of(q == 0 ? kk : NA + NE + kk)], cjf = TP.cjf;
+      if (lane >= 32 && lane < 32 + NA + NZ) vy += -cjf * wk * zbk;
     }
     const double vsum = wave_sum(vy);
-    xI = (bI - vsum) / TP.bord[0];
-    if (act) for (int cc = 0; cc < 4; cc++) y[cc] -= xI * TP.x2[cc][i];
+    xI = (l_bI - vsum) / bd;
+    if (act) { y[0] -= xI * x20; y[1] -= xI * x21; y[2] -= xI * x22; y[3] -= xI * x23; }
   }
   PL_SYNC();
   // e. write node unknowns, back-substitute j and the collectors
@@ -894,16 +981,15 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
     b[O_PE + i] = y[1];
     if (elec) {
       b[O_PS + jx] = y[2];
-      b[O_J + jx] = beta - (TP.phi4[0][i] * y[0] + TP.phi4[1][i] * y[1] + TP.phi4[2][i] * y[2] + TP.phi4[3][i] * y[3]);
+      b[O_J + jx] = beta - (l_ph0 * y[0] + l_ph1 * y[1] + l_ph2 * y[2] + l_ph3 * y[3]);
     }
   }
   if (lane == 0) b[O_I] = xI;
   if (!alg_only) {
     const double T0n = lane_bcast(y[3], tw_lane(0)), T29n = lane_bcast(y[3], tw_lane(NE - 1));
-    if (lane >= 32 && lane < 32 + NA + NZ) {
-      const int k = lane - 32, q = k < NA ? 0 : 1, kk = k < NA ? k : k - NA;
-      b[O_T + (q == 0 ? kk : NA + NE + kk)] = TP.zb[q][kk] - TP.zc[q][kk] * (q == 0 ? T0n : T29n) - TP.zI[q][kk] * xI;
-    }
+    const int k = lane >= 32 && lane < 32 + NA + NZ ? lane - 32 : 0, q = k < NA ? 0 : 1, kk = k < NA ? k : k - NA;
+    const double zck = TP.zc[q][kk], zIk = TP.zI[q][kk];
+    if (lane >= 32 && lane < 32 + NA + NZ) b[O_T + (q == 0 ? kk : NA + NE + kk)] = zbk - zck * (q == 0 ? T0n : T29n) - zIk * xI;
   }
   PL_SYNC();
   PL_TOCE(S, 2, 3);
@@ -957,7 +1043,7 @@ PL_DEV double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ 
     case TT_PE_TD: return TP.ptD[a];
     case TT_PE_TU: return TP.ptU[a];
     case TT_T_TL: return TP.aL[a];
-    case TT_T_TD: return TP.aD[a] - cj + ((a >= NA && a < NA + NE) ? TP.TtD[a - NA] : 0.0);
+    case TT_T_TD: return thermal_aD(TP, a) - cj + ((a >= NA && a < NA + NE) ? TP.TtD[a - NA] : 0.0);
     case TT_T_TU: return TP.aU[a];
     case TT_T_CL: return TP.TcL[a];
     case TT_T_CD: return TP.TcD[a];

@@ -7,13 +7,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pkgload
 pkg = pkgload.load()
-import torch
 import __graft_entry__ as g
 detail = 1 if "--detail" in sys.argv else 2 if "--detail2" in sys.argv else 3 if "--detail3" in sys.argv else 0
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 which = args[1] if len(args) > 1 else "iso"
 variant = {"iso": 0, "thermal": 4, "sei": 3, "iso2": 13}[which]
 lib = g.build_hip(extra_flags=["-DPL_PHASE_TIMERS"] + (["-DPL_PHASE_DETAIL=%d" % detail] if detail else []), lib=os.path.join(ROOT, "petlion.jl_amd", "_exp", "libplh_prof_%s%s.so" % (which, "_d%d" % detail if detail else "")), variants=[variant])
+if "--build-only" in sys.argv:          # (here, without a GPU: the library travels to the GPU box with the snapshot)
+    print(lib); sys.exit(0)
+import torch
 n = int(args[0]) if args else 1024
 if which == "thermal":
     p = pkg.petlion(pkg.LCO, temperature=True, _lib_path=lib)
