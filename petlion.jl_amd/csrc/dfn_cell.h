@@ -250,6 +250,11 @@ template <class M> struct alignas(16) CellLDS {
   long long cyc[8];    // per-phase cycle sums (profiling build only)
 #endif
   const Tables* tb;    // model tables (set by cell_setup)
+  // what one run hands to the next (SOC, end time, V / I / eta_plating at the end): kept HERE between the runs, read into run-local registers at the top of a run.  As
+  // loop-carried 64-bit registers of the run loop these were merged at the loop head from "new solution" and "continuation" paths, and hipcc 7.x twice dropped one HALF of
+  // such a merge when the two halves of the pair had been spilled to different places (AGPR / scratch): a run started with a garbage SOC.  A value that is
+  // loaded at the top of the run has one definition and nothing to merge.
+  double carry[5];     // [0] SOC, [1] t_global, [2] prev_V, [3] prev_I, [4] prev_etap
   plh_run runc;        // the run being integrated (copied from HBM once per run)
   CellConst cc;
   // closure inputs (PLH_VAL_EXPR; general instantiation only; kept last so that nothing else moves): the cell's theta row in HBM and the interpreter's value stack

@@ -841,14 +841,16 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
   const int lane = lane_id();
   IdaScalars I;
   int nout = 0;
-  double t_global = 0.0, SOC = SOC0, prev_V = 0, prev_I = 0, prev_etap = 0;
   bool have_prev = false;
   const double T0 = S.cc.T0;
+  // (what a run inherits from the one before -- SOC, end time, V / I / eta_plating -- travels through S.carry: see CellLDS)
   if (Yinit) {                                                          // simulate!(sol, ...): continue from sol.Y[end]
     PL_VEC(n) S.yy[n] = Yinit[n];
     PL_XSYNC();
-    have_prev = true; t_global = t_init; prev_V = cellV<M>(S.yy); prev_I = S.yy[O_I]; prev_etap = S.yy[O_PS + NP] - S.yy[O_PE + NP + NS];
-  }
+    have_prev = true;
+    if (lane == 0 && wave_id() == 0) { S.carry[0] = SOC0; S.carry[1] = t_init; S.carry[2] = cellV<M>(S.yy); S.carry[3] = S.yy[O_I]; S.carry[4] = S.yy[O_PS + NP] - S.yy[O_PE + NP + NS]; }
+  } else if (lane == 0 && wave_id() == 0) { S.carry[0] = SOC0; S.carry[1] = 0.0; S.carry[2] = 0.0; S.carry[3] = 0.0; S.carry[4] = 0.0; }
+  PL_XSYNC();
   auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
     const double Tav = (M::THERMAL && out.T) ? cellTavg<M>(S, Y) : T0;
     if constexpr ((F & GF_STOPS) != 0) if (out.Yall && idx < out.max_pts) { PL_VEC(n) out.Yall[(size_t)idx * NST + n] = Y[n]; }      // outputs = :all
@@ -867,6 +869,8 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     if (lane == 0 && wave_id() == 0) { S.runc = runs[r]; if (S.runc.value_cell) S.runc.value = S.runc.value_cell[cell]; if (S.runc.tf_cell) S.runc.tf = S.runc.tf_cell[cell]; }
     PL_XSYNC();
     const plh_run& run = S.runc;
+    double SOC = S.carry[0];
+    const double t_global = S.carry[1], prev_V = S.carry[2], prev_I = S.carry[3], prev_etap = S.carry[4];
     // PLH_MODE_DSTATE (x - YP[ind] = 0) runs as a control residual with no method part (PLH_MODE_RES) whose "closure" is YP[ind] (closure_input, gen_factor)
     const bool dstate = (F & GF_GENROW) && run.mode == PLH_MODE_DSTATE;
     const int mode = dstate ? PLH_MODE_RES : run.mode;
@@ -1017,7 +1021,9 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     }
     ri.flag = flag; ri.iterations = iter; ri.t_end = t_end; ri.V = cellV<M>(S.yy); ri.I = S.yy[O_I]; ri.SOC = SOC; ri.T_avg = cellTavg<M>(S, S.yy);
     if (lane == 0 && wave_id() == 0) info[r] = ri;
-    t_global = t_end; have_prev = true; prev_V = ri.V; prev_I = ri.I; prev_etap = S.yy[O_PS + NP] - S.yy[O_PE + NP + NS];
+    have_prev = true;
+    PL_XSYNC();
+    if (lane == 0 && wave_id() == 0) { S.carry[0] = SOC; S.carry[1] = t_end; S.carry[2] = ri.V; S.carry[3] = ri.I; S.carry[4] = S.yy[O_PS + NP] - S.yy[O_PE + NP + NS]; }
     if (flag < 0) { for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; z.iterations = 0; info[q] = z; } break; }
     PL_XSYNC();
   }

@@ -308,10 +308,18 @@ static int build_patterns(plh_model_s* m) {
   return 0;
 }
 
+// The communicator and the five transport operations plh_ensemble_run is written against (x_send / x_recv / x_bcast / x_allmin, grouped between x_group_start / _end).
+// Product build: RCCL on the communicator's stream, device buffers.  Test-only wave-emulator build: a file-backed LOOPBACK between processes on one machine (one file per
+// message in a directory named by the 128-byte id, written whole and renamed into place; receives poll with a timeout), so that the multi-rank control flow of the SAME
+// function -- shard offsets, ragged and cyclic partitions, per-cell protocol shards, the status agreements, the gather re-ordering, failures on one rank -- runs with
+// 2 or 3 processes on a machine without a GPU (tests/test_ensemble_loopback.py).  `dead`: a transport failure inside a collective phase leaves the fabric in an unknown
+// state; the communicator is aborted (ncclCommAbort) and refuses further use instead of letting the caller walk into a hang.
 #ifndef PL_WAVE_EMU
-struct plh_comm_s { ncclComm_t comm = nullptr; int n_ranks = 1, rank = 0, device = 0; hipStream_t st = nullptr; };
+struct plh_comm_s { ncclComm_t comm = nullptr; int n_ranks = 1, rank = 0, device = 0; hipStream_t st = nullptr; int* d_status = nullptr; bool dead = false; };
 #else
-struct plh_comm_s { int n_ranks = 1, rank = 0, device = 0; };
+#include <unistd.h>
+#include <sys/stat.h>
+struct plh_comm_s { int n_ranks = 1, rank = 0, device = 0; std::string dir; std::vector<long long> seq_tx, seq_rx; int* d_status = nullptr; bool dead = false; bool comm = false; };
 #endif
 
 extern "C" {
@@ -770,9 +778,80 @@ int plh_synchronize(plh_model_t m, void* stream) {
 // ---------------------------------------------------------------------------------------------------------------------
 // multi-GPU: RCCL scatter -> local integrate -> RCCL gather.  n_ranks == 1 makes no RCCL call at all.
 // ---------------------------------------------------------------------------------------------------------------------
+}  // extern "C" (the transport helpers below are internal)
+
 #ifndef PL_WAVE_EMU
 #define NCCLCHK(x) do { ncclResult_t r__ = (x); if (r__ != ncclSuccess) return fail(PLH_E_HIP, std::string(#x) + ": " + ncclGetErrorString(r__)); } while (0)
+static int x_group_start(plh_comm_s*) { NCCLCHK(ncclGroupStart()); return 0; }
+static int x_group_end(plh_comm_s*) { NCCLCHK(ncclGroupEnd()); return 0; }
+static int x_send(plh_comm_s* c, const void* dev, size_t bytes, int peer) { NCCLCHK(ncclSend(dev, bytes, ncclChar, peer, c->comm, c->st)); return 0; }
+static int x_recv(plh_comm_s* c, void* dev, size_t bytes, int peer) { NCCLCHK(ncclRecv(dev, bytes, ncclChar, peer, c->comm, c->st)); return 0; }
+static int x_bcast(plh_comm_s* c, void* dev, size_t bytes, int root) { NCCLCHK(ncclBroadcast(dev, dev, bytes, ncclChar, root, c->comm, c->st)); HIPCHK(hipStreamSynchronize(c->st)); return 0; }
+// min over the ranks of a host int, through the communicator's own status word (allocated with the communicator: it does not depend on any staging block of the call)
+static int x_allmin(plh_comm_s* c, int* v) {
+  HIPCHK(hipMemcpy(c->d_status, v, sizeof(int), hipMemcpyHostToDevice));
+  NCCLCHK(ncclAllReduce(c->d_status, c->d_status, 1, ncclInt, ncclMin, c->comm, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  HIPCHK(hipMemcpy(v, c->d_status, sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+static void x_abort(plh_comm_s* c) { if (c->comm) { ncclCommAbort(c->comm); c->comm = nullptr; } c->dead = true; }
+static bool x_multi(const plh_comm_s* c) { return c->comm != nullptr; }
+#else
+// ---- loopback transport of the emulator build (test infrastructure; never in libpetlion_hip.so) ----
+static double x_timeout_s() { const char* e = getenv("PLH_LOOPBACK_TIMEOUT_S"); return e ? atof(e) : 120.0; }
+static std::string x_name(const plh_comm_s* c, int src, int dst, long long seq) { return c->dir + "/m_" + std::to_string(src) + "_" + std::to_string(dst) + "_" + std::to_string(seq); }
+static int x_group_start(plh_comm_s*) { return 0; }
+static int x_group_end(plh_comm_s*) { return 0; }
+static int x_send(plh_comm_s* c, const void* buf, size_t bytes, int peer) {
+  const std::string nm = x_name(c, c->rank, peer, c->seq_tx[peer]++), tmp = nm + ".part";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f || (bytes && fwrite(buf, 1, bytes, f) != bytes)) { if (f) fclose(f); return fail(PLH_E_HIP, "loopback send: cannot write " + tmp); }
+  fclose(f);
+  if (rename(tmp.c_str(), nm.c_str()) != 0) return fail(PLH_E_HIP, "loopback send: rename failed for " + nm);
+  return 0;
+}
+static int x_recv(plh_comm_s* c, void* buf, size_t bytes, int peer) {
+  const std::string nm = x_name(c, peer, c->rank, c->seq_rx[peer]++);
+  const double limit = x_timeout_s();
+  for (double waited = 0.0;; waited += 0.002) {
+    struct stat sb;
+    if (stat(nm.c_str(), &sb) == 0) {
+      if ((size_t)sb.st_size != bytes) return fail(PLH_E_HIP, "loopback recv: " + nm + " has " + std::to_string((long long)sb.st_size) + " bytes, expected " + std::to_string(bytes));
+      FILE* f = fopen(nm.c_str(), "rb");
+      const bool ok = f && (bytes == 0 || fread(buf, 1, bytes, f) == bytes);
+      if (f) fclose(f);
+      unlink(nm.c_str());
+      return ok ? 0 : fail(PLH_E_HIP, "loopback recv: cannot read " + nm);
+    }
+    if (waited > limit) return fail(PLH_E_HIP, "loopback recv: timed out waiting for rank " + std::to_string(peer) + " (" + nm + ")");
+    usleep(2000);
+  }
+}
+static int x_bcast(plh_comm_s* c, void* buf, size_t bytes, int root) {
+  if (c->rank == root) { for (int r = 0; r < c->n_ranks; r++) if (r != root) if (int rc = x_send(c, buf, bytes, r)) return rc; return 0; }
+  return x_recv(c, buf, bytes, root);
+}
+static int x_allmin(plh_comm_s* c, int* v) {
+  if (c->rank != 0) { if (int rc = x_send(c, v, sizeof(int), 0)) return rc; return x_recv(c, v, sizeof(int), 0); }
+  for (int r = 1; r < c->n_ranks; r++) { int o = 0; if (int rc = x_recv(c, &o, sizeof(int), r)) return rc; if (o < *v) *v = o; }
+  for (int r = 1; r < c->n_ranks; r++) if (int rc = x_send(c, v, sizeof(int), r)) return rc;
+  return 0;
+}
+static void x_abort(plh_comm_s* c) { c->dead = true; }
+static bool x_multi(const plh_comm_s* c) { return c->comm; }
+// fault injection for the tests: PLH_TEST_FAIL = "<rank>:<phase>" makes that rank fail locally at that phase of plh_ensemble_run (0 arguments, 1 shape, 2 scatter
+// preparation, 3 integrate, 4 inside the gather -- a failure INSIDE a collective phase, which the others can only time out on)
+static bool x_inject(const plh_comm_s* c, int phase) {
+  const char* e = getenv("PLH_TEST_FAIL"); int r = -1, ph = -1;
+  return e && sscanf(e, "%d:%d", &r, &ph) == 2 && r == c->rank && ph == phase;
+}
 #endif
+#ifndef PL_WAVE_EMU
+static bool x_inject(const plh_comm_s*, int) { return false; }
+#endif
+
+extern "C" {
 
 int plh_comm_unique_id(char id[128]) {
   if (!id) return fail(PLH_E_ARG, "null argument");
@@ -780,7 +859,11 @@ int plh_comm_unique_id(char id[128]) {
   static_assert(sizeof(ncclUniqueId) == 128, "the 128-byte id of the header is ncclUniqueId");
   ncclUniqueId u; NCCLCHK(ncclGetUniqueId(&u)); memcpy(id, &u, 128);
 #else
+  // the id of the loopback transport is the name of a fresh directory (the ranks exchange their messages through it)
   memset(id, 0, 128);
+  const char* base = getenv("TMPDIR"); std::string t = std::string(base && *base ? base : "/tmp") + "/plh_loopback_XXXXXX";
+  if (t.size() >= 127 || !mkdtemp(&t[0])) return fail(PLH_E_HIP, "loopback: cannot create a message directory");
+  memcpy(id, t.c_str(), t.size());
 #endif
   return 0;
 }
@@ -797,14 +880,23 @@ int plh_comm_create(int n_ranks, int rank, const char id[128], int device, plh_c
   c->device = device;
   DeviceGuard guard(device);
   if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(PLH_E_HIP, "hipStreamCreate failed"); }
+  // the status word of the agreements between the phases of plh_ensemble_run: owned by the communicator, checked HERE, so that a staging failure of a later call can still be
+  // agreed on (the word used to live in a staging block of the call itself)
+  if (hipMalloc((void**)&c->d_status, 2 * sizeof(int)) != hipSuccess) { hipStreamDestroy(c->st); delete c; return fail(PLH_E_HIP, "hipMalloc failed (communicator status word)"); }
   if (id) {        // (a one-rank communicator with an id still initialises RCCL: the collective path then runs end to end on a single GPU)
     ncclUniqueId u; memcpy(&u, id, 128);
     const ncclResult_t r = ncclCommInitRank(&c->comm, n_ranks, u, rank);
-    if (r != ncclSuccess) { hipStreamDestroy(c->st); delete c; return fail(PLH_E_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+    if (r != ncclSuccess) { hipFree(c->d_status); hipStreamDestroy(c->st); delete c; return fail(PLH_E_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
   }
 #else
-  if (n_ranks > 1) { delete c; return fail(PLH_E_UNSUPPORTED, "the wave-emulator build has no RCCL"); }
   c->device = 0; (void)device;
+  if (id && id[0]) {
+    c->dir.assign(id, strnlen(id, 127));
+    struct stat sb;
+    if (stat(c->dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) { delete c; return fail(PLH_E_ARG, "loopback: the id does not name a message directory (plh_comm_unique_id)"); }
+    c->comm = true;
+  } else if (n_ranks > 1) { delete c; return fail(PLH_E_ARG, "a communicator of several ranks needs the id of plh_comm_unique_id"); }
+  c->seq_tx.assign(n_ranks, 0); c->seq_rx.assign(n_ranks, 0);
 #endif
   *out = c;
   return 0;
@@ -815,6 +907,7 @@ void plh_comm_destroy(plh_comm_t c) {
 #ifndef PL_WAVE_EMU
   DeviceGuard guard(c->device);
   if (c->comm) ncclCommDestroy(c->comm);
+  if (c->d_status) hipFree(c->d_status);
   if (c->st) hipStreamDestroy(c->st);
 #endif
   delete c;
@@ -836,7 +929,9 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
   // (misuse that every rank sees alike -- all ranks pass the same shape, protocol and options -- returns at once; everything that can differ between ranks is agreed on below)
   if (!c || n_total <= 0 || n_runs <= 0 || !runs || !opts) return fail(PLH_E_ARG, "bad argument");
   if (partition != PLH_PART_BLOCK && partition != PLH_PART_CYCLIC) return fail(PLH_E_ARG, "partition must be PLH_PART_BLOCK or PLH_PART_CYCLIC");
+  if (c->dead) return fail(PLH_E_HIP, "plh_ensemble_run: this communicator was aborted by an earlier transport failure; destroy it and create a new one");
   const int G = c->n_ranks, me = c->rank; const bool root = me == 0;
+  const bool multi = x_multi(c) && G > 1;
   DeviceGuard guard(m->device);
   const int P = m->P, N = m->N;
   const long long cnt = shard_count(n_total, G, me);
@@ -858,39 +953,36 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
   double* d_Y = (double*)s.dev_block(rows * N * sizeof(double));
   long long* d_meta = (long long*)s.dev_block(8 * sizeof(long long));
   double* d_ms = (double*)s.dev_block((size_t)G * sizeof(double));
-  // A return that only ONE rank takes would leave the others blocked in the next ncclSend / ncclRecv: before every phase the ranks agree on a status (all-reduce of the
-  // most negative return code) and leave together.
+  // A return that only ONE rank takes would leave the others blocked in the next send / receive: before every collective phase the ranks agree on a status (all-reduce of
+  // the most negative return code, through the communicator's own status word) and leave together.  Local failures BETWEEN the collectives -- arguments, staging, host /
+  // device copies, the rank's plh_integrate -- only set `rc0`; a transport failure INSIDE a collective phase cannot be agreed on any more: the communicator is aborted.
   auto agree = [&](int rc, const char* where) -> int {
-#ifndef PL_WAVE_EMU
-    if (c->comm && G > 1 && d_meta) {
+    if (multi) {
       int all = rc;
-      if (hipMemcpy(d_meta + 4, &all, sizeof(int), hipMemcpyHostToDevice) != hipSuccess || ncclAllReduce(d_meta + 4, d_meta + 4, 1, ncclInt, ncclMin, c->comm, st) != ncclSuccess ||
-          hipStreamSynchronize(st) != hipSuccess || hipMemcpy(&all, d_meta + 4, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
-        return rc != 0 ? rc : fail(PLH_E_HIP, std::string("plh_ensemble_run: status exchange failed (") + where + ")");
+      if (x_allmin(c, &all) != 0) { x_abort(c); return rc != 0 ? rc : fail(PLH_E_HIP, std::string("plh_ensemble_run: status exchange failed (") + where + "): " + g_err); }
       if (rc == 0 && all != 0) return fail(all, std::string("plh_ensemble_run: another rank failed (") + where + "); see its plh_last_error()");
     }
-#endif
-    (void)where;
     return rc;
   };
+  auto broken = [&](const char* where) -> int { const std::string why = g_err; x_abort(c); return fail(PLH_E_HIP, std::string("plh_ensemble_run: transport failure in ") + where + " (communicator aborted): " + why); };
+#define PL_LOCAL(x) do { if (rc0 == 0) { hipError_t e__ = (x); if (e__ != hipSuccess) rc0 = fail(PLH_E_HIP, std::string(#x) + ": " + hipGetErrorString(e__)); } } while (0)
   int rc0 = 0;
   if (s.bad) rc0 = fail(PLH_E_HIP, s.why);
   else if (root && (!theta || !SOC0 || !run_info)) rc0 = fail(PLH_E_ARG, "rank 0 needs theta, SOC0 and run_info");
   else if (m->device != c->device) rc0 = fail(PLH_E_ARG, "the model handle and the communicator must be bound to the same device");
+  if (x_inject(c, 0)) rc0 = fail(PLH_E_ARG, "injected failure (arguments)");
   if (int rc = agree(rc0, "arguments / staging")) return rc;
-  // 1. shape check: everybody must describe the same ensemble (ncclBroadcast from rank 0)
+  // 1. shape check: everybody must describe the same ensemble (broadcast from rank 0)
   long long meta[4] = {n_total, n_runs, partition, P};
-#ifndef PL_WAVE_EMU
-  if (c->comm) {
-    long long root_meta[4];
-    if (root) HIPCHK(hipMemcpy(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice));
-    NCCLCHK(ncclBroadcast(d_meta, d_meta, 4, ncclInt64, 0, c->comm, st));
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipMemcpy(root_meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost));
-    rc0 = memcmp(root_meta, meta, sizeof(meta)) != 0 ? fail(PLH_E_ARG, "plh_ensemble_run: this rank's (n_cells_total, n_runs, partition, model) differ from rank 0's") : 0;
-    if (int rc = agree(rc0, "ensemble shape")) return rc;
+  if (x_multi(c)) {
+    long long root_meta[4] = {0, 0, 0, 0};
+    if (root) PL_LOCAL(hipMemcpy(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice));
+    if (int rc = agree(rc0, "ensemble shape upload")) return rc;
+    if (x_bcast(c, d_meta, sizeof(meta), 0) != 0) return broken("the shape broadcast");
+    PL_LOCAL(hipMemcpy(root_meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost));
+    if (rc0 == 0 && memcmp(root_meta, meta, sizeof(meta)) != 0) rc0 = fail(PLH_E_ARG, "plh_ensemble_run: this rank's (n_cells_total, n_runs, partition, model) differ from rank 0's");
+    if (x_inject(c, 1)) rc0 = fail(PLH_E_ARG, "injected failure (shape)");
   }
-#endif
   // per-cell protocol arrays (plh_run.value_cell / tf_cell) are indexed by the GLOBAL cell: n_cells_total entries, the same on every rank like the rest of the protocol.
   // plh_integrate indexes them by the LOCAL cell, so each rank hands it its own shard of them, in shard order.
   std::vector<plh_run> lruns(runs, runs + n_runs);
@@ -906,24 +998,25 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
     }
   }
   // 2. scatter of the parameter rows (rank 0 permutes them into rank-contiguous order first)
-  if (root) {
+  if (root && rc0 == 0) {
     std::vector<double> th((size_t)n_total * P), soc(n_total);
     for (int r = 0; r < G; r++) for (long long k = 0; k < off[r + 1] - off[r]; k++) {
       const long long cell = shard_cell(n_total, G, r, k, partition);
       memcpy(&th[(size_t)(off[r] + k) * P], theta + (size_t)cell * P, P * sizeof(double)); soc[off[r] + k] = SOC0[cell];
     }
-    HIPCHK(hipMemcpy(d_th, th.data(), th.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_soc, soc.data(), soc.size() * sizeof(double), hipMemcpyHostToDevice));
+    PL_LOCAL(hipMemcpy(d_th, th.data(), th.size() * sizeof(double), hipMemcpyHostToDevice));
+    PL_LOCAL(hipMemcpy(d_soc, soc.data(), soc.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-#ifndef PL_WAVE_EMU
-  if (c->comm && G > 1) {
-    NCCLCHK(ncclGroupStart());
-    if (root) { for (int r = 1; r < G; r++) if (off[r + 1] > off[r]) { NCCLCHK(ncclSend(d_th + (size_t)off[r] * P, (size_t)(off[r + 1] - off[r]) * P, ncclDouble, r, c->comm, st));
-                                                                      NCCLCHK(ncclSend(d_soc + off[r], (size_t)(off[r + 1] - off[r]), ncclDouble, r, c->comm, st)); } }
-    else if (cnt > 0) { NCCLCHK(ncclRecv(d_th, (size_t)cnt * P, ncclDouble, 0, c->comm, st)); NCCLCHK(ncclRecv(d_soc, (size_t)cnt, ncclDouble, 0, c->comm, st)); }
-    NCCLCHK(ncclGroupEnd());
+  if (x_inject(c, 2)) rc0 = fail(PLH_E_HIP, "injected failure (scatter preparation)");
+  if (int rc = agree(rc0, "ensemble shape / scatter preparation")) return rc;
+  if (multi) {
+    bool ok = x_group_start(c) == 0;
+    if (root) { for (int r = 1; ok && r < G; r++) if (off[r + 1] > off[r]) ok = x_send(c, d_th + (size_t)off[r] * P, (size_t)(off[r + 1] - off[r]) * P * sizeof(double), r) == 0 &&
+                                                                                x_send(c, d_soc + off[r], (size_t)(off[r + 1] - off[r]) * sizeof(double), r) == 0; }
+    else if (cnt > 0) ok = ok && x_recv(c, d_th, (size_t)cnt * P * sizeof(double), 0) == 0 && x_recv(c, d_soc, (size_t)cnt * sizeof(double), 0) == 0;
+    ok = ok && x_group_end(c) == 0;
+    if (!ok) return broken("the scatter");
   }
-#endif
   // 3. the local shard: one plh_integrate launch, device pointers, on the communicator's stream -- no collective in the data path
   double ms = 0.0;
   if (cnt > 0) {
@@ -932,26 +1025,27 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
     rc0 = plh_integrate(m, (int)cnt, d_th, d_soc, nullptr, nullptr, n_runs, lruns.data(), opts, &o, PLH_DEVICE, st);
     if (rc0 == 0) ms = plh_last_kernel_ms(m);
   }
+  if (x_inject(c, 3)) rc0 = fail(PLH_E_HIP, "injected failure (integrate)");
+  PL_LOCAL(hipMemcpy(d_ms + me, &ms, sizeof(double), hipMemcpyHostToDevice));
   if (int rc = agree(rc0, "plh_integrate")) return rc;
   // 4. gather of the per-cell summaries to rank 0 (rank-contiguous order), then back to the caller's cell order
-  HIPCHK(hipMemcpy(d_ms + me, &ms, sizeof(double), hipMemcpyHostToDevice));
-#ifndef PL_WAVE_EMU
-  if (c->comm && G > 1) {
+  if (multi) {
+    if (x_inject(c, 4)) return broken("the gather (injected)");
     const size_t bi = (size_t)n_runs * sizeof(plh_run_info), bc = sizeof(plh_counters);
-    NCCLCHK(ncclGroupStart());
-    if (root) for (int r = 1; r < G; r++) {
+    bool ok = x_group_start(c) == 0;
+    if (root) for (int r = 1; ok && r < G; r++) {
       const size_t k = (size_t)(off[r + 1] - off[r]);
-      if (k) { NCCLCHK(ncclRecv((char*)d_info + (size_t)off[r] * bi, k * bi, ncclChar, r, c->comm, st)); NCCLCHK(ncclRecv((char*)d_cnt + (size_t)off[r] * bc, k * bc, ncclChar, r, c->comm, st));
-               NCCLCHK(ncclRecv(d_Y + (size_t)off[r] * N, k * N, ncclDouble, r, c->comm, st)); }
-      NCCLCHK(ncclRecv(d_ms + r, 1, ncclDouble, r, c->comm, st));
+      if (k) ok = x_recv(c, (char*)d_info + (size_t)off[r] * bi, k * bi, r) == 0 && x_recv(c, (char*)d_cnt + (size_t)off[r] * bc, k * bc, r) == 0 &&
+                  x_recv(c, d_Y + (size_t)off[r] * N, k * N * sizeof(double), r) == 0;
+      ok = ok && x_recv(c, d_ms + r, sizeof(double), r) == 0;
     } else {
-      if (cnt > 0) { NCCLCHK(ncclSend(d_info, (size_t)cnt * bi, ncclChar, 0, c->comm, st)); NCCLCHK(ncclSend(d_cnt, (size_t)cnt * bc, ncclChar, 0, c->comm, st));
-                     NCCLCHK(ncclSend(d_Y, (size_t)cnt * N, ncclDouble, 0, c->comm, st)); }
-      NCCLCHK(ncclSend(d_ms + me, 1, ncclDouble, 0, c->comm, st));
+      if (cnt > 0) ok = ok && x_send(c, d_info, (size_t)cnt * bi, 0) == 0 && x_send(c, d_cnt, (size_t)cnt * bc, 0) == 0 && x_send(c, d_Y, (size_t)cnt * N * sizeof(double), 0) == 0;
+      ok = ok && x_send(c, d_ms + me, sizeof(double), 0) == 0;
     }
-    NCCLCHK(ncclGroupEnd());
+    ok = ok && x_group_end(c) == 0;
+    if (!ok) return broken("the gather");
   }
-#endif
+  // (no collective after this point: a local failure is this rank's alone)
   HIPCHK(hipStreamSynchronize(st));
   if (root) {
     std::vector<plh_run_info> hi((size_t)n_total * n_runs); std::vector<plh_counters> hc(counters ? n_total : 0); std::vector<double> hy(Y_final ? (size_t)n_total * N : 0);
@@ -967,6 +1061,7 @@ int plh_ensemble_run(plh_comm_t c, plh_model_t m, int n_total, const double* the
     }
   }
   return 0;
+#undef PL_LOCAL
 }
 
 }  // extern "C"
