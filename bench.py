@@ -185,14 +185,18 @@ def general_path(pkg, p, inp, Theta, n_local, kernel_ms, reps=5):
              ("closure input", [clo] + proto[1:], {}, None),
              ("closure of the state with its derivative in the Newton matrix (general control row)", [clo_y] + proto[1:], {}, None),
              ("refine = 1", proto, dict(refine=1), None)]
+    skeys = [k for k in pkg.configs.SWEEP_KEYS if k in p.θ_keys]
+    if all(not isinstance(r.get("I", 0.0), str) or r["I"] == "rest" for r in proto) and all(set(r) & {"I", "V", "P"} for r in proto):
+        cases.append(("forward sensitivities dY/dtheta, dV/dtheta for %d parameters (%s): plh_integrate_sens" % (len(skeys), ", ".join(skeys)), proto, {}, None))
     out = {}
     for name, pr, okw, outputs in cases:
         o = pkg.Opts()
         for k, v in okw.items():
             setattr(o, k, v)
         ms = []
-        for r in range(reps + 1):
-            ens = pkg.simulate_ensemble(p, Theta, pr, SOC=inp["SOC"], device=True, opts=o, max_points=inp["max_points"], outputs=outputs)
+        for r in range(reps + 1 if "sensitivities" not in name else 2):
+            ens = pkg.simulate_ensemble(p, Theta, pr, SOC=inp["SOC"], device=True, opts=o, max_points=inp["max_points"], outputs=outputs, YP=False,
+                                        sens=skeys if "sensitivities" in name else None)
             torch.cuda.synchronize()
             if r:
                 ms.append(float(ens.kernel_ms))
@@ -265,7 +269,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        return pkg.simulate_ensemble(p, Theta, inp["protocol"], SOC=inp["SOC"], device=True, stream=stream, max_points=inp["max_points"])
+        # YP = False: the reference's default output set (opts.outputs = (:t, :V); var_keep.YP is off) -- Y_final, every per-step scalar, run_info and the counters are written
+        return pkg.simulate_ensemble(p, Theta, inp["protocol"], SOC=inp["SOC"], device=True, stream=stream, max_points=inp["max_points"], YP=False)
 
     for _ in range(args.warmup):
         ens = step()
@@ -331,6 +336,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == "f64" else "f64 (fp32 storage of the Newton-matrix factors)",
             "data": "synthetic",
             "config": {"workload": c["text"] % n_local, "cells_per_gpu": n_local, "cells_total": n_total, "sharding": "independent cells, contiguous blocks, no data-path collective",
+                       "outputs": "per cell: t, V, I, SOC (and T_avg) at every saved point, Y_final, run_info, counters (YP_final not requested: the reference keeps YP only with var_keep.YP)",
                        "steps_per_trajectory": float(ens.counters["n_steps"].mean()), "newton_iters_per_trajectory": float(ens.counters["n_newton"].mean()),
                        "rank_kernel_ms": rank_kernel_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

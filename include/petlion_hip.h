@@ -293,6 +293,19 @@ int plh_init_consistent(plh_model_t m, int n_cells, const double* theta, int mod
 int plh_integrate(plh_model_t m, int n_cells, const double* theta, const double* SOC0, const double* Y_init, const double* t_init,
                   int n_runs, const plh_run* runs, const plh_opts* opts, const plh_outputs* out, int ptr_kind, void* stream);
 
+/* ---- forward parameter sensitivities next to the states ("parameter-sensitivity (forward) outputs for estimation workflows").  The reference has no such
+ * output: its users difference whole simulate() calls (one more simulate() per parameter and direction, with the adaptive step control's noise in the quotient).  Here
+ * s_k(t) = dY(t)/d theta[sens_cols[k]] is integrated with the same steps and orders as Y by the staggered-direct method (one linear solve per parameter and accepted step with
+ * the factorisation the integrator already holds; csrc/dfn_sens.h); Y, the saved points, run_info and the counters are bit for bit those of plh_integrate.
+ *   dY_dtheta[cell][k][n_states]  at the end of the last completed run (NaN for a cell whose protocol failed); may be NULL
+ *   dV_dtheta[cell][k][max_pts]   at every saved point (the Jacobian of the voltage curve a least-squares fit needs); may be NULL
+ *   sens_stat[cell][2]            corrector iterations spent, solves that did not reach the tolerance; may be NULL
+ * Derivatives are partial derivatives AT FIXED TIME with respect to the absolute value of the parameter: a run that ends on a bound ends at a time that itself depends on
+ * theta; that shift is not included (the last point is interpolated like the state's, model_evaluation.jl:369-382).  Protocols: constant or :rest inputs in the modes
+ * I, V, P, eta_p, dT, any number of runs, new solutions only; everything else is PLH_E_UNSUPPORTED.  ptr_kind PLH_HOST or PLH_DEVICE (the call is synchronous). */
+int plh_integrate_sens(plh_model_t m, int n_cells, const double* theta, const double* SOC0, int n_runs, const plh_run* runs, const plh_opts* opts,
+                       const plh_outputs* out, int n_sens, const int* sens_cols, double* dY_dtheta, double* dV_dtheta, int* sens_stat, int ptr_kind, void* stream);
+
 /* timing of the last plh_integrate kernel on its stream, measured with HIP events (ms); <0 if unavailable */
 double plh_last_kernel_ms(plh_model_t m);
 

@@ -77,7 +77,7 @@ assert RUN_INFO_DTYPE.itemsize == C.sizeof(RunInfo) and COUNTERS_DTYPE.itemsize 
 EXPORTS = ["plh_model_create", "plh_model_destroy", "plh_register_grid_library", "plh_n_states", "plh_n_diff", "plh_n_theta", "plh_theta_key",
            "plh_theta_default", "plh_lds_bytes", "plh_n_sections", "plh_section", "plh_jac_pattern", "plh_jac_alg_pattern", "plh_last_error", "plh_abi_layout",
            "plh_initial_guess", "plh_residual", "plh_jacobian", "plh_linear_solve", "plh_linear_solve_refined", "plh_residual_diff", "plh_residual_alg",
-           "plh_jacobian_alg", "plh_init_consistent", "plh_integrate", "plh_last_kernel_ms", "plh_host_alloc", "plh_host_free", "plh_synchronize",
+           "plh_jacobian_alg", "plh_init_consistent", "plh_integrate", "plh_integrate_sens", "plh_last_kernel_ms", "plh_host_alloc", "plh_host_free", "plh_synchronize",
            "plh_comm_unique_id", "plh_comm_create", "plh_comm_destroy", "plh_comm_rank", "plh_comm_size", "plh_ensemble_run"]
 
 
@@ -135,6 +135,7 @@ def load(path=None):
     lib.plh_ensemble_run.argtypes = [vp, vp, i, vp, vp, i, C.POINTER(Run), C.POINTER(Opts), i, vp, vp, vp, vp]
     lib.plh_init_consistent.argtypes = [vp, i, vp, i, d, d, vp, vp, vp, vp, i, vp]
     lib.plh_integrate.argtypes = [vp, i, vp, vp, vp, vp, i, C.POINTER(Run), C.POINTER(Opts), C.POINTER(Outputs), i, vp]
+    lib.plh_integrate_sens.argtypes = [vp, i, vp, vp, i, C.POINTER(Run), C.POINTER(Opts), C.POINTER(Outputs), i, vp, vp, vp, vp, i, vp]
     _cache[path] = lib
     return lib
 

@@ -461,8 +461,10 @@ def simulate_b(sol, p, tf=1e6, **kw):
     return simulate(p, tf, sol=sol, **kw)
 
 
-def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, stream=None, max_points=None, keep_Y=False):
-    """one plh_integrate call; numpy in / numpy out (host pointers) or torch device tensors (device=True)."""
+def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, stream=None, max_points=None, keep_Y=False, keep_YP=True, sens=None):
+    """one plh_integrate call; numpy in / numpy out (host pointers) or torch device tensors (device=True).
+    keep_YP = False: YP_final is not requested (the reference keeps YP only with var_keep.YP; the kernel then does not store the previous point's YP per step).
+    sens: list of theta keys -> plh_integrate_sens, bufs["dY_dtheta"][cell, k, state], bufs["dV_dtheta"][cell, k, point], bufs["sens_stat"][cell, 2]."""
     lib, h = p._lib, p._h
     n = theta.shape[0]
     N = p.N.tot
@@ -499,10 +501,22 @@ def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, 
     if keep_Y:                          # outputs = :all : every saved state vector
         bufs["Y_all"] = mk(n, mp, N) if device else np.empty((n, mp, N))
         out.Y_all = cap.ptr(bufs["Y_all"])
-    out.n_pts, out.Y_final, out.YP_final = cap.ptr(bufs["n_pts"]), cap.ptr(bufs["Y"]), cap.ptr(bufs["YP"])
+    out.n_pts, out.Y_final, out.YP_final = cap.ptr(bufs["n_pts"]), cap.ptr(bufs["Y"]), cap.ptr(bufs["YP"]) if keep_YP else None
     out.run_info, out.counters = cap.ptr(bufs["run_info"]), cap.ptr(bufs["counters"])
-    cap.check(lib, lib.plh_integrate(h, n, cap.ptr(theta), cap.ptr(SOC0), cap.ptr(Y_init), cap.ptr(t_init), len(runs), arr,
-                                     C.byref(os_), C.byref(out), kind, stream), "plh_integrate")
+    if sens:
+        cols = np.ascontiguousarray([p.θ_keys.index(k) for k in sens], dtype=np.int32)
+        ns = len(cols)
+        if device:
+            bufs["dY_dtheta"], bufs["dV_dtheta"], bufs["sens_stat"] = mk(n, ns, N), mk(n, ns, mp), mk(n, 2, dt=torch.int32)
+        else:
+            bufs["dY_dtheta"], bufs["dV_dtheta"], bufs["sens_stat"] = np.empty((n, ns, N)), np.empty((n, ns, mp)), np.zeros((n, 2), np.int32)
+        if Y_init is not None:
+            raise ValueError("sensitivities are integrated for new solutions only")
+        cap.check(lib, lib.plh_integrate_sens(h, n, cap.ptr(theta), cap.ptr(SOC0), len(runs), arr, C.byref(os_), C.byref(out), ns, cols.ctypes.data,
+                                              cap.ptr(bufs["dY_dtheta"]), cap.ptr(bufs["dV_dtheta"]), cap.ptr(bufs["sens_stat"]), kind, stream), "plh_integrate_sens")
+    else:
+        cap.check(lib, lib.plh_integrate(h, n, cap.ptr(theta), cap.ptr(SOC0), cap.ptr(Y_init), cap.ptr(t_init), len(runs), arr,
+                                         C.byref(os_), C.byref(out), kind, stream), "plh_integrate")
     if device:
         if stream is not None and int(stream) != torch.cuda.current_stream(dev).cuda_stream:
             # the buffers were allocated on torch's current stream but the kernel runs on `stream`: tell the caching allocator, or it may hand the
@@ -531,6 +545,8 @@ class EnsembleSolution:
         self._counters = bufs["counters"]
         self.run_names = run_names
         self._kernel_ms = bufs.get("kernel_ms", -1.0)
+        # forward parameter sensitivities (simulate_ensemble(..., sens=[keys])): [cell, k, state] at the end of the protocol, [cell, k, point] for the voltage
+        self.dY_dtheta, self.dV_dtheta, self.sens_stat = bufs.get("dY_dtheta"), bufs.get("dV_dtheta"), bufs.get("sens_stat")
 
     # With device=True the launch is asynchronous: the per-cell summaries stay in HBM until they are looked at (the first access synchronises),
     # so a host loop can enqueue launches back to back.
@@ -601,12 +617,15 @@ def make_protocol(p, protocol, n_cells=None):
     return runs, names
 
 
-def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, stream=None, max_points=None, outputs=None):
+def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, stream=None, max_points=None, outputs=None, YP=True, sens=None):
     """Integrate an ensemble of independent cells on this process's GPU.
 
     Theta: [n_cells, n_theta] array in `p.θ_keys` order (numpy = host memory; torch CUDA tensor with device=True = already in HBM).
     protocol: list of run dicts (see make_protocol) shared by all cells.  SOC: scalar or [n_cells] initial SOC.
     outputs: "all" (or any state name) also returns every saved state vector as ens.Y_all [cell, point, state] -- 8 N bytes per point.
+    YP = False: do not return YP of the final point (the reference's default: var_keep.YP is off unless :YP is among the outputs).
+    sens = ["D_sp", "k_n", ...]: forward sensitivities with respect to these entries of θ next to the states (plh_integrate_sens): ens.dY_dtheta[cell, k, state] at the
+    end of the protocol, ens.dV_dtheta[cell, k, point] at every saved point; the states and saved points are those of the call without `sens`.
     """
     n = Theta.shape[0]
     runs, names = make_protocol(p, protocol, n)
@@ -618,7 +637,7 @@ def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, 
     else:
         soc0 = np.full(n, float(soc)) if np.isscalar(soc) else np.asarray(soc, dtype=np.float64)
     bufs = _integrate(p, Theta, soc0, runs, o, device=device, stream=stream, max_points=max_points,
-                      keep_Y=_wants_states(p, o.outputs if outputs is None else outputs))
+                      keep_Y=_wants_states(p, o.outputs if outputs is None else outputs), keep_YP=YP, sens=sens)
     return EnsembleSolution(p, bufs, names)
 
 

@@ -268,6 +268,17 @@ struct LaneRegs {
   double rcp[CS_PASS];  // thermal model: 1 / (kappa_p lam_r - cj) of the last factorisation for this lane's (particle, radial mode) of each pass -- the spectral resolvent's diagonal
 };
 
+// forward parameter sensitivities (dfn_sens.h): what plh_integrate hands the kernel
+struct SensArgs {               // (device pointers; part of IntegrateArgs)
+  int n_sens;                   // number of theta columns differentiated (0: none)
+  const int* cols;              // [n_sens] 0-based positions in theta_keys
+  const double* theta_pert;     // [n_cells][n_sens][P]: the cell's theta row with column cols[k] perturbed (relative 1e-7; built by plh_integrate)
+  double* hist;                 // [n_cells][n_sens][MAXORD + 1][NPAD]: BDF history of every s_k
+  double* dY;                   // [n_cells][n_sens][N] or nullptr: dY/dtheta_k at the end of the last completed run
+  double* dV;                   // [n_cells][n_sens][max_pts] or nullptr: dV/dtheta_k at every saved point
+  int* stat;                    // [n_cells][2] or nullptr: corrector iterations, solves that did not reach the tolerance
+};
+
 // An index the compiler must treat as opaque: `base + PL_OPAQUE_IDX(lane part)` keeps the lane-dependent part of an LDS address in ONE register and leaves the compile-time part to
 // the instruction's offset field.  Without it the constant parts of S.<array>[lane part + const] are folded into one large immediate per access, which ds_read2_b64's 8-bit
 // offsets cannot hold: the compiler then materialises a separate address (v_add / v_mad) for every pair of loads -- a quarter of the instructions of the particle phases.
@@ -555,7 +566,7 @@ __device__ __forceinline__ void sinh_cosh(double x, double& sh, double& ch) {
 __device__ __forceinline__ double hmean(double beta, double a, double b) { return a * b / (beta * b + (1.0 - beta) * a); }
 
 // thermal-model counterparts (dfn_thermal.h); the generic entry points below dispatch to them when M::THERMAL
-template <class M> PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th);
+template <class M, bool INIT = true> PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th);
 template <bool WANT_RES, bool WANT_JAC, class M>
 PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value);
 template <bool WANT_JAC, class M> PL_DEV void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const double* Y, const double* YP, double* Fo);
@@ -567,7 +578,9 @@ constexpr int PL_MODE_DT_TWIN = 16;   // dT control row with YP_T replaced by rh
 // ------------------------------------------------------------------------------------------------------------------
 // per-cell constants from theta (build_auxiliary_states!, reference aux...jl:6-52, and the Arrhenius closures)
 // ------------------------------------------------------------------------------------------------------------------
-template <class M>
+// INIT = false: only the numbers derived from theta are (re)computed -- the Jacobian pools, the factors, the LDS copies of the radial tables and the particle registers are
+// left alone (the parameter-sensitivity phase evaluates residuals with a perturbed theta row between two solves of the integrator's factorisation: dfn_sens.h)
+template <class M, bool INIT = true>
 PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb, const double* __restrict__ th) {
   PL_MODEL(M);
   const int lane = lane_id();
@@ -661,15 +674,17 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
       const double C = FAR * c.a_n / (3600.0 * c.I1C) * ln;
       for (int k = 0; k < NN; k++)
         S.sei.sohw[k] = C * (wq[k + 1] + (k < 3 ? wq[0] * e[k] : 0.0) + (k > NN - 4 ? wq[NN + 1] * e[NN - 1 - k] : 0.0));
-      S.sei.cjf = 0.0;
+      if constexpr (INIT) S.sei.cjf = 0.0;
     }
   }
+  if constexpr (INIT) {
   if constexpr (M::SD == 0) { if (wave_id() == M::NWAVES - 1) {
     for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->Mp()[k]; S.Mr[S.OFF_VR + k] = tb->Vp()[k]; S.Mr[S.OFF_WR + k] = tb->Wp()[k]; if constexpr (!M::THERMAL) { S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
     if constexpr (!M::THERMAL) { if (lane < NR) S.Mr[S.OFF_LAMR + lane] = tb->LAMp()[lane]; } } }
   for (int k = 0; k < CS_PASS; k++) { R.wreg[k] = 0.0; R.rcp[k] = 0.0; }
+  }
   PL_XSYNC();
-  if constexpr (M::THERMAL) thermal_setup(S, tb, th);
+  if constexpr (M::THERMAL) thermal_setup<M, INIT>(S, tb, th);
 }
 
 // initial_guess!, reference src/states_definition.jl:80-121

@@ -36,7 +36,8 @@ struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live 
 //   ... | GF_REFINE        + iterative refinement of every linear solve (plh_opts.refine, the parity diagnostic)
 //   ... | GF_GENROW        + a closure of the state with derivative programs: the general control row (GenRow, dfn_cell.h); separate from GF_EXPR because its
 //                           presence alone costs the plain-closure kernel 9 % (registers around the Newton loop)
-enum GenFlag { GF_STOPS = 1, GF_FUNC = 2, GF_EXPR = 4, GF_REFINE = 8, GF_GENROW = 16 };
+//   GF_STOPS | GF_SENS     + forward parameter sensitivities dY/dtheta_k next to the states (dfn_sens.h; constant-input protocols)
+enum GenFlag { GF_STOPS = 1, GF_FUNC = 2, GF_EXPR = 4, GF_REFINE = 8, GF_GENROW = 16, GF_SENS = 32 };
 
 // device counters: wave-uniform registers (every call site uses a compile-time index), written out once at the end; indices:
 enum Cnt { C_STEPS, C_RES, C_JAC, C_FACT, C_SOLVE, C_NEWTON, C_ERRFAIL, C_CONVFAIL, C_SUMKP2, C_INIT };
@@ -755,6 +756,8 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
   return 0;
 }
 
+#include "dfn_sens.h"
+
 // ---- stop conditions (check_simulation_stop!, src/checks.jl:1-224); scalars are wave-uniform ----
 struct PrevVals { double frac, V, SOC, I, c_s_n, c_e_min, eta_pl, dfilm, T; };
 
@@ -830,16 +833,22 @@ struct CellOut {
   int max_pts;
 };
 
-// the whole protocol for one cell.  Yprev/YPprev: per-cell scratch in HBM holding the previous accepted point (needed only for
-// the back-interpolation at the end of a run; written with coalesced fire-and-forget stores every step).
+// the whole protocol for one cell.  Yprev/YPprev: per-cell scratch in HBM.  The back-interpolation of a run that ends on a bound (interp_final_points!) needs the
+// PREVIOUS accepted point.  Its Y is not stored: after IDACompleteStep the BDF history holds phi[0] = y_n and phi[1] = y_n - y_(n-1) (the first modified divided
+// difference), so y_(n-1) = phi[0] - phi[1] to the last bit of y_n -- formed only when a bound fires, instead of N stores per step (r03: 1.0 MB of the 1.8 MB written per C3
+// trajectory).  Its YP is not a linear function of the current history once the order has dropped, so YPprev IS stored per step -- but only when the caller asked for
+// YP_final (the reference interpolates YP only with var_keep.YP, model_evaluation.jl:369-373; without it nothing reads YP of a run end: the next run starts from
+// newtons_method!, which resets it).  Yprev also keeps the point a run (re)starts from, for check_solve's first-step retry (checks.jl:227-237).
 // F: feature flags (GenFlag): constant-input protocols (the benchmark path) carry none of the general code
 template <int F, class M>
 PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
                                      const CellOut& out, int* n_pts_out, plh_run_info* info, Counters& cnt, double* Yfin, double* YPfin,
-                                     double* Yprev, double* YPprev, int cell, double* genW = nullptr) {
+                                     double* Yprev, double* YPprev, int cell, double* genW = nullptr, SensArgs sens = SensArgs(), const double* th0 = nullptr) {
   PL_MODEL(M);
   const int lane = lane_id();
   IdaScalars I;
+  [[maybe_unused]] SensCell<M> SX;
+  if constexpr ((F & GF_SENS) != 0) { SX.a = sens; SX.th0 = th0; SX.cell = cell; SX.P = tb->P; SX.max_pts = out.max_pts; SX.first = true; SX.n_it = 0; SX.n_fail = 0; }
   int nout = 0;
   bool have_prev = false;
   const double T0 = S.cc.T0;
@@ -942,6 +951,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     double tprev = 0.0, t = 0.0, t_prev_saved = t0; int iter = 1; bool stalled_once = false;
     double I_prev_pt = 0.0, t_restart = 0.0;
     bool first_init = true, again = false, init_failed = false;
+    [[maybe_unused]] int steps_since_restart = 2;                       // (accepted steps since a check_reinitialization! restart; 2 = "more than one")
     do {                                                                // (re)initialise -> integrate ; loops only for check_reinitialization!
     again = false;
     int ierr; { PL_TIC(); ierr = cell_init_consistent<F>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt, S.phi[0], o.refine,
@@ -956,6 +966,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
       PL_SYNC();
       I_prev_pt = S.yy[O_I];
+      if constexpr ((F & GF_SENS) != 0) sens_init(S, SX, mode, value, new_run, SOC0, o.reltol, o.abstol, nout - 1);
     }
     while (flag == PLH_FLAG_RUNNING) {
       double tret = t; tprev = t;
@@ -981,6 +992,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
         flag = sf; break;
       }
       iter++; t = tret;
+      if constexpr ((F & GF_FUNC) != 0) steps_since_restart++;
       PL_TIC(); PL_TICE(3);
       const double SOC_new = SOC + 0.5 * ((t + t0) - t_prev_saved) * (S.yy[O_I] + I_prev_pt) / 3600.0;   // calc_SOC, scalar_residual.jl:103-111
       SOC = SOC_new;
@@ -988,19 +1000,28 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       PL_TOCE(S, 3, 4);
       check_stop(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
       PL_TOCE(S, 3, 5);
+      if constexpr ((F & GF_SENS) != 0) sens_step(S, R, I, SX, mode, value, nout - 1);      // (the solution point in S.yy / S.yp is saved and restored around it)
       if (!is_fun && t == tprev) { flag = PLH_ERR_STALL; break; }      // (run_function has no stall test, checks.jl:251-269; run_residual -- res, dT, d<state> -- has: checks.jl:226)
       if (iter == o.maxiters) { flag = PLH_ERR_MAXITERS; break; }
       if (nout >= out.max_pts && out.max_pts > 0 && flag == PLH_FLAG_RUNNING) { flag = PLH_ERR_OUTPUT_FULL; break; }
       if (flag == PLH_FLAG_RUNNING) {
-#ifndef PL_EXP_NO_PREV      /* (experiment build: upper bound of what the per-step previous-point copy costs; results of runs that end on a bound are then wrong) */
-        PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }      // fire-and-forget: read back only when a bound fires
+#ifdef PL_EXP_STORE_PREV     /* (A/B build: r03's per-step copy of the whole previous point) */
+        PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
+#else
+        if (YPfin) { PL_VEC(n) YPprev[n] = S.yp[n]; }                // fire-and-forget: read back only when a bound fires (wave-uniform condition)
 #endif
         t_prev_saved = t + t0; I_prev_pt = S.yy[O_I];
         if constexpr ((F & GF_FUNC) != 0) if (is_fun && t - tprev < 1e-3 * o.reltol) {                    // check_reinitialization!, checks.jl:341-364
           const double t_new = t + o.reltol, v_new = run_input<F>(S, run, t_new, S.yy, S.yp);
           const double big = fabs(value) > fabs(v_new) ? fabs(value) : fabs(v_new);
           const double tolv = o.abstol > o.reltol * big ? o.abstol : o.reltol * big;
-          if (!(fabs(value - v_new) <= tolv)) { value = v_new; t_restart = t_new; again = true; }
+          if (!(fabs(value - v_new) <= tolv)) {
+            value = v_new; t_restart = t_new; again = true;
+            // the last saved point: check_solve's retry restores it, and if a bound fires on the FIRST step after the re-initialisation it is the previous point of the
+            // back-interpolation (the history then starts at the re-initialised state, whose algebraic part is not the saved one)
+            PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
+            steps_since_restart = 0;
+          }
         }
       }
       PL_TOC(S, PH_OUTPUT); PL_TOCE(S, 3, 6);
@@ -1013,12 +1034,20 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       const double fr = pv.frac;
       const double ti = fr * (t - tprev) + tprev;
       PL_XSYNC();
+#ifdef PL_EXP_STORE_PREV
       PL_VEC(n) { S.yy[n] = fr * (S.yy[n] - Yprev[n]) + Yprev[n]; S.yp[n] = fr * (S.yp[n] - YPprev[n]) + YPprev[n]; }
+#else
+      // (t > 1 excludes the point a run starts from: at least one step has been completed, phi[0] / phi[1] are those of the step that crossed the bound)
+      if ((F & GF_FUNC) && steps_since_restart == 1) { PL_VEC(n) { const double yprev = Yprev[n]; S.yy[n] = fr * (S.yy[n] - yprev) + yprev; } }
+      else { PL_VEC(n) { const double yprev = S.phi[0][n] - S.phi[1][n]; S.yy[n] = fr * (S.yy[n] - yprev) + yprev; } }
+      if (YPfin) { PL_VEC(n) { const double ypp = YPprev[n]; S.yp[n] = fr * (S.yp[n] - ypp) + ypp; } }
+#endif
       PL_XSYNC();
       SOC = SOC + 0.5 * ((ti + t0) - (t + t0)) * (S.yy[O_I] + S.yy[O_I]) / 3600.0;
       t_end = ti + t0;
       save_pt(nout - 1, t_end, S.yy, SOC);
     }
+    if constexpr ((F & GF_SENS) != 0) sens_finish(S, SX, flag > 0 && o.interp_final && t > 1.0, pv.frac, flag < 0, nout - 1);
     ri.flag = flag; ri.iterations = iter; ri.t_end = t_end; ri.V = cellV<M>(S.yy); ri.I = S.yy[O_I]; ri.SOC = SOC; ri.T_avg = cellTavg<M>(S, S.yy);
     if (lane == 0 && wave_id() == 0) info[r] = ri;
     have_prev = true;
@@ -1029,6 +1058,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
   }
   if (lane == 0 && wave_id() == 0 && n_pts_out) *n_pts_out = nout < out.max_pts ? nout : out.max_pts;
   PL_XSYNC();
+  if constexpr ((F & GF_SENS) != 0) { if (lane == 0 && wave_id() == 0 && sens.stat) { sens.stat[2 * cell] = SX.n_it; sens.stat[2 * cell + 1] = SX.n_fail; } }
   if (Yfin) PL_VEC(n) Yfin[n] = S.yy[n];
   if (YPfin) PL_VEC(n) YPfin[n] = S.yp[n];
 }

@@ -1,0 +1,227 @@
+// dfn_sens.h -- forward parameter sensitivities s_k(t) = dY(t)/d theta_k, integrated alongside the states ("parameter-sensitivity (forward) outputs for
+// estimation workflows").  The reference has no such output (its users difference whole simulate() calls); what is restated here is the textbook staggered-direct method of
+// DAE sensitivity analysis (Maly & Petzold 1996; the method SUNDIALS IDAS documents as IDA_STAGGERED with difference-quotient sensitivity residuals) on top of the
+// fixed-leading-coefficient BDF of dfn_integrate.h:
+//
+//   F(t, y, y', theta) = 0   =>   F_y s + F_y' s' + F_theta = 0        (one linear DAE per parameter, same step sizes and orders as y)
+//
+//   * after every ACCEPTED step (y_n, y'_n converged, the step's coefficients final) each s_k gets the BDF treatment of y: predictor from its own history of modified divided
+//     differences (same beta / gamma), s' = s'_pred + cj (s - s_pred), corrector  s <- s - c J~^-1 r(s)  with r(s) = F_y s + F_y' s' + F_theta and the integrator's CURRENT
+//     (possibly stale) factorisation J~ -- the matrix the Newton iteration of y has just converged with; c = 2 / (1 + cj/cj_factor) as in IDANls.  r is linear in s, so the
+//     iteration converges at the rate of that Newton iteration; it runs to a tolerance 1e-5 of the states' own error weights per unit relative parameter change.
+//   * the residual of the sensitivity system is formed by directional difference quotients of the model's own residual -- no second set of equations to keep in step:
+//     F_y s + F_y' s' = (F(y + e s, y' + e s') - F(y, y')) / e ,  F_theta = (F(.; theta + d e_k) - F(.; theta)) / d  (the cell constants are recomputed from the perturbed
+//     theta row for that one evaluation: cell_setup<M, false>).
+//   * the states are NOT affected: no error control on s (IDAS' errconS = false), the factorisation is only used, never refreshed, the solution point of the step is saved and
+//     restored around the phase -- a run with sensitivities takes bit for bit the steps of the run without.
+//   * start of a run: s_diff from the initial guess (difference quotient of initial_guess! in theta) or carried from the previous run; s_alg from the algebraic equations with
+//     the consistent initialisation's own factorisation; s'_diff = d rhs / d theta, s'_alg = 0 (the first step is BDF1: s' only seeds the predictor).
+//   * end of a run on a bound: the reference replaces the last point by a linear interpolation between the last two accepted points (interp_final_points!,
+//     model_evaluation.jl:369-382); s gets the same interpolation with the same fraction.  What is reported is the partial derivative AT FIXED TIME: the dependence of the
+//     stop time itself on theta (a bound crossed earlier or later) is not part of it.
+// The history of each s_k (MAXORD + 1 vectors) lives in HBM, lane-strided like every state vector; everything else is registers and the three LDS work vectors of the
+// integrator, which are dead between the output of a step and the next predictor.
+#pragma once
+// (included from dfn_integrate.h, inside namespace pl, after IdaScalars / PL_VEC / EWT)
+
+constexpr int SENS_MAXIT = 16;
+// weights of the sensitivity norms: 1 / (|y_n| + abstol / reltol) = the integrator's error weights with the tolerance divided out -- the corrector stops when a correction,
+// times the parameter, is below SENS_TOL of the scale of each state (the difference quotients carry ~1e-9 of rounding: a criterion that tightened with reltol could not be met)
+constexpr double SENS_TOL = 1e-7, SENS_FD = 1e-7;
+
+__device__ __forceinline__ double wave_max(double v) {
+  for (int o = WAVE / 2; o >= 1; o >>= 1) { const double r = __shfl_xor(v, o); v = v > r ? v : r; }
+  return v;
+}
+
+template <class M> struct SensCell {
+  SensArgs a; const double* th0; int cell, P, max_pts;
+  bool first;                   // the next accepted step is the first of this integrator instance: hist[1] holds s'(t0), not h s'
+  int n_it, n_fail;
+  __device__ __forceinline__ double* hist(int k, int j) const { return a.hist + (((size_t)cell * a.n_sens + k) * (MAXORD + 1) + j) * M::NPAD; }
+  __device__ __forceinline__ const double* thp(int k) const { return a.theta_pert + ((size_t)cell * a.n_sens + k) * P; }
+};
+
+// F(phi[0] + e s, ypn + e sp) -> S.delta   (S.yy / S.yp are the work vectors)
+template <class M>
+PL_DEV void sens_eval(CellLDS<M>& S, LaneRegs& R, const double (&s)[M::NTRIP], const double (&sp)[M::NTRIP], const double (&ypn)[M::NTRIP], double e, int mode, double value) {
+  PL_MODEL(M);
+  const int lane = lane_id();
+  PL_VEC(n) { S.yy[n] = S.phi[0][n] + e * s[k__]; S.yp[n] = ypn[k__] + e * sp[k__]; }
+  PL_XSYNC();
+  cell_residual(S, R, S.yy, S.yp, S.delta, mode, value);
+  PL_XSYNC();
+}
+
+// dV/dtheta_k of the point just saved: S.delta holds s_k
+template <class M>
+PL_DEV void sens_put_V(CellLDS<M>& S, const SensCell<M>& X, int k, int idx) {
+  PL_MODEL(M);
+  if (lane_id() == 0 && wave_id() == 0 && X.a.dV && idx >= 0 && idx < X.max_pts)
+    X.a.dV[((size_t)X.cell * X.a.n_sens + k) * X.max_pts + idx] = S.delta[O_PS] - S.delta[O_PS + NJ - 1];
+}
+
+// start of a run (after the consistent initialisation and ida_reinit: S.phi[0] = y0, S.yp = y'0, the algebraic block factored): s_k(t0), s'_k(t0) -> history
+template <class M>
+PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, bool new_solution, double SOC0, double rtol, double atol, int idx) {
+  PL_MODEL(M);
+  const int lane = lane_id();
+  LaneRegs Ra;                                            // (the algebraic solves do not touch the particle registers)
+  for (int q = 0; q < CS_PASS; q++) { Ra.wreg[q] = 0.0; Ra.rcp[q] = 0.0; }
+  const int amode = (M::THERMAL && mode == PLH_MODE_DT) ? PL_MODE_DT_TWIN : mode;      // the algebraic form of the dT row (cell_init_consistent)
+  double yn[NTRIP], ypn[NTRIP], f0[NTRIP], w[NTRIP], zero[NTRIP];
+  PL_VEC(n) { yn[k__] = S.yy[n]; ypn[k__] = S.yp[n]; zero[k__] = 0.0; w[k__] = 1.0 / (fabs(S.phi[0][n]) + atol / rtol); }
+  PL_XSYNC();
+  sens_eval(S, Ra, zero, zero, ypn, 0.0, amode, value);
+  PL_VEC(n) f0[k__] = S.delta[n];
+  for (int k = 0; k < X.a.n_sens; k++) {
+    const double* tp = X.thp(k); const int col = X.a.cols[k];
+    const double dth = tp[col] - X.th0[col], psc = fabs(X.th0[col]) > 0.0 ? fabs(X.th0[col]) : 1.0;
+    double s[NTRIP], fp[NTRIP];
+    double* h0 = X.hist(k, 0);
+    PL_XSYNC();
+    cell_setup<M, false>(S, Ra, S.tb, tp);                // constants of the perturbed theta row
+    if (new_solution) {                                   // d(initial guess)/d theta (initial_guess!, states_definition.jl:80-121): the differential states
+      cell_initial_guess(S, S.delta, SOC0);
+      PL_XSYNC();
+      PL_VEC(n) s[k__] = n < NDIFF ? (S.delta[n] - S.phi[0][n]) / dth : 0.0;
+      PL_XSYNC();
+    } else { PL_VEC(n) s[k__] = h0[n]; }                  // carried from the end of the previous run (the algebraic part: first guess only)
+    sens_eval(S, Ra, zero, zero, ypn, 0.0, amode, value);
+    PL_VEC(n) fp[k__] = (S.delta[n] - f0[k__]) / dth;
+    cell_setup<M, false>(S, Ra, S.tb, X.th0);
+    PL_XSYNC();
+    // algebraic part: G_ya s_a = -(G_yd s_d + G_theta), Newton-like with the factorisation of the last initialisation iterate
+    bool conv = false;
+    for (int it = 0; it < SENS_MAXIT; it++) {
+      double m = 0.0;
+      PL_VEC(n) { const double q = fabs(s[k__]) * w[k__]; m = q > m ? q : m; }
+      m = wave_max(m);
+      const double e = m > 0.0 ? SENS_FD / m : 1.0, re = 1.0 / e;
+      sens_eval(S, Ra, s, zero, ypn, e, amode, value);
+      PL_VEC(n) S.delta[n] = (S.delta[n] - f0[k__]) * re + fp[k__];
+      PL_XSYNC();
+      cell_solve(S, Ra, S.delta, amode, true);
+      PL_XSYNC();
+      double nr = 0.0;
+      PL_VEC(n) if (n >= NDIFF) { const double d = S.delta[n]; s[k__] -= d; const double q = d * w[k__] * psc; nr += q * q; }
+      nr = sqrt(wave_sum(nr) * (1.0 / NST));
+      X.n_it++;
+      PL_XSYNC();
+      if (nr <= SENS_TOL) { conv = true; break; }
+      if (!(nr == nr)) break;
+    }
+    if (!conv) X.n_fail++;
+    // s'_diff = d rhs_diff / dy s + d rhs_diff / d theta (F_diff = rhs - y'); s'_alg = 0
+    {
+      double m = 0.0;
+      PL_VEC(n) { const double q = fabs(s[k__]) * w[k__]; m = q > m ? q : m; }
+      m = wave_max(m);
+      const double e = m > 0.0 ? SENS_FD / m : 1.0, re = 1.0 / e;
+      sens_eval(S, Ra, s, zero, ypn, e, amode, value);
+      double* h1 = X.hist(k, 1);
+      PL_VEC(n) { h0[n] = s[k__]; h1[n] = n < NDIFF ? (S.delta[n] - f0[k__]) * re + fp[k__] : 0.0; }
+      PL_XSYNC();
+      PL_VEC(n) S.delta[n] = s[k__];
+      PL_XSYNC();
+      sens_put_V(S, X, k, idx);
+      PL_XSYNC();
+    }
+  }
+  X.first = true;
+  PL_VEC(n) { S.yy[n] = yn[k__]; S.yp[n] = ypn[k__]; }
+  PL_XSYNC();
+}
+
+// after an accepted step: advance every s_k over the same step (S.phi = history after IDACompleteStep, S.yy / S.yp = y(tn), y'(tn), I = the step's coefficients)
+template <class M>
+PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<M>& X, int mode, double value, int idx) {
+  PL_MODEL(M);
+  const int lane = lane_id();
+  const int ku = I.kused; const double cj = I.cj;
+  const double sc = (I.cjratio != 1.0) ? 2.0 / (1.0 + I.cjratio) : 1.0;
+  double yn[NTRIP], ypn[NTRIP], f0[NTRIP], zero[NTRIP];
+  PL_VEC(n) { yn[k__] = S.yy[n]; ypn[k__] = S.yp[n]; zero[k__] = 0.0; }
+  PL_XSYNC();
+  sens_eval(S, R, zero, zero, ypn, 0.0, mode, value);      // F(y_n, y'_n): the base of every difference quotient of this step
+  PL_VEC(n) f0[k__] = S.delta[n];
+  for (int k = 0; k < X.a.n_sens; k++) {
+    const double* tp = X.thp(k); const int col = X.a.cols[k];
+    const double dth = tp[col] - X.th0[col], psc = fabs(X.th0[col]) > 0.0 ? fabs(X.th0[col]) : 1.0;
+    double fp[NTRIP], a_[NTRIP], b_[NTRIP], s[NTRIP];
+    PL_XSYNC();
+    cell_setup<M, false>(S, R, S.tb, tp);
+    sens_eval(S, R, zero, zero, ypn, 0.0, mode, value);
+    PL_VEC(n) fp[k__] = (S.delta[n] - f0[k__]) / dth;
+    cell_setup<M, false>(S, R, S.tb, X.th0);
+    PL_XSYNC();
+    // predictor from the history (IDASetCoeffs' rescaling phi*_j = beta_j phi_j for j >= ns is applied in place, as form_iterate does for y)
+    double* h0 = X.hist(k, 0);
+    PL_VEC(n) { a_[k__] = h0[n]; b_[k__] = 0.0; }
+    for (int j = 1; j <= MAXORD; j++) if (j <= ku) {
+      double* hj = X.hist(k, j);
+      const double g = S.ida_gamma[j];
+      double bt = j >= I.ns ? S.ida_beta[j] : 1.0;
+      if (X.first && j == 1) bt = I.hused;               // first step of the integrator: hist[1] = s'(t0) -> h s'(t0) (beta_1 = 1 there)
+      PL_VEC(n) { const double p = hj[n] * bt; hj[n] = p; a_[k__] += p; b_[k__] += g * p; }
+    }
+    PL_VEC(n) s[k__] = a_[k__];
+    bool conv = false;
+    for (int it = 0; it < SENS_MAXIT; it++) {
+      double sp[NTRIP], m = 0.0;
+      PL_VEC(n) { sp[k__] = b_[k__] + cj * (s[k__] - a_[k__]); const double q = fabs(s[k__]) * EWT(n); m = q > m ? q : m; }
+      m = wave_max(m) * I.rtol;
+      const double e = m > 0.0 ? SENS_FD / m : 1.0, re = 1.0 / e;
+      sens_eval(S, R, s, sp, ypn, e, mode, value);
+      PL_VEC(n) S.delta[n] = (S.delta[n] - f0[k__]) * re + fp[k__];
+      PL_XSYNC();
+      cell_solve(S, R, S.delta, mode, false);
+      PL_XSYNC();
+      double nr = 0.0;
+      PL_VEC(n) { const double d = S.delta[n] * sc; s[k__] -= d; const double q = d * EWT(n) * (psc * I.rtol); nr += q * q; }
+      nr = sqrt(wave_sum(nr) * (1.0 / NST));
+      X.n_it++;
+      PL_XSYNC();
+      if (nr <= SENS_TOL) { conv = true; break; }
+      if (!(nr == nr)) break;
+    }
+    if (!conv) X.n_fail++;
+    // history update (IDACompleteStep): phi[ku+1] = e, phi[ku] += e, phi[j] += phi[j+1]
+    {
+      double acc[NTRIP];
+      PL_VEC(n) acc[k__] = s[k__] - a_[k__];
+      if (ku < I.maxord) { double* hn = X.hist(k, ku + 1); PL_VEC(n) hn[n] = acc[k__]; }
+      for (int j = MAXORD; j >= 0; j--) if (j <= ku) { double* hj = X.hist(k, j); PL_VEC(n) { acc[k__] += hj[n]; hj[n] = acc[k__]; } }
+      PL_VEC(n) S.delta[n] = acc[k__];                     // = s_k(t_n)
+      PL_XSYNC();
+      sens_put_V(S, X, k, idx);
+      PL_XSYNC();
+    }
+  }
+  X.first = false;
+  PL_VEC(n) { S.yy[n] = yn[k__]; S.yp[n] = ypn[k__]; }
+  PL_XSYNC();
+}
+
+// end of a run: s_k at the run's last point (back-interpolated like the states when the run ended on a bound) -> hist[0] (what the next run continues from), dY, dV
+template <class M>
+PL_DEV void sens_finish(CellLDS<M>& S, SensCell<M>& X, bool interp, double fr, bool failed, int idx) {
+  PL_MODEL(M);
+  const int lane = lane_id();
+  const double nan = __builtin_nan("");
+  for (int k = 0; k < X.a.n_sens; k++) {
+    double* h0 = X.hist(k, 0); const double* h1 = X.hist(k, 1);
+    PL_XSYNC();
+    PL_VEC(n) {
+      double v = h0[n];
+      if (interp && !X.first) { const double prev = v - h1[n]; v = fr * (v - prev) + prev; }      // (hist[1] = s_n - s_(n-1) once a step has been completed)
+      if (failed) v = nan;
+      h0[n] = v; S.delta[n] = v;
+      if (X.a.dY) X.a.dY[((size_t)X.cell * X.a.n_sens + k) * NST + n] = v;
+    }
+    PL_XSYNC();
+    if (interp || failed) sens_put_V(S, X, k, idx);
+  }
+  PL_XSYNC();
+}
+

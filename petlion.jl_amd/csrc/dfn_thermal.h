@@ -80,7 +80,7 @@ template <class TP_> __device__ __forceinline__ double thermal_aD(const TP_& TP,
   return -(TP.aL[it] + TP.aU[it]) - e;
 }
 
-template <class M>
+template <class M, bool INIT>
 PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const double* __restrict__ th) {
   static_assert((M::CHEM == PLH_CHEM_LCO_LIC6 || M::CHEM == PLH_CHEM_LGM50) && !M::SEI, "temperature = true is instantiated for LCO/LiC6 and NMC_LGM50/LiC6_LGM50 without aging");
   // Discretisations with temperature = true (reference src/params.jl:119-136 takes any N_p, N_s, N_n, N_a, N_z, N_r).  What the elimination needs: each electrode inside its
@@ -132,8 +132,10 @@ PL_DEV void thermal_setup(CellLDS<M>& S, const Tables* __restrict__ tb, const do
     if (it == 0) TP.qI[0] = c.I1C * c.I1C / th[ix[K_sig_a]] * rc;
     if (it == NT - 1) TP.qI[1] = c.I1C * c.I1C / th[ix[K_sig_z]] * rc;
   }
-  if (lane < 12) (&TP.TX2[0][0])[lane] = 0.0;
-  if (lane == 0) TP.cjf = 0.0;
+  if constexpr (INIT) {
+    if (lane < 12) (&TP.TX2[0][0])[lane] = 0.0;
+    if (lane == 0) TP.cjf = 0.0;
+  }
   PL_SYNC();
 }
 

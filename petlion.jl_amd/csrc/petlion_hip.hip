@@ -578,8 +578,31 @@ int plh_init_consistent(plh_model_t m, int n, const double* theta, int mode, dou
   return 0;
 }
 
-int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0, const double* Y_init, const double* t_init, int n_runs,
-                  const plh_run* runs, const plh_opts* opts, const plh_outputs* out, int kind, void* stream) {
+// forward parameter sensitivities of a plh_integrate_sens call (dfn_sens.h)
+struct SensReq { int n_sens; const int* cols; double* dY; double* dV; int* stat; };
+// theta_pert[cell][k][:] = the cell's theta row with column cols[k] moved by a relative 1e-7 (an absolute 1e-7 where the entry is zero)
+__host__ __device__ inline void theta_pert_entry(const double* theta, const int* cols, int n_sens, int P, double* out, size_t q) {
+  const int col = (int)(q % P), k = (int)((q / P) % n_sens); const size_t cell = q / ((size_t)P * n_sens);
+  const double v = theta[cell * P + col];
+  out[q] = col == cols[k] ? (v != 0.0 ? v * (1.0 + 1e-7) : 1e-7) : v;
+}
+#ifndef PL_WAVE_EMU
+__global__ void k_theta_pert(const double* theta, const int* cols, int n_cells, int n_sens, int P, double* out) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < (size_t)n_cells * n_sens * P) theta_pert_entry(theta, cols, n_sens, P, out, q);
+}
+#endif
+static void launch_theta_pert(hipStream_t st, const double* theta, const int* cols, int n_cells, int n_sens, int P, double* out) {
+  const size_t tot = (size_t)n_cells * n_sens * P;
+#ifndef PL_WAVE_EMU
+  hipLaunchKernelGGL(k_theta_pert, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, theta, cols, n_cells, n_sens, P, out);
+#else
+  (void)st; for (size_t q = 0; q < tot; q++) theta_pert_entry(theta, cols, n_sens, P, out, q);      // (the emulator's "device" memory is host memory)
+#endif
+}
+
+static int integrate_impl(plh_model_t m, int n, const double* theta, const double* SOC0, const double* Y_init, const double* t_init, int n_runs,
+                          const plh_run* runs, const plh_opts* opts, const plh_outputs* out, int kind, void* stream, const SensReq* sq) {
   CHECK_MODEL(m);
   if (kind != PLH_HOST && kind != PLH_DEVICE && kind != PLH_HOST_ASYNC) return fail(PLH_E_ARG, "bad ptr_kind");
   if (n <= 0 || !theta || !SOC0 || n_runs <= 0 || !runs || !opts || !out || !out->run_info) return fail(PLH_E_ARG, "bad argument");
@@ -652,6 +675,16 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   if (opts->n_tstops < 0 || (opts->n_tstops > 0 && !opts->tstops)) return fail(PLH_E_ARG, "tstops");
   for (int k = 0; k < opts->n_tstops; k++) if (!(opts->tstops[k] == opts->tstops[k])) return fail(PLH_E_ARG, "tstops must not contain NaN");
   if (opts->refine < 0 || opts->refine > 4) return fail(PLH_E_ARG, "refine must be 0 .. 4");
+  if (sq) {
+    if (sq->n_sens < 1 || sq->n_sens > 64 || !sq->cols || (!sq->dY && !sq->dV)) return fail(PLH_E_ARG, "plh_integrate_sens: 1 <= n_sens <= 64, theta columns and at least one of dY_dtheta / dV_dtheta");
+    for (int k = 0; k < sq->n_sens; k++) if (sq->cols[k] < 0 || sq->cols[k] >= m->P) return fail(PLH_E_ARG, "plh_integrate_sens: theta column out of range");
+    if (Y_init) return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: sensitivities of a continued solution (Y_init) are not carried across calls");
+    if (m->ops->w2) return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: one wavefront per cell only");
+    if (opts->refine > 0 || opts->n_tdiscon > 0) return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: not with refine / tdiscon");
+    for (int r = 0; r < n_runs; r++)
+      if ((runs[r].value_kind != PLH_VAL_CONST && runs[r].value_kind != PLH_VAL_REST) || runs[r].mode == PLH_MODE_RES || runs[r].mode == PLH_MODE_DSTATE)
+        return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: constant (or :rest) inputs in the modes I, V, P, eta_p, dT (a :hold value or a function input depends on theta through the previous run / the state)");
+  }
   DeviceGuard guard(m->device);
   Stage s(m, kind, stream);
   StreamCtx& cx = *s.cx;
@@ -725,6 +758,24 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   a.out.Y_all = s.buf(out->Y_all, np * m->N, false);
   a.out.Y_final = s.buf(out->Y_final, (size_t)n * m->N, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * m->N, false);
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
+  a.sens.n_sens = 0; a.sens.cols = nullptr; a.sens.theta_pert = nullptr; a.sens.hist = nullptr; a.sens.dY = nullptr; a.sens.dV = nullptr; a.sens.stat = nullptr;
+  size_t n_dY = 0, n_dV = 0;
+  if (sq) {
+    const int ns = sq->n_sens, NPAD = m->N + (m->N & 1);
+    n_dY = (size_t)n * ns * m->N; n_dV = (size_t)n * ns * out->max_pts;
+    a.sens.n_sens = ns;
+    a.sens.cols = s.in_host(sq->cols, ns);
+    double* tp = (double*)s.dev_block((size_t)n * ns * m->P * sizeof(double));
+    a.sens.hist = (double*)s.dev_block((size_t)n * ns * 6 * NPAD * sizeof(double));
+    a.sens.dY = s.buf(sq->dY, n_dY, false); a.sens.dV = s.buf(sq->dV, n_dV, false); a.sens.stat = s.buf(sq->stat, (size_t)2 * n, false);
+    CHECK_STAGE(s);
+    a.sens.theta_pert = tp;
+    launch_theta_pert(s.st, a.theta, a.sens.cols, n, ns, m->P, tp);
+    // outputs of cells that never get as far as writing them read as NaN (all-ones bytes)
+    if (a.sens.dY) HIPCHK(hipMemsetAsync(a.sens.dY, 0xff, n_dY * sizeof(double), s.st));
+    if (a.sens.dV) HIPCHK(hipMemsetAsync(a.sens.dV, 0xff, n_dV * sizeof(double), s.st));
+    if (a.sens.stat) HIPCHK(hipMemsetAsync(a.sens.stat, 0, (size_t)2 * n * sizeof(int), s.st));
+  }
   CHECK_STAGE(s);                                                     // a failed staging allocation must never reach the kernel as a NULL ("not requested") output
   hipEventRecord(cx.ev0, s.st);
   // the instantiation that has the features this call asks for (GenFlag, dfn_integrate.h): 1 = stop times / state dump, 2 = table inputs, 4 = closure inputs, 8 = refinement, 16 = general control row
@@ -733,18 +784,32 @@ int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0,
   for (int r = 0; r < n_runs; r++) { if (runs[r].value_kind == PLH_VAL_TABLE) features |= 1 | 2; if (runs[r].value_kind == PLH_VAL_EXPR) features |= 1 | 2 | 4; }
   if (need_genW) features |= 1 | 2 | 4 | 16;                                     // closures with derivative programs: the general control row
   if (opts->refine > 0) features |= 1 | 2 | 4 | 8;
+  if (sq) features = 1 | 32;                                                     // GF_STOPS | GF_SENS
   m->ops->integrate(s.st, a, features);
   hipEventRecord(cx.ev1, s.st);
   cx.timed = true; m->last = &cx;
   FINISH(s);
-  if (!plain && kind != PLH_HOST) HIPCHK(hipStreamSynchronize(s.st));   // staged tables / per-cell values are released below: the kernel must be done with them
+  if ((!plain || sq) && kind != PLH_HOST) HIPCHK(hipStreamSynchronize(s.st));   // staged tables / per-cell values / sensitivity workspaces are released below: the kernel must be done with them
   s.back(out->t, a.out.t, np); s.back(out->V, a.out.V, np); s.back(out->I, a.out.I, np); s.back(out->SOC, a.out.SOC, np);
   s.back(out->T_avg, a.out.T_avg, np); s.back(out->n_pts, a.out.n_pts, n); s.back(out->Y_all, a.out.Y_all, np * m->N);
   s.back(out->Y_final, a.out.Y_final, (size_t)n * m->N); s.back(out->YP_final, a.out.YP_final, (size_t)n * m->N);
   s.back(out->run_info, a.out.run_info, (size_t)n * n_runs); s.back(out->counters, a.out.counters, n);
+  if (sq) { s.back(sq->dY, a.sens.dY, n_dY); s.back(sq->dV, a.sens.dV, n_dV); s.back(sq->stat, a.sens.stat, (size_t)2 * n); }
   CHECK_STAGE(s);
   if (kind == PLH_HOST_ASYNC) s.defer();
   return 0;
+}
+
+int plh_integrate(plh_model_t m, int n, const double* theta, const double* SOC0, const double* Y_init, const double* t_init, int n_runs,
+                  const plh_run* runs, const plh_opts* opts, const plh_outputs* out, int kind, void* stream) {
+  return integrate_impl(m, n, theta, SOC0, Y_init, t_init, n_runs, runs, opts, out, kind, stream, nullptr);
+}
+
+int plh_integrate_sens(plh_model_t m, int n, const double* theta, const double* SOC0, int n_runs, const plh_run* runs, const plh_opts* opts, const plh_outputs* out,
+                       int n_sens, const int* sens_cols, double* dY_dtheta, double* dV_dtheta, int* sens_stat, int kind, void* stream) {
+  if (kind != PLH_HOST && kind != PLH_DEVICE) return fail(PLH_E_ARG, "plh_integrate_sens: ptr_kind must be PLH_HOST or PLH_DEVICE");
+  const SensReq sq = {n_sens, sens_cols, dY_dtheta, dV_dtheta, sens_stat};
+  return integrate_impl(m, n, theta, SOC0, nullptr, nullptr, n_runs, runs, opts, out, kind, stream, &sq);
 }
 
 double plh_last_kernel_ms(plh_model_t m) {

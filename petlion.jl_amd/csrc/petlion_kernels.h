@@ -149,7 +149,7 @@ template <class M, int F> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WA
   cell_simulate<F>(S, R, a.tb, a.SOC0[cell], a.Y_init ? a.Y_init + (size_t)cell * NST : nullptr, a.t_init ? a.t_init[cell] : 0.0, a.n_runs, a.runs, a.opts, co, a.out.n_pts ? a.out.n_pts + cell : nullptr,
                 a.out.run_info + (size_t)cell * a.n_runs, cnt,
                 a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
-                a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell, a.genW ? a.genW + (size_t)cell * NST : nullptr);
+                a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell, a.genW ? a.genW + (size_t)cell * NST : nullptr, a.sens, a.theta + (size_t)cell * a.tb->P);
   PL_TOC_TOTAL(S);
   PL_SYNC();
   if (threadIdx.x == 0 && a.out.counters) {
@@ -330,7 +330,8 @@ template <class M> struct OpsOf {
     PL_LAUNCH(k_init_consistent<M>, n, WAVE * M::NWAVES, st, tb, n, theta, mode, value, reltol_init, Y, YP, status, iters, nref);
   }
   static void integrate(hipStream_t st, const IntegrateArgs& a, int features) {     // features: GenFlag bits the call needs; the smallest instantiation that has them all
-    if (features & GF_REFINE) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR | GF_GENROW | GF_REFINE>), a.n_cells, WAVE * M::NWAVES, st, a);
+    if (features & GF_SENS) { if constexpr (!M::W2) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_SENS>), a.n_cells, WAVE * M::NWAVES, st, a); }
+    else if (features & GF_REFINE) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR | GF_GENROW | GF_REFINE>), a.n_cells, WAVE * M::NWAVES, st, a);
     else if (features & GF_GENROW) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR | GF_GENROW>), a.n_cells, WAVE * M::NWAVES, st, a);
     else if (features & GF_EXPR) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR>), a.n_cells, WAVE * M::NWAVES, st, a);
     else if (features & GF_FUNC) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC>), a.n_cells, WAVE * M::NWAVES, st, a);

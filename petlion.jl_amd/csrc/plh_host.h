@@ -31,6 +31,7 @@ struct IntegrateArgs {
   const pl::Tables* tb; int n_cells; const double* theta; const double* SOC0; const double* Y_init; const double* t_init; int n_runs; const plh_run* runs; plh_opts opts;
   plh_outputs out; double* scratch;   // scratch: [n_cells][2][NST]
   double* genW;                       // [n_cells][NST] or nullptr: border vector of the general control row (closures with derivative programs)
+  pl::SensArgs sens;                  // forward parameter sensitivities (dfn_sens.h); n_sens = 0: none
 };
 
 struct SectionInfo { const char* name; int start, len; };
@@ -63,5 +64,5 @@ PL_VARIANT_LIST(PL_DECLARE_OPS)
 extern "C" const VariantOps* plh_grid_variant_ops(int id);     // nullptr: variant not built into this grid library
 extern "C" void plh_grid_dims(int* grid6);
 // what a grid library was compiled against: bump PLH_HOST_ABI whenever VariantOps / IntegrateArgs / Tables change, so that a stale cached library is refused, not misread
-constexpr int PLH_HOST_ABI = 4;
+constexpr int PLH_HOST_ABI = 5;
 extern "C" void plh_grid_abi(int* abi, int* sizeof_ops, int* sizeof_args, int* sizeof_tables);

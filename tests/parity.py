@@ -405,3 +405,50 @@ def tight_compare(pkg, p, O, th, soc, protocol, sample_dt=50.0, tol=None, max_po
         end_err = max(float(np.abs(Yend[a:e] - Yref[a:e]).max() / scale[name]) for name, a, e in secs)
         legs.append((int(info[k]["flag"]), rr["flag"], te_d, te_o, end_err))
     return dict(tol=tol, traj=traj, worst=worst, by_field=by_field, V=dV, legs=legs, n_times=ntimes, steps=(int(ens.counters[0]["n_steps"]), ro["counters"]["n_steps"]), kernel_ms=ens.kernel_ms)
+
+
+# ---- forward sensitivities: the oracle differenced (there is no reference vector for derivatives) ----
+def oracle_fd_sens(O, variant, th, soc, runs, col, ts, rel_h=0.05, tol=None, max_out=40000):
+    """d Y(t_end) / d theta[col] and d V(ts) / d theta[col] by SIXTH-order central differences of the oracle at tight tolerance, step rel_h * theta[col], all runs with the same
+    stop times `ts` (so that V is compared at equal times and the adaptive step grids stay correlated).  What limits it is the integration error of the differenced runs
+    (~1e-7 of the states at 1e-8) divided by the step: ~2e-6 of theta * |dY/dtheta| relative to the state -- sections that barely depend on the parameter are noise."""
+    tol = dict(tol or TIGHT)
+    h = rel_h * th[col]
+    kw = dict(maxiters=400000, tstops=list(ts), **tol)
+
+    def run(f):
+        t2 = th.copy(); t2[col] += f * h
+        r = O.simulate(variant, t2, soc, runs, opts=O.default_opts(**kw), max_out=max_out)
+        if min(x["flag"] for x in r["runs"]) < 0:
+            raise RunFails("oracle", [(x["flag"], x["t_end"]) for x in r["runs"]])
+        return r
+    rs = {f: run(f) for f in (3, 2, 1, -1, -2, -3)}
+    d6 = lambda g: (g(rs[3]) / 60 - 3 * g(rs[2]) / 20 + 3 * g(rs[1]) / 4 - 3 * g(rs[-1]) / 4 + 3 * g(rs[-2]) / 20 - g(rs[-3]) / 60) / h
+
+    def V_at(r):
+        keep = np.concatenate([[True], np.diff(r["t"]) > 0])           # (a run boundary repeats its time: keep the first of the pair)
+        return np.interp(ts, r["t"][keep], r["V"][keep])
+    return d6(lambda r: r["Y"]), d6(V_at), [tuple(x["flag"] for x in r["runs"]) for r in rs.values()]
+
+
+def sens_compare(O, p, pkg, ens, i, th, soc, protocol, keys, ts, variant=None):
+    """device sensitivities of cell i (ens from simulate_ensemble(..., sens=keys) with opts.tstops = ts) against oracle_fd_sens.  Returns per key: (dV error relative to
+    max |dV/dtheta| over the stop times, {section: (dY error relative to the section's max |dY/dtheta|, theta |dY/dtheta| / |Y| of the section)})"""
+    runs = runs_to_oracle(O, p, pkg, protocol)
+    n = int(ens.n_pts[i]); td = np.asarray(ens.t[i, :n])
+    idx = [int(np.argmin(np.abs(td - t))) for t in ts]
+    assert np.abs(td[idx] - np.asarray(ts)).max() < 1e-6, "a stop time is not among the saved points"
+    out = {}
+    for k, key in enumerate(keys):
+        col = p.θ_keys.index(key)
+        dY, dV, _ = oracle_fd_sens(O, variant or p.variant, th, soc, runs, col, ts)
+        dVd = np.asarray(ens.dV_dtheta[i, k])[idx]
+        eV = float(np.abs(dVd - dV).max() / np.abs(dV).max())
+        sec = {}
+        Yd = np.asarray(ens.Y[i])
+        for name, a, e in sections_for(len(dY)):
+            sc = np.abs(dY[a:e]).max()
+            if sc > 0:
+                sec[name] = (float(np.abs(np.asarray(ens.dY_dtheta[i, k, a:e]) - dY[a:e]).max() / sc), float(abs(th[col]) * sc / max(np.abs(Yd[a:e]).max(), 1e-300)))
+        out[key] = (eV, sec)
+    return out

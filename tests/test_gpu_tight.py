@@ -48,12 +48,12 @@ ABS_CONTROLLED = ("j", "j_s")   # the algebraic flux sections, below abstol / re
 LADDER = (dict(reltol=1e-8, abstol=1e-10), dict(reltol=3e-8, abstol=3e-10), dict(reltol=1e-7, abstol=1e-9))
 
 
-def check_cell(pkg, p, O, th, soc, protocol, what, sample_dt=50.0, soc_quadrature_legs=(), max_points=20000, tols=(parity.TIGHT,), stats=None, variant=None):
+def check_cell(pkg, p, O, th, soc, protocol, what, sample_dt=50.0, soc_quadrature_legs=(), max_points=20000, tols=(parity.TIGHT,), stats=None, variant=None, extra_opts=None):
     """tight_compare at the first tolerance of `tols` at which BOTH implementations complete the protocol (stats[(reltol, who)] counts the rungs skipped and who failed
     there; the last rung must work), every deviation within FACTOR x that reltol"""
     for k, tol in enumerate(tols):
         try:
-            r = parity.tight_compare(pkg, p, O, th, soc, protocol, sample_dt=sample_dt, max_points=max_points, tol=tol, variant=variant)
+            r = parity.tight_compare(pkg, p, O, th, soc, protocol, sample_dt=sample_dt, max_points=max_points, tol=tol, variant=variant, extra_opts=extra_opts)
             break
         except parity.RunFails as e:
             if stats is not None:
@@ -168,6 +168,23 @@ def test_tight_c5_full_gitt_protocol(hip_model_nmc_sei, O, pkg):
     summarize("C5 GITT first 4 pulses, 32 cells", rows4, stats4)
 
 
+def test_tight_c5_refined_solves(hip_model_nmc_sei, O, pkg):
+    """C5 at 1e-8 / 1e-10 with ONE step of iterative refinement in every linear solve of BOTH implementations (plh_opts.refine = orc_opts.refine = 1).  Without it the oracle
+    gives up in the 7200 s rests at 1e-8 (its sparse LU's 3e-9 of solver noise is a third of the tolerance on c_s: test_tight_c5_full_gitt_protocol runs 30 of 32 cells at
+    3e-8); with refinement both solves are at 4e-12 (tests/parity.check_solver_accuracy), so the rung that was skipped is the solver's, not the integrator's.  Same 32 cells,
+    same criterion (100 x reltol = 1e-6); the summary says how many cells completed at 1e-8 and which implementation failed where one did not."""
+    p = hip_model_nmc_sei
+    cfg = pkg.configs.c5(p, 8192)
+    rows, stats = [], {}
+    for c in range(0, 8192, 256):
+        rows.append(check_cell(pkg, p, O, cfg["theta"][c], cfg["SOC"], cfg["protocol"], "C5 cell %d, refine = 1" % c, sample_dt=300.0, max_points=80000, tols=LADDER, stats=stats,
+                               extra_opts=dict(refine=1)))
+    summarize("C5 GITT 20 pulses, 32 cells, refine = 1 on both sides", rows, stats)
+    at_1e8 = sum(1 for r in rows if r["tol"]["reltol"] == 1e-8)
+    print("   cells at 1e-8: %d of %d" % (at_1e8, len(rows)))
+    assert at_1e8 > 2          # (r03 without refinement: 2 of 32)
+
+
 def test_tight_cc_cv_and_hold_chains(hip_model, O, pkg):
     p = hip_model
     rows = []
@@ -185,34 +202,60 @@ def test_tight_cc_cv_and_hold_chains(hip_model, O, pkg):
     summarize("CC-CV and pulse / rest / V-, P-, I-hold chains, 8 cells each", rows, stats)
 
 
+def _cores():
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def test_accuracy_against_tight_tolerance_c3_and_hold_legs(hip_model, hip_model_thermal, O, pkg):
     """is the device as ACCURATE as the reference path on the thermal model and on hold legs?  Device and oracle at the DEFAULT tolerances against the oracle at a
-    tolerance 1e5 x tighter (1e-8 / 1e-10; for the thermal protocol the tight run uses the oracle variant with the conduction stencil on differences), on protocols whose legs end at fixed times (so that all three
-    runs end at the same time).  Per cell: the device's error is within 1.5x the oracle's, or -- where the two took different step sequences through a hold leg, whose
-    errors are then two draws from the same controller -- within three times the tolerance both ran at (reltol 1e-3); over the ensemble the median ratio stays within [0.6, 1.6].  (Measured on the thermal protocol: the CC and CT legs keep identical decisions and a ratio of 1.000; in the V-hold leg the start-up phase of IDA -- order and step doubling -- amplifies a 1e-11 difference of the held voltage to 1e-4 of the current within twelve steps, in the oracle against a perturbed copy of itself just the same: DESIGN.md 5.)"""
+    tolerance 1e5 x tighter (1e-8 / 1e-10; for the thermal protocol the tight run uses the oracle variant with the conduction stencil on differences), on protocols whose legs
+    end at fixed times (so that all three runs end at the same time).  256 cells of the C3 ensemble (r03: 24 cells, median ratio 1.30 -- too few to tell bias from chance), every
+    PREFIX of the protocol (after the CC leg, after CC + CT, after all three) so that a bias can be pinned on a leg.  Per cell: the device's error is within 1.5x the
+    oracle's, or -- where the two took different step sequences through a hold leg, whose errors are then two draws from the same controller -- within three times the
+    tolerance both ran at (reltol 1e-3); over the ensemble the criterion is SYMMETRIC: the median of device error / oracle error within [0.8, 1.25] after every leg."""
+    from concurrent.futures import ThreadPoolExecutor
     cases = []
     pt = hip_model_thermal
-    cfg = pkg.configs.c3(pt, 64)
+    cfg = pkg.configs.c3(pt, 4096)
     kw = dict(T_max=400.0, V_max=5.0, I_max=10.0, I_min=0.0, SOC_max=2.0)            # bounds out of reach: every leg ends on its tf
     th_proto = [dict(I=4.0, tf=300.0, **kw), dict(dT="hold", tf=200.0, **kw), dict(V="hold", tf=300.0, **kw)]
-    cases.append(("C3 model, CC 300 s -> CT hold 200 s -> CV hold 300 s", pt, cfg["theta"][:24], 0.0, th_proto, parity.TIGHT, "lco_thermal_tdiff"))
+    cases.append(("C3 model, CC 300 s -> CT hold 200 s -> CV hold 300 s", pt, cfg["theta"][::16], 0.0, th_proto, parity.TIGHT, "lco_thermal_tdiff", (1, 2, 3)))
     p = hip_model
-    Th = pkg.configs.sweep_theta(p, np.arange(24), 4)
+    Th = pkg.configs.sweep_theta(p, np.arange(64), 4)
     hold = [dict(I=2.0, tf=900.0, V_max=5.0), dict(V="hold", tf=600.0, V_max=5.0, I_min=0.0), dict(P="hold", tf=100.0, V_max=5.0), dict(I="rest", tf=300.0), dict(I=-1.0, tf=600.0)]
-    cases.append(("LCO isothermal, CC -> CV hold -> P hold -> rest -> discharge", p, Th, 0.0, hold, parity.TIGHT, None))
-    for what, pm, Thm, soc, proto, tight, tight_variant in cases:
-        ens = pkg.simulate_ensemble(pm, Thm, proto, SOC=soc)
-        runs = parity.runs_to_oracle(O, pm, pkg, proto)
-        ratios = []
-        for i in range(len(Thm)):
-            ro = O.simulate(pm.variant, Thm[i], soc, runs)
-            rt = O.simulate(tight_variant or pm.variant, Thm[i], soc, runs, opts=O.default_opts(maxiters=1000000, **tight), max_out=200000)
-            assert [int(f) for f in ens.run_info[i]["flag"]] == [r["flag"] for r in ro["runs"]] == [r["flag"] for r in rt["runs"]] == [0] * len(proto), (what, i)
-            e_dev, e_orc = parity.state_rel_err(ens.Y[i], rt["Y"]), parity.state_rel_err(ro["Y"], rt["Y"])
-            assert e_dev <= max(1.5 * e_orc + 1e-9, 3e-3), (what, i, e_dev, e_orc)
-            ratios.append(e_dev / e_orc)
-        assert 0.6 <= np.median(ratios) <= 1.6, (what, np.median(ratios))
-        print("%s: accuracy vs reltol %g -- device error / oracle error in [%.4f, %.4f], median %.4f over %d cells" % (what, tight["reltol"], min(ratios), max(ratios), np.median(ratios), len(Thm)))
+    cases.append(("LCO isothermal, CC -> CV hold -> P hold -> rest -> discharge", p, Th, 0.0, hold, parity.TIGHT, None, (1, 2, 5)))
+    for what, pm, Thm, soc, proto_full, tight, tight_variant, prefixes in cases:
+        Thm = np.ascontiguousarray(Thm)
+        for npre in prefixes:
+            proto = proto_full[:npre]
+            ens = pkg.simulate_ensemble(pm, Thm, proto, SOC=soc)
+            runs = parity.runs_to_oracle(O, pm, pkg, proto)
+
+            def one(i):
+                ro = O.simulate(pm.variant, Thm[i], soc, runs)
+                rt = O.simulate(tight_variant or pm.variant, Thm[i], soc, runs, opts=O.default_opts(maxiters=1000000, **tight), max_out=200000)
+                return ro, rt
+            with ThreadPoolExecutor(_cores()) as ex:
+                both = list(ex.map(one, range(len(Thm))))
+            ratios, same = [], 0
+            for i, (ro, rt) in enumerate(both):
+                assert [int(f) for f in ens.run_info[i]["flag"]] == [r["flag"] for r in ro["runs"]] == [r["flag"] for r in rt["runs"]] == [0] * len(proto), (what, npre, i)
+                e_dev, e_orc = parity.state_rel_err(ens.Y[i], rt["Y"]), parity.state_rel_err(ro["Y"], rt["Y"])
+                assert e_dev <= max(1.5 * e_orc + 1e-9, 3e-3), (what, npre, i, e_dev, e_orc)
+                ratios.append(e_dev / e_orc)
+                same += int(ens.counters[i]["n_steps"]) == ro["counters"]["n_steps"]
+            med = float(np.median(ratios))
+            print("%s [first %d leg(s)]: accuracy vs reltol %g -- device error / oracle error in [%.4f, %.4f], median %.4f, mean log-ratio %+.3f over %d cells (%d with the oracle's step count)"
+                  % (what, npre, tight["reltol"], min(ratios), max(ratios), med, float(np.mean(np.log(ratios))), len(Thm), same))
+            assert 0.8 <= med <= 1.25, (what, npre, med)
 
 
 def test_soc_is_the_trapezoid_of_the_saved_current(hip_model, pkg):

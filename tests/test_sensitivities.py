@@ -1,0 +1,105 @@
+"""Forward parameter sensitivities next to the states (plh_integrate_sens, csrc/dfn_sens.h).
+
+The reference has no derivative output and no vector to pin one on; the oracle for dY/dtheta is the oracle itself, differenced: sixth-order central differences of six
+tight-tolerance runs per parameter with common stop times (parity.oracle_fd_sens).  Its own accuracy is ~2e-6 x |Y| / (theta |dY/dtheta|), so the criteria are
+  * dV/dtheta at every stop time within 1e-4 of max |dV/dtheta| over the trajectory (the Jacobian of the voltage curve: what a least-squares fit consumes);
+  * dY/dtheta at the end of the protocol within 1e-4 + 2e-5 / r of its scale in every state section, r = theta |dY/dtheta| / |Y| the section's relative sensitivity: the
+    second term is the differenced oracle's own noise (two tight-tolerance end states agree to ~1e-6 of their scale -- 100 x reltol, test_gpu_tight.py -- over a step of
+    5 % of theta; measured: going from second- to fourth- to sixth-order differences moved the device-vs-oracle gap of weakly dependent sections from 3e-3 to 7e-4 to
+    5e-5 while the device's numbers did not move).  Sections that depend on the parameter at all (r >= 0.1) are therefore held to ~3e-4, and the summary prints their worst;
+  * the states, saved points and counters of a call with sensitivities are BIT FOR BIT those of the call without (nothing of the integrator is touched);
+  * every corrector solve reached its tolerance (sens_stat)."""
+import numpy as np
+import pytest
+
+import parity
+
+
+def check_sens(pkg, p, O, Th, soc, protocol, keys, ts, tol=parity.TIGHT, variant=None, what=""):
+    o = pkg.Opts(); o.reltol, o.abstol, o.maxiters = tol["reltol"], tol["abstol"], 200000; o.tstops = list(ts)
+    Th = np.ascontiguousarray(Th)
+    ens = pkg.simulate_ensemble(p, Th, protocol, SOC=soc, opts=o, max_points=20000, sens=keys)
+    ref = pkg.simulate_ensemble(p, Th, protocol, SOC=soc, opts=o, max_points=20000)
+    assert np.array_equal(np.asarray(ens.Y), np.asarray(ref.Y)) and np.array_equal(ens.n_pts, ref.n_pts) and np.array_equal(np.asarray(ens.V), np.asarray(ref.V)), "the states changed with sensitivities on"
+    assert np.array_equal(ens.counters["n_steps"], ref.counters["n_steps"]) and np.array_equal(ens.counters["n_newton"], ref.counters["n_newton"])
+    assert (np.asarray(ens.sens_stat)[:, 1] == 0).all(), ("corrector solves without convergence", np.asarray(ens.sens_stat)[:, 1].max())
+    worstV, worstY = 0.0, 0.0
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    assert (ens.run_info["flag"] >= 0).all()
+    with ThreadPoolExecutor(min(16, len(os.sched_getaffinity(0)))) as ex:       # (the oracle runs release the GIL)
+        allres = list(ex.map(lambda i: parity.sens_compare(O, p, pkg, ens, i, Th[i], soc, protocol, keys, ts, variant=variant), range(Th.shape[0])))
+    for i, res in enumerate(allres):
+        for key, (eV, sec) in res.items():
+            assert eV <= 1e-4, (what, i, key, "dV/dtheta", eV)
+            worstV = max(worstV, eV)
+            for name, (err, rel) in sec.items():
+                lim = 1e-4 + 2e-5 / max(rel, 1e-12)
+                assert err <= lim, (what, i, key, name, err, rel)
+                if rel >= 0.1:
+                    worstY = max(worstY, err)
+    its = np.asarray(ens.sens_stat)[:, 0].sum() / max(1, int(ens.counters["n_steps"].sum()) * len(keys))
+    print("%s: %d cell(s) x %s -- dV/dtheta max %.1e, dY/dtheta (sections with relative sensitivity >= 0.1) max %.1e; %.2f corrector iterations per step and parameter; kernel %.2f ms (without: %.2f ms)"
+          % (what, Th.shape[0], keys, worstV, worstY, its, ens.kernel_ms, ref.kernel_ms))
+    return ens
+
+
+def test_sens_lco_discharge_emu(emu_model, O, pkg):
+    p = emu_model
+    check_sens(pkg, p, O, p.theta_vector()[None, :], 1.0, [{"I": -1.0, "tf": 600.0}], ["D_sp", "k_n", "D_s"], np.arange(50.0, 600.0, 50.0), what="LCO 1C 600 s (emulator)")
+
+
+def test_sens_through_run_changes_and_a_bound_emu(emu_model, O, pkg):
+    """three runs (discharge, rest, constant voltage): the differential part of s is carried, the algebraic part re-solved with the new control row at every run start"""
+    p = emu_model
+    proto = [{"I": -2.0, "tf": 200.0}, {"I": "rest", "tf": 100.0}, {"V": 4.0, "tf": 150.0}]
+    check_sens(pkg, p, O, p.theta_vector()[None, :], 0.9, proto, ["D_sp", "k_p"], np.arange(20.0, 200.0, 20.0), what="LCO 2C / rest / CV (emulator)")
+
+
+def test_sens_thermal_emu(emu_model_thermal, O, pkg):
+    p = emu_model_thermal
+    check_sens(pkg, p, O, p.theta_vector()[None, :], 0.2, [{"I": 3.0, "tf": 150.0}], ["h_cell", "k_p"], np.arange(25.0, 150.0, 25.0), variant="lco_thermal_tdiff", what="LCO thermal 3C charge (emulator)")
+
+
+def test_sens_refused_where_theta_enters_through_the_protocol(emu_model, pkg):
+    p = emu_model
+    for proto in ([{"I": -1.0, "tf": 100.0}, {"V": "hold", "tf": 50.0}], [{"I": (lambda t: -1.0 - 0.001 * t), "tf": 100.0}]):
+        with pytest.raises(Exception) as e:
+            pkg.simulate_ensemble(p, p.theta_vector()[None, :].copy(), proto, SOC=1.0, sens=["D_sp"])
+        assert "plh_integrate_sens" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_sens_c4_parameters_on_gpu(hip_model, O, pkg):
+    """the seven jittered parameters of C4 on 16 cells of the sweep: 1C discharge for 1800 s (every cell ends at tf: no event time to move)"""
+    p = hip_model
+    keys = [k for k in pkg.configs.SWEEP_KEYS]
+    Th = pkg.configs.sweep_theta(p, np.arange(0, 65536, 4096), 4)
+    check_sens(pkg, p, O, Th, 1.0, [{"I": -1.0, "tf": 1800.0}], keys, np.arange(100.0, 1800.0, 100.0), what="C4 cells, 1C 1800 s")
+
+
+@pytest.mark.gpu
+def test_sens_thermal_and_sei_on_gpu(hip_model_thermal, hip_model_nmc_sei, O, pkg):
+    pt = hip_model_thermal
+    cfg = pkg.configs.c3(pt, 4096)
+    check_sens(pkg, pt, O, cfg["theta"][::1024], 0.0, [{"I": 4.0, "tf": 250.0, "T_max": 400.0}], ["h_cell", "k_p", "D_sn"], np.arange(25.0, 250.0, 25.0), variant="lco_thermal_tdiff", what="C3 cells, 4C 250 s")
+    ps = hip_model_nmc_sei
+    cfg = pkg.configs.c5(ps, 8192)
+    check_sens(pkg, ps, O, cfg["theta"][::2048], 0.0, cfg["protocol"][:2], ["D_sp", "k_n"], np.arange(60.0, 180.0, 60.0), what="C5 cells, first pulse + rest")
+
+
+@pytest.mark.gpu
+def test_sens_full_c4_launch_on_gpu(hip_model, pkg):
+    """the whole 8192-cell C4 shard with seven sensitivities per cell at the default tolerances: states bit-identical to the plain launch, every solve converged, finite outputs"""
+    import torch
+    p = hip_model
+    cfg = pkg.configs.c4(p, 8192)
+    Thd = torch.from_numpy(np.ascontiguousarray(cfg["theta"])).cuda()
+    ens = pkg.simulate_ensemble(p, Thd, cfg["protocol"], SOC=cfg["SOC"], device=True, max_points=cfg["max_points"], sens=list(pkg.configs.SWEEP_KEYS))
+    ref = pkg.simulate_ensemble(p, Thd, cfg["protocol"], SOC=cfg["SOC"], device=True, max_points=cfg["max_points"])
+    torch.cuda.synchronize()
+    assert torch.equal(ens.Y, ref.Y) and torch.equal(ens.n_pts, ref.n_pts)
+    st = ens.sens_stat.cpu().numpy()
+    assert (st[:, 1] == 0).all() and torch.isfinite(ens.dY_dtheta).all()
+    print("C4 shard, 8192 cells x 7 sensitivities: kernel %.1f ms (plain %.1f ms: x%.1f), %.2f corrector iterations per step and parameter"
+          % (ens.kernel_ms, ref.kernel_ms, ens.kernel_ms / ref.kernel_ms, st[:, 0].sum() / (7.0 * ens.counters["n_steps"].sum())))
