@@ -230,6 +230,40 @@ function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.o
      flag = [info[end, i].flag for i in 1:n], t_end = [info[end, i].t_end for i in 1:n])
 end
 
+"""
+    simulate_ensemble_sens(m, p, Θ, protocol, keys; SOC, max_pts)
+
+`simulate_ensemble` with forward sensitivities (`plh_integrate_sens`): `keys` = the θ Symbols to differentiate (entries of `m.θ_keys`).  Adds
+`dY_dθ[:, k, i]` = ∂Y/∂θ[keys[k]] of cell i at the end of the protocol and `dV_dθ[:, k, i]` = ∂V/∂θ[keys[k]] at every saved point -- the Jacobian of the voltage curve a
+least-squares fit of `keys` needs, from ONE ensemble call instead of 2 length(keys) + 1.  Constant / `:rest` inputs only; the states are bit for bit those of
+`simulate_ensemble`.  Derivatives are with respect to the absolute parameter value, at fixed time.
+"""
+function simulate_ensemble_sens(m::Model, p, Θ::Matrix{Float64}, protocol, keys::Vector{Symbol}; SOC = p.opts.SOC, max_pts = 2048)
+    n = size(Θ, 1)
+    runs = [make_run(p, s) for s in protocol]
+    o = p.opts
+    ts = Float64.(o.tstops)
+    opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0, 0, C_NULL, 0, length(ts), isempty(ts) ? C_NULL : pointer(ts), 0))
+    cols = Cint[key_index(m, k) - 1 for k in keys]
+    ns = length(cols)
+    Θt = permutedims(Θ)
+    soc = SOC isa Number ? fill(Float64(SOC), n) : Vector{Float64}(SOC)
+    t = zeros(max_pts, n); V = similar(t); I = similar(t); S = similar(t)
+    npts = zeros(Cint, n); Y = zeros(m.N, n)
+    info = Matrix{RunInfo}(undef, length(runs), n); cnt = Vector{Counters}(undef, n)
+    Tavg = p.numerics.temperature ? zeros(max_pts, n) : Float64[]
+    dY = zeros(m.N, ns, n); dV = zeros(max_pts, ns, n); stat = zeros(Cint, 2, n)
+    GC.@preserve t V I S npts Y info cnt Tavg ts cols dY dV stat begin
+        out = Ref(Outputs(max_pts, pointer(t), pointer(V), pointer(I), pointer(S), isempty(Tavg) ? C_NULL : pointer(Tavg), pointer(npts), pointer(Y), C_NULL,
+                          pointer(info), pointer(cnt), C_NULL))
+        rc = ccall((:plh_integrate_sens, lib), Cint,
+                   (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Run}, Ref{Opts}, Ref{Outputs}, Cint, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Cint, Ptr{Cvoid}),
+                   m.h, n, Θt, soc, length(runs), runs, opts, out, ns, cols, dY, dV, stat, PLH_HOST, C_NULL)
+        check(rc, "plh_integrate_sens")
+    end
+    (t = t, V = V, I = I, SOC = S, T_avg = Tavg, n_pts = npts, Y = Y, run_info = info, counters = cnt, dY_dθ = dY, dV_dθ = dV, sens_stat = stat)
+end
+
 # ---- seam 1: the five generated functions of p.funcs (src/structures.jl:315-334) as single-cell evaluators ----
 function residual!(res::Vector{Float64}, m::Model, Y, YP, θ; mode = :I, value = 0.0)
     check(ccall((:plh_residual, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{Cdouble}, Cint, Ptr{Cvoid}),

@@ -251,6 +251,10 @@ int plh_jac_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval)
  * J_y_alg! of seam 1 (src/generate_functions.jl:318-325): N_alg columns, N_alg - 1 rows (the control row is not generated). */
 int plh_jac_alg_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* rowval);
 const char* plh_last_error(void);
+/* "hipcc=...;clang=...;flags=<hash>;src=<hash>" of this binary (the miscompile guard keys on it), and the number of HIP devices the library can see
+ * (0: no GPU or no driver -- hosts use it to decide whether the kernel self-test can run, without a second GPU runtime in the process) */
+const char* plh_build_info(void);
+int plh_device_count(void);
 /* sizeof / offsetof of every struct of this header as the library was compiled, for bindings that mirror them by hand (bindings/julia/PetlionHIP.jl,
  * the ctypes mirror of the tests): out[] receives, per struct in declaration order (plh_model_desc, plh_bounds, plh_run, plh_opts, plh_run_info,
  * plh_counters, plh_outputs): sizeof, number of fields, then the offset of each field.  Returns the number of ints written (or needed, if cap is short). */

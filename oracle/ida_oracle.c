@@ -399,6 +399,11 @@ typedef struct {   /* reference options_simulation, src/structures.jl:266-285 */
   /* bounded experiment on the step history of the reference's notebook (tests/test_oracle_golden.py::test_step_history_of_the_2C_charge_notebook): 1 = the integrator is
      started with YP_alg = 0, i.e. without newtons_method!'s finite-difference estimate of the algebraic derivatives (model_evaluation.jl:462-477) */
   int exp_yp_alg_zero;
+  /* reproducibility probe (tests only), the integrator's counterpart of fd_perturb: EVERY residual evaluation of the corrector gets the same evaluation-rounding-sized
+     perturbation, res_i += res_perturb * u * sum_c |J_ic Y_c| with the entries of the last evaluated Newton matrix and a fresh u in [-1, 1) per row and evaluation
+     (splitmix64 of perturb_seed, an evaluation counter and the row).  A second correct fp64 implementation differs from this one in exactly that way in every evaluation
+     (flux form or matrix form of a stencil, the order of a sum), not only in the one evaluation fd_perturb touches. */
+  double res_perturb;
 } orc_opts;
 
 typedef struct {
@@ -439,6 +444,7 @@ typedef struct {
   int has_yp, n_yp; int yp_k[512], yp_src[512], yp_dst[512]; double* yp_sub;
   double *tmp_nz, *w;
   double *ax_f, *aax_f, *rtmp, *xtmp;   /* the matrices as last factored (iterative refinement), work vectors */
+  int ax_valid;                          /* ax holds the values of an evaluated Newton matrix (perturb_residual) */
   double I1C;
   const orc_run* frun;   /* != NULL: the control value is frun's table / closure evaluated at the current time */
   double t_fun;          /* run-local time of the residual evaluations (closure inputs) */
@@ -655,6 +661,7 @@ static void J_full(evalb* e, const double* Y, const double* YP, double cj) {
   else if (e->mode == ORC_MODE_DSTATE) e->ax[e->ctrl_pos[0]] = -cj;
   ctrl_row_derivatives(e, Y, YP, cj, e->ax, e->ctrl_pos, e->n_base, e->n_ctrl, 0);
   if (e->cnt) e->cnt->n_jac++;
+  e->ax_valid = 1;
 }
 static void J_alg(evalb* e, const double* Y, const double* YP) {
   const orc_model* m = &e->m;
@@ -795,6 +802,20 @@ static double ida_set_coeffs(ida_t* I) {
 }
 
 /* nonlinear solve: IDANls + SUNNonlinSol_Newton + idaNlsConvTest + IDALs scaling.  returns 0 ok, >0 recoverable, <0 fatal */
+static unsigned long long g_res_perturb_calls = 0;      /* (one trajectory per thread-local integrator; the counter only decorrelates the draws) */
+static void perturb_residual(ida_t* I, double* res, const double* Y) {
+  evalb* e = I->e; const int N = I->N; const double eps = I->o->res_perturb;
+  double* term = (double*)calloc(N, sizeof(double));
+  for (int c = 0; c < N; c++) for (int q = e->cp[c]; q < e->cp[c + 1]; q++) term[e->ri[q]] += fabs(e->ax[q] * Y[c]);
+  const uint64_t call = (uint64_t)__atomic_add_fetch(&g_res_perturb_calls, 1ull, __ATOMIC_RELAXED);
+  for (int i = 0; i < N; i++) {
+    uint64_t z = ((uint64_t)I->o->perturb_seed * 0x9E3779B97F4A7C15ull) ^ (call * 0xD1B54A32D192ED03ull) ^ (uint64_t)i; z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    res[i] += eps * term[i] * (2.0 * ((double)(z >> 11) / 9007199254740992.0) - 1.0);
+  }
+  free(term);
+}
+
 static int ida_nls(ida_t* I) {
   evalb* e = I->e; int N = I->N; orc_counters* cnt = e->cnt;
   if (e->frun) { e->value = run_input(e->frun, I->tn, I->phi[0], I->phi[1], e->th); e->t_fun = I->tn; }     /* every residual of this step is evaluated at t = tn */
@@ -821,6 +842,7 @@ static int ida_nls(ida_t* I) {
       if (cnt) cnt->n_fact++;
       I->cjold = I->cj; I->cjratio = 1.0; I->ss = 20.0; jcur = 1;
     }
+    if (I->o->res_perturb != 0.0 && e->ax_valid) perturb_residual(I, I->delta, I->yy);
     int m = 0; double oldnrm = 0.0;
     for (;;) {
       if (cnt) { cnt->n_newton++; cnt->n_solve++; }
@@ -839,6 +861,7 @@ static int ida_nls(ida_t* I) {
       m++; if (m >= 4) { ret = 1; break; }
       for (int n = 0; n < N; n++) { I->yy[n] = I->ypred[n] + I->ee[n]; I->yp[n] = I->yppred[n] + I->cj * I->ee[n]; }
       R_full(e, I->delta, I->yy, I->yp);
+      if (I->o->res_perturb != 0.0) perturb_residual(I, I->delta, I->yy);
     }
     if (ret > 0 && !jcur) { callLSetup = 1; for (int n = 0; n < N; n++) I->ee[n] = 0.0; continue; }
     break;
@@ -964,6 +987,7 @@ static int ida_step(ida_t* I, double tstop, double* tret, double* yret, double* 
     break;
   }
   if (cnt) { cnt->n_steps++; cnt->sum_kp2 += I->kk + 2; }
+  if (getenv("ORC_TRACE")) fprintf(stderr, "orc step %d tn %.9g h %.6g k %d knew %d phase %d ns %d err_k %.6e err_km1 %.6e nef %d ncf %d\n", I->nst + 1, I->tn, I->hh, I->kk, I->knew, I->phase, I->ns, err_k, err_km1, nef, ncf);
   ida_complete_step(I, err_k, err_km1);
   /* IDAStopTest2 for ONE_STEP_TSTOP */
   double troundoff = 100.0 * I->uround * (fabs(I->tn) + fabs(I->hh));

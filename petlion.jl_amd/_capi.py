@@ -75,7 +75,7 @@ COUNTERS_DTYPE = np.dtype([(f, np.int64) for f in COUNTER_FIELDS] + [("cyc", np.
 assert RUN_INFO_DTYPE.itemsize == C.sizeof(RunInfo) and COUNTERS_DTYPE.itemsize == C.sizeof(CountersS)
 
 EXPORTS = ["plh_model_create", "plh_model_destroy", "plh_register_grid_library", "plh_n_states", "plh_n_diff", "plh_n_theta", "plh_theta_key",
-           "plh_theta_default", "plh_lds_bytes", "plh_n_sections", "plh_section", "plh_jac_pattern", "plh_jac_alg_pattern", "plh_last_error", "plh_abi_layout",
+           "plh_theta_default", "plh_lds_bytes", "plh_n_sections", "plh_section", "plh_jac_pattern", "plh_jac_alg_pattern", "plh_last_error", "plh_build_info", "plh_device_count", "plh_abi_layout",
            "plh_initial_guess", "plh_residual", "plh_jacobian", "plh_linear_solve", "plh_linear_solve_refined", "plh_residual_diff", "plh_residual_alg",
            "plh_jacobian_alg", "plh_init_consistent", "plh_integrate", "plh_integrate_sens", "plh_last_kernel_ms", "plh_host_alloc", "plh_host_free", "plh_synchronize",
            "plh_comm_unique_id", "plh_comm_create", "plh_comm_destroy", "plh_comm_rank", "plh_comm_size", "plh_ensemble_run"]
@@ -102,6 +102,7 @@ def load(path=None):
     lib.plh_theta_default.restype = C.c_double
     lib.plh_theta_default.argtypes = [C.c_void_p, C.c_int]
     lib.plh_last_error.restype = C.c_char_p
+    lib.plh_build_info.restype = C.c_char_p
     lib.plh_last_kernel_ms.restype = C.c_double
     lib.plh_last_kernel_ms.argtypes = [C.c_void_p]
     lib.plh_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]

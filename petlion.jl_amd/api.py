@@ -48,6 +48,7 @@ class Model:
         self.bounds = {LCO: bounds_LCO, NMC: bounds_NMC, NMC_LGM50: bounds_LGM50}[cathode]()
         self.opts = Opts()
         self._lib = cap.load(lib_path)
+        self._builtin_lib = lib_path is None          # the product library (not the tests' emulator build / an experiment build)
         if precision not in ("f64", "mixed"):
             raise ValueError("precision: 'f64' or 'mixed' (fp32 storage of the Newton-matrix factors, everything else fp64)")
         self.precision = precision
@@ -132,6 +133,7 @@ def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_
     p = Model(cathode, _N(p=N_p, s=N_s, n=N_n, a=N_a, z=N_z, r_p=N_r_p, r_n=N_r_n), temperature, aging, _lib_path, precision, device, solid_diffusion, thermodynamic_factor, rxn_p, waves_per_cell, _grid_lib)
     p.opts.SOC = SOC
     _selftest_new_grid_library(p)
+    _selftest_unvalidated_build(p)
     return p
 
 
@@ -159,31 +161,88 @@ def selftest(p, n_cells=2, tf=100.0):
         if not (np.array_equal(e.run_info["flag"], base.run_info["flag"]) and np.abs(e.run_info["t_end"] - base.run_info["t_end"]).max() == 0.0
                 and np.abs(e.run_info["SOC"] - base.run_info["SOC"]).max() < 1e-11 and np.abs(e.run_info["V"] - base.run_info["V"]).max() <= vtol and np.abs(e.SOC[:, 0] - 1.0).max() == 0.0):
             bad = name
+    if not bad:
+        # the continuation path (a second run inherits SOC, time, V / I from the first: the path of the miscompile that was seen) in the plain and the table instantiation,
+        # and the sensitivity instantiation, whose states must be those of the plain kernel bit for bit
+        two = [{"I": -1.0, "tf": tf / 2}, {"I": -1.0, "tf": tf / 2}]
+        two_tab = [{"I": -1.0, "tf": tf / 2}, {"I": ([0.0, 1e7], [-1.0, -1.0]), "tf": tf / 2}]
+        for name, proto in (("plain, two runs", two), ("table input, two runs", two_tab)):
+            e = simulate_ensemble(p, Th, proto, SOC=1.0)
+            if not ((e.run_info["flag"] == 0).all() and np.abs(e.run_info["SOC"][:, 1] - (1.0 - tf / 3600.0)).max() < 1e-11 and np.abs(e.run_info["t_end"][:, 1] - tf).max() < 1e-9
+                    and np.abs(e.run_info["V"][:, 1] - base.run_info["V"][:, 0]).max() <= 2e-3):
+                bad = name
+                break
+    if not bad and p.waves_per_cell != 2:
+        e = simulate_ensemble(p, Th, [{"I": -1.0, "tf": tf}], SOC=1.0, sens=[p.θ_keys[0]])
+        if not (np.array_equal(e.Y, base.Y) and np.array_equal(e.run_info["flag"], base.run_info["flag"]) and (np.asarray(e.sens_stat)[:, 1] == 0).all()):
+            bad = "sensitivity"
     if bad:
         raise RuntimeError("kernel self-test failed: the %s instantiation of %s does not reproduce the plain kernel on a 1C discharge -- a miscompiled build "
                            "(rebuild; see DESIGN.md 5a)" % (bad, p.variant))
 
 
-def _selftest_new_grid_library(p):
-    """a grid library compiled at first use (petlion.jl_amd/grids.py) is checked once per (library, variant) on the first machine with a GPU that loads it"""
-    lib = getattr(p, "_grid_lib_built", None)
-    if not lib:
-        return
-    marker = "%s.%s.selftest" % (lib, p.variant)
-    if os.path.exists(marker):
-        return
+def _gpu_visible(p):
+    """the library's own device count (no second GPU runtime in the process, no dependence on torch)"""
     try:
-        import torch
-        if not torch.cuda.is_available():
+        return p._lib.plh_device_count() > 0
+    except AttributeError:
+        return False
+
+
+def _guarded_selftest(p, marker, identity, what):
+    """run selftest(p) once per (marker file, identity string); warn -- never skip silently -- when no GPU is visible"""
+    import warnings
+    try:
+        if os.path.exists(marker) and open(marker).read().strip() == identity:
             return
-    except ImportError:
+    except OSError:
+        pass
+    if not _gpu_visible(p):
+        warnings.warn("petlion.jl_amd: kernel self-test of %s skipped (no GPU visible to the library); it runs on the first machine with a GPU" % what, RuntimeWarning)
         return
     selftest(p)
     try:
         with open(marker, "w") as f:
-            f.write("ok\n")
+            f.write(identity + "\n")
     except OSError:
         pass
+
+
+def _selftest_new_grid_library(p):
+    """a grid library compiled at first use (petlion.jl_amd/grids.py) is checked once per (library, variant, compiler / host build identity) on the first machine with a GPU
+    that loads it (a cache copied from another machine carries the identity it was checked under; a different compiler or host library checks again)"""
+    lib = getattr(p, "_grid_lib_built", None)
+    if not lib:
+        return
+    _guarded_selftest(p, "%s.%s.selftest" % (lib, p.variant), build_info(p), "the grid library %s" % os.path.basename(lib))
+
+
+def build_info(p=None):
+    """plh_build_info(): compiler versions, flag hash and source hash of the loaded library"""
+    lib = p._lib if p is not None else cap.load()
+    try:
+        return lib.plh_build_info().decode("utf-8", "replace")
+    except AttributeError:
+        return "unknown"
+
+
+_VALIDATED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "validated_build.json")
+
+
+def _selftest_unvalidated_build(p):
+    """the built-in kernels are validated by the GPU test suite, and profiles/validated_build.json records the identity of the binary that run validated.  A
+    library whose plh_build_info() differs -- another hipcc, other flags, edited sources -- has not been through that run: the first petlion() of each variant then runs the
+    kernel self-test (every k_integrate instantiation against the plain one, including a two-run continuation) once per build and machine."""
+    if not getattr(p, "_builtin_lib", False) or getattr(p, "_grid_lib_built", None):
+        return
+    info = build_info(p)
+    try:
+        import json
+        if json.load(open(_VALIDATED)).get("build_info") == info:
+            return
+    except (OSError, ValueError):
+        pass
+    _guarded_selftest(p, "%s.%s.selftest" % (cap.LIB_PATH, p.variant), info, "this build of libpetlion_hip.so (%s: not the validated binary)" % info)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -277,7 +277,9 @@ struct SensArgs {               // (device pointers; part of IntegrateArgs)
   double* dY;                   // [n_cells][n_sens][N] or nullptr: dY/dtheta_k at the end of the last completed run
   double* dV;                   // [n_cells][n_sens][max_pts] or nullptr: dV/dtheta_k at every saved point
   int* stat;                    // [n_cells][2] or nullptr: corrector iterations, solves that did not reach the tolerance
+  double* cbak;                 // [n_cells][SENS_CBAK]: the cell's theta-derived constants, saved once and copied back after every evaluation with a perturbed theta row
 };
+constexpr int SENS_CBAK = 384;
 
 // An index the compiler must treat as opaque: `base + PL_OPAQUE_IDX(lane part)` keeps the lane-dependent part of an LDS address in ONE register and leaves the compile-time part to
 // the instruction's offset field.  Without it the constant parts of S.<array>[lane part + const] are folded into one large immediate per access, which ds_read2_b64's 8-bit

@@ -746,6 +746,9 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
     break;
   }
   cnt_add(cnt, C_STEPS); cnt_add(cnt, C_SUMKP2, I.kk + 2);
+#ifdef PL_WAVE_EMU
+  if (getenv("PL_EMU_TRACE") && lane == 0 && blockIdx.x == 0) fprintf(stderr, "dev step %d tn %.9g h %.6g k %d knew %d phase %d ns %d err_k %.6e err_km1 %.6e nef %d ncf %d\n", I.nst + 1, I.tn, I.hh, I.kk, I.knew, I.phase, I.ns, err_k, err_km1, nef, ncf);
+#endif
   PL_TIC(); PL_TICE(3);
   const bool have_sol = ida_complete_step(S, I, err_k, err_km1, tstop);
   PL_TOCE(S, 3, 2);

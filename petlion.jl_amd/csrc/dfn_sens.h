@@ -42,6 +42,31 @@ template <class M> struct SensCell {
   __device__ __forceinline__ const double* thp(int k) const { return a.theta_pert + ((size_t)cell * a.n_sens + k) * P; }
 };
 
+// The cell's theta-derived constants (CellConst, the conduction / weighting tables of the thermal model, the SOH quadrature weights of the SEI model) are SAVED once and COPIED
+// back after every evaluation with a perturbed theta row.  Recomputing them from the unperturbed row would be the same arithmetic -- but in another inlined copy of cell_setup,
+// which the compiler is free to contract differently: measured on the GPU, a last-bit difference in one constant is enough to move a few of 8192 trajectories off the ones of the
+// plain kernel.  A copy is exact.
+template <bool SAVE, class M>
+PL_DEV void sens_consts(CellLDS<M>& S, const SensCell<M>& X) {
+  const int lane = lane_id();
+  double* b = X.a.cbak + (size_t)X.cell * SENS_CBAK;
+  constexpr int NC = (int)(sizeof(CellConst) / sizeof(double));
+  static_assert(sizeof(CellConst) % sizeof(double) == 0, "CellConst is copied as doubles");
+  double* c = reinterpret_cast<double*>(&S.cc);
+  int o = 0;
+  for (int k = lane; k < NC; k += WAVE) { if (SAVE) b[o + k] = c[k]; else c[k] = b[o + k]; }
+  o += NC;
+  if constexpr (M::THERMAL) {
+    double* t0 = &S.th.aL[0];
+    const int nt = (int)(&S.th.qI[0] + 2 - t0);             // aL, aU, wT5, aC2, rc5, qI: consecutive members of ThermalPool
+    static_assert(NC + 2 * NT + 16 + NN <= SENS_CBAK, "SENS_CBAK");
+    for (int k = lane; k < nt; k += WAVE) { if (SAVE) b[o + k] = t0[k]; else t0[k] = b[o + k]; }
+    o += nt;
+  }
+  if constexpr (M::SEI) { for (int k = lane; k < NN; k += WAVE) { if (SAVE) b[o + k] = S.sei.sohw[k]; else S.sei.sohw[k] = b[o + k]; } }
+  PL_XSYNC();
+}
+
 // F(phi[0] + e s, ypn + e sp) -> S.delta   (S.yy / S.yp are the work vectors)
 template <class M>
 PL_DEV void sens_eval(CellLDS<M>& S, LaneRegs& R, const double (&s)[M::NTRIP], const double (&sp)[M::NTRIP], const double (&ypn)[M::NTRIP], double e, int mode, double value) {
@@ -68,6 +93,7 @@ PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, boo
   const int lane = lane_id();
   LaneRegs Ra;                                            // (the algebraic solves do not touch the particle registers)
   for (int q = 0; q < CS_PASS; q++) { Ra.wreg[q] = 0.0; Ra.rcp[q] = 0.0; }
+  sens_consts<true>(S, X);
   const int amode = (M::THERMAL && mode == PLH_MODE_DT) ? PL_MODE_DT_TWIN : mode;      // the algebraic form of the dT row (cell_init_consistent)
   double yn[NTRIP], ypn[NTRIP], f0[NTRIP], w[NTRIP], zero[NTRIP];
   PL_VEC(n) { yn[k__] = S.yy[n]; ypn[k__] = S.yp[n]; zero[k__] = 0.0; w[k__] = 1.0 / (fabs(S.phi[0][n]) + atol / rtol); }
@@ -89,7 +115,7 @@ PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, boo
     } else { PL_VEC(n) s[k__] = h0[n]; }                  // carried from the end of the previous run (the algebraic part: first guess only)
     sens_eval(S, Ra, zero, zero, ypn, 0.0, amode, value);
     PL_VEC(n) fp[k__] = (S.delta[n] - f0[k__]) / dth;
-    cell_setup<M, false>(S, Ra, S.tb, X.th0);
+    sens_consts<false>(S, X);
     PL_XSYNC();
     // algebraic part: G_ya s_a = -(G_yd s_d + G_theta), Newton-like with the factorisation of the last initialisation iterate
     bool conv = false;
@@ -153,7 +179,7 @@ PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<
     cell_setup<M, false>(S, R, S.tb, tp);
     sens_eval(S, R, zero, zero, ypn, 0.0, mode, value);
     PL_VEC(n) fp[k__] = (S.delta[n] - f0[k__]) / dth;
-    cell_setup<M, false>(S, R, S.tb, X.th0);
+    sens_consts<false>(S, X);
     PL_XSYNC();
     // predictor from the history (IDASetCoeffs' rescaling phi*_j = beta_j phi_j for j >= ns is applied in place, as form_iterate does for y)
     double* h0 = X.hist(k, 0);

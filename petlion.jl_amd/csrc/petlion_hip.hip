@@ -468,6 +468,15 @@ int plh_jac_alg_pattern(plh_model_t m, int mode, int* nnz, int* colptr, int* row
   return 0;
 }
 
+// what this binary was built with (hipcc / clang versions, a hash of the per-variant compiler flags, a hash of the device and host sources): __graft_entry__.build_hip
+// passes it to this translation unit.  A kernel of this size sits at the register allocator's limits, and one build was seen to miscompile one instantiation:
+// the host compares this string with the one of the binary the committed GPU test run validated (profiles/validated_build.json) and runs the kernel self-test when they differ.
+#ifndef PLH_BUILD_INFO
+#define PLH_BUILD_INFO "unrecorded build (no -DPLH_BUILD_INFO: not built by __graft_entry__.build_hip)"
+#endif
+const char* plh_build_info(void) { return PLH_BUILD_INFO; }
+int plh_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
 int plh_abi_layout(int* out, int cap) {
   std::vector<int> v;
 #define PL_S(T, NF) v.push_back((int)sizeof(T)); v.push_back(NF);
@@ -758,7 +767,7 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
   a.out.Y_all = s.buf(out->Y_all, np * m->N, false);
   a.out.Y_final = s.buf(out->Y_final, (size_t)n * m->N, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * m->N, false);
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
-  a.sens.n_sens = 0; a.sens.cols = nullptr; a.sens.theta_pert = nullptr; a.sens.hist = nullptr; a.sens.dY = nullptr; a.sens.dV = nullptr; a.sens.stat = nullptr;
+  a.sens.n_sens = 0; a.sens.cols = nullptr; a.sens.theta_pert = nullptr; a.sens.hist = nullptr; a.sens.dY = nullptr; a.sens.dV = nullptr; a.sens.stat = nullptr; a.sens.cbak = nullptr;
   size_t n_dY = 0, n_dV = 0;
   if (sq) {
     const int ns = sq->n_sens, NPAD = m->N + (m->N & 1);
@@ -767,6 +776,7 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
     a.sens.cols = s.in_host(sq->cols, ns);
     double* tp = (double*)s.dev_block((size_t)n * ns * m->P * sizeof(double));
     a.sens.hist = (double*)s.dev_block((size_t)n * ns * 6 * NPAD * sizeof(double));
+    a.sens.cbak = (double*)s.dev_block((size_t)n * pl::SENS_CBAK * sizeof(double));
     a.sens.dY = s.buf(sq->dY, n_dY, false); a.sens.dV = s.buf(sq->dV, n_dV, false); a.sens.stat = s.buf(sq->stat, (size_t)2 * n, false);
     CHECK_STAGE(s);
     a.sens.theta_pert = tp;

