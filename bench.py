@@ -166,6 +166,17 @@ def spawn_ranks(n):
         raise SystemExit(rc)
 
 
+def closure_cases(p, inp):
+    """the first run of the config's protocol with its constant current written as a closure of (t, Y) and as a closure of the cell voltage (1e-9 C-rate per volt: the same
+    workload to 1e-9, with two derivative programs in the Newton matrix)"""
+    first = dict(inp["protocol"][0])
+    Ival = float(first["I"])
+    ps = p.ind["Φ_s"]
+    clo = dict(first); clo["I"] = lambda t, Y, P_: Ival + 0.0 * t + 0.0 * Y[0]
+    clo_y = dict(first); clo_y["I"] = lambda t, Y, P_: Ival + 1e-9 * (Y[ps.start] - Y[ps.stop - 1])
+    return clo, clo_y
+
+
 def general_path(pkg, p, inp, Theta, n_local, kernel_ms, reps=5):
     """what a call pays for the features beyond constant inputs -- each runs in the smallest k_integrate instantiation that has it (GenFlag, csrc/dfn_integrate.h):
     kernel time of the same workload with the feature switched on, relative to the plain kernel of the timed region"""
@@ -176,21 +187,25 @@ def general_path(pkg, p, inp, Theta, n_local, kernel_ms, reps=5):
         return None
     Ival, tf = float(first["I"]), float(first.get("tf", 1e6))
     tab = dict(first); tab["I"] = ([0.0, 1e7], [Ival, Ival])                         # the same constant current as a table / as a closure of t and the state
-    clo = dict(first); clo["I"] = lambda t, Y, P_: Ival + 0.0 * t + 0.0 * Y[0]
-    ps = p.ind["Φ_s"]                                                                  # (a 1e-9 C-rate per volt dependence on the cell voltage: the same workload to 1e-9, with two derivative programs)
-    clo_y = dict(first); clo_y["I"] = lambda t, Y, P_: Ival + 1e-9 * (Y[ps.start] - Y[ps.stop - 1])
+    clo, clo_y = closure_cases(p, inp)
     cases = [("stop times (opts.tstops; one stop beyond every run, so that the step sequence is the plain one)", proto, dict(tstops=[1e7]), None),
              ("state dump (outputs = :all)", proto, {}, "all"),
              ("table input", [tab] + proto[1:], {}, None),
              ("closure input", [clo] + proto[1:], {}, None),
              ("closure of the state with its derivative in the Newton matrix (general control row)", [clo_y] + proto[1:], {}, None),
-             ("refine = 1", proto, dict(refine=1), None)]
+             ("refine = 1", proto, dict(refine=1), None),
+             # the same two closures COMPILED into the kernels (closure_lib.py: hipcc once per closure set; the libraries of the four configs are built by
+             # tools/build_bench_closures.py and travel with the tree) -- what the reference does with a user's closure (scalar_residual.jl:231-416)
+             ("closure input, compiled (closure_lib)", [clo] + proto[1:], dict(_compile=True), None),
+             ("closure of the state with its derivative in the Newton matrix, compiled (closure_lib)", [clo_y] + proto[1:], dict(_compile=True), None)]
     skeys = [k for k in pkg.configs.SWEEP_KEYS if k in p.θ_keys]
     if all(not isinstance(r.get("I", 0.0), str) or r["I"] == "rest" for r in proto) and all(set(r) & {"I", "V", "P"} for r in proto):
         cases.append(("forward sensitivities dY/dtheta, dV/dtheta for %d parameters (%s): plh_integrate_sens" % (len(skeys), ", ".join(skeys)), proto, {}, None))
     out = {}
     for name, pr, okw, outputs in cases:
         o = pkg.Opts()
+        if okw.pop("_compile", False):
+            p.compile_closures(pr)
         for k, v in okw.items():
             setattr(o, k, v)
         ms = []
@@ -201,6 +216,8 @@ def general_path(pkg, p, inp, Theta, n_local, kernel_ms, reps=5):
             if r:
                 ms.append(float(ens.kernel_ms))
         assert (ens.run_info["flag"] >= 0).all(), name
+        if "compiled" in name:
+            assert p._lib.plh_last_integrate_compiled(p._h) == 1, name
         out[name] = {"kernel_ms": float(np.mean(ms)), "trajectories_per_s": n_local / (np.mean(ms) * 1e-3), "vs_plain_kernel": kernel_ms / float(np.mean(ms))}
         del ens
     return out

@@ -33,7 +33,8 @@ struct Bounds      # boundary_stop_conditions, src/structures.jl:237-250
 end
 struct Run
     mode::Cint; value_kind::Cint; value::Cdouble; tf::Cdouble; bounds::Bounds
-    n_tab::Cint; tab_t::Ptr{Cdouble}; tab_v::Ptr{Cdouble}     # VAL_TABLE: piecewise-linear input in run-local time (host arrays)
+    n_tab::Cint; closure_id::Cint                             # closure_id: written by the library (compiled closures), pass 0
+    tab_t::Ptr{Cdouble}; tab_v::Ptr{Cdouble}                  # VAL_TABLE: piecewise-linear input in run-local time (host arrays)
     value_cell::Ptr{Cdouble}; tf_cell::Ptr{Cdouble}           # per-cell input value / run length ([n_cells] host arrays) or C_NULL
     n_dcol::Cint                                              # VAL_EXPR of the state: number of derivative programs (0 = none)
     dstate::Cint                                              # MODE_DSTATE: which differential state's rate is held (PLH_DSTATE_*), 0 otherwise
@@ -121,11 +122,11 @@ function make_run(p, step::NamedTuple)
     b = bounds_of(p.bounds; kw...)
     tf = Float64(get(step, :tf, 1e6))
     if x isa Tuple{Vector{Float64},Vector{Float64}}      # (t, values): a tabulated I(t) / V(t) / P(t); the caller keeps the two vectors alive (GC.@preserve)
-        return Run(MODE[name], VAL_TABLE, x[2][1], tf, b, length(x[1]), pointer(x[1]), pointer(x[2]), C_NULL, C_NULL, 0, 0, C_NULL, C_NULL)
+        return Run(MODE[name], VAL_TABLE, x[2][1], tf, b, length(x[1]), 0, pointer(x[1]), pointer(x[2]), C_NULL, C_NULL, 0, 0, C_NULL, C_NULL)
     end
     if haskey(DSTATE, name)                              # the rate of one differential state held (number or :hold); the device picks the state per cell
         kind, val = x === :hold ? (VAL_HOLD, 0.0) : (VAL_CONST, Float64(x))
-        return Run(MODE[name], kind, val, tf, b, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, DSTATE[name], C_NULL, C_NULL)
+        return Run(MODE[name], kind, val, tf, b, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, DSTATE[name], C_NULL, C_NULL)
     end
     res_x = 0.0
     if name === :res && x isa Tuple                      # res = (x, f): x - f(t, Y, YP, p) = 0 (custom_res!, model_evaluation.jl:155-172)
@@ -134,11 +135,11 @@ function make_run(p, step::NamedTuple)
     if x isa Function                                    # a closure input: its expression as a postfix program (closure_program below)
         ops, args, n_main, dcol, dofs = closure_program(x, p)
         push!(KEEPALIVE, (ops, args, dcol, dofs))        # (the program arrays must outlive the call; emptied by simulate_ensemble when it returns)
-        return Run(MODE[name], VAL_EXPR, res_x, tf, b, n_main, pointer(ops), pointer(args), C_NULL, C_NULL, length(dcol), 0, isempty(dcol) ? C_NULL : pointer(dcol), isempty(dcol) ? C_NULL : pointer(dofs))
+        return Run(MODE[name], VAL_EXPR, res_x, tf, b, n_main, 0, pointer(ops), pointer(args), C_NULL, C_NULL, length(dcol), 0, isempty(dcol) ? C_NULL : pointer(dcol), isempty(dcol) ? C_NULL : pointer(dofs))
     end
-    x isa Vector{Float64} && return Run(MODE[name], VAL_CONST, x[1], tf, b, 0, C_NULL, C_NULL, pointer(x), C_NULL, 0, 0, C_NULL, C_NULL)   # one value per cell (caller keeps x alive)
+    x isa Vector{Float64} && return Run(MODE[name], VAL_CONST, x[1], tf, b, 0, 0, C_NULL, C_NULL, pointer(x), C_NULL, 0, 0, C_NULL, C_NULL)   # one value per cell (caller keeps x alive)
     kind, val = x === :hold ? (VAL_HOLD, 0.0) : x === :rest ? (VAL_REST, 0.0) : (VAL_CONST, Float64(x))
-    Run(MODE[name], kind, val, tf, b, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, 0, C_NULL, C_NULL)
+    Run(MODE[name], kind, val, tf, b, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, 0, C_NULL, C_NULL)
 end
 
 # Input closures `I = (t, Y, YP, p) -> ...` (input_methods.jl:159-176): PETLION itself traces them with Symbolics to differentiate the control row

@@ -167,7 +167,10 @@ typedef struct {
      piecewise-linear table; a repeated knot time is a jump (right-continuous), the last value holds beyond the last knot.  The arrays are HOST
      memory like the protocol itself (plh_integrate stages them).  List jump times in plh_opts.tdiscon as with the reference's `tdiscon`. */
   /* PLH_VAL_EXPR: n_tab instructions, tab_t[k] = opcode (PLH_OP_*, stored as a double), tab_v[k] = operand (see above); HOST arrays, staged like a table. */
-  int n_tab; const double* tab_t; const double* tab_v;
+  int n_tab;
+  int closure_id;  /* written by the library (the caller's value is ignored): which compiled closure of an attached closure library this run uses, -1 = interpreted
+                      (plh_model_attach_closure_library).  Sits in what was padding: no other field moved. */
+  const double* tab_t; const double* tab_v;
   /* ensemble axis of the protocol itself: per-cell input value (PLH_VAL_CONST only, e.g. a C-rate sweep) and per-cell run length, [n_cells] HOST
      arrays staged by plh_integrate; NULL = every cell uses `value` / `tf`.  (New: the reference runs one cell per simulate() call.) */
   const double* value_cell; const double* tf_cell;
@@ -309,6 +312,18 @@ int plh_integrate(plh_model_t m, int n_cells, const double* theta, const double*
  * I, V, P, eta_p, dT, any number of runs, new solutions only; everything else is PLH_E_UNSUPPORTED.  ptr_kind PLH_HOST or PLH_DEVICE (the call is synchronous). */
 int plh_integrate_sens(plh_model_t m, int n_cells, const double* theta, const double* SOC0, int n_runs, const plh_run* runs, const plh_opts* opts,
                        const plh_outputs* out, int n_sens, const int* sens_cols, double* dY_dtheta, double* dV_dtheta, int* sens_stat, int ptr_kind, void* stream);
+
+/* ---- compiled input closures.  The reference compiles the user's closure and its symbolic derivatives into its generated control-row functions
+ * (differentiate_residual_func, scalar_residual.jl:231-416); the built-in kernels interpret the PLH_VAL_EXPR programs instead.  A closure library is csrc/variant_tu.hip compiled once
+ * more for this model's variant and grid with the programs of ONE protocol written out as straight-line device code (petlion.jl_amd/closure_lib.py writes the header and runs
+ * hipcc; the library exports its variant table like a grid library, plus plh_closure_digest()).  After it is attached, plh_integrate uses its kernels for every call whose
+ * PLH_VAL_EXPR programs (opcodes, operands, derivative columns, in protocol order) hash to the digest the library was built for, and the interpreter for every other call --
+ * same arguments, same results (the expression is evaluated with the same operations in the same order).  One library per handle; attaching another replaces it. */
+int plh_model_attach_closure_library(plh_model_t m, const char* path);
+/* 1 if the handle's last plh_integrate ran the attached closure library's kernels, 0 if it interpreted (or had no closure input) */
+int plh_last_integrate_compiled(plh_model_t m);
+/* the digest plh_integrate computes for a protocol (0 if it has no PLH_VAL_EXPR run): what a builder embeds in the library */
+unsigned long long plh_closure_digest(int n_runs, const plh_run* runs);
 
 /* timing of the last plh_integrate kernel on its stream, measured with HIP events (ms); <0 if unavailable */
 double plh_last_kernel_ms(plh_model_t m);

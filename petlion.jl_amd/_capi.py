@@ -38,7 +38,7 @@ class Bounds(C.Structure):
 
 class Run(C.Structure):
     _fields_ = [("mode", C.c_int), ("value_kind", C.c_int), ("value", C.c_double), ("tf", C.c_double), ("bounds", Bounds),
-                ("n_tab", C.c_int), ("tab_t", C.POINTER(C.c_double)), ("tab_v", C.POINTER(C.c_double)),
+                ("n_tab", C.c_int), ("closure_id", C.c_int), ("tab_t", C.POINTER(C.c_double)), ("tab_v", C.POINTER(C.c_double)),
                 ("value_cell", C.POINTER(C.c_double)), ("tf_cell", C.POINTER(C.c_double)),
                 ("n_dcol", C.c_int), ("dstate", C.c_int), ("dcol", C.POINTER(C.c_int)), ("dofs", C.POINTER(C.c_int))]
 
@@ -77,7 +77,7 @@ assert RUN_INFO_DTYPE.itemsize == C.sizeof(RunInfo) and COUNTERS_DTYPE.itemsize 
 EXPORTS = ["plh_model_create", "plh_model_destroy", "plh_register_grid_library", "plh_n_states", "plh_n_diff", "plh_n_theta", "plh_theta_key",
            "plh_theta_default", "plh_lds_bytes", "plh_n_sections", "plh_section", "plh_jac_pattern", "plh_jac_alg_pattern", "plh_last_error", "plh_build_info", "plh_device_count", "plh_abi_layout",
            "plh_initial_guess", "plh_residual", "plh_jacobian", "plh_linear_solve", "plh_linear_solve_refined", "plh_residual_diff", "plh_residual_alg",
-           "plh_jacobian_alg", "plh_init_consistent", "plh_integrate", "plh_integrate_sens", "plh_last_kernel_ms", "plh_host_alloc", "plh_host_free", "plh_synchronize",
+           "plh_jacobian_alg", "plh_init_consistent", "plh_integrate", "plh_integrate_sens", "plh_model_attach_closure_library", "plh_last_integrate_compiled", "plh_closure_digest", "plh_last_kernel_ms", "plh_host_alloc", "plh_host_free", "plh_synchronize",
            "plh_comm_unique_id", "plh_comm_create", "plh_comm_destroy", "plh_comm_rank", "plh_comm_size", "plh_ensemble_run"]
 
 
@@ -136,6 +136,10 @@ def load(path=None):
     lib.plh_ensemble_run.argtypes = [vp, vp, i, vp, vp, i, C.POINTER(Run), C.POINTER(Opts), i, vp, vp, vp, vp]
     lib.plh_init_consistent.argtypes = [vp, i, vp, i, d, d, vp, vp, vp, vp, i, vp]
     lib.plh_integrate.argtypes = [vp, i, vp, vp, vp, vp, i, C.POINTER(Run), C.POINTER(Opts), C.POINTER(Outputs), i, vp]
+    lib.plh_model_attach_closure_library.argtypes = [vp, C.c_char_p]
+    lib.plh_last_integrate_compiled.argtypes = [vp]
+    lib.plh_closure_digest.argtypes = [i, C.POINTER(Run)]
+    lib.plh_closure_digest.restype = C.c_ulonglong
     lib.plh_integrate_sens.argtypes = [vp, i, vp, vp, i, C.POINTER(Run), C.POINTER(Opts), C.POINTER(Outputs), i, vp, vp, vp, vp, i, vp]
     _cache[path] = lib
     return lib

@@ -95,6 +95,18 @@ class Model:
 
     theta = property(lambda self: self.θ)
 
+    def compile_closures(self, protocol, n_cells=None, force=False, _emu_include=None):
+        """compile the input closures of `protocol` into device code and attach them to this model (closure_lib.py; hipcc, once per closure set, cached): later
+        simulate_ensemble / simulate calls with the same closures run them compiled instead of interpreted; every other call is unaffected.  Returns the library path
+        (None: the protocol has no closure input)."""
+        from . import closure_lib
+        runs, _ = make_protocol(self, protocol, n_cells)
+        lib = closure_lib.library(self, runs, force=force, emu_include=_emu_include)
+        if lib:
+            cap.check(self._lib, self._lib.plh_model_attach_closure_library(self._h, os.fsencode(lib)), "plh_model_attach_closure_library")
+            self._closure_digest = closure_lib.digest(closure_lib.expr_runs(runs))
+        return lib
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

@@ -87,8 +87,18 @@ PL_DEV double tab_eval(const plh_run& r, double t) {
 // value of a closure input (PLH_VAL_EXPR): a postfix program over t, Y, YP, theta (include/petlion_hip.h); wave-uniform, every lane runs it (scalar loads of the program,
 // broadcast LDS reads of the states).  The value stack is an LDS array -- every lane stores the same value at the same address -- because a runtime-indexed private array
 // would live in scratch memory, once per inlined copy of this function.
+// A closure library (petlion.jl_amd/closure_lib.py) compiles this file with the programs of one protocol written out as C++ (PL_CLOSURE_HEADER): expr_eval is then a call of
+// straight-line code -- `which` = -1 the closure itself, k its derivative program k -- and the interpreter below is not instantiated.
+#ifdef PL_CLOSURE_HEADER
+#include PL_CLOSURE_HEADER
+#endif
 template <class M>
-PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP, int k0 = 0, int k1 = -1) {      // instructions [k0, k1); default: the main program
+PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP, int k0 = 0, int k1 = -1, int which = -1) {      // instructions [k0, k1); default: the main program
+#ifdef PL_CLOSURE_COMPILED
+  (void)k0; (void)k1;
+  return pl_closure_compiled(r.closure_id, which, t, Y, YP, S.theta_row);
+#else
+  (void)which;
   double* st = S.xstk + PLH_EXPR_STACK * wave_id(); const double* th = S.theta_row; int sp = 0;
   if (k1 < 0) k1 = r.n_tab;
   for (int k = k0; k < k1; k++) {
@@ -112,6 +122,7 @@ PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double*
     }
   }
   return st[0];
+#endif
 }
 // value of the closure of a run as the control residual uses it: method(Y) - f for the input modes; for PLH_MODE_RES (method_res = 0; run_residual,
 // scalar_residual.jl:172: res = theta[:_residual_val] - f) the row is -(f - x) with x = plh_run.value
@@ -166,7 +177,7 @@ PL_DEV void gen_factor(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double cj, 
     }
     for (int k = 0; k < r.n_dcol; k++) {
       const int c = r.dcol[k];
-      const double v = -expr_eval(S, r, t, Y, YPe, r.dofs[k], r.dofs[k + 1]);
+      const double v = -expr_eval(S, r, t, Y, YPe, r.dofs[k], r.dofs[k + 1], k);
       if (c < NST) entry(c, v);                                                                               // - d f / d Y[c]
       else {                                                                                                    // - d f / d YP[i] of the differential state i = c - NST:
         const int i = c - NST;

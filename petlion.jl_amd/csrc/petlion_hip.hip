@@ -167,6 +167,8 @@ struct plh_model_s {
   std::vector<int> alg_colptr[PLH_N_MODES], alg_rowval[PLH_N_MODES], alg_sel[PLH_N_MODES];     // J_y_alg block: pattern + positions in the full CSC order
   std::vector<void*> d_tables;     // device copies of the pattern tables (freed with the handle)
   int* d_alg_sel[PLH_N_MODES] = {};
+  bool last_compiled = false;                                                  // the last plh_integrate ran the attached library's kernels
+  const VariantOps* cl_ops = nullptr; unsigned long long cl_digest = 0;      // attached closure library (plh_model_attach_closure_library): its kernels, the protocol digest it was built for
   std::vector<StreamCtx*> streams;
   StreamCtx* last = nullptr;
   StreamCtx& ctx(hipStream_t st) {
@@ -415,6 +417,44 @@ int plh_register_grid_library(const char* path) {
   return 0;
 }
 
+// FNV-1a (64 bit) over the closure programs of a protocol as the kernels see them; petlion.jl_amd/closure_lib.py::digest computes the same number when it builds a library
+static_assert(sizeof(plh_run) == 176, "plh_run: a field added outside the padding moves the others (bindings/julia, the ctypes mirror) -- and see DESIGN.md 5a");
+unsigned long long plh_closure_digest(int n_runs, const plh_run* runs) {
+  unsigned long long h = 0xcbf29ce484222325ull; bool any = false;
+  auto feed = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t k = 0; k < n; k++) { h ^= b[k]; h *= 0x100000001b3ull; } };
+  for (int r = 0; r < n_runs; r++) {
+    if (!runs || runs[r].value_kind != PLH_VAL_EXPR || !runs[r].tab_t || !runs[r].tab_v) continue;
+    any = true;
+    const int nd = runs[r].n_dcol > 0 ? runs[r].n_dcol : 0, n_all = nd > 0 ? runs[r].dofs[nd] : runs[r].n_tab;
+    feed(&runs[r].n_tab, sizeof(int)); feed(runs[r].tab_t, (size_t)n_all * sizeof(double)); feed(runs[r].tab_v, (size_t)n_all * sizeof(double));
+    feed(&nd, sizeof(int));
+    if (nd > 0) { feed(runs[r].dcol, (size_t)nd * sizeof(int)); feed(runs[r].dofs, (size_t)(nd + 1) * sizeof(int)); }
+  }
+  return any ? h : 0ull;
+}
+
+int plh_model_attach_closure_library(plh_model_t m, const char* path) {
+  CHECK_MODEL(m);
+  if (!path) return fail(PLH_E_ARG, "null path");
+  void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);          // (kept loaded for the life of the process, like a grid library)
+  if (!h) return fail(PLH_E_ARG, std::string("dlopen failed: ") + dlerror());
+  auto ops = (const VariantOps* (*)(int))dlsym(h, "plh_grid_variant_ops");
+  auto dims = (void (*)(int*))dlsym(h, "plh_grid_dims");
+  auto abi = (void (*)(int*, int*, int*, int*))dlsym(h, "plh_grid_abi");
+  auto dig = (unsigned long long (*)())dlsym(h, "plh_closure_library_digest");
+  if (!ops || !dims || !abi || !dig) { dlclose(h); return fail(PLH_E_ARG, "not a closure library (petlion.jl_amd/closure_lib.py builds one)"); }
+  { int v = 0, so = 0, sa = 0, st = 0; abi(&v, &so, &sa, &st);
+    if (v != PLH_HOST_ABI || so != (int)sizeof(VariantOps) || sa != (int)sizeof(IntegrateArgs) || st != (int)sizeof(Tables)) {
+      dlclose(h); return fail(PLH_E_ARG, "closure library was built against another version of the host interface (stale cache: rebuild it)"); } }
+  int g[6]; dims(g);
+  const VariantOps* o = ops(m->ops->id);
+  if (!o || memcmp(g, m->ops->grid, sizeof(g)) != 0 || !desc_matches(&m->desc, o)) { dlclose(h); return fail(PLH_E_ARG, "closure library: built for another model variant or discretisation"); }
+  m->cl_ops = o; m->cl_digest = dig();
+  return 0;
+}
+
+int plh_last_integrate_compiled(plh_model_t m) { return m && m->last_compiled ? 1 : 0; }
+
 void plh_model_destroy(plh_model_t m) {
   if (!m) return;
   DeviceGuard guard(m->device);
@@ -487,7 +527,7 @@ int plh_abi_layout(int* out, int cap) {
   PL_F(plh_model_desc, thermodynamic_factor) PL_F(plh_model_desc, rxn) PL_F(plh_model_desc, waves_per_cell)
   PL_S(plh_bounds, 11) PL_F(plh_bounds, V_max) PL_F(plh_bounds, V_min) PL_F(plh_bounds, SOC_max) PL_F(plh_bounds, SOC_min) PL_F(plh_bounds, T_max) PL_F(plh_bounds, c_s_n_max)
   PL_F(plh_bounds, I_max) PL_F(plh_bounds, I_min) PL_F(plh_bounds, eta_plating_min) PL_F(plh_bounds, c_e_min) PL_F(plh_bounds, dfilm_max)
-  PL_S(plh_run, 14) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, tab_t)
+  PL_S(plh_run, 15) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, closure_id) PL_F(plh_run, tab_t)
   PL_F(plh_run, tab_v) PL_F(plh_run, value_cell) PL_F(plh_run, tf_cell) PL_F(plh_run, n_dcol) PL_F(plh_run, dstate) PL_F(plh_run, dcol) PL_F(plh_run, dofs)
   PL_S(plh_opts, 16) PL_F(plh_opts, abstol) PL_F(plh_opts, reltol) PL_F(plh_opts, abstol_init) PL_F(plh_opts, reltol_init) PL_F(plh_opts, maxiters) PL_F(plh_opts, check_bounds)
   PL_F(plh_opts, interp_final) PL_F(plh_opts, max_order) PL_F(plh_opts, jac_every_step) PL_F(plh_opts, init_step) PL_F(plh_opts, n_tdiscon) PL_F(plh_opts, tdiscon) PL_F(plh_opts, refine)
@@ -737,6 +777,9 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
     HIPCHK(hipMalloc((void**)&cx.d_runs, n_runs * sizeof(plh_run))); cx.runs_cap = n_runs;
   }
   std::vector<plh_run> hruns(runs, runs + n_runs);                    // tables are host arrays: stage them and patch the device copies
+  // compiled closures: the attached library's kernels when this protocol's programs are the ones it was built from (and nothing asks for the refinement instantiation)
+  const bool compiled = m->cl_ops && opts->refine == 0 && !sq && plh_closure_digest(n_runs, runs) == m->cl_digest && m->cl_digest != 0;
+  { int cid = 0; for (int r = 0; r < n_runs; r++) hruns[r].closure_id = (compiled && hruns[r].value_kind == PLH_VAL_EXPR) ? cid++ : -1; }
   for (int r = 0; r < n_runs; r++) {
     if (hruns[r].value_kind == PLH_VAL_TABLE || hruns[r].value_kind == PLH_VAL_EXPR) {
       const bool der = hruns[r].value_kind == PLH_VAL_EXPR && runs[r].n_dcol > 0;
@@ -795,7 +838,8 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
   if (need_genW) features |= 1 | 2 | 4 | 16;                                     // closures with derivative programs: the general control row
   if (opts->refine > 0) features |= 1 | 2 | 4 | 8;
   if (sq) features = 1 | 32;                                                     // GF_STOPS | GF_SENS
-  m->ops->integrate(s.st, a, features);
+  m->last_compiled = compiled && (features & 4);
+  (m->last_compiled ? m->cl_ops : m->ops)->integrate(s.st, a, features);
   hipEventRecord(cx.ev1, s.st);
   cx.timed = true; m->last = &cx;
   FINISH(s);

@@ -330,6 +330,10 @@ template <class M> struct OpsOf {
     PL_LAUNCH(k_init_consistent<M>, n, WAVE * M::NWAVES, st, tb, n, theta, mode, value, reltol_init, Y, YP, status, iters, nref);
   }
   static void integrate(hipStream_t st, const IntegrateArgs& a, int features) {     // features: GenFlag bits the call needs; the smallest instantiation that has them all
+#ifdef PL_CLOSURE_COMPILED      /* a closure library holds the two closure instantiations only (plh_integrate sends it nothing else) */
+    if (features & GF_GENROW) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR | GF_GENROW>), a.n_cells, WAVE * M::NWAVES, st, a);
+    else if (features & GF_EXPR) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR>), a.n_cells, WAVE * M::NWAVES, st, a);
+#else
     if (features & GF_SENS) { if constexpr (!M::W2) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_SENS>), a.n_cells, WAVE * M::NWAVES, st, a); }
     else if (features & GF_REFINE) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR | GF_GENROW | GF_REFINE>), a.n_cells, WAVE * M::NWAVES, st, a);
     else if (features & GF_GENROW) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC | GF_EXPR | GF_GENROW>), a.n_cells, WAVE * M::NWAVES, st, a);
@@ -337,6 +341,7 @@ template <class M> struct OpsOf {
     else if (features & GF_FUNC) PL_LAUNCH((k_integrate<M, GF_STOPS | GF_FUNC>), a.n_cells, WAVE * M::NWAVES, st, a);
     else if (features & GF_STOPS) PL_LAUNCH((k_integrate<M, GF_STOPS>), a.n_cells, WAVE * M::NWAVES, st, a);
     else PL_LAUNCH((k_integrate<M, 0>), a.n_cells, WAVE * M::NWAVES, st, a);
+#endif
   }
   static const VariantOps* table(int id) {
 #if !defined(PL_PHASE_TIMERS) && !defined(PL_WAVE_EMU)

@@ -64,5 +64,5 @@ PL_VARIANT_LIST(PL_DECLARE_OPS)
 extern "C" const VariantOps* plh_grid_variant_ops(int id);     // nullptr: variant not built into this grid library
 extern "C" void plh_grid_dims(int* grid6);
 // what a grid library was compiled against: bump PLH_HOST_ABI whenever VariantOps / IntegrateArgs / Tables change, so that a stale cached library is refused, not misread
-constexpr int PLH_HOST_ABI = 5;
+constexpr int PLH_HOST_ABI = 6;
 extern "C" void plh_grid_abi(int* abi, int* sizeof_ops, int* sizeof_args, int* sizeof_tables);
