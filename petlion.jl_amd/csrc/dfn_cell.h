@@ -98,7 +98,11 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false, int 
   // LDS diet: the error weights and the accumulated Newton correction live in registers (IdaScalars::ew / ee: they are only touched by the
   // lane-strided vector phases), and so do the BDF history vectors of order >= PHI_LDS
   static constexpr int PHI_LDS = THERMAL_ ? 2 : MAXORD + 1;   // thermal: 40.7 kB -> four cells per CU
+#ifdef PL_EXP_SEI_PRED      /* (A/B build, tools/experiments/ab.py sei_pred: the predictor in registers for the SEI models too) */
+  static constexpr bool PRED_REGS = !THERMAL_;
+#else
   static constexpr bool PRED_REGS = !THERMAL_ && !SEI_;       // predictor (y, y') of the step kept in registers across the Newton iteration (else re-summed from phi)
+#endif
   static constexpr int NB = THERMAL_ ? 4 : 3;        // node block size of the block-Thomas solve: (c_e, Phi_e, Phi_s[, T])
   static constexpr int O_T = N_CECS;
   static constexpr int O_FILM = N_CECS + (THERMAL_ ? NT : 0), O_SOH = O_FILM + NN;

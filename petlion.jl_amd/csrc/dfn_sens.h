@@ -8,7 +8,7 @@
 //   * after every ACCEPTED step (y_n, y'_n converged, the step's coefficients final) each s_k gets the BDF treatment of y: predictor from its own history of modified divided
 //     differences (same beta / gamma), s' = s'_pred + cj (s - s_pred), corrector  s <- s - c J~^-1 r(s)  with r(s) = F_y s + F_y' s' + F_theta and the integrator's CURRENT
 //     (possibly stale) factorisation J~ -- the matrix the Newton iteration of y has just converged with; c = 2 / (1 + cj/cj_factor) as in IDANls.  r is linear in s, so the
-//     iteration converges at the rate of that Newton iteration; it runs to a tolerance 1e-5 of the states' own error weights per unit relative parameter change.
+//     iteration converges at the rate of that Newton iteration; it runs until a correction times the parameter is below max(1e-7, reltol / 100) of the scale of every state.
 //   * the residual of the sensitivity system is formed by directional difference quotients of the model's own residual -- no second set of equations to keep in step:
 //     F_y s + F_y' s' = (F(y + e s, y' + e s') - F(y, y')) / e ,  F_theta = (F(.; theta + d e_k) - F(.; theta)) / d  (the cell constants are recomputed from the perturbed
 //     theta row for that one evaluation: cell_setup<M, false>).
@@ -24,10 +24,12 @@
 #pragma once
 // (included from dfn_integrate.h, inside namespace pl, after IdaScalars / PL_VEC / EWT)
 
-constexpr int SENS_MAXIT = 16;
+constexpr int SENS_MAXIT = 24;
 // weights of the sensitivity norms: 1 / (|y_n| + abstol / reltol) = the integrator's error weights with the tolerance divided out -- the corrector stops when a correction,
 // times the parameter, is below SENS_TOL of the scale of each state (the difference quotients carry ~1e-9 of rounding: a criterion that tightened with reltol could not be met)
+// (and not below 1 % of the integration's own relative tolerance: at reltol 1e-3 a corrector driven to 1e-7 spends its iterations on digits the step does not have)
 constexpr double SENS_TOL = 1e-7, SENS_FD = 1e-7;
+__device__ __forceinline__ double sens_tol(double rtol) { const double t = 0.01 * rtol; return t > SENS_TOL ? t : SENS_TOL; }
 
 __device__ __forceinline__ double wave_max(double v) {
   for (int o = WAVE / 2; o >= 1; o >>= 1) { const double r = __shfl_xor(v, o); v = v > r ? v : r; }
@@ -134,7 +136,7 @@ PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, boo
       nr = sqrt(wave_sum(nr) * (1.0 / NST));
       X.n_it++;
       PL_XSYNC();
-      if (nr <= SENS_TOL) { conv = true; break; }
+      if (nr <= sens_tol(rtol)) { conv = true; break; }
       if (!(nr == nr)) break;
     }
     if (!conv) X.n_fail++;
@@ -208,7 +210,7 @@ PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<
       nr = sqrt(wave_sum(nr) * (1.0 / NST));
       X.n_it++;
       PL_XSYNC();
-      if (nr <= SENS_TOL) { conv = true; break; }
+      if (nr <= sens_tol(I.rtol)) { conv = true; break; }
       if (!(nr == nr)) break;
     }
     if (!conv) X.n_fail++;

@@ -21,6 +21,7 @@ BUILDS = {
     "th_nolso": ([4], EARLY + NOLSO, "c3", "c3_thermal"), "iso_nolso": ([0], LATE + NOLSO, "c2 c4", "c2_1024 or evaluators"), "sei_nolso": ([3], LATE + NOLSO, "c5", "c5_nmc_sei"),
     "th_novec": ([4], EARLY + NOLSO + NOVEC, "c3", "c3_thermal"), "iso_novec": ([0], LATE + NOLSO + NOVEC, "c2 c4", "c2_1024 or evaluators"),
     # round-3 final source (built from a git worktree of that commit into the same _exp/ directory: `git worktree add /tmp/r03 <commit>`; build only lists them for `run`)
+    "sei_pred": ([3], LATE + ["-DPL_EXP_SEI_PRED"], "c5", "c5_nmc_sei"),          # r04: predictor of the step in registers for the SEI models (PRED_REGS)
     "th_r03": ([4], None, "c3", "c3_thermal"), "iso_r03": ([0], None, "c2 c4", "c2_1024 or evaluators"), "sei_r03": ([3], None, "c5", "c5_nmc_sei"),
 }
 for k in list(BUILDS):          # every build also exists with the previous-point copy kept (r03) or dropped
