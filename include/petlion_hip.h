@@ -307,8 +307,11 @@ int plh_integrate(plh_model_t m, int n_cells, const double* theta, const double*
  *   dY_dtheta[cell][k][n_states]  at the end of the last completed run (NaN for a cell whose protocol failed); may be NULL
  *   dV_dtheta[cell][k][max_pts]   at every saved point (the Jacobian of the voltage curve a least-squares fit needs); may be NULL
  *   sens_stat[cell][2]            corrector iterations spent, solves that did not reach the tolerance; may be NULL
- * Derivatives are partial derivatives AT FIXED TIME with respect to the absolute value of the parameter: a run that ends on a bound ends at a time that itself depends on
- * theta; that shift is not included (the last point is interpolated like the state's, model_evaluation.jl:369-382).  Protocols: constant or :rest inputs in the modes
+ * Derivatives are with respect to the absolute value of the parameter.  Saved points at accepted steps / stop times: partial derivatives at fixed time.  The last point of a run
+ * that ended on a bound is the reference's linear back-interpolation between the last two accepted points (model_evaluation.jl:369-382), whose fraction depends on theta through
+ * the bounded quantity: its derivative -- and what the next run continues from -- includes that shift, i.e. it is the derivative of the end state as simulate() returns it
+ * (dV/dtheta = 0 at a voltage bound).  Bounds on V, I, T_avg, eta_plating, c_s_n, c_e, and SOC under a constant current; an SOC bound in another mode or the dfilm bound
+ * (a bound on YP) gives NaN from there on.  Protocols: constant or :rest inputs in the modes
  * I, V, P, eta_p, dT, any number of runs, new solutions only; everything else is PLH_E_UNSUPPORTED.  ptr_kind PLH_HOST or PLH_DEVICE (the call is synchronous). */
 int plh_integrate_sens(plh_model_t m, int n_cells, const double* theta, const double* SOC0, int n_runs, const plh_run* runs, const plh_opts* opts,
                        const plh_outputs* out, int n_sens, const int* sens_cols, double* dY_dtheta, double* dV_dtheta, int* sens_stat, int ptr_kind, void* stream);

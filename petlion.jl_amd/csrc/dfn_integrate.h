@@ -770,8 +770,6 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
   return 0;
 }
 
-#include "dfn_sens.h"
-
 // ---- stop conditions (check_simulation_stop!, src/checks.jl:1-224); scalars are wave-uniform ----
 struct PrevVals { double frac, V, SOC, I, c_s_n, c_e_min, eta_pl, dfilm, T; };
 
@@ -841,6 +839,8 @@ PL_DEV void check_stop(const CellLDS<M>& S, const plh_run& run, const plh_opts& 
     pv.dfilm = dm;
   }
 }
+
+#include "dfn_sens.h"
 
 struct CellOut {
   double *t, *V, *I, *SOC, *T, *Yall;
@@ -1061,7 +1061,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       t_end = ti + t0;
       save_pt(nout - 1, t_end, S.yy, SOC);
     }
-    if constexpr ((F & GF_SENS) != 0) sens_finish(S, SX, flag > 0 && o.interp_final && t > 1.0, pv.frac, flag < 0, nout - 1);
+    if constexpr ((F & GF_SENS) != 0) sens_finish(S, SX, flag > 0 && o.interp_final && t > 1.0, pv.frac, flag < 0, nout - 1, flag, run.bounds, mode);
     ri.flag = flag; ri.iterations = iter; ri.t_end = t_end; ri.V = cellV<M>(S.yy); ri.I = S.yy[O_I]; ri.SOC = SOC; ri.T_avg = cellTavg<M>(S, S.yy);
     if (lane == 0 && wave_id() == 0) info[r] = ri;
     have_prev = true;

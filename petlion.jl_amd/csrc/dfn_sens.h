@@ -17,8 +17,8 @@
 //   * start of a run: s_diff from the initial guess (difference quotient of initial_guess! in theta) or carried from the previous run; s_alg from the algebraic equations with
 //     the consistent initialisation's own factorisation; s'_diff = d rhs / d theta, s'_alg = 0 (the first step is BDF1: s' only seeds the predictor).
 //   * end of a run on a bound: the reference replaces the last point by a linear interpolation between the last two accepted points (interp_final_points!,
-//     model_evaluation.jl:369-382); s gets the same interpolation with the same fraction.  What is reported is the partial derivative AT FIXED TIME: the dependence of the
-//     stop time itself on theta (a bound crossed earlier or later) is not part of it.
+//     model_evaluation.jl:369-382); s gets the same interpolation AND the shift of the crossing with theta (sens_finish): what is reported, and what the next run continues
+//     from, is the derivative of the end state as simulate() returns it.
 // The history of each s_k (MAXORD + 1 vectors) lives in HBM, lane-strided like every state vector; everything else is registers and the three LDS work vectors of the
 // integrator, which are dead between the output of a step and the next predictor.
 #pragma once
@@ -231,19 +231,62 @@ PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<
   PL_XSYNC();
 }
 
-// end of a run: s_k at the run's last point (back-interpolated like the states when the run ended on a bound) -> hist[0] (what the next run continues from), dY, dV
+// the linear functional of the state whose crossing of a bound ended the run (check_stop), applied to an LDS vector; ix: the entry that held the extreme value for the
+// two max / min bounds.  Wave-uniform; every lane must call it (the average temperature is a wave reduction).
 template <class M>
-PL_DEV void sens_finish(CellLDS<M>& S, SensCell<M>& X, bool interp, double fr, bool failed, int idx) {
+PL_DEV double sens_event_g(const CellLDS<M>& S, int flag, int ix, const double* v) {
+  PL_MODEL(M);
+  if constexpr (M::THERMAL) { if (flag == 5) return cellTavg<M>(S, v); }
+  if (flag == 1 || flag == 2) return v[O_PS] - v[O_PS + NJ - 1];
+  if (flag == 7 || flag == 8) return v[O_I];
+  if (flag == 11) return v[O_PS + NP] - v[O_PE + NP + NS];
+  if (flag == 6 || flag == 9) return v[ix];
+  return 0.0;
+}
+
+// end of a run: s_k at the run's last point -> hist[0] (what the next run continues from), dY, dV.  A run that ended on a bound is back-interpolated by the reference between
+// its last two accepted points, y_e = y_(n-1) + fr (y_n - y_(n-1)) with fr = (g_(n-1) - b) / (g_(n-1) - g_n) from the bounded quantity g (interp_final_points!,
+// model_evaluation.jl:369-382; check_stop_*, checks.jl:31-224).  Its derivative has two parts: the same interpolation of s, and the shift of the crossing itself,
+// (y_n - y_(n-1)) d fr / d theta with d g / d theta = g(s) (g is linear in the state: V, I, the average temperature, eta_plating, one surface / electrolyte concentration).
+// Reported is the sum -- the derivative of the end state AS simulate() RETURNS IT; in particular dV/dtheta of a run that ends on a voltage bound is 0.  An SOC bound under a
+// constant current is crossed at a time that does not depend on theta (fr fixed); an SOC bound in another mode, and the dfilm bound (a bound on YP), give NaN.
+template <class M>
+PL_DEV void sens_finish(CellLDS<M>& S, SensCell<M>& X, bool interp, double fr, bool failed, int idx, int flag, const plh_bounds& bd, int mode) {
   PL_MODEL(M);
   const int lane = lane_id();
   const double nan = __builtin_nan("");
+  interp = interp && !X.first;                             // (hist[1] = s_n - s_(n-1) once a step has been completed)
+  bool shift = interp && !(flag == 3 || flag == 4), unknown = interp && (flag == 10 || ((flag == 3 || flag == 4) && mode != PLH_MODE_I));
+  double gn = 0.0, gp = 0.0, bnd = 0.0; int ix = 0;
+  if (shift && !unknown) {
+    const double* Y = S.phi[0];
+    if (flag == 6) { double cm = -1e300; for (int i = 0; i < NN; i++) { const int q = M::SD == 0 ? O_CS + NP * NR + (i + 1) * NR - 1 : O_CS + NP + i; if (Y[q] > cm) { cm = Y[q]; ix = q; } } }
+    if (flag == 9) { double cm = 1e300; for (int i = 0; i < NE; i++) { if (Y[O_CE + i] < cm) { cm = Y[O_CE + i]; ix = O_CE + i; } } }
+    bnd = flag == 1 ? bd.V_min : flag == 2 ? bd.V_max : flag == 5 ? bd.T_max : flag == 6 ? bd.c_s_n_max * S.cc.cmaxn : flag == 7 ? bd.I_max : flag == 8 ? bd.I_min
+        : flag == 9 ? bd.c_e_min : bd.eta_plating_min;
+    gn = sens_event_g(S, flag, ix, S.phi[0]);
+    gp = gn - sens_event_g(S, flag, ix, S.phi[1]);         // g(y_(n-1)) = g(phi0) - g(phi1)
+  }
   for (int k = 0; k < X.a.n_sens; k++) {
     double* h0 = X.hist(k, 0); const double* h1 = X.hist(k, 1);
+    double dfr = 0.0;
+    if (shift && !unknown) {
+      PL_XSYNC();
+      PL_VEC(n) S.delta[n] = h0[n];
+      PL_XSYNC();
+      const double gsn = sens_event_g(S, flag, ix, S.delta);
+      PL_XSYNC();
+      PL_VEC(n) S.delta[n] = h1[n];
+      PL_XSYNC();
+      const double gsp = gsn - sens_event_g(S, flag, ix, S.delta);
+      const double den = gp - gn;
+      dfr = (gsp * den - (gp - bnd) * (gsp - gsn)) / (den * den);
+    }
     PL_XSYNC();
     PL_VEC(n) {
       double v = h0[n];
-      if (interp && !X.first) { const double prev = v - h1[n]; v = fr * (v - prev) + prev; }      // (hist[1] = s_n - s_(n-1) once a step has been completed)
-      if (failed) v = nan;
+      if (interp) { const double d1 = h1[n]; v = (v - d1) + fr * d1 + S.phi[1][n] * dfr; }
+      if (failed || unknown) v = nan;
       h0[n] = v; S.delta[n] = v;
       if (X.a.dY) X.a.dY[((size_t)X.cell * X.a.n_sens + k) * NST + n] = v;
     }
@@ -252,4 +295,3 @@ PL_DEV void sens_finish(CellLDS<M>& S, SensCell<M>& X, bool interp, double fr, b
   }
   PL_XSYNC();
 }
-

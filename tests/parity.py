@@ -431,7 +431,7 @@ def oracle_fd_sens(O, variant, th, soc, runs, col, ts, rel_h=0.05, tol=None, max
     return d6(lambda r: r["Y"]), d6(V_at), [tuple(x["flag"] for x in r["runs"]) for r in rs.values()]
 
 
-def sens_compare(O, p, pkg, ens, i, th, soc, protocol, keys, ts, variant=None):
+def sens_compare(O, p, pkg, ens, i, th, soc, protocol, keys, ts, variant=None, rel_h=0.05):
     """device sensitivities of cell i (ens from simulate_ensemble(..., sens=keys) with opts.tstops = ts) against oracle_fd_sens.  Returns per key: (dV error relative to
     max |dV/dtheta| over the stop times, {section: (dY error relative to the section's max |dY/dtheta|, theta |dY/dtheta| / |Y| of the section)})"""
     runs = runs_to_oracle(O, p, pkg, protocol)
@@ -441,7 +441,7 @@ def sens_compare(O, p, pkg, ens, i, th, soc, protocol, keys, ts, variant=None):
     out = {}
     for k, key in enumerate(keys):
         col = p.θ_keys.index(key)
-        dY, dV, _ = oracle_fd_sens(O, variant or p.variant, th, soc, runs, col, ts)
+        dY, dV, _ = oracle_fd_sens(O, variant or p.variant, th, soc, runs, col, ts, rel_h=rel_h)
         dVd = np.asarray(ens.dV_dtheta[i, k])[idx]
         eV = (float(np.abs(dVd - dV).max() / np.abs(dV).max()), float(abs(th[col]) * np.abs(dV).max()))      # (error relative to max |dV/dtheta|, theta max |dV/dtheta| in volts)
         sec = {}

@@ -9,15 +9,17 @@ tight-tolerance runs per parameter with common stop times (parity.oracle_fd_sens
     5 % of theta; measured: going from second- to fourth- to sixth-order differences moved the device-vs-oracle gap of weakly dependent sections from 3e-3 to 7e-4 to
     5e-5 while the device's numbers did not move).  Sections that depend on the parameter at all (r >= 0.1) are therefore held to ~3e-4, and the summary prints their worst;
   * the states, saved points and counters of a call with sensitivities are BIT FOR BIT those of the call without (nothing of the integrator is touched);
-  * every corrector solve reached its tolerance (sens_stat)."""
+  * every corrector solve reached its tolerance (sens_stat);
+  * a run that ends on a bound: the derivative of the end state as simulate() returns it -- the reference's linear back-interpolation, including the shift of the crossing."""
 import numpy as np
 import pytest
 
 import parity
 
 
-def check_sens(pkg, p, O, Th, soc, protocol, keys, ts, tol=parity.TIGHT, variant=None, what=""):
-    o = pkg.Opts(); o.reltol, o.abstol, o.maxiters = tol["reltol"], tol["abstol"], 200000; o.tstops = list(ts)
+def check_sens(pkg, p, O, Th, soc, protocol, keys, ts, tol=parity.TIGHT, variant=None, what="", all_ts=None, rel_h=0.05, lim_a=1e-4, lim_b=2e-5):
+    """all_ts: the stop times the runs use (default ts); ts: the ones dV/dtheta is compared at.  rel_h, lim_a, lim_b: step of the differenced oracle and the criterion lim_a + lim_b / r"""
+    o = pkg.Opts(); o.reltol, o.abstol, o.maxiters = tol["reltol"], tol["abstol"], 200000; o.tstops = list(ts if all_ts is None else all_ts)
     Th = np.ascontiguousarray(Th)
     ens = pkg.simulate_ensemble(p, Th, protocol, SOC=soc, opts=o, max_points=20000, sens=keys)
     ref = pkg.simulate_ensemble(p, Th, protocol, SOC=soc, opts=o, max_points=20000)
@@ -32,18 +34,18 @@ def check_sens(pkg, p, O, Th, soc, protocol, keys, ts, tol=parity.TIGHT, variant
     from concurrent.futures import ThreadPoolExecutor
     assert (ens.run_info["flag"] >= 0).all()
     with ThreadPoolExecutor(min(16, len(os.sched_getaffinity(0)))) as ex:       # (the oracle runs release the GIL)
-        allres = list(ex.map(lambda i: parity.sens_compare(O, p, pkg, ens, i, Th[i], soc, protocol, keys, ts, variant=variant), range(Th.shape[0])))
+        allres = list(ex.map(lambda i: parity.sens_compare(O, p, pkg, ens, i, Th[i], soc, protocol, keys, ts, variant=variant, rel_h=rel_h), range(Th.shape[0])))
     for i, res in enumerate(allres):
         for key, (eV, sec) in res.items():
             eV, volts = eV
             # (the differenced oracle again: two tight-tolerance voltages agree to ~1e-8 V, over a step of 5 % of theta)
-            assert eV <= 1e-4 + 2e-7 / max(volts, 1e-12), (what, i, key, "dV/dtheta", eV, volts)
+            assert eV <= lim_a + 2e-7 / max(volts, 1e-12), (what, i, key, "dV/dtheta", eV, volts)
             if volts >= 1e-2:
                 worstV = max(worstV, eV)
             for name, (err, rel) in sec.items():
                 # (the algebraic flux sections are controlled ABSOLUTELY by both integrators -- |j| ~ 1e-5 against abstol 1e-10: 1e-5 of their scale, test_gpu_tight.py -- so
                 #  the differenced oracle is ten times noisier there)
-                lim = 1e-4 + (2e-4 if name in ("j", "j_s") else 2e-5) / max(rel, 1e-12)
+                lim = lim_a + (10 * lim_b if name in ("j", "j_s") else lim_b) / max(rel, 1e-12)
                 assert err <= lim, (what, i, key, name, err, rel)
                 if rel >= 0.1:
                     worstY = max(worstY, err)
@@ -63,6 +65,34 @@ def test_sens_through_run_changes_and_a_bound_emu(emu_model, O, pkg):
     p = emu_model
     proto = [{"I": -2.0, "tf": 200.0}, {"I": "rest", "tf": 100.0}, {"V": 4.0, "tf": 150.0}]
     check_sens(pkg, p, O, p.theta_vector()[None, :], 0.9, proto, ["D_sp", "k_p"], np.arange(20.0, 200.0, 20.0), what="LCO 2C / rest / CV (emulator)")
+
+
+@pytest.mark.gpu
+def test_sens_of_a_run_that_ends_on_a_voltage_bound_gpu(hip_model, O, pkg):
+    _event_case(hip_model, O, pkg, "LCO 2C to V_min, rest")
+
+
+def test_sens_of_a_run_that_ends_on_a_voltage_bound_emu(emu_model, O, pkg):
+    _event_case(emu_model, O, pkg, "LCO 2C to V_min, rest (emulator)")
+
+
+def _event_case(p, O, pkg, what):
+    """a 2C discharge that ends on V_min, then a rest: the end state of run 1 is the reference's linear back-interpolation, and its derivative includes the shift of the
+    crossing with theta (sens_finish) -- dV/dtheta of the interpolated point is 0 (the voltage there IS the bound), and the derivative of the final state agrees with the
+    differenced oracle, whose six runs each end at their own crossing.  (The oracle is noisier here: each of its runs locates the crossing on a 0.05 s stop grid; its step is
+    10 % of theta and the criterion 3e-4 + 5e-5 / r -- halving / doubling the step moves the device-vs-oracle gap of c_s between 7e-4 and 4e-4 while the device's numbers stay.)"""
+    th = p.theta_vector()
+    proto = [{"I": -2.0, "V_min": 3.75, "tf": 3000.0}, {"I": "rest", "tf": 120.0}]
+    o = pkg.Opts(); o.reltol, o.abstol, o.maxiters = 1e-8, 1e-10, 200000
+    e0 = pkg.simulate_ensemble(p, th[None, :].copy(), proto[:1], SOC=0.9, opts=o, max_points=20000)
+    assert int(e0.run_info[0, 0]["flag"]) == 1
+    te = float(e0.run_info[0, 0]["t_end"])
+    coarse = np.arange(50.0, te - 50.0, 50.0)          # (the differenced oracle moves theta by up to +-30 %: its runs cross the bound up to ~10 s earlier or later)
+    all_ts = np.unique(np.round(np.concatenate([coarse, np.arange(te - 15.0, te + 15.0, 0.05)]), 6))
+    ens = check_sens(pkg, p, O, th[None, :], 0.9, proto, ["D_sp", "k_n"], coarse, all_ts=all_ts, rel_h=0.1, lim_a=3e-4, lim_b=5e-5, what=what)
+    k1 = int(ens.run_info[0, 0]["iterations"])
+    dV = np.asarray(ens.dV_dtheta[0])
+    assert (np.abs(dV[:, k1 - 1]) <= 1e-8 * np.abs(dV[:, k1 - 2])).all(), (dV[:, k1 - 1], dV[:, k1 - 2])
 
 
 def test_sens_thermal_emu(emu_model_thermal, O, pkg):
