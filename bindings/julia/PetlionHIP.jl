@@ -74,6 +74,7 @@ mutable struct Model
                           Dict(:Fickian => 0, :quadratic => 1, :polynomial => 2)[p.numerics.solid_diffusion],
                           p.numerics.thermodynamic_factor === PETLION_thermodynamic_factor_nonlinear(p) ? 1 : 0, p.numerics.rxn_p === PETLION_rxn_MHC(p) ? 1 : 0, waves_per_cell))
         grid = (N.p, N.s, N.n, N.r_p, p.numerics.temperature == true ? N.a : 10, p.numerics.temperature == true ? N.z : 10)
+        N.r_n == N.r_p || (grid = (grid..., N.r_n))       # N_r_p != N_r_n: the anode's N_r as a 7th entry (petlion.jl_amd/grids.py::grid7)
         grid == (10, 10, 10, 10, 10, 10) || register_grid(grid_library(grid))     # another discretisation: its kernels are a library of their own (see grid_library)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:plh_model_create, lib), Cint, (Ref{ModelDesc}, Ref{Ptr{Cvoid}}), d, h), "plh_model_create")

@@ -234,7 +234,7 @@ int plh_model_create(const plh_model_desc* desc, plh_model_t* out);
 void plh_model_destroy(plh_model_t m);
 /* Other discretisations (reference src/params.jl:119-136: petlion(...; N_p, N_s, N_n, N_r_p, N_r_n, N_a, N_z)).  The kernels are compiled per grid, like the reference
    generates and caches its functions per model (generate_functions.jl:44-94): the built-in ones for the default 10 / 10 / 10 / 10, any other grid with 2 <= N_p, N_s, N_n,
-   N_p + N_s + N_n <= 48, 10 <= N_r_p = N_r_n <= 16 as a library built from csrc/variant_tu.hip (petlion.jl_amd/grids.py) and registered here BEFORE
+   N_p + N_s + N_n <= 48, 10 <= N_r_p, N_r_n <= 16 (the two particle grids may differ) as a library built from csrc/variant_tu.hip (petlion.jl_amd/grids.py) and registered here BEFORE
    plh_model_create is called with those dimensions.  Registering the same path twice is a no-op; the library stays loaded for the life of the process. */
 int plh_register_grid_library(const char* path);
 int plh_n_states(plh_model_t m);     /* p.N.tot  */

@@ -62,6 +62,9 @@ VARIANTS = {
     "nmc_iso_sei_g6_5_8_13": dict(cathode="NMC", aging=True, Np=6, Ns=5, Nn=8, Nrp=13, Nrn=13),
     # temperature = true on another grid: _g<N_p>_<N_s>_<N_n>_<N_r>_<N_a>_<N_z>
     "lco_thermal_g8_6_7_11_5_7": dict(cathode="LCO", temperature=True, Np=8, Ns=6, Nn=7, Nrp=11, Nrn=11, Na=5, Nz=7),
+    # N_r_p != N_r_n (params.jl:124-136: independent options): _rn<N_r_n> appended
+    "lco_iso_g7_6_8_12_rn10": dict(cathode="LCO", Np=7, Ns=6, Nn=8, Nrp=12, Nrn=10),
+    "lco_thermal_g8_6_7_11_5_7_rn13": dict(cathode="LCO", temperature=True, Np=8, Ns=6, Nn=7, Nrp=11, Nrn=13, Na=5, Nz=7),
 }
 
 

@@ -84,6 +84,9 @@ DECL_VARIANT(lco_thermal) DECL_THERMAL(lco_thermal)
 #ifdef ORC_HAVE_lco_thermal_g8_6_7_11_5_7
 DECL_VARIANT(lco_thermal_g8_6_7_11_5_7) DECL_THERMAL(lco_thermal_g8_6_7_11_5_7)
 #endif
+#ifdef ORC_HAVE_lco_thermal_g8_6_7_11_5_7_rn13
+DECL_VARIANT(lco_thermal_g8_6_7_11_5_7_rn13) DECL_THERMAL(lco_thermal_g8_6_7_11_5_7_rn13)
+#endif
 #ifdef ORC_HAVE_lgm50_thermal
 DECL_VARIANT(lgm50_thermal) DECL_THERMAL(lgm50_thermal)
 #endif
@@ -104,6 +107,9 @@ DECL_VARIANT(lgm50_iso)
 #endif
 #ifdef ORC_HAVE_lco_iso_g12_7_9_11
 DECL_VARIANT(lco_iso_g12_7_9_11)
+#endif
+#ifdef ORC_HAVE_lco_iso_g7_6_8_12_rn10
+DECL_VARIANT(lco_iso_g7_6_8_12_rn10)
 #endif
 #ifdef ORC_HAVE_nmc_iso_sei_g6_5_8_13
 DECL_VARIANT(nmc_iso_sei_g6_5_8_13)
@@ -189,6 +195,12 @@ static int get_model(const char* name, orc_model* m) {
 #endif
 #ifdef ORC_HAVE_lgm50_iso
   if (!strcmp(name, "lgm50_iso")) { FILL_VARIANT(m, lgm50_iso, 0, 0); return 0; }
+#endif
+#ifdef ORC_HAVE_lco_iso_g7_6_8_12_rn10      /* N_r_p = 12, N_r_n = 10 (reference src/params.jl:124-136: independent options) */
+  if (!strcmp(name, "lco_iso_g7_6_8_12_rn10")) { FILL_VARIANT_GRID(m, lco_iso_g7_6_8_12_rn10, 0, 7, 6, 8, 12); m->Nrn = 10; set_layout(m, 0, 0); return 0; }
+#endif
+#ifdef ORC_HAVE_lco_thermal_g8_6_7_11_5_7_rn13
+  if (!strcmp(name, "lco_thermal_g8_6_7_11_5_7_rn13")) { FILL_THERMAL_GRID(m, lco_thermal_g8_6_7_11_5_7_rn13, 8, 6, 7, 11, 5, 7); m->Nrn = 13; set_layout(m, 1, 0); return 0; }
 #endif
 #ifdef ORC_HAVE_lco_iso_g12_7_9_11
   if (!strcmp(name, "lco_iso_g12_7_9_11")) { FILL_VARIANT_GRID(m, lco_iso_g12_7_9_11, 0, 12, 7, 9, 11); return 0; }

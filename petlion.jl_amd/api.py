@@ -59,9 +59,9 @@ class Model:
         self.solid_diffusion, self.thermodynamic_factor, self.rxn = solid_diffusion, thermodynamic_factor, rxn
         # another discretisation than the built-in 10/10/10/10: its kernels are a library of their own, compiled on first use and cached (grids.py), registered before the
         # handle is created (`grid_lib`: a library built elsewhere -- the tests' emulator build)
-        if N.r_p != N.r_n and solid_diffusion == "Fickian":
-            raise NotImplementedError("N_r_p != N_r_n: the device kernels use one radial grid for both electrodes")
-        g = grids.grid_tuple(N.p, N.s, N.n, N.r_p if solid_diffusion == "Fickian" else 10, N.a if self.temperature else 10, N.z if self.temperature else 10)
+        # (N_r_p != N_r_n: a 7-entry grid, the anode's N_r last -- the particle phases then run on the larger of the two as lane stride, dfn_cell.h)
+        g = grids.grid_tuple(N.p, N.s, N.n, N.r_p if solid_diffusion == "Fickian" else 10, N.a if self.temperature else 10, N.z if self.temperature else 10,
+                             N.r_n if solid_diffusion == "Fickian" else None)
         grids.check(g, thermal=self.temperature, sei=bool(aging))
         if grid_lib is None and g != grids.DEFAULT:
             if lib_path is not None:
@@ -91,7 +91,7 @@ class Model:
                                           {"Fickian": "", "quadratic": "_quad", "polynomial": "_poly"}[solid_diffusion], "_nu" if thermodynamic_factor == "nonlinear" else "",
                                           "_mhc" if rxn == "MHC" else "")
         if g != grids.DEFAULT:
-            self.variant += "_g%d_%d_%d_%d" % g[:4] + ("_%d_%d" % g[4:] if self.temperature else "")
+            self.variant += "_g%d_%d_%d_%d" % g[:4] + ("_%d_%d" % g[4:6] if self.temperature else "") + ("_rn%d" % g[6] if len(g) == 7 else "")
 
     theta = property(lambda self: self.θ)
 

@@ -35,7 +35,7 @@ namespace pl {
 #endif
 
 constexpr int WAVE = 64;
-// Discretisation (reference src/params.jl:119-136: N_p, N_s, N_n, N_r_p = N_r_n, N_a, N_z): compile-time constants of a translation unit.  The library's built-in
+// Discretisation (reference src/params.jl:119-136: N_p, N_s, N_n, N_r_p, N_r_n, N_a, N_z): compile-time constants of a translation unit.  The library's built-in
 // variants use the reference default, 10 everywhere; another grid is one more build of variant_tu.hip with -DPL_NP=.. -DPL_NS=.. (and `pl` renamed per grid, so that
 // the two builds can live in one process), loaded through plh_register_grid_library (petlion.jl_amd/grids.py drives it; DESIGN.md "other discretisations").
 #ifndef PL_NP
@@ -50,16 +50,29 @@ constexpr int WAVE = 64;
 #ifndef PL_NR
 #define PL_NR 10
 #endif
+#ifndef PL_NRN
+#define PL_NRN PL_NR
+#endif
 #ifndef PL_NA
 #define PL_NA 10
 #endif
 #ifndef PL_NZ
 #define PL_NZ 10
 #endif
-constexpr int NP = PL_NP, NS = PL_NS, NN = PL_NN, NR = PL_NR, NE = NP + NS + NN, NJ = NP + NN;
+// N_r_p != N_r_n (reference src/params.jl:124-136: the two particle grids are independent options): the c_s_avg section keeps the reference's compact layout -- N_p particles
+// of NRP entries, then N_n particles of NRN --, the particle phases run on the common lane stride NR = max(NRP, NRN) (lane -> row l % NR of its particle) with the
+// radial operator of the smaller electrode zero-padded to NR x NR (cell_setup), so that every sum over k < NR is the sum over the electrode's own rows; lanes whose row
+// does not exist in their particle compute and do not store.  With NRP == NRN every expression below folds to what it was for one N_r.
+constexpr int NP = PL_NP, NS = PL_NS, NN = PL_NN, NRP = PL_NR, NRN = PL_NRN, NR = NRP > NRN ? NRP : NRN, NE = NP + NS + NN, NJ = NP + NN;
+constexpr bool NR_EQ = NRP == NRN;
+constexpr int NCS_FICK = NP * NRP + NN * NRN;                      // entries of c_s_avg with Fickian diffusion
+__host__ __device__ constexpr int nr_of(int p) { return NR_EQ ? NR : (p < NP ? NRP : NRN); }                             // radial nodes of particle p (0 .. NJ - 1)
+__host__ __device__ constexpr int cs_off(int p) { return NR_EQ ? p * NR : (p < NP ? p * NRP : NP * NRP + (p - NP) * NRN); }  // first c_s entry of particle p (relative to O_CS)
+__host__ __device__ constexpr int cs_surf(int p) { return cs_off(p) + nr_of(p) - 1; }                                   // its surface node
+__host__ __device__ constexpr int cs_particle(int q) { return NR_EQ ? q / NR : (q < NP * NRP ? q / NRP : NP + (q - NP * NRP) / NRN); }   // particle of c_s entry q
 constexpr int O_CE = 0, O_CS = NE;                                 // c_e and c_s_avg lead every layout (reference src/external.jl:275-365)
 constexpr int NA = PL_NA, NZ = PL_NZ, NT = NA + NE + NZ;         // current collectors; temperature nodes a|p|s|n|z
-constexpr bool GRID_DEFAULT = NP == 10 && NS == 10 && NN == 10 && NR == 10 && NA == 10 && NZ == 10;
+constexpr bool GRID_DEFAULT = NP == 10 && NS == 10 && NN == 10 && NRP == 10 && NRN == 10 && NA == 10 && NZ == 10;
 constexpr int NRMAX = 16;                                          // Tables has room for the radial operator of any supported N_r
 }  // namespace pl
 #include "radial_tables.h"      // PL_RADIAL_M / LAM / V / W: the radial operator of THIS translation unit's N_r as static const arrays -- device code may index them directly
@@ -67,7 +80,7 @@ namespace pl {
 // lane maps: the node pass gives control volume i to lane i; the twisted block sweeps put nodes 0 .. NE/2-1 in lanes 0 .. and nodes NE-1 .. NE/2 in lanes 32 .. (tw_node);
 // the particle phases give lane l row l % NR of particle pass * CS_G + l / NR
 static_assert(NP >= 2 && NS >= 2 && NN >= 2 && NE <= 48, "2 <= N_p, N_s, N_n and N_p + N_s + N_n <= 48 (one lane per node, two 32-lane halves in the sweeps)");
-static_assert(NR >= 10 && NR <= NRMAX, "10 <= N_r <= 16 (the radial operator of N_r = 9 has complex eigenvalues: no spectral resolvent; tools/gen_radial_tables.py)");
+static_assert(NRP >= 10 && NRN >= 10 && NR <= NRMAX, "10 <= N_r_p, N_r_n <= 16 (the radial operator of N_r = 9 has complex eigenvalues: no spectral resolvent; tools/gen_radial_tables.py)");
 constexpr int CS_G = WAVE / NR, CS_LANES = CS_G * NR, CS_PASS = (NJ + CS_G - 1) / CS_G;     // particles per pass, lanes in use, passes (default grid: 6, 60, 4)
 constexpr int MAXORD = 5;
 
@@ -84,8 +97,9 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false, int 
   static constexpr bool W2 = W2_ != 0;
   static constexpr int NWAVES = W2_ ? 2 : 1;
   static_assert(W2_ == 0 || (SD_ == 0 && !SEI_ && !THERMAL_), "two waves per cell: isothermal Fickian models without aging");
+  static_assert(W2_ == 0 || NR_EQ, "two waves per cell: N_r_p = N_r_n");
   static_assert(SD_ == 0 || (!SEI_ && !THERMAL_), "the quadratic / polynomial particle models are instantiated for the isothermal models without aging");
-  static constexpr int NCS = SD_ == 0 ? NJ * NR : NJ;    // entries of c_s_avg
+  static constexpr int NCS = SD_ == 0 ? NCS_FICK : NJ;   // entries of c_s_avg
   static constexpr int N_CECS = O_CS + NCS;
   static constexpr bool SEI = SEI_;
   static constexpr bool THERMAL = THERMAL_;
@@ -136,12 +150,16 @@ struct Tables {
   // radial operator M (N_r x N_r, row-major), its eigenvalues LAM and eigenvectors V, W = V^-1, packed back to back for THIS translation unit's N_r (so that the
   // offsets the kernels see do not depend on the largest supported N_r: vector global loads carry a 13-bit immediate offset); the host side fills the block through
   // the strides of the variant's own N_r (plh_model_create)
-  double RAD[3 * NRMAX * NRMAX + NRMAX];
-  __host__ __device__ const double* Mp() const { return RAD; }
-  __host__ __device__ const double* LAMp() const { return RAD + NR * NR; }
-  __host__ __device__ const double* Vp() const { return RAD + NR * NR + NR; }
-  __host__ __device__ const double* Wp() const { return RAD + 2 * NR * NR + NR; }
-  double BJ;                                            // surface-row BC factor
+  // (N_r_p != N_r_n: one block per electrode -- RAD the cathode's, RAD_N at the end of the struct the anode's --, each at the common stride NR = max(N_r_p, N_r_n), the
+  //  smaller operator zero-padded; el = 0 cathode, 1 anode.  With N_r_p = N_r_n the kernels read RAD only)
+  static constexpr int RADBLK = 3 * NRMAX * NRMAX + NRMAX;
+  double RAD[RADBLK];
+  __host__ __device__ const double* radp(int el) const { return (NR_EQ || el == 0) ? RAD : RAD_N; }
+  __host__ __device__ const double* Mp(int el = 0) const { return radp(el); }
+  __host__ __device__ const double* LAMp(int el = 0) const { return radp(el) + NR * NR; }
+  __host__ __device__ const double* Vp(int el = 0) const { return radp(el) + NR * NR + NR; }
+  __host__ __device__ const double* Wp(int el = 0) const { return radp(el) + 2 * NR * NR + NR; }
+  double BJ;                                            // surface-row BC factor (of the cathode's radial grid; BJ_N: the anode's)
   int thidx[K_COUNT];                                   // position of each key in the theta vector (-1: absent)
   int chem;
   int P;
@@ -150,6 +168,7 @@ struct Tables {
   // the same entries in row-major (CSR) order: row pointers, decode words, column indices -- used by the matrix-vector product of the
   // iterative-refinement mode (plh_opts.refine) and by nothing else
   const int* csr_ptr[PLH_N_MODES]; const unsigned* csr_code[PLH_N_MODES]; const unsigned short* csr_col[PLH_N_MODES];
+  double BJ_N, RAD_N[RADBLK];                           // the anode's radial grid (last: the offsets of everything above are those of the one-grid layout)
 };
 
 struct CellConst {
@@ -238,8 +257,10 @@ template <class M> struct alignas(16) CellLDS {
   // its eigen-decomposition (copies of Tables::V, W, LAM): the resolvents are rebuilt from them at every Jacobian refresh, and reading the tables from HBM there cost
   // 9.7 k cycles per refresh (two dependent rounds of global / scalar loads); from LDS, with the 2 N_r^2 entries spread over the wave, 1 k
   // (one array, so that the models without it -- thermal: 40 952 of the 40 960 B that four cells per CU allow -- pay 8 bytes, not 32)
-  alignas(16) double Mr[M::SD != 0 ? 1 : (M::THERMAL ? 3 * NR * NR : 3 * NR * NR + NR)];      // (thermal: M, V, W; the eigenvalues are only read at a factorisation)
+  static constexpr int MR_BLK = M::THERMAL ? 3 * NR * NR : 3 * NR * NR + NR;                  // (thermal: M, V, W; the eigenvalues are only read at a factorisation)
+  alignas(16) double Mr[M::SD != 0 ? 1 : (NR_EQ ? 1 : 2) * MR_BLK];                          // (N_r_p != N_r_n: the cathode's block, then the anode's, both at stride NR, zero-padded)
   static constexpr int OFF_VR = NR * NR, OFF_WR = 2 * NR * NR, OFF_LAMR = 3 * NR * NR;
+  static __host__ __device__ constexpr int mr_el(int el) { return NR_EQ ? 0 : el * MR_BLK; }  // offset of electrode el's block
   double resp[M::SD != 0 ? NJ : 1], rcjf[M::SD != 0 ? 2 : 1][2];    // quadratic / polynomial particles: d c_s* / d j after eliminating c_avg (and Q); 1/cj and 1/(-kappa - cj) of the factorisation
   double x2[M::THERMAL ? 1 : 3][M::THERMAL ? 1 : NE];      // (the thermal model keeps its own in ThermalPool: one placeholder element here)
   double ctrlJ[2], bord;           // P-mode control row at the last Jacobian pass (I*I1C, V*I1C); border pivot d - v.x2
@@ -623,7 +644,7 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     c.kp = th[ix[K_k_p]] * arr_kp; c.kn = th[ix[K_k_n]] * arr_kn;
     c.cmaxp = th[ix[K_c_max_p]]; c.cmaxn = th[ix[K_c_max_n]];
     c.kap_p = th[ix[K_D_sp]] * arr_dp / (Rp_p * Rp_p); c.kap_n = th[ix[K_D_sn]] * arr_dn / (Rp_n * Rp_n);
-    c.bj_p = -tb->BJ / Rp_p; c.bj_n = -tb->BJ / Rp_n;
+    c.bj_p = -tb->BJ / Rp_p; c.bj_n = -(NR_EQ ? tb->BJ : tb->BJ_N) / Rp_n;
     c.fRT = 0.5 * FAR / (RGAS * T0);
     c.tplus = th[ix[K_tplus]];
     c.Kfac = 2 * RGAS * (1 - c.tplus) * 1.0 / FAR;          // nu = 1: thermodynamic_factor_linear, custom_functions.jl:177
@@ -686,7 +707,11 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
   if constexpr (INIT) {
   if constexpr (M::SD == 0) { if (wave_id() == M::NWAVES - 1) {
     for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->Mp()[k]; S.Mr[S.OFF_VR + k] = tb->Vp()[k]; S.Mr[S.OFF_WR + k] = tb->Wp()[k]; if constexpr (!M::THERMAL) { S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
-    if constexpr (!M::THERMAL) { if (lane < NR) S.Mr[S.OFF_LAMR + lane] = tb->LAMp()[lane]; } } }
+    if constexpr (!M::THERMAL) { if (lane < NR) S.Mr[S.OFF_LAMR + lane] = tb->LAMp()[lane]; }
+    if constexpr (!NR_EQ) {                                 // the anode's block (the tables are already zero-padded to the common stride: plh_model_create)
+      for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[S.mr_el(1) + k] = tb->Mp(1)[k]; S.Mr[S.mr_el(1) + S.OFF_VR + k] = tb->Vp(1)[k]; S.Mr[S.mr_el(1) + S.OFF_WR + k] = tb->Wp(1)[k]; }
+      if constexpr (!M::THERMAL) { if (lane < NR) S.Mr[S.mr_el(1) + S.OFF_LAMR + lane] = tb->LAMp(1)[lane]; }
+    } } }
   for (int k = 0; k < CS_PASS; k++) { R.wreg[k] = 0.0; R.rcp[k] = 0.0; }
   }
   PL_XSYNC();
@@ -708,7 +733,7 @@ PL_DEV void cell_initial_guess(CellLDS<M>& S, double* Y, double SOC) {
   _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wave_id()); vok<M>(k__, lane, wave_id())) {
     double v = 0.0;
     if (n < O_CS) v = c.ce0;
-    else if (n < O_CS + (M::SD == 0 ? NP * NR : NP)) v = csp;
+    else if (n < O_CS + (M::SD == 0 ? NP * NRP : NP)) v = csp;
     else if (n < N_CECS) v = csn;
     else if (M::THERMAL && n < M::O_T + NT) v = c.T0;
     else if (n >= O_PS && n < O_PS + NP) v = Up;
@@ -739,7 +764,7 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   const double jv_l = Y[O_J + jx], ps_l = Y[O_PS + jx], yI = Y[O_I];
   // surface concentration: the last radial node (Fickian FDM) or c_avg + csj j (+ csq Q) (quadratic / polynomial, build_c_s_star!, aux...jl:193-248)
   double cs_l, cavg_l = 0.0, q_l = 0.0;
-  if constexpr (M::SD == 0) cs_l = Y[O_CS + jx * NR + NR - 1];
+  if constexpr (M::SD == 0) cs_l = Y[O_CS + cs_surf(jx)];
   else {
     cavg_l = Y[O_CS + jx]; if (M::SD == 2) q_l = Y[O_Q + jx];
     cs_l = cavg_l + c.csj[el] * jv_l + c.csq[el] * q_l;
@@ -971,6 +996,8 @@ PL_DEV void iso_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const
   const int r = lane % NR, g = lane < CS_LANES ? lane / NR : CS_G - 1;
   double Mrow[NR];
   for (int k = 0; k < NR; k++) Mrow[k] = S.Mr[r * NR + k];
+  [[maybe_unused]] double MrowN[NR_EQ ? 1 : NR];           // (N_r_p != N_r_n: the anode's operator row; padded rows and columns are zero)
+  if constexpr (!NR_EQ) for (int k = 0; k < NR; k++) MrowN[k] = S.Mr[S.mr_el(1) + r * NR + k];
   // the passes are independent: CS_PASS accumulation chains side by side (particle index clamped so that every lane computes)
   int pp[CS_PASS]; double acc[CS_PASS];
 #pragma unroll
@@ -980,22 +1007,25 @@ PL_DEV void iso_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const
 #pragma unroll
   for (int pass = 0; pass < CS_PASS; pass++) {
 #pragma unroll
-    for (int k = 0; k < NR; k++) v[pass][k] = Y[O_CS + pp[pass] * NR + k];
+    for (int k = 0; k < NR; k++) v[pass][k] = Y[O_CS + cs_off(pp[pass]) + k];     // (k beyond the particle's own rows: a neighbour's entries, times the operator's zero padding)
     jv[pass] = Y[O_J + pp[pass]];
-    ypv[pass] = YP[O_CS + pp[pass] * NR + r];
+    ypv[pass] = YP[O_CS + cs_off(pp[pass]) + r];
   }
   const double kap_p = c.kap_p, kap_n = c.kap_n, bj_p = c.bj_p, bj_n = c.bj_n;
 #pragma unroll
   for (int k = 0; k < NR; k++) {
 #pragma unroll
-    for (int pass = 0; pass < CS_PASS; pass++) acc[pass] += Mrow[k] * v[pass][k];
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      if constexpr (NR_EQ) acc[pass] += Mrow[k] * v[pass][k];
+      else acc[pass] += (pp[pass] < NP ? Mrow[k] : MrowN[k]) * v[pass][k];
+    }
   }
 #pragma unroll
   for (int pass = 0; pass < CS_PASS; pass++) {
     const int p = pass * CS_G + g;
     double rhs = (p < NP ? kap_p : kap_n) * acc[pass];
-    if (r == NR - 1) rhs += (p < NP ? bj_p : bj_n) * jv[pass];
-    if (lane < CS_LANES && p < NJ) Fo[O_CS + p * NR + r] = rhs - ypv[pass];
+    if (r == nr_of(p) - 1) rhs += (p < NP ? bj_p : bj_n) * jv[pass];
+    if (lane < CS_LANES && p < NJ && r < nr_of(p)) Fo[O_CS + cs_off(p) + r] = rhs - ypv[pass];
   }
 }
 
@@ -1196,7 +1226,8 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
   if (!alg_only && (!M::W2 || wave_id() == 1)) {          // (two waves per cell: the resolvents are wave 1's, next to wave 0's Jacobian node pass)
     const int r = lane % NR;
     // the 2 N_r reciprocals 1/(kappa lam_m - cj) are formed by 2 N_r lanes in parallel and passed through S.w9 (free outside the solves)
-    if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * S.Mr[S.OFF_LAMR + r] - cj);
+    if constexpr (NR_EQ) { if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * S.Mr[S.OFF_LAMR + r] - cj); }
+    else { if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * S.Mr[(lane < NR ? 0 : S.MR_BLK) + S.OFF_LAMR + r] - cj); }      // (padded modes: lam = 0, V = W = 0)
     PL_SYNC();
     // entry (row, k) of electrode el = sum_m V[row][m] w_el[m] W[m][k], m ascending; lanes 0..31 build the cathode's resolvent, 32..63 the anode's, RS_KG lanes per row with
     // RS_KW columns each (N_r = 10: 3 lanes x 4 columns)
@@ -1206,12 +1237,18 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     double acc[RS_KW];
     for (int kk = 0; kk < RS_KW; kk++) acc[kk] = 0.0;
     _Pragma("unroll 2") for (int m = 0; m < NR; m++) {            // (fully unrolled, the 60 operands of the sums are all live at once: 132 B/lane of scratch in the integrate kernel)
-      const double f = S.Mr[S.OFF_VR + row * NR + m] * S.w9[el * NR + m];
-      for (int kk = 0; kk < RS_KW; kk++) acc[kk] += f * S.Mr[S.OFF_WR + m * NR + (k0 + kk < NR ? k0 + kk : NR - 1)];
+      if constexpr (NR_EQ) {
+        const double f = S.Mr[S.OFF_VR + row * NR + m] * S.w9[el * NR + m];
+        for (int kk = 0; kk < RS_KW; kk++) acc[kk] += f * S.Mr[S.OFF_WR + m * NR + (k0 + kk < NR ? k0 + kk : NR - 1)];
+      } else {
+        const double f = S.Mr[el * S.MR_BLK + S.OFF_VR + row * NR + m] * S.w9[el * NR + m];
+        for (int kk = 0; kk < RS_KW; kk++) acc[kk] += f * S.Mr[el * S.MR_BLK + S.OFF_WR + m * NR + (k0 + kk < NR ? k0 + kk : NR - 1)];
+      }
     }
     if (act) for (int kk = 0; kk < RS_KW; kk++) if (k0 + kk < NR) {
       S.Ainv[el][row * NR + k0 + kk] = PL_F32(acc[kk]);
-      if (row == NR - 1 && k0 + kk == NR - 1) S.sig[el] = acc[kk];
+      if constexpr (NR_EQ) { if (row == NR - 1 && k0 + kk == NR - 1) S.sig[el] = acc[kk]; }
+      else { const int nl = (el ? NRN : NRP) - 1; if (row == nl && k0 + kk == nl) S.sig[el] = acc[kk]; }
     }
   }
   PL_XSYNC();
@@ -1358,7 +1395,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
 #pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) {
 #pragma unroll
-      for (int k = 0; k < NR; k++) bv[pass][k] = b[O_CS + pp[pass] * NR + k];
+      for (int k = 0; k < NR; k++) bv[pass][k] = b[O_CS + cs_off(pp[pass]) + k];
     }
 #pragma unroll
     for (int k = 0; k < NR; k++) {
@@ -1377,7 +1414,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
 #pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) {
       const int p = pass * CS_G + gg;
-      if (lane < CS_LANES && p < NJ && r == NR - 1) S.w9[p] = w[pass];
+      if (lane < CS_LANES && p < NJ && r == nr_of(p) - 1) S.w9[p] = w[pass];
       R.wreg[pass] = w[pass];
     }
   }
@@ -1509,7 +1546,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   if (!alg_only && (!M::W2 || wave_id() == 1)) {
     // unconditional loads with clamped indices first (one LDS latency), guarded stores last: a load inside `if (lane < ..)` is one exec-masked round trip per pass
     const int gg = lane < CS_LANES ? g : CS_G - 1;
-    const double aP = S.Ainv[0][r * NR + NR - 1] * c.bj_p, aN = S.Ainv[1][r * NR + NR - 1] * c.bj_n;
+    const double aP = S.Ainv[0][r * NR + NRP - 1] * c.bj_p, aN = S.Ainv[1][r * NR + NRN - 1] * c.bj_n;
     double dj[CS_PASS];
 #pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) { const int p = pass * CS_G + gg; dj[pass] = b[O_J + (p < NJ ? p : NJ - 1)]; }
@@ -1517,7 +1554,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
     for (int pass = 0; pass < CS_PASS; pass++) {
       const int p = pass * CS_G + gg;
       const double v = R.wreg[pass] - (p < NP ? aP : aN) * dj[pass];
-      if (lane < CS_LANES && p < NJ) b[O_CS + p * NR + r] = v;
+      if (lane < CS_LANES && p < NJ && r < nr_of(p)) b[O_CS + cs_off(p) + r] = v;
     }
   }
   PL_SYNC();
@@ -1541,7 +1578,8 @@ PL_DEV double iso_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ tb, 
     case JT_CE_D: return S.ceD[a] - cj;
     case JT_CE_U: return S.ceU[a];
     case JT_CE_J: return S.ceJ[a];
-    case JT_CS_CS: return (a < NP ? c.kap_p : c.kap_n) * tb->Mp()[bb * NR + cc] - (bb == cc ? cj : 0.0);
+    case JT_CS_CS: if constexpr (NR_EQ) return (a < NP ? c.kap_p : c.kap_n) * tb->Mp()[bb * NR + cc] - (bb == cc ? cj : 0.0);
+                   else return (a < NP ? c.kap_p : c.kap_n) * tb->Mp(a < NP ? 0 : 1)[bb * NR + cc] - (bb == cc ? cj : 0.0);
     case JT_CS_J: if constexpr (M::SD != 0) return c.csr[a < NP ? 0 : 1]; else return a < NP ? c.bj_p : c.bj_n;
     case JT_CSA_D: return -cj;
     case JT_Q_Q: return -(a < NP ? c.kap_p : c.kap_n) - cj;

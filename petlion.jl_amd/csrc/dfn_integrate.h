@@ -818,7 +818,7 @@ PL_DEV void check_stop(const CellLDS<M>& S, const plh_run& run, const plh_opts& 
     }
   }
   if (b.c_s_n_max == b.c_s_n_max) {                                                     // check_stop_c_s_surf, checks.jl:141-161
-    double cm = -1e300; for (int i = 0; i < NN; i++) { const double v = M::SD == 0 ? Y[O_CS + NP * NR + (i + 1) * NR - 1] : Y[O_CS + NP + i]; cm = v > cm ? v : cm; }     // (c_s_n_maximum, checks.jl:125-139)
+    double cm = -1e300; for (int i = 0; i < NN; i++) { const double v = M::SD == 0 ? Y[O_CS + cs_surf(NP + i)] : Y[O_CS + NP + i]; cm = v > cm ? v : cm; }     // (c_s_n_maximum, checks.jl:125-139)
     const double lim = b.c_s_n_max * S.cc.cmaxn;
     if (Ic > 0 && cm - lim > eps) { const double f = (pv.c_s_n - lim) / (pv.c_s_n - cm); if (f < pv.frac) { pv.frac = f; flag = 6; } }
     pv.c_s_n = cm;
@@ -900,9 +900,9 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     if constexpr ((F & GF_GENROW) != 0) {
       if (dstate) {      // which state: the extreme surface / electrolyte concentration of the state the run starts from (input_methods.jl:195-247; argmax / argmin: the first extreme)
         const int kind = run.dstate;
-        constexpr int CSTR = M::SD == 0 ? NR : 1, CSURF = M::SD == 0 ? NR - 1 : 0;
-        const int first = kind <= PLH_DSTATE_CS_P_MIN ? O_CS + CSURF : (kind <= PLH_DSTATE_CS_N_MIN ? O_CS + NP * CSTR + CSURF : O_CE);
-        const int count = kind <= PLH_DSTATE_CS_P_MIN ? NP : (kind <= PLH_DSTATE_CS_N_MIN ? NN : NE), stride = kind <= PLH_DSTATE_CS_N_MIN ? CSTR : 1;
+        const int first = kind <= PLH_DSTATE_CS_P_MIN ? O_CS + (M::SD == 0 ? cs_surf(0) : 0) : (kind <= PLH_DSTATE_CS_N_MIN ? O_CS + (M::SD == 0 ? cs_surf(NP) : NP) : O_CE);
+        const int count = kind <= PLH_DSTATE_CS_P_MIN ? NP : (kind <= PLH_DSTATE_CS_N_MIN ? NN : NE);
+        const int stride = M::SD != 0 ? 1 : (kind <= PLH_DSTATE_CS_P_MIN ? NRP : (kind <= PLH_DSTATE_CS_N_MIN ? NRN : 1));
         const bool want_max = (kind & 1) != 0;
         int best = first; double bv = S.yy[first];
         for (int q = 1; q < count; q++) { const double v = S.yy[first + q * stride]; if (want_max ? v > bv : v < bv) { bv = v; best = first + q * stride; } }

@@ -260,7 +260,7 @@ PL_DEV void sens_finish(CellLDS<M>& S, SensCell<M>& X, bool interp, double fr, b
   double gn = 0.0, gp = 0.0, bnd = 0.0; int ix = 0;
   if (shift && !unknown) {
     const double* Y = S.phi[0];
-    if (flag == 6) { double cm = -1e300; for (int i = 0; i < NN; i++) { const int q = M::SD == 0 ? O_CS + NP * NR + (i + 1) * NR - 1 : O_CS + NP + i; if (Y[q] > cm) { cm = Y[q]; ix = q; } } }
+    if (flag == 6) { double cm = -1e300; for (int i = 0; i < NN; i++) { const int q = M::SD == 0 ? O_CS + cs_surf(NP + i) : O_CS + NP + i; if (Y[q] > cm) { cm = Y[q]; ix = q; } } }
     if (flag == 9) { double cm = 1e300; for (int i = 0; i < NE; i++) { if (Y[O_CE + i] < cm) { cm = Y[O_CE + i]; ix = O_CE + i; } } }
     bnd = flag == 1 ? bd.V_min : flag == 2 ? bd.V_max : flag == 5 ? bd.T_max : flag == 6 ? bd.c_s_n_max * S.cc.cmaxn : flag == 7 ? bd.I_max : flag == 8 ? bd.I_min
         : flag == 9 ? bd.c_e_min : bd.eta_plating_min;

@@ -156,7 +156,7 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
   const int jx = sc == 0 ? i : i - NS;
   const int it = NA + i;
   const double ce = Y[O_CE + i], pe = Y[O_PE + i], T = Y[O_T + it], Tl = Y[O_T + it - 1], Tr = Y[O_T + it + 1];
-  const double jv_l = Y[O_J + jx], ps_l = Y[O_PS + jx], cs_l = Y[O_CS + jx * NR + NR - 1], yI = Y[O_I];
+  const double jv_l = Y[O_J + jx], ps_l = Y[O_PS + jx], cs_l = Y[O_CS + cs_surf(jx)], yI = Y[O_I];
   const double ypce = WANT_RES ? YP[O_CE + i] : 0.0, ypT = WANT_RES ? YP[O_T + it] : 0.0;
   const double h0 = c.h[0], h1 = c.h[1], h2 = c.h[2];
   const double h = sc == 0 ? h0 : (sc == 1 ? h1 : h2);
@@ -362,17 +362,25 @@ PL_DEV void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const 
   double Mrow[NR], Wrow[NR];
   // (the radial operator from its LDS copy, as in the isothermal models: r03 fetched it from the table in global memory in every residual and every solve)
   for (int k = 0; k < NR; k++) { Mrow[k] = S.Mr[r * NR + k]; if (WANT_JAC) Wrow[k] = S.Mr[S.OFF_WR + r * NR + k]; }
+  // (N_r_p != N_r_n: the anode's rows of M and W, zero-padded to the common stride like the cathode's -- a sum over k < NR is the sum over the particle's own rows, a lane
+  //  whose row does not exist in its particle computes 0 for W c and stores no residual)
+  [[maybe_unused]] double MrowN[NR_EQ ? 1 : NR], WrowN[NR_EQ ? 1 : NR];
+  if constexpr (!NR_EQ) for (int k = 0; k < NR; k++) { MrowN[k] = S.Mr[S.mr_el(1) + r * NR + k]; if (WANT_JAC) WrowN[k] = S.Mr[S.mr_el(1) + S.OFF_WR + r * NR + k]; }
 #pragma unroll
   for (int pass = 0; pass < CS_PASS; pass++) {
     const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
     double acc = 0.0, wc = 0.0;
 #pragma unroll
-    for (int k = 0; k < NR; k++) { const double v = Y[O_CS + p * NR + k]; acc += Mrow[k] * v; if (WANT_JAC) wc += Wrow[k] * v; }
+    for (int k = 0; k < NR; k++) {
+      const double v = Y[O_CS + cs_off(p) + k];
+      if constexpr (NR_EQ) { acc += Mrow[k] * v; if (WANT_JAC) wc += Wrow[k] * v; }
+      else { acc += (p < NP ? Mrow[k] : MrowN[k]) * v; if (WANT_JAC) wc += (p < NP ? Wrow[k] : WrowN[k]) * v; }
+    }
     // (every load unconditional -- p is clamped --, only the stores guarded: a load under `if` is one exec-masked LDS round trip of its own)
-    const double jv = Y[O_J + p], ypv = YP[O_CS + p * NR + r];
+    const double jv = Y[O_J + p], ypv = YP[O_CS + cs_off(p) + r];
     double rhs = TP.kapP[p] * acc;
-    if (r == NR - 1) rhs += (p < NP ? c.bj_p : c.bj_n) * jv;
-    if (lane < CS_LANES && p0 < NJ) { Fo[O_CS + p * NR + r] = rhs - ypv; if (WANT_JAC) TP.AinvQ[p][r] = wc; }
+    if (r == nr_of(p) - 1) rhs += (p < NP ? c.bj_p : c.bj_n) * jv;
+    if (lane < CS_LANES && p0 < NJ) { if (r < nr_of(p)) Fo[O_CS + cs_off(p) + r] = rhs - ypv; if (WANT_JAC) TP.AinvQ[p][r] = wc; }
   }
 }
 
@@ -575,23 +583,35 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
   //    lanes of the particle through the c_s section of S.yy, which is dead between a residual evaluation and the next form_iterate (thermal_solve uses it the same way).
   if (!alg_only) {
     if (lane < NJ) TP.kapF[lane] = TP.kapP[lane];
-    const double lam_r = PL_RADIAL_LAM[r];
+    // (N_r_p != N_r_n: eigenvalues and W[:, last] of the particle's own electrode from the padded tables -- a padded mode has lam = 0, its reciprocal -1/cj meets V = 0 --; the
+    //  reciprocals are shared through the particle's own c_s entries of S.yy, S.yy[O_CS + cs_off(p) + mode])
+    const double lam_r = NR_EQ ? PL_RADIAL_LAM[r] : tb->LAMp(0)[r];
+    [[maybe_unused]] const double lam_rN = NR_EQ ? 0.0 : tb->LAMp(1)[r];
     const int cs0 = PL_OPAQUE_IDX(g * NR + r);
     double wc[CS_PASS];
 #pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) {
       const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
-      R.rcp[pass] = 1.0 / (TP.kapP[p] * lam_r - cj);
+      R.rcp[pass] = 1.0 / (TP.kapP[p] * ((NR_EQ || p < NP) ? lam_r : lam_rN) - cj);
       wc[pass] = (&TP.AinvQ[0][0])[(p0 < NJ ? pass * CS_G * NR : (NJ - 1 - g) * NR) + cs0];      // AinvQ still holds W c  (clamped like p)
     }
 #pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) {
       const int p0 = pass * CS_G + g;
-      if (lane < CS_LANES && p0 < NJ) { S.yy[O_CS + pass * CS_G * NR + cs0] = R.rcp[pass]; (&TP.AinvQ[0][0])[pass * CS_G * NR + cs0] = wc[pass] * R.rcp[pass]; }
+      if (lane < CS_LANES && p0 < NJ) {
+        if constexpr (NR_EQ) S.yy[O_CS + pass * CS_G * NR + cs0] = R.rcp[pass];
+        else { if (r < nr_of(p0)) S.yy[O_CS + cs_off(p0) + r] = R.rcp[pass]; }
+        (&TP.AinvQ[0][0])[pass * CS_G * NR + cs0] = wc[pass] * R.rcp[pass];
+      }
     }
     PL_SYNC();
     double VW[NR], VL[NR];                                  // V[r][m] W[m][last] and V[r][m] lam_m: the constant factors of the two sums
-    for (int m = 0; m < NR; m++) { const double v = S.Mr[S.OFF_VR + r * NR + m]; VW[m] = v * PL_RADIAL_W[m * NR + NR - 1]; VL[m] = v * PL_RADIAL_LAM[m]; }
+    [[maybe_unused]] double VWN[NR_EQ ? 1 : NR], VLN[NR_EQ ? 1 : NR];
+    if constexpr (NR_EQ) { for (int m = 0; m < NR; m++) { const double v = S.Mr[S.OFF_VR + r * NR + m]; VW[m] = v * PL_RADIAL_W[m * NR + NR - 1]; VL[m] = v * PL_RADIAL_LAM[m]; } }
+    else for (int m = 0; m < NR; m++) {
+      const double v = S.Mr[S.OFF_VR + r * NR + m], vn = S.Mr[S.mr_el(1) + S.OFF_VR + r * NR + m];
+      VW[m] = v * tb->Wp(0)[m * NR + NRP - 1]; VL[m] = v * tb->LAMp(0)[m]; VWN[m] = vn * tb->Wp(1)[m * NR + NRN - 1]; VLN[m] = vn * tb->LAMp(1)[m];
+    }
     double ae[CS_PASS], aq[CS_PASS];
     const int pg0 = PL_OPAQUE_IDX(g * NR);
 #pragma unroll
@@ -599,8 +619,13 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       const int p0 = pass * CS_G + g;
       const int base = p0 < NJ ? pass * CS_G * NR + pg0 : (NJ - 1) * NR;
       ae[pass] = 0.0; aq[pass] = 0.0;
+      if constexpr (NR_EQ) {
 #pragma unroll
-      for (int m = 0; m < NR; m++) { ae[pass] += VW[m] * S.yy[O_CS + base + m]; aq[pass] += VL[m] * (&TP.AinvQ[0][0])[base + m]; }
+        for (int m = 0; m < NR; m++) { ae[pass] += VW[m] * S.yy[O_CS + base + m]; aq[pass] += VL[m] * (&TP.AinvQ[0][0])[base + m]; }
+      } else {
+        const int pc = p0 < NJ ? p0 : NJ - 1;
+        for (int m = 0; m < NR; m++) { ae[pass] += (pc < NP ? VW[m] : VWN[m]) * S.yy[O_CS + cs_off(pc) + m]; aq[pass] += (pc < NP ? VL[m] : VLN[m]) * (&TP.AinvQ[0][0])[base + m]; }
+      }
     }
     PL_SYNC();                                             // every lane has read the shared reciprocals and W c / d before they are overwritten
 #pragma unroll
@@ -642,7 +667,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     if (sc != 1) {
       const int jx = sc == 0 ? i : i - NS;
       const double bj = sc == 0 ? c.bj_p : c.bj_n;
-      const double sig = alg_only ? 0.0 : TP.AinvE[jx][NR - 1], tau = alg_only ? 0.0 : TP.AinvQ[jx][NR - 1];
+      const double sig = alg_only ? 0.0 : TP.AinvE[jx][nr_of(jx) - 1], tau = alg_only ? 0.0 : TP.AinvQ[jx][nr_of(jx) - 1];
       const double d = -1.0 - S.gcs[jx] * sig * bj;
       const double rd = 1.0 / d;
       S.dj[jx] = rd;
@@ -677,7 +702,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     else {
       D[0] = S.ceD[i] - cj; D[4] = S.pcD[i]; D[7] = TP.ptD[i];
       D[12] = TP.TcD[i]; D[13] = TP.TeD[i]; D[14] = TP.TsD[i]; D[15] = thermal_aD(TP, NA + i) - cj + TP.TtD[i];
-      if (elec) D[15] -= TP.Tcs[jx] * TP.AinvQ[jx][NR - 1];
+      if (elec) D[15] -= TP.Tcs[jx] * TP.AinvQ[jx][nr_of(jx) - 1];
       if (i == 0) D[15] -= TP.aL[NA] * TP.zc[0][NA - 1];
       if (i == NE - 1) D[15] -= TP.aU[NA + NE - 1] * TP.zc[1][0];
     }
@@ -863,19 +888,29 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
     const bool over = LASTP + g >= NJ;
     constexpr bool A16 = NR % 2 == 0 && O_CS % 2 == 0;      // particle rows start on 16-byte boundaries (b is one of the 16-byte aligned vectors of CellLDS)
     const lds_cptr bg = PL_LDS_BASE_A(A16, (const double*)b + O_CS + g * NR), bl = PL_LDS_BASE_A(A16, (const double*)b + O_CS + (over ? NJ - 1 : LASTP + g) * NR);
+    // (N_r_p != N_r_n: per-electrode rows of W and V, zero-padded; the particles sit at cs_off(p) in b and in S.yy, plain indexing instead of the affine address tricks)
+    [[maybe_unused]] double WrowN[NR_EQ ? 1 : NR], VrowN[NR_EQ ? 1 : NR];
+    if constexpr (!NR_EQ) for (int k = 0; k < NR; k++) { WrowN[k] = S.Mr[S.mr_el(1) + S.OFF_WR + r * NR + k]; VrowN[k] = S.Mr[S.mr_el(1) + S.OFF_VR + r * NR + k]; }
     double yv[CS_PASS];
 #pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) {
-      const lds_cptr bb = pass == CS_PASS - 1 ? bl : bg + pass * CS_G * NR;
       double y = 0.0;
+      if constexpr (NR_EQ) {
+        const lds_cptr bb = pass == CS_PASS - 1 ? bl : bg + pass * CS_G * NR;
 #pragma unroll
-      for (int k = 0; k < NR; k++) y += Wrow[k] * bb[k];
+        for (int k = 0; k < NR; k++) y += Wrow[k] * bb[k];
+      } else {
+        const int p0 = pass * CS_G + g, pc = p0 < NJ ? p0 : NJ - 1;
+        for (int k = 0; k < NR; k++) y += (pc < NP ? Wrow[k] : WrowN[k]) * b[O_CS + cs_off(pc) + k];
+      }
       yv[pass] = y * R.rcp[pass];
     }
     const lds_ptr yg = PL_LDS_BASE(S.yy + O_CS + g * NR + r);
 #pragma unroll
-    for (int pass = 0; pass < CS_PASS; pass++)
-      if (lane < CS_LANES && pass * CS_G + g < NJ) yg[pass * CS_G * NR] = yv[pass];   // S.yy is dead between a residual and the next form_iterate
+    for (int pass = 0; pass < CS_PASS; pass++) {
+      if constexpr (NR_EQ) { if (lane < CS_LANES && pass * CS_G + g < NJ) yg[pass * CS_G * NR] = yv[pass]; }   // S.yy is dead between a residual and the next form_iterate
+      else { const int p0 = pass * CS_G + g; if (lane < CS_LANES && p0 < NJ && r < nr_of(p0)) S.yy[O_CS + cs_off(p0) + r] = yv[pass]; }
+    }
     {
       // collector chains: lane 32 + k owns collector node k (aluminium 0 .. N_a - 1, then copper), the mapping of the residual rows and of phase e.  Both Thomas recurrences
       // run as systolic DPP chains (every lane re-evaluates its stage until its predecessor is final, as in the block sweeps): ONE LDS load per operand and lane instead of
@@ -901,11 +936,16 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
 #pragma unroll
     for (int pass = 0; pass < CS_PASS; pass++) {
       const int p0 = pass * CS_G + g;
-      const lds_cptr yb = pass == CS_PASS - 1 ? yl : yr + pass * CS_G * NR;
       double w = 0.0;
+      if constexpr (NR_EQ) {
+        const lds_cptr yb = pass == CS_PASS - 1 ? yl : yr + pass * CS_G * NR;
 #pragma unroll
-      for (int m = 0; m < NR; m++) w += Vrow[m] * yb[m];
-      if (lane < CS_LANES && p0 < NJ && r == NR - 1) S.w9[p0] = w;
+        for (int m = 0; m < NR; m++) w += Vrow[m] * yb[m];
+      } else {
+        const int pc = p0 < NJ ? p0 : NJ - 1;
+        for (int m = 0; m < NR; m++) w += (pc < NP ? Vrow[m] : VrowN[m]) * S.yy[O_CS + cs_off(pc) + m];
+      }
+      if (lane < CS_LANES && p0 < NJ && r == nr_of(p0) - 1) S.w9[p0] = w;
       R.wreg[pass] = w;
     }
   }
@@ -1009,7 +1049,7 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
       const int p = pass * CS_G + g;
       const double bj = p < NP ? c.bj_p : c.bj_n;
       const double v = R.wreg[pass] - ae[pass] * bj * dj[pass] - aq[pass] * dT[pass];
-      if (lane < CS_LANES && p < NJ) b[O_CS + p * NR + r] = v;
+      if (lane < CS_LANES && p < NJ && r < nr_of(p)) b[O_CS + cs_off(p) + r] = v;
     }
   }
   PL_SYNC();
@@ -1030,14 +1070,14 @@ PL_DEV double thermal_jac_entry(const CellLDS<M>& S, const Tables* __restrict__ 
   const int t = w >> 24, a = (w >> 16) & 255, bb = (w >> 8) & 255, cc = w & 255;
   const auto& TP = S.th;
   switch (t) {
-    case JT_CS_CS: return (FROZEN ? TP.kapF[a] : TP.kapP[a]) * tb->Mp()[bb * NR + cc] - (bb == cc ? cj : 0.0);   // (kapP follows every residual pass, kapF is the factored one)
+    case JT_CS_CS: return (FROZEN ? TP.kapF[a] : TP.kapP[a]) * tb->Mp(a < NP ? 0 : 1)[bb * NR + cc] - (bb == cc ? cj : 0.0);   // (kapP follows every residual pass, kapF is the factored one)
     case TT_CS_T: {                                      // d(kappa_p(T) (M c)_r)/dT
       double acc = 0.0;
       if (FROZEN) {                                      // q = kappa' M c of the last factorisation, rebuilt from A^-1 q: q = (kappa M - cj I) (A^-1 q)
-        for (int k = 0; k < NR; k++) acc += (TP.kapF[a] * tb->Mp()[bb * NR + k] - (bb == k ? TP.cjf : 0.0)) * TP.AinvQ[a][k];
+        for (int k = 0; k < nr_of(a); k++) acc += (TP.kapF[a] * tb->Mp(a < NP ? 0 : 1)[bb * NR + k] - (bb == k ? TP.cjf : 0.0)) * TP.AinvQ[a][k];
         return acc;
       }
-      for (int k = 0; k < NR; k++) acc += tb->Mp()[bb * NR + k] * S.yy[O_CS + a * NR + k];      // evaluated at the state in S.yy (plh_jacobian)
+      for (int k = 0; k < nr_of(a); k++) acc += tb->Mp(a < NP ? 0 : 1)[bb * NR + k] * S.yy[O_CS + cs_off(a) + k];      // evaluated at the state in S.yy (plh_jacobian)
       return TP.dkapP[a] * acc;
     }
     case TT_J_T: return TP.gT[a];

@@ -124,7 +124,7 @@ static const VariantOps* variant_ops(int id) {
   return nullptr;
 }
 // libraries of variants compiled for other discretisations (plh_register_grid_library): kept loaded for the life of the process
-struct GridLib { std::string path; void* handle; int grid[6]; const VariantOps* (*ops)(int); };
+struct GridLib { std::string path; void* handle; int grid[7]; const VariantOps* (*ops)(int); };
 static std::vector<GridLib> g_grid_libs;
 static std::mutex g_grid_mutex;
 static bool desc_matches(const plh_model_desc* d, const VariantOps* o) {
@@ -134,7 +134,7 @@ static bool desc_matches(const plh_model_desc* d, const VariantOps* o) {
 // N_a / N_z only exist with temperature = true, N_r only for Fickian diffusion (params.jl:119-136); an absent dimension matches anything
 static bool grid_matches(const plh_model_desc* d, const int* g) {
   if (d->N_p != g[0] || d->N_s != g[1] || d->N_n != g[2]) return false;
-  if (d->solid_diffusion == PLH_SD_FICKIAN && (d->N_r_p != g[3] || d->N_r_n != g[3])) return false;
+  if (d->solid_diffusion == PLH_SD_FICKIAN && (d->N_r_p != g[3] || d->N_r_n != g[6])) return false;
   if (d->temperature && (d->N_a != g[4] || d->N_z != g[5])) return false;
   return true;
 }
@@ -351,7 +351,7 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   }
   if (!ops && variant_exists)
     return fail(PLH_E_UNSUPPORTED, "discretisation: the library's built-in kernels are compiled for N_p = N_s = N_n = N_r_p = N_r_n = N_a = N_z = 10; another grid (2 <= N_p, N_s, N_n, "
-                                   "N_p + N_s + N_n <= 48, 10 <= N_r_p = N_r_n <= 16) is one more build of csrc/variant_tu.hip, registered with plh_register_grid_library() before "
+                                   "N_p + N_s + N_n <= 48, 10 <= N_r_p, N_r_n <= 16) is one more build of csrc/variant_tu.hip, registered with plh_register_grid_library() before "
                                    "plh_model_create (petlion.jl_amd/grids.py does both; INTEGRATION.md)");
   if (!ops) return fail(PLH_E_UNSUPPORTED, "this chemistry / temperature / aging / precision / model-option combination is not instantiated on the device (built in fp64: LCO and NMC "
                                            "isothermal with or without SEI aging, LGM50 isothermal and with temperature, LCO with temperature; LCO isothermal with ONE of: quadratic or polynomial solid diffusion, the nonlinear "
@@ -370,11 +370,18 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   m->desc = *d; m->desc.device = dev; m->device = dev; m->ops = ops;
   Tables& tb = m->h_tb;
   memset(&tb, 0, sizeof(tb));
-  { const int nr = ops->grid[3];                         // radial operator of the variant's N_r (packed N_r x N_r)
-    double* r = tb.RAD;                                  // (the variant's kernels read the block with their own N_r: Tables::Mp / LAMp / Vp / Wp)
-    memcpy(r, ops->rad_M, sizeof(double) * nr * nr); memcpy(r + nr * nr, ops->rad_LAM, sizeof(double) * nr);
-    memcpy(r + nr * nr + nr, ops->rad_V, sizeof(double) * nr * nr); memcpy(r + 2 * nr * nr + nr, ops->rad_W, sizeof(double) * nr * nr); }
-  tb.BJ = ops->rad_BJ; tb.chem = d->chemistry;
+  // radial operators of the variant's N_r_p / N_r_n: one block per electrode at the common stride S = max(N_r_p, N_r_n) -- M, LAM, V, W back to back, the smaller operator
+  // zero-padded (rows, columns and modes that do not exist contribute nothing to any sum over S entries); the variant's kernels read them through Tables::Mp / LAMp / Vp / Wp
+  { const int S = ops->grid[3] > ops->grid[6] ? ops->grid[3] : ops->grid[6];
+    for (int el = 0; el < 2; el++) {
+      const int nr = el == 0 ? ops->grid[3] : ops->grid[6];
+      double* r = el == 0 ? tb.RAD : tb.RAD_N;
+      for (int i = 0; i < nr; i++) {
+        r[S * S + i] = ops->rad_LAM[el][i];
+        for (int j = 0; j < nr; j++) { r[i * S + j] = ops->rad_M[el][i * nr + j]; r[S * S + S + i * S + j] = ops->rad_V[el][i * nr + j]; r[2 * S * S + S + i * S + j] = ops->rad_W[el][i * nr + j]; }
+      }
+    } }
+  tb.BJ = ops->rad_BJ[0]; tb.BJ_N = ops->rad_BJ[1]; tb.chem = d->chemistry;
   const VariantInfo vi = variant_keys(ops->chem, ops->sei, ops->thermal, ops->rxn);
   m->P = vi.nkeys; m->key_names = vi.keys; m->key_defaults = vi.defaults;
   tb.P = m->P;
@@ -446,7 +453,7 @@ int plh_model_attach_closure_library(plh_model_t m, const char* path) {
   { int v = 0, so = 0, sa = 0, st = 0; abi(&v, &so, &sa, &st);
     if (v != PLH_HOST_ABI || so != (int)sizeof(VariantOps) || sa != (int)sizeof(IntegrateArgs) || st != (int)sizeof(Tables)) {
       dlclose(h); return fail(PLH_E_ARG, "closure library was built against another version of the host interface (stale cache: rebuild it)"); } }
-  int g[6]; dims(g);
+  int g[7]; dims(g);
   const VariantOps* o = ops(m->ops->id);
   if (!o || memcmp(g, m->ops->grid, sizeof(g)) != 0 || !desc_matches(&m->desc, o)) { dlclose(h); return fail(PLH_E_ARG, "closure library: built for another model variant or discretisation"); }
   m->cl_ops = o; m->cl_digest = dig();

@@ -182,7 +182,7 @@ unsigned classify(const Tables& tb, int mode, int r, int c) {
     constexpr int O_T = M::O_T;
     const bool cT = c >= O_T && c < O_T + NT;
     const int ct = c - O_T;                         // T node of the column
-    if (r >= O_CS && r < N_CECS && cT) { const int p = (r - O_CS) / NR; return ct == NA + node_of_j(p) ? W(TT_CS_T, p, (r - O_CS) % NR, 0) : 0; }
+    if (r >= O_CS && r < N_CECS && cT) { const int p = cs_particle(r - O_CS); return ct == NA + node_of_j(p) ? W(TT_CS_T, p, r - O_CS - cs_off(p), 0) : 0; }
     if (r >= O_J && r < O_PE && cT) { const int jx = r - O_J; return ct == NA + node_of_j(jx) ? W(TT_J_T, jx, 0, 0) : 0; }
     if (r >= O_PE && r < O_PS && cT) {
       const int i = r - O_PE, k = ct - NA;
@@ -226,7 +226,7 @@ unsigned classify(const Tables& tb, int mode, int r, int c) {
         return 0;
       }
       if (c == O_J + jx) return W(TT_T_J, jx, 0, 0);
-      if (c == O_CS + jx * NR + NR - 1) return W(TT_T_CS, jx, 0, 0);
+      if (c == O_CS + cs_surf(jx)) return W(TT_T_CS, jx, 0, 0);
       return 0;
     }
     if (cT) return 0;
@@ -243,9 +243,9 @@ unsigned classify(const Tables& tb, int mode, int r, int c) {
     if (M::SD == 2 && r >= O_Q && r < O_Q + NJ) { const int p = r - O_Q; if (c == r) return W(JT_Q_Q, p, 0, 0); if (c == O_J + p) return W(JT_Q_J, p, 0, 0); return 0; }
   }
   if (r < N_CECS) {                                 // c_s row (p, rr)
-    const int p = (r - O_CS) / NR, rr = (r - O_CS) % NR;
-    if (c >= O_CS && c < N_CECS && (c - O_CS) / NR == p) { const int cc = (c - O_CS) % NR; return (tb.Mp()[rr * NR + cc] != 0.0 || rr == cc) ? W(JT_CS_CS, p, rr, cc) : 0; }
-    if (rr == NR - 1 && c == O_J + p) return W(JT_CS_J, p, 0, 0);
+    const int p = cs_particle(r - O_CS), rr = r - O_CS - cs_off(p);
+    if (c >= O_CS && c < N_CECS && cs_particle(c - O_CS) == p) { const int cc = c - O_CS - cs_off(p); return (tb.Mp(p < NP ? 0 : 1)[rr * NR + cc] != 0.0 || rr == cc) ? W(JT_CS_CS, p, rr, cc) : 0; }
+    if (rr == nr_of(p) - 1 && c == O_J + p) return W(JT_CS_J, p, 0, 0);
     return 0;
   }
   if (M::SEI && r < O_J) {                          // film rows (residuals_film!) and the SOH row (residuals_SOH!)
@@ -258,7 +258,7 @@ unsigned classify(const Tables& tb, int mode, int r, int c) {
     const int jx = r - O_J, nd = node_of_j(jx);
     if (M::SEI && jx >= NP && c == O_FILM + jx - NP) return W(JT_J_F, jx - NP, 0, 0);
     if (c == O_CE + nd) return W(JT_J_CE, jx, 0, 0);
-    if (c == (M::SD == 0 ? O_CS + jx * NR + NR - 1 : O_CS + jx)) return W(JT_J_CS, jx, 0, 0);
+    if (c == (M::SD == 0 ? O_CS + cs_surf(jx) : O_CS + jx)) return W(JT_J_CS, jx, 0, 0);
     if (M::SD == 2 && c == O_Q + jx) return W(JT_J_Q, jx, 0, 0);
     if (c == r) return W(JT_J_J, jx, 0, 0);
     if (c == O_PE + nd) return W(JT_J_PE, jx, 0, 0);
@@ -348,8 +348,8 @@ template <class M> struct OpsOf {
     // four cells per CU (160 kB of LDS, one wave per SIMD) is what every built-in kernel is tuned for: one byte over 40 960 drops the CU to three cells (-25 %)
     static_assert(!GRID_DEFAULT || sizeof(CellLDS<M>) <= 40960, "built-in variant: LDS per cell above 40 960 B, only three cells per CU would be resident");
 #endif
-    static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::MIXED ? 1 : 0, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, {NP, NS, NN, NR, NA, NZ},
-                                   PL_RADIAL_M, PL_RADIAL_LAM, PL_RADIAL_V, PL_RADIAL_W, PL_RADIAL_BJ_FACTOR, sizeof(CellLDS<M>), &classify<M>, &sections_of<M>,
+    static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::MIXED ? 1 : 0, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, {NP, NS, NN, NRP, NA, NZ, NRN},
+                                   {PL_RADIAL_M, PL_RADIAL_M_N}, {PL_RADIAL_LAM, PL_RADIAL_LAM_N}, {PL_RADIAL_V, PL_RADIAL_V_N}, {PL_RADIAL_W, PL_RADIAL_W_N}, {PL_RADIAL_BJ_FACTOR, PL_RADIAL_BJ_FACTOR_N}, sizeof(CellLDS<M>), &classify<M>, &sections_of<M>,
                                    &initial_guess, &residual, &jacobian, &linear_solve, &init_consistent, &integrate};
     return &ops;
   }

@@ -39,8 +39,8 @@ struct SectionInfo { const char* name; int start, len; };
 struct VariantOps {
   int id, chem, sei, thermal, mixed, sd, tf, rxn, w2;
   int N, Nd;
-  int grid[6];                                                                       // N_p, N_s, N_n, N_r (= N_r_p = N_r_n), N_a, N_z this table was compiled for
-  const double *rad_M, *rad_LAM, *rad_V, *rad_W; double rad_BJ;                      // radial operator tables of this N_r (radial_tables.h), N_r x N_r packed
+  int grid[7];                                                                       // N_p, N_s, N_n, N_r_p, N_a, N_z, N_r_n this table was compiled for
+  const double *rad_M[2], *rad_LAM[2], *rad_V[2], *rad_W[2]; double rad_BJ[2];       // radial operator tables of N_r_p / N_r_n (radial_tables.h), N_r x N_r packed
   size_t lds_bytes;                                                                  // sizeof(CellLDS<M>): LDS per cell (= per workgroup)
   unsigned (*classify)(const pl::Tables& tb, int mode, int r, int c);              // decode word of the structural Jacobian entry (r, c), 0 if structurally zero
   int (*sections)(SectionInfo* out);
@@ -62,7 +62,7 @@ PL_VARIANT_LIST(PL_DECLARE_OPS)
 // A library of variants compiled for ANOTHER discretisation (variant_tu.hip with -DPL_NP=.. etc. and -DPL_GRID_LIBRARY; petlion.jl_amd/grids.py) exports these two
 // C symbols; plh_register_grid_library() loads it and consults its tables in plh_model_create.
 extern "C" const VariantOps* plh_grid_variant_ops(int id);     // nullptr: variant not built into this grid library
-extern "C" void plh_grid_dims(int* grid6);
+extern "C" void plh_grid_dims(int* grid7);
 // what a grid library was compiled against: bump PLH_HOST_ABI whenever VariantOps / IntegrateArgs / Tables change, so that a stale cached library is refused, not misread
-constexpr int PLH_HOST_ABI = 6;
+constexpr int PLH_HOST_ABI = 7;
 extern "C" void plh_grid_abi(int* abi, int* sizeof_ops, int* sizeof_args, int* sizeof_tables);

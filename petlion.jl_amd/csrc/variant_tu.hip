@@ -26,7 +26,7 @@ extern "C" __attribute__((visibility("default"))) void plh_grid_abi(int* abi, in
 // a closure library (petlion.jl_amd/closure_lib.py): the digest of the protocol whose closures are compiled in (plh_model_attach_closure_library)
 extern "C" __attribute__((visibility("default"))) unsigned long long plh_closure_library_digest() { return pl::PL_CLOSURE_DIGEST; }
 #endif
-extern "C" __attribute__((visibility("default"))) void plh_grid_dims(int* g) { g[0] = pl::NP; g[1] = pl::NS; g[2] = pl::NN; g[3] = pl::NR; g[4] = pl::NA; g[5] = pl::NZ; }
+extern "C" __attribute__((visibility("default"))) void plh_grid_dims(int* g) { g[0] = pl::NP; g[1] = pl::NS; g[2] = pl::NN; g[3] = pl::NRP; g[4] = pl::NA; g[5] = pl::NZ; g[6] = pl::NRN; }
 #else
 
 #define PL_DEFINE_OPS(ID, CHEM, SEI, TH, MIX, SD, TF, RXN, W2) \

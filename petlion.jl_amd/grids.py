@@ -5,7 +5,7 @@ another build of csrc/variant_tu.hip -- the counterpart of the reference generat
 `saved_models/` cache).  `library(grid, variant_id)` compiles (hipcc, gfx950; once, cached under petlion.jl_amd/_grids/) a shared library holding the requested
 model variants for that grid; Model.__init__ registers it with plh_register_grid_library() and then creates the handle as usual.
 
-Limits (static_asserts in csrc/dfn_cell.h / dfn_thermal.h): 2 <= N_p, N_s, N_n; N_p + N_s + N_n <= 48; 10 <= N_r_p = N_r_n <= 16; with temperature = true additionally
+Limits (static_asserts in csrc/dfn_cell.h / dfn_thermal.h): 2 <= N_p, N_s, N_n; N_p + N_s + N_n <= 48; 10 <= N_r_p, N_r_n <= 16 (they may differ); with temperature = true additionally
 5 <= N_p <= N/2, 5 <= N_n < (N + 1)/2 for N = N_p + N_s + N_n (each electrode inside its own half of the twisted sweeps: the T rows of its last / first node reach back to a
 second neighbour), 2 <= N_a, N_z, N_a + N_z <= 30, N_a + N + N_z <= 64.  No CPU fallback: without hipcc the build fails loudly."""
 import json
@@ -39,18 +39,26 @@ def variant_id(chemistry, sei, thermal, mixed, sd, tf, rxn, w2):
     return None
 
 
-def grid_tuple(N_p, N_s, N_n, N_r, N_a=10, N_z=10):
-    return (int(N_p), int(N_s), int(N_n), int(N_r), int(N_a), int(N_z))
+def grid_tuple(N_p, N_s, N_n, N_r, N_a=10, N_z=10, N_r_n=None):
+    """(N_p, N_s, N_n, N_r_p, N_a, N_z) when the two particle grids are equal (the common case: the tag and the cache names of r01-r03), with N_r_n appended when they differ"""
+    g = (int(N_p), int(N_s), int(N_n), int(N_r), int(N_a), int(N_z))
+    return g if N_r_n is None or int(N_r_n) == int(N_r) else g + (int(N_r_n),)
+
+
+def grid7(grid):
+    """(N_p, N_s, N_n, N_r_p, N_a, N_z, N_r_n) of a 6- or 7-entry grid tuple"""
+    g = tuple(int(x) for x in grid)
+    return g if len(g) == 7 else g + (g[3],)
 
 
 def check(grid, thermal=False, sei=False):
-    p, s, n, r, a, z = grid
+    p, s, n, r, a, z, rn = grid7(grid)
     if sei and n < 3:
         raise ValueError("discretisation: aging = :SEI needs N_n >= 3 (the SOH row extrapolates j_s from three nodes, residuals.jl:278-297)")
     if min(p, s, n) < 2 or p + s + n > 48:
         raise ValueError("discretisation: 2 <= N_p, N_s, N_n and N_p + N_s + N_n <= 48 (one lane per node)")
-    if not 10 <= r <= 16:
-        raise ValueError("discretisation: 10 <= N_r_p = N_r_n <= 16 (radial operator tables: tools/gen_radial_tables.py)")
+    if not (10 <= r <= 16 and 10 <= rn <= 16):
+        raise ValueError("discretisation: 10 <= N_r_p, N_r_n <= 16 (radial operator tables: tools/gen_radial_tables.py)")
     if thermal:
         ne, mid = p + s + n, (p + s + n) // 2
         if not (5 <= p <= mid and 5 <= n < ne - mid and a >= 2 and z >= 2 and a + z <= 30 and a + ne + z <= 64):
@@ -59,9 +67,9 @@ def check(grid, thermal=False, sei=False):
 
 
 def defines(grid):
-    p, s, n, r, a, z = grid
-    tag = "g%d_%d_%d_%d_%d_%d" % grid
-    return tag, ["-DPL_NP=%d" % p, "-DPL_NS=%d" % s, "-DPL_NN=%d" % n, "-DPL_NR=%d" % r, "-DPL_NA=%d" % a, "-DPL_NZ=%d" % z, "-Dpl=pl_" + tag]
+    p, s, n, r, a, z, rn = grid7(grid)
+    tag = "g%d_%d_%d_%d_%d_%d" % (p, s, n, r, a, z) + ("_rn%d" % rn if rn != r else "")
+    return tag, ["-DPL_NP=%d" % p, "-DPL_NS=%d" % s, "-DPL_NN=%d" % n, "-DPL_NR=%d" % r, "-DPL_NRN=%d" % rn, "-DPL_NA=%d" % a, "-DPL_NZ=%d" % z, "-Dpl=pl_" + tag]
 
 
 def _sources_mtime():

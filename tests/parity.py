@@ -15,10 +15,10 @@ SECTIONS_QUAD = [("c_e", 0, 30), ("c_s", 30, 50), ("j", 50, 70), ("Phi_e", 70, 1
 SECTIONS_POLY = [("c_e", 0, 30), ("c_s", 30, 50), ("Q", 50, 70), ("j", 70, 90), ("Phi_e", 90, 120), ("Phi_s", 120, 140), ("I", 140, 141)]
 
 
-def grid_sections(Np, Ns, Nn, Nr, sei=False, thermal=None):
+def grid_sections(Np, Ns, Nn, Nr, sei=False, thermal=None, Nrn=None):
     """state sections of a Fickian model on another discretisation (reference state layout, src/external.jl:275-365); thermal = (N_a, N_z) with temperature = true"""
     out, o = [], 0
-    for name, n in (("c_e", Np + Ns + Nn), ("c_s", (Np + Nn) * Nr)) + ((("T", thermal[0] + Np + Ns + Nn + thermal[1]),) if thermal else ()) + ((("film", Nn), ("SOH", 1)) if sei else ()) + (("j", Np + Nn), ("Phi_e", Np + Ns + Nn), ("Phi_s", Np + Nn)) + \
+    for name, n in (("c_e", Np + Ns + Nn), ("c_s", Np * Nr + Nn * (Nrn or Nr))) + ((("T", thermal[0] + Np + Ns + Nn + thermal[1]),) if thermal else ()) + ((("film", Nn), ("SOH", 1)) if sei else ()) + (("j", Np + Nn), ("Phi_e", Np + Ns + Nn), ("Phi_s", Np + Nn)) + \
                    ((("j_s", Nn),) if sei else ()) + (("I", 1),):
         out.append((name, o, o + n)); o += n
     return out
@@ -26,7 +26,8 @@ def grid_sections(Np, Ns, Nn, Nr, sei=False, thermal=None):
 
 # (keyed by the number of states: every model the tests build has its own)
 SECTION_TABLES = {301: SECTIONS, 322: SECTIONS_SEI, 351: SECTIONS_THERMAL, 121: SECTIONS_QUAD, 141: SECTIONS_POLY,
-                  330: grid_sections(12, 7, 9, 11), 266: grid_sections(6, 5, 8, 13, sei=True), 271: grid_sections(8, 6, 7, 11, thermal=(5, 7))}
+                  330: grid_sections(12, 7, 9, 11), 266: grid_sections(6, 5, 8, 13, sei=True), 271: grid_sections(8, 6, 7, 11, thermal=(5, 7)),
+                  237: grid_sections(7, 6, 8, 12, Nrn=10), 285: grid_sections(8, 6, 7, 11, thermal=(5, 7), Nrn=13)}
 
 
 def sections_for(n_states):

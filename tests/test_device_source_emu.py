@@ -700,15 +700,16 @@ def test_f4_lgm50_chemistry(emu_models_f4, O, pkg):
 def emu_grid_model(pkg, cathode, grid, variant_id, **kw):
     """grid = (N_p, N_s, N_n, N_r) or, with temperature = true, (N_p, N_s, N_n, N_r, N_a, N_z)"""
     import build_emu
-    g = tuple(grid) + (10, 10) if len(grid) == 4 else tuple(grid)
-    return pkg.petlion(cathode, N_p=g[0], N_s=g[1], N_n=g[2], N_r_p=g[3], N_r_n=g[3], N_a=g[4], N_z=g[5], _lib_path=build_emu.build(), _grid_lib=build_emu.build_grid(g, [variant_id]), **kw)
+    g = tuple(grid) + (10, 10) if len(grid) == 4 else tuple(grid)       # (a 7th entry: N_r_n != N_r_p)
+    return pkg.petlion(cathode, N_p=g[0], N_s=g[1], N_n=g[2], N_r_p=g[3], N_r_n=g[6] if len(g) == 7 else g[3], N_a=g[4], N_z=g[5], _lib_path=build_emu.build(),
+                       _grid_lib=build_emu.build_grid(g, [variant_id]), **kw)
 
 
-def check_grid_model(p, O, pkg, identical=True):
+def check_grid_model(p, O, pkg, identical=True, solve_tol=1e-8):
     """a model on another grid against the oracle variant generated for that grid (oracle/codegen.py): theta keys and CSC pattern, residual 1e-12 / Jacobian 1e-9 /
     solve 1e-8, consistent initialisation, two 1C discharges"""
     parity.check_keys_and_pattern(p, O)
-    parity.check_evaluators(p, O, n_cells=2)
+    parity.check_evaluators(p, O, n_cells=2, solve_tol=solve_tol)
     parity.check_init(p, O, None)
     Th = pkg.theta_matrix(p, 2, {"D_sp": np.array([1.0, 0.6]) * p.θ["D_sp"]})
     ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0)
@@ -727,10 +728,10 @@ def test_other_discretisation_lco_12_7_9_11(pkg, O):
     check_grid_model(emu_grid_model(pkg, pkg.LCO, (12, 7, 9, 11), 0), O, pkg)
 
 
-def check_thermal_grid_model(p, O, pkg):
+def check_thermal_grid_model(p, O, pkg, solve_tol=1e-8):
     """temperature = true on another grid (N_p != N_n, N_a != N_z, N_r != 10) against the oracle variant generated for it: pattern, evaluators in every mode incl. dT,
     consistent initialisation, a 1C discharge with identical decisions, and the CC-CT-CV protocol (CC leg at 1e-6, hold legs at the default-tolerance floor)"""
-    check_grid_model(p, O, pkg)
+    check_grid_model(p, O, pkg, solve_tol=solve_tol)
     ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 1), CC_CT_CV, SOC=0.0)
     ro = O.simulate(p.variant, p.theta_vector(), 0.0, parity.runs_to_oracle(O, p, pkg, CC_CT_CV))
     fl = [int(f) for f in ens.run_info[0]["flag"]]
@@ -762,11 +763,39 @@ def test_other_discretisation_nmc_sei_6_5_8_13(pkg, O):
     check_grid_model(emu_grid_model(pkg, pkg.NMC, (6, 5, 8, 13), 3, aging="SEI"), O, pkg, identical=False)
 
 
+# ---- N_r_p != N_r_n (reference src/params.jl:124-136: the two particle grids are independent options) ----------------------------------------------------------------
+def test_unequal_particle_grids_lco_7_6_8_12_rn10(pkg, O):
+    """N_r_p = 12, N_r_n = 10 on N_p = 7, N_s = 6, N_n = 8 (237 states; five particles per pass on the lane stride 12, the anode's operator zero-padded): theta keys, CSC
+    pattern, evaluators, consistent initialisation and two 1C discharges against the oracle variant generated for this grid"""
+    check_grid_model(emu_grid_model(pkg, pkg.LCO, (7, 6, 8, 12, 10, 10, 10), 0), O, pkg)
+
+
+def test_unequal_particle_grids_thermal_8_6_7_11_5_7_rn13(pkg, O):
+    """temperature = true with N_r_p = 11 < N_r_n = 13 (the cathode's operator is the padded one): per-particle spectral resolvents from per-electrode tables, the CC-CT-CV protocol"""
+    # (solve: 5e-8 instead of 1e-8 -- thirteen radial nodes raise the stiffest particle mode and with it the condition number (2e16 for these matrices); the structured solve and the
+    #  oracle's LU differ by 1.7e-8 in the I entry of the eta_plating system and are BOTH 4.7e-8 from a dense LAPACK solve of the same matrix)
+    check_thermal_grid_model(emu_grid_model(pkg, pkg.LCO, (8, 6, 7, 11, 5, 7, 13), 4, temperature=True), O, pkg, solve_tol=5e-8)
+
+
+@pytest.mark.parametrize("grid,vid,kw", [((7, 6, 8, 10, 10, 10, 13), 0, {}), ((6, 5, 8, 11, 10, 10, 14), 2, dict(aging="SEI")), ((8, 6, 7, 14, 5, 7, 10), 4, dict(temperature=True)),
+                                         ((5, 3, 20, 16, 10, 10, 10), 0, {})])
+def test_unequal_particle_grids_self_consistency(pkg, grid, vid, kw):
+    """both orders of N_r_p / N_r_n, with SEI aging, with temperature, and the largest stride against the smallest grid: the device residual against the oracle's Python
+    restatement, the Jacobian against differences of the residual, the solve against a dense solve; a 600 s 1C discharge lands on the default grid's voltage"""
+    from oracle import dfn_model as dm
+    p = emu_grid_model(pkg, pkg.LCO, grid, vid, **kw)
+    assert p.ind["c_s_avg"].stop - p.ind["c_s_avg"].start == grid[0] * grid[3] + grid[2] * grid[6]
+    check_grid_self_consistency(p, pkg, dm)
+    ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 1), [{"I": -1.0, "tf": 600.0}], SOC=1.0)
+    assert ens.run_info[0, 0]["flag"] == 0 and abs(ens.run_info[0, 0]["t_end"] - 600.0) < 1e-9
+    assert abs(ens.run_info[0, 0]["V"] - (3.94638 if kw.get("temperature") else (3.94023 if kw.get("aging") else 3.945410))) < 2e-3, ens.run_info[0, 0]["V"]
+
+
 def check_grid_self_consistency(p, pkg, dm, n_fd=6):
     """grids without a generated oracle variant: the device residual against the oracle's PYTHON restatement evaluated directly (oracle/dfn_model.py, FloatOps), the
     device Jacobian against central differences of the device residual, the device solve against a dense solve of the device Jacobian"""
     lib, h, N = p._lib, p._h, p.N.tot
-    model = dm.Model(cathode="LCO", temperature=p.temperature, Np=p.N.p, Ns=p.N.s, Nn=p.N.n, Nrp=p.N.r_p, Nrn=p.N.r_n, **(dict(Na=p.N.a, Nz=p.N.z) if p.temperature else {}))
+    model = dm.Model(cathode={"LCO": "LCO", "NMC": "NMC", "NMC_LGM50": "LGM50"}.get(p.cathode, p.cathode), aging=bool(p.aging), temperature=p.temperature, Np=p.N.p, Ns=p.N.s, Nn=p.N.n, Nrp=p.N.r_p, Nrn=p.N.r_n, **(dict(Na=p.N.a, Nz=p.N.z) if p.temperature else {}))
     assert model.lay.N == N
     th = p.theta_vector()[None, :].copy()
     thd = dict(model.theta); thd.update(dict(zip(p.θ_keys, th[0])))
@@ -822,7 +851,7 @@ def test_extreme_discretisations(pkg, grid):
 
 
 def test_unsupported_discretisations_refuse(pkg, emu_model):
-    for kw in (dict(N_p=40, N_s=10, N_n=10), dict(N_r_p=9, N_r_n=9), dict(N_r_p=12, N_r_n=10), dict(N_p=1), dict(temperature=True, N_p=4), dict(temperature=True, N_p=20, N_s=4, N_n=6),
+    for kw in (dict(N_p=40, N_s=10, N_n=10), dict(N_r_p=9, N_r_n=9), dict(N_r_p=12, N_r_n=9), dict(N_r_p=10, N_r_n=17), dict(N_p=1), dict(temperature=True, N_p=4), dict(temperature=True, N_p=20, N_s=4, N_n=6),
                dict(temperature=True, N_a=20, N_z=20)):
         with pytest.raises((ValueError, NotImplementedError)):
             pkg.petlion(pkg.LCO, **kw)

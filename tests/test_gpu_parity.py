@@ -585,6 +585,30 @@ def test_other_discretisations(pkg, O, hip_model):
     assert abs(ens.run_info[0, 0]["V"] - 3.945410) < 1e-5
 
 
+def test_unequal_particle_grids_on_gpu(pkg, O, hip_model):
+    """N_r_p != N_r_n (reference src/params.jl:124-136: the two particle grids are independent options): the compact c_s_avg layout, the particle phases on the lane stride
+    max(N_r_p, N_r_n) with the smaller operator zero-padded.  Oracle parity (pattern, evaluators, consistent initialisation, 1C discharges with identical decisions; with
+    temperature also CC-CT-CV) on the two grids with a generated oracle variant, and a 1024-cell parameter sweep with its size-independent properties"""
+    import torch
+    import test_device_source_emu as te
+    p = pkg.petlion(pkg.LCO, N_p=7, N_s=6, N_n=8, N_r_p=12, N_r_n=10)
+    assert p.ind["c_s_avg"].stop - p.ind["c_s_avg"].start == 7 * 12 + 8 * 10 and p.variant == "lco_iso_g7_6_8_12_rn10"
+    te.check_grid_model(p, O, pkg)
+    te.check_thermal_grid_model(pkg.petlion(pkg.LCO, temperature=True, N_p=8, N_s=6, N_n=7, N_r_p=11, N_r_n=13, N_a=5, N_z=7), O, pkg, solve_tol=5e-8)
+    n = 1024
+    Th = pkg.configs.sweep_theta(p, np.arange(n), 4)
+    ens = pkg.simulate_ensemble(p, torch.from_numpy(Th).cuda(), [{"I": -1.0}], SOC=1.0, device=True, max_points=512)
+    torch.cuda.synchronize()
+    fl, tend = ens.run_info["flag"][:, 0], ens.run_info["t_end"][:, 0]
+    assert np.isin(fl, (1, 3)).all(), np.unique(fl)
+    assert np.abs(tend[fl == 3] - 3600.0).max(initial=0.0) < 1e-6 and np.abs(ens.run_info["SOC"][:, 0] - (1.0 - tend / 3600.0)).max() < 1e-9
+    # every 64th cell against the oracle (default tolerances: identical decisions or the floor of test_c4_sweep)
+    for i in range(0, n, 64):
+        ro = O.simulate(p.variant, Th[i], 1.0, parity.runs_to_oracle(O, p, pkg, [{"I": -1.0}]))
+        assert int(fl[i]) == ro["runs"][0]["flag"] and abs(tend[i] - ro["runs"][0]["t_end"]) < 1e-4 * ro["runs"][0]["t_end"], i
+    print("N_r_p = 12, N_r_n = 10 on 7/6/8: N = %d, LDS %d B/cell, 1024-cell sweep %.2f ms (%.0f trajectories/s)" % (p.N.tot, p.lds_bytes, ens.kernel_ms, n / ens.kernel_ms * 1e3))
+
+
 def test_user_tstops_on_gpu(hip_model, hip_model_thermal, hip_model_nmc_sei, O, pkg):
     """opts.tstops (model_evaluation.jl:292-294) on the GPU, three models"""
     import test_device_source_emu as te
