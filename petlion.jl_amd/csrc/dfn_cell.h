@@ -441,6 +441,12 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {               
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int lane_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }                       // wave-uniform src
+// a wave-uniform double handed to the scalar register file (v_readfirstlane of both halves; the value is the same in every lane, so nothing changes numerically): f64
+// arithmetic is VALU-only, so a uniform double otherwise occupies a VGPR pair for as long as it lives; as a scalar pair it spills into LANES of a VGPR (1/64 of a register)
+__device__ __forceinline__ double uni(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_mov0<0x111>(v); v += dpp_mov0<0x112>(v); v += dpp_mov0<0x114>(v); v += dpp_mov0<0x118>(v);   // row_shr 1,2,4,8: inclusive row scan
   return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
@@ -452,6 +458,7 @@ __device__ __forceinline__ double row_up2(double v) { const double r = __shfl_up
 __device__ __forceinline__ double row_down2(double v) { const double r = __shfl_down(v, 2); return (lane_id() & 15) > 13 ? 0.0 : r; }
 __device__ __forceinline__ double lane_bcast(double v, int src) { return __shfl(v, src); }
 __device__ __forceinline__ int lane_bcast_i(int v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ double uni(double v) { return v; }
 __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 1; o < 16; o <<= 1) { const double r = __shfl_up(v, o); if ((lane_id() & 15) >= o) v += r; }
   return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));

@@ -11,7 +11,15 @@ LATE = ["-DPL_DEV=__device__ inline", "-mllvm", "-amdgpu-function-calls=false"]
 EARLY = ["-DPL_DEV=__device__ __forceinline__"]
 NOLSO = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
 NOVEC = ["-mllvm", "-amdgpu-load-store-vectorizer=0"]
+NOLICM = ["-mllvm", "-disable-machine-licm"]          # r04: MachineLICM hoists (among others) the copies of the exp / log polynomial coefficients out of the step loop
+UNI = ["-DPL_EXP_UNI"]                                # r04: wave-uniform doubles of the step loop handed to scalar registers (uni(), dfn_cell.h)
 BUILDS = {
+    "th_prod": ([4], EARLY + NOLSO + NOVEC, "c3", "c3_thermal"),
+    "th_nolicm": ([4], EARLY + NOLSO + NOVEC + NOLICM, "c3", "c3_thermal"), "th_uni": ([4], EARLY + NOLSO + NOVEC + UNI, "c3", "c3_thermal"),
+    "th_uni_nolicm": ([4], EARLY + NOLSO + NOVEC + UNI + NOLICM, "c3", "c3_thermal"),
+    "iso_nolicm": ([0], LATE + NOLICM, "c2 c4", "c2_1024 or evaluators"), "iso_uni": ([0], LATE + UNI, "c2 c4", "c2_1024 or evaluators"),
+    "iso_uni_nolicm": ([0], LATE + UNI + NOLICM, "c2 c4", "c2_1024 or evaluators"),
+    "sei_nolicm": ([3], LATE + NOLICM, "c5", "c5_nmc_sei"), "sei_uni_nolicm": ([3], LATE + UNI + NOLICM, "c5", "c5_nmc_sei"),
     "th_base": ([4], EARLY, "c3", "c3_thermal"),
     "th_branchy": ([4], EARLY + ["-DPL_EXP_BRANCHY_PHI"], "c3", "c3_thermal"),          # r03's branching update of the register-resident BDF history
     "iso_base": ([0], LATE, "c2 c4", "c2_1024 or evaluators"),
