@@ -112,11 +112,9 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false, int 
   // LDS diet: the error weights and the accumulated Newton correction live in registers (IdaScalars::ew / ee: they are only touched by the
   // lane-strided vector phases), and so do the BDF history vectors of order >= PHI_LDS
   static constexpr int PHI_LDS = THERMAL_ ? 2 : MAXORD + 1;   // thermal: 40.7 kB -> four cells per CU
-#ifdef PL_EXP_SEI_PRED      /* (A/B build, tools/experiments/ab.py sei_pred: the predictor in registers for the SEI models too) */
+  // predictor (y, y') of the step kept in registers across the Newton iteration (else re-summed from phi).  SEI models: since r04 -- with MachineLICM off (__graft_entry__.py) the
+  // 24 registers are there (C5 24.6 k -> 25.2 k trajectories/s; with MachineLICM on it cost 1 %).  Thermal model: +0.3 %, within the noise of the boxes, left as it was.
   static constexpr bool PRED_REGS = !THERMAL_;
-#else
-  static constexpr bool PRED_REGS = !THERMAL_ && !SEI_;       // predictor (y, y') of the step kept in registers across the Newton iteration (else re-summed from phi)
-#endif
   static constexpr int NB = THERMAL_ ? 4 : 3;        // node block size of the block-Thomas solve: (c_e, Phi_e, Phi_s[, T])
   static constexpr int O_T = N_CECS;
   static constexpr int O_FILM = N_CECS + (THERMAL_ ? NT : 0), O_SOH = O_FILM + NN;
@@ -204,7 +202,7 @@ template <> struct SeiPool<true> {
 // are folded into the twisted elimination (modified neighbour blocks, two right-hand-side shares): see thermal_sweeps.
 template <bool TH, bool MIXED = false> struct ThermalPool {};
 template <bool MIXED> struct ThermalPool<true, MIXED> {
-  double Dpark[MIXED ? NE * 16 : 1];                       // mixed precision: fp64 parking of the node's own block during the factor sweep (fp64 variant: parks in LD)
+  double Dpark[MIXED ? NE * 16 : 1];                       // (until r04: fp64 parking of the node's own block during the factor sweep, which now keeps it in registers; the member stays so that the pool's layout does not move)
   // heat-conduction stencil of residuals_T! (residuals.jl:299-489), already divided by rho*Cp:  aL T[it-1] + aD T[it] + aU T[it+1] + aC with aD = -(aL + aU) [- aC2 at the
   // two convective ends] (thermal_aD: not stored -- r04's LDS diet: the 2.4 kB freed here hold the radial operator, which the particle phases otherwise fetched from global
   // memory in every residual and every solve, at one wave per SIMD with nothing to hide that latency behind)
@@ -441,12 +439,6 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {               
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int lane_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }                       // wave-uniform src
-// a wave-uniform double handed to the scalar register file (v_readfirstlane of both halves; the value is the same in every lane, so nothing changes numerically): f64
-// arithmetic is VALU-only, so a uniform double otherwise occupies a VGPR pair for as long as it lives; as a scalar pair it spills into LANES of a VGPR (1/64 of a register)
-__device__ __forceinline__ double uni(double v) {
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_mov0<0x111>(v); v += dpp_mov0<0x112>(v); v += dpp_mov0<0x114>(v); v += dpp_mov0<0x118>(v);   // row_shr 1,2,4,8: inclusive row scan
   return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
@@ -458,7 +450,6 @@ __device__ __forceinline__ double row_up2(double v) { const double r = __shfl_up
 __device__ __forceinline__ double row_down2(double v) { const double r = __shfl_down(v, 2); return (lane_id() & 15) > 13 ? 0.0 : r; }
 __device__ __forceinline__ double lane_bcast(double v, int src) { return __shfl(v, src); }
 __device__ __forceinline__ int lane_bcast_i(int v, int src) { return __shfl(v, src); }
-__device__ __forceinline__ double uni(double v) { return v; }
 __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 1; o < 16; o <<= 1) { const double r = __shfl_up(v, o); if ((lane_id() & 15) >= o) v += r; }
   return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));

@@ -42,15 +42,6 @@ enum GenFlag { GF_STOPS = 1, GF_FUNC = 2, GF_EXPR = 4, GF_REFINE = 8, GF_GENROW 
 // device counters: wave-uniform registers (every call site uses a compile-time index), written out once at the end; indices:
 enum Cnt { C_STEPS, C_RES, C_JAC, C_FACT, C_SOLVE, C_NEWTON, C_ERRFAIL, C_CONVFAIL, C_SUMKP2, C_INIT };
 struct Counters { int v[10]; };
-#ifdef PL_EXP_UNI
-#define PL_UNI(x) ((x) = uni(x))
-__device__ __forceinline__ void ida_uni(IdaScalars& I) {
-  PL_UNI(I.tn); PL_UNI(I.hh); PL_UNI(I.hused); PL_UNI(I.cj); PL_UNI(I.cjlast); PL_UNI(I.cjold); PL_UNI(I.cjratio); PL_UNI(I.ss); PL_UNI(I.rr); PL_UNI(I.h0_forced);
-}
-#else
-#define PL_UNI(x) ((void)0)
-__device__ __forceinline__ void ida_uni(IdaScalars&) {}
-#endif
 __device__ __forceinline__ void cnt_add(Counters& c, int k, int v = 1) { c.v[k] += v; }
 
 // lane-strided sweep over the N state entries: exactly 5 trips (301 = 4*64 + 45), fully unrolled so that the LDS loads of all
@@ -486,8 +477,8 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
     const double delnrm = sqrt(block_sum<M>(S, s) * (1.0 / NST));
     PL_SYNC();
     ret = 2;
-    if (m == 0) { oldnrm = delnrm; PL_UNI(oldnrm); if (delnrm <= toldel) ret = 0; }
-    else { const double q = delnrm / oldnrm; const double rate = (m == 1) ? q : pow(q, 1.0 / m); if (rate > 0.9) ret = 1; else { I.ss = rate / (1.0 - rate); PL_UNI(I.ss); } }
+    if (m == 0) { oldnrm = delnrm; if (delnrm <= toldel) ret = 0; }
+    else { const double q = delnrm / oldnrm; const double rate = (m == 1) ? q : pow(q, 1.0 / m); if (rate > 0.9) ret = 1; else I.ss = rate / (1.0 - rate); }
     if (ret == 2 && I.ss * delnrm <= epsNewt) ret = 0;
     if (!(delnrm == delnrm)) ret = 1;
     PL_TOC(S, PH_NEWTVEC);
@@ -739,12 +730,10 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
   if (I.nst == 0) { I.kk = 1; I.kused = 0; I.hused = 0.0; if (lane == 0 && wave_id() == 0) S.ida_psi[0] = I.hh; I.cj = 1.0 / I.hh; I.phase = 0; I.ns = 0; PL_XSYNC(); }
   for (;;) {
     double ck; { PL_TIC(); PL_TICE(3); ck = ida_set_coeffs(S, I); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 0); }
-    PL_UNI(ck); ida_uni(I);
     if constexpr ((F & GF_FUNC) != 0) { if (frun && frun->mode != PLH_MODE_DSTATE) value = run_input<F>(S, *frun, I.tn, S.yy, S.yp); }                           // every residual of this step attempt is evaluated at t = tn
     const int nflag = ida_nls<F>(S, R, tb, I, mode, value, o.jac_every_step, cnt, o.refine, ((F & GF_EXPR) && frun && (frun->value_kind == PLH_VAL_EXPR || frun->mode == PLH_MODE_DSTATE)) ? frun : nullptr, &value, g);
     int errfail = 0;
     if (nflag == 0) { PL_TIC(); PL_TICE(3); errfail = ida_test_error(S, I, ck, err_k, err_km1); PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 1); }
-    PL_UNI(err_k); PL_UNI(err_km1);
     if (nflag != 0 || errfail) {
       ida_restore(S, I, saved_t);
       I.phase = 1;
@@ -776,7 +765,6 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
   PL_TOCE(S, 3, 2);
   if (!have_sol) { ida_get_solution(S, I, tstop, S.yy, S.yp); tret = tstop; PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 3); return 0; }      // the step ended on tstop (|tn - tstop| <= troundoff)
   if ((I.tn + I.hh - tstop) * I.hh > 0.0) I.hh = (tstop - I.tn) * (1.0 - 4.0 * uround);
-  ida_uni(I);
   tret = I.tn;                                                                      // y(tn), y'(tn) are in S.yy / S.yp (ida_complete_step)
   PL_TOC(S, PH_STEPCTL); PL_TOCE(S, 3, 3);
   return 0;
@@ -801,54 +789,54 @@ PL_DEV void check_stop(const CellLDS<M>& S, const plh_run& run, const plh_opts& 
   PL_MODEL(M);
   const double eps = t < 1.0 ? o.reltol : 0.0;
   [[maybe_unused]] double Tav = 0.0, dTav = 0.0;
-  if constexpr (M::THERMAL) { Tav = cellTavg<M>(S, Y); dTav = cellTavg<M>(S, YP); PL_UNI(Tav); PL_UNI(dTav); }     // (all lanes, before any early return)
+  if constexpr (M::THERMAL) { Tav = cellTavg<M>(S, Y); dTav = cellTavg<M>(S, YP); }     // (all lanes, before any early return)
   if (t >= tf) { flag = 0; return; }
   if (!o.check_bounds || run.value_kind == PLH_VAL_REST) return;
   const plh_bounds& b = run.bounds;
   const double Ic = Y[O_I];
   if (run.mode != PLH_MODE_I) {                                                         // check_stop_I, checks.jl:31-54
     const double dI = YP[O_I];
-    if ((Ic - b.I_max > eps) && dI > 0) { const double f = (pv.I - b.I_max) / (pv.I - Ic); if (f < pv.frac) { pv.frac = f; PL_UNI(pv.frac); flag = 7; } }
-    else if ((b.I_min - Ic > eps) && dI < 0) { const double f = (pv.I - b.I_min) / (pv.I - Ic); if (f < pv.frac) { pv.frac = f; PL_UNI(pv.frac); flag = 8; } }
-    pv.I = Ic; PL_UNI(pv.I);
+    if ((Ic - b.I_max > eps) && dI > 0) { const double f = (pv.I - b.I_max) / (pv.I - Ic); if (f < pv.frac) { pv.frac = f; flag = 7; } }
+    else if ((b.I_min - Ic > eps) && dI < 0) { const double f = (pv.I - b.I_min) / (pv.I - Ic); if (f < pv.frac) { pv.frac = f; flag = 8; } }
+    pv.I = Ic;
   }
   if (run.mode != PLH_MODE_V) {                                                         // check_stop_V, checks.jl:56-81
     const double V = cellV<M>(Y), dV = cellV<M>(YP);
-    if ((b.V_min - V > eps) && dV < 0) { const double f = (pv.V - b.V_min) / (pv.V - V); if (f < pv.frac) { pv.frac = f; PL_UNI(pv.frac); flag = 1; } }
-    else if ((V - b.V_max > eps) && dV > 0) { const double f = (pv.V - b.V_max) / (pv.V - V); if (f < pv.frac) { pv.frac = f; PL_UNI(pv.frac); flag = 2; } }
-    pv.V = V; PL_UNI(pv.V);
+    if ((b.V_min - V > eps) && dV < 0) { const double f = (pv.V - b.V_min) / (pv.V - V); if (f < pv.frac) { pv.frac = f; flag = 1; } }
+    else if ((V - b.V_max > eps) && dV > 0) { const double f = (pv.V - b.V_max) / (pv.V - V); if (f < pv.frac) { pv.frac = f; flag = 2; } }
+    pv.V = V;
   }
   {                                                                                     // check_stop_SOC, checks.jl:83-104
-    if ((b.SOC_min - SOC > eps) && Ic < 0) { const double f = (pv.SOC - b.SOC_min) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; PL_UNI(pv.frac); flag = 3; } }
-    else if ((SOC - b.SOC_max > eps) && Ic > 0) { const double f = (pv.SOC - b.SOC_max) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; PL_UNI(pv.frac); flag = 4; } }
-    pv.SOC = SOC; PL_UNI(pv.SOC);
+    if ((b.SOC_min - SOC > eps) && Ic < 0) { const double f = (pv.SOC - b.SOC_min) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; flag = 3; } }
+    else if ((SOC - b.SOC_max > eps) && Ic > 0) { const double f = (pv.SOC - b.SOC_max) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; flag = 4; } }
+    pv.SOC = SOC;
   }
   if constexpr (M::THERMAL) {                                                           // check_stop_T, checks.jl:106-124
     if (b.T_max == b.T_max && run.mode != PLH_MODE_DT) {
-      if (Tav - b.T_max > eps && dTav > 0) { const double f = (pv.T - b.T_max) / (pv.T - Tav); if (f < pv.frac) { pv.frac = f; PL_UNI(pv.frac); flag = 5; } }
-      pv.T = Tav; PL_UNI(pv.T);
+      if (Tav - b.T_max > eps && dTav > 0) { const double f = (pv.T - b.T_max) / (pv.T - Tav); if (f < pv.frac) { pv.frac = f; flag = 5; } }
+      pv.T = Tav;
     }
   }
   if (b.c_s_n_max == b.c_s_n_max) {                                                     // check_stop_c_s_surf, checks.jl:141-161
     double cm = -1e300; for (int i = 0; i < NN; i++) { const double v = M::SD == 0 ? Y[O_CS + cs_surf(NP + i)] : Y[O_CS + NP + i]; cm = v > cm ? v : cm; }     // (c_s_n_maximum, checks.jl:125-139)
     const double lim = b.c_s_n_max * S.cc.cmaxn;
-    if (Ic > 0 && cm - lim > eps) { const double f = (pv.c_s_n - lim) / (pv.c_s_n - cm); if (f < pv.frac) { pv.frac = f; PL_UNI(pv.frac); flag = 6; } }
-    pv.c_s_n = cm; PL_UNI(pv.c_s_n);
+    if (Ic > 0 && cm - lim > eps) { const double f = (pv.c_s_n - lim) / (pv.c_s_n - cm); if (f < pv.frac) { pv.frac = f; flag = 6; } }
+    pv.c_s_n = cm;
   }
   if (b.c_e_min == b.c_e_min) {                                                         // check_stop_c_e, checks.jl:163-183
     double cm = 1e300; for (int i = 0; i < NE; i++) { const double v = Y[O_CE + i]; cm = v < cm ? v : cm; }
-    if (b.c_e_min - cm > eps) { const double f = (pv.c_e_min - b.c_e_min) / (pv.c_e_min - cm); if (f < pv.frac) { pv.frac = f; PL_UNI(pv.frac); flag = 9; } }
-    pv.c_e_min = cm; PL_UNI(pv.c_e_min);
+    if (b.c_e_min - cm > eps) { const double f = (pv.c_e_min - b.c_e_min) / (pv.c_e_min - cm); if (f < pv.frac) { pv.frac = f; flag = 9; } }
+    pv.c_e_min = cm;
   }
   if (b.eta_plating_min == b.eta_plating_min) {                                         // check_stop_η_plating, checks.jl:185-201
     const double ep = Y[O_PS + NP] - Y[O_PE + NP + NS], dep = YP[O_PS + NP] - YP[O_PE + NP + NS];
-    if (b.eta_plating_min - ep > eps && dep < 0) { const double f = (pv.eta_pl - b.eta_plating_min) / (pv.eta_pl - ep); if (f < pv.frac) { pv.frac = f; PL_UNI(pv.frac); flag = 11; } }
-    pv.eta_pl = ep; PL_UNI(pv.eta_pl);
+    if (b.eta_plating_min - ep > eps && dep < 0) { const double f = (pv.eta_pl - b.eta_plating_min) / (pv.eta_pl - ep); if (f < pv.frac) { pv.frac = f; flag = 11; } }
+    pv.eta_pl = ep;
   }
   if constexpr (M::SEI) {                                                               // check_stop_dfilm, checks.jl:203-224
     double dm = -1e300; for (int i = 0; i < NN; i++) { const double v = YP[O_FILM + i]; dm = v > dm ? v : dm; }
-    if (b.dfilm_max == b.dfilm_max && dm - b.dfilm_max > eps) { const double f = (pv.dfilm - b.dfilm_max) / (pv.dfilm - dm); if (f < pv.frac) { pv.frac = f; PL_UNI(pv.frac); flag = 10; } }
-    pv.dfilm = dm; PL_UNI(pv.dfilm);
+    if (b.dfilm_max == b.dfilm_max && dm - b.dfilm_max > eps) { const double f = (pv.dfilm - b.dfilm_max) / (pv.dfilm - dm); if (f < pv.frac) { pv.frac = f; flag = 10; } }
+    pv.dfilm = dm;
   }
 }
 
@@ -877,7 +865,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
   if constexpr ((F & GF_SENS) != 0) { SX.a = sens; SX.th0 = th0; SX.cell = cell; SX.P = tb->P; SX.max_pts = out.max_pts; SX.first = true; SX.n_it = 0; SX.n_fail = 0; }
   int nout = 0;
   bool have_prev = false;
-  const double T0 = uni(S.cc.T0);
+  const double T0 = S.cc.T0;
   // (what a run inherits from the one before -- SOC, end time, V / I / eta_plating -- travels through S.carry: see CellLDS)
   if (Yinit) {                                                          // simulate!(sol, ...): continue from sol.Y[end]
     PL_VEC(n) S.yy[n] = Yinit[n];
@@ -967,16 +955,14 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     PL_XSYNC();
     if (lane == 0 && wave_id() == 0) S.yy[O_I] = Iguess;
     PL_XSYNC();
-    PL_UNI(value); PL_UNI(t0); PL_UNI(SOC);
     GenRow grow;                                                        // closure of the state with derivative programs: general control row (dfn_cell.h)
     if constexpr ((F & GF_GENROW) != 0) { if (((run.value_kind == PLH_VAL_EXPR && run.n_dcol > 0) || dstate) && genW) { grow.run = &run; grow.W = genW; } }
     int flag = PLH_FLAG_RUNNING;
     plh_run_info ri; ri.flag = PLH_FLAG_RUNNING; ri.iterations = 0; ri.t_end = t_global; ri.V = 0; ri.I = 0; ri.SOC = SOC; ri.T_avg = T0;
-    PL_UNI(ri.t_end); PL_UNI(ri.SOC);
     // tstops = {tdiscon - reltol/2} U {1.0 if continuation} U {tf}   (postfix_integrator!, model_evaluation.jl:288-310)
     const bool continuation = !new_run;
     PrevVals pv; pv.frac = 1.0; pv.V = -1; pv.SOC = -1; pv.I = -1; pv.c_s_n = -1; pv.c_e_min = -1; pv.eta_pl = -1; pv.dfilm = -1; pv.T = -1;
-    double tprev = 0.0, t = 0.0, t_prev_saved = t0; PL_UNI(t_prev_saved); int iter = 1; bool stalled_once = false;
+    double tprev = 0.0, t = 0.0, t_prev_saved = t0; int iter = 1; bool stalled_once = false;
     double I_prev_pt = 0.0, t_restart = 0.0;
     bool first_init = true, again = false, init_failed = false;
     [[maybe_unused]] int steps_since_restart = 2;                       // (accepted steps since a check_reinitialization! restart; 2 = "more than one")
@@ -1001,7 +987,6 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       double tstop_now;
       if constexpr ((F & GF_STOPS) != 0) tstop_now = next_tstop(o, t, continuation, run.tf);
       else tstop_now = (continuation && run.tf > 1.0 && t < 1.0) ? 1.0 : run.tf;
-      PL_UNI(tstop_now);
       // two waves per cell: both evaluate the stop checks, SOC and I_prev_pt from S.yy redundantly; the wave that is ahead must not start overwriting S.yy (predictor of
       // the next step) while the other still reads the accepted point -- with a varying current its SOC, hence its stop flag, would differ
       if constexpr (M::W2) __syncthreads();
@@ -1024,11 +1009,10 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       if constexpr ((F & GF_FUNC) != 0) steps_since_restart++;
       PL_TIC(); PL_TICE(3);
       const double SOC_new = SOC + 0.5 * ((t + t0) - t_prev_saved) * (S.yy[O_I] + I_prev_pt) / 3600.0;   // calc_SOC, scalar_residual.jl:103-111
-      SOC = SOC_new; PL_UNI(SOC);
+      SOC = SOC_new;
       save_pt(nout, t + t0, S.yy, SOC); nout++;
       PL_TOCE(S, 3, 4);
       check_stop(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
-      PL_UNI(SOC); PL_UNI(t); PL_UNI(pv.frac); PL_UNI(pv.V); PL_UNI(pv.SOC); PL_UNI(pv.I); PL_UNI(pv.T); PL_UNI(pv.c_s_n); PL_UNI(pv.c_e_min); PL_UNI(pv.eta_pl); PL_UNI(pv.dfilm);
       PL_TOCE(S, 3, 5);
       if constexpr ((F & GF_SENS) != 0) sens_step(S, R, I, SX, mode, value, nout - 1);      // (the solution point in S.yy / S.yp is saved and restored around it)
       if (!is_fun && t == tprev) { flag = PLH_ERR_STALL; break; }      // (run_function has no stall test, checks.jl:251-269; run_residual -- res, dT, d<state> -- has: checks.jl:226)
@@ -1041,7 +1025,6 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
         if (YPfin) { PL_VEC(n) YPprev[n] = S.yp[n]; }                // fire-and-forget: read back only when a bound fires (wave-uniform condition)
 #endif
         t_prev_saved = t + t0; I_prev_pt = S.yy[O_I];
-        PL_UNI(t_prev_saved); PL_UNI(I_prev_pt);
         if constexpr ((F & GF_FUNC) != 0) if (is_fun && t - tprev < 1e-3 * o.reltol) {                    // check_reinitialization!, checks.jl:341-364
           const double t_new = t + o.reltol, v_new = run_input<F>(S, run, t_new, S.yy, S.yp);
           const double big = fabs(value) > fabs(v_new) ? fabs(value) : fabs(v_new);

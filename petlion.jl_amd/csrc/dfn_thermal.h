@@ -722,17 +722,16 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     const int nb = top ? (i > 0 ? i - 1 : 0) : (i < NE - 1 ? i + 1 : NE - 1);
     if (!act) { a.ce = a.pc = a.pe = a.pt = a.s = a.Tc = a.Te = a.Ts = a.Tt = 0.0; }
     for (int k = 0; k < 16; k++) Dn[k] = D[k];
-    // register diet for the sweep (every device function is inlined: ~80 integrator values are live around this loop): the node's own block D and
-    // the neighbour's off-diagonal block b are re-read from LDS in every stage instead of being held in 50 registers (D parks in S.LD[i], which is
-    // only written at the end)
-    double* park;
-    if constexpr (M::MIXED) park = &S.th.Dpark[i]; else park = &S.LD[0][i];      // (fp32 factor storage cannot hold the fp64 block)
-    if (act) for (int k = 0; k < 16; k++) park[k * NE] = D[k];      // (element k of node i at [k * NE + i]: the structure-of-arrays layout of the factor arrays)
     // second-neighbour T-row entries (see thermal_sweeps): nodes 2 / 27 see U_1 / L_28 modified by -fv (x) fw ; nodes 9 / 20 get a modified
     // lower / upper block once the factor of node 7 / 22 is final
     double fv[4] = {0.0, 0.0, 0.0, 0.0}, fw[3] = {0.0, 0.0, 0.0};
     constexpr int FAR_T = NP - 3, FAR_B = NN - 3;          // stage after which the factor of node N_p - 3 (top chain) / N_p + N_s + 2 (bottom chain) is final
     inv4(D, Dinv);
+    // the node's own block D and the neighbour's off-diagonal block b stay in registers across the stages (r04: with MachineLICM off -- __graft_entry__.py -- nothing
+    // spills any more, and the two LDS round trips per stage that re-read them were 2.5 % of C3; until then they were re-read to keep 50 registers free)
+    const OffBlk b = top ? upper_blk(S, nb, alg_only) : lower_blk(S, nb, alg_only);
+    double Dk[16];
+    for (int k = 0; k < 16; k++) Dk[k] = D[k];
 #pragma unroll 1
     for (int itr = 1; itr < TW_FWD; itr++) {
       PL_SYNC();                                            // (also keeps the reloads below inside the loop)
@@ -746,10 +745,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
           LDm[12 + k] = a.Tc * P[k] + a.Te * P[4 + k] + a.Ts * P[8 + k] + a.Tt * P[12 + k];
         }
       }
-      PL_SYNC();                                            // (the node's own block and the neighbour's off-diagonal block are fetched only now: P is dead)
-      const OffBlk b = top ? upper_blk(S, nb, alg_only) : lower_blk(S, nb, alg_only);
-      double D[16];
-      for (int k = 0; k < 16; k++) D[k] = park[k * NE];
+      const double* D = Dk;
       for (int rr = 0; rr < 4; rr++) {
         const double a0 = LDm[rr * 4], a1 = LDm[rr * 4 + 1], a2 = LDm[rr * 4 + 2], a3 = LDm[rr * 4 + 3];
         Dn[rr * 4 + 0] = ((D[rr * 4 + 0] - a0 * b.ce) - a1 * b.pc) - a3 * b.Tc;

@@ -112,7 +112,7 @@ def _library_locked(grid, variants, force, tag, defs):
         o = os.path.join(GRID_DIR, "%s_v%d.o" % (tag, v))
         objs.append(o)
         # the build mode of the built-in isothermal kernels (__graft_entry__.py): -O3, every device function inlined late
-        jobs.append(subprocess.Popen(common + ["-mllvm", "-amdgpu-function-calls=false", "-O3", "-DPL_VARIANT=%d" % v, "-c", src, "-o", o]))
+        jobs.append(subprocess.Popen(common + ["-mllvm", "-amdgpu-function-calls=false", "-mllvm", "-disable-machine-licm", "-O3", "-DPL_VARIANT=%d" % v, "-c", src, "-o", o]))
     glue = os.path.join(GRID_DIR, "%s_glue.o" % tag)
     jobs.append(subprocess.Popen(common + ["-O2", "-DPL_GRID_GLUE", "-c", src, "-o", glue]))
     if any(j.wait() for j in jobs):

@@ -19,6 +19,15 @@ BUILDS = {
     "th_uni_nolicm": ([4], EARLY + NOLSO + NOVEC + UNI + NOLICM, "c3", "c3_thermal"),
     "iso_nolicm": ([0], LATE + NOLICM, "c2 c4", "c2_1024 or evaluators"), "iso_uni": ([0], LATE + UNI, "c2 c4", "c2_1024 or evaluators"),
     "iso_uni_nolicm": ([0], LATE + UNI + NOLICM, "c2 c4", "c2_1024 or evaluators"),
+    "sei_pred_nolicm": ([3], LATE + UNI + NOLICM + ["-DPL_EXP_SEI_PRED"], "c5", "c5_nmc_sei"),
+    "th_late_nolicm": ([4], LATE + NOLSO + NOVEC + UNI + NOLICM, "c3", "c3_thermal"), "iso_early_nolicm": ([0], EARLY + UNI + NOLICM, "c2 c4", "c2_1024 or evaluators"),
+    "th_merge_nolicm": ([4], EARLY + UNI + NOLICM, "c3", "c3_thermal"),          # (DS merging back on, now that 16-byte register tuples are no longer scarce)
+    # (the sweep's blocks in registers: adopted in the source after th_sweepregs, +2.5 %) combinations on top of it:
+    "th_new": ([4], EARLY + NOLSO + NOVEC + NOLICM, "c3", "c3_thermal"), "th_new_merge": ([4], EARLY + NOLICM, "c3", "c3_thermal"),
+    "th_new_late_merge": ([4], LATE + NOLICM, "c3", "c3_thermal"), "th_new_late": ([4], LATE + NOLSO + NOVEC + NOLICM, "c3", "c3_thermal"),
+    "th_new_pred": ([4], EARLY + NOLSO + NOVEC + NOLICM + ["-DPL_EXP_ALL_PRED"], "c3", "c3_thermal"),          # predictor of the step in registers for the thermal model too
+    "lgm_nolicm": ([14], EARLY + NOLSO + NOVEC + NOLICM, "", ""), "lgm_licm": ([14], EARLY + NOLSO + NOVEC, "", ""),          # (tools/dbg/selftest_delta.py)
+    "sei_pred2": ([3], LATE + NOLICM + ["-DPL_EXP_SEI_PRED"], "c5", "c5_nmc_sei"), "iso_early2": ([0], EARLY + NOLICM, "c2 c4", "c2_1024 or evaluators"),
     "sei_nolicm": ([3], LATE + NOLICM, "c5", "c5_nmc_sei"), "sei_uni_nolicm": ([3], LATE + UNI + NOLICM, "c5", "c5_nmc_sei"),
     "th_base": ([4], EARLY, "c3", "c3_thermal"),
     "th_branchy": ([4], EARLY + ["-DPL_EXP_BRANCHY_PHI"], "c3", "c3_thermal"),          # r03's branching update of the register-resident BDF history
