@@ -11,6 +11,9 @@ LATE = ["-DPL_DEV=__device__ inline", "-mllvm", "-amdgpu-function-calls=false"]
 EARLY = ["-DPL_DEV=__device__ __forceinline__"]
 NOLSO = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
 NOVEC = ["-mllvm", "-amdgpu-load-store-vectorizer=0"]
+# (r04 note: -DPL_EXP_UNI, -DPL_EXP_SWEEP_REGS, -DPL_EXP_SEI_PRED and -DPL_EXP_ALL_PRED selected code paths that have since been adopted (sweep blocks in registers, SEI predictor
+#  in registers) or removed (uni(), thermal predictor in registers): the entries that name them are the record of what was measured -- gpurun_out/r04k..r04m, DESIGN.md 5a -- and
+#  now build the tree as it is)
 NOLICM = ["-mllvm", "-disable-machine-licm"]          # r04: MachineLICM hoists (among others) the copies of the exp / log polynomial coefficients out of the step loop
 UNI = ["-DPL_EXP_UNI"]                                # r04: wave-uniform doubles of the step loop handed to scalar registers (uni(), dfn_cell.h)
 BUILDS = {
@@ -26,6 +29,9 @@ BUILDS = {
     "th_new": ([4], EARLY + NOLSO + NOVEC + NOLICM, "c3", "c3_thermal"), "th_new_merge": ([4], EARLY + NOLICM, "c3", "c3_thermal"),
     "th_new_late_merge": ([4], LATE + NOLICM, "c3", "c3_thermal"), "th_new_late": ([4], LATE + NOLSO + NOVEC + NOLICM, "c3", "c3_thermal"),
     "th_new_pred": ([4], EARLY + NOLSO + NOVEC + NOLICM + ["-DPL_EXP_ALL_PRED"], "c3", "c3_thermal"),          # predictor of the step in registers for the thermal model too
+    "th_branchy_nolicm": ([4], EARLY + NOLSO + NOVEC + NOLICM + ["-DPL_EXP_BRANCHY_PHI"], "c3", "c3_thermal"), "th_branchy_merge": ([4], EARLY + NOLICM + ["-DPL_EXP_BRANCHY_PHI"], "c3", "c3_thermal"),
+    "th_fence": ([4], EARLY + NOLSO + NOVEC + NOLICM + ["-DPL_PHASE_FENCES"], "c3", "c3_thermal"), "iso_fence": ([0], LATE + NOLICM + ["-DPL_PHASE_FENCES"], "c2 c4", "c2_1024 or evaluators"),
+    "sei_fence": ([3], LATE + NOLICM + ["-DPL_PHASE_FENCES"], "c5", "c5_nmc_sei"), "iso_new": ([0], LATE + NOLICM, "c2 c4", "c2_1024 or evaluators"), "sei_new": ([3], LATE + NOLICM, "c5", "c5_nmc_sei"),
     "lgm_nolicm": ([14], EARLY + NOLSO + NOVEC + NOLICM, "", ""), "lgm_licm": ([14], EARLY + NOLSO + NOVEC, "", ""),          # (tools/dbg/selftest_delta.py)
     "sei_pred2": ([3], LATE + NOLICM + ["-DPL_EXP_SEI_PRED"], "c5", "c5_nmc_sei"), "iso_early2": ([0], EARLY + NOLICM, "c2 c4", "c2_1024 or evaluators"),
     "sei_nolicm": ([3], LATE + NOLICM, "c5", "c5_nmc_sei"), "sei_uni_nolicm": ([3], LATE + UNI + NOLICM, "c5", "c5_nmc_sei"),
