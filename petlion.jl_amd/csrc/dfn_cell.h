@@ -407,6 +407,19 @@ enum Phase { PH_RES, PH_JACFACT, PH_SOLVE, PH_NEWTVEC, PH_STEPCTL, PH_INIT, PH_O
 #define PL_TOCD(S_, slot) PL_MARK_("tocD " #slot)
 #define PL_TICE(mode) PL_MARK_("ticE " #mode)
 #define PL_TOCE(S_, mode, slot) PL_MARK_("tocE " #mode " " #slot)
+#elif defined(PL_PHASE_FENCES) && !defined(PL_PHASE_TIMERS) && !defined(PL_WAVE_EMU)
+// Compiler fences (no instruction) at the phase boundaries, i.e. where the profiling builds read the clock and the ISA builds put their marks: memory operations may not be
+// moved across them, which keeps the loads of one phase out of the previous one's register budget.  Thermal variants only (__graft_entry__.py VARIANT_FLAGS).
+#define PL_FENCE_() __asm__ volatile("" ::: "memory")
+#define PL_AMARK(txt) PL_FENCE_()
+#define PL_TIC() PL_FENCE_()
+#define PL_TOC(S_, ph) PL_FENCE_()
+#define PL_TIC_TOTAL() do {} while (0)
+#define PL_TOC_TOTAL(S_) do {} while (0)
+#define PL_TICD() PL_FENCE_()
+#define PL_TOCD(S_, slot) PL_FENCE_()
+#define PL_TICE(mode) PL_FENCE_()
+#define PL_TOCE(S_, mode, slot) PL_FENCE_()
 #else
 #define PL_TIC() PL_TIC_()
 #define PL_TOC(S_, ph) PL_TOC_(S_, ph)

@@ -17,7 +17,9 @@ def build(force=False, variant=None):
     deps.append(os.path.join(HERE, "hip", "hip_runtime.h"))
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", HERE, SRC, "-o", out, "-Wno-unused-variable", "-ldl"]
+    # -DPL_EXP_BRANCHY_PHI: the form of the register-resident BDF history update that the product's thermal variants 4 / 7 are built with since the end of r04
+    # (__graft_entry__.py THERMAL_R04; it only exists for the models that keep history orders in registers, i.e. the thermal ones)
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", HERE, SRC, "-o", out, "-Wno-unused-variable", "-ldl", "-DPL_EXP_BRANCHY_PHI"]
     if variant is not None:
         cmd.append("-DPL_VARIANT=%d" % variant)
     subprocess.check_call(cmd)

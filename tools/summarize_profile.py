@@ -22,7 +22,7 @@ L += ["", "`k_integrate`: %d dispatches, duration min/avg/max = %.1f / %.1f / %.
       % (len(d), min(d) / 1e3, sum(d) / len(d) / 1e3, max(d) / 1e3, rows[0][6], rows[0][7], rows[0][1], rows[0][2], rows[0][3], rows[0][4], rows[0][5]),
       "", "(register columns as rocprofv3 reports them; `accum_vgpr_count` reads 0 on this unified-file part -- the compiler's own figures for this kernel, `hipcc -Rpass-analysis=kernel-resource-usage`: "
       + {"C2": "256 VGPR + 129 AGPR, 92 VGPR spills into AGPRs, 298 SGPR spills, 0 B/lane scratch", "C4": "256 VGPR + 129 AGPR, 92 VGPR spills into AGPRs, 298 SGPR spills, 0 B/lane scratch",
-         "C3": "256 VGPR + 256 AGPR, 122 VGPR spills, 428 SGPR spills, 132 B/lane scratch", "C5": "256 VGPR + 214 AGPR, 104 VGPR spills into AGPRs, 370 SGPR spills, 0 B/lane scratch"}.get(workload, "see csrc/petlion_kernels.h") + ")",
+         "C3": "256 VGPR + 230 AGPR, 132 VGPR spills into AGPRs, 427 SGPR spills, 0 B/lane scratch", "C5": "256 VGPR + 214 AGPR, 104 VGPR spills into AGPRs, 370 SGPR spills, 0 B/lane scratch"}.get(workload, "see csrc/petlion_kernels.h") + ")",
       "", "Per dispatch in launch order (us): " + ", ".join("%.0f" % (x / 1e3) for x in d) + " -- the first launches of a process run slower (clock ramp); "
       "the steady state (last three: %.0f us) is what `bench.py` times after its warm-up steps (`roofline.kernel_ms_avg`, HIP events on the launch stream)." % (sum(d[-3:]) / 3e3), ""]
 L += ["## PMC passes (per k_integrate launch = %d cells = %d wavefronts; averages over the dispatches of the run)" % (cells, cells), "", "| counter | value per launch | per wavefront |", "|---|---|---|"]
