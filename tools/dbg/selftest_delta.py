@@ -28,3 +28,7 @@ for tf in (100.0, 1000.0):
     dv = np.abs(np.asarray(e.V[0, :k]) - np.asarray(base.V[0, :k])); dt = np.abs(np.asarray(e.t[0, :k]) - np.asarray(base.t[0, :k]))
     first = int(np.argmax((dv > 0) | (dt > 0))) if ((dv > 0) | (dt > 0)).any() else -1
     print("   first saved point that differs: %d of %d ; dV there %.3e dt %.3e ; max dV %.3e" % (first, k, dv[first] if first >= 0 else 0.0, dt[first] if first >= 0 else 0.0, dv.max()))
+try:
+    pkg.selftest(p); print("selftest of every instantiation: passed")
+except RuntimeError as e:
+    print("selftest:", str(e)[:160])

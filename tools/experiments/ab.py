@@ -33,6 +33,7 @@ BUILDS = {
     "th_fence": ([4], EARLY + NOLSO + NOVEC + NOLICM + ["-DPL_PHASE_FENCES"], "c3", "c3_thermal"), "iso_fence": ([0], LATE + NOLICM + ["-DPL_PHASE_FENCES"], "c2 c4", "c2_1024 or evaluators"),
     "sei_fence": ([3], LATE + NOLICM + ["-DPL_PHASE_FENCES"], "c5", "c5_nmc_sei"), "iso_new": ([0], LATE + NOLICM, "c2 c4", "c2_1024 or evaluators"), "sei_new": ([3], LATE + NOLICM, "c5", "c5_nmc_sei"),
     "th_fb": ([4], EARLY + NOLSO + NOVEC + NOLICM + ["-DPL_PHASE_FENCES", "-DPL_EXP_BRANCHY_PHI"], "c3", "c3_thermal"),          # = the production thermal build since the end of r04
+    "lgm_fb": ([14], EARLY + NOLSO + NOVEC + NOLICM + ["-DPL_PHASE_FENCES", "-DPL_EXP_BRANCHY_PHI"], "", ""),          # variant 14 with the flags of variants 4 / 7 (selftest_delta.py)
     "lgm_nolicm": ([14], EARLY + NOLSO + NOVEC + NOLICM, "", ""), "lgm_licm": ([14], EARLY + NOLSO + NOVEC, "", ""),          # (tools/dbg/selftest_delta.py)
     "sei_pred2": ([3], LATE + NOLICM + ["-DPL_EXP_SEI_PRED"], "c5", "c5_nmc_sei"), "iso_early2": ([0], EARLY + NOLICM, "c2 c4", "c2_1024 or evaluators"),
     "sei_nolicm": ([3], LATE + NOLICM, "c5", "c5_nmc_sei"), "sei_uni_nolicm": ([3], LATE + UNI + NOLICM, "c5", "c5_nmc_sei"),
