@@ -10,11 +10,17 @@ BASELINE.json per GPU ("Batch of 1024 LCO isothermal 1C CC discharges (identical
 contiguous blocks, no data-path collective.  --config selects C3 (4096 thermal cells, CC-CT-CV), C4 (8192 jittered cells per GPU, the shard of the
 65 536-cell sweep) or C5 (1024 NMC + SEI cells, 20 GITT pulses); their inputs are SURVEY.md 8(d)'s (petlion.jl_amd/configs.py).
 
-`value` is the rate with the parameters already resident in HBM (the contract of this benchmark).  The same JSON line also carries
-  "roofline":       algorithmic HBM bytes per launch (SURVEY.md 8(d) byte model x the device counters) / the integrate kernel's average duration
-                    (HIP events on its stream) vs the 8 TB/s HBM3E peak -- the metric BASELINE.json names.  The kernel is LDS-resident: its measured HBM
-                    traffic ("traffic", rocprofv3 PMC) is a fraction of a percent of the model bytes, so "frac" is an equivalent-streaming rate, not HBM
-                    utilisation; "hbm_utilisation" is the real one and "limiter" names what bounds the kernel;
+`value` is the rate with the parameters already resident in HBM (the contract of this benchmark: inputs in HBM when the timed region starts; the host-inclusive
+rate of SURVEY 8(d)'s shape is `host_inclusive` in the same line and is never `value`).  The same JSON line also carries
+  "roofline":       what actually bounds the kernel -- VALU ISSUE.  The cell state is LDS-resident, one wavefront per SIMD: the kernel moves 0.1 % of the bytes a streaming
+                    implementation would, and what a wave spends its life on is issuing fp64 VALU instructions (4 cycles each on the 16-lane fp64 pipe of a gfx950 SIMD).
+                    achieved = VALU-busy cycles per second over the launch = (cells x VALU-busy cycles per trajectory, from the committed rocprofv3 PMC pass of THIS binary and
+                    workload: 4 x SQ_ACTIVE_INST_VALU, profiles/*_pmc.json) / the kernel's average duration measured live (HIP events on the launch stream);
+                    peak = SIMDs occupied x 2.4 GHz (every cycle of every occupied SIMD issuing VALU); frac = achieved / peak.  Beside it: the s_waitcnt-parked, LDS and scalar
+                    shares of the wave's cycles, the instruction counts per step, the effective shader clock, and "traffic" (HBM bytes per launch, PMC);
+  "equivalent_streaming": SURVEY.md 8(d)'s algorithmic HBM bytes (byte model x the device counters) / the same kernel duration vs the 8 TB/s HBM3E peak -- the figure r01-r04
+                    reported as "roofline".  It prices bytes this kernel never moves (the LDS-resident design exceeds the ceiling a perfect streaming implementation of the
+                    north star would have, frac > 1 on C2): kept under its honest name, it bounds nothing;
   "cpu_baseline":   the oracle (plain-C port of the reference path) on one host core and on all usable cores, bounded sample of the same workload;
   "host_inclusive": SURVEY 8(d)'s measurement shape -- parameters start in (pinned) host memory, per-cell summaries and sampled outputs end there --
                     as a double-buffered PLH_HOST_ASYNC pipeline: median over >= 10 calls;
@@ -58,6 +64,56 @@ def algorithmic_bytes(c, counters, n_pts):
     b = ((k["n_res"] - ni - 2.0 * n_init_runs) * B_RES + (k["n_jac"] - ni) * B_JAC + (k["n_fact"] - ni) * B_FACT + (k["n_solve"] - ni - n_init_runs) * B_SOLVE
          + k["sum_kp2"] * B_STEP1 + (ni + 2.0 * n_init_runs) * B_RES_A + ni * (B_JAC_A + B_FACT_A) + (ni + n_init_runs) * B_SOLVE_A + n_pts.astype(np.float64) * c["SC"] * W)
     return float(b.sum())
+
+
+SIMDS = 256 * 4                  # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md, chip-level parameters)
+CLOCK_PEAK_HZ = 2.4e9            # max shader clock, same table
+FP64_ISSUE_CYCLES = 4            # a wave64 fp64 VALU instruction occupies the SIMD's 16-lane fp64 pipe for 4 cycles (78.6 TFLOP/s fp64 vector = 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
+
+
+def issue_roofline(pmc, traffic, n_local, kavg_ms, klast_ms, c, ens, pkg, p):
+    """the bound that bounds: VALU issue (module docstring).  Everything PMC comes from the committed pass of this binary and workload; the duration is measured live."""
+    secs = kavg_ms * 1e-3
+    waves_resident = min(n_local, SIMDS * max(1, (160 * 1024) // int(p.lds_bytes) // 4))      # cells resident at a time: one per SIMD (LDS: four per CU)
+    simds_busy = min(n_local, SIMDS)
+    peak = simds_busy * CLOCK_PEAK_HZ / 1e9                                                     # G VALU-busy cycles / s if every occupied SIMD issued VALU every cycle at 2.4 GHz
+    out = {"bound": "valu_issue", "unit": "G VALU-busy cycles/s", "peak": peak,
+           "peak_what": "%d occupied SIMDs x 2.4 GHz: every cycle of every SIMD that holds a cell issuing VALU (one wavefront per SIMD: LDS allows four cells per CU)" % simds_busy,
+           "achieved": None, "frac": None, "traffic": traffic,
+           "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes)",
+           "hbm_utilisation": (traffic / secs / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+           "kernel": "k_integrate<%s>" % c["variant"], "kernel_ms_avg": kavg_ms, "kernel_ms_last_launch": klast_ms, "cells_resident_at_a_time": waves_resident}
+    if not pmc or "counters" not in pmc:
+        out["note"] = "no profiles/*_pmc.json for this workload: run tools/prof.sh (rocprofv3 --pmc passes) and tools/summarize_profile.py"
+        return out
+    k = pmc["counters"]; cells = float(pmc["cells_per_launch"])
+    wave_cyc = 4.0 * k["SQ_WAVE_CYCLES"] / cells                       # shader cycles a wavefront (= a trajectory) lives; SQ_* cycle counters count quad-cycles
+    steps = float(ens.counters["n_steps"].mean())
+    if "SQ_ACTIVE_INST_VALU" in k:
+        valu_busy = 4.0 * k["SQ_ACTIVE_INST_VALU"] / cells             # cycles of it the VALU is executing this wave's instructions (measured)
+        how = "4 x SQ_ACTIVE_INST_VALU / cells"
+    else:                                                                # older passes: instruction count x the fp64 issue cost (a lower bound on the 32-bit share, an upper on none)
+        valu_busy = FP64_ISSUE_CYCLES * k["SQ_INSTS_VALU"] / cells
+        how = "%d x SQ_INSTS_VALU / cells (no SQ_ACTIVE_INST_VALU in the pass)" % FP64_ISSUE_CYCLES
+    achieved = n_local * valu_busy / secs / 1e9
+    out.update({"achieved": achieved, "frac": achieved / peak,
+                "valu_busy_cycles_per_trajectory": valu_busy, "valu_busy_from": how, "wave_cycles_per_trajectory": wave_cyc,
+                "valu_busy_share_of_wave_cycles": valu_busy / wave_cyc,
+                "valu_instructions_x4_share_of_wave_cycles": FP64_ISSUE_CYCLES * k["SQ_INSTS_VALU"] / cells / wave_cyc if "SQ_INSTS_VALU" in k else None,
+                "s_waitcnt_parked_share": (k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"]) if "SQ_WAIT_ANY" in k else None,
+                "issue_stall_share": (k["SQ_WAIT_INST_ANY"] / k["SQ_WAVE_CYCLES"]) if "SQ_WAIT_INST_ANY" in k else None,
+                "any_instruction_active_share": (k["SQ_ACTIVE_INST_ANY"] / k["SQ_WAVE_CYCLES"]) if "SQ_ACTIVE_INST_ANY" in k else None,
+                "lds_busy_share": (k["SQ_ACTIVE_INST_LDS"] / k["SQ_WAVE_CYCLES"]) if "SQ_ACTIVE_INST_LDS" in k else None,
+                "scalar_busy_share": (k["SQ_ACTIVE_INST_SCA"] / k["SQ_WAVE_CYCLES"]) if "SQ_ACTIVE_INST_SCA" in k else None,
+                "instructions_per_step": {nm: k[key] / cells / steps for nm, key in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS")) if key in k},
+                "fp64_instruction_mix_per_trajectory": {nm[14:].lower(): k[nm] / cells for nm in k if nm.startswith("SQ_INSTS_VALU_")} or None,
+                "effective_clock_ghz": (wave_cyc / secs / 1e9) if n_local <= SIMDS else None,
+                "pmc_file": pmc.get("file"), "pmc_binary_src": pmc.get("build_src"),
+                "pmc_binary_matches": (pmc.get("build_src") in pkg.api.build_info(p)) if pmc.get("build_src") else None,
+                "limiter": "one wavefront per SIMD issuing a dependent fp64 instruction stream: the VALU is busy for `valu_busy_share_of_wave_cycles` of the wave's life and the wave is "
+                           "parked on s_waitcnt (LDS / DPP results of its own previous instructions) for `s_waitcnt_parked_share`; a second resident wave would fill the parked cycles "
+                           "(LDS: 37 kB per cell allows four cells per CU), fewer instructions per step lower both"})
+    return out
 
 
 def usable_cores():
@@ -152,6 +208,45 @@ def host_inclusive(pkg, p, inp, n_local, kernel_ms, calls=None):
                                              "cost of first-touch output arrays, which depends on the allocator state of the calling process"}}
 
 
+def predicted_scaling(pkg, p, n_gpus=8, per_gpu=8192, reps=3):
+    """A PREDICTION, not a measurement, of the 8-GPU run of BASELINE configs[3] (65 536 jittered cells, 8192 per GPU): cells are independent and the data path has no collective
+    ("limited by load imbalance and launch overhead, not bandwidth"), so the 8-GPU launch time is the slowest shard's kernel time.  The eight shards of each
+    partition (PLH_PART_BLOCK: contiguous blocks; PLH_PART_CYCLIC: cell mod 8) are integrated ONE AFTER THE OTHER on this GPU; max / mean over the shards is the
+    load-imbalance efficiency the 8-GPU run will show, 65 536 / max the predicted aggregate rate (before the scatter / gather, whose one-rank host-to-host cost is reported
+    beside it: plh_ensemble_run through a one-rank communicator, no RCCL call)."""
+    import torch
+    n_tot = n_gpus * per_gpu
+    Th_all = np.ascontiguousarray(pkg.configs.c4(p, n_tot)["theta"])
+    out = {"what": "PREDICTION from one GPU: the %d shards of the %d-cell C4 sweep timed back to back on this GPU, block and cyclic partitions; not a SCALE record" % (n_gpus, n_tot)}
+    for part in ("block", "cyclic"):
+        ms = []
+        for g_ in range(n_gpus):
+            idx = np.arange(g_ * per_gpu, (g_ + 1) * per_gpu) if part == "block" else np.arange(g_, n_tot, n_gpus)
+            Th = torch.from_numpy(np.ascontiguousarray(Th_all[idx])).cuda()
+            t = []
+            for r in range(reps + 1):
+                ens = pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0, device=True, max_points=256, YP=False)
+                torch.cuda.synchronize()
+                if r:
+                    t.append(float(ens.kernel_ms))
+            ms.append(float(np.mean(t)))
+        ms = np.array(ms)
+        out[part] = {"shard_kernel_ms": [float(x) for x in ms], "max_over_mean": float(ms.max() / ms.mean()), "predicted_efficiency": float(ms.mean() / ms.max()),
+                     "predicted_8gpu_trajectories_per_s": n_tot / (ms.max() * 1e-3), "single_gpu_trajectories_per_s_mean_shard": per_gpu / (ms.mean() * 1e-3)}
+    # host-to-host cost of the C ABI's multi-GPU entry with one rank (scatter / gather degenerate to host staging): what every rank adds to its kernel time
+    try:
+        from petlion_jl_amd import distributed as pd
+        comm = pd.RcclComm(p._lib, 1, 0, bytes(pd.RcclComm.unique_id(p._lib)), device=torch.cuda.current_device())
+        Th = Th_all[:per_gpu]
+        pd.ensemble_run_capi(comm, p, Th, [{"I": -1.0}], 1.0, n_cells=per_gpu, partition="block")
+        t1 = time.perf_counter(); res = pd.ensemble_run_capi(comm, p, Th, [{"I": -1.0}], 1.0, n_cells=per_gpu, partition="block"); dt = time.perf_counter() - t1
+        out["ensemble_run_one_rank"] = {"wall_ms": 1e3 * dt, "kernel_ms": float(res[3][0]), "host_overhead_ms": 1e3 * dt - float(res[3][0]), "cells": per_gpu}
+        comm.close()
+    except Exception as e:                                   # noqa: BLE001
+        out["ensemble_run_one_rank"] = {"error": repr(e)[:200]}
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-run this command under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on a free local port"""
     import socket
@@ -234,7 +329,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--cells-per-gpu", type=int, default=0)
-    ap.add_argument("--precision", default="f64", choices=("f64", "mixed"))
+    ap.add_argument("--precision", default="f64", choices=("f64", "mixed", "f64_reforder"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--leg-timeout", type=int, default=240, help="N > 1: watchdog of the plh_ensemble_run leg (seconds)")
@@ -334,17 +429,27 @@ def main():
     else:
         rank_kernel_ms = [kavg_ms]
 
-    # measured HBM traffic per launch: PMC counters cannot be collected from inside the timed process, so the value is the one committed under profiles/ for this
-    # exact workload (same command under rocprofv3 --pmc, tools/prof.sh); null otherwise
-    traffic = None
+    # PMC counters cannot be collected from inside the timed process: instruction counts, VALU-busy cycles and HBM traffic per launch are those committed under profiles/ for
+    # this exact workload and binary (the same command under rocprofv3 --pmc in separate passes: tools/prof.sh -> tools/summarize_profile.py -> profiles/<round>_<config>_pmc.json).
+    # Instruction counts are a property of (binary, workload), not of the run: the file records the source hash of the binary it was taken from and a mismatch is reported.
+    pmc, traffic = None, None
     try:
         import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic*.json")), reverse=True):
+        cands = []
+        for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")):
             tj = json.load(open(f))
             if tj.get("cells_per_launch") == n_local and tj.get("workload") == args.config and tj.get("precision", "f64") == args.precision:
-                traffic = float(tj["hbm_bytes_per_launch"]); break
+                cands.append((os.path.basename(f), tj))
+        if cands:
+            pmc = sorted(cands)[-1][1]; pmc["file"] = "profiles/" + sorted(cands)[-1][0]
+            traffic = pmc.get("hbm_bytes_per_launch")
+        else:                                              # r04 and earlier: traffic only
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic*.json")), reverse=True):
+                tj = json.load(open(f))
+                if tj.get("cells_per_launch") == n_local and tj.get("workload") == args.config and tj.get("precision", "f64") == args.precision:
+                    traffic = float(tj["hbm_bytes_per_launch"]); break
     except Exception:
-        traffic = None
+        pmc, traffic = None, None
 
     out = None
     if rank == 0:
@@ -354,19 +459,18 @@ def main():
             "metric": "DFN full-discharge trajectories/sec (ensemble)" if args.config in ("C2", "C4") else "DFN protocol trajectories/sec (ensemble)",
             "value": traj_s, "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == "f64" else "f64 (fp32 storage of the Newton-matrix factors)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f64": "f64", "mixed": "f64 (fp32 storage of the Newton-matrix factors)", "f64_reforder": "f64 (finite-volume rows in the reference's operation order)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": c["text"] % n_local, "cells_per_gpu": n_local, "cells_total": n_total, "sharding": "independent cells, contiguous blocks, no data-path collective",
                        "outputs": "per cell: t, V, I, SOC (and T_avg) at every saved point, Y_final, run_info, counters (YP_final not requested: the reference keeps YP only with var_keep.YP)",
                        "steps_per_trajectory": float(ens.counters["n_steps"].mean()), "newton_iters_per_trajectory": float(ens.counters["n_newton"].mean()),
                        "rank_kernel_ms": rank_kernel_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, from profiles/*_traffic*.json)",
-                         "hbm_utilisation": (traffic / (kavg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "limiter": "dependent-instruction latency at one wavefront per SIMD (LDS-resident cell state; VALU-active / s_waitcnt shares in profiles/): 'achieved' and 'frac' "
-                                    "price the SURVEY 8(d) streaming model's bytes, which this kernel never moves -- read them as an equivalent-streaming rate, 'hbm_utilisation' is the real one",
-                         "kernel": "k_integrate<%s>" % c["variant"], "kernel_ms_avg": kavg_ms, "kernel_ms_last_launch": klast_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                         "algorithmic_bytes_per_trajectory": bytes_launch / n_local},
+            "roofline": issue_roofline(pmc, traffic, n_local, kavg_ms, klast_ms, c, ens, pkg, p),
+            "equivalent_streaming": {"what": "SURVEY.md 8(d) algorithmic bytes (streaming byte model x the device counters) / kernel duration vs the HBM3E peak: the figure r01-r04 "
+                                             "reported as roofline.  The LDS-resident kernel never moves these bytes (see roofline.traffic); a value above 1 means it beats the ceiling a "
+                                             "perfect HBM-streaming implementation of the north star's design would have.  Not a utilisation of anything.",
+                                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                                     "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_trajectory": bytes_launch / n_local},
         }
 
     # ---- N > 1: the C4 sweep through the C ABI's own multi-GPU entry (RCCL scatter -> integrate -> gather), block and cyclic partitions ----
@@ -433,6 +537,8 @@ def main():
         if world == 1 and not args.no_extras:
             out["host_inclusive"] = host_inclusive(pkg, p, inp, n_local, kavg_ms)
             out["general_path"] = general_path(pkg, p, inp, Theta, n_local, kavg_ms)
+            if args.config == "C4" and args.precision == "f64":
+                out["predicted_scaling"] = predicted_scaling(pkg, p)
             # measured device-to-device copy bandwidth of this box (read + write bytes), the second peak SURVEY 8(d) asks to quote
             a = torch.empty(1 << 28, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
             b.copy_(a); torch.cuda.synchronize()

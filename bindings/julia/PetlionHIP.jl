@@ -22,7 +22,7 @@ const VAL_CONST, VAL_HOLD, VAL_REST, VAL_TABLE, VAL_EXPR = Cint(0), Cint(1), Cin
 struct ModelDesc
     chemistry::Cint; N_p::Cint; N_s::Cint; N_n::Cint; N_a::Cint; N_z::Cint; N_r_p::Cint; N_r_n::Cint
     temperature::Cint; aging_SEI::Cint; real_bytes::Cint
-    precision::Cint      # 0 = fp64, 1 = mixed (fp32 storage of the Newton-matrix factors)
+    precision::Cint      # 0 = fp64, 1 = mixed (fp32 storage of the Newton-matrix factors), 2 = fp64 with the finite-volume rows in the reference's operation order (PLH_PREC_F64_REFORDER)
     device::Cint         # HIP device ordinal, -1 = current
     solid_diffusion::Cint; thermodynamic_factor::Cint; rxn::Cint     # 0 Fickian FDM / 1 quadratic / 2 polynomial ; 0 linear / 1 nonlinear ; 0 BV / 1 MHC
     waves_per_cell::Cint  # 1 (default) or 2 wavefronts per cell
@@ -47,6 +47,9 @@ struct Opts
     refine::Cint                                # iterative-refinement steps per linear solve (parity mode), 0 = off
     n_tstops::Cint; tstops::Ptr{Cdouble}       # opts.tstops (run-local times the integrator must hit; src/model_evaluation.jl:292-294), host array
     yp_alg_zero::Cint                           # 1: start the integrator with YP_alg = 0 (step history of the example notebooks' package version), 0 = today's source
+    n_stop::Cint; stop_ops::Ptr{Cdouble}; stop_args::Ptr{Cdouble}   # opts.stop_function as a postfix program g(t, Y, YP, θ) (PLH_OP_* opcodes / operands, host arrays): the run ends when
+                                                # g > 0, exit flag 12, back-interpolated like a built-in bound (src/checks.jl:26); n_stop = 0: none.  A Julia closure is traced into
+                                                # the program the same way an input closure is (closure_program below)
 end
 struct RunInfo
     flag::Cint; iterations::Cint; t_end::Cdouble; V::Cdouble; I::Cdouble; SOC::Cdouble; T_avg::Cdouble
@@ -209,7 +212,7 @@ function simulate_ensemble(m::Model, p, Θ::Matrix{Float64}, protocol; SOC = p.o
     o = p.opts
     td = Float64.(o.tdiscon); ts = Float64.(o.tstops)
     opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0,
-                    length(td), isempty(td) ? C_NULL : pointer(td), refine, length(ts), isempty(ts) ? C_NULL : pointer(ts), 0))
+                    length(td), isempty(td) ? C_NULL : pointer(td), refine, length(ts), isempty(ts) ? C_NULL : pointer(ts), 0, 0, C_NULL, C_NULL))
     Θt = permutedims(Θ)                                   # column-major n_theta × n_cells == row-major cells
     soc = SOC isa Number ? fill(Float64(SOC), n) : Vector{Float64}(SOC)
     t = zeros(max_pts, n); V = similar(t); I = similar(t); S = similar(t)
@@ -245,7 +248,7 @@ function simulate_ensemble_sens(m::Model, p, Θ::Matrix{Float64}, protocol, keys
     runs = [make_run(p, s) for s in protocol]
     o = p.opts
     ts = Float64.(o.tstops)
-    opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0, 0, C_NULL, 0, length(ts), isempty(ts) ? C_NULL : pointer(ts), 0))
+    opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0, 0, C_NULL, 0, length(ts), isempty(ts) ? C_NULL : pointer(ts), 0, 0, C_NULL, C_NULL))
     cols = Cint[key_index(m, k) - 1 for k in keys]
     ns = length(cols)
     Θt = permutedims(Θ)
@@ -339,7 +342,7 @@ function ensemble_run(c::Comm, m::Model, p, Θ::Matrix{Float64}, protocol; SOC =
     info = Matrix{RunInfo}(undef, length(runs), root ? n_cells : 0); cnt = Vector{Counters}(undef, root ? n_cells : 0); ms = zeros(comm_size(c))
     GC.@preserve td ts Θt soc info cnt ms begin
         opts = Ref(Opts(o.abstol, o.reltol, o.abstol, o.reltol, o.maxiters, o.check_bounds, o.interp_final, 5, 0, 0.0,
-                        length(td), isempty(td) ? C_NULL : pointer(td), refine, length(ts), isempty(ts) ? C_NULL : pointer(ts), 0))
+                        length(td), isempty(td) ? C_NULL : pointer(td), refine, length(ts), isempty(ts) ? C_NULL : pointer(ts), 0, 0, C_NULL, C_NULL))
         check(ccall((:plh_ensemble_run, lib), Cint,
                     (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Run}, Ref{Opts}, Cint, Ptr{RunInfo}, Ptr{Counters}, Ptr{Cdouble}, Ptr{Cdouble}),
                     c.h, m.h, n_cells, root ? pointer(Θt) : C_NULL, root ? pointer(soc) : C_NULL, length(runs), runs, opts, partition === :cyclic ? 1 : 0,

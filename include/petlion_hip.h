@@ -77,6 +77,11 @@ extern "C" {
 /* plh_model_desc.precision */
 #define PLH_PREC_F64 0    /* everything fp64 (default; the parity configuration) */
 #define PLH_PREC_MIXED 1  /* block-Thomas factors and particle resolvents stored in fp32 in LDS; states, residuals, Jacobian entries, time, error control fp64 */
+#define PLH_PREC_F64_REFORDER 2 /* everything fp64, and the finite-volume rows (c_e, Phi_e, heat conduction) evaluated in the reference's OPERATION ORDER: matrix form A x - f with
+                                   every product rounded before the sum (src/physics_equations/residuals.jl:6-106, 554-654, 299-489) instead of the default build's
+                                   conservative edge-flux / difference form.  Same equations and Jacobian; the rows carry the reference's evaluation rounding, so the
+                                   integrator's step / order decisions in :hold legs follow the reference's more closely.  LCO isothermal and LCO with
+                                   temperature. */
 
 /* how `value` is obtained (reference input_methods.jl:11-30,53-63; model_evaluation.jl:165-170) */
 #define PLH_VAL_CONST 0
@@ -130,6 +135,7 @@ extern "C" {
 #define PLH_ERR_STALL (-12)     /* "Model failed to converge at t = ...", src/checks.jl:233,236 */
 #define PLH_ERR_MAXITERS (-13)  /* "Reached max iterations", src/checks.jl:239 */
 #define PLH_ERR_OUTPUT_FULL (-14)
+#define PLH_FLAG_STOP_FUNCTION 12   /* the run ended on the caller's stop function (plh_opts.stop_ops): the reference's opts.stop_function hook, src/checks.jl:26 */
 
 typedef struct plh_model_s* plh_model_t;
 
@@ -200,6 +206,13 @@ typedef struct {
                                                         (src/model_evaluation.jl:462-477).  1: the integrator starts with YP_alg = 0, as the package version that produced the
                                                         reference's example notebooks did -- with it the printed step history of examples/model_inputs_and_outputs.ipynb
                                                         (121 saved points, sol.V[1:13], sol.c_e[1:5]) is reproduced to 1e-8 (tests/golden/notebook_kats.json) */
+  /* opts.stop_function (src/structures.jl:283, called after the eleven built-in checks at every accepted step, src/checks.jl:26; simulate(...; stop_function), src/model_evaluation.jl:32).
+     A Julia closure cannot cross the C ABI; its expression can: ONE postfix program g(t, Y, YP, theta) in the PLH_OP_* vocabulary of PLH_VAL_EXPR (n_stop instructions, opcodes in
+     stop_ops stored as doubles, operands in stop_args; HOST arrays staged like tdiscon; t = run-local time).  The run ends when g > 0 (g - 0 > eps with the eps of the built-in checks:
+     reltol while t < 1 s, else 0), exit flag PLH_FLAG_STOP_FUNCTION, with the interpolation fraction g_prev / (g_prev - g) entering the same linear back-interpolation as the
+     built-in bounds (interp_final_points!, src/model_evaluation.jl:369-382; the smallest fraction of all checks that fired wins, as in the reference).  Skipped in :rest runs and
+     with check_bounds = 0, like every other check.  n_stop = 0: none. */
+  int n_stop; const double* stop_ops; const double* stop_args;
 } plh_opts;
 
 /* per-cell, per-run summary == run_info + the printed summary (src/structures.jl:40-44, 678-746) */

@@ -56,6 +56,12 @@ VARIANTS = {
     # the LCO thermal model with the heat-conduction stencil evaluated on temperature differences (dfn_model.Model.t_conduction): same equations, 1e4 x less rounding in the
     # sum of the T rows that the dT control row and its twin form -- the tight-tolerance counterpart of the device's evaluation
     "lco_thermal_tdiff": dict(cathode="LCO", temperature=True, t_conduction="difference"),
+    # r05: the same two models with EVERY stencil that cancels large terms evaluated on differences -- T rows as in lco_thermal_tdiff and the [1, -2, 1] Laplacian of the Φ_s rows
+    # (Model.phi_s_form): the generated "matrix" rows add the 1e-6 V source to a 4 V potential before the Laplacian cancels and come out quantised at 8.9e-16 V, which J^-1
+    # amplifies above the local error of the first steps of a :hold leg.  Same equations; the evaluation order the device has.
+    "lco_iso_quiet": dict(cathode="LCO", phi_s_form="difference"),
+    "lco_thermal_quiet": dict(cathode="LCO", temperature=True, t_conduction="difference", phi_s_form="difference"),
+    "nmc_iso_sei_quiet": dict(cathode="NMC", temperature=False, aging=True, phi_s_form="difference"),      # config C5's model
     "lgm50_thermal": dict(cathode="LGM50", temperature=True),      # ... with temperature = true, the reference default of that chemistry (params.jl:695)
     # other discretisations (reference src/params.jl:119-136); the name suffix is _g<N_p>_<N_s>_<N_n>_<N_r>
     "lco_iso_g12_7_9_11": dict(cathode="LCO", Np=12, Ns=7, Nn=9, Nrp=11, Nrn=11),
@@ -138,8 +144,8 @@ def generate(name, verbose=True):
                         entries[(r, ysym[t])] = entries.get((r, ysym[t]), 0) + d * dt
     # intermediates that stay named in the RESIDUAL code (dT_k: the temperature differences of Model.t_conduction = "difference" -- substituting them back would let sympy
     # merge (T[k+1] - T[k]) - (T[k] - T[k-1]) into T[k-1] - 2 T[k] + T[k+1], the very cancellation they avoid); the Jacobian entries take all of them back
-    kept = {a: e for a, e in aux.items() if str(a).startswith("dT_")}
-    kept_defs = sorted(kept.items(), key=lambda ae: int(str(ae[0])[3:]))
+    kept = {a: e for a, e in aux.items() if str(a).startswith(("dT_", "dPs_"))}          # (dPs_k: the potential differences of Model.phi_s_form = "difference", for the same reason)
+    kept_defs = sorted(kept.items(), key=lambda ae: (str(ae[0]).split("_")[0], int(str(ae[0]).split("_")[1])))
     if aux:
         sub = {a: e for a, e in aux.items() if a not in kept}
         res = [e.xreplace(sub) for e in res]
@@ -183,7 +189,7 @@ def generate(name, verbose=True):
     L.append("const char* const %s_theta_keys[%d] = {%s};\n" % (pre, P, ",".join('"%s"' % k for k in keys)))
     sig = "double* out, const double* Y, const double* YP, const double* th"
     _emit_block(pre + "_f_diff", sig, res[:Nd], "out", pr, L, kept_defs)
-    _emit_block(pre + "_f_alg", sig, res[Nd:], "out", pr, L)
+    _emit_block(pre + "_f_alg", sig, res[Nd:], "out", pr, L, kept_defs)
     sigj = "double* nz, const double* Y, const double* YP, double cj, const double* th"
     _emit_block(pre + "_jac", sigj, nzexpr, "nz", pr, L)
     _emit_block(pre + "_jac_alg", sigj, a_expr, "nz", pr, L)

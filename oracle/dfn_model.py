@@ -262,7 +262,7 @@ class Layout:
 
 
 class Model:
-    def __init__(self, cathode="LCO", temperature=False, aging=False, solid_diffusion="Fickian", thermodynamic_factor="linear", rxn="BV", t_conduction="matrix", **Nkw):
+    def __init__(self, cathode="LCO", temperature=False, aging=False, solid_diffusion="Fickian", thermodynamic_factor="linear", rxn="BV", t_conduction="matrix", phi_s_form="matrix", **Nkw):
         """solid_diffusion: "Fickian" (finite difference), "quadratic", "polynomial" (params.jl:140); thermodynamic_factor: "linear" (nu = 1) or
         "nonlinear" (custom_functions.jl:177-203); rxn: "BV" or "MHC" for both electrodes (custom_functions.jl:212-298)"""
         assert solid_diffusion in ("Fickian", "quadratic", "polynomial") and thermodynamic_factor in ("linear", "nonlinear") and rxn in ("BV", "MHC")
@@ -273,6 +273,14 @@ class Model:
         # lco_thermal_tdiff exists so that the dT = :hold leg -- whose control row sums all fifty rows -- can be compared at tight tolerances.
         assert t_conduction in ("matrix", "difference")
         self.t_conduction = t_conduction
+        # phi_s_form: how the [1, -2, 1] Laplacian of residuals_Φ_s! (residuals.jl:656-703: block_tridiag(N) * Φ_s .- f) is EVALUATED.  "matrix": Φ_s[i-1] - 2 Φ_s[i] + Φ_s[i+1] - f_i
+        # as ONE sum, which the code generator orders its own way -- the generated C adds the source term f_i ~ 1e-6 V to a potential of ~4 V BEFORE the Laplacian cancels, so the
+        # row comes out quantised at ulp(Φ_s) = 8.9e-16 V (cathode).  J^-1 turns that into ~5e-11 V of common-mode noise in Φ_e / Φ_s and 1e-9 in I: 4e-8 ... 4e-7 in the weighted
+        # norm, i.e. ABOVE the local error (1e-8) of the first steps of a :hold leg, which restarts at h = 1e-3 s -- IDA's start-up order selection then reads noise (r05,
+        # DESIGN.md 5; measured with ORC_TRACE_EE).  "difference": the same stencil on named differences dPs_k = Φ_s[k+1] - Φ_s[k] (exact), like t_conduction = "difference".
+        # Algebraically identical; which of the two orders the reference's own generated code has is not knowable here (Symbolics' term order; no Julia).
+        assert phi_s_form in ("matrix", "difference")
+        self.phi_s_form = phi_s_form
         self.solid_diffusion, self.thermodynamic_factor, self.rxn = solid_diffusion, thermodynamic_factor, rxn
         self.lay = Layout(temperature=temperature, aging=aging, solid_diffusion=solid_diffusion, **Nkw)
         self.theta = {"LCO": theta_LCO, "NMC": theta_NMC, "LGM50": theta_LGM50}[cathode]()
@@ -691,13 +699,19 @@ def residual(model, ops, Y, YP, th, mode=MODE_I, value=0.0, with_control=True):
         res[lay.Phi_e[0] + i] = APhi[i] - f[i]
 
     # --- residuals_Φ_s! (residuals.jl:656-703) ---
+    Ps_p = Phi_s[:Np]; Ps_n = Phi_s[Np:]
+    ps_diff = model.phi_s_form == "difference"
+    dPs = {id(v): [ops.aux("dPs_%d" % (off + k), v[k + 1] - v[k]) for k in range(len(v) - 1)] for v, off in ((Ps_p, 0), (Ps_n, Np))} if ps_diff else None
+
     def lap(v, i, n):
+        if ps_diff:
+            d = dPs[id(v)]
+            return d[0] if i == 0 else (-d[n - 2] if i == n - 1 else d[i] - d[i - 1])
         if i == 0:
             return -v[0] + v[1]
         if i == n - 1:
             return v[n - 2] - v[n - 1]
         return v[i - 1] - 2 * v[i] + v[i + 1]
-    Ps_p = Phi_s[:Np]; Ps_n = Phi_s[Np:]
     for i in range(Np):
         fp_ = hp ** 2 * a_p * F * jt[i]
         if i == 0:

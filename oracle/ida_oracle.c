@@ -93,6 +93,15 @@ DECL_VARIANT(lgm50_thermal) DECL_THERMAL(lgm50_thermal)
 #ifdef ORC_HAVE_lco_thermal_tdiff
 DECL_VARIANT(lco_thermal_tdiff) DECL_THERMAL(lco_thermal_tdiff)
 #endif
+#ifdef ORC_HAVE_lco_thermal_quiet
+DECL_VARIANT(lco_thermal_quiet) DECL_THERMAL(lco_thermal_quiet)
+#endif
+#ifdef ORC_HAVE_lco_iso_quiet
+DECL_VARIANT(lco_iso_quiet)
+#endif
+#ifdef ORC_HAVE_nmc_iso_sei_quiet
+DECL_VARIANT(nmc_iso_sei_quiet)
+#endif
 #ifdef ORC_HAVE_lco_iso_sei
 DECL_VARIANT(lco_iso_sei)
 #endif
@@ -163,6 +172,9 @@ static int get_model(const char* name, orc_model* m) {
 #ifdef ORC_HAVE_lco_iso
   if (!strcmp(name, "lco_iso")) { FILL_VARIANT(m, lco_iso, 0, 0); return 0; }
 #endif
+#ifdef ORC_HAVE_lco_iso_quiet
+  if (!strcmp(name, "lco_iso_quiet")) { FILL_VARIANT(m, lco_iso_quiet, 0, 0); return 0; }
+#endif
 #ifdef ORC_HAVE_lco_thermal
   if (!strcmp(name, "lco_thermal")) { FILL_VARIANT(m, lco_thermal, 1, 0);
     m->nnz_twin = orc_lco_thermal_NNZ_DT_TWIN; m->twin_cols = orc_lco_thermal_dT_twin_cols;
@@ -173,6 +185,12 @@ static int get_model(const char* name, orc_model* m) {
   if (!strcmp(name, "lco_thermal_tdiff")) { FILL_VARIANT(m, lco_thermal_tdiff, 1, 0);
     m->nnz_twin = orc_lco_thermal_tdiff_NNZ_DT_TWIN; m->twin_cols = orc_lco_thermal_tdiff_dT_twin_cols;
     m->dT_twin = orc_lco_thermal_tdiff_dT_twin; m->dT_twin_jac = orc_lco_thermal_tdiff_dT_twin_jac; m->dT_weights = orc_lco_thermal_tdiff_dT_weights;
+    return 0; }
+#endif
+#ifdef ORC_HAVE_lco_thermal_quiet
+  if (!strcmp(name, "lco_thermal_quiet")) { FILL_VARIANT(m, lco_thermal_quiet, 1, 0);
+    m->nnz_twin = orc_lco_thermal_quiet_NNZ_DT_TWIN; m->twin_cols = orc_lco_thermal_quiet_dT_twin_cols;
+    m->dT_twin = orc_lco_thermal_quiet_dT_twin; m->dT_twin_jac = orc_lco_thermal_quiet_dT_twin_jac; m->dT_weights = orc_lco_thermal_quiet_dT_weights;
     return 0; }
 #endif
 #ifdef ORC_HAVE_lgm50_thermal
@@ -189,6 +207,9 @@ static int get_model(const char* name, orc_model* m) {
 #endif
 #ifdef ORC_HAVE_nmc_iso_sei
   if (!strcmp(name, "nmc_iso_sei")) { FILL_VARIANT(m, nmc_iso_sei, 0, 1); return 0; }
+#endif
+#ifdef ORC_HAVE_nmc_iso_sei_quiet
+  if (!strcmp(name, "nmc_iso_sei_quiet")) { FILL_VARIANT(m, nmc_iso_sei_quiet, 0, 1); return 0; }
 #endif
 #ifdef ORC_HAVE_nmc_iso
   if (!strcmp(name, "nmc_iso")) { FILL_VARIANT(m, nmc_iso, 0, 0); return 0; }
@@ -416,6 +437,9 @@ typedef struct {   /* reference options_simulation, src/structures.jl:266-285 */
      (splitmix64 of perturb_seed, an evaluation counter and the row).  A second correct fp64 implementation differs from this one in exactly that way in every evaluation
      (flux form or matrix form of a stencil, the order of a sum), not only in the one evaluation fd_perturb touches. */
   double res_perturb;
+  /* opts.stop_function (src/structures.jl:283; called after the built-in checks at every accepted step, src/checks.jl:26) as a postfix program g(t, Y, YP, theta) -- the
+     form in which the product's C ABI takes it (plh_opts.stop_ops): the run ends when g > 0, flag 12, interpolation fraction g_prev / (g_prev - g); n_stop = 0: none */
+  int n_stop; const double* stop_ops; const double* stop_args;
 } orc_opts;
 
 typedef struct {
@@ -502,10 +526,14 @@ static double tab_eval(const orc_run* r, double t) {
   const double dt = tt[k + 1] - tt[k];
   return dt > 0.0 ? vv[k] + (vv[k + 1] - vv[k]) * ((t - tt[k]) / dt) : vv[k + 1];
 }
+static double prog_eval_range(const double* ops, const double* args, double t, const double* Y, const double* YP, const double* th, int k0, int k1);
 static double expr_eval_range(const orc_run* r, double t, const double* Y, const double* YP, const double* th, int k0, int k1) {
+  return prog_eval_range(r->tab_t, r->tab_v, t, Y, YP, th, k0, k1);
+}
+static double prog_eval_range(const double* ops, const double* args, double t, const double* Y, const double* YP, const double* th, int k0, int k1) {
   double st[64]; int sp = 0;
   for (int k = k0; k < k1; k++) {
-    const int op = (int)r->tab_t[k]; const double a = r->tab_v[k];
+    const int op = (int)ops[k]; const double a = args[k];
     switch (op) {
       case OP_CONST: st[sp++] = a; break; case OP_T: st[sp++] = t; break; case OP_Y: st[sp++] = Y[(int)a]; break; case OP_YP: st[sp++] = YP[(int)a]; break;
       case OP_THETA: st[sp++] = th[(int)a]; break;
@@ -885,6 +913,7 @@ static int ida_nls(ida_t* I) {
 static int ida_test_error(ida_t* I, double ck, double* err_k, double* err_km1) {
   int N = I->N, kk = I->kk;
   double enorm_k = wrms(N, I->ee, I->ewt);
+  if (getenv("ORC_TRACE_EE") && I->nst < atoi(getenv("ORC_TRACE_EE"))) for (int n = 0; n < N; n++) fprintf(stderr, "orc ee %d %d %.6e %.6e\n", I->nst + 1, n, I->ee[n], I->ee[n] * I->ewt[n]);
   *err_k = I->sigma[kk] * enorm_k; double terr_k = (kk + 1) * (*err_k);
   I->knew = kk; *err_km1 = 0.0;
   if (kk > 1) {
@@ -1012,7 +1041,7 @@ static int ida_step(ida_t* I, double tstop, double* tret, double* yret, double* 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* PETLION run logic                                                                                            */
 /* ------------------------------------------------------------------------------------------------------------ */
-typedef struct { double frac, V, SOC, T, c_s_n, I, eta_plating, c_e_min, dfilm; } prev_vals;   /* src/structures.jl:174-184 */
+typedef struct { double frac, V, SOC, T, c_s_n, I, eta_plating, c_e_min, dfilm, g; } prev_vals;   /* src/structures.jl:174-184 */
 
 static double calc_V(const orc_model* m, const double* Y) { return Y[m->o_ps] - Y[m->o_ps + m->Np + m->Nn - 1]; }
 static double calc_Tavg(const orc_model* m, const double* w, const double* Y, double T0) {
@@ -1070,6 +1099,11 @@ static void check_stop(const orc_model* m, const evalb* e, const orc_run* run, c
     double dmax = -INFINITY; for (int i = 0; i < m->Nn; i++) dmax = fmax(dmax, YP[m->o_film + i]);
     if (!isnan(b->dfilm_max) && dmax - b->dfilm_max > eps) { double tf_ = (pv->dfilm - b->dfilm_max) / (pv->dfilm - dmax); if (tf_ < pv->frac) { pv->frac = tf_; *flag = 10; } }
     pv->dfilm = dmax;
+  }
+  if (o->n_stop > 0) {                                               /* opts.stop_function, checks.jl:26 */
+    double g = prog_eval_range(o->stop_ops, o->stop_args, t, Y, YP, e->th, 0, o->n_stop);
+    if (g > eps) { double tf_ = pv->g / (pv->g - g); if (tf_ < pv->frac) { pv->frac = tf_; *flag = 12; } }
+    pv->g = g;
   }
 }
 
@@ -1184,7 +1218,7 @@ static int simulate_core(orc_ctx* ctx, const double* theta, double SOC0, int n_r
     for (int a = 1; a < nts; a++) { double v = tstops[a]; int b = a - 1; while (b >= 0 && tstops[b] > v) { tstops[b + 1] = tstops[b]; b--; } tstops[b + 1] = v; }   /* sort! */
     { int first = 0; while (first < nts && tstops[first] <= 0.0) first++; if (first) { for (int a = first; a < nts; a++) tstops[a - first] = tstops[a]; nts -= first; } }
     { int w_ = 0; for (int a = 0; a < nts; a++) if (tstops[a] <= run->tf) tstops[w_++] = tstops[a]; nts = w_; }   /* stops beyond tf are never reached */
-    prev_vals pv = {1.0, -1, -1, -1, -1, -1, -1, -1, -1};
+    prev_vals pv = {1.0, -1, -1, -1, -1, -1, -1, -1, -1, -1};
     int flag = -1;
     /* set_vars! at t=0 of a new solution: a continuation run does not add a point (t0 = nextfloat(t_end)) ...
        the reference does push one (set_vars! is unconditional), so we do too. */

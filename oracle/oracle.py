@@ -35,7 +35,8 @@ class Opts(C.Structure):
     _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("abstol_init", C.c_double), ("reltol_init", C.c_double),
                 ("maxiters", C.c_int), ("check_bounds", C.c_int), ("interp_final", C.c_int), ("max_order", C.c_int),
                 ("jac_every_step", C.c_int), ("init_step", C.c_double), ("n_tdiscon", C.c_int), ("tdiscon", C.POINTER(C.c_double)),
-                ("refine", C.c_int), ("fd_perturb", C.c_double), ("perturb_seed", C.c_int), ("n_tstops", C.c_int), ("tstops", C.POINTER(C.c_double)), ("exp_yp_alg_zero", C.c_int), ("res_perturb", C.c_double)]
+                ("refine", C.c_int), ("fd_perturb", C.c_double), ("perturb_seed", C.c_int), ("n_tstops", C.c_int), ("tstops", C.POINTER(C.c_double)), ("exp_yp_alg_zero", C.c_int), ("res_perturb", C.c_double),
+                ("n_stop", C.c_int), ("stop_ops", C.POINTER(C.c_double)), ("stop_args", C.POINTER(C.c_double))]
 
 
 class RunInfo(C.Structure):
@@ -83,6 +84,7 @@ def default_opts(**over):
     d = dict(abstol=1e-6, reltol=1e-3, maxiters=10000, check_bounds=1, interp_final=1, max_order=5, jac_every_step=0, init_step=0.0, refine=0, fd_perturb=0.0, perturb_seed=0, exp_yp_alg_zero=0, res_perturb=0.0)
     tdiscon = np.ascontiguousarray(list(over.pop("tdiscon", [])), dtype=np.float64)
     tstops = np.ascontiguousarray(list(over.pop("tstops", [])), dtype=np.float64)
+    stop = over.pop("stop_program", None)               # (opcodes, operands): opts.stop_function as the postfix program the product's C ABI takes (plh_opts.stop_ops)
     d.update(over)
     d.setdefault("abstol_init", d["abstol"])
     d.setdefault("reltol_init", d["reltol"])
@@ -92,6 +94,11 @@ def default_opts(**over):
     o.n_tstops = tstops.size
     o.tstops = _dp(tstops) if tstops.size else None
     o._keep = (tdiscon, tstops)
+    o.n_stop, o.stop_ops, o.stop_args = 0, None, None
+    if stop is not None:
+        so, sa = np.ascontiguousarray(stop[0], dtype=np.float64), np.ascontiguousarray(stop[1], dtype=np.float64)
+        o.n_stop, o.stop_ops, o.stop_args = so.size, _dp(so), _dp(sa)
+        o._keep = o._keep + (so, sa)
     return o
 
 

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PETLION_HIP_LIB") or os.path.join(HERE, "libpetlion_hip.so")     # the override is for build experiments (tools/opt_level_check.sh)
 
 PLH_HOST, PLH_DEVICE, PLH_HOST_ASYNC = 0, 1, 2
-PREC_F64, PREC_MIXED = 0, 1
+PREC_F64, PREC_MIXED, PREC_F64_REFORDER = 0, 1, 2
 PART_BLOCK, PART_CYCLIC = 0, 1
 MODE_I, MODE_V, MODE_DT, MODE_P, MODE_ETA_P, MODE_RES, MODE_DSTATE = 0, 1, 2, 3, 4, 5, 6
 DSTATE = {"dc_s_p_max": 1, "dc_s_p_min": 2, "dc_s_n_max": 3, "dc_s_n_min": 4, "dc_e_max": 5, "dc_e_min": 6}
@@ -47,7 +47,8 @@ class Opts(C.Structure):
     _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("abstol_init", C.c_double), ("reltol_init", C.c_double),
                 ("maxiters", C.c_int), ("check_bounds", C.c_int), ("interp_final", C.c_int), ("max_order", C.c_int),
                 ("jac_every_step", C.c_int), ("init_step", C.c_double), ("n_tdiscon", C.c_int), ("tdiscon", C.POINTER(C.c_double)),
-                ("refine", C.c_int), ("n_tstops", C.c_int), ("tstops", C.POINTER(C.c_double)), ("yp_alg_zero", C.c_int)]
+                ("refine", C.c_int), ("n_tstops", C.c_int), ("tstops", C.POINTER(C.c_double)), ("yp_alg_zero", C.c_int),
+                ("n_stop", C.c_int), ("stop_ops", C.POINTER(C.c_double)), ("stop_args", C.POINTER(C.c_double))]
 
 
 class RunInfo(C.Structure):

@@ -48,12 +48,14 @@ class Model:
         self.bounds = {LCO: bounds_LCO, NMC: bounds_NMC, NMC_LGM50: bounds_LGM50}[cathode]()
         self.opts = Opts()
         self._lib = cap.load(lib_path)
+        self._lib_path = lib_path
         self._builtin_lib = lib_path is None          # the product library (not the tests' emulator build / an experiment build)
-        if precision not in ("f64", "mixed"):
-            raise ValueError("precision: 'f64' or 'mixed' (fp32 storage of the Newton-matrix factors, everything else fp64)")
+        if precision not in ("f64", "mixed", "f64_reforder"):
+            raise ValueError("precision: 'f64', 'mixed' (fp32 storage of the Newton-matrix factors, everything else fp64) or 'f64_reforder' (fp64 with the finite-volume rows in the "
+                             "reference's operation order: PLH_PREC_F64_REFORDER)")
         self.precision = precision
         desc = cap.ModelDesc({LCO: cap.CHEM_LCO, NMC: cap.CHEM_NMC, NMC_LGM50: cap.CHEM_LGM50}[cathode], N.p, N.s, N.n, N.a, N.z, N.r_p, N.r_n, int(self.temperature), int(bool(aging)), 8,
-                             cap.PREC_MIXED if precision == "mixed" else cap.PREC_F64, int(device),
+                             {"f64": cap.PREC_F64, "mixed": cap.PREC_MIXED, "f64_reforder": cap.PREC_F64_REFORDER}[precision], int(device),
                              {"Fickian": 0, "quadratic": 1, "polynomial": 2}[solid_diffusion], {"linear": 0, "nonlinear": 1}[thermodynamic_factor], {"BV": 0, "MHC": 1}[rxn], int(waves_per_cell))
         self.waves_per_cell = int(waves_per_cell)
         self.solid_diffusion, self.thermodynamic_factor, self.rxn = solid_diffusion, thermodynamic_factor, rxn
@@ -66,11 +68,13 @@ class Model:
         if grid_lib is None and g != grids.DEFAULT:
             if lib_path is not None:
                 raise ValueError("a non-default discretisation with an explicit library path needs grid_lib= as well")
-            vid = grids.variant_id({LCO: "LCO_LIC6", NMC: "NMC_LIC6", NMC_LGM50: "LGM50"}[cathode], bool(aging), self.temperature, precision == "mixed",
+            vid = grids.variant_id({LCO: "LCO_LIC6", NMC: "NMC_LIC6", NMC_LGM50: "LGM50"}[cathode], bool(aging), self.temperature, {"f64": 0, "mixed": 1, "f64_reforder": 2}[precision],
                                    solid_diffusion.upper(), thermodynamic_factor.upper(), rxn, waves_per_cell == 2)
             if vid is None:
                 raise NotImplementedError("this combination of model options is not instantiated on the device")
             grid_lib = grids.library(g, [vid])
+            if os.path.exists(grid_lib + ".use_licm"):          # this library failed the kernel self-test on this machine: its fall-back build (api.petlion)
+                grid_lib = grids.library(g, [vid], machine_licm=True)
             self._grid_lib_built = grid_lib
         if grid_lib:                                     # (False: register nothing -- the tests' way to reach the C ABI's own refusal)
             cap.check(self._lib, self._lib.plh_register_grid_library(os.fsencode(grid_lib)), "plh_register_grid_library")
@@ -142,9 +146,24 @@ def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_
         raise NotImplementedError("solid diffusion: Fickian (finite_difference), quadratic and polynomial are built; the BETA spectral method is not (SURVEY.md 8f)")
     if thermodynamic_factor not in ("linear", "nonlinear") or rxn_p not in ("BV", "MHC") or rxn_n != rxn_p:
         raise NotImplementedError("thermodynamic_factor: linear / nonlinear; rxn_p = rxn_n in (BV, MHC)")
-    p = Model(cathode, _N(p=N_p, s=N_s, n=N_n, a=N_a, z=N_z, r_p=N_r_p, r_n=N_r_n), temperature, aging, _lib_path, precision, device, solid_diffusion, thermodynamic_factor, rxn_p, waves_per_cell, _grid_lib)
+    mk = lambda: Model(cathode, _N(p=N_p, s=N_s, n=N_n, a=N_a, z=N_z, r_p=N_r_p, r_n=N_r_n), temperature, aging, _lib_path, precision, device, solid_diffusion, thermodynamic_factor, rxn_p, waves_per_cell, _grid_lib)
+    p = mk()
     p.opts.SOC = SOC
-    _selftest_new_grid_library(p)
+    try:
+        _selftest_new_grid_library(p)
+    except RuntimeError as err:
+        # a grid library compiled here with the built-in flags (buildflags.py) failed the kernel self-test: ONE rebuild with MachineLICM on -- the flag set every grid library of
+        # r04 passed under -- is registered after it (the latest registration wins in plh_model_create) and checked the same way; the marker makes later processes go there directly
+        import warnings
+        lib = getattr(p, "_grid_lib_built", None)
+        if not lib or lib.endswith("_licm.so"):
+            raise
+        warnings.warn("petlion.jl_amd: %s -- rebuilding %s with MachineLICM on (fall-back flags)" % (err, os.path.basename(lib)), RuntimeWarning)
+        with open(lib + ".use_licm", "w") as f:
+            f.write(str(err) + "\n")
+        p = mk()
+        p.opts.SOC = SOC
+        _selftest_new_grid_library(p)
     _selftest_unvalidated_build(p)
     return p
 
@@ -166,6 +185,12 @@ def selftest(p, n_cells=2, tf=100.0):
     bad = None
     if not ((base.run_info["flag"][:, 0] == 0).all() and np.abs(base.run_info["SOC"][:, 0] - (1.0 - tf / 3600.0)).max() < 1e-11 and np.abs(base.SOC[:, 0] - 1.0).max() == 0.0):
         bad = "plain"
+    if not bad:
+        # every comparison below is against the PLAIN kernel of the same build: a wrong plain kernel would pass them all.  Known answer first.
+        why = known_answer_check(p)
+        if why:
+            raise RuntimeError("kernel self-test failed: the plain kernel of %s does not reproduce the known answer of the validated binary (%s) -- a miscompiled or modified build "
+                               "(DESIGN.md 5a)" % (p.variant, why))
     for name, proto, o, vtol in cases:
         if bad:
             break
@@ -185,12 +210,94 @@ def selftest(p, n_cells=2, tf=100.0):
                 bad = name
                 break
     if not bad and p.waves_per_cell != 2:
+        # (compared like the other instantiations -- flags and end times equal, SOC to 1e-11, voltage and states within the tolerance the run was made at: the sensitivity kernel
+        #  is another compilation of the step loop, and on a build other than the validated one its sums may be contracted differently; bit-identity is what the validated
+        #  binary shows, tests/test_sensitivities.py, not what a correct build must show)
         e = simulate_ensemble(p, Th, [{"I": -1.0, "tf": tf}], SOC=1.0, sens=[p.θ_keys[0]])
-        if not (np.array_equal(e.Y, base.Y) and np.array_equal(e.run_info["flag"], base.run_info["flag"]) and (np.asarray(e.sens_stat)[:, 1] == 0).all()):
+        scale = np.abs(base.Y).max(axis=0) + 1e-300
+        if not (np.array_equal(e.run_info["flag"], base.run_info["flag"]) and np.abs(e.run_info["t_end"] - base.run_info["t_end"]).max() == 0.0
+                and np.abs(e.run_info["SOC"] - base.run_info["SOC"]).max() < 1e-11 and np.abs(e.run_info["V"] - base.run_info["V"]).max() <= 2e-3
+                and (np.abs(e.Y - base.Y) / scale).max() <= 10 * p.opts.reltol and (np.asarray(e.sens_stat)[:, 1] == 0).all()):
             bad = "sensitivity"
     if bad:
         raise RuntimeError("kernel self-test failed: the %s instantiation of %s does not reproduce the plain kernel on a 1C discharge -- a miscompiled build "
                            "(rebuild; see DESIGN.md 5a)" % (bad, p.variant))
+
+
+_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "selftest_golden.json")
+KA_TOL = 2e-6        # 200 x the reltol of the known-answer protocol: two correct builds (other compiler, other contraction of a sum) agree to ~1e-7 there (tests/test_gpu_tight.py)
+
+
+def known_answer_protocol(p):
+    """the fixed protocol of the kernel self-test's known answer: 2 cells (default theta; D_sp x 1.3, k_n x 0.8), 3 runs (1C discharge 100 s, V hold 50 s, rest 50 s) at reltol
+    1e-8 / abstol 1e-10 -- tight, so that the result does not depend on the last bits of the step selection (at the default tolerances two correct builds differ by 1e-6)"""
+    Th = np.tile(p.theta_vector(), (2, 1))
+    Th[1, p.θ_keys.index("D_sp")] *= 1.3
+    Th[1, p.θ_keys.index("k_n")] *= 0.8
+    o = Opts()
+    o.reltol, o.abstol, o.reltol_init, o.abstol_init, o.maxiters = 1e-8, 1e-10, 1e-8, 1e-10, 100000
+    return Th, [{"I": -1.0, "tf": 100.0}, {"V": "hold", "tf": 50.0}, {"I": "rest", "tf": 50.0}], o
+
+
+def known_answer_digest(p):
+    """what is compared: per run (t_end, V, I, SOC), per state section of the end state (max |Y|, sum Y)"""
+    Th, proto, o = known_answer_protocol(p)
+    e = simulate_ensemble(p, Th, proto, SOC=1.0, opts=o, max_points=20000)
+    d = {"flags": e.run_info["flag"].tolist(), "t_end": e.run_info["t_end"].tolist(), "V": e.run_info["V"].tolist(), "I": e.run_info["I"].tolist(), "SOC": e.run_info["SOC"].tolist(),
+         "sections": {nm: [[float(np.abs(e.Y[c, sl]).max()), float(e.Y[c, sl].sum())] for c in range(2)] for nm, sl in p.ind.items()}}
+    return d
+
+
+def _golden_key(p):
+    return "%s|%s" % (p.variant, p.precision)
+
+
+def known_answer_check(p):
+    """None if the plain kernel reproduces the committed known answer of this variant / grid (selftest_golden.json: produced by tools/make_selftest_golden.py on the binary that
+    profiles/validated_build.json names), else a description of the first disagreement.  A discretisation without a committed answer (a grid library for a grid of the user's
+    own) is checked against the built-in default-grid kernel of the same model instead -- two discretisations of the same cell agree to their truncation error, which catches a
+    broken equation, not a last-digit one."""
+    import json
+    try:
+        gold = json.load(open(_GOLDEN))["digests"]
+    except (OSError, ValueError, KeyError):
+        gold = {}
+    g = gold.get(_golden_key(p))
+    d = known_answer_digest(p)
+    if g is None:
+        return _cross_grid_check(p, d)
+    if d["flags"] != g["flags"]:
+        return "exit flags %r, known %r" % (d["flags"], g["flags"])
+    for k in ("t_end", "V", "I", "SOC"):
+        a, b = np.asarray(d[k]), np.asarray(g[k])
+        if not np.all(np.abs(a - b) <= KA_TOL * np.maximum(1.0, np.abs(b))):
+            return "%s of the runs %r, known %r" % (k, a.tolist(), b.tolist())
+    for nm, rows in g["sections"].items():
+        for c in range(2):
+            mx, sm = d["sections"][nm][c]
+            gmx, gsm = rows[c]
+            n = p.ind[nm].stop - p.ind[nm].start
+            if abs(mx - gmx) > KA_TOL * max(gmx, 1e-300) + 1e-12 or abs(sm - gsm) > KA_TOL * n * max(gmx, 1e-300) + 1e-12:
+                return "state section %s of cell %d: max |Y| %.12g (known %.12g), sum %.12g (known %.12g)" % (nm, c, mx, gmx, sm, gsm)
+    return None
+
+
+def _cross_grid_check(p, d):
+    """no committed answer for this discretisation: the same model on the built-in default grid (whose own answer IS committed) must give the same cell voltage, current and
+    SOC at the run ends to the truncation error of a coarse grid"""
+    if getattr(p, "_lib_path", None) is not None or not getattr(p, "_grid_lib_built", None):
+        return None
+    try:
+        ref = Model(p.cathode, _N(p=10, s=10, n=10, a=10, z=10, r_p=10, r_n=10), p.temperature, p.aging, None, p.precision, -1, p.solid_diffusion, p.thermodynamic_factor, p.rxn, p.waves_per_cell, None)
+    except Exception:
+        return None
+    g = known_answer_digest(ref)
+    if d["flags"] != g["flags"]:
+        return "exit flags %r, default grid %r" % (d["flags"], g["flags"])
+    # (a coarse grid -- 2 control volumes per section -- is tens of mV from the default one: this catches a broken equation, not a discretisation)
+    if np.abs(np.asarray(d["V"]) - np.asarray(g["V"])).max() > 0.15 or np.abs(np.asarray(d["SOC"]) - np.asarray(g["SOC"])).max() > 5e-3 or np.abs(np.asarray(d["t_end"]) - np.asarray(g["t_end"])).max() > 1e-6:
+        return "run-end V / SOC / t_end %r / %r / %r, default grid %r / %r / %r" % (d["V"], d["SOC"], d["t_end"], g["V"], g["SOC"], g["t_end"])
+    return None
 
 
 def _gpu_visible(p):
@@ -339,7 +446,7 @@ def _make_run(p, name, inp, tf, bounds):
     return r
 
 
-def _opts_struct(o):
+def _opts_struct(o, p=None):
     s = cap.Opts(o.abstol, o.reltol, o.abstol if o.abstol_init is None else o.abstol_init,
                  o.reltol if o.reltol_init is None else o.reltol_init, int(o.maxiters), int(bool(o.check_bounds)),
                  int(bool(o.interp_final)), int(o.max_order), int(bool(o.jac_every_step)), float(o.init_step))
@@ -352,6 +459,18 @@ def _opts_struct(o):
     s.tstops = ts.ctypes.data_as(C.POINTER(C.c_double)) if ts.size else None
     s._keep = (td, ts)                               # the arrays must outlive the struct
     s.yp_alg_zero = int(bool(getattr(o, "yp_alg_zero", False)))
+    # opts.stop_function (src/structures.jl:283, src/checks.jl:26): a closure g(t, Y, YP, p) traced into a postfix program like an input closure (closures.py); the run ends
+    # when g > 0, exit flag 12, with the same linear back-interpolation as the built-in bounds (plh_opts.stop_ops)
+    sf = getattr(o, "stop_function", None)
+    s.n_stop, s.stop_ops, s.stop_args = 0, None, None
+    if sf is not None:
+        if p is None:
+            raise ValueError("opts.stop_function needs the model it is traced for")
+        ops, args = sf if isinstance(sf, tuple) else closures.trace(sf, p)
+        ops, args = np.ascontiguousarray(ops, dtype=np.float64), np.ascontiguousarray(args, dtype=np.float64)
+        s.n_stop = ops.size
+        s.stop_ops, s.stop_args = ops.ctypes.data_as(C.POINTER(C.c_double)), args.ctypes.data_as(C.POINTER(C.c_double))
+        s._keep = s._keep + (ops, args)
     return s
 
 
@@ -540,7 +659,7 @@ def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, 
     n = theta.shape[0]
     N = p.N.tot
     arr = (cap.Run * len(runs))(*runs)
-    os_ = _opts_struct(o)
+    os_ = _opts_struct(o, p)
     mp = int(max_points or o.max_points)
     out = cap.Outputs()
     out.max_pts = mp
@@ -738,7 +857,7 @@ class HostPipeline:
         self.p, self.n, self.depth = p, int(n_cells), int(depth)
         self.runs, self.names = make_protocol(p, protocol, n_cells)
         self.arr = (cap.Run * len(self.runs))(*self.runs)
-        self.opts = _opts_struct(opts or p.opts)
+        self.opts = _opts_struct(opts or p.opts, p)
         self.mp = int(max_points)
         self._torch_streams = streams or [torch.cuda.Stream() for _ in range(self.depth)]
         self.streams = [s.cuda_stream for s in self._torch_streams]

@@ -1,0 +1,46 @@
+"""ONE table of hipcc flags for every translation unit of csrc/variant_tu.hip -- the built-in library (__graft_entry__.build_hip), the per-grid libraries compiled at first use
+(grids.py) and the per-protocol closure libraries (closure_lib.py).
+
+r04 had three copies that had drifted: the built-in variants dropped MachineLICM (+2 ... 21 %), the user-compiled libraries kept it, and a compiled closure then ran at 0.78 of the
+plain kernel where the interpreted one ran at 0.88.  Since r05 every builder asks `variant_flags(v)`; a library that fails the kernel self-test on the user's
+machine is rebuilt ONCE with `machine_licm=True` (the flag set every such library passed under in r04) and the fallback is reported (api._selftest_new_grid_library).
+
+Measured history of each switch: DESIGN.md 5a.
+"""
+from __future__ import annotations
+
+OPT = "-O3"
+# every device function is inlined into its kernel; WHEN differs:
+#   late  (isothermal / SEI kernels): functions are `inline`, the AMDGPU always-inline pass merges them after the function-level optimisations (0 B scratch)
+#   early (thermal kernels): functions are __forceinline__, merged before the optimisation pipeline -- the thermal kernels then no longer depend on the optimisation level
+LATE_INLINE = ["-mllvm", "-amdgpu-function-calls=false"]
+EARLY_INLINE = ["-DPL_DEV=__device__ __forceinline__"]
+# MachineLICM off (r04): the pre-RA loop-invariant code motion hoists whatever is invariant in the ONE step loop every device function is inlined into -- above all the register
+# copies of the exp / log polynomial coefficients of the thermal node pass -- to the top of the kernel and keeps it live across all phases (thermal: 392 B/lane of scratch with
+# it, 0 without; C3 +18.6 %, C5 +4.6 %, C2 / C4 +1.8 %)
+NO_MACHINE_LICM = ["-mllvm", "-disable-machine-licm"]
+# thermal kernels are register-bound: plain 8-byte DS accesses (no IR load/store vectoriser, no machine-level DS merging) +4 %
+NO_DS_MERGE = ["-mllvm", "-amdgpu-load-store-vectorizer=0", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
+# compiler fences at the phase boundaries (+2.9 % C3) and the branching update of the register-resident BDF history (+2.5 %), thermal variants only
+THERMAL_SRC = ["-DPL_PHASE_FENCES", "-DPL_EXP_BRANCHY_PHI"]
+# variants that keep MachineLICM in the built-in library (none at present; the mechanism stays for the next register-allocation miscompile of one instantiation)
+KEEP_MACHINE_LICM: set = set()
+
+
+def is_thermal(v):
+    from . import grids
+    return grids.variant_table()[v][2] == "true"
+
+
+def variant_flags(v, machine_licm=False, thermal=None):
+    """compile flags (after the common ones: arch, std, -fPIC, warnings, grid / namespace defines) of variant v's translation unit"""
+    th = is_thermal(v) if thermal is None else thermal
+    fl = (EARLY_INLINE + NO_DS_MERGE + THERMAL_SRC) if th else list(LATE_INLINE)
+    if not (machine_licm or v in KEEP_MACHINE_LICM):
+        fl = fl + NO_MACHINE_LICM
+    return fl + [OPT]
+
+
+def table_repr():
+    """what enters the build-identity hash (plh_build_info): the whole table"""
+    return repr((OPT, LATE_INLINE, EARLY_INLINE, NO_MACHINE_LICM, NO_DS_MERGE, THERMAL_SRC, sorted(KEEP_MACHINE_LICM)))

@@ -91,7 +91,7 @@ constexpr int MAXORD = 5;
 // W2_: two wavefronts per cell (a 128-thread workgroup; isothermal Fickian models): wave 1 owns the particle rows -- c_s residual rows, particle resolvents, particle
 //      partial solves and back-substitution, and the c_s entries of every vector phase -- and runs them next to wave 0's node pass / elimination / sweeps; the two waves of
 //      a cell share its LDS block and meet at s_barrier (PL_XSYNC).  Two waves per SIMD also means 256 registers per wave instead of 512.
-template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false, int SD_ = 0, int TF_ = 0, int RXN_ = 0, int W2_ = 0> struct ModelT {
+template <int CHEM_, bool SEI_, bool THERMAL_ = false, int PREC_ = 0, int SD_ = 0, int TF_ = 0, int RXN_ = 0, int W2_ = 0> struct ModelT {
   static constexpr int CHEM = CHEM_;                 // PLH_CHEM_LCO_LIC6 / PLH_CHEM_NMC_LIC6
   static constexpr int SD = SD_, TF = TF_, RXN = RXN_;
   static constexpr bool W2 = W2_ != 0;
@@ -107,8 +107,15 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false, bool MIXED_ = false, int 
   // resolvents -- are STORED in fp32; states, residuals, Jacobian partials, time, error control and all arithmetic stay fp64.  Pure fp32 is not offered: the
   // reltol-1e-3 Newton iteration would still converge, but SOH (1 - 1e-6 per pulse), film (1e-14 m) and t (41 h at 1e-6 s steps) are below fp32 resolution
   // (tools/fp32_study.py).
-  static constexpr bool MIXED = MIXED_;
-  using fact_t = typename std::conditional<MIXED_, float, double>::type;
+  static constexpr int PREC = PREC_;                 // plh_model_desc.precision: PLH_PREC_F64 / PLH_PREC_MIXED / PLH_PREC_F64_REFORDER
+  static constexpr bool MIXED = PREC_ == PLH_PREC_MIXED;
+  // PLH_PREC_F64_REFORDER: the finite-volume rows (c_e, Phi_e, and the heat conduction of the T rows) are evaluated in the REFERENCE's operation order -- matrix form,
+  // A x - f with every product A_ik x_k rounded before the sum (residuals.jl:6-106, 554-654, 299-489) -- instead of the conservative edge-flux / difference form of the
+  // default build.  Same equations; the rows then carry the reference's evaluation rounding (2e-13 per Phi_e row instead of 5e-15), which is what IDA's start-up order
+  // selection in a :hold leg sees.  For users who need the reference's step sequences, and for the A/B that tests that explanation.
+  static constexpr bool REFORD = PREC_ == PLH_PREC_F64_REFORDER;
+  static_assert(PREC_ >= 0 && PREC_ <= 2, "precision");
+  using fact_t = typename std::conditional<MIXED, float, double>::type;
   // LDS diet: the error weights and the accumulated Newton correction live in registers (IdaScalars::ew / ee: they are only touched by the
   // lane-strided vector phases), and so do the BDF history vectors of order >= PHI_LDS
   static constexpr int PHI_LDS = THERMAL_ ? 2 : MAXORD + 1;   // thermal: 40.7 kB -> four cells per CU
@@ -468,6 +475,29 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
 }
 #endif
+
+// a value the compiler must materialise: a product passed through it is ROUNDED before it enters a sum (no fma contraction) -- the reference's operation order of the
+// PLH_PREC_F64_REFORDER variants (Julia does not contract a*b + c; neither does the oracle's gcc build for x86-64)
+#ifdef PL_WAVE_EMU
+__device__ __forceinline__ double pl_rounded(double v) { volatile double r = v; return r; }
+#else
+__device__ __forceinline__ double pl_rounded(double v) { __asm__ volatile("" : "+v"(v)); return v; }
+#endif
+
+// Phi_s row of the PLH_PREC_F64_REFORDER variants: block_tridiag(N) * Phi_s .- f (residuals.jl:656-703) summed in the order of the notebook-pinned oracle's generated code
+// (oracle/gen/lco_iso.c: `-j x + Phi[i-1] - 2 Phi[i] + Phi[i+1]`, left to right): the source term src = f / sigma_eff ~ 1e-6 V joins a potential of ~4 V BEFORE the
+// Laplacian cancels, so the row is quantised at ulp(Phi_s) = 8.9e-16 V in the cathode (1.4e-17 in the anode).  J^-1 turns that into ~5e-11 V of common-mode noise in Phi_e / Phi_s
+// and 1e-9 in I -- 4e-8 ... 4e-7 in the weighted norm, above the local error of the first steps of a :hold leg (h restarts at 1e-3 s) -- and IDA's start-up order selection
+// reads it.  The oracle with this order reproduces the reference notebook's 37-point V-hold leg (t_end 2440.61 s); with the Laplacian formed first (what the default build
+// does, `lap - src`) it takes 38 points and ends at 2441.33 s: the reference's own generated code has this rounding, and this variant reproduces it (r05).
+// The first cathode row is `(-Phi[0] + Phi[1]) - src` in the generated code: clean.
+__device__ __forceinline__ double phi_s_row_reford(int i, bool first, bool last, double ps_p, double ps, double ps_n, double src) {
+  if (first && i == 0) return pl_rounded(-ps + ps_n) - src;
+  const double t = pl_rounded(-src);
+  if (first) return pl_rounded(pl_rounded(-ps) + t) + ps_n;                                  // -Phi[i] - src + Phi[i+1]
+  if (last) return pl_rounded(t - ps) + ps_p;                                                // -src - Phi[i] + Phi[i-1]
+  return pl_rounded(pl_rounded(t + ps_p) - 2.0 * ps) + ps_n;                                 // -src + Phi[i-1] - 2 Phi[i] + Phi[i+1]
+}
 
 // sum over all lanes of the cell: one wave, or (M::W2) both waves through two LDS slots and two barriers (every thread of the workgroup must call it)
 template <class M, class LDS> __device__ __forceinline__ double block_sum(LDS& S, double v) {
@@ -834,7 +864,10 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   double E = edge ? (M::TF == 1 ? w * (pe - pe_n) : w * (pe - pe_n) + cKfac * g) : 0.0;
   double Nf = edge ? Dh * dc : 0.0;                        // c_e-row edge flux
   const double E_p = shift_up1(E), Nf_p = shift_up1(Nf);
-  const double g_p = M::TF == 1 ? shift_up1(gE) : 0.0;
+  const double g_p = (M::TF == 1 || M::REFORD) ? shift_up1(gE) : 0.0;
+  // PLH_PREC_F64_REFORDER: the matrix-form rows need the left neighbour's states and the left edge's coefficients
+  [[maybe_unused]] double ce_pv = 0.0, pe_pv = 0.0, w_m = 0.0, dcoef = 0.0, dcoef_m = 0.0;
+  if constexpr (M::REFORD) { ce_pv = shift_up1(ce); pe_pv = shift_up1(pe); w_m = shift_up1(w); dcoef = Dh * rdist; dcoef_m = shift_up1(dcoef); }
   const double Em = i > 0 ? E_p : 0.0, Nm = i > 0 ? Nf_p : 0.0, gm = i > 0 ? g_p : 0.0;
   // electrode quantities
   const double a = sc == 0 ? ca_p : ca_n;
@@ -888,10 +921,26 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   const bool first = (i == 0) || (i == NP + NS), last = (i == NP - 1) || (i == NE - 1);
   if (WANT_RES) {
     if (act) {
+#ifdef PL_TEST_BREAK_NODE_PASS      /* tests/test_gpu_parity.py::test_selftest_catches_a_broken_plain_kernel: a deliberately wrong coefficient (1e-3 relative) in the c_e source */
+      const double src = elec ? (1 - ctplus) * nu * a * jt * 1.001 : 0.0;
+#else
       const double src = elec ? (1 - ctplus) * nu * a * jt : 0.0;
+#endif
+      if constexpr (!M::REFORD) {
       Fo[O_CE + i] = ((Nf - Nm) * rh + src) * reps - ypce;                 // residuals_c_e!, residuals.jl:6-106
       const double dE = M::TF == 1 ? (E - Em) + cKfac * nu * (gE - gm) : E - Em;
       Fo[O_PE + i] = (i < NE - 1) ? (dE - (elec ? h * FAR * a * jt : 0.0)) : pe;      // residuals_Φ_e!, residuals.jl:554-654
+      } else {
+        // PLH_PREC_F64_REFORDER: the reference's matrix form, A x - f with every product A_ik x_k rounded before the row sum, columns in ascending order
+        // (A_tot * c_e: residuals.jl:30-104; A_tot * Phi_e .- f with f = -K (g_i - g_{i-1}) + dx F a j: residuals.jl:577-648)
+        const double dL = i > 0 ? dcoef_m : 0.0, dU_ = edge ? dcoef : 0.0;          // D^_{i-1} / dist_{i-1}, D^_i / dist_i
+        const double accC = (pl_rounded(dL * ce_pv) + pl_rounded(-(dL + dU_) * ce)) + pl_rounded(dU_ * ce_n);
+        Fo[O_CE + i] = (accC * rh + src) * reps - ypce;
+        const double wL = i > 0 ? w_m : 0.0, wU = edge ? w : 0.0;
+        const double accP = (pl_rounded(-wL * pe_pv) + pl_rounded((wL + wU) * pe)) + pl_rounded(-wU * pe_n);
+        const double fE = pl_rounded(-(M::TF == 1 ? cKfac * nu : cKfac) * (gE - gm)) + (elec ? h * FAR * a * jt : 0.0);
+        Fo[O_PE + i] = (i < NE - 1) ? accP - fE : pe;
+      }
       if (elec) {
         Fo[O_J + jx] = (M::RXN == 0 ? 2.0 * kk * sq * sh : jc) - jv;                    // residuals_j!, residuals.jl:491-517
         if constexpr (M::SD != 0) {                                                    // residuals_c_s_avg! (quadratic / polynomial), residuals_Q!
@@ -903,7 +952,8 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
         const double Idens = yI * cI1C;
         if (i == 0) f += -Idens * h;
         if (i == NE - 1) f += Idens * h;
-        Fo[O_PS + jx] = lap - f * rsg;                                                  // residuals_Φ_s!, residuals.jl:656-703
+        if constexpr (!M::REFORD) Fo[O_PS + jx] = lap - f * rsg;                       // residuals_Φ_s!, residuals.jl:656-703
+        else Fo[O_PS + jx] = phi_s_row_reford(i, first, last, ps_p, ps, ps_n, f * rsg);
       }
     }
     if constexpr (M::SEI) {

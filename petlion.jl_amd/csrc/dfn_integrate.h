@@ -92,17 +92,12 @@ PL_DEV double tab_eval(const plh_run& r, double t) {
 #ifdef PL_CLOSURE_HEADER
 #include PL_CLOSURE_HEADER
 #endif
+// the interpreter: instructions [k0, k1) of the program (opcodes ops[], operands args[])
 template <class M>
-PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP, int k0 = 0, int k1 = -1, int which = -1) {      // instructions [k0, k1); default: the main program
-#ifdef PL_CLOSURE_COMPILED
-  (void)k0; (void)k1;
-  return pl_closure_compiled(r.closure_id, which, t, Y, YP, S.theta_row);
-#else
-  (void)which;
+PL_DEV double prog_eval(CellLDS<M>& S, const double* __restrict__ ops, const double* __restrict__ args, int k0, int k1, double t, const double* Y, const double* YP) {
   double* st = S.xstk + PLH_EXPR_STACK * wave_id(); const double* th = S.theta_row; int sp = 0;
-  if (k1 < 0) k1 = r.n_tab;
   for (int k = k0; k < k1; k++) {
-    const int op = (int)r.tab_t[k]; const double a = r.tab_v[k];
+    const int op = (int)ops[k]; const double a = args[k];
     if (op <= PLH_OP_THETA) {
       double v;
       switch (op) { case PLH_OP_CONST: v = a; break; case PLH_OP_T: v = t; break; case PLH_OP_Y: v = Y[(int)a]; break; case PLH_OP_YP: v = YP[(int)a]; break; default: v = th[(int)a]; }
@@ -122,6 +117,16 @@ PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double*
     }
   }
   return st[0];
+}
+template <class M>
+PL_DEV double expr_eval(CellLDS<M>& S, const plh_run& r, double t, const double* Y, const double* YP, int k0 = 0, int k1 = -1, int which = -1) {      // instructions [k0, k1); default: the main program
+#ifdef PL_CLOSURE_COMPILED
+  (void)k0; (void)k1;
+  return pl_closure_compiled(r.closure_id, which, t, Y, YP, S.theta_row);
+#else
+  (void)which;
+  if (k1 < 0) k1 = r.n_tab;
+  return prog_eval(S, r.tab_t, r.tab_v, k0, k1, t, Y, YP);
 #endif
 }
 // value of the closure of a run as the control residual uses it: method(Y) - f for the input modes; for PLH_MODE_RES (method_res = 0; run_residual,
@@ -496,6 +501,9 @@ PL_DEV int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, double& err_k
   const int kk = I.kk;
   PL_AMARK("test_error");
   double s0 = 0, s1 = 0, s2 = 0;
+#ifdef PL_WAVE_EMU
+  if (getenv("PL_EMU_TRACE_EE") && blockIdx.x == 0 && I.nst < atoi(getenv("PL_EMU_TRACE_EE"))) { PL_VEC(n) fprintf(stderr, "dev ee %d %d %.6e %.6e\n", I.nst + 1, n, EE(n), EE(n) * EWT(n)); }
+#endif
   // phi[kk], phi[kk-1] through a compile-time order index (wave-uniform branches): the history orders that live in registers (thermal model) are then read directly
   // instead of through a select chain per element
   // (with the whole history in LDS a runtime order is just an address, and the extra branches cost 2 % of the isothermal kernels: PHI_REGS selects the form)
@@ -771,7 +779,7 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
 }
 
 // ---- stop conditions (check_simulation_stop!, src/checks.jl:1-224); scalars are wave-uniform ----
-struct PrevVals { double frac, V, SOC, I, c_s_n, c_e_min, eta_pl, dfilm, T; };
+struct PrevVals { double frac, V, SOC, I, c_s_n, c_e_min, eta_pl, dfilm, T, g; };     // (g: the caller's stop function, plh_opts.stop_ops)
 
 template <class M>
 __device__ __forceinline__ double cellV(const double* Y) { return Y[M::O_PS] - Y[M::O_PS + NJ - 1]; }
@@ -783,8 +791,8 @@ __device__ __forceinline__ double cellTavg(const CellLDS<M>& S, const double* Y)
   else return S.cc.T0;
 }
 
-template <class M>
-PL_DEV void check_stop(const CellLDS<M>& S, const plh_run& run, const plh_opts& o, double t, double tf, const double* Y, const double* YP,
+template <int F = 0, class M>
+PL_DEV void check_stop(CellLDS<M>& S, const plh_run& run, const plh_opts& o, double t, double tf, const double* Y, const double* YP,
                                   double SOC, PrevVals& pv, int& flag) {
   PL_MODEL(M);
   const double eps = t < 1.0 ? o.reltol : 0.0;
@@ -837,6 +845,13 @@ PL_DEV void check_stop(const CellLDS<M>& S, const plh_run& run, const plh_opts& 
     double dm = -1e300; for (int i = 0; i < NN; i++) { const double v = YP[O_FILM + i]; dm = v > dm ? v : dm; }
     if (b.dfilm_max == b.dfilm_max && dm - b.dfilm_max > eps) { const double f = (pv.dfilm - b.dfilm_max) / (pv.dfilm - dm); if (f < pv.frac) { pv.frac = f; flag = 10; } }
     pv.dfilm = dm;
+  }
+  if constexpr ((F & GF_EXPR) != 0) {                                                   // opts.stop_function, checks.jl:26: after the built-in checks (plh_opts.stop_ops)
+    if (o.n_stop > 0) {
+      const double g = prog_eval(S, o.stop_ops, o.stop_args, 0, o.n_stop, t, Y, YP);
+      if (g > eps) { const double f = pv.g / (pv.g - g); if (f < pv.frac) { pv.frac = f; flag = PLH_FLAG_STOP_FUNCTION; } }
+      pv.g = g;
+    }
   }
 }
 
@@ -961,7 +976,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     plh_run_info ri; ri.flag = PLH_FLAG_RUNNING; ri.iterations = 0; ri.t_end = t_global; ri.V = 0; ri.I = 0; ri.SOC = SOC; ri.T_avg = T0;
     // tstops = {tdiscon - reltol/2} U {1.0 if continuation} U {tf}   (postfix_integrator!, model_evaluation.jl:288-310)
     const bool continuation = !new_run;
-    PrevVals pv; pv.frac = 1.0; pv.V = -1; pv.SOC = -1; pv.I = -1; pv.c_s_n = -1; pv.c_e_min = -1; pv.eta_pl = -1; pv.dfilm = -1; pv.T = -1;
+    PrevVals pv; pv.frac = 1.0; pv.V = -1; pv.SOC = -1; pv.I = -1; pv.c_s_n = -1; pv.c_e_min = -1; pv.eta_pl = -1; pv.dfilm = -1; pv.T = -1; pv.g = -1;
     double tprev = 0.0, t = 0.0, t_prev_saved = t0; int iter = 1; bool stalled_once = false;
     double I_prev_pt = 0.0, t_restart = 0.0;
     bool first_init = true, again = false, init_failed = false;
@@ -976,7 +991,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     if (first_init) {
       first_init = false;
       save_pt(nout, t0, S.yy, SOC); nout++;
-      check_stop(S, run, o, 0.0, run.tf, S.yy, S.yp, SOC, pv, flag);
+      check_stop<F>(S, run, o, 0.0, run.tf, S.yy, S.yp, SOC, pv, flag);
       PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
       PL_SYNC();
       I_prev_pt = S.yy[O_I];
@@ -1000,7 +1015,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
           // the reference's solve! has already pushed this (repeated) point and run the stop checks when check_solve shortens the first step
           // (model_evaluation.jl:319-327, checks.jl:227-231): run.info.iterations stays equal to the number of saved points of the run
           save_pt(nout, t + t0, S.yy, SOC); nout++;
-          check_stop(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
+          check_stop<F>(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
           continue;
         }
         flag = sf; break;
@@ -1012,7 +1027,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       SOC = SOC_new;
       save_pt(nout, t + t0, S.yy, SOC); nout++;
       PL_TOCE(S, 3, 4);
-      check_stop(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
+      check_stop<F>(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
       PL_TOCE(S, 3, 5);
       if constexpr ((F & GF_SENS) != 0) sens_step(S, R, I, SX, mode, value, nout - 1);      // (the solution point in S.yy / S.yp is saved and restored around it)
       if (!is_fun && t == tprev) { flag = PLH_ERR_STALL; break; }      // (run_function has no stall test, checks.jl:251-269; run_residual -- res, dT, d<state> -- has: checks.jl:226)

@@ -192,6 +192,8 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
   const double Nf = edge ? Dhm * dc : 0.0;
   const double E_p = shift_up1(E), Nf_p = shift_up1(Nf);
   const double Em = i > 0 ? E_p : 0.0, Nm = i > 0 ? Nf_p : 0.0;
+  [[maybe_unused]] double w_m = 0.0, g_m = 0.0, dcoef_m = 0.0;           // PLH_PREC_F64_REFORDER: coefficients of the left edge (cross-lane moves outside divergent control flow)
+  if constexpr (M::REFORD) { w_m = shift_up1(w); g_m = shift_up1(edge ? g : 0.0); dcoef_m = shift_up1(Dhm * rdist); }
   // electrode quantities with per-node Arrhenius factors
   const double a = sc == 0 ? c.a_p : c.a_n;
   const double jv = elec ? jv_l : 0.0, ps = elec ? ps_l : 0.0, cs = elec ? cs_l : 1.0;
@@ -246,8 +248,18 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
   if (WANT_RES) {
     if (act) {
       const double src = elec ? (1 - ctplus) * 1.0 * a * jv : 0.0;
+      if constexpr (!M::REFORD) {
       Fo[O_CE + i] = ((Nf - Nm) * rh + src) * reps - ypce;                 // residuals_c_e!, residuals.jl:6-106
       Fo[O_PE + i] = (i < NE - 1) ? (E - Em - (elec ? h * FAR * a * jv : 0.0)) : pe;   // residuals_Φ_e!, residuals.jl:554-654
+      } else {                                                             // PLH_PREC_F64_REFORDER: the reference's matrix form (see iso_node_pass)
+        const double dcoef = Dhm * rdist, dL = i > 0 ? dcoef_m : 0.0, dU_ = edge ? dcoef : 0.0;
+        const double accC = (pl_rounded(dL * ce_p) + pl_rounded(-(dL + dU_) * ce)) + pl_rounded(dU_ * ce_n);
+        Fo[O_CE + i] = (accC * rh + src) * reps - ypce;
+        const double wL = i > 0 ? w_m : 0.0, wU = edge ? w : 0.0;
+        const double accP = (pl_rounded(-wL * pe_p) + pl_rounded((wL + wU) * pe)) + pl_rounded(-wU * pe_n);
+        const double fE = pl_rounded(-cKfac * ((edge ? g : 0.0) - (i > 0 ? g_m : 0.0))) + (elec ? h * FAR * a * jv : 0.0);
+        Fo[O_PE + i] = (i < NE - 1) ? accP - fE : pe;
+      }
       if (elec) {
         Fo[O_J + jx] = 2.0 * kk * sq * sh - jv;                                        // residuals_j!, residuals.jl:491-517
         const double lap = first ? (-ps + ps_n) : (last ? (ps_p - ps) : (ps_p - 2 * ps + ps_n));
@@ -255,7 +267,8 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
         const double Idens = yI * cI1C;
         if (i == 0) f += -Idens * h;
         if (i == NE - 1) f += Idens * h;
-        Fo[O_PS + jx] = lap - f * rsg;                                                  // residuals_Φ_s!, residuals.jl:656-703
+        if constexpr (!M::REFORD) Fo[O_PS + jx] = lap - f * rsg;                       // residuals_Φ_s!, residuals.jl:656-703
+        else Fo[O_PS + jx] = phi_s_row_reford(i, first, last, ps_p, ps, ps_n, f * rsg);
       }
       // residuals_T!, residuals.jl:299-489 ; heat sources aux...jl:344-518
       const double qrr = Faj * (T * dUdT + eta);
@@ -265,13 +278,15 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
       // dT control row and its algebraic twin SUM the fifty rows (their conduction parts telescope to zero) and find the current from what is left: 1e-6 relative noise in I,
       // which at reltol <= 1e-6 is what made the dT = :hold leg stall on the device more often than in the oracle.  Differences of neighbouring temperatures
       // are exact to their own last bit, so the noise drops by T / dT ~ 1e4.
-      Fo[O_T + it] = TP.aL[it] * (Tl - T) + TP.aU[it] * (Tr - T) + (qrr + qohm) * rc - ypT;
+      if constexpr (!M::REFORD) Fo[O_T + it] = TP.aL[it] * (Tl - T) + TP.aU[it] * (Tr - T) + (qrr + qohm) * rc - ypT;
+      else Fo[O_T + it] = ((pl_rounded(TP.aL[it] * Tl) + pl_rounded(thermal_aD(TP, it) * T)) + pl_rounded(TP.aU[it] * Tr)) + (qrr + qohm) * rc - ypT;   // A_T * T, residuals.jl:299-489
     }
     if (lane >= 32 && lane < 32 + NA + NZ) {                                          // current-collector rows
       const int k = lane - 32, ic = k < NA ? k : NA + NE + (k - NA);
       const double Tc = Y[O_T + ic], Tcl = ic > 0 ? Y[O_T + ic - 1] : 0.0, Tcr = ic < NT - 1 ? Y[O_T + ic + 1] : 0.0;
       const double hcv = ic == 0 ? TP.aC2[0] : (ic == NT - 1 ? TP.aC2[1] : 0.0);      // convective end rows: h_cell (T_amb - T) / (h rho Cp)
-      Fo[O_T + ic] = TP.aL[ic] * (Tcl - Tc) + TP.aU[ic] * (Tcr - Tc) + hcv * (c.Tamb - Tc) + TP.qI[k < NA ? 0 : 1] * yI * yI - YP[O_T + ic];
+      if constexpr (!M::REFORD) Fo[O_T + ic] = TP.aL[ic] * (Tcl - Tc) + TP.aU[ic] * (Tcr - Tc) + hcv * (c.Tamb - Tc) + TP.qI[k < NA ? 0 : 1] * yI * yI - YP[O_T + ic];
+      else Fo[O_T + ic] = (((pl_rounded(TP.aL[ic] * Tcl) + pl_rounded(thermal_aD(TP, ic) * Tc)) + pl_rounded(TP.aU[ic] * Tcr)) + pl_rounded(hcv * c.Tamb)) + TP.qI[k < NA ? 0 : 1] * yI * yI - YP[O_T + ic];
     }
     if (mode == PLH_MODE_I || mode == PLH_MODE_V || mode == PLH_MODE_P || mode == PLH_MODE_ETA_P || mode == PLH_MODE_RES) {   // scalar_residual!, scalar_residual.jl:167-172
       const double Vc = Y[O_PS] - Y[O_PS + NJ - 1];

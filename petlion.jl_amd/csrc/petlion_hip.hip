@@ -128,7 +128,7 @@ struct GridLib { std::string path; void* handle; int grid[7]; const VariantOps* 
 static std::vector<GridLib> g_grid_libs;
 static std::mutex g_grid_mutex;
 static bool desc_matches(const plh_model_desc* d, const VariantOps* o) {
-  return o->chem == d->chemistry && o->sei == (d->aging_SEI ? 1 : 0) && o->thermal == (d->temperature ? 1 : 0) && o->mixed == (d->precision == PLH_PREC_MIXED ? 1 : 0) &&
+  return o->chem == d->chemistry && o->sei == (d->aging_SEI ? 1 : 0) && o->thermal == (d->temperature ? 1 : 0) && o->mixed == d->precision &&
          o->sd == d->solid_diffusion && o->tf == d->thermodynamic_factor && o->rxn == d->rxn && o->w2 == (d->waves_per_cell == 2 ? 1 : 0);
 }
 // N_a / N_z only exist with temperature = true, N_r only for Fickian diffusion (params.jl:119-136); an absent dimension matches anything
@@ -324,6 +324,25 @@ struct plh_comm_s { ncclComm_t comm = nullptr; int n_ranks = 1, rank = 0, device
 struct plh_comm_s { int n_ranks = 1, rank = 0, device = 0; std::string dir; std::vector<long long> seq_tx, seq_rx; int* d_status = nullptr; bool dead = false; bool comm = false; };
 #endif
 
+// a postfix program of the PLH_OP_* vocabulary (closure inputs, the stop function): checked here, the device interpreter trusts it
+static int check_postfix(const double* ops, const double* args, int k0, int k1, int N, int P) {
+  int sp = 0;
+  for (int k = k0; k < k1; k++) {
+    const double opd = ops[k]; const int op = (int)opd; const double a = args[k];
+    if (!(opd == (double)op) || op < 0 || op >= PLH_N_OPS) return fail(PLH_E_ARG, "PLH_VAL_EXPR: unknown opcode");
+    int pop = 2, idx_max = -1;
+    if (op <= PLH_OP_THETA) pop = 0; else if (op == PLH_OP_SELECT) pop = 3;
+    else if (op == PLH_OP_NEG || op == PLH_OP_SIN || op == PLH_OP_COS || op == PLH_OP_EXP || op == PLH_OP_LOG || op == PLH_OP_SQRT || op == PLH_OP_ABS || op == PLH_OP_TANH) pop = 1;
+    if (op == PLH_OP_Y || op == PLH_OP_YP) idx_max = N; else if (op == PLH_OP_THETA) idx_max = P;
+    if (idx_max >= 0 && !(a == (double)(int)a && a >= 0 && a < idx_max)) return fail(PLH_E_ARG, "PLH_VAL_EXPR: state / theta index out of range");
+    if (sp < pop) return fail(PLH_E_ARG, "PLH_VAL_EXPR: stack underflow");
+    sp += 1 - pop;
+    if (sp > PLH_EXPR_STACK) return fail(PLH_E_ARG, "PLH_VAL_EXPR: more than 16 values on the stack");
+  }
+  if (sp != 1) return fail(PLH_E_ARG, "PLH_VAL_EXPR: the program must leave exactly one value");
+  return 0;
+}
+
 extern "C" {
 
 const char* plh_last_error(void) { return g_err.c_str(); }
@@ -331,7 +350,7 @@ const char* plh_last_error(void) { return g_err.c_str(); }
 int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   if (!d || !out) return fail(PLH_E_ARG, "null argument");
   if (d->real_bytes != 8) return fail(PLH_E_UNSUPPORTED, "states, residuals and time are fp64 (real_bytes = 8); reduced precision is selected with precision = PLH_PREC_MIXED");
-  if (d->precision != PLH_PREC_F64 && d->precision != PLH_PREC_MIXED) return fail(PLH_E_ARG, "precision must be PLH_PREC_F64 or PLH_PREC_MIXED");
+  if (d->precision != PLH_PREC_F64 && d->precision != PLH_PREC_MIXED && d->precision != PLH_PREC_F64_REFORDER) return fail(PLH_E_ARG, "precision must be PLH_PREC_F64, PLH_PREC_MIXED or PLH_PREC_F64_REFORDER");
   if (d->chemistry != PLH_CHEM_LCO_LIC6 && d->chemistry != PLH_CHEM_NMC_LIC6 && d->chemistry != PLH_CHEM_LGM50) return fail(PLH_E_UNSUPPORTED, "unknown chemistry");
   if (d->solid_diffusion < 0 || d->solid_diffusion > PLH_SD_POLYNOMIAL || d->thermodynamic_factor < 0 || d->thermodynamic_factor > 1 || d->rxn < 0 || d->rxn > 1)
     return fail(PLH_E_ARG, "solid_diffusion / thermodynamic_factor / rxn out of range");
@@ -344,7 +363,9 @@ int plh_model_create(const plh_model_desc* d, plh_model_t* out) {
   }
   if (!ops) {                                            // another discretisation: a registered grid library
     std::lock_guard<std::mutex> lk(g_grid_mutex);
-    for (const GridLib& gl : g_grid_libs) {
+    // (latest registration first: a library that failed the kernel self-test is superseded by its fall-back build, registered after it -- api.petlion)
+    for (auto it = g_grid_libs.rbegin(); it != g_grid_libs.rend() && !ops; ++it) {
+      const GridLib& gl = *it;
       if (!grid_matches(d, gl.grid)) continue;
       for (int v = 0; v < PL_N_VARIANTS && !ops; v++) { const VariantOps* o = gl.ops(v); if (o && desc_matches(d, o)) { variant_exists = true; ops = o; } }
     }
@@ -536,9 +557,9 @@ int plh_abi_layout(int* out, int cap) {
   PL_F(plh_bounds, I_max) PL_F(plh_bounds, I_min) PL_F(plh_bounds, eta_plating_min) PL_F(plh_bounds, c_e_min) PL_F(plh_bounds, dfilm_max)
   PL_S(plh_run, 15) PL_F(plh_run, mode) PL_F(plh_run, value_kind) PL_F(plh_run, value) PL_F(plh_run, tf) PL_F(plh_run, bounds) PL_F(plh_run, n_tab) PL_F(plh_run, closure_id) PL_F(plh_run, tab_t)
   PL_F(plh_run, tab_v) PL_F(plh_run, value_cell) PL_F(plh_run, tf_cell) PL_F(plh_run, n_dcol) PL_F(plh_run, dstate) PL_F(plh_run, dcol) PL_F(plh_run, dofs)
-  PL_S(plh_opts, 16) PL_F(plh_opts, abstol) PL_F(plh_opts, reltol) PL_F(plh_opts, abstol_init) PL_F(plh_opts, reltol_init) PL_F(plh_opts, maxiters) PL_F(plh_opts, check_bounds)
+  PL_S(plh_opts, 19) PL_F(plh_opts, abstol) PL_F(plh_opts, reltol) PL_F(plh_opts, abstol_init) PL_F(plh_opts, reltol_init) PL_F(plh_opts, maxiters) PL_F(plh_opts, check_bounds)
   PL_F(plh_opts, interp_final) PL_F(plh_opts, max_order) PL_F(plh_opts, jac_every_step) PL_F(plh_opts, init_step) PL_F(plh_opts, n_tdiscon) PL_F(plh_opts, tdiscon) PL_F(plh_opts, refine)
-  PL_F(plh_opts, n_tstops) PL_F(plh_opts, tstops) PL_F(plh_opts, yp_alg_zero)
+  PL_F(plh_opts, n_tstops) PL_F(plh_opts, tstops) PL_F(plh_opts, yp_alg_zero) PL_F(plh_opts, n_stop) PL_F(plh_opts, stop_ops) PL_F(plh_opts, stop_args)
   PL_S(plh_run_info, 7) PL_F(plh_run_info, flag) PL_F(plh_run_info, iterations) PL_F(plh_run_info, t_end) PL_F(plh_run_info, V) PL_F(plh_run_info, I) PL_F(plh_run_info, SOC)
   PL_F(plh_run_info, T_avg)
   PL_S(plh_counters, 11) PL_F(plh_counters, n_steps) PL_F(plh_counters, n_res) PL_F(plh_counters, n_jac) PL_F(plh_counters, n_fact) PL_F(plh_counters, n_solve)
@@ -676,21 +697,7 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
       if (runs[r].n_tab < 1 || !runs[r].tab_t || !runs[r].tab_v) return fail(PLH_E_ARG, "PLH_VAL_EXPR needs n_tab >= 1 and both program arrays");
       if (runs[r].mode == PLH_MODE_DT) return fail(PLH_E_UNSUPPORTED, "function inputs for dT are not defined by the reference");
       auto check_program = [&](int k0, int k1) -> int {
-        int sp = 0;
-        for (int k = k0; k < k1; k++) {
-          const double opd = runs[r].tab_t[k]; const int op = (int)opd; const double a = runs[r].tab_v[k];
-          if (!(opd == (double)op) || op < 0 || op >= PLH_N_OPS) return fail(PLH_E_ARG, "PLH_VAL_EXPR: unknown opcode");
-          int pop = 2, idx_max = -1;
-          if (op <= PLH_OP_THETA) pop = 0; else if (op == PLH_OP_SELECT) pop = 3;
-          else if (op == PLH_OP_NEG || op == PLH_OP_SIN || op == PLH_OP_COS || op == PLH_OP_EXP || op == PLH_OP_LOG || op == PLH_OP_SQRT || op == PLH_OP_ABS || op == PLH_OP_TANH) pop = 1;
-          if (op == PLH_OP_Y || op == PLH_OP_YP) idx_max = m->N; else if (op == PLH_OP_THETA) idx_max = m->P;
-          if (idx_max >= 0 && !(a == (double)(int)a && a >= 0 && a < idx_max)) return fail(PLH_E_ARG, "PLH_VAL_EXPR: state / theta index out of range");
-          if (sp < pop) return fail(PLH_E_ARG, "PLH_VAL_EXPR: stack underflow");
-          sp += 1 - pop;
-          if (sp > PLH_EXPR_STACK) return fail(PLH_E_ARG, "PLH_VAL_EXPR: more than 16 values on the stack");
-        }
-        if (sp != 1) return fail(PLH_E_ARG, "PLH_VAL_EXPR: the program must leave exactly one value");
-        return 0;
+        return check_postfix(runs[r].tab_t, runs[r].tab_v, k0, k1, m->N, m->P);
       };
       if (int rc = check_program(0, runs[r].n_tab)) return rc;
       if (runs[r].n_dcol < 0 || runs[r].n_dcol > PLH_MAX_DCOL) return fail(PLH_E_ARG, "PLH_VAL_EXPR: n_dcol out of range (0 .. 60)");
@@ -731,12 +738,15 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
   if (opts->n_tstops < 0 || (opts->n_tstops > 0 && !opts->tstops)) return fail(PLH_E_ARG, "tstops");
   for (int k = 0; k < opts->n_tstops; k++) if (!(opts->tstops[k] == opts->tstops[k])) return fail(PLH_E_ARG, "tstops must not contain NaN");
   if (opts->refine < 0 || opts->refine > 4) return fail(PLH_E_ARG, "refine must be 0 .. 4");
+  if (opts->n_stop < 0 || (opts->n_stop > 0 && (!opts->stop_ops || !opts->stop_args))) return fail(PLH_E_ARG, "stop function: n_stop > 0 needs both program arrays");
+  if (opts->n_stop > 0) { if (int rc = check_postfix(opts->stop_ops, opts->stop_args, 0, opts->n_stop, m->N, m->P)) return rc; }
+  if (opts->n_stop > 0 && m->ops->w2) return fail(PLH_E_UNSUPPORTED, "stop function: one wavefront per cell only");
   if (sq) {
     if (sq->n_sens < 1 || sq->n_sens > 64 || !sq->cols || (!sq->dY && !sq->dV)) return fail(PLH_E_ARG, "plh_integrate_sens: 1 <= n_sens <= 64, theta columns and at least one of dY_dtheta / dV_dtheta");
     for (int k = 0; k < sq->n_sens; k++) if (sq->cols[k] < 0 || sq->cols[k] >= m->P) return fail(PLH_E_ARG, "plh_integrate_sens: theta column out of range");
     if (Y_init) return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: sensitivities of a continued solution (Y_init) are not carried across calls");
     if (m->ops->w2) return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: one wavefront per cell only");
-    if (opts->refine > 0 || opts->n_tdiscon > 0) return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: not with refine / tdiscon");
+    if (opts->refine > 0 || opts->n_tdiscon > 0 || opts->n_stop > 0) return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: not with refine / tdiscon / a stop function");
     for (int r = 0; r < n_runs; r++)
       if ((runs[r].value_kind != PLH_VAL_CONST && runs[r].value_kind != PLH_VAL_REST) || runs[r].mode == PLH_MODE_RES || runs[r].mode == PLH_MODE_DSTATE)
         return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: constant (or :rest) inputs in the modes I, V, P, eta_p, dT (a :hold value or a function input depends on theta through the previous run / the state)");
@@ -798,8 +808,11 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
     if (runs[r].value_cell) hruns[r].value_cell = s.in_host(runs[r].value_cell, n);       // per-cell protocol values: host arrays like the protocol
     if (runs[r].tf_cell) hruns[r].tf_cell = s.in_host(runs[r].tf_cell, n);
   }
+  // the stop function's program (opts.stop_function): host arrays like the protocol's tables
+  a.opts.stop_ops = nullptr; a.opts.stop_args = nullptr;
+  if (opts->n_stop > 0) { a.opts.stop_ops = s.in_host(opts->stop_ops, opts->n_stop); a.opts.stop_args = s.in_host(opts->stop_args, opts->n_stop); }
   CHECK_STAGE(s);
-  bool plain = true;                                                 // no staged arrays behind the descriptors
+  bool plain = opts->n_stop == 0;                                    // no staged arrays behind the descriptors
   {
     for (int r = 0; r < n_runs; r++) plain = plain && !hruns[r].tab_t && !hruns[r].value_cell && !hruns[r].tf_cell;
     const bool same = plain && (int)cx.runs_on_device.size() == n_runs && memcmp(cx.runs_on_device.data(), hruns.data(), n_runs * sizeof(plh_run)) == 0;
@@ -842,6 +855,7 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
   int features = 0;
   if (opts->n_tdiscon > 0 || opts->n_tstops > 0 || out->Y_all || opts->yp_alg_zero != 0) features |= 1;
   for (int r = 0; r < n_runs; r++) { if (runs[r].value_kind == PLH_VAL_TABLE) features |= 1 | 2; if (runs[r].value_kind == PLH_VAL_EXPR) features |= 1 | 2 | 4; }
+  if (opts->n_stop > 0) features |= 1 | 2 | 4;                                   // the stop function runs in the interpreter of the closure instantiations
   if (need_genW) features |= 1 | 2 | 4 | 16;                                     // closures with derivative programs: the general control row
   if (opts->refine > 0) features |= 1 | 2 | 4 | 8;
   if (sq) features = 1 | 32;                                                     // GF_STOPS | GF_SENS

@@ -21,7 +21,11 @@ namespace pl {
 //    LCO thermal      256 VGPR + 256 AGPR, 329 VGPR spills,              668 SGPR spills,                   368 B/lane
 // i.e. the arch-VGPR half is saturated everywhere and the AGPR half is the first spill level (v_accvgpr_read/write, one instruction each way); only what does not fit there
 // goes to scratch memory, and that traffic sits around the Jacobian refresh, not in the residual / solve loop.
-#if !defined(PL_WAVE_EMU) && !defined(PL_NO_WAVES_ATTR)      /* (PL_NO_WAVES_ATTR: experiment builds of tools/experiments/build_modes.py) */
+#if !defined(PL_WAVE_EMU) && !defined(PL_NO_WAVES_ATTR) && defined(PL_WAVES_PER_EU)
+// -DPL_WAVES_PER_EU=2 (r05 occupancy builds, tools/experiments/occupancy.py): two independent cells per SIMD -- 256 registers per lane, and the LDS of a cell must be <= 20 480 B
+// for eight of them to be resident on a CU
+#define PL_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(PL_WAVES_PER_EU, PL_WAVES_PER_EU)))
+#elif !defined(PL_WAVE_EMU) && !defined(PL_NO_WAVES_ATTR)      /* (PL_NO_WAVES_ATTR: experiment builds of tools/experiments/build_modes.py) */
 #define PL_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(M::NWAVES, M::NWAVES)))    /* one cell per SIMD: one wave (512 registers) or, M::W2, its two waves (256 each) */
 #else
 #define PL_ONE_WAVE_PER_SIMD
@@ -348,7 +352,7 @@ template <class M> struct OpsOf {
     // four cells per CU (160 kB of LDS, one wave per SIMD) is what every built-in kernel is tuned for: one byte over 40 960 drops the CU to three cells (-25 %)
     static_assert(!GRID_DEFAULT || sizeof(CellLDS<M>) <= 40960, "built-in variant: LDS per cell above 40 960 B, only three cells per CU would be resident");
 #endif
-    static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::MIXED ? 1 : 0, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, {NP, NS, NN, NRP, NA, NZ, NRN},
+    static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::PREC, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, {NP, NS, NN, NRP, NA, NZ, NRN},
                                    {PL_RADIAL_M, PL_RADIAL_M_N}, {PL_RADIAL_LAM, PL_RADIAL_LAM_N}, {PL_RADIAL_V, PL_RADIAL_V_N}, {PL_RADIAL_W, PL_RADIAL_W_N}, {PL_RADIAL_BJ_FACTOR, PL_RADIAL_BJ_FACTOR_N}, sizeof(CellLDS<M>), &classify<M>, &sections_of<M>,
                                    &initial_guess, &residual, &jacobian, &linear_solve, &init_consistent, &integrate};
     return &ops;

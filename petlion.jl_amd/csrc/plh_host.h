@@ -7,7 +7,7 @@
 #include <hip/hip_runtime.h>
 #include "dfn_cell.h"
 
-// id, chemistry, SEI aging, temperature, mixed precision (fp32 storage of the Newton-matrix factors), solid diffusion, thermodynamic factor, reaction kinetics,
+// id, chemistry, SEI aging, temperature, precision (false / true / 2 = PLH_PREC_F64 / PLH_PREC_MIXED: fp32 storage of the Newton-matrix factors / PLH_PREC_F64_REFORDER), solid diffusion, thermodynamic factor, reaction kinetics,
 // two waves per cell
 #define PL_VARIANT_LIST(X)                                                                         \
   X(0, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)          \
@@ -24,8 +24,10 @@
   X(11, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_MHC, 0)       \
   X(12, PLH_CHEM_LGM50, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)            \
   X(13, PLH_CHEM_LCO_LIC6, false, false, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 1)          \
-  X(14, PLH_CHEM_LGM50, false, true, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)
-constexpr int PL_N_VARIANTS = 15;
+  X(14, PLH_CHEM_LGM50, false, true, false, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)             \
+  X(15, PLH_CHEM_LCO_LIC6, false, false, 2, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)              \
+  X(16, PLH_CHEM_LCO_LIC6, false, true, 2, PLH_SD_FICKIAN, PLH_TF_LINEAR, PLH_RXN_BV, 0)
+constexpr int PL_N_VARIANTS = 17;
 
 struct IntegrateArgs {
   const pl::Tables* tb; int n_cells; const double* theta; const double* SOC0; const double* Y_init; const double* t_init; int n_runs; const plh_run* runs; plh_opts opts;
@@ -37,7 +39,7 @@ struct IntegrateArgs {
 struct SectionInfo { const char* name; int start, len; };
 
 struct VariantOps {
-  int id, chem, sei, thermal, mixed, sd, tf, rxn, w2;
+  int id, chem, sei, thermal, mixed, sd, tf, rxn, w2;       // (mixed: plh_model_desc.precision, PLH_PREC_*)
   int N, Nd;
   int grid[7];                                                                       // N_p, N_s, N_n, N_r_p, N_a, N_z, N_r_n this table was compiled for
   const double *rad_M[2], *rad_LAM[2], *rad_V[2], *rad_W[2]; double rad_BJ[2];       // radial operator tables of N_r_p / N_r_n (radial_tables.h), N_r x N_r packed

@@ -129,7 +129,7 @@ def ensemble_run_capi(comm, p, Theta, protocol, SOC=1.0, *, n_cells=None, partit
     n = int(Theta.shape[0] if root else n_cells)
     runs, _ = make_protocol(p, protocol, n)
     arr = (cap.Run * len(runs))(*runs)
-    o = _opts_struct(opts or p.opts)
+    o = _opts_struct(opts or p.opts, p)
     part = {"block": cap.PART_BLOCK, "cyclic": cap.PART_CYCLIC}[partition]
     if root:
         Theta = np.ascontiguousarray(Theta, dtype=np.float64)

@@ -31,7 +31,8 @@ def variant_table():
 
 def variant_id(chemistry, sei, thermal, mixed, sd, tf, rxn, w2):
     """id of the model variant with these options (the names are those of include/petlion_hip.h), None if it is not instantiated"""
-    want = ("PLH_CHEM_" + chemistry, "true" if sei else "false", "true" if thermal else "false", "true" if mixed else "false", "PLH_SD_" + sd, "PLH_TF_" + tf,
+    mixed = int(mixed)                                   # plh_model_desc.precision: 0 f64, 1 mixed, 2 f64 in the reference's operation order (spelled false / true / 2 in the table)
+    want = ("PLH_CHEM_" + chemistry, "true" if sei else "false", "true" if thermal else "false", {0: "false", 1: "true"}.get(mixed, str(mixed)), "PLH_SD_" + sd, "PLH_TF_" + tf,
             "PLH_RXN_" + rxn, str(int(w2)))
     for k, row in variant_table().items():
         if tuple(row) == want:
@@ -77,52 +78,55 @@ def _sources_mtime():
     return max(os.path.getmtime(f) for f in files)
 
 
-def library(grid, variants, force=False):
-    """path of the grid library holding (at least) `variants` for `grid`, building it if it is missing, stale, or lacks one of them"""
+def library(grid, variants, force=False, machine_licm=False, extra_flags=(), suffix=""):
+    """path of the grid library holding (at least) `variants` for `grid`, building it if it is missing, stale, or lacks one of them.  The kernels are compiled with the flags
+    of the built-in library (buildflags.variant_flags); machine_licm=True is the fall-back build of a library that failed the kernel self-test (api._selftest_new_grid_library),
+    its files carry the suffix "_licm".  extra_flags / suffix: experiment builds (tools/experiments/)."""
     check(grid, thermal=any(variant_table()[v][2] == "true" for v in variants))
     tag, defs = defines(grid)
     os.makedirs(GRID_DIR, exist_ok=True)
     import fcntl
     with open(os.path.join(GRID_DIR, "%s.lock" % tag), "w") as lock:        # one builder per grid at a time (the ranks of a multi-process job ask for the same library)
         fcntl.flock(lock, fcntl.LOCK_EX)
-        return _library_locked(grid, variants, force, tag, defs)
+        return _library_locked(grid, variants, force, tag, defs, machine_licm, list(extra_flags), suffix + ("_licm" if machine_licm else ""))
 
 
-def _library_locked(grid, variants, force, tag, defs):
+def _library_locked(grid, variants, force, tag, defs, machine_licm=False, extra_flags=(), suffix=""):
     # The file name carries the variant ids it holds: a library is never rebuilt in place under a path that plh_register_grid_library may already have dlopen'ed in this
     # process (registering a known path is a no-op) -- a second model on the same grid with another variant gets a NEW file holding the union, registered next to the first.
     import glob
+    from . import buildflags
     fresh, have_best = _sources_mtime(), []
-    for manifest in sorted(glob.glob(os.path.join(GRID_DIR, "libplh_%s_v*.json" % tag))):
+    for manifest in sorted(glob.glob(os.path.join(GRID_DIR, "libplh_%s_v*%s.json" % (tag, suffix)))):
         lib = manifest[:-5] + ".so"
-        if not os.path.exists(lib) or os.path.getmtime(lib) < fresh:
+        meta = json.load(open(manifest))
+        if not os.path.exists(lib) or os.path.getmtime(lib) < fresh or meta.get("suffix", "") != suffix:
             continue
-        have = json.load(open(manifest))["variants"]
+        have = meta["variants"]
         if not force and set(variants) <= set(have):
             return lib
         if len(have) > len(have_best):
             have_best = have
     allv = sorted(set(have_best) | set(variants))
-    stem = os.path.join(GRID_DIR, "libplh_%s_v%s" % (tag, "_".join(str(v) for v in allv)))
+    stem = os.path.join(GRID_DIR, "libplh_%s_v%s%s" % (tag, "_".join(str(v) for v in allv), suffix))
     lib, manifest = stem + ".so", stem + ".json"
     src = os.path.join(CSRC, "variant_tu.hip")
-    common = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-Wno-pass-failed"] + defs
+    common = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-Wno-pass-failed"] + defs + list(extra_flags)
     jobs, objs = [], []
     for v in allv:
-        o = os.path.join(GRID_DIR, "%s_v%d.o" % (tag, v))
+        o = os.path.join(GRID_DIR, "%s%s_v%d.o" % (tag, suffix, v))
         objs.append(o)
-        # the build mode of the built-in isothermal kernels (__graft_entry__.py): -O3, every device function inlined late -- WITH MachineLICM, unlike the built-in library since
-        # r04: of the eleven test grids built without it, one (SEI, closure instantiation) failed the kernel self-test (the register-allocation miscompile class of DESIGN.md
-        # 5a); a library compiled on the user's machine has only that self-test behind it, not the GPU suite, so it keeps the flags under which every grid has passed
-        jobs.append(subprocess.Popen(common + ["-mllvm", "-amdgpu-function-calls=false", "-O3", "-DPL_VARIANT=%d" % v, "-c", src, "-o", o]))
-    glue = os.path.join(GRID_DIR, "%s_glue.o" % tag)
+        # the flags of the built-in kernels of this variant (buildflags.py: ONE table since r05; r04's grid libraries kept MachineLICM and late inlining for every variant
+        # and ran 2 ... 21 % behind the built-in kernels for it).  A library that fails the self-test on the user's machine is rebuilt with machine_licm=True.
+        jobs.append(subprocess.Popen(common + buildflags.variant_flags(v, machine_licm=machine_licm) + ["-DPL_VARIANT=%d" % v, "-c", src, "-o", o]))
+    glue = os.path.join(GRID_DIR, "%s%s_glue.o" % (tag, suffix))
     jobs.append(subprocess.Popen(common + ["-O2", "-DPL_GRID_GLUE", "-c", src, "-o", glue]))
     if any(j.wait() for j in jobs):
         raise RuntimeError("hipcc failed building the kernels of discretisation %r" % (grid,))
     tmp = lib + ".tmp%d" % os.getpid()                      # (a forced rebuild replaces the file atomically: a process that has the old one mapped keeps its inode)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", glue] + objs + ["-o", tmp])
     os.replace(tmp, lib)
-    json.dump({"grid": list(grid), "variants": allv}, open(manifest, "w"))
+    json.dump({"grid": list(grid), "variants": allv, "suffix": suffix, "machine_licm": bool(machine_licm), "extra_flags": list(extra_flags)}, open(manifest, "w"))
     for o in objs + [glue]:
         os.remove(o)
     return lib

@@ -130,13 +130,16 @@ class Opts:
         self.refine = 0             # n > 0: n steps of iterative refinement of every linear solve (parity mode, plh_opts.refine)
         self.yp_alg_zero = False    # True: start the integrator with YP_alg = 0 (the package version of the reference's example notebooks; plh_opts.yp_alg_zero)
         self.max_points = 2048      # capacity of the per-cell output buffers
+        # reference opts.stop_function (src/structures.jl:283; src/checks.jl:26: called after the built-in checks at every accepted step).  Here a closure g(t, Y, YP, p)
+        # of the same kind as an input closure: the run ends when g > 0 (exit flag 12, "Stop function"), back-interpolated like a built-in bound.  None: no hook.
+        self.stop_function = None
 
 
 # reference exit strings, src/checks.jl:6-217
 EXIT_REASONS = {
     0: "Final time reached", 1: "Below min. voltage", 2: "Above max. voltage", 3: "Below min. SOC", 4: "Above max. SOC",
     5: "Above max. temperature", 6: "Above max. c_s_n", 7: "Above max. C-rate", 8: "Below min. C-rate", 9: "Below min. c_e",
-    10: "Above max. film growth rate", 11: "Below min. η_plating",
+    10: "Above max. film growth rate", 11: "Below min. η_plating", 12: "Stop function",
     -1: "(not run)", -11: "Could not initialize DAE", -12: "Model failed to converge", -13: "Reached max iterations",
     -14: "Output buffer full",
 }

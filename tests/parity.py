@@ -455,3 +455,78 @@ def sens_compare(O, p, pkg, ens, i, th, soc, protocol, keys, ts, variant=None, r
                 sec[name] = (float(np.abs(np.asarray(ens.dY_dtheta[i, k, a:e]) - dY[a:e]).max() / sc), float(abs(th[col]) * sc / max(np.abs(Yd[a:e]).max(), floor)))
         out[key] = (eV, sec)
     return out
+
+
+# ---- r05: the quiet oracle, the reference-order device variants, the stop function ----
+def check_quiet_oracle_parity(p, O, pkg, n_cells=6, tol=1e-9, thermal_proto=False):
+    """The device's default build against `<variant>_quiet` -- the oracle with the cancelling stencils evaluated on differences (oracle/codegen.py) -- through :hold legs, at the
+    DEFAULT tolerances, per cell, no floor: identical integrator decisions in every run of every cell and end states / run-end times within `tol`.  (Against the plain oracle
+    variants the same cells differ by 1e-6 ... 1e-2: their generated Phi_s rows are quantised at ulp(Phi_s) and IDA's start-up order selection in a :hold leg reads that
+    rounding -- tests/test_oracle_golden.py::test_the_generated_phi_s_rows_are_quantised_and_the_notebook_shows_it, DESIGN.md 5.)"""
+    q = p.variant + "_quiet"
+    if thermal_proto:
+        cfg = pkg.configs.c3(p, 4096)
+        Th = np.ascontiguousarray(cfg["theta"][:: 4096 // n_cells][:n_cells]); protos = [(cfg["protocol"], 0.0)]
+        kw = dict(T_max=400.0, V_max=5.0, I_max=10.0, I_min=0.0, SOC_max=2.0)
+        protos.append(([dict(I=4.0, tf=300.0, **kw), dict(dT="hold", tf=200.0, **kw), dict(V="hold", tf=300.0, **kw)], 0.0))
+    else:
+        Th = np.ascontiguousarray(pkg.configs.sweep_theta(p, np.arange(n_cells), 4))
+        protos = [([dict(I=2.0, tf=900.0, V_max=5.0), dict(V="hold", tf=600.0, V_max=5.0, I_min=0.0), dict(P="hold", tf=100.0, V_max=5.0), dict(I="rest", tf=300.0), dict(I=-1.0, tf=600.0)], 0.0),
+                  ([{"I": 2.0, "tf": 1800.0, "V_max": 4.1}, {"V": "hold", "V_max": 4.1, "I_min": 1 / 20}], 0.0), ([{"I": -1.0}], 1.0)]
+    worst = 0.0
+    for proto, soc in protos:
+        ens = pkg.simulate_ensemble(p, Th, proto, SOC=soc)
+        runs = runs_to_oracle(O, p, pkg, proto)
+        for i in range(len(Th)):
+            ro = O.simulate(q, Th[i], soc, runs)
+            assert [int(f) for f in ens.run_info[i]["flag"]] == [r["flag"] for r in ro["runs"]], (i, ens.run_info[i], ro["runs"])
+            for f in ("n_steps", "n_res", "n_jac", "n_newton", "n_errfail", "n_convfail"):
+                assert int(ens.counters[i][f]) == ro["counters"][f], (i, f, ens.counters[i], ro["counters"])
+            e = state_rel_err(ens.Y[i], ro["Y"])
+            te = max(abs(float(ens.run_info[i, k]["t_end"]) - r["t_end"]) / max(1.0, r["t_end"]) for k, r in enumerate(ro["runs"]))
+            assert e <= tol and te <= tol, (i, e, te)
+            worst = max(worst, e, te)
+    return worst
+
+
+def check_reforder_variant(pr, O, pkg, variant):
+    """PLH_PREC_F64_REFORDER (precision = "f64_reforder"): same keys / patterns / evaluators as the plain variant's oracle (1e-12 of the terms: the rows differ by their own
+    rounding only), consistent initialisation to 1e-12, and a CC discharge -- whose decisions do not hang on rounding -- with the oracle's decisions"""
+    assert pr.precision == "f64_reforder" and pr.variant == variant
+    check_keys_and_pattern(pr, O)
+    check_evaluators(pr, O)
+    th = pr.theta_vector()
+    soc, proto = (0.0, [{"I": 2.0, "tf": 600.0}]) if pr.temperature else (1.0, [{"I": -1.0, "tf": 1200.0}])
+    ens = pkg.simulate_ensemble(pr, th[None, :], proto, SOC=soc)
+    ro = O.simulate(variant, th, soc, runs_to_oracle(O, pr, pkg, proto))
+    compare_trajectory(ens, 0, ro, rtol_state=1e-5)
+
+
+def check_stop_function(p, O, pkg, variant=None):
+    """opts.stop_function (reference src/checks.jl:26, src/structures.jl:283) as a traced closure g(t, Y, YP, p): the run ends when g > 0, exit flag 12, back-interpolated like a
+    built-in bound -- same step, same end point as the oracle; a hook that never fires changes nothing; a built-in bound that fires earlier wins."""
+    variant = variant or p.variant
+    ce = p.ind["c_e"]
+    Th = np.ascontiguousarray(pkg.configs.sweep_theta(p, np.arange(3), 4)) if not p.temperature and not p.aging else np.tile(p.theta_vector(), (2, 1))
+    cases = [("c_e gradient", lambda t, Y, YP, P: (Y[ce.stop - 1] - Y[ce.start]) - 400.0, [{"I": -2.0}], 1.0, 12)]
+    if p.temperature:
+        T = p.ind["T"]
+        # T_max per NODE (the reference's built-in T bound is on the average): the hottest of three nodes, written with max
+        cases.append(("node temperature", lambda t, Y, YP, P: pkg.closures.maximum(pkg.closures.maximum(Y[T.start + 12], Y[T.start + 25]), Y[T.start + 38]) - 303.0, [{"I": 4.0, "T_max": 400.0}], 0.0, 12))
+    cases.append(("never fires", lambda t, Y, YP, P: Y[ce.start] - 1e9, [{"I": -1.0, "tf": 600.0}], 1.0, 0))
+    cases.append(("a built-in bound wins", lambda t, Y, YP, P: t - 5000.0, [{"I": -2.0, "V_min": 3.6}], 1.0, 1))
+    cases.append(("time, second run of a chain", lambda t, Y, YP, P: t - 100.0, [{"I": -1.0, "tf": 50.0}, {"I": -0.5, "tf": 600.0}], 1.0, 12))
+    for name, g, proto, soc, flag in cases:
+        o = pkg.Opts(); o.stop_function = g
+        ens = pkg.simulate_ensemble(p, Th, proto, SOC=soc, opts=o)
+        prog = pkg.closures.trace(g, p)
+        runs = runs_to_oracle(O, p, pkg, proto)
+        for i in range(len(Th)):
+            ro = O.simulate(variant, Th[i], soc, runs, opts=O.default_opts(stop_program=prog))
+            assert int(ens.run_info[i, -1]["flag"]) == ro["runs"][-1]["flag"] == flag, (name, i, ens.run_info[i], ro["runs"])
+            compare_trajectory(ens, i, ro, rtol_state=1e-5)
+            if flag == 12 and "time" not in name:
+                assert abs(pkg.closures.evaluate(prog, 0.0, ens.Y[i], ens.YP[i], Th[i])) < 1e-6 * 400.0, name          # linear in Y: the back-interpolated end point sits on g = 0
+        if name == "never fires":
+            base = pkg.simulate_ensemble(p, Th, proto, SOC=soc)
+            assert np.array_equal(base.run_info["t_end"], ens.run_info["t_end"]) and np.abs(base.Y - ens.Y).max() <= 1e-9 * np.abs(base.Y).max()

@@ -857,3 +857,62 @@ def test_unsupported_discretisations_refuse(pkg, emu_model):
             pkg.petlion(pkg.LCO, **kw)
     with pytest.raises(pkg._capi.PetlionHipError, match="plh_register_grid_library"):       # the C ABI itself: an unregistered grid is refused with the way out in the message
         pkg.petlion(pkg.LCO, N_p=11, _lib_path=emu_model._lib._name, _grid_lib=False)
+
+
+# ---- r05 ----
+def test_default_build_is_the_quiet_oracle_through_hold_legs(emu_model, O, pkg):
+    """identical decisions and 1e-9 per cell against lco_iso_quiet, default tolerances, CC-CV / five-leg hold chain / 1C discharge (parity.check_quiet_oracle_parity)"""
+    w = parity.check_quiet_oracle_parity(emu_model, O, pkg, n_cells=3)
+    print("device vs quiet oracle, worst deviation over cells / protocols: %.1e" % w)
+
+
+def test_default_build_is_the_quiet_oracle_thermal_cc_ct_cv(emu_model_thermal, O, pkg):
+    w = parity.check_quiet_oracle_parity(emu_model_thermal, O, pkg, n_cells=2, thermal_proto=True, tol=1e-8)
+    print("thermal device vs quiet oracle, worst deviation: %.1e" % w)
+
+
+@pytest.fixture(scope="module")
+def emu_models_reforder(pkg):
+    import build_emu
+    lib = build_emu.build()
+    return pkg.petlion(pkg.LCO, precision="f64_reforder", _lib_path=lib), pkg.petlion(pkg.LCO, temperature=True, precision="f64_reforder", _lib_path=lib)
+
+
+def test_reference_order_variants(emu_models_reforder, O, pkg):
+    """PLH_PREC_F64_REFORDER: the finite-volume rows in the generated code's operation order (matrix form, source term first)"""
+    parity.check_reforder_variant(emu_models_reforder[0], O, pkg, "lco_iso")
+    parity.check_reforder_variant(emu_models_reforder[1], O, pkg, "lco_thermal")
+
+
+def test_reference_order_variant_follows_the_notebook_pinned_oracle_in_a_hold_leg(emu_model, emu_models_reforder, O, pkg):
+    """The A/B of DESIGN.md 5 on a handful of cells (the GPU suite runs it on 256): CC 900 s -> V hold 600 s.  The default build keeps the QUIET oracle's decisions in every
+    cell; the reference-order build's error against the tight solution is distributed like the plain (notebook-pinned) oracle's, whose decisions it keeps far more often
+    than the default build does."""
+    proto = [dict(I=2.0, tf=900.0, V_max=5.0), dict(V="hold", tf=600.0, V_max=5.0, I_min=0.0)]
+    n = 8
+    p0, pr = emu_model, emu_models_reforder[0]
+    Th = np.ascontiguousarray(pkg.configs.sweep_theta(p0, np.arange(n), 4))
+    runs = parity.runs_to_oracle(O, p0, pkg, proto)
+    e0, er = pkg.simulate_ensemble(p0, Th, proto, SOC=0.0), pkg.simulate_ensemble(pr, Th, proto, SOC=0.0)
+    CNT = ("n_steps", "n_res", "n_jac", "n_newton", "n_errfail", "n_convfail")
+    same_q = same_r = same_0 = 0
+    ratio_r = []
+    for i in range(n):
+        ro, rq = O.simulate("lco_iso", Th[i], 0.0, runs), O.simulate("lco_iso_quiet", Th[i], 0.0, runs)
+        rt = O.simulate("lco_iso", Th[i], 0.0, runs, opts=O.default_opts(maxiters=1000000, **parity.TIGHT), max_out=200000)
+        same_q += all(int(e0.counters[i][f]) == rq["counters"][f] for f in CNT)
+        same_0 += int(e0.counters[i]["n_steps"]) == ro["counters"]["n_steps"]
+        same_r += int(er.counters[i]["n_steps"]) == ro["counters"]["n_steps"]
+        ratio_r.append(parity.state_rel_err(er.Y[i], rt["Y"]) / parity.state_rel_err(ro["Y"], rt["Y"]))
+        assert parity.state_rel_err(e0.Y[i], rq["Y"]) <= 1e-9
+    print("default build: quiet oracle's decisions in %d / %d cells, plain oracle's step count in %d; reference-order build: plain oracle's step count in %d, error ratio median %.3f"
+          % (same_q, n, same_0, same_r, float(np.median(ratio_r))))
+    assert same_q == n and same_r >= same_0 and 0.8 <= float(np.median(ratio_r)) <= 1.25
+
+
+def test_stop_function(emu_model, O, pkg):
+    parity.check_stop_function(emu_model, O, pkg)
+
+
+def test_stop_function_thermal_node_temperature(emu_model_thermal, O, pkg):
+    parity.check_stop_function(emu_model_thermal, O, pkg)

@@ -716,7 +716,8 @@ def test_lgm50_with_temperature_on_gpu(hip_model_lgm50_thermal, O, pkg):
 ALL_VARIANTS = [("LCO", {}), ("NMC", {}), ("LCO", dict(aging="SEI")), ("NMC", dict(aging="SEI")), ("LCO", dict(temperature=True)),
                 ("LCO", dict(precision="mixed")), ("NMC", dict(aging="SEI", precision="mixed")), ("LCO", dict(temperature=True, precision="mixed")),
                 ("LCO", dict(solid_diffusion="quadratic")), ("LCO", dict(solid_diffusion="polynomial")), ("LCO", dict(thermodynamic_factor="nonlinear")),
-                ("LCO", dict(rxn_p="MHC", rxn_n="MHC")), ("NMC_LGM50", dict(temperature=False)), ("LCO", dict(waves_per_cell=2)), ("NMC_LGM50", {})]
+                ("LCO", dict(rxn_p="MHC", rxn_n="MHC")), ("NMC_LGM50", dict(temperature=False)), ("LCO", dict(waves_per_cell=2)), ("NMC_LGM50", {}),
+                ("LCO", dict(precision="f64_reforder")), ("LCO", dict(temperature=True, precision="f64_reforder"))]
 
 
 def test_every_kernel_instantiation_of_every_variant(hip_model, pkg):
@@ -726,7 +727,7 @@ def test_every_kernel_instantiation_of_every_variant(hip_model, pkg):
     the same (stops, table, closure: the input is the same number) and to the integration tolerance where it is not.  The guard DESIGN.md 5a asks for: a build whose register
     allocation goes wrong in ONE instantiation (seen once: a garbage SOC accumulator in <LCO, tables>) fails here whatever the model."""
     cl = pkg.closures
-    assert len(ALL_VARIANTS) == 15
+    assert len(ALL_VARIANTS) == 17
     n = 32
     for chem, kw in ALL_VARIANTS:
         p = pkg.petlion(getattr(pkg, chem), **kw)
@@ -747,3 +748,75 @@ def test_every_kernel_instantiation_of_every_variant(hip_model, pkg):
             assert np.abs(e.run_info["SOC"] - base.run_info["SOC"]).max() < 1e-11 and np.abs(e.run_info["V"] - base.run_info["V"]).max() <= vtol, \
                 (p.variant, name, np.abs(e.run_info["SOC"] - base.run_info["SOC"]).max(), np.abs(e.run_info["V"] - base.run_info["V"]).max())
             assert np.abs(e.SOC[:, 0] - 1.0).max() == 0.0, (p.variant, name)                  # (the first saved point: the accumulator starts from SOC0)
+
+
+# ---- r05 ----
+def test_default_build_is_the_quiet_oracle_through_hold_legs(hip_model, hip_model_thermal, O, pkg):
+    """Per cell, default tolerances, no floor: the device against `<variant>_quiet` (the oracle with the cancelling stencils on differences) keeps identical decisions in every run
+    of every cell and agrees to 1e-9 -- CC-CV, the five-leg hold chain, a 1C discharge on 64 C4 cells; C3's CC-CT-CV and the fixed-time thermal chain on 32 C3 cells."""
+    w = parity.check_quiet_oracle_parity(hip_model, O, pkg, n_cells=64)
+    wt = parity.check_quiet_oracle_parity(hip_model_thermal, O, pkg, n_cells=32, thermal_proto=True, tol=1e-8)
+    print("device vs quiet oracle: worst deviation isothermal %.1e (64 cells x 3 protocols), thermal %.1e (32 cells x 2 protocols)" % (w, wt))
+
+
+def test_reference_order_variants_on_gpu(pkg, O, hip_model):
+    parity.check_reforder_variant(pkg.petlion(pkg.LCO, precision="f64_reforder"), O, pkg, "lco_iso")
+    parity.check_reforder_variant(pkg.petlion(pkg.LCO, temperature=True, precision="f64_reforder"), O, pkg, "lco_thermal")
+
+
+def test_hold_leg_evaluation_order_ab(hip_model, O, pkg):
+    """what decides the step sequence of a V = :hold leg is the rounding of the Phi_s rows.  256 C4 cells, CC 900 s -> V hold 600 s:
+      * default build vs the QUIET oracle: identical decisions in every cell, 1e-9;
+      * reference-order build (precision = "f64_reforder") vs the PLAIN, notebook-pinned oracle: error against the tight solution distributed like the oracle's own (median
+        ratio in [0.8, 1.25]; r04's default build: 1.49), and the oracle's step count kept at least as often as its last-bit-perturbed self keeps it, minus 15 points."""
+    from concurrent.futures import ThreadPoolExecutor
+    import test_gpu_ensemble as tge
+    n = 256
+    p0, pr = hip_model, pkg.petlion(pkg.LCO, precision="f64_reforder")
+    proto = [dict(I=2.0, tf=900.0, V_max=5.0), dict(V="hold", tf=600.0, V_max=5.0, I_min=0.0)]
+    Th = np.ascontiguousarray(pkg.configs.sweep_theta(p0, np.arange(n), 4))
+    runs = parity.runs_to_oracle(O, p0, pkg, proto)
+    e0, er = pkg.simulate_ensemble(p0, Th, proto, SOC=0.0), pkg.simulate_ensemble(pr, Th, proto, SOC=0.0)
+
+    def one(i):
+        ro, rq = O.simulate("lco_iso", Th[i], 0.0, runs), O.simulate("lco_iso_quiet", Th[i], 0.0, runs)
+        rt = O.simulate("lco_iso", Th[i], 0.0, runs, opts=O.default_opts(maxiters=1000000, **parity.TIGHT), max_out=200000)
+        rp = O.simulate("lco_iso", Th[i], 0.0, runs, opts=O.default_opts(fd_perturb=2.2e-16, res_perturb=2.2e-16, perturb_seed=1 + i % 7))
+        return ro, rq, rt, rp
+    with ThreadPoolExecutor(tge._cores()) as ex:
+        R = list(ex.map(one, range(n)))
+    CNT = tge.CNT
+    same_q = sum(all(int(e0.counters[i][f]) == R[i][1]["counters"][f] for f in CNT) for i in range(n))
+    dev_q = max(parity.state_rel_err(e0.Y[i], R[i][1]["Y"]) for i in range(n))
+    e_orc = np.array([parity.state_rel_err(R[i][0]["Y"], R[i][2]["Y"]) for i in range(n)])
+    ratio_r = np.array([parity.state_rel_err(er.Y[i], R[i][2]["Y"]) for i in range(n)]) / e_orc
+    ratio_0 = np.array([parity.state_rel_err(e0.Y[i], R[i][2]["Y"]) for i in range(n)]) / e_orc
+    steps_r = sum(int(er.counters[i]["n_steps"]) == R[i][0]["counters"]["n_steps"] for i in range(n))
+    steps_0 = sum(int(e0.counters[i]["n_steps"]) == R[i][0]["counters"]["n_steps"] for i in range(n))
+    steps_p = sum(R[i][3]["counters"]["n_steps"] == R[i][0]["counters"]["n_steps"] for i in range(n))
+    print("CC -> V hold, %d cells: default build keeps the QUIET oracle's decisions in %d cells (max deviation %.1e); against the plain oracle: step count kept by the default build in %d, "
+          "by the reference-order build in %d, by the last-bit-perturbed oracle in %d; error / oracle error median: default %.3f, reference-order %.3f"
+          % (n, same_q, dev_q, steps_0, steps_r, steps_p, float(np.median(ratio_0)), float(np.median(ratio_r))))
+    assert same_q == n and dev_q <= 1e-9
+    assert 0.8 <= float(np.median(ratio_r)) <= 1.25 and steps_r >= steps_p - 0.15 * n and steps_r > steps_0
+
+
+def test_stop_function_on_gpu(hip_model, hip_model_thermal, O, pkg):
+    parity.check_stop_function(hip_model, O, pkg)
+    parity.check_stop_function(hip_model_thermal, O, pkg)
+
+
+def test_selftest_catches_a_broken_plain_kernel(pkg, hip_model):
+    """every comparison of the kernel self-test was against the PLAIN kernel of the same build.  Since r05 the plain kernel is checked against a committed
+    known answer (petlion.jl_amd/selftest_golden.json, from the validated binary): a grid library of the (3, 2, 2, 10) grid built with a deliberately wrong coefficient
+    (-DPL_TEST_BREAK_NODE_PASS: the c_e source term 1e-3 too large, in every instantiation alike) passes every plain-relative check and must fail the known answer."""
+    grid = (3, 2, 2, 10, 10, 10)          # (a grid no other test uses: the broken library stays registered for the life of the process, and the latest registration wins)
+    good = pkg.petlion(pkg.LCO, N_p=3, N_s=2, N_n=2)
+    assert pkg.api.known_answer_check(good) is None
+    pkg.selftest(good)
+    lib = pkg.grids.library(grid, [0], extra_flags=["-DPL_TEST_BREAK_NODE_PASS"], suffix="_broken")
+    bad = pkg.api.Model(pkg.LCO, pkg.api._N(p=3, s=2, n=2, a=10, z=10, r_p=10, r_n=10), False, False, grid_lib=lib)
+    why = pkg.api.known_answer_check(bad)
+    assert why is not None, "the deliberately broken node pass passed the known-answer check"
+    with pytest.raises(RuntimeError, match="known answer"):
+        pkg.selftest(bad)

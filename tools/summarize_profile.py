@@ -48,6 +48,29 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --config %s --steps 2 --warmup 1 --no-cpu-baseline --no-extras`; " % workload +
                          "FETCH_SIZE x 1024 B x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE x 1024 B; see %s_rocprofv3_summary.md" % label},
               open(os.path.join(ROOT, "profiles", "%s_traffic.json" % label), "w"), indent=1)
+# everything the bench line's issue roofline needs, per launch (bench.py issue_roofline): instruction counts and busy cycles are a property of (binary, workload)
+try:
+    import json, subprocess
+    sys.path.insert(0, ROOT)
+    info = ""
+    try:
+        import pkgload
+        info = pkgload.load().api.build_info()
+    except Exception:
+        pass
+    src_hash = info.split("src=")[-1] if "src=" in info else None
+    json.dump({"workload": workload, "cells_per_launch": cells, "precision": precision, "build_info": info, "build_src": src_hash,
+               "hbm_bytes_per_launch": (vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024) if ("FETCH_SIZE" in vals and "WRITE_SIZE" in vals) else None,
+               "kernel_us_avg": sum(d) / len(d) / 1e3, "kernel_us_steady": sum(d[-3:]) / 3e3, "counters": vals,
+               "source": "rocprofv3 --pmc (separate passes, tools/prof.sh) on `python bench.py --config %s --steps 2 --warmup 1 --no-cpu-baseline --no-extras`; per-launch averages over the "
+                         "k_integrate dispatches; SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md)" % workload},
+              open(os.path.join(ROOT, "profiles", "%s_pmc.json" % label), "w"), indent=1)
+except Exception as e:
+    print("pmc.json not written:", e)
+if "SQ_ACTIVE_INST_VALU" in vals and "SQ_WAVE_CYCLES" in vals:
+    L += ["", "VALU-busy share of the wave's cycles (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES): %.1f %%; LDS-busy %.1f %%; scalar-busy %.1f %%; VALU instructions x 4 cycles / wave cycles: %.1f %%."
+          % (100 * vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_WAVE_CYCLES"], 100 * vals.get("SQ_ACTIVE_INST_LDS", 0) / vals["SQ_WAVE_CYCLES"],
+             100 * vals.get("SQ_ACTIVE_INST_SCA", 0) / vals["SQ_WAVE_CYCLES"], 100 * vals.get("SQ_INSTS_VALU", 0) / vals["SQ_WAVE_CYCLES"])]
 if "SQ_WAVE_CYCLES" in vals:
     L += ["", "SQ_WAVE_CYCLES etc. count quad-cycles: %.3g shader cycles per wavefront; VALU-active fraction %.0f %%, s_waitcnt-parked fraction %.0f %%."
           % (4 * vals["SQ_WAVE_CYCLES"] / cells, 100 * vals.get("SQ_ACTIVE_INST_ANY", 0) / vals["SQ_WAVE_CYCLES"], 100 * vals.get("SQ_WAIT_ANY", 0) / vals["SQ_WAVE_CYCLES"])]
