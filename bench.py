@@ -537,6 +537,16 @@ def main():
         if world == 1 and not args.no_extras:
             out["host_inclusive"] = host_inclusive(pkg, p, inp, n_local, kavg_ms)
             out["general_path"] = general_path(pkg, p, inp, Theta, n_local, kavg_ms)
+            # like-for-like with r01-r03, whose timed launches also stored YP_final (and with it YP of the previous point at every step): the same workload with YP = True
+            ms = []
+            for r in range(6):
+                e2 = pkg.simulate_ensemble(p, Theta, inp["protocol"], SOC=inp["SOC"], device=True, max_points=inp["max_points"], YP=True)
+                torch.cuda.synchronize()
+                if r:
+                    ms.append(float(e2.kernel_ms))
+            out["with_YP_final"] = {"kernel_ms": float(np.mean(ms)), "trajectories_per_s": n_local / (np.mean(ms) * 1e-3), "vs_timed_region": kavg_ms / float(np.mean(ms)),
+                                    "what": "the timed region requests the reference's default output set (YP not kept: var_keep.YP is off); with YP_final requested the kernel also stores YP "
+                                            "of the previous accepted point per step (the r01-r03 bench lines were measured this way)"}
             if args.config == "C4" and args.precision == "f64":
                 out["predicted_scaling"] = predicted_scaling(pkg, p)
             # measured device-to-device copy bandwidth of this box (read + write bytes), the second peak SURVEY 8(d) asks to quote

@@ -913,7 +913,7 @@ static int ida_nls(ida_t* I) {
 static int ida_test_error(ida_t* I, double ck, double* err_k, double* err_km1) {
   int N = I->N, kk = I->kk;
   double enorm_k = wrms(N, I->ee, I->ewt);
-  if (getenv("ORC_TRACE_EE") && I->nst < atoi(getenv("ORC_TRACE_EE"))) for (int n = 0; n < N; n++) fprintf(stderr, "orc ee %d %d %.6e %.6e\n", I->nst + 1, n, I->ee[n], I->ee[n] * I->ewt[n]);
+  if (getenv("ORC_TRACE_EE") && I->nst < atoi(getenv("ORC_TRACE_EE"))) for (int n = 0; n < N; n++) fprintf(stderr, "orc ee %d %d %.6e %.6e\n", (int)I->nst + 1, n, I->ee[n], I->ee[n] * I->ewt[n]);
   *err_k = I->sigma[kk] * enorm_k; double terr_k = (kk + 1) * (*err_k);
   I->knew = kk; *err_km1 = 0.0;
   if (kk > 1) {

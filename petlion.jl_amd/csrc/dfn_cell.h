@@ -118,10 +118,23 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false, int PREC_ = 0, int SD_ = 
   using fact_t = typename std::conditional<MIXED, float, double>::type;
   // LDS diet: the error weights and the accumulated Newton correction live in registers (IdaScalars::ew / ee: they are only touched by the
   // lane-strided vector phases), and so do the BDF history vectors of order >= PHI_LDS
-  static constexpr int PHI_LDS = THERMAL_ ? 2 : MAXORD + 1;   // thermal: 40.7 kB -> four cells per CU
+  // r05, two cells per SIMD (PL_OCC2 builds, tools/experiments/occupancy.py): the isothermal Fickian models (with or without SEI) keep BDF history orders >= 2 in
+  // GLOBAL memory (per-cell block of 4 vectors, lane-strided and coalesced; L2-resident: 6 cells per CU x 9.7 kB) and read the eigen-decomposition of the radial operator from the
+  // model tables at a Jacobian refresh instead of an LDS copy: 37.5 kB -> 26.2 kB per cell, six cells per CU, and the kernels are compiled for two waves per SIMD (256 registers).
+  // -DPL_OCC2=4 (r05, second experiment): only the orders 4 and 5 go to global memory -- they are in use in a minority of the steps at the default tolerances (mean order 2.2 on
+  // C2) -- and everything else stays as it is: 37.5 -> 32.7 kB, FIVE cells per CU (the SIMD that holds two runs both at 256 registers, which costs this kernel nothing: measured).
+#ifdef PL_OCC2
+  static constexpr bool PHI_GLOBAL = !THERMAL_ && SD_ == 0 && W2_ == 0 && PREC_ != PLH_PREC_MIXED && (PL_OCC2 + 0 != 4 || !SEI_);
+  static constexpr int PHI_GLOBAL_FROM = (PL_OCC2 + 0 == 4) ? 4 : 2;          // first history order kept in global memory
+#else
+  static constexpr bool PHI_GLOBAL = false;
+  static constexpr int PHI_GLOBAL_FROM = 2;
+#endif
+  static constexpr bool PHI_GLOBAL_ALL = PHI_GLOBAL && PHI_GLOBAL_FROM == 2;  // the 26 kB layout: also no LDS copy of the eigen-decomposition, no predictor registers
+  static constexpr int PHI_LDS = THERMAL_ ? 2 : (PHI_GLOBAL ? PHI_GLOBAL_FROM : MAXORD + 1);   // thermal: 40.7 kB -> four cells per CU
   // predictor (y, y') of the step kept in registers across the Newton iteration (else re-summed from phi).  SEI models: since r04 -- with MachineLICM off (__graft_entry__.py) the
   // 24 registers are there (C5 24.6 k -> 25.2 k trajectories/s; with MachineLICM on it cost 1 %).  Thermal model: +0.3 %, within the noise of the boxes, left as it was.
-  static constexpr bool PRED_REGS = !THERMAL_;
+  static constexpr bool PRED_REGS = !THERMAL_ && !PHI_GLOBAL_ALL;      // (the 26 kB layout: 256 registers per lane, the predictor is re-summed)
   static constexpr int NB = THERMAL_ ? 4 : 3;        // node block size of the block-Thomas solve: (c_e, Phi_e, Phi_s[, T])
   static constexpr int O_T = N_CECS;
   static constexpr int O_FILM = N_CECS + (THERMAL_ ? NT : 0), O_SOH = O_FILM + NN;
@@ -262,7 +275,7 @@ template <class M> struct alignas(16) CellLDS {
   // its eigen-decomposition (copies of Tables::V, W, LAM): the resolvents are rebuilt from them at every Jacobian refresh, and reading the tables from HBM there cost
   // 9.7 k cycles per refresh (two dependent rounds of global / scalar loads); from LDS, with the 2 N_r^2 entries spread over the wave, 1 k
   // (one array, so that the models without it -- thermal: 40 952 of the 40 960 B that four cells per CU allow -- pay 8 bytes, not 32)
-  static constexpr int MR_BLK = M::THERMAL ? 3 * NR * NR : 3 * NR * NR + NR;                  // (thermal: M, V, W; the eigenvalues are only read at a factorisation)
+  static constexpr int MR_BLK = M::PHI_GLOBAL_ALL ? NR * NR : (M::THERMAL ? 3 * NR * NR : 3 * NR * NR + NR);   // (thermal: M, V, W; the eigenvalues are only read at a factorisation; PHI_GLOBAL: M only)
   alignas(16) double Mr[M::SD != 0 ? 1 : (NR_EQ ? 1 : 2) * MR_BLK];                          // (N_r_p != N_r_n: the cathode's block, then the anode's, both at stride NR, zero-padded)
   static constexpr int OFF_VR = NR * NR, OFF_WR = 2 * NR * NR, OFF_LAMR = 3 * NR * NR;
   static __host__ __device__ constexpr int mr_el(int el) { return NR_EQ ? 0 : el * MR_BLK; }  // offset of electrode el's block
@@ -308,6 +321,9 @@ struct SensArgs {               // (device pointers; part of IntegrateArgs)
   double* dV;                   // [n_cells][n_sens][max_pts] or nullptr: dV/dtheta_k at every saved point
   int* stat;                    // [n_cells][2] or nullptr: corrector iterations, solves that did not reach the tolerance
   double* cbak;                 // [n_cells][SENS_CBAK]: the cell's theta-derived constants, saved once and copied back after every evaluation with a perturbed theta row
+  double* aux;                  // [n_cells][n_sens][4]: per parameter [0] d(held input value)/dtheta of the run being integrated (a :hold run: the previous run's end sensitivity of
+                                // the held quantity), [1] dSOC/dtheta (trapezoid of dI/dtheta over the saved points, like calc_SOC), [2] dI/dtheta at the previous saved point,
+                                // [3] the last step's increment of [1]
 };
 constexpr int SENS_CBAK = 384;
 
@@ -747,12 +763,16 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
   }
   if constexpr (INIT) {
   if constexpr (M::SD == 0) { if (wave_id() == M::NWAVES - 1) {
+    if constexpr (M::PHI_GLOBAL_ALL) {                      // M only: V, W, LAM are read from the tables at a factorisation (iso_factor)
+      for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->Mp()[k]; S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; if constexpr (!NR_EQ) S.Mr[S.mr_el(1) + k] = tb->Mp(1)[k]; }
+    } else {
     for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[k] = tb->Mp()[k]; S.Mr[S.OFF_VR + k] = tb->Vp()[k]; S.Mr[S.OFF_WR + k] = tb->Wp()[k]; if constexpr (!M::THERMAL) { S.Ainv[0][k] = 0.0; S.Ainv[1][k] = 0.0; } }
     if constexpr (!M::THERMAL) { if (lane < NR) S.Mr[S.OFF_LAMR + lane] = tb->LAMp()[lane]; }
     if constexpr (!NR_EQ) {                                 // the anode's block (the tables are already zero-padded to the common stride: plh_model_create)
       for (int k = lane; k < NR * NR; k += WAVE) { S.Mr[S.mr_el(1) + k] = tb->Mp(1)[k]; S.Mr[S.mr_el(1) + S.OFF_VR + k] = tb->Vp(1)[k]; S.Mr[S.mr_el(1) + S.OFF_WR + k] = tb->Wp(1)[k]; }
       if constexpr (!M::THERMAL) { if (lane < NR) S.Mr[S.mr_el(1) + S.OFF_LAMR + lane] = tb->LAMp(1)[lane]; }
-    } } }
+    } }
+    } }
   for (int k = 0; k < CS_PASS; k++) { R.wreg[k] = 0.0; R.rcp[k] = 0.0; }
   }
   PL_XSYNC();
@@ -1287,7 +1307,8 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
   if (!alg_only && (!M::W2 || wave_id() == 1)) {          // (two waves per cell: the resolvents are wave 1's, next to wave 0's Jacobian node pass)
     const int r = lane % NR;
     // the 2 N_r reciprocals 1/(kappa lam_m - cj) are formed by 2 N_r lanes in parallel and passed through S.w9 (free outside the solves)
-    if constexpr (NR_EQ) { if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * S.Mr[S.OFF_LAMR + r] - cj); }
+    if constexpr (M::PHI_GLOBAL_ALL) { if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * tb->LAMp(lane < NR ? 0 : 1)[r] - cj); }
+    else if constexpr (NR_EQ) { if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * S.Mr[S.OFF_LAMR + r] - cj); }
     else { if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * S.Mr[(lane < NR ? 0 : S.MR_BLK) + S.OFF_LAMR + r] - cj); }      // (padded modes: lam = 0, V = W = 0)
     PL_SYNC();
     // entry (row, k) of electrode el = sum_m V[row][m] w_el[m] W[m][k], m ascending; lanes 0..31 build the cathode's resolvent, 32..63 the anode's, RS_KG lanes per row with
@@ -1298,7 +1319,11 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     double acc[RS_KW];
     for (int kk = 0; kk < RS_KW; kk++) acc[kk] = 0.0;
     _Pragma("unroll 2") for (int m = 0; m < NR; m++) {            // (fully unrolled, the 60 operands of the sums are all live at once: 132 B/lane of scratch in the integrate kernel)
-      if constexpr (NR_EQ) {
+      if constexpr (M::PHI_GLOBAL_ALL) {                        // (the same sums in the same order; operands from the model tables: L2 hits, once per Jacobian refresh)
+        const double* __restrict__ Vt = tb->Vp(el); const double* __restrict__ Wt = tb->Wp(el);
+        const double f = Vt[row * NR + m] * S.w9[el * NR + m];
+        for (int kk = 0; kk < RS_KW; kk++) acc[kk] += f * Wt[m * NR + (k0 + kk < NR ? k0 + kk : NR - 1)];
+      } else if constexpr (NR_EQ) {
         const double f = S.Mr[S.OFF_VR + row * NR + m] * S.w9[el * NR + m];
         for (int kk = 0; kk < RS_KW; kk++) acc[kk] += f * S.Mr[S.OFF_WR + m * NR + (k0 + kk < NR ? k0 + kk : NR - 1)];
       } else {

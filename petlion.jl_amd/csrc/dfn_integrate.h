@@ -25,6 +25,7 @@ struct IdaScalars {   // the coefficient arrays psi/alpha/beta/sigma/gamma live 
   double pa[NTRIP_MAX], pb[NTRIP_MAX];   // predictor y_n(0), y'_n(0) of the step (models with M::PRED_REGS)   // per-lane entries of the BDF history vectors that are not kept in LDS (models with M::PHI_LDS < 6): [j - PHI_LDS][trip]
   int kk, kused, knew, phase, ns, maxord;
   int nst;
+  double* phg;               // models with M::PHI_GLOBAL: this cell's block of BDF history orders 2 .. 5 in global memory, [4][NPAD], entry n of a vector in lane n % 64
 };
 
 // Feature flags of the integrate kernel's instantiations.  The step loop keeps ~60 per-lane values live next to the cell's LDS block, and code that is merely PRESENT in it costs
@@ -47,14 +48,16 @@ __device__ __forceinline__ void cnt_add(Counters& c, int k, int v = 1) { c.v[k] 
 // lane-strided sweep over the N state entries: exactly 5 trips (301 = 4*64 + 45), fully unrolled so that the LDS loads of all
 // trips are issued back to back (one latency instead of five); only the last trip is predicated.
 // BDF history access inside a PL_VEC loop (k__ = compile-time trip index): vectors j < M::PHI_LDS are LDS arrays, the rest registers in I.ph
-#define PHI_RD(j, n) ((M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? S.phi[(M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? (j) : 0][n] : ((j) == M::PHI_LDS ? I.ph[0][k__] : ((j) == M::PHI_LDS + 1 ? I.ph[1][k__] : ((j) == M::PHI_LDS + 2 ? I.ph[2][k__] : I.ph[3][k__]))))
-#define PHI_WR(j, n, v) do { if (M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) S.phi[(M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? (j) : 0][n] = (v); \
+#define PHI_RD(j, n) (M::PHI_GLOBAL ? ((j) < M::PHI_LDS ? S.phi[(j) < M::PHI_LDS ? (j) : 0][n] : I.phg[((j) - M::PHI_LDS) * M::NPAD + (n)]) : PHI_RD_R(j, n))
+#define PHI_WR(j, n, v) do { if constexpr (M::PHI_GLOBAL) { if ((j) < M::PHI_LDS) S.phi[(j) < M::PHI_LDS ? (j) : 0][n] = (v); else I.phg[((j) - M::PHI_LDS) * M::NPAD + (n)] = (v); } else PHI_WR_R(j, n, v); } while (0)
+#define PHI_RD_R(j, n) ((M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? S.phi[(M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? (j) : 0][n] : ((j) == M::PHI_LDS ? I.ph[0][k__] : ((j) == M::PHI_LDS + 1 ? I.ph[1][k__] : ((j) == M::PHI_LDS + 2 ? I.ph[2][k__] : I.ph[3][k__]))))
+#define PHI_WR_R(j, n, v) do { if (M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) S.phi[(M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? (j) : 0][n] = (v); \
                              else if ((j) == M::PHI_LDS) I.ph[0][k__] = (v); else if ((j) == M::PHI_LDS + 1) I.ph[1][k__] = (v); \
                              else if ((j) == M::PHI_LDS + 2) I.ph[2][k__] = (v); else I.ph[3][k__] = (v); } while (0)
 // accumulated correction ee inside a PL_VEC loop
 #define EE(n) I.ee[k__]
 // some BDF history orders live in registers (thermal model): the step-control passes then index the history with compile-time orders under wave-uniform branches
-template <class M> constexpr bool PHI_REGS = M::PHI_LDS <= MAXORD;
+template <class M> constexpr bool PHI_REGS = M::PHI_LDS <= MAXORD && !M::PHI_GLOBAL;      // (history in global memory: a runtime order is just an address, as with the whole history in LDS)
 #ifdef PL_EXP_BRANCHY_PHI
 constexpr bool PL_BRANCHY_PHI = true;
 #else
@@ -673,7 +676,9 @@ PL_DEV void ida_get_solution(CellLDS<M>& S, const IdaScalars& I, double t, doubl
   PL_GS_STEP(1, rp0, rp1, c1, d0) PL_GS_STEP(2, rp1, rp2, c2, d1) PL_GS_STEP(3, rp2, rp3, c3, d2) PL_GS_STEP(4, rp3, rp4, c4, d3) PL_GS_STEP(5, rp4, rp5, c5, d4)
 #undef PL_GS_STEP
   PL_VEC(n) {
-    const double p1 = S.phi[1][n], p2 = PHI_RD(2, n), p3 = PHI_RD(3, n), p4 = PHI_RD(4, n), p5 = PHI_RD(5, n);
+    // (history in global memory: orders beyond the one in use have never been written)
+    const double p1 = S.phi[1][n], p2 = (!M::PHI_GLOBAL || kord >= 2) ? PHI_RD(2, n) : 0.0, p3 = (!M::PHI_GLOBAL || kord >= 3) ? PHI_RD(3, n) : 0.0,
+                 p4 = (!M::PHI_GLOBAL || kord >= 4) ? PHI_RD(4, n) : 0.0, p5 = (!M::PHI_GLOBAL || kord >= 5) ? PHI_RD(5, n) : 0.0;
     double s = S.phi[0][n] + c1 * p1, sp = d0 * p1;
     if (kord >= 2) { s += c2 * p2; sp += d1 * p2; }
     if (kord >= 3) { s += c3 * p3; sp += d2 * p3; }
@@ -872,10 +877,11 @@ struct CellOut {
 template <int F, class M>
 PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
                                      const CellOut& out, int* n_pts_out, plh_run_info* info, Counters& cnt, double* Yfin, double* YPfin,
-                                     double* Yprev, double* YPprev, int cell, double* genW = nullptr, SensArgs sens = SensArgs(), const double* th0 = nullptr) {
+                                     double* Yprev, double* YPprev, int cell, double* genW = nullptr, SensArgs sens = SensArgs(), const double* th0 = nullptr, double* phig = nullptr) {
   PL_MODEL(M);
   const int lane = lane_id();
   IdaScalars I;
+  I.phg = phig;
   [[maybe_unused]] SensCell<M> SX;
   if constexpr ((F & GF_SENS) != 0) { SX.a = sens; SX.th0 = th0; SX.cell = cell; SX.P = tb->P; SX.max_pts = out.max_pts; SX.first = true; SX.n_it = 0; SX.n_fail = 0; }
   int nout = 0;
@@ -979,6 +985,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     PrevVals pv; pv.frac = 1.0; pv.V = -1; pv.SOC = -1; pv.I = -1; pv.c_s_n = -1; pv.c_e_min = -1; pv.eta_pl = -1; pv.dfilm = -1; pv.T = -1; pv.g = -1;
     double tprev = 0.0, t = 0.0, t_prev_saved = t0; int iter = 1; bool stalled_once = false;
     double I_prev_pt = 0.0, t_restart = 0.0;
+    [[maybe_unused]] double soc_nm1_s = 0.0, dt_step_s = 0.0, soc_n_s = 0.0;      // (sensitivities: the trapezoid SOC at the last two accepted points and the step between them)
     bool first_init = true, again = false, init_failed = false;
     [[maybe_unused]] int steps_since_restart = 2;                       // (accepted steps since a check_reinitialization! restart; 2 = "more than one")
     do {                                                                // (re)initialise -> integrate ; loops only for check_reinitialization!
@@ -995,7 +1002,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
       PL_SYNC();
       I_prev_pt = S.yy[O_I];
-      if constexpr ((F & GF_SENS) != 0) sens_init(S, SX, mode, value, new_run, SOC0, o.reltol, o.abstol, nout - 1);
+      if constexpr ((F & GF_SENS) != 0) sens_init(S, SX, mode, value, new_run, SOC0, o.reltol, o.abstol, nout - 1, run.value_kind == PLH_VAL_HOLD && have_prev, prev_V, prev_I);
     }
     while (flag == PLH_FLAG_RUNNING) {
       double tret = t; tprev = t;
@@ -1015,6 +1022,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
           // the reference's solve! has already pushed this (repeated) point and run the stop checks when check_solve shortens the first step
           // (model_evaluation.jl:319-327, checks.jl:227-231): run.info.iterations stays equal to the number of saved points of the run
           save_pt(nout, t + t0, S.yy, SOC); nout++;
+          if constexpr ((F & GF_SENS) != 0) sens_repeat_point(S, SX, nout - 1);      // (the repeated point: the sensitivities of the point it repeats)
           check_stop<F>(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
           continue;
         }
@@ -1024,12 +1032,14 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       if constexpr ((F & GF_FUNC) != 0) steps_since_restart++;
       PL_TIC(); PL_TICE(3);
       const double SOC_new = SOC + 0.5 * ((t + t0) - t_prev_saved) * (S.yy[O_I] + I_prev_pt) / 3600.0;   // calc_SOC, scalar_residual.jl:103-111
+      [[maybe_unused]] const double dt_saved = (t + t0) - t_prev_saved, soc_before = SOC;
+      if constexpr ((F & GF_SENS) != 0) { soc_nm1_s = soc_before; dt_step_s = dt_saved; }
       SOC = SOC_new;
       save_pt(nout, t + t0, S.yy, SOC); nout++;
       PL_TOCE(S, 3, 4);
       check_stop<F>(S, run, o, t, run.tf, S.yy, S.yp, SOC, pv, flag);
       PL_TOCE(S, 3, 5);
-      if constexpr ((F & GF_SENS) != 0) sens_step(S, R, I, SX, mode, value, nout - 1);      // (the solution point in S.yy / S.yp is saved and restored around it)
+      if constexpr ((F & GF_SENS) != 0) sens_step(S, R, I, SX, mode, value, nout - 1, dt_saved);      // (the solution point in S.yy / S.yp is saved and restored around it)
       if (!is_fun && t == tprev) { flag = PLH_ERR_STALL; break; }      // (run_function has no stall test, checks.jl:251-269; run_residual -- res, dT, d<state> -- has: checks.jl:226)
       if (iter == o.maxiters) { flag = PLH_ERR_MAXITERS; break; }
       if (nout >= out.max_pts && out.max_pts > 0 && flag == PLH_FLAG_RUNNING) { flag = PLH_ERR_OUTPUT_FULL; break; }
@@ -1059,6 +1069,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     } while ((F & GF_FUNC) && again && flag == PLH_FLAG_RUNNING);
     if (init_failed) { if (lane == 0) info[r] = ri; for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; info[q] = z; } break; }
     double t_end = t + t0;
+    if constexpr ((F & GF_SENS) != 0) soc_n_s = SOC;
     if (flag > 0 && o.interp_final && t > 1.0) {                        // interp_final_points!, model_evaluation.jl:369-382
       const double fr = pv.frac;
       const double ti = fr * (t - tprev) + tprev;
@@ -1076,7 +1087,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       t_end = ti + t0;
       save_pt(nout - 1, t_end, S.yy, SOC);
     }
-    if constexpr ((F & GF_SENS) != 0) sens_finish(S, SX, flag > 0 && o.interp_final && t > 1.0, pv.frac, flag < 0, nout - 1, flag, run.bounds, mode);
+    if constexpr ((F & GF_SENS) != 0) sens_finish(S, SX, flag > 0 && o.interp_final && t > 1.0, pv.frac, flag < 0, nout - 1, flag, run.bounds, mode, soc_n_s, soc_nm1_s, dt_step_s, S.yy[O_I]);
     ri.flag = flag; ri.iterations = iter; ri.t_end = t_end; ri.V = cellV<M>(S.yy); ri.I = S.yy[O_I]; ri.SOC = SOC; ri.T_avg = cellTavg<M>(S, S.yy);
     if (lane == 0 && wave_id() == 0) info[r] = ri;
     have_prev = true;

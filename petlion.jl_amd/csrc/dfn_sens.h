@@ -24,7 +24,7 @@
 #pragma once
 // (included from dfn_integrate.h, inside namespace pl, after IdaScalars / PL_VEC / EWT)
 
-constexpr int SENS_MAXIT = 24;
+constexpr int SENS_MAXIT = 64;
 // weights of the sensitivity norms: 1 / (|y_n| + abstol / reltol) = the integrator's error weights with the tolerance divided out -- the corrector stops when a correction,
 // times the parameter, is below SENS_TOL of the scale of each state (the difference quotients carry ~1e-9 of rounding: a criterion that tightened with reltol could not be met)
 // (and not below 1 % of the integration's own relative tolerance: at reltol 1e-3 a corrector driven to 1e-7 spends its iterations on digits the step does not have)
@@ -42,7 +42,19 @@ template <class M> struct SensCell {
   int n_it, n_fail;
   __device__ __forceinline__ double* hist(int k, int j) const { return a.hist + (((size_t)cell * a.n_sens + k) * (MAXORD + 1) + j) * M::NPAD; }
   __device__ __forceinline__ const double* thp(int k) const { return a.theta_pert + ((size_t)cell * a.n_sens + k) * P; }
+  __device__ __forceinline__ double* aux(int k) const { return a.aux + ((size_t)cell * a.n_sens + k) * 4; }
 };
+
+// the quantity a :hold run holds, as a linear functional of a state vector (initial_current!, input_methods.jl:11-74: V = Phi_s[1] - Phi_s[end], I, eta_plating); power is
+// bilinear (I I1C V) and handled where it is used
+template <class M>
+__device__ __forceinline__ double sens_hold_g(int mode, const double* v) {
+  PL_MODEL(M);
+  if (mode == PLH_MODE_V) return v[O_PS] - v[O_PS + NJ - 1];
+  if (mode == PLH_MODE_I) return v[O_I];
+  if (mode == PLH_MODE_ETA_P) return v[O_PS + NP] - v[O_PE + NP + NS];
+  return 0.0;
+}
 
 // The cell's theta-derived constants (CellConst, the conduction / weighting tables of the thermal model, the SOH quadrature weights of the SEI model) are SAVED once and COPIED
 // back after every evaluation with a perturbed theta row.  Recomputing them from the unperturbed row would be the same arithmetic -- but in another inlined copy of cell_setup,
@@ -90,12 +102,14 @@ PL_DEV void sens_put_V(CellLDS<M>& S, const SensCell<M>& X, int k, int idx) {
 
 // start of a run (after the consistent initialisation and ida_reinit: S.phi[0] = y0, S.yp = y'0, the algebraic block factored): s_k(t0), s'_k(t0) -> history
 template <class M>
-PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, bool new_solution, double SOC0, double rtol, double atol, int idx) {
+PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, bool new_solution, double SOC0, double rtol, double atol, int idx,
+                      bool hold = false, double prev_V = 0.0, double prev_I = 0.0) {
   PL_MODEL(M);
   const int lane = lane_id();
   LaneRegs Ra;                                            // (the algebraic solves do not touch the particle registers)
   for (int q = 0; q < CS_PASS; q++) { Ra.wreg[q] = 0.0; Ra.rcp[q] = 0.0; }
   sens_consts<true>(S, X);
+  const double I1C0 = S.cc.I1C;
   const int amode = (M::THERMAL && mode == PLH_MODE_DT) ? PL_MODE_DT_TWIN : mode;      // the algebraic form of the dT row (cell_init_consistent)
   double yn[NTRIP], ypn[NTRIP], f0[NTRIP], w[NTRIP], zero[NTRIP];
   PL_VEC(n) { yn[k__] = S.yy[n]; ypn[k__] = S.yp[n]; zero[k__] = 0.0; w[k__] = 1.0 / (fabs(S.phi[0][n]) + atol / rtol); }
@@ -115,8 +129,20 @@ PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, boo
       PL_VEC(n) s[k__] = n < NDIFF ? (S.delta[n] - S.phi[0][n]) / dth : 0.0;
       PL_XSYNC();
     } else { PL_VEC(n) s[k__] = h0[n]; }                  // carried from the end of the previous run (the algebraic part: first guess only)
+    // A :hold run holds the value its quantity had at the end of the previous run (initial_current!, input_methods.jl:11-74) -- which depends on theta: d value / d theta_k is
+    // that quantity's sensitivity at the previous run's end (h0 still holds it), one constant term -d value / d theta_k in F_theta of the control row for the whole run.
+    // Power: value = I I1C V with I1C a function of theta (the perturbed constants are current here).  dT = :hold holds 0 K/s: no term.  A new solution holds nothing.
+    double dval = 0.0;
+    if (hold && !new_solution) {
+      if (mode == PLH_MODE_P) {
+        const double I1Cp = S.cc.I1C;                      // (of the perturbed row: cell_setup<M, false> above; I1C0: read before the k loop)
+        const double sV = h0[O_PS] - h0[O_PS + NJ - 1], sI = h0[O_I];
+        dval = I1C0 * (sI * prev_V + prev_I * sV) + prev_I * prev_V * ((I1Cp - I1C0) / dth);
+      } else dval = sens_hold_g<M>(mode, h0);
+    }
+    if (lane == 0 && wave_id() == 0) { double* ax = X.aux(k); ax[0] = dval; if (new_solution) { ax[1] = 0.0; ax[3] = 0.0; } }
     sens_eval(S, Ra, zero, zero, ypn, 0.0, amode, value);
-    PL_VEC(n) fp[k__] = (S.delta[n] - f0[k__]) / dth;
+    PL_VEC(n) { fp[k__] = (S.delta[n] - f0[k__]) / dth; if (n == O_I) fp[k__] -= dval; }
     sens_consts<false>(S, X);
     PL_XSYNC();
     // algebraic part: G_ya s_a = -(G_yd s_d + G_theta), Newton-like with the factorisation of the last initialisation iterate
@@ -153,6 +179,7 @@ PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, boo
       PL_VEC(n) S.delta[n] = s[k__];
       PL_XSYNC();
       sens_put_V(S, X, k, idx);
+      if (lane == 0 && wave_id() == 0) X.aux(k)[2] = S.delta[O_I];      // dI/dtheta at the first saved point of the run (the SOC trapezoid of the first step)
       PL_XSYNC();
     }
   }
@@ -163,7 +190,7 @@ PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, boo
 
 // after an accepted step: advance every s_k over the same step (S.phi = history after IDACompleteStep, S.yy / S.yp = y(tn), y'(tn), I = the step's coefficients)
 template <class M>
-PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<M>& X, int mode, double value, int idx) {
+PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<M>& X, int mode, double value, int idx, double dt_saved = 0.0) {
   PL_MODEL(M);
   const int lane = lane_id();
   const int ku = I.kused; const double cj = I.cj;
@@ -180,7 +207,8 @@ PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<
     PL_XSYNC();
     cell_setup<M, false>(S, R, S.tb, tp);
     sens_eval(S, R, zero, zero, ypn, 0.0, mode, value);
-    PL_VEC(n) fp[k__] = (S.delta[n] - f0[k__]) / dth;
+    const double dval = X.aux(k)[0];                       // d(held value)/d theta_k of a :hold run (sens_init), 0 otherwise: the control row is g(Y) - value
+    PL_VEC(n) { fp[k__] = (S.delta[n] - f0[k__]) / dth; if (n == O_I) fp[k__] -= dval; }
     sens_consts<false>(S, X);
     PL_XSYNC();
     // predictor from the history (IDASetCoeffs' rescaling phi*_j = beta_j phi_j for j >= ns is applied in place, as form_iterate does for y)
@@ -195,6 +223,7 @@ PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<
     }
     PL_VEC(n) s[k__] = a_[k__];
     bool conv = false;
+    double nr_old = 0.0;
     for (int it = 0; it < SENS_MAXIT; it++) {
       double sp[NTRIP], m = 0.0;
       PL_VEC(n) { sp[k__] = b_[k__] + cj * (s[k__] - a_[k__]); const double q = fabs(s[k__]) * EWT(n); m = q > m ? q : m; }
@@ -212,6 +241,12 @@ PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<
       PL_XSYNC();
       if (nr <= sens_tol(I.rtol)) { conv = true; break; }
       if (!(nr == nr)) break;
+      // r05: IDANls' own convergence test beside the fixed one -- the corrector is linear, its rate is that of the integrator's (possibly stale) matrix: with the estimated
+      // rate q the remaining error is q / (1 - q) x the last correction, and a sensitivity is converged for a step integrated at reltol once that is below 0.33 reltol of the
+      // state scale per unit relative parameter change (IDAS' criterion).  At tight tolerances 0.33 reltol is below sens_tol and nothing changes; at the default ones the
+      // steps near a voltage knee, where the stale matrix converges at 0.8 ... 0.9, no longer run into the iteration cap (r04: 4263 of 4.7 M solves of the C4 shard did)
+      if (it > 0) { const double q = nr / nr_old; if (q < 0.97 && q / (1.0 - q) * nr <= 0.33 * I.rtol) { conv = true; break; } }
+      nr_old = nr;
     }
     if (!conv) X.n_fail++;
     // history update (IDACompleteStep): phi[ku+1] = e, phi[ku] += e, phi[j] += phi[j+1]
@@ -223,11 +258,26 @@ PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<
       PL_VEC(n) S.delta[n] = acc[k__];                     // = s_k(t_n)
       PL_XSYNC();
       sens_put_V(S, X, k, idx);
+      // dSOC/dtheta: the trapezoid of dI/dtheta over the saved points, like calc_SOC (scalar_residual.jl:103-111)
+      if (lane == 0 && wave_id() == 0) { double* ax = X.aux(k); const double sI = S.delta[O_I], inc = 0.5 * dt_saved * (sI + ax[2]) / 3600.0; ax[1] += inc; ax[3] = inc; ax[2] = sI; }
       PL_XSYNC();
     }
   }
   X.first = false;
   PL_VEC(n) { S.yy[n] = yn[k__]; S.yp[n] = ypn[k__]; }
+  PL_XSYNC();
+}
+
+// the point check_solve's first-step retry repeats (checks.jl:227-237): dV/dtheta of the point it repeats (hist[0] = s at the start of the run)
+template <class M>
+PL_DEV void sens_repeat_point(CellLDS<M>& S, const SensCell<M>& X, int idx) {
+  PL_MODEL(M);
+  const int lane = lane_id();
+  for (int k = 0; k < X.a.n_sens; k++) {
+    const double* h0 = X.hist(k, 0);
+    PL_XSYNC();
+    if (lane == 0 && wave_id() == 0 && X.a.dV && idx >= 0 && idx < X.max_pts) X.a.dV[((size_t)X.cell * X.a.n_sens + k) * X.max_pts + idx] = h0[O_PS] - h0[O_PS + NJ - 1];
+  }
   PL_XSYNC();
 }
 
@@ -251,12 +301,15 @@ PL_DEV double sens_event_g(const CellLDS<M>& S, int flag, int ix, const double* 
 // Reported is the sum -- the derivative of the end state AS simulate() RETURNS IT; in particular dV/dtheta of a run that ends on a voltage bound is 0.  An SOC bound under a
 // constant current is crossed at a time that does not depend on theta (fr fixed); an SOC bound in another mode, and the dfilm bound (a bound on YP), give NaN.
 template <class M>
-PL_DEV void sens_finish(CellLDS<M>& S, SensCell<M>& X, bool interp, double fr, bool failed, int idx, int flag, const plh_bounds& bd, int mode) {
+PL_DEV void sens_finish(CellLDS<M>& S, SensCell<M>& X, bool interp, double fr, bool failed, int idx, int flag, const plh_bounds& bd, int mode,
+                        double soc_n = 0.0, double soc_nm1 = 0.0, double dt_step = 0.0, double I_end = 0.0) {
+  // (soc_n, soc_nm1: the trapezoid SOC at the last two accepted points, before the back-interpolation; dt_step = t_n - t_(n-1); I_end: the current of the interpolated end point)
   PL_MODEL(M);
   const int lane = lane_id();
   const double nan = __builtin_nan("");
   interp = interp && !X.first;                             // (hist[1] = s_n - s_(n-1) once a step has been completed)
-  bool shift = interp && !(flag == 3 || flag == 4), unknown = interp && (flag == 10 || ((flag == 3 || flag == 4) && mode != PLH_MODE_I));
+  const bool soc_ev = flag == 3 || flag == 4;              // an SOC bound: g = the trapezoid SOC, d g / d theta = the trapezoid of dI/dtheta (aux[1]); constant current: 0, fr fixed
+  bool shift = interp, unknown = interp && flag == 10;     // (the dfilm bound is a bound on YP)
   double gn = 0.0, gp = 0.0, bnd = 0.0; int ix = 0;
   if (shift && !unknown) {
     const double* Y = S.phi[0];
@@ -264,9 +317,13 @@ PL_DEV void sens_finish(CellLDS<M>& S, SensCell<M>& X, bool interp, double fr, b
     if (flag == 9) { double cm = 1e300; for (int i = 0; i < NE; i++) { if (Y[O_CE + i] < cm) { cm = Y[O_CE + i]; ix = O_CE + i; } } }
     bnd = flag == 1 ? bd.V_min : flag == 2 ? bd.V_max : flag == 5 ? bd.T_max : flag == 6 ? bd.c_s_n_max * S.cc.cmaxn : flag == 7 ? bd.I_max : flag == 8 ? bd.I_min
         : flag == 9 ? bd.c_e_min : bd.eta_plating_min;
+    if (soc_ev) { gn = soc_n; gp = soc_nm1; bnd = flag == 3 ? bd.SOC_min : bd.SOC_max; }
+    else {
     gn = sens_event_g(S, flag, ix, S.phi[0]);
     gp = gn - sens_event_g(S, flag, ix, S.phi[1]);         // g(y_(n-1)) = g(phi0) - g(phi1)
+    }
   }
+  const int col_cmaxn = S.tb->thidx[K_c_max_n];
   for (int k = 0; k < X.a.n_sens; k++) {
     double* h0 = X.hist(k, 0); const double* h1 = X.hist(k, 1);
     double dfr = 0.0;
@@ -278,20 +335,27 @@ PL_DEV void sens_finish(CellLDS<M>& S, SensCell<M>& X, bool interp, double fr, b
       PL_XSYNC();
       PL_VEC(n) S.delta[n] = h1[n];
       PL_XSYNC();
-      const double gsp = gsn - sens_event_g(S, flag, ix, S.delta);
+      double gsp = gsn - sens_event_g(S, flag, ix, S.delta);
+      double gsn_ = gsn;
+      if (soc_ev) { const double* ax = X.aux(k); gsn_ = ax[1]; gsp = ax[1] - ax[3]; }
       const double den = gp - gn;
-      dfr = (gsp * den - (gp - bnd) * (gsp - gsn)) / (den * den);
+      dfr = (gsp * den - (gp - bnd) * (gsp - gsn_)) / (den * den);
     }
+    // the c_s_n_max bound is c_s_n_max * c_max_n: with c_max_n among the parameters the bound itself moves -- not differentiated: NaN for that column (as every unknown case)
+    const bool unk_k = unknown || (interp && flag == 6 && X.a.cols[k] == col_cmaxn);
     PL_XSYNC();
     PL_VEC(n) {
       double v = h0[n];
       if (interp) { const double d1 = h1[n]; v = (v - d1) + fr * d1 + S.phi[1][n] * dfr; }
-      if (failed || unknown) v = nan;
+      if (failed || unk_k) v = nan;
       h0[n] = v; S.delta[n] = v;
       if (X.a.dY) X.a.dY[((size_t)X.cell * X.a.n_sens + k) * NST + n] = v;
     }
     PL_XSYNC();
     if (interp || failed) sens_put_V(S, X, k, idx);
+    // SOC of the interpolated end point: SOC_n + (fr - 1) dt I_e / 3600 (cell_simulate) -- its derivative, for the runs that follow
+    if (interp && lane == 0 && wave_id() == 0) { double* ax = X.aux(k); ax[1] += (dfr * dt_step * I_end + (fr - 1.0) * dt_step * S.delta[O_I]) / 3600.0; if (failed || unk_k) ax[1] = nan; }
+    PL_XSYNC();
   }
   PL_XSYNC();
 }

@@ -145,6 +145,7 @@ struct StageBlock { void* p; size_t bytes; bool busy; };
 struct StreamCtx {
   hipStream_t st = nullptr;
   double* scratch = nullptr; size_t scratch_cells = 0;     // [n_cells][2][N]: previous accepted point of every cell (back-interpolation)
+  double* phig = nullptr; size_t phig_cells = 0;           // [n_cells][4][NPAD]: BDF history orders 2 .. 5 of the variants that keep them in global memory (VariantOps::phig_doubles)
   double* genW = nullptr; size_t genW_cells = 0;           // [n_cells][N]: border vector of the general control row (closure inputs with derivative programs)
   plh_run* d_runs = nullptr; int runs_cap = 0;
   std::vector<plh_run> runs_on_device;                       // the protocol currently in d_runs (a repeated launch with the same protocol uploads nothing and does not synchronise)
@@ -491,6 +492,7 @@ void plh_model_destroy(plh_model_t m) {
   for (StreamCtx* c : m->streams) {
     if (c->scratch) hipFree(c->scratch);
     if (c->genW) hipFree(c->genW);
+    if (c->phig) hipFree(c->phig);
     if (c->d_runs) hipFree(c->d_runs);
     if (c->tdiscon.d) hipFree(c->tdiscon.d);
     if (c->tstops.d) hipFree(c->tstops.d);
@@ -748,8 +750,8 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
     if (m->ops->w2) return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: one wavefront per cell only");
     if (opts->refine > 0 || opts->n_tdiscon > 0 || opts->n_stop > 0) return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: not with refine / tdiscon / a stop function");
     for (int r = 0; r < n_runs; r++)
-      if ((runs[r].value_kind != PLH_VAL_CONST && runs[r].value_kind != PLH_VAL_REST) || runs[r].mode == PLH_MODE_RES || runs[r].mode == PLH_MODE_DSTATE)
-        return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: constant (or :rest) inputs in the modes I, V, P, eta_p, dT (a :hold value or a function input depends on theta through the previous run / the state)");
+      if ((runs[r].value_kind != PLH_VAL_CONST && runs[r].value_kind != PLH_VAL_REST && runs[r].value_kind != PLH_VAL_HOLD) || runs[r].mode == PLH_MODE_RES || runs[r].mode == PLH_MODE_DSTATE)
+        return fail(PLH_E_UNSUPPORTED, "plh_integrate_sens: constant, :rest or :hold inputs in the modes I, V, P, eta_p, dT (a function input depends on theta through the state)");
   }
   DeviceGuard guard(m->device);
   Stage s(m, kind, stream);
@@ -760,6 +762,11 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
     HIPCHK(hipMalloc((void**)&cx.scratch, (size_t)n * 2 * m->N * sizeof(double)));
     cx.scratch_cells = n;
   }
+  if (m->ops->phig_doubles > 0 && cx.phig_cells < (size_t)n) {           // BDF history orders >= 2 of the variants that keep them in global memory
+    if (cx.phig) { HIPCHK(hipStreamSynchronize(cx.st)); hipFree(cx.phig); cx.phig = nullptr; cx.phig_cells = 0; }
+    HIPCHK(hipMalloc((void**)&cx.phig, (size_t)n * m->ops->phig_doubles * sizeof(double)));
+    cx.phig_cells = n;
+  }
   bool need_genW = false;
   for (int r = 0; r < n_runs; r++) need_genW = need_genW || (runs[r].value_kind == PLH_VAL_EXPR && runs[r].n_dcol > 0) || runs[r].mode == PLH_MODE_DSTATE;
   if (need_genW && cx.genW_cells < (size_t)n) {
@@ -768,7 +775,7 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
     cx.genW_cells = n;
   }
   IntegrateArgs a;
-  a.tb = m->d_tb; a.n_cells = n; a.n_runs = n_runs; a.opts = *opts; a.scratch = cx.scratch; a.genW = need_genW ? cx.genW : nullptr;
+  a.tb = m->d_tb; a.n_cells = n; a.n_runs = n_runs; a.opts = *opts; a.scratch = cx.scratch; a.genW = need_genW ? cx.genW : nullptr; a.phig = m->ops->phig_doubles > 0 ? cx.phig : nullptr;
   a.theta = s.in(theta, (size_t)n * m->P); a.SOC0 = s.in(SOC0, n);
   a.Y_init = s.in(Y_init, (size_t)n * m->N); a.t_init = s.in(t_init, n);
   // tdiscon / tstops: sorted device copies, kept per stream (re-uploaded only when they change)
@@ -830,7 +837,7 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
   a.out.Y_all = s.buf(out->Y_all, np * m->N, false);
   a.out.Y_final = s.buf(out->Y_final, (size_t)n * m->N, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * m->N, false);
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
-  a.sens.n_sens = 0; a.sens.cols = nullptr; a.sens.theta_pert = nullptr; a.sens.hist = nullptr; a.sens.dY = nullptr; a.sens.dV = nullptr; a.sens.stat = nullptr; a.sens.cbak = nullptr;
+  a.sens.n_sens = 0; a.sens.cols = nullptr; a.sens.theta_pert = nullptr; a.sens.hist = nullptr; a.sens.dY = nullptr; a.sens.dV = nullptr; a.sens.stat = nullptr; a.sens.cbak = nullptr; a.sens.aux = nullptr;
   size_t n_dY = 0, n_dV = 0;
   if (sq) {
     const int ns = sq->n_sens, NPAD = m->N + (m->N & 1);
@@ -840,6 +847,7 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
     double* tp = (double*)s.dev_block((size_t)n * ns * m->P * sizeof(double));
     a.sens.hist = (double*)s.dev_block((size_t)n * ns * 6 * NPAD * sizeof(double));
     a.sens.cbak = (double*)s.dev_block((size_t)n * pl::SENS_CBAK * sizeof(double));
+    a.sens.aux = (double*)s.dev_block((size_t)n * ns * 4 * sizeof(double));
     a.sens.dY = s.buf(sq->dY, n_dY, false); a.sens.dV = s.buf(sq->dV, n_dV, false); a.sens.stat = s.buf(sq->stat, (size_t)2 * n, false);
     CHECK_STAGE(s);
     a.sens.theta_pert = tp;
@@ -848,6 +856,7 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
     if (a.sens.dY) HIPCHK(hipMemsetAsync(a.sens.dY, 0xff, n_dY * sizeof(double), s.st));
     if (a.sens.dV) HIPCHK(hipMemsetAsync(a.sens.dV, 0xff, n_dV * sizeof(double), s.st));
     if (a.sens.stat) HIPCHK(hipMemsetAsync(a.sens.stat, 0, (size_t)2 * n * sizeof(int), s.st));
+    if (a.sens.aux) HIPCHK(hipMemsetAsync(a.sens.aux, 0, (size_t)n * ns * 4 * sizeof(double), s.st));
   }
   CHECK_STAGE(s);                                                     // a failed staging allocation must never reach the kernel as a NULL ("not requested") output
   hipEventRecord(cx.ev0, s.st);

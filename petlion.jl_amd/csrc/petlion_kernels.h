@@ -13,20 +13,24 @@
 
 namespace pl {
 
-// Every kernel runs at most one wavefront per SIMD (LDS: >= 37 kB per single-wave workgroup), so the compiler may use the whole 512-entry register file of a lane.  It does:
-// hipcc -Rpass-analysis=kernel-resource-usage reports for the benchmark instantiation k_integrate<.., 0> (r03; rocprofv3's `accum_vgpr_count` shows 0 on this unified-file
-// part and is not the figure to read)
-//    LCO isothermal   256 VGPR + 239 AGPR,  82 VGPR spills (into AGPRs), 633 SGPR spills (into VGPR lanes),   0 B/lane of scratch
-//    NMC + SEI        256 VGPR + 256 AGPR, 100 VGPR spills,              702 SGPR spills,                   180 B/lane
-//    LCO thermal      256 VGPR + 256 AGPR, 329 VGPR spills,              668 SGPR spills,                   368 B/lane
-// i.e. the arch-VGPR half is saturated everywhere and the AGPR half is the first spill level (v_accvgpr_read/write, one instruction each way); only what does not fit there
-// goes to scratch memory, and that traffic sits around the Jacobian refresh, not in the residual / solve loop.
+// Registers.  The 301-state kernels run one wavefront per SIMD (LDS: >= 37 kB per cell), so the compiler may use the whole 512-entry register file of a lane.  hipcc
+// -Rpass-analysis=kernel-resource-usage for the benchmark instantiation k_integrate<.., 0> with the flags of petlion.jl_amd/buildflags.py (r04 / r05; rocprofv3's
+// `accum_vgpr_count` reads 0 on this unified-file part and is not the figure to read):
+//    LCO isothermal   256 VGPR +  54 AGPR, no VGPR spill,   0 B/lane of scratch
+//    NMC + SEI        256 VGPR +  66 AGPR, no VGPR spill,   0 B/lane
+//    LCO thermal      256 VGPR + 211 AGPR, 128 VGPR spills (into AGPRs: v_accvgpr_read / write, one instruction each way),   0 B/lane
+// (with MachineLICM on the thermal kernel had 392 B/lane of scratch: DESIGN.md 5a).  Compiled for two waves per SIMD (256 registers) the isothermal kernel spills 213 VGPRs,
+// 424 B/lane: DESIGN.md 2.
 #if !defined(PL_WAVE_EMU) && !defined(PL_NO_WAVES_ATTR) && defined(PL_WAVES_PER_EU)
-// -DPL_WAVES_PER_EU=2 (r05 occupancy builds, tools/experiments/occupancy.py): two independent cells per SIMD -- 256 registers per lane, and the LDS of a cell must be <= 20 480 B
-// for eight of them to be resident on a CU
+// -DPL_WAVES_PER_EU=n: experiment builds (tools/experiments/occupancy.py)
 #define PL_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(PL_WAVES_PER_EU, PL_WAVES_PER_EU)))
 #elif !defined(PL_WAVE_EMU) && !defined(PL_NO_WAVES_ATTR)      /* (PL_NO_WAVES_ATTR: experiment builds of tools/experiments/build_modes.py) */
-#define PL_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(M::NWAVES, M::NWAVES)))    /* one cell per SIMD: one wave (512 registers) or, M::W2, its two waves (256 each) */
+// One cell per SIMD (one wave with 512 registers; M::W2: its two waves with 256 each) for every model whose cell fills a quarter of the CU's LDS -- the 301-state models.  A cell
+// of <= 26 624 B leaves room for at least six on a CU: those kernels are compiled for TWO cells per SIMD (256 registers per lane).  Measured r05 (tools/experiments/occupancy.py):
+// quadratic particles (20.7 kB, 7 cells per CU) +42 %, polynomial +39 %, the (2, 2, 2, 10) grid (12.2 kB, 8 per CU) +63 %; three per SIMD +25 % only (168 registers).  The
+// 301-state models reach 26.2 kB only with the history in global memory (-DPL_OCC2, ModelT::PHI_GLOBAL) and lose 5 % there: they stay at one.
+#define PL_CELLS_PER_SIMD(M) ((sizeof(CellLDS<M>) <= (M::PHI_GLOBAL ? 32768 : 26624) && !M::W2) ? 2 : 1)      /* (the PL_OCC2 experiment layouts: five cells per CU count too) */
+#define PL_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(M::NWAVES * PL_CELLS_PER_SIMD(M), M::NWAVES * PL_CELLS_PER_SIMD(M))))
 #else
 #define PL_ONE_WAVE_PER_SIMD
 #endif
@@ -153,7 +157,8 @@ template <class M, int F> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WA
   cell_simulate<F>(S, R, a.tb, a.SOC0[cell], a.Y_init ? a.Y_init + (size_t)cell * NST : nullptr, a.t_init ? a.t_init[cell] : 0.0, a.n_runs, a.runs, a.opts, co, a.out.n_pts ? a.out.n_pts + cell : nullptr,
                 a.out.run_info + (size_t)cell * a.n_runs, cnt,
                 a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
-                a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell, a.genW ? a.genW + (size_t)cell * NST : nullptr, a.sens, a.theta + (size_t)cell * a.tb->P);
+                a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell, a.genW ? a.genW + (size_t)cell * NST : nullptr, a.sens, a.theta + (size_t)cell * a.tb->P,
+                (M::PHI_GLOBAL && a.phig) ? a.phig + (size_t)cell * (MAXORD + 1 - M::PHI_LDS) * M::NPAD : nullptr);
   PL_TOC_TOTAL(S);
   PL_SYNC();
   if (threadIdx.x == 0 && a.out.counters) {
@@ -353,7 +358,7 @@ template <class M> struct OpsOf {
     static_assert(!GRID_DEFAULT || sizeof(CellLDS<M>) <= 40960, "built-in variant: LDS per cell above 40 960 B, only three cells per CU would be resident");
 #endif
     static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::PREC, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, {NP, NS, NN, NRP, NA, NZ, NRN},
-                                   {PL_RADIAL_M, PL_RADIAL_M_N}, {PL_RADIAL_LAM, PL_RADIAL_LAM_N}, {PL_RADIAL_V, PL_RADIAL_V_N}, {PL_RADIAL_W, PL_RADIAL_W_N}, {PL_RADIAL_BJ_FACTOR, PL_RADIAL_BJ_FACTOR_N}, sizeof(CellLDS<M>), &classify<M>, &sections_of<M>,
+                                   {PL_RADIAL_M, PL_RADIAL_M_N}, {PL_RADIAL_LAM, PL_RADIAL_LAM_N}, {PL_RADIAL_V, PL_RADIAL_V_N}, {PL_RADIAL_W, PL_RADIAL_W_N}, {PL_RADIAL_BJ_FACTOR, PL_RADIAL_BJ_FACTOR_N}, sizeof(CellLDS<M>), M::PHI_GLOBAL ? (MAXORD + 1 - M::PHI_LDS) * M::NPAD : 0, &classify<M>, &sections_of<M>,
                                    &initial_guess, &residual, &jacobian, &linear_solve, &init_consistent, &integrate};
     return &ops;
   }

@@ -39,7 +39,8 @@ def hip_model(pkg):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import __graft_entry__ as g
-    g.build_hip()
+    if not os.environ.get("PETLION_HIP_LIB"):          # (an experiment library selected through the environment is used as it is: tools/experiments/)
+        g.build_hip()
     return pkg.petlion(pkg.LCO)
 
 

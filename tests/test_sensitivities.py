@@ -113,9 +113,44 @@ def test_sens_thermal_emu(emu_model_thermal, O, pkg):
     check_sens(pkg, p, O, p.theta_vector()[None, :], 0.2, [{"I": 3.0, "tf": 150.0}], ["h_cell", "k_p"], np.arange(25.0, 150.0, 25.0), variant="lco_thermal_tdiff", what="LCO thermal 3C charge (emulator)")
 
 
+def test_sens_through_hold_legs_emu(emu_model, O, pkg):
+    """r05: :hold runs.  The held value is the previous run's end value of the held quantity, so it depends on theta: d value / d theta_k = that quantity's sensitivity at the
+    previous run's end, one constant term in F_theta of the control row (dfn_sens.h sens_init).  CC (fixed time) -> V hold -> P hold -> I hold, against the differenced
+    quiet oracle (the plain variant's Phi_s-row rounding steers ITS hold legs: DESIGN.md 5)."""
+    p = emu_model
+    proto = [{"I": 2.0, "tf": 300.0, "V_max": 5.0}, {"V": "hold", "tf": 200.0, "V_max": 5.0, "I_min": 0.0}, {"P": "hold", "tf": 60.0, "V_max": 5.0}, {"I": "hold", "tf": 60.0, "V_max": 5.0}]
+    check_sens(pkg, p, O, p.theta_vector()[None, :], 0.2, proto, ["D_sp", "k_n"], np.arange(30.0, 300.0, 30.0), variant="lco_iso_quiet", what="LCO CC / V hold / P hold / I hold (emulator)")
+
+
+def _cccv_event_case(p, O, pkg, second, what, exact=True):
+    """CC until V_max (the crossing moves with theta), then V = :hold until the bound `second` fires: every run of the differenced oracle ends at its own crossings, so both
+    leg ends get the 0.05 s stop grid of the tight suite around them (run-local times; opts.tstops applies to every run)"""
+    th = p.theta_vector()
+    proto = [{"I": 2.0, "V_max": 4.0, "tf": 3000.0}, dict({"V": "hold", "V_max": 4.0, "tf": 3000.0}, **second)]
+    o = pkg.Opts(); o.reltol, o.abstol, o.maxiters = 1e-8, 1e-10, 200000
+    e0 = pkg.simulate_ensemble(p, th[None, :].copy(), proto, SOC=0.3, opts=o, max_points=20000)
+    assert [int(f) for f in e0.run_info[0]["flag"]] == [2, 8 if "I_min" in second and second["I_min"] > 0 else 4], e0.run_info[0]
+    te1 = float(e0.run_info[0, 0]["t_end"]); te2 = float(e0.run_info[0, 1]["t_end"]) - te1
+    coarse = np.arange(50.0, te1 - 50.0, 50.0)
+    fine = np.concatenate([np.arange(max(1.5, te - 15.0), te + 15.0, 0.05) for te in (te1, te2)])
+    all_ts = np.unique(np.round(np.concatenate([coarse, fine]), 6))
+    return check_sens(pkg, p, O, th[None, :], 0.3, proto, ["D_sp", "k_n"], coarse, all_ts=all_ts, variant=p.variant + "_quiet", rel_h=0.1, lim_a=3e-4, lim_b=1.5e-4, what=what, exact=exact)      # (two crossings per differenced run: three times the one-event noise)
+
+
+def test_sens_cc_cv_to_a_current_bound_emu(emu_model, O, pkg):
+    """r05: the commonest estimation protocol -- CC until V_max, then V = :hold until I_min (a current bound in a voltage run)"""
+    _cccv_event_case(emu_model, O, pkg, dict(I_min=0.5, SOC_max=2.0), "LCO CC to V_max / V hold to I_min (emulator)")
+
+
+def test_sens_cc_cv_to_an_soc_bound_emu(emu_model, O, pkg):
+    """r05: ... until SOC_max, an SOC bound under a VARYING current: the bounded quantity is the trapezoid SOC of the saved points (calc_SOC), its sensitivity the trapezoid of
+    dI/dtheta (C3's CC-CT-CV ends this way)"""
+    _cccv_event_case(emu_model, O, pkg, dict(I_min=0.0, SOC_max=0.6), "LCO CC to V_max / V hold to SOC_max (emulator)")
+
+
 def test_sens_refused_where_theta_enters_through_the_protocol(emu_model, pkg):
     p = emu_model
-    for proto in ([{"I": -1.0, "tf": 100.0}, {"V": "hold", "tf": 50.0}], [{"I": (lambda t: -1.0 - 0.001 * t), "tf": 100.0}]):
+    for proto in ([{"I": (lambda t: -1.0 - 0.001 * t), "tf": 100.0}],):
         with pytest.raises(Exception) as e:
             pkg.simulate_ensemble(p, p.theta_vector()[None, :].copy(), proto, SOC=1.0, sens=["D_sp"])
         assert "plh_integrate_sens" in str(e.value)
@@ -175,3 +210,40 @@ def test_sens_full_c4_launch_on_gpu(hip_model, pkg):
     assert nonfinite == 0 and st[:, 1].sum() <= 1e-3 * 7 * ens.counters["n_steps"].sum()
     print("C4 shard, 8192 cells x 7 sensitivities: kernel %.1f ms (plain %.1f ms: x%.1f), %.2f corrector iterations per step and parameter"
           % (ms_sens, plain.kernel_ms, ms_sens / plain.kernel_ms, st[:, 0].sum() / (7.0 * ens.counters["n_steps"].sum())))
+
+
+@pytest.mark.gpu
+def test_sens_default_tolerance_accuracy_on_gpu(hip_model, pkg):
+    """r05: sensitivities at the tolerances the benchmark runs at.  256 cells of the C4 sweep (every 256th of 65 536), 1C discharge for 1800 s with a stop
+    every 100 s, the seven sweep parameters: dV/dtheta at the stops from the run at reltol 1e-3 / abstol 1e-6 against the same cells' sensitivities at 1e-8 / 1e-10 -- within
+    10 x reltol of max |dV/dtheta| over the trajectory for every cell and parameter worth at least 1 mV per unit relative change -- and NO corrector solve ends at the iteration
+    cap (r04: 0.09 % did; the corrector now also stops on IDANls' rate-based estimate, dfn_sens.h)."""
+    p = hip_model
+    keys = list(pkg.configs.SWEEP_KEYS)
+    Th = np.ascontiguousarray(pkg.configs.sweep_theta(p, np.arange(0, 65536, 256), 4))
+    ts = list(np.arange(100.0, 1800.0, 100.0))
+    res = {}
+    for name, (rt, at) in (("default", (1e-3, 1e-6)), ("tight", (1e-8, 1e-10))):
+        o = pkg.Opts(); o.reltol, o.abstol, o.maxiters, o.tstops = rt, at, 200000, ts
+        res[name] = pkg.simulate_ensemble(p, Th, [{"I": -1.0, "tf": 1800.0}], SOC=1.0, opts=o, max_points=20000, sens=keys)
+        assert (res[name].run_info["flag"] == 0).all()
+    d, t = res["default"], res["tight"]
+    st = np.asarray(d.sens_stat)
+    worst = 0.0
+    for i in range(Th.shape[0]):
+        nd, nt = int(d.n_pts[i]), int(t.n_pts[i])
+        td, tt = np.asarray(d.t[i, :nd]), np.asarray(t.t[i, :nt])
+        id_, it_ = [int(np.argmin(np.abs(td - x))) for x in ts], [int(np.argmin(np.abs(tt - x))) for x in ts]
+        assert np.abs(td[id_] - ts).max() < 1e-6 and np.abs(tt[it_] - ts).max() < 1e-6
+        for k, key in enumerate(keys):
+            a, b = np.asarray(d.dV_dtheta[i, k])[id_], np.asarray(t.dV_dtheta[i, k])[it_]
+            sc = np.abs(b).max()
+            if sc * abs(Th[i, p.θ_keys.index(key)]) < 1e-3:          # (a parameter that moves the voltage by less than 1 mV per unit relative change: noise over ~0)
+                continue
+            e = float(np.abs(a - b).max() / sc)
+            worst = max(worst, e)
+            assert e <= 10 * 1e-3, (i, key, e)
+    its = st[:, 0].sum() / (len(keys) * float(d.counters["n_steps"].sum()))
+    print("default-tolerance sensitivities, 256 C4 cells x 7 parameters: dV/dtheta against the tight run max %.1e of max |dV/dtheta| (criterion 1e-2); %.2f corrector iterations per step and "
+          "parameter; solves at the iteration cap: %d" % (worst, its, int(st[:, 1].sum())))
+    assert st[:, 1].sum() == 0

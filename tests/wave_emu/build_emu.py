@@ -10,9 +10,9 @@ SRC = os.path.join(ROOT, "petlion.jl_amd", "csrc", "petlion_hip.hip")
 OUT = os.path.join(HERE, "libpetlion_emu.so")
 
 
-def build(force=False, variant=None):
+def build(force=False, variant=None, extra=(), tag=""):
     """variant=<id>: a developer's quick build holding that one model variant (libpetlion_emu_v<id>.so, ~20 s instead of ~2 min); the tests use the full library"""
-    out = OUT if variant is None else OUT[:-3] + "_v%d.so" % variant
+    out = OUT if variant is None else OUT[:-3] + "_v%d%s.so" % (variant, tag)            # (extra / tag: experiment builds, e.g. -DPL_OCC2)
     deps = [SRC] + [os.path.join(os.path.dirname(SRC), f) for f in os.listdir(os.path.dirname(SRC)) if f.endswith((".h", ".hip"))]
     deps.append(os.path.join(HERE, "hip", "hip_runtime.h"))
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
@@ -22,6 +22,7 @@ def build(force=False, variant=None):
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", HERE, SRC, "-o", out, "-Wno-unused-variable", "-ldl", "-DPL_EXP_BRANCHY_PHI"]
     if variant is not None:
         cmd.append("-DPL_VARIANT=%d" % variant)
+    cmd += list(extra)
     subprocess.check_call(cmd)
     return out
 

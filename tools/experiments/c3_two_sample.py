@@ -9,6 +9,7 @@ import os
 import sys
 
 import numpy as np
+import torch  # noqa: F401  (before the HIP library is loaded: torch brings its own ROCm runtime, and initialising it after libpetlion_hip.so's fails)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
