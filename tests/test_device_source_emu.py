@@ -916,3 +916,24 @@ def test_stop_function(emu_model, O, pkg):
 
 def test_stop_function_thermal_node_temperature(emu_model_thermal, O, pkg):
     parity.check_stop_function(emu_model_thermal, O, pkg)
+
+
+@pytest.mark.parametrize("flag,tag,lds", [("-DPL_OCC2", "_occ2", 26160), ("-DPL_OCC2=4", "_occ4", 32672)])
+def test_occupancy_experiment_layouts_are_bit_identical(pkg, flag, tag, lds):
+    """r05: the two layouts built to put a second 301-state cell on a SIMD -- BDF history orders >= 2 (26.2 kB, six cells per CU) or only 4 and 5 (32.7 kB, five) in
+    global memory -- are the same arithmetic in the same order: a CC -> V hold -> discharge chain and a 1C discharge, bit for bit the default layout's states.  (Measured on the GPU they
+    lose 5 % / 19 % on C4; they stay as experiment builds.)"""
+    import subprocess, sys, build_emu
+    la, lb = build_emu.build(variant=0), build_emu.build(variant=0, extra=[flag], tag=tag)
+    code = ("import sys; sys.path.insert(0, %r)\nimport numpy as np, pkgload\npkg = pkgload.load()\np = pkg.petlion(pkg.LCO, _lib_path=sys.argv[1])\n"
+            "Th = pkg.configs.sweep_theta(p, np.arange(2), 4)\n"
+            "e = pkg.simulate_ensemble(p, Th, [dict(I=2.0, tf=600.0, V_max=5.0), dict(V='hold', tf=300.0, V_max=5.0, I_min=0.0), dict(I=-1.0, tf=300.0)], SOC=0.0)\n"
+            "e2 = pkg.simulate_ensemble(p, Th, [{'I': -1.0}], SOC=1.0)\n"
+            "np.save(sys.argv[2], np.concatenate([e.Y.ravel(), e2.Y.ravel(), e.run_info['t_end'].ravel(), e2.run_info['t_end'].ravel(), [float(p.lds_bytes)]]))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = []
+    for lib in (la, lb):            # (one process per library: both export the same C symbols)
+        f = "/tmp/occ_layout_%s_%d.npy" % (tag, len(out))
+        subprocess.check_call([sys.executable, "-c", code, lib, f])
+        out.append(np.load(f))
+    assert out[1][-1] == lds and out[0][-1] == 37504
+    assert np.array_equal(out[0][:-1], out[1][:-1])
