@@ -294,7 +294,7 @@ def general_path(pkg, p, inp, Theta, n_local, kernel_ms, reps=5):
              ("closure input, compiled (closure_lib)", [clo] + proto[1:], dict(_compile=True), None),
              ("closure of the state with its derivative in the Newton matrix, compiled (closure_lib)", [clo_y] + proto[1:], dict(_compile=True), None)]
     skeys = [k for k in pkg.configs.SWEEP_KEYS if k in p.θ_keys]
-    if all(not isinstance(r.get("I", 0.0), str) or r["I"] == "rest" for r in proto) and all(set(r) & {"I", "V", "P"} for r in proto):
+    if all(all(not callable(r[m]) and not isinstance(r[m], (tuple, list)) for m in ("I", "V", "P", "dT") if m in r) for r in proto):      # constant / :rest / :hold inputs (r05: :hold legs too)
         cases.append(("forward sensitivities dY/dtheta, dV/dtheta for %d parameters (%s): plh_integrate_sens" % (len(skeys), ", ".join(skeys)), proto, {}, None))
     out = {}
     for name, pr, okw, outputs in cases:
@@ -346,6 +346,14 @@ def main():
         # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) through torch.distributed.run -- the same launch the
         # driver uses -- and relay rank 0's line
         return spawn_ranks(args.gpus)
+    # ONE JSON line on stdout whatever the libraries underneath print (RCCL's version banner, the driver's notes): everything else goes to stderr
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or unset WORLD_SIZE and let bench.py spawn its ranks" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
@@ -482,7 +490,7 @@ def main():
         def give_up():
             if rank == 0:
                 out["ensemble_run"] = {"error": "plh_ensemble_run leg did not finish within %d s (watchdog)" % args.leg_timeout}
-                print(json.dumps(out), flush=True)
+                emit(out)
             os._exit(0)
         dog = threading.Timer(args.leg_timeout, give_up); dog.daemon = True; dog.start()
         ens_run, comm = {}, None
@@ -558,7 +566,7 @@ def main():
                 b.copy_(a)
             e1.record(); torch.cuda.synchronize()
             out["roofline"]["measured_copy_peak"] = 10 * 2 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

@@ -309,6 +309,9 @@ int plh_init_consistent(plh_model_t m, int n_cells, const double* theta, int mod
  * Y_init / t_init (both NULL for a new solution): continue a previous solution like simulate!(sol, p, ...)
  * (src/model_evaluation.jl:87-97, 206-209): Y_init[cell][n_states] = sol.Y[end], t_init[cell] = sol.t[end],
  * SOC0[cell] = sol.SOC[end]; the first run is then a continuation run (t0 = nextfloat(t_init), tstop at 1 s, :hold works).
+ * Y_init WITHOUT t_init (t_init = NULL): simulate(p, ...; initial_states = Y) (src/model_evaluation.jl:15, 102-110, 193-199) -- a NEW solution (t0 = 0) that starts from
+ * the caller's state vectors instead of initial_guess!; the algebraic states are re-solved by the consistent initialisation as always; SOC0[cell] = calc_SOC(Y)
+ * (src/physics_equations/scalar_residual.jl:95-102: the anode's mean c_s_avg as a stoichiometry fraction), which the caller computes.
  * One wavefront integrates one cell for the whole protocol inside a single kernel launch. */
 int plh_integrate(plh_model_t m, int n_cells, const double* theta, const double* SOC0, const double* Y_init, const double* t_init,
                   int n_runs, const plh_run* runs, const plh_opts* opts, const plh_outputs* out, int ptr_kind, void* stream);

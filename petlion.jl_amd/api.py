@@ -598,9 +598,25 @@ def _wants_states(p, outputs):
     return "all" in outs or any(x in _STATE_OUTPUTS for x in outs)
 
 
-def simulate(p, tf=1e6, *, sol=None, SOC=None, **kw):
-    """simulate(p, tf; I=..|V=..|dT=.., SOC, abstol, reltol, ..., V_max, V_min, ...) for ONE cell (n_cells = 1 ensemble)."""
+def calc_SOC(p, Y):
+    """calc_SOC(Y, p) (reference src/physics_equations/scalar_residual.jl:95-102): the anode's mean c_s_avg as a fraction of its stoichiometry window"""
+    Y = np.asarray(Y, dtype=np.float64)
+    cs = p.ind["c_s_avg"]
+    n_p = p.N.p * p.N.r_p if p.solid_diffusion == "Fickian" else p.N.p
+    return (Y[..., cs.start + n_p:cs.stop].mean(axis=-1) / p.θ["c_max_n"] - p.θ["θ_min_n"]) / (p.θ["θ_max_n"] - p.θ["θ_min_n"])
+
+
+def simulate(p, tf=1e6, *, sol=None, SOC=None, initial_states=None, **kw):
+    """simulate(p, tf; I=..|V=..|dT=.., SOC, abstol, reltol, ..., V_max, V_min, ...) for ONE cell (n_cells = 1 ensemble).
+    initial_states = Y (reference src/model_evaluation.jl:15, 102-110, 193-199): a new solution that starts from this state vector instead of initial_guess!; its SOC is
+    calc_SOC(Y)."""
     inputs, bounds, rest = _split_kwargs(p, kw)
+    if initial_states is not None:
+        if sol is not None and not sol.isempty():
+            raise ValueError("Cannot set `initial_states` and continue a previous run.")         # model_evaluation.jl:105-108
+        initial_states = np.ascontiguousarray(initial_states, dtype=np.float64)
+        if initial_states.shape != (p.N.tot,):
+            raise ValueError("initial_states must have length N.tot")
     o = Opts()
     o.__dict__.update(p.opts.__dict__)
     for k, v in rest.items():
@@ -619,8 +635,10 @@ def simulate(p, tf=1e6, *, sol=None, SOC=None, **kw):
     sol = Solution() if sol is None else sol
     keep_Y = _wants_states(p, o.outputs) or sol.Y_all is not None
     soc0 = (p.opts.SOC if SOC is None else SOC) if new else sol.SOC[-1]
+    if initial_states is not None:
+        soc0 = float(calc_SOC(p, initial_states))                      # (starting_from_initial_state: the estimated SOC, model_evaluation.jl:197-199)
     ens = _integrate(p, p.theta_vector()[None, :], np.array([soc0]), [_make_run(p, name, inp, tf, bounds)], o,
-                     Y_init=None if new else sol.Y[None, :], t_init=None if new else np.array([sol.t[-1]]), keep_Y=keep_Y)
+                     Y_init=(None if initial_states is None else initial_states[None, :]) if new else sol.Y[None, :], t_init=None if new else np.array([sol.t[-1]]), keep_Y=keep_Y)
     n = int(ens["n_pts"][0])
     ri = ens["run_info"][0, 0]
     if ri["flag"] < 0:                                                # the reference's error() paths: `sol` is left untouched
@@ -680,7 +698,7 @@ def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, 
                     counters=np.zeros(n, cap.COUNTERS_DTYPE))
         if Y_init is not None:
             Y_init = np.ascontiguousarray(Y_init, dtype=np.float64)
-            t_init = np.ascontiguousarray(t_init, dtype=np.float64)
+            t_init = None if t_init is None else np.ascontiguousarray(t_init, dtype=np.float64)      # (None: initial_states -- a new solution from these states)
         kind = cap.PLH_HOST
     out.t, out.V, out.I, out.SOC = cap.ptr(bufs["t"]), cap.ptr(bufs["V"]), cap.ptr(bufs["I"]), cap.ptr(bufs["SOC"])
     out.T_avg = None
@@ -807,7 +825,7 @@ def make_protocol(p, protocol, n_cells=None):
     return runs, names
 
 
-def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, stream=None, max_points=None, outputs=None, YP=True, sens=None):
+def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, stream=None, max_points=None, outputs=None, YP=True, sens=None, initial_states=None):
     """Integrate an ensemble of independent cells on this process's GPU.
 
     Theta: [n_cells, n_theta] array in `p.θ_keys` order (numpy = host memory; torch CUDA tensor with device=True = already in HBM).
@@ -826,7 +844,16 @@ def simulate_ensemble(p, Theta, protocol, *, SOC=None, opts=None, device=False, 
         soc0 = soc if hasattr(soc, "device") else torch.full((n,), float(soc), dtype=torch.float64, device=Theta.device)
     else:
         soc0 = np.full(n, float(soc)) if np.isscalar(soc) else np.asarray(soc, dtype=np.float64)
-    bufs = _integrate(p, Theta, soc0, runs, o, device=device, stream=stream, max_points=max_points,
+    Y0 = None
+    if initial_states is not None:          # [n_cells, N.tot] (host array): every cell starts a NEW solution from its own state vector; SOC = calc_SOC of it unless given
+        if device:
+            raise ValueError("initial_states: host arrays (device = False)")
+        Y0 = np.ascontiguousarray(initial_states, dtype=np.float64)
+        if Y0.shape != (n, p.N.tot):
+            raise ValueError("initial_states must be [n_cells, N.tot]")
+        if SOC is None:
+            soc0 = np.ascontiguousarray(calc_SOC(p, Y0))
+    bufs = _integrate(p, Theta, soc0, runs, o, Y_init=Y0, device=device, stream=stream, max_points=max_points,
                       keep_Y=_wants_states(p, o.outputs if outputs is None else outputs), keep_YP=YP, sens=sens)
     return EnsembleSolution(p, bufs, names)
 

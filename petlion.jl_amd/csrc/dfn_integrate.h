@@ -877,7 +877,8 @@ struct CellOut {
 template <int F, class M>
 PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double SOC0, const double* Yinit, double t_init, int n_runs, const plh_run* runs, const plh_opts& o,
                                      const CellOut& out, int* n_pts_out, plh_run_info* info, Counters& cnt, double* Yfin, double* YPfin,
-                                     double* Yprev, double* YPprev, int cell, double* genW = nullptr, SensArgs sens = SensArgs(), const double* th0 = nullptr, double* phig = nullptr) {
+                                     double* Yprev, double* YPprev, int cell, double* genW = nullptr, SensArgs sens = SensArgs(), const double* th0 = nullptr, double* phig = nullptr,
+                                     bool from_states = false) {
   PL_MODEL(M);
   const int lane = lane_id();
   IdaScalars I;
@@ -888,12 +889,17 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
   bool have_prev = false;
   const double T0 = S.cc.T0;
   // (what a run inherits from the one before -- SOC, end time, V / I / eta_plating -- travels through S.carry: see CellLDS)
-  if (Yinit) {                                                          // simulate!(sol, ...): continue from sol.Y[end]
+  if (Yinit && !from_states) {                                          // simulate!(sol, ...): continue from sol.Y[end]
     PL_VEC(n) S.yy[n] = Yinit[n];
     PL_XSYNC();
     have_prev = true;
     if (lane == 0 && wave_id() == 0) { S.carry[0] = SOC0; S.carry[1] = t_init; S.carry[2] = cellV<M>(S.yy); S.carry[3] = S.yy[O_I]; S.carry[4] = S.yy[O_PS + NP] - S.yy[O_PE + NP + NS]; }
-  } else if (lane == 0 && wave_id() == 0) { S.carry[0] = SOC0; S.carry[1] = 0.0; S.carry[2] = 0.0; S.carry[3] = 0.0; S.carry[4] = 0.0; }
+  } else {
+    // simulate(p, ...; initial_states = Y) (model_evaluation.jl:15, 102-110, 193-199): a NEW solution -- t0 = 0, no tstop at 1 s, nothing to :hold -- that starts from the caller's
+    // state vector instead of initial_guess! (the algebraic part is re-solved by newtons_method! as always; SOC0 is the caller's calc_SOC(Y), scalar_residual.jl:95-102)
+    if (Yinit) { PL_VEC(n) S.yy[n] = Yinit[n]; PL_XSYNC(); }
+    if (lane == 0 && wave_id() == 0) { S.carry[0] = SOC0; S.carry[1] = 0.0; S.carry[2] = 0.0; S.carry[3] = 0.0; S.carry[4] = 0.0; }
+  }
   PL_XSYNC();
   auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
     const double Tav = (M::THERMAL && out.T) ? cellTavg<M>(S, Y) : T0;
@@ -935,7 +941,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     const bool new_run = !have_prev;
     double t0;
     // S.yy holds the current state Y, S.yp the current YP between steps
-    if (new_run) { t0 = 0.0; cell_initial_guess(S, S.yy, SOC0); SOC = SOC0; }
+    if (new_run) { t0 = 0.0; if (!(Yinit && from_states)) cell_initial_guess(S, S.yy, SOC0); SOC = SOC0; }
     else t0 = nextafter(t_global, 1e300);                               // initial_time, model_evaluation.jl:112
     // initial_current! (input_methods.jl:11-74)
     double value = run.value, Iguess;

@@ -735,7 +735,7 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
     if (runs[r].tf_cell) for (int c = 0; c < n; c++) if (!(runs[r].tf_cell[c] > 0)) return fail(PLH_E_ARG, "run length tf_cell must be positive");
   }
   if (out->max_pts < 0) return fail(PLH_E_ARG, "max_pts");
-  if ((Y_init == nullptr) != (t_init == nullptr)) return fail(PLH_E_ARG, "Y_init and t_init must be given together");
+  if (t_init && !Y_init) return fail(PLH_E_ARG, "t_init without Y_init");        // (Y_init without t_init: a new solution from the caller's states -- initial_states)
   if (opts->n_tdiscon < 0 || (opts->n_tdiscon > 0 && !opts->tdiscon)) return fail(PLH_E_ARG, "tdiscon");
   if (opts->n_tstops < 0 || (opts->n_tstops > 0 && !opts->tstops)) return fail(PLH_E_ARG, "tstops");
   for (int k = 0; k < opts->n_tstops; k++) if (!(opts->tstops[k] == opts->tstops[k])) return fail(PLH_E_ARG, "tstops must not contain NaN");

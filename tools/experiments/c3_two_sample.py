@@ -21,10 +21,10 @@ ap = argparse.ArgumentParser(); ap.add_argument("--cells", type=int, default=409
 a = ap.parse_args()
 pkg = pkgload.load(); O.build()
 out = []
-mk = dict(c3=dict(temperature=True), c4=dict(), c2=dict())[a.config]
-variants = dict(c3=("lco_thermal", "lco_thermal_tdiff", "lco_thermal_quiet"), c4=("lco_iso", "lco_iso_quiet"), c2=("lco_iso", "lco_iso_quiet"))[a.config]
-for prec in ("f64", "f64_reforder"):
-    p = pkg.petlion(pkg.LCO, precision=prec, **mk)
+mk = dict(c3=dict(temperature=True), c4=dict(), c2=dict(), c5=dict(aging="SEI"))[a.config]
+variants = dict(c3=("lco_thermal", "lco_thermal_tdiff", "lco_thermal_quiet"), c4=("lco_iso", "lco_iso_quiet"), c2=("lco_iso", "lco_iso_quiet"), c5=("nmc_iso_sei", "nmc_iso_sei_quiet"))[a.config]
+for prec in ("f64", "f64_reforder") if a.config != "c5" else ("f64",):
+    p = pkg.petlion(pkg.NMC if a.config == "c5" else pkg.LCO, precision=prec, **mk)
     cfg = getattr(pkg.configs, a.config)(p, a.cells)
     for variant in variants:
         r = T.two_sample(pkg, O, p, cfg, np.arange(a.cells), "%s device %s vs oracle %s" % (a.config.upper(), prec, variant), variant=variant, check=False)

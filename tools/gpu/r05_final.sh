@@ -1,10 +1,10 @@
 #!/bin/bash
 # r05 final GPU call: known answers of the self-test from THIS binary, the whole GPU suite, smoke(), rocprofv3 profiles (kernel trace + PMC passes), bench lines C2..C5
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r05d; mkdir -p $O
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05f; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python tools/make_selftest_golden.py > $O/golden.txt 2>&1
 cp petlion.jl_amd/selftest_golden.json $O/ 2>/dev/null
-timeout 3000 python -m pytest tests -m gpu -q -p no:cacheprovider -rs > $O/pytest.log 2>&1
+timeout 3000 python -m pytest tests -m gpu -q -s -p no:cacheprovider -rs > $O/pytest.log 2>&1
 tail -5 $O/pytest.log
 timeout 600 python __graft_entry__.py smoke > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 for C in C2 C3 C4 C5; do
