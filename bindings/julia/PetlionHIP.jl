@@ -257,7 +257,7 @@ function simulate_ensemble_sens(m::Model, p, Θ::Matrix{Float64}, protocol, keys
     npts = zeros(Cint, n); Y = zeros(m.N, n)
     info = Matrix{RunInfo}(undef, length(runs), n); cnt = Vector{Counters}(undef, n)
     Tavg = p.numerics.temperature ? zeros(max_pts, n) : Float64[]
-    dY = zeros(m.N, ns, n); dV = zeros(max_pts, ns, n); stat = zeros(Cint, 2, n)
+    dY = zeros(m.N, ns, n); dV = zeros(max_pts, ns, n); stat = zeros(Cint, 3, n)
     GC.@preserve t V I S npts Y info cnt Tavg ts cols dY dV stat begin
         out = Ref(Outputs(max_pts, pointer(t), pointer(V), pointer(I), pointer(S), isempty(Tavg) ? C_NULL : pointer(Tavg), pointer(npts), pointer(Y), C_NULL,
                           pointer(info), pointer(cnt), C_NULL))

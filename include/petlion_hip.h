@@ -322,7 +322,8 @@ int plh_integrate(plh_model_t m, int n_cells, const double* theta, const double*
  * the factorisation the integrator already holds; csrc/dfn_sens.h); Y, the saved points, run_info and the counters are bit for bit those of plh_integrate.
  *   dY_dtheta[cell][k][n_states]  at the end of the last completed run (NaN for a cell whose protocol failed); may be NULL
  *   dV_dtheta[cell][k][max_pts]   at every saved point (the Jacobian of the voltage curve a least-squares fit needs); may be NULL
- *   sens_stat[cell][2]            corrector iterations spent, solves that did not reach the tolerance; may be NULL
+ *   sens_stat[cell][3]            corrector iterations spent; solves that did not reach the tolerance; steps whose corrector factored the step's own matrix because the
+ *                                 integrator's (stale) one did not contract (the integrator's factorisation is saved and copied back: the states do not notice); may be NULL
  * Derivatives are with respect to the absolute value of the parameter.  Saved points at accepted steps / stop times: partial derivatives at fixed time.  The last point of a run
  * that ended on a bound is the reference's linear back-interpolation between the last two accepted points (model_evaluation.jl:369-382), whose fraction depends on theta through
  * the bounded quantity: its derivative -- and what the next run continues from -- includes that shift, i.e. it is the derivative of the end state as simulate() returns it

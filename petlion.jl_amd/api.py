@@ -85,6 +85,7 @@ class Model:
         self.N.diff = self._lib.plh_n_diff(h)
         self.N.alg = self.N.tot - self.N.diff
         self.lds_bytes = self._lib.plh_lds_bytes(h)            # LDS per cell of this variant
+        self.save_start_dict = {}                              # p.cache.save_start_dict (src/structures.jl:305): opts.save_start
         self.θ_keys = [self._lib.plh_theta_key(h, i).decode("utf-8") for i in range(self._lib.plh_n_theta(h))]
         self.ind = {}                       # p.ind: state name -> slice into Y (reference state_indices, src/external.jl:275-365)
         for i in range(self._lib.plh_n_sections(h)):
@@ -637,8 +638,24 @@ def simulate(p, tf=1e6, *, sol=None, SOC=None, initial_states=None, **kw):
     soc0 = (p.opts.SOC if SOC is None else SOC) if new else sol.SOC[-1]
     if initial_states is not None:
         soc0 = float(calc_SOC(p, initial_states))                      # (starting_from_initial_state: the estimated SOC, model_evaluation.jl:197-199)
+    # opts.save_start (src/structures.jl:281, model_evaluation.jl:384-411): the algebraic states a consistent initialisation ended with, kept per (method, SOC rounded to 4
+    # digits, input value rounded to 4 digits) in the model's cache and used as the first guess of the next initialisation with the same key.  The reference looks the key up for
+    # every run; here it is the warm start of a NEW solution with a numeric input (a continued run already starts from the previous run's states).
+    ss_key, ss_hit = None, False
+    if getattr(o, "save_start", False) and new and initial_states is None and isinstance(inp, (int, float)) and not isinstance(inp, bool):
+        ss_key = (name, round(float(soc0), 4), round(float(inp), 4))
+        ss_hit = ss_key in p.save_start_dict
+        if ss_hit:
+            th1 = p.theta_vector()[None, :]
+            Y0 = np.zeros((1, p.N.tot)); s1 = np.array([float(soc0)])
+            cap.check(p._lib, p._lib.plh_initial_guess(p._h, 1, th1.ctypes.data, s1.ctypes.data, Y0.ctypes.data, cap.PLH_HOST, None), "plh_initial_guess")
+            Y0[0, p.N.diff:] = p.save_start_dict[ss_key]
+            initial_states = Y0[0]
+    want_Y0 = ss_key is not None and not ss_hit                        # (a miss: the initialised algebraic states are the first saved state vector)
     ens = _integrate(p, p.theta_vector()[None, :], np.array([soc0]), [_make_run(p, name, inp, tf, bounds)], o,
-                     Y_init=(None if initial_states is None else initial_states[None, :]) if new else sol.Y[None, :], t_init=None if new else np.array([sol.t[-1]]), keep_Y=keep_Y)
+                     Y_init=(None if initial_states is None else initial_states[None, :]) if new else sol.Y[None, :], t_init=None if new else np.array([sol.t[-1]]), keep_Y=keep_Y or want_Y0)
+    if want_Y0 and int(ens["run_info"][0, 0]["flag"]) >= 0:
+        p.save_start_dict[ss_key] = ens["Y_all"][0, 0, p.N.diff:].copy()
     n = int(ens["n_pts"][0])
     ri = ens["run_info"][0, 0]
     if ri["flag"] < 0:                                                # the reference's error() paths: `sol` is left untouched
@@ -672,7 +689,7 @@ def simulate_b(sol, p, tf=1e6, **kw):
 def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, stream=None, max_points=None, keep_Y=False, keep_YP=True, sens=None):
     """one plh_integrate call; numpy in / numpy out (host pointers) or torch device tensors (device=True).
     keep_YP = False: YP_final is not requested (the reference keeps YP only with var_keep.YP; the kernel then does not store the previous point's YP per step).
-    sens: list of theta keys -> plh_integrate_sens, bufs["dY_dtheta"][cell, k, state], bufs["dV_dtheta"][cell, k, point], bufs["sens_stat"][cell, 2]."""
+    sens: list of theta keys -> plh_integrate_sens, bufs["dY_dtheta"][cell, k, state], bufs["dV_dtheta"][cell, k, point], bufs["sens_stat"][cell, 3]."""
     lib, h = p._lib, p._h
     n = theta.shape[0]
     N = p.N.tot
@@ -715,9 +732,9 @@ def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, 
         cols = np.ascontiguousarray([p.θ_keys.index(k) for k in sens], dtype=np.int32)
         ns = len(cols)
         if device:
-            bufs["dY_dtheta"], bufs["dV_dtheta"], bufs["sens_stat"] = mk(n, ns, N), mk(n, ns, mp), mk(n, 2, dt=torch.int32)
+            bufs["dY_dtheta"], bufs["dV_dtheta"], bufs["sens_stat"] = mk(n, ns, N), mk(n, ns, mp), mk(n, 3, dt=torch.int32)
         else:
-            bufs["dY_dtheta"], bufs["dV_dtheta"], bufs["sens_stat"] = np.empty((n, ns, N)), np.empty((n, ns, mp)), np.zeros((n, 2), np.int32)
+            bufs["dY_dtheta"], bufs["dV_dtheta"], bufs["sens_stat"] = np.empty((n, ns, N)), np.empty((n, ns, mp)), np.zeros((n, 3), np.int32)
         if Y_init is not None:
             raise ValueError("sensitivities are integrated for new solutions only")
         cap.check(lib, lib.plh_integrate_sens(h, n, cap.ptr(theta), cap.ptr(SOC0), len(runs), arr, C.byref(os_), C.byref(out), ns, cols.ctypes.data,

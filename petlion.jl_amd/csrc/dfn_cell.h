@@ -319,11 +319,12 @@ struct SensArgs {               // (device pointers; part of IntegrateArgs)
   double* hist;                 // [n_cells][n_sens][MAXORD + 1][NPAD]: BDF history of every s_k
   double* dY;                   // [n_cells][n_sens][N] or nullptr: dY/dtheta_k at the end of the last completed run
   double* dV;                   // [n_cells][n_sens][max_pts] or nullptr: dV/dtheta_k at every saved point
-  int* stat;                    // [n_cells][2] or nullptr: corrector iterations, solves that did not reach the tolerance
+  int* stat;                    // [n_cells][3] or nullptr: corrector iterations, solves that did not reach the tolerance, steps that factored their own matrix
   double* cbak;                 // [n_cells][SENS_CBAK]: the cell's theta-derived constants, saved once and copied back after every evaluation with a perturbed theta row
   double* aux;                  // [n_cells][n_sens][4]: per parameter [0] d(held input value)/dtheta of the run being integrated (a :hold run: the previous run's end sensitivity of
                                 // the held quantity), [1] dSOC/dtheta (trapezoid of dI/dtheta over the saved points, like calc_SOC), [2] dI/dtheta at the previous saved point,
                                 // [3] the last step's increment of [1]
+  double* fsave; int fsave_stride;   // [n_cells][fsave_stride]: where a step that factors its own matrix parks the integrator's factorisation (dfn_sens.h, sens_factor_copy)
 };
 constexpr int SENS_CBAK = 384;
 

@@ -884,7 +884,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
   IdaScalars I;
   I.phg = phig;
   [[maybe_unused]] SensCell<M> SX;
-  if constexpr ((F & GF_SENS) != 0) { SX.a = sens; SX.th0 = th0; SX.cell = cell; SX.P = tb->P; SX.max_pts = out.max_pts; SX.first = true; SX.n_it = 0; SX.n_fail = 0; }
+  if constexpr ((F & GF_SENS) != 0) { SX.a = sens; SX.th0 = th0; SX.cell = cell; SX.P = tb->P; SX.max_pts = out.max_pts; SX.first = true; SX.n_it = 0; SX.n_fail = 0; SX.n_refresh = 0; }
   int nout = 0;
   bool have_prev = false;
   const double T0 = S.cc.T0;
@@ -1104,7 +1104,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
   }
   if (lane == 0 && wave_id() == 0 && n_pts_out) *n_pts_out = nout < out.max_pts ? nout : out.max_pts;
   PL_XSYNC();
-  if constexpr ((F & GF_SENS) != 0) { if (lane == 0 && wave_id() == 0 && sens.stat) { sens.stat[2 * cell] = SX.n_it; sens.stat[2 * cell + 1] = SX.n_fail; } }
+  if constexpr ((F & GF_SENS) != 0) { if (lane == 0 && wave_id() == 0 && sens.stat) { sens.stat[3 * cell] = SX.n_it; sens.stat[3 * cell + 1] = SX.n_fail; sens.stat[3 * cell + 2] = SX.n_refresh; } }
   if (Yfin) PL_VEC(n) Yfin[n] = S.yy[n];
   if (YPfin) PL_VEC(n) YPfin[n] = S.yp[n];
 }

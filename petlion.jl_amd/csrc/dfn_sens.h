@@ -39,7 +39,7 @@ __device__ __forceinline__ double wave_max(double v) {
 template <class M> struct SensCell {
   SensArgs a; const double* th0; int cell, P, max_pts;
   bool first;                   // the next accepted step is the first of this integrator instance: hist[1] holds s'(t0), not h s'
-  int n_it, n_fail;
+  int n_it, n_fail, n_refresh;   // corrector iterations; solves that did not converge (after the refresh); steps / initialisations that factored their own matrix
   __device__ __forceinline__ double* hist(int k, int j) const { return a.hist + (((size_t)cell * a.n_sens + k) * (MAXORD + 1) + j) * M::NPAD; }
   __device__ __forceinline__ const double* thp(int k) const { return a.theta_pert + ((size_t)cell * a.n_sens + k) * P; }
   __device__ __forceinline__ double* aux(int k) const { return a.aux + ((size_t)cell * a.n_sens + k) * 4; }
@@ -92,6 +92,38 @@ PL_DEV void sens_eval(CellLDS<M>& S, LaneRegs& R, const double (&s)[M::NTRIP], c
   PL_XSYNC();
 }
 
+// r05: the factorisation as DATA -- everything cell_res_jac / cell_factor write: the structured Jacobian pool, the eliminated system, the resolvents and the SEI / thermal pools
+// (consecutive members of CellLDS from ceL up to the BDF coefficient arrays) and the per-lane registers.  A sensitivity corrector that does not converge with the integrator's
+// stale matrix (rate >= 0.97, or the iteration cap) saves the factorisation to HBM, factors the matrix of the step's OWN solution point and coefficient -- with which the linear
+// sensitivity system converges in one or two iterations -- and copies the integrator's factorisation back afterwards.  A copy, not a recomputation: a second inlined copy of the
+// Jacobian pass may be contracted differently by the compiler (see sens_consts), and the states must keep taking the steps of the run without sensitivities bit for bit.
+template <bool SAVE, class M>
+PL_DEV void sens_factor_copy(CellLDS<M>& S, LaneRegs& R, const SensCell<M>& X) {
+  const int lane = lane_id();
+  double* r0 = &S.ceL[0];
+  const int nd = (int)(&S.ida_psi[0] - r0);
+  double* b = X.a.fsave + (size_t)X.cell * X.a.fsave_stride;
+  PL_XSYNC();
+  for (int k = lane; k < nd; k += WAVE) { if (SAVE) b[k] = r0[k]; else r0[k] = b[k]; }
+  double* br = b + nd + (size_t)(wave_id() * WAVE + lane) * (2 * CS_PASS);
+  for (int q = 0; q < CS_PASS; q++) {
+    if (SAVE) { br[q] = R.wreg[q]; br[CS_PASS + q] = R.rcp[q]; } else { R.wreg[q] = br[q]; R.rcp[q] = br[CS_PASS + q]; }
+  }
+  PL_XSYNC();
+}
+
+// the matrix of the point in (S.phi[0], ypn) with coefficient cj, factored in place (alg_only: the algebraic block of the consistent initialisation)
+template <class M>
+PL_DEV void sens_refactor(CellLDS<M>& S, LaneRegs& R, const double (&ypn)[M::NTRIP], double cj, int mode, double value, bool alg_only) {
+  PL_MODEL(M);
+  const int lane = lane_id();
+  PL_VEC(n) { S.yy[n] = S.phi[0][n]; S.yp[n] = ypn[k__]; }
+  PL_XSYNC();
+  cell_res_jac(S, R, S.yy, S.yp, S.delta, mode, value);
+  cell_factor(S, R, S.tb, cj, mode, alg_only);
+  PL_XSYNC();
+}
+
 // dV/dtheta_k of the point just saved: S.delta holds s_k
 template <class M>
 PL_DEV void sens_put_V(CellLDS<M>& S, const SensCell<M>& X, int k, int idx) {
@@ -109,6 +141,7 @@ PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, boo
   LaneRegs Ra;                                            // (the algebraic solves do not touch the particle registers)
   for (int q = 0; q < CS_PASS; q++) { Ra.wreg[q] = 0.0; Ra.rcp[q] = 0.0; }
   sens_consts<true>(S, X);
+  bool refreshed = false;
   const double I1C0 = S.cc.I1C;
   const int amode = (M::THERMAL && mode == PLH_MODE_DT) ? PL_MODE_DT_TWIN : mode;      // the algebraic form of the dT row (cell_init_consistent)
   double yn[NTRIP], ypn[NTRIP], f0[NTRIP], w[NTRIP], zero[NTRIP];
@@ -147,14 +180,35 @@ PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, boo
     PL_XSYNC();
     // algebraic part: G_ya s_a = -(G_yd s_d + G_theta), Newton-like with the factorisation of the last initialisation iterate
     bool conv = false;
+    for (int attempt = 0; attempt < 2 && !conv; attempt++) {
+    // (not converged with the factorisation the initialisation left behind: the algebraic block of the initial point itself.  Nothing to put back: the integrator's first
+    //  step sets up its own matrix, ida_nls nst == 0)
+    if (attempt == 1) { if (refreshed) break; sens_refactor(S, Ra, ypn, 0.0, amode, value, true); refreshed = true; X.n_refresh++; }
+#ifdef PL_TEST_SENS_FORCE_REFRESH
+    if (attempt == 0 && k == 0) continue;
+#endif
+    double nr_old = 0.0;
     for (int it = 0; it < SENS_MAXIT; it++) {
       double m = 0.0;
       PL_VEC(n) { const double q = fabs(s[k__]) * w[k__]; m = q > m ? q : m; }
       m = wave_max(m);
       const double e = m > 0.0 ? SENS_FD / m : 1.0, re = 1.0 / e;
       sens_eval(S, Ra, s, zero, ypn, e, amode, value);
+#ifdef PL_WAVE_EMU
+      if (getenv("PL_EMU_TRACE_SENS") && lane == 0 && (attempt == 1 || it >= atoi(getenv("PL_EMU_TRACE_SENS")))) {
+        double rm = 0.0; int ir = 0;
+        fprintf(stderr, "   sI %.9e ctrl row F %.6e ", (S.yy[O_I] - S.phi[0][O_I]) * re, S.delta[O_I]);
+      }
+#endif
       PL_VEC(n) S.delta[n] = (S.delta[n] - f0[k__]) * re + fp[k__];
       PL_XSYNC();
+#ifdef PL_WAVE_EMU
+      if (getenv("PL_EMU_TRACE_SENS") && lane == 0 && (attempt == 1 || it >= atoi(getenv("PL_EMU_TRACE_SENS")))) {
+        double rm = 0.0; int ir = NDIFF;
+        for (int n = NDIFF; n < NST; n++) if (fabs(S.delta[n]) > rm) { rm = fabs(S.delta[n]); ir = n; }
+        fprintf(stderr, "r[I] %.6e largest alg r row %d %.6e\n", S.delta[O_I], ir, S.delta[ir]);
+      }
+#endif
       cell_solve(S, Ra, S.delta, amode, true);
       PL_XSYNC();
       double nr = 0.0;
@@ -162,8 +216,21 @@ PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, boo
       nr = sqrt(wave_sum(nr) * (1.0 / NST));
       X.n_it++;
       PL_XSYNC();
+#ifdef PL_WAVE_EMU
+      if (getenv("PL_EMU_TRACE_SENS") && lane == 0 && (attempt == 1 || it >= atoi(getenv("PL_EMU_TRACE_SENS")))) {
+        int im = NDIFF; double vm = 0.0;
+        for (int n = NDIFF; n < NST; n++) { const double q = fabs(S.delta[n]) / (fabs(S.phi[0][n]) + atol / rtol); if (q > vm) { vm = q; im = n; } }
+        fprintf(stderr, "sens init cell %d mode %d k %d attempt %d it %d nr %.3e m %.3e e %.3e worst row %d d %.3e y %.3e\n", X.cell, mode, k, attempt, it, nr, m, e, im, S.delta[im], S.phi[0][im]);
+      }
+#endif
       if (nr <= sens_tol(rtol)) { conv = true; break; }
       if (!(nr == nr)) break;
+      // the rate-based test of sens_step (IDAS' criterion) here too: at the start of a dT = :hold run the heat sources make the twin control row's difference quotient noisy
+      // (1e-5 ... 2e-4 in this norm, measured on C3 cells: the iteration contracts to that floor and is kicked off it again, for ever); 0.33 reltol is above that floor
+      // at the default tolerances and below sens_tol at tight ones, where nothing changes
+      if (it > 0) { const double q = nr / nr_old; if (q < 0.97 && q / (1.0 - q) * nr <= 0.33 * rtol) { conv = true; break; } }
+      nr_old = nr;
+    }
     }
     if (!conv) X.n_fail++;
     // s'_diff = d rhs_diff / dy s + d rhs_diff / d theta (F_diff = rhs - y'); s'_alg = 0
@@ -194,7 +261,8 @@ PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<
   PL_MODEL(M);
   const int lane = lane_id();
   const int ku = I.kused; const double cj = I.cj;
-  const double sc = (I.cjratio != 1.0) ? 2.0 / (1.0 + I.cjratio) : 1.0;
+  double sc = (I.cjratio != 1.0) ? 2.0 / (1.0 + I.cjratio) : 1.0;
+  bool refreshed = false;
   double yn[NTRIP], ypn[NTRIP], f0[NTRIP], zero[NTRIP];
   PL_VEC(n) { yn[k__] = S.yy[n]; ypn[k__] = S.yp[n]; zero[k__] = 0.0; }
   PL_XSYNC();
@@ -223,6 +291,17 @@ PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<
     }
     PL_VEC(n) s[k__] = a_[k__];
     bool conv = false;
+    const bool fresh0 = refreshed;                          // (an earlier parameter of this step already factored the step's matrix)
+    for (int attempt = 0; attempt < 2 && !conv; attempt++) {
+    if (attempt == 1) {
+      // not converged with the integrator's matrix: the step's own matrix (this and the remaining parameters of the step use it; the integrator gets its own back below)
+      if (!X.a.fsave || fresh0) break;
+      sens_factor_copy<true>(S, R, X); sens_refactor(S, R, ypn, cj, mode, value, false); refreshed = true; sc = 1.0; X.n_refresh++;
+      PL_VEC(n) s[k__] = a_[k__];
+    }
+#ifdef PL_TEST_SENS_FORCE_REFRESH
+    if (attempt == 0 && k == 0 && (X.n_it % 3) == 0) continue;      // (test build: every few steps the first parameter is sent through the refresh path)
+#endif
     double nr_old = 0.0;
     for (int it = 0; it < SENS_MAXIT; it++) {
       double sp[NTRIP], m = 0.0;
@@ -239,14 +318,22 @@ PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<
       nr = sqrt(wave_sum(nr) * (1.0 / NST));
       X.n_it++;
       PL_XSYNC();
+#ifdef PL_WAVE_EMU
+      if (getenv("PL_EMU_TRACE_SENS") && lane == 0 && (attempt == 1 || it >= atoi(getenv("PL_EMU_TRACE_SENS")))) fprintf(stderr, "sens step cell %d nst %d t %.6f k %d attempt %d it %d nr %.3e q %.3f cjratio %.3f\n", X.cell, I.nst, I.tn, k, attempt, it, nr, it ? nr / nr_old : 0.0, I.cjratio);
+#endif
       if (nr <= sens_tol(I.rtol)) { conv = true; break; }
       if (!(nr == nr)) break;
       // r05: IDANls' own convergence test beside the fixed one -- the corrector is linear, its rate is that of the integrator's (possibly stale) matrix: with the estimated
       // rate q the remaining error is q / (1 - q) x the last correction, and a sensitivity is converged for a step integrated at reltol once that is below 0.33 reltol of the
       // state scale per unit relative parameter change (IDAS' criterion).  At tight tolerances 0.33 reltol is below sens_tol and nothing changes; at the default ones the
       // steps near a voltage knee, where the stale matrix converges at 0.8 ... 0.9, no longer run into the iteration cap (r04: 4263 of 4.7 M solves of the C4 shard did)
-      if (it > 0) { const double q = nr / nr_old; if (q < 0.97 && q / (1.0 - q) * nr <= 0.33 * I.rtol) { conv = true; break; } }
+      if (it > 0) {
+        const double q = nr / nr_old;
+        if (q < 0.97 && q / (1.0 - q) * nr <= 0.33 * I.rtol) { conv = true; break; }
+        if (attempt == 0 && it >= 8 && q >= 0.97 && X.a.fsave) break;          // the stale matrix does not contract: no point in the other 55 iterations
+      }
       nr_old = nr;
+    }
     }
     if (!conv) X.n_fail++;
     // history update (IDACompleteStep): phi[ku+1] = e, phi[ku] += e, phi[j] += phi[j+1]
@@ -264,6 +351,7 @@ PL_DEV void sens_step(CellLDS<M>& S, LaneRegs& R, const IdaScalars& I, SensCell<
     }
   }
   X.first = false;
+  if (refreshed) sens_factor_copy<false>(S, R, X);        // the integrator's own factorisation, bit for bit
   PL_VEC(n) { S.yy[n] = yn[k__]; S.yp[n] = ypn[k__]; }
   PL_XSYNC();
 }

@@ -837,7 +837,7 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
   a.out.Y_all = s.buf(out->Y_all, np * m->N, false);
   a.out.Y_final = s.buf(out->Y_final, (size_t)n * m->N, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * m->N, false);
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
-  a.sens.n_sens = 0; a.sens.cols = nullptr; a.sens.theta_pert = nullptr; a.sens.hist = nullptr; a.sens.dY = nullptr; a.sens.dV = nullptr; a.sens.stat = nullptr; a.sens.cbak = nullptr; a.sens.aux = nullptr;
+  a.sens.n_sens = 0; a.sens.cols = nullptr; a.sens.theta_pert = nullptr; a.sens.hist = nullptr; a.sens.dY = nullptr; a.sens.dV = nullptr; a.sens.stat = nullptr; a.sens.cbak = nullptr; a.sens.aux = nullptr; a.sens.fsave = nullptr; a.sens.fsave_stride = 0;
   size_t n_dY = 0, n_dV = 0;
   if (sq) {
     const int ns = sq->n_sens, NPAD = m->N + (m->N & 1);
@@ -848,14 +848,16 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
     a.sens.hist = (double*)s.dev_block((size_t)n * ns * 6 * NPAD * sizeof(double));
     a.sens.cbak = (double*)s.dev_block((size_t)n * pl::SENS_CBAK * sizeof(double));
     a.sens.aux = (double*)s.dev_block((size_t)n * ns * 4 * sizeof(double));
-    a.sens.dY = s.buf(sq->dY, n_dY, false); a.sens.dV = s.buf(sq->dV, n_dV, false); a.sens.stat = s.buf(sq->stat, (size_t)2 * n, false);
+    a.sens.fsave_stride = m->ops->fsave_doubles;
+    a.sens.fsave = (double*)s.dev_block((size_t)n * a.sens.fsave_stride * sizeof(double));
+    a.sens.dY = s.buf(sq->dY, n_dY, false); a.sens.dV = s.buf(sq->dV, n_dV, false); a.sens.stat = s.buf(sq->stat, (size_t)3 * n, false);
     CHECK_STAGE(s);
     a.sens.theta_pert = tp;
     launch_theta_pert(s.st, a.theta, a.sens.cols, n, ns, m->P, tp);
     // outputs of cells that never get as far as writing them read as NaN (all-ones bytes)
     if (a.sens.dY) HIPCHK(hipMemsetAsync(a.sens.dY, 0xff, n_dY * sizeof(double), s.st));
     if (a.sens.dV) HIPCHK(hipMemsetAsync(a.sens.dV, 0xff, n_dV * sizeof(double), s.st));
-    if (a.sens.stat) HIPCHK(hipMemsetAsync(a.sens.stat, 0, (size_t)2 * n * sizeof(int), s.st));
+    if (a.sens.stat) HIPCHK(hipMemsetAsync(a.sens.stat, 0, (size_t)3 * n * sizeof(int), s.st));
     if (a.sens.aux) HIPCHK(hipMemsetAsync(a.sens.aux, 0, (size_t)n * ns * 4 * sizeof(double), s.st));
   }
   CHECK_STAGE(s);                                                     // a failed staging allocation must never reach the kernel as a NULL ("not requested") output
@@ -878,7 +880,7 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
   s.back(out->T_avg, a.out.T_avg, np); s.back(out->n_pts, a.out.n_pts, n); s.back(out->Y_all, a.out.Y_all, np * m->N);
   s.back(out->Y_final, a.out.Y_final, (size_t)n * m->N); s.back(out->YP_final, a.out.YP_final, (size_t)n * m->N);
   s.back(out->run_info, a.out.run_info, (size_t)n * n_runs); s.back(out->counters, a.out.counters, n);
-  if (sq) { s.back(sq->dY, a.sens.dY, n_dY); s.back(sq->dV, a.sens.dV, n_dV); s.back(sq->stat, a.sens.stat, (size_t)2 * n); }
+  if (sq) { s.back(sq->dY, a.sens.dY, n_dY); s.back(sq->dV, a.sens.dV, n_dV); s.back(sq->stat, a.sens.stat, (size_t)3 * n); }
   CHECK_STAGE(s);
   if (kind == PLH_HOST_ASYNC) s.defer();
   return 0;

@@ -358,7 +358,7 @@ template <class M> struct OpsOf {
     static_assert(!GRID_DEFAULT || sizeof(CellLDS<M>) <= 40960, "built-in variant: LDS per cell above 40 960 B, only three cells per CU would be resident");
 #endif
     static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::PREC, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, {NP, NS, NN, NRP, NA, NZ, NRN},
-                                   {PL_RADIAL_M, PL_RADIAL_M_N}, {PL_RADIAL_LAM, PL_RADIAL_LAM_N}, {PL_RADIAL_V, PL_RADIAL_V_N}, {PL_RADIAL_W, PL_RADIAL_W_N}, {PL_RADIAL_BJ_FACTOR, PL_RADIAL_BJ_FACTOR_N}, sizeof(CellLDS<M>), M::PHI_GLOBAL ? (MAXORD + 1 - M::PHI_LDS) * M::NPAD : 0, &classify<M>, &sections_of<M>,
+                                   {PL_RADIAL_M, PL_RADIAL_M_N}, {PL_RADIAL_LAM, PL_RADIAL_LAM_N}, {PL_RADIAL_V, PL_RADIAL_V_N}, {PL_RADIAL_W, PL_RADIAL_W_N}, {PL_RADIAL_BJ_FACTOR, PL_RADIAL_BJ_FACTOR_N}, sizeof(CellLDS<M>), (int)(sizeof(CellLDS<M>) / sizeof(double)) + M::NWAVES * WAVE * 2 * CS_PASS, M::PHI_GLOBAL ? (MAXORD + 1 - M::PHI_LDS) * M::NPAD : 0, &classify<M>, &sections_of<M>,
                                    &initial_guess, &residual, &jacobian, &linear_solve, &init_consistent, &integrate};
     return &ops;
   }

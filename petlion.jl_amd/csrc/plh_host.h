@@ -45,6 +45,7 @@ struct VariantOps {
   int grid[7];                                                                       // N_p, N_s, N_n, N_r_p, N_a, N_z, N_r_n this table was compiled for
   const double *rad_M[2], *rad_LAM[2], *rad_V[2], *rad_W[2]; double rad_BJ[2];       // radial operator tables of N_r_p / N_r_n (radial_tables.h), N_r x N_r packed
   size_t lds_bytes;                                                                  // sizeof(CellLDS<M>): LDS per cell (= per workgroup)
+  int fsave_doubles;                                                                 // doubles per cell a sensitivity step needs to park the integrator's factorisation (dfn_sens.h, sens_factor_copy)
   int phig_doubles;                                                                  // doubles of global-memory BDF history per cell (0: the history is LDS / register resident)
   unsigned (*classify)(const pl::Tables& tb, int mode, int r, int c);              // decode word of the structural Jacobian entry (r, c), 0 if structurally zero
   int (*sections)(SectionInfo* out);
@@ -68,5 +69,5 @@ PL_VARIANT_LIST(PL_DECLARE_OPS)
 extern "C" const VariantOps* plh_grid_variant_ops(int id);     // nullptr: variant not built into this grid library
 extern "C" void plh_grid_dims(int* grid7);
 // what a grid library was compiled against: bump PLH_HOST_ABI whenever VariantOps / IntegrateArgs / Tables change, so that a stale cached library is refused, not misread
-constexpr int PLH_HOST_ABI = 8;
+constexpr int PLH_HOST_ABI = 9;
 extern "C" void plh_grid_abi(int* abi, int* sizeof_ops, int* sizeof_args, int* sizeof_tables);

@@ -123,6 +123,7 @@ class Opts:
         self.tstops = []
         self.tdiscon = []           # known discontinuities of a time-dependent input (run-local times), reference opts.tdiscon
         self.interp_bc = "interpolate"
+        self.save_start = False     # warm start of the consistent initialisation from the model's cache (reference opts.save_start, model_evaluation.jl:384-411)
         # build-specific knobs (not in the reference)
         self.max_order = 5
         self.jac_every_step = False

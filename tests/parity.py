@@ -562,6 +562,27 @@ def check_initial_states(p, O, pkg):
             pkg.simulate(p, 100.0, I=1.0, sol=sol, initial_states=Y0[0])
 
 
+def check_save_start(p, pkg):
+    """opts.save_start (reference src/model_evaluation.jl:384-411): the first simulate() with a key fills p.save_start_dict with the initialised algebraic states and is otherwise
+    the plain call; the second starts its consistent initialisation from them -- fewer Newton iterations, the same trajectory to the initialisation tolerance."""
+    p.save_start_dict.clear()
+    plain = pkg.simulate(p, 600.0, I=-1.0, SOC=0.8)
+    a = pkg.simulate(p, 600.0, I=-1.0, SOC=0.8, save_start=True)
+    assert list(p.save_start_dict) == [("I", 0.8, -1.0)] and np.array_equal(a.V, plain.V) and np.array_equal(a.t, plain.t)
+    b = pkg.simulate(p, 600.0, I=-1.0, SOC=0.8, save_start=True)
+    assert len(p.save_start_dict) == 1 and abs(len(b.t) - len(a.t)) <= 2
+    # (another first guess, another last bit of the initialised state, another h0: the step grids differ by 1e-3 of h -- the trajectories are compared at equal times)
+    tt = a.t[1:-1]
+    dV = np.abs(np.asarray(b(tt).V) - a.V[1:-1]).max()
+    assert abs(b.V[0] - a.V[0]) < 1e-6 and dV < 1e-4 and abs(b.t[-1] - a.t[-1]) < 1e-9, (dV, b.V[0] - a.V[0])
+    ia, ib = int(a.counters["n_init_iters"]), int(b.counters["n_init_iters"])
+    assert ib < ia, (ia, ib)
+    c = pkg.simulate(p, 600.0, I=-2.0, SOC=0.8, save_start=True)                 # another key
+    assert len(p.save_start_dict) == 2 and c.V[-1] < a.V[-1]
+    print("save_start: initialisation Newton iterations %d -> %d with the cached algebraic states; |dV| at equal times %.1e" % (ia, ib, dV))
+    p.save_start_dict.clear()
+
+
 def pytest_raises(exc):
     import pytest
     return pytest.raises(exc)

@@ -941,3 +941,7 @@ def test_occupancy_experiment_layouts_are_bit_identical(pkg, flag, tag, lds):
 
 def test_initial_states(emu_model, O, pkg):
     parity.check_initial_states(emu_model, O, pkg)
+
+
+def test_save_start(emu_model, pkg):
+    parity.check_save_start(emu_model, pkg)

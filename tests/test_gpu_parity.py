@@ -825,3 +825,7 @@ def test_selftest_catches_a_broken_plain_kernel(pkg, hip_model):
 def test_initial_states_on_gpu(hip_model, hip_model_thermal, O, pkg):
     parity.check_initial_states(hip_model, O, pkg)
     parity.check_initial_states(hip_model_thermal, O, pkg)
+
+
+def test_save_start_on_gpu(hip_model, pkg):
+    parity.check_save_start(hip_model, pkg)

@@ -154,7 +154,8 @@ def test_sens_cc_cv_to_an_soc_bound_gpu(hip_model, O, pkg):
 @pytest.mark.gpu
 def test_sens_c3_protocol_on_gpu(hip_model_thermal, pkg):
     """r05: plh_integrate_sens accepts C3's CC-CT-CV protocol (4C -> dT = :hold -> V = :hold to SOC_max): every cell of a 256-cell sample finishes with finite sensitivities of
-    the end state with respect to h_cell, k_p and D_sn, states equal to the plain launch's decisions, no corrector solve at the cap"""
+    the end state with respect to h_cell, k_p and D_sn, states bit for bit the plain launch's, every corrector solve converged (where the integrator's stale matrix does not
+    contract, the step factors its own and copies the integrator's back: dfn_sens.h, sens_factor_copy)"""
     p = hip_model_thermal
     cfg = pkg.configs.c3(p, 4096)
     Th = np.ascontiguousarray(cfg["theta"][::16])
@@ -164,8 +165,10 @@ def test_sens_c3_protocol_on_gpu(hip_model_thermal, pkg):
     assert np.array_equal(ens.counters["n_steps"], ref.counters["n_steps"])
     dY = np.asarray(ens.dY_dtheta)
     st = np.asarray(ens.sens_stat)
-    print("C3 CC-CT-CV with three sensitivities, 256 cells: finite in %d cells; corrector solves at the cap: %d; kernel %.1f ms (plain %.1f ms)"
-          % (int(np.isfinite(dY).all(axis=(1, 2)).sum()), int(st[:, 1].sum()), ens.kernel_ms, ref.kernel_ms))
+    print("C3 CC-CT-CV with three sensitivities, 256 cells: finite in %d cells; corrector solves without convergence: %d; steps that factored their own matrix: %d of %d; kernel %.1f ms (plain %.1f ms)"
+          % (int(np.isfinite(dY).all(axis=(1, 2)).sum()), int(st[:, 1].sum()), int(st[:, 2].sum()), int(ens.counters["n_steps"].sum()), ens.kernel_ms, ref.kernel_ms))
+    # (the first GPU run of this test, before sens_step factored the step's own matrix when the integrator's stale one does not contract: 28 solves at the iteration cap)
+    assert np.array_equal(np.asarray(ens.Y), np.asarray(ref.Y)), "the states changed with sensitivities on"
     assert np.isfinite(dY).all() and st[:, 1].sum() == 0
 
 
@@ -227,8 +230,10 @@ def test_sens_full_c4_launch_on_gpu(hip_model, pkg):
     assert float(((ens.Y - ref.Y).abs() / (ref.Y.abs() + 1e-300)).max()) < 1e-6 and all(parity.state_rel_err(Ye[c], Yr[c]) < 1e-9 for c in bad)
     st = ens.sens_stat.cpu().numpy()
     nonfinite = int((~torch.isfinite(ens.dY_dtheta)).any(dim=2).any(dim=1).sum())
-    print("   corrector solves that did not reach the tolerance: %d in %d cells (of %d solves); cells with a non-finite sensitivity: %d" % (int(st[:, 1].sum()), int((st[:, 1] > 0).sum()), int(7 * ens.counters["n_steps"].sum()), nonfinite))
-    assert nonfinite == 0 and st[:, 1].sum() <= 1e-3 * 7 * ens.counters["n_steps"].sum()
+    print("   corrector solves that did not reach the tolerance: %d in %d cells (of %d solves); steps that factored their own matrix: %d in %d cells (of %d steps); cells with a non-finite sensitivity: %d"
+          % (int(st[:, 1].sum()), int((st[:, 1] > 0).sum()), int(7 * ens.counters["n_steps"].sum()), int(st[:, 2].sum()), int((st[:, 2] > 0).sum()), int(ens.counters["n_steps"].sum()), nonfinite))
+    # (until the first r05 GPU run: 2636 of the 4.7 M solves ran into the iteration cap with the integrator's stale matrix; since then such a step factors its own, dfn_sens.h)
+    assert nonfinite == 0 and st[:, 1].sum() == 0 and st[:, 2].sum() <= 0.01 * ens.counters["n_steps"].sum()
     print("C4 shard, 8192 cells x 7 sensitivities: kernel %.1f ms (plain %.1f ms: x%.1f), %.2f corrector iterations per step and parameter"
           % (ms_sens, plain.kernel_ms, ms_sens / plain.kernel_ms, st[:, 0].sum() / (7.0 * ens.counters["n_steps"].sum())))
 
@@ -271,3 +276,36 @@ def test_sens_default_tolerance_accuracy_on_gpu(hip_model, pkg):
           "step and parameter; solves at the iteration cap: %d" % (len(ev), *np.percentile(ev, (50, 90, 99)), ev.max(), sorted(errs, reverse=True)[:3], its, int(st[:, 1].sum())))
     assert np.percentile(ev, 99) <= 1e-2 and ev.max() <= 5e-2
     assert st[:, 1].sum() == 0
+
+
+@pytest.mark.parametrize("variant,kw", [(0, {}), (4, {"temperature": True})])
+def test_sens_refresh_path_emu(pkg, variant, kw):
+    """r05: a sensitivity corrector that does not converge with the integrator's (stale) matrix factors the step's own matrix and afterwards copies the integrator's factorisation
+    back (dfn_sens.h).  A test build sends the first parameter of every few steps -- and of every initialisation -- through that path (-DPL_TEST_SENS_FORCE_REFRESH): the states
+    stay bit for bit those of the normal build (the copy restores LDS pools and per-lane registers exactly), the sensitivities agree with the normal build's to the corrector's
+    tolerance, and the path was taken.  Isothermal and thermal (whose factorisation also lives in ThermalPool and in LaneRegs.rcp); CC -> hold -> rest, three parameters."""
+    import os, subprocess, sys, build_emu
+    la, lb = build_emu.build(variant=variant), build_emu.build(variant=variant, extra=["-DPL_TEST_SENS_FORCE_REFRESH"], tag="_sfr")
+    code = ("import sys; sys.path.insert(0, %r)\nimport numpy as np, pkgload\npkg = pkgload.load()\np = pkg.petlion(pkg.LCO, _lib_path=sys.argv[1], **%r)\n"
+            "Th = pkg.configs.sweep_theta(p, np.arange(2), 4)\n"
+            "proto = [dict(I=2.0, tf=300.0, V_max=4.1), dict(V='hold', tf=200.0, I_min=0.0), dict(I='rest', tf=60.0)]\n"
+            "e = pkg.simulate_ensemble(p, Th, proto, SOC=0.3, sens=['D_sp', 'k_n', 'D_s'])\n"
+            "r = pkg.simulate_ensemble(p, Th, proto, SOC=0.3)\n"
+            "assert np.array_equal(np.asarray(e.Y), np.asarray(r.Y)) and np.array_equal(e.counters['n_steps'], r.counters['n_steps']), 'the states changed with sensitivities on'\n"
+            "np.savez(sys.argv[2], Y=np.asarray(e.Y), dY=np.asarray(e.dY_dtheta), dV=np.asarray(e.dV_dtheta), st=np.asarray(e.sens_stat), npts=e.n_pts)\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), kw))
+    out = []
+    for lib in (la, lb):            # (one process per library: both export the same C symbols)
+        f = "/tmp/sens_refresh_%d_%d.npz" % (variant, len(out))
+        subprocess.check_call([sys.executable, "-c", code, lib, f])
+        out.append(np.load(f))
+    a, b = out
+    assert np.array_equal(a["Y"], b["Y"]) and np.array_equal(a["npts"], b["npts"])
+    assert (a["st"][:, 1] == 0).all() and (b["st"][:, 1] == 0).all() and (b["st"][:, 2] >= 3).all(), (a["st"], b["st"])
+    scale = np.abs(a["dY"]).max(axis=2, keepdims=True) + 1e-300
+    eY = (np.abs(a["dY"] - b["dY"]) / scale).max()
+    k = int(a["npts"].min())
+    eV = (np.abs(a["dV"][:, :, :k] - b["dV"][:, :, :k]).max(axis=2) / np.abs(a["dV"][:, :, :k]).max(axis=2)).max()
+    print("variant %d: refresh path in %s steps of the two cells (normal build: %s); dY/dtheta normal vs forced-refresh build %.1e, dV/dtheta %.1e (default tolerances)"
+          % (variant, b["st"][:, 2], a["st"][:, 2], eY, eV))
+    assert eY <= 5e-3 and eV <= 5e-3            # (both are converged to 0.33 reltol of the state scale: the rate-based exit of the stale iteration against one or two exact solves)
