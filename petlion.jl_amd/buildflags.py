@@ -19,10 +19,30 @@ EARLY_INLINE = ["-DPL_DEV=__device__ __forceinline__"]
 # copies of the exp / log polynomial coefficients of the thermal node pass -- to the top of the kernel and keeps it live across all phases (thermal: 392 B/lane of scratch with
 # it, 0 without; C3 +18.6 %, C5 +4.6 %, C2 / C4 +1.8 %)
 NO_MACHINE_LICM = ["-mllvm", "-disable-machine-licm"]
-# thermal kernels are register-bound: plain 8-byte DS accesses (no IR load/store vectoriser, no machine-level DS merging) +4 %
-NO_DS_MERGE = ["-mllvm", "-amdgpu-load-store-vectorizer=0", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
+# thermal kernels are register-bound: plain 8-byte DS accesses (no IR load/store vectoriser) +4 %
+# (until r05 the list also carried `-Xclang -target-feature -Xclang -load-store-opt`, which this compiler answers with "not a recognized feature for this target (ignoring
+#  feature)": the measured gain was the vectoriser switch alone)
+NO_DS_MERGE = ["-mllvm", "-amdgpu-load-store-vectorizer=0"]
 # compiler fences at the phase boundaries (+2.9 % C3) and the branching update of the register-resident BDF history (+2.5 %), thermal variants only
 THERMAL_SRC = ["-DPL_PHASE_FENCES", "-DPL_EXP_BRANCHY_PHI"]
+# r05: the GCN iterative scheduler with the ILP strategy instead of the default max-occupancy one.  Every kernel runs ONE wavefront per SIMD (waves_per_eu(1, 1); two for the small
+# cells): occupancy is not a goal, and nothing hides an LDS / DPP latency but the instruction order itself.  Measured (tools/experiments/sched_search.py, one MI355X): C2 +1.8 %,
+# C4 +2.7 %, C3 +5.2 %; max-ilp +0.4 % on the isothermal kernel and a MISCOMPILED thermal one (the kernel self-test caught it), max-memory-clause / metric-bias 0 / relaxed
+# occupancy / no unclustered reschedule +-0.3 %, the AMDGPU register-pressure trackers -5 %
+SCHED_DEFAULT = "iterative-ilp"
+
+
+def sched_flags():
+    """(experiment builds select another strategy through PETLION_SCHED_STRATEGY -- the option may only be given once on a command line; "" = LLVM's default)"""
+    import os
+    st = os.environ.get("PETLION_SCHED_STRATEGY", SCHED_DEFAULT)
+    return ["-mllvm", "-amdgpu-sched-strategy=" + st] if st else []
+
+
+# variants built with LLVM's default scheduler: 16 (LCO thermal, reference-order rows) -- under the iterative scheduler its table-input instantiation starts with a garbage
+# step size (flag 3 after 9 steps at t = 1e-16 s: tests/test_gpu_parity.py::test_every_kernel_instantiation_of_every_variant lists every failing instantiation; the other
+# 16 x 6 pass)
+DEFAULT_SCHED_VARIANTS = {16}
 # variants that keep MachineLICM in the built-in library (none at present; the mechanism stays for the next register-allocation miscompile of one instantiation)
 KEEP_MACHINE_LICM: set = set()
 
@@ -32,15 +52,19 @@ def is_thermal(v):
     return grids.variant_table()[v][2] == "true"
 
 
-def variant_flags(v, machine_licm=False, thermal=None):
-    """compile flags (after the common ones: arch, std, -fPIC, warnings, grid / namespace defines) of variant v's translation unit"""
+def variant_flags(v, machine_licm=False, thermal=None, default_sched=False):
+    """compile flags (after the common ones: arch, std, -fPIC, warnings, grid / namespace defines) of variant v's translation unit.
+    default_sched=True: LLVM's default scheduler instead of the iterative one -- what every builder retries ONE object with when hipcc dies on it (the iterative scheduler is
+    marked experimental upstream: it segfaults on the (2, 2, 2, 10) grid's isothermal kernel, r05) and what the self-test fall-back build (machine_licm=True) uses"""
     th = is_thermal(v) if thermal is None else thermal
     fl = (EARLY_INLINE + NO_DS_MERGE + THERMAL_SRC) if th else list(LATE_INLINE)
     if not (machine_licm or v in KEEP_MACHINE_LICM):
         fl = fl + NO_MACHINE_LICM
-    return fl + [OPT]
+    import os
+    excluded = v in DEFAULT_SCHED_VARIANTS and not os.environ.get("PETLION_SCHED_ALL")          # (PETLION_SCHED_ALL=1: tools/experiments/miscompile_repro.py)
+    return fl + ([] if (default_sched or machine_licm or excluded) else sched_flags()) + [OPT]
 
 
 def table_repr():
     """what enters the build-identity hash (plh_build_info): the whole table"""
-    return repr((OPT, LATE_INLINE, EARLY_INLINE, NO_MACHINE_LICM, NO_DS_MERGE, THERMAL_SRC, sorted(KEEP_MACHINE_LICM)))
+    return repr((OPT, LATE_INLINE, EARLY_INLINE, NO_MACHINE_LICM, NO_DS_MERGE, THERMAL_SRC, sched_flags(), sorted(DEFAULT_SCHED_VARIANTS), sorted(KEEP_MACHINE_LICM)))

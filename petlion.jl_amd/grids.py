@@ -12,6 +12,7 @@ import json
 import os
 import re
 import subprocess
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -118,15 +119,24 @@ def _library_locked(grid, variants, force, tag, defs, machine_licm=False, extra_
         objs.append(o)
         # the flags of the built-in kernels of this variant (buildflags.py: ONE table since r05; r04's grid libraries kept MachineLICM and late inlining for every variant
         # and ran 2 ... 21 % behind the built-in kernels for it).  A library that fails the self-test on the user's machine is rebuilt with machine_licm=True.
-        jobs.append(subprocess.Popen(common + buildflags.variant_flags(v, machine_licm=machine_licm) + ["-DPL_VARIANT=%d" % v, "-c", src, "-o", o]))
+        jobs.append((v, o, subprocess.Popen(common + buildflags.variant_flags(v, machine_licm=machine_licm) + ["-DPL_VARIANT=%d" % v, "-c", src, "-o", o], stderr=subprocess.PIPE)))
     glue = os.path.join(GRID_DIR, "%s%s_glue.o" % (tag, suffix))
-    jobs.append(subprocess.Popen(common + ["-O2", "-DPL_GRID_GLUE", "-c", src, "-o", glue]))
-    if any(j.wait() for j in jobs):
+    gj = subprocess.Popen(common + ["-O2", "-DPL_GRID_GLUE", "-c", src, "-o", glue])
+    default_sched = []
+    for v, o, j in jobs:
+        err = j.communicate()[1]
+        if j.returncode:
+            # hipcc died on this instantiation (the iterative scheduler is experimental upstream): ONCE more with LLVM's default scheduler
+            if subprocess.call(common + buildflags.variant_flags(v, machine_licm=machine_licm, default_sched=True) + ["-DPL_VARIANT=%d" % v, "-c", src, "-o", o]):
+                sys.stderr.write(err.decode(errors="replace")[-4000:])
+                raise RuntimeError("hipcc failed building the kernels of discretisation %r" % (grid,))
+            default_sched.append(v)
+    if gj.wait():
         raise RuntimeError("hipcc failed building the kernels of discretisation %r" % (grid,))
     tmp = lib + ".tmp%d" % os.getpid()                      # (a forced rebuild replaces the file atomically: a process that has the old one mapped keeps its inode)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", glue] + objs + ["-o", tmp])
     os.replace(tmp, lib)
-    json.dump({"grid": list(grid), "variants": allv, "suffix": suffix, "machine_licm": bool(machine_licm), "extra_flags": list(extra_flags)}, open(manifest, "w"))
+    json.dump({"grid": list(grid), "variants": allv, "suffix": suffix, "machine_licm": bool(machine_licm), "extra_flags": list(extra_flags), "default_sched_variants": default_sched}, open(manifest, "w"))
     for o in objs + [glue]:
         os.remove(o)
     return lib

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""r05: does another instruction scheduler help a kernel that runs ONE wavefront per SIMD (nothing hides a latency but the schedule itself)?
+
+    python tools/experiments/sched_search.py build          (here: hipcc cross-compiles; the libraries travel with the snapshot)
+    python tools/experiments/sched_search.py run            (on the GPU box: bench.py --config C2 / C4 with variant 0, C3 with variant 4, per library)
+
+One experiment library per flag set (variants 0 = LCO isothermal and 4 = LCO thermal, production flags + the set).  Prints per library the bench value and the kernel time; the
+result decides whether a set joins petlion.jl_amd/buildflags.py."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+EXP = os.path.join(ROOT, "petlion.jl_amd", "_exp")
+M = "-mllvm"
+# batch 2 (after iterative-ilp joined the flag table: "base2" is the production flag set); a value that starts with "sched=" replaces the strategy
+SETS2 = {
+    "base2": [],
+    "iter_minreg": ["sched=iterative-minreg"],
+    "iter_maxocc": ["sched=iterative-maxocc"],
+    "llvm_default": ["sched="],
+    "no_cluster": [M, "-misched-cluster=0"],
+    "no_postsched": [M, "-enable-post-misched=0"],
+    "no_lowocc_resched": [M, "-amdgpu-disable-clustered-low-occupancy-reschedule"],
+    "aa_sched": [M, "-enable-aa-sched-mi"],
+    "antidep_all": [M, "-break-anti-dependencies=all"],
+}
+SETS = {
+    "base": [],
+    "max_ilp": [M, "-amdgpu-sched-strategy=max-ilp"],
+    "max_clause": [M, "-amdgpu-sched-strategy=max-memory-clause"],
+    "iter_ilp": [M, "-amdgpu-sched-strategy=iterative-ilp"],
+    "bias0": [M, "-amdgpu-schedule-metric-bias=0"],
+    "trackers": [M, "-amdgpu-use-amdgpu-trackers"],
+    "relaxed": [M, "-amdgpu-schedule-relaxed-occupancy"],
+    "no_unclustered": [M, "-amdgpu-disable-unclustered-high-rp-reschedule"],
+}
+SETS.update(SETS2)
+
+
+def lib(name):
+    return os.path.join(EXP, "libplh_sched_%s.so" % name)
+
+
+def build(names):
+    import __graft_entry__ as g
+    os.makedirs(EXP, exist_ok=True)
+    for n in names:
+        try:
+            fl = [f for f in SETS[n] if not f.startswith("sched=")]
+            st = [f[6:] for f in SETS[n] if f.startswith("sched=")]
+            os.environ.pop("PETLION_SCHED_STRATEGY", None)
+            if st:
+                os.environ["PETLION_SCHED_STRATEGY"] = st[0]
+            print(n, g.build_hip(extra_flags=fl, lib=lib(n), variants=[0, 4]), flush=True)
+        except Exception as e:          # (a flag set the compiler rejects or dies on is a result too)
+            print(n, "FAILED", repr(e)[:300], flush=True)
+
+
+def run(names, configs):
+    rows = []
+    for n in names:
+        if not os.path.exists(lib(n)):
+            continue
+        for c in configs:
+            e = dict(os.environ, PETLION_HIP_LIB=lib(n))
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", c, "--no-cpu-baseline"], env=e, capture_output=True, text=True)
+            try:
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                rows.append(dict(set=n, config=c, value=d["value"], kernel_ms=d["roofline"]["kernel_ms_avg"]))
+            except Exception:
+                rows.append(dict(set=n, config=c, error=(r.stderr or r.stdout)[-300:]))
+            print(json.dumps(rows[-1]), flush=True)
+    return rows
+
+
+if __name__ == "__main__":
+    names = [a for a in sys.argv[2:] if a in SETS] or list(SETS)
+    if sys.argv[1] == "build":
+        build(names)
+    else:
+        rows = run(names, [a for a in sys.argv[2:] if a.startswith("C")] or ["C2", "C4", "C3"])
+        out = os.path.join(ROOT, "gpurun_out", "r05s"); os.makedirs(out, exist_ok=True)
+        json.dump(rows, open(os.path.join(out, "sched_search.json"), "w"), indent=1)

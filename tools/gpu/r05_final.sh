@@ -1,6 +1,6 @@
 #!/bin/bash
 # r05 final GPU call: known answers of the self-test from THIS binary, the whole GPU suite, smoke(), rocprofv3 profiles (kernel trace + PMC passes), bench lines C2..C5
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r05h; mkdir -p $O
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05k; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python tools/make_selftest_golden.py > $O/golden.txt 2>&1
 cp petlion.jl_amd/selftest_golden.json $O/ 2>/dev/null
@@ -25,3 +25,6 @@ import pkgload; print(pkgload.load().api.build_info())" > $O/build_info.txt 2>&1
 # keep the merge-back small: the raw rocprofv3 outputs stay on the box except the databases the summaries were made from
 du -sh gpurun_out/prof_r05_* 2>/dev/null | tail -4
 find gpurun_out/prof_r05_* -name "*.csv" -size +2M -delete 2>/dev/null
+# the miscompile reproducer (tools/experiments/miscompile_repro.py build ran before the snapshot)
+[ -f petlion.jl_amd/_exp/libplh_repro16_iter.so ] && timeout 600 python tools/experiments/miscompile_repro.py run > $O/miscompile_repro.txt 2>&1
+grep -v "amdgpu\|RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" $O/miscompile_repro.txt | cut -c1-400
