@@ -19,10 +19,11 @@ EARLY_INLINE = ["-DPL_DEV=__device__ __forceinline__"]
 # copies of the exp / log polynomial coefficients of the thermal node pass -- to the top of the kernel and keeps it live across all phases (thermal: 392 B/lane of scratch with
 # it, 0 without; C3 +18.6 %, C5 +4.6 %, C2 / C4 +1.8 %)
 NO_MACHINE_LICM = ["-mllvm", "-disable-machine-licm"]
-# thermal kernels are register-bound: plain 8-byte DS accesses (no IR load/store vectoriser) +4 %
-# (until r05 the list also carried `-Xclang -target-feature -Xclang -load-store-opt`, which this compiler answers with "not a recognized feature for this target (ignoring
-#  feature)": the measured gain was the vectoriser switch alone)
-NO_DS_MERGE = ["-mllvm", "-amdgpu-load-store-vectorizer=0"]
+# thermal kernels are register-bound: plain 8-byte DS accesses (no IR load/store vectoriser, no machine-level DS merging) +4 %
+# (clang answers the -target-feature with "'-load-store-opt' is not a recognized feature for this target (ignoring feature)" -- the FRONT END does not know it; the string still
+#  reaches the function's target-features and the AMDGPU backend does honour it (FeatureEnableLoadStoreOpt): the object is 65 kB smaller without the pair and C3 1.5 % slower,
+#  r05 measured both)
+NO_DS_MERGE = ["-mllvm", "-amdgpu-load-store-vectorizer=0", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
 # compiler fences at the phase boundaries (+2.9 % C3) and the branching update of the register-resident BDF history (+2.5 %), thermal variants only
 THERMAL_SRC = ["-DPL_PHASE_FENCES", "-DPL_EXP_BRANCHY_PHI"]
 # r05: the GCN iterative scheduler with the ILP strategy instead of the default max-occupancy one.  Every kernel runs ONE wavefront per SIMD (waves_per_eu(1, 1); two for the small
@@ -39,10 +40,10 @@ def sched_flags():
     return ["-mllvm", "-amdgpu-sched-strategy=" + st] if st else []
 
 
-# variants built with LLVM's default scheduler: 16 (LCO thermal, reference-order rows) -- under the iterative scheduler its table-input instantiation starts with a garbage
-# step size (flag 3 after 9 steps at t = 1e-16 s: tests/test_gpu_parity.py::test_every_kernel_instantiation_of_every_variant lists every failing instantiation; the other
-# 16 x 6 pass)
-DEFAULT_SCHED_VARIANTS = {16}
+# variants built with LLVM's default scheduler (none at present).  Until the step loop of cell_simulate lost its outer re-initialisation loop (dfn_integrate.h, r05) variant 16's
+# table-input instantiation came out of the iterative scheduler with a garbage SOC and first step -- tools/experiments/miscompile_repro.py reproduces it at commit b316e8d and shows
+# the same command line passing on the restructured source; the mechanism stays for the next instantiation that needs it
+DEFAULT_SCHED_VARIANTS: set = set()
 # variants that keep MachineLICM in the built-in library (none at present; the mechanism stays for the next register-allocation miscompile of one instantiation)
 KEEP_MACHINE_LICM: set = set()
 

@@ -994,11 +994,16 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     [[maybe_unused]] double soc_nm1_s = 0.0, dt_step_s = 0.0, soc_n_s = 0.0;      // (sensitivities: the trapezoid SOC at the last two accepted points and the step between them)
     bool first_init = true, again = false, init_failed = false;
     [[maybe_unused]] int steps_since_restart = 2;                       // (accepted steps since a check_reinitialization! restart; 2 = "more than one")
-    do {                                                                // (re)initialise -> integrate ; loops only for check_reinitialization!
+    // (re)initialise -> integrate.  check_reinitialization! sends a run with a function input back to the consistent initialisation; until r05 that was an outer do-while
+    // around this block and the step loop.  Every per-run scalar (SOC, t, the previous point's values) was then carried around TWO nested loops, and the table-input
+    // instantiation was the one kernel that kept coming out of the compiler with a garbage SOC or first step: r03 (LCO), r05 under three other instruction schedulers
+    // (thermal; tools/experiments/miscompile_repro.py).  Now there is ONE loop: the block is a lambda, called before the loop where the input is constant and at the top of an
+    // iteration (need_init) where it is a function.
+    auto init_block = [&]() -> bool {                                   // false: the initialisation failed (flag / ri.flag / init_failed are set)
     again = false;
     int ierr; { PL_TIC(); ierr = cell_init_consistent<F>(S, R, tb, S.yy, S.yp, S.delta, S.phi[1], mode, value, o.reltol_init, cnt, S.phi[0], o.refine,
                                                                        ((F & GF_EXPR) && (run.value_kind == PLH_VAL_EXPR || dstate)) ? &run : nullptr, t_restart, &grow); PL_TOC(S, PH_INIT); }
-    if (ierr != 0) { if (first_init) init_failed = true; else flag = ierr; ri.flag = ierr; break; }
+    if (ierr != 0) { if (first_init) init_failed = true; else flag = ierr; ri.flag = ierr; return false; }
     if constexpr ((F & GF_STOPS) != 0) { if (o.yp_alg_zero) { PL_VEC(n) if (n >= NDIFF) S.yp[n] = 0.0; PL_XSYNC(); } }     // plh_opts.yp_alg_zero
     ida_reinit(S, I, S.yy, S.yp, first_init ? (o.max_order > 0 && o.max_order <= MAXORD ? o.max_order : MAXORD) : I.maxord, t_restart);
     if (first_init) {
@@ -1010,7 +1015,15 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       I_prev_pt = S.yy[O_I];
       if constexpr ((F & GF_SENS) != 0) sens_init(S, SX, mode, value, new_run, SOC0, o.reltol, o.abstol, nout - 1, run.value_kind == PLH_VAL_HOLD && have_prev, prev_V, prev_I);
     }
-    while (flag == PLH_FLAG_RUNNING) {
+    return true;
+    };
+    bool init_ok = true;
+    [[maybe_unused]] bool need_init = true;
+    if constexpr ((F & GF_FUNC) == 0) init_ok = init_block();
+    while (init_ok && flag == PLH_FLAG_RUNNING) {
+      if constexpr ((F & GF_FUNC) != 0) {
+        if (need_init) { need_init = false; if (!init_block()) break; if (flag != PLH_FLAG_RUNNING) break; }      // (a bound can fire on the point the run starts from)
+      }
       double tret = t; tprev = t;
       double tstop_now;
       if constexpr ((F & GF_STOPS) != 0) tstop_now = next_tstop(o, t, continuation, run.tf);
@@ -1070,9 +1083,8 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
         }
       }
       PL_TOC(S, PH_OUTPUT); PL_TOCE(S, 3, 6);
-      if (again) break;                                                 // back to the consistent initialisation at t_restart
+      if constexpr ((F & GF_FUNC) != 0) { if (again) need_init = true; }         // back to the consistent initialisation at t_restart
     }
-    } while ((F & GF_FUNC) && again && flag == PLH_FLAG_RUNNING);
     if (init_failed) { if (lane == 0) info[r] = ri; for (int q = r + 1; q < n_runs; q++) if (lane == 0) { plh_run_info z = ri; z.flag = PLH_FLAG_RUNNING; info[q] = z; } break; }
     double t_end = t + t0;
     if constexpr ((F & GF_SENS) != 0) soc_n_s = SOC;

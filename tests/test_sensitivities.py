@@ -168,7 +168,15 @@ def test_sens_c3_protocol_on_gpu(hip_model_thermal, pkg):
     print("C3 CC-CT-CV with three sensitivities, 256 cells: finite in %d cells; corrector solves without convergence: %d; steps that factored their own matrix: %d of %d; kernel %.1f ms (plain %.1f ms)"
           % (int(np.isfinite(dY).all(axis=(1, 2)).sum()), int(st[:, 1].sum()), int(st[:, 2].sum()), int(ens.counters["n_steps"].sum()), ens.kernel_ms, ref.kernel_ms))
     # (the first GPU run of this test, before sens_step factored the step's own matrix when the integrator's stale one does not contract: 28 solves at the iteration cap)
-    assert np.array_equal(np.asarray(ens.Y), np.asarray(ref.Y)), "the states changed with sensitivities on"
+    # the states are those of the plain launch: every counter equal in every cell; bit for bit in (nearly) all of them -- the sensitivity instantiation is another compilation of the
+    # step loop and may contract a sum differently (the 8192-cell C4 test below: 23 cells at 1e-13 ... 1e-11)
+    Ye, Yr = np.asarray(ens.Y), np.asarray(ref.Y)
+    bad = np.nonzero((Ye != Yr).any(axis=1))[0]
+    worst = max([parity.state_rel_err(Ye[c], Yr[c]) for c in bad], default=0.0)
+    print("   cells whose end state differs in any bit from the plain launch's: %d of %d (worst %.1e)" % (len(bad), len(Ye), worst))
+    for fld in ("n_steps", "n_res", "n_jac", "n_newton", "n_errfail", "n_convfail"):
+        assert np.array_equal(ens.counters[fld], ref.counters[fld]), fld
+    assert len(bad) <= 0.05 * len(Ye) and worst < 1e-9, (len(bad), worst)
     assert np.isfinite(dY).all() and st[:, 1].sum() == 0
 
 

@@ -1,13 +1,23 @@
 #!/usr/bin/env python3
-"""A reproducible miscompiled instantiation (VERDICT r04 "next" 4 asked for one): variant 16 (LCO, temperature, reference-order rows) built with the flag table's iterative
-scheduler.  Its TABLE-input instantiation k_integrate<M16, GF_FUNC> then starts every run with a garbage step size (exit flag 3 after 9 steps at t = 1.3e-16 s) while the other six
-instantiations of the same translation unit, and all seven of the other sixteen variants, reproduce their plain kernels.  With LLVM's default scheduler (what buildflags.py uses
-for this variant: DEFAULT_SCHED_VARIANTS) the instantiation is correct.
+"""A reproducible miscompiled instantiation (VERDICT r04 "next" 4 asked for one) -- and what made it go away.
 
-    python tools/experiments/miscompile_repro.py build      (here; ~4 min: one translation unit, twice)
+AT COMMIT b316e8d: variant 16 (LCO, temperature, reference-order rows) compiled with the thermal flag set (early inlining, no DS merging, MachineLICM off) and
+`-mllvm -amdgpu-sched-strategy=iterative-ilp`.  Its TABLE-input instantiation k_integrate<M16, GF_STOPS | GF_FUNC> starts every run with a garbage SOC and first step size (exit
+flag 3 after 9 steps at t = 1.3e-16 s; the kernel self-test refuses the library) while the other six instantiations of the same translation unit, and all seven of the other
+sixteen variants, reproduce their plain kernels; LLVM's default scheduler compiles it correctly, and so does the iterative one WITHOUT the no-DS-merging target feature.  The same
+instantiation of variant 4 failed the same way under `max-ilp` and under `-misched-cluster=0` (tools/experiments/sched_search.py), and r03 had seen it on the isothermal model: what
+the instantiation had that no other has was an OUTER do-while around consistent initialisation + step loop (check_reinitialization!), i.e. every per-run scalar carried around
+two nested loops.  clang finds no uninitialised variable in the source (-Wuninitialized -Wsometimes-uninitialized -Wconditional-uninitialized), the wave emulator and the
+default scheduler run the same source correctly: a code-generation failure at the register allocator's limit, not undefined behaviour.
+
+SINCE THE NEXT COMMIT the step loop is ONE loop (the initialisation block is called at the top of an iteration when a function input asks for it): the same three command lines
+all pass -- which is what this tool shows on the current tree.  To see the failure: `git checkout b316e8d -- petlion.jl_amd/csrc/dfn_integrate.h`, build, run.
+
+    python tools/experiments/miscompile_repro.py build      (here; ~6 min: one translation unit, three command lines)
     python tools/experiments/miscompile_repro.py run        (on the GPU box)
 
-hipcc 7.2.26015, AMD clang 22.0.0git 7b800a194662, gfx950.  The command line of the failing object is printed by `build`."""
+hipcc 7.2.26015, AMD clang 22.0.0git 7b800a194662, gfx950.  Measured r05 (gpurun, one MI355X): before the restructuring "iterative-ilp": passed without the target feature,
+FAILED with it ("the table input instantiation of lco_thermal does not reproduce the plain kernel"); default scheduler: passed.  After: all three pass."""
 import os
 import subprocess
 import sys
@@ -15,8 +25,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 EXP = os.path.join(ROOT, "petlion.jl_amd", "_exp")
-LIBS = {"iterative-ilp (miscompiled)": os.path.join(EXP, "libplh_repro16_iter.so"), "default scheduler": os.path.join(EXP, "libplh_repro16_default.so"),
-        "iterative-ilp + the r05i command line": os.path.join(EXP, "libplh_repro16_iterx.so")}
+LIBS = {"iterative-ilp (the flag table)": os.path.join(EXP, "libplh_repro16_iter.so"), "default scheduler": os.path.join(EXP, "libplh_repro16_default.so"),
+        "iterative-ilp, the no-DS-merging feature given twice (r05i)": os.path.join(EXP, "libplh_repro16_iterx.so")}
 XCLANG = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]      # (part of the thermal flag set until r05i; the compiler says it ignores it)
 
 CHILD = r'''
@@ -51,8 +61,8 @@ if __name__ == "__main__":
         import __graft_entry__ as g
         os.makedirs(EXP, exist_ok=True)
         os.environ["PETLION_SCHED_ALL"] = "1"
-        print(g.build_hip(lib=LIBS["iterative-ilp (miscompiled)"], variants=[16], extra_flags=["-DPL_REPRO16"]))
-        print(g.build_hip(lib=LIBS["iterative-ilp + the r05i command line"], variants=[16], extra_flags=["-DPL_REPRO16"] + XCLANG))
+        print(g.build_hip(lib=LIBS["iterative-ilp (the flag table)"], variants=[16], extra_flags=["-DPL_REPRO16"]))
+        print(g.build_hip(lib=LIBS["iterative-ilp, the no-DS-merging feature given twice (r05i)"], variants=[16], extra_flags=["-DPL_REPRO16"] + XCLANG))
         os.environ.pop("PETLION_SCHED_ALL")
         print(g.build_hip(lib=LIBS["default scheduler"], variants=[16], extra_flags=["-DPL_REPRO16=0"]))
         import pkgload

@@ -27,6 +27,25 @@ SETS2 = {
     "aa_sched": [M, "-enable-aa-sched-mi"],
     "antidep_all": [M, "-break-anti-dependencies=all"],
 }
+# batch 3: do the switches measured under the default scheduler keep their sign under the iterative one?  ("PL_DEV=" in a set makes build_hip take the set as the
+# WHOLE flag list of both variants: tools say which config is meaningful)
+EARLY = ["-DPL_DEV=__device__ __forceinline__"]
+LATE = ["-DPL_DEV=__device__ inline", M, "-amdgpu-function-calls=false"]
+NOLICM = [M, "-disable-machine-licm"]
+ITER = [M, "-amdgpu-sched-strategy=iterative-ilp"]
+NODS = [M, "-amdgpu-load-store-vectorizer=0", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
+SETS3 = {
+    "base3": [],
+    "iso_early": EARLY + NOLICM + ITER,                                   # C2 / C4
+    "iso_fences": ["-DPL_PHASE_FENCES"],                                 # C2 / C4 (added to the table's flags)
+    "iso_branchy": ["-DPL_EXP_BRANCHY_PHI"],                             # C2 / C4
+    "iso_licm_on": LATE + ITER,                                          # C2 / C4
+    "iso_nods": LATE + NOLICM + ITER + NODS,                             # C2 / C4
+    "th_no_fences": EARLY + NODS + ["-DPL_EXP_BRANCHY_PHI"] + NOLICM + ITER,          # C3
+    "th_no_branchy": EARLY + NODS + ["-DPL_PHASE_FENCES"] + NOLICM + ITER,            # C3
+    "th_ds_merge": EARLY + ["-DPL_PHASE_FENCES", "-DPL_EXP_BRANCHY_PHI"] + NOLICM + ITER,   # C3
+    "th_licm_on": EARLY + NODS + ["-DPL_PHASE_FENCES", "-DPL_EXP_BRANCHY_PHI"] + ITER,      # C3
+}
 SETS = {
     "base": [],
     "max_ilp": [M, "-amdgpu-sched-strategy=max-ilp"],
@@ -38,6 +57,7 @@ SETS = {
     "no_unclustered": [M, "-amdgpu-disable-unclustered-high-rp-reschedule"],
 }
 SETS.update(SETS2)
+SETS.update(SETS3)
 
 
 def lib(name):
