@@ -11,8 +11,9 @@ from __future__ import annotations
 
 OPT = "-O3"
 # every device function is inlined into its kernel; WHEN differs:
-#   late  (isothermal / SEI kernels): functions are `inline`, the AMDGPU always-inline pass merges them after the function-level optimisations (0 B scratch)
-#   early (thermal kernels): functions are __forceinline__, merged before the optimisation pipeline -- the thermal kernels then no longer depend on the optimisation level
+#   late  (the conservative fall-back set of the isothermal / SEI kernels; their production set until r05): functions are `inline`, the AMDGPU always-inline pass merges them after the
+#         function-level optimisations
+#   early (every kernel since r05; thermal kernels since r04): functions are __forceinline__, merged before the optimisation pipeline -- the thermal kernels then no longer depend on the optimisation level
 LATE_INLINE = ["-mllvm", "-amdgpu-function-calls=false"]
 EARLY_INLINE = ["-DPL_DEV=__device__ __forceinline__"]
 # MachineLICM off (r04): the pre-RA loop-invariant code motion hoists whatever is invariant in the ONE step loop every device function is inlined into -- above all the register
@@ -53,12 +54,22 @@ def is_thermal(v):
     return grids.variant_table()[v][2] == "true"
 
 
+# r05, isothermal / SEI kernels under the iterative scheduler (tools/experiments/sched_search.py batches 4 / 5, variants 0 and 3, one box): early inlining + the backend's DS
+# merging off: C2 +3.6 %, C4 +3.1 %, C5 +5.0 % over late inlining (late + no DS merging +2.1 / +1.7 / +2.9 %; early + both vectoriser switches +2.1 / +2.4 / +3.1 %; the IR
+# vectoriser switch ALONE with late inlining: a variant-0 library that fails the kernel self-test).  The conservative set (machine_licm=True) keeps late inlining.
+NO_LSO = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
+ISO_FLAGS = EARLY_INLINE + NO_LSO
+# variant 8 (quadratic solid diffusion, two cells per SIMD): hipcc 7.2 segfaults in code generation with early inlining under the iterative scheduler -- it keeps the r05 late-inlining set
+ISO_LATE_VARIANTS = {8}
+
+
 def variant_flags(v, machine_licm=False, thermal=None, default_sched=False):
     """compile flags (after the common ones: arch, std, -fPIC, warnings, grid / namespace defines) of variant v's translation unit.
-    default_sched=True: LLVM's default scheduler instead of the iterative one -- what every builder retries ONE object with when hipcc dies on it (the iterative scheduler is
-    marked experimental upstream: it segfaults on the (2, 2, 2, 10) grid's isothermal kernel, r05) and what the self-test fall-back build (machine_licm=True) uses"""
+    default_sched=True: LLVM's default scheduler instead of the iterative one.  machine_licm=True is the CONSERVATIVE set -- late inlining for the isothermal kernels, MachineLICM
+    on, LLVM's default scheduler: what every builder retries ONE object with when hipcc dies on it (the iterative scheduler is marked experimental upstream: it segfaults on the
+    (2, 2, 2, 10) grid's isothermal kernel and on variant 8 with early inlining, r05) and what the self-test fall-back build uses"""
     th = is_thermal(v) if thermal is None else thermal
-    fl = (EARLY_INLINE + NO_DS_MERGE + THERMAL_SRC) if th else list(LATE_INLINE)
+    fl = (EARLY_INLINE + NO_DS_MERGE + THERMAL_SRC) if th else (list(LATE_INLINE) if (machine_licm or v in ISO_LATE_VARIANTS) else list(ISO_FLAGS))
     if not (machine_licm or v in KEEP_MACHINE_LICM):
         fl = fl + NO_MACHINE_LICM
     import os
@@ -68,4 +79,4 @@ def variant_flags(v, machine_licm=False, thermal=None, default_sched=False):
 
 def table_repr():
     """what enters the build-identity hash (plh_build_info): the whole table"""
-    return repr((OPT, LATE_INLINE, EARLY_INLINE, NO_MACHINE_LICM, NO_DS_MERGE, THERMAL_SRC, sched_flags(), sorted(DEFAULT_SCHED_VARIANTS), sorted(KEEP_MACHINE_LICM)))
+    return repr((OPT, LATE_INLINE, EARLY_INLINE, ISO_FLAGS, sorted(ISO_LATE_VARIANTS), NO_MACHINE_LICM, NO_DS_MERGE, THERMAL_SRC, sched_flags(), sorted(DEFAULT_SCHED_VARIANTS), sorted(KEEP_MACHINE_LICM)))

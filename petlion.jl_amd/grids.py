@@ -75,7 +75,7 @@ def defines(grid):
 
 
 def _sources_mtime():
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))] + [os.path.join(HERE, "..", "include", "petlion_hip.h")]
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))] + [os.path.join(HERE, "..", "include", "petlion_hip.h"), os.path.join(HERE, "buildflags.py")]
     return max(os.path.getmtime(f) for f in files)
 
 
@@ -126,8 +126,8 @@ def _library_locked(grid, variants, force, tag, defs, machine_licm=False, extra_
     for v, o, j in jobs:
         err = j.communicate()[1]
         if j.returncode:
-            # hipcc died on this instantiation (the iterative scheduler is experimental upstream): ONCE more with LLVM's default scheduler
-            if subprocess.call(common + buildflags.variant_flags(v, machine_licm=machine_licm, default_sched=True) + ["-DPL_VARIANT=%d" % v, "-c", src, "-o", o]):
+            # hipcc died on this instantiation (the iterative scheduler is experimental upstream): ONCE more with the conservative flag set (buildflags.variant_flags)
+            if subprocess.call(common + buildflags.variant_flags(v, machine_licm=True) + ["-DPL_VARIANT=%d" % v, "-c", src, "-o", o]):
                 sys.stderr.write(err.decode(errors="replace")[-4000:])
                 raise RuntimeError("hipcc failed building the kernels of discretisation %r" % (grid,))
             default_sched.append(v)
@@ -136,7 +136,7 @@ def _library_locked(grid, variants, force, tag, defs, machine_licm=False, extra_
     tmp = lib + ".tmp%d" % os.getpid()                      # (a forced rebuild replaces the file atomically: a process that has the old one mapped keeps its inode)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", glue] + objs + ["-o", tmp])
     os.replace(tmp, lib)
-    json.dump({"grid": list(grid), "variants": allv, "suffix": suffix, "machine_licm": bool(machine_licm), "extra_flags": list(extra_flags), "default_sched_variants": default_sched}, open(manifest, "w"))
+    json.dump({"grid": list(grid), "variants": allv, "suffix": suffix, "machine_licm": bool(machine_licm), "extra_flags": list(extra_flags), "fallback_variants": default_sched}, open(manifest, "w"))
     for o in objs + [glue]:
         os.remove(o)
     return lib

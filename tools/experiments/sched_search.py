@@ -46,6 +46,21 @@ SETS3 = {
     "th_ds_merge": EARLY + ["-DPL_PHASE_FENCES", "-DPL_EXP_BRANCHY_PHI"] + NOLICM + ITER,   # C3
     "th_licm_on": EARLY + NODS + ["-DPL_PHASE_FENCES", "-DPL_EXP_BRANCHY_PHI"] + ITER,      # C3
 }
+# batch 4: the isothermal candidates of batch 3 once more, with variant 3 (NMC + SEI: C5) in the library
+SETS4 = {
+    "base4": [],
+    "iso4_nods": LATE + NOLICM + ITER + NODS,
+    "iso4_early_nods": EARLY + NOLICM + ITER + NODS,
+    "iso4_nolsv": LATE + NOLICM + ITER + [M, "-amdgpu-load-store-vectorizer=0"],
+    "iso4_nolso": LATE + NOLICM + ITER + ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"],
+}
+NOLSO = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
+SETS4.update({
+    "iso5_early_nolso": EARLY + NOLICM + ITER + NOLSO,
+    "iso5_nolso_fences": LATE + NOLICM + ITER + NOLSO + ["-DPL_PHASE_FENCES"],
+    "iso5_nolso_branchy": LATE + NOLICM + ITER + NOLSO + ["-DPL_EXP_BRANCHY_PHI"],
+})
+VARIANTS = {n: [0, 3] for n in SETS4}
 SETS = {
     "base": [],
     "max_ilp": [M, "-amdgpu-sched-strategy=max-ilp"],
@@ -58,6 +73,7 @@ SETS = {
 }
 SETS.update(SETS2)
 SETS.update(SETS3)
+SETS.update(SETS4)
 
 
 def lib(name):
@@ -74,7 +90,7 @@ def build(names):
             os.environ.pop("PETLION_SCHED_STRATEGY", None)
             if st:
                 os.environ["PETLION_SCHED_STRATEGY"] = st[0]
-            print(n, g.build_hip(extra_flags=fl, lib=lib(n), variants=[0, 4]), flush=True)
+            print(n, g.build_hip(extra_flags=fl, lib=lib(n), variants=VARIANTS.get(n, [0, 4])), flush=True)
         except Exception as e:          # (a flag set the compiler rejects or dies on is a result too)
             print(n, "FAILED", repr(e)[:300], flush=True)
 
