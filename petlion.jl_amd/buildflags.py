@@ -20,11 +20,12 @@ EARLY_INLINE = ["-DPL_DEV=__device__ __forceinline__"]
 # copies of the exp / log polynomial coefficients of the thermal node pass -- to the top of the kernel and keeps it live across all phases (thermal: 392 B/lane of scratch with
 # it, 0 without; C3 +18.6 %, C5 +4.6 %, C2 / C4 +1.8 %)
 NO_MACHINE_LICM = ["-mllvm", "-disable-machine-licm"]
-# thermal kernels are register-bound: plain 8-byte DS accesses (no IR load/store vectoriser, no machine-level DS merging) +4 %
+# The backend's DS merging (SILoadStoreOptimizer) off, for every kernel: plain 8-byte DS accesses.  r04 had measured it together with the IR load/store vectoriser switch on the
+# thermal kernels (+4 %); r05 under the iterative scheduler, one switch at a time: thermal C3 +2.5 % with the backend switch ALONE over both (the vectoriser switch alone: -0.5 %),
+# isothermal see ISO_FLAGS below.
 # (clang answers the -target-feature with "'-load-store-opt' is not a recognized feature for this target (ignoring feature)" -- the FRONT END does not know it; the string still
-#  reaches the function's target-features and the AMDGPU backend does honour it (FeatureEnableLoadStoreOpt): the object is 65 kB smaller without the pair and C3 1.5 % slower,
-#  r05 measured both)
-NO_DS_MERGE = ["-mllvm", "-amdgpu-load-store-vectorizer=0", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
+#  reaches the function's target-features and the AMDGPU backend does honour it (FeatureEnableLoadStoreOpt): the objects differ by 65 kB)
+NO_LSO = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
 # compiler fences at the phase boundaries (+2.9 % C3) and the branching update of the register-resident BDF history (+2.5 %), thermal variants only
 THERMAL_SRC = ["-DPL_PHASE_FENCES", "-DPL_EXP_BRANCHY_PHI"]
 # r05: the GCN iterative scheduler with the ILP strategy instead of the default max-occupancy one.  Every kernel runs ONE wavefront per SIMD (waves_per_eu(1, 1); two for the small
@@ -57,7 +58,6 @@ def is_thermal(v):
 # r05, isothermal / SEI kernels under the iterative scheduler (tools/experiments/sched_search.py batches 4 / 5, variants 0 and 3, one box): early inlining + the backend's DS
 # merging off: C2 +3.6 %, C4 +3.1 %, C5 +5.0 % over late inlining (late + no DS merging +2.1 / +1.7 / +2.9 %; early + both vectoriser switches +2.1 / +2.4 / +3.1 %; the IR
 # vectoriser switch ALONE with late inlining: a variant-0 library that fails the kernel self-test).  The conservative set (machine_licm=True) keeps late inlining.
-NO_LSO = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
 ISO_FLAGS = EARLY_INLINE + NO_LSO
 # variant 8 (quadratic solid diffusion, two cells per SIMD): hipcc 7.2 segfaults in code generation with early inlining under the iterative scheduler -- it keeps the r05 late-inlining set
 ISO_LATE_VARIANTS = {8}
@@ -69,7 +69,7 @@ def variant_flags(v, machine_licm=False, thermal=None, default_sched=False):
     on, LLVM's default scheduler: what every builder retries ONE object with when hipcc dies on it (the iterative scheduler is marked experimental upstream: it segfaults on the
     (2, 2, 2, 10) grid's isothermal kernel and on variant 8 with early inlining, r05) and what the self-test fall-back build uses"""
     th = is_thermal(v) if thermal is None else thermal
-    fl = (EARLY_INLINE + NO_DS_MERGE + THERMAL_SRC) if th else (list(LATE_INLINE) if (machine_licm or v in ISO_LATE_VARIANTS) else list(ISO_FLAGS))
+    fl = (EARLY_INLINE + NO_LSO + THERMAL_SRC) if th else (list(LATE_INLINE) if (machine_licm or v in ISO_LATE_VARIANTS) else list(ISO_FLAGS))
     if not (machine_licm or v in KEEP_MACHINE_LICM):
         fl = fl + NO_MACHINE_LICM
     import os
@@ -79,4 +79,4 @@ def variant_flags(v, machine_licm=False, thermal=None, default_sched=False):
 
 def table_repr():
     """what enters the build-identity hash (plh_build_info): the whole table"""
-    return repr((OPT, LATE_INLINE, EARLY_INLINE, ISO_FLAGS, sorted(ISO_LATE_VARIANTS), NO_MACHINE_LICM, NO_DS_MERGE, THERMAL_SRC, sched_flags(), sorted(DEFAULT_SCHED_VARIANTS), sorted(KEEP_MACHINE_LICM)))
+    return repr((OPT, LATE_INLINE, EARLY_INLINE, ISO_FLAGS, sorted(ISO_LATE_VARIANTS), NO_MACHINE_LICM, NO_LSO, THERMAL_SRC, sched_flags(), sorted(DEFAULT_SCHED_VARIANTS), sorted(KEEP_MACHINE_LICM)))

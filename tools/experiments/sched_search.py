@@ -61,6 +61,15 @@ SETS4.update({
     "iso5_nolso_branchy": LATE + NOLICM + ITER + NOLSO + ["-DPL_EXP_BRANCHY_PHI"],
 })
 VARIANTS = {n: [0, 3] for n in SETS4}
+# batch 6: the thermal set with one of the two DS-merging switches at a time
+TH = ["-DPL_PHASE_FENCES", "-DPL_EXP_BRANCHY_PHI"]
+SETS6 = {
+    "base6": [],
+    "th6_nolso_only": EARLY + NOLSO + TH + NOLICM + ITER,
+    "th6_nolsv_only": EARLY + [M, "-amdgpu-load-store-vectorizer=0"] + TH + NOLICM + ITER,
+}
+SETS4.update(SETS6)
+VARIANTS.update({n: [4] for n in SETS6})
 SETS = {
     "base": [],
     "max_ilp": [M, "-amdgpu-sched-strategy=max-ilp"],

@@ -1,6 +1,6 @@
 #!/bin/bash
 # r05 final GPU call: known answers of the self-test from THIS binary, the whole GPU suite, smoke(), rocprofv3 profiles (kernel trace + PMC passes), bench lines C2..C5
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r05u; mkdir -p $O
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05v; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python tools/make_selftest_golden.py > $O/golden.txt 2>&1
 cp petlion.jl_amd/selftest_golden.json $O/ 2>/dev/null
