@@ -68,6 +68,15 @@ SETS6 = {
     "th6_nolso_only": EARLY + NOLSO + TH + NOLICM + ITER,
     "th6_nolsv_only": EARLY + [M, "-amdgpu-load-store-vectorizer=0"] + TH + NOLICM + ITER,
 }
+# batch 7: the thermal kernels' source switches on the isothermal ones, now that both share early inlining
+SETS7 = {
+    "base7": [],
+    "iso7_fences": EARLY + NOLSO + NOLICM + ITER + ["-DPL_PHASE_FENCES"],
+    "iso7_branchy": EARLY + NOLSO + NOLICM + ITER + ["-DPL_EXP_BRANCHY_PHI"],
+    "iso7_both": EARLY + NOLSO + NOLICM + ITER + TH,
+}
+SETS4.update(SETS7)
+VARIANTS.update({n: [0, 3] for n in SETS7})
 SETS4.update(SETS6)
 VARIANTS.update({n: [4] for n in SETS6})
 SETS = {
