@@ -77,6 +77,9 @@ SETS7 = {
 }
 SETS4.update(SETS7)
 VARIANTS.update({n: [0, 3] for n in SETS7})
+# batch 8: two switches of the r02 search (tools/flag_search.sh) again, on top of the final table
+SETS8 = {"base8": [], "t8_noslp": ["-fno-slp-vectorize"], "t8_ifcvt": [M, "-amdgpu-early-ifcvt=1"]}
+SETS4.update(SETS8)
 SETS4.update(SETS6)
 VARIANTS.update({n: [4] for n in SETS6})
 SETS = {
