@@ -142,10 +142,21 @@ template <int CHEM_, bool SEI_, bool THERMAL_ = false, int PREC_ = 0, int SD_ = 
   static constexpr int NDIFF = O_Q + (SD_ == 2 ? NJ : 0);
   static constexpr int O_J = NDIFF, O_PE = O_J + NJ, O_PS = O_PE + NE, O_JS = O_PS + NJ, O_I = SEI_ ? O_JS + NN : O_PS + NJ;
   static constexpr int NST = O_I + 1, NALG = NST - NDIFF;
-  static constexpr int NPAD = NST + (NST & 1);
   // trips of a lane through a state vector: one wave strides the whole vector; with two waves, wave 1 strides the NCS particle entries (4 trips), wave 0 the
   // other NST - NCS entries (2 trips) -- see vrow / vok
   static constexpr int NTRIP = W2_ ? (NCS + WAVE - 1) / WAVE : (NST + WAVE - 1) / WAVE;
+  // r06: the LDS state vectors of the isothermal models without aging are padded to whole trips (301 -> 320 entries) and the padding is kept at ZERO (cell_setup
+  // clears it once; every vector operation maps 0 to 0; residual / solve / global loads only touch the real entries), so that the lane-strided vector phases run WITHOUT a
+  // lane mask: the predicated last trip (lanes < 45) put an exec-mask save / branch / restore around its share of every vector statement and split each phase into
+  // basic blocks whose LDS loads could not be issued together.  +1.3 kB of LDS per cell (38.8 of the 40.96 kB that four cells per CU allow); the SEI models (322 states:
+  // 62 more entries x 9 vectors) and the thermal ones (at 40.95 kB) do not have the room and keep the mask.  -DPL_NO_VPAD: the r05 layout (A/B builds).
+#ifdef PL_NO_VPAD
+  static constexpr bool VPAD = false;
+#else
+  static constexpr bool VPAD = !SEI_ && !THERMAL_ && W2_ == 0 && !PHI_GLOBAL && NTRIP * WAVE - NST <= 24;
+#endif
+  static constexpr int NPADG = NST + (NST & 1);             // stride of the state-sized vectors kept in GLOBAL memory (sensitivity histories, PHI_GLOBAL block)
+  static constexpr int NPAD = VPAD ? NTRIP * WAVE : NPADG;  // length of the LDS state vectors
 };
 using ModelLcoIso = ModelT<PLH_CHEM_LCO_LIC6, false>;
 #define PL_MODEL(M) [[maybe_unused]] constexpr int O_J = M::O_J, O_PE = M::O_PE, O_PS = M::O_PS, O_I = M::O_I, NST = M::NST, NDIFF = M::NDIFF, NTRIP = M::NTRIP, \
@@ -372,9 +383,14 @@ template <class M> __device__ __forceinline__ int vrow(int k, int lane, int wv) 
   if constexpr (!M::W2) return lane + WAVE * k;
   else { const int m = lane + WAVE * k; return wv ? O_CS + m : (m < O_CS ? m : m + M::NCS); }
 }
-template <class M> __device__ __forceinline__ bool vok(int k, int lane, int wv) {
+// vokg: trip k of this lane is a real entry (what every access to a vector in GLOBAL memory must test); vok: the same for the LDS vectors -- always true with M::VPAD
+template <class M> __device__ __forceinline__ bool vokg(int k, int lane, int wv) {
   if constexpr (!M::W2) return k < M::NST / WAVE || lane + WAVE * k < M::NST;
   else return lane + WAVE * k < (wv ? M::NCS : M::NST - M::NCS);
+}
+template <class M> __device__ __forceinline__ bool vok(int k, int lane, int wv) {
+  if constexpr (M::VPAD) return true;
+  else return vokg<M>(k, lane, wv);
 }
 
 // Emulator only: with PL_EMU_POISON=1 in the environment the LDS block starts as garbage (on the GPU it holds whatever the previous workgroup
@@ -493,6 +509,59 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 #endif
 
+// ---- reciprocal, quotient and square root without the IEEE corner-case scaffolding (r06) ----
+// hipcc lowers an fp64 division to v_div_scale x2 / v_rcp_f64 / 5 fma / v_mul / v_div_fmas / v_div_fixup: 11 dependent VALU instructions of which four only serve operands
+// outside the normal range, and `sqrt` to 16 (ldexp scaling, class test, selects).  Every operand of the step loop is a physical quantity well inside the normal range, and a
+// single wavefront per SIMD pays every instruction of the chain in full (r05 PMC: 12 % of the VALU instructions of a step were division scaffolding).
+//   pl_rcp(x):  v_rcp_f64 (about 23 bits) + two Newton steps: 5 instructions, error below 1 ulp (not correctly rounded)
+//   pl_div(a, b): a * pl_rcp(b) + one residual correction: 8 instructions, correctly rounded except in rare half-ulp ties
+//   pl_sqrt(x): v_rsq_f64 + Goldschmidt / Newton as the compiler's own lowering, x > 0 normal (x = 0 -> 0 through one select)
+// x = 0 / inf / NaN give NaN or inf as they come; the callers either cannot see them or treat a NaN as a failed iteration (ida_nls).  The results differ from the IEEE quotient
+// by at most one rounding: far below the 1e-12 residual parity bar (tests/parity.py).  -DPL_IEEE_DIV restores the compiler's division everywhere (same-box A/B builds).
+#if defined(PL_WAVE_EMU) || defined(PL_IEEE_DIV)
+__device__ __forceinline__ double pl_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ double pl_div(double a, double b) { return a / b; }
+__device__ __forceinline__ double pl_sqrt(double x) { return sqrt(x); }
+#else
+__device__ __forceinline__ double pl_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double pl_div(double a, double b) {
+  const double r = pl_rcp(b);
+  const double q = a * r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double pl_sqrt(double x) {
+  const double xs = x > 0.0 ? x : 1.0;
+  const double y = __builtin_amdgcn_rsq(xs);
+  double g = xs * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, xs), h, g);
+  g = __builtin_fma(__builtin_fma(-g, g, xs), h, g);
+  return x > 0.0 ? g : x;          // (0 -> 0, NaN -> NaN, negative: the argument as it came -- the callers clamp first)
+}
+#endif
+// s = sqrt(x) and rs = 1 / sqrt(x) from ONE v_rsq_f64 (x > 0 and normal: the caller clamps): the Goldschmidt pair (g, h) -> (sqrt x, 1 / (2 sqrt x)) carries both
+#if defined(PL_WAVE_EMU) || defined(PL_IEEE_DIV)
+__device__ __forceinline__ void pl_sqrt_rsqrt(double x, double& s, double& rs) { s = sqrt(x); rs = 1.0 / s; }
+#else
+__device__ __forceinline__ void pl_sqrt_rsqrt(double x, double& s, double& rs) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  r = __builtin_fma(-h, g, 0.5);
+  h = __builtin_fma(h, r, h);
+  s = g; rs = h + h;
+}
+#endif
+
 // a value the compiler must materialise: a product passed through it is ROUNDED before it enters a sum (no fma contraction) -- the reference's operation order of the
 // PLH_PREC_F64_REFORDER variants (Julia does not contract a*b + c; neither does the oracle's gcc build for x86-64)
 #ifdef PL_WAVE_EMU
@@ -559,30 +628,36 @@ __device__ __forceinline__ void ocv_lco(double x, double T, int iso_ref, double&
   const double Q = -1 + 18.933 * x2 - 79.532 * x4 + 37.311 * x6 - 73.083 * x8 + 95.96 * x10;
   const double dP = x * (2 * 88.669 - 4 * 401.119 * x2 + 6 * 342.909 * x4 - 8 * 462.471 * x6 + 10 * 433.434 * x8);
   const double dQ = x * (2 * 18.933 - 4 * 79.532 * x2 + 6 * 37.311 * x4 - 8 * 73.083 * x6 + 10 * 95.96 * x8);
-  U = P / Q;
-  dUdx = (dP * Q - P * dQ) / (Q * Q);
+  const double rQ = pl_rcp(Q);                       // one reciprocal for the value and the derivative: U = P / Q, dU/dx = (P' - U Q') / Q
+  U = P * rQ;
+  dUdx = (dP - U * dQ) * rQ;
   if (!iso_ref) {
     const double x3 = x2 * x;
     const double n = 0.199521039 - 0.928373822 * x + 1.364550689000003 * x2 - 0.6115448939999998 * x3;
     const double d = 1 - 5.661479886999997 * x + 11.47636191 * x2 - 9.82431213599998 * x3 + 3.048755063 * x4;
     const double dn = -0.928373822 + 2 * 1.364550689000003 * x - 3 * 0.6115448939999998 * x2;
     const double dd = -5.661479886999997 + 2 * 11.47636191 * x - 3 * 9.82431213599998 * x2 + 4 * 3.048755063 * x3;
-    U += -0.001 * n / d * (T - TREF);
-    dUdx += -0.001 * (dn * d - n * dd) / (d * d) * (T - TREF);
+    const double rd = pl_rcp(d), nd = n * rd;
+    U += -0.001 * nd * (T - TREF);
+    dUdx += -0.001 * (dn - nd * dd) * rd * (T - TREF);
   }
 }
 
 // OCV_LiC6, custom_functions.jl:139-152
 __device__ __forceinline__ void ocv_lic6(double x, double T, int iso_ref, double& U, double& dUdx) {
-  const double s0 = sqrt(x > 0.0 ? x : 0.0);
-  const double xm = x > 1e-4 ? x : 1e-4;
-  const double s1 = sqrt(xm);
+  // one reciprocal (1 / x) and one reciprocal square root (of max(x, 1e-4)) serve the five quotients and two roots of the reference's expression; below x = 1e-4 --
+  // an anode emptied to a ten-thousandth of its capacity -- sqrt(x) and its reciprocal take the slow path
+  const bool big = x > 1e-4;
+  const double xm = big ? x : 1e-4;
+  double s1, rs1; pl_sqrt_rsqrt(xm, s1, rs1);
+  double s0 = s1, rs0 = rs1;
+  if (!big) { s0 = sqrt(x > 0.0 ? x : 0.0); rs0 = 1.0 / s0; }
+  const double rx = pl_rcp(x), rx2 = rx * rx;
   const double e1 = exp(0.9 - 15 * x), e2 = exp(0.4465 * x - 0.4108);
-  U = 0.7222 + 0.1387 * x + 0.029 * s0 - 0.0172 / x + 0.0019 / (s1 * x) + 0.2808 * e1 - 0.7984 * e2;
-  double d = 0.1387 + 0.0172 / (x * x) - 0.2808 * 15 * e1 - 0.7984 * 0.4465 * e2;
-  if (x > 0.0) d += 0.029 * 0.5 / s0;
-  if (x > 1e-4) d += 0.0019 * (-1.5) / (x * x * s1);
-  else d += -0.0019 / (s1 * x * x);
+  U = 0.7222 + 0.1387 * x + 0.029 * s0 - 0.0172 * rx + 0.0019 * (rs1 * rx) + 0.2808 * e1 - 0.7984 * e2;
+  double d = 0.1387 + 0.0172 * rx2 - 0.2808 * 15 * e1 - 0.7984 * 0.4465 * e2;
+  if (x > 0.0) d += 0.029 * 0.5 * rs0;
+  d += (big ? 0.0019 * (-1.5) : -0.0019) * (rx2 * rs1);
   dUdx = d;
   if (!iso_ref) {
     const double x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x, x6 = x3 * x3, x7 = x6 * x, x8 = x4 * x4;
@@ -590,8 +665,9 @@ __device__ __forceinline__ void ocv_lic6(double x, double T, int iso_ref, double
     const double q = 1 - 48.09287227 * x + 1017.234804 * x2 - 10481.80419 * x3 + 59431.3 * x4 - 195881.6488 * x5 + 374577.3152 * x6 - 385821.1607 * x7 + 165705.8597 * x8;
     const double dn = 0.001 * (3.299265709 - 2 * 91.79325798 * x + 3 * 1004.911008 * x2 - 4 * 5812.278127 * x3 + 5 * 19329.7549 * x4 - 6 * 37147.8947 * x5 + 7 * 38379.18127 * x6 - 8 * 16515.05308 * x7);
     const double dq = -48.09287227 + 2 * 1017.234804 * x - 3 * 10481.80419 * x2 + 4 * 59431.3 * x3 - 5 * 195881.6488 * x4 + 6 * 374577.3152 * x5 - 7 * 385821.1607 * x6 + 8 * 165705.8597 * x7;
-    U += n / q * (T - TREF);
-    dUdx += (dn * q - n * dq) / (q * q) * (T - TREF);
+    const double rq = pl_rcp(q), nq = n * rq;
+    U += nq * (T - TREF);
+    dUdx += (dn - nq * dq) * rq * (T - TREF);
   }
 }
 
@@ -605,15 +681,16 @@ __device__ __forceinline__ void ocv_lic6_nmc(double x, double& U, double& dUdx) 
   const double e1 = exp(-61.79 * x), e2 = exp(-665.8 * x), e3 = exp(39.42 * x - 41.92);
   const double a1 = 25.59 * x - 4.099, a2 = 32.49 * x - 15.74;
   U = 0.1493 + 0.8493 * e1 + 0.3824 * e2 - e3 - 0.03131 * atan(a1) - 0.009434 * atan(a2);
-  dUdx = -61.79 * 0.8493 * e1 - 665.8 * 0.3824 * e2 - 39.42 * e3 - 0.03131 * 25.59 / (1.0 + a1 * a1) - 0.009434 * 32.49 / (1.0 + a2 * a2);
+  dUdx = -61.79 * 0.8493 * e1 - 665.8 * 0.3824 * e2 - 39.42 * e3 - 0.03131 * 25.59 * pl_rcp(1.0 + a1 * a1) - 0.009434 * 32.49 * pl_rcp(1.0 + a2 * a2);
 }
 // D_eff(c_e, T), custom_functions.jl:83 (NMC system default, params.jl:407): 1e-4 * 10^(-4.43 - 54/(T - 229 - 5e-3 c) - 0.22e-3 c)
 __device__ __forceinline__ void deff_nmc(double c, double T, double& D, double& dD) {
   const double LN10 = 2.302585092994046;
   const double u = T - 229 - 5e-3 * c;
-  const double ex = -4.43 - 54.0 / u - 0.22e-3 * c;
+  const double ru = pl_rcp(u);
+  const double ex = -4.43 - 54.0 * ru - 0.22e-3 * c;
   D = 1e-4 * exp(LN10 * ex);
-  dD = D * LN10 * (-54.0 * 5e-3 / (u * u) - 0.22e-3);
+  dD = D * LN10 * (-54.0 * 5e-3 * (ru * ru) - 0.22e-3);
 }
 
 // LGM50 closures (reference src/params.jl:563-572, 627-636, 646, 660; dU/dT = 0)
@@ -642,7 +719,7 @@ PL_DEV void keff_lgm50(double c, double& K, double& dK) {
 //   u = e^x - 1 ;  sinh x = (u + u/(u+1))/2 ,  cosh x = sinh x + 1/(u+1)   -- accurate for small |x| as well (no cancellation)
 __device__ __forceinline__ void sinh_cosh(double x, double& sh, double& ch) {
   const double u = expm1(x);
-  const double r = 1.0 / (u + 1.0);
+  const double r = pl_rcp(u + 1.0);
   sh = 0.5 * (u + u * r);
   ch = sh + r;
 }
@@ -775,6 +852,12 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     } }
     } }
   for (int k = 0; k < CS_PASS; k++) { R.wreg[k] = 0.0; R.rcp[k] = 0.0; }
+  // the LDS state vectors start at zero, padding included: the padding of M::VPAD must be (and then stays) zero, and the branch-free history sums of the integrator multiply
+  // the orders that are not in use by 0.0 -- which must not meet the NaN a previous workgroup may have left behind
+  for (int k = (int)threadIdx.x; k < M::NPAD; k += WAVE * M::NWAVES) {
+    for (int j = 0; j < M::PHI_LDS; j++) S.phi[j][k] = 0.0;
+    S.yy[k] = 0.0; S.yp[k] = 0.0; S.delta[k] = 0.0;
+  }
   }
   PL_XSYNC();
   if constexpr (M::THERMAL) thermal_setup<M, INIT>(S, tb, th);
@@ -869,12 +952,12 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   if (i == NP - 1) { beta = c.beta_ps; rdist = c.rd_ps; }
   if (i == NP + NS - 1) { beta = c.beta_sn; rdist = c.rd_sn; }
   const bool edge = i < NE - 1;
-  const double rdenK = 1.0 / (beta * K_n + (1 - beta) * K), Kh = K * K_n * rdenK;
+  const double rdenK = pl_rcp(beta * K_n + (1 - beta) * K), Kh = K * K_n * rdenK;
   double rdenD = 0.0, Dh;
   if (M::CHEM == PLH_CHEM_LCO_LIC6) Dh = (i == NP - 1) ? c.Dh_ps : ((i == NP + NS - 1) ? c.Dh_sn : D);   // constant D: no division
-  else { rdenD = 1.0 / (beta * D_n + (1 - beta) * D); Dh = D * D_n * rdenD; }
+  else { rdenD = pl_rcp(beta * D_n + (1 - beta) * D); Dh = D * D_n * rdenD; }
   const double denC = beta * ce_n + (1 - beta) * ce;
-  const double rcb = denC / (ce * ce_n);                   // 1 / (harmonic mean of c_e at the edge)
+  const double rcb = denC * pl_rcp(ce * ce_n);             // 1 / (harmonic mean of c_e at the edge)
   const double Tb = cT0;                                   // harmonic mean of equal temperatures
   const double dc = (ce_n - ce) * rdist;
   const double w = Kh * rdist;
@@ -913,7 +996,9 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   const double jt = jv + js;                             // j_total (aux...jl:160-178) drives the c_e / Phi_e / Phi_s sources
   const double eta = (M::SEI && sc == 2) ? ps - pe - U - FAR * jv * Rfilm : ps - pe - U;
   const double arg = ce * cs * (cmax - cs);
-  const double sq = sqrt(arg > 0.0 ? arg : 0.0);
+  double sq, inv_sq;                                     // sqrt(arg) and its reciprocal (Jacobian partials) from one v_rsq_f64; both 0 where the reference's sqrt_ReLU clamps
+  pl_sqrt_rsqrt(arg > 0.0 ? arg : 1.0, sq, inv_sq);
+  if (!(arg > 0.0)) { sq = 0.0; inv_sq = 0.0; }
   const double xx = cfRT * eta;
   double sh = 0.0, chh = 0.0;
   // reaction rate j_calc and its partials with respect to (c_e, c_s*, eta): Butler-Volmer (rxn_BV) or Marcus-Hush-Chidsey (rxn_MHC, custom_functions.jl:241-298)
@@ -999,7 +1084,7 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
     if (lane == 0) { S.ctrlJ[0] = yI * cI1C; S.ctrlJ[1] = (Y[O_PS] - Y[O_PS + NJ - 1]) * cI1C; }   // scalar_jacobian! of method_P
     // edge derivatives
     const double dKh_a = dK * beta * K_n * K_n * (rdenK * rdenK), dKh_b = dK_n * (1 - beta) * K * K * (rdenK * rdenK);
-    const double rdenC = 1.0 / denC;
+    const double rdenC = pl_rcp(denC);
     const double dcb_a = beta * ce_n * ce_n * (rdenC * rdenC), dcb_b = (1 - beta) * ce * ce * (rdenC * rdenC);
     const double Tq = Tb * rdist;
     const double dg_a = Tq * (dKh_a * (ce_n - ce) * rcb - Kh * rcb - Kh * (ce_n - ce) * dcb_a * (rcb * rcb));
@@ -1032,8 +1117,6 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
       }
       if (elec) {
         const double ch = chh;
-        const double pos = arg > 0.0 ? 1.0 : 0.0;
-        const double inv_sq = pos > 0 ? 1.0 / sq : 0.0;
         if constexpr (M::RXN == 0) {
           S.gce[jx] = kk * sh * cs * (cmax - cs) * inv_sq;
           S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * ch * cfRT * (-dU * rcm));
@@ -1768,7 +1851,7 @@ PL_DEV void gen_solve(CellLDS<M>& S, LaneRegs& R, double* b, bool alg_only, cons
   PL_XSYNC();
   const double xI = (rho - g.dot(b, alg_only ? NDIFF : 0)) / g.bord;
   PL_XSYNC();
-  _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) b[n] += xI * g.W[n];
+  _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vokg<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) b[n] += xI * g.W[n];
   PL_XSYNC();
 }
 
@@ -1789,7 +1872,7 @@ PL_DEV void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restr
   const double cj = alg_only ? 0.0 : cjf;
   double xr[NTRIP];
   const int wv = wave_id();
-  _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv)) bsave[n] = b[n];
+  _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vokg<M>(k__, lane, wv)) bsave[n] = b[n];
   PL_XSYNC();
   for (int it = 0; it <= nref; it++) {
     if (it > 0) {
@@ -1799,7 +1882,7 @@ PL_DEV void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restr
       _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) {
         const int n = vrow<M>(k__, lane, wv);
         xr[k__] = 0.0; rr[k__] = 0.0;
-        if (vok<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) {
+        if (vokg<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) {
           xr[k__] = b[n];
           double s = 0.0;
           for (int k = ptr[n]; k < ptr[n + 1]; k++) { const int c = col[k]; if (!alg_only || c >= NDIFF) s += jac_entry<true>(S, tb, code[k], cj) * b[c]; }
@@ -1808,12 +1891,12 @@ PL_DEV void cell_solve_refined(CellLDS<M>& S, LaneRegs& R, const Tables* __restr
         }
       }
       PL_XSYNC();
-      _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) b[n] = rr[k__];
+      _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vokg<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) b[n] = rr[k__];
       PL_XSYNC();
     }
     if (g) gen_solve(S, R, b, alg_only, *g); else cell_solve(S, R, b, mode, alg_only);
     if (it > 0) {
-      _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) b[n] += xr[k__];
+      _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vokg<M>(k__, lane, wv) && (!alg_only || n >= NDIFF)) b[n] += xr[k__];
       PL_SYNC();
     }
   }

@@ -48,8 +48,8 @@ __device__ __forceinline__ void cnt_add(Counters& c, int k, int v = 1) { c.v[k] 
 // lane-strided sweep over the N state entries: exactly 5 trips (301 = 4*64 + 45), fully unrolled so that the LDS loads of all
 // trips are issued back to back (one latency instead of five); only the last trip is predicated.
 // BDF history access inside a PL_VEC loop (k__ = compile-time trip index): vectors j < M::PHI_LDS are LDS arrays, the rest registers in I.ph
-#define PHI_RD(j, n) (M::PHI_GLOBAL ? ((j) < M::PHI_LDS ? S.phi[(j) < M::PHI_LDS ? (j) : 0][n] : I.phg[((j) - M::PHI_LDS) * M::NPAD + (n)]) : PHI_RD_R(j, n))
-#define PHI_WR(j, n, v) do { if constexpr (M::PHI_GLOBAL) { if ((j) < M::PHI_LDS) S.phi[(j) < M::PHI_LDS ? (j) : 0][n] = (v); else I.phg[((j) - M::PHI_LDS) * M::NPAD + (n)] = (v); } else PHI_WR_R(j, n, v); } while (0)
+#define PHI_RD(j, n) (M::PHI_GLOBAL ? ((j) < M::PHI_LDS ? S.phi[(j) < M::PHI_LDS ? (j) : 0][n] : I.phg[((j) - M::PHI_LDS) * M::NPADG + (n)]) : PHI_RD_R(j, n))
+#define PHI_WR(j, n, v) do { if constexpr (M::PHI_GLOBAL) { if ((j) < M::PHI_LDS) S.phi[(j) < M::PHI_LDS ? (j) : 0][n] = (v); else I.phg[((j) - M::PHI_LDS) * M::NPADG + (n)] = (v); } else PHI_WR_R(j, n, v); } while (0)
 #define PHI_RD_R(j, n) ((M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? S.phi[(M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? (j) : 0][n] : ((j) == M::PHI_LDS ? I.ph[0][k__] : ((j) == M::PHI_LDS + 1 ? I.ph[1][k__] : ((j) == M::PHI_LDS + 2 ? I.ph[2][k__] : I.ph[3][k__]))))
 #define PHI_WR_R(j, n, v) do { if (M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) S.phi[(M::PHI_LDS > MAXORD || (j) < M::PHI_LDS) ? (j) : 0][n] = (v); \
                              else if ((j) == M::PHI_LDS) I.ph[0][k__] = (v); else if ((j) == M::PHI_LDS + 1) I.ph[1][k__] = (v); \
@@ -63,7 +63,20 @@ constexpr bool PL_BRANCHY_PHI = true;
 #else
 constexpr bool PL_BRANCHY_PHI = false;
 #endif
+// r06: the step-control passes over the BDF history of the models that keep the WHOLE history in LDS are written without control flow around the LDS accesses: orders 1 .. 3 are
+// always processed with wave-uniform 0 / 1 factors (p * 1.0, fma(0.0, p, a), fma(1.0, p, a) are exact: the sums are those of the branching form bit for bit -- the device of the
+// register-resident orders of the thermal model, r03), orders 4 and 5 under ONE wave-uniform branch, every load of a pass is issued before its arithmetic and the stores follow
+// at the end.  r05's form had a branch per order (and, inside the error test, per trip): each arm waited for its own LDS round trip, and with one wavefront per SIMD nothing
+// hides that -- the phase timers charged 2.2 k cycles per Newton iteration to the iterate / norm passes and 3.6 k per step to IDACompleteStep.  Cells are zero-initialised
+// (cell_setup) so that an order that has never been written is finite.  -DPL_NO_FLAT: the r05 form (A/B builds).
+#ifdef PL_NO_FLAT
+template <class M> constexpr bool PL_FLAT = false;
+#else
+template <class M> constexpr bool PL_FLAT = M::PHI_LDS > MAXORD && !M::PHI_GLOBAL && !M::W2;
+#endif
 #define PL_VEC(n) _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wave_id()); vok<M>(k__, lane, wave_id()))
+// the same for statements that touch a vector in GLOBAL memory (NST entries: no padding there): always masked
+#define PL_VECG(n) _Pragma("unroll") for (int k__ = 0; k__ < NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wave_id()); vokg<M>(k__, lane, wave_id()))
 
 template <class M>
 __device__ __forceinline__ double wrms(const double* v, const double* w) {
@@ -204,7 +217,7 @@ PL_DEV void gen_factor(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double cj, 
   PL_XSYNC();
   cell_solve(S, R, tmp, PLH_MODE_I, alg_only);
   PL_XSYNC();
-  PL_VEC(n) g.W[n] = tmp[n];
+  PL_VECG(n) g.W[n] = tmp[n];
   g.bord = g.dot(tmp, alg_only ? NDIFF : 0);
   PL_XSYNC();
 }
@@ -327,7 +340,7 @@ template <class M>
 PL_DEV void set_ewt(CellLDS<M>& S, IdaScalars& I, double rtol, double atol) {
   PL_MODEL(M);
   const int lane = lane_id();
-  PL_VEC(n) { const double w = 1.0 / (rtol * fabs(S.phi[0][n]) + atol); I.ew[k__] = w; }
+  PL_VEC(n) { const double w = pl_rcp(rtol * fabs(S.phi[0][n]) + atol); I.ew[k__] = w; }
   PL_SYNC();
 }
 #define EWT(n) I.ew[k__]
@@ -350,10 +363,10 @@ PL_DEV double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
     const double po_im1 = i > 0 ? S.ida_psi[i - 1] : 1.0, po_im2 = i > 1 ? S.ida_psi[i - 2] : 1.0;
     const double pn_i = i > 0 ? po_im1 + hh : hh;
     const double pn_im1 = i > 1 ? po_im2 + hh : hh;
-    const double al = i > 0 ? hh / pn_i : 1.0;
-    const double q = i > 0 ? pn_im1 / po_im1 : 1.0;
-    const double al_prev = i > 1 ? hh / pn_im1 : 1.0;
-    const double g = i > 0 ? al_prev / hh : 0.0;
+    const double al = i > 0 ? pl_div(hh, pn_i) : 1.0;
+    const double q = i > 0 ? pl_div(pn_im1, po_im1) : 1.0;
+    const double al_prev = i > 1 ? pl_div(hh, pn_im1) : 1.0;
+    const double g = i > 0 ? pl_div(al_prev, hh) : 0.0;
     double bm = 1.0, sg = 1.0, gm = 0.0, myb = q, mys = 1.0, myg = g;
     _Pragma("unroll") for (int m = 1; m <= MAXORD; m++) if (m <= kk) {
       const double qm = lane_bcast(q, m), am = lane_bcast(al, m), gmm = lane_bcast(g, m);
@@ -367,7 +380,7 @@ PL_DEV double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
   } else {
     for (int m = 0; m < kk; m++) { alphas -= (m == 0 ? rinv[0] : m == 1 ? rinv[1] : m == 2 ? rinv[2] : m == 3 ? rinv[3] : rinv[4]); alpha0 -= S.ida_alpha[m]; }
   }
-  I.cjlast = I.cj; I.cj = -alphas / hh;
+  I.cjlast = I.cj; I.cj = pl_div(-alphas, hh);
   const double ak = S.ida_alpha[kk];
   double ck = fabs(ak + alphas - alpha0); if (ck < ak) ck = ak;
   // (IDASetCoeffs' rescaling phi[m] *= beta[m], m = ns .. kk, is done by the first form_iterate of the step, in the pass that sums the predictor anyway: same
@@ -391,6 +404,34 @@ PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
   // history vector outermost, the lane's trips innermost: the LDS loads of one order are issued back to back (a runtime-bounded inner
   // loop over the orders would expose one LDS round trip per order and trip); same summation order as before
   double a[NTRIP], b[NTRIP];
+  if constexpr (PL_FLAT<M>) {
+    const int kk = I.kk, ns = I.ns;
+    double gm[MAXORD + 1], bt[MAXORD + 1];
+    _Pragma("unroll") for (int j = 1; j <= MAXORD; j++) { gm[j] = S.ida_gamma[j]; bt[j] = S.ida_beta[j]; }
+    double p[3][NTRIP];
+    PL_VEC(n) { a[k__] = S.phi[0][n]; b[k__] = 0.0; }
+    _Pragma("unroll") for (int j = 1; j <= 3; j++) PL_VEC(n) p[j - 1][k__] = S.phi[j][n];
+    bool resc[4];
+    _Pragma("unroll") for (int j = 1; j <= 3; j++) {
+      const bool on = j <= kk; resc[j] = on && first && j >= ns;
+      const double f = resc[j] ? bt[j] : 1.0, m = on ? 1.0 : 0.0, g = on ? gm[j] : 0.0;
+      PL_VEC(n) { const double q = p[j - 1][k__] * f; p[j - 1][k__] = q; a[k__] += m * q; b[k__] += g * q; }
+    }
+    if (kk > 3) {
+      double p4[NTRIP], p5[NTRIP];
+      PL_VEC(n) { p4[k__] = S.phi[4][n]; p5[k__] = S.phi[5][n]; }
+      const bool on5 = kk > 4, r4 = first && 4 >= ns, r5 = on5 && first && 5 >= ns;
+      const double f4 = r4 ? bt[4] : 1.0, f5 = r5 ? bt[5] : 1.0, m5 = on5 ? 1.0 : 0.0, g5 = on5 ? gm[5] : 0.0;
+      PL_VEC(n) { const double q = p4[k__] * f4; p4[k__] = q; a[k__] += q; b[k__] += gm[4] * q; }
+      PL_VEC(n) { const double q = p5[k__] * f5; p5[k__] = q; a[k__] += m5 * q; b[k__] += g5 * q; }
+      if (r4) { PL_VEC(n) S.phi[4][n] = p4[k__]; }
+      if (r5) { PL_VEC(n) S.phi[5][n] = p5[k__]; }
+    }
+    // (the rescaled orders go back last: stores only under the wave-uniform branches)
+    if (resc[1]) { PL_VEC(n) S.phi[1][n] = p[0][k__]; }
+    if (resc[2]) { PL_VEC(n) S.phi[2][n] = p[1][k__]; }
+    if (resc[3]) { PL_VEC(n) S.phi[3][n] = p[2][k__]; }
+  } else {
   PL_VEC(n) { a[k__] = S.phi[0][n]; b[k__] = 0.0; }
   if constexpr (PHI_REGS<M> && !PL_BRANCHY_PHI) {
     // History orders that live in registers (thermal model): NO control flow around them.  A wave-uniform branch whose arm rewrites a register-resident order makes the
@@ -415,6 +456,7 @@ PL_DEV void form_iterate(CellLDS<M>& S, IdaScalars& I, bool first = true) {
       PL_VEC(n) { const double p = PHI_RD(j, n) * bt; PHI_WR(j, n, p); a[k__] += p; b[k__] += g * p; }
     } else PL_VEC(n) { const double p = PHI_RD(j, n); a[k__] += p; b[k__] += g * p; }
   }
+  }
   PL_VEC(n) { const double e = EE(n); S.yy[n] = a[k__] + e; S.yp[n] = b[k__] + I.cj * e; if (M::PRED_REGS) { I.pa[k__] = a[k__]; I.pb[k__] = b[k__]; } }
   PL_XSYNC();
   PL_AMARK("form_iterate end");
@@ -432,7 +474,7 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
   int callLSetup = 0;
   if (I.nst == 0) { I.cjold = I.cj; I.ss = 20.0; callLSetup = 1; }
   else {
-    I.cjratio = I.cj / I.cjold;
+    I.cjratio = pl_div(I.cj, I.cjold);
     const double temp1 = (1.0 - 0.25) / (1.0 + 0.25), temp2 = 1.0 / temp1;
     if (I.cjratio < temp1 || I.cjratio > temp2) callLSetup = 1;
     if (I.cj != I.cjlast) I.ss = 100.0;
@@ -479,14 +521,14 @@ PL_DEV int ida_nls(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I, 
 #endif
     PL_TOC(S, PH_SOLVE); }
     PL_TIC();
-    const double sc = (I.cjratio != 1.0) ? -2.0 / (1.0 + I.cjratio) : -1.0;
+    const double sc = (I.cjratio != 1.0) ? -2.0 * pl_rcp(1.0 + I.cjratio) : -1.0;
     double s = 0.0;
     PL_VEC(n) { const double d = S.delta[n] * sc; EE(n) += d; const double p = d * EWT(n); s += p * p; }
-    const double delnrm = sqrt(block_sum<M>(S, s) * (1.0 / NST));
+    const double delnrm = pl_sqrt(block_sum<M>(S, s) * (1.0 / NST));
     PL_SYNC();
     ret = 2;
     if (m == 0) { oldnrm = delnrm; if (delnrm <= toldel) ret = 0; }
-    else { const double q = delnrm / oldnrm; const double rate = (m == 1) ? q : pow(q, 1.0 / m); if (rate > 0.9) ret = 1; else I.ss = rate / (1.0 - rate); }
+    else { const double q = pl_div(delnrm, oldnrm); const double rate = (m == 1) ? q : pow(q, 1.0 / m); if (rate > 0.9) ret = 1; else I.ss = pl_div(rate, 1.0 - rate); }
     if (ret == 2 && I.ss * delnrm <= epsNewt) ret = 0;
     if (!(delnrm == delnrm)) ret = 1;
     PL_TOC(S, PH_NEWTVEC);
@@ -510,7 +552,18 @@ PL_DEV int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, double& err_k
   // phi[kk], phi[kk-1] through a compile-time order index (wave-uniform branches): the history orders that live in registers (thermal model) are then read directly
   // instead of through a select chain per element
   // (with the whole history in LDS a runtime order is just an address, and the extra branches cost 2 % of the isothermal kernels: PHI_REGS selects the form)
-  if constexpr (PHI_REGS<M>) {
+  if constexpr (PL_FLAT<M>) {
+    // phi[kk] and phi[kk - 1] through clamped runtime indices, all three sums unconditionally (those of the orders the decision does not look at are computed and ignored)
+    const int j1 = kk, j2 = kk > 1 ? kk - 1 : 0;
+    double pk[NTRIP], pkm1[NTRIP];
+    PL_VEC(n) { pk[k__] = S.phi[j1][n]; pkm1[k__] = S.phi[j2][n]; }
+    PL_VEC(n) {
+      const double w = EWT(n), e = EE(n);
+      double p = e * w; s0 += p * p;
+      const double d1 = pk[k__] + e; p = d1 * w; s1 += p * p;
+      const double d2 = d1 + pkm1[k__]; p = d2 * w; s2 += p * p;
+    }
+  } else if constexpr (PHI_REGS<M>) {
     double pk[NTRIP], pkm1[NTRIP];
     PL_VEC(n) { pk[k__] = 0.0; pkm1[k__] = 0.0; }
     _Pragma("unroll") for (int j = 1; j <= MAXORD; j++) {
@@ -531,14 +584,16 @@ PL_DEV int ida_test_error(CellLDS<M>& S, IdaScalars& I, double ck, double& err_k
         if (kk > 2) { const double d2 = d1 + PHI_RD(kk - 1, n); p = d2 * w; s2 += p * p; } }
     }
   }
+  // (the three sigma entries are read before the reduction: clamped indices, unconditional)
+  const double sg_k = S.ida_sigma[kk], sg_km1 = S.ida_sigma[kk > 1 ? kk - 1 : 0], sg_km2 = S.ida_sigma[kk > 2 ? kk - 2 : 0];
   block_sum3<M>(S, s0, s1, s2);                         // (all three at once: one pair of barriers with two waves per cell)
-  const double enorm_k = sqrt(s0 * (1.0 / NST));
-  err_k = S.ida_sigma[kk] * enorm_k; const double terr_k = (kk + 1) * err_k;
+  const double enorm_k = pl_sqrt(s0 * (1.0 / NST));
+  err_k = sg_k * enorm_k; const double terr_k = (kk + 1) * err_k;
   I.knew = kk; err_km1 = 0.0;
   if (kk > 1) {
-    const double enorm_km1 = sqrt(s1 * (1.0 / NST)); err_km1 = S.ida_sigma[kk - 1] * enorm_km1; const double terr_km1 = kk * err_km1;
+    const double enorm_km1 = pl_sqrt(s1 * (1.0 / NST)); err_km1 = sg_km1 * enorm_km1; const double terr_km1 = kk * err_km1;
     if (kk > 2) {
-      const double enorm_km2 = sqrt(s2 * (1.0 / NST)); const double err_km2 = S.ida_sigma[kk - 2] * enorm_km2; const double terr_km2 = (kk - 1) * err_km2;
+      const double enorm_km2 = pl_sqrt(s2 * (1.0 / NST)); const double err_km2 = sg_km2 * enorm_km2; const double terr_km2 = (kk - 1) * err_km2;
       if ((terr_km1 > terr_km2 ? terr_km1 : terr_km2) <= terr_k) I.knew = kk - 1;
     } else if (terr_km1 <= 0.5 * terr_k) I.knew = kk - 1;
   }
@@ -601,7 +656,7 @@ PL_DEV bool ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double
   // d_{j-1} of IDAGetSolution at t = tn (delt = 0: c_j = 0 for j >= 1, gam_j = psi[j-1] / psi[j]); the reciprocals of psi by lanes 0..ku in parallel as in ida_get_solution
   double dc1 = 0, dc2 = 0, dc3 = 0, dc4 = 0, dc5 = 0;
   if (!at_tstop) {
-    const double rp_mine = 1.0 / S.ida_psi[lane <= MAXORD ? lane : MAXORD];
+    const double rp_mine = pl_rcp(S.ida_psi[lane <= MAXORD ? lane : MAXORD]);
     const double rp0 = lane_bcast(rp_mine, 0), rp1 = lane_bcast(rp_mine, 1), rp2 = lane_bcast(rp_mine, 2), rp3 = lane_bcast(rp_mine, 3), rp4 = lane_bcast(rp_mine, 4),
                  rp5 = lane_bcast(rp_mine, 5);
     const double delt = 0.0;
@@ -614,7 +669,33 @@ PL_DEV bool ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double
     double acc[NTRIP], sp[NTRIP];
     const double dku = ku == 1 ? dc1 : ku == 2 ? dc2 : ku == 3 ? dc3 : ku == 4 ? dc4 : dc5;
     // (the order index of every history access is a compile-time constant under a wave-uniform branch: direct register access for the orders kept in registers)
-    if constexpr (PHI_REGS<M> && PL_BRANCHY_PHI) {      // (r03 form, kept for same-box A/B builds: tools/experiments/build_modes.py th_branchy)
+    if constexpr (PL_FLAT<M>) {
+      // the running sum starts as ee and runs from the top order down; order j joins it iff j <= ku (factor 1.0 / 0.0: exact), takes the sum back iff j <= ku, takes ee iff
+      // j = ku + 1 <= maxord, and enters y' with d_{j-1} (dc_j is 0 beyond ku).  Orders 4, 5 under one branch (ku >= 3), orders 0 .. 3 always: loads, sums, then the stores.
+      (void)dku;
+      const bool grow = ku < I.maxord;
+      PL_VEC(n) { acc[k__] = EE(n); sp[k__] = 0.0; }
+      if (ku >= 3) {
+        double q5[NTRIP], q4[NTRIP];
+        PL_VEC(n) { q5[k__] = S.phi[5][n]; q4[k__] = S.phi[4][n]; }
+        const double m5 = ku >= 5 ? 1.0 : 0.0, m4 = ku >= 4 ? 1.0 : 0.0;
+        PL_VEC(n) { acc[k__] += m5 * q5[k__]; q5[k__] = acc[k__]; sp[k__] += dc5 * acc[k__]; acc[k__] += m4 * q4[k__]; q4[k__] = acc[k__]; sp[k__] += dc4 * acc[k__]; }
+        if (ku >= 5) { PL_VEC(n) S.phi[5][n] = q5[k__]; } else if (grow && ku == 4) { PL_VEC(n) S.phi[5][n] = EE(n); }
+        if (ku >= 4) { PL_VEC(n) S.phi[4][n] = q4[k__]; } else if (grow) { PL_VEC(n) S.phi[4][n] = EE(n); }      // (ku == 3 here)
+      }
+      double q[4][NTRIP];
+      _Pragma("unroll") for (int j = 3; j >= 0; j--) PL_VEC(n) q[j][k__] = S.phi[j][n];
+      const double m3 = ku >= 3 ? 1.0 : 0.0, m2 = ku >= 2 ? 1.0 : 0.0;
+      PL_VEC(n) {
+        acc[k__] += m3 * q[3][k__]; q[3][k__] = acc[k__]; sp[k__] += dc3 * acc[k__];
+        acc[k__] += m2 * q[2][k__]; q[2][k__] = acc[k__]; sp[k__] += dc2 * acc[k__];
+        acc[k__] += q[1][k__]; q[1][k__] = acc[k__]; sp[k__] += dc1 * acc[k__];
+        acc[k__] += q[0][k__];
+      }
+      if (ku >= 3) { PL_VEC(n) S.phi[3][n] = q[3][k__]; } else if (grow && ku == 2) { PL_VEC(n) S.phi[3][n] = EE(n); }
+      if (ku >= 2) { PL_VEC(n) S.phi[2][n] = q[2][k__]; } else if (grow) { PL_VEC(n) S.phi[2][n] = EE(n); }           // (ku == 1 here)
+      PL_VEC(n) { S.phi[1][n] = q[1][k__]; S.phi[0][n] = acc[k__]; }
+    } else if constexpr (PHI_REGS<M> && PL_BRANCHY_PHI) {      // (r03 form, kept for same-box A/B builds: tools/experiments/build_modes.py th_branchy)
       _Pragma("unroll") for (int j = MAXORD; j >= 0; j--) {
         if (j == ku + 1 && ku < I.maxord) { PL_VEC(n) PHI_WR(j, n, EE(n)); }
         else if (j == ku) { PL_VEC(n) { acc[k__] = PHI_RD(j, n) + EE(n); PHI_WR(j, n, acc[k__]); sp[k__] = dku * acc[k__]; } }
@@ -667,7 +748,7 @@ PL_DEV void ida_get_solution(CellLDS<M>& S, const IdaScalars& I, double t, doubl
   int kord = I.kused; if (kord == 0) kord = 1;
   const double delt = t - I.tn;
   // reciprocals of psi[0..kord] by lanes 0..kord in parallel (the recurrence below is then division-free)
-  const double rp_mine = 1.0 / S.ida_psi[lane <= MAXORD ? lane : MAXORD];
+  const double rp_mine = pl_rcp(S.ida_psi[lane <= MAXORD ? lane : MAXORD]);
   const double rp0 = lane_bcast(rp_mine, 0), rp1 = lane_bcast(rp_mine, 1), rp2 = lane_bcast(rp_mine, 2), rp3 = lane_bcast(rp_mine, 3),
                rp4 = lane_bcast(rp_mine, 4), rp5 = lane_bcast(rp_mine, 5);
   double c = 1.0, d = 0.0, gam = delt * rp0;
@@ -796,6 +877,16 @@ __device__ __forceinline__ double cellTavg(const CellLDS<M>& S, const double* Y)
   else return S.cc.T0;
 }
 
+// a set of wave-uniform values the compiler must have in registers HERE: one empty asm that reads them all -- the loads that produce them are issued together above it
+// and waited for once (LLVM otherwise sinks every load into the branch that uses it: one exposed LDS round trip per test, and a wave that runs alone on its SIMD has
+// nothing to hide it behind)
+#ifdef PL_WAVE_EMU
+template <class... T> __device__ __forceinline__ void pl_pin(T&...) {}
+#else
+__device__ __forceinline__ void pl_pin1(double& a) { __asm__ volatile("" : "+v"(a)); }
+template <class... T> __device__ __forceinline__ void pl_pin(T&... v) { (pl_pin1(v), ...); }
+#endif
+
 template <int F = 0, class M>
 PL_DEV void check_stop(CellLDS<M>& S, const plh_run& run, const plh_opts& o, double t, double tf, const double* Y, const double* YP,
                                   double SOC, PrevVals& pv, int& flag) {
@@ -803,52 +894,56 @@ PL_DEV void check_stop(CellLDS<M>& S, const plh_run& run, const plh_opts& o, dou
   const double eps = t < 1.0 ? o.reltol : 0.0;
   [[maybe_unused]] double Tav = 0.0, dTav = 0.0;
   if constexpr (M::THERMAL) { Tav = cellTavg<M>(S, Y); dTav = cellTavg<M>(S, YP); }     // (all lanes, before any early return)
-  if (t >= tf) { flag = 0; return; }
-  if (!o.check_bounds || run.value_kind == PLH_VAL_REST) return;
+  // r06: every operand of the tests that run at every accepted step -- the bounds of the run (LDS copy of the descriptor) and the handful of state entries they look at --
+  // is loaded here, together; r05 loaded each where its test used it: ten dependent LDS round trips per step (1.5 k cycles by the phase timers for a dozen comparisons)
   const plh_bounds& b = run.bounds;
-  const double Ic = Y[O_I];
-  if (run.mode != PLH_MODE_I) {                                                         // check_stop_I, checks.jl:31-54
-    const double dI = YP[O_I];
-    if ((Ic - b.I_max > eps) && dI > 0) { const double f = (pv.I - b.I_max) / (pv.I - Ic); if (f < pv.frac) { pv.frac = f; flag = 7; } }
-    else if ((b.I_min - Ic > eps) && dI < 0) { const double f = (pv.I - b.I_min) / (pv.I - Ic); if (f < pv.frac) { pv.frac = f; flag = 8; } }
+  double bImax = b.I_max, bImin = b.I_min, bVmin = b.V_min, bVmax = b.V_max, bSmin = b.SOC_min, bSmax = b.SOC_max, bcs = b.c_s_n_max, bce = b.c_e_min;
+  double bep = b.eta_plating_min, Ic = Y[O_I], dI = YP[O_I], V = cellV<M>(Y), dV = cellV<M>(YP), ep = Y[O_PS + NP] - Y[O_PE + NP + NS], dep = YP[O_PS + NP] - YP[O_PE + NP + NS];
+  [[maybe_unused]] double bTmax = M::THERMAL ? b.T_max : 0.0;
+  const int rmode = run.mode, vkind = run.value_kind;
+  pl_pin(bImax, bImin, bVmin, bVmax, bSmin, bSmax, bcs, bce); pl_pin(bep, Ic, dI, V, dV, ep, dep, bTmax);
+  if (t >= tf) { flag = 0; return; }
+  if (!o.check_bounds || vkind == PLH_VAL_REST) return;
+  if (rmode != PLH_MODE_I) {                                                            // check_stop_I, checks.jl:31-54
+    if ((Ic - bImax > eps) && dI > 0) { const double f = (pv.I - bImax) / (pv.I - Ic); if (f < pv.frac) { pv.frac = f; flag = 7; } }
+    else if ((bImin - Ic > eps) && dI < 0) { const double f = (pv.I - bImin) / (pv.I - Ic); if (f < pv.frac) { pv.frac = f; flag = 8; } }
     pv.I = Ic;
   }
-  if (run.mode != PLH_MODE_V) {                                                         // check_stop_V, checks.jl:56-81
-    const double V = cellV<M>(Y), dV = cellV<M>(YP);
-    if ((b.V_min - V > eps) && dV < 0) { const double f = (pv.V - b.V_min) / (pv.V - V); if (f < pv.frac) { pv.frac = f; flag = 1; } }
-    else if ((V - b.V_max > eps) && dV > 0) { const double f = (pv.V - b.V_max) / (pv.V - V); if (f < pv.frac) { pv.frac = f; flag = 2; } }
+  if (rmode != PLH_MODE_V) {                                                            // check_stop_V, checks.jl:56-81
+    if ((bVmin - V > eps) && dV < 0) { const double f = (pv.V - bVmin) / (pv.V - V); if (f < pv.frac) { pv.frac = f; flag = 1; } }
+    else if ((V - bVmax > eps) && dV > 0) { const double f = (pv.V - bVmax) / (pv.V - V); if (f < pv.frac) { pv.frac = f; flag = 2; } }
     pv.V = V;
   }
   {                                                                                     // check_stop_SOC, checks.jl:83-104
-    if ((b.SOC_min - SOC > eps) && Ic < 0) { const double f = (pv.SOC - b.SOC_min) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; flag = 3; } }
-    else if ((SOC - b.SOC_max > eps) && Ic > 0) { const double f = (pv.SOC - b.SOC_max) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; flag = 4; } }
+    if ((bSmin - SOC > eps) && Ic < 0) { const double f = (pv.SOC - bSmin) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; flag = 3; } }
+    else if ((SOC - bSmax > eps) && Ic > 0) { const double f = (pv.SOC - bSmax) / (pv.SOC - SOC); if (f < pv.frac) { pv.frac = f; flag = 4; } }
     pv.SOC = SOC;
   }
   if constexpr (M::THERMAL) {                                                           // check_stop_T, checks.jl:106-124
-    if (b.T_max == b.T_max && run.mode != PLH_MODE_DT) {
-      if (Tav - b.T_max > eps && dTav > 0) { const double f = (pv.T - b.T_max) / (pv.T - Tav); if (f < pv.frac) { pv.frac = f; flag = 5; } }
+    if (bTmax == bTmax && rmode != PLH_MODE_DT) {
+      if (Tav - bTmax > eps && dTav > 0) { const double f = (pv.T - bTmax) / (pv.T - Tav); if (f < pv.frac) { pv.frac = f; flag = 5; } }
       pv.T = Tav;
     }
   }
-  if (b.c_s_n_max == b.c_s_n_max) {                                                     // check_stop_c_s_surf, checks.jl:141-161
+  if (bcs == bcs) {                                                                     // check_stop_c_s_surf, checks.jl:141-161
     double cm = -1e300; for (int i = 0; i < NN; i++) { const double v = M::SD == 0 ? Y[O_CS + cs_surf(NP + i)] : Y[O_CS + NP + i]; cm = v > cm ? v : cm; }     // (c_s_n_maximum, checks.jl:125-139)
-    const double lim = b.c_s_n_max * S.cc.cmaxn;
+    const double lim = bcs * S.cc.cmaxn;
     if (Ic > 0 && cm - lim > eps) { const double f = (pv.c_s_n - lim) / (pv.c_s_n - cm); if (f < pv.frac) { pv.frac = f; flag = 6; } }
     pv.c_s_n = cm;
   }
-  if (b.c_e_min == b.c_e_min) {                                                         // check_stop_c_e, checks.jl:163-183
+  if (bce == bce) {                                                                     // check_stop_c_e, checks.jl:163-183
     double cm = 1e300; for (int i = 0; i < NE; i++) { const double v = Y[O_CE + i]; cm = v < cm ? v : cm; }
-    if (b.c_e_min - cm > eps) { const double f = (pv.c_e_min - b.c_e_min) / (pv.c_e_min - cm); if (f < pv.frac) { pv.frac = f; flag = 9; } }
+    if (bce - cm > eps) { const double f = (pv.c_e_min - bce) / (pv.c_e_min - cm); if (f < pv.frac) { pv.frac = f; flag = 9; } }
     pv.c_e_min = cm;
   }
-  if (b.eta_plating_min == b.eta_plating_min) {                                         // check_stop_η_plating, checks.jl:185-201
-    const double ep = Y[O_PS + NP] - Y[O_PE + NP + NS], dep = YP[O_PS + NP] - YP[O_PE + NP + NS];
-    if (b.eta_plating_min - ep > eps && dep < 0) { const double f = (pv.eta_pl - b.eta_plating_min) / (pv.eta_pl - ep); if (f < pv.frac) { pv.frac = f; flag = 11; } }
+  if (bep == bep) {                                                                     // check_stop_η_plating, checks.jl:185-201
+    if (bep - ep > eps && dep < 0) { const double f = (pv.eta_pl - bep) / (pv.eta_pl - ep); if (f < pv.frac) { pv.frac = f; flag = 11; } }
     pv.eta_pl = ep;
   }
   if constexpr (M::SEI) {                                                               // check_stop_dfilm, checks.jl:203-224
+    const double bdf = b.dfilm_max;
     double dm = -1e300; for (int i = 0; i < NN; i++) { const double v = YP[O_FILM + i]; dm = v > dm ? v : dm; }
-    if (b.dfilm_max == b.dfilm_max && dm - b.dfilm_max > eps) { const double f = (pv.dfilm - b.dfilm_max) / (pv.dfilm - dm); if (f < pv.frac) { pv.frac = f; flag = 10; } }
+    if (bdf == bdf && dm - bdf > eps) { const double f = (pv.dfilm - bdf) / (pv.dfilm - dm); if (f < pv.frac) { pv.frac = f; flag = 10; } }
     pv.dfilm = dm;
   }
   if constexpr ((F & GF_EXPR) != 0) {                                                   // opts.stop_function, checks.jl:26: after the built-in checks (plh_opts.stop_ops)
@@ -890,24 +985,26 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
   const double T0 = S.cc.T0;
   // (what a run inherits from the one before -- SOC, end time, V / I / eta_plating -- travels through S.carry: see CellLDS)
   if (Yinit && !from_states) {                                          // simulate!(sol, ...): continue from sol.Y[end]
-    PL_VEC(n) S.yy[n] = Yinit[n];
+    PL_VECG(n) S.yy[n] = Yinit[n];
     PL_XSYNC();
     have_prev = true;
     if (lane == 0 && wave_id() == 0) { S.carry[0] = SOC0; S.carry[1] = t_init; S.carry[2] = cellV<M>(S.yy); S.carry[3] = S.yy[O_I]; S.carry[4] = S.yy[O_PS + NP] - S.yy[O_PE + NP + NS]; }
   } else {
     // simulate(p, ...; initial_states = Y) (model_evaluation.jl:15, 102-110, 193-199): a NEW solution -- t0 = 0, no tstop at 1 s, nothing to :hold -- that starts from the caller's
     // state vector instead of initial_guess! (the algebraic part is re-solved by newtons_method! as always; SOC0 is the caller's calc_SOC(Y), scalar_residual.jl:95-102)
-    if (Yinit) { PL_VEC(n) S.yy[n] = Yinit[n]; PL_XSYNC(); }
+    if (Yinit) { PL_VECG(n) S.yy[n] = Yinit[n]; PL_XSYNC(); }
     if (lane == 0 && wave_id() == 0) { S.carry[0] = SOC0; S.carry[1] = 0.0; S.carry[2] = 0.0; S.carry[3] = 0.0; S.carry[4] = 0.0; }
   }
   PL_XSYNC();
   auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
     const double Tav = (M::THERMAL && out.T) ? cellTavg<M>(S, Y) : T0;
-    if constexpr ((F & GF_STOPS) != 0) if (out.Yall && idx < out.max_pts) { PL_VEC(n) out.Yall[(size_t)idx * NST + n] = Y[n]; }      // outputs = :all
+    if constexpr ((F & GF_STOPS) != 0) if (out.Yall && idx < out.max_pts) { PL_VECG(n) out.Yall[(size_t)idx * NST + n] = Y[n]; }      // outputs = :all
+    double Vv = cellV<M>(Y), Iv = Y[O_I];                              // (read by every lane AHEAD of the one-lane store block: no LDS round trip inside it)
+    pl_pin(Vv, Iv);
     if (lane == 0 && wave_id() == 0 && idx < out.max_pts) {
       if (out.t) out.t[idx] = tt;
-      if (out.V) out.V[idx] = cellV<M>(Y);
-      if (out.I) out.I[idx] = Y[O_I];
+      if (out.V) out.V[idx] = Vv;
+      if (out.I) out.I[idx] = Iv;
       if (out.SOC) out.SOC[idx] = soc;
       if (out.T) out.T[idx] = Tav;
     }
@@ -1010,7 +1107,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       first_init = false;
       save_pt(nout, t0, S.yy, SOC); nout++;
       check_stop<F>(S, run, o, 0.0, run.tf, S.yy, S.yp, SOC, pv, flag);
-      PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
+      PL_VECG(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
       PL_SYNC();
       I_prev_pt = S.yy[O_I];
       if constexpr ((F & GF_SENS) != 0) sens_init(S, SX, mode, value, new_run, SOC0, o.reltol, o.abstol, nout - 1, run.value_kind == PLH_VAL_HOLD && have_prev, prev_V, prev_I);
@@ -1035,7 +1132,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       if (sf != 0) {
         if (I.nst == 0 && !stalled_once) {                              // check_solve, checks.jl:227-237
           stalled_once = true;
-          PL_VEC(n) { S.yy[n] = Yprev[n]; S.yp[n] = YPprev[n]; }
+          PL_VECG(n) { S.yy[n] = Yprev[n]; S.yp[n] = YPprev[n]; }
           PL_XSYNC();
           ida_reinit(S, I, S.yy, S.yp, I.maxord); I.h0_forced = o.reltol; iter++; t = tprev;
           // the reference's solve! has already pushed this (repeated) point and run the stop checks when check_solve shortens the first step
@@ -1050,7 +1147,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       iter++; t = tret;
       if constexpr ((F & GF_FUNC) != 0) steps_since_restart++;
       PL_TIC(); PL_TICE(3);
-      const double SOC_new = SOC + 0.5 * ((t + t0) - t_prev_saved) * (S.yy[O_I] + I_prev_pt) / 3600.0;   // calc_SOC, scalar_residual.jl:103-111
+      const double SOC_new = SOC + pl_div(0.5 * ((t + t0) - t_prev_saved) * (S.yy[O_I] + I_prev_pt), 3600.0);   // calc_SOC, scalar_residual.jl:103-111
       [[maybe_unused]] const double dt_saved = (t + t0) - t_prev_saved, soc_before = SOC;
       if constexpr ((F & GF_SENS) != 0) { soc_nm1_s = soc_before; dt_step_s = dt_saved; }
       SOC = SOC_new;
@@ -1064,9 +1161,9 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       if (nout >= out.max_pts && out.max_pts > 0 && flag == PLH_FLAG_RUNNING) { flag = PLH_ERR_OUTPUT_FULL; break; }
       if (flag == PLH_FLAG_RUNNING) {
 #ifdef PL_EXP_STORE_PREV     /* (A/B build: r03's per-step copy of the whole previous point) */
-        PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
+        PL_VECG(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
 #else
-        if (YPfin) { PL_VEC(n) YPprev[n] = S.yp[n]; }                // fire-and-forget: read back only when a bound fires (wave-uniform condition)
+        if (YPfin) { PL_VECG(n) YPprev[n] = S.yp[n]; }                // fire-and-forget: read back only when a bound fires (wave-uniform condition)
 #endif
         t_prev_saved = t + t0; I_prev_pt = S.yy[O_I];
         if constexpr ((F & GF_FUNC) != 0) if (is_fun && t - tprev < 1e-3 * o.reltol) {                    // check_reinitialization!, checks.jl:341-364
@@ -1077,7 +1174,7 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
             value = v_new; t_restart = t_new; again = true;
             // the last saved point: check_solve's retry restores it, and if a bound fires on the FIRST step after the re-initialisation it is the previous point of the
             // back-interpolation (the history then starts at the re-initialised state, whose algebraic part is not the saved one)
-            PL_VEC(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
+            PL_VECG(n) { Yprev[n] = S.yy[n]; YPprev[n] = S.yp[n]; }
             steps_since_restart = 0;
           }
         }
@@ -1093,12 +1190,12 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
       const double ti = fr * (t - tprev) + tprev;
       PL_XSYNC();
 #ifdef PL_EXP_STORE_PREV
-      PL_VEC(n) { S.yy[n] = fr * (S.yy[n] - Yprev[n]) + Yprev[n]; S.yp[n] = fr * (S.yp[n] - YPprev[n]) + YPprev[n]; }
+      PL_VECG(n) { S.yy[n] = fr * (S.yy[n] - Yprev[n]) + Yprev[n]; S.yp[n] = fr * (S.yp[n] - YPprev[n]) + YPprev[n]; }
 #else
       // (t > 1 excludes the point a run starts from: at least one step has been completed, phi[0] / phi[1] are those of the step that crossed the bound)
-      if ((F & GF_FUNC) && steps_since_restart == 1) { PL_VEC(n) { const double yprev = Yprev[n]; S.yy[n] = fr * (S.yy[n] - yprev) + yprev; } }
+      if ((F & GF_FUNC) && steps_since_restart == 1) { PL_VECG(n) { const double yprev = Yprev[n]; S.yy[n] = fr * (S.yy[n] - yprev) + yprev; } }
       else { PL_VEC(n) { const double yprev = S.phi[0][n] - S.phi[1][n]; S.yy[n] = fr * (S.yy[n] - yprev) + yprev; } }
-      if (YPfin) { PL_VEC(n) { const double ypp = YPprev[n]; S.yp[n] = fr * (S.yp[n] - ypp) + ypp; } }
+      if (YPfin) { PL_VECG(n) { const double ypp = YPprev[n]; S.yp[n] = fr * (S.yp[n] - ypp) + ypp; } }
 #endif
       PL_XSYNC();
       SOC = SOC + 0.5 * ((ti + t0) - (t + t0)) * (S.yy[O_I] + S.yy[O_I]) / 3600.0;
@@ -1117,8 +1214,8 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
   if (lane == 0 && wave_id() == 0 && n_pts_out) *n_pts_out = nout < out.max_pts ? nout : out.max_pts;
   PL_XSYNC();
   if constexpr ((F & GF_SENS) != 0) { if (lane == 0 && wave_id() == 0 && sens.stat) { sens.stat[3 * cell] = SX.n_it; sens.stat[3 * cell + 1] = SX.n_fail; sens.stat[3 * cell + 2] = SX.n_refresh; } }
-  if (Yfin) PL_VEC(n) Yfin[n] = S.yy[n];
-  if (YPfin) PL_VEC(n) YPfin[n] = S.yp[n];
+  if (Yfin) PL_VECG(n) Yfin[n] = S.yy[n];
+  if (YPfin) PL_VECG(n) YPfin[n] = S.yp[n];
 }
 
 }  // namespace pl

@@ -23,6 +23,11 @@
 // integrator, which are dead between the output of a step and the next predictor.
 #pragma once
 // (included from dfn_integrate.h, inside namespace pl, after IdaScalars / PL_VEC / EWT)
+// Every vector statement of this file is lane-masked (PL_VECG): the sensitivity histories live in GLOBAL memory at the unpadded stride (M::NPADG), and the padding of the LDS
+// vectors (M::VPAD) must stay zero -- the masked form never touches it.
+#pragma push_macro("PL_VEC")
+#undef PL_VEC
+#define PL_VEC(n) PL_VECG(n)
 
 constexpr int SENS_MAXIT = 64;
 // weights of the sensitivity norms: 1 / (|y_n| + abstol / reltol) = the integrator's error weights with the tolerance divided out -- the corrector stops when a correction,
@@ -40,7 +45,7 @@ template <class M> struct SensCell {
   SensArgs a; const double* th0; int cell, P, max_pts;
   bool first;                   // the next accepted step is the first of this integrator instance: hist[1] holds s'(t0), not h s'
   int n_it, n_fail, n_refresh;   // corrector iterations; solves that did not converge (after the refresh); steps / initialisations that factored their own matrix
-  __device__ __forceinline__ double* hist(int k, int j) const { return a.hist + (((size_t)cell * a.n_sens + k) * (MAXORD + 1) + j) * M::NPAD; }
+  __device__ __forceinline__ double* hist(int k, int j) const { return a.hist + (((size_t)cell * a.n_sens + k) * (MAXORD + 1) + j) * M::NPADG; }
   __device__ __forceinline__ const double* thp(int k) const { return a.theta_pert + ((size_t)cell * a.n_sens + k) * P; }
   __device__ __forceinline__ double* aux(int k) const { return a.aux + ((size_t)cell * a.n_sens + k) * 4; }
 };
@@ -459,3 +464,4 @@ PL_DEV void sens_finish(CellLDS<M>& S, SensCell<M>& X, bool interp, double fr, b
   }
   PL_XSYNC();
 }
+#pragma pop_macro("PL_VEC")

@@ -40,11 +40,11 @@ namespace pl {
 // ---------------------------------------------------------------------------------------------------------------------
 template <class M> __device__ __forceinline__ void load_vec(double* dst, const double* __restrict__ src) {
   const int lane = lane_id(), wv = wave_id();
-  _Pragma("unroll") for (int k__ = 0; k__ < M::NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv)) dst[n] = src[n];
+  _Pragma("unroll") for (int k__ = 0; k__ < M::NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vokg<M>(k__, lane, wv)) dst[n] = src[n];
 }
 template <class M> __device__ __forceinline__ void store_vec(double* __restrict__ dst, const double* src) {
   const int lane = lane_id(), wv = wave_id();
-  _Pragma("unroll") for (int k__ = 0; k__ < M::NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vok<M>(k__, lane, wv)) dst[n] = src[n];
+  _Pragma("unroll") for (int k__ = 0; k__ < M::NTRIP; k__++) if (const int n = vrow<M>(k__, lane, wv); vokg<M>(k__, lane, wv)) dst[n] = src[n];
 }
 
 template <class M> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WAVE_PER_SIMD void k_initial_guess(const Tables* tb, int n_cells, const double* theta, const double* SOC, double* Y) {
@@ -158,7 +158,7 @@ template <class M, int F> __global__ __launch_bounds__(64 * M::NWAVES) PL_ONE_WA
                 a.out.run_info + (size_t)cell * a.n_runs, cnt,
                 a.out.Y_final ? a.out.Y_final + (size_t)cell * NST : nullptr, a.out.YP_final ? a.out.YP_final + (size_t)cell * NST : nullptr,
                 a.scratch + (size_t)cell * 2 * NST, a.scratch + (size_t)cell * 2 * NST + NST, cell, a.genW ? a.genW + (size_t)cell * NST : nullptr, a.sens, a.theta + (size_t)cell * a.tb->P,
-                (M::PHI_GLOBAL && a.phig) ? a.phig + (size_t)cell * (MAXORD + 1 - M::PHI_LDS) * M::NPAD : nullptr, a.Y_init && !a.t_init);
+                (M::PHI_GLOBAL && a.phig) ? a.phig + (size_t)cell * (MAXORD + 1 - M::PHI_LDS) * M::NPADG : nullptr, a.Y_init && !a.t_init);
   PL_TOC_TOTAL(S);
   PL_SYNC();
   if (threadIdx.x == 0 && a.out.counters) {
@@ -358,7 +358,7 @@ template <class M> struct OpsOf {
     static_assert(!GRID_DEFAULT || sizeof(CellLDS<M>) <= 40960, "built-in variant: LDS per cell above 40 960 B, only three cells per CU would be resident");
 #endif
     static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::PREC, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, {NP, NS, NN, NRP, NA, NZ, NRN},
-                                   {PL_RADIAL_M, PL_RADIAL_M_N}, {PL_RADIAL_LAM, PL_RADIAL_LAM_N}, {PL_RADIAL_V, PL_RADIAL_V_N}, {PL_RADIAL_W, PL_RADIAL_W_N}, {PL_RADIAL_BJ_FACTOR, PL_RADIAL_BJ_FACTOR_N}, sizeof(CellLDS<M>), (int)(sizeof(CellLDS<M>) / sizeof(double)) + M::NWAVES * WAVE * 2 * CS_PASS, M::PHI_GLOBAL ? (MAXORD + 1 - M::PHI_LDS) * M::NPAD : 0, &classify<M>, &sections_of<M>,
+                                   {PL_RADIAL_M, PL_RADIAL_M_N}, {PL_RADIAL_LAM, PL_RADIAL_LAM_N}, {PL_RADIAL_V, PL_RADIAL_V_N}, {PL_RADIAL_W, PL_RADIAL_W_N}, {PL_RADIAL_BJ_FACTOR, PL_RADIAL_BJ_FACTOR_N}, sizeof(CellLDS<M>), (int)(sizeof(CellLDS<M>) / sizeof(double)) + M::NWAVES * WAVE * 2 * CS_PASS, M::PHI_GLOBAL ? (MAXORD + 1 - M::PHI_LDS) * M::NPADG : 0, &classify<M>, &sections_of<M>,
                                    &initial_guess, &residual, &jacobian, &linear_solve, &init_consistent, &integrate};
     return &ops;
   }

@@ -49,6 +49,13 @@ BUILDS = {
     "sei_pred": ([3], LATE + ["-DPL_EXP_SEI_PRED"], "c5", "c5_nmc_sei"),          # r04: predictor of the step in registers for the SEI models (PRED_REGS)
     "th_r03": ([4], None, "c3", "c3_thermal"), "iso_r03": ([0], None, "c2 c4", "c2_1024 or evaluators"), "sei_r03": ([3], None, "c5", "c5_nmc_sei"),
 }
+# r06: the instruction / latency diet of the isothermal kernels (variant 0, production flag table): everything on, and one switch off at a time
+BUILDS.update({
+    "r06_all": ([0], [], "c2 c4", "c2_1024 or evaluators"), "r06_noflat": ([0], ["-DPL_NO_FLAT"], "c2 c4", "c2_1024 or evaluators"),
+    "r06_novpad": ([0], ["-DPL_NO_VPAD"], "c2 c4", "c2_1024 or evaluators"), "r06_ieeediv": ([0], ["-DPL_IEEE_DIV"], "c2 c4", "c2_1024 or evaluators"),
+    "r06_none": ([0], ["-DPL_NO_FLAT", "-DPL_NO_VPAD", "-DPL_IEEE_DIV"], "c2 c4", "c2_1024 or evaluators"),
+    "r05": ([0], None, "c2 c4", "c2_1024 or evaluators"),          # the r05 library as committed (copied to _exp/libplh_r05.so)
+})
 for k in list(BUILDS):          # every build also exists with the previous-point copy kept (r03) or dropped
     pass
 
@@ -68,6 +75,7 @@ if __name__ == "__main__":
     what, names = sys.argv[1], sys.argv[2].split(",")
     os.makedirs(os.path.join(ROOT, "petlion.jl_amd", "_exp"), exist_ok=True)
     if what == "build":
+        g._flags()                               # (import the package once before the pool: pkgload.load() is not re-entrant across threads)
         with ThreadPoolExecutor(4) as ex:
             print(list(ex.map(build, names)))
     else:
