@@ -71,6 +71,26 @@ CLOCK_PEAK_HZ = 2.4e9            # max shader clock, same table
 FP64_ISSUE_CYCLES = 4            # a wave64 fp64 VALU instruction occupies the SIMD's 16-lane fp64 pipe for 4 cycles (78.6 TFLOP/s fp64 vector = 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
 
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (MI355X_MICROARCH.md): 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+
+
+def work_figures(k, cells, n_local, secs):
+    """r06: figures that reward doing LESS.  `frac` above is a busy fraction -- it rises when the kernel wastes VALU instructions; these do not:
+         flop_frac                 64 lanes x (2 FMA + MUL + ADD + TRANS) fp64 instructions per second / the 78.6 TFLOP/s fp64 vector peak (work / peak; lanes that a wave
+                                   masks off count as work here, `lane_utilisation` says how many are live)
+         fp64_arith_share_of_valu  (FMA + MUL + ADD + TRANS) / SQ_INSTS_VALU: the share of the VALU stream that is arithmetic (r05: 0.515; the rest is moves, selects,
+                                   DPP shifts, lane broadcasts, SGPR spill traffic, division scaffolding)
+         lane_utilisation          SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): mean fraction of the 64 lanes active per VALU instruction"""
+    names = ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")
+    if not all(nm in k for nm in names) or "SQ_INSTS_VALU" not in k:
+        return {"flop_frac": None, "fp64_arith_share_of_valu": None, "lane_utilisation": None}
+    fma, mul, add, trans = (k[nm] / cells for nm in names)
+    flops = 64.0 * (2.0 * fma + mul + add + trans) * n_local / secs
+    return {"flop_frac": flops / (FP64_VECTOR_PEAK_TFLOPS * 1e12), "fp64_tflops": flops / 1e12, "flop_frac_what": "64 x (2 FMA + MUL + ADD + TRANS) fp64 VALU instructions per second / 78.6 TFLOP/s",
+            "fp64_arith_share_of_valu": (fma + mul + add + trans) * cells / k["SQ_INSTS_VALU"],
+            "lane_utilisation": (k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"])) if "SQ_THREAD_CYCLES_VALU" in k and "SQ_ACTIVE_INST_VALU" in k else None}
+
+
 def issue_roofline(pmc, traffic, n_local, kavg_ms, klast_ms, c, ens, pkg, p):
     """the bound that bounds: VALU issue (module docstring).  Everything PMC comes from the committed pass of this binary and workload; the duration is measured live."""
     secs = kavg_ms * 1e-3
@@ -108,6 +128,7 @@ def issue_roofline(pmc, traffic, n_local, kavg_ms, klast_ms, c, ens, pkg, p):
                 "instructions_per_step": {nm: k[key] / cells / steps for nm, key in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS")) if key in k},
                 "fp64_instruction_mix_per_trajectory": {nm[14:].lower(): k[nm] / cells for nm in k if nm.startswith("SQ_INSTS_VALU_")} or None,
                 "effective_clock_ghz": (wave_cyc / secs / 1e9) if n_local <= SIMDS else None,
+                **work_figures(k, cells, n_local, secs),
                 "pmc_file": pmc.get("file"), "pmc_binary_src": pmc.get("build_src"),
                 "pmc_binary_matches": (pmc.get("build_src") in pkg.api.build_info(p)) if pmc.get("build_src") else None,
                 "limiter": "one wavefront per SIMD issuing a dependent fp64 instruction stream: the VALU is busy for `valu_busy_share_of_wave_cycles` of the wave's life and the wave is "

@@ -217,6 +217,16 @@ struct CellConst {
   int iso_ref;   // T0 == TREF exactly (temperature_switch, reference custom_functions.jl:1)
 };
 
+// r06: the per-section and per-edge constants of the isothermal node pass as LDS tables that a lane indexes with ITS OWN section (0 = p, 1 = s, 2 = n) and edge kind
+// (0 .. 2 = interior edge of section p / s / n, 3 = p|s interface, 4 = s|n interface): one load per constant with a per-lane address instead of three wave-uniform loads
+// and a chain of 64-bit selects (r05: 71 v_cndmask per node pass, 10 % of the kernel's static VALU stream).  Same numbers, copied by cell_setup from CellConst; 456 B per
+// cell -- the thermal model (at 40 952 of 40 960 B) has its own node pass and does not carry them.
+template <bool ON> struct NodeTab {};
+template <> struct NodeTab<true> {
+  struct alignas(16) Sec { double h, eps, bf, Dc, rh, reps, a, cmax, kk, rsg, rcm, pad; } sec[3];      // (section s: the anode's electrode entries, as the selects of r05 gave it: unused)
+  struct alignas(16) Edge { double beta, rdist, Dh, pad; } edge[5];
+};
+
 // Jacobian pool of the SEI rows (anode nodes k = 0..NN-1); empty for models without aging so that their LDS footprint is unchanged
 template <bool SEI> struct SeiPool {};
 template <> struct SeiPool<true> {
@@ -311,6 +321,7 @@ template <class M> struct alignas(16) CellLDS {
   double carry[5];     // [0] SOC, [1] t_global, [2] prev_V, [3] prev_I, [4] prev_etap
   plh_run runc;        // the run being integrated (copied from HBM once per run)
   CellConst cc;
+  NodeTab<!M::THERMAL> nt;      // (outside the range sens_factor_copy saves; sens_consts saves it with cc)
   // closure inputs (PLH_VAL_EXPR; general instantiation only; kept last so that nothing else moves): the cell's theta row in HBM and the interpreter's value stack
   const double* theta_row;
   double xstk[PLH_EXPR_STACK * M::NWAVES];      // (one stack per wave)
@@ -363,7 +374,23 @@ template <bool A16> __device__ __forceinline__ lds_cptr pl_lds_base_a(const doub
 #define PL_LDS_BASE_A(A16, p) pl_lds_base_a<A16>(p)
 #endif
 
+// lane_id_pred(): the lane number for code whose use of it is PREDICATES (which control volume, which section, first / last of an electrode, node of the twisted layout):
+// its own copy per call site, so that the compares are made where they are used (one v_cmp each) instead of once at the top of the kernel -- where every lane predicate of
+// every inlined phase then lives in an SGPR pair across the whole step loop, i.e. in a spill lane of a VGPR (v_writelane / two v_readlane per use: r05 code object, 1 036 of them)
+// (-DPL_LANE_OPAQUE=0: off; =1: every lane_id(), including the particle phases' lane / N_r arithmetic)
+#ifndef PL_LANE_OPAQUE
+#define PL_LANE_OPAQUE 0
+#endif
+#if PL_LANE_OPAQUE + 0 == 1 && !defined(PL_WAVE_EMU)
+__device__ __forceinline__ int lane_id() { int i = (int)threadIdx.x & (WAVE - 1); __asm__ volatile("" : "+v"(i)); return i; }
+#else
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x & (WAVE - 1); }
+#endif
+#if PL_LANE_OPAQUE + 0 >= 1 && !defined(PL_WAVE_EMU)
+__device__ __forceinline__ int lane_id_pred() { int i = (int)threadIdx.x & (WAVE - 1); __asm__ volatile("" : "+v"(i)); return i; }
+#else
+__device__ __forceinline__ int lane_id_pred() { return (int)threadIdx.x & (WAVE - 1); }
+#endif
 __device__ __forceinline__ int wave_id() { return (int)threadIdx.x >> 6; }     // 0 for the one-wave kernels; 0 / 1 for M::W2
 
 // Phase separator between LDS producers and consumers.  A workgroup here is exactly ONE wavefront, and the LDS instructions of one
@@ -509,6 +536,18 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 #endif
 
+// a set of wave-uniform values the compiler must have in registers HERE: one empty asm that reads them all -- the loads that produce them are issued together above it
+// and waited for once (LLVM otherwise sinks every load into the branch that uses it: one exposed LDS round trip per test, and a wave that runs alone on its SIMD has
+// nothing to hide it behind)
+#ifdef PL_WAVE_EMU
+template <class... T> __device__ __forceinline__ void pl_pin(const T&...) {}
+#else
+// (input-only: the values keep their identity -- and with it the compiler's knowledge that they are wave-uniform, i.e. scalar branches on them; an in/out operand made
+//  every test below a divergent one, with exec-mask bookkeeping around each arm)
+__device__ __forceinline__ void pl_pin1(const double& a) { __asm__ volatile("" :: "v"(a)); }
+template <class... T> __device__ __forceinline__ void pl_pin(const T&... v) { (pl_pin1(v), ...); }
+#endif
+
 // ---- reciprocal, quotient and square root without the IEEE corner-case scaffolding (r06) ----
 // hipcc lowers an fp64 division to v_div_scale x2 / v_rcp_f64 / 5 fma / v_mul / v_div_fmas / v_div_fixup: 11 dependent VALU instructions of which four only serve operands
 // outside the normal range, and `sqrt` to 16 (ldexp scaling, class test, selects).  Every operand of the step loop is a physical quantity well inside the normal range, and a
@@ -559,6 +598,24 @@ __device__ __forceinline__ void pl_sqrt_rsqrt(double x, double& s, double& rs) {
   r = __builtin_fma(-h, g, 0.5);
   h = __builtin_fma(h, r, h);
   s = g; rs = h + h;
+}
+#endif
+
+// x^(-1/n), n = 2 .. 6: IDA's step-size ratio (2 err + 1e-4)^(-1/(k+1)) (SUNRpowerR; the oracle calls pow).  ocml's fp64 log + exp are ~250 dependent instructions of
+// double-double arithmetic -- at every accepted step, for a number that is then clipped to [0.5, 0.9] or compared with 1 and 2.  Here: the fp32 transcendental unit's log2 / exp2
+// for seven digits, then two Newton steps on y^-n = x in fp64 (error (n+1)/2 d^2: 4e-7 -> 6e-13 -> rounding): ~25 instructions, within 1-2 ulp of the exact power like pow itself.
+#if defined(PL_WAVE_EMU) || defined(PL_IEEE_DIV)
+__device__ __forceinline__ double pl_inv_root(double x, int n) { return exp(-log(x) / n); }
+#else
+__device__ __forceinline__ double pl_inv_root(double x, int n) {
+  const double rn = n == 2 ? 0.5 : n == 3 ? 1.0 / 3 : n == 4 ? 0.25 : n == 5 ? 0.2 : 1.0 / 6;          // (n = k + 1 with the BDF order k = 1 .. 5)
+  double y = (double)__builtin_amdgcn_exp2f(-__builtin_amdgcn_logf((float)x) * (float)rn);
+  _Pragma("unroll") for (int it = 0; it < 2; it++) {
+    double p = y * y;
+    if (n == 3) p *= y; else if (n == 4) p *= p; else if (n == 5) p = p * p * y; else if (n != 2) p = p * p * p;
+    y = __builtin_fma(y * rn, __builtin_fma(-x, p, 1.0), y);
+  }
+  return y;
 }
 #endif
 
@@ -796,6 +853,14 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
     c.rsg_p = 1.0 / c.sig_p; c.rsg_n = 1.0 / c.sig_n; c.rcm_p = 1.0 / c.cmaxp; c.rcm_n = 1.0 / c.cmaxn;
     c.Dh_ps = hmean(c.beta_ps, c.Dc[0], c.Dc[1]); c.Dh_sn = hmean(c.beta_sn, c.Dc[1], c.Dc[2]);   // D_eff_linear: constant edge means
     S.tb = tb;
+    if constexpr (!M::THERMAL) {
+      for (int q = 0; q < 3; q++) {
+        const bool pq = q == 0;
+        S.nt.sec[q] = {c.h[q], c.eps[q], c.bf[q], c.Dc[q], c.rh[q], c.reps[q], pq ? c.a_p : c.a_n, pq ? c.cmaxp : c.cmaxn, pq ? c.kp : c.kn, pq ? c.rsg_p : c.rsg_n, pq ? c.rcm_p : c.rcm_n, 0.0};
+        S.nt.edge[q] = {0.5, c.rh[q], c.Dc[q], 0.0};
+      }
+      S.nt.edge[3] = {c.beta_ps, c.rd_ps, c.Dh_ps, 0.0}; S.nt.edge[4] = {c.beta_sn, c.rd_sn, c.Dh_sn, 0.0};
+    }
     c.R_SEI = c.rkag = c.Mrho = c.i0F = c.wexp = c.Uref = 0.0;
     c.EaKp = c.EaKn = c.EaDp = c.EaDn = 0.0; c.Tamb = 0.0;
     {   // quadratic / polynomial particle models (aux...jl:212-248, residuals.jl:108-127, 237-258); D_s_eff = D_s * Arrhenius factor
@@ -896,7 +961,7 @@ template <bool WANT_RES, bool WANT_JAC, class M>
 PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, double* Fo, int mode, double value) {
   PL_MODEL(M);
   if constexpr (M::W2) { if (wave_id() != 0) return; }       // two waves per cell: the finite-volume rows belong to wave 0
-  const int lane = lane_id();
+  const int lane = lane_id_pred();
   const CellConst& c = S.cc;
   const int i = lane < NE ? lane : NE - 1;
   const bool act = lane < NE;
@@ -921,17 +986,18 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   if constexpr (M::SEI) { js = Y[O_JS + ks]; film = Y[O_FILM + ks]; if (WANT_RES) ypfilm = YP[O_FILM + ks]; if (sc != 2) { js = 0.0; film = 0.0; } }
   const double cRSEI = c.R_SEI, crkag = c.rkag, cMrho = c.Mrho, ci0F = c.i0F, cwexp = c.wexp, cUref = c.Uref;
   const double Rfilm = cRSEI + film * crkag;
-  const double h0 = c.h[0], h1 = c.h[1], h2 = c.h[2], e0 = c.eps[0], e1 = c.eps[1], e2 = c.eps[2];
-  const double bf0 = c.bf[0], bf1 = c.bf[1], bf2 = c.bf[2], dc0 = c.Dc[0], dc1 = c.Dc[1], dc2 = c.Dc[2];
   const double cT0 = c.T0, cKfac = c.Kfac, ctplus = c.tplus, cfRT = c.fRT, cI1C = c.I1C;
-  const double ca_p = c.a_p, ca_n = c.a_n, csg_p = c.sig_p, csg_n = c.sig_n, ckp = c.kp, ckn = c.kn, ccmp = c.cmaxp, ccmn = c.cmaxn;
   const int ciso = c.iso_ref;
-  const double h = sc == 0 ? h0 : (sc == 1 ? h1 : h2);
-  const double epsc = sc == 0 ? e0 : (sc == 1 ? e1 : e2);
-  const double bfc = sc == 0 ? bf0 : (sc == 1 ? bf1 : bf2);
+  // the constants of this lane's section and edge: one table row each, read with a per-lane address (NodeTab)
+  const typename NodeTab<true>::Sec& qs = S.nt.sec[sc];
+  const int ek = i == NP - 1 ? 3 : (i == NP + NS - 1 ? 4 : sc);
+  const typename NodeTab<true>::Edge& qe = S.nt.edge[ek];
+  const double h = qs.h, epsc = qs.eps, bfc = qs.bf;
   // divisions by per-cell constants are multiplications by reciprocals formed once in cell_setup (an fp64 division costs ~80 cycles of
   // dependent latency on gfx950; the results differ from the reference's by one rounding, far below the 1e-12 residual parity bar)
-  const double rh = c.rh[sc], reps = c.reps[sc];
+  const double rh = qs.rh, reps = qs.reps;
+  const double a = qs.a, cmax = qs.cmax, kk = qs.kk, rsg = qs.rsg, rcm = qs.rcm, dcs = qs.Dc;
+  const double beta = qe.beta, rdist = qe.rdist, Dh_edge = qe.Dh;
  double K, dK;
   if (M::CHEM == PLH_CHEM_LGM50) keff_lgm50(ce, K, dK); else keff(ce, cT0, K, dK);
   K *= bfc; dK *= bfc;
@@ -942,19 +1008,16 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
     dnu = (-0.12 / sx + 1.5 * tfac * sx) * 1e-3;
   }
   double D, dD;
-  if (M::CHEM == PLH_CHEM_LCO_LIC6) { D = sc == 0 ? dc0 : (sc == 1 ? dc1 : dc2); dD = 0.0; }
+  if (M::CHEM == PLH_CHEM_LCO_LIC6) { D = dcs; dD = 0.0; }
   else if (M::CHEM == PLH_CHEM_LGM50) { deff_lgm50(ce, c.De, D, dD); D *= bfc; dD *= bfc; }
   else { deff_nmc(ce, cT0, D, dD); D *= bfc; dD *= bfc; }
   const double ce_n = shift_down1(ce), pe_n = shift_down1(pe), K_n = shift_down1(K), dK_n = shift_down1(dK), D_n = shift_down1(D);
   const double dD_n = (WANT_JAC && M::CHEM != PLH_CHEM_LCO_LIC6) ? shift_down1(dD) : 0.0;
   // edge i : geometry (numerical_tools.jl:106-215)
-  double beta = 0.5, rdist = rh;
-  if (i == NP - 1) { beta = c.beta_ps; rdist = c.rd_ps; }
-  if (i == NP + NS - 1) { beta = c.beta_sn; rdist = c.rd_sn; }
   const bool edge = i < NE - 1;
   const double rdenK = pl_rcp(beta * K_n + (1 - beta) * K), Kh = K * K_n * rdenK;
   double rdenD = 0.0, Dh;
-  if (M::CHEM == PLH_CHEM_LCO_LIC6) Dh = (i == NP - 1) ? c.Dh_ps : ((i == NP + NS - 1) ? c.Dh_sn : D);   // constant D: no division
+  if (M::CHEM == PLH_CHEM_LCO_LIC6) Dh = Dh_edge;                                                        // constant D: the edge means are constants too (no division)
   else { rdenD = pl_rcp(beta * D_n + (1 - beta) * D); Dh = D * D_n * rdenD; }
   const double denC = beta * ce_n + (1 - beta) * ce;
   const double rcb = denC * pl_rcp(ce * ce_n);             // 1 / (harmonic mean of c_e at the edge)
@@ -972,16 +1035,11 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
   // PLH_PREC_F64_REFORDER: the matrix-form rows need the left neighbour's states and the left edge's coefficients
   [[maybe_unused]] double ce_pv = 0.0, pe_pv = 0.0, w_m = 0.0, dcoef = 0.0, dcoef_m = 0.0;
   if constexpr (M::REFORD) { ce_pv = shift_up1(ce); pe_pv = shift_up1(pe); w_m = shift_up1(w); dcoef = Dh * rdist; dcoef_m = shift_up1(dcoef); }
-  const double Em = i > 0 ? E_p : 0.0, Nm = i > 0 ? Nf_p : 0.0, gm = i > 0 ? g_p : 0.0;
+  const double Em = E_p, Nm = Nf_p, gm = g_p;             // (shift_up1 hands lane 0 a zero: the left edge of the first control volume carries no flux)
   // electrode quantities
-  const double a = sc == 0 ? ca_p : ca_n;
   const double jv = elec ? jv_l : 0.0;
   const double ps = elec ? ps_l : 0.0;
   const double cs = elec ? cs_l : 1.0;
-  const double cmax = sc == 0 ? ccmp : ccmn;
-  const double kk = sc == 0 ? ckp : ckn;
-  const double sg = sc == 0 ? csg_p : csg_n;
-  const double rsg = sc == 0 ? c.rsg_p : c.rsg_n, rcm = sc == 0 ? c.rcm_p : c.rcm_n;
   double U = 0, dU = 0;
   if (M::CHEM == PLH_CHEM_LCO_LIC6) {
     if (sc == 0) ocv_lco(cs * rcm, cT0, ciso, U, dU);
@@ -1282,14 +1340,16 @@ __device__ __forceinline__ double u22_of(int n) { return (n < NE - 1 && sec_of(n
 template <class M>
 __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only, double& r0, double& r1, double& r2) {
   PL_MODEL(M);
-  const int lane = lane_id();
+  const int lane = lane_id_pred();
   const int nd = tw_node(lane);
   const bool act = nd >= 0, top = lane < TW_MID;
   const int i = act ? nd : 0;
   // every load is unconditional (i is a valid node in every lane) and masked afterwards: a guarded load `act ? S.x[i] : 0` compiles to one
   // exec-masked branch per element, which serialises the loads of this prologue
+  // (r06: no masks on the factors.  An idle lane reads node 0's: the head of the forward chain, whose L D'^-1 is ZERO -- with its right-hand side zeroed below its
+  //  recurrence stays at zero whatever its neighbours hold --, and the closing block multiplies a broadcast that is masked instead of its nine entries: 48 selects less)
   double C[9], Di[9], G[9], Lm[9];
-  for (int k = 0; k < 9; k++) { const double c = S.LD[k][i], d = S.Dinv[k][i], l = S.LDmid[k]; C[k] = act ? c : 0.0; Di[k] = act ? d : 0.0; Lm[k] = nd == TW_MID ? l : 0.0; }
+  for (int k = 0; k < 9; k++) { C[k] = S.LD[k][i]; Di[k] = S.Dinv[k][i]; Lm[k] = S.LDmid[k]; }
   {   // back-substitution block: top x_n = z_n - Dinv U_n x_{n+1}; bottom x_n = z_n - Dinv L_n x_{n-1}; node TW_MID is closed (G = 0)
     const bool z = !act || nd == TW_MID;
     const double ceu = S.ceU[i], cel = S.ceL[i], pcu = S.pcU[i], pcl = S.pcL[i], peu = S.peU[i], pel = S.peL[i];
@@ -1341,7 +1401,9 @@ __device__ __forceinline__ void thomas_sweeps(const CellLDS<M>& S, bool alg_only
 #undef PL_FWD_STAGE
   }
   {   // closing node: y_mid -= (L_mid Dinv_{mid-1}) y_{mid-1}
-    const double m0 = lane_bcast(y0, TW_MID - 1), m1 = lane_bcast(y1, TW_MID - 1), m2 = lane_bcast(y2, TW_MID - 1);
+    const bool mid = nd == TW_MID;
+    const double b0 = lane_bcast(y0, TW_MID - 1), b1 = lane_bcast(y1, TW_MID - 1), b2 = lane_bcast(y2, TW_MID - 1);
+    const double m0 = mid ? b0 : 0.0, m1 = mid ? b1 : 0.0, m2 = mid ? b2 : 0.0;
     y0 = PL_NMS3(y0, Lm[0], m0, Lm[1], m1, Lm[2], m2); y1 = PL_NMS3(y1, Lm[3], m0, Lm[4], m1, Lm[5], m2); y2 = PL_NMS3(y2, Lm[6], m0, Lm[7], m1, Lm[8], m2);
   }
   double z0 = Di[0] * y0 + Di[1] * y1 + Di[2] * y2, z1 = Di[3] * y0 + Di[4] * y1 + Di[5] * y2, z2 = Di[6] * y0 + Di[7] * y1 + Di[8] * y2;
@@ -1595,7 +1657,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   double bjp = 0.0, bjs = 0.0, bfl = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0;
   [[maybe_unused]] double bca = 0.0, bq = 0.0;       // right-hand sides of the c_avg / Q rows of this node (quadratic / polynomial particles)
   int jx = 0; bool elec = false, sei_node = false;
-  const int nd = tw_node(lane);                 // node of this lane in the twisted layout of thomas_sweeps (-1: idle)
+  const int nd = tw_node(lane_id_pred());       // node of this lane in the twisted layout of thomas_sweeps (-1: idle)
   if constexpr (M::SD == 0 && !M::SEI) {       // (measured: +1.5 % on the isothermal kernels, -2 % with SEI, whose integrate kernel is already spilling: selected per model)
     // every LDS operand of this phase is loaded unconditionally, with indices clamped into range for the lanes / nodes that do not use it, and selected afterwards:
     // loads under the nested `if`s (node lane? electrode node? current mode?) were three dependent LDS round trips

@@ -352,21 +352,26 @@ PL_DEV double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
   const int kk = I.kk; const double hh = I.hh;
   if (hh != I.hused || kk != I.kused) I.ns = 0;
   I.ns = (I.ns + 1 < I.kused + 2) ? I.ns + 1 : I.kused + 2;
-  double alphas = 0.0, alpha0 = 0.0;
+  double alphas = 0.0, alpha0 = 0.0, ak;
   const double rinv[MAXORD + 1] = {1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6};     // (compile-time quotients: identical values, no runtime division)
   if (kk + 1 >= I.ns) {
     // IDASetCoeffs recurrences; the divisions are done by lanes 0..kk in parallel, the (division-free) prefix products / sums by every lane from register broadcasts
     // (no LDS round trip per order), each lane m <= kk then stores entry m:
     //   psi_new[0] = h, psi_new[i] = psi_old[i-1] + h ; alpha[i] = h/psi_new[i] ; beta[i] = prod_{m<=i} psi_new[m-1]/psi_old[m-1] ;
     //   sigma[i] = i sigma[i-1] alpha[i] ; gamma[i] = gamma[i-1] + alpha[i-1]/h
+    // (loads with clamped indices and all four quotients unconditionally, selected afterwards: a guarded load or quotient is an exec-masked branch of its own, and four
+    //  quotients in four basic blocks are four dependent chains one after the other instead of four interleaved ones)
     const int i = lane <= kk ? lane : 0;
-    const double po_im1 = i > 0 ? S.ida_psi[i - 1] : 1.0, po_im2 = i > 1 ? S.ida_psi[i - 2] : 1.0;
+    const double ld1 = S.ida_psi[i > 0 ? i - 1 : 0], ld2 = S.ida_psi[i > 1 ? i - 2 : 0];
+    const double po_im1 = i > 0 ? ld1 : 1.0, po_im2 = i > 1 ? ld2 : 1.0;
     const double pn_i = i > 0 ? po_im1 + hh : hh;
     const double pn_im1 = i > 1 ? po_im2 + hh : hh;
-    const double al = i > 0 ? pl_div(hh, pn_i) : 1.0;
-    const double q = i > 0 ? pl_div(pn_im1, po_im1) : 1.0;
-    const double al_prev = i > 1 ? pl_div(hh, pn_im1) : 1.0;
-    const double g = i > 0 ? pl_div(al_prev, hh) : 0.0;
+    const double d_al = pl_div(hh, pn_i), d_q = pl_div(pn_im1, po_im1), d_ap = pl_div(hh, pn_im1);
+    const double al = i > 0 ? d_al : 1.0;
+    const double q = i > 0 ? d_q : 1.0;
+    const double al_prev = i > 1 ? d_ap : 1.0;
+    const double d_g = pl_div(al_prev, hh);
+    const double g = i > 0 ? d_g : 0.0;
     double bm = 1.0, sg = 1.0, gm = 0.0, myb = q, mys = 1.0, myg = g;
     _Pragma("unroll") for (int m = 1; m <= MAXORD; m++) if (m <= kk) {
       const double qm = lane_bcast(q, m), am = lane_bcast(al, m), gmm = lane_bcast(g, m);
@@ -374,14 +379,15 @@ PL_DEV double ida_set_coeffs(CellLDS<M>& S, IdaScalars& I) {
       if (lane == m) { myb = bm; mys = sg; myg = gm; }
     }
     _Pragma("unroll") for (int m = 0; m < MAXORD; m++) if (m < kk) { alphas -= rinv[m]; alpha0 -= lane_bcast(al, m); }
+    ak = lane_bcast(al, kk);                         // alpha[kk] (from the register of lane kk: no LDS round trip behind the stores below)
     PL_XSYNC();                                      // (every lane has read the old psi)
     if (lane <= kk && wave_id() == 0) { S.ida_psi[lane] = pn_i; S.ida_alpha[lane] = al; S.ida_beta[lane] = myb; S.ida_sigma[lane] = mys; S.ida_gamma[lane] = myg; }
     PL_XSYNC();
   } else {
     for (int m = 0; m < kk; m++) { alphas -= (m == 0 ? rinv[0] : m == 1 ? rinv[1] : m == 2 ? rinv[2] : m == 3 ? rinv[3] : rinv[4]); alpha0 -= S.ida_alpha[m]; }
+    ak = S.ida_alpha[kk];
   }
   I.cjlast = I.cj; I.cj = pl_div(-alphas, hh);
-  const double ak = S.ida_alpha[kk];
   double ck = fabs(ak + alphas - alpha0); if (ck < ak) ck = ak;
   // (IDASetCoeffs' rescaling phi[m] *= beta[m], m = ns .. kk, is done by the first form_iterate of the step, in the pass that sums the predictor anyway: same
   //  products, one pass over the history less; ida_restore undoes it from the same beta / ns)
@@ -639,14 +645,14 @@ PL_DEV bool ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double
       if constexpr (PHI_REGS<M>) {
         _Pragma("unroll") for (int j = 2; j <= MAXORD; j++) if (j == I.kk + 1) { PL_VEC(n) { const double p = (EE(n) - PHI_RD(j, n)) * EWT(n); s += p * p; } }
       } else { PL_VEC(n) { const double p = (EE(n) - PHI_RD(I.kk + 1, n)) * EWT(n); s += p * p; } }
-      const double enorm = sqrt(block_sum<M>(S, s) * (1.0 / NST)); err_kp1 = enorm / (I.kk + 2);
+      const double enorm = pl_sqrt(block_sum<M>(S, s) * (1.0 / NST)); err_kp1 = pl_div(enorm, (double)(I.kk + 2));
       const double terr_k = (I.kk + 1) * err_k, terr_kp1 = (I.kk + 2) * err_kp1;
       if (I.kk == 1) action = (terr_kp1 >= 0.5 * terr_k) ? 2 : 3;
       else { const double terr_km1 = I.kk * err_km1;
         if (terr_km1 <= (terr_k < terr_kp1 ? terr_k : terr_kp1)) action = 1; else if (terr_kp1 >= terr_k) action = 2; else action = 3; }
     }
     if (action == 3) { I.kk++; err_knew = err_kp1; } else if (action == 1) { I.kk--; err_knew = err_km1; } else err_knew = err_k;
-    double hnew = I.hh; I.rr = exp(-log(2.0 * err_knew + 0.0001) / (I.kk + 1));   // = (2 err + 1e-4)^(-1/(k+1))
+    double hnew = I.hh; I.rr = pl_inv_root(2.0 * err_knew + 0.0001, I.kk + 1);   // = (2 err + 1e-4)^(-1/(k+1))
     if (I.rr >= 2.0) hnew = 2.0 * I.hh;
     else if (I.rr <= 1.0) { I.rr = I.rr < 0.9 ? I.rr : 0.9; I.rr = I.rr > 0.5 ? I.rr : 0.5; hnew = I.hh * I.rr; }
     I.hh = hnew;
@@ -656,12 +662,16 @@ PL_DEV bool ida_complete_step(CellLDS<M>& S, IdaScalars& I, double err_k, double
   // d_{j-1} of IDAGetSolution at t = tn (delt = 0: c_j = 0 for j >= 1, gam_j = psi[j-1] / psi[j]); the reciprocals of psi by lanes 0..ku in parallel as in ida_get_solution
   double dc1 = 0, dc2 = 0, dc3 = 0, dc4 = 0, dc5 = 0;
   if (!at_tstop) {
-    const double rp_mine = pl_rcp(S.ida_psi[lane <= MAXORD ? lane : MAXORD]);
+    const double ps0 = S.ida_psi[0], ps1 = S.ida_psi[1], ps2 = S.ida_psi[2], ps3 = S.ida_psi[3], ps4 = S.ida_psi[4];      // (one batch of loads: the steps below are wave-uniform branches)
+    const double ps_mine = S.ida_psi[lane <= MAXORD ? lane : MAXORD];
+    pl_pin(ps0, ps1, ps2, ps3, ps4, ps_mine);
+    const double ps_of[5] = {ps0, ps1, ps2, ps3, ps4};
+    const double rp_mine = pl_rcp(ps_mine);
     const double rp0 = lane_bcast(rp_mine, 0), rp1 = lane_bcast(rp_mine, 1), rp2 = lane_bcast(rp_mine, 2), rp3 = lane_bcast(rp_mine, 3), rp4 = lane_bcast(rp_mine, 4),
                  rp5 = lane_bcast(rp_mine, 5);
     const double delt = 0.0;
     double c = 1.0, d = 0.0, gam = delt * rp0;
-#define PL_GS_STEP(J, RPJM1, RPJ, DV) if (J <= ku) { d = d * gam + c * RPJM1; c = c * gam; gam = (delt + S.ida_psi[J - 1]) * RPJ; DV = d; }
+#define PL_GS_STEP(J, RPJM1, RPJ, DV) if (J <= ku) { d = d * gam + c * RPJM1; c = c * gam; gam = (delt + ps_of[J - 1]) * RPJ; DV = d; }
     PL_GS_STEP(1, rp0, rp1, dc1) PL_GS_STEP(2, rp1, rp2, dc2) PL_GS_STEP(3, rp2, rp3, dc3) PL_GS_STEP(4, rp3, rp4, dc4) PL_GS_STEP(5, rp4, rp5, dc5)
 #undef PL_GS_STEP
   }
@@ -838,7 +848,7 @@ PL_DEV int ida_step(CellLDS<M>& S, LaneRegs& R, const Tables* tb, IdaScalars& I,
       } else {
         cnt_add(cnt, C_ERRFAIL); nef++;
         if (nef == 1) { const double err_knew = (I.kk == I.knew) ? err_k : err_km1; I.kk = I.knew;
-          I.rr = 0.9 * exp(-log(2.0 * err_knew + 0.0001) / (I.kk + 1)); I.rr = I.rr < 0.9 ? I.rr : 0.9; I.rr = I.rr > 0.25 ? I.rr : 0.25; I.hh *= I.rr; }
+          I.rr = 0.9 * pl_inv_root(2.0 * err_knew + 0.0001, I.kk + 1); I.rr = I.rr < 0.9 ? I.rr : 0.9; I.rr = I.rr > 0.25 ? I.rr : 0.25; I.hh *= I.rr; }
         else if (nef == 2) { I.kk = I.knew; I.rr = 0.25; I.hh *= I.rr; }
         else if (nef < 10) { I.kk = 1; I.rr = 0.25; I.hh *= I.rr; }
         else return PLH_ERR_STALL;
@@ -876,16 +886,6 @@ __device__ __forceinline__ double cellTavg(const CellLDS<M>& S, const double* Y)
   if constexpr (M::THERMAL) { const int lane = lane_id(); return wave_sum(lane < NT ? S.th.wT5[tsec_of(lane)] * Y[M::O_T + lane] : 0.0); }
   else return S.cc.T0;
 }
-
-// a set of wave-uniform values the compiler must have in registers HERE: one empty asm that reads them all -- the loads that produce them are issued together above it
-// and waited for once (LLVM otherwise sinks every load into the branch that uses it: one exposed LDS round trip per test, and a wave that runs alone on its SIMD has
-// nothing to hide it behind)
-#ifdef PL_WAVE_EMU
-template <class... T> __device__ __forceinline__ void pl_pin(T&...) {}
-#else
-__device__ __forceinline__ void pl_pin1(double& a) { __asm__ volatile("" : "+v"(a)); }
-template <class... T> __device__ __forceinline__ void pl_pin(T&... v) { (pl_pin1(v), ...); }
-#endif
 
 template <int F = 0, class M>
 PL_DEV void check_stop(CellLDS<M>& S, const plh_run& run, const plh_opts& o, double t, double tf, const double* Y, const double* YP,
@@ -996,18 +996,16 @@ PL_DEV void cell_simulate(CellLDS<M>& S, LaneRegs& R, const Tables* tb, double S
     if (lane == 0 && wave_id() == 0) { S.carry[0] = SOC0; S.carry[1] = 0.0; S.carry[2] = 0.0; S.carry[3] = 0.0; S.carry[4] = 0.0; }
   }
   PL_XSYNC();
+  double* const outp = wave_id() != 0 ? nullptr : (lane == 0 ? out.t : (lane == 1 ? out.V : (lane == 2 ? out.I : (lane == 3 ? out.SOC : (lane == 4 ? out.T : nullptr)))));
   auto save_pt = [&](int idx, double tt, const double* Y, double soc) {
     const double Tav = (M::THERMAL && out.T) ? cellTavg<M>(S, Y) : T0;
     if constexpr ((F & GF_STOPS) != 0) if (out.Yall && idx < out.max_pts) { PL_VECG(n) out.Yall[(size_t)idx * NST + n] = Y[n]; }      // outputs = :all
-    double Vv = cellV<M>(Y), Iv = Y[O_I];                              // (read by every lane AHEAD of the one-lane store block: no LDS round trip inside it)
+    double Vv = cellV<M>(Y), Iv = Y[O_I];                              // (read by every lane AHEAD of the store: no LDS round trip under the lane mask)
     pl_pin(Vv, Iv);
-    if (lane == 0 && wave_id() == 0 && idx < out.max_pts) {
-      if (out.t) out.t[idx] = tt;
-      if (out.V) out.V[idx] = Vv;
-      if (out.I) out.I[idx] = Iv;
-      if (out.SOC) out.SOC[idx] = soc;
-      if (out.T) out.T[idx] = Tav;
-    }
+    // r06: lanes 0 .. 4 each own ONE of the five per-point output arrays (pointer in the lane: outp) and store their value with one instruction; r05 had lane 0 walk five
+    // `if (pointer) store` blocks whose addresses were rebuilt from spilled scalar registers every step (~100 instructions per saved point)
+    const double val = lane == 0 ? tt : (lane == 1 ? Vv : (lane == 2 ? Iv : (lane == 3 ? soc : Tav)));
+    if (outp && idx < out.max_pts) outp[idx] = val;
   };
   for (int r = 0; r < n_runs; r++) {
     // the run descriptor is staged in LDS once per run: reading it from global memory in every step costs ~1.4 k cycles per step (scalar

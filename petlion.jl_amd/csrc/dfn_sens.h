@@ -82,7 +82,13 @@ PL_DEV void sens_consts(CellLDS<M>& S, const SensCell<M>& X) {
     for (int k = lane; k < nt; k += WAVE) { if (SAVE) b[o + k] = t0[k]; else t0[k] = b[o + k]; }
     o += nt;
   }
-  if constexpr (M::SEI) { for (int k = lane; k < NN; k += WAVE) { if (SAVE) b[o + k] = S.sei.sohw[k]; else S.sei.sohw[k] = b[o + k]; } }
+  if constexpr (M::SEI) { for (int k = lane; k < NN; k += WAVE) { if (SAVE) b[o + k] = S.sei.sohw[k]; else S.sei.sohw[k] = b[o + k]; } o += NN; }
+  if constexpr (!M::THERMAL) {                              // the node-pass tables (NodeTab): copies of CellConst entries
+    constexpr int NTB = (int)(sizeof(S.nt) / sizeof(double));
+    static_assert(NC + NN + NTB <= SENS_CBAK, "SENS_CBAK");
+    double* t0 = reinterpret_cast<double*>(&S.nt);
+    for (int k = lane; k < NTB; k += WAVE) { if (SAVE) b[o + k] = t0[k]; else t0[k] = b[o + k]; }
+  }
   PL_XSYNC();
 }
 

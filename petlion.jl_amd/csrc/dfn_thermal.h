@@ -40,30 +40,35 @@ __device__ __forceinline__ void ocv_lco_T(double x, double T, double& U, double&
   const double d = 1 - 5.661479886999997 * x + 11.47636191 * x2 - 9.82431213599998 * x3 + 3.048755063 * x4;
   const double dn = -0.928373822 + 2 * 1.364550689000003 * x - 3 * 0.6115448939999998 * x2;
   const double dd = -5.661479886999997 + 2 * 11.47636191 * x - 3 * 9.82431213599998 * x2 + 4 * 3.048755063 * x3;
-  dUdT = -0.001 * n / d;
-  ddUdT = -0.001 * (dn * d - n * dd) / (d * d);
-  U = P / Q + dUdT * (T - TREF);
-  dUdx = (dP * Q - P * dQ) / (Q * Q) + ddUdT * (T - TREF);
+  const double rd = pl_rcp(d), rQ = pl_rcp(Q), nd = n * rd, PQ = P * rQ;      // (one reciprocal per rational function serves its value and its derivative: dfn_cell.h ocv_lco)
+  dUdT = -0.001 * nd;
+  ddUdT = -0.001 * (dn - nd * dd) * rd;
+  U = PQ + dUdT * (T - TREF);
+  dUdx = (dP - PQ * dQ) * rQ + ddUdT * (T - TREF);
 }
 
 // OCV_LiC6, custom_functions.jl:139-152
 __device__ __forceinline__ void ocv_lic6_T(double x, double T, double& U, double& dUdx, double& dUdT, double& ddUdT) {
-  const double s0 = sqrt(x > 0.0 ? x : 0.0);
-  const double xm = x > 1e-4 ? x : 1e-4;
-  const double s1 = sqrt(xm);
+  // (1 / x and 1 / sqrt(max(x, 1e-4)) once, as in dfn_cell.h ocv_lic6)
+  const bool big = x > 1e-4;
+  const double xm = big ? x : 1e-4;
+  double s1, rs1; pl_sqrt_rsqrt(xm, s1, rs1);
+  double s0 = s1, rs0 = rs1;
+  if (!big) { s0 = sqrt(x > 0.0 ? x : 0.0); rs0 = 1.0 / s0; }
+  const double rx = pl_rcp(x), rx2 = rx * rx;
   const double e1 = exp(0.9 - 15 * x), e2 = exp(0.4465 * x - 0.4108);
-  U = 0.7222 + 0.1387 * x + 0.029 * s0 - 0.0172 / x + 0.0019 / (s1 * x) + 0.2808 * e1 - 0.7984 * e2;
-  double dv = 0.1387 + 0.0172 / (x * x) - 0.2808 * 15 * e1 - 0.7984 * 0.4465 * e2;
-  if (x > 0.0) dv += 0.029 * 0.5 / s0;
-  if (x > 1e-4) dv += 0.0019 * (-1.5) / (x * x * s1);
-  else dv += -0.0019 / (s1 * x * x);
+  U = 0.7222 + 0.1387 * x + 0.029 * s0 - 0.0172 * rx + 0.0019 * (rs1 * rx) + 0.2808 * e1 - 0.7984 * e2;
+  double dv = 0.1387 + 0.0172 * rx2 - 0.2808 * 15 * e1 - 0.7984 * 0.4465 * e2;
+  if (x > 0.0) dv += 0.029 * 0.5 * rs0;
+  dv += (big ? 0.0019 * (-1.5) : -0.0019) * (rx2 * rs1);
   const double x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x, x6 = x3 * x3, x7 = x6 * x, x8 = x4 * x4;
   const double n = 0.001 * (0.005269056 + 3.299265709 * x - 91.79325798 * x2 + 1004.911008 * x3 - 5812.278127 * x4 + 19329.7549 * x5 - 37147.8947 * x6 + 38379.18127 * x7 - 16515.05308 * x8);
   const double q = 1 - 48.09287227 * x + 1017.234804 * x2 - 10481.80419 * x3 + 59431.3 * x4 - 195881.6488 * x5 + 374577.3152 * x6 - 385821.1607 * x7 + 165705.8597 * x8;
   const double dn = 0.001 * (3.299265709 - 2 * 91.79325798 * x + 3 * 1004.911008 * x2 - 4 * 5812.278127 * x3 + 5 * 19329.7549 * x4 - 6 * 37147.8947 * x5 + 7 * 38379.18127 * x6 - 8 * 16515.05308 * x7);
   const double dq = -48.09287227 + 2 * 1017.234804 * x - 3 * 10481.80419 * x2 + 4 * 59431.3 * x3 - 5 * 195881.6488 * x4 + 6 * 374577.3152 * x5 - 7 * 385821.1607 * x6 + 8 * 165705.8597 * x7;
-  dUdT = n / q;
-  ddUdT = (dn * q - n * dq) / (q * q);
+  const double rq = pl_rcp(q);
+  dUdT = n * rq;
+  ddUdT = (dn - dUdT * dq) * rq;
   U += dUdT * (T - TREF);
   dUdx = dv + ddUdT * (T - TREF);
 }
@@ -177,14 +182,14 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
   if (i == NP - 1) { beta = c.beta_ps; rdist = c.rd_ps; }
   if (i == NP + NS - 1) { beta = c.beta_sn; rdist = c.rd_sn; }
   const bool edge = i < NE - 1;
-  const double rdenK = 1.0 / (beta * K_n + (1 - beta) * K), Kh = K * K_n * rdenK;
+  const double rdenK = pl_rcp(beta * K_n + (1 - beta) * K), Kh = K * K_n * rdenK;
   const double D_n = shift_down1(D);
   const double dD_n = (WANT_JAC && LGM) ? shift_down1(dD) : 0.0;
   double rdenD = 0.0, Dhm;
-  if constexpr (LGM) { rdenD = 1.0 / (beta * D_n + (1 - beta) * D); Dhm = D * D_n * rdenD; }     // harmonic edge mean of D_eff(c_e)
+  if constexpr (LGM) { rdenD = pl_rcp(beta * D_n + (1 - beta) * D); Dhm = D * D_n * rdenD; }     // harmonic edge mean of D_eff(c_e)
   else Dhm = (i == NP - 1) ? c.Dh_ps : ((i == NP + NS - 1) ? c.Dh_sn : D);   // constant edge means of D_eff_linear (cell_setup)
-  const double denC = beta * ce_n + (1 - beta) * ce, rcb = denC / (ce * ce_n);
-  const double rdenT = 1.0 / (beta * T_n + (1 - beta) * T), Tb = T * T_n * rdenT;
+  const double denC = beta * ce_n + (1 - beta) * ce, rcb = denC * pl_rcp(ce * ce_n);
+  const double rdenT = pl_rcp(beta * T_n + (1 - beta) * T), Tb = T * T_n * rdenT;
   const double dc = (ce_n - ce) * rdist;
   const double w = Kh * rdist;
   const double g = Kh * Tb * dc * rcb;
@@ -199,7 +204,7 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
   const double jv = elec ? jv_l : 0.0, ps = elec ? ps_l : 0.0, cs = elec ? cs_l : 1.0;
   const double cmax = sc == 0 ? c.cmaxp : c.cmaxn;
   const double sg = sc == 0 ? c.sig_p : c.sig_n;
-  const double rT = 1.0 / T;
+  const double rT = pl_rcp(T);
   const double dinv = rT - 1.0 / TREF;
   const double EaK = sc == 0 ? c.EaKp : c.EaKn, EaD = sc == 0 ? c.EaDp : c.EaDn;
   const double kk = (sc == 0 ? c.kp : c.kn) * exp(-EaK * dinv);
@@ -216,7 +221,9 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
   }
   const double eta = ps - pe - U;
   const double arg = ce * cs * (cmax - cs);
-  const double sq = sqrt(arg > 0.0 ? arg : 0.0);
+  double sq, inv_sq;                                     // (dfn_cell.h iso_node_pass)
+  pl_sqrt_rsqrt(arg > 0.0 ? arg : 1.0, sq, inv_sq);
+  if (!(arg > 0.0)) { sq = 0.0; inv_sq = 0.0; }
   const double fRT = 0.5 * FAR / RGAS * rT;
   const double xx = fRT * eta;
   double sh, chh; sinh_cosh(xx, sh, chh);
@@ -272,7 +279,8 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
       }
       // residuals_T!, residuals.jl:299-489 ; heat sources aux...jl:344-518
       const double qrr = Faj * (T * dUdT + eta);
-      const double qohm = K * dPe * dPe + cKfac * K * T * (dce / ce) * dPe + (elec ? sg * dPs * dPs : 0.0);
+      const double rce = pl_rcp(ce);
+      const double qohm = K * dPe * dPe + cKfac * K * T * (dce * rce) * dPe + (elec ? sg * dPs * dPs : 0.0);
       // Conduction in DIFFERENCE form, aL (T_l - T) + aU (T_r - T)  (aD = -(aL + aU) on every interior row): the matrix form aL T_l + aD T + aU T_r of the reference
       // (residuals.jl:299-489) sums three terms of 6e6 K/s that cancel to ~0.1 K/s, i.e. carries 1e-9 K/s of rounding per row -- harmless for the row itself, but the
       // dT control row and its algebraic twin SUM the fifty rows (their conduction parts telescope to zero) and find the current from what is left: 1e-6 relative noise in I,
@@ -305,7 +313,7 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
     if (lane == 0) { TP.qIJ[0] = 2.0 * TP.qI[0] * yI; TP.qIJ[1] = 2.0 * TP.qI[1] * yI; }   // d(collector row)/dI (Joule heat ~ I^2)
     if (lane == 0) { S.ctrlJ[0] = yI * cI1C; S.ctrlJ[1] = (Y[O_PS] - Y[O_PS + NJ - 1]) * cI1C; }   // scalar_jacobian! of method_P
     const double dKh_a = beta * K_n * K_n * (rdenK * rdenK), dKh_b = (1 - beta) * K * K * (rdenK * rdenK);   // dKh/dK_i, dKh/dK_{i+1}
-    const double rdenC = 1.0 / denC;
+    const double rdenC = pl_rcp(denC);
     const double dcb_a = beta * ce_n * ce_n * (rdenC * rdenC), dcb_b = (1 - beta) * ce * ce * (rdenC * rdenC);
     const double dTb_a = beta * T_n * T_n * (rdenT * rdenT), dTb_b = (1 - beta) * T * T * (rdenT * rdenT);
     const double Tq = Tb * rdist;
@@ -338,8 +346,6 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
         TP.ptL[i] = 0; TP.ptD[i] = 0; TP.ptU[i] = 0;
       }
       if (elec) {
-        const double pos = arg > 0.0 ? 1.0 : 0.0;
-        const double inv_sq = pos > 0 ? 1.0 / sq : 0.0;
         S.gce[jx] = kk * sh * cs * (cmax - cs) * inv_sq;
         S.gcs[jx] = 2.0 * kk * (sh * ce * (cmax - 2 * cs) * 0.5 * inv_sq + sq * chh * fRT * (-dU * rcm));
         S.gps[jx] = 2.0 * kk * sq * chh * fRT;
@@ -350,14 +356,15 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
         TP.Tcs[jx] = rc * Faj * (T * ddUdT - dU) * rcm;
       }
       // T row: couplings to (c_e, Phi_e, Phi_s, T) of nodes i-1, i, i+1 (+ the second neighbour at the four one-sided stencils)
-      const double qPe = 2.0 * K * dPe + cKfac * K * T * (dce / ce);               // dQ/d(dPe)
-      const double qCe = cKfac * K * T * dPe / ce;                                   // dQ/d(dce)
+      const double rce = pl_rcp(ce);
+      const double qPe = 2.0 * K * dPe + cKfac * K * T * (dce * rce);               // dQ/d(dPe)
+      const double qCe = cKfac * K * T * dPe * rce;                                  // dQ/d(dce)
       const double qPs = elec ? 2.0 * sg * dPs : 0.0;                                // dQ/d(dPs)
-      const double qce_loc = dKc * dPe * dPe + cKfac * T * dPe * (dKc * dce / ce - K * dce / (ce * ce));
+      const double qce_loc = dKc * dPe * dPe + cKfac * T * dPe * (dKc * dce * rce - K * dce * (rce * rce));
       TP.TcL[i] = rc * qCe * em; TP.TcD[i] = rc * (qCe * e0 + qce_loc); TP.TcU[i] = rc * qCe * ep;
       TP.TeL[i] = rc * qPe * em; TP.TeD[i] = rc * (qPe * e0 - Faj); TP.TeU[i] = rc * qPe * ep;
       TP.TsL[i] = rc * qPs * sm; TP.TsD[i] = rc * (qPs * s0 + Faj); TP.TsU[i] = rc * qPs * sp;
-      TP.TtD[i] = rc * (dKT * dPe * dPe + cKfac * (dKT * T + K) * (dce / ce) * dPe);   // (the reversible + reaction heat has no net dT term)
+      TP.TtD[i] = rc * (dKT * dPe * dPe + cKfac * (dKT * T + K) * (dce * rce) * dPe);   // (the reversible + reaction heat has no net dT term)
       if (i == 0) { TP.TX2[0][0] = rc * qCe * e2; TP.TX2[0][1] = rc * qPe * e2; TP.TX2[0][2] = rc * qPs * s2; }
       if (i == NP - 1) { TP.TX2[1][0] = 0.0; TP.TX2[1][1] = 0.0; TP.TX2[1][2] = rc * qPs * s2; }
       if (i == NP + NS) { TP.TX2[2][0] = 0.0; TP.TX2[2][1] = 0.0; TP.TX2[2][2] = rc * qPs * s2; }

@@ -1,25 +1,24 @@
 """EVERY cell of the BASELINE configurations at full size against the oracle at the reference's DEFAULT tolerances (reltol 1e-3 / abstol 1e-6), as a pass / fail statement.
 
-What can be asserted at these tolerances, and why in this form (the reproducibility floor of the reference algorithm).  Two correct fp64 implementations of
-the reference's algorithm do not agree to 1e-6 per cell at reltol 1e-3: the finite-difference estimate of YP_alg in newtons_method! (model_evaluation.jl:462-477) turns last-bit
-differences of a residual evaluation into 1e-6 of h0, the whole step grid scales with h0, the reference's LINEAR back-interpolation of a run end (model_evaluation.jl:369-382)
-turns that into up to 1e-4 at a voltage knee, and a leg that starts from a :hold set point decorrelates altogether.  The oracle shows the same spread against ITSELF when
-EVERY residual evaluation is perturbed by one unit of evaluation rounding (orc_opts.fd_perturb for the finite difference of the initialisation, orc_opts.res_perturb for every
-evaluation of the corrector: res_i += 2.2e-16 u sum_c |J_ic Y_c|, a fresh u in [-1, 1) per row and evaluation) -- which is how a second correct implementation differs from the
-first: the flux form or the matrix form of a stencil, the order of a sum, in every evaluation.  So the statement is a two-sample one, over the full ensemble:
+What decides whether two correct fp64 implementations of the reference's algorithm take the SAME steps at these tolerances (r05; the r02-r04 "reproducibility
+floor" reading of this module was falsified there): the rounding of the Phi_s rows.  The notebook-pinned oracle variants (`lco_iso`, `lco_thermal`, `nmc_iso_sei`) sum a Phi_s
+row as the reference's generated code does, `-j x + Phi[i-1] - 2 Phi[i] + Phi[i+1]`: the source term joins a ~4 V potential before the Laplacian cancels, so the row is quantised
+at ulp(Phi_s), J^-1 turns that into 4e-8 ... 4e-7 of weighted-norm noise, and IDA's start-up order selection in a leg that restarts from a held set point reads it.  The device's
+default build forms the Laplacian first (`*_quiet` oracle variants: the same model, tied to the pinned ones row by row at 1e-12 and through every reference vector except the
+37-point hold leg -- tests/test_oracle_golden.py lists that one).  Hence two pairings, and nothing else:
 
-  (1) exit flags equal in every run of every cell (no tolerance), and
-  (2) the distribution of the device-vs-oracle deviation is no worse than the distribution of the oracle-vs-perturbed-oracle deviation ON THE SAME CELLS:
-      quantile_q(device vs oracle) <= 1.5 x quantile_q(perturbed oracle vs oracle) for q = 50 %, 90 %, 99 % (floored at 1e-7: below it both are rounding), for the end
-      state (max over the state sections of max|dY| / max|Y|: parity.state_rel_err) and for the run-end times;
-  (3) the fraction of cells with identical integrator decisions (all counters equal) is not smaller than the perturbed oracle's by more than 5 points.
-C3 is the one configuration in the BIMODAL regime: its two hold legs restart the integrator from a state that carries the previous leg's noise, and a cell either keeps identical
-decisions (deviation ~1e-7) or decorrelates (~1e-2) -- in the oracle against its perturbed self in 76 % of the cells, in the device against the oracle in 65-72 %.  The median of
-such a mixture sits in the lower part of the decorrelated mode and compares how that mode is populated: measured, the device's 1.2e-2 against the floor's 2.9e-3 -- 4x, NOT
-within 1.5x, and it is reported as such.  What is asserted for a configuration in that regime is the 90 % and 99 % quantiles within 1.5x (3.5e-2 / 7.2e-2 against 2.7e-2 / 5.3e-2),
-the median within the floor's own 90 % quantile, (1) and (3).
+  default build  <->  `*_quiet` oracle, ABSOLUTE thresholds: identical integrator decisions in >= 97 ... 100 % of the cells, end-state quantiles at rounding level; and for EVERY
+                      cell whose decisions differ (C3: tens of 4096, C4: tens of 65 536) the assertion "a different step sequence, the same accuracy": the device's error against
+                      that cell's reltol-1e-8 solution is at most 2 x the oracle's own (`divergent_cells_equally_accurate`);
+  `f64_reforder` build (the reference's evaluation order: what reproduces the reference's step sequences on hold legs, 11 % slower on C3)  <->  the plain, notebook-pinned oracle,
+                      two-sample criterion: exit flags equal in every run of every cell, quantile_q(device vs oracle) <= 1.5 x quantile_q(perturbed oracle vs oracle) for
+                      q = 50, 90, 99 % (end state and run-end times, floored at 1e-7), identical-decision fraction within 5 points of the perturbed oracle's.
 
-C2: 1024 cells (identical parameters: one oracle run serves all), C3: 4096, C4: every 8th of 65 536 (8192 cells; the launch is the full 65 536), C5: 8192 (40 runs per cell).
+Beside them ONE loose gate per configuration of the default build against the PLAIN oracle (the default build's distance from the reference's own rounding must stay
+bounded by an asserted number): flags equal in every cell, and end-state quantiles below fixed ceilings a little above what r05 measured -- C2 / C4 / C5 at rounding to 1e-3
+level, C3 (two hold legs: the default build does not take the plain oracle's step sequences there) p50 / p90 / p99 <= 3e-2 / 7e-2 / 1.5e-1.
+
+C2: 1024 cells (identical parameters), C3: 4096, C4: all 65 536 against the quiet oracle, every 8th against the plain one, C5: 8192 (40 runs per cell).
 The tight-tolerance suite (test_gpu_tight.py) is the per-cell 1e-6 statement; this module is the every-cell statement at the tolerances the benchmark runs at."""
 import os
 from concurrent.futures import ThreadPoolExecutor
@@ -47,9 +46,9 @@ def _cores():
     return n
 
 
-def two_sample(pkg, O, p, cfg, cells, what, variant=None, check=True, bimodal_branch=True):
-    """device launch over all cells of cfg, oracle + one perturbed oracle re-run for every cell of `cells`; asserts (1)-(3) of the module docstring.  variant: the oracle variant
-    (default p.variant)"""
+def two_sample(pkg, O, p, cfg, cells, what, variant=None, check=True):
+    """device launch over all cells of cfg, oracle + one perturbed oracle re-run for every cell of `cells`; check=True asserts the two-sample criterion of the module docstring
+    (flags, quantiles within 1.5 x the perturbed oracle's, identical-decision fraction); the caller adds absolute thresholds.  variant: the oracle variant (default p.variant)"""
     variant = variant or p.variant
     import torch
     Th_all = np.ascontiguousarray(cfg["theta"])
@@ -83,60 +82,53 @@ def two_sample(pkg, O, p, cfg, cells, what, variant=None, check=True, bimodal_br
     stats = dict(what=what, variant=variant, precision=getattr(p, "precision", "f64"), cells=len(cells), flags_equal=int(fl_dev.sum()), flags_equal_perturbed=int(fl_pert.sum()),
                  identical_decisions_device=float(same_d.mean()), identical_decisions_perturbed=float(same_p.mean()), end_state_device=[float(x) for x in qd],
                  end_state_perturbed=[float(x) for x in qp], t_end_device=[float(x) for x in qtd], t_end_perturbed=[float(x) for x in qtp], kernel_ms=float(ens.kernel_ms))
-    if not check:
-        return dict(e_d=e_d, e_p=e_p, same_d=same_d, same_p=same_p, stats=stats)
+    out = dict(e_d=e_d, e_p=e_p, same_d=same_d, same_p=same_p, stats=stats, Yd=Yd, Th=Th_all, cells=np.asarray(cells), runs=runs, cfg=cfg, variant=variant, flags_equal=fl_dev, bad=bad)
     assert fl_dev.all(), ("exit flags differ", what, bad)
-    # (bimodal regime: when fewer than half of the cells keep identical decisions in EITHER sample the median sits inside the decorrelated mode, where it measures how the
-    #  mode is populated, not how far apart two runs are: the device's median must then lie within the floor's 90 % quantile -- module docstring, C3)
-    bimodal = bimodal_branch and same_d.mean() < 0.5 and same_p.mean() < 0.5
+    if not check:
+        return out
     for name, qa, qb in (("end state", qd, qp), ("run-end times", qtd, qtp)):
         for q, a, b in zip(QS, qa, qb):
-            lim = FACTOR * max(b, FLOOR) if not (bimodal and q == 50) else max(FACTOR * max(b, FLOOR), qb[1])
-            assert a <= lim, (name, what, q, a, b)
+            assert a <= FACTOR * max(b, FLOOR), (name, what, q, a, b)
     assert same_d.mean() >= same_p.mean() - 0.05, ("identical decisions", what, same_d.mean(), same_p.mean())
-    return dict(e_d=e_d, e_p=e_p, same_d=same_d, same_p=same_p, stats=stats)
+    return out
 
 
-def test_every_cell_c2(hip_model, O, pkg):
-    p = hip_model
-    cfg = pkg.configs.c2(p, 1024)
-    r = two_sample(pkg, O, p, cfg, np.arange(1024), "C2")
-    assert r["same_d"].all() and r["e_d"].max() <= 1e-6          # identical parameters, identical decisions: every cell within 1e-6 outright
+def divergent_cells_equally_accurate(O, r, what, factor=2.0, floor=2e-6, tight=None):
+    """"a different step sequence, the same accuracy" as an assertion: for EVERY cell of the sample whose integrator decisions differ from the oracle's,
+    the device's end state is compared with that cell's reltol-1e-8 oracle solution and must be at most `factor` x as far from it as the oracle's own default-tolerance end state
+    (floored: where both are at rounding level there is nothing to compare).  A cell whose tight reference does not complete is reported and skipped (none in r05 / r06)."""
+    tight = tight or parity.TIGHT
+    idx = np.nonzero(~r["same_d"])[0]
+    if idx.size == 0:
+        print("%s: no decision-divergent cell" % what)
+        return []
+    variant, runs, cfg = r["variant"], r["runs"], r["cfg"]
+
+    def one(k):
+        i = int(r["cells"][k])
+        ref = O.simulate(variant, r["Th"][i], cfg["SOC"], runs, max_out=8, opts=O.default_opts(**tight))
+        if any(rr["flag"] < 0 for rr in ref["runs"]):
+            return (i, None, None)
+        ro = O.simulate(variant, r["Th"][i], cfg["SOC"], runs, max_out=8)
+        return (i, parity.state_rel_err(r["Yd"][i], ref["Y"]), parity.state_rel_err(ro["Y"], ref["Y"]))
+    with ThreadPoolExecutor(_cores()) as ex:
+        rows = list(ex.map(one, idx))
+    done = [x for x in rows if x[1] is not None]
+    worst = max(done, key=lambda x: x[1] / max(x[2], floor)) if done else None
+    print("%s: %d decision-divergent cells, %d with a reltol-1e-8 reference; error against it, device / oracle: median %.1e / %.1e, max %.1e / %.1e; worst ratio %.2f (cell %d: %.1e vs %.1e)"
+          % (what, idx.size, len(done), np.median([x[1] for x in done]) if done else 0, np.median([x[2] for x in done]) if done else 0, max([x[1] for x in done], default=0),
+             max([x[2] for x in done], default=0), (worst[1] / max(worst[2], floor)) if worst else 0, worst[0] if worst else -1, worst[1] if worst else 0, worst[2] if worst else 0))
+    badc = [x for x in done if x[1] > factor * max(x[2], floor)]
+    assert not badc, ("decision-divergent cells less accurate than the oracle", what, badc[:5])
+    assert len(done) >= 0.9 * idx.size, ("tight references that did not complete", what, [x[0] for x in rows if x[1] is None][:5])
+    return rows
 
 
-def test_every_cell_c3(hip_model_thermal, O, pkg):
-    # the oracle variant that evaluates the heat-conduction stencil on temperature differences, like the device (same equations as lco_thermal row by row to 1e-12 of the
-    # terms and on the thermal notebook KATs: tests/test_oracle_golden.py).  Against the matrix form the device differs by that form's own rounding, 1e-9 K/s per T row -- 1e4 x the
-    # last-bit perturbation the floor is measured with (the numbers against either variant: DESIGN.md 5 "every cell, asserted")
-    p = hip_model_thermal
-    two_sample(pkg, O, p, pkg.configs.c3(p, 4096), np.arange(4096), "C3", variant="lco_thermal_tdiff")
-
-
-def test_every_cell_c3_against_the_quiet_oracle(hip_model_thermal, O, pkg):
-    """r05: C3 against `lco_thermal_quiet` (T rows AND Phi_s rows on differences: the device's evaluation order), every one of the 4096 cells, the two-sample criterion WITHOUT the
-    bimodal relaxation -- and far inside it: the device keeps the quiet oracle's decisions in (nearly) every cell, so the deviation quantiles are rounding, not a floor.  What
-    made C3 bimodal against the other two variants is the rounding of THEIR Phi_s rows (tests/test_oracle_golden.py)."""
-    p = hip_model_thermal
-    r = two_sample(pkg, O, p, pkg.configs.c3(p, 4096), np.arange(4096), "C3 vs the quiet oracle", variant="lco_thermal_quiet", bimodal_branch=False)
-    # measured r05: identical decisions in 98.9 % of the 4096 cells (against the plain variant: 27.7 %), end state p50 / p90 / p99 = 7.3e-7 / 1.3e-5 / 4.1e-4 (1.3e-2 / 3.5e-2 / 7.6e-2)
-    assert r["same_d"].mean() >= 0.97 and np.percentile(r["e_d"], 50) <= 5e-6 and np.percentile(r["e_d"], 90) <= 1e-4, (r["same_d"].mean(), np.percentile(r["e_d"], (50, 90, 99)))
-
-
-def test_every_cell_c3_reference_order_build(hip_model_thermal, O, pkg):
-    """r05: the reference-order build (precision = "f64_reforder": finite-volume and Phi_s rows in the generated code's operation order) against the PLAIN, notebook-pinned oracle
-    `lco_thermal` on all 4096 C3 cells: the two-sample criterion at every quantile including the median, WITHOUT the bimodal relaxation r04 needed for the default build."""
-    p = pkg.petlion(pkg.LCO, temperature=True, precision="f64_reforder")
-    two_sample(pkg, O, p, pkg.configs.c3(p, 4096), np.arange(4096), "C3, reference-order build vs the plain oracle", variant="lco_thermal", bimodal_branch=False)
-
-
-def test_every_8th_cell_c4(hip_model, O, pkg):
-    p = hip_model
-    two_sample(pkg, O, p, pkg.configs.c4(p, 65536), np.arange(0, 65536, 8), "C4")
-
-
-def test_every_cell_c5(hip_model_nmc_sei, O, pkg):
-    p = hip_model_nmc_sei
-    two_sample(pkg, O, p, pkg.configs.c5(p, 8192), np.arange(8192), "C5")
+def loose_gate(r, what, p50, p90, p99):
+    """the default build against the PLAIN (notebook-pinned) oracle: a bounded, asserted distance (module docstring)"""
+    q = np.percentile(r["e_d"], QS)
+    print("%s: default build vs the plain oracle, end state p50 / p90 / p99 %.1e / %.1e / %.1e (ceilings %.0e / %.0e / %.0e), identical decisions %.1f %%" % (what, *q, p50, p90, p99, 100 * r["same_d"].mean()))
+    assert q[0] <= p50 and q[1] <= p90 and q[2] <= p99, (what, q)
 
 
 def _quiet(r, same, p50, p99, mx):
@@ -144,17 +136,55 @@ def _quiet(r, same, p50, p99, mx):
     assert r["same_d"].mean() >= same and q[0] <= p50 and q[1] <= p99 and r["e_d"].max() <= mx, (r["same_d"].mean(), q, r["e_d"].max())
 
 
+# ---- default build <-> quiet oracle: absolute thresholds + every decision-divergent cell equally accurate ----
 def test_every_cell_c2_c4_c5_against_the_quiet_oracle(hip_model, hip_model_nmc_sei, O, pkg):
-    """r05: the isothermal configurations against the oracle variants whose Phi_s rows are evaluated on differences (`lco_iso_quiet`, `nmc_iso_sei_quiet`: the same model as the plain
-    variants, tests/test_oracle_golden.py) -- the device's evaluation order.  With the one systematic rounding difference between device and oracle removed, the DEFAULT-tolerance
-    trajectories agree nearly as tightly as the reltol-1e-8 ones: measured r05 (gpurun_out/r05e -> profiles/r05_two_sample_quiet.json), identical decisions / end state p50, p99, max:
-      C2 1024 / 1024 cells, 6.5e-12;   C4 65 504 / 65 536 (ALL cells of the sweep: 99.95 %), 4.1e-12, 9.7e-10, 8.5e-3 (the 32 cells that decide differently);   C5 8192 / 8192 (40 runs each), 4.7e-8, 6.0e-7, 1.6e-6
-    (against the plain variants: C4 99.7 %, p99 9.8e-6; C5 92.8 %, p99 6.0e-4 -- the two-sample tests above).  These are ABSOLUTE thresholds, not relative to a perturbed oracle."""
+    """the isothermal configurations against `lco_iso_quiet` / `nmc_iso_sei_quiet`.  Measured r05 (profiles/r05_two_sample_quiet.json), identical decisions / end state p50, p99, max:
+      C2 1024 / 1024 cells, 6.5e-12;   C4 65 504 / 65 536 (ALL cells of the sweep: 99.95 %), 4.1e-12, 9.7e-10, 8.5e-3 (the 32 cells that decide differently);   C5 8192 / 8192 (40 runs each), 4.7e-8, 6.0e-7, 1.6e-6"""
     p = hip_model
-    r = two_sample(pkg, O, p, pkg.configs.c2(p, 1024), np.arange(1024), "C2 vs the quiet oracle", variant="lco_iso_quiet", bimodal_branch=False)
+    r = two_sample(pkg, O, p, pkg.configs.c2(p, 1024), np.arange(1024), "C2 vs the quiet oracle", variant="lco_iso_quiet", check=False)
     _quiet(r, 1.0, 1e-9, 1e-9, 1e-9)
-    r = two_sample(pkg, O, p, pkg.configs.c4(p, 65536), np.arange(65536), "C4 vs the quiet oracle, all 65 536 cells", variant="lco_iso_quiet", bimodal_branch=False)
+    r = two_sample(pkg, O, p, pkg.configs.c4(p, 65536), np.arange(65536), "C4 vs the quiet oracle, all 65 536 cells", variant="lco_iso_quiet", check=False)
     _quiet(r, 0.995, 1e-9, 1e-7, 2e-2)
+    divergent_cells_equally_accurate(O, r, "C4")
     p = hip_model_nmc_sei
-    r = two_sample(pkg, O, p, pkg.configs.c5(p, 8192), np.arange(8192), "C5 vs the quiet oracle", variant="nmc_iso_sei_quiet", bimodal_branch=False)
+    r = two_sample(pkg, O, p, pkg.configs.c5(p, 8192), np.arange(8192), "C5 vs the quiet oracle", variant="nmc_iso_sei_quiet", check=False)
     _quiet(r, 0.99, 1e-6, 1e-5, 1e-3)
+    divergent_cells_equally_accurate(O, r, "C5")
+
+
+def test_every_cell_c3_against_the_quiet_oracle(hip_model_thermal, O, pkg):
+    """C3 against `lco_thermal_quiet` (T rows AND Phi_s rows on differences: the device's evaluation order), every one of the 4096 cells.  Measured r05: identical decisions in
+    98.9 % of the cells (against the plain variant: 27.7 %), end state p50 / p90 / p99 = 7.3e-7 / 1.3e-5 / 4.1e-4; 47 cells decide differently (max 3.2e-2)."""
+    p = hip_model_thermal
+    r = two_sample(pkg, O, p, pkg.configs.c3(p, 4096), np.arange(4096), "C3 vs the quiet oracle", variant="lco_thermal_quiet", check=False)
+    assert r["same_d"].mean() >= 0.97 and np.percentile(r["e_d"], 50) <= 5e-6 and np.percentile(r["e_d"], 90) <= 1e-4, (r["same_d"].mean(), np.percentile(r["e_d"], (50, 90, 99)))
+    divergent_cells_equally_accurate(O, r, "C3")
+
+
+# ---- reference-order build <-> plain (notebook-pinned) oracle: the two-sample criterion ----
+def test_every_cell_c3_reference_order_build(hip_model_thermal, O, pkg):
+    """the reference-order build (precision = "f64_reforder": finite-volume and Phi_s rows in the generated code's operation order) against the PLAIN, notebook-pinned oracle
+    `lco_thermal` on all 4096 C3 cells: the two-sample criterion at every quantile including the median"""
+    p = pkg.petlion(pkg.LCO, temperature=True, precision="f64_reforder")
+    two_sample(pkg, O, p, pkg.configs.c3(p, 4096), np.arange(4096), "C3, reference-order build vs the plain oracle", variant="lco_thermal")
+
+
+def test_every_cell_c2_reference_order_build(O, pkg):
+    p = pkg.petlion(pkg.LCO, precision="f64_reforder")
+    r = two_sample(pkg, O, p, pkg.configs.c2(p, 1024), np.arange(1024), "C2, reference-order build vs the plain oracle", variant="lco_iso")
+    assert r["same_d"].all() and r["e_d"].max() <= 1e-6          # identical parameters, identical decisions: every cell within 1e-6 outright
+
+
+# ---- default build vs the plain oracle: one loose, asserted gate per configuration ----
+def test_default_build_stays_near_the_plain_oracle(hip_model, hip_model_thermal, hip_model_nmc_sei, O, pkg):
+    p = hip_model
+    r = two_sample(pkg, O, p, pkg.configs.c2(p, 1024), np.arange(0, 1024, 64), "C2", check=False)          # (identical parameters: 16 cells say what 1024 do)
+    loose_gate(r, "C2", 1e-6, 1e-6, 1e-6)
+    r = two_sample(pkg, O, p, pkg.configs.c4(p, 65536), np.arange(0, 65536, 16), "C4, every 16th cell", check=False)
+    loose_gate(r, "C4", 1e-8, 1e-6, 1e-4)           # (r05: 99.7 % identical decisions, p99 9.8e-6)
+    p = hip_model_nmc_sei
+    r = two_sample(pkg, O, p, pkg.configs.c5(p, 8192), np.arange(0, 8192, 4), "C5, every 4th cell", check=False)
+    loose_gate(r, "C5", 1e-5, 1e-3, 5e-3)           # (r05: 92.8 % identical decisions, p99 6.0e-4)
+    p = hip_model_thermal
+    r = two_sample(pkg, O, p, pkg.configs.c3(p, 4096), np.arange(0, 4096, 4), "C3, every 4th cell", variant="lco_thermal", check=False)
+    loose_gate(r, "C3", 3e-2, 7e-2, 1.5e-1)         # (r05: 1.2e-2 / 3.5e-2 / 7.2e-2 -- the hold legs: the default build does not take the plain oracle's step sequences there)
