@@ -227,6 +227,7 @@ def selftest(p, n_cells=2, tf=100.0):
 
 _GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "selftest_golden.json")
 KA_TOL = 2e-6        # 200 x the reltol of the known-answer protocol: two correct builds (other compiler, other contraction of a sum) agree to ~1e-7 there (tests/test_gpu_tight.py)
+KA_ATOL = 1e-9       # 10 x the abstol of the known-answer protocol: the absolute floor of a state-section comparison (known_answer_check)
 
 
 def known_answer_protocol(p):
@@ -278,7 +279,9 @@ def known_answer_check(p):
             mx, sm = d["sections"][nm][c]
             gmx, gsm = rows[c]
             n = p.ind[nm].stop - p.ind[nm].start
-            if abs(mx - gmx) > KA_TOL * max(gmx, 1e-300) + 1e-12 or abs(sm - gsm) > KA_TOL * n * max(gmx, 1e-300) + 1e-12:
+            # (absolute floor: ten times the ABSOLUTE tolerance the protocol is integrated with -- a field that has relaxed to ~1e-5 of its scale, Phi_e at the end of the rest, is
+            #  only determined to abstol, and two correct builds whose step sequences differ in one step differ there by that much: r06, 1.1e-10 in max |Phi_e| = 2.08e-5 V)
+            if abs(mx - gmx) > KA_TOL * max(gmx, 1e-300) + KA_ATOL or abs(sm - gsm) > KA_TOL * n * max(gmx, 1e-300) + n * KA_ATOL:
                 return "state section %s of cell %d: max |Y| %.12g (known %.12g), sum %.12g (known %.12g)" % (nm, c, mx, gmx, sm, gsm)
     return None
 
