@@ -82,6 +82,10 @@ namespace pl {
 static_assert(NP >= 2 && NS >= 2 && NN >= 2 && NE <= 48, "2 <= N_p, N_s, N_n and N_p + N_s + N_n <= 48 (one lane per node, two 32-lane halves in the sweeps)");
 static_assert(NRP >= 10 && NRN >= 10 && NR <= NRMAX, "10 <= N_r_p, N_r_n <= 16 (the radial operator of N_r = 9 has complex eigenvalues: no spectral resolvent; tools/gen_radial_tables.py)");
 constexpr int CS_G = WAVE / NR, CS_LANES = CS_G * NR, CS_PASS = (NJ + CS_G - 1) / CS_G;     // particles per pass, lanes in use, passes (default grid: 6, 60, 4)
+// r06, isothermal / SEI models: the particle phases in the ROW layout -- one particle per 16-lane DPP row (lane -> row r = lane % 16 of particle pass * 4 + lane / 16, rows
+// r < N_r live), so that the matrix-vector products take their vector operand from the row's own lanes through `row_newbcast` (see rowb_fmac) instead of from LDS
+constexpr int CSD_G = WAVE / 16, CSD_PASS = (NJ + CSD_G - 1) / CSD_G;                       // default grid: 4 particles per pass, 5 passes
+constexpr int LR_PASS = CS_PASS > CSD_PASS ? CS_PASS : CSD_PASS;                            // per-lane registers that persist across phases: one per pass of either layout
 constexpr int MAXORD = 5;
 
 // Model traits: state layout  Y = [ c_e | c_s_avg | T (thermal) | film, SOH (SEI) || j | Phi_e | Phi_s | j_s (SEI) | I ]  and closures.
@@ -329,8 +333,8 @@ template <class M> struct alignas(16) CellLDS {
 
 // per-lane registers that persist across phases
 struct LaneRegs {
-  double wreg[CS_PASS]; // particle partial solutions kept across the Thomas phase
-  double rcp[CS_PASS];  // thermal model: 1 / (kappa_p lam_r - cj) of the last factorisation for this lane's (particle, radial mode) of each pass -- the spectral resolvent's diagonal
+  double wreg[LR_PASS]; // particle partial solutions kept across the Thomas phase
+  double rcp[LR_PASS];  // thermal model: 1 / (kappa_p lam_r - cj) of the last factorisation for this lane's (particle, radial mode) of each pass -- the spectral resolvent's diagonal
 };
 
 // forward parameter sensitivities (dfn_sens.h): what plh_integrate hands the kernel
@@ -617,6 +621,34 @@ __device__ __forceinline__ double pl_inv_root(double x, int n) {
   }
   return y;
 }
+#endif
+
+// ---- particle mat-vecs without LDS traffic for the vector operand (r06) ----
+// acc += (c of lane K of this lane's 16-lane DPP row) * m  as ONE instruction: v_fmac_f64 with the DPP control row_newbcast:K (gfx90a+: the only DPP control the fp64 ALU
+// takes).  With one particle per DPP row -- lane r of the row holds entry r of the particle's vector -- row r of a radial operator times that vector is N_r of these, and the
+// vector costs ONE LDS load per lane and pass instead of N_r (r05: 40 loads + 40 fma per lane for the four 6-particle passes; now 5 loads + 50 fused broadcast-fma for five
+// 4-particle passes).  hipcc has no intrinsic that selects the DPP form of an fp64 fma (it emits v_mov_b64_dpp + v_fma: two instructions), hence the inline assembly; the
+// operand that is broadcast comes from an LDS load (csd_settle), never from a VALU result, so the VALU-write -> DPP-read hazard (2 wait states) the assembler cannot see
+// does not arise.  All 64 lanes must be active.  K is a compile-time constant (static_for).
+#ifdef PL_WAVE_EMU
+template <int K> __device__ __forceinline__ void rowb_fmac(double& acc, double c, double m) { acc += __shfl(c, (lane_id() & ~15) + K) * m; }
+__device__ __forceinline__ void csd_settle1(double&) {}
+__device__ __forceinline__ void csd_settle_end() {}
+#else
+template <int K> __device__ __forceinline__ void rowb_fmac(double& acc, double c, double m) {
+  __asm__("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(m), "n"(K));
+}
+// the broadcast operands, after their loads have landed and two wait states later: whatever wrote the registers last, a DPP read is safe from here on
+__device__ __forceinline__ void csd_settle1(double& c) { __asm__ volatile("" : "+v"(c)); }
+__device__ __forceinline__ void csd_settle_end() { __asm__ volatile("s_nop 1"); }
+#endif
+template <int K, int NK, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (K < NK) { f(std::integral_constant<int, K>{}); static_for<K + 1, NK>(f); }
+}
+#ifdef PL_NO_CSDPP
+template <class M> constexpr bool PL_CSDPP = false;
+#else
+template <class M> constexpr bool PL_CSDPP = M::SD == 0 && !M::THERMAL && !M::W2;
 #endif
 
 // a value the compiler must materialise: a product passed through it is ROUNDED before it enters a sum (no fma contraction) -- the reference's operation order of the
@@ -916,7 +948,7 @@ PL_DEV void cell_setup(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
       if constexpr (!M::THERMAL) { if (lane < NR) S.Mr[S.mr_el(1) + S.OFF_LAMR + lane] = tb->LAMp(1)[lane]; }
     } }
     } }
-  for (int k = 0; k < CS_PASS; k++) { R.wreg[k] = 0.0; R.rcp[k] = 0.0; }
+  for (int k = 0; k < LR_PASS; k++) { R.wreg[k] = 0.0; R.rcp[k] = 0.0; }
   // the LDS state vectors start at zero, padding included: the padding of M::VPAD must be (and then stays) zero, and the branch-free history sums of the integrator multiply
   // the orders that are not in use by 0.0 -- which must not meet the NaN a previous workgroup may have left behind
   for (int k = (int)threadIdx.x; k < M::NPAD; k += WAVE * M::NWAVES) {
@@ -1210,9 +1242,51 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
 }
 
 // c_s rows (residuals_c_s_avg!, Fickian FDM, residuals.jl:128-180): lane -> (particle = pass*CS_G + lane/NR, row = lane%NR)   (default grid: 4 passes of 6 particles)
+// ROW layout (PL_CSDPP): lane -> (particle = pass * 4 + lane / 16, row = lane % 16), the vector operand through rowb_fmac.  Same sums in the same order as the LDS form below.
+template <class M>
+PL_DEV void iso_cs_rows_rowb(CellLDS<M>& S, const double* Y, const double* YP, double* Fo) {
+  PL_MODEL(M);
+  const int lane = lane_id();
+  const CellConst& c = S.cc;
+  const int q = lane >> 4, r = lane & 15, rc = r < NR ? r : NR - 1;      // (lanes beyond N_r of a row read valid rows and do not store)
+  double Mrow[NR];
+  for (int k = 0; k < NR; k++) Mrow[k] = S.Mr[rc * NR + k];
+  [[maybe_unused]] double MrowN[NR_EQ ? 1 : NR];
+  if constexpr (!NR_EQ) for (int k = 0; k < NR; k++) MrowN[k] = S.Mr[S.mr_el(1) + rc * NR + k];
+  int pp[CSD_PASS]; double acc[CSD_PASS], cv[CSD_PASS], jv[CSD_PASS], ypv[CSD_PASS];
+#pragma unroll
+  for (int pass = 0; pass < CSD_PASS; pass++) {
+    const int p = pass * CSD_G + q; pp[pass] = p < NJ ? p : NJ - 1; acc[pass] = 0.0;
+    const int rk = rc < nr_of(pp[pass]) ? rc : nr_of(pp[pass]) - 1;       // (a lane beyond the particle's own rows: a finite entry, times the operator's zero padding)
+    cv[pass] = Y[O_CS + cs_off(pp[pass]) + rk];
+    jv[pass] = Y[O_J + pp[pass]];
+    ypv[pass] = YP[O_CS + cs_off(pp[pass]) + rk];
+  }
+#pragma unroll
+  for (int pass = 0; pass < CSD_PASS; pass++) csd_settle1(cv[pass]);
+  csd_settle_end();
+  static_for<0, NR>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+#pragma unroll
+    for (int pass = 0; pass < CSD_PASS; pass++) {
+      if constexpr (NR_EQ) rowb_fmac<k>(acc[pass], cv[pass], Mrow[k]);
+      else rowb_fmac<k>(acc[pass], cv[pass], pp[pass] < NP ? Mrow[k] : MrowN[k]);
+    }
+  });
+  const double kap_p = c.kap_p, kap_n = c.kap_n, bj_p = c.bj_p, bj_n = c.bj_n;
+#pragma unroll
+  for (int pass = 0; pass < CSD_PASS; pass++) {
+    const int p = pass * CSD_G + q;
+    double rhs = (p < NP ? kap_p : kap_n) * acc[pass];
+    if (r == nr_of(pp[pass]) - 1) rhs += (p < NP ? bj_p : bj_n) * jv[pass];
+    if (p < NJ && r < nr_of(pp[pass])) Fo[O_CS + cs_off(p) + r] = rhs - ypv[pass];
+  }
+}
+
 template <class M>
 PL_DEV void iso_cs_rows(CellLDS<M>& S, const LaneRegs& R, const double* Y, const double* YP, double* Fo) {
   PL_MODEL(M);
+  if constexpr (PL_CSDPP<M>) { iso_cs_rows_rowb(S, Y, YP, Fo); return; }
   if constexpr (M::W2) { if (wave_id() != 1) return; }       // two waves per cell: the particle rows belong to wave 1
   const int lane = lane_id();
   const CellConst& c = S.cc;
@@ -1615,6 +1689,36 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   const int r = lane % NR, g = lane / NR;
   PL_TICE(2);
   // a. particle partial solutions  w = A^-1 b_cs : four independent accumulation chains (pass = particles pass*6 .. pass*6+5)
+  if constexpr (PL_CSDPP<M>) {
+    if (!alg_only) {       // ROW layout: one particle per 16-lane DPP row, the right-hand side through rowb_fmac (same sums, same order)
+      const int q = lane >> 4, rr = lane & 15, rc = rr < NR ? rr : NR - 1;
+      double AP[NR], AN[NR];
+#pragma unroll
+      for (int k = 0; k < NR; k++) { AP[k] = S.Ainv[0][rc * NR + k]; AN[k] = S.Ainv[1][rc * NR + k]; }
+      int pp[CSD_PASS]; double w[CSD_PASS], bc[CSD_PASS];
+#pragma unroll
+      for (int pass = 0; pass < CSD_PASS; pass++) {
+        const int p = pass * CSD_G + q; pp[pass] = p < NJ ? p : NJ - 1; w[pass] = 0.0;
+        const int rk = rc < nr_of(pp[pass]) ? rc : nr_of(pp[pass]) - 1;
+        bc[pass] = b[O_CS + cs_off(pp[pass]) + rk];
+      }
+#pragma unroll
+      for (int pass = 0; pass < CSD_PASS; pass++) csd_settle1(bc[pass]);
+      csd_settle_end();
+      static_for<0, NR>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+#pragma unroll
+        for (int pass = 0; pass < CSD_PASS; pass++)      // (a pass that lies entirely in one electrode takes that electrode's resolvent without a select: known per pass after unrolling)
+          rowb_fmac<k>(w[pass], bc[pass], (pass + 1) * CSD_G <= NP ? AP[k] : (pass * CSD_G >= NP ? AN[k] : (pp[pass] < NP ? AP[k] : AN[k])));
+      });
+#pragma unroll
+      for (int pass = 0; pass < CSD_PASS; pass++) {
+        const int p = pass * CSD_G + q;
+        if (p < NJ && rr == nr_of(pp[pass]) - 1) S.w9[p] = w[pass];
+        R.wreg[pass] = w[pass];
+      }
+    }
+  } else
   if constexpr (M::SD == 0)
   if (!alg_only && (!M::W2 || wave_id() == 1)) {
     const int gg = lane < CS_LANES ? g : CS_G - 1;
@@ -1774,6 +1878,21 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   PL_XSYNC();
   PL_TOCE(S, 2, 3);
   // f. particles:  dc = w - (A^-1 e_last) * bj * dj
+  if constexpr (PL_CSDPP<M>) {
+    if (!alg_only) {       // ROW layout
+      const int q = lane >> 4, rr = lane & 15, rc = rr < NR ? rr : NR - 1;
+      const double aP = S.Ainv[0][rc * NR + NRP - 1] * c.bj_p, aN = S.Ainv[1][rc * NR + NRN - 1] * c.bj_n;
+      double dj[CSD_PASS];
+#pragma unroll
+      for (int pass = 0; pass < CSD_PASS; pass++) { const int p = pass * CSD_G + q; dj[pass] = b[O_J + (p < NJ ? p : NJ - 1)]; }
+#pragma unroll
+      for (int pass = 0; pass < CSD_PASS; pass++) {
+        const int p = pass * CSD_G + q;
+        const double v = R.wreg[pass] - (p < NP ? aP : aN) * dj[pass];
+        if (p < NJ && rr < nr_of(p < NJ ? p : NJ - 1)) b[O_CS + cs_off(p) + rr] = v;
+      }
+    }
+  } else
   if constexpr (M::SD == 0)
   if (!alg_only && (!M::W2 || wave_id() == 1)) {
     // unconditional loads with clamped indices first (one LDS latency), guarded stores last: a load inside `if (lane < ..)` is one exec-masked round trip per pass

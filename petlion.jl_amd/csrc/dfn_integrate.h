@@ -232,7 +232,7 @@ PL_DEV int cell_init_consistent_impl(CellLDS<M>& S, const Tables* tb, double* Y,
                                                       int mode, double value, double reltol_init, double* bsave = nullptr, int nref = 0, const plh_run* frun = nullptr, double t_fun = 0.0,
                                                       GenRow* g = nullptr) {
   LaneRegs R;                                                        // (the algebraic solves do not touch the particle registers)
-  for (int k = 0; k < CS_PASS; k++) { R.wreg[k] = 0.0; R.rcp[k] = 0.0; }
+  for (int k = 0; k < LR_PASS; k++) { R.wreg[k] = 0.0; R.rcp[k] = 0.0; }
   int iters = 0;
   PL_MODEL(M);
   const int lane = lane_id();

@@ -116,9 +116,9 @@ PL_DEV void sens_factor_copy(CellLDS<M>& S, LaneRegs& R, const SensCell<M>& X) {
   double* b = X.a.fsave + (size_t)X.cell * X.a.fsave_stride;
   PL_XSYNC();
   for (int k = lane; k < nd; k += WAVE) { if (SAVE) b[k] = r0[k]; else r0[k] = b[k]; }
-  double* br = b + nd + (size_t)(wave_id() * WAVE + lane) * (2 * CS_PASS);
-  for (int q = 0; q < CS_PASS; q++) {
-    if (SAVE) { br[q] = R.wreg[q]; br[CS_PASS + q] = R.rcp[q]; } else { R.wreg[q] = br[q]; R.rcp[q] = br[CS_PASS + q]; }
+  double* br = b + nd + (size_t)(wave_id() * WAVE + lane) * (2 * LR_PASS);
+  for (int q = 0; q < LR_PASS; q++) {
+    if (SAVE) { br[q] = R.wreg[q]; br[LR_PASS + q] = R.rcp[q]; } else { R.wreg[q] = br[q]; R.rcp[q] = br[LR_PASS + q]; }
   }
   PL_XSYNC();
 }
@@ -150,7 +150,7 @@ PL_DEV void sens_init(CellLDS<M>& S, SensCell<M>& X, int mode, double value, boo
   PL_MODEL(M);
   const int lane = lane_id();
   LaneRegs Ra;                                            // (the algebraic solves do not touch the particle registers)
-  for (int q = 0; q < CS_PASS; q++) { Ra.wreg[q] = 0.0; Ra.rcp[q] = 0.0; }
+  for (int q = 0; q < LR_PASS; q++) { Ra.wreg[q] = 0.0; Ra.rcp[q] = 0.0; }
   sens_consts<true>(S, X);
   bool refreshed = false;
   const double I1C0 = S.cc.I1C;

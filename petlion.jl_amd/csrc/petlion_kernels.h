@@ -13,14 +13,11 @@
 
 namespace pl {
 
-// Registers.  The 301-state kernels run one wavefront per SIMD (LDS: >= 37 kB per cell), so the compiler may use the whole 512-entry register file of a lane.  hipcc
-// -Rpass-analysis=kernel-resource-usage for the benchmark instantiation k_integrate<.., 0> with the flags of petlion.jl_amd/buildflags.py (r04 / r05; rocprofv3's
-// `accum_vgpr_count` reads 0 on this unified-file part and is not the figure to read):
-//    LCO isothermal   256 VGPR +  54 AGPR, no VGPR spill,   0 B/lane of scratch
-//    NMC + SEI        256 VGPR +  66 AGPR, no VGPR spill,   0 B/lane
-//    LCO thermal      256 VGPR + 211 AGPR, 128 VGPR spills (into AGPRs: v_accvgpr_read / write, one instruction each way),   0 B/lane
-// (with MachineLICM on the thermal kernel had 392 B/lane of scratch: DESIGN.md 5a).  Compiled for two waves per SIMD (256 registers) the isothermal kernel spills 213 VGPRs,
-// 424 B/lane: DESIGN.md 2.
+// Registers.  The 301-state kernels run one wavefront per SIMD (LDS: >= 37 kB per cell), so the compiler may use the whole 512-entry register file of a lane.  What it makes of
+// that -- VGPRs, AGPRs, spills, scratch bytes per lane and LDS per workgroup of EVERY instantiation of every variant -- is read out of the code objects after each build
+// (tools/kernel_resources.py -> petlion.jl_amd/libpetlion_hip.so.resources.json) and committed for the validated binary in profiles/validated_build.json
+// ("kernel_resources"); tests/test_build_records.py fails when a plain benchmark kernel of the isothermal / SEI models uses scratch.  No figures are typed in here: r05's
+// said "0 B/lane" for the thermal kernel while the shipped object had 28.  (rocprofv3's `accum_vgpr_count` reads 0 on this unified-file part and is not the figure to read.)
 #if !defined(PL_WAVE_EMU) && !defined(PL_NO_WAVES_ATTR) && defined(PL_WAVES_PER_EU)
 // -DPL_WAVES_PER_EU=n: experiment builds (tools/experiments/occupancy.py)
 #define PL_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(PL_WAVES_PER_EU, PL_WAVES_PER_EU)))
@@ -358,7 +355,7 @@ template <class M> struct OpsOf {
     static_assert(!GRID_DEFAULT || sizeof(CellLDS<M>) <= 40960, "built-in variant: LDS per cell above 40 960 B, only three cells per CU would be resident");
 #endif
     static const VariantOps ops = {id, M::CHEM, M::SEI ? 1 : 0, M::THERMAL ? 1 : 0, M::PREC, M::SD, M::TF, M::RXN, M::W2 ? 1 : 0, M::NST, M::NDIFF, {NP, NS, NN, NRP, NA, NZ, NRN},
-                                   {PL_RADIAL_M, PL_RADIAL_M_N}, {PL_RADIAL_LAM, PL_RADIAL_LAM_N}, {PL_RADIAL_V, PL_RADIAL_V_N}, {PL_RADIAL_W, PL_RADIAL_W_N}, {PL_RADIAL_BJ_FACTOR, PL_RADIAL_BJ_FACTOR_N}, sizeof(CellLDS<M>), (int)(sizeof(CellLDS<M>) / sizeof(double)) + M::NWAVES * WAVE * 2 * CS_PASS, M::PHI_GLOBAL ? (MAXORD + 1 - M::PHI_LDS) * M::NPADG : 0, &classify<M>, &sections_of<M>,
+                                   {PL_RADIAL_M, PL_RADIAL_M_N}, {PL_RADIAL_LAM, PL_RADIAL_LAM_N}, {PL_RADIAL_V, PL_RADIAL_V_N}, {PL_RADIAL_W, PL_RADIAL_W_N}, {PL_RADIAL_BJ_FACTOR, PL_RADIAL_BJ_FACTOR_N}, sizeof(CellLDS<M>), (int)(sizeof(CellLDS<M>) / sizeof(double)) + M::NWAVES * WAVE * 2 * LR_PASS, M::PHI_GLOBAL ? (MAXORD + 1 - M::PHI_LDS) * M::NPADG : 0, &classify<M>, &sections_of<M>,
                                    &initial_guess, &residual, &jacobian, &linear_solve, &init_consistent, &integrate};
     return &ops;
   }
