@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <functional>
 #include <vector>
 
 #include <dlfcn.h>
@@ -153,6 +155,7 @@ struct StreamCtx {
   struct TimeList { double* d = nullptr; int cap = 0; std::vector<double> on_device; };
   TimeList tdiscon, tstops;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
+  std::vector<hipEvent_t> ret_ev;                           // one event per output array of a synchronous host call (host_return): grown on demand, kept
   std::vector<void*> pending;                               // staging blocks of PLH_HOST_ASYNC launches: released by plh_synchronize
 };
 struct plh_model_s {
@@ -264,6 +267,42 @@ struct Stage {
   // PLH_HOST_ASYNC: the staging blocks stay busy until plh_synchronize
   void defer() { cx->pending.insert(cx->pending.end(), tmp.begin(), tmp.end()); tmp.clear(); }
 };
+// ---- r06: the way back of a synchronous host call (PLH_HOST) ----
+// r05 copied every output after the kernel, one after the other: hipMemcpy into a pinned bounce buffer, then memcpy into the caller's array -- whose pages, when the caller
+// allocates its outputs per call (numpy.empty, a Julia Vector{Float64}(undef, n)), are all touched there for the first time: a third of the kernel rate on C2 / C4 (VERDICT r05
+// weak 7).  Now (i) the caller's output pages are touched WHILE THE KERNEL RUNS (the host thread has nothing else to do; several threads when there are many pages), (ii) the
+// per-point arrays come back only up to the longest trajectory of the call (n_pts is read first; a 2-D copy of max(n_pts) of the max_pts columns -- entries beyond n_pts[cell]
+// were never defined), (iii) every device-to-host copy is issued at once, asynchronously, into ONE pinned block, and the host copies array k into the caller's memory while
+// arrays k+1 ... are still in flight.
+struct HostRet { char* host; const char* dev; size_t rows, width, pitch, pin_off; };      // rows x width bytes; both sides keep their rows `pitch` bytes apart (one row: a plain copy)
+static void par_chunks(size_t n_items, size_t min_per_thread, const std::function<void(size_t, size_t)>& f) {
+  unsigned nt = (unsigned)std::min<size_t>(4, n_items / (min_per_thread ? min_per_thread : 1));
+#ifdef PL_WAVE_EMU
+  nt = 1;
+#endif
+  if (nt <= 1) { f(0, n_items); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n_items + nt - 1) / nt;
+  for (unsigned k = 1; k < nt; k++) th.emplace_back(f, std::min(n_items, k * per), std::min(n_items, (k + 1) * per));
+  f(0, std::min(n_items, per));
+  for (auto& t : th) t.join();
+}
+// first touch of the caller's output pages (they are overwritten afterwards: writing a zero is harmless).  Rows longer than a page: only the pages the prefix copy can reach
+static void prefault(const std::vector<HostRet>& rets, size_t prefix_bytes_of_wide_rows) {
+  const size_t PG = 4096;
+  for (const HostRet& r : rets) {
+    if (!r.host) continue;
+    if (r.rows <= 1 || r.pitch <= PG) {
+      const size_t bytes = r.rows <= 1 ? r.width : r.rows * r.pitch, pages = (bytes + PG - 1) / PG;
+      char* h = r.host;
+      par_chunks(pages, 256, [h, bytes](size_t a, size_t b) { for (size_t k = a; k < b; k++) ((volatile char*)h)[std::min(bytes - 1, k * PG)] = 0; });
+    } else {
+      const size_t span = std::min(r.width, prefix_bytes_of_wide_rows), per_row = (span + PG - 1) / PG;
+      char* h = r.host; const size_t pitch = r.pitch;
+      par_chunks(r.rows, 64, [h, pitch, span, per_row](size_t a, size_t b) { for (size_t q = a; q < b; q++) for (size_t k = 0; k < per_row; k++) ((volatile char*)h)[q * pitch + std::min(span - 1, k * PG)] = 0; });
+    }
+  }
+}
 #define CHECK_MODEL(m) do { if (!(m)) return fail(PLH_E_ARG, "null model"); } while (0)
 #define CHECK_MODE(mode) do { if ((mode) != PLH_MODE_I && (mode) != PLH_MODE_V && (mode) != PLH_MODE_P && (mode) != PLH_MODE_ETA_P && !((mode) == PLH_MODE_DT && m->desc.temperature)) \
     return fail(PLH_E_UNSUPPORTED, "operating mode not available for this model (I, V, P, eta_p; dT with temperature = true)"); } while (0)
@@ -498,6 +537,7 @@ void plh_model_destroy(plh_model_t m) {
     if (c->tstops.d) hipFree(c->tstops.d);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->ret_ev) hipEventDestroy(e);
     delete c;
   }
   for (auto& b : m->stage_cache) hipFree(b.p);
@@ -834,6 +874,9 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
   a.out = *out;
   a.out.t = s.buf(out->t, np, false); a.out.V = s.buf(out->V, np, false); a.out.I = s.buf(out->I, np, false);
   a.out.SOC = s.buf(out->SOC, np, false); a.out.T_avg = s.buf(out->T_avg, np, false); a.out.n_pts = s.buf(out->n_pts, n, false);
+  // (a synchronous host call brings the per-point arrays back only up to the longest trajectory: it needs n_pts on the device whether or not the caller asked for it)
+  const bool host_ret = kind == PLH_HOST && !sq;
+  if (host_ret && !a.out.n_pts && np > 0 && (out->t || out->V || out->I || out->SOC || out->T_avg || out->Y_all)) a.out.n_pts = (int*)s.dev_block((size_t)n * sizeof(int));
   a.out.Y_all = s.buf(out->Y_all, np * m->N, false);
   a.out.Y_final = s.buf(out->Y_final, (size_t)n * m->N, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * m->N, false);
   a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
@@ -874,6 +917,65 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
   (m->last_compiled ? m->cl_ops : m->ops)->integrate(s.st, a, features);
   hipEventRecord(cx.ev1, s.st);
   cx.timed = true; m->last = &cx;
+  if (host_ret) {
+    // ---- the way back of a synchronous host call (see HostRet) ----
+    std::vector<HostRet> rets;
+    const size_t W8 = sizeof(double), mp = (size_t)out->max_pts;
+    auto add2 = [&](void* host, const void* dev, size_t rows, size_t elem) { if (host && dev && rows && mp) rets.push_back({(char*)host, (const char*)dev, rows, mp * elem, mp * elem, 0}); };
+    auto add1 = [&](void* host, const void* dev, size_t bytes) { if (host && dev && bytes) rets.push_back({(char*)host, (const char*)dev, 1, bytes, bytes, 0}); };
+    add2(out->t, a.out.t, n, W8); add2(out->V, a.out.V, n, W8); add2(out->I, a.out.I, n, W8); add2(out->SOC, a.out.SOC, n, W8); add2(out->T_avg, a.out.T_avg, n, W8);
+    add2(out->Y_all, a.out.Y_all, n, W8 * m->N);
+    const size_t n_2d = rets.size();
+    add1(out->Y_final, a.out.Y_final, (size_t)n * m->N * W8); add1(out->YP_final, a.out.YP_final, (size_t)n * m->N * W8);
+    add1(out->run_info, a.out.run_info, (size_t)n * n_runs * sizeof(plh_run_info)); add1(out->counters, a.out.counters, (size_t)n * sizeof(plh_counters));
+    prefault(rets, 4096);                                              // (while the kernel runs)
+    // n_pts first: it bounds the per-point copies (and ends the wait for the kernel)
+    std::vector<int> npts_h;
+    size_t maxn = mp;
+    if (a.out.n_pts && n_2d > 0) {
+      npts_h.resize(n);
+      HIPCHK(hipMemcpyAsync(npts_h.data(), a.out.n_pts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s.st));
+      HIPCHK(hipStreamSynchronize(s.st));
+      maxn = 0; for (int c = 0; c < n; c++) maxn = std::max(maxn, (size_t)std::max(0, npts_h[c]));
+      maxn = std::min(maxn, mp);
+      if (out->n_pts) memcpy(out->n_pts, npts_h.data(), (size_t)n * sizeof(int));
+    } else {
+      HIPCHK(hipStreamSynchronize(s.st));
+      if (out->n_pts && a.out.n_pts) add1(out->n_pts, a.out.n_pts, (size_t)n * sizeof(int));
+    }
+    HIPCHK(hipGetLastError());
+    // every copy at once into one pinned block (per-point arrays: the first maxn columns), an event behind each
+    size_t total = 0;
+    for (size_t k = 0; k < rets.size(); k++) {
+      if (k < n_2d) rets[k].width = maxn * (rets[k].pitch / mp);
+      rets[k].pin_off = total; total += (rets[k].rows * rets[k].width + 255) / 256 * 256;
+    }
+    char* pb = total ? (char*)m->pinned(total) : nullptr;
+    if (total && !pb) return fail(PLH_E_HIP, "pinned staging block of the host return path");
+    while (cx.ret_ev.size() < rets.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); cx.ret_ev.push_back(e); }
+    for (size_t k = 0; k < rets.size(); k++) {
+      const HostRet& r = rets[k];
+      if (r.width == 0) continue;
+      if (r.rows > 1 && r.width < r.pitch) HIPCHK(hipMemcpy2DAsync(pb + r.pin_off, r.width, r.dev, r.pitch, r.width, r.rows, hipMemcpyDeviceToHost, s.st));
+      else HIPCHK(hipMemcpyAsync(pb + r.pin_off, r.dev, r.rows * r.width, hipMemcpyDeviceToHost, s.st));
+      HIPCHK(hipEventRecord(cx.ret_ev[k], s.st));
+    }
+    for (size_t k = 0; k < rets.size(); k++) {                         // array k into the caller's memory while k+1 ... are still in flight
+      const HostRet& r = rets[k];
+      if (r.width == 0) continue;
+      HIPCHK(hipEventSynchronize(cx.ret_ev[k]));
+      const char* src = pb + r.pin_off;
+      if (r.rows > 1 && r.width < r.pitch) {
+        char* h = r.host; const size_t w = r.width, pitch = r.pitch;
+        par_chunks(r.rows, (2u << 20) / (w ? w : 1) + 1, [h, src, w, pitch](size_t qa, size_t qb) { for (size_t q = qa; q < qb; q++) memcpy(h + q * pitch, src + q * w, w); });
+      } else {
+        char* h = r.host; const size_t bytes = r.rows * r.width;
+        par_chunks(bytes, 2u << 20, [h, src](size_t qa, size_t qb) { memcpy(h + qa, src + qa, qb - qa); });
+      }
+    }
+    CHECK_STAGE(s);
+    return 0;
+  }
   FINISH(s);
   if ((!plain || sq) && kind != PLH_HOST) HIPCHK(hipStreamSynchronize(s.st));   // staged tables / per-cell values / sensitivity workspaces are released below: the kernel must be done with them
   s.back(out->t, a.out.t, np); s.back(out->V, a.out.V, np); s.back(out->I, a.out.I, np); s.back(out->SOC, a.out.SOC, np);

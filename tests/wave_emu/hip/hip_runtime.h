@@ -136,6 +136,7 @@ inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? 
 inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t w, size_t h, int, hipStream_t) { for (size_t r = 0; r < h; r++) memcpy((char*)d + r * dpitch, (const char*)s + r * spitch, w); return 0; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
