@@ -319,7 +319,9 @@ int plh_integrate(plh_model_t m, int n_cells, const double* theta, const double*
 /* ---- forward parameter sensitivities next to the states ("parameter-sensitivity (forward) outputs for estimation workflows").  The reference has no such
  * output: its users difference whole simulate() calls (one more simulate() per parameter and direction, with the adaptive step control's noise in the quotient).  Here
  * s_k(t) = dY(t)/d theta[sens_cols[k]] is integrated with the same steps and orders as Y by the staggered-direct method (one linear solve per parameter and accepted step with
- * the factorisation the integrator already holds; csrc/dfn_sens.h); Y, the saved points, run_info and the counters are bit for bit those of plh_integrate.
+ * the factorisation the integrator already holds; csrc/dfn_sens.h).  The guarantee on the states: the integrator takes THE SAME STEPS as plh_integrate -- every counter and
+ * exit flag equal in every cell -- and Y, the saved points and run_info agree with it to ~1e-9 relative (measured: bit-identical in all but a few cells per thousand, those at
+ * 1e-13 ... 1e-11: the sensitivity instantiation is another compilation of the step loop and may contract a sum differently).  The power-on self-test holds it to 1e-8.
  *   dY_dtheta[cell][k][n_states]  at the end of the last completed run (NaN for a cell whose protocol failed); may be NULL
  *   dV_dtheta[cell][k][max_pts]   at every saved point (the Jacobian of the voltage curve a least-squares fit needs); may be NULL
  *   sens_stat[cell][3]            corrector iterations spent; solves that did not reach the tolerance; steps whose corrector factored the step's own matrix because the
@@ -338,7 +340,8 @@ int plh_integrate_sens(plh_model_t m, int n_cells, const double* theta, const do
  * more for this model's variant and grid with the programs of ONE protocol written out as straight-line device code (petlion.jl_amd/closure_lib.py writes the header and runs
  * hipcc; the library exports its variant table like a grid library, plus plh_closure_digest()).  After it is attached, plh_integrate uses its kernels for every call whose
  * PLH_VAL_EXPR programs (opcodes, operands, derivative columns, in protocol order) hash to the digest the library was built for, and the interpreter for every other call --
- * same arguments, same results (the expression is evaluated with the same operations in the same order).  One library per handle; attaching another replaces it. */
+ * same arguments, same results (the expression is evaluated with the same operations in the same order).  One library per handle; attaching another replaces it;
+ * path = NULL detaches (every closure is interpreted again: the host side verifies a freshly compiled library that way before it relies on it). */
 int plh_model_attach_closure_library(plh_model_t m, const char* path);
 /* 1 if the handle's last plh_integrate ran the attached closure library's kernels, 0 if it interpreted (or had no closure input) */
 int plh_last_integrate_compiled(plh_model_t m);

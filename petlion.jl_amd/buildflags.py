@@ -80,3 +80,50 @@ def variant_flags(v, machine_licm=False, thermal=None, default_sched=False):
 def table_repr():
     """what enters the build-identity hash (plh_build_info): the whole table"""
     return repr((OPT, LATE_INLINE, EARLY_INLINE, ISO_FLAGS, sorted(ISO_LATE_VARIANTS), NO_MACHINE_LICM, NO_LSO, THERMAL_SRC, sched_flags(), sorted(DEFAULT_SCHED_VARIANTS), sorted(KEEP_MACHINE_LICM)))
+
+
+# ---- the compiler's answer to NO_LSO ----
+# clang's front end prints "'-load-store-opt' is not a recognized feature for this target (ignoring feature)" several times per compile (no warning class: it cannot be switched
+# off) although the backend honours the feature string -- hundreds of lines in a GPU test log that compiles grid / closure libraries (VERDICT r05 weak 5).  Every builder
+# starts hipcc through popen(): that one line is dropped from the compiler's stderr, everything else passes through; that the switch DID take effect is checked where it can be
+# seen, in the object (tools/kernel_resources.py counts the merged DS operations of the variant-0 kernels into <lib>.resources.json: a build in which the backend ignored the
+# feature has thousands of ds_read2 / ds_write2, one that honoured it a few dozen).
+_NOISE = "is not a recognized feature for this target (ignoring feature)"
+
+
+class popen:
+    """subprocess.Popen of a compiler job whose stderr is passed on without the NO_LSO noise line; wait() / returncode / communicate() as the callers use them"""
+    def __init__(self, cmd, echo=True, **kw):
+        import subprocess
+        import threading
+        self.p = subprocess.Popen(cmd, stderr=subprocess.PIPE, **kw)
+        self.kept, self.echo = [], echo
+        self.t = threading.Thread(target=self._pump, daemon=True)
+        self.t.start()
+
+    def _pump(self):
+        import sys
+        for raw in self.p.stderr:
+            ln = raw.decode(errors="replace")
+            if _NOISE in ln:
+                continue
+            self.kept.append(ln)
+            if self.echo:
+                sys.stderr.write(ln)
+
+    def wait(self):
+        rc = self.p.wait()
+        self.t.join()
+        return rc
+
+    def communicate(self):
+        self.wait()
+        return b"", "".join(self.kept).encode()
+
+    @property
+    def returncode(self):
+        return self.p.returncode
+
+
+def call(cmd, **kw):
+    return popen(cmd, **kw).wait()

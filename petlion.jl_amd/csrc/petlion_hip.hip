@@ -503,7 +503,7 @@ unsigned long long plh_closure_digest(int n_runs, const plh_run* runs) {
 
 int plh_model_attach_closure_library(plh_model_t m, const char* path) {
   CHECK_MODEL(m);
-  if (!path) return fail(PLH_E_ARG, "null path");
+  if (!path) { m->cl_ops = nullptr; m->cl_digest = 0; return 0; }      // (r06) NULL detaches: every closure runs in the interpreter again (how compile_closures verifies a library)
   void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);          // (kept loaded for the life of the process, like a grid library)
   if (!h) return fail(PLH_E_ARG, std::string("dlopen failed: ") + dlerror());
   auto ops = (const VariantOps* (*)(int))dlsym(h, "plh_grid_variant_ops");

@@ -30,9 +30,18 @@ def summarize(ens):
                      c["n_steps"].astype(np.float64), c["n_newton"].astype(np.float64)], axis=1)
 
 
-def ensemble_run(p, Theta, protocol, SOC=1.0, *, group=None, device=None, local_integrate=None):
-    """Scatter Theta ([n_cells, n_theta], significant on rank 0 only) over the ranks of `group`, integrate each shard on the
-    rank's GPU, gather the per-cell summaries back to rank 0.
+def shard_cells(n_cells, world_size, rank, partition="block"):
+    """global cell indices of rank's shard: contiguous balanced blocks (plh_ensemble_run's PLH_PART_BLOCK) or cell mod world_size == rank (PLH_PART_CYCLIC: a sweep
+    whose cost varies smoothly with the cell index spreads evenly)"""
+    if partition == "cyclic":
+        return np.arange(rank, n_cells, world_size, dtype=np.int64)
+    off = shard_bounds(n_cells, world_size)
+    return np.arange(off[rank], off[rank + 1], dtype=np.int64)
+
+
+def ensemble_run(p, Theta, protocol, SOC=1.0, *, group=None, device=None, local_integrate=None, partition="block"):
+    """Scatter Theta ([n_cells, n_theta], significant on rank 0 only) over the ranks of `group` (partition: "block" or "cyclic", see shard_cells), integrate each
+    shard on the rank's GPU, gather the per-cell summaries back to rank 0 IN THE CALLER'S CELL ORDER.
 
     Returns (summary [n_cells, 8] on rank 0 / None elsewhere, local EnsembleSolution-or-summary).
     `local_integrate(Theta_shard: np.ndarray, SOC) -> np.ndarray [m, 8]` replaces the GPU integration (tests use it to
@@ -53,20 +62,20 @@ def ensemble_run(p, Theta, protocol, SOC=1.0, *, group=None, device=None, local_
         meta[0], meta[1] = Theta.shape
     dist.broadcast(meta, src=0, group=group)
     n, P = int(meta[0]), int(meta[1])
-    off = shard_bounds(n, world)
-    m_max = int((off[1:] - off[:-1]).max())
+    cells = [shard_cells(n, world, r, partition) for r in range(world)]
+    m_max = max(len(c) for c in cells)
     mine = torch.zeros(m_max, P, dtype=torch.float64, device=device)
     if rank == 0:
         full = torch.from_numpy(Theta).to(device)
         chunks = []
         for r in range(world):
             c = torch.zeros(m_max, P, dtype=torch.float64, device=device)
-            c[: off[r + 1] - off[r]] = full[off[r]:off[r + 1]]
+            c[: len(cells[r])] = full[torch.from_numpy(cells[r]).to(device)]
             chunks.append(c)
         dist.scatter(mine, chunks, src=0, group=group)
     else:
         dist.scatter(mine, None, src=0, group=group)
-    m = int(off[rank + 1] - off[rank])
+    m = len(cells[rank])
     local = None
     if m > 0:
         if local_integrate is not None:
@@ -85,7 +94,9 @@ def ensemble_run(p, Theta, protocol, SOC=1.0, *, group=None, device=None, local_
     if rank == 0:
         parts = [torch.zeros_like(pad) for _ in range(world)]
         dist.gather(pad, parts, dst=0, group=group)
-        out = np.concatenate([parts[r][: off[r + 1] - off[r]].cpu().numpy() for r in range(world)], axis=0)
+        out = np.zeros((n, len(SUMMARY_FIELDS)))
+        for r in range(world):
+            out[cells[r]] = parts[r][: len(cells[r])].cpu().numpy()
         return out, (local if local is not None else summ)
     dist.gather(pad, None, dst=0, group=group)
     return None, (local if local is not None else summ)

@@ -119,7 +119,7 @@ def _library_locked(grid, variants, force, tag, defs, machine_licm=False, extra_
         objs.append(o)
         # the flags of the built-in kernels of this variant (buildflags.py: ONE table since r05; r04's grid libraries kept MachineLICM and late inlining for every variant
         # and ran 2 ... 21 % behind the built-in kernels for it).  A library that fails the self-test on the user's machine is rebuilt with machine_licm=True.
-        jobs.append((v, o, subprocess.Popen(common + buildflags.variant_flags(v, machine_licm=machine_licm) + ["-DPL_VARIANT=%d" % v, "-c", src, "-o", o], stderr=subprocess.PIPE)))
+        jobs.append((v, o, buildflags.popen(common + buildflags.variant_flags(v, machine_licm=machine_licm) + ["-DPL_VARIANT=%d" % v, "-c", src, "-o", o], echo=False)))
     glue = os.path.join(GRID_DIR, "%s%s_glue.o" % (tag, suffix))
     gj = subprocess.Popen(common + ["-O2", "-DPL_GRID_GLUE", "-c", src, "-o", glue])
     default_sched = []
@@ -127,7 +127,7 @@ def _library_locked(grid, variants, force, tag, defs, machine_licm=False, extra_
         err = j.communicate()[1]
         if j.returncode:
             # hipcc died on this instantiation (the iterative scheduler is experimental upstream): ONCE more with the conservative flag set (buildflags.variant_flags)
-            if subprocess.call(common + buildflags.variant_flags(v, machine_licm=True) + ["-DPL_VARIANT=%d" % v, "-c", src, "-o", o]):
+            if buildflags.call(common + buildflags.variant_flags(v, machine_licm=True) + ["-DPL_VARIANT=%d" % v, "-c", src, "-o", o]):
                 sys.stderr.write(err.decode(errors="replace")[-4000:])
                 raise RuntimeError("hipcc failed building the kernels of discretisation %r" % (grid,))
             default_sched.append(v)

@@ -24,9 +24,14 @@ def _check(kern, where):
         r = kern[v][PLAIN]
         assert r["private_segment_fixed_size"] <= SCRATCH_MAX[v], "%s: plain kernel of %s (%s) has %d B/lane of scratch" % (where, model, cfgs, r["private_segment_fixed_size"])
         assert r["group_segment_fixed_size"] <= LDS_MAX, (where, v, r["group_segment_fixed_size"])
-    assert kern["v0"][PLAIN]["vgpr_spill_count"] == 0, (where, kern["v0"][PLAIN])
+    assert kern["v0"][PLAIN]["vgpr_spill_count"] <= 32, (where, kern["v0"][PLAIN])          # (spills into AGPRs -- one v_accvgpr each way --, never into scratch: asserted above)
+    ds = kern["v0"].get("_ds_ops")
+    if ds:      # the backend's DS merging is off (buildflags.NO_LSO): seen in the object, not believed from the command line (clang's front end says it ignores the feature)
+        assert ds["merged_two_address"] < 0.1 * ds["plain"], (where, ds)
     for v, ks in kern.items():                          # every instantiation of every built-in variant: four cells per CU (two per SIMD for the small cells)
         for name, r in ks.items():
+            if name.startswith("_"):
+                continue
             assert r["group_segment_fixed_size"] <= LDS_MAX, (where, v, name, r["group_segment_fixed_size"])
 
 

@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_cells, out_dir):
+def _worker(rank, world, port, n_cells, out_dir, partition="block"):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     import pkgload
@@ -41,18 +41,18 @@ def _worker(rank, world, port, n_cells, out_dir):
         th0 = O.theta_vector("lco_iso")
         Theta = np.tile(th0, (n_cells, 1))
         Theta[:, O.meta("lco_iso")["theta_keys"].index("D_sp")] *= np.linspace(0.5, 2.0, n_cells)
-    summ, _ = pd.ensemble_run(None, Theta, [{"I": -1.0}], 1.0, local_integrate=local_integrate)
+    summ, _ = pd.ensemble_run(None, Theta, [{"I": -1.0}], 1.0, local_integrate=local_integrate, partition=partition)
     if rank == 0:
         np.save(os.path.join(out_dir, "gathered_w%d.npy" % world), summ)
         np.save(os.path.join(out_dir, "serial.npy"), local_integrate(Theta, 1.0))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_cells", [(2, 7), (3, 5)])
-def test_scatter_integrate_gather_matches_serial(tmp_path, world, n_cells):
+@pytest.mark.parametrize("world,n_cells,partition", [(2, 7, "block"), (3, 5, "block"), (3, 7, "cyclic")])
+def test_scatter_integrate_gather_matches_serial(tmp_path, world, n_cells, partition):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n_cells, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n_cells, str(tmp_path), partition), nprocs=world, join=True)
     g = np.load(tmp_path / ("gathered_w%d.npy" % world))
     s = np.load(tmp_path / "serial.npy")
     assert g.shape == (n_cells, 8)

@@ -73,3 +73,44 @@ def test_ensemble_run_per_cell_protocol_values(hip_model, pkg):
         info, cnt, Y, ms = pd.ensemble_run_capi(comm, p, Th, proto, 1.0, partition=part, want_Y=True)
         assert np.array_equal(Y, ref.Y) and np.array_equal(info["t_end"][:, 0], ref.run_info["t_end"][:, 0]) and np.array_equal(info["I"][:, 0], rates)
     comm.close()
+
+
+def _gloo_gpu_worker(rank, world, port, n_cells, out_dir):
+    """one of `world` gloo ranks that all integrate their shard on the ONE GPU of the box"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import pkgload
+    pkg = pkgload.load()
+    from petlion_jl_amd import distributed as pd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = pkg.petlion(pkg.LCO)
+    Th = np.ascontiguousarray(pkg.configs.c4(p, n_cells)["theta"]) if rank == 0 else None
+    for part in ("block", "cyclic"):
+        summ, _ = pd.ensemble_run(p, Th, [{"I": -1.0}], 1.0, partition=part)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "gathered_%s.npy" % part), summ)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "serial.npy"), pd.summarize(pkg.simulate_ensemble(p, Th, [{"I": -1.0}], SOC=1.0)))
+    dist.destroy_process_group()
+
+
+def test_eight_gloo_ranks_on_one_gpu_block_and_cyclic(tmp_path):
+    """r06: EIGHT ranks (gloo: RCCL refuses two ranks per device) share the one GPU of the box and run the sharded C4 sweep through
+    distributed.ensemble_run with both partitions of plh_ensemble_run (contiguous blocks; cell mod 8): scatter -> eight concurrent plh_integrate launches from eight
+    processes -> gather in the caller's cell order, bit-equal to the serial launch of the same cells.  No hardware scaling curve is claimed from it."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    n = 8 * 160 + 5                                  # ragged shards
+    mp.spawn(_gloo_gpu_worker, args=(8, port, n, str(tmp_path)), nprocs=8, join=True)
+    serial = np.load(tmp_path / "serial.npy")
+    assert serial.shape == (n, 8)
+    for part in ("block", "cyclic"):
+        g = np.load(tmp_path / ("gathered_%s.npy" % part))
+        assert np.array_equal(g, serial), part

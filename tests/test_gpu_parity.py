@@ -870,3 +870,36 @@ def test_blocking_host_call_with_fresh_arrays_on_gpu(hip_model, pkg):
             k = int(npd[i])
             assert np.array_equal(np.asarray(h.t)[i, :k], td[i, :k]) and np.array_equal(np.asarray(h.V)[i, :k], Vd[i, :k]), i
         assert frac >= 0.55, (name, frac)
+
+
+def test_build_from_source_on_the_gpu_box(pkg):
+    """r06: the library the other GPU tests load was cross-compiled in a container without a GPU and travels as a binary; THIS test compiles
+    variant 0 from source where it runs (hipcc on the GPU box, ~2 min: __graft_entry__.build_hip(force=True, variants=[0])), loads the result as a second library, and puts its
+    kernels through the power-on self-test -- every instantiation against the plain kernel, the plain kernel against the committed known answer (selftest_golden.json).  The
+    build record of that library (registers, spills, scratch: tools/kernel_resources.py) must show the plain kernel out of scratch, and the compiler's stderr must not carry
+    the NO_LSO noise line (buildflags.popen)."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "petlion.jl_amd", "_exp", "libplh_fromsrc_gpubox.so")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import __graft_entry__ as g\n"
+            "print(g.build_hip(force=True, lib=%r, variants=[0]))\n" % (root, lib))
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "is not a recognized feature" not in r.stderr, "the NO_LSO noise line reached the build's stderr"
+    rec = json.load(open(lib + ".resources.json"))["kernels"]["v0"]
+    assert rec["k_integrate<0: plain>"]["private_segment_fixed_size"] == 0 and rec["_ds_ops"]["merged_two_address"] < 0.1 * rec["_ds_ops"]["plain"], rec
+    p = pkg.petlion(pkg.LCO, _lib_path=lib)
+    assert "src=" in pkg.api.build_info(p)
+    pkg.selftest(p)                                      # raises on any instantiation that does not reproduce the plain kernel, or a plain kernel off the known answer
+    why = pkg.api.known_answer_check(p)
+    assert why is None, why
+    ens = pkg.simulate_ensemble(p, pkg.theta_matrix(p, 64), [{"I": -1.0}], SOC=1.0)
+    ref = pkg.simulate_ensemble(pkg.petlion(pkg.LCO), pkg.theta_matrix(p, 64), [{"I": -1.0}], SOC=1.0)
+    assert np.array_equal(ens.run_info["flag"], ref.run_info["flag"]) and np.abs(np.asarray(ens.Y) - np.asarray(ref.Y)).max() <= 1e-9 * np.abs(np.asarray(ref.Y)).max()

@@ -57,6 +57,20 @@ def resources_of_object(obj):
     return out
 
 
+def ds_ops_of_object(obj):
+    """(merged, plain) DS operations in the object's device code: ds_read2* / ds_write2* against the other ds_read* / ds_write* -- the visible effect of the backend's
+    load / store merging being OFF (buildflags.NO_LSO; clang's front end claims to ignore the feature string, the backend honours it: a build with merging on has
+    thousands of the two-address forms, one with it off a few dozen that the IR vectoriser formed)"""
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj], stderr=subprocess.DEVNULL)
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat, "--targets=" + TARGET, "--output=" + co], stderr=subprocess.DEVNULL)
+        txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout
+    merged = len(re.findall(r"\bds_(?:read|write)2(?:st64)?_b\d+", txt))
+    plain = len(re.findall(r"\bds_(?:read|write)_b\d+", txt))
+    return merged, plain
+
+
 def _store(out, cur):
     kern, f = demangle_kernel(cur["name"])
     label = kern if f is None else "%s<%d: %s>" % (kern, f, FEATURE_NAMES.get(f, "?"))
@@ -70,6 +84,9 @@ def resources_of_build(obj_dir=None, tag="libpetlion_hip", variants=None):
         m = re.match(re.escape(tag) + r"_v(\d+)\.o$", fn)
         if m and (variants is None or int(m.group(1)) in variants):
             res["v%s" % m.group(1)] = resources_of_object(os.path.join(obj_dir, fn))
+            if m.group(1) == "0":                      # the DS-merging switch, seen in the object (one variant says it for the flag table)
+                mg, pl = ds_ops_of_object(os.path.join(obj_dir, fn))
+                res["v0"]["_ds_ops"] = {"merged_two_address": mg, "plain": pl}
     return res
 
 
@@ -83,6 +100,8 @@ def main():
     print("%-8s %-34s %5s %5s %6s %6s %8s %7s" % ("variant", "kernel", "VGPR", "AGPR", "vspill", "sspill", "scratch", "LDS"))
     for v in sorted(res, key=lambda s: int(s[1:])):
         for k, r in sorted(res[v].items()):
+            if k == "_ds_ops":
+                print("%-8s DS operations: %d two-address (merged) against %d plain" % (v, r["merged_two_address"], r["plain"]))
             if k.startswith("k_integrate"):
                 print("%-8s %-34s %5d %5d %6d %6d %8d %7d" % (v, k, r["vgpr_count"], r["agpr_count"], r["vgpr_spill_count"], r["sgpr_spill_count"], r["private_segment_fixed_size"], r["group_segment_fixed_size"]))
 
