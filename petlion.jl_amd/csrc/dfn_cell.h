@@ -632,15 +632,19 @@ __device__ __forceinline__ double pl_inv_root(double x, int n) {
 // does not arise.  All 64 lanes must be active.  K is a compile-time constant (static_for).
 #ifdef PL_WAVE_EMU
 template <int K> __device__ __forceinline__ void rowb_fmac(double& acc, double c, double m) { acc += __shfl(c, (lane_id() & ~15) + K) * m; }
-__device__ __forceinline__ void csd_settle1(double&) {}
-__device__ __forceinline__ void csd_settle_end() {}
+template <int N> __device__ __forceinline__ void csd_settle(double (&)[N]) {}
 #else
 template <int K> __device__ __forceinline__ void rowb_fmac(double& acc, double c, double m) {
   __asm__("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(m), "n"(K));
 }
 // the broadcast operands, after their loads have landed and two wait states later: whatever wrote the registers last, a DPP read is safe from here on
-__device__ __forceinline__ void csd_settle1(double& c) { __asm__ volatile("" : "+v"(c)); }
-__device__ __forceinline__ void csd_settle_end() { __asm__ volatile("s_nop 1"); }
+// (the wait states sit in an asm that takes the operands in and hands them out: whatever wrote them -- an LDS load or a VALU instruction -- is done before it, and every
+//  rowb_fmac that reads them comes after it BY DATA FLOW, not by the order of statements)
+template <int N> __device__ __forceinline__ void csd_settle(double (&c)[N]) {
+  if constexpr (N == 5) __asm__ volatile("s_nop 1" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]));
+  else if constexpr (N == 4) __asm__ volatile("s_nop 1" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+  else { _Pragma("unroll") for (int k = 0; k < N; k++) __asm__ volatile("s_nop 1" : "+v"(c[k])); }
+}
 #endif
 template <int K, int NK, class F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (K < NK) { f(std::integral_constant<int, K>{}); static_for<K + 1, NK>(f); }
@@ -649,6 +653,11 @@ template <int K, int NK, class F> __device__ __forceinline__ void static_for(F&&
 template <class M> constexpr bool PL_CSDPP = false;
 #else
 template <class M> constexpr bool PL_CSDPP = M::SD == 0 && !M::THERMAL && !M::W2;
+#endif
+#ifdef PL_NO_THROWB
+constexpr bool PL_THROWB = false;
+#else
+constexpr bool PL_THROWB = true;          // the thermal model's particle phases in the row layout (dfn_thermal.h)
 #endif
 
 // a value the compiler must materialise: a product passed through it is ROUNDED before it enters a sum (no fma contraction) -- the reference's operation order of the
@@ -1262,9 +1271,7 @@ PL_DEV void iso_cs_rows_rowb(CellLDS<M>& S, const double* Y, const double* YP, d
     jv[pass] = Y[O_J + pp[pass]];
     ypv[pass] = YP[O_CS + cs_off(pp[pass]) + rk];
   }
-#pragma unroll
-  for (int pass = 0; pass < CSD_PASS; pass++) csd_settle1(cv[pass]);
-  csd_settle_end();
+  csd_settle(cv);
   static_for<0, NR>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
 #pragma unroll
@@ -1702,9 +1709,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
         const int rk = rc < nr_of(pp[pass]) ? rc : nr_of(pp[pass]) - 1;
         bc[pass] = b[O_CS + cs_off(pp[pass]) + rk];
       }
-#pragma unroll
-      for (int pass = 0; pass < CSD_PASS; pass++) csd_settle1(bc[pass]);
-      csd_settle_end();
+      csd_settle(bc);
       static_for<0, NR>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
 #pragma unroll

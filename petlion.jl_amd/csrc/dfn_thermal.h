@@ -380,6 +380,39 @@ PL_DEV void thermal_cs_rows(CellLDS<M>& S, const Tables* __restrict__ tb, const 
   const int lane = lane_id();
   const CellConst& c = S.cc;
   auto& TP = S.th;
+  if constexpr (PL_THROWB) {
+    // r06, ROW layout (dfn_cell.h rowb_fmac): one particle per 16-lane DPP row, lane -> (particle = pass * 4 + lane / 16, row = lane % 16); the particle's vector costs one
+    // LDS load per lane and pass, the sums run over row_newbcast operands -- same terms, same order as the LDS form below
+    const int q = lane >> 4, rr = lane & 15, rc = rr < NR ? rr : NR - 1;
+    double Mr_[NR], Wr_[WANT_JAC ? NR : 1];
+    for (int k = 0; k < NR; k++) { Mr_[k] = S.Mr[rc * NR + k]; if constexpr (WANT_JAC) Wr_[k] = S.Mr[S.OFF_WR + rc * NR + k]; }
+    [[maybe_unused]] double MrN[NR_EQ ? 1 : NR], WrN[(NR_EQ || !WANT_JAC) ? 1 : NR];
+    if constexpr (!NR_EQ) for (int k = 0; k < NR; k++) { MrN[k] = S.Mr[S.mr_el(1) + rc * NR + k]; if constexpr (WANT_JAC) WrN[k] = S.Mr[S.mr_el(1) + S.OFF_WR + rc * NR + k]; }
+    int pp[CSD_PASS]; double acc[CSD_PASS], wc[CSD_PASS], cv[CSD_PASS], jv[CSD_PASS], ypv[CSD_PASS], kp[CSD_PASS];
+#pragma unroll
+    for (int pass = 0; pass < CSD_PASS; pass++) {
+      const int p0 = pass * CSD_G + q; pp[pass] = p0 < NJ ? p0 : NJ - 1; acc[pass] = 0.0; wc[pass] = 0.0;
+      const int rk = rc < nr_of(pp[pass]) ? rc : nr_of(pp[pass]) - 1;
+      cv[pass] = Y[O_CS + cs_off(pp[pass]) + rk]; jv[pass] = Y[O_J + pp[pass]]; ypv[pass] = YP[O_CS + cs_off(pp[pass]) + rk]; kp[pass] = TP.kapP[pp[pass]];
+    }
+    csd_settle(cv);
+    static_for<0, NR>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+#pragma unroll
+      for (int pass = 0; pass < CSD_PASS; pass++) {
+        if constexpr (NR_EQ) { rowb_fmac<k>(acc[pass], cv[pass], Mr_[k]); if constexpr (WANT_JAC) rowb_fmac<k>(wc[pass], cv[pass], Wr_[k]); }
+        else { rowb_fmac<k>(acc[pass], cv[pass], pp[pass] < NP ? Mr_[k] : MrN[k]); if constexpr (WANT_JAC) rowb_fmac<k>(wc[pass], cv[pass], pp[pass] < NP ? Wr_[k] : WrN[k]); }
+      }
+    });
+#pragma unroll
+    for (int pass = 0; pass < CSD_PASS; pass++) {
+      const int p0 = pass * CSD_G + q, p = pp[pass];
+      double rhs = kp[pass] * acc[pass];
+      if (rr == nr_of(p) - 1) rhs += (p < NP ? c.bj_p : c.bj_n) * jv[pass];
+      if (p0 < NJ && rr < NR) { if (rr < nr_of(p)) Fo[O_CS + cs_off(p) + rr] = rhs - ypv[pass]; if (WANT_JAC) TP.AinvQ[p][rr] = wc[pass]; }
+    }
+    return;
+  }
   const int r = lane % NR, g = lane < CS_LANES ? lane / NR : CS_G - 1;
   double Mrow[NR], Wrow[NR];
   // (the radial operator from its LDS copy, as in the isothermal models: r03 fetched it from the table in global memory in every residual and every solve)
@@ -490,7 +523,9 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
   // register diet: C (forward sweep), then Lm (closing), then G (backward sweep) are formed one after the other, so that at most two of the 4x4 blocks
   // are live at a time next to the integrator's per-lane state (the three at once were half of the register file); PL_SYNC keeps the loads where they are
   double C[16], Di[16];
-  for (int k = 0; k < 16; k++) { const double c = S.LD[k][i], d = S.Dinv[k][i]; C[k] = act ? c : 0.0; Di[k] = act ? d : 0.0; }
+  // (r06: no masks -- an idle lane reads node 0's factors, the head of the forward chain whose L D'^-1 is zero, and with its right-hand side zeroed below its recurrence
+  //  stays at zero: dfn_cell.h thomas_sweeps.  64 selects less per solve)
+  for (int k = 0; k < 16; k++) { C[k] = S.LD[k][i]; Di[k] = S.Dinv[k][i]; }
   // ---- the four T rows with a second-neighbour entry (one-sided stencils at nodes 0, 9, 20, 29) inside the twisted elimination ----
   // "far ahead" (node 0 -> node 2, node 29 -> node 27): eliminating x_0 puts -LD_1[:,3] (x) w into U_1, so node 1's (node 28's)
   // back-substitution block is G - (Dinv C[:,3]) (x) w, and x_0 (x_29) gets -Dinv[:,3] (w . x_2) after the sweep.
@@ -536,11 +571,13 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
   }
   PL_SYNC();
   double Lm[16];
-  for (int k = 0; k < 16; k++) { const double l = S.LDmid[k]; Lm[k] = nd == TW_MID ? l : 0.0; }
+  for (int k = 0; k < 16; k++) Lm[k] = S.LDmid[k];          // (unmasked: the broadcast it multiplies is, 8 selects instead of 32)
+  const bool mid = nd == TW_MID;
   double z[NRHS][4];
 #pragma unroll
   for (int q = 0; q < NRHS; q++) {
-    const double m0 = lane_bcast(y[q][0], TW_MID - 1), m1 = lane_bcast(y[q][1], TW_MID - 1), m2 = lane_bcast(y[q][2], TW_MID - 1), m3 = lane_bcast(y[q][3], TW_MID - 1);
+    const double bm0 = lane_bcast(y[q][0], TW_MID - 1), bm1 = lane_bcast(y[q][1], TW_MID - 1), bm2 = lane_bcast(y[q][2], TW_MID - 1), bm3 = lane_bcast(y[q][3], TW_MID - 1);
+    const double m0 = mid ? bm0 : 0.0, m1 = mid ? bm1 : 0.0, m2 = mid ? bm2 : 0.0, m3 = mid ? bm3 : 0.0;
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) y[q][rr] = PL_NMS4(y[q][rr], Lm[rr * 4], m0, Lm[rr * 4 + 1], m1, Lm[rr * 4 + 2], m2, Lm[rr * 4 + 3], m3);
 #pragma unroll
@@ -605,6 +642,43 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
   //    lanes of the particle through the c_s section of S.yy, which is dead between a residual evaluation and the next form_iterate (thermal_solve uses it the same way).
   if (!alg_only) {
     if (lane < NJ) TP.kapF[lane] = TP.kapP[lane];
+    if constexpr (PL_THROWB) {
+      // r06, ROW layout: lane (row q, rr) owns mode rr of particle pass * 4 + q.  The reciprocals and W c / d of a particle's modes sit in the lanes of its DPP row: the two
+      // sums over the modes take them through row_newbcast (rowb_fmac) -- no round trip through the c_s section of S.yy, no phase separator
+      const int q = lane >> 4, rr = lane & 15, rc = rr < NR ? rr : NR - 1;
+      const double lam_r = NR_EQ ? PL_RADIAL_LAM[rc] : tb->LAMp(0)[rc];
+      [[maybe_unused]] const double lam_rN = NR_EQ ? 0.0 : tb->LAMp(1)[rc];
+      double VW[NR], VL[NR];                                  // V[r][m] W[m][last] and V[r][m] lam_m: the constant factors of the two sums
+      [[maybe_unused]] double VWN[NR_EQ ? 1 : NR], VLN[NR_EQ ? 1 : NR];
+      if constexpr (NR_EQ) { for (int m = 0; m < NR; m++) { const double v = S.Mr[S.OFF_VR + rc * NR + m]; VW[m] = v * PL_RADIAL_W[m * NR + NR - 1]; VL[m] = v * PL_RADIAL_LAM[m]; } }
+      else for (int m = 0; m < NR; m++) {
+        const double v = S.Mr[S.OFF_VR + rc * NR + m], vn = S.Mr[S.mr_el(1) + S.OFF_VR + rc * NR + m];
+        VW[m] = v * tb->Wp(0)[m * NR + NRP - 1]; VL[m] = v * tb->LAMp(0)[m]; VWN[m] = vn * tb->Wp(1)[m * NR + NRN - 1]; VLN[m] = vn * tb->LAMp(1)[m];
+      }
+      int pp[CSD_PASS]; double rcv[CSD_PASS], wq[CSD_PASS], ae[CSD_PASS], aq[CSD_PASS], dk[CSD_PASS];
+#pragma unroll
+      for (int pass = 0; pass < CSD_PASS; pass++) {
+        const int p0 = pass * CSD_G + q, pq = p0 < NJ ? p0 : NJ - 1; pp[pass] = pq;
+        R.rcp[pass] = 1.0 / (TP.kapP[pq] * ((NR_EQ || pq < NP) ? lam_r : lam_rN) - cj);
+        rcv[pass] = R.rcp[pass]; wq[pass] = TP.AinvQ[pq][rc] * R.rcp[pass];      // AinvQ still holds W c
+        dk[pass] = TP.dkapP[pq]; ae[pass] = 0.0; aq[pass] = 0.0;
+      }
+      csd_settle(rcv); csd_settle(wq);
+      static_for<0, NR>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+#pragma unroll
+        for (int pass = 0; pass < CSD_PASS; pass++) {
+          if constexpr (NR_EQ) { rowb_fmac<m>(ae[pass], rcv[pass], VW[m]); rowb_fmac<m>(aq[pass], wq[pass], VL[m]); }
+          else { rowb_fmac<m>(ae[pass], rcv[pass], pp[pass] < NP ? VW[m] : VWN[m]); rowb_fmac<m>(aq[pass], wq[pass], pp[pass] < NP ? VL[m] : VLN[m]); }
+        }
+      });
+      PL_SYNC();                                             // every lane has read W c before it is overwritten
+#pragma unroll
+      for (int pass = 0; pass < CSD_PASS; pass++) {
+        const int p0 = pass * CSD_G + q;
+        if (p0 < NJ && rr < NR) { TP.AinvE[pp[pass]][rr] = ae[pass]; TP.AinvQ[pp[pass]][rr] = aq[pass] * dk[pass]; }
+      }
+    } else {
     // (N_r_p != N_r_n: eigenvalues and W[:, last] of the particle's own electrode from the padded tables -- a padded mode has lam = 0, its reciprocal -1/cj meets V = 0 --; the
     //  reciprocals are shared through the particle's own c_s entries of S.yy, S.yy[O_CS + cs_off(p) + mode])
     const double lam_r = NR_EQ ? PL_RADIAL_LAM[r] : tb->LAMp(0)[r];
@@ -654,6 +728,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
     for (int pass = 0; pass < CS_PASS; pass++) {
       const int p0 = pass * CS_G + g, p = p0 < NJ ? p0 : NJ - 1;
       if (lane < CS_LANES && p0 < NJ) { TP.AinvE[p][r] = ae[pass]; TP.AinvQ[p][r] = aq[pass] * TP.dkapP[p]; }
+    }
     }
     // 2. collector chains: (aL, aD - cj, aU) x = rhs by the Thomas algorithm, lane 32 + k = collector node k (systolic DPP chains as in thermal_solve: one LDS load per
     //    operand and lane).  Two fixed right-hand sides: the coupling to T of the neighbouring cell node (Al: last row, through aU; Cu: first row, through aL) and the column of I
@@ -898,6 +973,82 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
   // a. particle partial solutions w = A_p^-1 b_cs  (two mat-vecs through the spectral form, the diagonal from R.rcp); collector forward/backward substitution
   double zbk = 0.0;                                        // lane 32 + k: chain solution of collector node k (T^-1 b_T restricted to the chain)
   if (!alg_only) {
+    auto collectors = [&]() {
+      // collector chains: lane 32 + k owns collector node k (aluminium 0 .. N_a - 1, then copper), the mapping of the residual rows and of phase e.  Both Thomas recurrences
+      // run as systolic DPP chains (every lane re-evaluates its stage until its predecessor is final, as in the block sweeps): ONE LDS load per operand and lane instead of
+      // the 4 N_a loads per lane of a single-lane recurrence -- the LDS array, shared by the four cells of the CU, is what the particle phases wait for -- and straight-line
+      // code the scheduler interleaves with the mat-vecs.  The chain heads have a zero multiplier, so the copper chain ignores the lane below it.
+      const int ck = lane - 32;
+      const bool cact = ck >= 0 && ck < NA + NZ;
+      const int kq = cact ? ck : 0, q = kq < NA ? 0 : 1, kk = q == 0 ? kq : kq - NA, ic = q == 0 ? kk : NA + NE + kk, nq = q == 0 ? NA : NZ;
+      const double l_bv = b[O_T + ic], l_aL = TP.aL[ic], l_aU = TP.aU[ic], l_cp = TP.cP[q][kk];
+      const double cp_prev = shift_up1(l_cp);
+      const double cm = (cact && kk > 0) ? l_aL * cp_prev : 0.0, up = (cact && kk < nq - 1) ? l_aU : 0.0, bv = cact ? l_bv : 0.0, cpk = cact ? l_cp : 0.0;
+      constexpr int NC = NA > NZ ? NA : NZ;
+      double f = bv;
+#pragma unroll
+      for (int st = 1; st < NC; st++) { const double fp = shift_up1(f); f = bv - cm * fp; }
+      double x = f * cpk;
+#pragma unroll
+      for (int st = 1; st < NC; st++) { const double xn = shift_down1(x); x = (f - up * xn) * cpk; }
+      zbk = x;
+    };
+    if constexpr (PL_THROWB) {
+      double yvr[CSD_PASS];                                 // W b / d per pass, handed from the first mat-vec to the second in registers
+        // r06, ROW layout: y = diag(1 / (kappa lam - cj)) W b with b through row_newbcast; the second mat-vec (below, behind the collector chains) takes y from the lanes of
+        // the row as well -- r05 wrote y to the c_s section of S.yy and read it back behind a phase separator
+        const int q = lane >> 4, rr = lane & 15, rc = rr < NR ? rr : NR - 1;
+        double Wr_[NR];
+        for (int k = 0; k < NR; k++) Wr_[k] = S.Mr[S.OFF_WR + rc * NR + k];
+        [[maybe_unused]] double WrN[NR_EQ ? 1 : NR];
+        if constexpr (!NR_EQ) for (int k = 0; k < NR; k++) WrN[k] = S.Mr[S.mr_el(1) + S.OFF_WR + rc * NR + k];
+        int pp[CSD_PASS]; double bc[CSD_PASS];
+  #pragma unroll
+        for (int pass = 0; pass < CSD_PASS; pass++) {
+          const int p0 = pass * CSD_G + q; pp[pass] = p0 < NJ ? p0 : NJ - 1; yvr[pass] = 0.0;
+          const int rk = rc < nr_of(pp[pass]) ? rc : nr_of(pp[pass]) - 1;
+          bc[pass] = b[O_CS + cs_off(pp[pass]) + rk];
+        }
+        csd_settle(bc);
+        static_for<0, NR>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+  #pragma unroll
+          for (int pass = 0; pass < CSD_PASS; pass++) {
+            if constexpr (NR_EQ) rowb_fmac<k>(yvr[pass], bc[pass], Wr_[k]);
+            else rowb_fmac<k>(yvr[pass], bc[pass], pp[pass] < NP ? Wr_[k] : WrN[k]);
+          }
+        });
+  #pragma unroll
+        for (int pass = 0; pass < CSD_PASS; pass++) yvr[pass] *= R.rcp[pass];
+      collectors();
+      // second mat-vec: w = V y with y from the lanes of the row (registers: no LDS round trip, no phase separator)
+      {
+        const int q = lane >> 4, rr = lane & 15, rc = rr < NR ? rr : NR - 1;
+        double Vr_[NR];
+        for (int m = 0; m < NR; m++) Vr_[m] = S.Mr[S.OFF_VR + rc * NR + m];
+        [[maybe_unused]] double VrN[NR_EQ ? 1 : NR];
+        if constexpr (!NR_EQ) for (int m = 0; m < NR; m++) VrN[m] = S.Mr[S.mr_el(1) + S.OFF_VR + rc * NR + m];
+        double w[CSD_PASS];
+#pragma unroll
+        for (int pass = 0; pass < CSD_PASS; pass++) w[pass] = 0.0;
+        csd_settle(yvr);
+        static_for<0, NR>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+#pragma unroll
+          for (int pass = 0; pass < CSD_PASS; pass++) {
+            const int p0 = pass * CSD_G + q, pc = p0 < NJ ? p0 : NJ - 1;
+            if constexpr (NR_EQ) rowb_fmac<m>(w[pass], yvr[pass], Vr_[m]);
+            else rowb_fmac<m>(w[pass], yvr[pass], pc < NP ? Vr_[m] : VrN[m]);
+          }
+        });
+#pragma unroll
+        for (int pass = 0; pass < CSD_PASS; pass++) {
+          const int p0 = pass * CSD_G + q;
+          if (p0 < NJ && rr == nr_of(p0 < NJ ? p0 : NJ - 1) - 1) S.w9[p0] = w[pass];
+          R.wreg[pass] = w[pass];
+        }
+      }
+    } else {
     double Wrow[NR], Vrow[NR];
     for (int k = 0; k < NR; k++) { Wrow[k] = S.Mr[S.OFF_WR + r * NR + k]; Vrow[k] = S.Mr[S.OFF_VR + r * NR + k]; }
     // (one address register per array for the lane's particle group; pass and column go into the offset fields.  The last pass may reach beyond the last particle: its
@@ -929,26 +1080,7 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
       if constexpr (NR_EQ) { if (lane < CS_LANES && pass * CS_G + g < NJ) yg[pass * CS_G * NR] = yv[pass]; }   // S.yy is dead between a residual and the next form_iterate
       else { const int p0 = pass * CS_G + g; if (lane < CS_LANES && p0 < NJ && r < nr_of(p0)) S.yy[O_CS + cs_off(p0) + r] = yv[pass]; }
     }
-    {
-      // collector chains: lane 32 + k owns collector node k (aluminium 0 .. N_a - 1, then copper), the mapping of the residual rows and of phase e.  Both Thomas recurrences
-      // run as systolic DPP chains (every lane re-evaluates its stage until its predecessor is final, as in the block sweeps): ONE LDS load per operand and lane instead of
-      // the 4 N_a loads per lane of a single-lane recurrence -- the LDS array, shared by the four cells of the CU, is what the particle phases wait for -- and straight-line
-      // code the scheduler interleaves with the mat-vecs.  The chain heads have a zero multiplier, so the copper chain ignores the lane below it.
-      const int ck = lane - 32;
-      const bool cact = ck >= 0 && ck < NA + NZ;
-      const int kq = cact ? ck : 0, q = kq < NA ? 0 : 1, kk = q == 0 ? kq : kq - NA, ic = q == 0 ? kk : NA + NE + kk, nq = q == 0 ? NA : NZ;
-      const double l_bv = b[O_T + ic], l_aL = TP.aL[ic], l_aU = TP.aU[ic], l_cp = TP.cP[q][kk];
-      const double cp_prev = shift_up1(l_cp);
-      const double cm = (cact && kk > 0) ? l_aL * cp_prev : 0.0, up = (cact && kk < nq - 1) ? l_aU : 0.0, bv = cact ? l_bv : 0.0, cpk = cact ? l_cp : 0.0;
-      constexpr int NC = NA > NZ ? NA : NZ;
-      double f = bv;
-#pragma unroll
-      for (int st = 1; st < NC; st++) { const double fp = shift_up1(f); f = bv - cm * fp; }
-      double x = f * cpk;
-#pragma unroll
-      for (int st = 1; st < NC; st++) { const double xn = shift_down1(x); x = (f - up * xn) * cpk; }
-      zbk = x;
-    }
+    collectors();
     PL_SYNC();
     const lds_cptr yr = PL_LDS_BASE_A(A16, (const double*)S.yy + O_CS + g * NR), yl = PL_LDS_BASE_A(A16, (const double*)S.yy + O_CS + (over ? NJ - 1 : LASTP + g) * NR);
 #pragma unroll
@@ -965,6 +1097,7 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
       }
       if (lane < CS_LANES && p0 < NJ && r == nr_of(p0) - 1) S.w9[p0] = w;
       R.wreg[pass] = w;
+    }
     }
   }
   PL_SYNC();
@@ -1054,6 +1187,24 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
   PL_SYNC();
   PL_TOCE(S, 2, 3);
   // f. particles: dc = w - A^-1 e_last bj dj - A^-1 q dT
+  if constexpr (PL_THROWB) {
+    if (!alg_only) {       // ROW layout
+      const int q = lane >> 4, rr = lane & 15, rc = rr < NR ? rr : NR - 1;
+      double ae[CSD_PASS], aq[CSD_PASS], dj[CSD_PASS], dT[CSD_PASS];
+#pragma unroll
+      for (int pass = 0; pass < CSD_PASS; pass++) {
+        const int p0 = pass * CSD_G + q, p = p0 < NJ ? p0 : NJ - 1, ndp = p < NP ? p : p + NS;
+        ae[pass] = TP.AinvE[p][rc]; aq[pass] = TP.AinvQ[p][rc]; dj[pass] = b[O_J + p]; dT[pass] = b[O_T + NA + ndp];
+      }
+#pragma unroll
+      for (int pass = 0; pass < CSD_PASS; pass++) {
+        const int p0 = pass * CSD_G + q, p = p0 < NJ ? p0 : NJ - 1;
+        const double bj = p < NP ? c.bj_p : c.bj_n;
+        const double v = R.wreg[pass] - ae[pass] * bj * dj[pass] - aq[pass] * dT[pass];
+        if (p0 < NJ && rr < nr_of(p)) b[O_CS + cs_off(p) + rr] = v;
+      }
+    }
+  } else
   if (!alg_only) {
     // (unconditional clamped loads first, guarded stores last -- see iso_solve)
     double ae[CS_PASS], aq[CS_PASS], dj[CS_PASS], dT[CS_PASS];
