@@ -30,7 +30,7 @@ for n in names + [x for x in L["C5"]["general_path"] if x not in names]:
     row = []
     for C in L:
         g = L[C]["general_path"]
-        key = n if n in g else next((x for x in g if x[:40] == n[:40]), None)
+        key = n if n in g else None          # (exact names only: matching on a prefix printed the 7-parameter sensitivity row twice)
         row.append("%.2f" % g[key]["vs_plain_kernel"] if key and "vs_plain_kernel" in g[key] else "--")
     print("| %s | %s |" % (n.split(":")[0][:110], " | ".join(row)))
 ps = L["C4"].get("predicted_scaling")

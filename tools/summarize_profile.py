@@ -7,6 +7,19 @@ workload = sys.argv[3] if len(sys.argv) > 3 else "C2"                       # us
 cells = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 precision = sys.argv[5] if len(sys.argv) > 5 else "f64"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_record(workload):
+    """the plain kernel of the workload's variant in the build record next to the library (tools/kernel_resources.py; the same figures go into profiles/validated_build.json)"""
+    import json
+    try:
+        k = json.load(open(os.path.join(ROOT, "petlion.jl_amd", "libpetlion_hip.so.resources.json")))["kernels"][{"C2": "v0", "C4": "v0", "C3": "v4", "C5": "v3"}[workload]]["k_integrate<0: plain>"]
+        return ("petlion.jl_amd/libpetlion_hip.so.resources.json: %d registers (%d of them AGPRs), %d VGPR spills, %d SGPR spills, %d B/lane of scratch, %d B of LDS per cell"
+                % (k["vgpr_count"], k["agpr_count"], k["vgpr_spill_count"], k["sgpr_spill_count"], k["private_segment_fixed_size"], k["group_segment_fixed_size"]))
+    except Exception as e:
+        return "no build record next to the library (%r)" % (e,)
+
+
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 out = os.path.join(ROOT, "profiles", "%s_rocprofv3_summary.md" % label)
 L = ["# rocprofv3 summary `%s`" % label, "",
@@ -20,9 +33,8 @@ rows = cur.execute("select duration, vgpr_count, accum_vgpr_count, sgpr_count, l
 d = [r[0] for r in rows]
 L += ["", "`k_integrate`: %d dispatches, duration min/avg/max = %.1f / %.1f / %.1f us; grid %d x wg %d; arch VGPR %s, AGPR %s, SGPR %s, LDS %s B, scratch %s B/lane"
       % (len(d), min(d) / 1e3, sum(d) / len(d) / 1e3, max(d) / 1e3, rows[0][6], rows[0][7], rows[0][1], rows[0][2], rows[0][3], rows[0][4], rows[0][5]),
-      "", "(register columns as rocprofv3 reports them; `accum_vgpr_count` reads 0 on this unified-file part -- the compiler's own figures for this kernel, `hipcc -Rpass-analysis=kernel-resource-usage`: "
-      + {"C2": "256 VGPR + 129 AGPR, 92 VGPR spills into AGPRs, 298 SGPR spills, 0 B/lane scratch", "C4": "256 VGPR + 129 AGPR, 92 VGPR spills into AGPRs, 298 SGPR spills, 0 B/lane scratch",
-         "C3": "256 VGPR + 230 AGPR, 132 VGPR spills into AGPRs, 427 SGPR spills, 0 B/lane scratch", "C5": "256 VGPR + 214 AGPR, 104 VGPR spills into AGPRs, 370 SGPR spills, 0 B/lane scratch"}.get(workload, "see csrc/petlion_kernels.h") + ")",
+      "", "(register columns as rocprofv3 reports them; `accum_vgpr_count` reads 0 on this unified-file part.  What the compiler built, from the code object's own notes -- "
+      + build_record(workload) + ")",
       "", "Per dispatch in launch order (us): " + ", ".join("%.0f" % (x / 1e3) for x in d) + " -- the first launches of a process run slower (clock ramp); "
       "the steady state (last three: %.0f us) is what `bench.py` times after its warm-up steps (`roofline.kernel_ms_avg`, HIP events on the launch stream)." % (sum(d[-3:]) / 3e3), ""]
 L += ["## PMC passes (per k_integrate launch = %d cells = %d wavefronts; averages over the dispatches of the run)" % (cells, cells), "", "| counter | value per launch | per wavefront |", "|---|---|---|"]
