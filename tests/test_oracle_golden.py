@@ -61,22 +61,22 @@ def test_symbolic_jacobian_vs_complex_step(O):
         assert np.abs(J[:, c] - col).max() <= 1e-10 * (np.abs(col).max() + 1e-300), c
 
 
-def test_V0_known_answer(O):
-    th = O.theta_vector("lco_iso")
-    Y0 = O.initial_guess("lco_iso", th, 0.0); Y0[-1] = 2.0
-    rc, Y, YP, it = O.init_consistent("lco_iso", th, Y0, O.MODE_I, 2.0)
+def test_V0_known_answer(O, variant="lco_iso"):
+    th = O.theta_vector(variant)
+    Y0 = O.initial_guess(variant, th, 0.0); Y0[-1] = 2.0
+    rc, Y, YP, it = O.init_consistent(variant, th, Y0, O.MODE_I, 2.0)
     assert rc == 0 and it == 4
     assert abs((Y[280] - Y[299]) - G["V0_2C_charge"]["value"]) < G["V0_2C_charge"]["tol_abs"]
 
 
-def test_notebook_runs(O):
-    th = O.theta_vector("lco_iso")
+def test_notebook_runs(O, variant="lco_iso"):
+    th = O.theta_vector(variant)
     k = G["runs"]["discharge_1C"]
-    r = O.simulate("lco_iso", th, 1.0, [dict(mode=O.MODE_I, value=-1.0)])["runs"][0]
+    r = O.simulate(variant, th, 1.0, [dict(mode=O.MODE_I, value=-1.0)])["runs"][0]
     assert r["flag"] == k["flag"] and abs(r["t_end"] - k["t_end"]) <= k["tol"]["t_end_rel"] * k["t_end"]
     assert abs(r["V"] - k["V_end"]) < k["tol"]["V_abs"] and abs(r["SOC"]) < 1e-12
     b = O.default_bounds(V_max=4.1)
-    ro = O.simulate("lco_iso", th, 0.0, [dict(mode=O.MODE_I, value=2.0, tf=1800.0, bounds=b),
+    ro = O.simulate(variant, th, 0.0, [dict(mode=O.MODE_I, value=2.0, tf=1800.0, bounds=b),
                                           dict(mode=O.MODE_V, value_kind=O.VAL_HOLD, bounds=O.default_bounds(V_max=4.1, I_min=1 / 20))])
     k1, k2 = G["runs"]["charge_2C_to_4p1"], G["runs"]["cv_hold_after_2C"]
     r1, r2 = ro["runs"]
@@ -116,15 +116,15 @@ def check_notebook_step_history(sim, exact_hold_leg=True):
     assert abs(len(r0["t"]) - 121) <= 8 and abs(r0["V"][0] - k["values"][0]) < 1e-10 and abs(1e3 * r0["t"][1] - 1.3035) < 1e-3
 
 
-def test_step_history_of_the_2C_charge_notebook(O):
+def test_step_history_of_the_2C_charge_notebook(O, variant="lco_iso", exact_hold_leg=True):
     """examples/model_inputs_and_outputs.ipynb cells 6-12 (lines 152-164, 236-240)"""
-    th = O.theta_vector("lco_iso")
+    th = O.theta_vector(variant)
     runs = [dict(mode=O.MODE_I, value=2.0, tf=1e6, bounds=O.default_bounds(V_max=4.1)), dict(mode=O.MODE_V, value_kind=O.VAL_HOLD, tf=1e6, bounds=O.default_bounds(V_max=4.1))]
 
     def sim(z):
-        r = O.simulate("lco_iso", th, 0.0, runs, opts=O.default_opts(exp_yp_alg_zero=int(z)), keep_Y=True)
+        r = O.simulate(variant, th, 0.0, runs, opts=O.default_opts(exp_yp_alg_zero=int(z)), keep_Y=True)
         return dict(t=r["t"], V=r["V"], c_e=r["Y_all"][:, :30], runs=r["runs"])
-    check_notebook_step_history(sim)
+    check_notebook_step_history(sim, exact_hold_leg)
 
 
 def test_tolerance_tightening_converges(O):
@@ -290,6 +290,30 @@ def test_the_generated_phi_s_rows_are_quantised_and_the_notebook_shows_it(O):
     assert np.abs(Fa[o_ps:o_ps + 10] - Fb[o_ps:o_ps + 10]).max() <= 1.01 * ulp                      # ... within one ulp of the quiet evaluation
 
 
+def test_quiet_variants_and_the_notebook_kats(O):
+    """the known-answer tests of the reference's notebooks, run through the QUIET oracle variants (the ones the device's default build is compared with
+    cell by cell), with the one they fail named.
+
+    pass (same thresholds as the plain, notebook-pinned variants):
+      * V(t = 0) of the 2C charge, 4 Newton iterations                      (model_inputs_and_outputs.ipynb; test_V0_known_answer)
+      * 1C discharge: 3600.0 s, flag 3, V_end; 2C charge to 4.1 V: t_end, SOC, P; V = :hold to I_min: t_end, I_end       (test_notebook_runs)
+      * the printed step history of the 2C charge: 84 saved points, sol.V[1:13] to 1e-8, the step times, five c_e profiles, the last twelve voltages, 1388.68 s
+      * the four function-input results                                       (variable_input_functions.ipynb; test_function_inputs_notebook)
+      * CC-CT-CV: 357.56 s / 686.41 s / flags / T_avg = 40 C                  (fast_charging_CC-CT-CV.ipynb; lco_thermal_quiet)
+    FAIL -- exactly one:
+      * the number of saved points of the `simulate!(sol, p, V = :hold)` leg of model_inputs_and_outputs.ipynb: the notebook has 37 (121 in total), the quiet variant takes
+        38 and ends at 2441.33 s / 0.1944 C instead of 2440.61 s / 0.1955 C -- the same solution within the integration tolerance on another step sequence.  That is the r05
+        finding itself (test_the_generated_phi_s_rows_are_quantised_and_the_notebook_shows_it: the reference's generated Phi_s rows are quantised at ulp(Phi_s), the noise steers
+        the start-up order selection of a hold leg); a device build that reproduces it exists (precision = "f64_reforder")."""
+    test_V0_known_answer(O, "lco_iso_quiet")
+    test_notebook_runs(O, "lco_iso_quiet")
+    test_function_inputs_notebook(O, "lco_iso_quiet")
+    test_step_history_of_the_2C_charge_notebook(O, "lco_iso_quiet", exact_hold_leg=False)           # everything but the hold leg's point count / end time to two decimals
+    with pytest.raises(AssertionError):                                                             # ... which is the one KAT it fails
+        test_step_history_of_the_2C_charge_notebook(O, "lco_iso_quiet", exact_hold_leg=True)
+    test_thermal_cc_ct_cv_notebook(O, "lco_thermal_quiet")
+
+
 def test_thermal_jacobian_vs_complex_step(O):
     m = dm.Model("LCO", temperature=True)
     th = O.theta_vector("lco_thermal")
@@ -328,14 +352,14 @@ def test_nmc_sei_variant(O):
     assert abs(ro["runs"][1]["SOC"] - 0.05) < 1e-6
 
 
-def test_function_inputs_notebook(O):
+def test_function_inputs_notebook(O, variant="lco_iso"):
     """reference examples/variable_input_functions.ipynb: time-dependent current (a step with and without tdiscon, two ramps) given here as
     piecewise-linear tables (run_function: scalar_residual.jl:169-170, tstops of tdiscon model_evaluation.jl:295-297, checks.jl:251-269,341-364)"""
-    th = O.theta_vector("lco_iso")
+    th = O.theta_vector(variant)
     I1C = 29.23                                       # printed to 2 decimals in the notebooks; the exact value is pinned in test_I1C
     for key in ("func_step_no_tdiscon", "func_step_tdiscon", "func_ramp_100", "func_ramp_10"):
         k = G["runs"][key]
-        ro = O.simulate("lco_iso", th, k["SOC0"], [dict(mode=O.MODE_I, table=k["table"], tf=k["tf"])], opts=O.default_opts(tdiscon=k["tdiscon"]))
+        ro = O.simulate(variant, th, k["SOC0"], [dict(mode=O.MODE_I, table=k["table"], tf=k["tf"])], opts=O.default_opts(tdiscon=k["tdiscon"]))
         r = ro["runs"][0]
         assert r["flag"] == k["flag"] and abs(r["t_end"] - k["t_end"]) < 1e-9
         assert abs(r["I"] - k["I_end"]) < 1e-12 and abs(r["V"] - k["V_end"]) < k["tol"]["V_abs"], (key, r["V"])
