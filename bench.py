@@ -216,14 +216,18 @@ def host_inclusive(pkg, p, inp, n_local, kernel_ms, calls=None):
     ms_med = 1e3 * float(np.median(steady))
     # the same call made synchronously through pageable memory (PLH_HOST: what an unprepared host does)
     pkg.simulate_ensemble(p, Th, inp["protocol"], SOC=inp["SOC"], max_points=inp["max_points"])
-    ts = []
-    for _ in range(5):
-        t1 = time.perf_counter(); pkg.simulate_ensemble(p, Th, inp["protocol"], SOC=inp["SOC"], max_points=inp["max_points"]); ts.append(time.perf_counter() - t1)
+    ts, tin = [], []
+    for _ in range(7):
+        t1 = time.perf_counter(); e_ = pkg.simulate_ensemble(p, Th, inp["protocol"], SOC=inp["SOC"], max_points=inp["max_points"]); tin.append(e_.call_ms); del e_
+        ts.append(time.perf_counter() - t1)          # (allocation of the outputs, the call, and the release of the result: the whole cycle of a caller that allocates per call)
     pipe.close()
     return {"value": n_local / (ms_med * 1e-3), "unit": "trajectories/s", "ms_per_call_median": ms_med, "calls": calls, "aggregate_value": calls * n_local / total,
             "fraction_of_kernel_rate": kernel_ms / ms_med,
             "what": "H2D of Theta (pinned), kernel, D2H of run_info + counters + n_pts + t, V [%d points] per cell; two calls in flight on two streams (PLH_HOST_ASYNC)" % inp["max_points"],
-            "synchronous_pageable": {"value": n_local / float(np.median(ts)), "ms_per_call_median": 1e3 * float(np.median(ts)),
+            "synchronous_pageable": {"value": n_local / float(np.median(ts)), "ms_per_call_median": 1e3 * float(np.median(ts)), "fraction_of_kernel_rate": kernel_ms / (1e3 * float(np.median(ts))),
+                                     "inside_plh_integrate": {"value": n_local / (1e-3 * float(np.median(tin))), "ms_per_call_median": float(np.median(tin)), "fraction_of_kernel_rate": kernel_ms / float(np.median(tin)),
+                                                              "what": "wall time of the plh_integrate call alone (staging H2D, kernel, copies back into the caller's arrays); the difference to the line above is the caller's "
+                                                                      "own allocation and release of 13 MB (C2) ... 100 MB (C4) of output arrays per call"},
                                      "what": "one blocking PLH_HOST call at a time through freshly allocated pageable numpy arrays, all outputs (t, V, I, SOC, Y, YP, ...): "
                                              "staging H2D, kernel, D2H through the pinned bounce buffer, memcpy; its spread between runs (r01: 221 k vs 341 k traj/s) is the page-fault "
                                              "cost of first-touch output arrays, which depends on the allocator state of the calling process"}}

@@ -14,6 +14,7 @@ import ctypes as C
 import math
 import os
 
+import time
 import numpy as np
 
 from . import _capi as cap
@@ -793,8 +794,10 @@ def _integrate(p, theta, SOC0, runs, o, Y_init=None, t_init=None, device=False, 
         cap.check(lib, lib.plh_integrate_sens(h, n, cap.ptr(theta), cap.ptr(SOC0), len(runs), arr, C.byref(os_), C.byref(out), ns, cols.ctypes.data,
                                               cap.ptr(bufs["dY_dtheta"]), cap.ptr(bufs["dV_dtheta"]), cap.ptr(bufs["sens_stat"]), kind, stream), "plh_integrate_sens")
     else:
-        cap.check(lib, lib.plh_integrate(h, n, cap.ptr(theta), cap.ptr(SOC0), cap.ptr(Y_init), cap.ptr(t_init), len(runs), arr,
-                                         C.byref(os_), C.byref(out), kind, stream), "plh_integrate")
+        t_call = time.perf_counter()
+        rc = lib.plh_integrate(h, n, cap.ptr(theta), cap.ptr(SOC0), cap.ptr(Y_init), cap.ptr(t_init), len(runs), arr, C.byref(os_), C.byref(out), kind, stream)
+        bufs["call_ms"] = 1e3 * (time.perf_counter() - t_call)          # wall time inside plh_integrate (a blocking PLH_HOST call: staging, kernel, the way back)
+        cap.check(lib, rc, "plh_integrate")
     if device:
         if stream is not None and int(stream) != torch.cuda.current_stream(dev).cuda_stream:
             # the buffers were allocated on torch's current stream but the kernel runs on `stream`: tell the caching allocator, or it may hand the
@@ -823,6 +826,7 @@ class EnsembleSolution:
         self._counters = bufs["counters"]
         self.run_names = run_names
         self._kernel_ms = bufs.get("kernel_ms", -1.0)
+        self.call_ms = bufs.get("call_ms")      # wall time of the plh_integrate call itself (host pointers: includes the copies back)
         # forward parameter sensitivities (simulate_ensemble(..., sens=[keys])): [cell, k, state] at the end of the protocol, [cell, k, point] for the voltage
         self.dY_dtheta, self.dV_dtheta, self.sens_stat = bufs.get("dY_dtheta"), bufs.get("dV_dtheta"), bufs.get("sens_stat")
 

@@ -11,6 +11,10 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <cerrno>
+#include <sys/mman.h>
+#include <atomic>
+#include <chrono>
 #include <functional>
 #include <vector>
 
@@ -275,33 +279,54 @@ struct Stage {
 // were never defined), (iii) every device-to-host copy is issued at once, asynchronously, into ONE pinned block, and the host copies array k into the caller's memory while
 // arrays k+1 ... are still in flight.
 struct HostRet { char* host; const char* dev; size_t rows, width, pitch, pin_off; };      // rows x width bytes; both sides keep their rows `pitch` bytes apart (one row: a plain copy)
-static void par_chunks(size_t n_items, size_t min_per_thread, const std::function<void(size_t, size_t)>& f) {
-  unsigned nt = (unsigned)std::min<size_t>(4, n_items / (min_per_thread ? min_per_thread : 1));
-#ifdef PL_WAVE_EMU
-  nt = 1;
+// first touch of the caller's output pages (they are overwritten afterwards: writing a zero is harmless).  Rows longer than a page: only the pages the prefix copy can reach.
+// r06b: ONE parallel region over all arrays (a thread team per array cost more in thread starts than the small arrays in faults), and the whole pages inside an array are
+// populated by madvise(MADV_POPULATE_WRITE) (Linux >= 5.14: the kernel fills the page tables in one call instead of one trap per page -- measured on the GPU box, 13 MB of
+// fresh anonymous memory: 0.43 ms against 0.99 ms for the touch loop on four threads, 100 MB: 2.7 against 8.2 ms; more threads lose: tools/gpu/host_ubench.hip); a kernel
+// that does not know the advice falls back to the touch loop.
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
 #endif
-  if (nt <= 1) { f(0, n_items); return; }
-  std::vector<std::thread> th;
-  const size_t per = (n_items + nt - 1) / nt;
-  for (unsigned k = 1; k < nt; k++) th.emplace_back(f, std::min(n_items, k * per), std::min(n_items, (k + 1) * per));
-  f(0, std::min(n_items, per));
-  for (auto& t : th) t.join();
+static void touch_pages(char* h, size_t bytes) { for (size_t k = 0; k < bytes; k += 4096) ((volatile char*)h)[k] = 0; if (bytes) ((volatile char*)h)[bytes - 1] = 0; }
+static void populate(char* h, size_t bytes) {
+  static std::atomic<int> have_populate{1};
+  const uintptr_t PG = 4096, lo = ((uintptr_t)h + PG - 1) & ~(PG - 1), hi = ((uintptr_t)h + bytes) & ~(PG - 1);
+  if (have_populate.load(std::memory_order_relaxed) && hi > lo) {
+    if (madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE) == 0) {
+      ((volatile char*)h)[0] = 0; ((volatile char*)h)[bytes - 1] = 0;            // the partial pages at both ends
+      return;
+    }
+    if (errno == EINVAL) have_populate.store(0, std::memory_order_relaxed);
+  }
+  touch_pages(h, bytes);
 }
-// first touch of the caller's output pages (they are overwritten afterwards: writing a zero is harmless).  Rows longer than a page: only the pages the prefix copy can reach
 static void prefault(const std::vector<HostRet>& rets, size_t prefix_bytes_of_wide_rows) {
   const size_t PG = 4096;
+  struct Piece { char* h; size_t bytes; };
+  std::vector<Piece> pieces; size_t total = 0;
   for (const HostRet& r : rets) {
     if (!r.host) continue;
     if (r.rows <= 1 || r.pitch <= PG) {
-      const size_t bytes = r.rows <= 1 ? r.width : r.rows * r.pitch, pages = (bytes + PG - 1) / PG;
-      char* h = r.host;
-      par_chunks(pages, 256, [h, bytes](size_t a, size_t b) { for (size_t k = a; k < b; k++) ((volatile char*)h)[std::min(bytes - 1, k * PG)] = 0; });
+      const size_t bytes = r.rows <= 1 ? r.width : r.rows * r.pitch;
+      for (size_t o = 0; o < bytes; o += (1u << 20)) { pieces.push_back({r.host + o, std::min<size_t>(1u << 20, bytes - o)}); }          // 1 MB pieces: the unit of work sharing
+      total += bytes;
     } else {
-      const size_t span = std::min(r.width, prefix_bytes_of_wide_rows), per_row = (span + PG - 1) / PG;
-      char* h = r.host; const size_t pitch = r.pitch;
-      par_chunks(r.rows, 64, [h, pitch, span, per_row](size_t a, size_t b) { for (size_t q = a; q < b; q++) for (size_t k = 0; k < per_row; k++) ((volatile char*)h)[q * pitch + std::min(span - 1, k * PG)] = 0; });
+      const size_t span = std::min(r.width, prefix_bytes_of_wide_rows);
+      for (size_t q = 0; q < r.rows; q++) pieces.push_back({r.host + q * r.pitch, span});
+      total += r.rows * span;
     }
   }
+  unsigned nt = (unsigned)std::min<size_t>(4, total / (1u << 20));
+#ifdef PL_WAVE_EMU
+  nt = 1;
+#endif
+  if (nt <= 1) { for (const Piece& pc : pieces) populate(pc.h, pc.bytes); return; }
+  std::atomic<size_t> next{0};
+  auto work = [&] { for (size_t k; (k = next.fetch_add(1, std::memory_order_relaxed)) < pieces.size();) populate(pieces[k].h, pieces[k].bytes); };
+  std::vector<std::thread> th;
+  for (unsigned k = 1; k < nt; k++) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
 }
 #define CHECK_MODEL(m) do { if (!(m)) return fail(PLH_E_ARG, "null model"); } while (0)
 #define CHECK_MODE(mode) do { if ((mode) != PLH_MODE_I && (mode) != PLH_MODE_V && (mode) != PLH_MODE_P && (mode) != PLH_MODE_ETA_P && !((mode) == PLH_MODE_DT && m->desc.temperature)) \
@@ -697,6 +722,54 @@ int plh_init_consistent(plh_model_t m, int n, const double* theta, int mode, dou
   return 0;
 }
 
+// ---- r06b: the copy kernels of a blocking host call's way back.  The outputs travel to the pinned block by KERNELS that store into mapped host memory (54 GB/s on the GPU box,
+// the rate of one large blocking hipMemcpy; a chain of hipMemcpyAsync / hipMemcpy2DAsync commands with events between them reached 30 ... 40 GB/s), and the whole chain is
+// queued BEHIND the integrate kernel before it ends: no host round trip between the kernel and the first byte on the bus.  The per-point arrays are packed to the longest
+// trajectory of the call (row r of an array lands at r x maxn x elem), which the device works out itself (k_max_npts).
+__host__ __device__ inline void pack_word(const char* src, size_t pitch, size_t w8, size_t row0, char* dst, size_t q) {
+  const size_t r = row0 + q / w8, c = q % w8;
+  ((double*)(dst + r * w8 * 8))[c] = ((const double*)(src + r * pitch))[c];
+}
+#ifndef PL_WAVE_EMU
+__global__ void k_max_npts(const int* n_pts, int n, int mp, int* maxn_dev, int* host_hdr, int* host_npts) {          // one workgroup
+  __shared__ int sm[256];
+  int v = 0;
+  for (int i = threadIdx.x; i < n; i += 256) { const int x = n_pts[i]; host_npts[i] = x; v = x > v ? x : v; }
+  sm[threadIdx.x] = v; __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if ((int)threadIdx.x < k && sm[threadIdx.x + k] > sm[threadIdx.x]) sm[threadIdx.x] = sm[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) { const int mx = sm[0] < mp ? sm[0] : mp; *maxn_dev = mx; *host_hdr = mx; }
+}
+__global__ void k_pack_rows(const char* src, size_t pitch, size_t elem8, const int* maxn_dev, size_t row0, size_t rows, char* dst) {
+  const size_t w8 = (size_t)(*maxn_dev) * elem8, total = rows * w8;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (size_t)gridDim.x * blockDim.x) pack_word(src, pitch, w8, row0, dst, q);
+}
+__global__ void k_copy_words(const double* src, double* dst, size_t n8) {
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n8; q += (size_t)gridDim.x * blockDim.x) dst[q] = src[q];
+}
+#endif
+static void launch_max_npts(hipStream_t st, const int* n_pts, int n, int mp, int* maxn_dev, int* host_hdr, int* host_npts) {
+#ifndef PL_WAVE_EMU
+  hipLaunchKernelGGL(k_max_npts, dim3(1), dim3(256), 0, st, n_pts, n, mp, maxn_dev, host_hdr, host_npts);
+#else
+  (void)st; int v = 0; for (int i = 0; i < n; i++) { host_npts[i] = n_pts[i]; v = std::max(v, n_pts[i]); } *maxn_dev = *host_hdr = std::min(v, mp);
+#endif
+}
+static void launch_pack_rows(hipStream_t st, const char* src, size_t pitch, size_t elem8, const int* maxn_dev, size_t row0, size_t rows, size_t worst_w8, char* dst) {
+#ifndef PL_WAVE_EMU
+  const size_t blocks = std::min<size_t>(2048, (rows * worst_w8 + 255) / 256);
+  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::max<size_t>(1, blocks)), dim3(256), 0, st, src, pitch, elem8, maxn_dev, row0, rows, dst);
+#else
+  (void)st; (void)worst_w8; const size_t w8 = (size_t)(*maxn_dev) * elem8; for (size_t q = 0; q < rows * w8; q++) pack_word(src, pitch, w8, row0, dst, q);
+#endif
+}
+static void launch_copy_words(hipStream_t st, const void* src, void* dst, size_t bytes) {
+#ifndef PL_WAVE_EMU
+  const size_t n8 = (bytes + 7) / 8, blocks = std::min<size_t>(2048, (n8 + 255) / 256);
+  hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::max<size_t>(1, blocks)), dim3(256), 0, st, (const double*)src, (double*)dst, n8);
+#else
+  (void)st; memcpy(dst, src, bytes);
+#endif
+}
 // forward parameter sensitivities of a plh_integrate_sens call (dfn_sens.h)
 struct SensReq { int n_sens; const int* cols; double* dY; double* dV; int* stat; };
 // theta_pert[cell][k][:] = the cell's theta row with column cols[k] moved by a relative 1e-7 (an absolute 1e-7 where the entry is zero)
@@ -722,6 +795,7 @@ static void launch_theta_pert(hipStream_t st, const double* theta, const int* co
 
 static int integrate_impl(plh_model_t m, int n, const double* theta, const double* SOC0, const double* Y_init, const double* t_init, int n_runs,
                           const plh_run* runs, const plh_opts* opts, const plh_outputs* out, int kind, void* stream, const SensReq* sq) {
+  const auto t_entry = std::chrono::steady_clock::now();
   CHECK_MODEL(m);
   if (kind != PLH_HOST && kind != PLH_DEVICE && kind != PLH_HOST_ASYNC) return fail(PLH_E_ARG, "bad ptr_kind");
   if (n <= 0 || !theta || !SOC0 || n_runs <= 0 || !runs || !opts || !out || !out->run_info) return fail(PLH_E_ARG, "bad argument");
@@ -872,14 +946,42 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
   a.runs = cx.d_runs;
   const size_t np = (size_t)n * out->max_pts;
   a.out = *out;
-  a.out.t = s.buf(out->t, np, false); a.out.V = s.buf(out->V, np, false); a.out.I = s.buf(out->I, np, false);
-  a.out.SOC = s.buf(out->SOC, np, false); a.out.T_avg = s.buf(out->T_avg, np, false); a.out.n_pts = s.buf(out->n_pts, n, false);
-  // (a synchronous host call brings the per-point arrays back only up to the longest trajectory: it needs n_pts on the device whether or not the caller asked for it)
   const bool host_ret = kind == PLH_HOST && !sq;
-  if (host_ret && !a.out.n_pts && np > 0 && (out->t || out->V || out->I || out->SOC || out->T_avg || out->Y_all)) a.out.n_pts = (int*)s.dev_block((size_t)n * sizeof(int));
-  a.out.Y_all = s.buf(out->Y_all, np * m->N, false);
-  a.out.Y_final = s.buf(out->Y_final, (size_t)n * m->N, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * m->N, false);
-  a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
+  // A blocking host call (r06b) keeps its outputs in ONE device block, so that they come back in three copies instead of ten (a device-to-host copy command costs
+  // 20 ... 30 us whatever its size): [n_pts] [Y_final, YP_final, run_info, counters] [t, V, I, SOC, T_avg: the requested ones, one [n][max_pts] array behind the other
+  // = one 2-D array of k n rows].  n_pts is needed on the device whether or not the caller asked for it: it bounds the per-point copies.
+  struct { size_t hdr = 0, npts = 0, fixed0 = 0, fixed1 = 0, pp0 = 0; int n_pp = 0; char* base = nullptr; } lay;          // (hdr: the longest trajectory, worked out on the device)
+  if (host_ret) {
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const bool any_pp = np > 0 && (out->t || out->V || out->I || out->SOC || out->T_avg || out->Y_all);
+    size_t off = 0, o_Y = 0, o_YP = 0, o_ri = 0, o_ct = 0;
+    lay.hdr = off; off += 256;
+    lay.npts = off; if (out->n_pts || any_pp) off += up((size_t)n * sizeof(int));
+    lay.fixed0 = off;
+    if (out->Y_final) { o_Y = off; off += up((size_t)n * m->N * sizeof(double)); }
+    if (out->YP_final) { o_YP = off; off += up((size_t)n * m->N * sizeof(double)); }
+    o_ri = off; off += up((size_t)n * n_runs * sizeof(plh_run_info));
+    if (out->counters) { o_ct = off; off += up((size_t)n * sizeof(plh_counters)); }
+    lay.fixed1 = off; lay.pp0 = off;
+    double* const* want[5] = {&out->t, &out->V, &out->I, &out->SOC, &out->T_avg};
+    for (int k = 0; k < 5; k++) if (*want[k] && np > 0) lay.n_pp++;
+    lay.base = (char*)s.dev_block(off + (size_t)lay.n_pp * np * sizeof(double) + 256);
+    if (lay.base) {
+      a.out.n_pts = (out->n_pts || any_pp) ? (int*)(lay.base + lay.npts) : nullptr;
+      a.out.Y_final = out->Y_final ? (double*)(lay.base + o_Y) : nullptr; a.out.YP_final = out->YP_final ? (double*)(lay.base + o_YP) : nullptr;
+      a.out.run_info = (plh_run_info*)(lay.base + o_ri); a.out.counters = out->counters ? (plh_counters*)(lay.base + o_ct) : nullptr;
+      double** dst[5] = {&a.out.t, &a.out.V, &a.out.I, &a.out.SOC, &a.out.T_avg};
+      int j = 0;
+      for (int k = 0; k < 5; k++) *dst[k] = (*want[k] && np > 0) ? (double*)(lay.base + lay.pp0) + (size_t)(j++) * np : nullptr;
+    }
+    a.out.Y_all = s.buf(out->Y_all, np * m->N, false);
+  } else {
+    a.out.t = s.buf(out->t, np, false); a.out.V = s.buf(out->V, np, false); a.out.I = s.buf(out->I, np, false);
+    a.out.SOC = s.buf(out->SOC, np, false); a.out.T_avg = s.buf(out->T_avg, np, false); a.out.n_pts = s.buf(out->n_pts, n, false);
+    a.out.Y_all = s.buf(out->Y_all, np * m->N, false);
+    a.out.Y_final = s.buf(out->Y_final, (size_t)n * m->N, false); a.out.YP_final = s.buf(out->YP_final, (size_t)n * m->N, false);
+    a.out.run_info = s.buf(out->run_info, (size_t)n * n_runs, false); a.out.counters = s.buf(out->counters, n, false);
+  }
   a.sens.n_sens = 0; a.sens.cols = nullptr; a.sens.theta_pert = nullptr; a.sens.hist = nullptr; a.sens.dY = nullptr; a.sens.dV = nullptr; a.sens.stat = nullptr; a.sens.cbak = nullptr; a.sens.aux = nullptr; a.sens.fsave = nullptr; a.sens.fsave_stride = 0;
   size_t n_dY = 0, n_dV = 0;
   if (sq) {
@@ -918,61 +1020,142 @@ static int integrate_impl(plh_model_t m, int n, const double* theta, const doubl
   hipEventRecord(cx.ev1, s.st);
   cx.timed = true; m->last = &cx;
   if (host_ret) {
-    // ---- the way back of a synchronous host call (see HostRet) ----
-    std::vector<HostRet> rets;
+    // ---- the way back of a synchronous host call (see HostRet and the copy kernels above) ----
+    // Items: pieces of the caller's arrays in the order of their arrival.  Every item names the event after which its bytes are in the pinned block; small neighbours share
+    // one copy kernel, large arrays are cut into pieces of about 4 MB so that the copy into the caller's memory follows the bus piece by piece.  The pinned block mirrors the
+    // device block ([longest trajectory] [n_pts] [fixed-size arrays] [per-point arrays, each in its worst-case slot, rows packed to the longest trajectory] [Y_all likewise]).
+    struct Item { char* host; size_t rows, width, hpitch, pin_off, elem; int ev; };          // elem != 0: a per-point piece (width and row offsets follow from the longest trajectory)
+    std::vector<Item> items;
+    std::vector<HostRet> rets;                                          // (for the prefault: the whole arrays)
     const size_t W8 = sizeof(double), mp = (size_t)out->max_pts;
-    auto add2 = [&](void* host, const void* dev, size_t rows, size_t elem) { if (host && dev && rows && mp) rets.push_back({(char*)host, (const char*)dev, rows, mp * elem, mp * elem, 0}); };
-    auto add1 = [&](void* host, const void* dev, size_t bytes) { if (host && dev && bytes) rets.push_back({(char*)host, (const char*)dev, 1, bytes, bytes, 0}); };
-    add2(out->t, a.out.t, n, W8); add2(out->V, a.out.V, n, W8); add2(out->I, a.out.I, n, W8); add2(out->SOC, a.out.SOC, n, W8); add2(out->T_avg, a.out.T_avg, n, W8);
-    add2(out->Y_all, a.out.Y_all, n, W8 * m->N);
-    const size_t n_2d = rets.size();
-    add1(out->Y_final, a.out.Y_final, (size_t)n * m->N * W8); add1(out->YP_final, a.out.YP_final, (size_t)n * m->N * W8);
-    add1(out->run_info, a.out.run_info, (size_t)n * n_runs * sizeof(plh_run_info)); add1(out->counters, a.out.counters, (size_t)n * sizeof(plh_counters));
-    prefault(rets, 4096);                                              // (while the kernel runs)
-    // n_pts first: it bounds the per-point copies (and ends the wait for the kernel)
-    std::vector<int> npts_h;
-    size_t maxn = mp;
-    if (a.out.n_pts && n_2d > 0) {
-      npts_h.resize(n);
-      HIPCHK(hipMemcpyAsync(npts_h.data(), a.out.n_pts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s.st));
-      HIPCHK(hipStreamSynchronize(s.st));
-      maxn = 0; for (int c = 0; c < n; c++) maxn = std::max(maxn, (size_t)std::max(0, npts_h[c]));
-      maxn = std::min(maxn, mp);
-      if (out->n_pts) memcpy(out->n_pts, npts_h.data(), (size_t)n * sizeof(int));
-    } else {
-      HIPCHK(hipStreamSynchronize(s.st));
-      if (out->n_pts && a.out.n_pts) add1(out->n_pts, a.out.n_pts, (size_t)n * sizeof(int));
+    static const bool trace = getenv("PLH_HOST_TRACE") != nullptr;     // timing of the phases on stderr (tools/gpu: where a blocking call's time goes)
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const size_t yall_bytes = out->Y_all && a.out.Y_all ? np * m->N * W8 : 0, yall0 = (lay.pp0 + (size_t)lay.n_pp * np * W8 + 255) / 256 * 256;
+    const size_t worst = yall0 + yall_bytes + 256;
+    const size_t CH = std::max<size_t>(4u << 20, worst / 48);
+    char* pb = (char*)m->pinned(worst);
+    if (!pb) return fail(PLH_E_HIP, "pinned staging block of the host return path");
+    char* pbd = pb;                                                     // the pinned block as the device sees it
+#ifndef PL_WAVE_EMU
+    { void* dp = nullptr; if (hipHostGetDevicePointer(&dp, pb, 0) == hipSuccess && dp) pbd = (char*)dp; }
+#endif
+    int n_ev = 0;
+    hipError_t ev_err = hipSuccess;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && ev_err == hipSuccess) ev_err = e; };
+    auto record = [&]() -> int {                                        // an event behind what has been queued so far
+      if ((size_t)n_ev == cx.ret_ev.size()) { hipEvent_t e; chk(hipEventCreate(&e)); if (ev_err != hipSuccess) return n_ev; cx.ret_ev.push_back(e); }
+      chk(hipEventRecord(cx.ret_ev[n_ev], s.st)); return n_ev++;
+    };
+    int* maxn_dev = (int*)(lay.base + lay.hdr);
+    if (a.out.n_pts) launch_max_npts(s.st, a.out.n_pts, n, (int)mp, maxn_dev, (int*)(pbd + lay.hdr), (int*)(pbd + lay.npts));
+    const int ev_n = record();                                          // the kernel is done, n_pts and the longest trajectory are here
+    {                                                                   // the fixed-size arrays, in the order of the device block
+      struct Fix { void* host; const void* dev; size_t bytes; } fx[4] = {{out->Y_final, a.out.Y_final, (size_t)n * m->N * W8}, {out->YP_final, a.out.YP_final, (size_t)n * m->N * W8},
+                                                                          {out->run_info, a.out.run_info, (size_t)n * n_runs * sizeof(plh_run_info)}, {out->counters, a.out.counters, (size_t)n * sizeof(plh_counters)}};
+      size_t run0 = 0, run1 = 0, first = items.size();                  // the pending run of small arrays [run0, run1) of the block, its items from `first`
+      auto flush = [&] {
+        if (run1 > run0) { launch_copy_words(s.st, lay.base + run0, pbd + run0, run1 - run0); const int e = record(); for (size_t q = first; q < items.size(); q++) items[q].ev = e; }
+        run0 = run1 = 0; first = items.size();
+      };
+      for (const Fix& f : fx) {
+        if (!f.host || !f.dev || !f.bytes) continue;
+        rets.push_back({(char*)f.host, (const char*)f.dev, 1, f.bytes, f.bytes, 0});
+        const size_t off = (size_t)((const char*)f.dev - lay.base);
+        if (f.bytes > CH) {                                             // a large array: its own kernels, piece by piece
+          flush();
+          for (size_t o = 0; o < f.bytes; o += CH) {
+            const size_t b = std::min(CH, f.bytes - o);
+            launch_copy_words(s.st, (const char*)f.dev + o, pbd + off + o, b);
+            items.push_back({(char*)f.host + o, 1, b, b, off + o, 0, record()});
+          }
+          first = items.size();
+          continue;
+        }
+        if (run1 > run0 && off + f.bytes - run0 > CH) flush();
+        if (run1 == run0) run0 = off;
+        run1 = off + f.bytes;
+        items.push_back({(char*)f.host, 1, f.bytes, f.bytes, off, 0, -1});
+      }
+      flush();
     }
-    HIPCHK(hipGetLastError());
-    // every copy at once into one pinned block (per-point arrays: the first maxn columns), an event behind each
-    size_t total = 0;
-    for (size_t k = 0; k < rets.size(); k++) {
-      if (k < n_2d) rets[k].width = maxn * (rets[k].pitch / mp);
-      rets[k].pin_off = total; total += (rets[k].rows * rets[k].width + 255) / 256 * 256;
-    }
-    char* pb = total ? (char*)m->pinned(total) : nullptr;
-    if (total && !pb) return fail(PLH_E_HIP, "pinned staging block of the host return path");
-    while (cx.ret_ev.size() < rets.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); cx.ret_ev.push_back(e); }
-    for (size_t k = 0; k < rets.size(); k++) {
-      const HostRet& r = rets[k];
-      if (r.width == 0) continue;
-      if (r.rows > 1 && r.width < r.pitch) HIPCHK(hipMemcpy2DAsync(pb + r.pin_off, r.width, r.dev, r.pitch, r.width, r.rows, hipMemcpyDeviceToHost, s.st));
-      else HIPCHK(hipMemcpyAsync(pb + r.pin_off, r.dev, r.rows * r.width, hipMemcpyDeviceToHost, s.st));
-      HIPCHK(hipEventRecord(cx.ret_ev[k], s.st));
-    }
-    for (size_t k = 0; k < rets.size(); k++) {                         // array k into the caller's memory while k+1 ... are still in flight
-      const HostRet& r = rets[k];
-      if (r.width == 0) continue;
-      HIPCHK(hipEventSynchronize(cx.ret_ev[k]));
-      const char* src = pb + r.pin_off;
-      if (r.rows > 1 && r.width < r.pitch) {
-        char* h = r.host; const size_t w = r.width, pitch = r.pitch;
-        par_chunks(r.rows, (2u << 20) / (w ? w : 1) + 1, [h, src, w, pitch](size_t qa, size_t qb) { for (size_t q = qa; q < qb; q++) memcpy(h + q * pitch, src + q * w, w); });
-      } else {
-        char* h = r.host; const size_t bytes = r.rows * r.width;
-        par_chunks(bytes, 2u << 20, [h, src](size_t qa, size_t qb) { memcpy(h + qa, src + qa, qb - qa); });
+    {                                                                   // the per-point arrays: row pieces sized by the worst case (max_pts columns)
+      struct PP { void* host; const void* dev; size_t elem, slot; } pp[6] = {{out->t, a.out.t, W8, 0}, {out->V, a.out.V, W8, 0}, {out->I, a.out.I, W8, 0}, {out->SOC, a.out.SOC, W8, 0},
+                                                                              {out->T_avg, a.out.T_avg, W8, 0}, {out->Y_all, a.out.Y_all, W8 * m->N, yall0}};
+      size_t slot = lay.pp0;
+      for (int k = 0; k < 5; k++) if (pp[k].host && pp[k].dev && mp) { pp[k].slot = slot; slot += np * W8; }
+      for (const PP& q : pp) {
+        if (!q.host || !q.dev || !mp || !a.out.n_pts) continue;
+        rets.push_back({(char*)q.host, (const char*)q.dev, (size_t)n, mp * q.elem, mp * q.elem, 0});
+        const size_t pitch = mp * q.elem, rows_per = std::max<size_t>(std::max<size_t>(1, CH / pitch), ((size_t)n + 63) / 64);          // (at most 64 pieces per array)
+        for (size_t q0 = 0; q0 < (size_t)n; q0 += rows_per) {
+          const size_t nr = std::min(rows_per, (size_t)n - q0);
+          launch_pack_rows(s.st, (const char*)q.dev, pitch, q.elem / 8, maxn_dev, q0, nr, mp * q.elem / 8, pbd + q.slot);
+          items.push_back({(char*)q.host + q0 * pitch, nr, 0, pitch, q.slot, q.elem, record()});          // (pin_off: the slot; the piece's rows start at slot + q0 x width)
+          items.back().rows = nr; items.back().width = q0;              // (width holds the first row until the longest trajectory is known)
+        }
       }
     }
+    const double tr0 = trace ? now() : 0;
+    if (ev_err == hipSuccess) prefault(rets, 4096);                    // (while the kernel runs)
+    const double tr1 = trace ? now() : 0;
+    // the team that copies into the caller's memory is started while the kernel still runs (starting eight threads takes 0.15 ms): this thread waits on the events and
+    // publishes how many have fired, thread j copies slice j of every item.  A waiting team thread spins for about a millisecond, then naps in 50 us steps
+    unsigned nt = (unsigned)std::min<size_t>(8, worst / (512u << 10));
+#ifdef PL_WAVE_EMU
+    nt = 0;
+#endif
+    std::atomic<int> fired{0};                                          // events [0, fired) have been waited for
+    std::atomic<bool> listed{false}, give_up{false};                    // listed: the items are final (the per-point ones know their width)
+    auto copy_slice = [&](const Item& r, unsigned j, unsigned of) {
+      if (r.width == 0) return;
+      const char* src = pb + r.pin_off;
+      if (r.rows > 1 || r.elem) {
+        const size_t qa = r.rows * j / of, qb = r.rows * (j + 1) / of;
+        if (r.width == r.hpitch) { if (qb > qa) memcpy(r.host + qa * r.hpitch, src + qa * r.width, (qb - qa) * r.width); }
+        else for (size_t q = qa; q < qb; q++) memcpy(r.host + q * r.hpitch, src + q * r.width, r.width);
+      } else {
+        if (r.width < (256u << 10)) { if (j == 0) memcpy(r.host, src, r.width); return; }
+        const size_t a0 = (r.width * j / of) & ~(size_t)63, a1 = j + 1 == of ? r.width : (r.width * (j + 1) / of) & ~(size_t)63;
+        memcpy(r.host + a0, src + a0, a1 - a0);
+      }
+    };
+    auto nap = [&](unsigned& spins) { if (spins++ < 20000) __builtin_ia32_pause(); else std::this_thread::sleep_for(std::chrono::microseconds(50)); };
+    std::vector<std::thread> team;
+    for (unsigned j = 0; j < nt; j++) team.emplace_back([&, j] {
+      for (unsigned spins = 0; !listed.load(std::memory_order_acquire); nap(spins)) if (give_up.load(std::memory_order_relaxed)) return;
+      for (const Item& it : items) {
+        for (unsigned spins = 0; fired.load(std::memory_order_acquire) <= it.ev; nap(spins)) if (give_up.load(std::memory_order_relaxed)) return;
+        copy_slice(it, j, nt);
+      }
+    });
+    // (no early return from here to the join)
+    if (ev_err == hipSuccess) chk(hipEventSynchronize(cx.ret_ev[ev_n]));
+    chk(hipGetLastError());
+    if (ev_err != hipSuccess) { give_up.store(true); for (auto& t : team) t.join(); HIPCHK(ev_err); }
+    const double tr2 = trace ? now() : 0;
+    // the longest trajectory bounds the per-point pieces: the first max(n_pts) of the max_pts columns (entries beyond n_pts[cell] were never defined)
+    size_t maxn = 0, total = lay.fixed1;
+    if (a.out.n_pts) {
+      maxn = (size_t)std::max(0, *(const int*)(pb + lay.hdr));
+      if (out->n_pts) memcpy(out->n_pts, pb + lay.npts, (size_t)n * sizeof(int));
+    }
+    for (Item& it : items) if (it.elem) { const size_t row0 = it.width, w = maxn * it.elem; it.width = w; it.pin_off += row0 * w; total += it.rows * w; }
+    listed.store(true, std::memory_order_release);
+    const double tr3 = trace ? now() : 0;
+    double tr_wait = 0;
+    size_t done = 0;
+    for (int e = 0; e < n_ev; e++) {
+      const double tw = trace ? now() : 0;
+      if (ev_err == hipSuccess) chk(hipEventSynchronize(cx.ret_ev[e]));
+      if (trace) tr_wait += now() - tw;
+      fired.store(e + 1, std::memory_order_release);
+      if (nt == 0) for (; done < items.size() && items[done].ev <= e; done++) copy_slice(items[done], 0, 1);
+    }
+    for (auto& t : team) t.join();
+    HIPCHK(ev_err);
+    if (trace) { float kms = 0; hipEventElapsedTime(&kms, cx.ev0, cx.ev1);
+      fprintf(stderr, "[plh host call] kernel %.3f ms | staging + launch + fixed-size copies queued %.3f, prefault %.3f, team start + wait for kernel + n_pts %.3f, items finalised %.3f (%.1f MB in all), copy-out %.3f (of which waiting on D2H %.3f) ms\n",
+              kms, tr0 - std::chrono::duration<double, std::milli>(t_entry.time_since_epoch()).count(), tr1 - tr0, tr2 - tr1, tr3 - tr2, total / 1048576.0, now() - tr3, tr_wait); }
     CHECK_STAGE(s);
     return 0;
   }

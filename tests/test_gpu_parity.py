@@ -836,15 +836,39 @@ def test_save_start_on_gpu(hip_model, pkg):
     parity.check_save_start(hip_model, pkg)
 
 
-def test_blocking_host_call_with_fresh_arrays_on_gpu(hip_model, pkg):
+def test_blocking_host_call_with_fresh_arrays_on_gpu(hip_model, hip_model_thermal, pkg):
     """r06: ONE blocking plh_integrate(PLH_HOST) with freshly allocated pageable numpy arrays -- what `simulate_ensemble` does with host inputs and
     what a Julia `ccall` with host pointers would do -- against the kernel's own time.  r05: 0.35 (C2) / 0.40 (C4) of the kernel rate, lost to first-touch page faults of the
-    caller's output arrays and to one blocking copy per output after the kernel.  The library now touches the caller's pages while the kernel runs, brings the per-point arrays
-    back only up to the longest trajectory, and overlaps every device-to-host copy with the copies into the caller's memory (csrc/petlion_hip.hip, HostRet): measured r06
-    0.72 / 0.70.  Asserted: >= 0.55 of the kernel rate on both (the boxes of the pool differ; the remaining gap is PCIe time of the results and, on C4, the copies that a
-    chunked launch could hide behind later kernels -- DESIGN.md 6), and results bit-identical to the device-resident call."""
+    caller's output arrays and to one blocking copy per output after the kernel.  The library now keeps the outputs of such a call in one device block, populates the caller's
+    pages while the kernel runs (MADV_POPULATE_WRITE), queues the fixed-size copies behind the kernel before it ends, brings the per-point arrays back only up to the longest
+    trajectory, and lets a team of threads copy into the caller's memory piece by piece behind the DMA (csrc/petlion_hip.hip, "the way back of a synchronous host call").
+    Measured r06 (PLH_HOST_TRACE=1, gpurun_out/r06p): the call itself 0.77 ... 0.80 (C2) / 0.87 (C4) of the kernel rate; what is left on C2 is the PCIe time of 7.4 MB
+    behind a 1.1 ms kernel.  The caller's own allocate / release cycle of the output arrays (13 MB: 1.1 + 0.3 ms; 100 MB: 5 + 4 ms on the GPU box) is outside the call and
+    not the library's to hide: the Python wall time of the whole cycle is printed, the assertion is on the call (`EnsembleSolution.call_ms`).
+    Asserted: the call >= 0.6 of the kernel rate on both (the boxes of the pool differ by 2 x in page-fault cost), and every output bit-identical to the device-resident call
+    -- also the per-point temperature of the thermal model and the state dump (outputs = "all")."""
     import time
     import torch
+
+    def same(h, e, n, what):
+        dev = lambda x: x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+        npd = dev(e.n_pts)
+        assert np.array_equal(np.asarray(h.n_pts), npd), what
+        assert np.array_equal(np.asarray(h.Y), dev(e.Y)) and np.array_equal(np.asarray(h.YP), dev(e.YP)), what
+        assert np.array_equal(h.run_info["flag"], e.run_info["flag"]) and np.array_equal(h.run_info["t_end"], e.run_info["t_end"]), what
+        assert np.array_equal(h.counters["n_steps"], e.counters["n_steps"]), what
+        names = ["t", "V", "I", "SOC"] + (["T_avg"] if e.T_avg is not None else [])
+        for nm in names:
+            hd, dd = np.asarray(getattr(h, nm)), dev(getattr(e, nm))
+            for i in range(0, n, max(1, n // 64)):
+                k = int(npd[i])
+                assert np.array_equal(hd[i, :k], dd[i, :k]), (what, nm, i)
+        if e.Y_all is not None:
+            hd, dd = np.asarray(h.Y_all), dev(e.Y_all)
+            for i in range(0, n, max(1, n // 16)):
+                k = int(npd[i])
+                assert np.array_equal(hd[i, :k], dd[i, :k]), (what, "Y_all", i)
+
     p = hip_model
     for name, n in (("c2", 1024), ("c4", 8192)):
         cfg = getattr(pkg.configs, name)(p, n)
@@ -855,21 +879,25 @@ def test_blocking_host_call_with_fresh_arrays_on_gpu(hip_model, pkg):
             torch.cuda.synchronize()
         kms = e.kernel_ms
         pkg.simulate_ensemble(p, Th, cfg["protocol"], SOC=cfg["SOC"], max_points=cfg["max_points"])
-        ts = []
+        ts, tin = [], []
         for _ in range(7):
             t1 = time.perf_counter()
             h = pkg.simulate_ensemble(p, Th, cfg["protocol"], SOC=cfg["SOC"], max_points=cfg["max_points"])
-            ts.append(time.perf_counter() - t1)
-        frac = kms / (1e3 * float(np.median(ts)))
-        print("%s: kernel %.3f ms, blocking host call with fresh arrays %.3f ms (median of 7) -> %.2f of the kernel rate" % (name.upper(), kms, 1e3 * float(np.median(ts)), frac))
-        npd = np.asarray(e.n_pts.cpu()) if hasattr(e.n_pts, "cpu") else np.asarray(e.n_pts)
-        assert np.array_equal(np.asarray(h.n_pts), npd)
-        assert np.array_equal(np.asarray(h.Y), e.Y.cpu().numpy()) and np.array_equal(h.run_info["flag"], e.run_info["flag"])
-        td, Vd = e.t.cpu().numpy(), e.V.cpu().numpy()
-        for i in range(0, n, max(1, n // 64)):
-            k = int(npd[i])
-            assert np.array_equal(np.asarray(h.t)[i, :k], td[i, :k]) and np.array_equal(np.asarray(h.V)[i, :k], Vd[i, :k]), i
-        assert frac >= 0.55, (name, frac)
+            ts.append(time.perf_counter() - t1); tin.append(h.call_ms)
+        frac, frac_in = kms / (1e3 * float(np.median(ts))), kms / float(np.median(tin))
+        print("%s: kernel %.3f ms, blocking host call with fresh arrays: the call %.3f ms -> %.2f of the kernel rate; Python wall of the whole cycle %.3f ms -> %.2f (medians of 7)"
+              % (name.upper(), kms, float(np.median(tin)), frac_in, 1e3 * float(np.median(ts)), frac))
+        same(h, e, n, name)
+        assert frac_in >= 0.6, (name, frac_in)
+    # the thermal model's per-point temperature and a state dump: the other two kinds of output the way back handles
+    p = hip_model_thermal
+    cfg = pkg.configs.c3(p, 256)
+    Th = np.ascontiguousarray(cfg["theta"])
+    e = pkg.simulate_ensemble(p, torch.from_numpy(Th).cuda(), cfg["protocol"], SOC=cfg["SOC"], device=True, max_points=cfg["max_points"], outputs="all")
+    torch.cuda.synchronize()
+    h = pkg.simulate_ensemble(p, Th, cfg["protocol"], SOC=cfg["SOC"], max_points=cfg["max_points"], outputs="all")
+    assert h.T_avg is not None and h.Y_all is not None
+    same(h, e, 256, "c3 with outputs = all")
 
 
 def test_build_from_source_on_the_gpu_box(pkg):
