@@ -1370,7 +1370,7 @@ PL_DEV void cell_res_jac(CellLDS<M>& S, const LaneRegs& R, const double* Y, cons
 __device__ __forceinline__ void inv3(const double* A, double* B) {
   const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
   const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
-  const double id = 1.0 / det;
+  const double id = pl_rcp(det);
   B[0] = c00 * id; B[1] = (A[2] * A[7] - A[1] * A[8]) * id; B[2] = (A[1] * A[5] - A[2] * A[4]) * id;
   B[3] = c01 * id; B[4] = (A[0] * A[8] - A[2] * A[6]) * id; B[5] = (A[2] * A[3] - A[0] * A[5]) * id;
   B[6] = c02 * id; B[7] = (A[1] * A[6] - A[0] * A[7]) * id; B[8] = (A[0] * A[4] - A[1] * A[3]) * id;
@@ -1534,9 +1534,9 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
   if (!alg_only && (!M::W2 || wave_id() == 1)) {          // (two waves per cell: the resolvents are wave 1's, next to wave 0's Jacobian node pass)
     const int r = lane % NR;
     // the 2 N_r reciprocals 1/(kappa lam_m - cj) are formed by 2 N_r lanes in parallel and passed through S.w9 (free outside the solves)
-    if constexpr (M::PHI_GLOBAL_ALL) { if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * tb->LAMp(lane < NR ? 0 : 1)[r] - cj); }
-    else if constexpr (NR_EQ) { if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * S.Mr[S.OFF_LAMR + r] - cj); }
-    else { if (lane < 2 * NR) S.w9[lane] = 1.0 / ((lane < NR ? c.kap_p : c.kap_n) * S.Mr[(lane < NR ? 0 : S.MR_BLK) + S.OFF_LAMR + r] - cj); }      // (padded modes: lam = 0, V = W = 0)
+    if constexpr (M::PHI_GLOBAL_ALL) { if (lane < 2 * NR) S.w9[lane] = pl_rcp((lane < NR ? c.kap_p : c.kap_n) * tb->LAMp(lane < NR ? 0 : 1)[r] - cj); }
+    else if constexpr (NR_EQ) { if (lane < 2 * NR) S.w9[lane] = pl_rcp((lane < NR ? c.kap_p : c.kap_n) * S.Mr[S.OFF_LAMR + r] - cj); }
+    else { if (lane < 2 * NR) S.w9[lane] = pl_rcp((lane < NR ? c.kap_p : c.kap_n) * S.Mr[(lane < NR ? 0 : S.MR_BLK) + S.OFF_LAMR + r] - cj); }      // (padded modes: lam = 0, V = W = 0)
     PL_SYNC();
     // entry (row, k) of electrode el = sum_m V[row][m] w_el[m] W[m][k], m ascending; lanes 0..31 build the cathode's resolvent, 32..63 the anode's, RS_KG lanes per row with
     // RS_KW columns each (N_r = 10: 3 lanes x 4 columns)
@@ -1607,7 +1607,7 @@ PL_DEV void iso_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__ tb
       }
       if (!local3) {
         const double d = -1.0 - schur;
-        const double rd = 1.0 / d;
+        const double rd = pl_rcp(d);
         S.dj[jx] = rd;                                     // the reciprocal pivot: the solves multiply
         ph0 = alg_only ? 0.0 : S.gce[jx] * rd; ph1 = S.gpe[jx] * rd; ph2 = S.gps[jx] * rd;
       }
@@ -1835,7 +1835,7 @@ PL_DEV void iso_solve(CellLDS<M>& S, LaneRegs& R, double* b, int mode, bool alg_
   else {
     double vm = (mode == PLH_MODE_ETA_P) ? lane_bcast(m2, tw_lane(NP + NS)) - lane_bcast(m1, tw_lane(NP + NS)) : lane_bcast(m2, tw_lane(0)) - lane_bcast(m2, tw_lane(NE - 1));
     if (mode == PLH_MODE_P) vm *= S.ctrlJ[0];
-    xI = (b[O_I] - vm) / S.bord;
+    xI = pl_div(b[O_I] - vm, S.bord);
     if (nd >= 0) { mx[0] -= xI * S.x2[0][nd]; mx[1] -= xI * S.x2[1][nd]; mx[2] -= xI * S.x2[2][nd]; }
   }
   PL_SYNC();

@@ -449,7 +449,7 @@ __device__ __forceinline__ void inv4(const double* A, double* B) {
   const double c5 = A[10] * A[15] - A[14] * A[11], c4 = A[9] * A[15] - A[13] * A[11], c3 = A[9] * A[14] - A[13] * A[10];
   const double c2 = A[8] * A[15] - A[12] * A[11], c1 = A[8] * A[14] - A[12] * A[10], c0 = A[8] * A[13] - A[12] * A[9];
   const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
-  const double id = 1.0 / det;
+  const double id = pl_rcp(det);
   B[0] = (A[5] * c5 - A[6] * c4 + A[7] * c3) * id;
   B[1] = (-A[1] * c5 + A[2] * c4 - A[3] * c3) * id;
   B[2] = (A[13] * s5 - A[14] * s4 + A[15] * s3) * id;
@@ -545,6 +545,54 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
   // grid: one interruption of the stage loop serves both; two when N_p != N_n)
   constexpr int FAR_T = NP - 3, FAR_B = NN - 3, FAR_LO = FAR_T < FAR_B ? FAR_T : FAR_B, FAR_HI = FAR_T < FAR_B ? FAR_B : FAR_T;
   constexpr int NSEG = FAR_LO == FAR_HI ? 2 : 3;
+  // r06b: one level of recursive doubling, as in thomas_sweeps (dfn_cell.h): y_n = (r_n - C_n r_{n-1}) + (C_n C_{n-1}) y_{n-2} -- the odd and the even nodes of a half
+  // advance together two lanes apart (row_shr:2: each half sits inside one 16-lane DPP row) in 7 stages instead of 14, for one parallel pre-pass (the 4x4 product P = C C_prev
+  // and the shifted right-hand side: 80 FMAs).  The chain of DPP shift + four dependent FMAs per stage is latency at one wave per SIMD: 5.7 k cycles per solve before.  The
+  // far-behind share q . y(node N_p - 3) leaves r_{N_p - 1} once that y is final (after stage (N_p - 3) / 2); r_{N_p - 1} sits in TWO of the combined right-hand sides,
+  // its own and the next node's (through -C_next r_{N_p - 1}), so the next lane gets + C_next[:, 3] x the same share.  Default-shaped grids only (both electrodes alike,
+  // halves inside a DPP row); one right-hand side.
+#ifdef PL_NO_STRIDE2T
+  constexpr bool STRIDE2T = false;
+#else
+  constexpr bool STRIDE2T = NRHS == 1 && FAR_T == FAR_B && FAR_T >= 1 && TW_FWD <= 15 && TW_MID <= 15;
+#endif
+  if constexpr (STRIDE2T) {
+    double P[16];
+    {
+      double Cs[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) Cs[k] = shift_up1(C[k]);                 // C of the previous node of the chain
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) P[a * 4 + b] = ((C[a * 4] * Cs[b] + C[a * 4 + 1] * Cs[4 + b]) + C[a * 4 + 2] * Cs[8 + b]) + C[a * 4 + 3] * Cs[12 + b];
+      const double s0 = shift_up1(r[0][0]), s1 = shift_up1(r[0][1]), s2 = shift_up1(r[0][2]), s3 = shift_up1(r[0][3]);
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) r[0][rr] = PL_NMS4(r[0][rr], C[rr * 4], s0, C[rr * 4 + 1], s1, C[rr * 4 + 2], s2, C[rr * 4 + 3], s3);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) y[0][k] = r[0][k];
+    constexpr int S_INT = FAR_T / 2, NST2 = (TW_FWD - 1 + 1) / 2;          // positions <= 2 s + 1 of a chain are final after s stages; the last position is TW_FWD - 1
+    auto stages = [&](int lo, int hi) {
+#pragma unroll
+      for (int it = lo; it < hi; it++) {
+        const double p0 = row_up2(y[0][0]), p1 = row_up2(y[0][1]), p2 = row_up2(y[0][2]), p3 = row_up2(y[0][3]);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) y[0][rr] = (((r[0][rr] + P[rr * 4] * p0) + P[rr * 4 + 1] * p1) + P[rr * 4 + 2] * p2) + P[rr * 4 + 3] * p3;
+      }
+    };
+    stages(0, S_INT);
+    {
+      double d = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const double a7 = lane_bcast(y[0][k], tw_lane(NP - 3)), a22 = lane_bcast(y[0][k], tw_lane(NP + NS + 2)); d += qf[k] * (nd == NP - 1 ? a7 : a22); }
+      const double dm = far_behind ? d : 0.0, dn = shift_up1(dm);          // (qf = 0 outside the two far-behind lanes; dn: the share as the next lane of the chain sees it)
+      r[0][3] -= dm;
+#pragma unroll
+      for (int k = 0; k < 4; k++) r[0][k] += cT[k] * dn;
+    }
+    stages(S_INT, NST2);
+  } else {
 #pragma unroll 1
   for (int seg = 0; seg < NSEG; seg++) {
     const int lo = seg == 0 ? 1 : (seg == 1 ? FAR_LO + 1 : FAR_HI + 1), hi = seg == 0 ? FAR_LO + 1 : ((seg == 1 && NSEG == 3) ? FAR_HI + 1 : TW_FWD);
@@ -568,6 +616,7 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
         if (mine) r[q][3] -= d;                             // (qf = 0 in every other lane)
       }
     }
+  }
   }
   PL_SYNC();
   double Lm[16];
@@ -605,6 +654,30 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
       }
     }
   }
+  if constexpr (STRIDE2T) {                                                // x_n = (z_n - G_n z_{n+1}) + (G_n G_{n+1}) x_{n+2}  ("n+1" = the next lane of the chain)
+    double Q[16];
+    {
+      double Gs[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) Gs[k] = shift_down1(G[k]);
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) Q[a * 4 + b] = ((G[a * 4] * Gs[b] + G[a * 4 + 1] * Gs[4 + b]) + G[a * 4 + 2] * Gs[8 + b]) + G[a * 4 + 3] * Gs[12 + b];
+      const double s0 = shift_down1(z[0][0]), s1 = shift_down1(z[0][1]), s2 = shift_down1(z[0][2]), s3 = shift_down1(z[0][3]);
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) z[0][rr] = PL_NMS4(z[0][rr], G[rr * 4], s0, G[rr * 4 + 1], s1, G[rr * 4 + 2], s2, G[rr * 4 + 3], s3);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[0][k] = z[0][k];
+    constexpr int NST2B = (TW_MID + 1) / 2;                                 // lane 0 is TW_MID steps from the ghost of the closing node
+#pragma unroll
+    for (int it = 0; it < NST2B; it++) {
+      const double q0 = row_down2(r[0][0]), q1 = row_down2(r[0][1]), q2 = row_down2(r[0][2]), q3 = row_down2(r[0][3]);
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) r[0][rr] = (((z[0][rr] + Q[rr * 4] * q0) + Q[rr * 4 + 1] * q1) + Q[rr * 4 + 2] * q2) + Q[rr * 4 + 3] * q3;
+    }
+  } else {
 #pragma unroll 2
   for (int itr = 0; itr < TW_MID; itr++) {
 #pragma unroll
@@ -613,6 +686,7 @@ __device__ __forceinline__ void thermal_sweeps(const CellLDS<M>& S, bool alg_onl
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) r[q][rr] = PL_NMS4(z[q][rr], G[rr * 4], q0, G[rr * 4 + 1], q1, G[rr * 4 + 2], q2, G[rr * 4 + 3], q3);
     }
+  }
   }
 #pragma unroll
   for (int q = 0; q < NRHS; q++) {                          // x_0 -= Dinv_0[:,3] (w . x_2) ; x_29 -= Dinv_29[:,3] (w . x_27)
@@ -659,7 +733,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
 #pragma unroll
       for (int pass = 0; pass < CSD_PASS; pass++) {
         const int p0 = pass * CSD_G + q, pq = p0 < NJ ? p0 : NJ - 1; pp[pass] = pq;
-        R.rcp[pass] = 1.0 / (TP.kapP[pq] * ((NR_EQ || pq < NP) ? lam_r : lam_rN) - cj);
+        R.rcp[pass] = pl_rcp(TP.kapP[pq] * ((NR_EQ || pq < NP) ? lam_r : lam_rN) - cj);
         rcv[pass] = R.rcp[pass]; wq[pass] = TP.AinvQ[pq][rc] * R.rcp[pass];      // AinvQ still holds W c
         dk[pass] = TP.dkapP[pq]; ae[pass] = 0.0; aq[pass] = 0.0;
       }
@@ -742,12 +816,12 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       const double aU_prev = shift_up1(l_aU);
       const double rcpl = !cact ? 0.0 : ((q == 0 && kk == NA - 1) ? l_aU : ((q == 1 && kk == 0) ? l_aL : 0.0));
       constexpr int NC = NA > NZ ? NA : NZ;
-      double cp = 1.0 / dk, fc = rcpl, fi = qij;
+      double cp = pl_rcp(dk), fc = rcpl, fi = qij;
 #pragma unroll 1
       for (int st = 1; st < NC; st++) {
         const double cpp = shift_up1(cp), fcp = shift_up1(fc), fip = shift_up1(fi);
         const double mlt = aLk * cpp;
-        cp = 1.0 / (dk - mlt * aU_prev); fc = rcpl - mlt * fcp; fi = qij - mlt * fip;
+        cp = pl_rcp(dk - mlt * aU_prev); fc = rcpl - mlt * fcp; fi = qij - mlt * fip;
       }
       double xc = fc * cp, xi = fi * cp;
 #pragma unroll
@@ -766,7 +840,7 @@ PL_DEV_FACTOR void thermal_factor(CellLDS<M>& S, LaneRegs& R, const Tables* __re
       const double bj = sc == 0 ? c.bj_p : c.bj_n;
       const double sig = alg_only ? 0.0 : TP.AinvE[jx][nr_of(jx) - 1], tau = alg_only ? 0.0 : TP.AinvQ[jx][nr_of(jx) - 1];
       const double d = -1.0 - S.gcs[jx] * sig * bj;
-      const double rd = 1.0 / d;
+      const double rd = pl_rcp(d);
       S.dj[jx] = rd;
       p0 = alg_only ? 0.0 : S.gce[jx] * rd; p1 = S.gpe[jx] * rd; p2 = S.gps[jx] * rd; p3 = alg_only ? 0.0 : (TP.gT[jx] - S.gcs[jx] * tau) * rd;
       t0 = alg_only ? 0.0 : S.ceJ[i]; t1 = S.peJ[i]; t2 = S.psJ[jx]; t3 = alg_only ? 0.0 : TP.TJ[jx] - TP.Tcs[jx] * sig * bj;
@@ -1164,7 +1238,7 @@ PL_DEV void thermal_solve(CellLDS<M>& S, LaneRegs& R, const Tables* __restrict__
       if (lane >= 32 && lane < 32 + NA + NZ) vy += -cjf * wk * zbk;
     }
     const double vsum = wave_sum(vy);
-    xI = (l_bI - vsum) / bd;
+    xI = pl_div(l_bI - vsum, bd);
     if (act) { y[0] -= xI * x20; y[1] -= xI * x21; y[2] -= xI * x22; y[3] -= xI * x23; }
   }
   PL_SYNC();
