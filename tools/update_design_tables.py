@@ -25,7 +25,7 @@ def swap_table(s, new):
 
 for t in (bench_t, roof_t, feat_t):
     s = swap_table(s, t)
-m = re.search(r"partitions: block: shard kernel ms .*?; cyclic: shard kernel ms [^\n]*", s)
+m = re.search(r"partitions: block: shard kernel ms .*?; cyclic: shard kernel ms .*?trajectories/s\.", s, re.S)          # (the prose may have been re-wrapped: tools/wrap_design.py)
 assert m, "predicted_scaling line"
 s = s[:m.start()] + "partitions: " + "; ".join(x.strip() for x in pred[:2]) + "." + s[m.end():]
 open(p, "w").write(s)
