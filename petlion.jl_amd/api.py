@@ -73,10 +73,10 @@ class Model:
                                    solid_diffusion.upper(), thermodynamic_factor.upper(), rxn, waves_per_cell == 2)
             if vid is None:
                 raise NotImplementedError("this combination of model options is not instantiated on the device")
-            grid_lib = grids.library(g, [vid])
-            if os.path.exists(grid_lib + ".use_licm"):          # this library failed the kernel self-test on this machine: its fall-back build (api.petlion)
-                grid_lib = grids.library(g, [vid], machine_licm=True)
-            self._grid_lib_built = grid_lib
+            # (a variant that failed the kernel self-test on this machine with the built-in flags -- under THIS flag table and these sources: the marker carries the build
+            #  identity -- goes to its fall-back build directly, and grids.library keeps it out of every union library of the built-in flags: ADVICE r05)
+            grid_lib = grids.library(g, [vid], machine_licm=True) if grids.needs_fallback(g, vid) else grids.library(g, [vid])
+            self._grid_lib_built, self._grid_key = grid_lib, (g, vid)
         if grid_lib:                                     # (False: register nothing -- the tests' way to reach the C ABI's own refusal)
             cap.check(self._lib, self._lib.plh_register_grid_library(os.fsencode(grid_lib)), "plh_register_grid_library")
         h = C.c_void_p()
@@ -210,8 +210,7 @@ def petlion(cathode=LCO, *, N_p=10, N_s=10, N_n=10, N_a=10, N_z=10, N_r_p=10, N_
         if not lib or lib.endswith("_licm.so"):
             raise
         warnings.warn("petlion.jl_amd: %s -- rebuilding %s with MachineLICM on (fall-back flags)" % (err, os.path.basename(lib)), RuntimeWarning)
-        with open(lib + ".use_licm", "w") as f:
-            f.write(str(err) + "\n")
+        grids.mark_fallback(*p._grid_key, err)
         p = mk()
         p.opts.SOC = SOC
         _selftest_new_grid_library(p)

@@ -92,6 +92,33 @@ def library(grid, variants, force=False, machine_licm=False, extra_flags=(), suf
         return _library_locked(grid, variants, force, tag, defs, machine_licm, list(extra_flags), suffix + ("_licm" if machine_licm else ""))
 
 
+def _licm_marker(grid, vid):
+    return os.path.join(GRID_DIR, "fallback_%s_v%d.json" % (defines(grid)[0], vid))
+
+
+def _build_identity():
+    """what a fall-back marker is valid for: the flag table and the device sources (a marker written under other flags or older sources expires)"""
+    import hashlib
+    from . import buildflags
+    return {"flags": hashlib.sha1(buildflags.table_repr().encode()).hexdigest()[:12], "sources_mtime": _sources_mtime()}
+
+
+def mark_fallback(grid, vid, why):
+    """remember that variant `vid` on `grid` failed the kernel self-test with the built-in flags on this machine: later processes go to its fall-back build directly, and no
+    union library built with the built-in flags carries this variant any more (a later union library registered after the `_licm` one shadowed it)"""
+    os.makedirs(GRID_DIR, exist_ok=True)
+    json.dump(dict(_build_identity(), why=str(why)), open(_licm_marker(grid, vid), "w"))
+
+
+def needs_fallback(grid, vid):
+    try:
+        m = json.load(open(_licm_marker(grid, vid)))
+    except (OSError, ValueError):
+        return False
+    idn = _build_identity()
+    return m.get("flags") == idn["flags"] and m.get("sources_mtime", 0) >= idn["sources_mtime"]
+
+
 def _library_locked(grid, variants, force, tag, defs, machine_licm=False, extra_flags=(), suffix=""):
     # The file name carries the variant ids it holds: a library is never rebuilt in place under a path that plh_register_grid_library may already have dlopen'ed in this
     # process (registering a known path is a no-op) -- a second model on the same grid with another variant gets a NEW file holding the union, registered next to the first.
@@ -104,10 +131,14 @@ def _library_locked(grid, variants, force, tag, defs, machine_licm=False, extra_
         if not os.path.exists(lib) or os.path.getmtime(lib) < fresh or meta.get("suffix", "") != suffix:
             continue
         have = meta["variants"]
+        if not machine_licm and not extra_flags and any(v not in variants and needs_fallback(grid, v) for v in have):
+            continue          # (holds kernels of a variant that failed the self-test with these flags: registered after that variant's fall-back library it would shadow it)
         if not force and set(variants) <= set(have):
             return lib
         if len(have) > len(have_best):
             have_best = have
+    if not machine_licm and not extra_flags:          # a variant that needs its fall-back build never rides along in a library of the built-in flags
+        have_best = [v for v in have_best if v in variants or not needs_fallback(grid, v)]
     allv = sorted(set(have_best) | set(variants))
     stem = os.path.join(GRID_DIR, "libplh_%s_v%s%s" % (tag, "_".join(str(v) for v in allv), suffix))
     lib, manifest = stem + ".so", stem + ".json"

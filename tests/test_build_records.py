@@ -55,3 +55,42 @@ def test_source_comments_quote_the_record_not_numbers():
     """petlion_kernels.h used to carry a hand-typed register table that said "0 B/lane" next to a binary with 28: the header now points at the record"""
     txt = open(os.path.join(ROOT, "petlion.jl_amd", "csrc", "petlion_kernels.h")).read()
     assert "validated_build.json" in txt and "B/lane of scratch in the integrate kernel" not in txt.split("namespace pl")[1][:2500]
+
+
+def test_fallback_markers_carry_the_build_identity_and_keep_a_failed_variant_out_of_union_libraries(pkg, tmp_path, monkeypatch):
+    """a grid library that fails the kernel self-test is rebuilt with the fall-back flags and registered after the failed one ("latest registration wins").
+    A union library of the built-in flags built LATER for a second variant on the same grid used to carry the failed variant too, was registered after the fall-back library
+    and shadowed it; and the marker was keyed on a file name, so it never expired.  Now the marker is per (grid, variant), carries the flag table's hash and the sources' age,
+    and grids.library neither returns nor builds a built-in-flags library that holds a marked variant it was not asked for."""
+    import json
+    import time
+    grids, buildflags = pkg.grids, pkg.buildflags
+    monkeypatch.setattr(grids, "GRID_DIR", str(tmp_path))
+    g = grids.grid_tuple(6, 5, 8, 12, 10, 10, None)
+    assert not grids.needs_fallback(g, 8)
+    grids.mark_fallback(g, 8, "selftest: V differs")
+    assert grids.needs_fallback(g, 8) and not grids.needs_fallback(g, 0)
+    # an existing union library of the built-in flags that holds the marked variant must not be handed out for variant 0 ...
+    tag = grids.defines(g)[0]
+    stem = os.path.join(str(tmp_path), "libplh_%s_v0_8" % tag)
+    open(stem + ".so", "w").write("x")
+    json.dump({"grid": list(g), "variants": [0, 8], "suffix": "", "machine_licm": False, "extra_flags": [], "fallback_variants": []}, open(stem + ".json", "w"))
+    future = time.time() + 3600
+    os.utime(stem + ".so", (future, future))
+    asked = []
+
+    class Stop(Exception):
+        pass
+
+    def fake_popen(cmd, **kw):
+        asked.append(cmd)
+        raise Stop()
+    monkeypatch.setattr(buildflags, "popen", fake_popen)
+    with pytest.raises(Stop):
+        grids.library(g, [0])                       # ... it starts a build of a library without variant 8 instead
+    assert any(("-DPL_VARIANT=0" in c) for c in asked) and not any(("-DPL_VARIANT=8" in c) for c in asked)
+    # the marked variant itself, asked for with the built-in flags (a caller that ignores the marker), still gets what it asks for
+    assert grids.library(g, [8]) == stem + ".so"
+    # a marker written under another flag table has expired
+    monkeypatch.setattr(buildflags, "table_repr", lambda: "another table")
+    assert not grids.needs_fallback(g, 8)
