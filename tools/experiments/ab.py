@@ -59,6 +59,8 @@ BUILDS.update({
     "th_r06f": ([4], [], "c3", "c3_thermal"), "th_r06f_nothrowb": ([4], ["-DPL_NO_THROWB"], "c3", "c3_thermal"),
     "th_r06g": ([4], [], "c3", "c3_thermal"), "th_r06g_nostride2": ([4], ["-DPL_NO_STRIDE2T"], "c3", "c3_thermal"),          # one level of recursive doubling in the 4x4 sweeps of a solve
     "r05": ([0], None, "c2 c4", "c2_1024 or evaluators"),          # the r05 library as committed (copied to _exp/libplh_r05.so)
+    "r06v": ([0], None, "c2 c4", "c2_1024 or evaluators"),         # the validated r06 library (copied to _exp/libplh_r06v.so)
+    "r06e_base": ([0], [], "c2 c4", "c2_1024 or evaluators"), "r06e_sw": ([0], ["-DPL_SWCACHE"], "c2 c4", "c2_1024 or evaluators"),          # blocks of the doubled sweeps kept in registers from the factorisation
 })
 for k in list(BUILDS):          # every build also exists with the previous-point copy kept (r03) or dropped
     pass
