@@ -220,17 +220,29 @@ def host_inclusive(pkg, p, inp, n_local, kernel_ms, calls=None):
     for _ in range(7):
         t1 = time.perf_counter(); e_ = pkg.simulate_ensemble(p, Th, inp["protocol"], SOC=inp["SOC"], max_points=inp["max_points"]); tin.append(e_.call_ms); del e_
         ts.append(time.perf_counter() - t1)          # (allocation of the outputs, the call, and the release of the result: the whole cycle of a caller that allocates per call)
+    # the caller's side of that cycle alone, in the allocator state this process is in right now: the same arrays allocated, every page touched, released.  glibc serves
+    # arrays of this size either from recycled heap pages (~0.1 ms for C2) or from fresh mappings that it unmaps again on release (~1.4 ms for C2: page faults + munmap),
+    # depending on the history of the process -- which is why `value` below is bimodal between runs while the call itself is not
+    tc = []
+    n_, mp_, N_ = n_local, int(inp["max_points"]), p.N.tot
+    for _ in range(5):
+        t1 = time.perf_counter()
+        arrs = [np.empty((n_, mp_)) for _ in range(4)] + [np.empty((n_, N_)) for _ in range(2)]
+        for x_ in arrs:
+            x_.reshape(-1)[::512] = 0.0
+        del arrs, x_
+        tc.append(time.perf_counter() - t1)
     pipe.close()
     return {"value": n_local / (ms_med * 1e-3), "unit": "trajectories/s", "ms_per_call_median": ms_med, "calls": calls, "aggregate_value": calls * n_local / total,
             "fraction_of_kernel_rate": kernel_ms / ms_med,
             "what": "H2D of Theta (pinned), kernel, D2H of run_info + counters + n_pts + t, V [%d points] per cell; two calls in flight on two streams (PLH_HOST_ASYNC)" % inp["max_points"],
             "synchronous_pageable": {"value": n_local / float(np.median(ts)), "ms_per_call_median": 1e3 * float(np.median(ts)), "fraction_of_kernel_rate": kernel_ms / (1e3 * float(np.median(ts))),
+                                     "callers_allocation_cycle_ms": 1e3 * float(np.median(tc)),
                                      "inside_plh_integrate": {"value": n_local / (1e-3 * float(np.median(tin))), "ms_per_call_median": float(np.median(tin)), "fraction_of_kernel_rate": kernel_ms / float(np.median(tin)),
                                                               "what": "wall time of the plh_integrate call alone (staging H2D, kernel, copies back into the caller's arrays); the difference to the line above is the caller's "
                                                                       "own allocation and release of 13 MB (C2) ... 100 MB (C4) of output arrays per call"},
-                                     "what": "one blocking PLH_HOST call at a time through freshly allocated pageable numpy arrays, all outputs (t, V, I, SOC, Y, YP, ...): "
-                                             "staging H2D, kernel, D2H through the pinned bounce buffer, memcpy; its spread between runs (r01: 221 k vs 341 k traj/s) is the page-fault "
-                                             "cost of first-touch output arrays, which depends on the allocator state of the calling process"}}
+                                     "what": "the whole cycle of a caller that allocates per call: numpy arrays allocated, ONE blocking PLH_HOST call with all outputs (t, V, I, SOC, Y, YP, ...), the "
+                                             "result released.  Bimodal between runs with the allocator's state (callers_allocation_cycle_ms); the call alone is inside_plh_integrate"}}
 
 
 def predicted_scaling(pkg, p, n_gpus=8, per_gpu=8192, reps=3):
