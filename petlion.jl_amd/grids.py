@@ -74,9 +74,51 @@ def defines(grid):
     return tag, ["-DPL_NP=%d" % p, "-DPL_NS=%d" % s, "-DPL_NN=%d" % n, "-DPL_NR=%d" % r, "-DPL_NRN=%d" % rn, "-DPL_NA=%d" % a, "-DPL_NZ=%d" % z, "-Dpl=pl_" + tag]
 
 
+def _source_files():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))) + [os.path.join(HERE, "..", "include", "petlion_hip.h"), os.path.join(HERE, "buildflags.py")]
+
+
 def _sources_mtime():
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))] + [os.path.join(HERE, "..", "include", "petlion_hip.h"), os.path.join(HERE, "buildflags.py")]
-    return max(os.path.getmtime(f) for f in files)
+    return max(os.path.getmtime(f) for f in _source_files())
+
+
+_HASH_CACHE = {}
+
+
+def _sources_hash():
+    """content hash of the device sources, the header and the flag table: what a cached grid / closure library is valid for.  (r06: the age of the files decided until
+    now -- a `git checkout` of an unchanged source file, or a copy of the tree that does not keep time stamps, made every cached library look stale and the first GPU test
+    that needed one rebuilt it on the box.)"""
+    import hashlib
+    files = _source_files()
+    sig = tuple((f, os.path.getmtime(f), os.path.getsize(f)) for f in files)
+    if _HASH_CACHE.get("sig") != sig:
+        h = hashlib.sha1()
+        for f in files:
+            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+        _HASH_CACHE["sig"], _HASH_CACHE["hash"] = sig, h.hexdigest()[:16]
+    return _HASH_CACHE["hash"]
+
+
+def is_fresh(lib, manifest):
+    """the library at `lib` was built from the sources as they are: by content (manifest["src_hash"]); a manifest written before r06 has no hash -- the age rule decides
+    once and the hash is recorded"""
+    try:
+        meta = json.load(open(manifest))
+    except (OSError, ValueError):
+        return False
+    if not os.path.exists(lib):
+        return False
+    if "src_hash" in meta:
+        return meta["src_hash"] == _sources_hash()
+    if os.path.getmtime(lib) >= _sources_mtime():
+        meta["src_hash"] = _sources_hash()
+        try:
+            json.dump(meta, open(manifest, "w"))
+        except OSError:
+            pass
+        return True
+    return False
 
 
 def library(grid, variants, force=False, machine_licm=False, extra_flags=(), suffix=""):
@@ -100,7 +142,7 @@ def _build_identity():
     """what a fall-back marker is valid for: the flag table and the device sources (a marker written under other flags or older sources expires)"""
     import hashlib
     from . import buildflags
-    return {"flags": hashlib.sha1(buildflags.table_repr().encode()).hexdigest()[:12], "sources_mtime": _sources_mtime()}
+    return {"flags": hashlib.sha1(buildflags.table_repr().encode()).hexdigest()[:12], "src_hash": _sources_hash()}
 
 
 def mark_fallback(grid, vid, why):
@@ -116,7 +158,7 @@ def needs_fallback(grid, vid):
     except (OSError, ValueError):
         return False
     idn = _build_identity()
-    return m.get("flags") == idn["flags"] and m.get("sources_mtime", 0) >= idn["sources_mtime"]
+    return m.get("flags") == idn["flags"] and m.get("src_hash") == idn["src_hash"]
 
 
 def _library_locked(grid, variants, force, tag, defs, machine_licm=False, extra_flags=(), suffix=""):
@@ -124,11 +166,11 @@ def _library_locked(grid, variants, force, tag, defs, machine_licm=False, extra_
     # process (registering a known path is a no-op) -- a second model on the same grid with another variant gets a NEW file holding the union, registered next to the first.
     import glob
     from . import buildflags
-    fresh, have_best = _sources_mtime(), []
+    have_best = []
     for manifest in sorted(glob.glob(os.path.join(GRID_DIR, "libplh_%s_v*%s.json" % (tag, suffix)))):
         lib = manifest[:-5] + ".so"
         meta = json.load(open(manifest))
-        if not os.path.exists(lib) or os.path.getmtime(lib) < fresh or meta.get("suffix", "") != suffix:
+        if not is_fresh(lib, manifest) or meta.get("suffix", "") != suffix:
             continue
         have = meta["variants"]
         if not machine_licm and not extra_flags and any(v not in variants and needs_fallback(grid, v) for v in have):
@@ -167,7 +209,8 @@ def _library_locked(grid, variants, force, tag, defs, machine_licm=False, extra_
     tmp = lib + ".tmp%d" % os.getpid()                      # (a forced rebuild replaces the file atomically: a process that has the old one mapped keeps its inode)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", glue] + objs + ["-o", tmp])
     os.replace(tmp, lib)
-    json.dump({"grid": list(grid), "variants": allv, "suffix": suffix, "machine_licm": bool(machine_licm), "extra_flags": list(extra_flags), "fallback_variants": default_sched}, open(manifest, "w"))
+    json.dump({"grid": list(grid), "variants": allv, "suffix": suffix, "machine_licm": bool(machine_licm), "extra_flags": list(extra_flags), "fallback_variants": default_sched,
+               "src_hash": _sources_hash()}, open(manifest, "w"))
     for o in objs + [glue]:
         os.remove(o)
     return lib

@@ -94,3 +94,26 @@ def test_fallback_markers_carry_the_build_identity_and_keep_a_failed_variant_out
     # a marker written under another flag table has expired
     monkeypatch.setattr(buildflags, "table_repr", lambda: "another table")
     assert not grids.needs_fallback(g, 8)
+
+
+def test_cached_libraries_are_fresh_by_content_not_by_age(pkg, tmp_path, monkeypatch):
+    """r06: a grid / closure library is valid for the device sources it was built from, by CONTENT (manifest["src_hash"]).  Until now the files' ages decided: a `git checkout`
+    of an unchanged source file made every cached library look stale, and the first GPU test that needed one rebuilt it on the box (397 s for six tests)."""
+    import json
+    import time
+    grids = pkg.grids
+    lib, man = str(tmp_path / "libplh_x.so"), str(tmp_path / "libplh_x.json")
+    open(lib, "w").write("x")
+    json.dump({"variants": [0], "src_hash": grids._sources_hash()}, open(man, "w"))
+    past = time.time() - 10 * 365 * 86400
+    os.utime(lib, (past, past))                                   # older than every source file: still fresh, the content matches
+    assert grids.is_fresh(lib, man)
+    json.dump({"variants": [0], "src_hash": "0" * 16}, open(man, "w"))
+    future = time.time() + 3600
+    os.utime(lib, (future, future))                               # newer than every source file: still stale, the content differs
+    assert not grids.is_fresh(lib, man)
+    json.dump({"variants": [0]}, open(man, "w"))                  # a manifest written before r06: the age rule decides once, and the hash is recorded
+    assert grids.is_fresh(lib, man) and json.load(open(man))["src_hash"] == grids._sources_hash()
+    os.utime(lib, (past, past))
+    json.dump({"variants": [0]}, open(man, "w"))
+    assert not grids.is_fresh(lib, man)
