@@ -14,7 +14,10 @@ OPT = "-O3"
 #   late  (the conservative fall-back set of the isothermal / SEI kernels; their production set until r05): functions are `inline`, the AMDGPU always-inline pass merges them after the
 #         function-level optimisations
 #   early (every kernel since r05; thermal kernels since r04): functions are __forceinline__, merged before the optimisation pipeline -- the thermal kernels then no longer depend on the optimisation level
-LATE_INLINE = ["-mllvm", "-amdgpu-function-calls=false"]
+# (r06: -DPL_OCML_EXP with every late-inlining build -- the library's exp / expm1 instead of pl_exp / pl_expm1 (dfn_cell.h).  hipcc 7.2 fails on variant 8 with them
+#  ("Illegal instruction detected: Operand has incorrect register class.  V_CMP_NE_U32_e32 0, $src_shared_base"), whichever way their results are returned; the late-inlining
+#  set is also the conservative fall-back, which should not carry this round's new code either)
+LATE_INLINE = ["-mllvm", "-amdgpu-function-calls=false", "-DPL_OCML_EXP"]
 EARLY_INLINE = ["-DPL_DEV=__device__ __forceinline__"]
 # MachineLICM off (r04): the pre-RA loop-invariant code motion hoists whatever is invariant in the ONE step loop every device function is inlined into -- above all the register
 # copies of the exp / log polynomial coefficients of the thermal node pass -- to the top of the kernel and keeps it live across all phases (thermal: 392 B/lane of scratch with

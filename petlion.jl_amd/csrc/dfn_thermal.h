@@ -56,7 +56,7 @@ __device__ __forceinline__ void ocv_lic6_T(double x, double T, double& U, double
   double s0 = s1, rs0 = rs1;
   if (!big) { s0 = sqrt(x > 0.0 ? x : 0.0); rs0 = 1.0 / s0; }
   const double rx = pl_rcp(x), rx2 = rx * rx;
-  const double e1 = exp(0.9 - 15 * x), e2 = exp(0.4465 * x - 0.4108);
+  const double e1 = pl_exp(0.9 - 15 * x), e2 = pl_exp(0.4465 * x - 0.4108);
   U = 0.7222 + 0.1387 * x + 0.029 * s0 - 0.0172 * rx + 0.0019 * (rs1 * rx) + 0.2808 * e1 - 0.7984 * e2;
   double dv = 0.1387 + 0.0172 * rx2 - 0.2808 * 15 * e1 - 0.7984 * 0.4465 * e2;
   if (x > 0.0) dv += 0.029 * 0.5 * rs0;
@@ -207,8 +207,8 @@ PL_DEV void thermal_node_pass(CellLDS<M>& S, const double* Y, const double* YP, 
   const double rT = pl_rcp(T);
   const double dinv = rT - 1.0 / TREF;
   const double EaK = sc == 0 ? c.EaKp : c.EaKn, EaD = sc == 0 ? c.EaDp : c.EaDn;
-  const double kk = (sc == 0 ? c.kp : c.kn) * exp(-EaK * dinv);
-  const double kap = (sc == 0 ? c.kap_p : c.kap_n) * exp(-EaD * dinv);
+  const double kk = (sc == 0 ? c.kp : c.kn) * pl_exp(-EaK * dinv);
+  const double kap = (sc == 0 ? c.kap_p : c.kap_n) * pl_exp(-EaD * dinv);
   if (act && elec) { TP.kapP[jx] = kap; if (WANT_JAC) TP.dkapP[jx] = kap * EaD * rT * rT; }
   double U = 0, dU = 0, dUdT = 0, ddUdT = 0;
   const double rcm = sc == 0 ? c.rcm_p : c.rcm_n, rsg = sc == 0 ? c.rsg_p : c.rsg_n;

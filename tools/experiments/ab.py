@@ -59,7 +59,10 @@ BUILDS.update({
     "th_r06f": ([4], [], "c3", "c3_thermal"), "th_r06f_nothrowb": ([4], ["-DPL_NO_THROWB"], "c3", "c3_thermal"),
     "th_r06g": ([4], [], "c3", "c3_thermal"), "th_r06g_nostride2": ([4], ["-DPL_NO_STRIDE2T"], "c3", "c3_thermal"),          # one level of recursive doubling in the 4x4 sweeps of a solve
     "r05": ([0], None, "c2 c4", "c2_1024 or evaluators"),          # the r05 library as committed (copied to _exp/libplh_r05.so)
-    "r06v": ([0], None, "c2 c4", "c2_1024 or evaluators"),         # the validated r06 library (copied to _exp/libplh_r06v.so)
+    "r06v": ([0], None, "c2 c4", "c2_1024 or evaluators"),
+    "r06g_both": ([0], None, "c2 c4", "c2_1024 or evaluators"), "r06g_sei": ([3], None, "c5", "c5_nmc_sei"), "r06g_sei_ocml": ([3], None, "c5", "c5_nmc_sei"),          # + the sweep blocks formed together
+    "r06f_exp": ([0], None, "c2 c4", "c2_1024 or evaluators"), "r06f_ocml": ([0], None, "c2 c4", "c2_1024 or evaluators"),          # lean exp / expm1 in the node passes (built in a worktree)
+    "th_r06h_exp": ([4], None, "c3", "c3_thermal"), "th_r06h_ocml": ([4], None, "c3", "c3_thermal"),         # the validated r06 library (copied to _exp/libplh_r06v.so)
     "r06e_base": ([0], [], "c2 c4", "c2_1024 or evaluators"), "r06e_sw": ([0], ["-DPL_SWCACHE"], "c2 c4", "c2_1024 or evaluators"),          # blocks of the doubled sweeps kept in registers from the factorisation
 })
 for k in list(BUILDS):          # every build also exists with the previous-point copy kept (r03) or dropped
