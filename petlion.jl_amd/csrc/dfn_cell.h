@@ -752,6 +752,28 @@ __device__ __forceinline__ PlExpRed pl_expm1_reduced(double x) {
 __device__ __forceinline__ double pl_exp(double x) { const PlExpRed e = pl_expm1_reduced(x); return ldexp(1.0 + e.s, (int)e.n); }
 __device__ __forceinline__ double pl_expm1(double x) { const PlExpRed e = pl_expm1_reduced(x); const double t = ldexp(1.0, (int)e.n); return __builtin_fma(t, e.s, t - 1.0); }
 #endif
+// x^w and x^(w - 1) for x > 0 normal (the SEI side reaction's (I / I_1C)^w): exp(w log x) with the classic log -- x = m 2^k, m in [sqrt(1/2), sqrt(2)), f = m - 1,
+// s = f / (2 + f), log(1 + f) = f - f^2 / 2 + s (f^2 / 2 + R(s^2)), R of degree 7 (fdlibm's coefficients, < 1 ulp) -- and the second power from the first by one reciprocal.
+// ocml's pow carries the logarithm in double-double and three IEEE divisions: ~200 instructions a call, three calls in a Jacobian pass of the anode's nodes.  The result is
+// within |w log x| + 1 ulp of the exact power (a few ulp for the arguments of this row); the emulator build and -DPL_OCML_EXP keep the library's pow.
+#if defined(PL_WAVE_EMU) || defined(PL_OCML_EXP)
+__device__ __forceinline__ void pl_pow_pair(double x, double w, double& pw, double& pwm1) { pw = pow(x, w); pwm1 = pow(x, w - 1.0); }
+__device__ __forceinline__ double pl_pow(double x, double w) { return pow(x, w); }
+#else
+__device__ __forceinline__ double pl_log(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);                                        // [1/2, 1)
+  int k = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.7071067811865476;
+  m = lo ? m + m : m; k = lo ? k - 1 : k;
+  const double f = m - 1.0, s = f * pl_rcp(2.0 + f), z = s * s, w = z * z, dk = (double)k;
+  const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1, hfsq = 0.5 * f * f;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+__device__ __forceinline__ double pl_pow(double x, double w) { return pl_exp(w * pl_log(x)); }
+__device__ __forceinline__ void pl_pow_pair(double x, double w, double& pw, double& pwm1) { pw = pl_pow(x, w); pwm1 = pw * pl_rcp(x); }
+#endif
 
 // OCV_LCO, custom_functions.jl:123-136 ; U(x,T) and dU/dx
 __device__ __forceinline__ void ocv_lco(double x, double T, int iso_ref, double& U, double& dUdx) {
@@ -1198,7 +1220,7 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
     if constexpr (M::SEI) {
       const double Idens = yI * cI1C;
       double calc = 0.0;                                                               // residuals_j_s!, residuals.jl:519-552
-      if (Idens > 0.0) calc = -(ci0F * pow(Idens / cI1C, cwexp)) * pl_exp(-cfRT * (ps - pe - cUref - FAR * jt * Rfilm));
+      if (Idens > 0.0) calc = -(ci0F * pl_pow(pl_div(Idens, cI1C), cwexp)) * pl_exp(-cfRT * (ps - pe - cUref - FAR * jt * Rfilm));
       if (act && sc == 2) {
         Fo[O_JS + ks] = js - calc;
         Fo[O_FILM + ks] = -js * cMrho - ypfilm;                                        // residuals_film!, residuals.jl:260-276
@@ -1267,13 +1289,14 @@ PL_DEV void iso_node_pass(CellLDS<M>& S, const double* Y, const double* YP, doub
             S.sei.jjF[ks] = -S.gps[jx] * FAR * jv * crkag;   // d(j row)/d film
             const double Idens = yI * cI1C;
             if (Idens > 0.0) {
-              const double Cr = Idens / cI1C;
+              const double Cr = pl_div(Idens, cI1C);
               const double Ex = pl_exp(-cfRT * (ps - pe - cUref - FAR * jt * Rfilm));
-              const double aAE = cfRT * ci0F * pow(Cr, cwexp) * Ex;
+              double pwC, pwCm1; pl_pow_pair(Cr, cwexp, pwC, pwCm1);
+              const double aAE = cfRT * ci0F * pwC * Ex;
               S.sei.jsPS[ks] = -aAE; S.sei.jsPE[ks] = aAE;
               S.sei.jsJ[ks] = aAE * FAR * Rfilm; S.sei.jsJS[ks] = 1.0 + aAE * FAR * Rfilm;
               S.sei.jsF[ks] = aAE * FAR * jt * crkag;
-              S.sei.jsI[ks] = cwexp * ci0F * pow(Cr, cwexp - 1.0) * Ex;
+              S.sei.jsI[ks] = cwexp * ci0F * pwCm1 * Ex;
             } else {
               S.sei.jsPS[ks] = 0.0; S.sei.jsPE[ks] = 0.0; S.sei.jsJ[ks] = 0.0; S.sei.jsJS[ks] = 1.0; S.sei.jsF[ks] = 0.0; S.sei.jsI[ks] = 0.0;
             }

@@ -12,7 +12,7 @@ k = lambda x: "%.1f k" % (x / 1e3) if x < 1e5 else "%.0f k" % (x / 1e3)
 print("| config | cells | kernel | `value` (traj/s) | host-inclusive pipeline | with `YP_final` | oracle, 1 core / %d cores |" % L["C2"]["cpu_baseline_all_cores"]["cores"])
 print("|---|---|---|---|---|---|---|")
 for C, b in L.items():
-    print("| %s | %d | %.3f ms | **%s** | %s | %s | %.0f / %s |" % (C, b["config"]["cells_per_gpu"], b["roofline"]["kernel_ms_avg"], k(b["value"]), k(b["host_inclusive"]["value"]),
+    print("| %s | %d | %.3f ms | **%s** | %s | %s | %.0f / %s |" % (C, b["config"]["cells_per_gpu"], b["roofline"]["kernel_ms_avg"], k(b["value"]), k(b["host_inclusive"]["aggregate_value"]),
                                                               k(b["with_YP_final"]["trajectories_per_s"]), b["cpu_baseline"]["value"], k(b["cpu_baseline_all_cores"]["value"])))
 print()
 print("| config | `roofline.frac` (VALU issue) | VALU-busy / s_waitcnt-parked / LDS-busy / scalar-busy share of the wave's cycles | VALU / SALU / LDS instructions per step | fp64 FMA / MUL / ADD / transcendental per trajectory | HBM bytes per launch (utilisation) | `equivalent_streaming.frac` |")
